@@ -1,0 +1,232 @@
+/*
+ * tds_hip.h — C ABI of libtds_hip.so, the MI355X-native many-instance stepper.
+ *
+ * This is the drop-in boundary for ONE path of tiny-differentiable-simulator (TDS):
+ * the per-environment simulation step
+ *     PD -> forward_dynamics (ABA) -> integrate_euler_qdd -> World::step -> integrate_euler
+ * (reference: examples/environments/locomotion_contact_simulation.h:151-304) replayed over
+ * N independent environments.  Everything in this header is plain C: pointers, sizes,
+ * ints.  No torch / STL types cross it.
+ *
+ * Two layers are exported:
+ *
+ *  (1) The handle API  tds_hip_*  — resident device state, explicit stream, status codes.
+ *      It replaces  VectorizedEnvironment::CustomForwardDynamicsStepper::step
+ *      (reference: examples/ars/ars_vectorized_environment.h:75-85) without the
+ *      host<->device copy per step that the reference CUDA stepper performs
+ *      (reference: examples/ars/ars_train_policy_cuda.cpp:246-308).
+ *
+ *  (2) The legacy  <model>_forward_zero{,_meta,_allocate,_deallocate}  symbols, exactly as the
+ *      reference's generated CUDA libraries export them and as CudaModel<double> dlopen()s
+ *      them (reference: examples/ars/ars_train_policy_cuda.cpp:220-229, 345-359; emitter
+ *      src/utils/cuda_codegen.hpp:146-262).  They live in the thin shim libraries
+ *      cuda_model_ant.so / cuda_model_laikago.so (csrc/legacy_shim.cpp) and forward to (1).
+ *
+ * The model description (tds_model_t) is a POD "flattened MultiBody + World": it is what
+ * include/tds_hip_stepper.hpp::flatten_model() produces from an intact tds::MultiBody /
+ * tds::World built by TDS's own URDF loader, so that every loader quirk is inherited.
+ */
+#ifndef TDS_HIP_H
+#define TDS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDS_HIP_ABI_VERSION 1
+
+#define TDS_MAX_LINKS 32
+#define TDS_MAX_GEOMS 32
+#define TDS_MAX_VISUALS 32
+#define TDS_MAX_ACTIONS 32
+/* contact points per environment: sphere 1, capsule 2, box 8 (contact_point.hpp:96-198) */
+#define TDS_MAX_CONTACTS 32
+
+/* status codes returned by every tds_hip_* function */
+enum {
+  TDS_OK = 0,
+  TDS_ERR_INVALID_ARG = 1,
+  TDS_ERR_UNSUPPORTED = 2, /* model uses a feature the HIP path does not implement */
+  TDS_ERR_HIP = 3,         /* a HIP runtime call failed; see tds_hip_last_error() */
+  TDS_ERR_NO_DEVICE = 4
+};
+
+/* joint types — numeric values identical to tds::JointType (src/link.hpp:9-21) */
+enum {
+  TDS_JOINT_FIXED = -1,
+  TDS_JOINT_PRISMATIC_X = 0,
+  TDS_JOINT_PRISMATIC_Y = 1,
+  TDS_JOINT_PRISMATIC_Z = 2,
+  TDS_JOINT_PRISMATIC_AXIS = 3,
+  TDS_JOINT_REVOLUTE_X = 4,
+  TDS_JOINT_REVOLUTE_Y = 5,
+  TDS_JOINT_REVOLUTE_Z = 6,
+  TDS_JOINT_REVOLUTE_AXIS = 7,
+  TDS_JOINT_SPHERICAL = 8
+};
+
+/* geometry types — numeric values identical to tds::GeometryTypes (src/geometry.hpp:30-38) */
+enum {
+  TDS_GEOM_SPHERE = 0,
+  TDS_GEOM_PLANE = 1,
+  TDS_GEOM_CAPSULE = 2,
+  TDS_GEOM_MESH = 3,
+  TDS_GEOM_BOX = 4
+};
+
+/* which call sequence one "step" replays */
+enum {
+  /* PD -> ABA -> integrate_euler_qdd -> contacts + MLCP/PGS -> integrate_euler -> pack
+     (locomotion_contact_simulation.h:151-304).  x = [q | qd | action | kp kd max_force] */
+  TDS_STEP_LOCOMOTION = 0,
+  /* joint torques given directly, no PD:              x = [q | qd | tau]
+       has_plane == 0:  ABA -> clear_forces -> integrate_euler   (cartpole_environment.h:88-94)
+       has_plane == 1:  ABA -> clear_forces -> integrate_euler_qdd -> World::step -> integrate_euler
+                        (examples/soft_contact_example.cpp:107-115)                     */
+  TDS_STEP_TAU = 1
+};
+
+/* scalar type the kernels compute in */
+enum { TDS_DTYPE_F64 = 0, TDS_DTYPE_F32 = 1 };
+
+/* All 3x3 matrices are row-major: m[3*r+c].  Transforms are TDS "right-associative":
+   X.rot maps child-frame vectors into the parent frame, X.trans is the child origin in the
+   parent frame (src/math/transform.hpp:123-137). */
+typedef struct tds_link {
+  int32_t joint_type; /* TDS_JOINT_* */
+  int32_t parent;     /* parent link index, -1 = base */
+  int32_t q_index;    /* index into q,  -2 for fixed joints (multi_body.hpp:324-349) */
+  int32_t qd_index;   /* index into qd, -2 for fixed joints */
+  double X_T_rot[9];  /* parent link -> joint frame (link.hpp:39) */
+  double X_T_trans[3];
+  double S[6];        /* motion subspace [angular | linear], NOT normalised (link.hpp:125-193) */
+  double mass;        /* RigidBodyInertia (src/math/inertia.hpp:9-37) */
+  double com[3];
+  double inertia[9];
+  double stiffness;   /* link.hpp:88-89 (always 0 from the URDF loader) */
+  double damping;
+} tds_link_t;
+
+typedef struct tds_geom {
+  int32_t link; /* owning link, -1 = base */
+  int32_t type; /* TDS_GEOM_SPHERE / CAPSULE / BOX */
+  double radius;
+  double length;     /* capsule */
+  double extents[3]; /* box full extents */
+  double X_rot[9];   /* X_collision: geometry frame in link frame (link.hpp:75) */
+  double X_trans[3];
+} tds_geom_t;
+
+typedef struct tds_visual {
+  int32_t link; /* owning link (>= 0; base visuals are not packed by the reference) */
+  int32_t pad_;
+  double X_rot[9]; /* X_visual (link.hpp:78-79) */
+  double X_trans[3];
+} tds_visual_t;
+
+typedef struct tds_model {
+  int32_t abi_version; /* TDS_HIP_ABI_VERSION */
+  int32_t step_mode;   /* TDS_STEP_* */
+  int32_t num_links;
+  int32_t dof_q;       /* mb.dof()    */
+  int32_t dof_qd;      /* mb.dof_qd() */
+  int32_t is_floating; /* must be 0: floating base is SURVEY §8(f) N4 */
+  int32_t num_geoms;
+  int32_t num_visuals;
+  int32_t action_dim;    /* LOCOMOTION: #PD targets; TAU: dof_qd */
+  int32_t pd_start_link; /* first link the PD loop visits (base_dof_=6, locomotion_contact_simulation.h:180) */
+  int32_t has_plane;     /* 1: multi_bodies_[0] is the implicit plane (plane first!) */
+  int32_t pgs_iterations;
+  int32_t input_dim;  /* doubles per env in the reference record x */
+  int32_t output_dim; /* doubles per env in the reference record y */
+  int32_t pack_visuals; /* 1: y carries 7 doubles per visual + up_dot_z */
+  int32_t pad_;
+  double dt;
+  double gravity[3];
+  double base_X_world_rot[9];
+  double base_X_world_trans[3];
+  double plane_normal[3]; /* unit */
+  double plane_constant;
+  double cfm;         /* mb_constraint_solver.hpp:64-67 */
+  double erp;
+  double friction;    /* World::default_friction   (world.hpp:68) */
+  double restitution; /* World::default_restitution (world.hpp:69) */
+  double action_limit; /* 0.4 (locomotion_contact_simulation.h:234) */
+  double initial_poses[TDS_MAX_ACTIONS];
+  tds_link_t links[TDS_MAX_LINKS];
+  tds_geom_t geoms[TDS_MAX_GEOMS];
+  tds_visual_t visuals[TDS_MAX_VISUALS];
+  char name[32];
+} tds_model_t;
+
+typedef struct tds_hip_sim tds_hip_sim_t; /* opaque */
+
+/* Human-readable text of the last failure on the calling thread ("" if none). */
+const char *tds_hip_last_error(void);
+
+/* Library/ABI introspection. */
+int tds_hip_abi_version(void);
+int tds_hip_device_count(void);
+
+/* Validate a model against what the HIP path implements (joint/geometry coverage,
+   sizes).  TDS_OK or TDS_ERR_UNSUPPORTED / TDS_ERR_INVALID_ARG. */
+int tds_hip_model_check(const tds_model_t *model);
+
+/* Create a simulation of num_envs independent copies of `model` on HIP device `device`.
+   dtype = TDS_DTYPE_F64 (parity-gated) or TDS_DTYPE_F32.  Device buffers owned by the
+   handle: x [N][input_dim], y [N][output_dim] (both in the compute dtype). */
+int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype,
+                   tds_hip_sim_t **out);
+int tds_hip_destroy(tds_hip_sim_t *sim);
+
+/* All launches / copies of this handle are enqueued on `hip_stream` (a hipStream_t;
+   NULL = the default stream).  The library never synchronises unless documented. */
+int tds_hip_set_stream(tds_hip_sim_t *sim, void *hip_stream);
+
+int tds_hip_num_envs(const tds_hip_sim_t *sim);
+int tds_hip_input_dim(const tds_hip_sim_t *sim);
+int tds_hip_output_dim(const tds_hip_sim_t *sim);
+int tds_hip_dtype(const tds_hip_sim_t *sim);
+
+/* Device pointers of the resident records, for zero-copy consumers (e.g. a torch tensor
+   wrapping them).  Layout: env-major [N][dim], compute dtype. */
+void *tds_hip_x_device(tds_hip_sim_t *sim);
+void *tds_hip_y_device(tds_hip_sim_t *sim);
+
+/* Host <-> resident record transfers (double on the host side, converted to the compute
+   dtype).  These synchronise the handle's stream. */
+int tds_hip_set_inputs(tds_hip_sim_t *sim, const double *x_host /* [N*input_dim] */);
+int tds_hip_get_inputs(tds_hip_sim_t *sim, double *x_host /* [N*input_dim] */);
+int tds_hip_get_outputs(tds_hip_sim_t *sim, double *y_host /* [N*output_dim] */);
+
+/* y = f(x) on caller-provided DEVICE buffers in the compute dtype (pure function, the
+   reference's forward_zero semantics).  Asynchronous on the handle's stream. */
+int tds_hip_forward_zero_device(tds_hip_sim_t *sim, const void *x_dev, void *y_dev);
+
+/* One closed-loop environment step on the resident records, asynchronous:
+     - if actions_dev != NULL, x[:, dof_q+dof_qd : +action_dim] <- actions_dev [N][action_dim]
+     - y = f(x)
+     - x[:, 0 : dof_q+dof_qd] <- y[:, 0 : dof_q+dof_qd]     (what VectorizedEnvironment::step
+       does on the host, ars_vectorized_environment.h:240-289, minus reward/reset)
+   Repeated `substeps` times with the same action. */
+int tds_hip_step(tds_hip_sim_t *sim, const void *actions_dev, int substeps);
+
+/* Blocking convenience with HOST buffers in double, any N <= num_envs:
+   H2D(x) -> kernel -> D2H(y), i.e. exactly what the reference's <model>_forward_zero does. */
+int tds_hip_forward_zero_host(tds_hip_sim_t *sim, int n, const double *x_host, double *y_host);
+
+/* Time of the most recent kernel launch sequence measured with HIP events on the handle's
+   stream, in milliseconds (enabled by tds_hip_set_timing(sim, 1); synchronises). */
+int tds_hip_set_timing(tds_hip_sim_t *sim, int enable);
+int tds_hip_last_kernel_ms(tds_hip_sim_t *sim, float *ms);
+
+/* Static resource usage of the step kernel for this handle (for DESIGN.md / bench). */
+int tds_hip_kernel_info(const tds_hip_sim_t *sim, int *lds_bytes_per_env, int *threads_per_env,
+                        int *envs_per_block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDS_HIP_H */

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE.  Generates, FROM THE REAL REFERENCE (oracle/_ref/libtds_ref.so built
+from /root/reference by oracle/Makefile):
+
+  * tiny-differentiable-simulator_amd/models/<name>.json — the flattened model blobs of the
+    BASELINE.json configs (what TDS's own URDF loader + env constructors produce), and
+  * tests/golden/<name>.npz — seeded input/output vectors of the reference step:
+        x [N,in]  y [N,out]            single steps from randomised states (contacts on/off)
+        traj_x0 [in]  traj_y [T,out]   a T-step closed-loop rollout (y[:nq+nd] fed back)
+        qdd [N,nd]  M [N,nd,nd]        intermediates (ABA result, CRBA mass matrix)
+
+Run only where /root/reference exists:   python oracle/gen_golden.py
+The committed outputs are what travels to the GPU box."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import reflib  # noqa: E402
+import tds_amd  # noqa: E402
+
+# model name -> (reference constructor string, tweaks)
+MODELS = {
+    "cartpole": dict(ref="cartpole.urdf", dt=1e-3),                 # config 1
+    "pendulum5": dict(ref="pendulum5.urdf", dt=1e-3),               # config 2
+    "ant": dict(ref="ant"),                                         # config 3 / 5
+    "laikago": dict(ref="laikago"),                                 # env defaults (cfm 1e-5, erp 0.2)
+    "laikago_soft": dict(ref="laikago", soft=(1e4, 1e2)),           # config 4: cfm/erp from k, d
+    "pendulum5_plane": dict(ref="pendulum5.urdf+plane", dt=1e-3),   # sphere contacts on a chain
+    "cartpole_plane": dict(ref="cartpole.urdf+plane", dt=1e-3),     # plane-box (8 corner spheres)
+}
+
+
+def make_ref(name):
+    spec = MODELS[name]
+    r = reflib.RefSim(spec["ref"])
+    if "dt" in spec:
+        r.set_dt(spec["dt"])
+    m = r.flatten()
+    if "soft" in spec:
+        m.set_soft_contact(*spec["soft"])
+        r.set_solver(m.cfm, m.erp, m.pgs_iterations, m.friction, m.restitution)
+        m = r.flatten()
+    m.name = name.encode()
+    return r, m
+
+
+def random_inputs(name, m, n, rng):
+    """Synthetic states as SURVEY.md §8(d): mirrors the envs' reset distributions, widened so
+    that contacts are both active and inactive."""
+    nq, nd = m.dof_q, m.dof_qd
+    x = np.zeros((n, m.input_dim))
+    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
+        x[:, 0:2] = rng.uniform(-1, 1, (n, 2))
+        x[:, 2] = rng.uniform(0.15, 0.6, n)
+        x[:, 3:6] = rng.uniform(-0.6, 0.6, (n, 3))
+        ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
+        x[:, 6:nq] = ip + rng.uniform(-0.4, 0.4, (n, nq - 6))
+        x[:, nq:nq + nd] = rng.uniform(-2, 2, (n, nd))
+        x[:, nq + nd:nq + nd + m.action_dim] = rng.uniform(-0.6, 0.6, (n, m.action_dim))
+        x[:, -3:] = [15, 0.3, 3] if name.startswith("ant") else [100, 2, 50]
+    else:
+        x[:, :nq] = rng.uniform(-1, 1, (n, nq))
+        x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+        x[:, nq + nd:] = rng.uniform(-1, 1, (n, nd)) * (10 if "cartpole" in name else 1)
+        if name == "pendulum5_plane":
+            # the chain lies along +y in the plane z=0 at q=0: small angles straddle the ground
+            x[:, :nq] = rng.uniform(-0.25, 0.25, (n, nq))
+    return x
+
+
+def rollout_start(name, m, rng):
+    nq, nd = m.dof_q, m.dof_qd
+    x = np.zeros(m.input_dim)
+    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
+        ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
+        x[2] = 0.48
+        x[6:nq] = ip + 0.05 * rng.uniform(-1, 1, nq - 6)
+        x[-3:] = [15, 0.3, 3] if name.startswith("ant") else [100, 2, 50]
+    else:
+        x[:nq] = rng.uniform(-1, 1, nq)
+        if name == "pendulum5_plane":
+            x[:nq] = [0.3, -0.2, 0.1, 0.0, 0.1]
+    return x
+
+
+def main():
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    mdir = os.path.join(ROOT, "tiny-differentiable-simulator_amd", "models")
+    os.makedirs(mdir, exist_ok=True)
+    for idx, name in enumerate(MODELS):
+        r, m = make_ref(name)
+        tds_amd.save_model(m, os.path.join(mdir, name + ".json"))
+        rng = np.random.default_rng(1000 + idx)
+        n = 48
+        x = random_inputs(name, m, n, rng)
+        y = r.step(x)
+        nq, nd = m.dof_q, m.dof_qd
+        qdd = np.zeros((n, nd))
+        M = np.zeros((n, nd, nd))
+        ncs = np.zeros(n, dtype=np.int32)
+        for i in range(n):
+            d = r.debug(x[i], m)
+            qdd[i], M[i] = d["qdd"], d["M"]
+            ncs[i] = int((d["contacts"][:, 9] < 0).sum()) if len(d["contacts"]) else 0
+        T = 200 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION or m.has_plane else 100
+        x0 = rollout_start(name, m, rng)
+        xt = x0.copy()
+        traj = np.zeros((T, m.output_dim))
+        acts = rng.uniform(-0.4, 0.4, (T, m.action_dim))
+        if m.step_mode != tds_amd.TDS_STEP_LOCOMOTION:
+            acts *= 0.0 if name.startswith("pendulum5") else 25.0
+        for t in range(T):
+            xt[nq + nd:nq + nd + m.action_dim] = acts[t]
+            traj[t] = r.step(xt)[0]
+            xt[:nq + nd] = traj[t, :nq + nd]
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + ".npz"),
+                            x=x, y=y, qdd=qdd, M=M, active_contacts=ncs,
+                            traj_x0=x0, traj_actions=acts, traj_y=traj)
+        print(f"{name}: links={m.num_links} dof={nd} contacts={m.num_contacts} in={m.input_dim} "
+              f"out={m.output_dim} active contacts/state: min {ncs.min()} max {ncs.max()} "
+              f"mean {ncs.mean():.1f}")
+        r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,387 @@
+// ref_harness.cpp — TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Compiles the *unmodified* reference headers where they lie under /root/reference
+// (recipe: oracle/Makefile, target _ref/libtds_ref.so) and exposes them over a tiny C ABI so
+// that python tests / gen_golden.py can
+//   (a) flatten the reference's own MultiBody + World into the tds_model_t blob
+//       (same traversal a maintainer would do with include/tds_hip_stepper.hpp), and
+//   (b) run the reference's own step as ground truth:
+//         examples/environments/locomotion_contact_simulation.h:151-304 (Ant / Laikago)
+//         examples/environments/cartpole_environment.h:88-94            (free ABA + Euler)
+// Nothing here re-implements the algorithm; it only calls the reference.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "math/tiny/tiny_algebra.hpp"
+#include "math/tiny/tiny_double_utils.h"
+
+using namespace TINY;
+using namespace tds;
+typedef TinyAlgebra<double, ::TINY::DoubleUtils> Alg;
+
+#include "ant_environment2.h"
+#include "laikago_environment2.h"
+#include "dynamics/mass_matrix.hpp"
+#include "dynamics/jacobian.hpp"
+
+#include "tds_hip.h"
+
+namespace {
+
+typedef LocomotionContactSimulation<Alg, 3> LocoSim;
+
+static void copy_mat3(const Alg::Matrix3 &m, double *out) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) out[3 * r + c] = m(r, c);
+}
+static void copy_vec3(const Alg::Vector3 &v, double *out) {
+  out[0] = v[0];
+  out[1] = v[1];
+  out[2] = v[2];
+}
+
+struct RefSim {
+  std::string name;
+  // exactly one of the two is used
+  AntEnv2<Alg> *ant = nullptr;
+  LaikagoEnv<Alg> *laikago = nullptr;
+  // generic model (URDF file from the reference data dir, optional plane)
+  UrdfCache<Alg> cache;
+  World<Alg> *gworld = nullptr;
+  MultiBody<Alg> *gmb = nullptr;
+  bool g_plane = false;
+  double g_dt = 1e-3;
+
+  World<Alg> &world() {
+    if (ant) return ant->contact_sim.world;
+    if (laikago) return laikago->contact_sim.world;
+    return *gworld;
+  }
+  MultiBody<Alg> *mb() {
+    if (ant) return ant->contact_sim.mb_;
+    if (laikago) return laikago->contact_sim.mb_;
+    return gmb;
+  }
+  LocoSim *loco() {
+    if (ant) return &ant->contact_sim;
+    if (laikago) return &laikago->contact_sim;
+    return nullptr;
+  }
+  bool has_plane() { return loco() ? true : g_plane; }
+  double dt() { return loco() ? loco()->dt : g_dt; }
+
+  int input_dim() {
+    if (loco()) return loco()->input_dim_with_action_and_variables();
+    return gmb->dof() + gmb->dof_qd() + gmb->dof_qd();
+  }
+  int num_visuals() {
+    int n = 0;
+    for (const auto &l : *mb()) n += (int)l.X_visuals.size();
+    return n;
+  }
+  int output_dim() {
+    if (loco()) return loco()->output_dim();
+    return gmb->dof() + gmb->dof_qd() + 7 * num_visuals() + 1;
+  }
+
+  // generic step: the reference call sequence with tau given directly.
+  //   no plane : forward_dynamics; clear_forces; integrate_euler          (cartpole_environment.h:88-94)
+  //   plane    : forward_dynamics; clear_forces; integrate_euler_qdd; world.step; integrate_euler
+  //              (locomotion_contact_simulation.h:261-269, examples/soft_contact_example.cpp:107-115)
+  void generic_step(const double *x, double *y) {
+    MultiBody<Alg> &m = *gmb;
+    m.initialize();
+    for (int i = 0; i < m.dof(); ++i) m.q(i) = x[i];
+    for (int i = 0; i < m.dof_qd(); ++i) m.qd(i) = x[m.dof() + i];
+    for (int i = 0; i < m.dof_actuated(); ++i) m.tau(i) = x[m.dof() + m.dof_qd() + i];
+    forward_dynamics(m, gworld->get_gravity());
+    m.clear_forces();
+    if (g_plane) {
+      integrate_euler_qdd(m, g_dt);
+      gworld->step(g_dt);
+      integrate_euler(m, g_dt);
+    } else {
+      integrate_euler(m, g_dt);
+    }
+    int j = 0;
+    for (int i = 0; i < m.dof(); ++i) y[j++] = m.q(i);
+    for (int i = 0; i < m.dof_qd(); ++i) y[j++] = m.qd(i);
+    for (const auto &link : m) {
+      for (size_t v = 0; v < link.X_visuals.size(); ++v) {
+        auto vx = link.X_world * link.X_visuals[v];
+        y[j++] = vx.translation[0];
+        y[j++] = vx.translation[1];
+        y[j++] = vx.translation[2];
+        auto orn = Alg::matrix_to_quat(vx.rotation);
+        y[j++] = orn.x();
+        y[j++] = orn.y();
+        y[j++] = orn.z();
+        y[j++] = orn.w();
+      }
+    }
+    y[j++] = m.get_world_transform(-1).rotation(2, 2);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+// name: "ant" | "laikago" | "<file>.urdf" | "<file>.urdf+plane"   (file relative to <ref>/data)
+void *tdsref_create(const char *name_c, const char *reference_root) {
+  std::string name(name_c);
+  RefSim *s = new RefSim;
+  s->name = name;
+  if (name == "ant") {
+    s->ant = new AntEnv2<Alg>(false);
+  } else if (name == "laikago") {
+    s->laikago = new LaikagoEnv<Alg>(false);
+  } else {
+    std::string file = name;
+    size_t p = file.find("+plane");
+    if (p != std::string::npos) {
+      s->g_plane = true;
+      file = file.substr(0, p);
+    }
+    std::string root(reference_root);
+    s->gworld = new World<Alg>();
+    if (s->g_plane) {
+      // plane FIRST, so it is multi_bodies_[0] == mb_a (locomotion_contact_simulation.h:100-123)
+      s->cache.construct(root + "/data/plane_implicit.urdf", *s->gworld, false, false);
+    }
+    s->gmb = s->cache.construct(root + "/data/" + file, *s->gworld, false, false);
+    s->gmb->base_X_world().set_identity();
+    s->gworld->default_friction = 1;
+    s->gworld->get_mb_constraint_solver()->keep_all_points_ = true;
+  }
+  return s;
+}
+
+void tdsref_destroy(void *h) {
+  RefSim *s = (RefSim *)h;
+  delete s->ant;
+  delete s->laikago;
+  delete s->gworld;
+  delete s;
+}
+
+int tdsref_input_dim(void *h) { return ((RefSim *)h)->input_dim(); }
+int tdsref_output_dim(void *h) { return ((RefSim *)h)->output_dim(); }
+
+void tdsref_set_dt(void *h, double dt) {
+  RefSim *s = (RefSim *)h;
+  if (s->loco())
+    s->loco()->dt = dt;
+  else
+    s->g_dt = dt;
+}
+void tdsref_set_gravity(void *h, double gx, double gy, double gz) {
+  ((RefSim *)h)->world().set_gravity(Alg::Vector3(gx, gy, gz));
+}
+void tdsref_set_solver(void *h, double cfm, double erp, int pgs_iterations, double friction,
+                       double restitution) {
+  RefSim *s = (RefSim *)h;
+  auto *solver = s->world().get_mb_constraint_solver();
+  solver->cfm_ = cfm;
+  solver->erp_ = erp;
+  solver->pgs_iterations_ = pgs_iterations;
+  s->world().default_friction = friction;
+  s->world().default_restitution = restitution;
+}
+
+// Flatten the reference's MultiBody + World into the C-ABI blob.
+int tdsref_flatten(void *h, tds_model_t *out) {
+  RefSim *s = (RefSim *)h;
+  MultiBody<Alg> &m = *s->mb();
+  memset(out, 0, sizeof(*out));
+  out->abi_version = TDS_HIP_ABI_VERSION;
+  LocoSim *loco = s->loco();
+  out->step_mode = loco ? TDS_STEP_LOCOMOTION : TDS_STEP_TAU;
+  out->num_links = (int)m.num_links();
+  out->dof_q = m.dof();
+  out->dof_qd = m.dof_qd();
+  out->is_floating = m.is_floating() ? 1 : 0;
+  out->action_dim = loco ? loco->action_dim() : m.dof_qd();
+  out->pd_start_link = loco ? (m.is_floating() ? 0 : loco->base_dof_) : 0;
+  out->has_plane = s->has_plane() ? 1 : 0;
+  auto *solver = s->world().get_mb_constraint_solver();
+  out->pgs_iterations = solver->pgs_iterations_;
+  out->input_dim = s->input_dim();
+  out->output_dim = s->output_dim();
+  out->pack_visuals = 1;
+  out->dt = s->dt();
+  copy_vec3(s->world().get_gravity(), out->gravity);
+  copy_mat3(m.base_X_world().rotation, out->base_X_world_rot);
+  copy_vec3(m.base_X_world().translation, out->base_X_world_trans);
+  out->plane_normal[2] = 1.0;
+  out->plane_constant = 0.0;
+  if (s->has_plane()) {
+    // The plane body is multi_bodies_[0] (plane loaded first) but World keeps
+    // multi_bodies_ private; reach it through the public contact list of one dry-run step.
+    m.initialize();
+    Alg::VectorX qd_save = m.qd();
+    forward_kinematics(m, m.q(), m.qd());
+    s->world().step(s->dt());
+    m.qd() = qd_save;
+    if (s->world().mb_contacts_.empty() || s->world().mb_contacts_[0].empty()) return -5;
+    const auto &cp = s->world().mb_contacts_[0][0];
+    const auto &pg = cp.multi_body_a->collision_geometries(-1);
+    if (pg.size() != 1 || pg[0]->get_type() != TINY_PLANE_TYPE) return -6;
+    const Plane<Alg> *plane = (const Plane<Alg> *)pg[0];
+    copy_vec3(plane->get_normal(), out->plane_normal);
+    out->plane_constant = plane->get_constant();
+    m.initialize();
+  }
+  out->cfm = solver->cfm_;
+  out->erp = solver->erp_;
+  out->friction = s->world().default_friction;
+  out->restitution = s->world().default_restitution;
+  out->action_limit = 0.4;
+  if (loco) {
+    if ((int)loco->initial_poses_.size() > TDS_MAX_ACTIONS) return -1;
+    for (size_t i = 0; i < loco->initial_poses_.size(); ++i)
+      out->initial_poses[i] = loco->initial_poses_[i];
+  }
+  if (out->num_links > TDS_MAX_LINKS) return -2;
+  int ng = 0, nv = 0;
+  // base-link collision geometry of the robot (none in the five configs)
+  for (size_t g = 0; g < m.collision_geometries(-1).size(); ++g) {
+    if (ng >= TDS_MAX_GEOMS) return -3;
+    tds_geom_t &G = out->geoms[ng++];
+    const Geometry<Alg> *geom = m.collision_geometries(-1)[g];
+    G.link = -1;
+    G.type = geom->get_type();
+    if (G.type == TINY_SPHERE_TYPE) G.radius = ((const Sphere<Alg> *)geom)->get_radius();
+    if (G.type == TINY_CAPSULE_TYPE) {
+      G.radius = ((const Capsule<Alg> *)geom)->get_radius();
+      G.length = ((const Capsule<Alg> *)geom)->get_length();
+    }
+    if (G.type == TINY_BOX_TYPE) {
+      copy_vec3(((const Box<Alg> *)geom)->get_extents(), G.extents);
+      G.radius = ((const Box<Alg> *)geom)->get_radius();
+    }
+    copy_mat3(m.collision_transforms(-1)[g].rotation, G.X_rot);
+    copy_vec3(m.collision_transforms(-1)[g].translation, G.X_trans);
+  }
+  for (int i = 0; i < out->num_links; ++i) {
+    const Link<Alg> &l = m[i];
+    tds_link_t &L = out->links[i];
+    L.joint_type = (int)l.joint_type;
+    L.parent = l.parent_index;
+    L.q_index = l.q_index;
+    L.qd_index = l.qd_index;
+    copy_mat3(l.X_T.rotation, L.X_T_rot);
+    copy_vec3(l.X_T.translation, L.X_T_trans);
+    for (int k = 0; k < 6; ++k) L.S[k] = l.S[k];
+    L.mass = l.rbi.mass;
+    copy_vec3(l.rbi.com, L.com);
+    copy_mat3(l.rbi.inertia, L.inertia);
+    L.stiffness = l.stiffness;
+    L.damping = l.damping;
+    for (size_t g = 0; g < l.collision_geometries.size(); ++g) {
+      if (ng >= TDS_MAX_GEOMS) return -3;
+      tds_geom_t &G = out->geoms[ng++];
+      const Geometry<Alg> *geom = l.collision_geometries[g];
+      G.link = i;
+      G.type = geom->get_type();
+      if (G.type == TINY_SPHERE_TYPE) G.radius = ((const Sphere<Alg> *)geom)->get_radius();
+      if (G.type == TINY_CAPSULE_TYPE) {
+        G.radius = ((const Capsule<Alg> *)geom)->get_radius();
+        G.length = ((const Capsule<Alg> *)geom)->get_length();
+      }
+      if (G.type == TINY_BOX_TYPE) {
+        copy_vec3(((const Box<Alg> *)geom)->get_extents(), G.extents);
+        G.radius = ((const Box<Alg> *)geom)->get_radius();
+      }
+      copy_mat3(l.X_collisions[g].rotation, G.X_rot);
+      copy_vec3(l.X_collisions[g].translation, G.X_trans);
+    }
+    for (size_t v = 0; v < l.X_visuals.size(); ++v) {
+      if (nv >= TDS_MAX_VISUALS) return -4;
+      tds_visual_t &V = out->visuals[nv++];
+      V.link = i;
+      copy_mat3(l.X_visuals[v].rotation, V.X_rot);
+      copy_vec3(l.X_visuals[v].translation, V.X_trans);
+    }
+  }
+  out->num_geoms = ng;
+  out->num_visuals = nv;
+  snprintf(out->name, sizeof(out->name), "%s", s->name.c_str());
+  return 0;
+}
+
+// y[n][output_dim] = reference_step(x[n][input_dim]); y is zero-filled first (the reference's
+// callers hand in zero-initialised vectors, ars_vectorized_environment.h:218-219).
+void tdsref_step(void *h, int n, const double *x, double *y) {
+  RefSim *s = (RefSim *)h;
+  const int in = s->input_dim(), out = s->output_dim();
+  LocoSim *loco = s->loco();
+  std::vector<double> xi(in), yi(out);
+  for (int e = 0; e < n; ++e) {
+    xi.assign(x + (size_t)e * in, x + (size_t)(e + 1) * in);
+    std::fill(yi.begin(), yi.end(), 0.0);
+    if (loco)
+      loco->step_forward_original(xi, yi);
+    else
+      s->generic_step(xi.data(), yi.data());
+    memcpy(y + (size_t)e * out, yi.data(), sizeof(double) * out);
+  }
+}
+
+// Intermediates for localising a parity failure.  All computed by calling the reference's own
+// public functions on the state x (q, qd taken from x; tau = 0 unless generic model).
+//   qdd[dof_qd]           forward_dynamics (ABA)                 forward_dynamics.hpp:11
+//   M[dof_qd*dof_qd]      mass_matrix (CRBA), row-major          mass_matrix.hpp:13
+//   contacts[n_c*10]      (normal_on_b[3], point_on_b[3], point_on_a[3], distance) per contact,
+//                         from World::compute_contacts_multi_body  world.hpp:206-282
+//   jac[n_c*3*dof_qd]     point_jacobian2(robot, link_b, point_on_b) jacobian.hpp:85-90
+//   links[n_links]        link_b per contact
+// returns n_c
+int tdsref_debug(void *h, const double *x, double *qdd, double *M, double *contacts, double *jac,
+                 int *links, double *X_world /* n_links*12: rot(9) trans(3) */) {
+  RefSim *s = (RefSim *)h;
+  MultiBody<Alg> &m = *s->mb();
+  m.initialize();
+  for (int i = 0; i < m.dof(); ++i) m.q(i) = x[i];
+  for (int i = 0; i < m.dof_qd(); ++i) m.qd(i) = x[m.dof() + i];
+  if (!s->loco())
+    for (int i = 0; i < m.dof_actuated(); ++i) m.tau(i) = x[m.dof() + m.dof_qd() + i];
+  forward_dynamics(m, s->world().get_gravity());
+  for (int i = 0; i < m.dof_qd(); ++i) qdd[i] = m.qdd(i);
+  for (int i = 0; i < (int)m.num_links(); ++i) {
+    copy_mat3(m[i].X_world.rotation, X_world + 12 * i);
+    copy_vec3(m[i].X_world.translation, X_world + 12 * i + 9);
+  }
+  int n_c = 0;
+  Alg::MatrixX Mm(m.dof_qd(), m.dof_qd());
+  mass_matrix(m, &Mm);
+  for (int r = 0; r < m.dof_qd(); ++r)
+    for (int c = 0; c < m.dof_qd(); ++c) M[r * m.dof_qd() + c] = Mm(r, c);
+  if (s->has_plane()) {
+    // run one World::step on a copy of the velocities so that mb_contacts_ (public) is filled
+    Alg::VectorX qd_save = m.qd();
+    s->world().step(s->dt());
+    m.qd() = qd_save;
+    if (!s->world().mb_contacts_.empty()) {
+      const auto &cps = s->world().mb_contacts_[0];
+      n_c = (int)cps.size();
+      for (int i = 0; i < n_c; ++i) {
+        const auto &cp = cps[i];
+        double *c = contacts + 10 * i;
+        copy_vec3(cp.world_normal_on_b, c);
+        copy_vec3(cp.world_point_on_b, c + 3);
+        copy_vec3(cp.world_point_on_a, c + 6);
+        c[9] = cp.distance;
+        links[i] = cp.link_b;
+        auto J = point_jacobian2(m, cp.link_b, cp.world_point_on_b, false);
+        for (int r = 0; r < 3; ++r)
+          for (int d = 0; d < m.dof_qd(); ++d) jac[(i * 3 + r) * m.dof_qd() + d] = J(r, d);
+      }
+    }
+  }
+  return n_c;
+}
+
+}  // extern "C"

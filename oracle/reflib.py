@@ -1,0 +1,96 @@
+"""TEST INFRASTRUCTURE.  ctypes access to oracle/_ref/libtds_ref.so — the REAL reference
+compiled from /root/reference by oracle/Makefile (only buildable where the reference is
+present).  Used by tests/ and oracle/gen_golden.py; never by the product."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+import tds_amd  # noqa: E402
+
+REF_ROOT = os.environ.get("TDS_REFERENCE_ROOT", "/root/reference")
+_LIB_PATH = os.path.join(_HERE, "_ref", "libtds_ref.so")
+
+
+def available() -> bool:
+    return os.path.exists(_LIB_PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(_LIB_PATH)
+        L.tdsref_create.restype = C.c_void_p
+        L.tdsref_create.argtypes = [C.c_char_p, C.c_char_p]
+        L.tdsref_destroy.argtypes = [C.c_void_p]
+        L.tdsref_input_dim.argtypes = [C.c_void_p]
+        L.tdsref_output_dim.argtypes = [C.c_void_p]
+        L.tdsref_set_dt.argtypes = [C.c_void_p, C.c_double]
+        L.tdsref_set_gravity.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.tdsref_set_solver.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double,
+                                        C.c_double]
+        L.tdsref_flatten.argtypes = [C.c_void_p, C.POINTER(tds_amd.Model)]
+        L.tdsref_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.tdsref_debug.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        _lib = L
+    return _lib
+
+
+class RefSim:
+    """name: "ant" | "laikago" | "<file>.urdf" | "<file>.urdf+plane" (file under <ref>/data)."""
+
+    def __init__(self, name: str):
+        # the reference prints "Loading URDF ..." to stdout; harmless
+        self.h = lib().tdsref_create(name.encode(), REF_ROOT.encode())
+        self.name = name
+        self.input_dim = lib().tdsref_input_dim(self.h)
+        self.output_dim = lib().tdsref_output_dim(self.h)
+
+    def close(self):
+        if self.h:
+            lib().tdsref_destroy(self.h)
+            self.h = None
+
+    def set_dt(self, dt):
+        lib().tdsref_set_dt(self.h, dt)
+
+    def set_gravity(self, g):
+        lib().tdsref_set_gravity(self.h, *map(float, g))
+
+    def set_solver(self, cfm, erp, pgs_iterations=1, friction=1.0, restitution=0.0):
+        lib().tdsref_set_solver(self.h, cfm, erp, pgs_iterations, friction, restitution)
+
+    def flatten(self) -> "tds_amd.Model":
+        m = tds_amd.Model()
+        rc = lib().tdsref_flatten(self.h, C.byref(m))
+        if rc != 0:
+            raise RuntimeError(f"tdsref_flatten failed rc={rc}")
+        return m
+
+    def step(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.input_dim)
+        y = np.zeros((x.shape[0], self.output_dim), dtype=np.float64)
+        lib().tdsref_step(self.h, x.shape[0], x.ctypes.data, y.ctypes.data)
+        return y
+
+    def debug(self, x: np.ndarray, model):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        nd, nl = model.dof_qd, model.num_links
+        ncmax = 64
+        qdd = np.zeros(nd)
+        M = np.zeros((nd, nd))
+        contacts = np.zeros((ncmax, 10))
+        jac = np.zeros((ncmax, 3, nd))
+        links = np.zeros(ncmax, dtype=np.int32)
+        Xw = np.zeros((nl, 12))
+        nc = lib().tdsref_debug(self.h, x.ctypes.data, qdd.ctypes.data, M.ctypes.data,
+                                contacts.ctypes.data, jac.ctypes.data, links.ctypes.data,
+                                Xw.ctypes.data)
+        return dict(qdd=qdd, M=M, contacts=contacts[:nc], jac=jac[:nc], links=links[:nc],
+                    X_world=Xw)

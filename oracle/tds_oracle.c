@@ -1,0 +1,839 @@
+/* tds_oracle.c — TEST INFRASTRUCTURE ONLY (see tds_oracle.h for the pinning statement).
+ *
+ * Plain-C restatement of the reference's per-environment step.  "ref:" comments give the
+ * file:line under /root/reference that each block follows.  Default (right-associative)
+ * transform convention, TinyAlgebra<double> arithmetic.
+ */
+#include "tds_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NL TDS_MAX_LINKS
+#define ND 32
+#define NCMAX 64
+#define NR (3 * NCMAX)
+
+typedef struct { double r[9], t[3]; } xf_t;      /* Transform: rotation (row-major), translation */
+typedef struct { double a[3], l[3]; } sv_t;      /* spatial vector: top (angular), bottom (linear) */
+typedef struct { double I[9], H[9], M[9]; } abi_t; /* ArticulatedBodyInertia blocks */
+
+/* ---------------------------------------------------------------- 3-vector / 3x3 helpers */
+static void v3_cross(const double *a, const double *b, double *o) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static double v3_dot(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void m3_mulv(const double *m, const double *v, double *o) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  double y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  double z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3_tmulv(const double *m, const double *v, double *o) { /* m^T v */
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  double y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  double z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3_mul(const double *a, const double *b, double *o) {
+  double t[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      t[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c] + a[3 * r + 2] * b[6 + c];
+  memcpy(o, t, sizeof(t));
+}
+static void m3_transpose(const double *a, double *o) {
+  double t[9] = {a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8]};
+  memcpy(o, t, sizeof(t));
+}
+static void m3_identity(double *m) { memset(m, 0, 9 * sizeof(double)); m[0] = m[4] = m[8] = 1.0; }
+/* ref: src/math/tiny/tiny_matrix3x3.h:1015-1021 */
+static void m3_cross_matrix(const double *v, double *m) {
+  m[0] = 0; m[1] = -v[2]; m[2] = v[1];
+  m[3] = v[2]; m[4] = 0; m[5] = -v[0];
+  m[6] = -v[1]; m[7] = v[0]; m[8] = 0;
+}
+
+/* ---------------------------------------------------------------- quaternions (x,y,z,w) */
+/* ref: src/math/tiny/tiny_matrix3x3.h:315-340 (setRotation, right-associative branch) */
+static void quat_to_matrix(const double *q, double *m) {
+  double d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (d == 0.0) { return; }
+  double s = 2.0 / d;
+  double xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+  double wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+  double xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+  double yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+  m[0] = 1.0 - (yy + zz); m[1] = xy - wz; m[2] = xz + wy;
+  m[3] = xy + wz; m[4] = 1.0 - (xx + zz); m[5] = yz - wx;
+  m[6] = xz - wy; m[7] = yz + wx; m[8] = 1.0 - (xx + yy);
+}
+/* ref: src/math/tiny/tiny_matrix3x3.h:432-465 (getRotation, non-CppAD, right-associative:
+   off-diagonal differences transposed w.r.t. Bullet and w negated) */
+static void matrix_to_quat(const double *m, double *q) {
+  double trace = m[0] + m[4] + m[8];
+  double temp[4];
+  if (trace < 0.0) {
+    int i = m[0] < m[4] ? (m[4] < m[8] ? 2 : 1) : (m[0] < m[8] ? 2 : 0);
+    int j = (i + 1) % 3, k = (i + 2) % 3;
+    double tmp = ((m[3 * i + i] - m[3 * j + j]) - m[3 * k + k]) + 1.0;
+    double s = sqrt(tmp);
+    temp[i] = s * 0.5;
+    s = 0.5 / s;
+    temp[3] = (m[3 * j + k] - m[3 * k + j]) * s;
+    temp[j] = (m[3 * i + j] + m[3 * j + i]) * s;
+    temp[k] = (m[3 * i + k] + m[3 * k + i]) * s;
+  } else {
+    double s = sqrt(trace + 1.0);
+    temp[3] = s * 0.5;
+    s = 0.5 / s;
+    temp[0] = (m[5] - m[7]) * s;
+    temp[1] = (m[6] - m[2]) * s;
+    temp[2] = (m[1] - m[3]) * s;
+  }
+  q[0] = temp[0]; q[1] = temp[1]; q[2] = temp[2]; q[3] = -temp[3];
+}
+/* ref: src/math/tiny/tiny_algebra.hpp:219-222 */
+static void quat_normalize(double *q) {
+  double ql = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] /= ql; q[1] /= ql; q[2] /= ql; q[3] /= ql;
+}
+/* ref: src/math/tiny/tiny_quaternion.h:171-176, 306-345 (q * v) * q^-1 */
+static void quat_rotate(const double *q, const double *v, double *o) {
+  double t[4] = {q[3] * v[0] + q[1] * v[2] - q[2] * v[1], q[3] * v[1] + q[2] * v[0] - q[0] * v[2],
+                 q[3] * v[2] + q[0] * v[1] - q[1] * v[0], -q[0] * v[0] - q[1] * v[1] - q[2] * v[2]};
+  double i[4] = {-q[0], -q[1], -q[2], q[3]};
+  /* t *= i  (tiny_quaternion.h:90-96) */
+  o[0] = t[3] * i[0] + t[0] * i[3] + t[1] * i[2] - t[2] * i[1];
+  o[1] = t[3] * i[1] + t[1] * i[3] + t[2] * i[0] - t[0] * i[2];
+  o[2] = t[3] * i[2] + t[2] * i[3] + t[0] * i[1] - t[1] * i[0];
+}
+
+/* ---------------------------------------------------------------- Transform */
+static void xf_identity(xf_t *x) { m3_identity(x->r); x->t[0] = x->t[1] = x->t[2] = 0; }
+/* ref: src/math/transform.hpp:123-131  (A*B).t = A.t + A.R B.t ; R = A.R B.R */
+static void xf_mul(const xf_t *a, const xf_t *b, xf_t *o) {
+  xf_t r;
+  double rt[3];
+  m3_mulv(a->r, b->t, rt);
+  for (int k = 0; k < 3; ++k) r.t[k] = a->t[k] + rt[k];
+  m3_mul(a->r, b->r, r.r);
+  *o = r;
+}
+/* ref: src/math/transform.hpp:210-226  X*V = (E w, E (v - r x w)),  E = R^T */
+static void xf_apply_motion(const xf_t *x, const sv_t *in, sv_t *o) {
+  double rxw[3], v_rxw[3];
+  sv_t r;
+  v3_cross(x->t, in->a, rxw);
+  for (int k = 0; k < 3; ++k) v_rxw[k] = in->l[k] - rxw[k];
+  m3_tmulv(x->r, in->a, r.a);
+  m3_tmulv(x->r, v_rxw, r.l);
+  *o = r;
+}
+/* ref: src/math/transform.hpp:232-243  inv(X)*V = (R w, R v + r x (R w)) */
+static void xf_apply_inverse_motion(const xf_t *x, const sv_t *in, sv_t *o) {
+  sv_t r;
+  double c[3];
+  m3_mulv(x->r, in->a, r.a);
+  m3_mulv(x->r, in->l, r.l);
+  v3_cross(x->t, r.a, c);
+  for (int k = 0; k < 3; ++k) r.l[k] += c[k];
+  *o = r;
+}
+/* ref: src/math/transform.hpp:249-262  X^T F = (R n + r x (R f), R f) */
+static void xf_apply_force(const xf_t *x, const sv_t *in, sv_t *o) {
+  sv_t r;
+  double c[3];
+  m3_mulv(x->r, in->l, r.l);
+  m3_mulv(x->r, in->a, r.a);
+  v3_cross(x->t, r.l, c);
+  for (int k = 0; k < 3; ++k) r.a[k] += c[k];
+  *o = r;
+}
+/* ref: src/math/transform.hpp:72-87  matrix(): [E 0; -E rx  E], E = R^T */
+static void xf_matrix(const xf_t *x, double *m /*36*/) {
+  double E[9], rx[9], mErx[9];
+  m3_transpose(x->r, E);
+  m3_cross_matrix(x->t, rx);
+  m3_mul(E, rx, mErx);
+  for (int k = 0; k < 9; ++k) mErx[k] = -mErx[k];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      m[6 * r + c] = E[3 * r + c];
+      m[6 * r + 3 + c] = 0.0;
+      m[6 * (r + 3) + c] = mErx[3 * r + c];
+      m[6 * (r + 3) + 3 + c] = E[3 * r + c];
+    }
+}
+/* ref: src/math/transform.hpp:89-104  matrix_transpose(): [Et (-E rx)^T; 0 Et] */
+static void xf_matrix_transpose(const xf_t *x, double *m /*36*/) {
+  double E[9], rx[9], mErx[9], mErxT[9];
+  m3_transpose(x->r, E);
+  m3_cross_matrix(x->t, rx);
+  m3_mul(E, rx, mErx);
+  for (int k = 0; k < 9; ++k) mErx[k] = -mErx[k];
+  m3_transpose(mErx, mErxT);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      m[6 * r + c] = x->r[3 * r + c];
+      m[6 * r + 3 + c] = mErxT[3 * r + c];
+      m[6 * (r + 3) + c] = 0.0;
+      m[6 * (r + 3) + 3 + c] = x->r[3 * r + c];
+    }
+}
+
+/* ---------------------------------------------------------------- spatial algebra */
+/* ref: src/math/tiny/tiny_algebra.hpp:101-105  V1 x V2 = (w1 x w2, w1 x v2 + v1 x w2) */
+static void sv_cross_mm(const sv_t *a, const sv_t *b, sv_t *o) {
+  sv_t r;
+  double c1[3], c2[3];
+  v3_cross(a->a, b->a, r.a);
+  v3_cross(a->a, b->l, c1);
+  v3_cross(a->l, b->a, c2);
+  for (int k = 0; k < 3; ++k) r.l[k] = c1[k] + c2[k];
+  *o = r;
+}
+/* ref: src/math/tiny/tiny_algebra.hpp:112-115  V x* F = (w x n + v x f, w x f) */
+static void sv_cross_mf(const sv_t *a, const sv_t *b, sv_t *o) {
+  sv_t r;
+  double c1[3], c2[3];
+  v3_cross(a->a, b->a, c1);
+  v3_cross(a->l, b->l, c2);
+  for (int k = 0; k < 3; ++k) r.a[k] = c1[k] + c2[k];
+  v3_cross(a->a, b->l, r.l);
+  *o = r;
+}
+static double sv_dot(const sv_t *a, const sv_t *b) { return v3_dot(a->a, b->a) + v3_dot(a->l, b->l); }
+
+/* ref: src/math/inertia.hpp:121-130  ABI from RBI */
+static void abi_from_rbi(double mass, const double *com, const double *inertia, abi_t *o) {
+  double H[9], Ht[9], HHt[9];
+  m3_cross_matrix(com, H);
+  m3_transpose(H, Ht);
+  m3_mul(H, Ht, HHt);
+  for (int k = 0; k < 9; ++k) o->I[k] = inertia[k] + HHt[k] * mass;
+  memset(o->M, 0, sizeof(o->M));
+  o->M[0] = o->M[4] = o->M[8] = mass;
+  for (int k = 0; k < 9; ++k) o->H[k] = H[k] * mass;
+}
+/* ref: src/math/inertia.hpp:205-210  IA*v = (I w + H v, M v + H^T w) */
+static void abi_mul(const abi_t *A, const sv_t *v, sv_t *o) {
+  sv_t r;
+  double t1[3], t2[3];
+  m3_mulv(A->I, v->a, t1);
+  m3_mulv(A->H, v->l, t2);
+  for (int k = 0; k < 3; ++k) r.a[k] = t1[k] + t2[k];
+  m3_mulv(A->M, v->l, t1);
+  m3_tmulv(A->H, v->a, t2);
+  for (int k = 0; k < 3; ++k) r.l[k] = t1[k] + t2[k];
+  *o = r;
+}
+/* ref: src/math/inertia.hpp:152-160 */
+static void abi_matrix(const abi_t *A, double *m /*36*/) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      m[6 * r + c] = A->I[3 * r + c];
+      m[6 * r + 3 + c] = A->H[3 * r + c];
+      m[6 * (r + 3) + c] = A->H[3 * c + r];
+      m[6 * (r + 3) + 3 + c] = A->M[3 * r + c];
+    }
+}
+/* ref: src/math/inertia.hpp:138-143  only I, H (upper right) and M blocks are read */
+static void abi_from_matrix(const double *m, abi_t *A) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      A->I[3 * r + c] = m[6 * r + c];
+      A->H[3 * r + c] = m[6 * r + 3 + c];
+      A->M[3 * r + c] = m[6 * (r + 3) + 3 + c];
+    }
+}
+static void m6_mul(const double *a, const double *b, double *o) {
+  double t[36];
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) {
+      double s = 0.0;
+      for (int k = 0; k < 6; ++k) s += a[6 * r + k] * b[6 * k + c];
+      t[6 * r + c] = s;
+    }
+  memcpy(o, t, sizeof(t));
+}
+/* ref: forward_dynamics.hpp:187-189 / mass_matrix.hpp:45-46  X^T * Ia * X as dense 6x6 */
+static void abi_congruence(const xf_t *X, const abi_t *Ia, abi_t *out) {
+  double xt[36], im[36], xm[36], tmp[36], xix[36];
+  xf_matrix_transpose(X, xt);
+  abi_matrix(Ia, im);
+  xf_matrix(X, xm);
+  m6_mul(xt, im, tmp);
+  m6_mul(tmp, xm, xix);
+  abi_from_matrix(xix, out);
+}
+
+/* ---------------------------------------------------------------- per-env scratch */
+typedef struct {
+  xf_t X_J, X_parent, X_world;
+  sv_t S, vJ, v, c, a, pA, U;
+  abi_t abi;
+  double D, u;
+} lstate_t;
+
+typedef struct {
+  double normal[3], point_a[3], point_b[3], distance;
+  int link_b;
+} contact_t;
+
+typedef struct {
+  lstate_t L[NL];
+  xf_t base_X_world;
+  double q[ND], qd[ND], qdd[ND], tau[ND];
+  contact_t cps[NCMAX];
+  int n_c;
+  double M[ND * ND], Minv[ND * ND];
+  double J[NR * ND], JM[NR * ND], A[NR * NR], b[NR], p[NR], lo[NR], hi[NR];
+  int dep[NR];
+  double jac[3 * ND];
+} scratch_t;
+
+static void link_xf(const tds_link_t *l, xf_t *x) {
+  memcpy(x->r, l->X_T_rot, sizeof(x->r));
+  memcpy(x->t, l->X_T_trans, sizeof(x->t));
+}
+
+/* ref: src/link.hpp:229-287 (X_J, X_parent) and :289-329 (vJ) */
+static void jcalc(const tds_link_t *l, double q, double qd, int have_qd, lstate_t *s) {
+  xf_t XT;
+  link_xf(l, &XT);
+  xf_identity(&s->X_J);
+  double c = cos(q), sn = sin(q);
+  switch (l->joint_type) {
+    case TDS_JOINT_PRISMATIC_X: s->X_J.t[0] = q; break;
+    case TDS_JOINT_PRISMATIC_Y: s->X_J.t[1] = q; break;
+    case TDS_JOINT_PRISMATIC_Z: s->X_J.t[2] = q; break;
+    case TDS_JOINT_PRISMATIC_AXIS:
+      for (int k = 0; k < 3; ++k) s->X_J.t[k] = l->S[3 + k] * q;
+      break;
+    case TDS_JOINT_REVOLUTE_X: { /* ref: tiny_matrix3x3.h:218-234 */
+      double m[9] = {1, 0, 0, 0, c, -sn, 0, sn, c};
+      memcpy(s->X_J.r, m, sizeof(m));
+      break;
+    }
+    case TDS_JOINT_REVOLUTE_Y: {
+      double m[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c};
+      memcpy(s->X_J.r, m, sizeof(m));
+      break;
+    }
+    case TDS_JOINT_REVOLUTE_Z: {
+      double m[9] = {c, -sn, 0, sn, c, 0, 0, 0, 1};
+      memcpy(s->X_J.r, m, sizeof(m));
+      break;
+    }
+    case TDS_JOINT_REVOLUTE_AXIS: { /* ref: link.hpp:256-261, tiny_quaternion.h:178-183 */
+      const double *axis = l->S;
+      double d = sqrt(v3_dot(axis, axis));
+      double sh = sin(q * 0.5) / d;
+      double quat[4] = {axis[0] * sh, axis[1] * sh, axis[2] * sh, cos(q * 0.5)};
+      quat_to_matrix(quat, s->X_J.r);
+      break;
+    }
+    default: break; /* JOINT_FIXED: identity */
+  }
+  xf_mul(&XT, &s->X_J, &s->X_parent); /* ref: link.hpp:283 */
+  /* vJ: every jcalc(qd) variant writes S-aligned components only == S*qd (S unit-axis for _X/_Y/_Z) */
+  if (!have_qd) qd = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    s->vJ.a[k] = l->S[k] * qd;
+    s->vJ.l[k] = l->S[3 + k] * qd;
+  }
+}
+
+/* ref: src/dynamics/kinematics.hpp:18-148 (fixed base) */
+static void forward_kinematics(const tds_model_t *m, scratch_t *s, int have_qd) {
+  for (int i = 0; i < m->num_links; ++i) {
+    const tds_link_t *l = &m->links[i];
+    lstate_t *L = &s->L[i];
+    double q = l->q_index >= 0 ? s->q[l->q_index] : 0.0;   /* multi_body.hpp:490-500 */
+    double qd = l->qd_index >= 0 ? s->qd[l->qd_index] : 0.0;
+    jcalc(l, q, qd, have_qd, L);
+    if (l->parent >= 0) {
+      xf_mul(&s->L[l->parent].X_world, &L->X_parent, &L->X_world); /* :82 */
+      sv_t xv;
+      xf_apply_motion(&L->X_parent, &s->L[l->parent].v, &xv); /* :86 */
+      for (int k = 0; k < 3; ++k) { L->v.a[k] = xv.a[k] + L->vJ.a[k]; L->v.l[k] = xv.l[k] + L->vJ.l[k]; }
+    } else {
+      xf_mul(&s->base_X_world, &L->X_parent, &L->X_world); /* :92 */
+      L->v = L->vJ;
+    }
+    sv_cross_mm(&L->v, &L->vJ, &L->c); /* :96-97 (cJ == 0) */
+    abi_from_rbi(l->mass, l->com, l->inertia, &L->abi); /* :99 */
+    sv_t Iv;
+    abi_mul(&L->abi, &L->v, &Iv);
+    sv_cross_mf(&L->v, &Iv, &L->pA); /* :132, f_ext == 0 after clear_forces */
+  }
+}
+
+/* ref: src/dynamics/forward_dynamics.hpp:11-326 (fixed base, 1-DoF + fixed joints) */
+static void forward_dynamics(const tds_model_t *m, scratch_t *s) {
+  forward_kinematics(m, s, 1);
+  for (int i = m->num_links - 1; i >= 0; --i) {
+    const tds_link_t *l = &m->links[i];
+    lstate_t *L = &s->L[i];
+    abi_mul(&L->abi, &L->S, &L->U);           /* :111 */
+    L->D = sv_dot(&L->S, &L->U);              /* :115 */
+    double tau_val = 0.0;                      /* multi_body.hpp:557-570 */
+    if (l->joint_type != TDS_JOINT_FIXED) tau_val = s->tau[l->qd_index];
+    double qv = l->q_index >= 0 ? s->q[l->q_index] : 0.0;
+    double qdv = l->qd_index >= 0 ? s->qd[l->qd_index] : 0.0;
+    tau_val -= l->stiffness * qv;              /* :122 */
+    tau_val -= l->damping * qdv;               /* :123 */
+    L->u = tau_val - sv_dot(&L->S, &L->pA);    /* :129 */
+    double invD = l->joint_type == TDS_JOINT_FIXED ? 0.0 : 1.0 / L->D; /* :153 */
+    /* u_dinv_ut = U (U invD)^T  (inertia.hpp:333-348) */
+    abi_t Ia;
+    sv_t Ub;
+    for (int k = 0; k < 3; ++k) { Ub.a[k] = L->U.a[k] * invD; Ub.l[k] = L->U.l[k] * invD; }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        Ia.I[3 * r + c] = L->abi.I[3 * r + c] - L->U.a[r] * Ub.a[c];
+        Ia.H[3 * r + c] = L->abi.H[3 * r + c] - L->U.a[r] * Ub.l[c];
+        Ia.M[3 * r + c] = L->abi.M[3 * r + c] - L->U.l[r] * Ub.l[c];
+      }                                         /* :168 */
+    sv_t Ia_c, pa, UuD;
+    abi_mul(&Ia, &L->c, &Ia_c);                /* :171 */
+    double uinvD = L->u * invD;
+    for (int k = 0; k < 3; ++k) { UuD.a[k] = L->U.a[k] * uinvD; UuD.l[k] = L->U.l[k] * uinvD; } /* :162 */
+    for (int k = 0; k < 3; ++k) {
+      pa.a[k] = L->pA.a[k] + Ia_c.a[k] + UuD.a[k];
+      pa.l[k] = L->pA.l[k] + Ia_c.l[k] + UuD.l[k];
+    }                                           /* :173 */
+    if (l->parent >= 0) {
+      sv_t dpA;
+      abi_t dI;
+      xf_apply_force(&L->X_parent, &pa, &dpA); /* :181 */
+      abi_congruence(&L->X_parent, &Ia, &dI);  /* :187-189 */
+      lstate_t *P = &s->L[l->parent];
+      for (int k = 0; k < 3; ++k) { P->pA.a[k] += dpA.a[k]; P->pA.l[k] += dpA.l[k]; }
+      for (int k = 0; k < 9; ++k) { P->abi.I[k] += dI.I[k]; P->abi.H[k] += dI.H[k]; P->abi.M[k] += dI.M[k]; }
+    }
+  }
+  sv_t a_base; /* :242  base_acceleration = -spatial_gravity (not rotated: rbdl_convention=false) */
+  for (int k = 0; k < 3; ++k) { a_base.a[k] = 0.0; a_base.l[k] = -m->gravity[k]; }
+  for (int i = 0; i < m->num_links; ++i) { /* :245-302 */
+    const tds_link_t *l = &m->links[i];
+    lstate_t *L = &s->L[i];
+    const sv_t *ap = l->parent >= 0 ? &s->L[l->parent].a : &a_base;
+    sv_t xa;
+    xf_apply_motion(&L->X_parent, ap, &xa);
+    for (int k = 0; k < 3; ++k) { L->a.a[k] = xa.a[k] + L->c.a[k]; L->a.l[k] = xa.l[k] + L->c.l[k]; }
+    if (l->qd_index >= 0) {
+      double invD = l->joint_type == TDS_JOINT_FIXED ? 0.0 : 1.0 / L->D;
+      double Ut_a = sv_dot(&L->U, &L->a);
+      double qdd = invD * (L->u - Ut_a);
+      s->qdd[l->qd_index] = qdd;
+      for (int k = 0; k < 3; ++k) { L->a.a[k] += L->S.a[k] * qdd; L->a.l[k] += L->S.l[k] * qdd; }
+    }
+  }
+}
+
+/* ref: src/dynamics/mass_matrix.hpp:13-127 (fixed base, 1-DoF + fixed joints) */
+static void mass_matrix(const tds_model_t *m, scratch_t *s) {
+  const int n = m->num_links, nd = m->dof_qd;
+  forward_kinematics(m, s, 0); /* :37  qd empty -> v = 0 */
+  memset(s->M, 0, sizeof(double) * nd * nd);
+  for (int i = n - 1; i >= 0; --i) {
+    const tds_link_t *l = &m->links[i];
+    lstate_t *L = &s->L[i];
+    if (l->parent >= 0) {
+      abi_t dI;
+      abi_congruence(&L->X_parent, &L->abi, &dI); /* :45-46 */
+      lstate_t *P = &s->L[l->parent];
+      for (int k = 0; k < 9; ++k) { P->abi.I[k] += dI.I[k]; P->abi.H[k] += dI.H[k]; P->abi.M[k] += dI.M[k]; }
+    }
+    if (l->joint_type == TDS_JOINT_FIXED) continue; /* :56 */
+    int qd_i = l->qd_index;
+    sv_t Fi;
+    abi_mul(&L->abi, &L->S, &Fi);              /* :87 */
+    s->M[qd_i * nd + qd_i] = sv_dot(&L->S, &Fi); /* :89 */
+    int j = i;
+    while (m->links[j].parent != -1) {         /* :92-109 */
+      xf_apply_force(&s->L[j].X_parent, &Fi, &Fi);
+      j = m->links[j].parent;
+      if (m->links[j].joint_type == TDS_JOINT_FIXED) continue;
+      int qd_j = m->links[j].qd_index;
+      double h = sv_dot(&Fi, &s->L[j].S);
+      s->M[qd_i * nd + qd_j] = h;
+      s->M[qd_j * nd + qd_i] = h;
+    }
+  }
+}
+
+/* ref: src/math/tiny/tiny_matrix_x.h:240-345  A^-1 = L^-T L^-1 through Cholesky.
+   returns 0 if not positive definite */
+static int symmetric_inverse(const double *A, double *a, int n) {
+  double diag[ND];
+  /* a[i][j] in the reference is column-major; the matrix is symmetric so we use row-major */
+  for (int i = 0; i < n * n; ++i) a[i] = A[i];
+  for (int i = 0; i < n; i++) {
+    for (int j = i; j < n; j++) {
+      double sum = a[i * n + j];
+      for (int k = i - 1; k >= 0; k--) sum -= a[i * n + k] * a[j * n + k];
+      if (i == j) {
+        if (sum <= 0.0) return 0;
+        diag[i] = sqrt(sum);
+      } else {
+        a[j * n + i] = sum / diag[i];
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    a[i * n + i] = 1.0 / diag[i];
+    for (int j = i + 1; j < n; j++) {
+      double sum = 0.0;
+      for (int k = i; k < j; k++) sum -= a[j * n + k] * a[k * n + i];
+      a[j * n + i] = sum / diag[j];
+    }
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++) a[i * n + j] = 0.0;
+  for (int i = 0; i < n; i++) {
+    a[i * n + i] = a[i * n + i] * a[i * n + i];
+    for (int k = i + 1; k < n; k++) a[i * n + i] += a[k * n + i] * a[k * n + i];
+    for (int j = i + 1; j < n; j++)
+      for (int k = j; k < n; k++) a[i * n + j] += a[k * n + i] * a[k * n + j];
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) a[i * n + j] = a[j * n + i];
+  return 1;
+}
+
+/* ref: src/dynamics/jacobian.hpp:13-83 (fixed base, world point).  forward_kinematics_q
+   (kinematics.hpp:168-236) recomputes the same X_world the links already hold for this q. */
+static void point_jacobian(const tds_model_t *m, const scratch_t *s, int link_index,
+                           const double *point, double *jac /* 3 x nd */) {
+  const int nd = m->dof_qd;
+  memset(jac, 0, sizeof(double) * 3 * nd);
+  int i = link_index;
+  while (i >= 0) {
+    const tds_link_t *l = &m->links[i];
+    if (l->joint_type != TDS_JOINT_FIXED) {
+      sv_t st;
+      xf_apply_inverse_motion(&s->L[i].X_world, &s->L[i].S, &st); /* :74 */
+      /* point_tf.apply(st): rotation = I, translation = point (transform.hpp:210-226) */
+      double rxw[3];
+      v3_cross(point, st.a, rxw);
+      for (int r = 0; r < 3; ++r) jac[r * nd + l->qd_index] = st.l[r] - rxw[r]; /* :76 */
+    }
+    i = l->parent;
+  }
+}
+
+/* ref: src/contact_point.hpp:96-125 */
+static void contact_plane_sphere(const tds_model_t *m, const double *pos, double radius, int link,
+                                 scratch_t *s) {
+  const double *n = m->plane_normal;
+  contact_t *c = &s->cps[s->n_c++];
+  double mn[3] = {-n[0], -n[1], -n[2]};
+  double t = -(v3_dot(pos, mn) + m->plane_constant);
+  for (int k = 0; k < 3; ++k) {
+    c->point_a[k] = pos[k] + t * mn[k];
+    c->point_b[k] = pos[k] - radius * n[k];
+    c->normal[k] = mn[k];
+  }
+  c->distance = t - radius;
+  c->link_b = link;
+}
+
+/* ref: src/world.hpp:206-282 with mb_a = plane (one geom on its base), mb_b = robot;
+   dispatch through contact_point.hpp:444-496 (plane-sphere / plane-capsule / plane-box) */
+static void compute_contacts(const tds_model_t *m, scratch_t *s) {
+  s->n_c = 0;
+  if (!m->has_plane) return;
+  for (int g = 0; g < m->num_geoms; ++g) {
+    const tds_geom_t *G = &m->geoms[g];
+    xf_t local, tr;
+    memcpy(local.r, G->X_rot, sizeof(local.r));
+    memcpy(local.t, G->X_trans, sizeof(local.t));
+    const xf_t *Xw = G->link >= 0 ? &s->L[G->link].X_world : &s->base_X_world;
+    xf_mul(Xw, &local, &tr);                 /* world.hpp:242 */
+    double orn[4];
+    matrix_to_quat(tr.r, orn);               /* world.hpp:244-245 */
+    quat_normalize(orn);
+    if (G->type == TDS_GEOM_SPHERE) {
+      contact_plane_sphere(m, tr.t, G->radius, G->link, s);
+    } else if (G->type == TDS_GEOM_CAPSULE) { /* contact_point.hpp:127-161 */
+      for (int e = 0; e < 2; ++e) {
+        double off[3] = {0.0, 0.0, (e == 0 ? 0.5 : -0.5) * G->length}, ro[3], p[3];
+        quat_rotate(orn, off, ro);           /* pose.hpp:47-53 */
+        for (int k = 0; k < 3; ++k) p[k] = tr.t[k] + ro[k];
+        contact_plane_sphere(m, p, G->radius, G->link, s);
+      }
+    } else if (G->type == TDS_GEOM_BOX) {    /* contact_point.hpp:163-198, geometry.hpp:244-259 */
+      double cr = G->radius > 1e-2 ? G->radius : 1e-2;
+      double dx = G->extents[0] * 0.5 - cr, dy = G->extents[1] * 0.5 - cr, dz = G->extents[2] * 0.5 - cr;
+      for (int c = 0; c < 8; ++c) {
+        double off[3] = {(c & 4) ? -dx : dx, (c & 2) ? -dy : dy, (c & 1) ? -dz : dz}, ro[3], p[3];
+        quat_rotate(orn, off, ro);
+        for (int k = 0; k < 3; ++k) p[k] = tr.t[k] + ro[k];
+        contact_plane_sphere(m, p, cr, G->link, s);
+      }
+    }
+  }
+}
+
+/* ref: src/mb_constraint_solver.hpp:506-520 (branch-free form incl. its quirks) */
+static void plane_space(const double *n, double *p, double *q) {
+  double n_sqr = n[2] * n[2];
+  int gt = n_sqr > 0.5;
+  double a = n[1] * n[1] + (gt ? n_sqr : n[0] * n[0]);
+  double k = sqrt(a);
+  p[0] = gt ? 0.0 : -n[1] * k;
+  p[1] = gt ? -n[2] * k : n[0] * k;
+  p[2] = n[1] * k;
+  q[0] = gt ? a * k : -n[2] * p[1];
+  q[1] = gt ? -n[0] * p[2] : n[2] * p[0];
+  q[2] = gt ? n[0] * p[1] : a * k;
+}
+
+/* ref: src/mb_constraint_solver.hpp:101-142 */
+static void solve_pgs(const double *A, const double *b, double *x, int n, int iters, const double *lo,
+                      const double *hi, const int *dep) {
+  for (int k = 0; k < iters; ++k) {
+    for (int i = 0; i < n; ++i) {
+      double delta = 0.0;
+      for (int j = 0; j < i; j++) delta += A[i * n + j] * x[j];
+      for (int j = i + 1; j < n; j++) delta += A[i * n + j] * x[j];
+      x[i] = (b[i] - delta) / A[i * n + i];
+      double sc = 1.0;
+      if (dep[i] >= 0) {
+        sc = x[dep[i]];
+        if (sc < 0.0) sc = 0.0;
+      }
+      if (x[i] < lo[i] * sc) x[i] = lo[i] * sc; /* Algebra::max */
+      if (x[i] > hi[i] * sc) x[i] = hi[i] * sc; /* Algebra::min */
+    }
+  }
+}
+
+/* ref: src/mb_constraint_solver.hpp:191-498 with mb_a = plane (n_a = 0), mb_b = robot,
+   keep_all_points_ = true (locomotion_contact_simulation.h:135) */
+static int resolve_collision(const tds_model_t *m, scratch_t *s, tds_oracle_debug_t *dbg) {
+  const int n_c = s->n_c, nd = m->dof_qd, nr = 3 * n_c;
+  if (n_c == 0 || nd == 0) return 0;
+  mass_matrix(m, s);                                   /* :232-233 */
+  if (!symmetric_inverse(s->M, s->Minv, nd)) return -1; /* :245-246 */
+  memset(s->J, 0, sizeof(double) * nr * nd);
+  memset(s->b, 0, sizeof(double) * nr);
+  for (int i = 0; i < n_c; ++i) {
+    const contact_t *cp = &s->cps[i];
+    double collision = cp->distance < 0.0 ? 1.0 : 0.0; /* :285 */
+    point_jacobian(m, s, cp->link_b, cp->point_b, s->jac); /* :295 */
+    if (dbg && dbg->jac) memcpy(dbg->jac + (size_t)i * 3 * nd, s->jac, sizeof(double) * 3 * nd);
+    double nrm[3] = {cp->normal[0] * collision, cp->normal[1] * collision, cp->normal[2] * collision};
+    for (int d = 0; d < nd; ++d) /* :300-307  jac_b^T (n*collision) */
+      s->J[i * nd + d] = s->jac[d] * nrm[0] + s->jac[nd + d] * nrm[1] + s->jac[2 * nd + d] * nrm[2];
+    double vel_b[3] = {0, 0, 0};                       /* :314 */
+    for (int r = 0; r < 3; ++r)
+      for (int d = 0; d < nd; ++d) vel_b[r] += s->jac[r * nd + d] * s->qd[d];
+    double rel_vel[3] = {-vel_b[0], -vel_b[1], -vel_b[2]}; /* :315 (vel_a = 0) */
+    double normal_rel_vel = v3_dot(cp->normal, rel_vel);
+    double baumgarte = m->erp * cp->distance / m->dt;  /* :321 */
+    s->b[i] = (-(1.0 + m->restitution) * normal_rel_vel - baumgarte) * collision; /* :323-325 */
+    double f1[3], f2[3];
+    plane_space(cp->normal, f1, f2);                   /* :361 */
+    for (int k = 0; k < 3; ++k) { f1[k] *= collision; f2[k] *= collision; }
+    s->b[n_c + i] = -v3_dot(f1, rel_vel);              /* :365-366 */
+    s->b[2 * n_c + i] = -v3_dot(f2, rel_vel);          /* :369-370 */
+    for (int d = 0; d < nd; ++d) {                     /* :378-384 */
+      s->J[(n_c + i) * nd + d] = s->jac[d] * f1[0] + s->jac[nd + d] * f1[1] + s->jac[2 * nd + d] * f1[2];
+      s->J[(2 * n_c + i) * nd + d] = s->jac[d] * f2[0] + s->jac[nd + d] * f2[1] + s->jac[2 * nd + d] * f2[2];
+    }
+  }
+  /* :397  lcp_A = jac_con * mass_matrix_inv * jac_con_t  (tiny_matrix_x.h:127-141 i-j-k) */
+  for (int i = 0; i < nr; ++i)
+    for (int j = 0; j < nd; ++j) {
+      double sum = 0.0;
+      for (int k = 0; k < nd; ++k) sum += s->J[i * nd + k] * s->Minv[k * nd + j];
+      s->JM[i * nd + j] = sum;
+    }
+  for (int i = 0; i < nr; ++i)
+    for (int j = 0; j < nr; ++j) {
+      double sum = 0.0;
+      for (int k = 0; k < nd; ++k) sum += s->JM[i * nd + k] * s->J[j * nd + k];
+      s->A[i * nr + j] = sum;
+    }
+  for (int i = 0; i < nr; ++i) s->A[i * nr + i] += m->cfm; /* :408-410 */
+  for (int i = 0; i < n_c; ++i) {                          /* :424-436 */
+    s->dep[i] = -1; s->lo[i] = 0.0; s->hi[i] = 100000.0;
+    s->lo[n_c + i] = -m->friction; s->hi[n_c + i] = m->friction; s->dep[n_c + i] = i;
+    s->lo[2 * n_c + i] = -m->friction; s->hi[2 * n_c + i] = m->friction; s->dep[2 * n_c + i] = i;
+  }
+  memset(s->p, 0, sizeof(double) * nr);
+  solve_pgs(s->A, s->b, s->p, nr, m->pgs_iterations, s->lo, s->hi, s->dep); /* :440 */
+  /* :476-496  qd_b -= M_b^-1 J^T p  (the three blocks summed) */
+  double JtP[ND];
+  for (int d = 0; d < nd; ++d) {
+    double sum = 0.0;
+    for (int i = 0; i < nr; ++i) sum += s->J[i * nd + d] * s->p[i];
+    JtP[d] = sum;
+  }
+  for (int d = 0; d < nd; ++d) {
+    double sum = 0.0;
+    for (int k = 0; k < nd; ++k) sum += s->Minv[d * nd + k] * JtP[k];
+    s->qd[d] -= sum;
+  }
+  if (dbg) {
+    if (dbg->M) memcpy(dbg->M, s->M, sizeof(double) * nd * nd);
+    if (dbg->Minv) memcpy(dbg->Minv, s->Minv, sizeof(double) * nd * nd);
+    if (dbg->lcp_A) memcpy(dbg->lcp_A, s->A, sizeof(double) * nr * nr);
+    if (dbg->lcp_b) memcpy(dbg->lcp_b, s->b, sizeof(double) * nr);
+    if (dbg->lcp_p) memcpy(dbg->lcp_p, s->p, sizeof(double) * nr);
+  }
+  return 0;
+}
+
+/* ref: examples/environments/locomotion_contact_simulation.h:151-304 (LOCOMOTION) and
+   examples/environments/cartpole_environment.h:71-117 (TAU) */
+static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t *s,
+                    tds_oracle_debug_t *dbg) {
+  const int nq = m->dof_q, nd = m->dof_qd;
+  if (m->is_floating || m->num_links > NL || nd > ND) return -2;
+  if (m->has_plane) {
+    int nc = 0;
+    for (int g = 0; g < m->num_geoms; ++g)
+      nc += m->geoms[g].type == TDS_GEOM_SPHERE ? 1 : m->geoms[g].type == TDS_GEOM_CAPSULE ? 2
+            : m->geoms[g].type == TDS_GEOM_BOX ? 8 : 0;
+    if (nc > NCMAX) return -3;
+  }
+  /* mb_->initialize(): zero state (multi_body.hpp:324-378) */
+  memset(s->q, 0, sizeof(s->q)); memset(s->qd, 0, sizeof(s->qd));
+  memset(s->qdd, 0, sizeof(s->qdd)); memset(s->tau, 0, sizeof(s->tau));
+  memcpy(s->base_X_world.r, m->base_X_world_rot, sizeof(s->base_X_world.r));
+  memcpy(s->base_X_world.t, m->base_X_world_trans, sizeof(s->base_X_world.t));
+  for (int i = 0; i < m->num_links; ++i)
+    for (int k = 0; k < 3; ++k) { s->L[i].S.a[k] = m->links[i].S[k]; s->L[i].S.l[k] = m->links[i].S[3 + k]; }
+  for (int i = 0; i < nq; ++i) s->q[i] = x[i];            /* :154-159 */
+  for (int i = 0; i < nd; ++i) s->qd[i] = x[nq + i];
+  if (m->step_mode == TDS_STEP_LOCOMOTION) {
+    const int action_offset = nq + nd, var = nq + nd + m->action_dim;
+    const double kp = x[var], kd = x[var + 1], max_force = x[var + 2]; /* :164-166 */
+    int pose_index = 0;
+    for (int i = m->pd_start_link; i < m->num_links; ++i) { /* :181-257 */
+      const tds_link_t *l = &m->links[i];
+      if (l->joint_type == TDS_JOINT_FIXED) continue;
+      double a = x[action_offset + pose_index];
+      if (a > m->action_limit) a = m->action_limit;        /* :235-236 */
+      if (a < -m->action_limit) a = -m->action_limit;
+      double q_des = m->initial_poses[pose_index++] + a;   /* :238 */
+      double f = kp * (q_des - s->q[l->q_index]) + kd * (0.0 - s->qd[l->qd_index]); /* :242-245 */
+      if (f < -max_force) f = -max_force;                  /* :247 */
+      if (f > max_force) f = max_force;
+      s->tau[l->qd_index] = f;
+    }
+  } else {
+    for (int i = 0; i < nd; ++i) s->tau[i] = x[nq + nd + i];
+  }
+  forward_dynamics(m, s);                                  /* :261 */
+  if (dbg && dbg->qdd) memcpy(dbg->qdd, s->qdd, sizeof(double) * nd);
+  if (dbg && dbg->X_world)
+    for (int i = 0; i < m->num_links; ++i) {
+      memcpy(dbg->X_world + 12 * i, s->L[i].X_world.r, 9 * sizeof(double));
+      memcpy(dbg->X_world + 12 * i + 9, s->L[i].X_world.t, 3 * sizeof(double));
+    }
+  /* integrate_euler_qdd: qd += qdd*dt (integrator.hpp:141-182); qdd = 0 (:194) */
+  for (int i = 0; i < m->num_links; ++i) {
+    const tds_link_t *l = &m->links[i];
+    if (l->joint_type != TDS_JOINT_FIXED) s->qd[l->qd_index] += s->qdd[l->qd_index] * m->dt;
+  }
+  if (m->has_plane) {                                      /* world.step (world.hpp:293-366) */
+    compute_contacts(m, s);
+    if (dbg) {
+      dbg->n_c = s->n_c;
+      if (dbg->contacts)
+        for (int i = 0; i < s->n_c; ++i) {
+          double *c = dbg->contacts + 10 * i;
+          memcpy(c, s->cps[i].normal, 24); memcpy(c + 3, s->cps[i].point_b, 24);
+          memcpy(c + 6, s->cps[i].point_a, 24); c[9] = s->cps[i].distance;
+        }
+    }
+    int rc = resolve_collision(m, s, dbg);
+    if (rc) return rc;
+  }
+  /* integrate_euler with qdd == 0: q += qd*dt (integrator.hpp:126-131) */
+  for (int i = 0; i < m->num_links; ++i) {
+    const tds_link_t *l = &m->links[i];
+    if (l->joint_type != TDS_JOINT_FIXED) s->q[l->q_index] += s->qd[l->qd_index] * m->dt;
+  }
+  /* pack (:273-303); the rest of y is zero (caller's vector is zero-initialised) */
+  int j = 0;
+  for (int i = 0; i < m->output_dim; ++i) y[i] = 0.0;
+  for (int i = 0; i < nq; ++i) y[j++] = s->q[i];
+  for (int i = 0; i < nd; ++i) y[j++] = s->qd[i];
+  if (m->pack_visuals) {
+    for (int v = 0; v < m->num_visuals; ++v) {
+      const tds_visual_t *V = &m->visuals[v];
+      xf_t lv, vx;
+      double orn[4];
+      memcpy(lv.r, V->X_rot, sizeof(lv.r)); memcpy(lv.t, V->X_trans, sizeof(lv.t));
+      xf_mul(&s->L[V->link].X_world, &lv, &vx);            /* :285 (X_world is pre-step) */
+      y[j++] = vx.t[0]; y[j++] = vx.t[1]; y[j++] = vx.t[2];
+      matrix_to_quat(vx.r, orn);                           /* :291 */
+      y[j++] = orn[0]; y[j++] = orn[1]; y[j++] = orn[2]; y[j++] = orn[3];
+    }
+    y[j++] = s->base_X_world.r[8];                         /* :301-303 */
+  }
+  return 0;
+}
+
+int tds_oracle_step_debug(const tds_model_t *model, const double *x, double *y,
+                          tds_oracle_debug_t *dbg) {
+  scratch_t *s = (scratch_t *)calloc(1, sizeof(scratch_t));
+  if (!s) return -10;
+  int rc = step_one(model, x, y, s, dbg);
+  free(s);
+  return rc;
+}
+
+int tds_oracle_step(const tds_model_t *model, int n, const double *x, double *y) {
+  scratch_t *s = (scratch_t *)calloc(1, sizeof(scratch_t));
+  if (!s) return -10;
+  int rc = 0;
+  for (int e = 0; e < n && !rc; ++e)
+    rc = step_one(model, x + (size_t)e * model->input_dim, y + (size_t)e * model->output_dim, s, NULL);
+  free(s);
+  return rc;
+}
+
+int tds_oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+int tds_oracle_step_omp(const tds_model_t *model, int n, const double *x, double *y, int num_threads) {
+  int rc_all = 0;
+#ifdef _OPENMP
+  if (num_threads <= 0) num_threads = omp_get_max_threads();
+#pragma omp parallel num_threads(num_threads)
+  {
+    scratch_t *s = (scratch_t *)calloc(1, sizeof(scratch_t));
+#pragma omp for schedule(static)
+    for (int e = 0; e < n; ++e) {
+      int rc = step_one(model, x + (size_t)e * model->input_dim, y + (size_t)e * model->output_dim, s, NULL);
+      if (rc) {
+#pragma omp atomic write
+        rc_all = rc;
+      }
+    }
+    free(s);
+  }
+#else
+  (void)num_threads;
+  rc_all = tds_oracle_step(model, n, x, y);
+#endif
+  return rc_all;
+}

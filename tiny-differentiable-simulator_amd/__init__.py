@@ -1,0 +1,5 @@
+"""tiny-differentiable-simulator_amd — MI355X-native many-instance replay of the TDS
+per-environment step.  Import through the repo-root alias ``tds_amd`` (the directory name
+is not a valid Python identifier)."""
+from .model import *  # noqa: F401,F403
+from . import model  # noqa: F401

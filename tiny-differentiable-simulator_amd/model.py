@@ -1,0 +1,222 @@
+"""ctypes mirror of ``tds_model_t`` (include/tds_hip.h) and JSON (de)serialisation.
+
+The blob is the flattened output of TDS's own URDF loader + World set-up
+(reference: src/urdf/urdf_to_multi_body.hpp:41-220, examples/environments/
+locomotion_contact_simulation.h:88-136).  On a machine where the reference is present it is
+produced by ``include/tds_hip_stepper.hpp::flatten_model`` (C++) or ``oracle/gen_golden.py``;
+the four models of BASELINE.json's configs are committed under ``models/*.json`` so that the
+GPU box (which has no /root/reference) can run them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+TDS_HIP_ABI_VERSION = 1
+TDS_MAX_LINKS = 32
+TDS_MAX_GEOMS = 32
+TDS_MAX_VISUALS = 32
+TDS_MAX_ACTIONS = 32
+TDS_MAX_CONTACTS = 32
+
+TDS_STEP_LOCOMOTION = 0
+TDS_STEP_TAU = 1
+TDS_DTYPE_F64 = 0
+TDS_DTYPE_F32 = 1
+
+JOINT_FIXED = -1
+JOINT_PRISMATIC_X, JOINT_PRISMATIC_Y, JOINT_PRISMATIC_Z, JOINT_PRISMATIC_AXIS = 0, 1, 2, 3
+JOINT_REVOLUTE_X, JOINT_REVOLUTE_Y, JOINT_REVOLUTE_Z, JOINT_REVOLUTE_AXIS = 4, 5, 6, 7
+JOINT_SPHERICAL = 8
+GEOM_SPHERE, GEOM_PLANE, GEOM_CAPSULE, GEOM_MESH, GEOM_BOX = 0, 1, 2, 3, 4
+
+
+class Link(C.Structure):
+    _fields_ = [
+        ("joint_type", C.c_int32),
+        ("parent", C.c_int32),
+        ("q_index", C.c_int32),
+        ("qd_index", C.c_int32),
+        ("X_T_rot", C.c_double * 9),
+        ("X_T_trans", C.c_double * 3),
+        ("S", C.c_double * 6),
+        ("mass", C.c_double),
+        ("com", C.c_double * 3),
+        ("inertia", C.c_double * 9),
+        ("stiffness", C.c_double),
+        ("damping", C.c_double),
+    ]
+
+
+class Geom(C.Structure):
+    _fields_ = [
+        ("link", C.c_int32),
+        ("type", C.c_int32),
+        ("radius", C.c_double),
+        ("length", C.c_double),
+        ("extents", C.c_double * 3),
+        ("X_rot", C.c_double * 9),
+        ("X_trans", C.c_double * 3),
+    ]
+
+
+class Visual(C.Structure):
+    _fields_ = [
+        ("link", C.c_int32),
+        ("pad_", C.c_int32),
+        ("X_rot", C.c_double * 9),
+        ("X_trans", C.c_double * 3),
+    ]
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("step_mode", C.c_int32),
+        ("num_links", C.c_int32),
+        ("dof_q", C.c_int32),
+        ("dof_qd", C.c_int32),
+        ("is_floating", C.c_int32),
+        ("num_geoms", C.c_int32),
+        ("num_visuals", C.c_int32),
+        ("action_dim", C.c_int32),
+        ("pd_start_link", C.c_int32),
+        ("has_plane", C.c_int32),
+        ("pgs_iterations", C.c_int32),
+        ("input_dim", C.c_int32),
+        ("output_dim", C.c_int32),
+        ("pack_visuals", C.c_int32),
+        ("pad_", C.c_int32),
+        ("dt", C.c_double),
+        ("gravity", C.c_double * 3),
+        ("base_X_world_rot", C.c_double * 9),
+        ("base_X_world_trans", C.c_double * 3),
+        ("plane_normal", C.c_double * 3),
+        ("plane_constant", C.c_double),
+        ("cfm", C.c_double),
+        ("erp", C.c_double),
+        ("friction", C.c_double),
+        ("restitution", C.c_double),
+        ("action_limit", C.c_double),
+        ("initial_poses", C.c_double * TDS_MAX_ACTIONS),
+        ("links", Link * TDS_MAX_LINKS),
+        ("geoms", Geom * TDS_MAX_GEOMS),
+        ("visuals", Visual * TDS_MAX_VISUALS),
+        ("name", C.c_char * 32),
+    ]
+
+    # ---- helpers ---------------------------------------------------------------------
+    def copy(self) -> "Model":
+        m = Model()
+        C.memmove(C.byref(m), C.byref(self), C.sizeof(Model))
+        return m
+
+    @property
+    def num_contacts(self) -> int:
+        """Contact points vs. the plane: sphere 1, capsule 2, box 8
+        (reference: src/contact_point.hpp:96-198)."""
+        n = 0
+        for g in range(self.num_geoms):
+            t = self.geoms[g].type
+            n += {GEOM_SPHERE: 1, GEOM_CAPSULE: 2, GEOM_BOX: 8}.get(t, 0)
+        return n if self.has_plane else 0
+
+    def set_soft_contact(self, stiffness: float, damping: float) -> None:
+        """cfm/erp from a contact stiffness/damping pair — the only "spring-damper" contact
+        the reference has (reference: examples/environments/ant_environment.h:79-92)."""
+        dt = self.dt
+        self.cfm = 1.0 / (dt * stiffness + damping)
+        self.erp = dt * stiffness / (dt * stiffness + damping)
+
+
+_SCALARS = [
+    "abi_version", "step_mode", "num_links", "dof_q", "dof_qd", "is_floating", "num_geoms",
+    "num_visuals", "action_dim", "pd_start_link", "has_plane", "pgs_iterations", "input_dim",
+    "output_dim", "pack_visuals", "dt", "plane_constant", "cfm", "erp", "friction",
+    "restitution", "action_limit",
+]
+_VECTORS = ["gravity", "base_X_world_rot", "base_X_world_trans", "plane_normal"]
+
+
+def _struct_to_dict(s, skip=()):
+    d = {}
+    for name, typ in s._fields_:
+        if name in skip or name == "pad_":
+            continue
+        v = getattr(s, name)
+        if hasattr(v, "__len__") and not isinstance(v, (bytes, str)):
+            d[name] = [float(x) for x in v]
+        else:
+            d[name] = v
+    return d
+
+
+def _dict_to_struct(d, s):
+    for name, typ in s._fields_:
+        if name == "pad_" or name not in d:
+            continue
+        v = d[name]
+        if isinstance(v, list):
+            arr = getattr(s, name)
+            for i, x in enumerate(v):
+                arr[i] = x
+        else:
+            setattr(s, name, v)
+
+
+def model_to_dict(m: Model) -> dict:
+    d = {k: getattr(m, k) for k in _SCALARS}
+    for k in _VECTORS:
+        d[k] = [float(x) for x in getattr(m, k)]
+    d["name"] = m.name.decode()
+    d["initial_poses"] = [float(m.initial_poses[i]) for i in range(m.action_dim)] \
+        if m.step_mode == TDS_STEP_LOCOMOTION else []
+    d["links"] = [_struct_to_dict(m.links[i]) for i in range(m.num_links)]
+    d["geoms"] = [_struct_to_dict(m.geoms[i]) for i in range(m.num_geoms)]
+    d["visuals"] = [_struct_to_dict(m.visuals[i]) for i in range(m.num_visuals)]
+    return d
+
+
+def model_from_dict(d: dict) -> Model:
+    m = Model()
+    for k in _SCALARS:
+        setattr(m, k, d[k])
+    for k in _VECTORS:
+        arr = getattr(m, k)
+        for i, x in enumerate(d[k]):
+            arr[i] = x
+    m.name = d["name"].encode()
+    for i, x in enumerate(d["initial_poses"]):
+        m.initial_poses[i] = x
+    for i, l in enumerate(d["links"]):
+        _dict_to_struct(l, m.links[i])
+    for i, g in enumerate(d["geoms"]):
+        _dict_to_struct(g, m.geoms[i])
+    for i, v in enumerate(d["visuals"]):
+        _dict_to_struct(v, m.visuals[i])
+    if m.abi_version != TDS_HIP_ABI_VERSION:
+        raise ValueError(f"model blob ABI {m.abi_version} != {TDS_HIP_ABI_VERSION}")
+    return m
+
+
+def save_model(m: Model, path: str) -> None:
+    with open(path, "w") as f:
+        json.dump(model_to_dict(m), f, indent=1)
+        f.write("\n")
+
+
+def load_model(name_or_path: str) -> Model:
+    """Load a committed model by name ("ant", "laikago", "cartpole", "pendulum5", ...) or
+    from an explicit JSON path."""
+    path = name_or_path
+    if not os.path.exists(path):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models",
+                            name_or_path + ".json")
+    with open(path) as f:
+        return model_from_dict(json.load(f))
+
+
+def available_models():
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+    return sorted(p[:-5] for p in os.listdir(d) if p.endswith(".json"))
