@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MODELS = ["cartpole", "pendulum5", "ant", "laikago", "laikago_soft", "pendulum5_plane", "cartpole_plane"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build the product library and the C oracle once per session (no GPU needed)."""
+    import __graft_entry__ as g
+
+    g.build()
+    return True
+
+
+def rel_err(a, b, floor=1e-3):
+    """max |a-b| / max(|b|, floor) — the 'relative per-step' metric of BASELINE.json with an
+    absolute floor so that exact zeros do not blow up."""
+    import numpy as np
+
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))

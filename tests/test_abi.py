@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tds_hip.h declares; host-side
+model handling; loud failure without a GPU (no CPU fallback in the product path)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import MODELS, ROOT
+
+import tds_amd
+from tds_amd import hip_backend
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "tds_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(tds_hip_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    L = hip_backend.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(hip_backend.EXPORTED_SYMBOLS) == syms
+    assert L.tds_hip_abi_version() == tds_amd.TDS_HIP_ABI_VERSION
+
+
+def test_struct_layout_matches_c(built):
+    """sizeof(tds_model_t) as seen by C must equal the ctypes mirror."""
+    import subprocess
+    import tempfile
+    src = '#include <stdio.h>\n#include "tds_hip.h"\nint main(){printf("%zu %zu %zu %zu",sizeof(tds_model_t),sizeof(tds_link_t),sizeof(tds_geom_t),sizeof(tds_visual_t));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
+    assert [int(v) for v in out] == [C.sizeof(tds_amd.Model), C.sizeof(tds_amd.model.Link),
+                                     C.sizeof(tds_amd.model.Geom), C.sizeof(tds_amd.model.Visual)]
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_models_pass_model_check(name, built):
+    m = tds_amd.load_model(name)
+    hip_backend.model_check(m)
+    assert m.input_dim > 0 and m.output_dim > 0
+    # JSON round trip
+    assert tds_amd.model_to_dict(tds_amd.model_from_dict(tds_amd.model_to_dict(m))) == tds_amd.model_to_dict(m)
+
+
+def test_model_check_rejects_unsupported(built):
+    m = tds_amd.load_model("ant")
+    m.is_floating = 1
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.model_check(m)
+    m = tds_amd.load_model("ant")
+    m.links[7].joint_type = tds_amd.model.JOINT_SPHERICAL
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.model_check(m)
+    m = tds_amd.load_model("ant")
+    m.abi_version = 99
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.model_check(m)
+
+
+def test_no_gpu_fails_loudly(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = tds_amd.load_model("ant")
+    h = C.c_void_p()
+    rc = hip_backend.lib().tds_hip_create(C.byref(m), 8, 0, 0, C.byref(h))
+    assert rc in (3, 4) and not h.value  # TDS_ERR_HIP / TDS_ERR_NO_DEVICE, never a silent CPU path
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.HipSim(m, 8)

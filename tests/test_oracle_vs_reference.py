@@ -1,0 +1,55 @@
+"""CPU, only where /root/reference exists: the plain-C oracle and the committed model blobs
+against the REAL reference compiled by oracle/Makefile (oracle/_ref/libtds_ref.so)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, rel_err
+
+import tds_amd
+import oraclelib
+import reflib
+
+pytestmark = pytest.mark.skipif(not (os.path.isdir(reflib.REF_ROOT + "/src")),
+                                reason="reference tree not present on this machine")
+
+
+@pytest.fixture(scope="module")
+def gen():
+    import gen_golden
+    return gen_golden
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_blob_matches_reference_flatten(name, built, gen):
+    r, m_ref = gen.make_ref(name)
+    m = tds_amd.load_model(name)
+    assert tds_amd.model_to_dict(m) == tds_amd.model_to_dict(m_ref)
+    r.close()
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_oracle_matches_reference_on_fresh_states(name, built, gen):
+    r, m = gen.make_ref(name)
+    rng = np.random.default_rng(4242)
+    x = gen.random_inputs(name, m, 64, rng)
+    y_ref = r.step(x)
+    y = oraclelib.step(m, x)
+    assert rel_err(y, y_ref) < 1e-9
+    r.close()
+
+
+def test_reference_intermediates(built, gen):
+    r, m = gen.make_ref("ant")
+    rng = np.random.default_rng(7)
+    x = gen.random_inputs("ant", m, 8, rng)
+    for i in range(8):
+        x[i, -3:] = 0.0  # tau = 0 on both sides (reference debug path has no PD)
+        dr = r.debug(x[i], m)
+        do = oraclelib.step_debug(m, x[i])
+        assert rel_err(do["qdd"], dr["qdd"], 1e-6) < 1e-9
+        assert rel_err(do["M"], dr["M"], 1e-9) < 1e-9
+        assert rel_err(do["contacts"], dr["contacts"], 1e-9) < 1e-10
+        assert rel_err(do["jac"], dr["jac"], 1e-9) < 1e-10
+    r.close()

@@ -3,3 +3,5 @@ per-environment step.  Import through the repo-root alias ``tds_amd`` (the direc
 is not a valid Python identifier)."""
 from .model import *  # noqa: F401,F403
 from . import model  # noqa: F401
+
+from . import hip_backend  # noqa: F401,E402

@@ -1,0 +1,300 @@
+// tds_api.hip — implementation of the C ABI declared in include/tds_hip.h.
+//
+// Replaces, on the reference side:
+//   * VectorizedEnvironment::CustomForwardDynamicsStepper::step
+//       (examples/ars/ars_vectorized_environment.h:75-85)
+//   * the generated <model>_forward_zero{,_meta,_allocate,_deallocate} library
+//       (examples/ars/ars_train_policy_cuda.cpp:220-308; src/utils/cuda_codegen.hpp:146-262)
+// There is NO CPU fallback in this library: without a HIP device every entry point that needs
+// one returns TDS_ERR_NO_DEVICE / TDS_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "tds_device_model.h"
+#include "tds_hip.h"
+#include "tds_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "") {
+  snprintf(g_err, sizeof(g_err), fmt, detail);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      snprintf(g_err, sizeof(g_err), "%s failed: %s", #expr, hipGetErrorString(e_));       \
+      return TDS_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+int default_lanes_per_env(int num_links) {
+  const char *env = getenv("TDS_HIP_LANES_PER_ENV");
+  int g = env ? atoi(env) : 0;
+  if (g == 16 || g == 32 || g == 64) {
+    if (g >= num_links) return g;
+  }
+  return num_links <= 16 ? 16 : (num_links <= 32 ? 32 : 64);
+}
+
+}  // namespace
+
+struct tds_hip_sim {
+  tds_model_t model;
+  int num_envs = 0, device = 0, dtype = TDS_DTYPE_F64, lanes = 64;
+  size_t elem = 8;
+  hipStream_t stream = nullptr;
+  void *d_model = nullptr;  // DevModel<T>
+  DevModel<double> h64;
+  DevModel<float> h32;
+  TdsLds lds;
+  void *d_x = nullptr, *d_y = nullptr;
+  std::vector<double> stage;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  bool have_ms = false;
+
+  int input_dim() const { return model.input_dim; }
+  int output_dim() const { return model.output_dim; }
+};
+
+namespace {
+
+int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, int n) {
+  if (s->timing) hipEventRecord(s->ev0, s->stream);
+  int rc;
+  if (s->dtype == TDS_DTYPE_F64)
+    rc = tds_launch_step<double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes, (const double *)x,
+                                 (double *)y, (const double *)actions, (double *)fb, n, s->stream);
+  else
+    rc = tds_launch_step<float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)x,
+                                (float *)y, (const float *)actions, (float *)fb, n, s->stream);
+  if (rc != 0) {
+    snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad lanes_per_env");
+    return TDS_ERR_HIP;
+  }
+  if (s->timing) {
+    hipEventRecord(s->ev1, s->stream);
+    s->have_ms = true;
+  }
+  return TDS_OK;
+}
+
+// host double <-> device compute dtype
+int upload(tds_hip_sim *s, void *dst, const double *src, size_t count) {
+  if (s->dtype == TDS_DTYPE_F64) {
+    HIP_TRY(hipMemcpyAsync(dst, src, count * 8, hipMemcpyHostToDevice, s->stream));
+  } else {
+    std::vector<float> tmp(count);
+    for (size_t i = 0; i < count; ++i) tmp[i] = (float)src[i];
+    HIP_TRY(hipMemcpyAsync(dst, tmp.data(), count * 4, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  return TDS_OK;
+}
+int download(tds_hip_sim *s, double *dst, const void *src, size_t count) {
+  if (s->dtype == TDS_DTYPE_F64) {
+    HIP_TRY(hipMemcpyAsync(dst, src, count * 8, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  } else {
+    std::vector<float> tmp(count);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), src, count * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (size_t i = 0; i < count; ++i) dst[i] = (double)tmp[i];
+  }
+  return TDS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tds_hip_last_error(void) { return g_err; }
+int tds_hip_abi_version(void) { return TDS_HIP_ABI_VERSION; }
+
+int tds_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int tds_hip_model_check(const tds_model_t *model) {
+  if (!model) return fail(TDS_ERR_INVALID_ARG, "model is NULL");
+  DevModel<double> *d = new (std::nothrow) DevModel<double>;
+  if (!d) return fail(TDS_ERR_INVALID_ARG, "out of host memory");
+  char why[128];
+  int rc = tds_build_dev_model<double>(model, d, why);
+  delete d;
+  if (rc != TDS_OK) return fail(rc, "%s", why);
+  if (model->num_links > 64) return fail(TDS_ERR_UNSUPPORTED, "more than 64 links");
+  return TDS_OK;
+}
+
+int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype, tds_hip_sim_t **out) {
+  if (!out) return fail(TDS_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (num_envs <= 0) return fail(TDS_ERR_INVALID_ARG, "num_envs must be positive");
+  if (dtype != TDS_DTYPE_F64 && dtype != TDS_DTYPE_F32) return fail(TDS_ERR_INVALID_ARG, "unknown dtype");
+  int rc = tds_hip_model_check(model);
+  if (rc != TDS_OK) return rc;
+  int ndev = tds_hip_device_count();
+  if (ndev <= 0) return fail(TDS_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(TDS_ERR_INVALID_ARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  tds_hip_sim *s = new (std::nothrow) tds_hip_sim;
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "out of host memory");
+  s->model = *model;
+  s->num_envs = num_envs;
+  s->device = device;
+  s->dtype = dtype;
+  s->elem = dtype == TDS_DTYPE_F64 ? 8 : 4;
+  s->lanes = default_lanes_per_env(model->num_links);
+  char why[128];
+  size_t msize;
+  const void *hsrc;
+  if (dtype == TDS_DTYPE_F64) {
+    tds_build_dev_model<double>(model, &s->h64, why);
+    s->lds = tds_make_lds_layout<double>(s->h64);
+    msize = sizeof(DevModel<double>);
+    hsrc = &s->h64;
+  } else {
+    tds_build_dev_model<float>(model, &s->h32, why);
+    s->lds = tds_make_lds_layout<float>(s->h32);
+    msize = sizeof(DevModel<float>);
+    hsrc = &s->h32;
+  }
+  const int epw = 64 / s->lanes;
+  const int lds_bytes = (int)((size_t)s->lds.stride * epw * s->elem);
+  if (lds_bytes > 160 * 1024) {
+    delete s;
+    return fail(TDS_ERR_UNSUPPORTED, "model needs more than 160 KiB of LDS per workgroup");
+  }
+  if (lds_bytes > 64 * 1024) {
+    int e = dtype == TDS_DTYPE_F64 ? tds_kernel_max_dynamic_lds<double>(s->lanes, lds_bytes)
+                                   : tds_kernel_max_dynamic_lds<float>(s->lanes, lds_bytes);
+    if (e != 0) {
+      delete s;
+      return fail(TDS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    }
+  }
+#define CREATE_TRY(expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      snprintf(g_err, sizeof(g_err), "%s failed: %s", #expr, hipGetErrorString(e_));       \
+      tds_hip_destroy(s);                                                                  \
+      return TDS_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+  CREATE_TRY(hipMalloc(&s->d_model, msize));
+  CREATE_TRY(hipMemcpy(s->d_model, hsrc, msize, hipMemcpyHostToDevice));
+  CREATE_TRY(hipMalloc(&s->d_x, (size_t)num_envs * model->input_dim * s->elem));
+  CREATE_TRY(hipMalloc(&s->d_y, (size_t)num_envs * model->output_dim * s->elem));
+  CREATE_TRY(hipMemset(s->d_x, 0, (size_t)num_envs * model->input_dim * s->elem));
+  CREATE_TRY(hipMemset(s->d_y, 0, (size_t)num_envs * model->output_dim * s->elem));
+  CREATE_TRY(hipEventCreate(&s->ev0));
+  CREATE_TRY(hipEventCreate(&s->ev1));
+#undef CREATE_TRY
+  *out = s;
+  return TDS_OK;
+}
+
+int tds_hip_destroy(tds_hip_sim_t *s) {
+  if (!s) return TDS_OK;
+  if (s->d_model) hipFree(s->d_model);
+  if (s->d_x) hipFree(s->d_x);
+  if (s->d_y) hipFree(s->d_y);
+  if (s->ev0) hipEventDestroy(s->ev0);
+  if (s->ev1) hipEventDestroy(s->ev1);
+  delete s;
+  return TDS_OK;
+}
+
+int tds_hip_set_stream(tds_hip_sim_t *s, void *hip_stream) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  s->stream = (hipStream_t)hip_stream;
+  return TDS_OK;
+}
+
+int tds_hip_num_envs(const tds_hip_sim_t *s) { return s ? s->num_envs : 0; }
+int tds_hip_input_dim(const tds_hip_sim_t *s) { return s ? s->model.input_dim : 0; }
+int tds_hip_output_dim(const tds_hip_sim_t *s) { return s ? s->model.output_dim : 0; }
+int tds_hip_dtype(const tds_hip_sim_t *s) { return s ? s->dtype : -1; }
+void *tds_hip_x_device(tds_hip_sim_t *s) { return s ? s->d_x : nullptr; }
+void *tds_hip_y_device(tds_hip_sim_t *s) { return s ? s->d_y : nullptr; }
+
+int tds_hip_set_inputs(tds_hip_sim_t *s, const double *x_host) {
+  if (!s || !x_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  int rc = upload(s, s->d_x, x_host, (size_t)s->num_envs * s->model.input_dim);
+  if (rc != TDS_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TDS_OK;
+}
+int tds_hip_get_inputs(tds_hip_sim_t *s, double *x_host) {
+  if (!s || !x_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  return download(s, x_host, s->d_x, (size_t)s->num_envs * s->model.input_dim);
+}
+int tds_hip_get_outputs(tds_hip_sim_t *s, double *y_host) {
+  if (!s || !y_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  return download(s, y_host, s->d_y, (size_t)s->num_envs * s->model.output_dim);
+}
+
+int tds_hip_forward_zero_device(tds_hip_sim_t *s, const void *x_dev, void *y_dev) {
+  if (!s || !x_dev || !y_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  return launch(s, x_dev, y_dev, nullptr, nullptr, s->num_envs);
+}
+
+int tds_hip_step(tds_hip_sim_t *s, const void *actions_dev, int substeps) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  if (substeps < 1) return fail(TDS_ERR_INVALID_ARG, "substeps must be >= 1");
+  for (int k = 0; k < substeps; ++k) {
+    // the first substep installs the action into the resident record; feedback writes q, qd
+    int rc = launch(s, s->d_x, s->d_y, actions_dev, s->d_x, s->num_envs);
+    if (rc != TDS_OK) return rc;
+  }
+  return TDS_OK;
+}
+
+int tds_hip_forward_zero_host(tds_hip_sim_t *s, int n, const double *x_host, double *y_host) {
+  if (!s || !x_host || !y_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (n < 1 || n > s->num_envs) return fail(TDS_ERR_INVALID_ARG, "n out of range");
+  int rc = upload(s, s->d_x, x_host, (size_t)n * s->model.input_dim);
+  if (rc != TDS_OK) return rc;
+  rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, n);
+  if (rc != TDS_OK) return rc;
+  return download(s, y_host, s->d_y, (size_t)n * s->model.output_dim);
+}
+
+int tds_hip_set_timing(tds_hip_sim_t *s, int enable) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  s->timing = enable != 0;
+  s->have_ms = false;
+  return TDS_OK;
+}
+int tds_hip_last_kernel_ms(tds_hip_sim_t *s, float *ms) {
+  if (!s || !ms) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (!s->have_ms) return fail(TDS_ERR_INVALID_ARG, "no timed launch recorded");
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return TDS_OK;
+}
+
+int tds_hip_kernel_info(const tds_hip_sim_t *s, int *lds_bytes_per_env, int *threads_per_env, int *envs_per_block) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  if (lds_bytes_per_env) *lds_bytes_per_env = (int)(s->lds.stride * s->elem);
+  if (threads_per_env) *threads_per_env = s->lanes;
+  if (envs_per_block) *envs_per_block = 64 / s->lanes;
+  return TDS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+// tds_device_model.h — kernel-side constant model ("DevModel") and its host builder.
+//
+// The C-ABI blob tds_model_t (include/tds_hip.h) is the flattened tds::MultiBody + World.
+// The kernels want the same information re-organised for lane-indexed access:
+//   * per-link arrays stored component-major  a[c][link]  so that lane == link reads are coalesced,
+//   * tree schedule (level of each link, ancestor masks, (link, ancestor) pair list for CRBA),
+//   * contact POINTS (sphere centres in link coordinates) instead of geometries:
+//     sphere 1, capsule 2, box 8 points  (reference: src/contact_point.hpp:96-198),
+//   * the contact frame of the plane (normal_on_b, two tangents) evaluated once on the host
+//     with the reference's own plane_space() quirks (src/mb_constraint_solver.hpp:506-520).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "tds_hip.h"
+
+#define TDS_NL TDS_MAX_LINKS           // 32
+#define TDS_ND 32                      // max dof
+#define TDS_NCP TDS_MAX_CONTACTS       // 32 contact points
+#define TDS_NV TDS_MAX_VISUALS         // 32
+#define TDS_NPAIR (TDS_NL * 12)        // (link, strict ancestor) pairs
+
+template <typename T>
+struct DevModel {
+  int num_links, dof_q, dof_qd, num_levels;
+  int num_cp, num_visuals, action_dim, input_dim, output_dim;
+  int step_mode, has_plane, pgs_iterations, pack_visuals;
+  int num_pairs, pad0_, pad1_;
+  T dt, cfm, erp_over_dt, friction, restitution, action_limit;
+  T grav[3];       // base acceleration = -grav (forward_dynamics.hpp:242), world frame
+  T base_R[9], base_t[3];
+  T plane_n[3], plane_c;
+  T nb[3], t1[3], t2[3];  // world_normal_on_b = -n and plane_space(nb)
+  // per link ---------------------------------------------------------------------------
+  int parent[TDS_NL], level[TDS_NL], joint_type[TDS_NL], q_index[TDS_NL], qd_index[TDS_NL];
+  int act_index[TDS_NL];        // PD pose_index of this link or -1 (locomotion_contact_simulation.h:179-257)
+  uint32_t anc_dofs[TDS_NL];    // bit d set: dof d lies on the path base -> link (incl. own)
+  T X_T[12][TDS_NL];            // rot (row-major 9) | trans (3)
+  T S[6][TDS_NL];
+  T mass[TDS_NL], com[3][TDS_NL], inertia[9][TDS_NL];
+  T stiffness[TDS_NL], damping[TDS_NL], init_pose[TDS_NL];
+  // per dof ----------------------------------------------------------------------------
+  int dof_link[TDS_ND];
+  // contact points ---------------------------------------------------------------------
+  int cp_link[TDS_NCP];
+  T cp_local[3][TDS_NCP], cp_radius[TDS_NCP];
+  // visuals ----------------------------------------------------------------------------
+  int vis_link[TDS_NV];
+  T vis_X[12][TDS_NV];
+  // CRBA off-diagonal work list: M[qd(i)][qd(j)] for j a strict ancestor of i, both with a dof
+  int16_t pair_i[TDS_NPAIR], pair_j[TDS_NPAIR];
+};
+
+// reference: src/mb_constraint_solver.hpp:506-520 (incl. k = sqrt(a) and p[2] quirks)
+static inline void tds_plane_space(const double *n, double *p, double *q) {
+  double n_sqr = n[2] * n[2];
+  int gt = n_sqr > 0.5;
+  double a = n[1] * n[1] + (gt ? n_sqr : n[0] * n[0]);
+  double k = sqrt(a);
+  p[0] = gt ? 0.0 : -n[1] * k;
+  p[1] = gt ? -n[2] * k : n[0] * k;
+  p[2] = n[1] * k;
+  q[0] = gt ? a * k : -n[2] * p[1];
+  q[1] = gt ? -n[0] * p[2] : n[2] * p[0];
+  q[2] = gt ? n[0] * p[1] : a * k;
+}
+
+// Returns TDS_OK or an error code; `why` (>= 128 bytes) receives the reason.
+template <typename T>
+static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) {
+  memset(d, 0, sizeof(*d));
+  why[0] = 0;
+#define TDS_FAIL(code, msg)          \
+  do {                               \
+    strncpy(why, msg, 127);          \
+    why[127] = 0;                    \
+    return code;                     \
+  } while (0)
+  if (m->abi_version != TDS_HIP_ABI_VERSION) TDS_FAIL(TDS_ERR_INVALID_ARG, "model abi_version mismatch");
+  if (m->num_links < 1 || m->num_links > TDS_NL) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_links out of range");
+  if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd)
+    TDS_FAIL(TDS_ERR_UNSUPPORTED, "dof out of range or dof_q != dof_qd (spherical joints unsupported)");
+  if (m->is_floating) TDS_FAIL(TDS_ERR_UNSUPPORTED, "floating base is not implemented (SURVEY 8f N4)");
+  if (m->num_geoms < 0 || m->num_geoms > TDS_MAX_GEOMS) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_geoms out of range");
+  if (m->num_visuals < 0 || m->num_visuals > TDS_NV) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_visuals out of range");
+  if (m->step_mode != TDS_STEP_LOCOMOTION && m->step_mode != TDS_STEP_TAU)
+    TDS_FAIL(TDS_ERR_INVALID_ARG, "unknown step_mode");
+  if (m->pgs_iterations < 1) TDS_FAIL(TDS_ERR_INVALID_ARG, "pgs_iterations < 1");
+  d->num_links = m->num_links;
+  d->dof_q = m->dof_q;
+  d->dof_qd = m->dof_qd;
+  d->num_visuals = m->pack_visuals ? m->num_visuals : 0;
+  d->action_dim = m->action_dim;
+  d->input_dim = m->input_dim;
+  d->output_dim = m->output_dim;
+  d->step_mode = m->step_mode;
+  d->has_plane = m->has_plane;
+  d->pgs_iterations = m->pgs_iterations;
+  d->pack_visuals = m->pack_visuals;
+  const int nq = m->dof_q, nd = m->dof_qd;
+  const int need_in = nq + nd + m->action_dim + (m->step_mode == TDS_STEP_LOCOMOTION ? 3 : 0);
+  if (m->input_dim < need_in) TDS_FAIL(TDS_ERR_INVALID_ARG, "input_dim too small for [q|qd|action|vars]");
+  const int need_out = nq + nd + (m->pack_visuals ? 7 * m->num_visuals + 1 : 0);
+  if (m->output_dim < need_out) TDS_FAIL(TDS_ERR_INVALID_ARG, "output_dim too small for [q|qd|visuals|up]");
+  if (m->step_mode == TDS_STEP_TAU && m->action_dim != nd)
+    TDS_FAIL(TDS_ERR_INVALID_ARG, "TAU mode needs action_dim == dof_qd");
+  d->dt = (T)m->dt;
+  d->cfm = (T)m->cfm;
+  d->erp_over_dt = (T)(m->erp / m->dt);
+  d->friction = (T)m->friction;
+  d->restitution = (T)m->restitution;
+  d->action_limit = (T)m->action_limit;
+  // base acceleration is -gravity taken in BASE coordinates (rbdl_convention = false,
+  // forward_dynamics.hpp:237-243); the kernels work in world coordinates, so rotate it.
+  for (int r = 0; r < 3; ++r) {
+    double g = 0;
+    for (int c = 0; c < 3; ++c) g += m->base_X_world_rot[3 * r + c] * m->gravity[c];
+    d->grav[r] = (T)g;
+  }
+  for (int k = 0; k < 9; ++k) d->base_R[k] = (T)m->base_X_world_rot[k];
+  for (int k = 0; k < 3; ++k) d->base_t[k] = (T)m->base_X_world_trans[k];
+  double nb[3], t1[3], t2[3];
+  for (int k = 0; k < 3; ++k) {
+    d->plane_n[k] = (T)m->plane_normal[k];
+    nb[k] = -m->plane_normal[k];
+  }
+  d->plane_c = (T)m->plane_constant;
+  tds_plane_space(nb, t1, t2);
+  for (int k = 0; k < 3; ++k) {
+    d->nb[k] = (T)nb[k];
+    d->t1[k] = (T)t1[k];
+    d->t2[k] = (T)t2[k];
+  }
+  // links
+  int max_level = 0, pose_index = 0, ndof = 0;
+  uint32_t anc_links[TDS_NL];
+  for (int i = 0; i < m->num_links; ++i) {
+    const tds_link_t &l = m->links[i];
+    if (l.parent >= i || l.parent < -1) TDS_FAIL(TDS_ERR_INVALID_ARG, "links must be ordered parent-before-child");
+    if (l.joint_type == TDS_JOINT_SPHERICAL || l.joint_type < TDS_JOINT_FIXED || l.joint_type > TDS_JOINT_SPHERICAL)
+      TDS_FAIL(TDS_ERR_UNSUPPORTED, "spherical / unknown joint type (SURVEY 8f N4)");
+    d->parent[i] = l.parent;
+    d->level[i] = l.parent >= 0 ? d->level[l.parent] + 1 : 0;
+    if (d->level[i] > max_level) max_level = d->level[i];
+    d->joint_type[i] = l.joint_type;
+    const bool fixed = l.joint_type == TDS_JOINT_FIXED;
+    if (!fixed) {
+      if (l.q_index != ndof || l.qd_index != ndof) TDS_FAIL(TDS_ERR_INVALID_ARG, "q/qd indices must be dense in link order");
+      d->dof_link[ndof++] = i;
+    }
+    d->q_index[i] = fixed ? -1 : l.q_index;
+    d->qd_index[i] = fixed ? -1 : l.qd_index;
+    d->anc_dofs[i] = (l.parent >= 0 ? d->anc_dofs[l.parent] : 0u) | (fixed ? 0u : (1u << l.qd_index));
+    anc_links[i] = (l.parent >= 0 ? anc_links[l.parent] | (1u << l.parent) : 0u);
+    d->act_index[i] = -1;
+    if (m->step_mode == TDS_STEP_LOCOMOTION && i >= m->pd_start_link && !fixed) {
+      if (pose_index >= m->action_dim) TDS_FAIL(TDS_ERR_INVALID_ARG, "more PD links than action_dim");
+      d->act_index[i] = pose_index;
+      d->init_pose[i] = (T)m->initial_poses[pose_index];
+      ++pose_index;
+    }
+    for (int k = 0; k < 9; ++k) d->X_T[k][i] = (T)l.X_T_rot[k];
+    for (int k = 0; k < 3; ++k) d->X_T[9 + k][i] = (T)l.X_T_trans[k];
+    for (int k = 0; k < 6; ++k) d->S[k][i] = (T)l.S[k];
+    d->mass[i] = (T)l.mass;
+    for (int k = 0; k < 3; ++k) d->com[k][i] = (T)l.com[k];
+    for (int k = 0; k < 9; ++k) d->inertia[k][i] = (T)l.inertia[k];
+    d->stiffness[i] = (T)l.stiffness;
+    d->damping[i] = (T)l.damping;
+  }
+  if (ndof != nd) TDS_FAIL(TDS_ERR_INVALID_ARG, "dof_qd does not match the joints");
+  d->num_levels = max_level + 1;
+  // CRBA pair list
+  int np = 0;
+  for (int i = 0; i < m->num_links; ++i) {
+    if (d->qd_index[i] < 0) continue;
+    for (int j = 0; j < i; ++j)
+      if ((anc_links[i] >> j) & 1u) {
+        if (d->qd_index[j] < 0) continue;
+        if (np >= TDS_NPAIR) TDS_FAIL(TDS_ERR_UNSUPPORTED, "kinematic tree too deep for the CRBA pair list");
+        d->pair_i[np] = (int16_t)i;
+        d->pair_j[np] = (int16_t)j;
+        ++np;
+      }
+  }
+  d->num_pairs = np;
+  // contact points (only generated when a plane is present: world.hpp:206-282 pairs bodies)
+  int ncp = 0;
+  if (m->has_plane) {
+    for (int g = 0; g < m->num_geoms; ++g) {
+      const tds_geom_t &G = m->geoms[g];
+      if (G.link < -1 || G.link >= m->num_links) TDS_FAIL(TDS_ERR_INVALID_ARG, "geom link out of range");
+      int npts = 0;
+      double off[8][3];
+      double radius = G.radius;
+      if (G.type == TDS_GEOM_SPHERE) {
+        npts = 1;
+        off[0][0] = off[0][1] = off[0][2] = 0;
+      } else if (G.type == TDS_GEOM_CAPSULE) {  // contact_point.hpp:127-161
+        npts = 2;
+        for (int e = 0; e < 2; ++e) {
+          off[e][0] = off[e][1] = 0;
+          off[e][2] = (e == 0 ? 0.5 : -0.5) * G.length;
+        }
+      } else if (G.type == TDS_GEOM_BOX) {  // contact_point.hpp:163-198, geometry.hpp:244-259
+        npts = 8;
+        radius = G.radius > 1e-2 ? G.radius : 1e-2;
+        double dx = G.extents[0] * 0.5 - radius, dy = G.extents[1] * 0.5 - radius, dz = G.extents[2] * 0.5 - radius;
+        for (int c = 0; c < 8; ++c) {
+          off[c][0] = (c & 4) ? -dx : dx;
+          off[c][1] = (c & 2) ? -dy : dy;
+          off[c][2] = (c & 1) ? -dz : dz;
+        }
+      } else {
+        continue;  // meshes etc. are ignored by the reference too (urdf_to_multi_body.hpp:273-274)
+      }
+      for (int p = 0; p < npts; ++p) {
+        if (ncp >= TDS_NCP) TDS_FAIL(TDS_ERR_UNSUPPORTED, "too many contact points");
+        d->cp_link[ncp] = G.link;
+        d->cp_radius[ncp] = (T)radius;
+        for (int r = 0; r < 3; ++r) {
+          double v = G.X_trans[r];
+          for (int c = 0; c < 3; ++c) v += G.X_rot[3 * r + c] * off[p][c];
+          d->cp_local[r][ncp] = (T)v;
+        }
+        ++ncp;
+      }
+    }
+  }
+  d->num_cp = ncp;
+  for (int v = 0; v < d->num_visuals; ++v) {
+    const tds_visual_t &V = m->visuals[v];
+    if (V.link < 0 || V.link >= m->num_links) TDS_FAIL(TDS_ERR_INVALID_ARG, "visual link out of range");
+    d->vis_link[v] = V.link;
+    for (int k = 0; k < 9; ++k) d->vis_X[k][v] = (T)V.X_rot[k];
+    for (int k = 0; k < 3; ++k) d->vis_X[9 + k][v] = (T)V.X_trans[k];
+  }
+#undef TDS_FAIL
+  return TDS_OK;
+}

@@ -1,0 +1,27 @@
+// tds_kernels.h — host-visible interface of tds_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tds_device_model.h"
+
+// Per-environment LDS layout, offsets in units of the compute scalar T (see tds_make_lds_layout).
+struct TdsLds {
+  int stride;              // scalars per environment
+  int NLp, NDs, NCPp;      // padded links, dof row stride (odd), contact-point stride
+  int xrec, Xw, swd, M, dinv, cp, rowb, rowai, rowx;
+  int v, IA, pA, Ic, F;    // sweep arrays            } these two groups alias each other:
+  int J, B;                // constraint rows         } rows are built after the sweeps are done
+};
+
+template <typename T>
+TdsLds tds_make_lds_layout(const DevModel<T> &m);
+
+// Enqueue one step  y = f(x)  for n_envs environments on `stream`.
+//   actions    (optional) [n_envs][action_dim] overrides the action slice of x
+//   x_feedback (optional) [n_envs][input_dim]  receives the new q, qd (closed-loop stepping)
+template <typename T>
+int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
+                    const T *x_in, T *y_out, const T *actions, T *x_feedback, int n_envs, hipStream_t stream);
+
+template <typename T>
+int tds_kernel_max_dynamic_lds(int lanes_per_env, int bytes);

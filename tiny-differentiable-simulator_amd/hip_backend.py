@@ -1,0 +1,193 @@
+"""ctypes binding of libtds_hip.so (C ABI: include/tds_hip.h).
+
+PyTorch is used for what it is good at here — device memory, streams, torch.distributed —
+never for the arithmetic: every step goes through the hand-written HIP kernel.  If the
+shared library is missing or no HIP device is visible the constructors raise; there is no
+CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import model as _model
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtds_hip.so")
+
+TDS_OK = 0
+
+_lib = None
+
+
+class TdsHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libtds_hip.so (raises if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TdsHipError(f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        P = C.POINTER(_model.Model)
+        L.tds_hip_last_error.restype = C.c_char_p
+        L.tds_hip_model_check.argtypes = [P]
+        L.tds_hip_create.argtypes = [P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.tds_hip_destroy.argtypes = [C.c_void_p]
+        L.tds_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        for f in ("tds_hip_num_envs", "tds_hip_input_dim", "tds_hip_output_dim", "tds_hip_dtype"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.tds_hip_x_device.restype = C.c_void_p
+        L.tds_hip_x_device.argtypes = [C.c_void_p]
+        L.tds_hip_y_device.restype = C.c_void_p
+        L.tds_hip_y_device.argtypes = [C.c_void_p]
+        L.tds_hip_set_inputs.argtypes = [C.c_void_p, C.c_void_p]
+        L.tds_hip_get_inputs.argtypes = [C.c_void_p, C.c_void_p]
+        L.tds_hip_get_outputs.argtypes = [C.c_void_p, C.c_void_p]
+        L.tds_hip_forward_zero_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tds_hip_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.tds_hip_forward_zero_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.tds_hip_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.tds_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.tds_hip_kernel_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "tds_hip_last_error", "tds_hip_abi_version", "tds_hip_device_count", "tds_hip_model_check",
+    "tds_hip_create", "tds_hip_destroy", "tds_hip_set_stream", "tds_hip_num_envs",
+    "tds_hip_input_dim", "tds_hip_output_dim", "tds_hip_dtype", "tds_hip_x_device",
+    "tds_hip_y_device", "tds_hip_set_inputs", "tds_hip_get_inputs", "tds_hip_get_outputs",
+    "tds_hip_forward_zero_device", "tds_hip_step", "tds_hip_forward_zero_host",
+    "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info",
+]
+
+
+def _check(rc):
+    if rc != TDS_OK:
+        raise TdsHipError(f"tds_hip error {rc}: {lib().tds_hip_last_error().decode()}")
+
+
+def model_check(m: _model.Model) -> None:
+    _check(lib().tds_hip_model_check(C.byref(m)))
+
+
+class HipSim:
+    """N resident environments of one model on one GPU.
+
+    ``x`` / ``y`` are torch views (no copy) of the library-owned env-major records
+    [N, input_dim] / [N, output_dim] in the compute dtype.
+    """
+
+    def __init__(self, m: _model.Model, num_envs: int, device: int = 0, dtype: str = "f64",
+                 lanes_per_env: int | None = None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise TdsHipError("no HIP device visible (the HIP path has no CPU fallback)")
+        self.model = m.copy()
+        self.num_envs = int(num_envs)
+        self.device = int(device)
+        self.dtype = _model.TDS_DTYPE_F64 if dtype in ("f64", "float64") else _model.TDS_DTYPE_F32
+        self.torch_dtype = torch.float64 if self.dtype == _model.TDS_DTYPE_F64 else torch.float32
+        if lanes_per_env is not None:
+            os.environ["TDS_HIP_LANES_PER_ENV"] = str(lanes_per_env)
+        h = C.c_void_p()
+        try:
+            _check(lib().tds_hip_create(C.byref(self.model), self.num_envs, self.device, self.dtype, C.byref(h)))
+        finally:
+            if lanes_per_env is not None:
+                os.environ.pop("TDS_HIP_LANES_PER_ENV", None)
+        self.h = h
+        self.input_dim = self.model.input_dim
+        self.output_dim = self.model.output_dim
+        self.x = self._wrap(lib().tds_hip_x_device(self.h), (self.num_envs, self.input_dim))
+        self.y = self._wrap(lib().tds_hip_y_device(self.h), (self.num_envs, self.output_dim))
+        self.use_current_stream()
+
+    # -- zero-copy torch view of library-owned device memory -------------------------------
+    def _wrap(self, ptr, shape):
+        import torch
+
+        n = 1
+        for s in shape:
+            n *= s
+        itemsize = 8 if self.dtype == _model.TDS_DTYPE_F64 else 4
+        typestr = "<f8" if itemsize == 8 else "<f4"
+
+        class _Holder:
+            pass
+
+        hld = _Holder()
+        hld.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+            "strides": None,
+        }
+        t = torch.as_tensor(hld, device=f"cuda:{self.device}")
+        t._tds_owner = self  # keep the handle alive as long as the view lives
+        return t
+
+    def use_current_stream(self):
+        import torch
+
+        st = torch.cuda.current_stream(self.device)
+        _check(lib().tds_hip_set_stream(self.h, C.c_void_p(st.cuda_stream)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tds_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the hot path -----------------------------------------------------------------------
+    def forward_zero(self, x, y=None):
+        """y = f(x) on device tensors [N, input_dim] -> [N, output_dim] (async)."""
+        import torch
+
+        assert x.is_cuda and x.dtype == self.torch_dtype and x.is_contiguous()
+        assert tuple(x.shape) == (self.num_envs, self.input_dim)
+        if y is None:
+            y = torch.empty((self.num_envs, self.output_dim), dtype=self.torch_dtype, device=x.device)
+        assert y.is_cuda and y.dtype == self.torch_dtype and y.is_contiguous()
+        _check(lib().tds_hip_forward_zero_device(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
+        return y
+
+    def step(self, actions=None, substeps: int = 1):
+        """Closed-loop step on the resident records (async): x[:, act] <- actions, y = f(x),
+        x[:, :nq+nd] <- y[:, :nq+nd]."""
+        ap = None
+        if actions is not None:
+            assert actions.is_cuda and actions.dtype == self.torch_dtype and actions.is_contiguous()
+            assert tuple(actions.shape) == (self.num_envs, self.model.action_dim)
+            ap = C.c_void_p(actions.data_ptr())
+        _check(lib().tds_hip_step(self.h, ap, int(substeps)))
+
+    def forward_zero_host(self, x_np):
+        """Blocking host-buffer call with the reference's <model>_forward_zero semantics."""
+        import numpy as np
+
+        x_np = np.ascontiguousarray(x_np, dtype=np.float64).reshape(-1, self.input_dim)
+        y_np = np.zeros((x_np.shape[0], self.output_dim), dtype=np.float64)
+        _check(lib().tds_hip_forward_zero_host(self.h, x_np.shape[0], x_np.ctypes.data, y_np.ctypes.data))
+        return y_np
+
+    def set_timing(self, on: bool):
+        _check(lib().tds_hip_set_timing(self.h, 1 if on else 0))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(lib().tds_hip_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def kernel_info(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().tds_hip_kernel_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(lds_bytes_per_env=a.value, lanes_per_env=b.value, envs_per_block=c.value)
