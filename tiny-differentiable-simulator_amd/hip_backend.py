@@ -30,6 +30,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise TdsHipError(f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  Import torch
+        # first so that libtds_hip.so binds to the runtime torch already loaded (same streams,
+        # same device contexts) instead of pulling a second copy from /opt/rocm.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         P = C.POINTER(_model.Model)
         L.tds_hip_last_error.restype = C.c_char_p
