@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the many-instance Ant step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one closed-loop environment step of every resident env: fresh action batch (already
+in HBM) -> HIP step kernel (PD, ABA, plane contacts, MLCP/PGS, Euler, record packing) -> new
+state fed back on device, plus the [obs | reward | done] record written by the same launch.
+With N > 1 ranks each GPU owns its own shard of environments (no data-path collective inside
+the step) and the observation records are all-gathered over RCCL once per step.
+
+Prints ONE JSON line on rank 0 (contract in the project brief): value = total env-steps / s
+over all GPUs, plus `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM) and
+`cpu_baseline` (the checker libraries timed on the host cores; reported, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(model_name, n_envs, budget_s=12.0):
+    """Checker libraries as the CPU baseline, rank 0 only, bounded sample.
+    kind "reference": oracle/_ref/libtds_ref.so — the reference's own header-only double path,
+                      one simulation object per thread.
+    kind "port":      oracle/libtds_oracle.so — the plain-C restatement with OpenMP."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tds_amd
+    import oraclelib
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", model_name + ".npz"))
+    m = tds_amd.load_model(model_name)
+    rng = np.random.default_rng(0)
+    x = g["x"][rng.integers(0, g["x"].shape[0], n_envs)]
+    cores = os.cpu_count() or 1
+    out = {}
+    # port: OpenMP over envs
+    threads = min(cores, oraclelib.max_threads())
+    oraclelib.step(m, x[:64], threads=threads)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        oraclelib.step(m, x, threads=threads)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s / 2 or reps >= 50:
+            break
+    dt = time.perf_counter() - t0
+    out["port"] = {"value": reps * n_envs / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+                   "sample": f"{reps} x {n_envs} {model_name} steps, oracle/tds_oracle.c, OpenMP"}
+    # reference: one RefSim per thread (python threads; ctypes releases the GIL)
+    try:
+        import reflib
+        if reflib.available():
+            import threading
+            nth = min(cores, 32)
+            sims = [reflib.RefSim(model_name) for _ in range(nth)]
+            chunk = max(1, min(256, n_envs // nth))
+            counts = [0] * nth
+            stop = time.perf_counter() + budget_s / 2
+
+            def work(i):
+                xs = x[(i * chunk) % n_envs:(i * chunk) % n_envs + chunk]
+                while time.perf_counter() < stop:
+                    sims[i].step(xs)
+                    counts[i] += xs.shape[0]
+
+            t0 = time.perf_counter()
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(nth)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            dt = time.perf_counter() - t0
+            out["reference"] = {"value": sum(counts) / dt, "unit": "env-steps/s", "cores": nth, "kind": "reference",
+                                "sample": f"{sum(counts)} {model_name} steps of step_forward_original "
+                                          f"(header-only double path, one sim per thread) in {dt:.1f}s"}
+    except Exception as e:  # the real-reference library is optional on the GPU box
+        out["reference_error"] = repr(e)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--model", default="ant")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per env (16/32/64), 0 = library default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import tds_amd
+    from tds_amd import hip_backend
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    m = tds_amd.load_model(args.model)
+    n = args.envs_per_gpu
+    sim = hip_backend.HipSim(m, n, device=local_rank, dtype=args.dtype,
+                             lanes_per_env=args.lanes if args.lanes else None)
+    tdt = sim.torch_dtype
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+
+    # synthetic inputs: reset-like states, seed 3 (+rank), settle, fresh actions/step
+    rng = np.random.default_rng(3 + rank)
+    x0 = np.zeros((n, m.input_dim))
+    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
+        ip = np.array([m.initial_poses[i] for i in range(adim)])
+        x0[:, 2] = 0.48
+        x0[:, 6:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
+        x0[:, -3:] = [15, 0.3, 3] if args.model.startswith("ant") else [100, 2, 50]
+    else:
+        x0[:, :nq] = rng.uniform(-1, 1, (n, nq))
+    sim.x.copy_(torch.from_numpy(x0).to(tdt).cuda())
+    for _ in range(10):  # 10 settle steps with zero action (ant_environment2.h:137-152)
+        sim.step(None)
+    pool = 16
+    amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
+    actions = torch.from_numpy(rng.uniform(-amp, amp, (pool, n, adim))).to(tdt).cuda().contiguous()
+    obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
+    gathered = torch.zeros((world * n, sim.obs_dim + 2), dtype=tdt, device="cuda") if world > 1 else None
+
+    def one_step(i):
+        sim.step(actions[i % pool], 1, obs)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, obs)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    K = args.steps
+    use_events = not args.no_events
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] if use_events else []
+    t0 = time.perf_counter()
+    for i in range(K):
+        if use_events:
+            evs[i][0].record()
+            sim.step(actions[i % pool], 1, obs)
+            evs[i][1].record()
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, obs)
+        else:
+            one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = None
+    if use_events:
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    finite = bool(torch.isfinite(sim.y).all().item())
+    if rank == 0:
+        elem = 8 if args.dtype == "f64" else 4
+        bytes_per_env_step = (m.input_dim + m.output_dim) * elem  # x record in + y record out
+        total_steps = world * n * K
+        value = total_steps / elapsed
+        roof = None
+        if kernel_ms:
+            achieved = n * bytes_per_env_step / (kernel_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "kernel": "tds_step_kernel", "kernel_ms_avg": kernel_ms,
+                    "algorithmic_bytes_per_launch": n * bytes_per_env_step,
+                    "note": "algorithmic bytes = (input_dim+output_dim)*sizeof(T) per env-step; the path is "
+                            "VALU/LDS-latency bound, see DESIGN.md"}
+        out = {
+            "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K,
+            "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.model} (gym Ant 14-dof + plane, 17 contact points, PGS 1 iter), "
+                                   f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
+                       if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
+                       "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
+                       "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(obs|reward|done)" if world > 1 else ""),
+                       "lanes_per_env": sim.kernel_info()["lanes_per_env"],
+                       "lds_bytes_per_env": sim.kernel_info()["lds_bytes_per_env"]},
+            "roofline": roof, "finite": finite,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb = cpu_baseline(args.model, min(n, 4096))
+            primary = cb.get("reference") or cb.get("port")
+            out["cpu_baseline"] = primary
+            out["cpu_baseline_port"] = cb.get("port")
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,17 @@ enum {
   TDS_STEP_TAU = 1
 };
 
+/* reward / termination rule written into the observation record (tds_hip_step_obs) */
+enum {
+  TDS_REWARD_NONE = 0,
+  /* reward = (x_t - x_{t-1})/dt, done = z < 0.26 (reward 0 when done)
+     (examples/environments/ant_environment2.h:75-106) */
+  TDS_REWARD_ANT = 1,
+  /* reward = x, done = up_dot_world_z < 0.6 || z < 0.2, up from rpy = q[3..5]
+     (examples/environments/laikago_environment2.h:130-171) */
+  TDS_REWARD_LAIKAGO = 2
+};
+
 /* scalar type the kernels compute in */
 enum { TDS_DTYPE_F64 = 0, TDS_DTYPE_F32 = 1 };
 
@@ -142,7 +153,7 @@ typedef struct tds_model {
   int32_t input_dim;  /* doubles per env in the reference record x */
   int32_t output_dim; /* doubles per env in the reference record y */
   int32_t pack_visuals; /* 1: y carries 7 doubles per visual + up_dot_z */
-  int32_t pad_;
+  int32_t reward_mode;  /* TDS_REWARD_*: which env's compute_reward_done the obs record mirrors */
   double dt;
   double gravity[3];
   double base_X_world_rot[9];
@@ -212,6 +223,15 @@ int tds_hip_forward_zero_device(tds_hip_sim_t *sim, const void *x_dev, void *y_d
        does on the host, ars_vectorized_environment.h:240-289, minus reward/reset)
    Repeated `substeps` times with the same action. */
 int tds_hip_step(tds_hip_sim_t *sim, const void *actions_dev, int substeps);
+
+/* tds_hip_step plus the per-env observation record the vectorised env hands to the policy
+   (ars_vectorized_environment.h:250-289), written by the same kernel launch:
+     obs_dev [N][obs_dim + 2] = [ q | qd  with obs[0] = obs[1] = 0 | reward | done ]   (compute dtype)
+   obs_dim = dof_q + dof_qd.  reward/done follow model->reward_mode for the LAST substep (what
+   repeated VectorizedEnvironment::step calls would report).  This record is what a multi-GPU
+   job all-gathers. */
+int tds_hip_step_obs(tds_hip_sim_t *sim, const void *actions_dev, int substeps, void *obs_dev);
+int tds_hip_obs_dim(const tds_hip_sim_t *sim);
 
 /* Blocking convenience with HOST buffers in double, any N <= num_envs:
    H2D(x) -> kernel -> D2H(y), i.e. exactly what the reference's <model>_forward_zero does. */

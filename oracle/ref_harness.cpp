@@ -211,6 +211,7 @@ int tdsref_flatten(void *h, tds_model_t *out) {
   out->input_dim = s->input_dim();
   out->output_dim = s->output_dim();
   out->pack_visuals = 1;
+  out->reward_mode = s->ant ? TDS_REWARD_ANT : (s->laikago ? TDS_REWARD_LAIKAGO : TDS_REWARD_NONE);
   out->dt = s->dt();
   copy_vec3(s->world().get_gravity(), out->gravity);
   copy_mat3(m.base_X_world().rotation, out->base_X_world_rot);

@@ -70,21 +70,21 @@ struct tds_hip_sim {
 
 namespace {
 
-int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, int n) {
-  if (s->timing) hipEventRecord(s->ev0, s->stream);
+int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n) {
+  if (s->timing) (void)hipEventRecord(s->ev0, s->stream);
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes, (const double *)x,
-                                 (double *)y, (const double *)actions, (double *)fb, n, s->stream);
+                                 (double *)y, (const double *)actions, (double *)fb, (double *)obs, n, s->stream);
   else
     rc = tds_launch_step<float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)x,
-                                (float *)y, (const float *)actions, (float *)fb, n, s->stream);
+                                (float *)y, (const float *)actions, (float *)fb, (float *)obs, n, s->stream);
   if (rc != 0) {
     snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad lanes_per_env");
     return TDS_ERR_HIP;
   }
   if (s->timing) {
-    hipEventRecord(s->ev1, s->stream);
+    (void)hipEventRecord(s->ev1, s->stream);
     s->have_ms = true;
   }
   return TDS_OK;
@@ -211,11 +211,11 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
 
 int tds_hip_destroy(tds_hip_sim_t *s) {
   if (!s) return TDS_OK;
-  if (s->d_model) hipFree(s->d_model);
-  if (s->d_x) hipFree(s->d_x);
-  if (s->d_y) hipFree(s->d_y);
-  if (s->ev0) hipEventDestroy(s->ev0);
-  if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->d_model) (void)hipFree(s->d_model);
+  if (s->d_x) (void)hipFree(s->d_x);
+  if (s->d_y) (void)hipFree(s->d_y);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
   return TDS_OK;
 }
@@ -251,26 +251,33 @@ int tds_hip_get_outputs(tds_hip_sim_t *s, double *y_host) {
 
 int tds_hip_forward_zero_device(tds_hip_sim_t *s, const void *x_dev, void *y_dev) {
   if (!s || !x_dev || !y_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
-  return launch(s, x_dev, y_dev, nullptr, nullptr, s->num_envs);
+  return launch(s, x_dev, y_dev, nullptr, nullptr, nullptr, s->num_envs);
 }
 
-int tds_hip_step(tds_hip_sim_t *s, const void *actions_dev, int substeps) {
+int tds_hip_step_obs(tds_hip_sim_t *s, const void *actions_dev, int substeps, void *obs_dev) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   if (substeps < 1) return fail(TDS_ERR_INVALID_ARG, "substeps must be >= 1");
   for (int k = 0; k < substeps; ++k) {
-    // the first substep installs the action into the resident record; feedback writes q, qd
-    int rc = launch(s, s->d_x, s->d_y, actions_dev, s->d_x, s->num_envs);
+    // every substep installs the same action into the resident record; feedback writes q, qd;
+    // the observation record is produced by the last substep's launch
+    int rc = launch(s, s->d_x, s->d_y, actions_dev, s->d_x, k == substeps - 1 ? obs_dev : nullptr, s->num_envs);
     if (rc != TDS_OK) return rc;
   }
   return TDS_OK;
 }
+
+int tds_hip_step(tds_hip_sim_t *s, const void *actions_dev, int substeps) {
+  return tds_hip_step_obs(s, actions_dev, substeps, nullptr);
+}
+
+int tds_hip_obs_dim(const tds_hip_sim_t *s) { return s ? s->model.dof_q + s->model.dof_qd : 0; }
 
 int tds_hip_forward_zero_host(tds_hip_sim_t *s, int n, const double *x_host, double *y_host) {
   if (!s || !x_host || !y_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (n < 1 || n > s->num_envs) return fail(TDS_ERR_INVALID_ARG, "n out of range");
   int rc = upload(s, s->d_x, x_host, (size_t)n * s->model.input_dim);
   if (rc != TDS_OK) return rc;
-  rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, n);
+  rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n);
   if (rc != TDS_OK) return rc;
   return download(s, y_host, s->d_y, (size_t)n * s->model.output_dim);
 }

@@ -26,7 +26,7 @@ struct DevModel {
   int num_links, dof_q, dof_qd, num_levels;
   int num_cp, num_visuals, action_dim, input_dim, output_dim;
   int step_mode, has_plane, pgs_iterations, pack_visuals;
-  int num_pairs, pad0_, pad1_;
+  int num_pairs, reward_mode, pad1_;
   T dt, cfm, erp_over_dt, friction, restitution, action_limit;
   T grav[3];       // base acceleration = -grav (forward_dynamics.hpp:242), world frame
   T base_R[9], base_t[3];
@@ -98,6 +98,7 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
   d->has_plane = m->has_plane;
   d->pgs_iterations = m->pgs_iterations;
   d->pack_visuals = m->pack_visuals;
+  d->reward_mode = m->reward_mode;
   const int nq = m->dof_q, nd = m->dof_qd;
   const int need_in = nq + nd + m->action_dim + (m->step_mode == TDS_STEP_LOCOMOTION ? 3 : 0);
   if (m->input_dim < need_in) TDS_FAIL(TDS_ERR_INVALID_ARG, "input_dim too small for [q|qd|action|vars]");

@@ -19,9 +19,11 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m);
 // Enqueue one step  y = f(x)  for n_envs environments on `stream`.
 //   actions    (optional) [n_envs][action_dim] overrides the action slice of x
 //   x_feedback (optional) [n_envs][input_dim]  receives the new q, qd (closed-loop stepping)
+//   obs_out    (optional) [n_envs][dof_q+dof_qd+2]  observation | reward | done
 template <typename T>
 int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
-                    const T *x_in, T *y_out, const T *actions, T *x_feedback, int n_envs, hipStream_t stream);
+                    const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, int n_envs,
+                    hipStream_t stream);
 
 template <typename T>
 int tds_kernel_max_dynamic_lds(int lanes_per_env, int bytes);

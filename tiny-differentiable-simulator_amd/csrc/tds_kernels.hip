@@ -164,9 +164,9 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
 // ------------------------------------------------------------------------------------------
 template <typename T, int G>
 __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl, TdsLds L,
-                                                      const T *__restrict__ x_in, T *__restrict__ y_out,
-                                                      const T *__restrict__ actions, T *__restrict__ x_feedback,
-                                                      int n_envs) {
+                                                      const T *x_in, T *__restrict__ y_out,
+                                                      const T *__restrict__ actions, T *x_feedback /* may alias x_in */,
+                                                      T *__restrict__ obs_out, int n_envs) {
   extern __shared__ __align__(16) unsigned char tds_smem_raw[];
   T *const sm = reinterpret_cast<T *>(tds_smem_raw);
   constexpr int EPW = 64 / G;
@@ -765,6 +765,51 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   // ---- M. integrate_euler: q += qd dt (integrator.hpp:126-131) and pack y -------------------
   q_new = q + qd_new * dt;
+
+  // ---- N. observation record [q | qd (obs[0] = obs[1] = 0) | reward | done]
+  //         (ars_vectorized_environment.h:250-289; ant_environment2.h:75-106;
+  //          laikago_environment2.h:130-171)
+  if (obs_out != nullptr) {
+    __syncthreads();
+    if (di == 0) xr[nq + nd] = q;  // x_{t-1}; the action slots are dead by now
+    if (di >= 0) xr[di] = q_new;
+    __syncthreads();
+    if (valid) {
+      T *const ob = obs_out + (size_t)env * (nq + nd + 2);
+      if (di >= 0) {
+        ob[di] = di < 2 ? T(0) : q_new;
+        ob[nq + di] = qd_new;
+      }
+      if (lane == 0) {
+        T reward = T(0);
+        bool done = false;
+        const int rm = mdl->reward_mode;
+        if (rm == TDS_REWARD_ANT && nq > 2) {
+          const T vel_x = (xr[0] - xr[nq + nd]) / dt;
+          done = xr[2] < T(0.26);
+          reward = done ? T(0) : vel_x;
+        } else if (rm == TDS_REWARD_LAIKAGO && nq > 5) {
+          // up_dot_world_z = quat_to_matrix(quat_from_euler_rpy(q[3..5]))(2,2)
+          // (tiny_quaternion.h set_euler_rpy, tiny_matrix3x3.h:315-340)
+          T sp, cp, st, ct, ss, cs2;
+          sincos_t<T>(xr[3] * T(0.5), &sp, &cp);
+          sincos_t<T>(xr[4] * T(0.5), &st, &ct);
+          sincos_t<T>(xr[5] * T(0.5), &ss, &cs2);
+          const T qx = sp * ct * cs2 - cp * st * ss;
+          const T qy = cp * st * cs2 + sp * ct * ss;
+          const T qz = cp * ct * ss - sp * st * cs2;
+          const T qw = cp * ct * cs2 + sp * st * ss;
+          const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+          const T up = T(1) - (qx * (qx * s2) + qy * (qy * s2));
+          done = (up < T(0.6)) || (xr[2] < T(0.2));
+          reward = done ? T(0) : xr[0];
+        }
+        ob[nq + nd] = reward;
+        ob[nq + nd + 1] = done ? T(1) : T(0);
+      }
+    }
+  }
+
   T *const yo = y_out + (size_t)env * out_dim;
   if (valid) {
     if (di >= 0) {
@@ -855,20 +900,21 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m) {
 
 template <typename T>
 int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
-                    const T *x_in, T *y_out, const T *actions, T *x_feedback, int n_envs, hipStream_t stream) {
+                    const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, int n_envs,
+                    hipStream_t stream) {
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
   const size_t shmem = (size_t)L.stride * epw * sizeof(T);
   (void)h_model;
   switch (lanes_per_env) {
     case 64:
-      hipLaunchKernelGGL((tds_step_kernel<T, 64>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, n_envs);
+      hipLaunchKernelGGL((tds_step_kernel<T, 64>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, n_envs);
       break;
     case 32:
-      hipLaunchKernelGGL((tds_step_kernel<T, 32>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, n_envs);
+      hipLaunchKernelGGL((tds_step_kernel<T, 32>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, n_envs);
       break;
     case 16:
-      hipLaunchKernelGGL((tds_step_kernel<T, 16>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, n_envs);
+      hipLaunchKernelGGL((tds_step_kernel<T, 16>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, n_envs);
       break;
     default:
       return -1;
@@ -890,7 +936,7 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int bytes) {
 
 template TdsLds tds_make_lds_layout<double>(const DevModel<double> &);
 template TdsLds tds_make_lds_layout<float>(const DevModel<float> &);
-template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, int, hipStream_t);
-template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, int, hipStream_t);
+template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, int, hipStream_t);
+template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, int, hipStream_t);
 template int tds_kernel_max_dynamic_lds<double>(int, int);
 template int tds_kernel_max_dynamic_lds<float>(int, int);

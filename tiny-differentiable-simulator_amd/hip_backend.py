@@ -52,6 +52,8 @@ def lib():
         L.tds_hip_get_outputs.argtypes = [C.c_void_p, C.c_void_p]
         L.tds_hip_forward_zero_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.tds_hip_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.tds_hip_step_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.tds_hip_obs_dim.argtypes = [C.c_void_p]
         L.tds_hip_forward_zero_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tds_hip_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -65,7 +67,8 @@ EXPORTED_SYMBOLS = [
     "tds_hip_create", "tds_hip_destroy", "tds_hip_set_stream", "tds_hip_num_envs",
     "tds_hip_input_dim", "tds_hip_output_dim", "tds_hip_dtype", "tds_hip_x_device",
     "tds_hip_y_device", "tds_hip_set_inputs", "tds_hip_get_inputs", "tds_hip_get_outputs",
-    "tds_hip_forward_zero_device", "tds_hip_step", "tds_hip_forward_zero_host",
+    "tds_hip_forward_zero_device", "tds_hip_step", "tds_hip_step_obs", "tds_hip_obs_dim",
+    "tds_hip_forward_zero_host",
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info",
 ]
 
@@ -164,15 +167,25 @@ class HipSim:
         _check(lib().tds_hip_forward_zero_device(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
         return y
 
-    def step(self, actions=None, substeps: int = 1):
+    def step(self, actions=None, substeps: int = 1, obs=None):
         """Closed-loop step on the resident records (async): x[:, act] <- actions, y = f(x),
-        x[:, :nq+nd] <- y[:, :nq+nd]."""
+        x[:, :nq+nd] <- y[:, :nq+nd].  ``obs`` (optional) [N, obs_dim+2] receives
+        [observation | reward | done] from the same launch."""
         ap = None
         if actions is not None:
             assert actions.is_cuda and actions.dtype == self.torch_dtype and actions.is_contiguous()
             assert tuple(actions.shape) == (self.num_envs, self.model.action_dim)
             ap = C.c_void_p(actions.data_ptr())
-        _check(lib().tds_hip_step(self.h, ap, int(substeps)))
+        op = None
+        if obs is not None:
+            assert obs.is_cuda and obs.dtype == self.torch_dtype and obs.is_contiguous()
+            assert tuple(obs.shape) == (self.num_envs, self.obs_dim + 2)
+            op = C.c_void_p(obs.data_ptr())
+        _check(lib().tds_hip_step_obs(self.h, ap, int(substeps), op))
+
+    @property
+    def obs_dim(self) -> int:
+        return self.model.dof_q + self.model.dof_qd
 
     def forward_zero_host(self, x_np):
         """Blocking host-buffer call with the reference's <model>_forward_zero semantics."""

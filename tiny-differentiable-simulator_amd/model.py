@@ -22,6 +22,7 @@ TDS_MAX_CONTACTS = 32
 
 TDS_STEP_LOCOMOTION = 0
 TDS_STEP_TAU = 1
+TDS_REWARD_NONE, TDS_REWARD_ANT, TDS_REWARD_LAIKAGO = 0, 1, 2
 TDS_DTYPE_F64 = 0
 TDS_DTYPE_F32 = 1
 
@@ -87,7 +88,7 @@ class Model(C.Structure):
         ("input_dim", C.c_int32),
         ("output_dim", C.c_int32),
         ("pack_visuals", C.c_int32),
-        ("pad_", C.c_int32),
+        ("reward_mode", C.c_int32),
         ("dt", C.c_double),
         ("gravity", C.c_double * 3),
         ("base_X_world_rot", C.c_double * 9),
@@ -133,7 +134,7 @@ class Model(C.Structure):
 _SCALARS = [
     "abi_version", "step_mode", "num_links", "dof_q", "dof_qd", "is_floating", "num_geoms",
     "num_visuals", "action_dim", "pd_start_link", "has_plane", "pgs_iterations", "input_dim",
-    "output_dim", "pack_visuals", "dt", "plane_constant", "cfm", "erp", "friction",
+    "output_dim", "pack_visuals", "reward_mode", "dt", "plane_constant", "cfm", "erp", "friction",
     "restitution", "action_limit",
 ]
 _VECTORS = ["gravity", "base_X_world_rot", "base_X_world_trans", "plane_normal"]
