@@ -62,7 +62,7 @@ def cpu_baseline(model_name, n_envs, budget_s=12.0):
         import reflib
         if reflib.available():
             import threading
-            nth = min(cores, 32)
+            nth = min(cores, 64)
             sims = [reflib.RefSim(model_name) for _ in range(nth)]
             chunk = max(1, min(256, n_envs // nth))
             counts = [0] * nth

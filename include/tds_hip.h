@@ -242,6 +242,13 @@ int tds_hip_forward_zero_host(tds_hip_sim_t *sim, int n, const double *x_host, d
 int tds_hip_set_timing(tds_hip_sim_t *sim, int enable);
 int tds_hip_last_kernel_ms(tds_hip_sim_t *sim, float *ms);
 
+/* Diagnostic: run y = f(x) once on the resident records with the instrumented kernel build and
+   return 14 shader-clock timestamps taken by workgroup 0 at the phase boundaries
+   (A load, B jcalc, C kinematics sweep, D inertias, E ABA/CRBA sweep, F acceleration sweep,
+    G mass matrix, H LDL^T, I narrowphase, J Jacobian rows, K row solves, L PGS, M pack, end).
+   Synchronises the stream. */
+int tds_hip_profile_phases(tds_hip_sim_t *sim, long long *cycles_host, int n);
+
 /* Static resource usage of the step kernel for this handle (for DESIGN.md / bench). */
 int tds_hip_kernel_info(const tds_hip_sim_t *sim, int *lds_bytes_per_env, int *threads_per_env,
                         int *envs_per_block);

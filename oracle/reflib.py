@@ -46,8 +46,21 @@ class RefSim:
     """name: "ant" | "laikago" | "<file>.urdf" | "<file>.urdf+plane" (file under <ref>/data)."""
 
     def __init__(self, name: str):
-        # the reference prints "Loading URDF ..." to stdout; harmless
-        self.h = lib().tdsref_create(name.encode(), REF_ROOT.encode())
+        # the reference printf()s "Loading URDF ..." to C stdout: silence it (fd-level) so that
+        # callers that print machine-readable output (bench.py) stay clean
+        L = lib()
+        libc = C.CDLL(None)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+        try:
+            self.h = L.tdsref_create(name.encode(), REF_ROOT.encode())
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+            os.close(devnull)
         self.name = name
         self.input_dim = lib().tdsref_input_dim(self.h)
         self.output_dim = lib().tdsref_output_dim(self.h)

@@ -296,6 +296,29 @@ int tds_hip_last_kernel_ms(tds_hip_sim_t *s, float *ms) {
   return TDS_OK;
 }
 
+int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
+  if (!s || !cycles_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (n < TDS_NUM_PHASE_STAMPS) return fail(TDS_ERR_INVALID_ARG, "need room for 14 stamps");
+  long long *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(long long) * TDS_NUM_PHASE_STAMPS));
+  HIP_TRY(hipMemset(d, 0, sizeof(long long) * TDS_NUM_PHASE_STAMPS));
+  int rc;
+  if (s->dtype == TDS_DTYPE_F64)
+    rc = tds_launch_step<double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes, (const double *)s->d_x,
+                                 (double *)s->d_y, nullptr, nullptr, nullptr, s->num_envs, s->stream, d);
+  else
+    rc = tds_launch_step<float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)s->d_x,
+                                (float *)s->d_y, nullptr, nullptr, nullptr, s->num_envs, s->stream, d);
+  if (rc != 0) {
+    (void)hipFree(d);
+    return fail(TDS_ERR_HIP, "profiling launch failed");
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(cycles_host, d, sizeof(long long) * TDS_NUM_PHASE_STAMPS, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return TDS_OK;
+}
+
 int tds_hip_kernel_info(const tds_hip_sim_t *s, int *lds_bytes_per_env, int *threads_per_env, int *envs_per_block) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   if (lds_bytes_per_env) *lds_bytes_per_env = (int)(s->lds.stride * s->elem);

@@ -4,6 +4,8 @@
 
 #include "tds_device_model.h"
 
+#define TDS_NUM_PHASE_STAMPS 14
+
 // Per-environment LDS layout, offsets in units of the compute scalar T (see tds_make_lds_layout).
 struct TdsLds {
   int stride;              // scalars per environment
@@ -23,7 +25,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m);
 template <typename T>
 int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                     const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, int n_envs,
-                    hipStream_t stream);
+                    hipStream_t stream, long long *prof = nullptr);  // prof: 14 phase stamps of workgroup 0 (diagnostic)
 
 template <typename T>
 int tds_kernel_max_dynamic_lds(int lanes_per_env, int bytes);

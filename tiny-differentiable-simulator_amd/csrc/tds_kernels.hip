@@ -162,11 +162,19 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
 // ------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------
-template <typename T, int G>
+// TDS_STAMP: phase-boundary timestamps (shader clock) of workgroup 0, PROF builds only
+#define TDS_STAMP(k)                                                        \
+  do {                                                                      \
+    if (PROF) {                                                             \
+      if (blockIdx.x == 0 && threadIdx.x == 0) prof[k] = (long long)__builtin_amdgcn_s_memtime(); \
+    }                                                                       \
+  } while (0)
+
+template <typename T, int G, bool PROF>
 __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl, TdsLds L,
                                                       const T *x_in, T *__restrict__ y_out,
                                                       const T *__restrict__ actions, T *x_feedback /* may alias x_in */,
-                                                      T *__restrict__ obs_out, int n_envs) {
+                                                      T *__restrict__ obs_out, long long *prof, int n_envs) {
   extern __shared__ __align__(16) unsigned char tds_smem_raw[];
   T *const sm = reinterpret_cast<T *>(tds_smem_raw);
   constexpr int EPW = 64 / G;
@@ -181,6 +189,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   const int NLp = L.NLp, NDs = L.NDs;
   const T dt = mdl->dt;
 
+  TDS_STAMP(0);
   // ---- A. x record -> LDS (coalesced: consecutive lanes, consecutive doubles) ---------------
   T *const xr = E + L.xrec;
   for (int i = lane; i < in_dim; i += G) xr[i] = valid ? x_in[(size_t)env * in_dim + i] : T(0);
@@ -222,6 +231,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // joint stiffness / damping (forward_dynamics.hpp:122-123)
   if (isl) tau -= mdl->stiffness[lsafe] * q + mdl->damping[lsafe] * qd;
 
+  TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
   T Sl[6];
 #pragma unroll
@@ -274,6 +284,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     tp[2] = tT[2] + r[2];
   }
 
+  TDS_STAMP(2);
   // ---- C. top-down sweep: X_world, world motion axis s, velocity v  (kinematics.hpp:64-97) ---
   T *const Xw = E + L.Xw;    // [12][NLp]
   T *const swd = E + L.swd;  // [6][NDs]   per dof
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     __syncthreads();
   }
 
+  TDS_STAMP(3);
   // ---- D. bias terms and world-frame inertias (kinematics.hpp:96-132, inertia.hpp:121-130) ---
   T *const IAs = E + L.IA;  // [21][NLp]  I(6) H(9) M(6)
   T *const pAs = E + L.pA;  // [6][NLp]
@@ -428,6 +440,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   }
   __syncthreads();
 
+  TDS_STAMP(4);
   // ---- E. bottom-up sweep: ABA articulated inertia / bias, CRBA composite inertia -----------
   //      (forward_dynamics.hpp:50-216, mass_matrix.hpp:39-56) in world coordinates
   T U[6], Dinv = T(0), uu = T(0);
@@ -521,6 +534,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     __syncthreads();
   }
 
+  TDS_STAMP(5);
   // ---- F. top-down sweep: accelerations, qdd  (forward_dynamics.hpp:245-302) ----------------
   //      a overwrites v in LDS (v of every link is already in registers)
   T qdd = T(0);
@@ -555,6 +569,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   if (mdl->has_plane && mdl->num_cp > 0) {
     if (di >= 0) xr[nq + di] = qd_new;
+    TDS_STAMP(6);
     // ---- G. CRBA entries: M_ii = s_i.F_i,  M_ij = F_i.s_j for ancestors j (mass_matrix.hpp:87-109)
     T *const Fs = E + L.F;    // [6][NLp]
     T *const Ms = E + L.M;    // [nd][NDs]  lower: M / LDL^T workspace, strict upper: L^T
@@ -577,6 +592,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     __syncthreads();
 
+    TDS_STAMP(7);
     // ---- H. M = L D L^T, right-looking, lane == row.  L[r][k] is written to the strict upper
     //         triangle slot [k][r] so that column k stays readable during step k.
     {
@@ -594,6 +610,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       }
     }
 
+    TDS_STAMP(8);
     // ---- I. narrowphase: plane vs sphere points (world.hpp:206-282, contact_point.hpp:96-125),
     //         compaction of penetrating points in contact order
     T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, link
@@ -650,6 +667,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     __syncthreads();  // J/B alias the sweep arrays (IA, pA, Ic, v, F): all of those are dead now
 
+    TDS_STAMP(9);
     // ---- J. constraint Jacobian rows (jacobian.hpp:13-83, mb_constraint_solver.hpp:278-388)
     //         row a: normal, na+a: tangent 1, 2na+a: tangent 2;  lane == dof
     T *const Js = E + L.J;  // [3na][NDs]
@@ -687,6 +705,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     __syncthreads();
 
+    TDS_STAMP(10);
     // ---- K. per row: b, B = M^-1 J^T (L D L^T solves), 1/(J.B + cfm); lane == row -----------
     const T cfm = mdl->cfm, erp_dt = mdl->erp_over_dt, rest = mdl->restitution;
     for (int r = lane; r < nr; r += G) {
@@ -722,6 +741,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     __syncthreads();
 
+    TDS_STAMP(11);
     // ---- L. projected Gauss-Seidel on w = M^-1 J^T x  (mb_constraint_solver.hpp:101-142);
     //         lane == dof holds w_d
     {
@@ -763,6 +783,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     if (di >= 0) qd_new = xr[nq + di];
   }
 
+  TDS_STAMP(12);
   // ---- M. integrate_euler: q += qd dt (integrator.hpp:126-131) and pack y -------------------
   q_new = q + qd_new * dt;
 
@@ -854,6 +875,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     for (int i = tail + lane; i < out_dim; i += G) yo[i] = T(0);
   }
+  TDS_STAMP(13);
 }
 
 }  // namespace
@@ -901,20 +923,23 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m) {
 template <typename T>
 int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                     const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, int n_envs,
-                    hipStream_t stream) {
+                    hipStream_t stream, long long *prof) {
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
   const size_t shmem = (size_t)L.stride * epw * sizeof(T);
   (void)h_model;
   switch (lanes_per_env) {
     case 64:
-      hipLaunchKernelGGL((tds_step_kernel<T, 64>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, n_envs);
+      if (prof) hipLaunchKernelGGL((tds_step_kernel<T, 64, true>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
+      else hipLaunchKernelGGL((tds_step_kernel<T, 64, false>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
       break;
     case 32:
-      hipLaunchKernelGGL((tds_step_kernel<T, 32>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, n_envs);
+      if (prof) hipLaunchKernelGGL((tds_step_kernel<T, 32, true>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
+      else hipLaunchKernelGGL((tds_step_kernel<T, 32, false>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
       break;
     case 16:
-      hipLaunchKernelGGL((tds_step_kernel<T, 16>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, n_envs);
+      if (prof) hipLaunchKernelGGL((tds_step_kernel<T, 16, true>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
+      else hipLaunchKernelGGL((tds_step_kernel<T, 16, false>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
       break;
     default:
       return -1;
@@ -926,9 +951,12 @@ template <typename T>
 int tds_kernel_max_dynamic_lds(int lanes_per_env, int bytes) {
   hipError_t e = hipSuccess;
   switch (lanes_per_env) {
-    case 64: e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
-    case 32: e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
-    case 16: e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
+    case 64: e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
+    case 32: e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
+    case 16: e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
     default: return -1;
   }
   return (int)e;
@@ -936,7 +964,7 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int bytes) {
 
 template TdsLds tds_make_lds_layout<double>(const DevModel<double> &);
 template TdsLds tds_make_lds_layout<float>(const DevModel<float> &);
-template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, int, hipStream_t);
-template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, int, hipStream_t);
+template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, int, hipStream_t, long long *);
+template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, int, hipStream_t, long long *);
 template int tds_kernel_max_dynamic_lds<double>(int, int);
 template int tds_kernel_max_dynamic_lds<float>(int, int);

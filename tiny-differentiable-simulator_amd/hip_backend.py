@@ -57,6 +57,7 @@ def lib():
         L.tds_hip_forward_zero_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tds_hip_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.tds_hip_profile_phases.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
         L.tds_hip_kernel_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
@@ -69,7 +70,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_y_device", "tds_hip_set_inputs", "tds_hip_get_inputs", "tds_hip_get_outputs",
     "tds_hip_forward_zero_device", "tds_hip_step", "tds_hip_step_obs", "tds_hip_obs_dim",
     "tds_hip_forward_zero_host",
-    "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info",
+    "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
 ]
 
 
@@ -203,6 +204,17 @@ class HipSim:
         ms = C.c_float()
         _check(lib().tds_hip_last_kernel_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+    PHASES = ["A load+PD", "B jcalc", "C kinematics sweep", "D inertias/bias", "E ABA+CRBA sweep",
+              "F accel sweep", "G mass matrix", "H LDLt", "I narrowphase", "J jacobian rows",
+              "K row solves", "L PGS", "M/N pack"]
+
+    def profile_phases(self):
+        """Shader-clock cycles spent by workgroup 0 in each phase of one step (diagnostic)."""
+        buf = (C.c_longlong * 14)()
+        _check(lib().tds_hip_profile_phases(self.h, buf, 14))
+        st = list(buf)
+        return {name: st[i + 1] - st[i] for i, name in enumerate(self.PHASES)}
 
     def kernel_info(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
