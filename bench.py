@@ -143,12 +143,13 @@ def main():
     amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
     actions = torch.from_numpy(rng.uniform(-amp, amp, (pool, n, adim))).to(tdt).cuda().contiguous()
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
-    gathered = torch.zeros((world * n, sim.obs_dim + 2), dtype=tdt, device="cuda") if world > 1 else None
+    # the one exchange of the multi-GPU path: all-gather of [obs | reward | done] per step
+    gather = tds_amd.sharded.ObsGather(world * n, sim.obs_dim + 2, tdt, "cuda") if world > 1 else None
 
     def one_step(i):
         sim.step(actions[i % pool], 1, obs)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, obs)
+            gather(obs)
 
     for i in range(args.warmup):
         one_step(i)
@@ -167,7 +168,7 @@ def main():
             sim.step(actions[i % pool], 1, obs)
             evs[i][1].record()
             if world > 1:
-                dist.all_gather_into_tensor(gathered, obs)
+                gather(obs)
         else:
             one_step(i)
     torch.cuda.synchronize()

@@ -1,0 +1,236 @@
+// tds_hip_stepper.hpp — the reference-side binding: what a TDS maintainer includes to run
+// VectorizedEnvironment on libtds_hip.so.  Header-only C++17, compiled against the UNMODIFIED
+// TDS headers (it needs them on the include path; it is not part of libtds_hip.so itself).
+//
+//   * tds_hip::flatten_multibody / flatten_world / flatten_locomotion_env
+//       walk an intact tds::MultiBody + tds::World (built by TDS's own URDF loader, so every
+//       loader quirk is inherited) and fill the POD blob tds_model_t of include/tds_hip.h.
+//   * tds_hip::HipStepper<Algebra, Sim>
+//       implements VectorizedEnvironment<Algebra,Sim>::CustomForwardDynamicsStepper
+//       (reference: examples/ars/ars_vectorized_environment.h:75-85) exactly like the
+//       reference's own CudaStepper (examples/ars/ars_train_policy_cuda.cpp:476-499):
+//           HipStepper<MyAlgebra, Sim> stepper(env.contact_sim, batch_size);
+//           vec_env.default_stepper_ = &stepper;
+//
+// oracle/ref_harness.cpp includes this header, so it is compile- and run-tested against the
+// real reference wherever /root/reference exists.
+#pragma once
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "tds_hip.h"
+
+namespace tds_hip {
+
+namespace detail {
+template <typename Algebra, typename M3>
+inline void copy_mat3(const M3 &m, double *out) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) out[3 * r + c] = Algebra::to_double(m(r, c));
+}
+template <typename Algebra, typename V3>
+inline void copy_vec3(const V3 &v, double *out) {
+  for (int k = 0; k < 3; ++k) out[k] = Algebra::to_double(v[k]);
+}
+template <typename Algebra>
+inline int fill_geom(const tds::Geometry<Algebra> *geom, const tds::Transform<Algebra> &X, int link, tds_geom_t *G) {
+  memset(G, 0, sizeof(*G));
+  G->link = link;
+  G->type = geom->get_type();
+  switch (G->type) {
+    case tds::TINY_SPHERE_TYPE:
+      G->radius = Algebra::to_double(static_cast<const tds::Sphere<Algebra> *>(geom)->get_radius());
+      break;
+    case tds::TINY_CAPSULE_TYPE:
+      G->radius = Algebra::to_double(static_cast<const tds::Capsule<Algebra> *>(geom)->get_radius());
+      G->length = Algebra::to_double(static_cast<const tds::Capsule<Algebra> *>(geom)->get_length());
+      break;
+    case tds::TINY_BOX_TYPE:
+      copy_vec3<Algebra>(static_cast<const tds::Box<Algebra> *>(geom)->get_extents(), G->extents);
+      G->radius = Algebra::to_double(static_cast<const tds::Box<Algebra> *>(geom)->get_radius());
+      break;
+    default:
+      break;  // planes / meshes: kept for completeness, the HIP path ignores them like the reference's dispatcher
+  }
+  copy_mat3<Algebra>(X.rotation, G->X_rot);
+  copy_vec3<Algebra>(X.translation, G->X_trans);
+  return 0;
+}
+}  // namespace detail
+
+// Links, collision geometry, visuals and base transform of one articulated body.
+// Returns 0, or a negative code if the body exceeds the blob's capacity.
+template <typename Algebra>
+int flatten_multibody(const tds::MultiBody<Algebra> &mb, tds_model_t *out) {
+  using namespace detail;
+  out->num_links = static_cast<int>(mb.num_links());
+  if (out->num_links > TDS_MAX_LINKS) return -2;
+  out->dof_q = mb.dof();
+  out->dof_qd = mb.dof_qd();
+  out->is_floating = mb.is_floating() ? 1 : 0;
+  copy_mat3<Algebra>(mb.base_X_world().rotation, out->base_X_world_rot);
+  copy_vec3<Algebra>(mb.base_X_world().translation, out->base_X_world_trans);
+  int ng = 0, nv = 0;
+  for (size_t g = 0; g < mb.collision_geometries(-1).size(); ++g) {
+    if (ng >= TDS_MAX_GEOMS) return -3;
+    fill_geom<Algebra>(mb.collision_geometries(-1)[g], mb.collision_transforms(-1)[g], -1, &out->geoms[ng++]);
+  }
+  for (int i = 0; i < out->num_links; ++i) {
+    const tds::Link<Algebra> &l = mb[i];
+    tds_link_t &L = out->links[i];
+    memset(&L, 0, sizeof(L));
+    L.joint_type = static_cast<int>(l.joint_type);
+    L.parent = l.parent_index;
+    L.q_index = l.q_index;
+    L.qd_index = l.qd_index;
+    copy_mat3<Algebra>(l.X_T.rotation, L.X_T_rot);
+    copy_vec3<Algebra>(l.X_T.translation, L.X_T_trans);
+    for (int k = 0; k < 6; ++k) L.S[k] = Algebra::to_double(l.S[k]);
+    L.mass = Algebra::to_double(l.rbi.mass);
+    copy_vec3<Algebra>(l.rbi.com, L.com);
+    copy_mat3<Algebra>(l.rbi.inertia, L.inertia);
+    L.stiffness = Algebra::to_double(l.stiffness);
+    L.damping = Algebra::to_double(l.damping);
+    for (size_t g = 0; g < l.collision_geometries.size(); ++g) {
+      if (ng >= TDS_MAX_GEOMS) return -3;
+      fill_geom<Algebra>(l.collision_geometries[g], l.X_collisions[g], i, &out->geoms[ng++]);
+    }
+    for (size_t v = 0; v < l.X_visuals.size(); ++v) {
+      if (nv >= TDS_MAX_VISUALS) return -4;
+      tds_visual_t &V = out->visuals[nv++];
+      memset(&V, 0, sizeof(V));
+      V.link = i;
+      copy_mat3<Algebra>(l.X_visuals[v].rotation, V.X_rot);
+      copy_vec3<Algebra>(l.X_visuals[v].translation, V.X_trans);
+    }
+  }
+  out->num_geoms = ng;
+  out->num_visuals = nv;
+  return 0;
+}
+
+// Gravity, contact-solver parameters and default contact material of the World
+// (reference: src/world.hpp:65-71, src/mb_constraint_solver.hpp:59-70).
+template <typename Algebra>
+void flatten_world(tds::World<Algebra> &world, tds_model_t *out) {
+  detail::copy_vec3<Algebra>(world.get_gravity(), out->gravity);
+  auto *solver = world.get_mb_constraint_solver();
+  out->pgs_iterations = solver->pgs_iterations_;
+  out->cfm = Algebra::to_double(solver->cfm_);
+  out->erp = Algebra::to_double(solver->erp_);
+  out->friction = Algebra::to_double(world.default_friction);
+  out->restitution = Algebra::to_double(world.default_restitution);
+}
+
+// The implicit ground plane is multi_bodies_[0] of the env's World (it is loaded first,
+// locomotion_contact_simulation.h:100-123) but World keeps its bodies private; reach it through
+// the public contact list of one dry-run World::step at q = 0.  Returns 0 on success.
+template <typename Algebra>
+int flatten_plane(tds::World<Algebra> &world, tds::MultiBody<Algebra> &robot, double dt, tds_model_t *out) {
+  robot.initialize();
+  auto qd_save = robot.qd();
+  tds::forward_kinematics(robot, robot.q(), robot.qd());
+  world.step(Algebra::from_double(dt));
+  robot.qd() = qd_save;
+  if (world.mb_contacts_.empty() || world.mb_contacts_[0].empty()) return -5;
+  const auto &cp = world.mb_contacts_[0][0];
+  if (cp.multi_body_b != &robot) return -7;  // plane must be body a (dispatcher swap path)
+  const auto &pg = cp.multi_body_a->collision_geometries(-1);
+  if (pg.size() != 1 || pg[0]->get_type() != tds::TINY_PLANE_TYPE) return -6;
+  const auto *plane = static_cast<const tds::Plane<Algebra> *>(pg[0]);
+  detail::copy_vec3<Algebra>(plane->get_normal(), out->plane_normal);
+  out->plane_constant = Algebra::to_double(plane->get_constant());
+  out->has_plane = 1;
+  robot.initialize();
+  return 0;
+}
+
+// Everything for a LocomotionContactSimulation-derived environment (AntContactSimulation2,
+// LaikagoContactSimulation, ...): x = [q | qd | action | kp kd max_force], PD step mode.
+template <typename Algebra, typename Sim>
+int flatten_locomotion_env(Sim &sim, tds_model_t *out, int reward_mode = TDS_REWARD_NONE) {
+  memset(out, 0, sizeof(*out));
+  out->abi_version = TDS_HIP_ABI_VERSION;
+  out->step_mode = TDS_STEP_LOCOMOTION;
+  int rc = flatten_multibody<Algebra>(*sim.mb_, out);
+  if (rc) return rc;
+  flatten_world<Algebra>(sim.world, out);
+  out->dt = Algebra::to_double(sim.dt);
+  out->action_dim = sim.action_dim();
+  if (out->action_dim > TDS_MAX_ACTIONS) return -1;
+  out->pd_start_link = sim.mb_->is_floating() ? 0 : sim.base_dof_;
+  out->input_dim = sim.input_dim_with_action_and_variables();
+  out->output_dim = sim.output_dim();
+  out->pack_visuals = 1;
+  out->reward_mode = reward_mode;
+  out->action_limit = 0.4;  // locomotion_contact_simulation.h:234
+  for (size_t i = 0; i < sim.initial_poses_.size(); ++i) out->initial_poses[i] = Algebra::to_double(sim.initial_poses_[i]);
+  out->plane_normal[2] = 1.0;
+  rc = flatten_plane<Algebra>(sim.world, *sim.mb_, out->dt, out);
+  if (rc) return rc;
+  snprintf(out->name, sizeof(out->name), "%s", sim.env_name().c_str());
+  return 0;
+}
+
+#ifdef ARS_VECTORIZED_ENVIRONMENT_H
+// Drop-in for the reference's CudaStepper.  Errors are reported the way the reference's generated
+// library reports them for launch/allocation failures — fprintf(stderr) + exit — unless
+// throw_on_error is set, in which case std::runtime_error is thrown instead.
+template <typename Algebra, typename Sim>
+struct HipStepper : public VectorizedEnvironment<Algebra, Sim>::CustomForwardDynamicsStepper {
+  using Scalar = typename Algebra::Scalar;
+  tds_model_t model_;
+  tds_hip_sim_t *sim_ = nullptr;
+  int batch_size_;
+  bool throw_on_error_;
+  std::vector<double> in_, out_;
+
+  HipStepper(Sim &contact_sim, int batch_size, int device = 0, bool throw_on_error = false,
+             int reward_mode = TDS_REWARD_NONE)
+      : batch_size_(batch_size), throw_on_error_(throw_on_error) {
+    int rc = flatten_locomotion_env<Algebra>(contact_sim, &model_, reward_mode);
+    if (rc) fail("flatten_locomotion_env failed", rc);
+    rc = tds_hip_create(&model_, batch_size, device, TDS_DTYPE_F64, &sim_);
+    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    in_.resize((size_t)batch_size * model_.input_dim);
+    out_.resize((size_t)batch_size * model_.output_dim);
+  }
+  virtual ~HipStepper() { tds_hip_destroy(sim_); }
+
+  void fail(const char *what, int rc) {
+    std::string msg = std::string("tds_hip: ") + what + " (code " + std::to_string(rc) + ")";
+    if (throw_on_error_) throw std::runtime_error(msg);
+    fprintf(stderr, "%s\n", msg.c_str());
+    exit(rc);
+  }
+
+  // Same contract as CudaStepper::step: every env is stepped (dones are ignored, as the
+  // reference CUDA stepper does, ars_train_policy_cuda.cpp:492-499); blocking.
+  void step(const std::vector<std::vector<Scalar>> &thread_inputs, std::vector<std::vector<Scalar>> &thread_outputs,
+            std::vector<bool> &dones, int num_threads_per_block = 32,
+            const std::vector<Scalar> &global_input = {}) override {
+    (void)dones;
+    (void)num_threads_per_block;
+    (void)global_input;
+    const int n = static_cast<int>(thread_inputs.size());
+    if (n > batch_size_ || (int)thread_outputs.size() != n) fail("batch size mismatch", TDS_ERR_INVALID_ARG);
+    const int in = model_.input_dim, od = model_.output_dim;
+    for (int e = 0; e < n; ++e) {
+      if ((int)thread_inputs[e].size() != in) fail("input record size mismatch", TDS_ERR_INVALID_ARG);
+      for (int k = 0; k < in; ++k) in_[(size_t)e * in + k] = Algebra::to_double(thread_inputs[e][k]);
+    }
+    int rc = tds_hip_forward_zero_host(sim_, n, in_.data(), out_.data());
+    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    for (int e = 0; e < n; ++e) {
+      if ((int)thread_outputs[e].size() != od) fail("output record size mismatch", TDS_ERR_INVALID_ARG);
+      for (int k = 0; k < od; ++k) thread_outputs[e][k] = Algebra::from_double(out_[(size_t)e * od + k]);
+    }
+  }
+};
+#endif  // ARS_VECTORIZED_ENVIRONMENT_H
+
+}  // namespace tds_hip

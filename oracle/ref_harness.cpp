@@ -9,6 +9,7 @@
 //         examples/environments/locomotion_contact_simulation.h:151-304 (Ant / Laikago)
 //         examples/environments/cartpole_environment.h:88-94            (free ABA + Euler)
 // Nothing here re-implements the algorithm; it only calls the reference.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -25,8 +26,10 @@ typedef TinyAlgebra<double, ::TINY::DoubleUtils> Alg;
 #include "laikago_environment2.h"
 #include "dynamics/mass_matrix.hpp"
 #include "dynamics/jacobian.hpp"
+#include "../ars/ars_vectorized_environment.h"
 
 #include "tds_hip.h"
+#include "tds_hip_stepper.hpp"
 
 namespace {
 
@@ -191,126 +194,78 @@ void tdsref_set_solver(void *h, double cfm, double erp, int pgs_iterations, doub
   s->world().default_restitution = restitution;
 }
 
-// Flatten the reference's MultiBody + World into the C-ABI blob.
+// Flatten the reference's MultiBody + World into the C-ABI blob, through the SAME header a TDS
+// maintainer would use (include/tds_hip_stepper.hpp) — so that header is exercised here.
 int tdsref_flatten(void *h, tds_model_t *out) {
   RefSim *s = (RefSim *)h;
-  MultiBody<Alg> &m = *s->mb();
-  memset(out, 0, sizeof(*out));
-  out->abi_version = TDS_HIP_ABI_VERSION;
-  LocoSim *loco = s->loco();
-  out->step_mode = loco ? TDS_STEP_LOCOMOTION : TDS_STEP_TAU;
-  out->num_links = (int)m.num_links();
-  out->dof_q = m.dof();
-  out->dof_qd = m.dof_qd();
-  out->is_floating = m.is_floating() ? 1 : 0;
-  out->action_dim = loco ? loco->action_dim() : m.dof_qd();
-  out->pd_start_link = loco ? (m.is_floating() ? 0 : loco->base_dof_) : 0;
-  out->has_plane = s->has_plane() ? 1 : 0;
-  auto *solver = s->world().get_mb_constraint_solver();
-  out->pgs_iterations = solver->pgs_iterations_;
-  out->input_dim = s->input_dim();
-  out->output_dim = s->output_dim();
-  out->pack_visuals = 1;
-  out->reward_mode = s->ant ? TDS_REWARD_ANT : (s->laikago ? TDS_REWARD_LAIKAGO : TDS_REWARD_NONE);
-  out->dt = s->dt();
-  copy_vec3(s->world().get_gravity(), out->gravity);
-  copy_mat3(m.base_X_world().rotation, out->base_X_world_rot);
-  copy_vec3(m.base_X_world().translation, out->base_X_world_trans);
-  out->plane_normal[2] = 1.0;
-  out->plane_constant = 0.0;
-  if (s->has_plane()) {
-    // The plane body is multi_bodies_[0] (plane loaded first) but World keeps
-    // multi_bodies_ private; reach it through the public contact list of one dry-run step.
-    m.initialize();
-    Alg::VectorX qd_save = m.qd();
-    forward_kinematics(m, m.q(), m.qd());
-    s->world().step(s->dt());
-    m.qd() = qd_save;
-    if (s->world().mb_contacts_.empty() || s->world().mb_contacts_[0].empty()) return -5;
-    const auto &cp = s->world().mb_contacts_[0][0];
-    const auto &pg = cp.multi_body_a->collision_geometries(-1);
-    if (pg.size() != 1 || pg[0]->get_type() != TINY_PLANE_TYPE) return -6;
-    const Plane<Alg> *plane = (const Plane<Alg> *)pg[0];
-    copy_vec3(plane->get_normal(), out->plane_normal);
-    out->plane_constant = plane->get_constant();
-    m.initialize();
+  int rc;
+  if (s->ant) {
+    rc = tds_hip::flatten_locomotion_env<Alg>(s->ant->contact_sim, out, TDS_REWARD_ANT);
+  } else if (s->laikago) {
+    rc = tds_hip::flatten_locomotion_env<Alg>(s->laikago->contact_sim, out, TDS_REWARD_LAIKAGO);
+  } else {
+    memset(out, 0, sizeof(*out));
+    out->abi_version = TDS_HIP_ABI_VERSION;
+    out->step_mode = TDS_STEP_TAU;
+    rc = tds_hip::flatten_multibody<Alg>(*s->gmb, out);
+    if (rc) return rc;
+    tds_hip::flatten_world<Alg>(*s->gworld, out);
+    out->dt = s->g_dt;
+    out->action_dim = s->gmb->dof_qd();
+    out->input_dim = s->input_dim();
+    out->output_dim = s->output_dim();
+    out->pack_visuals = 1;
+    out->reward_mode = TDS_REWARD_NONE;
+    out->action_limit = 0.4;
+    out->plane_normal[2] = 1.0;
+    if (s->g_plane) rc = tds_hip::flatten_plane<Alg>(*s->gworld, *s->gmb, s->g_dt, out);
   }
-  out->cfm = solver->cfm_;
-  out->erp = solver->erp_;
-  out->friction = s->world().default_friction;
-  out->restitution = s->world().default_restitution;
-  out->action_limit = 0.4;
-  if (loco) {
-    if ((int)loco->initial_poses_.size() > TDS_MAX_ACTIONS) return -1;
-    for (size_t i = 0; i < loco->initial_poses_.size(); ++i)
-      out->initial_poses[i] = loco->initial_poses_[i];
-  }
-  if (out->num_links > TDS_MAX_LINKS) return -2;
-  int ng = 0, nv = 0;
-  // base-link collision geometry of the robot (none in the five configs)
-  for (size_t g = 0; g < m.collision_geometries(-1).size(); ++g) {
-    if (ng >= TDS_MAX_GEOMS) return -3;
-    tds_geom_t &G = out->geoms[ng++];
-    const Geometry<Alg> *geom = m.collision_geometries(-1)[g];
-    G.link = -1;
-    G.type = geom->get_type();
-    if (G.type == TINY_SPHERE_TYPE) G.radius = ((const Sphere<Alg> *)geom)->get_radius();
-    if (G.type == TINY_CAPSULE_TYPE) {
-      G.radius = ((const Capsule<Alg> *)geom)->get_radius();
-      G.length = ((const Capsule<Alg> *)geom)->get_length();
-    }
-    if (G.type == TINY_BOX_TYPE) {
-      copy_vec3(((const Box<Alg> *)geom)->get_extents(), G.extents);
-      G.radius = ((const Box<Alg> *)geom)->get_radius();
-    }
-    copy_mat3(m.collision_transforms(-1)[g].rotation, G.X_rot);
-    copy_vec3(m.collision_transforms(-1)[g].translation, G.X_trans);
-  }
-  for (int i = 0; i < out->num_links; ++i) {
-    const Link<Alg> &l = m[i];
-    tds_link_t &L = out->links[i];
-    L.joint_type = (int)l.joint_type;
-    L.parent = l.parent_index;
-    L.q_index = l.q_index;
-    L.qd_index = l.qd_index;
-    copy_mat3(l.X_T.rotation, L.X_T_rot);
-    copy_vec3(l.X_T.translation, L.X_T_trans);
-    for (int k = 0; k < 6; ++k) L.S[k] = l.S[k];
-    L.mass = l.rbi.mass;
-    copy_vec3(l.rbi.com, L.com);
-    copy_mat3(l.rbi.inertia, L.inertia);
-    L.stiffness = l.stiffness;
-    L.damping = l.damping;
-    for (size_t g = 0; g < l.collision_geometries.size(); ++g) {
-      if (ng >= TDS_MAX_GEOMS) return -3;
-      tds_geom_t &G = out->geoms[ng++];
-      const Geometry<Alg> *geom = l.collision_geometries[g];
-      G.link = i;
-      G.type = geom->get_type();
-      if (G.type == TINY_SPHERE_TYPE) G.radius = ((const Sphere<Alg> *)geom)->get_radius();
-      if (G.type == TINY_CAPSULE_TYPE) {
-        G.radius = ((const Capsule<Alg> *)geom)->get_radius();
-        G.length = ((const Capsule<Alg> *)geom)->get_length();
-      }
-      if (G.type == TINY_BOX_TYPE) {
-        copy_vec3(((const Box<Alg> *)geom)->get_extents(), G.extents);
-        G.radius = ((const Box<Alg> *)geom)->get_radius();
-      }
-      copy_mat3(l.X_collisions[g].rotation, G.X_rot);
-      copy_vec3(l.X_collisions[g].translation, G.X_trans);
-    }
-    for (size_t v = 0; v < l.X_visuals.size(); ++v) {
-      if (nv >= TDS_MAX_VISUALS) return -4;
-      tds_visual_t &V = out->visuals[nv++];
-      V.link = i;
-      copy_mat3(l.X_visuals[v].rotation, V.X_rot);
-      copy_vec3(l.X_visuals[v].translation, V.X_trans);
-    }
-  }
-  out->num_geoms = ng;
-  out->num_visuals = nv;
+  if (rc) return rc;
   snprintf(out->name, sizeof(out->name), "%s", s->name.c_str());
   return 0;
+}
+
+// Compile + behaviour check of the reference-side plug-in: build the reference's own
+// VectorizedEnvironment for Ant, install tds_hip::HipStepper as default_stepper_ and run
+// `steps` env steps of `batch` envs with zero actions; the same rollout through the reference's
+// SerialForwardStepper must agree.  Returns 0 on success; on failure returns non-zero and writes
+// the message (e.g. "no HIP device visible" on a machine without a GPU).
+int tdsref_hipstepper_selftest(int batch, int steps, double *obs0, char *msg, int msg_len) {
+  typedef AntContactSimulation2<Alg> Sim;
+  typedef VectorizedEnvironment<Alg, Sim> VecEnv;
+  AntEnv2<Alg> env(false);
+  VecEnv vec_env(env.contact_sim, batch);
+  ARSConfig config;
+  config.batch_size = batch;
+  config.auto_reset_when_done = false;
+  try {
+    tds_hip::HipStepper<Alg, Sim> stepper(env.contact_sim, batch, 0, /*throw_on_error=*/true, TDS_REWARD_ANT);
+    vec_env.seed(42);
+    auto observations = vec_env.reset(config);
+    vec_env.default_stepper_ = &stepper;
+    std::vector<std::vector<double>> actions(batch, std::vector<double>(env.contact_sim.action_dim(), 0.0));
+    std::vector<double> rewards(batch);
+    std::vector<bool> dones(batch, false);
+    for (int t = 0; t < steps; ++t) vec_env.step(actions, observations, rewards, dones, config);
+    for (size_t k = 0; k < observations[0].size(); ++k) obs0[k] = observations[0][k];
+    VecEnv vec_ref(env.contact_sim, batch);
+    vec_ref.seed(42);
+    auto obs_ref = vec_ref.reset(config);
+    vec_ref.default_stepper_ = &vec_ref.serial_stepper_;
+    std::vector<bool> dones_ref(batch, false);
+    for (int t = 0; t < steps; ++t) vec_ref.step(actions, obs_ref, rewards, dones_ref, config);
+    double err = 0;
+    for (int e = 0; e < batch; ++e)
+      for (size_t k = 0; k < obs_ref[e].size(); ++k) {
+        double d = std::fabs(obs_ref[e][k] - observations[e][k]) / std::max(std::fabs(obs_ref[e][k]), 1e-3);
+        if (d > err) err = d;
+      }
+    snprintf(msg, msg_len, "ok max_rel_err_vs_SerialForwardStepper=%.3e", err);
+    return err < 1e-6 ? 0 : -100;
+  } catch (const std::exception &e) {
+    snprintf(msg, msg_len, "%s", e.what());
+    return 1000;
+  }
 }
 
 // y[n][output_dim] = reference_step(x[n][input_dim]); y is zero-filled first (the reference's

@@ -25,6 +25,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  (libtds_ref.so links libtds_hip.so: one HIP runtime per process)
         L = C.CDLL(_LIB_PATH)
         L.tdsref_create.restype = C.c_void_p
         L.tdsref_create.argtypes = [C.c_char_p, C.c_char_p]
@@ -38,8 +39,28 @@ def lib():
         L.tdsref_flatten.argtypes = [C.c_void_p, C.POINTER(tds_amd.Model)]
         L.tdsref_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tdsref_debug.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        L.tdsref_hipstepper_selftest.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
         _lib = L
     return _lib
+
+
+def hipstepper_selftest(batch=8, steps=5):
+    """Reference VectorizedEnvironment + tds_hip::HipStepper (include/tds_hip_stepper.hpp).
+    returns (rc, message, obs0)."""
+    obs0 = np.zeros(64)
+    msg = C.create_string_buffer(512)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    try:
+        rc = lib().tdsref_hipstepper_selftest(batch, steps, obs0.ctypes.data, msg, 512)
+        C.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
+    return rc, msg.value.decode(), obs0
 
 
 class RefSim:

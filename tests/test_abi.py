@@ -75,3 +75,24 @@ def test_no_gpu_fails_loudly(built):
     assert rc in (3, 4) and not h.value  # TDS_ERR_HIP / TDS_ERR_NO_DEVICE, never a silent CPU path
     with pytest.raises(hip_backend.TdsHipError):
         hip_backend.HipSim(m, 8)
+
+
+@pytest.mark.parametrize("name", ["ant", "laikago"])
+def test_legacy_shim_exports_reference_symbols(name, built):
+    """cuda_model_<env>.so must export exactly what CudaModel<double> dlsym()s
+    (reference: examples/ars/ars_train_policy_cuda.cpp:220-229, 345-359)."""
+    import torch  # noqa: F401  one HIP runtime per process
+    path = os.path.join(ROOT, "tiny-differentiable-simulator_amd", f"cuda_model_{name}.so")
+    L = C.CDLL(path)
+
+    class Meta(C.Structure):
+        _fields_ = [("output_dim", C.c_int), ("input_dim", C.c_int), ("global_dim", C.c_int)]
+
+    base = f"cuda_model_{name}_forward_zero"
+    for suffix in ("", "_meta", "_allocate", "_deallocate"):
+        assert hasattr(L, base + suffix)
+    meta = getattr(L, base + "_meta")
+    meta.restype = Meta
+    md = meta()
+    m = tds_amd.load_model(name)
+    assert (md.output_dim, md.input_dim, md.global_dim) == (m.output_dim, m.input_dim, 0)

@@ -134,3 +134,36 @@ def test_f32_measured_error(built):
         err = rel_err(y[:, :nqd], g["y"][:, :nqd])
         print(f"{name} f32: max rel err (q, qd) vs reference {err:.3e}")
         assert err < (1e-4 if name == "pendulum5" else 5e-2)
+
+
+def test_reference_vecenv_dropin(built):
+    """The reference's own VectorizedEnvironment (compiled into oracle/_ref/libtds_ref.so, which
+    travels to the GPU box) stepping through tds_hip::HipStepper must reproduce its
+    SerialForwardStepper rollout.  Skipped when the prebuilt reference library is absent."""
+    import reflib
+    if not reflib.available():
+        pytest.skip("oracle/_ref/libtds_ref.so not built (needs /root/reference at build time)")
+    rc, msg, obs0 = reflib.hipstepper_selftest(16, 20)
+    print("HipStepper in VectorizedEnvironment:", msg)
+    assert rc == 0, msg
+
+
+@pytest.mark.parametrize("name", ["ant", "laikago"])
+def test_legacy_forward_zero_library(name, built):
+    """dlopen cuda_model_<env>.so the way the reference's CudaModel does and call
+    <model>_forward_zero with flat host arrays."""
+    import ctypes as C
+    from conftest import ROOT
+    _torch()
+    L = C.CDLL(os.path.join(ROOT, "tiny-differentiable-simulator_amd", f"cuda_model_{name}.so"))
+    base = f"cuda_model_{name}_forward_zero"
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = g["x"].shape[0]
+    getattr(L, base + "_allocate")(C.c_int(n))
+    x = np.ascontiguousarray(g["x"])
+    y = np.zeros_like(g["y"])
+    fn = getattr(L, base)
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    fn(n, (n + 63) // 64, 64, y.ctypes.data, x.ctypes.data)
+    getattr(L, base + "_deallocate")()
+    assert rel_err(y, g["y"]) < TOL

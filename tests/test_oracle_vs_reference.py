@@ -53,3 +53,13 @@ def test_reference_intermediates(built, gen):
         assert rel_err(do["contacts"], dr["contacts"], 1e-9) < 1e-10
         assert rel_err(do["jac"], dr["jac"], 1e-9) < 1e-10
     r.close()
+
+
+def test_hipstepper_header_compiles_and_fails_loudly_without_gpu(built):
+    """include/tds_hip_stepper.hpp::HipStepper inside the reference's own VectorizedEnvironment:
+    compiled into oracle/_ref/libtds_ref.so; without a GPU it must raise, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_hip_parity.py::test_reference_vecenv_dropin")
+    rc, msg, _ = reflib.hipstepper_selftest(4, 2)
+    assert rc != 0 and "no HIP device" in msg

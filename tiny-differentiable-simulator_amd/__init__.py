@@ -5,3 +5,4 @@ from .model import *  # noqa: F401,F403
 from . import model  # noqa: F401
 
 from . import hip_backend  # noqa: F401,E402
+from . import sharded  # noqa: F401,E402

@@ -1,0 +1,61 @@
+"""Multi-GPU layout of the hot path: environments are independent, so they shard across
+ranks with NO collective inside the step; the only exchange is one all-gather per policy step of
+the per-env record [obs | reward | done] that the step kernel writes.
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL on ROCm, "gloo" for CPU tests).
+"""
+from __future__ import annotations
+
+
+def shard_bounds(n_global: int, world: int, rank: int):
+    """Contiguous block [lo, hi) of global environment indices owned by `rank`
+    (block r = [r*N/G, (r+1)*N/G) with the remainder spread over the first ranks)."""
+    base, rem = divmod(n_global, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+class ObsGather:
+    """All-gather of the per-env records.  Equal shards use a single
+    ``all_gather_into_tensor`` (one direct exchange per peer over xGMI — every rank's shard goes
+    to every peer on its own link; no ring); ragged shards pad to the largest shard."""
+
+    def __init__(self, n_global: int, width: int, dtype, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_global = n_global
+        self.width = width
+        self.bounds = [shard_bounds(n_global, self.world, r) for r in range(self.world)]
+        self.sizes = [hi - lo for lo, hi in self.bounds]
+        self.equal = len(set(self.sizes)) == 1
+        self.max_size = max(self.sizes)
+        self.out = torch.zeros((n_global, width), dtype=dtype, device=device)
+        if not self.equal:
+            self._pad_in = torch.zeros((self.max_size, width), dtype=dtype, device=device)
+            self._pad_out = torch.zeros((self.world * self.max_size, width), dtype=dtype, device=device)
+
+    @property
+    def local_size(self) -> int:
+        return self.sizes[self.rank]
+
+    def __call__(self, local):
+        """local: [local_size, width] on this rank -> [n_global, width] on every rank (async on
+        the current stream for nccl; the returned tensor is reused between calls)."""
+        assert tuple(local.shape) == (self.local_size, self.width), (tuple(local.shape), self.local_size, self.width)
+        if self.world == 1:
+            self.out.copy_(local)
+            return self.out
+        if self.equal:
+            self.dist.all_gather_into_tensor(self.out, local.contiguous(), group=self.group)
+            return self.out
+        self._pad_in[: self.local_size].copy_(local)
+        self.dist.all_gather_into_tensor(self._pad_out, self._pad_in, group=self.group)
+        for r, (lo, hi) in enumerate(self.bounds):
+            self.out[lo:hi].copy_(self._pad_out[r * self.max_size: r * self.max_size + (hi - lo)])
+        return self.out
