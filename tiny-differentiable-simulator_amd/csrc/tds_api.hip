@@ -37,13 +37,15 @@ int fail(int code, const char *fmt, const char *detail = "") {
     }                                                                                      \
   } while (0)
 
-int default_lanes_per_env(int num_links) {
+// lanes per environment: the smallest wave-group that holds every link and every padded dof
+int default_lanes_per_env(int num_links, int dof) {
+  const int need = num_links > tds_padded_dof(dof) ? num_links : tds_padded_dof(dof);
   const char *env = getenv("TDS_HIP_LANES_PER_ENV");
   int g = env ? atoi(env) : 0;
   if (g == 16 || g == 32 || g == 64) {
-    if (g >= num_links) return g;
+    if (g >= need) return g;
   }
-  return num_links <= 16 ? 16 : (num_links <= 32 ? 32 : 64);
+  return need <= 16 ? 16 : (need <= 32 ? 32 : 64);
 }
 
 }  // namespace
@@ -158,7 +160,7 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   s->device = device;
   s->dtype = dtype;
   s->elem = dtype == TDS_DTYPE_F64 ? 8 : 4;
-  s->lanes = default_lanes_per_env(model->num_links);
+  s->lanes = default_lanes_per_env(model->num_links, model->dof_qd);
   char why[128];
   size_t msize;
   const void *hsrc;
@@ -180,8 +182,8 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     return fail(TDS_ERR_UNSUPPORTED, "model needs more than 160 KiB of LDS per workgroup");
   }
   if (lds_bytes > 64 * 1024) {
-    int e = dtype == TDS_DTYPE_F64 ? tds_kernel_max_dynamic_lds<double>(s->lanes, lds_bytes)
-                                   : tds_kernel_max_dynamic_lds<float>(s->lanes, lds_bytes);
+    int e = dtype == TDS_DTYPE_F64 ? tds_kernel_max_dynamic_lds<double>(s->lanes, s->lds.NDP, lds_bytes)
+                                   : tds_kernel_max_dynamic_lds<float>(s->lanes, s->lds.NDP, lds_bytes);
     if (e != 0) {
       delete s;
       return fail(TDS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");

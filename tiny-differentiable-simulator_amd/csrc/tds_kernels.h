@@ -9,10 +9,10 @@
 // Per-environment LDS layout, offsets in units of the compute scalar T (see tds_make_lds_layout).
 struct TdsLds {
   int stride;              // scalars per environment
-  int NLp, NDs, NCPp;      // padded links, dof row stride (odd), contact-point stride
-  int xrec, Xw, swd, M, dinv, cp, rowb, rowai, rowx;
+  int NLp, NDP, NDs, NCPp; // links, padded dof (8/16/24/32), dof row stride (odd), contact-point stride
+  int xrec, Xw, swd, Lp, dinv, cp, rowb, rowai, rowx;
   int v, IA, pA, Ic, F;    // sweep arrays            } these two groups alias each other:
-  int J, B;                // constraint rows         } rows are built after the sweeps are done
+  int Z;                   // constraint rows         } rows are built after the sweeps are done
 };
 
 template <typename T>
@@ -28,4 +28,6 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
                     hipStream_t stream, long long *prof = nullptr);  // prof: 14 phase stamps of workgroup 0 (diagnostic)
 
 template <typename T>
-int tds_kernel_max_dynamic_lds(int lanes_per_env, int bytes);
+int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes);
+
+int tds_padded_dof(int nd);

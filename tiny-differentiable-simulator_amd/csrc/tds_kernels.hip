@@ -29,6 +29,8 @@
 //     penetrating contacts are materialised, in the reference's row order.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "tds_device_model.h"
 #include "tds_kernels.h"
 
@@ -85,9 +87,25 @@ __device__ __forceinline__ void mat3_tmulv(const T *m, const T *v, T *o) {  // m
   o[1] = y;
   o[2] = z;
 }
+// 1/x to full precision: hardware reciprocal estimate + Newton-Raphson (2 steps f64, 1 step f32).
+// ~5 dependent instructions instead of the ~12 of an IEEE division; operands here are pivots /
+// diagonal entries in the normal range, no denormal or infinity handling needed.
 template <typename T>
-__device__ __forceinline__ T rcp_full(T x) {
-  return T(1) / x;
+__device__ __forceinline__ T rcp_full(T x);
+template <>
+__device__ __forceinline__ double rcp_full<double>(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+template <>
+__device__ __forceinline__ float rcp_full<float>(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  return __builtin_fmaf(r, e, r);
 }
 template <typename T>
 __device__ __forceinline__ void sincos_t(T a, T *s, T *c);
@@ -110,12 +128,57 @@ __device__ __forceinline__ float sqrt_t<float>(float a) {
   return sqrtf(a);
 }
 
-// sum over the G lanes of an environment; every lane receives the total
+// v + (v moved by a DPP cross-lane pattern inside each row of 16 lanes); VALU latency, no LDS
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return v + __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over the G lanes of an environment; every lane receives the total.  Strides 8,4,2,1 are
+// row rotations (DPP row_ror), wider strides go through the LDS crossbar (ds_bpermute).
 template <typename T, int G>
 __device__ __forceinline__ T group_sum(T v) {
+  v = dpp_add<0x128>(v);  // row_ror:8
+  v = dpp_add<0x124>(v);  // row_ror:4
+  v = dpp_add<0x122>(v);  // row_ror:2
+  v = dpp_add<0x121>(v);  // row_ror:1
 #pragma unroll
-  for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, G);
+  for (int m = 16; m < G; m <<= 1) v += __shfl_xor(v, m, G);
   return v;
+}
+
+// value held by lane SRC of the environment's lane group, delivered to every lane of the group.
+// All sources live in lanes 0..NDP-1; for NDP <= 16 that is one 16-lane DPP row -> row_newbcast
+// (a VALU move, no LDS round trip); wider groups go through ds_bpermute.
+template <int SRC>
+__device__ __forceinline__ double dpp_bcast(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + SRC, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + SRC, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int SRC>
+__device__ __forceinline__ float dpp_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + SRC, 0xF, 0xF, false));
+}
+template <typename T, int G, int NDP, int SRC>
+__device__ __forceinline__ T lane_bcast(T v) {
+  if constexpr (NDP <= 16)
+    return dpp_bcast<SRC & 15>(v);
+  else
+    return __shfl(v, SRC, G);
+}
+// compile-time loop helper (the DPP control must be an immediate)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 
 // reference: src/math/tiny/tiny_matrix3x3.h:432-465 (getRotation, right-associative build:
@@ -170,7 +233,7 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
     }                                                                       \
   } while (0)
 
-template <typename T, int G, bool PROF>
+template <typename T, int G, int NDP, bool PROF>
 __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl, TdsLds L,
                                                       const T *x_in, T *__restrict__ y_out,
                                                       const T *__restrict__ actions, T *x_feedback /* may alias x_in */,
@@ -570,47 +633,65 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   if (mdl->has_plane && mdl->num_cp > 0) {
     if (di >= 0) xr[nq + di] = qd_new;
     TDS_STAMP(6);
-    // ---- G. CRBA entries: M_ii = s_i.F_i,  M_ij = F_i.s_j for ancestors j (mass_matrix.hpp:87-109)
-    T *const Fs = E + L.F;    // [6][NLp]
-    T *const Ms = E + L.M;    // [nd][NDs]  lower: M / LDL^T workspace, strict upper: L^T
-    T *const dinv = E + L.dinv;
-    for (int i = lane; i < nd * NDs; i += G) Ms[i] = T(0);
+    // ---- G. mass-matrix row of dof d, straight into registers (lane == dof == row):
+    //         M[d][j] = F_d . s_j for j on the path base -> d   (mass_matrix.hpp:87-109)
+    T *const Fs = E + L.F;      // [6][NLp]
+    T *const Lp = E + L.Lp;     // strictly-lower L packed row-major: L[r][j] at r(r-1)/2 + j
+    T *const dvec = E + L.dinv; // [2][NDP]: 1/D_k | sqrt(1/D_k)
     if (isl) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) Fs[k * NLp + li] = Fc[k];
     }
     __syncthreads();
-    if (di >= 0) Ms[di * NDs + di] = dot3(sw, Fc) + dot3(sw + 3, Fc + 3);
-    const int npairs = mdl->num_pairs;
-    for (int pi = lane; pi < npairs; pi += G) {
-      const int i = mdl->pair_i[pi], j = mdl->pair_j[pi];
-      const int dI = mdl->qd_index[i], dJ = mdl->qd_index[j];
-      T s = T(0);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s += Fs[k * NLp + i] * swd[k * NDs + dJ];
-      Ms[dI * NDs + dJ] = s;  // lower triangle only (dJ < dI)
-    }
-    __syncthreads();
-
-    TDS_STAMP(7);
-    // ---- H. M = L D L^T, right-looking, lane == row.  L[r][k] is written to the strict upper
-    //         triangle slot [k][r] so that column k stays readable during step k.
+    T Mr[NDP];
     {
-      const int r = lane;
-      for (int k = 0; k < nd; ++k) {
-        const T dk = Ms[k * NDs + k];
-        const T inv = rcp_full<T>(dk);
-        if (r > k && r < nd) {
-          const T l = Ms[r * NDs + k] * inv;
-          for (int c = k + 1; c <= r; ++c) Ms[r * NDs + c] -= l * Ms[c * NDs + k];
-          Ms[k * NDs + r] = l;
+      const int d = lane;
+      const bool isd = d < nd;
+      const int lk = isd ? mdl->dof_link[d] : 0;
+      const unsigned anc = isd ? mdl->anc_dofs[lk] : 0u;
+      T Fd[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Fd[k] = isd ? Fs[k * NLp + lk] : T(0);
+#pragma unroll
+      for (int j = 0; j < NDP; ++j) {
+        T s = T(0);
+        if (j < nd) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s += Fd[k] * swd[k * NDs + j];
         }
-        if (r == k) dinv[k] = inv;
-        __syncthreads();
+        s = ((anc >> j) & 1u) ? s : T(0);
+        Mr[j] = (!isd && j == d) ? T(1) : s;  // padding rows: identity
       }
     }
-
+    TDS_STAMP(7);
+    // ---- H. M = L D L^T entirely in registers (replaces the Cholesky inverse,
+    //         tiny_matrix_x.h:240-345).  Right-looking; column k is gathered from the lanes that
+    //         own rows k..NDP-1 with cross-lane shuffles, no LDS traffic, no barriers.
+    //         Entries above the diagonal of a lane's row are never read by anyone.
+    static_for<0, NDP>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const T dk = lane_bcast<T, G, NDP, k>(Mr[k]);
+      const T inv = rcp_full<T>(dk);
+      const T lr = Mr[k] * inv;
+      static_for<k + 1, NDP>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const T mck = lane_bcast<T, G, NDP, c>(Mr[k]);
+        Mr[c] -= lr * mck;
+      });
+      if (lane == k) {
+        dvec[k] = inv;
+        dvec[NDP + k] = sqrt_t<T>(inv);
+      }
+      Mr[k] = lane > k ? lr : Mr[k];
+    });
+    if (lane < NDP) {
+      const int off = (lane * (lane - 1)) / 2;
+#pragma unroll
+      for (int j = 0; j < NDP - 1; ++j)
+        if (j < lane) Lp[off + j] = Mr[j];
+    }
     TDS_STAMP(8);
+
     // ---- I. narrowphase: plane vs sphere points (world.hpp:206-282, contact_point.hpp:96-125),
     //         compaction of penetrating points in contact order
     T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, link
@@ -665,13 +746,12 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       }
       na += __popcll(mine);
     }
-    __syncthreads();  // J/B alias the sweep arrays (IA, pA, Ic, v, F): all of those are dead now
-
+    __syncthreads();  // Z aliases the sweep arrays (IA, pA, Ic, v, F): all of those are dead now
     TDS_STAMP(9);
+
     // ---- J. constraint Jacobian rows (jacobian.hpp:13-83, mb_constraint_solver.hpp:278-388)
     //         row a: normal, na+a: tangent 1, 2na+a: tangent 2;  lane == dof
-    T *const Js = E + L.J;  // [3na][NDs]
-    T *const Bs = E + L.B;  // [3na][NDs]
+    T *const Zs = E + L.Z;  // [3na][NDs]: J rows, overwritten in place by z~ = D^-1/2 L^-1 J^T
     T *const rowb = E + L.rowb;
     T *const rowai = E + L.rowai;
     T *const rowx = E + L.rowx;
@@ -688,95 +768,112 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         const T P[3] = {cpx[0 * NCPp + a], cpx[1 * NCPp + a], cpx[2 * NCPp + a]};
         const int lk = (int)cpx[4 * NCPp + a];
         const unsigned msk = lk >= 0 ? mdl->anc_dofs[lk] : 0u;
-        if (d < nd) {
+        if (d < NDP) {
           T col[3] = {T(0), T(0), T(0)};
-          if ((msk >> d) & 1u) {  // xs.bottom = st.bottom - point x st.top
+          if (d < nd && ((msk >> d) & 1u)) {  // xs.bottom = st.bottom - point x st.top
             T c[3];
             cross3(P, sd, c);
             col[0] = sd[3] - c[0];
             col[1] = sd[4] - c[1];
             col[2] = sd[5] - c[2];
           }
-          Js[a * NDs + d] = dot3(nb, col);
-          Js[(na + a) * NDs + d] = dot3(t1, col);
-          Js[(2 * na + a) * NDs + d] = dot3(t2, col);
+          Zs[a * NDs + d] = dot3(nb, col);
+          Zs[(na + a) * NDs + d] = dot3(t1, col);
+          Zs[(2 * na + a) * NDs + d] = dot3(t2, col);
         }
       }
     }
     __syncthreads();
-
     TDS_STAMP(10);
-    // ---- K. per row: b, B = M^-1 J^T (L D L^T solves), 1/(J.B + cfm); lane == row -----------
+
+    // ---- K. per row (lane == row): b_r, forward substitution  L z = J_r^T  in registers,
+    //         G_rr = z.D^-1.z,  1/(G_rr + cfm);  the row is stored back as z~ = D^-1/2 z so that
+    //         A_rs = J_r M^-1 J_s^T = z~_r . z~_s  — one matrix instead of J and M^-1 J^T.
     const T cfm = mdl->cfm, erp_dt = mdl->erp_over_dt, rest = mdl->restitution;
     for (int r = lane; r < nr; r += G) {
-      const T *Jr = Js + r * NDs;
-      T *Br = Bs + r * NDs;
+      T *Zr = Zs + r * NDs;
+      T z[NDP];
+#pragma unroll
+      for (int k = 0; k < NDP; ++k) z[k] = Zr[k];
       T vrow = T(0);
-      for (int d = 0; d < nd; ++d) vrow += Jr[d] * xr[nq + d];
+#pragma unroll
+      for (int k = 0; k < NDP; ++k)
+        if (k < nd) vrow += z[k] * xr[nq + k];
       // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
-      T b;
-      if (r < na)
-        b = (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + r];
-      else
-        b = vrow;
-      rowb[r] = b;
-      // forward: L z = J_r^T     (L[k][j] lives at Ms[j][k], j < k)
-      for (int k = 0; k < nd; ++k) {
-        T s = Jr[k];
-        for (int j = 0; j < k; ++j) s -= Ms[j * NDs + k] * Br[j];
-        Br[k] = s;
-      }
-      for (int k = 0; k < nd; ++k) Br[k] *= dinv[k];
-      // backward: L^T y = z
-      for (int k = nd - 1; k >= 0; --k) {
-        T s = Br[k];
-        for (int j = k + 1; j < nd; ++j) s -= Ms[k * NDs + j] * Br[j];
-        Br[k] = s;
+      rowb[r] = r < na ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + r] : vrow;
+#pragma unroll
+      for (int k = 1; k < NDP; ++k) {
+        const int off = (k * (k - 1)) / 2;
+#pragma unroll
+        for (int j = 0; j < k; ++j) z[k] -= Lp[off + j] * z[j];
       }
       T g = T(0);
-      for (int d = 0; d < nd; ++d) g += Jr[d] * Br[d];
+#pragma unroll
+      for (int k = 0; k < NDP; ++k) {
+        const T zt = z[k] * dvec[NDP + k];
+        g += zt * zt;
+        Zr[k] = zt;
+      }
       rowai[r] = rcp_full<T>(g + cfm);
       rowai[nr + r] = g;
       rowx[r] = T(0);
     }
     __syncthreads();
-
     TDS_STAMP(11);
-    // ---- L. projected Gauss-Seidel on w = M^-1 J^T x  (mb_constraint_solver.hpp:101-142);
-    //         lane == dof holds w_d
+
+    // ---- L. projected Gauss-Seidel (mb_constraint_solver.hpp:101-142) on u~ = sum_r z~_r x_r:
+    //         delta_i = sum_{j != i} A_ij x_j = z~_i . u~ - G_ii x_i;   lane == dof holds u~_k
     {
       const int d = lane;
-      T w = T(0);
+      const bool dz = d < NDP;
+      T u = T(0);
       const T mu = mdl->friction;
       const int iters = mdl->pgs_iterations;
       for (int it = 0; it < iters; ++it) {
+        // software pipeline: everything row r+1 needs that does not depend on row r is loaded
+        // before row r's cross-lane reduction, so only the reduction + clamp sit on the chain
+        T zn = (nr > 0 && dz) ? Zs[d] : T(0);
+        T bn = nr > 0 ? rowb[0] : T(0), an = nr > 0 ? rowai[0] : T(0), gn = nr > 0 ? rowai[nr] : T(0);
+        T xon = (nr > 0 && it > 0) ? rowx[0] : T(0);
         for (int r = 0; r < nr; ++r) {
-          const T jr = d < nd ? Js[r * NDs + d] : T(0);
-          const T br = d < nd ? Bs[r * NDs + d] : T(0);
-          const T jw = group_sum<T, G>(jr * w);
-          const T x_old = rowx[r];
-          const T delta = jw - rowai[nr + r] * x_old;
-          T xn = (rowb[r] - delta) * rowai[r];
+          const T zr = zn, br = bn, ar = an, gr = gn, x_old = xon;
+          const int rn = r + 1;
+          if (rn < nr) {
+            zn = dz ? Zs[rn * NDs + d] : T(0);
+            bn = rowb[rn];
+            an = rowai[rn];
+            gn = rowai[nr + rn];
+            xon = it > 0 ? rowx[rn] : T(0);
+          }
+          // friction rows scale their box by the normal impulse of the same contact
+          // (limit_dependency_, mb_constraint_solver.hpp:417-436); that row is >= na rows back
+          T sdep = T(1);
+          if (r >= na) sdep = rowx[r < 2 * na ? r - na : r - 2 * na];
+          const T jw = group_sum<T, G>(zr * u);
+          const T delta = jw - gr * x_old;
+          T xn = (br - delta) * ar;
           T lo, hi;
           if (r < na) {
             lo = T(0);
             hi = T(100000);
           } else {
-            const int dep = r < 2 * na ? r - na : r - 2 * na;
-            T s = rowx[dep];
-            s = s < T(0) ? T(0) : s;
-            lo = -mu * s;
-            hi = mu * s;
+            const T sc = sdep < T(0) ? T(0) : sdep;
+            lo = -mu * sc;
+            hi = mu * sc;
           }
           xn = xn > lo ? xn : lo;  // Algebra::max(x, lo*s)
           xn = xn < hi ? xn : hi;  // Algebra::min(x, hi*s)
-          w += br * (xn - x_old);
-          __builtin_amdgcn_wave_barrier();
-          rowx[r] = xn;
-          __builtin_amdgcn_wave_barrier();
+          u += zr * (xn - x_old);
+          if (lane == 0) rowx[r] = xn;
         }
       }
-      // qd_b -= M_b^-1 J^T p  (mb_constraint_solver.hpp:476-496) -- lane d <-> link with that dof
+      // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
+      T w = dz ? u * dvec[NDP + d] : T(0);
+      static_for<0, NDP - 1>([&](auto ic) {
+        constexpr int k = NDP - 1 - decltype(ic)::value;
+        const T wk = lane_bcast<T, G, NDP, k>(w);
+        if (d < k) w -= Lp[(k * (k - 1)) / 2 + d] * wk;
+      });
       if (d < nd) xr[nq + d] -= w;
     }
     __syncthreads();
@@ -883,13 +980,17 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 // ------------------------------------------------------------------------------------------
 // host side: LDS layout + launch
 // ------------------------------------------------------------------------------------------
+int tds_padded_dof(int nd) { return nd <= 8 ? 8 : (nd <= 16 ? 16 : (nd <= 24 ? 24 : 32)); }
+
 template <typename T>
 TdsLds tds_make_lds_layout(const DevModel<T> &m) {
   TdsLds L;
   memset(&L, 0, sizeof(L));
-  const int nl = m.num_links, nd = m.dof_qd;
+  const int nl = m.num_links;
+  const int ndp = tds_padded_dof(m.dof_qd);
   L.NLp = nl;
-  L.NDs = nd | 1;  // odd row stride: lane == row accesses hit distinct LDS banks
+  L.NDP = ndp;
+  L.NDs = ndp + 1;  // odd row stride: lane == row accesses hit distinct LDS banks
   const int ncp = m.has_plane ? m.num_cp : 0;
   L.NCPp = ncp > 0 ? ncp : 1;
   const int nr = 3 * ncp;
@@ -897,13 +998,13 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m) {
   L.xrec = o; o += m.input_dim;
   L.Xw = o;   o += 12 * L.NLp;
   L.swd = o;  o += 6 * L.NDs;
-  L.M = o;    o += ncp ? nd * L.NDs : 0;
-  L.dinv = o; o += ncp ? nd : 0;
+  L.Lp = o;   o += ncp ? (ndp * (ndp - 1)) / 2 : 0;
+  L.dinv = o; o += ncp ? 2 * ndp : 0;
   L.cp = o;   o += ncp ? 5 * L.NCPp : 0;
   L.rowb = o; o += nr;
   L.rowai = o; o += 2 * nr;
   L.rowx = o; o += nr;
-  // union { sweep arrays } / { J, B }
+  // union { sweep arrays } / { Z }
   const int u = o;
   int s = u;
   L.v = s;  s += 6 * L.NLp;
@@ -912,8 +1013,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m) {
   L.Ic = s; s += 10 * L.NLp;
   L.F = s;  s += 6 * L.NLp;
   int j = u;
-  L.J = j; j += nr * L.NDs;
-  L.B = j; j += nr * L.NDs;
+  L.Z = j; j += nr * L.NDs;
   o = s > j ? s : j;
   o = (o + 1) & ~1;  // keep 16-byte alignment of every env region for T = double
   L.stride = o;
@@ -928,37 +1028,59 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
   const int blocks = (n_envs + epw - 1) / epw;
   const size_t shmem = (size_t)L.stride * epw * sizeof(T);
   (void)h_model;
-  switch (lanes_per_env) {
-    case 64:
-      if (prof) hipLaunchKernelGGL((tds_step_kernel<T, 64, true>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
-      else hipLaunchKernelGGL((tds_step_kernel<T, 64, false>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
-      break;
-    case 32:
-      if (prof) hipLaunchKernelGGL((tds_step_kernel<T, 32, true>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
-      else hipLaunchKernelGGL((tds_step_kernel<T, 32, false>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
-      break;
-    case 16:
-      if (prof) hipLaunchKernelGGL((tds_step_kernel<T, 16, true>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
-      else hipLaunchKernelGGL((tds_step_kernel<T, 16, false>), dim3(blocks), dim3(64), shmem, stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);
-      break;
+#define TDS_LAUNCH(GG, NN)                                                                                   \
+  do {                                                                                                       \
+    if (prof)                                                                                                \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, true>), dim3(blocks), dim3(64), shmem, stream, d_model, L, \
+                         x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);                           \
+    else                                                                                                     \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false>), dim3(blocks), dim3(64), shmem, stream, d_model, L, \
+                         x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);                           \
+  } while (0)
+  const int key = lanes_per_env * 100 + L.NDP;
+  switch (key) {
+    case 1608: TDS_LAUNCH(16, 8); break;
+    case 1616: TDS_LAUNCH(16, 16); break;
+    case 3208: TDS_LAUNCH(32, 8); break;
+    case 3216: TDS_LAUNCH(32, 16); break;
+    case 3224: TDS_LAUNCH(32, 24); break;
+    case 3232: TDS_LAUNCH(32, 32); break;
+    case 6408: TDS_LAUNCH(64, 8); break;
+    case 6416: TDS_LAUNCH(64, 16); break;
+    case 6424: TDS_LAUNCH(64, 24); break;
+    case 6432: TDS_LAUNCH(64, 32); break;
     default:
       return -1;
   }
+#undef TDS_LAUNCH
   return (int)hipGetLastError();
 }
 
 template <typename T>
-int tds_kernel_max_dynamic_lds(int lanes_per_env, int bytes) {
+int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
   hipError_t e = hipSuccess;
-  switch (lanes_per_env) {
-    case 64: e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
-    case 32: e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
-    case 16: e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)tds_step_kernel<T, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); break;
+#define TDS_ATTR(GG, NN)                                                                                        \
+  do {                                                                                                          \
+    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false>,                                    \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                 \
+    if (e == hipSuccess)                                                                                        \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, true>,                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
+  } while (0)
+  switch (lanes_per_env * 100 + ndp) {
+    case 1608: TDS_ATTR(16, 8); break;
+    case 1616: TDS_ATTR(16, 16); break;
+    case 3208: TDS_ATTR(32, 8); break;
+    case 3216: TDS_ATTR(32, 16); break;
+    case 3224: TDS_ATTR(32, 24); break;
+    case 3232: TDS_ATTR(32, 32); break;
+    case 6408: TDS_ATTR(64, 8); break;
+    case 6416: TDS_ATTR(64, 16); break;
+    case 6424: TDS_ATTR(64, 24); break;
+    case 6432: TDS_ATTR(64, 32); break;
     default: return -1;
   }
+#undef TDS_ATTR
   return (int)e;
 }
 
@@ -966,5 +1088,5 @@ template TdsLds tds_make_lds_layout<double>(const DevModel<double> &);
 template TdsLds tds_make_lds_layout<float>(const DevModel<float> &);
 template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, int, hipStream_t, long long *);
 template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, int, hipStream_t, long long *);
-template int tds_kernel_max_dynamic_lds<double>(int, int);
-template int tds_kernel_max_dynamic_lds<float>(int, int);
+template int tds_kernel_max_dynamic_lds<double>(int, int, int);
+template int tds_kernel_max_dynamic_lds<float>(int, int, int);
