@@ -167,3 +167,25 @@ def test_legacy_forward_zero_library(name, built):
     fn(n, (n + 63) // 64, 64, y.ctypes.data, x.ctypes.data)
     getattr(L, base + "_deallocate")()
     assert rel_err(y, g["y"]) < TOL
+
+
+@pytest.mark.parametrize("na_cap", [1, 3, 8, 17])
+def test_constraint_row_overflow_slab(na_cap, built):
+    """Constraint rows beyond the LDS capacity (na_cap contacts) live in a global scratch slab.
+    Every capacity must give the same answer, incl. states with all 17 Ant points penetrating."""
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    g = np.load(os.path.join(GOLDEN, "ant.npz"))
+    x = g["x"].copy()
+    extra = x[:16].copy()
+    extra[:, 2] = 0.02       # torso pressed into the ground: many / all points penetrate
+    extra[:, 3:6] *= 0.1
+    x = np.concatenate([x, extra])
+    y_ref = oraclelib.step(m, x)
+    d = oraclelib.step_debug(m, extra[0])
+    assert int((d["contacts"][:, 9] < 0).sum()) >= 13
+    sim = hip_backend.HipSim(m, x.shape[0], dtype="f64", na_cap=na_cap)
+    y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = rel_err(y, y_ref)
+    print(f"na_cap={na_cap}: lds/env {sim.kernel_info()['lds_bytes_per_env']} B, max rel err {err:.3e}")
+    assert err < TOL

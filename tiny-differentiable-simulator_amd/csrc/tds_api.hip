@@ -59,7 +59,7 @@ struct tds_hip_sim {
   DevModel<double> h64;
   DevModel<float> h32;
   TdsLds lds;
-  void *d_x = nullptr, *d_y = nullptr;
+  void *d_x = nullptr, *d_y = nullptr, *d_ovf = nullptr;
   std::vector<double> stage;
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -77,10 +77,10 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes, (const double *)x,
-                                 (double *)y, (const double *)actions, (double *)fb, (double *)obs, n, s->stream);
+                                 (double *)y, (const double *)actions, (double *)fb, (double *)obs, (double *)s->d_ovf, n, s->stream);
   else
     rc = tds_launch_step<float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)x,
-                                (float *)y, (const float *)actions, (float *)fb, (float *)obs, n, s->stream);
+                                (float *)y, (const float *)actions, (float *)fb, (float *)obs, (float *)s->d_ovf, n, s->stream);
   if (rc != 0) {
     snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad lanes_per_env");
     return TDS_ERR_HIP;
@@ -161,17 +161,20 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   s->dtype = dtype;
   s->elem = dtype == TDS_DTYPE_F64 ? 8 : 4;
   s->lanes = default_lanes_per_env(model->num_links, model->dof_qd);
+  // contacts whose constraint rows stay in LDS (TDS_HIP_NA_CAP overrides; surplus goes to a slab)
+  int na_cap = 8;
+  if (const char *e = getenv("TDS_HIP_NA_CAP")) na_cap = atoi(e);
   char why[128];
   size_t msize;
   const void *hsrc;
   if (dtype == TDS_DTYPE_F64) {
     tds_build_dev_model<double>(model, &s->h64, why);
-    s->lds = tds_make_lds_layout<double>(s->h64);
+    s->lds = tds_make_lds_layout<double>(s->h64, na_cap);
     msize = sizeof(DevModel<double>);
     hsrc = &s->h64;
   } else {
     tds_build_dev_model<float>(model, &s->h32, why);
-    s->lds = tds_make_lds_layout<float>(s->h32);
+    s->lds = tds_make_lds_layout<float>(s->h32, na_cap);
     msize = sizeof(DevModel<float>);
     hsrc = &s->h32;
   }
@@ -204,6 +207,8 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   CREATE_TRY(hipMalloc(&s->d_y, (size_t)num_envs * model->output_dim * s->elem));
   CREATE_TRY(hipMemset(s->d_x, 0, (size_t)num_envs * model->input_dim * s->elem));
   CREATE_TRY(hipMemset(s->d_y, 0, (size_t)num_envs * model->output_dim * s->elem));
+  if (s->lds.ovrows > 0)
+    CREATE_TRY(hipMalloc(&s->d_ovf, (size_t)num_envs * s->lds.ovrows * (s->lds.NDs + 3) * s->elem));
   CREATE_TRY(hipEventCreate(&s->ev0));
   CREATE_TRY(hipEventCreate(&s->ev1));
 #undef CREATE_TRY
@@ -216,6 +221,7 @@ int tds_hip_destroy(tds_hip_sim_t *s) {
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->d_x) (void)hipFree(s->d_x);
   if (s->d_y) (void)hipFree(s->d_y);
+  if (s->d_ovf) (void)hipFree(s->d_ovf);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -307,10 +313,10 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes, (const double *)s->d_x,
-                                 (double *)s->d_y, nullptr, nullptr, nullptr, s->num_envs, s->stream, d);
+                                 (double *)s->d_y, nullptr, nullptr, nullptr, (double *)s->d_ovf, s->num_envs, s->stream, d);
   else
     rc = tds_launch_step<float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)s->d_x,
-                                (float *)s->d_y, nullptr, nullptr, nullptr, s->num_envs, s->stream, d);
+                                (float *)s->d_y, nullptr, nullptr, nullptr, (float *)s->d_ovf, s->num_envs, s->stream, d);
   if (rc != 0) {
     (void)hipFree(d);
     return fail(TDS_ERR_HIP, "profiling launch failed");

@@ -10,21 +10,24 @@
 struct TdsLds {
   int stride;              // scalars per environment
   int NLp, NDP, NDs, NCPp; // links, padded dof (8/16/24/32), dof row stride (odd), contact-point stride
-  int xrec, Xw, swd, Lp, dinv, cp, rowb, rowai, rowx;
-  int v, IA, pA, Ic, F;    // sweep arrays            } these two groups alias each other:
-  int Z;                   // constraint rows         } rows are built after the sweeps are done
+  int zrows, ovrows;       // constraint rows held in LDS / surplus rows per env in the global slab
+  int xrec, swd, cp, Lp, dinv, rows, xrow;  // persistent
+  int Xw, v;               // phase group 1 (kinematics sweep)   } the three groups alias
+  int IA, pA, F, Ic, a;    // phase group 2 (dynamics sweeps)     } each other
+  int Z;                   // phase group 3 (constraint rows)     }
 };
 
 template <typename T>
-TdsLds tds_make_lds_layout(const DevModel<T> &m);
+TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap);  // na_cap: contacts whose rows stay in LDS (<=0: all)
 
 // Enqueue one step  y = f(x)  for n_envs environments on `stream`.
 //   actions    (optional) [n_envs][action_dim] overrides the action slice of x
 //   x_feedback (optional) [n_envs][input_dim]  receives the new q, qd (closed-loop stepping)
 //   obs_out    (optional) [n_envs][dof_q+dof_qd+2]  observation | reward | done
+//   ovf        [n_envs][ovrows][NDs+3] scratch slab for surplus constraint rows (NULL iff ovrows == 0)
 template <typename T>
 int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
-                    const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, int n_envs,
+                    const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
                     hipStream_t stream, long long *prof = nullptr);  // prof: 14 phase stamps of workgroup 0 (diagnostic)
 
 template <typename T>

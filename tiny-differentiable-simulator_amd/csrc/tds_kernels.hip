@@ -237,7 +237,7 @@ template <typename T, int G, int NDP, bool PROF>
 __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl, TdsLds L,
                                                       const T *x_in, T *__restrict__ y_out,
                                                       const T *__restrict__ actions, T *x_feedback /* may alias x_in */,
-                                                      T *__restrict__ obs_out, long long *prof, int n_envs) {
+                                                      T *__restrict__ obs_out, T *ovf, long long *prof, int n_envs) {
   extern __shared__ __align__(16) unsigned char tds_smem_raw[];
   T *const sm = reinterpret_cast<T *>(tds_smem_raw);
   constexpr int EPW = 64 / G;
@@ -412,6 +412,101 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   }
 
   TDS_STAMP(3);
+  // ---- I. narrowphase right after the kinematics sweep (it only needs X_world), so that the
+  //         LDS holding X_world / v can be recycled by the dynamics sweeps
+  T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, link
+  const int NCPp = L.NCPp;
+  int na = 0;
+  if (mdl->has_plane) {
+    const int ncp = mdl->num_cp;
+    for (int base = 0; base < ncp; base += G) {
+      const int k = base + lane;
+      bool act = false;
+      T Pb[3] = {T(0), T(0), T(0)}, dist = T(0);
+      int lk = -1;
+      if (k < ncp) {
+        lk = mdl->cp_link[k];
+        T Rl[9], pl[3];
+        if (lk >= 0) {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) Rl[c] = Xw[c * NLp + lk];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) pl[c] = Xw[(9 + c) * NLp + lk];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) Rl[c] = mdl->base_R[c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) pl[c] = mdl->base_t[c];
+        }
+        const T loc[3] = {mdl->cp_local[0][k], mdl->cp_local[1][k], mdl->cp_local[2][k]};
+        T ctr[3];
+        mat3_mulv(Rl, loc, ctr);
+        ctr[0] += pl[0];
+        ctr[1] += pl[1];
+        ctr[2] += pl[2];
+        const T n[3] = {mdl->plane_n[0], mdl->plane_n[1], mdl->plane_n[2]};
+        const T rad = mdl->cp_radius[k];
+        // t = -(dot(p, -n) + c);  distance = t - r;  point_on_b = p - r n
+        const T t = -((-dot3(ctr, n)) + mdl->plane_c);
+        dist = t - rad;
+        Pb[0] = ctr[0] - rad * n[0];
+        Pb[1] = ctr[1] - rad * n[1];
+        Pb[2] = ctr[2] - rad * n[2];
+        act = valid && dist < T(0);  // collision mask, mb_constraint_solver.hpp:285
+      }
+      const unsigned long long bal = __ballot(act);
+      const unsigned long long mine = (G == 64) ? bal : ((bal >> (grp * G)) & ((1ull << (G & 63)) - 1ull));
+      const int pre = __popcll(mine & ((1ull << lane) - 1ull));
+      if (act) {
+        const int slot = na + pre;
+        cpx[0 * NCPp + slot] = Pb[0];
+        cpx[1 * NCPp + slot] = Pb[1];
+        cpx[2 * NCPp + slot] = Pb[2];
+        cpx[3 * NCPp + slot] = dist;
+        cpx[4 * NCPp + slot] = T(lk);
+      }
+      na += __popcll(mine);
+    }
+  }
+  // does any environment of this wavefront have a penetrating contact?  If not, the whole
+  // constraint pipeline (CRBA, LDL^T, rows, PGS) is skipped: with keep_all_points_ the reference
+  // still solves, but every row is identically zero and leaves qd untouched.
+  const bool wave_contacts = __any(na > 0) != 0;
+
+  // ---- M1. visual poses of y (they use the PRE-step X_world, locomotion_contact_simulation.h:281-299)
+  {
+    T *const yo = y_out + (size_t)env * out_dim;
+    const int nv = mdl->num_visuals;
+    const int vbase = nq + nd;
+    if (valid) {
+      for (int k = lane; k < nv; k += G) {
+        const int lk = mdl->vis_link[k];
+        T Rl[9], pl[3], Rv[9], pv[3];
+  #pragma unroll
+        for (int c = 0; c < 9; ++c) Rl[c] = Xw[c * NLp + lk];
+  #pragma unroll
+        for (int c = 0; c < 3; ++c) pl[c] = Xw[(9 + c) * NLp + lk];
+  #pragma unroll
+        for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
+  #pragma unroll
+        for (int c = 0; c < 3; ++c) pv[c] = mdl->vis_X[9 + c][k];
+        T Ro[9], po[3], qo[4];
+        mat3_mul(Rl, Rv, Ro);
+        mat3_mulv(Rl, pv, po);
+        matrix_to_quat(Ro, qo);
+        T *o = yo + vbase + 7 * k;
+        o[0] = pl[0] + po[0];
+        o[1] = pl[1] + po[1];
+        o[2] = pl[2] + po[2];
+        o[3] = qo[0];
+        o[4] = qo[1];
+        o[5] = qo[2];
+        o[6] = qo[3];
+      }
+    }
+  }
+  __syncthreads();  // X_world / v in LDS are dead from here on (their space is reused)
+
   // ---- D. bias terms and world-frame inertias (kinematics.hpp:96-132, inertia.hpp:121-130) ---
   T *const IAs = E + L.IA;  // [21][NLp]  I(6) H(9) M(6)
   T *const pAs = E + L.pA;  // [6][NLp]
@@ -510,7 +605,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   T Fc[6];  // CRBA: F_i = Ic_i s_i
 #pragma unroll
   for (int k = 0; k < 6; ++k) U[k] = Fc[k] = T(0);
-  const bool want_crba = mdl->has_plane != 0;
+  const bool want_crba = wave_contacts;
   for (int lev = nlev - 1; lev >= 0; --lev) {
     if (level == lev) {
       T I6[6], H9[9], M6[6], pa[6];
@@ -599,14 +694,14 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   TDS_STAMP(5);
   // ---- F. top-down sweep: accelerations, qdd  (forward_dynamics.hpp:245-302) ----------------
-  //      a overwrites v in LDS (v of every link is already in registers)
+  T *const aas = E + L.a;  // [6][NLp]
   T qdd = T(0);
   for (int lev = 0; lev < nlev; ++lev) {
     if (level == lev) {
       T a[6];
       if (parent >= 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) a[k] = vv[k * NLp + parent];
+        for (int k = 0; k < 6; ++k) a[k] = aas[k * NLp + parent];
       } else {  // base acceleration = -gravity (linear part)
         a[0] = a[1] = a[2] = T(0);
         a[3] = -mdl->grav[0];
@@ -622,7 +717,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         for (int k = 0; k < 6; ++k) a[k] += sw[k] * qdd;
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) vv[k * NLp + li] = a[k];
+      for (int k = 0; k < 6; ++k) aas[k * NLp + li] = a[k];
     }
     __syncthreads();
   }
@@ -630,7 +725,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   T qd_new = qd + qdd * dt;
   T q_new = q;
 
-  if (mdl->has_plane && mdl->num_cp > 0) {
+  if (wave_contacts) {
     if (di >= 0) xr[nq + di] = qd_new;
     TDS_STAMP(6);
     // ---- G. mass-matrix row of dof d, straight into registers (lane == dof == row):
@@ -692,69 +787,22 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     TDS_STAMP(8);
 
-    // ---- I. narrowphase: plane vs sphere points (world.hpp:206-282, contact_point.hpp:96-125),
-    //         compaction of penetrating points in contact order
-    T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, link
-    const int NCPp = L.NCPp;
-    const int ncp = mdl->num_cp;
-    int na = 0;
-    for (int base = 0; base < ncp; base += G) {
-      const int k = base + lane;
-      bool act = false;
-      T Pb[3] = {T(0), T(0), T(0)}, dist = T(0);
-      int lk = -1;
-      if (k < ncp) {
-        lk = mdl->cp_link[k];
-        T Rl[9], pl[3];
-        if (lk >= 0) {
-#pragma unroll
-          for (int c = 0; c < 9; ++c) Rl[c] = Xw[c * NLp + lk];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) pl[c] = Xw[(9 + c) * NLp + lk];
-        } else {
-#pragma unroll
-          for (int c = 0; c < 9; ++c) Rl[c] = mdl->base_R[c];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) pl[c] = mdl->base_t[c];
-        }
-        const T loc[3] = {mdl->cp_local[0][k], mdl->cp_local[1][k], mdl->cp_local[2][k]};
-        T ctr[3];
-        mat3_mulv(Rl, loc, ctr);
-        ctr[0] += pl[0];
-        ctr[1] += pl[1];
-        ctr[2] += pl[2];
-        const T n[3] = {mdl->plane_n[0], mdl->plane_n[1], mdl->plane_n[2]};
-        const T rad = mdl->cp_radius[k];
-        // t = -(dot(p, -n) + c);  distance = t - r;  point_on_b = p - r n
-        const T t = -((-dot3(ctr, n)) + mdl->plane_c);
-        dist = t - rad;
-        Pb[0] = ctr[0] - rad * n[0];
-        Pb[1] = ctr[1] - rad * n[1];
-        Pb[2] = ctr[2] - rad * n[2];
-        act = dist < T(0);  // collision mask, mb_constraint_solver.hpp:285
-      }
-      const unsigned long long bal = __ballot(act);
-      const unsigned long long mine = (G == 64) ? bal : ((bal >> (grp * G)) & ((1ull << (G & 63)) - 1ull));
-      const int pre = __popcll(mine & ((1ull << lane) - 1ull));
-      if (act) {
-        const int slot = na + pre;
-        cpx[0 * NCPp + slot] = Pb[0];
-        cpx[1 * NCPp + slot] = Pb[1];
-        cpx[2 * NCPp + slot] = Pb[2];
-        cpx[3 * NCPp + slot] = dist;
-        cpx[4 * NCPp + slot] = T(lk);
-      }
-      na += __popcll(mine);
-    }
-    __syncthreads();  // Z aliases the sweep arrays (IA, pA, Ic, v, F): all of those are dead now
+    __syncthreads();  // Z aliases the sweep arrays (IA, pA, Ic, a, F): all of those are dead now
     TDS_STAMP(9);
 
     // ---- J. constraint Jacobian rows (jacobian.hpp:13-83, mb_constraint_solver.hpp:278-388)
     //         row a: normal, na+a: tangent 1, 2na+a: tangent 2;  lane == dof
-    T *const Zs = E + L.Z;  // [3na][NDs]: J rows, overwritten in place by z~ = D^-1/2 L^-1 J^T
-    T *const rowb = E + L.rowb;
-    T *const rowai = E + L.rowai;
-    T *const rowx = E + L.rowx;
+    // Rows 0..ZR-1 of an environment live in LDS; an environment with more than ZR/3 penetrating
+    // contacts keeps the surplus rows (and their scalars) in a global scratch slab — rare, slow,
+    // exact.  Sizing LDS for the typical contact count instead of the worst case is what lets four
+    // workgroups share a CU.
+    T *const Zs = E + L.Z;  // [ZR][NDs]: J rows, overwritten in place by z~ = D^-1/2 L^-1 J^T
+    T *const rws = E + L.rows;  // [3][ZR]: b | 1/(G+cfm) | G
+    T *const xs = E + L.xrow;   // [3 ncp]: the impulses x of ALL rows stay in LDS (read back within the wave)
+    const int ZR = L.zrows;
+    const int OVR = L.ovrows;  // surplus rows available per environment in the slab
+    T *const zov = (ovf != nullptr && valid) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
+    T *const rov = zov != nullptr ? zov + (size_t)OVR * NDs : nullptr;  // [3][OVR]
     const int nr = 3 * na;
     const T nb[3] = {mdl->nb[0], mdl->nb[1], mdl->nb[2]};
     const T t1[3] = {mdl->t1[0], mdl->t1[1], mdl->t1[2]};
@@ -777,9 +825,11 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
             col[1] = sd[4] - c[1];
             col[2] = sd[5] - c[2];
           }
-          Zs[a * NDs + d] = dot3(nb, col);
-          Zs[(na + a) * NDs + d] = dot3(t1, col);
-          Zs[(2 * na + a) * NDs + d] = dot3(t2, col);
+          const T jn = dot3(nb, col), j1 = dot3(t1, col), j2 = dot3(t2, col);
+          const int r0 = a, r1 = na + a, r2 = 2 * na + a;
+          if (r0 < ZR) Zs[r0 * NDs + d] = jn; else zov[(r0 - ZR) * NDs + d] = jn;
+          if (r1 < ZR) Zs[r1 * NDs + d] = j1; else zov[(r1 - ZR) * NDs + d] = j1;
+          if (r2 < ZR) Zs[r2 * NDs + d] = j2; else zov[(r2 - ZR) * NDs + d] = j2;
         }
       }
     }
@@ -791,16 +841,22 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     //         A_rs = J_r M^-1 J_s^T = z~_r . z~_s  — one matrix instead of J and M^-1 J^T.
     const T cfm = mdl->cfm, erp_dt = mdl->erp_over_dt, rest = mdl->restitution;
     for (int r = lane; r < nr; r += G) {
-      T *Zr = Zs + r * NDs;
+      const bool in_lds = r < ZR;
+      T *const Zr = in_lds ? nullptr : zov + (size_t)(r - ZR) * NDs;
       T z[NDP];
+      if (in_lds) {
 #pragma unroll
-      for (int k = 0; k < NDP; ++k) z[k] = Zr[k];
+        for (int k = 0; k < NDP; ++k) z[k] = Zs[r * NDs + k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < NDP; ++k) z[k] = Zr[k];
+      }
       T vrow = T(0);
 #pragma unroll
       for (int k = 0; k < NDP; ++k)
         if (k < nd) vrow += z[k] * xr[nq + k];
       // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
-      rowb[r] = r < na ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + r] : vrow;
+      const T brow = r < na ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + r] : vrow;
 #pragma unroll
       for (int k = 1; k < NDP; ++k) {
         const int off = (k * (k - 1)) / 2;
@@ -810,13 +866,24 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       T g = T(0);
 #pragma unroll
       for (int k = 0; k < NDP; ++k) {
-        const T zt = z[k] * dvec[NDP + k];
-        g += zt * zt;
-        Zr[k] = zt;
+        z[k] *= dvec[NDP + k];
+        g += z[k] * z[k];
       }
-      rowai[r] = rcp_full<T>(g + cfm);
-      rowai[nr + r] = g;
-      rowx[r] = T(0);
+      const T ai = rcp_full<T>(g + cfm);
+      if (in_lds) {
+#pragma unroll
+        for (int k = 0; k < NDP; ++k) Zs[r * NDs + k] = z[k];
+        rws[r] = brow;
+        rws[ZR + r] = ai;
+        rws[2 * ZR + r] = g;
+      } else {
+#pragma unroll
+        for (int k = 0; k < NDP; ++k) Zr[k] = z[k];
+        rov[r - ZR] = brow;
+        rov[OVR + r - ZR] = ai;
+        rov[2 * OVR + r - ZR] = g;
+      }
+      xs[r] = T(0);
     }
     __syncthreads();
     TDS_STAMP(11);
@@ -829,26 +896,29 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       T u = T(0);
       const T mu = mdl->friction;
       const int iters = mdl->pgs_iterations;
+      // row scalars / row vector element of row r for this lane, from LDS or the surplus slab
+      auto row_z = [&](int r) -> T { return r < ZR ? Zs[r * NDs + d] : zov[(size_t)(r - ZR) * NDs + d]; };
+      auto row_s = [&](int which, int r) -> T { return r < ZR ? rws[which * ZR + r] : rov[which * OVR + r - ZR]; };
       for (int it = 0; it < iters; ++it) {
         // software pipeline: everything row r+1 needs that does not depend on row r is loaded
         // before row r's cross-lane reduction, so only the reduction + clamp sit on the chain
-        T zn = (nr > 0 && dz) ? Zs[d] : T(0);
-        T bn = nr > 0 ? rowb[0] : T(0), an = nr > 0 ? rowai[0] : T(0), gn = nr > 0 ? rowai[nr] : T(0);
-        T xon = (nr > 0 && it > 0) ? rowx[0] : T(0);
+        T zn = (nr > 0 && dz) ? row_z(0) : T(0);
+        T bn = nr > 0 ? row_s(0, 0) : T(0), an = nr > 0 ? row_s(1, 0) : T(0), gn = nr > 0 ? row_s(2, 0) : T(0);
+        T xon = (nr > 0 && it > 0) ? xs[0] : T(0);
         for (int r = 0; r < nr; ++r) {
           const T zr = zn, br = bn, ar = an, gr = gn, x_old = xon;
           const int rn = r + 1;
           if (rn < nr) {
-            zn = dz ? Zs[rn * NDs + d] : T(0);
-            bn = rowb[rn];
-            an = rowai[rn];
-            gn = rowai[nr + rn];
-            xon = it > 0 ? rowx[rn] : T(0);
+            zn = dz ? row_z(rn) : T(0);
+            bn = row_s(0, rn);
+            an = row_s(1, rn);
+            gn = row_s(2, rn);
+            xon = it > 0 ? xs[rn] : T(0);
           }
           // friction rows scale their box by the normal impulse of the same contact
           // (limit_dependency_, mb_constraint_solver.hpp:417-436); that row is >= na rows back
           T sdep = T(1);
-          if (r >= na) sdep = rowx[r < 2 * na ? r - na : r - 2 * na];
+          if (r >= na) sdep = xs[r < 2 * na ? r - na : r - 2 * na];
           const T jw = group_sum<T, G>(zr * u);
           const T delta = jw - gr * x_old;
           T xn = (br - delta) * ar;
@@ -864,7 +934,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
           xn = xn > lo ? xn : lo;  // Algebra::max(x, lo*s)
           xn = xn < hi ? xn : hi;  // Algebra::min(x, hi*s)
           u += zr * (xn - x_old);
-          if (lane == 0) rowx[r] = xn;
+          if (lane == 0) xs[r] = xn;
         }
       }
       // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
@@ -940,30 +1010,6 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     const int nv = mdl->num_visuals;
     const int vbase = nq + nd;
-    for (int k = lane; k < nv; k += G) {
-      const int lk = mdl->vis_link[k];
-      T Rl[9], pl[3], Rv[9], pv[3];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) Rl[c] = Xw[c * NLp + lk];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) pl[c] = Xw[(9 + c) * NLp + lk];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) pv[c] = mdl->vis_X[9 + c][k];
-      T Ro[9], po[3], qo[4];
-      mat3_mul(Rl, Rv, Ro);
-      mat3_mulv(Rl, pv, po);
-      matrix_to_quat(Ro, qo);
-      T *o = yo + vbase + 7 * k;
-      o[0] = pl[0] + po[0];
-      o[1] = pl[1] + po[1];
-      o[2] = pl[2] + po[2];
-      o[3] = qo[0];
-      o[4] = qo[1];
-      o[5] = qo[2];
-      o[6] = qo[3];
-    }
     int tail = vbase;
     if (mdl->pack_visuals) {
       tail = vbase + 7 * nv;
@@ -983,7 +1029,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 int tds_padded_dof(int nd) { return nd <= 8 ? 8 : (nd <= 16 ? 16 : (nd <= 24 ? 24 : 32)); }
 
 template <typename T>
-TdsLds tds_make_lds_layout(const DevModel<T> &m) {
+TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap) {
   TdsLds L;
   memset(&L, 0, sizeof(L));
   const int nl = m.num_links;
@@ -993,28 +1039,35 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m) {
   L.NDs = ndp + 1;  // odd row stride: lane == row accesses hit distinct LDS banks
   const int ncp = m.has_plane ? m.num_cp : 0;
   L.NCPp = ncp > 0 ? ncp : 1;
-  const int nr = 3 * ncp;
+  if (na_cap <= 0 || na_cap > ncp) na_cap = ncp;
+  L.zrows = 3 * na_cap;            // constraint rows kept in LDS
+  L.ovrows = 3 * ncp - L.zrows;    // surplus rows per environment (global scratch slab)
   int o = 0;
+  // persistent for the whole step
   L.xrec = o; o += m.input_dim;
-  L.Xw = o;   o += 12 * L.NLp;
   L.swd = o;  o += 6 * L.NDs;
+  L.cp = o;   o += ncp ? 5 * L.NCPp : 0;
   L.Lp = o;   o += ncp ? (ndp * (ndp - 1)) / 2 : 0;
   L.dinv = o; o += ncp ? 2 * ndp : 0;
-  L.cp = o;   o += ncp ? 5 * L.NCPp : 0;
-  L.rowb = o; o += nr;
-  L.rowai = o; o += 2 * nr;
-  L.rowx = o; o += nr;
-  // union { sweep arrays } / { Z }
+  L.rows = o; o += 3 * L.zrows;
+  L.xrow = o; o += 3 * ncp;
+  // three phase groups share one region:
+  //   1. kinematics sweep:   X_world[12], v[6]
+  //   2. dynamics sweeps:    IA[21], pA[6] (later F), Ic[10], a[6]
+  //   3. constraint rows:    Z[zrows][NDs]
   const int u = o;
-  int s = u;
-  L.v = s;  s += 6 * L.NLp;
-  L.IA = s; s += 21 * L.NLp;
-  L.pA = s; s += 6 * L.NLp;
-  L.Ic = s; s += 10 * L.NLp;
-  L.F = s;  s += 6 * L.NLp;
-  int j = u;
-  L.Z = j; j += nr * L.NDs;
-  o = s > j ? s : j;
+  int g1 = u;
+  L.Xw = g1; g1 += 12 * L.NLp;
+  L.v = g1;  g1 += 6 * L.NLp;
+  int g2 = u;
+  L.IA = g2; g2 += 21 * L.NLp;
+  L.pA = g2; L.F = g2; g2 += 6 * L.NLp;
+  L.Ic = g2; g2 += 10 * L.NLp;
+  L.a = g2;  g2 += 6 * L.NLp;
+  int g3 = u;
+  L.Z = g3; g3 += L.zrows * L.NDs;
+  o = g1 > g2 ? g1 : g2;
+  o = o > g3 ? o : g3;
   o = (o + 1) & ~1;  // keep 16-byte alignment of every env region for T = double
   L.stride = o;
   return L;
@@ -1022,7 +1075,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m) {
 
 template <typename T>
 int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
-                    const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, int n_envs,
+                    const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
                     hipStream_t stream, long long *prof) {
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
@@ -1032,10 +1085,10 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
   do {                                                                                                       \
     if (prof)                                                                                                \
       hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, true>), dim3(blocks), dim3(64), shmem, stream, d_model, L, \
-                         x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);                           \
+                         x_in, y_out, actions, x_feedback, obs_out, ovf, prof, n_envs);                      \
     else                                                                                                     \
       hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false>), dim3(blocks), dim3(64), shmem, stream, d_model, L, \
-                         x_in, y_out, actions, x_feedback, obs_out, prof, n_envs);                           \
+                         x_in, y_out, actions, x_feedback, obs_out, ovf, prof, n_envs);                      \
   } while (0)
   const int key = lanes_per_env * 100 + L.NDP;
   switch (key) {
@@ -1084,9 +1137,9 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
   return (int)e;
 }
 
-template TdsLds tds_make_lds_layout<double>(const DevModel<double> &);
-template TdsLds tds_make_lds_layout<float>(const DevModel<float> &);
-template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, int, hipStream_t, long long *);
-template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, int, hipStream_t, long long *);
+template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int);
+template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int);
+template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, double *, int, hipStream_t, long long *);
+template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, float *, int, hipStream_t, long long *);
 template int tds_kernel_max_dynamic_lds<double>(int, int, int);
 template int tds_kernel_max_dynamic_lds<float>(int, int, int);

@@ -91,7 +91,7 @@ class HipSim:
     """
 
     def __init__(self, m: _model.Model, num_envs: int, device: int = 0, dtype: str = "f64",
-                 lanes_per_env: int | None = None):
+                 lanes_per_env: int | None = None, na_cap: int | None = None):
         import torch
 
         if not torch.cuda.is_available():
@@ -103,12 +103,16 @@ class HipSim:
         self.torch_dtype = torch.float64 if self.dtype == _model.TDS_DTYPE_F64 else torch.float32
         if lanes_per_env is not None:
             os.environ["TDS_HIP_LANES_PER_ENV"] = str(lanes_per_env)
+        if na_cap is not None:
+            os.environ["TDS_HIP_NA_CAP"] = str(na_cap)
         h = C.c_void_p()
         try:
             _check(lib().tds_hip_create(C.byref(self.model), self.num_envs, self.device, self.dtype, C.byref(h)))
         finally:
             if lanes_per_env is not None:
                 os.environ.pop("TDS_HIP_LANES_PER_ENV", None)
+            if na_cap is not None:
+                os.environ.pop("TDS_HIP_NA_CAP", None)
         self.h = h
         self.input_dim = self.model.input_dim
         self.output_dim = self.model.output_dim
@@ -205,9 +209,9 @@ class HipSim:
         _check(lib().tds_hip_last_kernel_ms(self.h, C.byref(ms)))
         return float(ms.value)
 
-    PHASES = ["A load+PD", "B jcalc", "C kinematics sweep", "D inertias/bias", "E ABA+CRBA sweep",
-              "F accel sweep", "G mass matrix", "H LDLt", "I narrowphase", "J jacobian rows",
-              "K row solves", "L PGS", "M/N pack"]
+    PHASES = ["A load+PD", "B jcalc", "C kinematics sweep", "I narrowphase + visuals + D inertias",
+              "E ABA+CRBA sweep", "F accel sweep", "G mass matrix rows", "H LDLt", "(barrier)",
+              "J jacobian rows", "K row solves", "L PGS", "M/N pack"]
 
     def profile_phases(self):
         """Shader-clock cycles spent by workgroup 0 in each phase of one step (diagnostic)."""
