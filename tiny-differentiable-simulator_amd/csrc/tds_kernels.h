@@ -5,6 +5,9 @@
 #include "tds_device_model.h"
 
 #define TDS_NUM_PHASE_STAMPS 14
+// strides (in scalars, odd) of the per-link LDS records of the two sweep groups
+#define TDS_S1 19  // X_world rot(9) trans(3) | v(6)
+#define TDS_S2 43  // IA(21) | pA or F(6) | Ic(10) | a(6)
 
 // Per-environment LDS layout, offsets in units of the compute scalar T (see tds_make_lds_layout).
 struct TdsLds {

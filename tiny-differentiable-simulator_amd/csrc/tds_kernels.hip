@@ -118,6 +118,22 @@ __device__ __forceinline__ void sincos_t<float>(float a, float *s, float *c) {
   sincosf(a, s, c);
 }
 template <typename T>
+__device__ __forceinline__ T max_t(T a, T b) {
+  return a > b ? a : b;
+}
+template <typename T>
+__device__ __forceinline__ T min_t(T a, T b) {
+  return a < b ? a : b;
+}
+template <>
+__device__ __forceinline__ double max_t<double>(double a, double b) {
+  return fmax(a, b);
+}
+template <>
+__device__ __forceinline__ double min_t<double>(double a, double b) {
+  return fmin(a, b);
+}
+template <typename T>
 __device__ __forceinline__ T sqrt_t(T a);
 template <>
 __device__ __forceinline__ double sqrt_t<double>(double a) {
@@ -131,14 +147,38 @@ __device__ __forceinline__ float sqrt_t<float>(float a) {
 // v + (v moved by a DPP cross-lane pattern inside each row of 16 lanes); VALU latency, no LDS
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  const int l = __double2loint(v), h = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(l, l, CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, 0xF, 0xF, false);
   return v + __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+  const int b = __float_as_int(v);
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, 0xF, 0xF, false));
 }
+// 32 payload bits carried through an LDS slot of the compute scalar (no arithmetic on them)
+template <typename T>
+__device__ __forceinline__ T bits_to_scalar(unsigned b);
+template <>
+__device__ __forceinline__ double bits_to_scalar<double>(unsigned b) {
+  return __hiloint2double(0, (int)b);
+}
+template <>
+__device__ __forceinline__ float bits_to_scalar<float>(unsigned b) {
+  return __int_as_float((int)b);
+}
+template <typename T>
+__device__ __forceinline__ unsigned scalar_to_bits(T v);
+template <>
+__device__ __forceinline__ unsigned scalar_to_bits<double>(double v) {
+  return (unsigned)__double2loint(v);
+}
+template <>
+__device__ __forceinline__ unsigned scalar_to_bits<float>(float v) {
+  return (unsigned)__float_as_int(v);
+}
+
 // sum over the G lanes of an environment; every lane receives the total.  Strides 8,4,2,1 are
 // row rotations (DPP row_ror), wider strides go through the LDS crossbar (ds_bpermute).
 template <typename T, int G>
@@ -157,13 +197,15 @@ __device__ __forceinline__ T group_sum(T v) {
 // (a VALU move, no LDS round trip); wider groups go through ds_bpermute.
 template <int SRC>
 __device__ __forceinline__ double dpp_bcast(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + SRC, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + SRC, 0xF, 0xF, false);
+  const int l = __double2loint(v), h = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(l, l, 0x150 + SRC, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(h, h, 0x150 + SRC, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 template <int SRC>
 __device__ __forceinline__ float dpp_bcast(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + SRC, 0xF, 0xF, false));
+  const int b = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x150 + SRC, 0xF, 0xF, false));
 }
 template <typename T, int G, int NDP, int SRC>
 __device__ __forceinline__ T lane_bcast(T v) {
@@ -229,7 +271,10 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
 #define TDS_STAMP(k)                                                        \
   do {                                                                      \
     if (PROF) {                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                    \
+      __builtin_amdgcn_s_waitcnt(0);                                        \
       if (blockIdx.x == 0 && threadIdx.x == 0) prof[k] = (long long)__builtin_amdgcn_s_memtime(); \
+      __builtin_amdgcn_sched_barrier(0);                                    \
     }                                                                       \
   } while (0)
 
@@ -249,7 +294,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   const int nl = mdl->num_links, nq = mdl->dof_q, nd = mdl->dof_qd;
   const int in_dim = mdl->input_dim, out_dim = mdl->output_dim, adim = mdl->action_dim;
-  const int NLp = L.NLp, NDs = L.NDs;
+  constexpr int NDs = NDP + 1;  // odd row stride of every [row][dof] array
   const T dt = mdl->dt;
 
   TDS_STAMP(0);
@@ -299,6 +344,14 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   T Sl[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) Sl[k] = isl ? mdl->S[k][lsafe] : T(0);
+  // rigid-body inertia constants are fetched here, long before phase D needs them, so that the
+  // L2 latency of the model table hides behind the kinematics sweep
+  const T mass_l = isl ? mdl->mass[lsafe] : T(0);
+  T com_l[3], Il[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) com_l[k] = isl ? mdl->com[k][lsafe] : T(0);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Il[k] = isl ? mdl->inertia[k][lsafe] : T(0);
   T Rp[9], tp[3];
   {
     T RT[9], tT[3];
@@ -349,9 +402,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   TDS_STAMP(2);
   // ---- C. top-down sweep: X_world, world motion axis s, velocity v  (kinematics.hpp:64-97) ---
-  T *const Xw = E + L.Xw;    // [12][NLp]
+  T *const Xw = E + L.Xw;    // link-major records [link][TDS_S1]: X_world rot(9) trans(3) | v(6)
   T *const swd = E + L.swd;  // [6][NDs]   per dof
-  T *const vv = E + L.v;     // [6][NLp]   v, later a
+  T *const vv = E + L.v;     // (= Xw + 12)
   T R[9], p[3], sw[6], vJ[6], v[6];
 #pragma unroll
   for (int k = 0; k < 9; ++k) R[k] = T(0);
@@ -365,11 +418,11 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       T Rq[9], pq[3], vq[6];
       if (parent >= 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rq[k] = Xw[k * NLp + parent];
+        for (int k = 0; k < 9; ++k) Rq[k] = Xw[parent * TDS_S1 + k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pq[k] = Xw[(9 + k) * NLp + parent];
+        for (int k = 0; k < 3; ++k) pq[k] = Xw[parent * TDS_S1 + 9 + k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) vq[k] = vv[k * NLp + parent];
+        for (int k = 0; k < 6; ++k) vq[k] = vv[parent * TDS_S1 + k];
       } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rq[k] = mdl->base_R[k];
@@ -398,11 +451,11 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         v[k] = vq[k] + vJ[k];
       }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Xw[k * NLp + li] = R[k];
+      for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) Xw[(9 + k) * NLp + li] = p[k];
+      for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) vv[k * NLp + li] = v[k];
+      for (int k = 0; k < 6; ++k) vv[li * TDS_S1 + k] = v[k];
       if (di >= 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) swd[k * NDs + di] = sw[k];
@@ -414,7 +467,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   TDS_STAMP(3);
   // ---- I. narrowphase right after the kinematics sweep (it only needs X_world), so that the
   //         LDS holding X_world / v can be recycled by the dynamics sweeps
-  T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, link
+  T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, ancestor-dof mask (bit pattern)
   const int NCPp = L.NCPp;
   int na = 0;
   if (mdl->has_plane) {
@@ -429,9 +482,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         T Rl[9], pl[3];
         if (lk >= 0) {
 #pragma unroll
-          for (int c = 0; c < 9; ++c) Rl[c] = Xw[c * NLp + lk];
+          for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) pl[c] = Xw[(9 + c) * NLp + lk];
+          for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
         } else {
 #pragma unroll
           for (int c = 0; c < 9; ++c) Rl[c] = mdl->base_R[c];
@@ -463,7 +516,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         cpx[1 * NCPp + slot] = Pb[1];
         cpx[2 * NCPp + slot] = Pb[2];
         cpx[3 * NCPp + slot] = dist;
-        cpx[4 * NCPp + slot] = T(lk);
+        cpx[4 * NCPp + slot] = bits_to_scalar<T>(lk >= 0 ? mdl->anc_dofs[lk] : 0u);
       }
       na += __popcll(mine);
     }
@@ -483,9 +536,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         const int lk = mdl->vis_link[k];
         T Rl[9], pl[3], Rv[9], pv[3];
   #pragma unroll
-        for (int c = 0; c < 9; ++c) Rl[c] = Xw[c * NLp + lk];
+        for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
   #pragma unroll
-        for (int c = 0; c < 3; ++c) pl[c] = Xw[(9 + c) * NLp + lk];
+        for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
   #pragma unroll
         for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
   #pragma unroll
@@ -508,9 +561,12 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   __syncthreads();  // X_world / v in LDS are dead from here on (their space is reused)
 
   // ---- D. bias terms and world-frame inertias (kinematics.hpp:96-132, inertia.hpp:121-130) ---
-  T *const IAs = E + L.IA;  // [21][NLp]  I(6) H(9) M(6)
-  T *const pAs = E + L.pA;  // [6][NLp]
-  T *const Ics = E + L.Ic;  // [10][NLp]  I(6) h(3) m
+  // link-major records [link][TDS_S2]: IA I(6) H(9) M(6) | pA(6) (later F) | Ic I(6) h(3) m | a(6).
+  // The sweeps touch one or a few links per level, so a record per link gives one base address per
+  // lane and immediate offsets for every component (no per-access address arithmetic).
+  T *const IAs = E + L.IA;
+  T *const pAs = E + L.pA;
+  T *const Ics = E + L.Ic;
   T cb[6];                  // c = v x vJ
   {
     cross3(v, vJ, cb);
@@ -522,14 +578,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     cb[5] = c1[2] + c2[2];
   }
   if (isl) {
-    const T m = mdl->mass[lsafe];
-    T com[3], Il[9];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) com[k] = mdl->com[k][lsafe];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Il[k] = mdl->inertia[k][lsafe];
+    const T m = mass_l;
     T cw[3];
-    mat3_mulv(R, com, cw);
+    mat3_mulv(R, com_l, cw);
     cw[0] += p[0];
     cw[1] += p[1];
     cw[2] += p[2];
@@ -570,31 +621,31 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     cross3(v, Iv + 3, pa0 + 3);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      IAs[k * NLp + li] = Is[k];
-      Ics[k * NLp + li] = Is[k];
-      pAs[k * NLp + li] = pa0[k];
+      IAs[li * TDS_S2 + k] = Is[k];
+      Ics[li * TDS_S2 + k] = Is[k];
+      pAs[li * TDS_S2 + k] = pa0[k];
     }
     // H = [h]x
-    IAs[6 * NLp + li] = T(0);
-    IAs[7 * NLp + li] = -h[2];
-    IAs[8 * NLp + li] = h[1];
-    IAs[9 * NLp + li] = h[2];
-    IAs[10 * NLp + li] = T(0);
-    IAs[11 * NLp + li] = -h[0];
-    IAs[12 * NLp + li] = -h[1];
-    IAs[13 * NLp + li] = h[0];
-    IAs[14 * NLp + li] = T(0);
+    IAs[li * TDS_S2 + 6] = T(0);
+    IAs[li * TDS_S2 + 7] = -h[2];
+    IAs[li * TDS_S2 + 8] = h[1];
+    IAs[li * TDS_S2 + 9] = h[2];
+    IAs[li * TDS_S2 + 10] = T(0);
+    IAs[li * TDS_S2 + 11] = -h[0];
+    IAs[li * TDS_S2 + 12] = -h[1];
+    IAs[li * TDS_S2 + 13] = h[0];
+    IAs[li * TDS_S2 + 14] = T(0);
     // M = m 1
-    IAs[15 * NLp + li] = m;
-    IAs[16 * NLp + li] = T(0);
-    IAs[17 * NLp + li] = T(0);
-    IAs[18 * NLp + li] = m;
-    IAs[19 * NLp + li] = T(0);
-    IAs[20 * NLp + li] = m;
-    Ics[6 * NLp + li] = h[0];
-    Ics[7 * NLp + li] = h[1];
-    Ics[8 * NLp + li] = h[2];
-    Ics[9 * NLp + li] = m;
+    IAs[li * TDS_S2 + 15] = m;
+    IAs[li * TDS_S2 + 16] = T(0);
+    IAs[li * TDS_S2 + 17] = T(0);
+    IAs[li * TDS_S2 + 18] = m;
+    IAs[li * TDS_S2 + 19] = T(0);
+    IAs[li * TDS_S2 + 20] = m;
+    Ics[li * TDS_S2 + 6] = h[0];
+    Ics[li * TDS_S2 + 7] = h[1];
+    Ics[li * TDS_S2 + 8] = h[2];
+    Ics[li * TDS_S2 + 9] = m;
   }
   __syncthreads();
 
@@ -610,13 +661,13 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     if (level == lev) {
       T I6[6], H9[9], M6[6], pa[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) I6[k] = IAs[k * NLp + li];
+      for (int k = 0; k < 6; ++k) I6[k] = IAs[li * TDS_S2 + k];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) H9[k] = IAs[(6 + k) * NLp + li];
+      for (int k = 0; k < 9; ++k) H9[k] = IAs[li * TDS_S2 + 6 + k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) M6[k] = IAs[(15 + k) * NLp + li];
+      for (int k = 0; k < 6; ++k) M6[k] = IAs[li * TDS_S2 + 15 + k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pa[k] = pAs[k * NLp + li];
+      for (int k = 0; k < 6; ++k) pa[k] = pAs[li * TDS_S2 + k];
       // U = IA s
       T t3[3];
       sym3_mulv(I6, sw, U);
@@ -661,21 +712,21 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       for (int k = 0; k < 6; ++k) pa[k] += Iac[k] + U[k] * ud;
       if (parent >= 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[k * NLp + parent], I6[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[parent * TDS_S2 + k], I6[k]);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&IAs[(6 + k) * NLp + parent], H9[k]);
+        for (int k = 0; k < 9; ++k) atomicAdd(&IAs[parent * TDS_S2 + 6 + k], H9[k]);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[(15 + k) * NLp + parent], M6[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[parent * TDS_S2 + 15 + k], M6[k]);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&pAs[k * NLp + parent], pa[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(&pAs[parent * TDS_S2 + k], pa[k]);
       }
       if (want_crba) {
         T Ic[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) Ic[k] = Ics[k * NLp + li];
+        for (int k = 0; k < 10; ++k) Ic[k] = Ics[li * TDS_S2 + k];
         if (parent >= 0) {
 #pragma unroll
-          for (int k = 0; k < 10; ++k) atomicAdd(&Ics[k * NLp + parent], Ic[k]);
+          for (int k = 0; k < 10; ++k) atomicAdd(&Ics[parent * TDS_S2 + k], Ic[k]);
         }
         // F = Ic s = (I w + h x v, m v - h x w)
         sym3_mulv(Ic, sw, Fc);
@@ -694,14 +745,14 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   TDS_STAMP(5);
   // ---- F. top-down sweep: accelerations, qdd  (forward_dynamics.hpp:245-302) ----------------
-  T *const aas = E + L.a;  // [6][NLp]
+  T *const aas = E + L.a;
   T qdd = T(0);
   for (int lev = 0; lev < nlev; ++lev) {
     if (level == lev) {
       T a[6];
       if (parent >= 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) a[k] = aas[k * NLp + parent];
+        for (int k = 0; k < 6; ++k) a[k] = aas[parent * TDS_S2 + k];
       } else {  // base acceleration = -gravity (linear part)
         a[0] = a[1] = a[2] = T(0);
         a[3] = -mdl->grav[0];
@@ -717,7 +768,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         for (int k = 0; k < 6; ++k) a[k] += sw[k] * qdd;
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) aas[k * NLp + li] = a[k];
+      for (int k = 0; k < 6; ++k) aas[li * TDS_S2 + k] = a[k];
     }
     __syncthreads();
   }
@@ -730,12 +781,12 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     TDS_STAMP(6);
     // ---- G. mass-matrix row of dof d, straight into registers (lane == dof == row):
     //         M[d][j] = F_d . s_j for j on the path base -> d   (mass_matrix.hpp:87-109)
-    T *const Fs = E + L.F;      // [6][NLp]
+    T *const Fs = E + L.F;      // (= pA slot of the link records)
     T *const Lp = E + L.Lp;     // strictly-lower L packed row-major: L[r][j] at r(r-1)/2 + j
     T *const dvec = E + L.dinv; // [2][NDP]: 1/D_k | sqrt(1/D_k)
     if (isl) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Fs[k * NLp + li] = Fc[k];
+      for (int k = 0; k < 6; ++k) Fs[li * TDS_S2 + k] = Fc[k];
     }
     __syncthreads();
     T Mr[NDP];
@@ -746,7 +797,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       const unsigned anc = isd ? mdl->anc_dofs[lk] : 0u;
       T Fd[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Fd[k] = isd ? Fs[k * NLp + lk] : T(0);
+      for (int k = 0; k < 6; ++k) Fd[k] = isd ? Fs[lk * TDS_S2 + k] : T(0);
 #pragma unroll
       for (int j = 0; j < NDP; ++j) {
         T s = T(0);
@@ -814,8 +865,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       for (int k = 0; k < 6; ++k) sd[k] = d < nd ? swd[k * NDs + d] : T(0);
       for (int a = 0; a < na; ++a) {
         const T P[3] = {cpx[0 * NCPp + a], cpx[1 * NCPp + a], cpx[2 * NCPp + a]};
-        const int lk = (int)cpx[4 * NCPp + a];
-        const unsigned msk = lk >= 0 ? mdl->anc_dofs[lk] : 0u;
+        const unsigned msk = scalar_to_bits<T>(cpx[4 * NCPp + a]);
         if (d < NDP) {
           T col[3] = {T(0), T(0), T(0)};
           if (d < nd && ((msk >> d) & 1u)) {  // xs.bottom = st.bottom - point x st.top
@@ -857,11 +907,11 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         if (k < nd) vrow += z[k] * xr[nq + k];
       // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
       const T brow = r < na ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + r] : vrow;
+      // column-oriented: once z[j] is final, every later z[k] takes its update independently
 #pragma unroll
-      for (int k = 1; k < NDP; ++k) {
-        const int off = (k * (k - 1)) / 2;
+      for (int j = 0; j < NDP - 1; ++j) {
 #pragma unroll
-        for (int j = 0; j < k; ++j) z[k] -= Lp[off + j] * z[j];
+        for (int k = j + 1; k < NDP; ++k) z[k] -= Lp[(k * (k - 1)) / 2 + j] * z[j];
       }
       T g = T(0);
 #pragma unroll
@@ -917,22 +967,17 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
           }
           // friction rows scale their box by the normal impulse of the same contact
           // (limit_dependency_, mb_constraint_solver.hpp:417-436); that row is >= na rows back
-          T sdep = T(1);
-          if (r >= na) sdep = xs[r < 2 * na ? r - na : r - 2 * na];
+          const bool is_n = r < na;
+          const int dep = r - (r >= na ? na : 0) - (r >= 2 * na ? na : 0);
+          const T sdep = xs[dep];
           const T jw = group_sum<T, G>(zr * u);
           const T delta = jw - gr * x_old;
           T xn = (br - delta) * ar;
-          T lo, hi;
-          if (r < na) {
-            lo = T(0);
-            hi = T(100000);
-          } else {
-            const T sc = sdep < T(0) ? T(0) : sdep;
-            lo = -mu * sc;
-            hi = mu * sc;
-          }
-          xn = xn > lo ? xn : lo;  // Algebra::max(x, lo*s)
-          xn = xn < hi ? xn : hi;  // Algebra::min(x, hi*s)
+          const T sc = sdep < T(0) ? T(0) : sdep;  // where_lt(s, 0, 0, s)
+          const T lo = is_n ? T(0) : -mu * sc;
+          const T hi = is_n ? T(100000) : mu * sc;
+          xn = max_t<T>(xn, lo);  // Algebra::max(x, lo*s)
+          xn = min_t<T>(xn, hi);  // Algebra::min(x, hi*s)
           u += zr * (xn - x_old);
           if (lane == 0) xs[r] = xn;
         }
@@ -1052,18 +1097,14 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap) {
   L.rows = o; o += 3 * L.zrows;
   L.xrow = o; o += 3 * ncp;
   // three phase groups share one region:
-  //   1. kinematics sweep:   X_world[12], v[6]
-  //   2. dynamics sweeps:    IA[21], pA[6] (later F), Ic[10], a[6]
+  //   1. kinematics sweep:   per-link records [X_world(12) | v(6)]              stride TDS_S1
+  //   2. dynamics sweeps:    per-link records [IA(21) | pA/F(6) | Ic(10) | a(6)] stride TDS_S2
   //   3. constraint rows:    Z[zrows][NDs]
   const int u = o;
   int g1 = u;
-  L.Xw = g1; g1 += 12 * L.NLp;
-  L.v = g1;  g1 += 6 * L.NLp;
+  L.Xw = g1; L.v = g1 + 12; g1 += TDS_S1 * L.NLp;
   int g2 = u;
-  L.IA = g2; g2 += 21 * L.NLp;
-  L.pA = g2; L.F = g2; g2 += 6 * L.NLp;
-  L.Ic = g2; g2 += 10 * L.NLp;
-  L.a = g2;  g2 += 6 * L.NLp;
+  L.IA = g2; L.pA = g2 + 21; L.F = g2 + 21; L.Ic = g2 + 27; L.a = g2 + 37; g2 += TDS_S2 * L.NLp;
   int g3 = u;
   L.Z = g3; g3 += L.zrows * L.NDs;
   o = g1 > g2 ? g1 : g2;
