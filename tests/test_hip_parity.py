@@ -18,7 +18,11 @@ TOL = 1e-6
 
 
 def lanes_options(m):
-    return [g for g in (16, 32, 64) if g >= m.num_links]
+    """lane-group widths the library instantiates for this model (G >= links, G >= padded dof;
+    G = 64 only for <= 16 dof)"""
+    ndp = 8 if m.dof_qd <= 8 else 16 if m.dof_qd <= 16 else 24 if m.dof_qd <= 24 else 32
+    need = max(m.num_links, ndp)
+    return [g for g in (16, 32, 64) if g >= need and (g < 64 or ndp <= 16)]
 
 
 def _torch():
@@ -34,6 +38,7 @@ def test_golden_single_steps(name, built):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     for lanes in lanes_options(m):
         sim = hip_backend.HipSim(m, g["x"].shape[0], dtype="f64", lanes_per_env=lanes)
+        assert sim.kernel_info()["lanes_per_env"] == lanes
         y = sim.forward_zero(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
         err = rel_err(y, g["y"])
         print(f"{name} G={lanes}: max rel err vs reference golden {err:.3e}")
@@ -189,3 +194,51 @@ def test_constraint_row_overflow_slab(na_cap, built):
     err = rel_err(y, y_ref)
     print(f"na_cap={na_cap}: lds/env {sim.kernel_info()['lds_bytes_per_env']} B, max rel err {err:.3e}")
     assert err < TOL
+
+
+def _chain_model(n_links, with_plane=True):
+    """synthetic serial chain (pendulum5's link repeated) to exercise the wide (NDP = 24 / 32)
+    kernel instantiations that no reference model reaches"""
+    m = tds_amd.load_model("pendulum5_plane" if with_plane else "pendulum5")
+    src_link = m.links[1]
+    src_geom = m.geoms[1]
+    src_vis = m.visuals[1]
+    import ctypes as C
+    for i in range(5, n_links):
+        C.memmove(C.byref(m.links[i]), C.byref(src_link), C.sizeof(src_link))
+        m.links[i].parent = i - 1
+        m.links[i].q_index = i
+        m.links[i].qd_index = i
+        m.links[i].joint_type = tds_amd.model.JOINT_REVOLUTE_X if i % 2 else tds_amd.model.JOINT_REVOLUTE_Y
+        m.links[i].S[0] = 1.0 if i % 2 else 0.0
+        m.links[i].S[1] = 0.0 if i % 2 else 1.0
+        C.memmove(C.byref(m.geoms[i]), C.byref(src_geom), C.sizeof(src_geom))
+        m.geoms[i].link = i
+        C.memmove(C.byref(m.visuals[i]), C.byref(src_vis), C.sizeof(src_vis))
+        m.visuals[i].link = i
+    m.num_links = m.dof_q = m.dof_qd = m.action_dim = n_links
+    m.num_geoms = m.num_visuals = n_links
+    m.input_dim = 3 * n_links
+    m.output_dim = 2 * n_links + 7 * n_links + 1
+    return m
+
+
+@pytest.mark.parametrize("n_links", [12, 20, 28])
+def test_synthetic_chain_wide_systems(n_links, built):
+    torch = _torch()
+    m = _chain_model(n_links)
+    rng = np.random.default_rng(n_links)
+    n = 40
+    x = np.zeros((n, m.input_dim))
+    x[:, :n_links] = rng.uniform(-0.12, 0.12, (n, n_links))
+    x[:, n_links:2 * n_links] = rng.uniform(-0.5, 0.5, (n, n_links))
+    x[:, 2 * n_links:] = rng.uniform(-0.2, 0.2, (n, n_links))
+    y_ref = oraclelib.step(m, x)
+    nact = [int((oraclelib.step_debug(m, x[i])["contacts"][:, 9] < 0).sum()) for i in range(4)]
+    for lanes in lanes_options(m):
+        sim = hip_backend.HipSim(m, n, dtype="f64", lanes_per_env=lanes)
+        assert sim.kernel_info()["lanes_per_env"] == lanes
+        y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+        err = rel_err(y, y_ref)
+        print(f"chain{n_links} G={lanes}: active contacts {nact}, max rel err vs oracle {err:.3e}")
+        assert err < TOL

@@ -42,7 +42,10 @@ int default_lanes_per_env(int num_links, int dof) {
   const int need = num_links > tds_padded_dof(dof) ? num_links : tds_padded_dof(dof);
   const char *env = getenv("TDS_HIP_LANES_PER_ENV");
   int g = env ? atoi(env) : 0;
-  if (g == 16 || g == 32 || g == 64) {
+  // 64 lanes per environment is only instantiated for systems of <= 16 dof: the <G=64, NDP>=24>
+  // build was miscompiled by hipcc 7.2 under its register pressure (caught by the golden tests),
+  // and it is never the fast choice anyway.
+  if (g == 16 || g == 32 || (g == 64 && tds_padded_dof(dof) <= 16)) {
     if (g >= need) return g;
   }
   return need <= 16 ? 16 : (need <= 32 ? 32 : 64);

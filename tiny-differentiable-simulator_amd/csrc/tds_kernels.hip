@@ -267,6 +267,21 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
 // ------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------
+// A workgroup is exactly ONE wavefront, and the LDS executes the DS instructions of a wavefront in
+// issue order, so cross-lane hand-offs through LDS need no s_barrier and no s_waitcnt drain:
+// all that is required is that the compiler keeps the program order of the LDS accesses.  A real
+// __syncthreads() would also wait for every outstanding GLOBAL store (the early y writes), which
+// single-wave-per-SIMD occupancy cannot hide.
+#ifdef TDS_FULL_BARRIER
+#define TDS_WAVE_SYNC() __syncthreads()
+#else
+#define TDS_WAVE_SYNC()                                        \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+  } while (0)
+#endif
+
 // TDS_STAMP: phase-boundary timestamps (shader clock) of workgroup 0, PROF builds only
 #define TDS_STAMP(k)                                                        \
   do {                                                                      \
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   for (int i = lane; i < in_dim; i += G) xr[i] = valid ? x_in[(size_t)env * in_dim + i] : T(0);
   if (actions != nullptr && valid)
     for (int i = lane; i < adim; i += G) xr[nq + nd + i] = actions[(size_t)env * adim + i];
-  __syncthreads();
+  TDS_WAVE_SYNC();
 
   // ---- lane == link: constants -------------------------------------------------------------
   const int li = lane;
@@ -461,7 +476,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         for (int k = 0; k < 6; ++k) swd[k * NDs + di] = sw[k];
       }
     }
-    __syncthreads();
+    TDS_WAVE_SYNC();
   }
 
   TDS_STAMP(3);
@@ -558,7 +573,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       }
     }
   }
-  __syncthreads();  // X_world / v in LDS are dead from here on (their space is reused)
+  TDS_WAVE_SYNC();  // X_world / v in LDS are dead from here on (their space is reused)
 
   // ---- D. bias terms and world-frame inertias (kinematics.hpp:96-132, inertia.hpp:121-130) ---
   // link-major records [link][TDS_S2]: IA I(6) H(9) M(6) | pA(6) (later F) | Ic I(6) h(3) m | a(6).
@@ -647,7 +662,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     Ics[li * TDS_S2 + 8] = h[2];
     Ics[li * TDS_S2 + 9] = m;
   }
-  __syncthreads();
+  TDS_WAVE_SYNC();
 
   TDS_STAMP(4);
   // ---- E. bottom-up sweep: ABA articulated inertia / bias, CRBA composite inertia -----------
@@ -740,7 +755,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         Fc[5] = Ic[9] * sw[5] - t3[2];
       }
     }
-    __syncthreads();
+    TDS_WAVE_SYNC();
   }
 
   TDS_STAMP(5);
@@ -770,7 +785,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
       for (int k = 0; k < 6; ++k) aas[li * TDS_S2 + k] = a[k];
     }
-    __syncthreads();
+    TDS_WAVE_SYNC();
   }
   // integrate_euler_qdd: qd += qdd dt  (integrator.hpp:169-181)
   T qd_new = qd + qdd * dt;
@@ -783,12 +798,12 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     //         M[d][j] = F_d . s_j for j on the path base -> d   (mass_matrix.hpp:87-109)
     T *const Fs = E + L.F;      // (= pA slot of the link records)
     T *const Lp = E + L.Lp;     // strictly-lower L packed row-major: L[r][j] at r(r-1)/2 + j
-    T *const dvec = E + L.dinv; // [2][NDP]: 1/D_k | sqrt(1/D_k)
+    T *const dvec = E + L.dinv; // [3][NDP]: 1/D_k | sqrt(1/D_k) | column scratch (NDP > 16)
     if (isl) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) Fs[li * TDS_S2 + k] = Fc[k];
     }
-    __syncthreads();
+    TDS_WAVE_SYNC();
     T Mr[NDP];
     {
       const int d = lane;
@@ -807,6 +822,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         }
         s = ((anc >> j) & 1u) ? s : T(0);
         Mr[j] = (!isd && j == d) ? T(1) : s;  // padding rows: identity
+        // bound the scheduler's load hoisting: 6 NDP LDS loads in flight at once was the register
+        // peak of the whole kernel
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
     TDS_STAMP(7);
@@ -816,19 +834,42 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     //         Entries above the diagonal of a lane's row are never read by anyone.
     static_for<0, NDP>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      const T dk = lane_bcast<T, G, NDP, k>(Mr[k]);
-      const T inv = rcp_full<T>(dk);
-      const T lr = Mr[k] * inv;
-      static_for<k + 1, NDP>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        const T mck = lane_bcast<T, G, NDP, c>(Mr[k]);
-        Mr[c] -= lr * mck;
-      });
-      if (lane == k) {
-        dvec[k] = inv;
-        dvec[NDP + k] = sqrt_t<T>(inv);
+      if constexpr (NDP <= 16) {
+        // column k lives in one 16-lane DPP row: gather it with row_newbcast moves (VALU latency)
+        const T dk = lane_bcast<T, G, NDP, k>(Mr[k]);
+        const T inv = rcp_full<T>(dk);
+        const T lr = Mr[k] * inv;
+        static_for<k + 1, NDP>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          const T mck = lane_bcast<T, G, NDP, c>(Mr[k]);
+          Mr[c] -= lr * mck;
+        });
+        if (lane == k) {
+          dvec[k] = inv;
+          dvec[NDP + k] = sqrt_t<T>(inv);
+        }
+        Mr[k] = lane > k ? lr : Mr[k];
+      } else {
+        // wider systems: every lane publishes its column-k entry once, all lanes read the column
+        // back as LDS broadcasts (immediate offsets; ds_bpermute needed one address VGPR per source
+        // lane and drove the NDP=24 kernels into 140 AGPR + SGPR spills)
+        T *const colb = dvec + 2 * NDP;
+        if (lane < NDP) colb[lane] = Mr[k];
+        TDS_WAVE_SYNC();
+        const T dk = colb[k];
+        const T inv = rcp_full<T>(dk);
+        const T lr = Mr[k] * inv;
+        static_for<k + 1, NDP>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          Mr[c] -= lr * colb[c];
+        });
+        if (lane == k) {
+          dvec[k] = inv;
+          dvec[NDP + k] = sqrt_t<T>(inv);
+        }
+        Mr[k] = lane > k ? lr : Mr[k];
+        TDS_WAVE_SYNC();
       }
-      Mr[k] = lane > k ? lr : Mr[k];
     });
     if (lane < NDP) {
       const int off = (lane * (lane - 1)) / 2;
@@ -838,7 +879,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     TDS_STAMP(8);
 
-    __syncthreads();  // Z aliases the sweep arrays (IA, pA, Ic, a, F): all of those are dead now
+    TDS_WAVE_SYNC();  // Z aliases the sweep arrays (IA, pA, Ic, a, F): all of those are dead now
     TDS_STAMP(9);
 
     // ---- J. constraint Jacobian rows (jacobian.hpp:13-83, mb_constraint_solver.hpp:278-388)
@@ -883,7 +924,11 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         }
       }
     }
-    __syncthreads();
+    TDS_WAVE_SYNC();
+    // surplus rows went through global memory: drain the stores before other lanes load them.
+    // (a fence, NOT __syncthreads(): hipcc 7.2 miscompiled the <f64,G=64,NDP=24> kernel when an
+    //  s_barrier sat in this conditional block — caught by tests/test_hip_parity.py)
+    if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     TDS_STAMP(10);
 
     // ---- K. per row (lane == row): b_r, forward substitution  L z = J_r^T  in registers,
@@ -912,6 +957,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       for (int j = 0; j < NDP - 1; ++j) {
 #pragma unroll
         for (int k = j + 1; k < NDP; ++k) z[k] -= Lp[(k * (k - 1)) / 2 + j] * z[j];
+        if constexpr (NDP > 16) {
+          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
       }
       T g = T(0);
 #pragma unroll
@@ -935,7 +983,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       }
       xs[r] = T(0);
     }
-    __syncthreads();
+    TDS_WAVE_SYNC();
+    if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     TDS_STAMP(11);
 
     // ---- L. projected Gauss-Seidel (mb_constraint_solver.hpp:101-142) on u~ = sum_r z~_r x_r:
@@ -991,7 +1040,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       });
       if (d < nd) xr[nq + d] -= w;
     }
-    __syncthreads();
+    TDS_WAVE_SYNC();
     if (di >= 0) qd_new = xr[nq + di];
   }
 
@@ -1003,10 +1052,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   //         (ars_vectorized_environment.h:250-289; ant_environment2.h:75-106;
   //          laikago_environment2.h:130-171)
   if (obs_out != nullptr) {
-    __syncthreads();
+    TDS_WAVE_SYNC();
     if (di == 0) xr[nq + nd] = q;  // x_{t-1}; the action slots are dead by now
     if (di >= 0) xr[di] = q_new;
-    __syncthreads();
+    TDS_WAVE_SYNC();
     if (valid) {
       T *const ob = obs_out + (size_t)env * (nq + nd + 2);
       if (di >= 0) {
@@ -1093,7 +1142,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap) {
   L.swd = o;  o += 6 * L.NDs;
   L.cp = o;   o += ncp ? 5 * L.NCPp : 0;
   L.Lp = o;   o += ncp ? (ndp * (ndp - 1)) / 2 : 0;
-  L.dinv = o; o += ncp ? 2 * ndp : 0;
+  L.dinv = o; o += ncp ? 3 * ndp : 0;  // 1/D | sqrt(1/D) | column scratch of the wide LDL^T
   L.rows = o; o += 3 * L.zrows;
   L.xrow = o; o += 3 * ncp;
   // three phase groups share one region:
@@ -1141,8 +1190,6 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
     case 3232: TDS_LAUNCH(32, 32); break;
     case 6408: TDS_LAUNCH(64, 8); break;
     case 6416: TDS_LAUNCH(64, 16); break;
-    case 6424: TDS_LAUNCH(64, 24); break;
-    case 6432: TDS_LAUNCH(64, 32); break;
     default:
       return -1;
   }
@@ -1170,8 +1217,6 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
     case 3232: TDS_ATTR(32, 32); break;
     case 6408: TDS_ATTR(64, 8); break;
     case 6416: TDS_ATTR(64, 16); break;
-    case 6424: TDS_ATTR(64, 24); break;
-    case 6432: TDS_ATTR(64, 32); break;
     default: return -1;
   }
 #undef TDS_ATTR

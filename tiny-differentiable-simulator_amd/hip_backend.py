@@ -13,7 +13,7 @@ import os
 from . import model as _model
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtds_hip.so")
+LIB_PATH = os.environ.get("TDS_HIP_LIB", os.path.join(_HERE, "libtds_hip.so"))
 
 TDS_OK = 0
 
