@@ -104,12 +104,26 @@ def main():
     import torch
     import torch.distributed as dist
 
-    import tds_amd
-    from tds_amd import hip_backend
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # the native library normally travels prebuilt with the tree; if it is missing, local rank 0
+    # builds it (hipcc, ~1 min) while the other ranks wait for the file to appear
+    lib_path = os.path.join(ROOT, "tiny-differentiable-simulator_amd", "libtds_hip.so")
+    if not os.path.exists(lib_path):
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(lib_path) and time.time() - t_wait < 900:
+                time.sleep(2.0)
+            time.sleep(5.0)
+
+    import tds_amd
+    from tds_amd import hip_backend
+
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
