@@ -265,6 +265,132 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
 }
 
 // ------------------------------------------------------------------------------------------
+// constraint-row helpers.  SLAB = false: every row of the wavefront's environments fits the LDS
+// row store (the common case) and the code touches LDS only.  SLAB = true: rows >= ZR live in the
+// global scratch slab; those accesses go through volatile pointers so that hipcc can never fold
+// "LDS row or slab row" into one FLAT access through a selected pointer (that cost 3x on PGS).
+// ------------------------------------------------------------------------------------------
+// per row (lane == row): b_r, forward substitution L z = J_r^T in registers, G_rr = z.D^-1.z,
+// 1/(G_rr + cfm); the row is stored back as z~ = D^-1/2 z so that A_rs = J_r M^-1 J_s^T = z~_r.z~_s
+template <bool SLAB, typename T, int G, int NDP>
+__device__ __forceinline__ void tds_row_solve(int lane, int nr, int na, int nd, int ZR, int OVR, int NCPp,
+                                              T *Zs, T *rws, T *xs, const T *qdv, const T *cpx, const T *Lp,
+                                              const T *dvec, volatile T *zov, volatile T *rov, T cfm, T erp_dt,
+                                              T rest) {
+  constexpr int NDs = NDP + 1;
+  for (int r = lane; r < nr; r += G) {
+    bool in_lds = true;
+    if constexpr (SLAB) in_lds = r < ZR;
+    T z[NDP];
+    if (in_lds) {
+#pragma unroll
+      for (int k = 0; k < NDP; ++k) z[k] = Zs[r * NDs + k];
+    } else {
+      volatile T *const Zr = zov + (size_t)(r - ZR) * NDs;
+#pragma unroll
+      for (int k = 0; k < NDP; ++k) z[k] = Zr[k];
+    }
+    T vrow = T(0);
+#pragma unroll
+    for (int k = 0; k < NDP; ++k)
+      if (k < nd) vrow += z[k] * qdv[k];
+    // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
+    const T brow = r < na ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + r] : vrow;
+    // column-oriented: once z[j] is final, every later z[k] takes its update independently
+#pragma unroll
+    for (int j = 0; j < NDP - 1; ++j) {
+#pragma unroll
+      for (int k = j + 1; k < NDP; ++k) z[k] -= Lp[(k * (k - 1)) / 2 + j] * z[j];
+    }
+    T g = T(0);
+#pragma unroll
+    for (int k = 0; k < NDP; ++k) {
+      z[k] *= dvec[NDP + k];
+      g += z[k] * z[k];
+    }
+    const T ai = rcp_full<T>(g + cfm);
+    if (in_lds) {
+#pragma unroll
+      for (int k = 0; k < NDP; ++k) Zs[r * NDs + k] = z[k];
+      rws[r] = brow;
+      rws[ZR + r] = ai;
+      rws[2 * ZR + r] = g;
+    } else {
+      volatile T *const Zr = zov + (size_t)(r - ZR) * NDs;
+#pragma unroll
+      for (int k = 0; k < NDP; ++k) Zr[k] = z[k];
+      rov[r - ZR] = brow;
+      rov[OVR + r - ZR] = ai;
+      rov[2 * OVR + r - ZR] = g;
+    }
+    xs[r] = T(0);
+  }
+}
+
+// projected Gauss-Seidel (mb_constraint_solver.hpp:101-142) on u~ = sum_r z~_r x_r:
+//   delta_i = sum_{j != i} A_ij x_j = z~_i . u~ - G_ii x_i;   lane == dof holds u~_k (returned)
+template <bool SLAB, typename T, int G, int NDP>
+__device__ __forceinline__ T tds_pgs(int lane, int nr, int na, int ZR, int OVR, int iters, T mu, const T *Zs,
+                                     const T *rws, T *xs, volatile const T *zov, volatile const T *rov) {
+  constexpr int NDs = NDP + 1;
+  const int d = lane;
+  const bool dz = d < NDP;
+  T u = T(0);
+  for (int it = 0; it < iters; ++it) {
+    // software pipeline: everything row r+1 needs that does not depend on row r is loaded before
+    // row r's cross-lane reduction, so only the reduction + clamp sit on the dependent chain
+    T zn = T(0), bn = T(0), an = T(0), gn = T(0), xon = T(0);
+    T sdn = T(0);  // dependency impulse of the NEXT row (row 0 is a normal row: unused there)
+    if (nr > 0) {
+      zn = dz ? Zs[d] : T(0);
+      bn = rws[0];
+      an = rws[ZR];
+      gn = rws[2 * ZR];
+      xon = it > 0 ? xs[0] : T(0);
+    }
+    for (int r = 0; r < nr; ++r) {
+      const T zr = zn, br = bn, ar = an, gr = gn, x_old = xon;
+      const int rn = r + 1;
+      if (rn < nr) {
+        bool nlds = true;
+        if constexpr (SLAB) nlds = rn < ZR;
+        if (nlds) {
+          zn = dz ? Zs[rn * NDs + d] : T(0);
+          bn = rws[rn];
+          an = rws[ZR + rn];
+          gn = rws[2 * ZR + rn];
+        } else {
+          zn = dz ? zov[(size_t)(rn - ZR) * NDs + d] : T(0);
+          bn = rov[rn - ZR];
+          an = rov[OVR + rn - ZR];
+          gn = rov[2 * OVR + rn - ZR];
+        }
+        xon = it > 0 ? xs[rn] : T(0);
+      }
+      // friction rows scale their box by the normal impulse of the same contact
+      // (limit_dependency_, mb_constraint_solver.hpp:417-436); that row is >= na rows back, so
+      // for na >= 2 it was stored at least one iteration ago and its load was issued then
+      const bool is_n = r < na;
+      T sdep = sdn;
+      if (na < 2) sdep = xs[r - (r >= na ? na : 0) - (r >= 2 * na ? na : 0)];
+      if (na >= 2 && rn < nr) sdn = xs[rn - (rn >= na ? na : 0) - (rn >= 2 * na ? na : 0)];
+      const T jw = group_sum<T, G>(zr * u);
+      const T delta = jw - gr * x_old;
+      T xn = (br - delta) * ar;
+      const T sc = sdep < T(0) ? T(0) : sdep;  // where_lt(s, 0, 0, s)
+      const T lo = is_n ? T(0) : -mu * sc;
+      const T hi = is_n ? T(100000) : mu * sc;
+      xn = max_t<T>(xn, lo);  // Algebra::max(x, lo*s)
+      xn = min_t<T>(xn, hi);  // Algebra::min(x, hi*s)
+      u += zr * (xn - x_old);
+      if (lane == 0) xs[r] = xn;
+    }
+  }
+  return u;
+}
+
+
+// ------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------
 // A workgroup is exactly ONE wavefront, and the LDS executes the DS instructions of a wavefront in
@@ -893,8 +1019,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     T *const xs = E + L.xrow;   // [3 ncp]: the impulses x of ALL rows stay in LDS (read back within the wave)
     const int ZR = L.zrows;
     const int OVR = L.ovrows;  // surplus rows available per environment in the slab
-    T *const zov = (ovf != nullptr && valid) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
-    T *const rov = zov != nullptr ? zov + (size_t)OVR * NDs : nullptr;  // [3][OVR]
+    volatile T *const zov = (ovf != nullptr && valid) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
+    volatile T *const rov = zov != nullptr ? zov + (size_t)OVR * NDs : nullptr;  // [3][OVR]
     const int nr = 3 * na;
     const T nb[3] = {mdl->nb[0], mdl->nb[1], mdl->nb[2]};
     const T t1[3] = {mdl->t1[0], mdl->t1[1], mdl->t1[2]};
@@ -935,54 +1061,13 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     //         G_rr = z.D^-1.z,  1/(G_rr + cfm);  the row is stored back as z~ = D^-1/2 z so that
     //         A_rs = J_r M^-1 J_s^T = z~_r . z~_s  — one matrix instead of J and M^-1 J^T.
     const T cfm = mdl->cfm, erp_dt = mdl->erp_over_dt, rest = mdl->restitution;
-    for (int r = lane; r < nr; r += G) {
-      const bool in_lds = r < ZR;
-      T *const Zr = in_lds ? nullptr : zov + (size_t)(r - ZR) * NDs;
-      T z[NDP];
-      if (in_lds) {
-#pragma unroll
-        for (int k = 0; k < NDP; ++k) z[k] = Zs[r * NDs + k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < NDP; ++k) z[k] = Zr[k];
-      }
-      T vrow = T(0);
-#pragma unroll
-      for (int k = 0; k < NDP; ++k)
-        if (k < nd) vrow += z[k] * xr[nq + k];
-      // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
-      const T brow = r < na ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + r] : vrow;
-      // column-oriented: once z[j] is final, every later z[k] takes its update independently
-#pragma unroll
-      for (int j = 0; j < NDP - 1; ++j) {
-#pragma unroll
-        for (int k = j + 1; k < NDP; ++k) z[k] -= Lp[(k * (k - 1)) / 2 + j] * z[j];
-        if constexpr (NDP > 16) {
-          if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      T g = T(0);
-#pragma unroll
-      for (int k = 0; k < NDP; ++k) {
-        z[k] *= dvec[NDP + k];
-        g += z[k] * z[k];
-      }
-      const T ai = rcp_full<T>(g + cfm);
-      if (in_lds) {
-#pragma unroll
-        for (int k = 0; k < NDP; ++k) Zs[r * NDs + k] = z[k];
-        rws[r] = brow;
-        rws[ZR + r] = ai;
-        rws[2 * ZR + r] = g;
-      } else {
-#pragma unroll
-        for (int k = 0; k < NDP; ++k) Zr[k] = z[k];
-        rov[r - ZR] = brow;
-        rov[OVR + r - ZR] = ai;
-        rov[2 * OVR + r - ZR] = g;
-      }
-      xs[r] = T(0);
-    }
+    const bool any_slab = __any(nr > ZR) != 0;  // wave-uniform
+    if (any_slab)
+      tds_row_solve<true, T, G, NDP>(lane, nr, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov, rov,
+                                     cfm, erp_dt, rest);
+    else
+      tds_row_solve<false, T, G, NDP>(lane, nr, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov, rov,
+                                      cfm, erp_dt, rest);
     TDS_WAVE_SYNC();
     if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     TDS_STAMP(11);
@@ -992,45 +1077,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     {
       const int d = lane;
       const bool dz = d < NDP;
-      T u = T(0);
       const T mu = mdl->friction;
       const int iters = mdl->pgs_iterations;
-      // row scalars / row vector element of row r for this lane, from LDS or the surplus slab
-      auto row_z = [&](int r) -> T { return r < ZR ? Zs[r * NDs + d] : zov[(size_t)(r - ZR) * NDs + d]; };
-      auto row_s = [&](int which, int r) -> T { return r < ZR ? rws[which * ZR + r] : rov[which * OVR + r - ZR]; };
-      for (int it = 0; it < iters; ++it) {
-        // software pipeline: everything row r+1 needs that does not depend on row r is loaded
-        // before row r's cross-lane reduction, so only the reduction + clamp sit on the chain
-        T zn = (nr > 0 && dz) ? row_z(0) : T(0);
-        T bn = nr > 0 ? row_s(0, 0) : T(0), an = nr > 0 ? row_s(1, 0) : T(0), gn = nr > 0 ? row_s(2, 0) : T(0);
-        T xon = (nr > 0 && it > 0) ? xs[0] : T(0);
-        for (int r = 0; r < nr; ++r) {
-          const T zr = zn, br = bn, ar = an, gr = gn, x_old = xon;
-          const int rn = r + 1;
-          if (rn < nr) {
-            zn = dz ? row_z(rn) : T(0);
-            bn = row_s(0, rn);
-            an = row_s(1, rn);
-            gn = row_s(2, rn);
-            xon = it > 0 ? xs[rn] : T(0);
-          }
-          // friction rows scale their box by the normal impulse of the same contact
-          // (limit_dependency_, mb_constraint_solver.hpp:417-436); that row is >= na rows back
-          const bool is_n = r < na;
-          const int dep = r - (r >= na ? na : 0) - (r >= 2 * na ? na : 0);
-          const T sdep = xs[dep];
-          const T jw = group_sum<T, G>(zr * u);
-          const T delta = jw - gr * x_old;
-          T xn = (br - delta) * ar;
-          const T sc = sdep < T(0) ? T(0) : sdep;  // where_lt(s, 0, 0, s)
-          const T lo = is_n ? T(0) : -mu * sc;
-          const T hi = is_n ? T(100000) : mu * sc;
-          xn = max_t<T>(xn, lo);  // Algebra::max(x, lo*s)
-          xn = min_t<T>(xn, hi);  // Algebra::min(x, hi*s)
-          u += zr * (xn - x_old);
-          if (lane == 0) xs[r] = xn;
-        }
-      }
+      const T u = any_slab ? tds_pgs<true, T, G, NDP>(lane, nr, na, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov)
+                           : tds_pgs<false, T, G, NDP>(lane, nr, na, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov);
       // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
       T w = dz ? u * dvec[NDP + d] : T(0);
       static_for<0, NDP - 1>([&](auto ic) {
