@@ -340,7 +340,6 @@ __device__ __forceinline__ T tds_pgs(int lane, int nr, int na, int ZR, int OVR, 
     // software pipeline: everything row r+1 needs that does not depend on row r is loaded before
     // row r's cross-lane reduction, so only the reduction + clamp sit on the dependent chain
     T zn = T(0), bn = T(0), an = T(0), gn = T(0), xon = T(0);
-    T sdn = T(0);  // dependency impulse of the NEXT row (row 0 is a normal row: unused there)
     if (nr > 0) {
       zn = dz ? Zs[d] : T(0);
       bn = rws[0];
@@ -368,12 +367,10 @@ __device__ __forceinline__ T tds_pgs(int lane, int nr, int na, int ZR, int OVR, 
         xon = it > 0 ? xs[rn] : T(0);
       }
       // friction rows scale their box by the normal impulse of the same contact
-      // (limit_dependency_, mb_constraint_solver.hpp:417-436); that row is >= na rows back, so
-      // for na >= 2 it was stored at least one iteration ago and its load was issued then
+      // (limit_dependency_, mb_constraint_solver.hpp:417-436); that row is >= na rows back
       const bool is_n = r < na;
-      T sdep = sdn;
-      if (na < 2) sdep = xs[r - (r >= na ? na : 0) - (r >= 2 * na ? na : 0)];
-      if (na >= 2 && rn < nr) sdn = xs[rn - (rn >= na ? na : 0) - (rn >= 2 * na ? na : 0)];
+      const int dep = r - (r >= na ? na : 0) - (r >= 2 * na ? na : 0);
+      const T sdep = xs[dep];
       const T jw = group_sum<T, G>(zr * u);
       const T delta = jw - gr * x_old;
       T xn = (br - delta) * ar;
