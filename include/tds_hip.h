@@ -41,6 +41,7 @@ extern "C" {
 #define TDS_MAX_GEOMS 32
 #define TDS_MAX_VISUALS 32
 #define TDS_MAX_ACTIONS 32
+#define TDS_MAX_DOF 32
 /* contact points per environment: sphere 1, capsule 2, box 8 (contact_point.hpp:96-198) */
 #define TDS_MAX_CONTACTS 32
 
@@ -166,6 +167,14 @@ typedef struct tds_model {
   double restitution; /* World::default_restitution (world.hpp:69) */
   double action_limit; /* 0.4 (locomotion_contact_simulation.h:234) */
   double initial_poses[TDS_MAX_ACTIONS];
+  /* environment reset (examples/environments/ant_environment2.h:109-165,
+     laikago_environment2.h:63-116): q = reset_q + reset_noise * U(-1,1) per coordinate, qd = 0,
+     followed by settle_steps steps with zero action.  The reference draws U from std::rand();
+     the device uses a counter-based generator keyed by (seed, env, reset count, coordinate). */
+  double reset_q[TDS_MAX_DOF];
+  double reset_noise[TDS_MAX_DOF];
+  int32_t settle_steps;
+  int32_t pad2_;
   tds_link_t links[TDS_MAX_LINKS];
   tds_geom_t geoms[TDS_MAX_GEOMS];
   tds_visual_t visuals[TDS_MAX_VISUALS];
@@ -232,6 +241,21 @@ int tds_hip_step(tds_hip_sim_t *sim, const void *actions_dev, int substeps);
    job all-gathers. */
 int tds_hip_step_obs(tds_hip_sim_t *sim, const void *actions_dev, int substeps, void *obs_dev);
 int tds_hip_obs_dim(const tds_hip_sim_t *sim);
+
+/* On-device environment reset — replaces the host loop of VectorizedEnvironment::reset / the
+   auto-reset branch of VectorizedEnvironment::step (ars_vectorized_environment.h:196-211, 262-277).
+   tds_hip_reset: re-initialise the environments selected by mask_dev (uint8 [N], NULL = all) from
+     the model's reset distribution, run model->settle_steps zero-action steps, write the new state
+     into the resident x record and, if obs_dev != NULL, the observation part of their obs record
+     (reward / done slots are left untouched).  One kernel launch, asynchronous.
+   tds_hip_set_auto_reset(enable): tds_hip_step / tds_hip_step_obs then reset every environment whose
+     step ends with done (model->reward_mode) inside the same launch: y, reward and done describe
+     the terminal step, x and the observation describe the freshly reset + settled environment —
+     exactly what the reference's auto_reset_when_done does.
+   seed selects the random stream (counter-based: deterministic for a given seed, environment
+   index and per-environment reset count, independent of launch geometry). */
+int tds_hip_set_auto_reset(tds_hip_sim_t *sim, int enable, unsigned long long seed);
+int tds_hip_reset(tds_hip_sim_t *sim, const unsigned char *mask_dev, void *obs_dev);
 
 /* Blocking convenience with HOST buffers in double, any N <= num_envs:
    H2D(x) -> kernel -> D2H(y), i.e. exactly what the reference's <model>_forward_zero does. */

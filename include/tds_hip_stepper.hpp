@@ -169,6 +169,18 @@ int flatten_locomotion_env(Sim &sim, tds_model_t *out, int reward_mode = TDS_REW
   out->reward_mode = reward_mode;
   out->action_limit = 0.4;  // locomotion_contact_simulation.h:234
   for (size_t i = 0; i < sim.initial_poses_.size(); ++i) out->initial_poses[i] = Algebra::to_double(sim.initial_poses_[i]);
+  // reset distribution of the fixed-base locomotion envs (ant_environment2.h:124-135,
+  // laikago_environment2.h:78-90): base at m_start_base_position with zero rpy, joints at
+  // initial_poses + 0.05 * U(-1,1), 10 settle steps
+  if (!sim.mb_->is_floating() && out->dof_q <= TDS_MAX_DOF) {
+    for (int k = 0; k < 3; ++k) out->reset_q[k] = Algebra::to_double(sim.m_start_base_position[k]);
+    const int qoffset = 6;
+    for (size_t j = 0; j < sim.initial_poses_.size() && qoffset + (int)j < out->dof_q; ++j) {
+      out->reset_q[qoffset + j] = Algebra::to_double(sim.initial_poses_[j]);
+      out->reset_noise[qoffset + j] = 0.05;
+    }
+    out->settle_steps = 10;
+  }
   out->plane_normal[2] = 1.0;
   rc = flatten_plane<Algebra>(sim.world, *sim.mb_, out->dt, out);
   if (rc) return rc;

@@ -242,3 +242,136 @@ def test_synthetic_chain_wide_systems(n_links, built):
         err = rel_err(y, y_ref)
         print(f"chain{n_links} G={lanes}: active contacts {nact}, max rel err vs oracle {err:.3e}")
         assert err < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# in-kernel step loop: substeps, on-device reset / auto-reset, python env mirror (N3)
+# ---------------------------------------------------------------------------------------------
+def _uniform01(seed, env, count, j):
+    """python twin of tds_uniform01 (tds_kernels.hip): splitmix64 finaliser"""
+    M = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (((env << 32) | (count * 64 + j + 1)) & M)) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z = z ^ (z >> 31)
+    return (z >> 11) * (1.0 / 9007199254740992.0)
+
+
+def _host_reset(m, x_row, seed, env, count):
+    """reset distribution + settle steps, on the host with the oracle"""
+    nq, nd = m.dof_q, m.dof_qd
+    x = x_row.copy()
+    for j in range(nd):
+        x[j] = m.reset_q[j] + m.reset_noise[j] * ((_uniform01(seed, env, count, j) - 0.5) * 2.0)
+        x[nq + j] = 0.0
+    x[nq + nd:nq + nd + m.action_dim] = 0.0
+    for _ in range(m.settle_steps):
+        y = oraclelib.step(m, x)[0]
+        x[:nq + nd] = y[:nq + nd]
+    return x[:nq + nd]
+
+
+@pytest.mark.parametrize("name", ["ant", "laikago"])
+def test_substeps_in_kernel_equal_repeated_steps(name, built):
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x0 = torch.from_numpy(g["x"]).cuda()
+    n = x0.shape[0]
+    a = torch.from_numpy(np.random.default_rng(1).uniform(-0.4, 0.4, (n, m.action_dim))).cuda()
+    s1 = hip_backend.HipSim(m, n)
+    s2 = hip_backend.HipSim(m, n)
+    s1.x.copy_(x0)
+    s2.x.copy_(x0)
+    for _ in range(5):
+        s1.step(a, 1)
+    s2.step(a, 5)
+    assert torch.equal(s1.x, s2.x)
+    assert torch.equal(s1.y, s2.y)
+
+
+@pytest.mark.parametrize("name", ["ant", "laikago"])
+def test_forced_reset_matches_host_emulation(name, built):
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    n, seed = 24, 1234
+    sim = hip_backend.HipSim(m, n)
+    sim.set_auto_reset(False, seed)
+    vars3 = [15, 0.3, 3] if name == "ant" else [100, 2, 50]
+    sim.x[:, -3:] = torch.tensor(vars3, dtype=torch.float64, device="cuda")
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    mask[::3] = 1
+    x_before = sim.x.clone()
+    obs = torch.full((n, sim.obs_dim + 2), -7.0, dtype=torch.float64, device="cuda")
+    sim.reset(mask, obs)
+    x_after = sim.x.cpu().numpy()
+    nqd = m.dof_q + m.dof_qd
+    for e in range(n):
+        if e % 3 == 0:
+            ref = _host_reset(m, x_before[e].cpu().numpy(), seed, e, 0)
+            assert rel_err(x_after[e, :nqd], ref) < TOL, e
+            o = obs[e].cpu().numpy()
+            assert o[0] == 0 and o[1] == 0 and rel_err(o[2:nqd], ref[2:]) < TOL
+            assert o[nqd] == -7.0 and o[nqd + 1] == -7.0  # reward / done untouched
+        else:
+            assert np.array_equal(x_after[e], x_before[e].cpu().numpy())
+            assert (obs[e] == -7.0).all()
+    # second reset of everybody draws the NEXT sample of each environment's stream
+    sim.reset(None, None)
+    x2 = sim.x.cpu().numpy()
+    for e in (0, 1):
+        ref = _host_reset(m, x_after[e], seed, e, 1 if e % 3 == 0 else 0)
+        assert rel_err(x2[e, :nqd], ref) < TOL
+
+
+def test_auto_reset_inside_step(built):
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    g = np.load(os.path.join(GOLDEN, "ant.npz"))
+    n, seed = 32, 99
+    x = g["x"][:n].copy()
+    x[::2, 2] = 0.20            # torso below 0.26 after the step -> done
+    x[1::2, 2] = 0.50
+    x[:, 3:6] *= 0.2
+    a = np.random.default_rng(3).uniform(-0.4, 0.4, (n, m.action_dim))
+    sim = hip_backend.HipSim(m, n)
+    sim.set_auto_reset(True, seed)
+    sim.x.copy_(torch.from_numpy(x).cuda())
+    obs = torch.zeros((n, sim.obs_dim + 2), dtype=torch.float64, device="cuda")
+    sim.step(torch.from_numpy(a).cuda(), 1, obs)
+    xs = x.copy()
+    xs[:, 28:36] = a
+    y_ref = oraclelib.step(m, xs)
+    yd, od, xd = sim.y.cpu().numpy(), obs.cpu().numpy(), sim.x.cpu().numpy()
+    assert rel_err(yd, y_ref) < TOL                      # y always describes the terminal step
+    done_ref = y_ref[:, 2] < 0.26
+    assert done_ref[::2].all() and not done_ref[1::2].any()
+    assert np.array_equal(od[:, 29] != 0, done_ref)
+    rew_ref = np.where(done_ref, 0.0, (y_ref[:, 0] - x[:, 0]) / m.dt)
+    assert rel_err(od[:, 28], rew_ref, 1e-6) < 1e-6
+    for e in range(n):
+        if done_ref[e]:
+            ref = _host_reset(m, xs[e], seed, e, 0)
+            assert rel_err(xd[e, :28], ref) < TOL, e
+            assert od[e, 0] == 0 and od[e, 1] == 0 and rel_err(od[e, 2:28], ref[2:]) < TOL
+        else:
+            assert rel_err(xd[e, :28], y_ref[e, :28]) < TOL
+            assert rel_err(od[e, 2:28], y_ref[e, 2:28]) < TOL
+
+
+def test_vectorized_env_python_mirror(built):
+    """pytinydiffsim.VectorizedAntEnv-shaped API (python/examples/vec_ant.py loop)."""
+    torch = _torch()
+    env = tds_amd.VectorizedAntEnv(256, auto_reset_when_done=True, seed=5)
+    assert env.action_dim() == 8 and env.obs_dim() == 28
+    obs = env.reset()
+    assert obs.shape == (256, 28) and torch.isfinite(obs).all()
+    assert (obs[:, :2] == 0).all()
+    assert (obs[:, 2] > 0.2).all() and (obs[:, 2] < 0.6).all()   # settled near the ground
+    actions = torch.zeros((256, 8), dtype=torch.float64, device="cuda")
+    for _ in range(20):
+        out = env.step(actions)
+    assert out.obs.shape == (256, 28) and out.rewards.shape == (256,) and out.dones.shape == (256,)
+    assert out.visual_world_transforms.shape == (256, 155)
+    assert torch.isfinite(out.obs).all() and torch.isfinite(out.rewards).all()
+    assert set(out.dones.unique().tolist()) <= {0.0, 1.0}

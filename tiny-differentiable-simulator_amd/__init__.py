@@ -6,3 +6,5 @@ from . import model  # noqa: F401
 
 from . import hip_backend  # noqa: F401,E402
 from . import sharded  # noqa: F401,E402
+from . import vec_env  # noqa: F401,E402
+from .vec_env import VectorizedAntEnv, VectorizedLaikagoEnv, VectorizedEnv  # noqa: F401,E402

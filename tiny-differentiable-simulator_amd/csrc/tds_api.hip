@@ -63,6 +63,9 @@ struct tds_hip_sim {
   DevModel<float> h32;
   TdsLds lds;
   void *d_x = nullptr, *d_y = nullptr, *d_ovf = nullptr;
+  unsigned int *d_reset_count = nullptr;
+  bool auto_reset = false;
+  unsigned long long seed = 0x5DEECE66Dull;
   std::vector<double> stage;
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -75,15 +78,25 @@ struct tds_hip_sim {
 
 namespace {
 
-int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n) {
+int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n, int nsub,
+           int reset_mode, const unsigned char *mask) {
   if (s->timing) (void)hipEventRecord(s->ev0, s->stream);
+  TdsStepCtl ctl;
+  ctl.nsub = nsub;
+  ctl.reset_mode = reset_mode;
+  ctl.settle_steps = s->model.settle_steps < 0 ? 0 : s->model.settle_steps;
+  ctl.seed = s->seed;
+  ctl.mask = mask;
+  ctl.reset_count = s->d_reset_count;
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes, (const double *)x,
-                                 (double *)y, (const double *)actions, (double *)fb, (double *)obs, (double *)s->d_ovf, n, s->stream);
+                                 (double *)y, (const double *)actions, (double *)fb, (double *)obs,
+                                 (double *)s->d_ovf, n, s->stream, ctl);
   else
     rc = tds_launch_step<float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)x,
-                                (float *)y, (const float *)actions, (float *)fb, (float *)obs, (float *)s->d_ovf, n, s->stream);
+                                (float *)y, (const float *)actions, (float *)fb, (float *)obs, (float *)s->d_ovf, n,
+                                s->stream, ctl);
   if (rc != 0) {
     snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad lanes_per_env");
     return TDS_ERR_HIP;
@@ -212,6 +225,8 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   CREATE_TRY(hipMemset(s->d_y, 0, (size_t)num_envs * model->output_dim * s->elem));
   if (s->lds.ovrows > 0)
     CREATE_TRY(hipMalloc(&s->d_ovf, (size_t)num_envs * s->lds.ovrows * (s->lds.NDs + 3) * s->elem));
+  CREATE_TRY(hipMalloc((void **)&s->d_reset_count, (size_t)num_envs * sizeof(unsigned int)));
+  CREATE_TRY(hipMemset(s->d_reset_count, 0, (size_t)num_envs * sizeof(unsigned int)));
   CREATE_TRY(hipEventCreate(&s->ev0));
   CREATE_TRY(hipEventCreate(&s->ev1));
 #undef CREATE_TRY
@@ -225,6 +240,7 @@ int tds_hip_destroy(tds_hip_sim_t *s) {
   if (s->d_x) (void)hipFree(s->d_x);
   if (s->d_y) (void)hipFree(s->d_y);
   if (s->d_ovf) (void)hipFree(s->d_ovf);
+  if (s->d_reset_count) (void)hipFree(s->d_reset_count);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -262,19 +278,31 @@ int tds_hip_get_outputs(tds_hip_sim_t *s, double *y_host) {
 
 int tds_hip_forward_zero_device(tds_hip_sim_t *s, const void *x_dev, void *y_dev) {
   if (!s || !x_dev || !y_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
-  return launch(s, x_dev, y_dev, nullptr, nullptr, nullptr, s->num_envs);
+  return launch(s, x_dev, y_dev, nullptr, nullptr, nullptr, s->num_envs, 1, TDS_RESET_NONE, nullptr);
 }
 
 int tds_hip_step_obs(tds_hip_sim_t *s, const void *actions_dev, int substeps, void *obs_dev) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   if (substeps < 1) return fail(TDS_ERR_INVALID_ARG, "substeps must be >= 1");
-  for (int k = 0; k < substeps; ++k) {
-    // every substep installs the same action into the resident record; feedback writes q, qd;
-    // the observation record is produced by the last substep's launch
-    int rc = launch(s, s->d_x, s->d_y, actions_dev, s->d_x, k == substeps - 1 ? obs_dev : nullptr, s->num_envs);
-    if (rc != TDS_OK) return rc;
-  }
+  // ONE launch: the kernel loops over the substeps (same action) with the state kept in LDS, writes
+  // y / reward / done of the last substep and, with auto-reset on, re-initialises + settles the
+  // environments that ended with done before it writes their observation and resident state
+  return launch(s, s->d_x, s->d_y, actions_dev, s->d_x, obs_dev, s->num_envs, substeps,
+                s->auto_reset ? TDS_RESET_AUTO : TDS_RESET_NONE, nullptr);
+}
+
+int tds_hip_set_auto_reset(tds_hip_sim_t *s, int enable, unsigned long long seed) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  if (enable && s->model.reward_mode == TDS_REWARD_NONE)
+    return fail(TDS_ERR_INVALID_ARG, "auto-reset needs a model with a termination rule (reward_mode)");
+  s->auto_reset = enable != 0;
+  s->seed = seed;
   return TDS_OK;
+}
+
+int tds_hip_reset(tds_hip_sim_t *s, const unsigned char *mask_dev, void *obs_dev) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  return launch(s, s->d_x, s->d_y, nullptr, s->d_x, obs_dev, s->num_envs, 0, TDS_RESET_FORCED, mask_dev);
 }
 
 int tds_hip_step(tds_hip_sim_t *s, const void *actions_dev, int substeps) {
@@ -288,7 +316,7 @@ int tds_hip_forward_zero_host(tds_hip_sim_t *s, int n, const double *x_host, dou
   if (n < 1 || n > s->num_envs) return fail(TDS_ERR_INVALID_ARG, "n out of range");
   int rc = upload(s, s->d_x, x_host, (size_t)n * s->model.input_dim);
   if (rc != TDS_OK) return rc;
-  rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n);
+  rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n, 1, TDS_RESET_NONE, nullptr);
   if (rc != TDS_OK) return rc;
   return download(s, y_host, s->d_y, (size_t)n * s->model.output_dim);
 }
@@ -313,13 +341,16 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   long long *d = nullptr;
   HIP_TRY(hipMalloc(&d, sizeof(long long) * TDS_NUM_PHASE_STAMPS));
   HIP_TRY(hipMemset(d, 0, sizeof(long long) * TDS_NUM_PHASE_STAMPS));
+  TdsStepCtl ctl;
+  memset(&ctl, 0, sizeof(ctl));
+  ctl.nsub = 1;
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes, (const double *)s->d_x,
-                                 (double *)s->d_y, nullptr, nullptr, nullptr, (double *)s->d_ovf, s->num_envs, s->stream, d);
+                                 (double *)s->d_y, nullptr, nullptr, nullptr, (double *)s->d_ovf, s->num_envs, s->stream, ctl, d);
   else
     rc = tds_launch_step<float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)s->d_x,
-                                (float *)s->d_y, nullptr, nullptr, nullptr, (float *)s->d_ovf, s->num_envs, s->stream, d);
+                                (float *)s->d_y, nullptr, nullptr, nullptr, (float *)s->d_ovf, s->num_envs, s->stream, ctl, d);
   if (rc != 0) {
     (void)hipFree(d);
     return fail(TDS_ERR_HIP, "profiling launch failed");

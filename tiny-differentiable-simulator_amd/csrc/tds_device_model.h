@@ -26,7 +26,7 @@ struct DevModel {
   int num_links, dof_q, dof_qd, num_levels;
   int num_cp, num_visuals, action_dim, input_dim, output_dim;
   int step_mode, has_plane, pgs_iterations, pack_visuals;
-  int num_pairs, reward_mode, pad1_;
+  int num_pairs, reward_mode, settle_steps;
   T dt, cfm, erp_over_dt, friction, restitution, action_limit;
   T grav[3];       // base acceleration = -grav (forward_dynamics.hpp:242), world frame
   T base_R[9], base_t[3];
@@ -42,6 +42,7 @@ struct DevModel {
   T stiffness[TDS_NL], damping[TDS_NL], init_pose[TDS_NL];
   // per dof ----------------------------------------------------------------------------
   int dof_link[TDS_ND];
+  T reset_q[TDS_ND], reset_noise[TDS_ND];
   // contact points ---------------------------------------------------------------------
   int cp_link[TDS_NCP];
   T cp_local[3][TDS_NCP], cp_radius[TDS_NCP];
@@ -99,6 +100,11 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
   d->pgs_iterations = m->pgs_iterations;
   d->pack_visuals = m->pack_visuals;
   d->reward_mode = m->reward_mode;
+  d->settle_steps = m->settle_steps < 0 ? 0 : m->settle_steps;
+  for (int k = 0; k < TDS_ND && k < TDS_MAX_DOF; ++k) {
+    d->reset_q[k] = (T)m->reset_q[k];
+    d->reset_noise[k] = (T)m->reset_noise[k];
+  }
   const int nq = m->dof_q, nd = m->dof_qd;
   const int need_in = nq + nd + m->action_dim + (m->step_mode == TDS_STEP_LOCOMOTION ? 3 : 0);
   if (m->input_dim < need_in) TDS_FAIL(TDS_ERR_INVALID_ARG, "input_dim too small for [q|qd|action|vars]");

@@ -20,6 +20,19 @@ struct TdsLds {
   int Z;                   // phase group 3 (constraint rows)     }
 };
 
+// what one launch does besides the physics (see the step loop in tds_kernels.hip)
+#define TDS_RESET_NONE 0
+#define TDS_RESET_AUTO 1    // re-initialise + settle the environments whose last step ends with done
+#define TDS_RESET_FORCED 2  // re-initialise + settle the environments selected by mask (NULL = all)
+struct TdsStepCtl {
+  int nsub;                   // normal steps in this launch (0 for a pure reset launch)
+  int reset_mode;             // TDS_RESET_*
+  int settle_steps;           // zero-action steps after a re-initialisation
+  unsigned long long seed;    // random stream of the reset distribution
+  const unsigned char *mask;  // forced mode: per-env selection (device), NULL = all
+  unsigned int *reset_count;  // [n_envs] per-env reset counter (device), position in the random stream
+};
+
 template <typename T>
 TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap);  // na_cap: contacts whose rows stay in LDS (<=0: all)
 
@@ -31,7 +44,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap);  // na_cap: contac
 template <typename T>
 int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                     const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
-                    hipStream_t stream, long long *prof = nullptr);  // prof: 14 phase stamps of workgroup 0 (diagnostic)
+                    hipStream_t stream, const TdsStepCtl &ctl, long long *prof = nullptr);  // prof: 14 phase stamps of workgroup 0 (diagnostic)
 
 template <typename T>
 int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes);

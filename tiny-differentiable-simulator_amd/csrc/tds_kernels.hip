@@ -405,22 +405,40 @@ __device__ __forceinline__ T tds_pgs(int lane, int nr, int na, int ZR, int OVR, 
   } while (0)
 #endif
 
+// per-group state machine of the in-kernel step loop
+#define TDS_MODE_IDLE 0
+#define TDS_MODE_RUN 1
+#define TDS_MODE_SETTLE 2
+
+// counter-based uniform in [0,1): splitmix64 finaliser of (seed, env, reset count, coordinate).
+// Stateless, so a reset is reproducible whatever the launch geometry or order.
+__device__ __forceinline__ double tds_uniform01(unsigned long long seed, unsigned env, unsigned count, unsigned j) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)env << 32) | (unsigned long long)(count * 64u + j + 1u));
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // TDS_STAMP: phase-boundary timestamps (shader clock) of workgroup 0, PROF builds only
 #define TDS_STAMP(k)                                                        \
   do {                                                                      \
     if (PROF) {                                                             \
       __builtin_amdgcn_sched_barrier(0);                                    \
       __builtin_amdgcn_s_waitcnt(0);                                        \
-      if (blockIdx.x == 0 && threadIdx.x == 0) prof[k] = (long long)__builtin_amdgcn_s_memtime(); \
+      if (blockIdx.x == 0 && threadIdx.x == 0 && tds_iter == 0) prof[k] = (long long)__builtin_amdgcn_s_memtime(); \
       __builtin_amdgcn_sched_barrier(0);                                    \
     }                                                                       \
   } while (0)
 
-template <typename T, int G, int NDP, bool PROF>
-__global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl, TdsLds L,
+// LOOP = false: exactly one normal step per launch, no reset -> straight-line code (the bench /
+// forward_zero path; no loop-carried live ranges).  LOOP = true: the general step loop (substeps,
+// auto / forced reset + settle steps) at the price of ~60 more live registers.
+template <typename T, int G, int NDP, bool PROF, bool LOOP>
+__global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const T *x_in, T *__restrict__ y_out,
                                                       const T *__restrict__ actions, T *x_feedback /* may alias x_in */,
-                                                      T *__restrict__ obs_out, T *ovf, long long *prof, int n_envs) {
+                                                      T *__restrict__ obs_out, T *ovf, long long *prof, TdsStepCtl ctl, int n_envs) {
   extern __shared__ __align__(16) unsigned char tds_smem_raw[];
   T *const sm = reinterpret_cast<T *>(tds_smem_raw);
   constexpr int EPW = 64 / G;
@@ -430,11 +448,14 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   const bool valid = env < n_envs;
   T *const E = sm + grp * L.stride;
 
+  const DevModel<T> *mdl = mdl_arg;
   const int nl = mdl->num_links, nq = mdl->dof_q, nd = mdl->dof_qd;
   const int in_dim = mdl->input_dim, out_dim = mdl->output_dim, adim = mdl->action_dim;
   constexpr int NDs = NDP + 1;  // odd row stride of every [row][dof] array
   const T dt = mdl->dt;
 
+  int tds_iter = 0;
+  (void)tds_iter;
   TDS_STAMP(0);
   // ---- A. x record -> LDS (coalesced: consecutive lanes, consecutive doubles) ---------------
   T *const xr = E + L.xrec;
@@ -442,6 +463,50 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   if (actions != nullptr && valid)
     for (int i = lane; i < adim; i += G) xr[nq + nd + i] = actions[(size_t)env * adim + i];
   TDS_WAVE_SYNC();
+
+  // ---- in-kernel step loop: `nsub` normal steps, then (auto / forced reset) the environments that
+  //      need it are re-initialised and run `settle_steps` zero-action steps — all inside this launch,
+  //      state carried in the LDS record.  mode / left are uniform within a lane group.
+  const int nset = (LOOP && ctl.reset_mode != TDS_RESET_NONE) ? ctl.settle_steps : 0;
+  int mode = (valid && (!LOOP || ctl.nsub > 0)) ? TDS_MODE_RUN : TDS_MODE_IDLE;
+  int left = LOOP ? ctl.nsub : 1;
+  // q = reset_q + reset_noise * U(-1,1), qd = 0  (ant_environment2.h:124-135)
+  auto reset_state = [&]() {
+    const unsigned cnt = ctl.reset_count != nullptr ? ctl.reset_count[env] : 0u;
+    if (lane < nd) {
+      const T u01 = (T)tds_uniform01(ctl.seed, (unsigned)env, cnt, (unsigned)lane);
+      xr[lane] = mdl->reset_q[lane] + mdl->reset_noise[lane] * ((u01 - T(0.5)) * T(2));
+      xr[nq + lane] = T(0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && ctl.reset_count != nullptr) ctl.reset_count[env] = cnt + 1u;
+  };
+  if constexpr (LOOP) {
+    bool finished0 = false;  // forced reset with zero settle steps: nothing to simulate
+    if (ctl.reset_mode == TDS_RESET_FORCED && valid && (ctl.mask == nullptr || ctl.mask[env] != 0)) {
+      reset_state();
+      if (nset > 0) {
+        mode = TDS_MODE_SETTLE;
+        left = nset;
+      } else {
+        finished0 = true;
+      }
+    }
+    TDS_WAVE_SYNC();
+    if (finished0) {
+      if (lane < nd) {
+        if (obs_out != nullptr) {
+          T *const ob = obs_out + (size_t)env * (nq + nd + 2);
+          ob[lane] = lane < 2 ? T(0) : xr[lane];
+          ob[nq + lane] = xr[nq + lane];
+        }
+        if (x_feedback != nullptr) {
+          x_feedback[(size_t)env * in_dim + lane] = xr[lane];
+          x_feedback[(size_t)env * in_dim + nq + lane] = xr[nq + lane];
+        }
+      }
+    }
+  }
 
   // ---- lane == link: constants -------------------------------------------------------------
   const int li = lane;
@@ -451,6 +516,18 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   const int level = isl ? mdl->level[lsafe] : -1;
   const int jt = isl ? mdl->joint_type[lsafe] : TDS_JOINT_FIXED;
   const int di = isl ? mdl->qd_index[lsafe] : -1;  // == q_index (1-DoF joints only)
+  for (;;) {  // ================================ step loop ================================
+  if constexpr (LOOP) {
+    if (!__any(mode != TDS_MODE_IDLE)) break;
+  }
+  // Launder the model pointer once per iteration: otherwise LICM hoists every model-table load of
+  // the body out of the loop and keeps ~100 VGPRs / ~200 SGPRs of constants live across all phases
+  // (measured: 194 -> 256 VGPR + 73 AGPR + 214 spilled SGPRs).
+  const DevModel<T> *mdl = mdl_arg;
+  if constexpr (LOOP) asm volatile("" : "+s"(mdl));
+  const bool live = mode != TDS_MODE_IDLE;
+  const bool last_run = mode == TDS_MODE_RUN && left == 1;
+  const bool settling = LOOP && mode == TDS_MODE_SETTLE;
   const T q = di >= 0 ? xr[di] : T(0);
   const T qd = di >= 0 ? xr[nq + di] : T(0);
 
@@ -461,7 +538,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     if (ai >= 0) {
       const int var = nq + nd + adim;
       const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
-      T a = xr[nq + nd + ai];
+      T a = settling ? T(0) : xr[nq + nd + ai];  // reset settles with zero action
       const T lim = mdl->action_limit;
       a = a < lim ? a : lim;       // Algebra::min(clamped_action, ACTION_LIMIT)
       a = a > -lim ? a : -lim;     // Algebra::max(clamped_action, -ACTION_LIMIT)
@@ -472,7 +549,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       tau = f;
     }
   } else if (di >= 0) {
-    tau = xr[nq + nd + di];
+    tau = settling ? T(0) : xr[nq + nd + di];
   }
   // joint stiffness / damping (forward_dynamics.hpp:122-123)
   if (isl) tau -= mdl->stiffness[lsafe] * q + mdl->damping[lsafe] * qd;
@@ -643,7 +720,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         Pb[0] = ctr[0] - rad * n[0];
         Pb[1] = ctr[1] - rad * n[1];
         Pb[2] = ctr[2] - rad * n[2];
-        act = valid && dist < T(0);  // collision mask, mb_constraint_solver.hpp:285
+        act = live && dist < T(0);  // collision mask, mb_constraint_solver.hpp:285
       }
       const unsigned long long bal = __ballot(act);
       const unsigned long long mine = (G == 64) ? bal : ((bal >> (grp * G)) & ((1ull << (G & 63)) - 1ull));
@@ -669,7 +746,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     T *const yo = y_out + (size_t)env * out_dim;
     const int nv = mdl->num_visuals;
     const int vbase = nq + nd;
-    if (valid) {
+    if (last_run) {  // y describes the last normal step of the launch
       for (int k = lane; k < nv; k += G) {
         const int lk = mdl->vis_link[k];
         T Rl[9], pl[3], Rv[9], pv[3];
@@ -1016,7 +1093,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     T *const xs = E + L.xrow;   // [3 ncp]: the impulses x of ALL rows stay in LDS (read back within the wave)
     const int ZR = L.zrows;
     const int OVR = L.ovrows;  // surplus rows available per environment in the slab
-    volatile T *const zov = (ovf != nullptr && valid) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
+    volatile T *const zov = (ovf != nullptr && live) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
     volatile T *const rov = zov != nullptr ? zov + (size_t)OVR * NDs : nullptr;  // [3][OVR]
     const int nr = 3 * na;
     const T nb[3] = {mdl->nb[0], mdl->nb[1], mdl->nb[2]};
@@ -1095,70 +1172,127 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // ---- M. integrate_euler: q += qd dt (integrator.hpp:126-131) and pack y -------------------
   q_new = q + qd_new * dt;
 
-  // ---- N. observation record [q | qd (obs[0] = obs[1] = 0) | reward | done]
-  //         (ars_vectorized_environment.h:250-289; ant_environment2.h:75-106;
-  //          laikago_environment2.h:130-171)
-  if (obs_out != nullptr) {
-    TDS_WAVE_SYNC();
-    if (di == 0) xr[nq + nd] = q;  // x_{t-1}; the action slots are dead by now
-    if (di >= 0) xr[di] = q_new;
-    TDS_WAVE_SYNC();
-    if (valid) {
-      T *const ob = obs_out + (size_t)env * (nq + nd + 2);
-      if (di >= 0) {
-        ob[di] = di < 2 ? T(0) : q_new;
-        ob[nq + di] = qd_new;
-      }
-      if (lane == 0) {
-        T reward = T(0);
-        bool done = false;
-        const int rm = mdl->reward_mode;
-        if (rm == TDS_REWARD_ANT && nq > 2) {
-          const T vel_x = (xr[0] - xr[nq + nd]) / dt;
-          done = xr[2] < T(0.26);
-          reward = done ? T(0) : vel_x;
-        } else if (rm == TDS_REWARD_LAIKAGO && nq > 5) {
-          // up_dot_world_z = quat_to_matrix(quat_from_euler_rpy(q[3..5]))(2,2)
-          // (tiny_quaternion.h set_euler_rpy, tiny_matrix3x3.h:315-340)
-          T sp, cp, st, ct, ss, cs2;
-          sincos_t<T>(xr[3] * T(0.5), &sp, &cp);
-          sincos_t<T>(xr[4] * T(0.5), &st, &ct);
-          sincos_t<T>(xr[5] * T(0.5), &ss, &cs2);
-          const T qx = sp * ct * cs2 - cp * st * ss;
-          const T qy = cp * st * cs2 + sp * ct * ss;
-          const T qz = cp * ct * ss - sp * st * cs2;
-          const T qw = cp * ct * cs2 + sp * st * ss;
-          const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
-          const T up = T(1) - (qx * (qx * s2) + qy * (qy * s2));
-          done = (up < T(0.6)) || (xr[2] < T(0.2));
-          reward = done ? T(0) : xr[0];
-        }
-        ob[nq + nd] = reward;
-        ob[nq + nd + 1] = done ? T(1) : T(0);
-      }
-    }
+  // carry the state in the LDS record (slot in_dim keeps x_{t-1} for the Ant reward)
+  TDS_WAVE_SYNC();
+  if (di == 0) xr[in_dim] = q;
+  if (di >= 0) {
+    xr[di] = q_new;
+    xr[nq + di] = qd_new;
   }
+  TDS_WAVE_SYNC();
 
-  T *const yo = y_out + (size_t)env * out_dim;
-  if (valid) {
+  // ---- y record (q, qd, up, zero padding; the visual poses went out in M1) of the last normal step
+  if (last_run) {
+    T *const yo = y_out + (size_t)env * out_dim;
     if (di >= 0) {
       yo[di] = q_new;
       yo[nq + di] = qd_new;
-      if (x_feedback != nullptr) {
-        x_feedback[(size_t)env * in_dim + di] = q_new;
-        x_feedback[(size_t)env * in_dim + nq + di] = qd_new;
-      }
     }
     const int nv = mdl->num_visuals;
-    const int vbase = nq + nd;
-    int tail = vbase;
+    int tail = nq + nd;
     if (mdl->pack_visuals) {
-      tail = vbase + 7 * nv;
+      tail += 7 * nv;
       if (lane == 0) yo[tail] = mdl->base_R[8];  // up_dot_world_z
       tail += 1;
     }
     for (int i = tail + lane; i < out_dim; i += G) yo[i] = T(0);
   }
+
+  // ---- N. reward / done of the last normal step
+  //         (ars_vectorized_environment.h:250-289; ant_environment2.h:75-106;
+  //          laikago_environment2.h:130-171)
+  if (last_run && lane == 0) {
+    T reward = T(0);
+    bool done = false;
+    const int rm = mdl->reward_mode;
+    if (rm == TDS_REWARD_ANT && nq > 2) {
+      const T vel_x = (xr[0] - xr[in_dim]) / dt;
+      done = xr[2] < T(0.26);
+      reward = done ? T(0) : vel_x;
+    } else if (rm == TDS_REWARD_LAIKAGO && nq > 5) {
+      // up_dot_world_z = quat_to_matrix(quat_from_euler_rpy(q[3..5]))(2,2)
+      // (tiny_quaternion.h set_euler_rpy, tiny_matrix3x3.h:315-340)
+      T sp, cp, st, ct, ss, cs2;
+      sincos_t<T>(xr[3] * T(0.5), &sp, &cp);
+      sincos_t<T>(xr[4] * T(0.5), &st, &ct);
+      sincos_t<T>(xr[5] * T(0.5), &ss, &cs2);
+      const T qx = sp * ct * cs2 - cp * st * ss;
+      const T qy = cp * st * cs2 + sp * ct * ss;
+      const T qz = cp * ct * ss - sp * st * cs2;
+      const T qw = cp * ct * cs2 + sp * st * ss;
+      const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+      const T up = T(1) - (qx * (qx * s2) + qy * (qy * s2));
+      done = (up < T(0.6)) || (xr[2] < T(0.2));
+      reward = done ? T(0) : xr[0];
+    }
+    if (obs_out != nullptr) {
+      T *const ob = obs_out + (size_t)env * (nq + nd + 2);
+      ob[nq + nd] = reward;
+      ob[nq + nd + 1] = done ? T(1) : T(0);
+    }
+    xr[in_dim + 1] = done ? T(1) : T(0);
+  }
+  if constexpr (!LOOP) {
+    // straight-line build: exactly one normal step, no reset -> the environment is finished here;
+    // observation (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288) and resident state go
+    // out straight from registers
+    if (live && di >= 0) {
+      if (obs_out != nullptr) {
+        T *const ob = obs_out + (size_t)env * (nq + nd + 2);
+        ob[di] = di < 2 ? T(0) : q_new;
+        ob[nq + di] = qd_new;
+      }
+      if (x_feedback != nullptr) {
+        x_feedback[(size_t)env * in_dim + di] = q_new;
+        x_feedback[(size_t)env * in_dim + nq + di] = qd_new;
+      }
+    }
+  } else {
+    TDS_WAVE_SYNC();
+    const bool will_reset = last_run && ctl.reset_mode == TDS_RESET_AUTO && xr[in_dim + 1] != T(0);
+
+    // ---- mode transition of this lane group
+    bool finished = false;
+    if (mode == TDS_MODE_RUN) {
+      if (--left == 0) {
+        if (will_reset) {  // auto_reset_when_done (ars_vectorized_environment.h:262-277)
+          reset_state();
+          if (nset > 0) {
+            mode = TDS_MODE_SETTLE;
+            left = nset;
+          } else {
+            mode = TDS_MODE_IDLE;
+            finished = true;
+          }
+        } else {
+          mode = TDS_MODE_IDLE;
+          finished = true;
+        }
+      }
+    } else if (mode == TDS_MODE_SETTLE) {
+      if (--left == 0) {
+        mode = TDS_MODE_IDLE;
+        finished = true;
+      }
+    }
+    TDS_WAVE_SYNC();
+    // ---- the environment is done with this launch: observation (obs[0] = obs[1] = 0,
+    //      ars_vectorized_environment.h:283-288) and resident state
+    if (finished && lane < nd) {
+      if (obs_out != nullptr) {
+        T *const ob = obs_out + (size_t)env * (nq + nd + 2);
+        ob[lane] = lane < 2 ? T(0) : xr[lane];
+        ob[nq + lane] = xr[nq + lane];
+      }
+      if (x_feedback != nullptr) {
+        x_feedback[(size_t)env * in_dim + lane] = xr[lane];
+        x_feedback[(size_t)env * in_dim + nq + lane] = xr[nq + lane];
+      }
+    }
+  }
+  ++tds_iter;
+  if constexpr (!LOOP) break;
+  }  // ================================ end of the step loop ================================
   TDS_STAMP(13);
 }
 
@@ -1185,7 +1319,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap) {
   L.ovrows = 3 * ncp - L.zrows;    // surplus rows per environment (global scratch slab)
   int o = 0;
   // persistent for the whole step
-  L.xrec = o; o += m.input_dim;
+  L.xrec = o; o += m.input_dim + 2;  // + x_{t-1} and the done flag of the step loop
   L.swd = o;  o += 6 * L.NDs;
   L.cp = o;   o += ncp ? 5 * L.NCPp : 0;
   L.Lp = o;   o += ncp ? (ndp * (ndp - 1)) / 2 : 0;
@@ -1213,7 +1347,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap) {
 template <typename T>
 int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                     const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
-                    hipStream_t stream, long long *prof) {
+                    hipStream_t stream, const TdsStepCtl &ctl, long long *prof) {
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
   const size_t shmem = (size_t)L.stride * epw * sizeof(T);
@@ -1221,12 +1355,17 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \
     if (prof)                                                                                                \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, true>), dim3(blocks), dim3(64), shmem, stream, d_model, L, \
-                         x_in, y_out, actions, x_feedback, obs_out, ovf, prof, n_envs);                      \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, true, false>), dim3(blocks), dim3(64), shmem, stream,   \
+                         d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
+    else if (simple)                                                                                         \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, false>), dim3(blocks), dim3(64), shmem, stream,  \
+                         d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else                                                                                                     \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false>), dim3(blocks), dim3(64), shmem, stream, d_model, L, \
-                         x_in, y_out, actions, x_feedback, obs_out, ovf, prof, n_envs);                      \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, true>), dim3(blocks), dim3(64), shmem, stream,   \
+                         d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
   } while (0)
+  // straight-line kernel when the launch is exactly one normal step without any reset
+  const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE;
   const int key = lanes_per_env * 100 + L.NDP;
   switch (key) {
     case 1608: TDS_LAUNCH(16, 8); break;
@@ -1249,10 +1388,13 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
   hipError_t e = hipSuccess;
 #define TDS_ATTR(GG, NN)                                                                                        \
   do {                                                                                                          \
-    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false>,                                    \
+    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, false>,                             \
                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                 \
     if (e == hipSuccess)                                                                                        \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, true>,                                   \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, true>,                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
+    if (e == hipSuccess)                                                                                        \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, true, false>,                            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
@@ -1272,7 +1414,7 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
 
 template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int);
 template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int);
-template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, double *, int, hipStream_t, long long *);
-template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, float *, int, hipStream_t, long long *);
+template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, double *, int, hipStream_t, const TdsStepCtl &, long long *);
+template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, float *, int, hipStream_t, const TdsStepCtl &, long long *);
 template int tds_kernel_max_dynamic_lds<double>(int, int, int);
 template int tds_kernel_max_dynamic_lds<float>(int, int, int);

@@ -54,6 +54,8 @@ def lib():
         L.tds_hip_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.tds_hip_step_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.tds_hip_obs_dim.argtypes = [C.c_void_p]
+        L.tds_hip_set_auto_reset.argtypes = [C.c_void_p, C.c_int, C.c_ulonglong]
+        L.tds_hip_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.tds_hip_forward_zero_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tds_hip_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -69,6 +71,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_input_dim", "tds_hip_output_dim", "tds_hip_dtype", "tds_hip_x_device",
     "tds_hip_y_device", "tds_hip_set_inputs", "tds_hip_get_inputs", "tds_hip_get_outputs",
     "tds_hip_forward_zero_device", "tds_hip_step", "tds_hip_step_obs", "tds_hip_obs_dim",
+    "tds_hip_set_auto_reset", "tds_hip_reset",
     "tds_hip_forward_zero_host",
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
 ]
@@ -187,6 +190,26 @@ class HipSim:
             assert tuple(obs.shape) == (self.num_envs, self.obs_dim + 2)
             op = C.c_void_p(obs.data_ptr())
         _check(lib().tds_hip_step_obs(self.h, ap, int(substeps), op))
+
+    def set_auto_reset(self, enable: bool, seed: int = 0):
+        """Reset (+ settle) environments whose step ends with done inside the step launch."""
+        _check(lib().tds_hip_set_auto_reset(self.h, 1 if enable else 0, C.c_ulonglong(seed & (2 ** 64 - 1))))
+
+    def reset(self, mask=None, obs=None):
+        """Re-initialise + settle the environments selected by ``mask`` (uint8 [N] device tensor,
+        None = all) on device; optionally write their observation into ``obs``."""
+        mp = None
+        if mask is not None:
+            import torch
+
+            assert mask.is_cuda and mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == self.num_envs
+            mp = C.c_void_p(mask.data_ptr())
+        op = None
+        if obs is not None:
+            assert obs.is_cuda and obs.dtype == self.torch_dtype and obs.is_contiguous()
+            assert tuple(obs.shape) == (self.num_envs, self.obs_dim + 2)
+            op = C.c_void_p(obs.data_ptr())
+        _check(lib().tds_hip_reset(self.h, mp, op))
 
     @property
     def obs_dim(self) -> int:

@@ -18,6 +18,7 @@ TDS_MAX_LINKS = 32
 TDS_MAX_GEOMS = 32
 TDS_MAX_VISUALS = 32
 TDS_MAX_ACTIONS = 32
+TDS_MAX_DOF = 32
 TDS_MAX_CONTACTS = 32
 
 TDS_STEP_LOCOMOTION = 0
@@ -101,6 +102,10 @@ class Model(C.Structure):
         ("restitution", C.c_double),
         ("action_limit", C.c_double),
         ("initial_poses", C.c_double * TDS_MAX_ACTIONS),
+        ("reset_q", C.c_double * TDS_MAX_DOF),
+        ("reset_noise", C.c_double * TDS_MAX_DOF),
+        ("settle_steps", C.c_int32),
+        ("pad2_", C.c_int32),
         ("links", Link * TDS_MAX_LINKS),
         ("geoms", Geom * TDS_MAX_GEOMS),
         ("visuals", Visual * TDS_MAX_VISUALS),
@@ -134,7 +139,7 @@ class Model(C.Structure):
 _SCALARS = [
     "abi_version", "step_mode", "num_links", "dof_q", "dof_qd", "is_floating", "num_geoms",
     "num_visuals", "action_dim", "pd_start_link", "has_plane", "pgs_iterations", "input_dim",
-    "output_dim", "pack_visuals", "reward_mode", "dt", "plane_constant", "cfm", "erp", "friction",
+    "output_dim", "pack_visuals", "reward_mode", "settle_steps", "dt", "plane_constant", "cfm", "erp", "friction",
     "restitution", "action_limit",
 ]
 _VECTORS = ["gravity", "base_X_world_rot", "base_X_world_trans", "plane_normal"]
@@ -173,6 +178,8 @@ def model_to_dict(m: Model) -> dict:
     d["name"] = m.name.decode()
     d["initial_poses"] = [float(m.initial_poses[i]) for i in range(m.action_dim)] \
         if m.step_mode == TDS_STEP_LOCOMOTION else []
+    d["reset_q"] = [float(m.reset_q[i]) for i in range(m.dof_q)]
+    d["reset_noise"] = [float(m.reset_noise[i]) for i in range(m.dof_q)]
     d["links"] = [_struct_to_dict(m.links[i]) for i in range(m.num_links)]
     d["geoms"] = [_struct_to_dict(m.geoms[i]) for i in range(m.num_geoms)]
     d["visuals"] = [_struct_to_dict(m.visuals[i]) for i in range(m.num_visuals)]
@@ -190,6 +197,10 @@ def model_from_dict(d: dict) -> Model:
     m.name = d["name"].encode()
     for i, x in enumerate(d["initial_poses"]):
         m.initial_poses[i] = x
+    for i, x in enumerate(d.get("reset_q", [])):
+        m.reset_q[i] = x
+    for i, x in enumerate(d.get("reset_noise", [])):
+        m.reset_noise[i] = x
     for i, l in enumerate(d["links"]):
         _dict_to_struct(l, m.links[i])
     for i, g in enumerate(d["geoms"]):
