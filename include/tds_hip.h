@@ -261,6 +261,13 @@ int tds_hip_reset(tds_hip_sim_t *sim, const unsigned char *mask_dev, void *obs_d
    H2D(x) -> kernel -> D2H(y), i.e. exactly what the reference's <model>_forward_zero does. */
 int tds_hip_forward_zero_host(tds_hip_sim_t *sim, int n, const double *x_host, double *y_host);
 
+/* The same call split the way the reference's newer generated-library ABI splits it
+   (src/utils/cuda/cuda_function.hpp:11-20, 78-99: <fn>_send_local, then <fn>):
+   send_local uploads the first n input records; forward_zero_fetch runs the kernel on the
+   first n resident records and downloads their outputs. Both block. */
+int tds_hip_send_local(tds_hip_sim_t *sim, int n, const double *x_host);
+int tds_hip_forward_zero_fetch(tds_hip_sim_t *sim, int n, double *y_host);
+
 /* Time of the most recent kernel launch sequence measured with HIP events on the handle's
    stream, in milliseconds (enabled by tds_hip_set_timing(sim, 1); synchronises). */
 int tds_hip_set_timing(tds_hip_sim_t *sim, int enable);

@@ -96,3 +96,29 @@ def test_legacy_shim_exports_reference_symbols(name, built):
     md = meta()
     m = tds_amd.load_model(name)
     assert (md.output_dim, md.input_dim, md.global_dim) == (m.output_dim, m.input_dim, 0)
+
+
+@pytest.mark.parametrize("name", ["ant", "laikago"])
+def test_newer_abi_library_exports_reference_symbols(name, built):
+    """cudalib_<env>.so must export what CudaLibrary<double> / CudaFunction<double> dlsym()
+    (reference: src/utils/cuda/cuda_library.hpp:50-56, cuda_function.hpp:78-99)."""
+    import torch  # noqa: F401  one HIP runtime per process
+    L = C.CDLL(os.path.join(ROOT, "tiny-differentiable-simulator_amd", f"cudalib_{name}.so"))
+
+    class Meta(C.Structure):
+        _fields_ = [("output_dim", C.c_int), ("local_input_dim", C.c_int),
+                    ("global_input_dim", C.c_int), ("accumulated_output", C.c_bool)]
+
+    names = C.POINTER(C.c_char_p)()
+    count = C.c_int(0)
+    L.model_info(C.byref(names), C.byref(count))
+    assert count.value == 1 and names[0].decode() == f"cuda_model_{name}"
+    base = names[0].decode() + "_forward_zero"
+    for suffix in ("", "_meta", "_allocate", "_deallocate", "_send_local", "_send_global"):
+        assert hasattr(L, base + suffix)
+    meta = getattr(L, base + "_meta")
+    meta.restype = Meta
+    md = meta()
+    m = tds_amd.load_model(name)
+    assert (md.output_dim, md.local_input_dim, md.global_input_dim, md.accumulated_output) == \
+        (m.output_dim, m.input_dim, 0, False)

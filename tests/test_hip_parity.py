@@ -174,6 +174,41 @@ def test_legacy_forward_zero_library(name, built):
     assert rel_err(y, g["y"]) < TOL
 
 
+@pytest.mark.parametrize("name", ["ant", "laikago"])
+def test_newer_abi_forward_zero_library(name, built):
+    """cudalib_<env>.so driven the way CudaFunction<double>::operator() drives a generated library
+    (reference: src/utils/cuda/cuda_function.hpp:117-140): send_global, send_local, then launch."""
+    import ctypes as C
+    from conftest import ROOT
+    _torch()
+    L = C.CDLL(os.path.join(ROOT, "tiny-differentiable-simulator_amd", f"cudalib_{name}.so"))
+    base = f"cuda_model_{name}_forward_zero"
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = g["x"].shape[0]
+    x = np.ascontiguousarray(g["x"])
+    y = np.zeros_like(g["y"])
+    send_local = getattr(L, base + "_send_local")
+    send_local.argtypes = [C.c_int, C.c_void_p]
+    send_local.restype = C.c_bool
+    send_global = getattr(L, base + "_send_global")
+    send_global.argtypes = [C.c_void_p]
+    send_global.restype = C.c_bool
+    assert not send_local(n, x.ctypes.data)          # before allocate: message + false
+    getattr(L, base + "_allocate")(C.c_int(n))
+    assert send_global(x.ctypes.data) and send_local(n, x.ctypes.data)
+    fn = getattr(L, base)
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    fn(n, (n + 63) // 64, 64, y.ctypes.data)
+    assert rel_err(y, g["y"]) < TOL
+    # a smaller batch through the same allocation
+    k = n // 2
+    y2 = np.zeros((k, y.shape[1]))
+    assert send_local(k, x[n - k:].ctypes.data)
+    fn(k, 1, 64, y2.ctypes.data)
+    getattr(L, base + "_deallocate")()
+    assert rel_err(y2, g["y"][n - k:]) < TOL
+
+
 @pytest.mark.parametrize("na_cap", [1, 3, 8, 17])
 def test_constraint_row_overflow_slab(na_cap, built):
     """Constraint rows beyond the LDS capacity (na_cap contacts) live in a global scratch slab.

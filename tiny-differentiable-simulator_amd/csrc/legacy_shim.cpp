@@ -11,6 +11,20 @@
 //                               Float *output, const Float *input);       // Float = double
 // Semantics kept: file-scope state (one instance per process), blocking call, input =
 // [global_dim globals | N * input_dim], output = N * output_dim, errors -> fprintf(stderr) + exit.
+//
+// Compiled with -DTDS_SHIM_ABI2 the same file builds  cudalib_<name>.so  with the reference's NEWER
+// generated-library ABI instead (loader src/utils/cuda/cuda_library.hpp:38-70, cuda_model.hpp:14-25,
+// cuda_function.hpp:4-20,78-140; emitter src/utils/cuda/cuda_codegen.hpp:32-231):
+//     void model_info(const char *const **names, int *count);          // -> {"cuda_model_<name>"}
+//     CudaFunctionMetaData <model>_forward_zero_meta();                // {output_dim, local_input_dim,
+//                                                                      //  global_input_dim, accumulated_output}
+//     void <model>_forward_zero_allocate(int);  void <model>_forward_zero_deallocate();
+//     bool <model>_forward_zero_send_local(int N, const Float *);      // fprintf(stderr) + false on error
+//     bool <model>_forward_zero_send_global(const Float *);            // global_input_dim == 0: no-op, true
+//     void <model>_forward_zero(int N, int num_blocks, int num_threads_per_block, Float *output);
+// (<model>_jacobian is absent, which CudaFunction tolerates: is_available() == false.)
+// The two ABIs reuse symbol names with different signatures, hence two libraries.
+//
 // num_blocks / num_threads_per_block are accepted and ignored: the launch shape of the MI355X
 // kernel (wave-group per environment) is not the one-thread-per-environment shape of the
 // generated CUDA kernel.
@@ -30,11 +44,20 @@
 
 typedef double Float;
 
+#ifdef TDS_SHIM_ABI2
+struct CudaFunctionMetaData {
+  int output_dim;
+  int local_input_dim;
+  int global_input_dim;
+  bool accumulated_output;
+};
+#else
 struct CudaFunctionMetaData {
   int output_dim;
   int input_dim;
   int global_dim;
 };
+#endif
 
 static const unsigned char g_blob[] = {
 #include TDS_SHIM_BLOB
@@ -59,6 +82,24 @@ static const tds_model_t *shim_model(void) {
 
 extern "C" {
 
+#ifdef TDS_SHIM_ABI2
+#define TDS_STR2(x) #x
+#define TDS_STR(x) TDS_STR2(x)
+void model_info(const char *const **names, int *count) {
+  static const char *const g_names[] = {"cuda_model_" TDS_STR(TDS_SHIM_MODEL)};
+  *names = g_names;
+  *count = 1;
+}
+
+CudaFunctionMetaData SHIM_FN(_forward_zero_meta)(void) {
+  CudaFunctionMetaData d;
+  d.output_dim = shim_model()->output_dim;
+  d.local_input_dim = shim_model()->input_dim;
+  d.global_input_dim = 0;
+  d.accumulated_output = false;
+  return d;
+}
+#else
 CudaFunctionMetaData SHIM_FN(_forward_zero_meta)(void) {
   CudaFunctionMetaData d;
   d.output_dim = shim_model()->output_dim;
@@ -66,6 +107,7 @@ CudaFunctionMetaData SHIM_FN(_forward_zero_meta)(void) {
   d.global_dim = 0;
   return d;
 }
+#endif
 
 void SHIM_FN(_forward_zero_allocate)(int num_total_threads) {
   if (g_sim) {
@@ -89,6 +131,38 @@ void SHIM_FN(_forward_zero_deallocate)(void) {
   g_capacity = 0;
 }
 
+#ifdef TDS_SHIM_ABI2
+bool SHIM_FN(_forward_zero_send_local)(int num_total_threads, const Float *input) {
+  if (!g_sim || num_total_threads > g_capacity) {
+    fprintf(stderr, "tds_hip shim: send_local(%d) without a matching allocate(%d)\n", num_total_threads, g_capacity);
+    return false;
+  }
+  if (tds_hip_send_local(g_sim, num_total_threads, input) != TDS_OK) {
+    fprintf(stderr, "tds_hip shim: send_local failed: %s\n", tds_hip_last_error());
+    return false;
+  }
+  return true;
+}
+
+bool SHIM_FN(_forward_zero_send_global)(const Float *input) {
+  (void)input;  // global_input_dim == 0
+  return true;
+}
+
+void SHIM_FN(_forward_zero)(int num_total_threads, int num_blocks, int num_threads_per_block, Float *output) {
+  (void)num_blocks;
+  (void)num_threads_per_block;
+  if (!g_sim || num_total_threads > g_capacity) {
+    fprintf(stderr, "tds_hip shim: forward_zero(%d) without a matching allocate(%d)\n", num_total_threads, g_capacity);
+    exit(1);
+  }
+  int rc = tds_hip_forward_zero_fetch(g_sim, num_total_threads, output);
+  if (rc != TDS_OK) {
+    fprintf(stderr, "tds_hip shim: forward_zero failed: %s\n", tds_hip_last_error());
+    exit(rc);
+  }
+}
+#else
 void SHIM_FN(_forward_zero)(int num_total_threads, int num_blocks, int num_threads_per_block, Float *output,
                             const Float *input) {
   (void)num_blocks;
@@ -103,5 +177,6 @@ void SHIM_FN(_forward_zero)(int num_total_threads, int num_blocks, int num_threa
     exit(rc);
   }
 }
+#endif
 
 }  // extern "C"

@@ -321,6 +321,20 @@ int tds_hip_forward_zero_host(tds_hip_sim_t *s, int n, const double *x_host, dou
   return download(s, y_host, s->d_y, (size_t)n * s->model.output_dim);
 }
 
+int tds_hip_send_local(tds_hip_sim_t *s, int n, const double *x_host) {
+  if (!s || !x_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (n < 1 || n > s->num_envs) return fail(TDS_ERR_INVALID_ARG, "n out of range");
+  return upload(s, s->d_x, x_host, (size_t)n * s->model.input_dim);
+}
+
+int tds_hip_forward_zero_fetch(tds_hip_sim_t *s, int n, double *y_host) {
+  if (!s || !y_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (n < 1 || n > s->num_envs) return fail(TDS_ERR_INVALID_ARG, "n out of range");
+  int rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n, 1, TDS_RESET_NONE, nullptr);
+  if (rc != TDS_OK) return rc;
+  return download(s, y_host, s->d_y, (size_t)n * s->model.output_dim);
+}
+
 int tds_hip_set_timing(tds_hip_sim_t *s, int enable) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   s->timing = enable != 0;

@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_y_device", "tds_hip_set_inputs", "tds_hip_get_inputs", "tds_hip_get_outputs",
     "tds_hip_forward_zero_device", "tds_hip_step", "tds_hip_step_obs", "tds_hip_obs_dim",
     "tds_hip_set_auto_reset", "tds_hip_reset",
-    "tds_hip_forward_zero_host",
+    "tds_hip_forward_zero_host", "tds_hip_send_local", "tds_hip_forward_zero_fetch",
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
 ]
 
