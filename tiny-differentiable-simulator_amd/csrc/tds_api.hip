@@ -185,12 +185,12 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   const void *hsrc;
   if (dtype == TDS_DTYPE_F64) {
     tds_build_dev_model<double>(model, &s->h64, why);
-    s->lds = tds_make_lds_layout<double>(s->h64, na_cap);
+    s->lds = tds_make_lds_layout<double>(s->h64, na_cap, s->lanes);
     msize = sizeof(DevModel<double>);
     hsrc = &s->h64;
   } else {
     tds_build_dev_model<float>(model, &s->h32, why);
-    s->lds = tds_make_lds_layout<float>(s->h32, na_cap);
+    s->lds = tds_make_lds_layout<float>(s->h32, na_cap, s->lanes);
     msize = sizeof(DevModel<float>);
     hsrc = &s->h32;
   }

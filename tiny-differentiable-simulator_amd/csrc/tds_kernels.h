@@ -12,7 +12,7 @@
 // Per-environment LDS layout, offsets in units of the compute scalar T (see tds_make_lds_layout).
 struct TdsLds {
   int stride;              // scalars per environment
-  int NLp, NDP, NDs, NCPp; // links, padded dof (8/16/24/32), dof row stride (odd), contact-point stride
+  int NLp, NDP, NDs, NCPp; // links, padded dof (8/14/16/18/24/32), dof row stride (odd), contact-point stride
   int zrows, ovrows;       // constraint rows held in LDS / surplus rows per env in the global slab
   int xrec, swd, cp, Lp, dinv, rows, xrow;  // persistent
   int Xw, v;               // phase group 1 (kinematics sweep)   } the three groups alias
@@ -34,7 +34,7 @@ struct TdsStepCtl {
 };
 
 template <typename T>
-TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap);  // na_cap: contacts whose rows stay in LDS (<=0: all)
+TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env);  // na_cap: contacts whose rows stay in LDS (<=0: all)
 
 // Enqueue one step  y = f(x)  for n_envs environments on `stream`.
 //   actions    (optional) [n_envs][action_dim] overrides the action slice of x
@@ -49,4 +49,4 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
 template <typename T>
 int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes);
 
-int tds_padded_dof(int nd);
+int tds_padded_dof(int nd, int lanes_per_env = 0);

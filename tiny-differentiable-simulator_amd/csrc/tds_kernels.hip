@@ -1290,8 +1290,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       }
     }
   }
-  ++tds_iter;
   if constexpr (!LOOP) break;
+  ++tds_iter;
   }  // ================================ end of the step loop ================================
   TDS_STAMP(13);
 }
@@ -1301,14 +1301,21 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 // ------------------------------------------------------------------------------------------
 // host side: LDS layout + launch
 // ------------------------------------------------------------------------------------------
-int tds_padded_dof(int nd) { return nd <= 8 ? 8 : (nd <= 16 ? 16 : (nd <= 24 ? 24 : 32)); }
+// padded dof count = template parameter NDP of the kernel.  Besides the coarse widths (8/16/24/32) the
+// widths of the two benchmark robots are instantiated exactly for their natural lane count
+// (Ant: 14 dof on 16 lanes, Laikago: 18 dof on 32 lanes): LDL^T and the row solves scale with NDP^2.
+int tds_padded_dof(int nd, int lanes) {
+  if (lanes == 16 && nd > 8 && nd <= 14) return 14;
+  if (lanes == 32 && nd > 16 && nd <= 18) return 18;
+  return nd <= 8 ? 8 : (nd <= 16 ? 16 : (nd <= 24 ? 24 : 32));
+}
 
 template <typename T>
-TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap) {
+TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) {
   TdsLds L;
   memset(&L, 0, sizeof(L));
   const int nl = m.num_links;
-  const int ndp = tds_padded_dof(m.dof_qd);
+  const int ndp = tds_padded_dof(m.dof_qd, lanes_per_env);
   L.NLp = nl;
   L.NDP = ndp;
   L.NDs = ndp + 1;  // odd row stride: lane == row accesses hit distinct LDS banks
@@ -1369,6 +1376,8 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
   const int key = lanes_per_env * 100 + L.NDP;
   switch (key) {
     case 1608: TDS_LAUNCH(16, 8); break;
+    case 1614: TDS_LAUNCH(16, 14); break;
+    case 3218: TDS_LAUNCH(32, 18); break;
     case 1616: TDS_LAUNCH(16, 16); break;
     case 3208: TDS_LAUNCH(32, 8); break;
     case 3216: TDS_LAUNCH(32, 16); break;
@@ -1399,6 +1408,8 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
     case 1608: TDS_ATTR(16, 8); break;
+    case 1614: TDS_ATTR(16, 14); break;
+    case 3218: TDS_ATTR(32, 18); break;
     case 1616: TDS_ATTR(16, 16); break;
     case 3208: TDS_ATTR(32, 8); break;
     case 3216: TDS_ATTR(32, 16); break;
@@ -1412,8 +1423,8 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
   return (int)e;
 }
 
-template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int);
-template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int);
+template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int);
+template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int, int);
 template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, double *, int, hipStream_t, const TdsStepCtl &, long long *);
 template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, float *, int, hipStream_t, const TdsStepCtl &, long long *);
 template int tds_kernel_max_dynamic_lds<double>(int, int, int);
