@@ -11,6 +11,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "tds_hip.h"
@@ -36,6 +37,10 @@ struct DevModel {
   int parent[TDS_NL], level[TDS_NL], joint_type[TDS_NL], q_index[TDS_NL], qd_index[TDS_NL];
   int act_index[TDS_NL];        // PD pose_index of this link or -1 (locomotion_contact_simulation.h:179-257)
   uint32_t anc_dofs[TDS_NL];    // bit d set: dof d lies on the path base -> link (incl. own)
+  // chain hand-over of the tree sweeps (lane == link): bit 0: parent == link - 1 inside one 16-lane
+  // DPP row -> sweep state travels by DPP row shift; bit 1: link + 1 is such a child of mine;
+  // bit 2: I have children that are NOT link + 1 -> they use my per-link LDS record
+  int chain_flags[TDS_NL];
   T X_T[12][TDS_NL];            // rot (row-major 9) | trans (3)
   T S[6][TDS_NL];
   T mass[TDS_NL], com[3][TDS_NL], inertia[9][TDS_NL];
@@ -177,6 +182,21 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
     d->damping[i] = (T)l.damping;
   }
   if (ndof != nd) TDS_FAIL(TDS_ERR_INVALID_ARG, "dof_qd does not match the joints");
+  {
+    // TDS_HIP_NO_CHAIN=1 sends every parent/child hand-over through LDS (A/B testing of the two paths)
+    const char *nc = getenv("TDS_HIP_NO_CHAIN");
+    const bool use_chain = !(nc && nc[0] == '1');
+    for (int i = 0; i < m->num_links; ++i) {
+      const int par = m->links[i].parent;
+      if (par < 0) continue;
+      if (use_chain && par == i - 1 && (i % 16) != 0) {
+        d->chain_flags[i] |= 1;
+        d->chain_flags[par] |= 2;
+      } else {
+        d->chain_flags[par] |= 4;
+      }
+    }
+  }
   d->num_levels = max_level + 1;
   // CRBA pair list
   int np = 0;

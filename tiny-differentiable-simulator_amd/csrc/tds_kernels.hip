@@ -157,6 +157,21 @@ __device__ __forceinline__ float dpp_add(float v) {
   const int b = __float_as_int(v);
   return v + __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, 0xF, 0xF, false));
 }
+// value of the neighbouring lane inside a 16-lane DPP row (VALU move, no LDS): FROM_NEXT: lane i
+// receives lane i+1 (row_shl:1), else lane i receives lane i-1 (row_shr:1); 0 at the row boundary.
+template <bool FROM_NEXT>
+__device__ __forceinline__ double dpp_neighbour(double v) {
+  constexpr int CTRL = FROM_NEXT ? 0x101 : 0x111;
+  const int l = __double2loint(v), h = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, l, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, h, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <bool FROM_NEXT>
+__device__ __forceinline__ float dpp_neighbour(float v) {
+  constexpr int CTRL = FROM_NEXT ? 0x101 : 0x111;
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 // 32 payload bits carried through an LDS slot of the compute scalar (no arithmetic on them)
 template <typename T>
 __device__ __forceinline__ T bits_to_scalar(unsigned b);
@@ -387,6 +402,65 @@ __device__ __forceinline__ T tds_pgs(int lane, int nr, int na, int ZR, int OVR, 
 }
 
 
+// The common case of tds_pgs: every row of the wavefront's environments is in LDS.  Wave-uniform
+// trip count (groups with fewer rows run zero rows that leave u~ untouched) and NO control flow
+// around the loads: everything row r + 1 needs — including the normal impulse its friction box
+// depends on — is fetched unconditionally (row index clamped) while row r is being reduced, so the
+// loop-carried chain is only: u~ -> dot -> 4 DPP adds -> clamp -> u~.
+template <bool FIRST, typename T, int G, int NDP>
+__device__ __forceinline__ T tds_pgs_sweep(T u, int lane, int nr, int na, int ZR, T mu, const T *Zs, const T *rws,
+                                           T *xs) {
+  constexpr int NDs = NDP + 1;
+  const int dcl = lane < NDP ? lane : NDP - 1;  // lanes >= NDP read a valid slot and discard it
+  const bool dz = lane < NDP;
+  const int na2 = 2 * na;
+  const int last = ZR - 1;
+  T zn = Zs[dcl], bn = rws[0], an = rws[ZR], gn = rws[2 * ZR], xon = FIRST ? T(0) : xs[0], sn = T(0);
+  bool act = nr > 0;
+  for (int r = 0; __any(r < nr); ++r) {
+    const bool live = act && dz;
+    const T zr = live ? zn : T(0);
+    const T br = act ? bn : T(0), ar = act ? an : T(0), gr = act ? gn : T(0);
+    const T x_old = (!FIRST && act) ? xon : T(0);
+    const T sdep = sn;
+    const int rn = r + 1;
+    const int rl = rn < last ? rn : last;  // clamped: the load is unconditional
+    // limit_dependency_ of row r + 1 (mb_constraint_solver.hpp:417-436): its contact's normal row
+    int depn = rn - (rn >= na ? na : 0) - (rn >= na2 ? na : 0);
+    const bool dep_is_r = depn == r;
+    depn = depn < last ? depn : last;
+    zn = Zs[rl * NDs + dcl];
+    bn = rws[rl];
+    an = rws[ZR + rl];
+    gn = rws[2 * ZR + rl];
+    if constexpr (!FIRST) xon = xs[rl];
+    const T sload = xs[depn];  // stale only if depn == r (single contact): patched below
+    const bool is_n = r < na;
+    const T jw = group_sum<T, G>(zr * u);
+    T delta = jw;
+    if constexpr (!FIRST) delta -= gr * x_old;
+    T xn = (br - delta) * ar;
+    const T sc = sdep > T(0) ? sdep : T(0);  // where_lt(s, 0, 0, s)
+    const T lo = is_n ? T(0) : -mu * sc;
+    const T hi = is_n ? T(100000) : mu * sc;
+    xn = max_t<T>(xn, lo);  // Algebra::max(x, lo*s)
+    xn = min_t<T>(xn, hi);  // Algebra::min(x, hi*s)
+    if constexpr (FIRST) u += zr * xn; else u += zr * (xn - x_old);
+    if (lane == 0 && act) xs[r] = xn;
+    sn = dep_is_r ? xn : sload;
+    act = rn < nr;
+  }
+  return u;
+}
+
+template <typename T, int G, int NDP>
+__device__ __forceinline__ T tds_pgs_lds(int lane, int nr, int na, int ZR, int iters, T mu, const T *Zs,
+                                         const T *rws, T *xs) {
+  T u = tds_pgs_sweep<true, T, G, NDP>(T(0), lane, nr, na, ZR, mu, Zs, rws, xs);
+  for (int it = 1; it < iters; ++it) u = tds_pgs_sweep<false, T, G, NDP>(u, lane, nr, na, ZR, mu, Zs, rws, xs);
+  return u;
+}
+
 // ------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------
@@ -516,6 +590,13 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   const int level = isl ? mdl->level[lsafe] : -1;
   const int jt = isl ? mdl->joint_type[lsafe] : TDS_JOINT_FIXED;
   const int di = isl ? mdl->qd_index[lsafe] : -1;  // == q_index (1-DoF joints only)
+  // Serial chains (parent == lane - 1, the common case for URDF-derived trees) hand their sweep
+  // state from lane to lane with DPP row shifts; only the other parent/child links go through the
+  // per-link LDS records (see DESIGN.md "chain hand-over").
+  const int cflags = isl ? mdl->chain_flags[lsafe] : 0;
+  const bool chain_child = (cflags & 1) != 0;      // my parent is lane - 1
+  const bool has_chain_child = (cflags & 2) != 0;  // lane + 1 is my child and hands over by DPP
+  const bool lds_children = (cflags & 4) != 0;     // I have children that are not lane + 1
   for (;;) {  // ================================ step loop ================================
   if constexpr (LOOP) {
     if (!__any(mode != TDS_MODE_IDLE)) break;
@@ -629,16 +710,34 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   for (int k = 0; k < 6; ++k) sw[k] = vJ[k] = v[k] = T(0);
   const int nlev = mdl->num_levels;
   for (int lev = 0; lev < nlev; ++lev) {
-    if (level == lev) {
-      T Rq[9], pq[3], vq[6];
-      if (parent >= 0) {
+    const bool mine = level == lev;
+    const bool by_dpp = mine && chain_child;
+    const bool by_lds = mine && parent >= 0 && !chain_child;
+    T Rq[9], pq[3], vq[6];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rq[k] = Xw[parent * TDS_S1 + k];
+    for (int k = 0; k < 9; ++k) Rq[k] = T(0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pq[k] = Xw[parent * TDS_S1 + 9 + k];
+    for (int k = 0; k < 3; ++k) pq[k] = T(0);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) vq[k] = vv[parent * TDS_S1 + k];
-      } else {
+    for (int k = 0; k < 6; ++k) vq[k] = T(0);
+    if (__any(by_dpp)) {  // wave-uniform; the moves themselves run on every lane
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rq[k] = dpp_neighbour<false>(R[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pq[k] = dpp_neighbour<false>(p[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vq[k] = dpp_neighbour<false>(v[k]);
+    }
+    if (by_lds) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rq[k] = Xw[parent * TDS_S1 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pq[k] = Xw[parent * TDS_S1 + 9 + k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vq[k] = vv[parent * TDS_S1 + k];
+    }
+    if (mine) {
+      if (parent < 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rq[k] = mdl->base_R[k];
 #pragma unroll
@@ -665,19 +764,29 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         vJ[k] = sw[k] * qd;
         v[k] = vq[k] + vJ[k];
       }
+      if (lds_children) {  // children other than lane + 1 read my record
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
+        for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
+        for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) vv[li * TDS_S1 + k] = v[k];
-      if (di >= 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) swd[k * NDs + di] = sw[k];
+        for (int k = 0; k < 6; ++k) vv[li * TDS_S1 + k] = v[k];
       }
     }
-    TDS_WAVE_SYNC();
+    if (__any(mine && lds_children)) TDS_WAVE_SYNC();
   }
+  // X_world of the remaining links (narrowphase, visual poses) and the world motion axes per dof
+  if (isl && !lds_children) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
+  }
+  if (di >= 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) swd[k * NDs + di] = sw[k];
+  }
+  TDS_WAVE_SYNC();
 
   TDS_STAMP(3);
   // ---- I. narrowphase right after the kinematics sweep (it only needs X_world), so that the
@@ -792,6 +901,16 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     cb[4] = c1[1] + c2[1];
     cb[5] = c1[2] + c2[2];
   }
+  // The link's own articulated inertia IA = [I H; H^T M] (I, M symmetric), bias pA and CRBA composite
+  // inertia Ic = (I, h, m) stay in REGISTERS; a record in LDS exists only to collect the children that
+  // are not lane + 1 (zeroed here, accumulated with ds_add in the sweep).
+  T I6[6], H9[9], M6[6], pa[6], Ic[10];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) I6[k] = M6[k] = pa[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) H9[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) Ic[k] = T(0);
   if (isl) {
     const T m = mass_l;
     T cw[3];
@@ -807,17 +926,17 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
       for (int c = 0; c < 3; ++c) Iw[3 * r + c] = RI[3 * r] * R[3 * c] + RI[3 * r + 1] * R[3 * c + 1] + RI[3 * r + 2] * R[3 * c + 2];
     const T c2 = dot3(cw, cw);
-    T Is[6];  // I = Icom + m (|c|^2 1 - c c^T)
-    Is[0] = Iw[0] + m * (c2 - cw[0] * cw[0]);
-    Is[1] = T(0.5) * (Iw[1] + Iw[3]) - m * cw[0] * cw[1];
-    Is[2] = T(0.5) * (Iw[2] + Iw[6]) - m * cw[0] * cw[2];
-    Is[3] = Iw[4] + m * (c2 - cw[1] * cw[1]);
-    Is[4] = T(0.5) * (Iw[5] + Iw[7]) - m * cw[1] * cw[2];
-    Is[5] = Iw[8] + m * (c2 - cw[2] * cw[2]);
+    // I = Icom + m (|c|^2 1 - c c^T)
+    I6[0] = Iw[0] + m * (c2 - cw[0] * cw[0]);
+    I6[1] = T(0.5) * (Iw[1] + Iw[3]) - m * cw[0] * cw[1];
+    I6[2] = T(0.5) * (Iw[2] + Iw[6]) - m * cw[0] * cw[2];
+    I6[3] = Iw[4] + m * (c2 - cw[1] * cw[1]);
+    I6[4] = T(0.5) * (Iw[5] + Iw[7]) - m * cw[1] * cw[2];
+    I6[5] = Iw[8] + m * (c2 - cw[2] * cw[2]);
     const T h[3] = {m * cw[0], m * cw[1], m * cw[2]};
     // I v = (I w + h x v_lin, m v_lin - h x w)
     T Iv[6], t3[3];
-    sym3_mulv(Is, v, Iv);
+    sym3_mulv(I6, v, Iv);
     cross3(h, v + 3, t3);
     Iv[0] += t3[0];
     Iv[1] += t3[1];
@@ -827,40 +946,32 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     Iv[4] = m * v[4] - t3[1];
     Iv[5] = m * v[5] - t3[2];
     // pA = v x* (I v) = (w x n + v x f, w x f)      (f_ext = 0 after clear_forces)
-    T pa0[6], u3[3];
-    cross3(v, Iv, pa0);
+    T u3[3];
+    cross3(v, Iv, pa);
     cross3(v + 3, Iv + 3, u3);
-    pa0[0] += u3[0];
-    pa0[1] += u3[1];
-    pa0[2] += u3[2];
-    cross3(v, Iv + 3, pa0 + 3);
+    pa[0] += u3[0];
+    pa[1] += u3[1];
+    pa[2] += u3[2];
+    cross3(v, Iv + 3, pa + 3);
+    // H = [h]x,  M = m 1
+    H9[1] = -h[2]; H9[2] = h[1];
+    H9[3] = h[2];  H9[5] = -h[0];
+    H9[6] = -h[1]; H9[7] = h[0];
+    M6[0] = M6[3] = M6[5] = m;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      IAs[li * TDS_S2 + k] = Is[k];
-      Ics[li * TDS_S2 + k] = Is[k];
-      pAs[li * TDS_S2 + k] = pa0[k];
+    for (int k = 0; k < 6; ++k) Ic[k] = I6[k];
+    Ic[6] = h[0];
+    Ic[7] = h[1];
+    Ic[8] = h[2];
+    Ic[9] = m;
+    if (lds_children) {
+#pragma unroll
+      for (int k = 0; k < 21; ++k) IAs[li * TDS_S2 + k] = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = T(0);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) Ics[li * TDS_S2 + k] = T(0);
     }
-    // H = [h]x
-    IAs[li * TDS_S2 + 6] = T(0);
-    IAs[li * TDS_S2 + 7] = -h[2];
-    IAs[li * TDS_S2 + 8] = h[1];
-    IAs[li * TDS_S2 + 9] = h[2];
-    IAs[li * TDS_S2 + 10] = T(0);
-    IAs[li * TDS_S2 + 11] = -h[0];
-    IAs[li * TDS_S2 + 12] = -h[1];
-    IAs[li * TDS_S2 + 13] = h[0];
-    IAs[li * TDS_S2 + 14] = T(0);
-    // M = m 1
-    IAs[li * TDS_S2 + 15] = m;
-    IAs[li * TDS_S2 + 16] = T(0);
-    IAs[li * TDS_S2 + 17] = T(0);
-    IAs[li * TDS_S2 + 18] = m;
-    IAs[li * TDS_S2 + 19] = T(0);
-    IAs[li * TDS_S2 + 20] = m;
-    Ics[li * TDS_S2 + 6] = h[0];
-    Ics[li * TDS_S2 + 7] = h[1];
-    Ics[li * TDS_S2 + 8] = h[2];
-    Ics[li * TDS_S2 + 9] = m;
   }
   TDS_WAVE_SYNC();
 
@@ -873,16 +984,23 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   for (int k = 0; k < 6; ++k) U[k] = Fc[k] = T(0);
   const bool want_crba = wave_contacts;
   for (int lev = nlev - 1; lev >= 0; --lev) {
-    if (level == lev) {
-      T I6[6], H9[9], M6[6], pa[6];
+    const bool mine = level == lev;
+    if (mine && lds_children) {  // what the children other than lane + 1 handed over
 #pragma unroll
-      for (int k = 0; k < 6; ++k) I6[k] = IAs[li * TDS_S2 + k];
+      for (int k = 0; k < 6; ++k) I6[k] += IAs[li * TDS_S2 + k];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) H9[k] = IAs[li * TDS_S2 + 6 + k];
+      for (int k = 0; k < 9; ++k) H9[k] += IAs[li * TDS_S2 + 6 + k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) M6[k] = IAs[li * TDS_S2 + 15 + k];
+      for (int k = 0; k < 6; ++k) M6[k] += IAs[li * TDS_S2 + 15 + k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pa[k] = pAs[li * TDS_S2 + k];
+      for (int k = 0; k < 6; ++k) pa[k] += pAs[li * TDS_S2 + k];
+      if (want_crba) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) Ic[k] += Ics[li * TDS_S2 + k];
+      }
+    }
+    const bool to_lds = mine && parent >= 0 && !chain_child;
+    if (mine) {
       // U = IA s
       T t3[3];
       sym3_mulv(I6, sw, U);
@@ -898,7 +1016,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       const T D = dot3(sw, U) + dot3(sw + 3, U + 3);
       uu = tau - (dot3(sw, pa) + dot3(sw + 3, pa + 3));
       Dinv = di >= 0 ? rcp_full<T>(D) : T(0);  // forward_dynamics.hpp:153
-      // Ia = IA - U U^T / D
+      // Ia = IA - U U^T / D   (in place: the registers now hold what the parent receives)
       T Ub[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) Ub[k] = U[k] * Dinv;
@@ -925,24 +1043,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       const T ud = uu * Dinv;
 #pragma unroll
       for (int k = 0; k < 6; ++k) pa[k] += Iac[k] + U[k] * ud;
-      if (parent >= 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[parent * TDS_S2 + k], I6[k]);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&IAs[parent * TDS_S2 + 6 + k], H9[k]);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[parent * TDS_S2 + 15 + k], M6[k]);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&pAs[parent * TDS_S2 + k], pa[k]);
-      }
       if (want_crba) {
-        T Ic[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) Ic[k] = Ics[li * TDS_S2 + k];
-        if (parent >= 0) {
-#pragma unroll
-          for (int k = 0; k < 10; ++k) atomicAdd(&Ics[parent * TDS_S2 + k], Ic[k]);
-        }
         // F = Ic s = (I w + h x v, m v - h x w)
         sym3_mulv(Ic, sw, Fc);
         cross3(Ic + 6, sw + 3, t3);
@@ -954,38 +1055,83 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         Fc[4] = Ic[9] * sw[4] - t3[1];
         Fc[5] = Ic[9] * sw[5] - t3[2];
       }
+      if (to_lds) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[parent * TDS_S2 + k], I6[k]);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) atomicAdd(&IAs[parent * TDS_S2 + 6 + k], H9[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[parent * TDS_S2 + 15 + k], M6[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&pAs[parent * TDS_S2 + k], pa[k]);
+        if (want_crba) {
+#pragma unroll
+          for (int k = 0; k < 10; ++k) atomicAdd(&Ics[parent * TDS_S2 + k], Ic[k]);
+        }
+      }
     }
-    TDS_WAVE_SYNC();
+    if (__any(mine && chain_child)) {  // wave-uniform: lane i takes over from its child in lane i + 1
+      // (select by multiplication: one FMA instead of two 32-bit selects and an add per value)
+      const T recv = (has_chain_child && level + 1 == lev) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) I6[k] += recv * dpp_neighbour<true>(I6[k]);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) H9[k] += recv * dpp_neighbour<true>(H9[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) M6[k] += recv * dpp_neighbour<true>(M6[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pa[k] += recv * dpp_neighbour<true>(pa[k]);
+      if (want_crba) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) Ic[k] += recv * dpp_neighbour<true>(Ic[k]);
+      }
+    }
+    if (__any(to_lds)) TDS_WAVE_SYNC();
   }
 
   TDS_STAMP(5);
   // ---- F. top-down sweep: accelerations, qdd  (forward_dynamics.hpp:245-302) ----------------
   T *const aas = E + L.a;
   T qdd = T(0);
-  for (int lev = 0; lev < nlev; ++lev) {
-    if (level == lev) {
-      T a[6];
-      if (parent >= 0) {
+  T acc[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) a[k] = aas[parent * TDS_S2 + k];
-      } else {  // base acceleration = -gravity (linear part)
-        a[0] = a[1] = a[2] = T(0);
-        a[3] = -mdl->grav[0];
-        a[4] = -mdl->grav[1];
-        a[5] = -mdl->grav[2];
+  for (int k = 0; k < 6; ++k) acc[k] = T(0);
+  for (int lev = 0; lev < nlev; ++lev) {
+    const bool mine = level == lev;
+    const bool by_dpp = mine && chain_child;
+    const bool by_lds = mine && parent >= 0 && !chain_child;
+    T ap[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ap[k] = T(0);
+    if (__any(by_dpp)) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ap[k] = dpp_neighbour<false>(acc[k]);
+    }
+    if (by_lds) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ap[k] = aas[parent * TDS_S2 + k];
+    }
+    if (mine) {
+      if (parent < 0) {  // base acceleration = -gravity (linear part)
+        ap[0] = ap[1] = ap[2] = T(0);
+        ap[3] = -mdl->grav[0];
+        ap[4] = -mdl->grav[1];
+        ap[5] = -mdl->grav[2];
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) a[k] += cb[k];
+      for (int k = 0; k < 6; ++k) acc[k] = ap[k] + cb[k];
       if (di >= 0) {
-        const T Uta = dot3(U, a) + dot3(U + 3, a + 3);
+        const T Uta = dot3(U, acc) + dot3(U + 3, acc + 3);
         qdd = Dinv * (uu - Uta);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) a[k] += sw[k] * qdd;
+        for (int k = 0; k < 6; ++k) acc[k] += sw[k] * qdd;
       }
+      if (lds_children) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) aas[li * TDS_S2 + k] = a[k];
+        for (int k = 0; k < 6; ++k) aas[li * TDS_S2 + k] = acc[k];
+      }
     }
-    TDS_WAVE_SYNC();
+    if (__any(mine && lds_children)) TDS_WAVE_SYNC();
   }
   // integrate_euler_qdd: qd += qdd dt  (integrator.hpp:169-181)
   T qd_new = qd + qdd * dt;
@@ -1032,6 +1178,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     //         tiny_matrix_x.h:240-345).  Right-looking; column k is gathered from the lanes that
     //         own rows k..NDP-1 with cross-lane shuffles, no LDS traffic, no barriers.
     //         Entries above the diagonal of a lane's row are never read by anyone.
+    T my_inv = T(1);  // 1 / D_lane
     static_for<0, NDP>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       if constexpr (NDP <= 16) {
@@ -1044,10 +1191,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
           const T mck = lane_bcast<T, G, NDP, c>(Mr[k]);
           Mr[c] -= lr * mck;
         });
-        if (lane == k) {
-          dvec[k] = inv;
-          dvec[NDP + k] = sqrt_t<T>(inv);
-        }
+        my_inv = lane == k ? inv : my_inv;
         Mr[k] = lane > k ? lr : Mr[k];
       } else {
         // wider systems: every lane publishes its column-k entry once, all lanes read the column
@@ -1063,15 +1207,14 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
           constexpr int c = decltype(cc)::value;
           Mr[c] -= lr * colb[c];
         });
-        if (lane == k) {
-          dvec[k] = inv;
-          dvec[NDP + k] = sqrt_t<T>(inv);
-        }
+        my_inv = lane == k ? inv : my_inv;
         Mr[k] = lane > k ? lr : Mr[k];
         TDS_WAVE_SYNC();
       }
     });
     if (lane < NDP) {
+      dvec[lane] = my_inv;
+      dvec[NDP + lane] = sqrt_t<T>(my_inv);
       const int off = (lane * (lane - 1)) / 2;
 #pragma unroll
       for (int j = 0; j < NDP - 1; ++j)
@@ -1154,7 +1297,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       const T mu = mdl->friction;
       const int iters = mdl->pgs_iterations;
       const T u = any_slab ? tds_pgs<true, T, G, NDP>(lane, nr, na, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov)
-                           : tds_pgs<false, T, G, NDP>(lane, nr, na, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov);
+                           : tds_pgs_lds<T, G, NDP>(lane, nr, na, ZR, iters, mu, Zs, rws, xs);
       // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
       T w = dz ? u * dvec[NDP + d] : T(0);
       static_for<0, NDP - 1>([&](auto ic) {
