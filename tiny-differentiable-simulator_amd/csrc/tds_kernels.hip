@@ -528,6 +528,39 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   constexpr int NDs = NDP + 1;  // odd row stride of every [row][dof] array
   const T dt = mdl->dt;
 
+  // ---- lane == link: constants -------------------------------------------------------------
+  const int li = lane;
+  const bool isl = li < nl;
+  const int lsafe = isl ? li : 0;
+  const int parent = isl ? mdl->parent[lsafe] : -1;
+  const int level = isl ? mdl->level[lsafe] : -1;
+  const int jt = isl ? mdl->joint_type[lsafe] : TDS_JOINT_FIXED;
+  const int di = isl ? mdl->qd_index[lsafe] : -1;  // == q_index (1-DoF joints only)
+  // Serial chains (parent == lane - 1, the common case for URDF-derived trees) hand their sweep
+  // state from lane to lane with DPP row shifts; only the other parent/child links go through the
+  // per-link LDS records (see DESIGN.md "chain hand-over").
+  const int cflags = isl ? mdl->chain_flags[lsafe] : 0;
+  const bool chain_child = (cflags & 1) != 0;      // my parent is lane - 1
+  const bool has_chain_child = (cflags & 2) != 0;  // lane + 1 is my child and hands over by DPP
+  const bool lds_children = (cflags & 4) != 0;     // I have children that are not lane + 1
+  // per-link model constants (joint axis, X_T, rigid inertia).  The straight-line build fetches
+  // them HERE, ahead of the x record, so that their L2 latency overlaps the HBM latency of x; the
+  // step-loop build re-fetches them per iteration (keeping ~60 VGPRs live across the loop costs more).
+  T Sl[6], mass_l, com_l[3], Il[9], RT[9], tT[3];
+  auto load_link_consts = [&](const DevModel<T> *md) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Sl[k] = md->S[k][lsafe];
+    mass_l = md->mass[lsafe];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) com_l[k] = md->com[k][lsafe];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Il[k] = md->inertia[k][lsafe];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) RT[k] = md->X_T[k][lsafe];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tT[k] = md->X_T[9 + k][lsafe];
+  };
+  if constexpr (!LOOP) load_link_consts(mdl);
   int tds_iter = 0;
   (void)tds_iter;
   TDS_STAMP(0);
@@ -582,21 +615,6 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
   }
 
-  // ---- lane == link: constants -------------------------------------------------------------
-  const int li = lane;
-  const bool isl = li < nl;
-  const int lsafe = isl ? li : 0;
-  const int parent = isl ? mdl->parent[lsafe] : -1;
-  const int level = isl ? mdl->level[lsafe] : -1;
-  const int jt = isl ? mdl->joint_type[lsafe] : TDS_JOINT_FIXED;
-  const int di = isl ? mdl->qd_index[lsafe] : -1;  // == q_index (1-DoF joints only)
-  // Serial chains (parent == lane - 1, the common case for URDF-derived trees) hand their sweep
-  // state from lane to lane with DPP row shifts; only the other parent/child links go through the
-  // per-link LDS records (see DESIGN.md "chain hand-over").
-  const int cflags = isl ? mdl->chain_flags[lsafe] : 0;
-  const bool chain_child = (cflags & 1) != 0;      // my parent is lane - 1
-  const bool has_chain_child = (cflags & 2) != 0;  // lane + 1 is my child and hands over by DPP
-  const bool lds_children = (cflags & 4) != 0;     // I have children that are not lane + 1
   for (;;) {  // ================================ step loop ================================
   if constexpr (LOOP) {
     if (!__any(mode != TDS_MODE_IDLE)) break;
@@ -637,24 +655,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
-  T Sl[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) Sl[k] = isl ? mdl->S[k][lsafe] : T(0);
-  // rigid-body inertia constants are fetched here, long before phase D needs them, so that the
-  // L2 latency of the model table hides behind the kinematics sweep
-  const T mass_l = isl ? mdl->mass[lsafe] : T(0);
-  T com_l[3], Il[9];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) com_l[k] = isl ? mdl->com[k][lsafe] : T(0);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) Il[k] = isl ? mdl->inertia[k][lsafe] : T(0);
+  if constexpr (LOOP) load_link_consts(mdl);
   T Rp[9], tp[3];
   {
-    T RT[9], tT[3];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) RT[k] = isl ? mdl->X_T[k][lsafe] : T(k % 4 == 0);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tT[k] = isl ? mdl->X_T[9 + k][lsafe] : T(0);
     const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
     const bool pris = jt >= TDS_JOINT_PRISMATIC_X && jt <= TDS_JOINT_PRISMATIC_AXIS;
     T RJ[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
