@@ -87,6 +87,19 @@ def cpu_baseline(model_name, n_envs, budget_s=12.0):
     return out
 
 
+def pmc_traffic(model, n, dtype):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json; PMC
+    counters cannot be collected from inside this process).  Guide corrections: FETCH_SIZE / WRITE_SIZE
+    are KiB; on gfx950 FETCH_SIZE counts coalesced streaming reads at half their bytes -> doubled
+    (an upper bound for our 8-byte-per-lane loads)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            e = json.load(f)[model][str(n)][dtype]
+        return int((2.0 * e["fetch_kib"] + e["write_kib"]) * 1024), e["source"]
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +110,8 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (16/32/64), 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout-steps", type=int, default=0,
+                    help="also time the on-device policy rollout with this many policy steps per launch")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
     args = ap.parse_args()
 
@@ -213,6 +228,24 @@ def main():
             kernel_ms = kernel_ms_isolated
 
     finite = bool(torch.isfinite(sim.y).all().item())
+
+    # secondary (not the headline): the same environments driven by per-environment linear policies
+    # entirely on device, R policy steps per launch (tds_hip_rollout)
+    rollout = None
+    if args.rollout_steps > 0 and world == 1 and m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
+        od = sim.obs_dim
+        pol = torch.from_numpy(rng.normal(0.0, 0.05, (n, adim * od + adim))).to(tdt).cuda().contiguous()
+        sim.rollout(pol, args.rollout_steps)
+        torch.cuda.synchronize()
+        reps = 5
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            sim.rollout(pol, args.rollout_steps)
+        torch.cuda.synchronize()
+        dt_r = time.perf_counter() - t1
+        rollout = {"value": n * args.rollout_steps * reps / dt_r, "unit": "env-steps/s",
+                   "policy_steps_per_launch": args.rollout_steps, "launches": reps,
+                   "what": "linear policy + step + reward/done + return bookkeeping, one launch per rollout"}
     if rank == 0:
         elem = 8 if args.dtype == "f64" else 4
         bytes_per_env_step = (m.input_dim + m.output_dim) * elem  # x record in + y record out
@@ -221,8 +254,9 @@ def main():
         roof = None
         if kernel_ms:
             achieved = n * bytes_per_env_step / (kernel_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(args.model, n, args.dtype)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "tds_step_kernel", "kernel_ms_avg": kernel_ms,
                     "kernel_ms_isolated": kernel_ms_isolated,
                     "algorithmic_bytes_per_launch": n * bytes_per_env_step,
@@ -241,6 +275,8 @@ def main():
                        "lds_bytes_per_env": sim.kernel_info()["lds_bytes_per_env"]},
             "roofline": roof, "finite": finite,
         }
+        if rollout is not None:
+            out["on_device_rollout"] = rollout
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(args.model, min(n, 4096))
             primary = cb.get("reference") or cb.get("port")

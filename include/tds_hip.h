@@ -257,6 +257,26 @@ int tds_hip_obs_dim(const tds_hip_sim_t *sim);
 int tds_hip_set_auto_reset(tds_hip_sim_t *sim, int enable, unsigned long long seed);
 int tds_hip_reset(tds_hip_sim_t *sim, const unsigned char *mask_dev, void *obs_dev);
 
+/* Policy rollout entirely on device: n_steps times { action = W obs + b with the
+   environment's OWN parameters; step; reward / done; return bookkeeping } in ONE launch, on the
+   resident records.  It is Worker::rollouts + VectorizedEnvironment::policy/step of the reference
+   (examples/ars/ars_vectorized_worker.h:51-140, ars_vectorized_environment.h:213-300) for the linear
+   policy those build (one linear layer obs_dim -> action_dim with bias, identity activation):
+     policy_dev        [num_envs][action_dim*obs_dim + action_dim] in the compute dtype, NeuralNetwork
+                       parameter order: weights row-major (row = action), then biases
+                       (src/math/neural_network.hpp:406-415); obs_dim = dof_q + dof_qd
+     obs               [q | qd] with obs[0] = obs[1] = 0 (ars_vectorized_environment.h:283-288);
+                       flags bit 0: the FIRST step sees the raw base x, y, as it does right after
+                       VectorizedEnvironment::reset (:196-211)
+     return_sum_dev    [num_envs] compute dtype: sum of (reward - shift) over the steps taken while the
+                       environment was not done; return_steps_dev [num_envs] int: their number
+                       (total_rewards / vec_steps of Worker::rollouts); either may be NULL
+     obs_dev           optional [num_envs][obs_dim + 2]: final observation | last reward | done
+   With tds_hip_set_auto_reset a done environment is re-initialised + settled and keeps collecting;
+   without it, it stays done (the state keeps stepping, as under the reference's custom stepper). */
+int tds_hip_rollout(tds_hip_sim_t *sim, const void *policy_dev, int n_steps, double shift, int flags,
+                    void *return_sum_dev, int *return_steps_dev, void *obs_dev);
+
 /* Blocking convenience with HOST buffers in double, any N <= num_envs:
    H2D(x) -> kernel -> D2H(y), i.e. exactly what the reference's <model>_forward_zero does. */
 int tds_hip_forward_zero_host(tds_hip_sim_t *sim, int n, const double *x_host, double *y_host);

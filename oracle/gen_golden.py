@@ -8,6 +8,9 @@ from /root/reference by oracle/Makefile):
         x [N,in]  y [N,out]            single steps from randomised states (contacts on/off)
         traj_x0 [in]  traj_y [T,out]   a T-step closed-loop rollout (y[:nq+nd] fed back)
         qdd [N,nd]  M [N,nd,nd]        intermediates (ABA result, CRBA mass matrix)
+  * tests/golden/<ant|laikago>_rollout.npz — the reference's Worker::rollouts loop (per-environment linear
+    policy, step, reward/done, return bookkeeping) from seeded start states: x0, params, total_rewards,
+    vec_steps, final_obs
 
 Run only where /root/reference exists:   python oracle/gen_golden.py
 The committed outputs are what travels to the GPU box."""
@@ -88,6 +91,30 @@ def rollout_start(name, m, rng):
     return x
 
 
+def rollout_fixture(name, n=24, steps=25, shift=0.5, seed=77):
+    """Worker::rollouts of the REAL reference (reflib.rollout) from settled start states with small random
+    per-environment linear policies; every 5th environment starts in a state that ends (done) early."""
+    r, m = make_ref(name)
+    rng = np.random.default_rng(seed)
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    od = nq + nd
+    x = np.stack([rollout_start(name, m, rng) for _ in range(n)])
+    for _ in range(10):  # settle with zero action, as the envs' reset() does
+        y = r.step(x)
+        x[:, :od] = y[:, :od]
+    if name == "ant":
+        x[::5, 2] -= 0.12          # torso close to the 0.26 threshold
+        x[::5, 3] = 0.5
+    else:
+        x[::5, 3] = 0.92           # strongly rolled chassis: up.z drops below 0.6 during the rollout
+        x[::10, 3] = 1.0           # ... or is below it from the first step
+    params = rng.normal(0.0, 0.05, (n, adim * od + adim))
+    tot, cnt, fin = reflib.rollout(name, x[:, :od], params, steps, shift)
+    r.close()
+    return dict(x0=x, params=params, steps=np.int32(steps), shift=np.float64(shift), total_rewards=tot,
+                vec_steps=cnt, final_obs=fin)
+
+
 def main():
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     mdir = os.path.join(ROOT, "tiny-differentiable-simulator_amd", "models")
@@ -125,6 +152,11 @@ def main():
               f"out={m.output_dim} active contacts/state: min {ncs.min()} max {ncs.max()} "
               f"mean {ncs.mean():.1f}")
         r.close()
+    for name in ("ant", "laikago"):
+        f = rollout_fixture(name)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_rollout.npz"), **f)
+        print(f"{name}_rollout: steps taken {f['vec_steps'].min()}..{f['vec_steps'].max()} of {int(f['steps'])}, "
+              f"returns {f['total_rewards'].min():.3f}..{f['total_rewards'].max():.3f}")
 
 
 if __name__ == "__main__":

@@ -268,6 +268,65 @@ int tdsref_hipstepper_selftest(int batch, int steps, double *obs0, char *msg, in
   }
 }
 
+// The reference's OWN rollout loop on its header-only CPU path: Worker::rollouts
+// (examples/ars/ars_vectorized_worker.h:51-140) = per step { VectorizedEnvironment::policy (one linear
+// layer per environment), VectorizedEnvironment::step with the SerialForwardStepper, return bookkeeping },
+// started from given states instead of reset() (whose std::rand stream cannot be shared).  Pins the
+// on-device rollout (tds_hip_rollout) against the real reference.
+//   x0 [batch][dof_q + dof_qd], params [batch][action_dim*obs_dim + action_dim],
+//   total_rewards [batch], vec_steps [batch], final_obs [batch][obs_dim]
+extern "C++" {
+template <typename Sim, typename Env>
+static int ref_rollout(int batch, int steps, double shift, const double *x0, const double *params,
+                       double *total_rewards, int *vec_steps, double *final_obs) {
+  typedef VectorizedEnvironment<Alg, Sim> VecEnv;
+  Env env(false);
+  VecEnv vec_env(env.contact_sim, batch);
+  vec_env.default_stepper_ = &vec_env.serial_stepper_;
+  ARSConfig config;
+  config.batch_size = batch;
+  config.auto_reset_when_done = false;
+  const int od = env.contact_sim.input_dim();
+  const int np = env.contact_sim.action_dim() * od + env.contact_sim.action_dim();
+  std::vector<std::vector<double>> observations(batch);
+  for (int e = 0; e < batch; ++e) {
+    vec_env.sim_states_[e].assign(env.contact_sim.input_dim_with_action_and_variables(), 0.0);
+    for (int k = 0; k < od; ++k) vec_env.sim_states_[e][k] = x0[(size_t)e * od + k];
+    observations[e].assign(x0 + (size_t)e * od, x0 + (size_t)(e + 1) * od);  // as returned by reset(): raw x, y
+    vec_env.init_neural_network(e, std::vector<double>(params + (size_t)e * np, params + (size_t)(e + 1) * np));
+    total_rewards[e] = 0.0;
+    vec_steps[e] = 0;
+  }
+  std::vector<double> rewards(batch);
+  std::vector<bool> dones(batch, false);
+  std::vector<std::vector<double>> actions(batch);
+  for (int r = 0; r < steps; ++r) {
+    for (int e = 0; e < batch; ++e) actions[e] = vec_env.policy(e, observations[e]);
+    vec_env.step(actions, observations, rewards, dones, config);
+    for (int e = 0; e < batch; ++e)
+      if (!dones[e]) {
+        total_rewards[e] += rewards[e] - shift;
+        vec_steps[e]++;
+      }
+  }
+  for (int e = 0; e < batch; ++e)
+    for (int k = 0; k < od; ++k) final_obs[(size_t)e * od + k] = observations[e][k];
+  return 0;
+}
+}  // extern "C++"
+
+int tdsref_rollout(const char *name, int batch, int steps, double shift, const double *x0, const double *params,
+                   double *total_rewards, int *vec_steps, double *final_obs) {
+  const std::string n(name);
+  if (n == "ant")
+    return ref_rollout<AntContactSimulation2<Alg>, AntEnv2<Alg>>(batch, steps, shift, x0, params, total_rewards,
+                                                                 vec_steps, final_obs);
+  if (n == "laikago")
+    return ref_rollout<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, shift, x0, params,
+                                                                       total_rewards, vec_steps, final_obs);
+  return -1;
+}
+
 // y[n][output_dim] = reference_step(x[n][input_dim]); y is zero-filled first (the reference's
 // callers hand in zero-initialised vectors, ars_vectorized_environment.h:218-219).
 void tdsref_step(void *h, int n, const double *x, double *y) {

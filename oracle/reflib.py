@@ -40,6 +40,9 @@ def lib():
         L.tdsref_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tdsref_debug.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         L.tdsref_hipstepper_selftest.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        if hasattr(L, "tdsref_rollout"):
+            L.tdsref_rollout.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -61,6 +64,33 @@ def hipstepper_selftest(batch=8, steps=5):
         os.close(saved)
         os.close(devnull)
     return rc, msg.value.decode(), obs0
+
+
+def rollout(name, x0, params, steps, shift=0.0):
+    """The reference's own rollout loop (Worker::rollouts + VectorizedEnvironment::policy/step, serial
+    stepper) from the states x0 [B, dof_q+dof_qd] with per-environment linear policies params [B, P].
+    returns (total_rewards [B], vec_steps [B] int32, final_obs [B, obs_dim])."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    b, od = x0.shape
+    tot = np.zeros(b)
+    cnt = np.zeros(b, dtype=np.int32)
+    fin = np.zeros((b, od))
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    try:
+        rc = lib().tdsref_rollout(name.encode(), b, int(steps), float(shift), x0.ctypes.data, params.ctypes.data,
+                                  tot.ctypes.data, cnt.ctypes.data, fin.ctypes.data)
+        C.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
+    if rc != 0:
+        raise RuntimeError(f"tdsref_rollout({name}) failed: {rc}")
+    return tot, cnt, fin
 
 
 class RefSim:

@@ -410,3 +410,87 @@ def test_vectorized_env_python_mirror(built):
     assert out.visual_world_transforms.shape == (256, 155)
     assert torch.isfinite(out.obs).all() and torch.isfinite(out.rewards).all()
     assert set(out.dones.unique().tolist()) <= {0.0, 1.0}
+
+
+def _rollout_inputs(name, n, seed):
+    """start states + small random per-environment linear policies (NeuralNetwork parameter order)
+    taken from the reference-generated rollout fixture"""
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + "_rollout.npz"))
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, g["x0"].shape[0], n)
+    return m, g["x0"][idx].copy(), g["params"][idx].copy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ant", "laikago"])
+def test_rollout_matches_reference_worker_loop(name, built):
+    """tds_hip_rollout (policy + step + reward/done + return bookkeeping in ONE launch) against the
+    reference's own Worker::rollouts / VectorizedEnvironment::policy+step loop run on its header-only
+    CPU path — committed fixture tests/golden/<name>_rollout.npz (oracle/gen_golden.py), and the live
+    reference library where oracle/_ref travelled along."""
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + "_rollout.npz"))
+    x, params, steps, shift = g["x0"], g["params"], int(g["steps"]), float(g["shift"])
+    tot_ref, cnt_ref, fin_ref = g["total_rewards"], g["vec_steps"], g["final_obs"]
+    n, od = x.shape[0], m.dof_q + m.dof_qd
+    import reflib
+    if reflib.available():
+        tot_live, cnt_live, fin_live = reflib.rollout(name, x[:, :od], params, steps, shift)
+        assert np.array_equal(cnt_live, cnt_ref) and rel_err(tot_live, tot_ref) < 1e-9
+    assert 0 < (cnt_ref < steps).sum() < n          # some environments end early, some run through
+    sim = hip_backend.HipSim(m, n)
+    sim.x.copy_(torch.from_numpy(x).cuda())
+    obs = torch.zeros((n, od + 2), dtype=torch.float64, device="cuda")
+    ret, cnt = sim.rollout(torch.from_numpy(params).cuda(), steps, shift, first_obs_raw=True, obs=obs)
+    ret, cnt, ob = ret.cpu().numpy(), cnt.cpu().numpy(), obs.cpu().numpy()
+    assert np.array_equal(cnt, cnt_ref)
+    err = rel_err(ret, tot_ref, 1e-3)
+    ferr = rel_err(ob[:, 2:od], fin_ref[:, 2:], 1e-3)
+    print(f"{name}: return max rel err {err:.2e}, final observation {ferr:.2e}, steps {cnt.min()}..{cnt.max()}")
+    assert err < 1e-6 and ferr < 1e-6
+    assert (ob[:, :2] == 0).all()
+    assert np.array_equal(ob[:, od + 1] != 0, cnt_ref < steps)   # done latch
+
+
+@pytest.mark.gpu
+def test_rollout_equals_stepwise_launches_with_auto_reset(built):
+    """the same rollout driven step by step from the host (policy in numpy, one launch per step,
+    auto-reset inside the step) must give the same returns / step counts / final state."""
+    torch = _torch()
+    n, steps, shift, seed = 32, 40, 0.1, 1234
+    m, x, params = _rollout_inputs("ant", n, 5)
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    od = nq + nd
+    W = params[:, :adim * od].reshape(n, adim, od)
+    b = params[:, adim * od:]
+    # (a) stepwise
+    sim = hip_backend.HipSim(m, n)
+    sim.set_auto_reset(True, seed)
+    sim.x.copy_(torch.from_numpy(x).cuda())
+    obs = torch.zeros((n, od + 2), dtype=torch.float64, device="cuda")
+    o = x[:, :od].copy()
+    o[:, :2] = 0.0
+    tot = np.zeros(n)
+    cnt = np.zeros(n, dtype=np.int32)
+    n_done = 0
+    for _ in range(steps):
+        a = np.einsum("eao,eo->ea", W, o) + b
+        sim.step(torch.from_numpy(a).cuda().contiguous(), 1, obs)
+        ob = obs.cpu().numpy()
+        done = ob[:, od + 1] != 0
+        tot += np.where(done, 0.0, ob[:, od] - shift)
+        cnt += (~done).astype(np.int32)
+        n_done += int(done.sum())
+        o = ob[:, :od].copy()
+    assert n_done >= 3
+    x_fin = sim.x.cpu().numpy()
+    # (b) one launch
+    sim2 = hip_backend.HipSim(m, n)
+    sim2.set_auto_reset(True, seed)
+    sim2.x.copy_(torch.from_numpy(x).cuda())
+    ret2, cnt2 = sim2.rollout(torch.from_numpy(params).cuda(), steps, shift)
+    assert np.array_equal(cnt2.cpu().numpy(), cnt)
+    assert rel_err(ret2.cpu().numpy(), tot, 1e-3) < 1e-7
+    assert rel_err(sim2.x.cpu().numpy()[:, :od], x_fin[:, :od], 1e-3) < 1e-7

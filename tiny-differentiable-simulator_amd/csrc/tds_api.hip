@@ -78,10 +78,26 @@ struct tds_hip_sim {
 
 namespace {
 
+struct Rollout {
+  const void *policy;
+  void *ret_sum;
+  int *ret_steps;
+  double shift;
+  int flags;
+};
+
 int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n, int nsub,
-           int reset_mode, const unsigned char *mask) {
+           int reset_mode, const unsigned char *mask, const Rollout *ro = nullptr) {
   if (s->timing) (void)hipEventRecord(s->ev0, s->stream);
   TdsStepCtl ctl;
+  memset(&ctl, 0, sizeof(ctl));
+  if (ro) {
+    ctl.policy = ro->policy;
+    ctl.ret_sum = ro->ret_sum;
+    ctl.ret_steps = ro->ret_steps;
+    ctl.shift = ro->shift;
+    ctl.flags = ro->flags;
+  }
   ctl.nsub = nsub;
   ctl.reset_mode = reset_mode;
   ctl.settle_steps = s->model.settle_steps < 0 ? 0 : s->model.settle_steps;
@@ -319,6 +335,21 @@ int tds_hip_forward_zero_host(tds_hip_sim_t *s, int n, const double *x_host, dou
   rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n, 1, TDS_RESET_NONE, nullptr);
   if (rc != TDS_OK) return rc;
   return download(s, y_host, s->d_y, (size_t)n * s->model.output_dim);
+}
+
+int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, double shift, int flags,
+                    void *return_sum_dev, int *return_steps_dev, void *obs_dev) {
+  if (!s || !policy_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (n_steps < 1) return fail(TDS_ERR_INVALID_ARG, "n_steps < 1");
+  if (s->model.action_dim < 1) return fail(TDS_ERR_INVALID_ARG, "model has no actions");
+  Rollout ro;
+  ro.policy = policy_dev;
+  ro.ret_sum = return_sum_dev;
+  ro.ret_steps = return_steps_dev;
+  ro.shift = shift;
+  ro.flags = flags;
+  return launch(s, s->d_x, s->d_y, nullptr, s->d_x, obs_dev, s->num_envs, n_steps,
+                s->auto_reset ? TDS_RESET_AUTO : TDS_RESET_NONE, nullptr, &ro);
 }
 
 int tds_hip_send_local(tds_hip_sim_t *s, int n, const double *x_host) {

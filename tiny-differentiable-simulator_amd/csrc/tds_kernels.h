@@ -31,6 +31,13 @@ struct TdsStepCtl {
   unsigned long long seed;    // random stream of the reset distribution
   const unsigned char *mask;  // forced mode: per-env selection (device), NULL = all
   unsigned int *reset_count;  // [n_envs] per-env reset counter (device), position in the random stream
+  // rollout mode (policy != NULL): every one of the nsub steps evaluates the environment's own linear
+  // policy on its observation, steps, computes reward / done and accumulates the return on device
+  const void *policy;         // [n_envs][action_dim * obs_dim + action_dim]: weights (row = action), then biases
+  void *ret_sum;              // [n_envs] T: sum of (reward - shift) over the steps taken while not done
+  int *ret_steps;             // [n_envs]   : number of those steps
+  double shift;
+  int flags;                  // bit 0: the first step observes the raw base x, y (state fresh from reset())
 };
 
 template <typename T>

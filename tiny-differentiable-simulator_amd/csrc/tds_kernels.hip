@@ -576,7 +576,13 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   //      state carried in the LDS record.  mode / left are uniform within a lane group.
   const int nset = (LOOP && ctl.reset_mode != TDS_RESET_NONE) ? ctl.settle_steps : 0;
   int mode = (valid && (!LOOP || ctl.nsub > 0)) ? TDS_MODE_RUN : TDS_MODE_IDLE;
-  int left = LOOP ? ctl.nsub : 1;
+  int left = LOOP ? ctl.nsub : 1;  // normal steps still to run
+  int sleft = 0;                   // settle steps still to run (mode SETTLE)
+  // rollout mode: return accumulated so far, its step count, "done and not auto-reset" latch
+  const bool pol = LOOP && ctl.policy != nullptr;
+  T ret = T(0);
+  int cnt = 0;
+  bool frozen = false;
   // q = reset_q + reset_noise * U(-1,1), qd = 0  (ant_environment2.h:124-135)
   auto reset_state = [&]() {
     const unsigned cnt = ctl.reset_count != nullptr ? ctl.reset_count[env] : 0u;
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       reset_state();
       if (nset > 0) {
         mode = TDS_MODE_SETTLE;
-        left = nset;
+        sleft = nset;
       } else {
         finished0 = true;
       }
@@ -627,6 +633,27 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   const bool live = mode != TDS_MODE_IDLE;
   const bool last_run = mode == TDS_MODE_RUN && left == 1;
   const bool settling = LOOP && mode == TDS_MODE_SETTLE;
+  if constexpr (LOOP) {
+    // ---- rollout mode: action = W obs + b with the environment's own parameters
+    //      (VectorizedEnvironment::policy -> NeuralNetwork::compute, one linear layer with bias, identity:
+    //       ars_vectorized_environment.h:165-180,293-300; neural_network.hpp:223-262);
+    //      obs = [q | qd] with obs[0] = obs[1] = 0 (ars_vectorized_environment.h:283-288)
+    if (pol && __any(mode == TDS_MODE_RUN)) {
+      const int od = nq + nd;
+      const bool raw_xy = (ctl.flags & 1) != 0 && tds_iter == 0;
+      if (mode == TDS_MODE_RUN && lane < adim) {
+        const T *const W = (const T *)ctl.policy + (size_t)env * (adim * od + adim);
+        T acc = W[adim * od + lane];
+        for (int o = 0; o < od; ++o) {
+          const T ob = (o < 2 && !raw_xy) ? T(0) : xr[o];
+          acc += ob * W[lane * od + o];
+        }
+        xr[nq + nd + lane] = acc;
+      }
+      TDS_WAVE_SYNC();
+    }
+  }
+  const bool do_reward = last_run || (pol && mode == TDS_MODE_RUN);
   const T q = di >= 0 ? xr[di] : T(0);
   const T qd = di >= 0 ? xr[nq + di] : T(0);
 
@@ -1347,8 +1374,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // ---- N. reward / done of the last normal step
   //         (ars_vectorized_environment.h:250-289; ant_environment2.h:75-106;
   //          laikago_environment2.h:130-171)
-  if (last_run && lane == 0) {
-    T reward = T(0);
+  T reward = T(0);  // (lane 0)
+  if (do_reward && lane == 0) {
     bool done = false;
     const int rm = mdl->reward_mode;
     if (rm == TDS_REWARD_ANT && nq > 2) {
@@ -1371,10 +1398,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       done = (up < T(0.6)) || (xr[2] < T(0.2));
       reward = done ? T(0) : xr[0];
     }
-    if (obs_out != nullptr) {
+    if (obs_out != nullptr && last_run) {
       T *const ob = obs_out + (size_t)env * (nq + nd + 2);
       ob[nq + nd] = reward;
-      ob[nq + nd + 1] = done ? T(1) : T(0);
+      ob[nq + nd + 1] = (done || frozen) ? T(1) : T(0);
     }
     xr[in_dim + 1] = done ? T(1) : T(0);
   }
@@ -1395,31 +1422,54 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
   } else {
     TDS_WAVE_SYNC();
-    const bool will_reset = last_run && ctl.reset_mode == TDS_RESET_AUTO && xr[in_dim + 1] != T(0);
+    const bool done_now = do_reward && xr[in_dim + 1] != T(0);
+    const bool auto_r = ctl.reset_mode == TDS_RESET_AUTO;
 
     // ---- mode transition of this lane group
     bool finished = false;
     if (mode == TDS_MODE_RUN) {
-      if (--left == 0) {
-        if (will_reset) {  // auto_reset_when_done (ars_vectorized_environment.h:262-277)
-          reset_state();
-          if (nset > 0) {
-            mode = TDS_MODE_SETTLE;
-            left = nset;
+      --left;
+      bool reset_now;
+      if (pol) {
+        // return bookkeeping of Worker::rollouts (ars_vectorized_worker.h:121-137) on top of
+        // VectorizedEnvironment::step (ars_vectorized_environment.h:240-289): the step that ends with
+        // done is not counted; without auto-reset the environment stays done for the rest of the rollout
+        if (!frozen) {
+          if (done_now) {
+            frozen = !auto_r;
           } else {
-            mode = TDS_MODE_IDLE;
-            finished = true;
+            ret += reward - (T)ctl.shift;
+            ++cnt;
           }
+        }
+        reset_now = done_now && auto_r;
+      } else {
+        reset_now = left == 0 && done_now && auto_r;
+      }
+      if (reset_now) {  // auto_reset_when_done (ars_vectorized_environment.h:262-277)
+        reset_state();
+        if (nset > 0) {
+          mode = TDS_MODE_SETTLE;
+          sleft = nset;
+        }
+      }
+      if (mode == TDS_MODE_RUN && left == 0) {
+        mode = TDS_MODE_IDLE;
+        finished = true;
+      }
+    } else if (mode == TDS_MODE_SETTLE) {
+      if (--sleft == 0) {
+        if (left > 0) {
+          mode = TDS_MODE_RUN;
         } else {
           mode = TDS_MODE_IDLE;
           finished = true;
         }
       }
-    } else if (mode == TDS_MODE_SETTLE) {
-      if (--left == 0) {
-        mode = TDS_MODE_IDLE;
-        finished = true;
-      }
+    }
+    if (finished && pol && lane == 0) {
+      if (ctl.ret_sum != nullptr) ((T *)ctl.ret_sum)[env] = ret;
+      if (ctl.ret_steps != nullptr) ctl.ret_steps[env] = cnt;
     }
     TDS_WAVE_SYNC();
     // ---- the environment is done with this launch: observation (obs[0] = obs[1] = 0,
@@ -1518,7 +1568,7 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
   } while (0)
   // straight-line kernel when the launch is exactly one normal step without any reset
-  const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE;
+  const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
   const int key = lanes_per_env * 100 + L.NDP;
   switch (key) {
     case 1608: TDS_LAUNCH(16, 8); break;

@@ -56,6 +56,8 @@ def lib():
         L.tds_hip_obs_dim.argtypes = [C.c_void_p]
         L.tds_hip_set_auto_reset.argtypes = [C.c_void_p, C.c_int, C.c_ulonglong]
         L.tds_hip_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tds_hip_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
         L.tds_hip_forward_zero_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tds_hip_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -71,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_input_dim", "tds_hip_output_dim", "tds_hip_dtype", "tds_hip_x_device",
     "tds_hip_y_device", "tds_hip_set_inputs", "tds_hip_get_inputs", "tds_hip_get_outputs",
     "tds_hip_forward_zero_device", "tds_hip_step", "tds_hip_step_obs", "tds_hip_obs_dim",
-    "tds_hip_set_auto_reset", "tds_hip_reset",
+    "tds_hip_set_auto_reset", "tds_hip_reset", "tds_hip_rollout",
     "tds_hip_forward_zero_host", "tds_hip_send_local", "tds_hip_forward_zero_fetch",
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
 ]
@@ -210,6 +212,27 @@ class HipSim:
             assert tuple(obs.shape) == (self.num_envs, self.obs_dim + 2)
             op = C.c_void_p(obs.data_ptr())
         _check(lib().tds_hip_reset(self.h, mp, op))
+
+    def rollout(self, policy, n_steps: int, shift: float = 0.0, first_obs_raw: bool = False, obs=None):
+        """n_steps of { action = W obs + b (per-environment linear policy); step; reward/done } in ONE
+        launch (tds_hip_rollout).  ``policy``: [N, action_dim*obs_dim + action_dim] device tensor in
+        NeuralNetwork parameter order.  Returns (return_sum [N], steps [N] int32) device tensors."""
+        import torch
+
+        adim, od = self.model.action_dim, self.obs_dim
+        assert policy.is_cuda and policy.dtype == self.torch_dtype and policy.is_contiguous()
+        assert tuple(policy.shape) == (self.num_envs, adim * od + adim)
+        ret = torch.zeros(self.num_envs, dtype=self.torch_dtype, device=policy.device)
+        steps = torch.zeros(self.num_envs, dtype=torch.int32, device=policy.device)
+        op = None
+        if obs is not None:
+            assert obs.is_cuda and obs.dtype == self.torch_dtype and obs.is_contiguous()
+            assert tuple(obs.shape) == (self.num_envs, od + 2)
+            op = C.c_void_p(obs.data_ptr())
+        _check(lib().tds_hip_rollout(self.h, C.c_void_p(policy.data_ptr()), int(n_steps), C.c_double(shift),
+                                     1 if first_obs_raw else 0, C.c_void_p(ret.data_ptr()),
+                                     C.c_void_p(steps.data_ptr()), op))
+        return ret, steps
 
     @property
     def obs_dim(self) -> int:
