@@ -304,6 +304,52 @@ int tds_hip_profile_phases(tds_hip_sim_t *sim, long long *cycles_host, int n);
 int tds_hip_kernel_info(const tds_hip_sim_t *sim, int *lds_bytes_per_env, int *threads_per_env,
                         int *envs_per_block);
 
+/* ======================================================================================
+ * Free rigid bodies: World::step for worlds that hold tds::RigidBody
+ * objects — apply gravity, pairwise narrowphase, RigidBodyConstraintSolver (sequential impulses
+ * with Baumgarte stabilisation and Coulomb friction), integrate.
+ * Reference: src/world.hpp:293-366 (step), :163-204 (pairs), src/rigid_body.hpp:26-123,
+ * src/rb_constraint_solver.hpp:65-168, src/contact_point.hpp:43-125,444-506 (sphere-sphere,
+ * plane-sphere incl. the swapped order).  N independent worlds of the same bodies, one launch.
+ * ====================================================================================== */
+#define TDS_RB_MAX_BODIES 16
+#define TDS_RB_STATE 13 /* per body: position(3) | orientation quaternion x y z w (4) | linear velocity(3) | angular velocity(3) */
+
+typedef struct tds_rb_body {
+  double mass;          /* 0: static (inv_mass = 0, inv_inertia = 0; rigid_body.hpp:49-53), else inv_inertia = 1 */
+  int32_t geom_type;    /* TDS_GEOM_SPHERE or TDS_GEOM_PLANE */
+  int32_t pad_;
+  double radius;        /* sphere */
+  double plane_normal[3];
+  double plane_constant;
+} tds_rb_body_t;
+
+typedef struct tds_rb_model {
+  int32_t abi_version;  /* TDS_HIP_ABI_VERSION */
+  int32_t num_bodies;   /* <= TDS_RB_MAX_BODIES */
+  int32_t solver_iterations; /* World::num_solver_iterations (default 1) */
+  int32_t pad_;
+  double dt;
+  double gravity[3];    /* World::gravity_acceleration_ (default 0 0 -9.81) */
+  double restitution;   /* World::default_restitution (0) */
+  double friction;      /* World::default_friction (0.5) */
+  double erp;           /* RigidBodyConstraintSolver::erp_ (0.1) */
+  tds_rb_body_t bodies[TDS_RB_MAX_BODIES];
+} tds_rb_model_t;
+
+typedef struct tds_rb_sim tds_rb_sim_t;
+
+const char *tds_rb_last_error(void);
+int tds_rb_create(const tds_rb_model_t *model, int num_worlds, int device, int dtype, tds_rb_sim_t **out);
+int tds_rb_destroy(tds_rb_sim_t *sim);
+int tds_rb_set_stream(tds_rb_sim_t *sim, void *hip_stream);
+/* resident state, world-major [num_worlds][num_bodies][TDS_RB_STATE] in the compute dtype */
+void *tds_rb_state_device(tds_rb_sim_t *sim);
+int tds_rb_set_state(tds_rb_sim_t *sim, const double *state_host);
+int tds_rb_get_state(tds_rb_sim_t *sim, double *state_host);
+/* `steps` World::step calls on every world, one launch (async on the stream) */
+int tds_rb_step(tds_rb_sim_t *sim, int steps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,7 @@ def lib():
         L.tds_oracle_step.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p]
         L.tds_oracle_step_omp.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.tds_oracle_step_debug.argtypes = [P, C.c_void_p, C.c_void_p, C.POINTER(_Debug)]
+        L.tds_oracle_rb_step.argtypes = [C.POINTER(tds_amd.RbModel), C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -53,6 +54,15 @@ def step(model, x, threads=1):
     if rc:
         raise RuntimeError(f"tds_oracle_step rc={rc}")
     return y
+
+
+def rb_step(model, state, steps=1):
+    """free rigid bodies (row a20): state [n, num_bodies, 13] advanced by `steps` World::step calls"""
+    st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, model.num_bodies, 13)
+    rc = lib().tds_oracle_rb_step(C.byref(model), st.shape[0], int(steps), st.ctypes.data)
+    if rc:
+        raise RuntimeError(f"tds_oracle_rb_step rc={rc}")
+    return st
 
 
 def max_threads():

@@ -327,6 +327,56 @@ int tdsref_rollout(const char *name, int batch, int steps, double shift, const d
   return -1;
 }
 
+// Free rigid bodies: the reference's World::step on tds::RigidBody objects
+// (world.hpp:293-366, rigid_body.hpp, rb_constraint_solver.hpp) for n worlds described by the same
+// tds_rb_model_t; state[n][num_bodies][13] = position | quaternion xyzw | linear | angular velocity.
+int tdsref_rb_step(const tds_rb_model_t *m, int n, int steps, double *state) {
+  typedef RigidBody<Alg> RB;
+  for (int e = 0; e < n; ++e) {
+    World<Alg> world;
+    world.set_gravity(Alg::Vector3(m->gravity[0], m->gravity[1], m->gravity[2]));
+    world.num_solver_iterations = m->solver_iterations;
+    world.default_friction = m->friction;
+    world.default_restitution = m->restitution;
+    world.get_rb_constraint_solver()->erp_ = m->erp;
+    std::vector<RB *> bodies;
+    double *S = state + (size_t)e * m->num_bodies * 13;
+    for (int i = 0; i < m->num_bodies; ++i) {
+      const tds_rb_body_t &b = m->bodies[i];
+      const Geometry<Alg> *g;
+      if (b.geom_type == TDS_GEOM_SPHERE) {
+        g = world.create_sphere(b.radius);
+      } else {
+        Plane<Alg> *pl = world.create_plane();
+        *pl = Plane<Alg>(Alg::Vector3(b.plane_normal[0], b.plane_normal[1], b.plane_normal[2]), b.plane_constant);
+        g = pl;
+      }
+      RB *rb = world.create_rigid_body(b.mass, g);
+      const double *B = S + i * 13;
+      rb->world_pose_.position_ = Alg::Vector3(B[0], B[1], B[2]);
+      rb->world_pose_.orientation_ = Alg::quat_from_xyzw(B[3], B[4], B[5], B[6]);
+      rb->linear_velocity_ = Alg::Vector3(B[7], B[8], B[9]);
+      rb->angular_velocity_ = Alg::Vector3(B[10], B[11], B[12]);
+      bodies.push_back(rb);
+    }
+    for (int s = 0; s < steps; ++s) world.step(m->dt);
+    for (int i = 0; i < m->num_bodies; ++i) {
+      double *B = S + i * 13;
+      const RB *rb = bodies[i];
+      for (int k = 0; k < 3; ++k) {
+        B[k] = rb->world_pose_.position_[k];
+        B[7 + k] = rb->linear_velocity_[k];
+        B[10 + k] = rb->angular_velocity_[k];
+      }
+      B[3] = rb->world_pose_.orientation_.x();
+      B[4] = rb->world_pose_.orientation_.y();
+      B[5] = rb->world_pose_.orientation_.z();
+      B[6] = rb->world_pose_.orientation_.w();
+    }
+  }
+  return 0;
+}
+
 // y[n][output_dim] = reference_step(x[n][input_dim]); y is zero-filled first (the reference's
 // callers hand in zero-initialised vectors, ars_vectorized_environment.h:218-219).
 void tdsref_step(void *h, int n, const double *x, double *y) {

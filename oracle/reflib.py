@@ -40,6 +40,8 @@ def lib():
         L.tdsref_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tdsref_debug.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         L.tdsref_hipstepper_selftest.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        if hasattr(L, "tdsref_rb_step"):
+            L.tdsref_rb_step.argtypes = [C.POINTER(tds_amd.RbModel), C.c_int, C.c_int, C.c_void_p]
         if hasattr(L, "tdsref_rollout"):
             L.tdsref_rollout.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
@@ -91,6 +93,15 @@ def rollout(name, x0, params, steps, shift=0.0):
     if rc != 0:
         raise RuntimeError(f"tdsref_rollout({name}) failed: {rc}")
     return tot, cnt, fin
+
+
+def rb_step(model, state, steps=1):
+    """the reference's World::step on RigidBody objects; state [n, num_bodies, 13]"""
+    st = np.array(state, dtype=np.float64, order="C", copy=True).reshape(-1, model.num_bodies, 13)
+    rc = lib().tdsref_rb_step(C.byref(model), st.shape[0], int(steps), st.ctypes.data)
+    if rc:
+        raise RuntimeError(f"tdsref_rb_step rc={rc}")
+    return st
 
 
 class RefSim:

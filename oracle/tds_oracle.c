@@ -837,3 +837,161 @@ int tds_oracle_step_omp(const tds_model_t *model, int n, const double *x, double
 #endif
   return rc_all;
 }
+
+
+/* ============================ free rigid bodies ============================ */
+typedef struct { double nb[3], pa[3], pb[3], dist; int a, b; } rb_contact_t;
+
+/* contact_point.hpp:43-94 (non-CppAD branch): emitted only when the centres are > 1e-5 apart */
+static int rb_sphere_sphere(const double *pa, double ra, const double *pb, double rb, rb_contact_t *c) {
+  double diff[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+  double length = sqrt(v3_dot(diff, diff));
+  double distance = length - (ra + rb);
+  if (!(length > 1.0 / 100000.0)) return 0;
+  for (int k = 0; k < 3; ++k) {
+    c->nb[k] = 1.0 / length * diff[k];
+    c->pa[k] = pa[k] - ra * c->nb[k];
+    c->pb[k] = c->pa[k] - distance * c->nb[k];
+  }
+  c->dist = distance;
+  return 1;
+}
+/* contact_point.hpp:96-125: A = plane, B = sphere */
+static int rb_plane_sphere(const double *n, double constant, const double *pb, double rb, rb_contact_t *c) {
+  double mn[3] = {-n[0], -n[1], -n[2]};
+  double t = -(v3_dot(pb, mn) + constant);
+  for (int k = 0; k < 3; ++k) {
+    c->pa[k] = pb[k] + t * mn[k];
+    c->pb[k] = pb[k] - rb * n[k];
+    c->nb[k] = mn[k];
+  }
+  c->dist = t - rb;
+  return 1;
+}
+
+static void rb_world_step(const tds_rb_model_t *m, double *S /* [nb][13] */) {
+  const int nb = m->num_bodies;
+  const double dt = m->dt;
+  double inv_mass[TDS_RB_MAX_BODIES], inv_in[TDS_RB_MAX_BODIES];
+  for (int i = 0; i < nb; ++i) {
+    inv_mass[i] = m->bodies[i].mass == 0.0 ? 0.0 : 1.0 / m->bodies[i].mass; /* rigid_body.hpp:49-53 */
+    inv_in[i] = m->bodies[i].mass == 0.0 ? 0.0 : 1.0;                       /* eye3 or zero33 */
+  }
+  /* apply_gravity + apply_force_impulse + clear_forces (world.hpp:301-310, rigid_body.hpp:81-97) */
+  for (int i = 0; i < nb; ++i)
+    for (int k = 0; k < 3; ++k) S[i * 13 + 7 + k] += (m->bodies[i].mass * m->gravity[k]) * inv_mass[i] * dt;
+  /* pairwise narrowphase, i < j (world.hpp:163-191), dispatcher incl. swap (contact_point.hpp:468-496) */
+  rb_contact_t cs[TDS_RB_MAX_BODIES * TDS_RB_MAX_BODIES / 2];
+  int nc = 0;
+  for (int i = 0; i < nb; ++i)
+    for (int j = i + 1; j < nb; ++j) {
+      const tds_rb_body_t *A = &m->bodies[i], *B = &m->bodies[j];
+      rb_contact_t c;
+      int got = 0;
+      if (A->geom_type == TDS_GEOM_SPHERE && B->geom_type == TDS_GEOM_SPHERE) {
+        got = rb_sphere_sphere(S + i * 13, A->radius, S + j * 13, B->radius, &c);
+      } else if (A->geom_type == TDS_GEOM_PLANE && B->geom_type == TDS_GEOM_SPHERE) {
+        got = rb_plane_sphere(A->plane_normal, A->plane_constant, S + j * 13, B->radius, &c);
+      } else if (A->geom_type == TDS_GEOM_SPHERE && B->geom_type == TDS_GEOM_PLANE) {
+        got = rb_plane_sphere(B->plane_normal, B->plane_constant, S + i * 13, A->radius, &c);
+        if (got) { /* swap normal and points a, b */
+          for (int k = 0; k < 3; ++k) {
+            double t = c.pa[k];
+            c.pa[k] = c.pb[k];
+            c.pb[k] = t;
+            c.nb[k] = -c.nb[k];
+          }
+        }
+      }
+      if (got) {
+        c.a = i;
+        c.b = j;
+        cs[nc++] = c;
+      }
+    }
+  /* sequential impulses (world.hpp:336-340, rb_constraint_solver.hpp:112-165) */
+  for (int it = 0; it < m->solver_iterations; ++it)
+    for (int ci = 0; ci < nc; ++ci) {
+      const rb_contact_t *c = &cs[ci];
+      if (!(c->dist < 0.0)) continue;
+      double *Sa = S + c->a * 13, *Sb = S + c->b * 13;
+      double ra[3], rb[3], va[3], vb[3], rel[3], t3[3];
+      for (int k = 0; k < 3; ++k) {
+        ra[k] = c->pa[k] - Sa[k];
+        rb[k] = c->pb[k] - Sb[k];
+      }
+      const double baumgarte = m->erp * c->dist / dt;
+      v3_cross(Sa + 10, ra, t3);
+      for (int k = 0; k < 3; ++k) va[k] = Sa[7 + k] + t3[k];
+      v3_cross(Sb + 10, rb, t3);
+      for (int k = 0; k < 3; ++k) vb[k] = Sb[7 + k] + t3[k];
+      for (int k = 0; k < 3; ++k) rel[k] = va[k] - vb[k];
+      const double nrv = v3_dot(c->nb, rel);
+      if (!(nrv < 0.0)) continue;
+      double t1[3], t2[3], x1[3], x2[3], sum[3];
+      v3_cross(ra, c->nb, t1);
+      v3_cross(rb, c->nb, t2);
+      for (int k = 0; k < 3; ++k) {
+        t1[k] *= inv_in[c->a];
+        t2[k] *= inv_in[c->b];
+      }
+      v3_cross(t1, ra, x1);
+      v3_cross(t2, rb, x2);
+      for (int k = 0; k < 3; ++k) sum[k] = x1[k] + x2[k];
+      const double ang = v3_dot(c->nb, sum);
+      const double denom = inv_mass[c->a] + inv_mass[c->b] + ang;
+      const double impulse = (-(1.0 + m->restitution) * nrv - baumgarte) / denom;
+      if (!(impulse > 0.0)) continue;
+      double iv[3];
+      for (int k = 0; k < 3; ++k) iv[k] = impulse * c->nb[k];
+      /* apply_impulse(iv, ra) on a, (-iv, rb) on b: rigid_body.hpp:103-108 */
+      for (int k = 0; k < 3; ++k) Sa[7 + k] += inv_mass[c->a] * iv[k];
+      v3_cross(ra, iv, t3);
+      for (int k = 0; k < 3; ++k) Sa[10 + k] += inv_in[c->a] * t3[k];
+      for (int k = 0; k < 3; ++k) Sb[7 + k] += inv_mass[c->b] * -iv[k];
+      double miv[3] = {-iv[0], -iv[1], -iv[2]};
+      v3_cross(rb, miv, t3);
+      for (int k = 0; k < 3; ++k) Sb[10 + k] += inv_in[c->b] * t3[k];
+      /* friction uses the PRE-impulse relative velocity */
+      double lat[3];
+      for (int k = 0; k < 3; ++k) lat[k] = rel[k] - nrv * c->nb[k];
+      const double latn = sqrt(v3_dot(lat, lat));
+      const double trial = latn / denom;
+      const double fimp = trial < m->friction * impulse ? trial : m->friction * impulse;
+      if (latn > 1.0 / 10000.0) {
+        double fd[3], fa[3], fb[3];
+        for (int k = 0; k < 3; ++k) {
+          fd[k] = lat[k] * (1.0 / latn);
+          fa[k] = -fimp * fd[k];
+          fb[k] = fimp * fd[k];
+        }
+        for (int k = 0; k < 3; ++k) Sa[7 + k] += inv_mass[c->a] * fa[k];
+        v3_cross(ra, fa, t3);
+        for (int k = 0; k < 3; ++k) Sa[10 + k] += inv_in[c->a] * t3[k];
+        for (int k = 0; k < 3; ++k) Sb[7 + k] += inv_mass[c->b] * fb[k];
+        v3_cross(rb, fb, t3);
+        for (int k = 0; k < 3; ++k) Sb[10 + k] += inv_in[c->b] * t3[k];
+      }
+    }
+  /* integrate (rigid_body.hpp:116-122, tiny_algebra.hpp:604-614) */
+  for (int i = 0; i < nb; ++i) {
+    double *B = S + i * 13;
+    for (int k = 0; k < 3; ++k) B[k] += B[7 + k] * dt;
+    const double qx = B[3], qy = B[4], qz = B[5], qw = B[6];
+    const double *w = B + 10;
+    const double ww = (-qx * w[0] - qy * w[1] - qz * w[2]) * (0.5 * dt);
+    const double xx = (qw * w[0] + qz * w[1] - qy * w[2]) * (0.5 * dt);
+    const double yy = (qw * w[1] + qx * w[2] - qz * w[0]) * (0.5 * dt);
+    const double zz = (qw * w[2] + qy * w[0] - qx * w[1]) * (0.5 * dt);
+    double q[4] = {qx + xx, qy + yy, qz + zz, qw + ww};
+    quat_normalize(q);
+    for (int k = 0; k < 4; ++k) B[3 + k] = q[k];
+  }
+}
+
+int tds_oracle_rb_step(const tds_rb_model_t *model, int n, int steps, double *state) {
+  if (!model || model->num_bodies < 1 || model->num_bodies > TDS_RB_MAX_BODIES) return -1;
+  for (int e = 0; e < n; ++e)
+    for (int s = 0; s < steps; ++s) rb_world_step(model, state + (size_t)e * model->num_bodies * 13);
+  return 0;
+}

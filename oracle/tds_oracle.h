@@ -46,6 +46,9 @@ int tds_oracle_step_debug(const tds_model_t *model, const double *x, double *y,
                           tds_oracle_debug_t *dbg);
 int tds_oracle_max_threads(void);
 
+/* free rigid bodies (row a20): state[n][num_bodies][13] advanced by `steps` World::step calls */
+int tds_oracle_rb_step(const tds_rb_model_t *model, int n, int steps, double *state);
+
 #ifdef __cplusplus
 }
 #endif

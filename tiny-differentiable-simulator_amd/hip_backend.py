@@ -59,6 +59,15 @@ def lib():
         L.tds_hip_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
         L.tds_hip_forward_zero_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.tds_rb_last_error.restype = C.c_char_p
+        L.tds_rb_create.argtypes = [C.POINTER(_model.RbModel), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.tds_rb_destroy.argtypes = [C.c_void_p]
+        L.tds_rb_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.tds_rb_state_device.argtypes = [C.c_void_p]
+        L.tds_rb_state_device.restype = C.c_void_p
+        L.tds_rb_set_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.tds_rb_get_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.tds_rb_step.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.tds_hip_profile_phases.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
@@ -76,6 +85,8 @@ EXPORTED_SYMBOLS = [
     "tds_hip_set_auto_reset", "tds_hip_reset", "tds_hip_rollout",
     "tds_hip_forward_zero_host", "tds_hip_send_local", "tds_hip_forward_zero_fetch",
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
+    "tds_rb_last_error", "tds_rb_create", "tds_rb_destroy", "tds_rb_set_stream", "tds_rb_state_device",
+    "tds_rb_set_state", "tds_rb_get_state", "tds_rb_step",
 ]
 
 
@@ -270,3 +281,42 @@ class HipSim:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _check(lib().tds_hip_kernel_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(lds_bytes_per_env=a.value, lanes_per_env=b.value, envs_per_block=c.value)
+
+
+class RigidBodySim:
+    """N independent worlds of free rigid bodies (spheres, planes) on one GPU — World::step of the
+    reference for tds::RigidBody objects (SURVEY 8a row a20).  ``state`` is a zero-copy torch view
+    [N, num_bodies, 13]: position | quaternion xyzw | linear velocity | angular velocity."""
+
+    def __init__(self, m: _model.RbModel, num_worlds: int, device: int = 0, dtype: str = "f64"):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise TdsHipError("no HIP device visible (the HIP path has no CPU fallback)")
+        self.model, self.num_worlds, self.device = m, int(num_worlds), int(device)
+        self.dtype = _model.TDS_DTYPE_F64 if dtype in ("f64", "float64") else _model.TDS_DTYPE_F32
+        self.torch_dtype = torch.float64 if self.dtype == _model.TDS_DTYPE_F64 else torch.float32
+        h = C.c_void_p()
+        rc = lib().tds_rb_create(C.byref(m), self.num_worlds, self.device, self.dtype, C.byref(h))
+        if rc != TDS_OK:
+            raise TdsHipError(f"tds_rb_create error {rc}: {lib().tds_rb_last_error().decode()}")
+        self.h = h
+        lib().tds_rb_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        self.state = HipSim._wrap(self, lib().tds_rb_state_device(self.h),
+                                  (self.num_worlds, m.num_bodies, _model.TDS_RB_STATE))
+
+    def step(self, steps: int = 1):
+        rc = lib().tds_rb_step(self.h, int(steps))
+        if rc != TDS_OK:
+            raise TdsHipError(f"tds_rb_step error {rc}: {lib().tds_rb_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tds_rb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

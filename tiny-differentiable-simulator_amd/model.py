@@ -232,3 +232,63 @@ def load_model(name_or_path: str) -> Model:
 def available_models():
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
     return sorted(p[:-5] for p in os.listdir(d) if p.endswith(".json"))
+
+
+# ---------------------------------------------------------------------------------------------
+# free rigid bodies (include/tds_hip.h: tds_rb_body_t / tds_rb_model_t)
+# ---------------------------------------------------------------------------------------------
+TDS_RB_MAX_BODIES = 16
+TDS_RB_STATE = 13
+
+
+class RbBody(C.Structure):
+    _fields_ = [
+        ("mass", C.c_double),
+        ("geom_type", C.c_int32),
+        ("pad_", C.c_int32),
+        ("radius", C.c_double),
+        ("plane_normal", C.c_double * 3),
+        ("plane_constant", C.c_double),
+    ]
+
+
+class RbModel(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("num_bodies", C.c_int32),
+        ("solver_iterations", C.c_int32),
+        ("pad_", C.c_int32),
+        ("dt", C.c_double),
+        ("gravity", C.c_double * 3),
+        ("restitution", C.c_double),
+        ("friction", C.c_double),
+        ("erp", C.c_double),
+        ("bodies", RbBody * TDS_RB_MAX_BODIES),
+    ]
+
+
+def make_rb_model(bodies, dt=1.0 / 240.0, gravity=(0.0, 0.0, -9.81), solver_iterations=1,
+                  restitution=0.0, friction=0.5, erp=0.1) -> RbModel:
+    """bodies: list of dicts {"mass": m, "sphere": radius} or {"mass": 0, "plane": (nx, ny, nz, constant)};
+    the defaults are the reference's (world.hpp:65-71, rb_constraint_solver.hpp:45)."""
+    m = RbModel()
+    m.abi_version = TDS_HIP_ABI_VERSION
+    m.num_bodies = len(bodies)
+    assert 1 <= len(bodies) <= TDS_RB_MAX_BODIES
+    m.solver_iterations = solver_iterations
+    m.dt = dt
+    for k in range(3):
+        m.gravity[k] = gravity[k]
+    m.restitution, m.friction, m.erp = restitution, friction, erp
+    for i, b in enumerate(bodies):
+        m.bodies[i].mass = b["mass"]
+        if "sphere" in b:
+            m.bodies[i].geom_type = GEOM_SPHERE
+            m.bodies[i].radius = b["sphere"]
+        else:
+            m.bodies[i].geom_type = GEOM_PLANE
+            nx, ny, nz, c = b["plane"]
+            for k, v in enumerate((nx, ny, nz)):
+                m.bodies[i].plane_normal[k] = v
+            m.bodies[i].plane_constant = c
+    return m
