@@ -41,6 +41,12 @@ struct DevModel {
   // DPP row -> sweep state travels by DPP row shift; bit 1: link + 1 is such a child of mine;
   // bit 2: I have children that are NOT link + 1 -> they use my per-link LDS record
   int chain_flags[TDS_NL];
+  // root joint: links 0..root_last form a serial chain from the base whose links 0..root_last-1 are
+  // massless with a single child (the 6 "virtual" prismatic/revolute links URDF-derived fixed-base
+  // robots carry their free motion on).  The dynamics sweeps then treat joints 0..root_last as ONE
+  // (root_last+1)-dof joint of link root_last (one small SPD solve) instead of root_last+1 tree
+  // levels.  -1: no such chain.
+  int root_last;
   T X_T[12][TDS_NL];            // rot (row-major 9) | trans (3)
   T S[6][TDS_NL];
   T mass[TDS_NL], com[3][TDS_NL], inertia[9][TDS_NL];
@@ -195,6 +201,28 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
       } else {
         d->chain_flags[par] |= 4;
       }
+    }
+    d->root_last = -1;
+    {
+      const char *nr = getenv("TDS_HIP_NO_ROOTJOINT");
+      int nchild[TDS_NL] = {0}, nroots = 0;
+      for (int i = 0; i < m->num_links; ++i) {
+        if (m->links[i].parent >= 0) nchild[m->links[i].parent]++;
+        else ++nroots;
+      }
+      auto massless = [&](int i) {
+        const tds_link_t &l = m->links[i];
+        if (l.mass != 0.0) return false;
+        for (int c = 0; c < 9; ++c)
+          if (l.inertia[c] != 0.0) return false;
+        return true;
+      };
+      const bool ok = use_chain && !(nr && nr[0] == '1') && nroots == 1;
+      int k = 0;  // first link of the root chain that is not (massless, single child, movable)
+      while (ok && k < m->num_links - 1 && k < 5 && massless(k) && nchild[k] == 1 && m->links[k + 1].parent == k &&
+             m->links[k].joint_type != TDS_JOINT_FIXED)
+        ++k;
+      if (ok && k >= 1 && m->links[k].joint_type != TDS_JOINT_FIXED) d->root_last = k;
     }
   }
   d->num_levels = max_level + 1;

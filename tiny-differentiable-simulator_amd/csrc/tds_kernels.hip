@@ -87,6 +87,21 @@ __device__ __forceinline__ void mat3_tmulv(const T *m, const T *v, T *o) {  // m
   o[1] = y;
   o[2] = z;
 }
+// [I H; H^T M] v  for the articulated inertia stored as I (sym 6), H (9), M (sym 6)
+template <typename T>
+__device__ __forceinline__ void abi_mulv(const T *I6, const T *H9, const T *M6, const T *v, T *o) {
+  T t3[3];
+  sym3_mulv(I6, v, o);
+  mat3_mulv(H9, v + 3, t3);
+  o[0] += t3[0];
+  o[1] += t3[1];
+  o[2] += t3[2];
+  sym3_mulv(M6, v + 3, o + 3);
+  mat3_tmulv(H9, v, t3);
+  o[3] += t3[0];
+  o[4] += t3[1];
+  o[5] += t3[2];
+}
 // 1/x to full precision: hardware reciprocal estimate + Newton-Raphson (2 steps f64, 1 step f32).
 // ~5 dependent instructions instead of the ~12 of an IEEE division; operands here are pivots /
 // diagonal entries in the normal range, no denormal or infinity handling needed.
@@ -172,6 +187,18 @@ __device__ __forceinline__ float dpp_neighbour(float v) {
   constexpr int CTRL = FROM_NEXT ? 0x101 : 0x111;
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+// lane i receives lane i - D of its 16-lane DPP row (row_shr:D), zero where that lane does not exist
+template <int D>
+__device__ __forceinline__ double dpp_shr(double v) {
+  const int l = __double2loint(v), h = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, l, 0x110 + D, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, h, 0x110 + D, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int D>
+__device__ __forceinline__ float dpp_shr(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xF, 0xF, true));
+}
 // 32 payload bits carried through an LDS slot of the compute scalar (no arithmetic on them)
 template <typename T>
 __device__ __forceinline__ T bits_to_scalar(unsigned b);
@@ -221,6 +248,18 @@ template <int SRC>
 __device__ __forceinline__ float dpp_bcast(float v) {
   const int b = __float_as_int(v);
   return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x150 + SRC, 0xF, 0xF, false));
+}
+// lane SRC (of each 16-lane DPP row) to every lane, without the register copy dpp_bcast needs
+template <int SRC>
+__device__ __forceinline__ double dpp_bcast0(double v) {
+  const int l = __double2loint(v), h = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, l, 0x150 + SRC, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, h, 0x150 + SRC, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int SRC>
+__device__ __forceinline__ float dpp_bcast0(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + SRC, 0xF, 0xF, true));
 }
 template <typename T, int G, int NDP, int SRC>
 __device__ __forceinline__ T lane_bcast(T v) {
@@ -739,7 +778,72 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
   for (int k = 0; k < 6; ++k) sw[k] = vJ[k] = v[k] = T(0);
   const int nlev = mdl->num_levels;
-  for (int lev = 0; lev < nlev; ++lev) {
+  const int rkc = mdl->root_last;  // root chain 0..rkc in lanes 0..rkc (see E'): -1 = none
+  if (rkc >= 0) {
+    // The root chain's world transforms are a prefix product of the local ones along consecutive lanes:
+    // inclusive scan with DPP row shifts (3 rounds) instead of rkc+1 tree levels.
+    //   (Ra, ta) o (Rb, tb) = (Ra Rb, ta + Ra tb)        (transform.hpp:123-131)
+    const bool inch = isl && li <= rkc;
+    if (li == 0) {  // link 0 hangs off the base
+      mat3_mul(mdl->base_R, Rp, R);
+      T r[3];
+      mat3_mulv(mdl->base_R, tp, r);
+      p[0] = mdl->base_t[0] + r[0];
+      p[1] = mdl->base_t[1] + r[1];
+      p[2] = mdl->base_t[2] + r[2];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = Rp[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p[k] = tp[k];
+    }
+    static_for<0, 3>([&](auto dc) {
+      constexpr int D = 1 << decltype(dc)::value;
+      T Rq[9], pq[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rq[k] = dpp_shr<D>(R[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pq[k] = dpp_shr<D>(p[k]);
+      if (D <= rkc) {  // wave-uniform
+        T Rn[9], r[3];
+        mat3_mul(Rq, R, Rn);
+        mat3_mulv(Rq, p, r);
+        const bool upd = inch && li >= D;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = upd ? Rn[k] : R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = upd ? pq[k] + r[k] : p[k];
+      }
+    });
+    // world motion axes and velocities of the chain: v_i = sum_{j <= i} s_j qd_j (prefix sum)
+    if (inch) {
+      mat3_mulv(R, Sl, sw);
+      mat3_mulv(R, Sl + 3, sw + 3);
+      T c[3];
+      cross3(p, sw, c);
+      sw[3] += c[0];
+      sw[4] += c[1];
+      sw[5] += c[2];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[k] = vJ[k] = sw[k] * qd;
+    }
+    static_for<0, 3>([&](auto dc) {
+      constexpr int D = 1 << decltype(dc)::value;
+      const T m = (inch && li >= D) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[k] += m * dpp_shr<D>(v[k]);
+    });
+    if (inch && lds_children) {  // children other than lane + 1 read my record
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vv[li * TDS_S1 + k] = v[k];
+    }
+    TDS_WAVE_SYNC();
+  }
+  for (int lev = rkc + 1; lev < nlev; ++lev) {
     const bool mine = level == lev;
     const bool by_dpp = mine && chain_child;
     const bool by_lds = mine && parent >= 0 && !chain_child;
@@ -1013,7 +1117,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
   for (int k = 0; k < 6; ++k) U[k] = Fc[k] = T(0);
   const bool want_crba = wave_contacts;
-  for (int lev = nlev - 1; lev >= 0; --lev) {
+  // with a root joint (DevModel::root_last) the levels 0..root_last are handled after the loop
+  const int rk = mdl->root_last;  // == level of that link; -1: none
+  for (int lev = nlev - 1; lev > rk; --lev) {
     const bool mine = level == lev;
     if (mine && lds_children) {  // what the children other than lane + 1 handed over
 #pragma unroll
@@ -1119,6 +1225,162 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     if (__any(to_lds)) TDS_WAVE_SYNC();
   }
 
+  // ---- E'. root joint: joints 0..rk of the massless base chain as ONE (rk+1)-dof joint of link rk.
+  //      Massless links transmit the joint force unchanged (world coordinates), so
+  //        s_i . (IA_rk a_rk + pA_rk) = tau_i,   a_rk = a_base + sum_i c_i + sum_i s_i qdd_i      (i = 0..rk)
+  //      i.e. (S^T IA S) qdd = tau - S^T (IA (a_base + c_tot) + pA): one 6x6 SPD solve in registers
+  //      replaces rk+1 levels of the bottom-up AND of the top-down sweep.  In exact arithmetic this is
+  //      the same elimination the reference performs joint by joint (forward_dynamics.hpp:50-302).
+  T qdd_root = T(0);
+  T a_root[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) a_root[k] = T(0);
+  if (rk >= 0) {  // wave-uniform
+    if (li == rk && lds_children) {  // rows the non-chain children of link rk left in its record
+#pragma unroll
+      for (int k = 0; k < 6; ++k) I6[k] += IAs[li * TDS_S2 + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) H9[k] += IAs[li * TDS_S2 + 6 + k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) M6[k] += IAs[li * TDS_S2 + 15 + k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pa[k] += pAs[li * TDS_S2 + k];
+      if (want_crba) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) Ic[k] += Ics[li * TDS_S2 + k];
+      }
+    }
+    // The 6x6 system is spread over lanes 0..5 of the group (lane j = joint j = column j of A):
+    // link rk's IA / pA go to every lane through its LDS record, each lane forms W_j = IA s_j and its
+    // column A_ij = s_i . W_j, then an LDL^T across the six lanes with DPP broadcasts (as phase H).
+    if (li == rk) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) IAs[li * TDS_S2 + k] = I6[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) IAs[li * TDS_S2 + 6 + k] = H9[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) IAs[li * TDS_S2 + 15 + k] = M6[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = pa[k];
+    }
+    TDS_WAVE_SYNC();
+    T Ig[6], Hg[9], Mg[6], pg[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Ig[k] = IAs[rk * TDS_S2 + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Hg[k] = IAs[rk * TDS_S2 + 6 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Mg[k] = IAs[rk * TDS_S2 + 15 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pg[k] = pAs[rk * TDS_S2 + k];
+    // axes / biases / torques of the chain lanes; everything else contributes zeros
+    const bool inchain = isl && li <= rk;
+    T swm[6], ab[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      swm[c] = inchain ? sw[c] : T(0);
+      ab[c] = inchain ? cb[c] : T(0);
+    }
+    const T taum = inchain ? tau : T(0);
+    // ab = a_base + sum of the chain's c_i (sum over the 16-lane row: only chain lanes are non-zero)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      ab[c] = dpp_add<0x128>(ab[c]);
+      ab[c] = dpp_add<0x124>(ab[c]);
+      ab[c] = dpp_add<0x122>(ab[c]);
+      ab[c] = dpp_add<0x121>(ab[c]);
+    }
+    ab[3] -= mdl->grav[0];  // base acceleration = -gravity (linear part)
+    ab[4] -= mdl->grav[1];
+    ab[5] -= mdl->grav[2];
+    T Wj[6], tvec[6];
+    abi_mulv(Ig, Hg, Mg, swm, Wj);
+    abi_mulv(Ig, Hg, Mg, ab, tvec);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tvec[c] += pg[c];
+    // rhs_j = tau_j - s_j . (IA ab + pA);  column j of A = S^T IA S;  lanes beyond the chain: identity
+    T yv = taum - (dot3(swm, tvec) + dot3(swm + 3, tvec + 3));
+    T Mr6[6];
+    static_for<0, 6>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      T si[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) si[c] = dpp_bcast0<i>(swm[c]);
+      const T aij = dot3(si, Wj) + dot3(si + 3, Wj + 3);
+      Mr6[i] = (!inchain && li == i) ? T(1) : aij;
+    });
+    // A = L D L^T, right-looking across lanes 0..5 (lane j keeps row j: L[j][k] in Mr6[k], k < j)
+    T dinv_l = T(1);
+    static_for<0, 6>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const T dk = dpp_bcast0<k>(Mr6[k]);
+      const T inv = rcp_full<T>(dk);
+      const T lr = Mr6[k] * inv;
+      static_for<k + 1, 6>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const T mck = dpp_bcast0<c>(Mr6[k]);
+        Mr6[c] -= lr * mck;
+      });
+      dinv_l = li == k ? inv : dinv_l;
+      Mr6[k] = li > k ? lr : Mr6[k];
+    });
+    // forward substitution L y = rhs (column-oriented), diagonal, then L^T x = z with the rows of L
+    // exchanged through the (now free) pA slots of the chain's records
+    static_for<0, 5>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const T yk = dpp_bcast0<k>(yv);
+      yv = li > k ? yv - Mr6[k] * yk : yv;
+    });
+    T xv = yv * dinv_l;
+    if (inchain) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = Mr6[k];
+    }
+    TDS_WAVE_SYNC();
+    static_for<0, 5>([&](auto ic) {
+      constexpr int i = 5 - decltype(ic)::value;  // 5 .. 1
+      const T xi = dpp_bcast0<i>(xv);
+      if (i <= rk) {  // wave-uniform; rows beyond the chain are identity
+        const T lij = (inchain && li < i) ? pAs[i * TDS_S2 + (li < 6 ? li : 0)] : T(0);
+        xv -= lij * xi;
+      }
+    });
+    qdd_root = xv;
+    // a_rk = a_base + c_tot + S qdd
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      T t = swm[c] * xv;
+      t = dpp_add<0x128>(t);
+      t = dpp_add<0x124>(t);
+      t = dpp_add<0x122>(t);
+      t = dpp_add<0x121>(t);
+      a_root[c] = ab[c] + t;
+    }
+    TDS_WAVE_SYNC();
+    // CRBA: the composite inertia passes unchanged through the massless links: F_i = Ic_rk s_i
+    if (want_crba) {
+      if (li == rk) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) Ics[li * TDS_S2 + k] = Ic[k];
+      }
+      TDS_WAVE_SYNC();
+      if (isl && li <= rk) {
+        T Icr[10], t3[3];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) Icr[k] = Ics[rk * TDS_S2 + k];
+        sym3_mulv(Icr, sw, Fc);
+        cross3(Icr + 6, sw + 3, t3);
+        Fc[0] += t3[0];
+        Fc[1] += t3[1];
+        Fc[2] += t3[2];
+        cross3(Icr + 6, sw, t3);
+        Fc[3] = Icr[9] * sw[3] - t3[0];
+        Fc[4] = Icr[9] * sw[4] - t3[1];
+        Fc[5] = Icr[9] * sw[5] - t3[2];
+      }
+    }
+  }
+
   TDS_STAMP(5);
   // ---- F. top-down sweep: accelerations, qdd  (forward_dynamics.hpp:245-302) ----------------
   T *const aas = E + L.a;
@@ -1126,7 +1388,19 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   T acc[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) acc[k] = T(0);
-  for (int lev = 0; lev < nlev; ++lev) {
+  if (rk >= 0) {
+    if (isl && li <= rk) qdd = qdd_root;
+    if (li == rk) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] = a_root[k];
+      if (lds_children) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) aas[li * TDS_S2 + k] = acc[k];
+      }
+    }
+    TDS_WAVE_SYNC();
+  }
+  for (int lev = rk + 1; lev < nlev; ++lev) {
     const bool mine = level == lev;
     const bool by_dpp = mine && chain_child;
     const bool by_lds = mine && parent >= 0 && !chain_child;
