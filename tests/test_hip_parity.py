@@ -494,3 +494,51 @@ def test_rollout_equals_stepwise_launches_with_auto_reset(built):
     assert np.array_equal(cnt2.cpu().numpy(), cnt)
     assert rel_err(ret2.cpu().numpy(), tot, 1e-3) < 1e-7
     assert rel_err(sim2.x.cpu().numpy()[:, :od], x_fin[:, :od], 1e-3) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["ant", "laikago", "pendulum5_plane"])
+@pytest.mark.parametrize("var", ["TDS_HIP_NO_ROOTJOINT", "TDS_HIP_NO_CHAIN"])
+def test_general_tree_paths_still_match(name, var, built):
+    """the root-joint / chain hand-over shortcuts are optimisations of the general tree sweeps: with them
+    switched off (every hand-over through LDS, every level swept) the results must be the same"""
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    os.environ[var] = "1"
+    try:
+        sim = hip_backend.HipSim(m, g["x"].shape[0])
+    finally:
+        del os.environ[var]
+    y = sim.forward_zero(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    err = rel_err(y, g["y"])
+    print(f"{name} with {var}=1: max rel err {err:.2e}")
+    assert err < TOL
+
+
+@pytest.mark.parametrize("massless", [1, 2])
+def test_short_root_chains(massless, built):
+    """root joint of fewer than six joints (the 6x6 system is padded with identity rows): a chain whose
+    first `massless` links carry no inertia"""
+    torch = _torch()
+    m = _chain_model(7)
+    for i in range(massless):
+        m.links[i].mass = 0.0
+        for k in range(9):
+            m.links[i].inertia[k] = 0.0
+        for k in range(3):
+            m.links[i].com[k] = 0.0
+    m.links[1].joint_type = tds_amd.model.JOINT_REVOLUTE_Y   # not all axes parallel: regular joint-space inertia
+    m.links[1].S[0], m.links[1].S[1] = 0.0, 1.0
+    rng = np.random.default_rng(10 + massless)
+    n = 48
+    x = np.zeros((n, m.input_dim))
+    x[:, :7] = rng.uniform(-0.7, 0.7, (n, 7))
+    x[:, 7:14] = rng.uniform(-1, 1, (n, 7))
+    x[:, 14:21] = rng.uniform(-2, 2, (n, 7))
+    y_ref = oraclelib.step(m, x)
+    assert np.isfinite(y_ref).all()
+    sim = hip_backend.HipSim(m, n)
+    y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = rel_err(y, y_ref)
+    print(f"{massless} massless root links: max rel err {err:.2e}")
+    assert err < TOL
