@@ -1,0 +1,161 @@
+"""GPU: randomised kinematic trees against the plain-C oracle — branching and chains in any link order,
+massless virtual root chains of every length, fixed joints, all eight 1-dof joint types, spheres /
+capsules / boxes on a tilted plane.  Exercises the general sweeps, the DPP chain hand-over (incl. the
+DPP-row boundary at lane 16) and the root joint on structures no reference model has."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+import tds_amd
+from tds_amd import hip_backend
+import oraclelib
+
+pytestmark = pytest.mark.gpu
+M = tds_amd.model
+
+
+def _rot(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def random_tree_model(seed):
+    rng = np.random.default_rng(seed)
+    m = tds_amd.Model()
+    m.abi_version = tds_amd.TDS_HIP_ABI_VERSION
+    m.step_mode = tds_amd.TDS_STEP_TAU
+    nl = int(rng.integers(3, 23))
+    n_virtual = int(rng.integers(0, 6)) if rng.random() < 0.6 else 0     # massless root chain length
+    n_virtual = min(n_virtual, nl - 2)
+    style = rng.integers(0, 3)           # 0: serial chain, 1: DFS-ordered tree, 2: arbitrary parents
+    ndof = 0
+    # a 6-dof virtual chain must span the motion space: prismatic x, y, z then revolute x, y, z (as URDF loaders build it)
+    virt = [M.JOINT_PRISMATIC_X, M.JOINT_PRISMATIC_Y, M.JOINT_PRISMATIC_Z, M.JOINT_REVOLUTE_X, M.JOINT_REVOLUTE_Y]
+    for i in range(nl):
+        l = m.links[i]
+        if i == 0:
+            l.parent = -1
+        elif i <= n_virtual or style == 0:
+            l.parent = i - 1
+        elif style == 1:
+            l.parent = int(rng.choice([i - 1, i - 1, int(rng.integers(n_virtual, i))]))
+        else:
+            l.parent = int(rng.integers(max(n_virtual - 1, 0), i))
+        if i < n_virtual:
+            jt = virt[i]
+        else:
+            jt = int(rng.integers(0, 8)) if (rng.random() < 0.9 or i == n_virtual) else M.JOINT_FIXED
+        l.joint_type = jt
+        S = np.zeros(6)
+        if jt in (M.JOINT_PRISMATIC_X, M.JOINT_PRISMATIC_Y, M.JOINT_PRISMATIC_Z):
+            S[3 + jt - M.JOINT_PRISMATIC_X] = 1.0
+        elif jt == M.JOINT_PRISMATIC_AXIS:
+            S[3:] = rng.normal(size=3) * 0.8
+        elif jt in (M.JOINT_REVOLUTE_X, M.JOINT_REVOLUTE_Y, M.JOINT_REVOLUTE_Z):
+            S[jt - M.JOINT_REVOLUTE_X] = 1.0
+        elif jt == M.JOINT_REVOLUTE_AXIS:
+            S[:3] = rng.normal(size=3) * 0.9          # unnormalised on purpose
+        for k in range(6):
+            l.S[k] = S[k]
+        if jt != M.JOINT_FIXED:
+            l.q_index = l.qd_index = ndof
+            ndof += 1
+        else:
+            l.q_index = l.qd_index = -1
+        R = _rot(rng) if i >= n_virtual else np.eye(3)
+        t = rng.uniform(-0.25, 0.25, 3) if i >= n_virtual else np.zeros(3)
+        for k in range(9):
+            l.X_T_rot[k] = R.flat[k]
+        for k in range(3):
+            l.X_T_trans[k] = t[k]
+        if i >= n_virtual:
+            l.mass = float(rng.uniform(0.2, 2.0))
+            A = rng.normal(size=(3, 3))
+            I = (A @ A.T + 3 * np.eye(3)) * 0.01 * l.mass
+            for k in range(9):
+                l.inertia[k] = I.flat[k]
+            c = rng.uniform(-0.1, 0.1, 3)
+            for k in range(3):
+                l.com[k] = c[k]
+        l.stiffness = float(rng.uniform(0, 2)) if rng.random() < 0.2 else 0.0
+        l.damping = float(rng.uniform(0, 0.5)) if rng.random() < 0.2 else 0.0
+    m.num_links = nl
+    m.dof_q = m.dof_qd = m.action_dim = ndof
+    # contact geometry: a plane (slightly tilted) and spheres / capsules / boxes on random links
+    m.has_plane = 1
+    n = np.array([rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), 1.0])
+    n /= np.linalg.norm(n)
+    for k in range(3):
+        m.plane_normal[k] = n[k]
+    m.plane_constant = 0.0
+    ng, ncp = 0, 0
+    for i in range(n_virtual, nl):
+        if rng.random() < 0.6 and ng < tds_amd.TDS_MAX_GEOMS:
+            g = m.geoms[ng]
+            kind = rng.choice(["sphere", "capsule", "box"], p=[0.6, 0.3, 0.1])
+            need = {"sphere": 1, "capsule": 2, "box": 8}[kind]
+            if ncp + need > 24:
+                continue
+            ncp += need
+            g.link = i
+            g.type = {"sphere": M.GEOM_SPHERE, "capsule": M.GEOM_CAPSULE, "box": M.GEOM_BOX}[kind]
+            g.radius = float(rng.uniform(0.05, 0.15))
+            g.length = float(rng.uniform(0.1, 0.3))
+            for k in range(3):
+                g.extents[k] = float(rng.uniform(0.05, 0.2))
+            Rg = _rot(rng)
+            tg = rng.uniform(-0.1, 0.1, 3)
+            for k in range(9):
+                g.X_rot[k] = Rg.flat[k]
+            for k in range(3):
+                g.X_trans[k] = tg[k]
+            ng += 1
+    m.num_geoms = ng
+    m.num_visuals = 0
+    m.pack_visuals = 0
+    m.pgs_iterations = int(rng.integers(1, 3))
+    m.input_dim = 3 * ndof
+    m.output_dim = 2 * ndof
+    m.dt = 0.005
+    for k, v in enumerate((0.0, 0.0, -9.81)):
+        m.gravity[k] = v
+    for k in range(9):
+        m.base_X_world_rot[k] = np.eye(3).flat[k]
+    m.cfm, m.erp, m.friction, m.restitution = 1e-5, 0.2, float(rng.uniform(0.3, 1.0)), 0.0
+    m.action_limit = 1e9
+    m.name = f"rand{seed}".encode()
+    return m, n_virtual, style
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_tree_against_oracle(seed, built):
+    import torch
+    m, n_virtual, style = random_tree_model(seed)
+    rng = np.random.default_rng(1000 + seed)
+    n, nd = 24, m.dof_qd
+    x = np.zeros((n, m.input_dim))
+    x[:, :nd] = rng.uniform(-0.6, 0.6, (n, nd))
+    if n_virtual >= 3:
+        x[:, 2] = rng.uniform(0.0, 0.4, n)            # height of the virtual base above the plane
+    x[:, nd:2 * nd] = rng.uniform(-1, 1, (n, nd))
+    x[:, 2 * nd:] = rng.uniform(-1, 1, (n, nd))
+    try:
+        y_ref = oraclelib.step(m, x)
+    except RuntimeError:      # the reference's Cholesky inverse fails: singular joint-space inertia
+        pytest.skip("degenerate random model (joint-space inertia not positive definite)")
+    if not np.isfinite(y_ref).all() or np.abs(y_ref).max() > 1e6:
+        pytest.skip("degenerate random model (singular joint-space inertia)")
+    sim = hip_backend.HipSim(m, n)
+    y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = rel_err(y, y_ref)
+    active = int((np.array([(oraclelib.step_debug(m, x[i])["contacts"][:, 9] < 0).sum() if m.num_geoms else 0
+                            for i in range(4)])).max())
+    print(f"seed {seed}: {m.num_links} links ({n_virtual} virtual, style {style}), {nd} dof, "
+          f"{m.num_contacts} contact points (<= {active} active), lanes {sim.kernel_info()['lanes_per_env']}: "
+          f"max rel err {err:.2e}")
+    assert err < 1e-6
