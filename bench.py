@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=0,
                     help="also time the on-device policy rollout with this many policy steps per launch")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the N > 1 step loop (pipelined record gather) even with one rank: exercises that code path on a 1-GPU box")
     args = ap.parse_args()
 
     import numpy as np
@@ -172,16 +174,28 @@ def main():
     amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
     actions = torch.from_numpy(rng.uniform(-amp, amp, (pool, n, adim))).to(tdt).cuda().contiguous()
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
-    # the one exchange of the multi-GPU path: all-gather of [obs | reward | done] per step
-    gather = tds_amd.sharded.ObsGather(world * n, sim.obs_dim + 2, tdt, "cuda") if world > 1 else None
+    # the one exchange of the multi-GPU path: all-gather of [obs | reward | done] per step over RCCL,
+    # double-buffered on a side stream so that the records of step i travel while step i+1 computes
+    # (nothing in the step depends on them; every gather still completes inside the timed region)
+    gather = None
+    multi = world > 1 or args.force_gather
+    if multi:
+        gather = tds_amd.sharded.PipelinedObsGather(world * n, sim.obs_dim + 2, tdt, f"cuda:{local_rank}")
+        obs2 = [obs, torch.zeros_like(obs)]
 
     def one_step(i):
-        sim.step(actions[i % pool], 1, obs)
-        if world > 1:
-            gather(obs)
+        if multi:
+            slot = i & 1
+            gather.before_reuse(slot)
+            sim.step(actions[i % pool], 1, obs2[slot])
+            gather.submit(obs2[slot], slot)
+        else:
+            sim.step(actions[i % pool], 1, obs)
 
     for i in range(args.warmup):
         one_step(i)
+    if gather is not None:
+        gather.wait_all()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,6 +213,8 @@ def main():
     ev0.record()
     for i in range(K):
         one_step(i)
+    if gather is not None:
+        gather.wait_all()
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -270,7 +286,7 @@ def main():
                                    f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
                        if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
-                       "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(obs|reward|done)" if world > 1 else ""),
+                       "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(obs|reward|done) per step, overlapped with the next step" if world > 1 else ""),
                        "lanes_per_env": sim.kernel_info()["lanes_per_env"],
                        "lds_bytes_per_env": sim.kernel_info()["lds_bytes_per_env"]},
             "roofline": roof, "finite": finite,

@@ -59,3 +59,71 @@ class ObsGather:
         for r, (lo, hi) in enumerate(self.bounds):
             self.out[lo:hi].copy_(self._pad_out[r * self.max_size: r * self.max_size + (hi - lo)])
         return self.out
+
+
+class PipelinedObsGather:
+    """The same exchange, overlapped with the NEXT step's kernel: the record buffer is double-buffered
+    and each all-gather runs on a side stream (RCCL) / as an async work item (gloo), so that step i+1
+    computes while the records of step i travel over xGMI.  Nothing in the step depends on the gathered
+    records (per-environment policies run on device, `tds_hip_rollout`; a central learner consumes them
+    one step late), which is what makes the overlap legal.
+
+        g = PipelinedObsGather(n_global, width, dtype, device)
+        for i in range(steps):
+            slot = i & 1
+            g.before_reuse(slot)              # the producer may overwrite local[slot] again
+            produce(local[slot])              # e.g. HipSim.step(actions, 1, local[slot])
+            g.submit(local[slot], slot)
+        all_records = g.result(slot)          # [n_global, width] of the last submitted step
+    """
+
+    def __init__(self, n_global: int, width: int, dtype, device, group=None, slots: int = 2):
+        import torch
+
+        self.torch = torch
+        self.slots = slots
+        self.gathers = [ObsGather(n_global, width, dtype, device, group) for _ in range(slots)]
+        self.world = self.gathers[0].world
+        self.is_cuda = torch.device(device).type == "cuda"
+        self._work = [None] * slots
+        if self.is_cuda:
+            self.stream = torch.cuda.Stream(device=device)
+            self._done = [torch.cuda.Event() for _ in range(slots)]
+            self._pending = [False] * slots
+
+    @property
+    def local_size(self) -> int:
+        return self.gathers[0].local_size
+
+    def submit(self, local, slot: int):
+        torch = self.torch
+        g = self.gathers[slot]
+        if self.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            self.stream.wait_event(ready)
+            with torch.cuda.stream(self.stream):
+                g(local)
+                self._done[slot].record(self.stream)
+            self._pending[slot] = True
+        elif g.world > 1 and g.equal:
+            self._work[slot] = g.dist.all_gather_into_tensor(g.out, local.contiguous(), group=g.group, async_op=True)
+        else:
+            g(local)
+
+    def before_reuse(self, slot: int):
+        """order the producer (current stream / host) after the gather that last read `local[slot]`"""
+        if self.is_cuda:
+            if self._pending[slot]:
+                self.torch.cuda.current_stream().wait_event(self._done[slot])
+        elif self._work[slot] is not None:
+            self._work[slot].wait()
+            self._work[slot] = None
+
+    def result(self, slot: int):
+        self.before_reuse(slot)
+        return self.gathers[slot].out
+
+    def wait_all(self):
+        for s in range(self.slots):
+            self.before_reuse(s)
