@@ -163,14 +163,15 @@ __device__ __forceinline__ float sqrt_t<float>(float a) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) {
   const int l = __double2loint(v), h = __double2hiint(v);
-  const int lo = __builtin_amdgcn_update_dpp(l, l, CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, 0xF, 0xF, false);
+  // old = 0 / bound_ctrl: row rotations have no invalid source lane, and the mov needs no register copy
+  const int lo = __builtin_amdgcn_update_dpp(0, l, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, h, CTRL, 0xF, 0xF, true);
   return v + __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   const int b = __float_as_int(v);
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, 0xF, 0xF, false));
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, b, CTRL, 0xF, 0xF, true));
 }
 // value of the neighbouring lane inside a 16-lane DPP row (VALU move, no LDS): FROM_NEXT: lane i
 // receives lane i+1 (row_shl:1), else lane i receives lane i-1 (row_shr:1); 0 at the row boundary.
@@ -240,14 +241,14 @@ __device__ __forceinline__ T group_sum(T v) {
 template <int SRC>
 __device__ __forceinline__ double dpp_bcast(double v) {
   const int l = __double2loint(v), h = __double2hiint(v);
-  const int lo = __builtin_amdgcn_update_dpp(l, l, 0x150 + SRC, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(h, h, 0x150 + SRC, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, l, 0x150 + SRC, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, h, 0x150 + SRC, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 template <int SRC>
 __device__ __forceinline__ float dpp_bcast(float v) {
   const int b = __float_as_int(v);
-  return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x150 + SRC, 0xF, 0xF, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, b, 0x150 + SRC, 0xF, 0xF, true));
 }
 // lane SRC (of each 16-lane DPP row) to every lane, without the register copy dpp_bcast needs
 template <int SRC>
