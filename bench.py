@@ -87,6 +87,10 @@ def cpu_baseline(model_name, n_envs, budget_s=12.0):
     return out
 
 
+# flops per env-step counted on the reference's own (dense) formulation, SURVEY.md 8(d)
+ALG_FLOPS = {"ant": 1.5e5, "laikago": 7e4, "laikago_soft": 7e4, "pendulum5": 5e3, "cartpole": 2e3}
+
+
 def pmc_traffic(model, n, dtype):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json; PMC
     counters cannot be collected from inside this process).  Guide corrections: FETCH_SIZE / WRITE_SIZE
@@ -276,6 +280,11 @@ def main():
                     "kernel": "tds_step_kernel", "kernel_ms_avg": kernel_ms,
                     "kernel_ms_isolated": kernel_ms_isolated,
                     "algorithmic_bytes_per_launch": n * bytes_per_env_step,
+                    # secondary view: flops of the reference's dense formulation per env-step
+                    "algorithmic_flops_per_env_step": ALG_FLOPS.get(args.model),
+                    "algorithmic_tflops": (ALG_FLOPS[args.model] * n / (kernel_ms * 1e-3) / 1e12
+                                           if args.model in ALG_FLOPS else None),
+                    "valu_peak_tflops_f64": 78.6,
                     "note": "algorithmic bytes = (input_dim+output_dim)*sizeof(T) per env-step; the path is "
                             "VALU/LDS-latency bound, see DESIGN.md"}
         out = {
