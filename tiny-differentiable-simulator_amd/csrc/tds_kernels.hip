@@ -453,38 +453,42 @@ __device__ __forceinline__ T tds_pgs_sweep(T u, int lane, int nr, int na, int ZR
   constexpr int NDs = NDP + 1;
   const int dcl = lane < NDP ? lane : NDP - 1;  // lanes >= NDP read a valid slot and discard it
   const bool dz = lane < NDP;
-  const int na2 = 2 * na;
   const int last = ZR - 1;
   T zn = Zs[dcl], bn = rws[0], an = rws[ZR], gn = rws[2 * ZR], xon = FIRST ? T(0) : xs[0], sn = T(0);
   bool act = nr > 0;
+  // limit_dependency_ (mb_constraint_solver.hpp:417-436): row r of contact r mod na scales its friction
+  // box by that contact's normal impulse x[r mod na]; tracked incrementally for the row being fetched
+  int depn = 0;
   for (int r = 0; __any(r < nr); ++r) {
-    const bool live = act && dz;
-    const T zr = live ? zn : T(0);
-    const T br = act ? bn : T(0), ar = act ? an : T(0), gr = act ? gn : T(0);
-    const T x_old = (!FIRST && act) ? xon : T(0);
+    // only z is masked for the rows a group does not have: b / a / g / sdep may be stale there, the
+    // resulting xn is discarded below and u~ sees zr = 0
+    const T zr = (act && dz) ? zn : T(0);
+    const T br = bn, ar = an, gr = gn;
+    const T x_old = FIRST ? T(0) : (act ? xon : T(0));
     const T sdep = sn;
     const int rn = r + 1;
     const int rl = rn < last ? rn : last;  // clamped: the load is unconditional
-    // limit_dependency_ of row r + 1 (mb_constraint_solver.hpp:417-436): its contact's normal row
-    int depn = rn - (rn >= na ? na : 0) - (rn >= na2 ? na : 0);
-    const bool dep_is_r = depn == r;
-    depn = depn < last ? depn : last;
+    depn = depn + 1 == na ? 0 : depn + 1;   // == rn mod na
+    const bool dep_is_r = depn == r;        // single contact: the value is produced by this very row
+    const int depl = depn < last ? depn : last;
     zn = Zs[rl * NDs + dcl];
     bn = rws[rl];
     an = rws[ZR + rl];
     gn = rws[2 * ZR + rl];
     if constexpr (!FIRST) xon = xs[rl];
-    const T sload = xs[depn];  // stale only if depn == r (single contact): patched below
+    const T sload = xs[depl];
     const bool is_n = r < na;
     const T jw = group_sum<T, G>(zr * u);
     T delta = jw;
     if constexpr (!FIRST) delta -= gr * x_old;
     T xn = (br - delta) * ar;
     const T sc = sdep > T(0) ? sdep : T(0);  // where_lt(s, 0, 0, s)
-    const T lo = is_n ? T(0) : -mu * sc;
-    const T hi = is_n ? T(100000) : mu * sc;
+    const T h = mu * sc;
+    const T lo = is_n ? T(0) : -h;
+    const T hi = is_n ? T(100000) : h;
     xn = max_t<T>(xn, lo);  // Algebra::max(x, lo*s)
     xn = min_t<T>(xn, hi);  // Algebra::min(x, hi*s)
+    xn = act ? xn : T(0);
     if constexpr (FIRST) u += zr * xn; else u += zr * (xn - x_old);
     if (lane == 0 && act) xs[r] = xn;
     sn = dep_is_r ? xn : sload;
