@@ -321,8 +321,12 @@ def test_substeps_in_kernel_equal_repeated_steps(name, built):
     for _ in range(5):
         s1.step(a, 1)
     s2.step(a, 5)
-    assert torch.equal(s1.x, s2.x)
-    assert torch.equal(s1.y, s2.y)
+    # two separately compiled kernels (straight-line vs step-loop build): same arithmetic, but the
+    # compiler may contract / order it differently -> agreement to round-off, not bitwise
+    ex = rel_err(s2.x.cpu().numpy(), s1.x.cpu().numpy())
+    ey = rel_err(s2.y.cpu().numpy(), s1.y.cpu().numpy())
+    print(f"{name}: 5 in-kernel substeps vs 5 launches: x {ex:.2e}, y {ey:.2e}")
+    assert ex < 1e-9 and ey < 1e-9
 
 
 @pytest.mark.parametrize("name", ["ant", "laikago"])

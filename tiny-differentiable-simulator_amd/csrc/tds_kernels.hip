@@ -775,13 +775,26 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   T *const Xw = E + L.Xw;    // link-major records [link][TDS_S1]: X_world rot(9) trans(3) | v(6)
   T *const swd = E + L.swd;  // [6][NDs]   per dof
   T *const vv = E + L.v;     // (= Xw + 12)
+  T *const a0s = E + L.Xw + 18;  // (= Xw + 18) bias acceleration of the link records
   T R[9], p[3], sw[6], vJ[6], v[6];
+  // cb = v x vJ (velocity-product acceleration, kinematics.hpp:96-99); a0 = acceleration the link would
+  // have with all joint accelerations zero: a0_i = a0_parent + cb_i, a0_base = -gravity
+  T cb[6], a0[6];
 #pragma unroll
   for (int k = 0; k < 9; ++k) R[k] = T(0);
 #pragma unroll
   for (int k = 0; k < 3; ++k) p[k] = T(0);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) sw[k] = vJ[k] = v[k] = T(0);
+  for (int k = 0; k < 6; ++k) sw[k] = vJ[k] = v[k] = cb[k] = a0[k] = T(0);
+  auto bias_accel = [&]() {  // cb from v, vJ
+    cross3(v, vJ, cb);
+    T c1[3], c2[3];
+    cross3(v, vJ + 3, c1);
+    cross3(v + 3, vJ, c2);
+    cb[3] = c1[0] + c2[0];
+    cb[4] = c1[1] + c2[1];
+    cb[5] = c1[2] + c2[2];
+  };
   const int nlev = mdl->num_levels;
   const int rkc = mdl->root_last;  // root chain 0..rkc in lanes 0..rkc (see E'): -1 = none
   if (rkc >= 0) {
@@ -838,13 +851,33 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
       for (int k = 0; k < 6; ++k) v[k] += m * dpp_shr<D>(v[k]);
     });
+    // bias accelerations of the chain: prefix sum of cb on top of the base acceleration -gravity
+    if (inch) {
+      bias_accel();
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a0[k] = cb[k];
+    }
+    static_for<0, 3>([&](auto dc) {
+      constexpr int D = 1 << decltype(dc)::value;
+      const T m = (inch && li >= D) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a0[k] += m * dpp_shr<D>(a0[k]);
+    });
+    if (inch) {
+      a0[3] -= mdl->grav[0];
+      a0[4] -= mdl->grav[1];
+      a0[5] -= mdl->grav[2];
+    }
     if (inch && lds_children) {  // children other than lane + 1 read my record
 #pragma unroll
       for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) vv[li * TDS_S1 + k] = v[k];
+      for (int k = 0; k < 6; ++k) {
+        vv[li * TDS_S1 + k] = v[k];
+        a0s[li * TDS_S1 + k] = a0[k];
+      }
     }
     TDS_WAVE_SYNC();
   }
@@ -852,20 +885,23 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     const bool mine = level == lev;
     const bool by_dpp = mine && chain_child;
     const bool by_lds = mine && parent >= 0 && !chain_child;
-    T Rq[9], pq[3], vq[6];
+    T Rq[9], pq[3], vq[6], aq[6];
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rq[k] = T(0);
 #pragma unroll
     for (int k = 0; k < 3; ++k) pq[k] = T(0);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) vq[k] = T(0);
+    for (int k = 0; k < 6; ++k) vq[k] = aq[k] = T(0);
     if (__any(by_dpp)) {  // wave-uniform; the moves themselves run on every lane
 #pragma unroll
       for (int k = 0; k < 9; ++k) Rq[k] = dpp_neighbour<false>(R[k]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) pq[k] = dpp_neighbour<false>(p[k]);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) vq[k] = dpp_neighbour<false>(v[k]);
+      for (int k = 0; k < 6; ++k) {
+        vq[k] = dpp_neighbour<false>(v[k]);
+        aq[k] = dpp_neighbour<false>(a0[k]);
+      }
     }
     if (by_lds) {
 #pragma unroll
@@ -873,7 +909,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
       for (int k = 0; k < 3; ++k) pq[k] = Xw[parent * TDS_S1 + 9 + k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) vq[k] = vv[parent * TDS_S1 + k];
+      for (int k = 0; k < 6; ++k) {
+        vq[k] = vv[parent * TDS_S1 + k];
+        aq[k] = a0s[parent * TDS_S1 + k];
+      }
     }
     if (mine) {
       if (parent < 0) {
@@ -882,7 +921,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
         for (int k = 0; k < 3; ++k) pq[k] = mdl->base_t[k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) vq[k] = T(0);
+        for (int k = 0; k < 6; ++k) vq[k] = aq[k] = T(0);
+        aq[3] = -mdl->grav[0];  // base acceleration = -gravity (forward_dynamics.hpp:237-243)
+        aq[4] = -mdl->grav[1];
+        aq[5] = -mdl->grav[2];
       }
       mat3_mul(Rq, Rp, R);
       T r[3];
@@ -903,13 +945,19 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         vJ[k] = sw[k] * qd;
         v[k] = vq[k] + vJ[k];
       }
+      bias_accel();
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a0[k] = aq[k] + cb[k];
       if (lds_children) {  // children other than lane + 1 read my record
 #pragma unroll
         for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) vv[li * TDS_S1 + k] = v[k];
+        for (int k = 0; k < 6; ++k) {
+          vv[li * TDS_S1 + k] = v[k];
+          a0s[li * TDS_S1 + k] = a0[k];
+        }
       }
     }
     if (__any(mine && lds_children)) TDS_WAVE_SYNC();
@@ -1023,33 +1071,23 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   }
   TDS_WAVE_SYNC();  // X_world / v in LDS are dead from here on (their space is reused)
 
-  // ---- D. bias terms and world-frame inertias (kinematics.hpp:96-132, inertia.hpp:121-130) ---
-  // link-major records [link][TDS_S2]: IA I(6) H(9) M(6) | pA(6) (later F) | Ic I(6) h(3) m | a(6).
-  // The sweeps touch one or a few links per level, so a record per link gives one base address per
-  // lane and immediate offsets for every component (no per-access address arithmetic).
-  T *const IAs = E + L.IA;
+  // ---- D. world-frame rigid inertias and the forces of the "all joint accelerations zero" motion
+  //         (kinematics.hpp:96-132, inertia.hpp:121-130).
+  // Forward dynamics is NOT done with the articulated-body recursion here: the joint-space inertia
+  // M = L D L^T is needed anyway for the contact solve (phases G, H), and with it
+  //        qdd = M^-1 (tau - C),   C_i = s_i . f_i,   f_i = sum over the subtree of (I a0 + v x* I v)
+  // costs one substitution, while the bias forces C ride on the composite-inertia sweep as six more
+  // numbers per link.  The same q̈ the reference's ABA (forward_dynamics.hpp:11-326) produces, to
+  // round-off; a 6x6 articulated inertia never has to travel up the tree.
+  // per-link records [link][TDS_S2]: (21 unused) | f or F(6) | Ic I(6) h(3) m | (6 unused).  A record is
+  // an accumulation target only for links with children that are not lane + 1.
   T *const pAs = E + L.pA;
   T *const Ics = E + L.Ic;
-  T cb[6];                  // c = v x vJ
-  {
-    cross3(v, vJ, cb);
-    T c1[3], c2[3];
-    cross3(v, vJ + 3, c1);
-    cross3(v + 3, vJ, c2);
-    cb[3] = c1[0] + c2[0];
-    cb[4] = c1[1] + c2[1];
-    cb[5] = c1[2] + c2[2];
-  }
-  // The link's own articulated inertia IA = [I H; H^T M] (I, M symmetric), bias pA and CRBA composite
-  // inertia Ic = (I, h, m) stay in REGISTERS; a record in LDS exists only to collect the children that
-  // are not lane + 1 (zeroed here, accumulated with ds_add in the sweep).
-  T I6[6], H9[9], M6[6], pa[6], Ic[10];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) I6[k] = M6[k] = pa[k] = T(0);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) H9[k] = T(0);
+  T Ic[10], fc[6];  // composite inertia (I sym 6 | h | m) and composite bias force of my subtree so far
 #pragma unroll
   for (int k = 0; k < 10; ++k) Ic[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) fc[k] = T(0);
   if (isl) {
     const T m = mass_l;
     T cw[3];
@@ -1066,16 +1104,20 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       for (int c = 0; c < 3; ++c) Iw[3 * r + c] = RI[3 * r] * R[3 * c] + RI[3 * r + 1] * R[3 * c + 1] + RI[3 * r + 2] * R[3 * c + 2];
     const T c2 = dot3(cw, cw);
     // I = Icom + m (|c|^2 1 - c c^T)
-    I6[0] = Iw[0] + m * (c2 - cw[0] * cw[0]);
-    I6[1] = T(0.5) * (Iw[1] + Iw[3]) - m * cw[0] * cw[1];
-    I6[2] = T(0.5) * (Iw[2] + Iw[6]) - m * cw[0] * cw[2];
-    I6[3] = Iw[4] + m * (c2 - cw[1] * cw[1]);
-    I6[4] = T(0.5) * (Iw[5] + Iw[7]) - m * cw[1] * cw[2];
-    I6[5] = Iw[8] + m * (c2 - cw[2] * cw[2]);
-    const T h[3] = {m * cw[0], m * cw[1], m * cw[2]};
-    // I v = (I w + h x v_lin, m v_lin - h x w)
-    T Iv[6], t3[3];
-    sym3_mulv(I6, v, Iv);
+    Ic[0] = Iw[0] + m * (c2 - cw[0] * cw[0]);
+    Ic[1] = T(0.5) * (Iw[1] + Iw[3]) - m * cw[0] * cw[1];
+    Ic[2] = T(0.5) * (Iw[2] + Iw[6]) - m * cw[0] * cw[2];
+    Ic[3] = Iw[4] + m * (c2 - cw[1] * cw[1]);
+    Ic[4] = T(0.5) * (Iw[5] + Iw[7]) - m * cw[1] * cw[2];
+    Ic[5] = Iw[8] + m * (c2 - cw[2] * cw[2]);
+    Ic[6] = m * cw[0];
+    Ic[7] = m * cw[1];
+    Ic[8] = m * cw[2];
+    Ic[9] = m;
+    const T *const h = Ic + 6;
+    // I x = (I w + h x x_lin, m x_lin - h x w)  for x = v and x = a0
+    T Iv[6], Ia[6], t3[3];
+    sym3_mulv(Ic, v, Iv);
     cross3(h, v + 3, t3);
     Iv[0] += t3[0];
     Iv[1] += t3[1];
@@ -1084,28 +1126,26 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     Iv[3] = m * v[3] - t3[0];
     Iv[4] = m * v[4] - t3[1];
     Iv[5] = m * v[5] - t3[2];
-    // pA = v x* (I v) = (w x n + v x f, w x f)      (f_ext = 0 after clear_forces)
+    sym3_mulv(Ic, a0, Ia);
+    cross3(h, a0 + 3, t3);
+    Ia[0] += t3[0];
+    Ia[1] += t3[1];
+    Ia[2] += t3[2];
+    cross3(h, a0, t3);
+    Ia[3] = m * a0[3] - t3[0];
+    Ia[4] = m * a0[4] - t3[1];
+    Ia[5] = m * a0[5] - t3[2];
+    // f = I a0 + v x* (I v),  v x* f = (w x n + v_lin x f_lin, w x f_lin)      (f_ext = 0 after clear_forces)
     T u3[3];
-    cross3(v, Iv, pa);
+    cross3(v, Iv, fc);
     cross3(v + 3, Iv + 3, u3);
-    pa[0] += u3[0];
-    pa[1] += u3[1];
-    pa[2] += u3[2];
-    cross3(v, Iv + 3, pa + 3);
-    // H = [h]x,  M = m 1
-    H9[1] = -h[2]; H9[2] = h[1];
-    H9[3] = h[2];  H9[5] = -h[0];
-    H9[6] = -h[1]; H9[7] = h[0];
-    M6[0] = M6[3] = M6[5] = m;
+    fc[0] += u3[0];
+    fc[1] += u3[1];
+    fc[2] += u3[2];
+    cross3(v, Iv + 3, fc + 3);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) Ic[k] = I6[k];
-    Ic[6] = h[0];
-    Ic[7] = h[1];
-    Ic[8] = h[2];
-    Ic[9] = m;
+    for (int k = 0; k < 6; ++k) fc[k] += Ia[k];
     if (lds_children) {
-#pragma unroll
-      for (int k = 0; k < 21; ++k) IAs[li * TDS_S2 + k] = T(0);
 #pragma unroll
       for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = T(0);
 #pragma unroll
@@ -1115,339 +1155,87 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   TDS_WAVE_SYNC();
 
   TDS_STAMP(4);
-  // ---- E. bottom-up sweep: ABA articulated inertia / bias, CRBA composite inertia -----------
-  //      (forward_dynamics.hpp:50-216, mass_matrix.hpp:39-56) in world coordinates
-  T U[6], Dinv = T(0), uu = T(0);
-  T Fc[6];  // CRBA: F_i = Ic_i s_i
+  // ---- E. bottom-up sweep: composite inertia (CRBA, mass_matrix.hpp:39-56) and composite bias force
+  //         (the backward pass of inverse dynamics) in world coordinates: plain sums up the tree
+  T Fc[6], Cb = T(0);  // F_i = Ic_i s_i (mass-matrix phase), C_i = s_i . f_i
 #pragma unroll
-  for (int k = 0; k < 6; ++k) U[k] = Fc[k] = T(0);
-  const bool want_crba = wave_contacts;
-  // with a root joint (DevModel::root_last) the levels 0..root_last are handled after the loop
+  for (int k = 0; k < 6; ++k) Fc[k] = T(0);
+  auto project = [&](const T *Icx, const T *fx) {  // F = Ic s = (I w + h x v, m v - h x w);  C = s . f
+    T t3[3];
+    sym3_mulv(Icx, sw, Fc);
+    cross3(Icx + 6, sw + 3, t3);
+    Fc[0] += t3[0];
+    Fc[1] += t3[1];
+    Fc[2] += t3[2];
+    cross3(Icx + 6, sw, t3);
+    Fc[3] = Icx[9] * sw[3] - t3[0];
+    Fc[4] = Icx[9] * sw[4] - t3[1];
+    Fc[5] = Icx[9] * sw[5] - t3[2];
+    Cb = dot3(sw, fx) + dot3(sw + 3, fx + 3);
+  };
+  // with a root joint (DevModel::root_last) the massless base chain 0..rk-1 is handled after the loop
   const int rk = mdl->root_last;  // == level of that link; -1: none
   for (int lev = nlev - 1; lev > rk; --lev) {
     const bool mine = level == lev;
     if (mine && lds_children) {  // what the children other than lane + 1 handed over
 #pragma unroll
-      for (int k = 0; k < 6; ++k) I6[k] += IAs[li * TDS_S2 + k];
+      for (int k = 0; k < 6; ++k) fc[k] += pAs[li * TDS_S2 + k];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) H9[k] += IAs[li * TDS_S2 + 6 + k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) M6[k] += IAs[li * TDS_S2 + 15 + k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pa[k] += pAs[li * TDS_S2 + k];
-      if (want_crba) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) Ic[k] += Ics[li * TDS_S2 + k];
-      }
+      for (int k = 0; k < 10; ++k) Ic[k] += Ics[li * TDS_S2 + k];
     }
     const bool to_lds = mine && parent >= 0 && !chain_child;
     if (mine) {
-      // U = IA s
-      T t3[3];
-      sym3_mulv(I6, sw, U);
-      mat3_mulv(H9, sw + 3, t3);
-      U[0] += t3[0];
-      U[1] += t3[1];
-      U[2] += t3[2];
-      sym3_mulv(M6, sw + 3, U + 3);
-      mat3_tmulv(H9, sw, t3);
-      U[3] += t3[0];
-      U[4] += t3[1];
-      U[5] += t3[2];
-      const T D = dot3(sw, U) + dot3(sw + 3, U + 3);
-      uu = tau - (dot3(sw, pa) + dot3(sw + 3, pa + 3));
-      Dinv = di >= 0 ? rcp_full<T>(D) : T(0);  // forward_dynamics.hpp:153
-      // Ia = IA - U U^T / D   (in place: the registers now hold what the parent receives)
-      T Ub[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Ub[k] = U[k] * Dinv;
-      I6[0] -= U[0] * Ub[0]; I6[1] -= U[0] * Ub[1]; I6[2] -= U[0] * Ub[2];
-      I6[3] -= U[1] * Ub[1]; I6[4] -= U[1] * Ub[2]; I6[5] -= U[2] * Ub[2];
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) H9[3 * r + c] -= U[r] * Ub[3 + c];
-      M6[0] -= U[3] * Ub[3]; M6[1] -= U[3] * Ub[4]; M6[2] -= U[3] * Ub[5];
-      M6[3] -= U[4] * Ub[4]; M6[4] -= U[4] * Ub[5]; M6[5] -= U[5] * Ub[5];
-      // pa = pA + Ia c + U u / D
-      T Iac[6];
-      sym3_mulv(I6, cb, Iac);
-      mat3_mulv(H9, cb + 3, t3);
-      Iac[0] += t3[0];
-      Iac[1] += t3[1];
-      Iac[2] += t3[2];
-      sym3_mulv(M6, cb + 3, Iac + 3);
-      mat3_tmulv(H9, cb, t3);
-      Iac[3] += t3[0];
-      Iac[4] += t3[1];
-      Iac[5] += t3[2];
-      const T ud = uu * Dinv;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pa[k] += Iac[k] + U[k] * ud;
-      if (want_crba) {
-        // F = Ic s = (I w + h x v, m v - h x w)
-        sym3_mulv(Ic, sw, Fc);
-        cross3(Ic + 6, sw + 3, t3);
-        Fc[0] += t3[0];
-        Fc[1] += t3[1];
-        Fc[2] += t3[2];
-        cross3(Ic + 6, sw, t3);
-        Fc[3] = Ic[9] * sw[3] - t3[0];
-        Fc[4] = Ic[9] * sw[4] - t3[1];
-        Fc[5] = Ic[9] * sw[5] - t3[2];
-      }
+      project(Ic, fc);
       if (to_lds) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[parent * TDS_S2 + k], I6[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(&pAs[parent * TDS_S2 + k], fc[k]);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&IAs[parent * TDS_S2 + 6 + k], H9[k]);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&IAs[parent * TDS_S2 + 15 + k], M6[k]);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&pAs[parent * TDS_S2 + k], pa[k]);
-        if (want_crba) {
-#pragma unroll
-          for (int k = 0; k < 10; ++k) atomicAdd(&Ics[parent * TDS_S2 + k], Ic[k]);
-        }
+        for (int k = 0; k < 10; ++k) atomicAdd(&Ics[parent * TDS_S2 + k], Ic[k]);
       }
     }
     if (__any(mine && chain_child)) {  // wave-uniform: lane i takes over from its child in lane i + 1
       // (select by multiplication: one FMA instead of two 32-bit selects and an add per value)
       const T recv = (has_chain_child && level + 1 == lev) ? T(1) : T(0);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) I6[k] += recv * dpp_neighbour<true>(I6[k]);
+      for (int k = 0; k < 6; ++k) fc[k] += recv * dpp_neighbour<true>(fc[k]);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) H9[k] += recv * dpp_neighbour<true>(H9[k]);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) M6[k] += recv * dpp_neighbour<true>(M6[k]);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pa[k] += recv * dpp_neighbour<true>(pa[k]);
-      if (want_crba) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) Ic[k] += recv * dpp_neighbour<true>(Ic[k]);
-      }
+      for (int k = 0; k < 10; ++k) Ic[k] += recv * dpp_neighbour<true>(Ic[k]);
     }
     if (__any(to_lds)) TDS_WAVE_SYNC();
   }
-
-  // ---- E'. root joint: joints 0..rk of the massless base chain as ONE (rk+1)-dof joint of link rk.
-  //      Massless links transmit the joint force unchanged (world coordinates), so
-  //        s_i . (IA_rk a_rk + pA_rk) = tau_i,   a_rk = a_base + sum_i c_i + sum_i s_i qdd_i      (i = 0..rk)
-  //      i.e. (S^T IA S) qdd = tau - S^T (IA (a_base + c_tot) + pA): one 6x6 SPD solve in registers
-  //      replaces rk+1 levels of the bottom-up AND of the top-down sweep.  In exact arithmetic this is
-  //      the same elimination the reference performs joint by joint (forward_dynamics.hpp:50-302).
-  T qdd_root = T(0);
-  T a_root[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) a_root[k] = T(0);
+  // ---- E'. root joint: the links 0..rk-1 of the base chain are massless, so the composite inertia and
+  //      force of link rk pass through them unchanged: F_i = Ic_rk s_i, C_i = s_i . f_rk for i <= rk,
+  //      all at once instead of rk+1 more levels
   if (rk >= 0) {  // wave-uniform
-    if (li == rk && lds_children) {  // rows the non-chain children of link rk left in its record
+    if (li == rk) {
+      if (lds_children) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) I6[k] += IAs[li * TDS_S2 + k];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) H9[k] += IAs[li * TDS_S2 + 6 + k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) M6[k] += IAs[li * TDS_S2 + 15 + k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pa[k] += pAs[li * TDS_S2 + k];
-      if (want_crba) {
+        for (int k = 0; k < 6; ++k) fc[k] += pAs[li * TDS_S2 + k];
 #pragma unroll
         for (int k = 0; k < 10; ++k) Ic[k] += Ics[li * TDS_S2 + k];
       }
-    }
-    // The 6x6 system is spread over lanes 0..5 of the group (lane j = joint j = column j of A):
-    // link rk's IA / pA go to every lane through its LDS record, each lane forms W_j = IA s_j and its
-    // column A_ij = s_i . W_j, then an LDL^T across the six lanes with DPP broadcasts (as phase H).
-    if (li == rk) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) IAs[li * TDS_S2 + k] = I6[k];
+      for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = fc[k];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) IAs[li * TDS_S2 + 6 + k] = H9[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) IAs[li * TDS_S2 + 15 + k] = M6[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = pa[k];
+      for (int k = 0; k < 10; ++k) Ics[li * TDS_S2 + k] = Ic[k];
     }
     TDS_WAVE_SYNC();
-    T Ig[6], Hg[9], Mg[6], pg[6];
+    if (isl && li <= rk) {
+      T Icr[10], fr[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) Ig[k] = IAs[rk * TDS_S2 + k];
+      for (int k = 0; k < 10; ++k) Icr[k] = Ics[rk * TDS_S2 + k];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Hg[k] = IAs[rk * TDS_S2 + 6 + k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Mg[k] = IAs[rk * TDS_S2 + 15 + k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) pg[k] = pAs[rk * TDS_S2 + k];
-    // axes / biases / torques of the chain lanes; everything else contributes zeros
-    const bool inchain = isl && li <= rk;
-    T swm[6], ab[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      swm[c] = inchain ? sw[c] : T(0);
-      ab[c] = inchain ? cb[c] : T(0);
-    }
-    const T taum = inchain ? tau : T(0);
-    // ab = a_base + sum of the chain's c_i (sum over the 16-lane row: only chain lanes are non-zero)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      ab[c] = dpp_add<0x128>(ab[c]);
-      ab[c] = dpp_add<0x124>(ab[c]);
-      ab[c] = dpp_add<0x122>(ab[c]);
-      ab[c] = dpp_add<0x121>(ab[c]);
-    }
-    ab[3] -= mdl->grav[0];  // base acceleration = -gravity (linear part)
-    ab[4] -= mdl->grav[1];
-    ab[5] -= mdl->grav[2];
-    T Wj[6], tvec[6];
-    abi_mulv(Ig, Hg, Mg, swm, Wj);
-    abi_mulv(Ig, Hg, Mg, ab, tvec);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) tvec[c] += pg[c];
-    // rhs_j = tau_j - s_j . (IA ab + pA);  column j of A = S^T IA S;  lanes beyond the chain: identity
-    T yv = taum - (dot3(swm, tvec) + dot3(swm + 3, tvec + 3));
-    T Mr6[6];
-    static_for<0, 6>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      T si[6];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) si[c] = dpp_bcast0<i>(swm[c]);
-      const T aij = dot3(si, Wj) + dot3(si + 3, Wj + 3);
-      Mr6[i] = (!inchain && li == i) ? T(1) : aij;
-    });
-    // A = L D L^T, right-looking across lanes 0..5 (lane j keeps row j: L[j][k] in Mr6[k], k < j)
-    T dinv_l = T(1);
-    static_for<0, 6>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      const T dk = dpp_bcast0<k>(Mr6[k]);
-      const T inv = rcp_full<T>(dk);
-      const T lr = Mr6[k] * inv;
-      static_for<k + 1, 6>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        const T mck = dpp_bcast0<c>(Mr6[k]);
-        Mr6[c] -= lr * mck;
-      });
-      dinv_l = li == k ? inv : dinv_l;
-      Mr6[k] = li > k ? lr : Mr6[k];
-    });
-    // forward substitution L y = rhs (column-oriented), diagonal, then L^T x = z with the rows of L
-    // exchanged through the (now free) pA slots of the chain's records
-    static_for<0, 5>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      const T yk = dpp_bcast0<k>(yv);
-      yv = li > k ? yv - Mr6[k] * yk : yv;
-    });
-    T xv = yv * dinv_l;
-    if (inchain) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = Mr6[k];
+      for (int k = 0; k < 6; ++k) fr[k] = pAs[rk * TDS_S2 + k];
+      project(Icr, fr);
     }
     TDS_WAVE_SYNC();
-    static_for<0, 5>([&](auto ic) {
-      constexpr int i = 5 - decltype(ic)::value;  // 5 .. 1
-      const T xi = dpp_bcast0<i>(xv);
-      if (i <= rk) {  // wave-uniform; rows beyond the chain are identity
-        const T lij = (inchain && li < i) ? pAs[i * TDS_S2 + (li < 6 ? li : 0)] : T(0);
-        xv -= lij * xi;
-      }
-    });
-    qdd_root = xv;
-    // a_rk = a_base + c_tot + S qdd
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      T t = swm[c] * xv;
-      t = dpp_add<0x128>(t);
-      t = dpp_add<0x124>(t);
-      t = dpp_add<0x122>(t);
-      t = dpp_add<0x121>(t);
-      a_root[c] = ab[c] + t;
-    }
-    TDS_WAVE_SYNC();
-    // CRBA: the composite inertia passes unchanged through the massless links: F_i = Ic_rk s_i
-    if (want_crba) {
-      if (li == rk) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) Ics[li * TDS_S2 + k] = Ic[k];
-      }
-      TDS_WAVE_SYNC();
-      if (isl && li <= rk) {
-        T Icr[10], t3[3];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) Icr[k] = Ics[rk * TDS_S2 + k];
-        sym3_mulv(Icr, sw, Fc);
-        cross3(Icr + 6, sw + 3, t3);
-        Fc[0] += t3[0];
-        Fc[1] += t3[1];
-        Fc[2] += t3[2];
-        cross3(Icr + 6, sw, t3);
-        Fc[3] = Icr[9] * sw[3] - t3[0];
-        Fc[4] = Icr[9] * sw[4] - t3[1];
-        Fc[5] = Icr[9] * sw[5] - t3[2];
-      }
-    }
   }
 
   TDS_STAMP(5);
-  // ---- F. top-down sweep: accelerations, qdd  (forward_dynamics.hpp:245-302) ----------------
-  T *const aas = E + L.a;
-  T qdd = T(0);
-  T acc[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) acc[k] = T(0);
-  if (rk >= 0) {
-    if (isl && li <= rk) qdd = qdd_root;
-    if (li == rk) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) acc[k] = a_root[k];
-      if (lds_children) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) aas[li * TDS_S2 + k] = acc[k];
-      }
-    }
-    TDS_WAVE_SYNC();
-  }
-  for (int lev = rk + 1; lev < nlev; ++lev) {
-    const bool mine = level == lev;
-    const bool by_dpp = mine && chain_child;
-    const bool by_lds = mine && parent >= 0 && !chain_child;
-    T ap[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ap[k] = T(0);
-    if (__any(by_dpp)) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ap[k] = dpp_neighbour<false>(acc[k]);
-    }
-    if (by_lds) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ap[k] = aas[parent * TDS_S2 + k];
-    }
-    if (mine) {
-      if (parent < 0) {  // base acceleration = -gravity (linear part)
-        ap[0] = ap[1] = ap[2] = T(0);
-        ap[3] = -mdl->grav[0];
-        ap[4] = -mdl->grav[1];
-        ap[5] = -mdl->grav[2];
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) acc[k] = ap[k] + cb[k];
-      if (di >= 0) {
-        const T Uta = dot3(U, acc) + dot3(U + 3, acc + 3);
-        qdd = Dinv * (uu - Uta);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] += sw[k] * qdd;
-      }
-      if (lds_children) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) aas[li * TDS_S2 + k] = acc[k];
-      }
-    }
-    if (__any(mine && lds_children)) TDS_WAVE_SYNC();
-  }
-  // integrate_euler_qdd: qd += qdd dt  (integrator.hpp:169-181)
-  T qd_new = qd + qdd * dt;
+  T qd_new = qd;
   T q_new = q;
 
-  if (wave_contacts) {
-    if (di >= 0) xr[nq + di] = qd_new;
+  {
     TDS_STAMP(6);
     // ---- G. mass-matrix row of dof d, straight into registers (lane == dof == row):
     //         M[d][j] = F_d . s_j for j on the path base -> d   (mass_matrix.hpp:87-109)
@@ -1529,10 +1317,37 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       for (int j = 0; j < NDP - 1; ++j)
         if (j < lane) Lp[off + j] = Mr[j];
     }
+    // ---- F. forward dynamics: qdd = M^-1 (tau - C) with the factorisation just computed, then
+    //         integrate_euler_qdd: qd += qdd dt (integrator.hpp:169-181).  tau - C travels from the link
+    //         lanes to the dof lanes through the (now free) column scratch of dvec.
+    T *const rhsx = dvec + 2 * NDP;
+    if (lane < NDP) rhsx[lane] = T(0);
+    TDS_WAVE_SYNC();
+    if (di >= 0) rhsx[di] = tau - Cb;
+    TDS_WAVE_SYNC();
+    {
+      const int d = lane;
+      T yv = d < NDP ? rhsx[d] : T(0);
+      // L y = rhs (L unit lower, row d of it in Mr[0..d-1]), column by column
+      static_for<0, NDP - 1>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const T yk = lane_bcast<T, G, NDP, k>(yv);
+        yv = d > k ? yv - Mr[k] * yk : yv;
+      });
+      T xv = yv * my_inv;
+      // L^T x = D^-1 y with the packed copy of L in LDS
+      static_for<0, NDP - 1>([&](auto ic) {
+        constexpr int k = NDP - 1 - decltype(ic)::value;
+        const T xk = lane_bcast<T, G, NDP, k>(xv);
+        if (d < k) xv -= Lp[(k * (k - 1)) / 2 + d] * xk;
+      });
+      if (d < nd) xr[nq + d] += xv * dt;
+    }
     TDS_STAMP(8);
 
-    TDS_WAVE_SYNC();  // Z aliases the sweep arrays (IA, pA, Ic, a, F): all of those are dead now
+    TDS_WAVE_SYNC();  // Z aliases the sweep arrays (f, Ic, F): all of those are dead now
     TDS_STAMP(9);
+    if (wave_contacts) {
 
     // ---- J. constraint Jacobian rows (jacobian.hpp:13-83, mb_constraint_solver.hpp:278-388)
     //         row a: normal, na+a: tangent 1, 2na+a: tangent 2;  lane == dof
@@ -1616,6 +1431,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       });
       if (d < nd) xr[nq + d] -= w;
     }
+    }  // wave_contacts
     TDS_WAVE_SYNC();
     if (di >= 0) qd_new = xr[nq + di];
   }
@@ -1804,8 +1620,8 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
   L.xrec = o; o += m.input_dim + 2;  // + x_{t-1} and the done flag of the step loop
   L.swd = o;  o += 6 * L.NDs;
   L.cp = o;   o += ncp ? 5 * L.NCPp : 0;
-  L.Lp = o;   o += ncp ? (ndp * (ndp - 1)) / 2 : 0;
-  L.dinv = o; o += ncp ? 3 * ndp : 0;  // 1/D | sqrt(1/D) | column scratch of the wide LDL^T
+  L.Lp = o;   o += (ndp * (ndp - 1)) / 2;
+  L.dinv = o; o += 3 * ndp;  // 1/D | sqrt(1/D) | column scratch of the wide LDL^T / rhs exchange
   L.rows = o; o += 3 * L.zrows;
   L.xrow = o; o += 3 * ncp;
   // three phase groups share one region:
