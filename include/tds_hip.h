@@ -295,8 +295,9 @@ int tds_hip_last_kernel_ms(tds_hip_sim_t *sim, float *ms);
 
 /* Diagnostic: run y = f(x) once on the resident records with the instrumented kernel build and
    return 14 shader-clock timestamps taken by workgroup 0 at the phase boundaries
-   (A load, B jcalc, C kinematics sweep, D inertias, E ABA/CRBA sweep, F acceleration sweep,
-    G mass matrix, H LDL^T, I narrowphase, J Jacobian rows, K row solves, L PGS, M pack, end).
+   (A load + PD, B jcalc, C kinematics sweep, I narrowphase + visuals + D inertias, E composite
+    inertia / bias force sweep, G mass matrix, H LDL^T, F forward-dynamics solve, (sync), J Jacobian rows,
+    K row solves, L PGS, M pack, end).
    Synchronises the stream. */
 int tds_hip_profile_phases(tds_hip_sim_t *sim, long long *cycles_host, int n);
 

@@ -1236,7 +1236,6 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   T q_new = q;
 
   {
-    TDS_STAMP(6);
     // ---- G. mass-matrix row of dof d, straight into registers (lane == dof == row):
     //         M[d][j] = F_d . s_j for j on the path base -> d   (mass_matrix.hpp:87-109)
     T *const Fs = E + L.F;      // (= pA slot of the link records)
@@ -1270,7 +1269,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    TDS_STAMP(7);
+    TDS_STAMP(6);
     // ---- H. M = L D L^T entirely in registers (replaces the Cholesky inverse,
     //         tiny_matrix_x.h:240-345).  Right-looking; column k is gathered from the lanes that
     //         own rows k..NDP-1 with cross-lane shuffles, no LDS traffic, no barriers.
@@ -1317,6 +1316,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       for (int j = 0; j < NDP - 1; ++j)
         if (j < lane) Lp[off + j] = Mr[j];
     }
+    TDS_STAMP(7);
     // ---- F. forward dynamics: qdd = M^-1 (tau - C) with the factorisation just computed, then
     //         integrate_euler_qdd: qd += qdd dt (integrator.hpp:169-181).  tau - C travels from the link
     //         lanes to the dof lanes through the (now free) column scratch of dvec.

@@ -267,7 +267,8 @@ class HipSim:
         return float(ms.value)
 
     PHASES = ["A load+PD", "B jcalc", "C kinematics sweep", "I narrowphase + visuals + D inertias",
-              "E ABA+CRBA sweep", "F accel sweep", "G mass matrix rows", "H LDLt", "(barrier)",
+              "E composite inertia + bias force sweep", "G mass matrix rows", "H LDLt",
+              "F forward dynamics solve", "(barrier)",
               "J jacobian rows", "K row solves", "L PGS", "M/N pack"]
 
     def profile_phases(self):
