@@ -1264,9 +1264,6 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         }
         s = ((anc >> j) & 1u) ? s : T(0);
         Mr[j] = (!isd && j == d) ? T(1) : s;  // padding rows: identity
-        // bound the scheduler's load hoisting: 6 NDP LDS loads in flight at once was the register
-        // peak of the whole kernel
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
     TDS_STAMP(6);
