@@ -41,6 +41,8 @@ struct DevModel {
   // DPP row -> sweep state travels by DPP row shift; bit 1: link + 1 is such a child of mine;
   // bit 2: I have children that are NOT link + 1 -> they use my per-link LDS record
   int chain_flags[TDS_NL];
+  // links with children that are not lane + 1 publish (v, a0) in a side record: its slot, or -1
+  int lc_slot[TDS_NL], num_lc_slots;
   // root joint: links 0..root_last form a serial chain from the base whose links 0..root_last-1 are
   // massless with a single child (the 6 "virtual" prismatic/revolute links URDF-derived fixed-base
   // robots carry their free motion on).  The dynamics sweeps then treat joints 0..root_last as ONE
@@ -202,6 +204,7 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
         d->chain_flags[par] |= 4;
       }
     }
+    for (int i = 0; i < m->num_links; ++i) d->lc_slot[i] = (d->chain_flags[i] & 4) ? d->num_lc_slots++ : -1;
     d->root_last = -1;
     {
       const char *nr = getenv("TDS_HIP_NO_ROOTJOINT");

@@ -6,8 +6,8 @@
 
 #define TDS_NUM_PHASE_STAMPS 14
 // strides (in scalars, odd) of the per-link LDS records of the two sweep groups
-#define TDS_S1 25  // X_world rot(9) trans(3) | v(6) | a0(6)
-#define TDS_S2 43  // (21 unused) | f or F(6) | Ic(10) | (6 unused)
+#define TDS_S1 13  // X_world rot(9) trans(3), odd stride; (v | a0) only in the side records of branching links
+#define TDS_S2 17  // f or F(6) | Ic(10), odd stride
 
 // Per-environment LDS layout, offsets in units of the compute scalar T (see tds_make_lds_layout).
 struct TdsLds {

@@ -587,6 +587,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   const bool chain_child = (cflags & 1) != 0;      // my parent is lane - 1
   const bool has_chain_child = (cflags & 2) != 0;  // lane + 1 is my child and hands over by DPP
   const bool lds_children = (cflags & 4) != 0;     // I have children that are not lane + 1
+  const int my_slot = isl ? mdl->lc_slot[lsafe] : -1;                        // my (v, a0) side record
+  const int par_slot = (isl && parent >= 0) ? mdl->lc_slot[parent] : -1;     // my parent's
   // per-link model constants (joint axis, X_T, rigid inertia).  The straight-line build fetches
   // them HERE, ahead of the x record, so that their L2 latency overlaps the HBM latency of x; the
   // step-loop build re-fetches them per iteration (keeping ~60 VGPRs live across the loop costs more).
@@ -774,8 +776,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // ---- C. top-down sweep: X_world, world motion axis s, velocity v  (kinematics.hpp:64-97) ---
   T *const Xw = E + L.Xw;    // link-major records [link][TDS_S1]: X_world rot(9) trans(3) | v(6)
   T *const swd = E + L.swd;  // [6][NDs]   per dof
-  T *const vv = E + L.v;     // (= Xw + 12)
-  T *const a0s = E + L.Xw + 18;  // (= Xw + 18) bias acceleration of the link records
+  T *const va = E + L.v;     // side records [slot][TDS_S1]: v(6) | a0(6) of the links with non-chain children
   T R[9], p[3], sw[6], vJ[6], v[6];
   // cb = v x vJ (velocity-product acceleration, kinematics.hpp:96-99); a0 = acceleration the link would
   // have with all joint accelerations zero: a0_i = a0_parent + cb_i, a0_base = -gravity
@@ -875,8 +876,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        vv[li * TDS_S1 + k] = v[k];
-        a0s[li * TDS_S1 + k] = a0[k];
+        va[my_slot * TDS_S1 + k] = v[k];
+        va[my_slot * TDS_S1 + 6 + k] = a0[k];
       }
     }
     TDS_WAVE_SYNC();
@@ -910,8 +911,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       for (int k = 0; k < 3; ++k) pq[k] = Xw[parent * TDS_S1 + 9 + k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        vq[k] = vv[parent * TDS_S1 + k];
-        aq[k] = a0s[parent * TDS_S1 + k];
+        vq[k] = va[par_slot * TDS_S1 + k];
+        aq[k] = va[par_slot * TDS_S1 + 6 + k];
       }
     }
     if (mine) {
@@ -955,8 +956,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          vv[li * TDS_S1 + k] = v[k];
-          a0s[li * TDS_S1 + k] = a0[k];
+          va[my_slot * TDS_S1 + k] = v[k];
+          va[my_slot * TDS_S1 + 6 + k] = a0[k];
         }
       }
     }
@@ -1079,7 +1080,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // costs one substitution, while the bias forces C ride on the composite-inertia sweep as six more
   // numbers per link.  The same q̈ the reference's ABA (forward_dynamics.hpp:11-326) produces, to
   // round-off; a 6x6 articulated inertia never has to travel up the tree.
-  // per-link records [link][TDS_S2]: (21 unused) | f or F(6) | Ic I(6) h(3) m | (6 unused).  A record is
+  // per-link records [link][TDS_S2]: f or F(6) | Ic I(6) h(3) m.  A record is
   // an accumulation target only for links with children that are not lane + 1.
   T *const pAs = E + L.pA;
   T *const Ics = E + L.Ic;
@@ -1623,13 +1624,14 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
   L.xrow = o; o += 3 * ncp;
   // three phase groups share one region:
   //   1. kinematics sweep:   per-link records [X_world(12) | v(6)]              stride TDS_S1
-  //   2. dynamics sweeps:    per-link records [IA(21) | pA/F(6) | Ic(10) | a(6)] stride TDS_S2
+  //   2. composite sweep:    per-link records [f or F(6) | Ic(10)] stride TDS_S2
   //   3. constraint rows:    Z[zrows][NDs]
   const int u = o;
   int g1 = u;
-  L.Xw = g1; L.v = g1 + 12; g1 += TDS_S1 * L.NLp;
+  L.Xw = g1; g1 += TDS_S1 * L.NLp;
+  L.v = g1; g1 += TDS_S1 * m.num_lc_slots;
   int g2 = u;
-  L.IA = g2; L.pA = g2 + 21; L.F = g2 + 21; L.Ic = g2 + 27; L.a = g2 + 37; g2 += TDS_S2 * L.NLp;
+  L.IA = g2; L.pA = g2; L.F = g2; L.Ic = g2 + 6; L.a = g2; g2 += TDS_S2 * L.NLp;
   int g3 = u;
   L.Z = g3; g3 += L.zrows * L.NDs;
   o = g1 > g2 ? g1 : g2;
