@@ -328,49 +328,63 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
 // per row (lane == row): b_r, forward substitution L z = J_r^T in registers, G_rr = z.D^-1.z,
 // 1/(G_rr + cfm); the row is stored back as z~ = D^-1/2 z so that A_rs = J_r M^-1 J_s^T = z~_r.z~_s
 template <bool SLAB, typename T, int G, int NDP>
-__device__ __forceinline__ void tds_row_solve(int lane, int nr, int na, int nd, int ZR, int OVR, int NCPp,
+__device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, int ZR, int OVR, int NCPp,
                                               T *Zs, T *rws, T *xs, const T *qdv, const T *cpx, const T *Lp,
                                               const T *dvec, volatile T *zov, volatile T *rov, T cfm, T erp_dt,
                                               T rest) {
   constexpr int NDs = NDP + 1;
-  for (int r = lane; r < nr; r += G) {
+  // ROW LAYOUT (wave-uniform): NA = largest number of penetrating contacts among the wavefront's
+  // environments; row a = normal of contact a, NA + a = tangent 1, 2 NA + a = tangent 2.  An environment
+  // with fewer contacts has empty slots a >= na: they are stored as all-zero rows (x = 0, no effect),
+  // so that the Gauss-Seidel loop needs no per-environment control flow.  The order among an
+  // environment's real rows is the reference's (normals, tangent 1, tangent 2, each by contact).
+  const int nrw = 3 * NA;
+  for (int r = lane; r < nrw; r += G) {
+    const int t = (r >= NA ? 1 : 0) + (r >= 2 * NA ? 1 : 0);
+    const int a = r - t * NA;
+    const bool real = a < na;
     bool in_lds = true;
     if constexpr (SLAB) in_lds = r < ZR;
     T z[NDP];
-    if (in_lds) {
+    T brow = T(0), ai = T(0), g = T(0);
+    if (real) {
+      if (in_lds) {
 #pragma unroll
-      for (int k = 0; k < NDP; ++k) z[k] = Zs[r * NDs + k];
+        for (int k = 0; k < NDP; ++k) z[k] = Zs[r * NDs + k];
+      } else {
+        volatile T *const Zr = zov + (size_t)(r - ZR) * NDs;
+#pragma unroll
+        for (int k = 0; k < NDP; ++k) z[k] = Zr[k];
+      }
+      T vrow = T(0);
+#pragma unroll
+      for (int k = 0; k < NDP; ++k)
+        if (k < nd) vrow += z[k] * qdv[k];
+      // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
+      brow = t == 0 ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + a] : vrow;
+      // column-oriented: once z[j] is final, every later z[k] takes its update independently
+#pragma unroll
+      for (int j = 0; j < NDP - 1; ++j) {
+#pragma unroll
+        for (int k = j + 1; k < NDP; ++k) z[k] -= Lp[(k * (k - 1)) / 2 + j] * z[j];
+      }
+#pragma unroll
+      for (int k = 0; k < NDP; ++k) {
+        z[k] *= dvec[NDP + k];
+        g += z[k] * z[k];
+      }
+      ai = rcp_full<T>(g + cfm);
     } else {
-      volatile T *const Zr = zov + (size_t)(r - ZR) * NDs;
 #pragma unroll
-      for (int k = 0; k < NDP; ++k) z[k] = Zr[k];
+      for (int k = 0; k < NDP; ++k) z[k] = T(0);
     }
-    T vrow = T(0);
-#pragma unroll
-    for (int k = 0; k < NDP; ++k)
-      if (k < nd) vrow += z[k] * qdv[k];
-    // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
-    const T brow = r < na ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + r] : vrow;
-    // column-oriented: once z[j] is final, every later z[k] takes its update independently
-#pragma unroll
-    for (int j = 0; j < NDP - 1; ++j) {
-#pragma unroll
-      for (int k = j + 1; k < NDP; ++k) z[k] -= Lp[(k * (k - 1)) / 2 + j] * z[j];
-    }
-    T g = T(0);
-#pragma unroll
-    for (int k = 0; k < NDP; ++k) {
-      z[k] *= dvec[NDP + k];
-      g += z[k] * z[k];
-    }
-    const T ai = rcp_full<T>(g + cfm);
     if (in_lds) {
 #pragma unroll
       for (int k = 0; k < NDP; ++k) Zs[r * NDs + k] = z[k];
       rws[r] = brow;
       rws[ZR + r] = ai;
       rws[2 * ZR + r] = g;
-    } else {
+    } else if (zov != nullptr) {  // (groups without a live environment have no slab)
       volatile T *const Zr = zov + (size_t)(r - ZR) * NDs;
 #pragma unroll
       for (int k = 0; k < NDP; ++k) Zr[k] = z[k];
@@ -385,11 +399,12 @@ __device__ __forceinline__ void tds_row_solve(int lane, int nr, int na, int nd, 
 // projected Gauss-Seidel (mb_constraint_solver.hpp:101-142) on u~ = sum_r z~_r x_r:
 //   delta_i = sum_{j != i} A_ij x_j = z~_i . u~ - G_ii x_i;   lane == dof holds u~_k (returned)
 template <bool SLAB, typename T, int G, int NDP>
-__device__ __forceinline__ T tds_pgs(int lane, int nr, int na, int ZR, int OVR, int iters, T mu, const T *Zs,
+__device__ __forceinline__ T tds_pgs(int lane, int NA, int ZR, int OVR, int iters, T mu, const T *Zs,
                                      const T *rws, T *xs, volatile const T *zov, volatile const T *rov) {
   constexpr int NDs = NDP + 1;
   const int d = lane;
   const bool dz = d < NDP;
+  const int nr = 3 * NA;  // wave-uniform row layout, see tds_row_solve
   T u = T(0);
   for (int it = 0; it < iters; ++it) {
     // software pipeline: everything row r+1 needs that does not depend on row r is loaded before
@@ -413,18 +428,20 @@ __device__ __forceinline__ T tds_pgs(int lane, int nr, int na, int ZR, int OVR, 
           bn = rws[rn];
           an = rws[ZR + rn];
           gn = rws[2 * ZR + rn];
-        } else {
+        } else if (zov != nullptr) {
           zn = dz ? zov[(size_t)(rn - ZR) * NDs + d] : T(0);
           bn = rov[rn - ZR];
           an = rov[OVR + rn - ZR];
           gn = rov[2 * OVR + rn - ZR];
+        } else {  // group without a live environment: zero rows
+          zn = bn = an = gn = T(0);
         }
         xon = it > 0 ? xs[rn] : T(0);
       }
       // friction rows scale their box by the normal impulse of the same contact
-      // (limit_dependency_, mb_constraint_solver.hpp:417-436); that row is >= na rows back
-      const bool is_n = r < na;
-      const int dep = r - (r >= na ? na : 0) - (r >= 2 * na ? na : 0);
+      // (limit_dependency_, mb_constraint_solver.hpp:417-436); that row is NA or 2 NA rows back
+      const bool is_n = r < NA;
+      const int dep = r - (r >= NA ? NA : 0) - (r >= 2 * NA ? NA : 0);
       const T sdep = xs[dep];
       const T jw = group_sum<T, G>(zr * u);
       const T delta = jw - gr * x_old;
@@ -442,66 +459,63 @@ __device__ __forceinline__ T tds_pgs(int lane, int nr, int na, int ZR, int OVR, 
 }
 
 
-// The common case of tds_pgs: every row of the wavefront's environments is in LDS.  Wave-uniform
-// trip count (groups with fewer rows run zero rows that leave u~ untouched) and NO control flow
-// around the loads: everything row r + 1 needs — including the normal impulse its friction box
-// depends on — is fetched unconditionally (row index clamped) while row r is being reduced, so the
-// loop-carried chain is only: u~ -> dot -> 4 DPP adds -> clamp -> u~.
+// The common case of tds_pgs: every row of the wavefront's environments is in LDS.  With the
+// wave-uniform row layout the loop has no per-environment control flow at all: empty slots are zero
+// rows, the row kind (normal / friction) and the row of the limiting normal impulse are wave-uniform,
+// and everything row r + 1 needs is fetched while row r is being reduced, so that the loop-carried
+// chain is only: u~ -> dot -> 4 DPP adds -> clamp -> u~.
 template <bool FIRST, typename T, int G, int NDP>
-__device__ __forceinline__ T tds_pgs_sweep(T u, int lane, int nr, int na, int ZR, T mu, const T *Zs, const T *rws,
-                                           T *xs) {
+__device__ __forceinline__ T tds_pgs_sweep(T u, int lane, int NA, int ZR, T mu, const T *Zs, const T *rws, T *xs) {
   constexpr int NDs = NDP + 1;
   const int dcl = lane < NDP ? lane : NDP - 1;  // lanes >= NDP read a valid slot and discard it
   const bool dz = lane < NDP;
+  const int nr = 3 * NA;
   const int last = ZR - 1;
-  T zn = Zs[dcl], bn = rws[0], an = rws[ZR], gn = rws[2 * ZR], xon = FIRST ? T(0) : xs[0], sn = T(0);
-  bool act = nr > 0;
-  // limit_dependency_ (mb_constraint_solver.hpp:417-436): row r of contact r mod na scales its friction
-  // box by that contact's normal impulse x[r mod na]; tracked incrementally for the row being fetched
-  int depn = 0;
-  for (int r = 0; __any(r < nr); ++r) {
-    // only z is masked for the rows a group does not have: b / a / g / sdep may be stale there, the
-    // resulting xn is discarded below and u~ sees zr = 0
-    const T zr = (act && dz) ? zn : T(0);
-    const T br = bn, ar = an, gr = gn;
-    const T x_old = FIRST ? T(0) : (act ? xon : T(0));
-    const T sdep = sn;
+  T zn = Zs[dcl], bn = rws[0], an = rws[ZR], gn = FIRST ? T(0) : rws[2 * ZR], xon = FIRST ? T(0) : xs[0];
+  T sn = T(0), x0 = T(0);
+  for (int r = 0; r < nr; ++r) {
+    const T zr = dz ? zn : T(0);
+    const T br = bn, ar = an, gr = gn, x_old = xon, sdep = sn;
+    // prefetch row r + 1 (index clamped: the loads are unconditional)
     const int rn = r + 1;
-    const int rl = rn < last ? rn : last;  // clamped: the load is unconditional
-    depn = depn + 1 == na ? 0 : depn + 1;   // == rn mod na
-    const bool dep_is_r = depn == r;        // single contact: the value is produced by this very row
-    const int depl = depn < last ? depn : last;
+    const int rl = rn < last ? rn : last;
     zn = Zs[rl * NDs + dcl];
     bn = rws[rl];
     an = rws[ZR + rl];
-    gn = rws[2 * ZR + rl];
-    if constexpr (!FIRST) xon = xs[rl];
-    const T sload = xs[depl];
-    const bool is_n = r < na;
+    if constexpr (!FIRST) {
+      gn = rws[2 * ZR + rl];
+      xon = xs[rl];
+    }
+    // limit_dependency_ (mb_constraint_solver.hpp:417-436): the friction box of row rn scales with the
+    // normal impulse of its contact, row rn - NA (tangent 1) or rn - 2 NA (tangent 2)
+    const int depn = rn - (rn >= NA ? NA : 0) - (rn >= 2 * NA ? NA : 0);
+    const T sload = xs[depn < last ? depn : last];
     const T jw = group_sum<T, G>(zr * u);
     T delta = jw;
     if constexpr (!FIRST) delta -= gr * x_old;
     T xn = (br - delta) * ar;
-    const T sc = sdep > T(0) ? sdep : T(0);  // where_lt(s, 0, 0, s)
-    const T h = mu * sc;
-    const T lo = is_n ? T(0) : -h;
-    const T hi = is_n ? T(100000) : h;
-    xn = max_t<T>(xn, lo);  // Algebra::max(x, lo*s)
-    xn = min_t<T>(xn, hi);  // Algebra::min(x, hi*s)
-    xn = act ? xn : T(0);
+    if (r < NA) {  // wave-uniform: normal row, bounds [0, 1e5]
+      xn = max_t<T>(xn, T(0));
+      xn = min_t<T>(xn, T(100000));
+    } else {       // friction row, bounds -/+ mu max(x_normal, 0)
+      const T h = mu * (sdep > T(0) ? sdep : T(0));  // where_lt(s, 0, 0, s)
+      xn = max_t<T>(xn, -h);  // Algebra::max(x, lo*s)
+      xn = min_t<T>(xn, h);   // Algebra::min(x, hi*s)
+    }
     if constexpr (FIRST) u += zr * xn; else u += zr * (xn - x_old);
-    if (lane == 0 && act) xs[r] = xn;
-    sn = dep_is_r ? xn : sload;
-    act = rn < nr;
+    if (lane == 0) xs[r] = xn;
+    if (r == 0) x0 = xn;
+    // with a single contact slot row 1 depends on the row just computed (its prefetch is stale)
+    sn = NA == 1 ? x0 : sload;
   }
   return u;
 }
 
 template <typename T, int G, int NDP>
-__device__ __forceinline__ T tds_pgs_lds(int lane, int nr, int na, int ZR, int iters, T mu, const T *Zs,
-                                         const T *rws, T *xs) {
-  T u = tds_pgs_sweep<true, T, G, NDP>(T(0), lane, nr, na, ZR, mu, Zs, rws, xs);
-  for (int it = 1; it < iters; ++it) u = tds_pgs_sweep<false, T, G, NDP>(u, lane, nr, na, ZR, mu, Zs, rws, xs);
+__device__ __forceinline__ T tds_pgs_lds(int lane, int NA, int ZR, int iters, T mu, const T *Zs, const T *rws,
+                                         T *xs) {
+  T u = tds_pgs_sweep<true, T, G, NDP>(T(0), lane, NA, ZR, mu, Zs, rws, xs);
+  for (int it = 1; it < iters; ++it) u = tds_pgs_sweep<false, T, G, NDP>(u, lane, NA, ZR, mu, Zs, rws, xs);
   return u;
 }
 
@@ -1360,7 +1374,15 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     const int OVR = L.ovrows;  // surplus rows available per environment in the slab
     volatile T *const zov = (ovf != nullptr && live) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
     volatile T *const rov = zov != nullptr ? zov + (size_t)OVR * NDs : nullptr;  // [3][OVR]
-    const int nr = 3 * na;
+    // wave-uniform row layout (see tds_row_solve): NA = the largest contact count in this wavefront
+    int NAv = na;
+#pragma unroll
+    for (int msk = G; msk < 64; msk <<= 1) {
+      const int o = __shfl_xor(NAv, msk, 64);
+      NAv = o > NAv ? o : NAv;
+    }
+    const int NA = __builtin_amdgcn_readfirstlane(NAv);
+    const int nr = 3 * NA;
     const T nb[3] = {mdl->nb[0], mdl->nb[1], mdl->nb[2]};
     const T t1[3] = {mdl->t1[0], mdl->t1[1], mdl->t1[2]};
     const T t2[3] = {mdl->t2[0], mdl->t2[1], mdl->t2[2]};
@@ -1382,7 +1404,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
             col[2] = sd[5] - c[2];
           }
           const T jn = dot3(nb, col), j1 = dot3(t1, col), j2 = dot3(t2, col);
-          const int r0 = a, r1 = na + a, r2 = 2 * na + a;
+          const int r0 = a, r1 = NA + a, r2 = 2 * NA + a;
           if (r0 < ZR) Zs[r0 * NDs + d] = jn; else zov[(r0 - ZR) * NDs + d] = jn;
           if (r1 < ZR) Zs[r1 * NDs + d] = j1; else zov[(r1 - ZR) * NDs + d] = j1;
           if (r2 < ZR) Zs[r2 * NDs + d] = j2; else zov[(r2 - ZR) * NDs + d] = j2;
@@ -1400,12 +1422,12 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     //         G_rr = z.D^-1.z,  1/(G_rr + cfm);  the row is stored back as z~ = D^-1/2 z so that
     //         A_rs = J_r M^-1 J_s^T = z~_r . z~_s  — one matrix instead of J and M^-1 J^T.
     const T cfm = mdl->cfm, erp_dt = mdl->erp_over_dt, rest = mdl->restitution;
-    const bool any_slab = __any(nr > ZR) != 0;  // wave-uniform
+    const bool any_slab = nr > ZR;  // wave-uniform
     if (any_slab)
-      tds_row_solve<true, T, G, NDP>(lane, nr, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov, rov,
+      tds_row_solve<true, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov, rov,
                                      cfm, erp_dt, rest);
     else
-      tds_row_solve<false, T, G, NDP>(lane, nr, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov, rov,
+      tds_row_solve<false, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov, rov,
                                       cfm, erp_dt, rest);
     TDS_WAVE_SYNC();
     if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1418,8 +1440,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       const bool dz = d < NDP;
       const T mu = mdl->friction;
       const int iters = mdl->pgs_iterations;
-      const T u = any_slab ? tds_pgs<true, T, G, NDP>(lane, nr, na, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov)
-                           : tds_pgs_lds<T, G, NDP>(lane, nr, na, ZR, iters, mu, Zs, rws, xs);
+      const T u = any_slab ? tds_pgs<true, T, G, NDP>(lane, NA, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov)
+                           : tds_pgs_lds<T, G, NDP>(lane, NA, ZR, iters, mu, Zs, rws, xs);
       // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
       T w = dz ? u * dvec[NDP + d] : T(0);
       static_for<0, NDP - 1>([&](auto ic) {
