@@ -621,6 +621,45 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     for (int k = 0; k < 3; ++k) tT[k] = md->X_T[9 + k][lsafe];
   };
   if constexpr (!LOOP) load_link_consts(mdl);
+  // The same for the constants of the later phases (first narrowphase pass: contact point == lane,
+  // visual == lane, mass-matrix row == lane, contact frame and solver scalars): issued here, their
+  // L2 / scalar-cache latency is long gone when the phase starts; fetched where they are used, each
+  // of those phases began with a dependent round trip to L2.
+  int pf_cp_link = -1, pf_vis_link = 0, pf_dof_link = 0;
+  unsigned pf_anc = 0u, pf_cp_anc = 0u;
+  T pf_cp_loc[3] = {T(0), T(0), T(0)}, pf_cp_rad = T(0), pf_vis_X[12];
+  T pf_nb[3], pf_t1[3], pf_t2[3], pf_plane_n[3], pf_plane_c, pf_cfm, pf_erp_dt, pf_rest, pf_mu;
+  int pf_iters, pf_ncp, pf_nv;
+  auto load_phase_consts = [&](const DevModel<T> *md) {
+    pf_ncp = md->has_plane ? md->num_cp : 0;
+    pf_nv = md->num_visuals;
+    const int kc = lane < pf_ncp ? lane : 0;
+    pf_cp_link = md->cp_link[kc];
+    pf_cp_anc = md->anc_dofs[pf_cp_link >= 0 ? pf_cp_link : 0];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pf_cp_loc[c] = md->cp_local[c][kc];
+    pf_cp_rad = md->cp_radius[kc];
+    const int kv = lane < pf_nv ? lane : 0;
+    pf_vis_link = md->vis_link[kv];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) pf_vis_X[c] = md->vis_X[c][kv];
+    pf_dof_link = md->dof_link[lane < md->dof_qd ? lane : 0];
+    pf_anc = md->anc_dofs[pf_dof_link];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      pf_nb[c] = md->nb[c];
+      pf_t1[c] = md->t1[c];
+      pf_t2[c] = md->t2[c];
+      pf_plane_n[c] = md->plane_n[c];
+    }
+    pf_plane_c = md->plane_c;
+    pf_cfm = md->cfm;
+    pf_erp_dt = md->erp_over_dt;
+    pf_rest = md->restitution;
+    pf_mu = md->friction;
+    pf_iters = md->pgs_iterations;
+  };
+  if constexpr (!LOOP) load_phase_consts(mdl);
   int tds_iter = 0;
   (void)tds_iter;
   TDS_STAMP(0);
@@ -743,6 +782,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
   if constexpr (LOOP) load_link_consts(mdl);
+  if constexpr (LOOP) load_phase_consts(mdl);
   T Rp[9], tp[3];
   {
     const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
@@ -996,15 +1036,22 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, ancestor-dof mask (bit pattern)
   const int NCPp = L.NCPp;
   int na = 0;
-  if (mdl->has_plane) {
-    const int ncp = mdl->num_cp;
+  if (pf_ncp > 0) {
+    const int ncp = pf_ncp;
     for (int base = 0; base < ncp; base += G) {
       const int k = base + lane;
       bool act = false;
       T Pb[3] = {T(0), T(0), T(0)}, dist = T(0);
       int lk = -1;
+      unsigned lk_anc = 0u;
       if (k < ncp) {
-        lk = mdl->cp_link[k];
+        const bool first = base == 0;  // wave-uniform: the first pass was prefetched at kernel start
+        lk = pf_cp_link;
+        lk_anc = pf_cp_anc;
+        if (!first) {
+          lk = mdl->cp_link[k];
+          lk_anc = mdl->anc_dofs[lk >= 0 ? lk : 0];
+        }
         T Rl[9], pl[3];
         if (lk >= 0) {
 #pragma unroll
@@ -1017,16 +1064,22 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
           for (int c = 0; c < 3; ++c) pl[c] = mdl->base_t[c];
         }
-        const T loc[3] = {mdl->cp_local[0][k], mdl->cp_local[1][k], mdl->cp_local[2][k]};
+        T loc[3] = {pf_cp_loc[0], pf_cp_loc[1], pf_cp_loc[2]};
+        T rad = pf_cp_rad;
+        if (!first) {
+          loc[0] = mdl->cp_local[0][k];
+          loc[1] = mdl->cp_local[1][k];
+          loc[2] = mdl->cp_local[2][k];
+          rad = mdl->cp_radius[k];
+        }
         T ctr[3];
         mat3_mulv(Rl, loc, ctr);
         ctr[0] += pl[0];
         ctr[1] += pl[1];
         ctr[2] += pl[2];
-        const T n[3] = {mdl->plane_n[0], mdl->plane_n[1], mdl->plane_n[2]};
-        const T rad = mdl->cp_radius[k];
+        const T n[3] = {pf_plane_n[0], pf_plane_n[1], pf_plane_n[2]};
         // t = -(dot(p, -n) + c);  distance = t - r;  point_on_b = p - r n
-        const T t = -((-dot3(ctr, n)) + mdl->plane_c);
+        const T t = -((-dot3(ctr, n)) + pf_plane_c);
         dist = t - rad;
         Pb[0] = ctr[0] - rad * n[0];
         Pb[1] = ctr[1] - rad * n[1];
@@ -1042,7 +1095,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         cpx[1 * NCPp + slot] = Pb[1];
         cpx[2 * NCPp + slot] = Pb[2];
         cpx[3 * NCPp + slot] = dist;
-        cpx[4 * NCPp + slot] = bits_to_scalar<T>(lk >= 0 ? mdl->anc_dofs[lk] : 0u);
+        cpx[4 * NCPp + slot] = bits_to_scalar<T>(lk >= 0 ? lk_anc : 0u);
       }
       na += __popcll(mine);
     }
@@ -1055,20 +1108,28 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // ---- M1. visual poses of y (they use the PRE-step X_world, locomotion_contact_simulation.h:281-299)
   {
     T *const yo = y_out + (size_t)env * out_dim;
-    const int nv = mdl->num_visuals;
+    const int nv = pf_nv;
     const int vbase = nq + nd;
     if (last_run) {  // y describes the last normal step of the launch
       for (int k = lane; k < nv; k += G) {
-        const int lk = mdl->vis_link[k];
+        const bool first = k == lane;  // wave-uniform: visual == lane was prefetched at kernel start
+        int lk = pf_vis_link;
+        if (!first) lk = mdl->vis_link[k];
         T Rl[9], pl[3], Rv[9], pv[3];
   #pragma unroll
         for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
   #pragma unroll
         for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
   #pragma unroll
-        for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
+        for (int c = 0; c < 9; ++c) Rv[c] = pf_vis_X[c];
   #pragma unroll
-        for (int c = 0; c < 3; ++c) pv[c] = mdl->vis_X[9 + c][k];
+        for (int c = 0; c < 3; ++c) pv[c] = pf_vis_X[9 + c];
+        if (!first) {
+  #pragma unroll
+          for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
+  #pragma unroll
+          for (int c = 0; c < 3; ++c) pv[c] = mdl->vis_X[9 + c][k];
+        }
         T Ro[9], po[3], qo[4];
         mat3_mul(Rl, Rv, Ro);
         mat3_mulv(Rl, pv, po);
@@ -1265,8 +1326,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     {
       const int d = lane;
       const bool isd = d < nd;
-      const int lk = isd ? mdl->dof_link[d] : 0;
-      const unsigned anc = isd ? mdl->anc_dofs[lk] : 0u;
+      const int lk = isd ? pf_dof_link : 0;
+      const unsigned anc = isd ? pf_anc : 0u;
       T Fd[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) Fd[k] = isd ? Fs[lk * TDS_S2 + k] : T(0);
@@ -1383,9 +1444,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     const int NA = __builtin_amdgcn_readfirstlane(NAv);
     const int nr = 3 * NA;
-    const T nb[3] = {mdl->nb[0], mdl->nb[1], mdl->nb[2]};
-    const T t1[3] = {mdl->t1[0], mdl->t1[1], mdl->t1[2]};
-    const T t2[3] = {mdl->t2[0], mdl->t2[1], mdl->t2[2]};
+    const T nb[3] = {pf_nb[0], pf_nb[1], pf_nb[2]};
+    const T t1[3] = {pf_t1[0], pf_t1[1], pf_t1[2]};
+    const T t2[3] = {pf_t2[0], pf_t2[1], pf_t2[2]};
     {
       const int d = lane;
       T sd[6];
@@ -1421,7 +1482,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     // ---- K. per row (lane == row): b_r, forward substitution  L z = J_r^T  in registers,
     //         G_rr = z.D^-1.z,  1/(G_rr + cfm);  the row is stored back as z~ = D^-1/2 z so that
     //         A_rs = J_r M^-1 J_s^T = z~_r . z~_s  — one matrix instead of J and M^-1 J^T.
-    const T cfm = mdl->cfm, erp_dt = mdl->erp_over_dt, rest = mdl->restitution;
+    const T cfm = pf_cfm, erp_dt = pf_erp_dt, rest = pf_rest;
     const bool any_slab = nr > ZR;  // wave-uniform
     if (any_slab)
       tds_row_solve<true, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov, rov,
@@ -1438,8 +1499,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     {
       const int d = lane;
       const bool dz = d < NDP;
-      const T mu = mdl->friction;
-      const int iters = mdl->pgs_iterations;
+      const T mu = pf_mu;
+      const int iters = pf_iters;
       const T u = any_slab ? tds_pgs<true, T, G, NDP>(lane, NA, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov)
                            : tds_pgs_lds<T, G, NDP>(lane, NA, ZR, iters, mu, Zs, rws, xs);
       // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
