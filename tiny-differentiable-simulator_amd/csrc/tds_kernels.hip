@@ -1104,6 +1104,15 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // constraint pipeline (CRBA, LDL^T, rows, PGS) is skipped: with keep_all_points_ the reference
   // still solves, but every row is identically zero and leaves qd untouched.
   const bool wave_contacts = __any(na > 0) != 0;
+  // wave-uniform constraint-row layout (see tds_row_solve): NA = the largest contact count among the
+  // wavefront's environments (computed here, long before phase J needs it)
+  int NAv = na;
+#pragma unroll
+  for (int msk = G; msk < 64; msk <<= 1) {
+    const int o = __shfl_xor(NAv, msk, 64);
+    NAv = o > NAv ? o : NAv;
+  }
+  const int NA = __builtin_amdgcn_readfirstlane(NAv);
 
   // ---- M1. visual poses of y (they use the PRE-step X_world, locomotion_contact_simulation.h:281-299)
   {
@@ -1435,36 +1444,40 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     const int OVR = L.ovrows;  // surplus rows available per environment in the slab
     volatile T *const zov = (ovf != nullptr && live) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
     volatile T *const rov = zov != nullptr ? zov + (size_t)OVR * NDs : nullptr;  // [3][OVR]
-    // wave-uniform row layout (see tds_row_solve): NA = the largest contact count in this wavefront
-    int NAv = na;
-#pragma unroll
-    for (int msk = G; msk < 64; msk <<= 1) {
-      const int o = __shfl_xor(NAv, msk, 64);
-      NAv = o > NAv ? o : NAv;
-    }
-    const int NA = __builtin_amdgcn_readfirstlane(NAv);
     const int nr = 3 * NA;
     const T nb[3] = {pf_nb[0], pf_nb[1], pf_nb[2]};
     const T t1[3] = {pf_t1[0], pf_t1[1], pf_t1[2]};
     const T t2[3] = {pf_t2[0], pf_t2[1], pf_t2[2]};
     {
+      // column d of the point Jacobian of contact point P: col = s_lin - P x s_ang  (xs.bottom = st.bottom -
+      // point x st.top, jacobian.hpp:56-72); its components along n, t1, t2 are affine in P:
+      //   e . col = e . s_lin + P . (e x s_ang)      -> three FMAs per row instead of a cross and a dot
       const int d = lane;
       T sd[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) sd[k] = d < nd ? swd[k * NDs + d] : T(0);
-      for (int a = 0; a < na; ++a) {
-        const T P[3] = {cpx[0 * NCPp + a], cpx[1 * NCPp + a], cpx[2 * NCPp + a]};
-        const unsigned msk = scalar_to_bits<T>(cpx[4 * NCPp + a]);
-        if (d < NDP) {
-          T col[3] = {T(0), T(0), T(0)};
-          if (d < nd && ((msk >> d) & 1u)) {  // xs.bottom = st.bottom - point x st.top
-            T c[3];
-            cross3(P, sd, c);
-            col[0] = sd[3] - c[0];
-            col[1] = sd[4] - c[1];
-            col[2] = sd[5] - c[2];
-          }
-          const T jn = dot3(nb, col), j1 = dot3(t1, col), j2 = dot3(t2, col);
+      T cnv[3], c1v[3], c2v[3];
+      cross3(nb, sd, cnv);
+      cross3(t1, sd, c1v);
+      cross3(t2, sd, c2v);
+      const T cn0 = dot3(nb, sd + 3), c10 = dot3(t1, sd + 3), c20 = dot3(t2, sd + 3);
+      // software pipeline over the wavefront's contact slots: slot a + 1 is fetched while a is written
+      T Pn[3] = {cpx[0], cpx[NCPp], cpx[2 * NCPp]};
+      unsigned mskn = scalar_to_bits<T>(cpx[4 * NCPp]);
+      const int lastc = NCPp - 1;
+      for (int a = 0; a < NA; ++a) {
+        const T P[3] = {Pn[0], Pn[1], Pn[2]};
+        const unsigned msk = mskn;
+        const int an = a + 1 < lastc ? a + 1 : lastc;
+        Pn[0] = cpx[0 * NCPp + an];
+        Pn[1] = cpx[1 * NCPp + an];
+        Pn[2] = cpx[2 * NCPp + an];
+        mskn = scalar_to_bits<T>(cpx[4 * NCPp + an]);
+        if (d < NDP && a < na) {
+          const bool on = d < nd && ((msk >> d) & 1u);
+          const T jn = on ? cn0 + dot3(P, cnv) : T(0);
+          const T j1 = on ? c10 + dot3(P, c1v) : T(0);
+          const T j2 = on ? c20 + dot3(P, c2v) : T(0);
           const int r0 = a, r1 = NA + a, r2 = 2 * NA + a;
           if (r0 < ZR) Zs[r0 * NDs + d] = jn; else zov[(r0 - ZR) * NDs + d] = jn;
           if (r1 < ZR) Zs[r1 * NDs + d] = j1; else zov[(r1 - ZR) * NDs + d] = j1;
