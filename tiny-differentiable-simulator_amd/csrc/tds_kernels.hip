@@ -1689,11 +1689,13 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 // padded dof count = template parameter NDP of the kernel.  Besides the coarse widths (8/16/24/32) the
 // widths of the two benchmark robots are instantiated exactly for their natural lane count
 // (Ant: 14 dof on 16 lanes, Laikago: 18 dof on 32 lanes): LDL^T and the row solves scale with NDP^2.
+#if !defined(TDS_ONLY_F32)
 int tds_padded_dof(int nd, int lanes) {
   if (lanes == 16 && nd > 8 && nd <= 14) return 14;
   if (lanes == 32 && nd > 16 && nd <= 18) return 18;
   return nd <= 8 ? 8 : (nd <= 16 ? 16 : (nd <= 24 ? 24 : 32));
 }
+#endif
 
 template <typename T>
 TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) {
@@ -1809,9 +1811,15 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
   return (int)e;
 }
 
+// The file is compiled twice (csrc/Makefile): -DTDS_ONLY_F64 and -DTDS_ONLY_F32 each instantiate one
+// compute dtype, so that the two halves of the kernel set build in parallel.
+#if !defined(TDS_ONLY_F32)
 template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int);
-template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int, int);
 template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, double *, int, hipStream_t, const TdsStepCtl &, long long *);
-template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, float *, int, hipStream_t, const TdsStepCtl &, long long *);
 template int tds_kernel_max_dynamic_lds<double>(int, int, int);
+#endif
+#if !defined(TDS_ONLY_F64)
+template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int, int);
+template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, float *, int, hipStream_t, const TdsStepCtl &, long long *);
 template int tds_kernel_max_dynamic_lds<float>(int, int, int);
+#endif
