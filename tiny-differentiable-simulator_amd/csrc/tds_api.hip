@@ -193,24 +193,39 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   s->dtype = dtype;
   s->elem = dtype == TDS_DTYPE_F64 ? 8 : 4;
   s->lanes = default_lanes_per_env(model->num_links, model->dof_qd);
-  // contacts whose constraint rows stay in LDS (TDS_HIP_NA_CAP overrides; surplus goes to a slab)
-  int na_cap = 8;
-  if (const char *e = getenv("TDS_HIP_NA_CAP")) na_cap = atoi(e);
   char why[128];
   size_t msize;
   const void *hsrc;
+  const int epw = 64 / s->lanes;
   if (dtype == TDS_DTYPE_F64) {
     tds_build_dev_model<double>(model, &s->h64, why);
-    s->lds = tds_make_lds_layout<double>(s->h64, na_cap, s->lanes);
     msize = sizeof(DevModel<double>);
     hsrc = &s->h64;
   } else {
     tds_build_dev_model<float>(model, &s->h32, why);
-    s->lds = tds_make_lds_layout<float>(s->h32, na_cap, s->lanes);
     msize = sizeof(DevModel<float>);
     hsrc = &s->h32;
   }
-  const int epw = 64 / s->lanes;
+  auto layout = [&](int cap) {
+    return dtype == TDS_DTYPE_F64 ? tds_make_lds_layout<double>(s->h64, cap, s->lanes)
+                                  : tds_make_lds_layout<float>(s->h32, cap, s->lanes);
+  };
+  // Contacts whose constraint rows stay in LDS (the surplus goes to a global slab: exact, slower).
+  // Default: up to 8, lowered (not below 5) if that is what lets EIGHT workgroups share a CU's 160 KiB,
+  // i.e. two wavefronts per SIMD, which hides most of the instruction-stream latency once the batch
+  // provides them (Ant f64: 6 -> 19.8 KiB per workgroup).  TDS_HIP_NA_CAP overrides.
+  int na_cap = 8;
+  if (const char *e = getenv("TDS_HIP_NA_CAP")) {
+    na_cap = atoi(e);
+  } else {
+    const size_t budget = (160 * 1024) / 8;
+    for (int cap = 8; cap >= 5; --cap)
+      if ((size_t)layout(cap).stride * epw * s->elem <= budget) {
+        na_cap = cap;
+        break;
+      }
+  }
+  s->lds = layout(na_cap);
   const int lds_bytes = (int)((size_t)s->lds.stride * epw * s->elem);
   if (lds_bytes > 160 * 1024) {
     delete s;

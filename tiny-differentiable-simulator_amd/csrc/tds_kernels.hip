@@ -392,7 +392,6 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
       rov[OVR + r - ZR] = ai;
       rov[2 * OVR + r - ZR] = g;
     }
-    xs[r] = T(0);
   }
 }
 
@@ -1714,12 +1713,19 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
   int o = 0;
   // persistent for the whole step
   L.xrec = o; o += m.input_dim + 2;  // + x_{t-1} and the done flag of the step loop
-  L.swd = o;  o += 6 * L.NDs;
-  L.cp = o;   o += ncp ? 5 * L.NCPp : 0;
+  // two pairs with disjoint lifetimes share their storage:
+  //   swd  (world motion axes per dof: phases C..J)  |  rows (b, 1/(G+cfm), G per constraint row: K..L)
+  //   cp   (contact points: phases I..K)             |  xrow (impulses x of all rows: L)
+  {
+    const int a = 6 * L.NDs, b = 3 * L.zrows;
+    L.swd = o; L.rows = o; o += a > b ? a : b;
+  }
+  {
+    const int a = ncp ? 5 * L.NCPp : 0, b = 3 * ncp;
+    L.cp = o; L.xrow = o; o += a > b ? a : b;
+  }
   L.Lp = o;   o += (ndp * (ndp - 1)) / 2;
   L.dinv = o; o += 3 * ndp;  // 1/D | sqrt(1/D) | column scratch of the wide LDL^T / rhs exchange
-  L.rows = o; o += 3 * L.zrows;
-  L.xrow = o; o += 3 * ncp;
   // three phase groups share one region:
   //   1. kinematics sweep:   per-link records [X_world(12) | v(6)]              stride TDS_S1
   //   2. composite sweep:    per-link records [f or F(6) | Ic(10)] stride TDS_S2
