@@ -6,10 +6,11 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one closed-loop environment step of every resident env: fresh action batch (already
-in HBM) -> HIP step kernel (PD, ABA, plane contacts, MLCP/PGS, Euler, record packing) -> new
+in HBM) -> HIP step kernel (PD, forward dynamics, plane contacts, MLCP/PGS, Euler, record packing) -> new
 state fed back on device, plus the [obs | reward | done] record written by the same launch.
 With N > 1 ranks each GPU owns its own shard of environments (no data-path collective inside
-the step) and the observation records are all-gathered over RCCL once per step.
+the step) and the observation records are all-gathered over RCCL once per step, on a side stream,
+overlapped with the next step.
 
 Prints ONE JSON line on rank 0 (contract in the project brief): value = total env-steps / s
 over all GPUs, plus `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM) and
