@@ -310,17 +310,21 @@ int tds_hip_kernel_info(const tds_hip_sim_t *sim, int *lds_bytes_per_env, int *t
  * objects — apply gravity, pairwise narrowphase, RigidBodyConstraintSolver (sequential impulses
  * with Baumgarte stabilisation and Coulomb friction), integrate.
  * Reference: src/world.hpp:293-366 (step), :163-204 (pairs), src/rigid_body.hpp:26-123,
- * src/rb_constraint_solver.hpp:65-168, src/contact_point.hpp:43-125,444-506 (sphere-sphere,
- * plane-sphere incl. the swapped order).  N independent worlds of the same bodies, one launch.
+ * src/rb_constraint_solver.hpp:65-168, src/contact_point.hpp:43-198,405-506: every pair the
+ * reference's CollisionDispatcher knows — sphere-sphere, plane-sphere, plane-capsule (2 end spheres),
+ * plane-box (8 corner spheres), capsule-sphere, each also in the swapped order; any other pair
+ * produces no contact, as in the reference.  N independent worlds of the same bodies, one launch.
  * ====================================================================================== */
 #define TDS_RB_MAX_BODIES 16
 #define TDS_RB_STATE 13 /* per body: position(3) | orientation quaternion x y z w (4) | linear velocity(3) | angular velocity(3) */
 
 typedef struct tds_rb_body {
   double mass;          /* 0: static (inv_mass = 0, inv_inertia = 0; rigid_body.hpp:49-53), else inv_inertia = 1 */
-  int32_t geom_type;    /* TDS_GEOM_SPHERE or TDS_GEOM_PLANE */
+  int32_t geom_type;    /* TDS_GEOM_SPHERE / PLANE / CAPSULE / BOX */
   int32_t pad_;
-  double radius;        /* sphere */
+  double radius;        /* sphere, capsule (box: radius of the rounded corners, normally 0) */
+  double length;        /* capsule: distance of the end-sphere centres along local z */
+  double extents[3];    /* box: full edge lengths */
   double plane_normal[3];
   double plane_constant;
 } tds_rb_body_t;

@@ -346,6 +346,12 @@ int tdsref_rb_step(const tds_rb_model_t *m, int n, int steps, double *state) {
       const Geometry<Alg> *g;
       if (b.geom_type == TDS_GEOM_SPHERE) {
         g = world.create_sphere(b.radius);
+      } else if (b.geom_type == TDS_GEOM_CAPSULE) {
+        g = world.create_capsule(b.radius, b.length);
+      } else if (b.geom_type == TDS_GEOM_BOX) {
+        Box<Alg> *bx = world.create_box(Alg::Vector3(b.extents[0], b.extents[1], b.extents[2]));
+        bx->set_radius(b.radius);
+        g = bx;
       } else {
         Plane<Alg> *pl = world.create_plane();
         *pl = Plane<Alg>(Alg::Vector3(b.plane_normal[0], b.plane_normal[1], b.plane_normal[2]), b.plane_constant);

@@ -880,21 +880,69 @@ static void rb_world_step(const tds_rb_model_t *m, double *S /* [nb][13] */) {
   /* apply_gravity + apply_force_impulse + clear_forces (world.hpp:301-310, rigid_body.hpp:81-97) */
   for (int i = 0; i < nb; ++i)
     for (int k = 0; k < 3; ++k) S[i * 13 + 7 + k] += (m->bodies[i].mass * m->gravity[k]) * inv_mass[i] * dt;
-  /* pairwise narrowphase, i < j (world.hpp:163-191), dispatcher incl. swap (contact_point.hpp:468-496) */
-  rb_contact_t cs[TDS_RB_MAX_BODIES * TDS_RB_MAX_BODIES / 2];
+  /* pairwise narrowphase, i < j (world.hpp:163-191), dispatcher incl. swap (contact_point.hpp:468-496).
+     Capsules and boxes collide as sets of spheres placed by Pose * offset (contact_point.hpp:127-198,
+     405-438): capsule = 2 end spheres at local (0,0,+-L/2), box = 8 corner spheres of radius
+     max(1e-2, box radius) at the corners pulled in by that radius (geometry.hpp:244-262). */
+  rb_contact_t cs[TDS_RB_MAX_BODIES * TDS_RB_MAX_BODIES * 4];
   int nc = 0;
   for (int i = 0; i < nb; ++i)
     for (int j = i + 1; j < nb; ++j) {
-      const tds_rb_body_t *A = &m->bodies[i], *B = &m->bodies[j];
-      rb_contact_t c;
-      int got = 0;
-      if (A->geom_type == TDS_GEOM_SPHERE && B->geom_type == TDS_GEOM_SPHERE) {
-        got = rb_sphere_sphere(S + i * 13, A->radius, S + j * 13, B->radius, &c);
-      } else if (A->geom_type == TDS_GEOM_PLANE && B->geom_type == TDS_GEOM_SPHERE) {
-        got = rb_plane_sphere(A->plane_normal, A->plane_constant, S + j * 13, B->radius, &c);
-      } else if (A->geom_type == TDS_GEOM_SPHERE && B->geom_type == TDS_GEOM_PLANE) {
-        got = rb_plane_sphere(B->plane_normal, B->plane_constant, S + i * 13, A->radius, &c);
-        if (got) { /* swap normal and points a, b */
+      const int ti = m->bodies[i].geom_type, tj = m->bodies[j].geom_type;
+      /* P = the plane / the single sphere of the pair, Q = the body expanded into spheres */
+      int p = -1, q = -1, kind = -1; /* kind 0: plane(p) vs spheres(q); 1: spheres(p = capsule or sphere) vs sphere(q) */
+      int swap = 0;
+      if (ti == TDS_GEOM_PLANE && (tj == TDS_GEOM_SPHERE || tj == TDS_GEOM_CAPSULE || tj == TDS_GEOM_BOX)) {
+        p = i; q = j; kind = 0;
+      } else if (tj == TDS_GEOM_PLANE && (ti == TDS_GEOM_SPHERE || ti == TDS_GEOM_CAPSULE || ti == TDS_GEOM_BOX)) {
+        p = j; q = i; kind = 0; swap = 1;
+      } else if ((ti == TDS_GEOM_SPHERE || ti == TDS_GEOM_CAPSULE) && tj == TDS_GEOM_SPHERE) {
+        p = i; q = j; kind = 1;
+      } else if (ti == TDS_GEOM_SPHERE && tj == TDS_GEOM_CAPSULE) {
+        p = j; q = i; kind = 1; swap = 1;
+      } else {
+        continue;
+      }
+      /* the spheres of the expanded body: e = q (kind 0) or p (kind 1) */
+      const int e = kind == 0 ? q : p;
+      const tds_rb_body_t *E = &m->bodies[e];
+      double off[8][3], rad;
+      int ns;
+      if (E->geom_type == TDS_GEOM_SPHERE) {
+        ns = 1; rad = E->radius; off[0][0] = off[0][1] = off[0][2] = 0.0;
+      } else if (E->geom_type == TDS_GEOM_CAPSULE) {
+        ns = 2; rad = E->radius;
+        off[0][0] = off[0][1] = 0.0; off[0][2] = 0.5 * E->length;
+        off[1][0] = off[1][1] = 0.0; off[1][2] = -0.5 * E->length;
+      } else {
+        ns = 8; rad = E->radius > 1e-2 ? E->radius : 1e-2;
+        const double dx = E->extents[0] * 0.5 - rad, dy = E->extents[1] * 0.5 - rad, dz = E->extents[2] * 0.5 - rad;
+        for (int c = 0; c < 8; ++c) {
+          off[c][0] = (c & 4) ? -dx : dx;
+          off[c][1] = (c & 2) ? -dy : dy;
+          off[c][2] = (c & 1) ? -dz : dz;
+        }
+      }
+      for (int sidx = 0; sidx < ns; ++sidx) {
+        double ctr[3], r3[3];
+        if (E->geom_type == TDS_GEOM_SPHERE) {
+          for (int k = 0; k < 3; ++k) ctr[k] = S[e * 13 + k];
+        } else {
+          quat_rotate(S + e * 13 + 3, off[sidx], r3); /* Pose::operator*, pose.hpp:47-53 */
+          for (int k = 0; k < 3; ++k) ctr[k] = S[e * 13 + k] + r3[k];
+        }
+        rb_contact_t c;
+        int got;
+        if (kind == 0) {
+          /* Plane's constructor normalises the normal (geometry.hpp:163-168) */
+          const double *pn = m->bodies[p].plane_normal;
+          const double nl = sqrt(v3_dot(pn, pn));
+          const double nn[3] = {pn[0] / nl, pn[1] / nl, pn[2] / nl};
+          got = rb_plane_sphere(nn, m->bodies[p].plane_constant, ctr, rad, &c);
+        }
+        else got = rb_sphere_sphere(ctr, rad, S + q * 13, m->bodies[q].radius, &c);
+        if (!got) continue;
+        if (swap) { /* swap normal and points a, b */
           for (int k = 0; k < 3; ++k) {
             double t = c.pa[k];
             c.pa[k] = c.pb[k];
@@ -902,8 +950,6 @@ static void rb_world_step(const tds_rb_model_t *m, double *S /* [nb][13] */) {
             c.nb[k] = -c.nb[k];
           }
         }
-      }
-      if (got) {
         c.a = i;
         c.b = j;
         cs[nc++] = c;

@@ -34,6 +34,33 @@ def make_worlds(n, seed, plane_last=False):
     return m, st
 
 
+def make_mixed_worlds(n, seed, order):
+    """spheres, capsules and boxes tumbling on a slightly tilted plane, in a given body order (the order
+    decides which pairs the reference's dispatcher runs swapped)"""
+    rng = np.random.default_rng(seed)
+    lib = {"plane": {"mass": 0.0, "plane": (0.05, 0.0, 1.0, 0.0)},
+           "s1": {"mass": 1.0, "sphere": 0.15}, "s2": {"mass": 0.7, "sphere": 0.10},
+           "c1": {"mass": 1.2, "capsule": (0.08, 0.40)}, "c2": {"mass": 0.9, "capsule": (0.10, 0.25)},
+           "b1": {"mass": 2.0, "box": (0.30, 0.20, 0.25)}, "b2": {"mass": 1.5, "box": (0.20, 0.20, 0.20)}}
+    bodies = [lib[k] for k in order]
+    m = tds_amd.make_rb_model(bodies, dt=1.0 / 120.0, solver_iterations=3, friction=0.5, restitution=0.1)
+    nb = len(bodies)
+    st = np.zeros((n, nb, 13))
+    st[:, :, 6] = 1.0
+    for i, k in enumerate(order):
+        if k == "plane":
+            continue
+        st[:, i, 0:2] = rng.uniform(-0.5, 0.5, (n, 2))
+        st[:, i, 2] = rng.uniform(0.05, 0.7, n)
+        q = rng.normal(size=(n, 4))
+        st[:, i, 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+        st[:, i, 7:10] = rng.uniform(-1, 1, (n, 3))
+        st[:, i, 10:13] = rng.uniform(-3, 3, (n, 3))
+    return m, st
+
+
+MIXED = {"c": ["plane", "s1", "c1", "b1", "s2", "c2", "b2"], "d": ["c1", "s1", "b1", "plane", "s2", "c2"],
+         "e": ["s1", "c1", "s2", "b1", "plane"]}
 FIXTURE = os.path.join(GOLDEN, "rigid_bodies.npz")
 
 
@@ -45,6 +72,10 @@ def test_oracle_matches_committed_fixture(built):
         out = oraclelib.rb_step(m, st, int(g["steps"]))
         assert rel_err(out, g["y_" + tag], 1e-6) < 1e-12
         assert np.abs(out - st).max() > 0.1          # the spheres did fall / collide
+    for tag, order in MIXED.items():
+        m, st = make_mixed_worlds(16, 21, order)
+        assert np.array_equal(st, g["x_" + tag])
+        assert rel_err(oraclelib.rb_step(m, st, int(g["steps_mixed"])), g["y_" + tag], 1e-6) < 1e-12
 
 
 @pytest.mark.skipif(not os.path.isdir(reflib.REF_ROOT + "/src"), reason="reference tree not present")
@@ -55,6 +86,11 @@ def test_oracle_and_fixture_match_reference_world_step(built):
         ref = reflib.rb_step(m, st, int(g["steps"]))
         assert np.array_equal(ref, g["y_" + tag])                       # the fixture IS the reference's output
         assert np.array_equal(oraclelib.rb_step(m, st, int(g["steps"])), ref)
+    for tag, order in MIXED.items():                                        # capsules, boxes, swapped pairs
+        m, st = make_mixed_worlds(16, 21, order)
+        ref = reflib.rb_step(m, st, int(g["steps_mixed"]))
+        assert np.array_equal(ref, g["y_" + tag])
+        assert np.array_equal(oraclelib.rb_step(m, st, int(g["steps_mixed"])), ref)
     # single steps from fresh states, every contact kind active
     m, st = make_worlds(64, 99)
     st[:, 1:, 2] = np.random.default_rng(1).uniform(0.02, 0.3, (64, 5))      # many penetrating
@@ -76,6 +112,14 @@ def test_hip_rigid_body_worlds(dtype, tol, built):
         out = sim.state.double().cpu().numpy()
         err = rel_err(out, g["y_" + tag], 1e-2)
         print(f"rigid bodies {dtype} ({'plane last' if last else 'plane first'}): {steps} steps, max rel err {err:.2e}")
+        assert err < tol
+    for tag, order in MIXED.items():
+        m, st = make_mixed_worlds(16, 21, order)
+        sim = hip_backend.RigidBodySim(m, 16, dtype=dtype)
+        sim.state.copy_(torch.from_numpy(st).to(sim.torch_dtype).cuda())
+        sim.step(int(g["steps_mixed"]))
+        err = rel_err(sim.state.double().cpu().numpy(), g["y_" + tag], 1e-2)
+        print(f"rigid bodies {dtype} mixed geometries {order}: max rel err {err:.2e}")
         assert err < tol
     # many worlds, one step at a time == all steps in one launch; ragged world count
     m, st = make_worlds(1000, 5)

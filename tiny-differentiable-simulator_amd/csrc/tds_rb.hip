@@ -4,14 +4,16 @@
 // Reference: src/world.hpp:293-366 (step: gravity impulse, pairwise narrowphase, num_solver_iterations
 // sweeps of RigidBodyConstraintSolver::resolve_collision over the contacts, integrate),
 // src/rigid_body.hpp:26-123, src/rb_constraint_solver.hpp:112-165 (the non-CppAD branch),
-// src/contact_point.hpp:43-125, 468-496 (sphere-sphere, plane-sphere, swapped order).
+// src/contact_point.hpp:43-198, 405-438, 468-496 (sphere-sphere, plane-sphere, plane-capsule, plane-box,
+// capsule-sphere, and each in the swapped order).
 //
 // Mapping: none of the five benchmark configurations creates a RigidBody, so this path is built for
 // coverage, not speed: one LANE per world (the reference's own CUDA mapping), positions and velocities
 // of a world's bodies in LDS as [component][lane] (bank-conflict free, dynamic body index without
-// scratch), quaternions stay in HBM (touched once per step).  The contact list is not stored: body
-// positions do not change during the solver sweeps, so each sweep re-derives the contact of a pair from
-// the positions — the same numbers the reference keeps in rb_contacts_.
+// scratch).  The contact list is not stored: body
+// poses do not change during the solver sweeps, so each sweep re-derives the contacts of a pair from
+// the poses — the same numbers the reference keeps in rb_contacts_.  Capsules and boxes collide as the
+// reference's sets of spheres (2 end spheres / 8 corner spheres placed by Pose * offset).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
@@ -33,9 +35,12 @@ template <typename T>
 struct RbDev {
   int nb, iters;
   T dt, grav[3], restitution, friction, erp;
-  T mass[TDS_RB_MAX_BODIES], inv_mass[TDS_RB_MAX_BODIES], inv_in[TDS_RB_MAX_BODIES], radius[TDS_RB_MAX_BODIES];
+  T mass[TDS_RB_MAX_BODIES], inv_mass[TDS_RB_MAX_BODIES], inv_in[TDS_RB_MAX_BODIES];
+  T radius[TDS_RB_MAX_BODIES];  // of the body's collision spheres (box: max(1e-2, corner radius))
   T pn[TDS_RB_MAX_BODIES][3], pc[TDS_RB_MAX_BODIES];
   int type[TDS_RB_MAX_BODIES];
+  int ns[TDS_RB_MAX_BODIES];    // collision spheres of the body: sphere 1, capsule 2, box 8 (plane 0)
+  T off[TDS_RB_MAX_BODIES][8][3];  // their centres in body coordinates
 };
 
 template <typename T>
@@ -49,11 +54,28 @@ __device__ __forceinline__ T dot3(const T *a, const T *b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 
-// LDS slot of (body b, component c) for this lane; c: 0..2 position, 3..5 linear, 6..8 angular velocity
-#define RB_AT(b, c) sm[((b)*9 + (c)) * 64 + lane]
+// q v q^-1 for a unit quaternion (x, y, z, w) — tiny_quaternion.h:171-176
+template <typename T>
+__device__ __forceinline__ void quat_rotate(const T *q, const T *v, T *o) {
+  const T t0 = q[3] * v[0] + q[1] * v[2] - q[2] * v[1];
+  const T t1 = q[3] * v[1] + q[2] * v[0] - q[0] * v[2];
+  const T t2 = q[3] * v[2] + q[0] * v[1] - q[1] * v[0];
+  const T t3 = -q[0] * v[0] - q[1] * v[1] - q[2] * v[2];
+  const T i0 = -q[0], i1 = -q[1], i2 = -q[2], i3 = q[3];
+  o[0] = t3 * i0 + t0 * i3 + t1 * i2 - t2 * i1;
+  o[1] = t3 * i1 + t1 * i3 + t2 * i0 - t0 * i2;
+  o[2] = t3 * i2 + t2 * i3 + t0 * i1 - t1 * i0;
+}
+
+// LDS slot of (body b, component c) for this lane; c: 0..2 position, 3..5 linear, 6..8 angular velocity,
+// 9..12 orientation quaternion (x, y, z, w)
+#define RB_NC 13
+#define RB_AT(b, c) sm[((b)*RB_NC + (c)) * 64 + lane]
 
 template <typename T>
-__global__ __launch_bounds__(64) void tds_rb_kernel(RbDev<T> M, T *__restrict__ state, int n_worlds, int steps) {
+__global__ __launch_bounds__(64) void tds_rb_kernel(const RbDev<T> *__restrict__ Mp, T *__restrict__ state, int n_worlds,
+                                                    int steps) {
+  const RbDev<T> &M = *Mp;  // (too large for the kernel-argument segment)
   extern __shared__ __align__(16) unsigned char rb_smem_raw[];
   T *const sm = reinterpret_cast<T *>(rb_smem_raw);
   const int lane = threadIdx.x;
@@ -68,6 +90,8 @@ __global__ __launch_bounds__(64) void tds_rb_kernel(RbDev<T> M, T *__restrict__ 
       RB_AT(b, 3 + k) = valid ? S[b * TDS_RB_STATE + 7 + k] : T(0);
       RB_AT(b, 6 + k) = valid ? S[b * TDS_RB_STATE + 10 + k] : T(0);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) RB_AT(b, 9 + k) = valid ? S[b * TDS_RB_STATE + 3 + k] : T(k == 3);
   }
   const T dt = M.dt;
   for (int st = 0; st < steps; ++st) {
@@ -81,46 +105,74 @@ __global__ __launch_bounds__(64) void tds_rb_kernel(RbDev<T> M, T *__restrict__ 
       for (int i = 0; i < nb; ++i) {
         for (int j = i + 1; j < nb; ++j) {
           const int ti = M.type[i], tj = M.type[j];  // wave-uniform
-          T nbv[3], pa[3], pb[3], dist;
-          bool got = false;
+          // dispatcher (contact_point.hpp:444-496): P = the plane or the lone sphere, the other body is
+          // expanded into its collision spheres; swapped = the reference ran the pair as (j, i)
+          int pp, qq, kind;  // kind 0: plane(pp) vs spheres of qq;  1: spheres of pp (capsule / sphere) vs sphere qq
+          bool swapped = false;
+          const bool jball = tj == TDS_GEOM_SPHERE || tj == TDS_GEOM_CAPSULE || tj == TDS_GEOM_BOX;
+          const bool iball = ti == TDS_GEOM_SPHERE || ti == TDS_GEOM_CAPSULE || ti == TDS_GEOM_BOX;
+          if (ti == TDS_GEOM_PLANE && jball) {
+            pp = i; qq = j; kind = 0;
+          } else if (tj == TDS_GEOM_PLANE && iball) {
+            pp = j; qq = i; kind = 0; swapped = true;
+          } else if ((ti == TDS_GEOM_SPHERE || ti == TDS_GEOM_CAPSULE) && tj == TDS_GEOM_SPHERE) {
+            pp = i; qq = j; kind = 1;
+          } else if (ti == TDS_GEOM_SPHERE && tj == TDS_GEOM_CAPSULE) {
+            pp = j; qq = i; kind = 1; swapped = true;
+          } else {
+            continue;
+          }
+          const int eb = kind == 0 ? qq : pp;  // the expanded body
           const T pi[3] = {RB_AT(i, 0), RB_AT(i, 1), RB_AT(i, 2)};
           const T pj[3] = {RB_AT(j, 0), RB_AT(j, 1), RB_AT(j, 2)};
-          if (ti == TDS_GEOM_SPHERE && tj == TDS_GEOM_SPHERE) {  // contact_point.hpp:43-94
-            const T diff[3] = {pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2]};
+          const T qe[4] = {RB_AT(eb, 9), RB_AT(eb, 10), RB_AT(eb, 11), RB_AT(eb, 12)};
+          const T pe[3] = {RB_AT(eb, 0), RB_AT(eb, 1), RB_AT(eb, 2)};
+          const T rad = M.radius[eb];
+          for (int sx = 0; sx < M.ns[eb]; ++sx) {
+          T ctr[3];
+          if (M.type[eb] == TDS_GEOM_SPHERE) {
+            ctr[0] = pe[0]; ctr[1] = pe[1]; ctr[2] = pe[2];
+          } else {  // Pose * offset (pose.hpp:47-53)
+            const T ov[3] = {M.off[eb][sx][0], M.off[eb][sx][1], M.off[eb][sx][2]};
+            T r3[3];
+            quat_rotate(qe, ov, r3);
+            ctr[0] = pe[0] + r3[0]; ctr[1] = pe[1] + r3[1]; ctr[2] = pe[2] + r3[2];
+          }
+          T nbv[3], pa[3], pb[3], dist;
+          bool got;
+          if (kind == 0) {  // contact_plane_sphere (contact_point.hpp:96-125): A = plane, B = sphere at ctr
+            const T mn[3] = {-M.pn[pp][0], -M.pn[pp][1], -M.pn[pp][2]};
+            const T t = -(dot3(ctr, mn) + M.pc[pp]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              pa[k] = ctr[k] + t * mn[k];
+              pb[k] = ctr[k] - rad * M.pn[pp][k];
+              nbv[k] = mn[k];
+            }
+            dist = t - rad;
+            got = true;
+          } else {          // contact_sphere_sphere (contact_point.hpp:43-94): A = sphere at ctr, B = body qq
+            const T cq[3] = {RB_AT(qq, 0), RB_AT(qq, 1), RB_AT(qq, 2)};
+            const T diff[3] = {ctr[0] - cq[0], ctr[1] - cq[1], ctr[2] - cq[2]};
             const T length = sqrt(dot3(diff, diff));
-            dist = length - (M.radius[i] + M.radius[j]);
+            dist = length - (rad + M.radius[qq]);
             got = length > T(1) / T(100000);
             const T il = T(1) / length;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
               nbv[k] = il * diff[k];
-              pa[k] = pi[k] - M.radius[i] * nbv[k];
+              pa[k] = ctr[k] - rad * nbv[k];
               pb[k] = pa[k] - dist * nbv[k];
             }
-          } else if (ti == TDS_GEOM_PLANE && tj == TDS_GEOM_SPHERE) {  // contact_point.hpp:96-125
-            const T mn[3] = {-M.pn[i][0], -M.pn[i][1], -M.pn[i][2]};
-            const T t = -(dot3(pj, mn) + M.pc[i]);
+          }
+          if (swapped) {  // swap normal and points a, b (contact_point.hpp:484-491)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-              pa[k] = pj[k] + t * mn[k];
-              pb[k] = pj[k] - M.radius[j] * M.pn[i][k];
-              nbv[k] = mn[k];
+              const T t = pa[k];
+              pa[k] = pb[k];
+              pb[k] = t;
+              nbv[k] = -nbv[k];
             }
-            dist = t - M.radius[j];
-            got = true;
-          } else if (ti == TDS_GEOM_SPHERE && tj == TDS_GEOM_PLANE) {  // dispatcher swap, :478-493
-            const T mn[3] = {-M.pn[j][0], -M.pn[j][1], -M.pn[j][2]};
-            const T t = -(dot3(pi, mn) + M.pc[j]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              pb[k] = pi[k] + t * mn[k];
-              pa[k] = pi[k] - M.radius[i] * M.pn[j][k];
-              nbv[k] = -mn[k];
-            }
-            dist = t - M.radius[i];
-            got = true;
-          } else {
-            continue;
           }
           // RigidBodyConstraintSolver::resolve_collision (rb_constraint_solver.hpp:112-165)
           if (!(got && dist < T(0))) continue;
@@ -207,6 +259,7 @@ __global__ __launch_bounds__(64) void tds_rb_kernel(RbDev<T> M, T *__restrict__ 
               RB_AT(j, 6 + k) += M.inv_in[j] * t3[k];
             }
           }
+          }  // collision spheres of the expanded body
         }
       }
     }
@@ -214,9 +267,8 @@ __global__ __launch_bounds__(64) void tds_rb_kernel(RbDev<T> M, T *__restrict__ 
     for (int b = 0; b < nb; ++b) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) RB_AT(b, k) += RB_AT(b, 3 + k) * dt;
-      if (valid) {
-        T *const Q = S + b * TDS_RB_STATE + 3;
-        const T qx = Q[0], qy = Q[1], qz = Q[2], qw = Q[3];
+      {
+        const T qx = RB_AT(b, 9), qy = RB_AT(b, 10), qz = RB_AT(b, 11), qw = RB_AT(b, 12);
         const T w0 = RB_AT(b, 6), w1 = RB_AT(b, 7), w2 = RB_AT(b, 8);
         const T hd = T(0.5) * dt;
         const T ww = (-qx * w0 - qy * w1 - qz * w2) * hd;
@@ -225,10 +277,10 @@ __global__ __launch_bounds__(64) void tds_rb_kernel(RbDev<T> M, T *__restrict__ 
         const T zz = (qw * w2 + qy * w0 - qx * w1) * hd;
         const T nx = qx + xx, ny = qy + yy, nz = qz + zz, nw = qw + ww;
         const T ql = sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
-        Q[0] = nx / ql;
-        Q[1] = ny / ql;
-        Q[2] = nz / ql;
-        Q[3] = nw / ql;
+        RB_AT(b, 9) = nx / ql;
+        RB_AT(b, 10) = ny / ql;
+        RB_AT(b, 11) = nz / ql;
+        RB_AT(b, 12) = nw / ql;
       }
     }
   }
@@ -240,6 +292,8 @@ __global__ __launch_bounds__(64) void tds_rb_kernel(RbDev<T> M, T *__restrict__ 
         S[b * TDS_RB_STATE + 7 + k] = RB_AT(b, 3 + k);
         S[b * TDS_RB_STATE + 10 + k] = RB_AT(b, 6 + k);
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) S[b * TDS_RB_STATE + 3 + k] = RB_AT(b, 9 + k);
     }
   }
 }
@@ -259,8 +313,25 @@ void rb_build(const tds_rb_model_t *m, RbDev<T> *d) {
     d->mass[i] = (T)b.mass;
     d->inv_mass[i] = b.mass == 0.0 ? T(0) : (T)(1.0 / b.mass);  // rigid_body.hpp:49-53
     d->inv_in[i] = b.mass == 0.0 ? T(0) : T(1);                  // zero33 / eye3
-    d->radius[i] = (T)b.radius;
     d->type[i] = b.geom_type;
+    double rad = b.radius;
+    if (b.geom_type == TDS_GEOM_SPHERE) {
+      d->ns[i] = 1;
+    } else if (b.geom_type == TDS_GEOM_CAPSULE) {  // contact_point.hpp:143-158
+      d->ns[i] = 2;
+      d->off[i][0][2] = (T)(0.5 * b.length);
+      d->off[i][1][2] = (T)(-0.5 * b.length);
+    } else if (b.geom_type == TDS_GEOM_BOX) {      // contact_point.hpp:179-196, geometry.hpp:244-259
+      d->ns[i] = 8;
+      rad = b.radius > 1e-2 ? b.radius : 1e-2;
+      const double dx = b.extents[0] * 0.5 - rad, dy = b.extents[1] * 0.5 - rad, dz = b.extents[2] * 0.5 - rad;
+      for (int c = 0; c < 8; ++c) {
+        d->off[i][c][0] = (T)((c & 4) ? -dx : dx);
+        d->off[i][c][1] = (T)((c & 2) ? -dy : dy);
+        d->off[i][c][2] = (T)((c & 1) ? -dz : dz);
+      }
+    }
+    d->radius[i] = (T)rad;
     // Plane's constructor normalises the normal (geometry.hpp:163-168)
     double nl = sqrt(b.plane_normal[0] * b.plane_normal[0] + b.plane_normal[1] * b.plane_normal[1] +
                      b.plane_normal[2] * b.plane_normal[2]);
@@ -277,7 +348,7 @@ struct tds_rb_sim {
   int num_worlds = 0, device = 0, dtype = TDS_DTYPE_F64;
   size_t elem = 8;
   hipStream_t stream = nullptr;
-  void *d_state = nullptr;
+  void *d_state = nullptr, *d_model = nullptr;
   RbDev<double> h64;
   RbDev<float> h32;
   std::vector<float> stage;
@@ -303,8 +374,9 @@ int tds_rb_create(const tds_rb_model_t *model, int num_worlds, int device, int d
   if (model->num_bodies < 1 || model->num_bodies > TDS_RB_MAX_BODIES) return rb_fail(TDS_ERR_INVALID_ARG, "num_bodies out of range");
   if (model->solver_iterations < 0 || !(model->dt > 0)) return rb_fail(TDS_ERR_INVALID_ARG, "bad solver_iterations / dt");
   for (int i = 0; i < model->num_bodies; ++i)
-    if (model->bodies[i].geom_type != TDS_GEOM_SPHERE && model->bodies[i].geom_type != TDS_GEOM_PLANE)
-      return rb_fail(TDS_ERR_UNSUPPORTED, "rigid bodies support sphere and plane geometries");
+    if (model->bodies[i].geom_type != TDS_GEOM_SPHERE && model->bodies[i].geom_type != TDS_GEOM_PLANE &&
+        model->bodies[i].geom_type != TDS_GEOM_CAPSULE && model->bodies[i].geom_type != TDS_GEOM_BOX)
+      return rb_fail(TDS_ERR_UNSUPPORTED, "rigid bodies support sphere, plane, capsule and box geometries");
   if (num_worlds < 1) return rb_fail(TDS_ERR_INVALID_ARG, "num_worlds < 1");
   if (dtype != TDS_DTYPE_F64 && dtype != TDS_DTYPE_F32) return rb_fail(TDS_ERR_INVALID_ARG, "unknown dtype");
   int ndev = 0;
@@ -326,7 +398,16 @@ int tds_rb_create(const tds_rb_model_t *model, int num_worlds, int device, int d
     return rb_fail(TDS_ERR_HIP, "hipMalloc of the state failed");
   }
   (void)hipMemset(s->d_state, 0, bytes);
-  const int lds = model->num_bodies * 9 * 64 * (int)s->elem;
+  {
+    const size_t msz = dtype == TDS_DTYPE_F64 ? sizeof(RbDev<double>) : sizeof(RbDev<float>);
+    const void *src = dtype == TDS_DTYPE_F64 ? (const void *)&s->h64 : (const void *)&s->h32;
+    if (hipMalloc(&s->d_model, msz) != hipSuccess || hipMemcpy(s->d_model, src, msz, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(s->d_state);
+      delete s;
+      return rb_fail(TDS_ERR_HIP, "upload of the rigid-body model failed");
+    }
+  }
+  const int lds = model->num_bodies * RB_NC * 64 * (int)s->elem;
   if (dtype == TDS_DTYPE_F64)
     (void)hipFuncSetAttribute((const void *)tds_rb_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   else
@@ -339,6 +420,7 @@ int tds_rb_destroy(tds_rb_sim_t *s) {
   if (!s) return TDS_OK;
   (void)hipSetDevice(s->device);
   (void)hipFree(s->d_state);
+  (void)hipFree(s->d_model);
   delete s;
   return TDS_OK;
 }
@@ -384,12 +466,14 @@ int tds_rb_step(tds_rb_sim_t *s, int steps) {
   if (!s) return rb_fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   if (steps < 1) return rb_fail(TDS_ERR_INVALID_ARG, "steps < 1");
   const int blocks = (s->num_worlds + 63) / 64;
-  const size_t lds = (size_t)s->model.num_bodies * 9 * 64 * s->elem;
+  const size_t lds = (size_t)s->model.num_bodies * RB_NC * 64 * s->elem;
   if (s->dtype == TDS_DTYPE_F64)
-    hipLaunchKernelGGL(tds_rb_kernel<double>, dim3(blocks), dim3(64), lds, s->stream, s->h64, (double *)s->d_state,
+    hipLaunchKernelGGL(tds_rb_kernel<double>, dim3(blocks), dim3(64), lds, s->stream, (const RbDev<double> *)s->d_model,
+                       (double *)s->d_state,
                        s->num_worlds, steps);
   else
-    hipLaunchKernelGGL(tds_rb_kernel<float>, dim3(blocks), dim3(64), lds, s->stream, s->h32, (float *)s->d_state,
+    hipLaunchKernelGGL(tds_rb_kernel<float>, dim3(blocks), dim3(64), lds, s->stream, (const RbDev<float> *)s->d_model,
+                       (float *)s->d_state,
                        s->num_worlds, steps);
   RB_TRY(hipGetLastError());
   return TDS_OK;

@@ -247,6 +247,8 @@ class RbBody(C.Structure):
         ("geom_type", C.c_int32),
         ("pad_", C.c_int32),
         ("radius", C.c_double),
+        ("length", C.c_double),
+        ("extents", C.c_double * 3),
         ("plane_normal", C.c_double * 3),
         ("plane_constant", C.c_double),
     ]
@@ -269,7 +271,8 @@ class RbModel(C.Structure):
 
 def make_rb_model(bodies, dt=1.0 / 240.0, gravity=(0.0, 0.0, -9.81), solver_iterations=1,
                   restitution=0.0, friction=0.5, erp=0.1) -> RbModel:
-    """bodies: list of dicts {"mass": m, "sphere": radius} or {"mass": 0, "plane": (nx, ny, nz, constant)};
+    """bodies: list of dicts {"mass": m, "sphere": radius} | {"mass": m, "capsule": (radius, length)} |
+    {"mass": m, "box": (ex, ey, ez)} | {"mass": 0, "plane": (nx, ny, nz, constant)};
     the defaults are the reference's (world.hpp:65-71, rb_constraint_solver.hpp:45)."""
     m = RbModel()
     m.abi_version = TDS_HIP_ABI_VERSION
@@ -285,6 +288,13 @@ def make_rb_model(bodies, dt=1.0 / 240.0, gravity=(0.0, 0.0, -9.81), solver_iter
         if "sphere" in b:
             m.bodies[i].geom_type = GEOM_SPHERE
             m.bodies[i].radius = b["sphere"]
+        elif "capsule" in b:
+            m.bodies[i].geom_type = GEOM_CAPSULE
+            m.bodies[i].radius, m.bodies[i].length = b["capsule"]
+        elif "box" in b:
+            m.bodies[i].geom_type = GEOM_BOX
+            for k, v in enumerate(b["box"]):
+                m.bodies[i].extents[k] = v
         else:
             m.bodies[i].geom_type = GEOM_PLANE
             nx, ny, nz, c = b["plane"]
