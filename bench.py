@@ -83,6 +83,26 @@ def cpu_baseline(model_name, n_envs, budget_s=12.0):
             out["reference"] = {"value": sum(counts) / dt, "unit": "env-steps/s", "cores": nth, "kind": "reference",
                                 "sample": f"{sum(counts)} {model_name} steps of step_forward_original "
                                           f"(header-only double path, one sim per thread) in {dt:.1f}s"}
+            # B2: the reference's committed generated kernels (what its OpenMPForwardStepper runs)
+            if model_name in ("ant", "laikago") and hasattr(reflib.lib(), "tdsref_generated_step"):
+                counts = [0] * nth
+                stop = time.perf_counter() + budget_s / 3
+
+                def work2(i):
+                    xs = x[(i * chunk) % n_envs:(i * chunk) % n_envs + chunk]
+                    while time.perf_counter() < stop:
+                        reflib.generated_step(model_name, xs, m.output_dim)
+                        counts[i] += xs.shape[0]
+
+                t0 = time.perf_counter()
+                ths = [threading.Thread(target=work2, args=(i,)) for i in range(nth)]
+                [t.start() for t in ths]
+                [t.join() for t in ths]
+                dt = time.perf_counter() - t0
+                out["generated"] = {"value": sum(counts) / dt, "unit": "env-steps/s", "cores": nth,
+                                    "kind": "reference",
+                                    "sample": f"{sum(counts)} {model_name} steps of the reference's committed "
+                                              f"omp_model_{model_name}_forward_zero_kernel in {dt:.1f}s"}
     except Exception as e:  # the real-reference library is optional on the GPU box
         out["reference_error"] = repr(e)
     return out
@@ -308,6 +328,7 @@ def main():
             primary = cb.get("reference") or cb.get("port")
             out["cpu_baseline"] = primary
             out["cpu_baseline_port"] = cb.get("port")
+            out["cpu_baseline_generated"] = cb.get("generated")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

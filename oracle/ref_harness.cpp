@@ -383,6 +383,23 @@ int tdsref_rb_step(const tds_rb_model_t *m, int n, int steps, double *state) {
   return 0;
 }
 
+// The reference's COMMITTED generated kernels (examples/environments/omp_model_{ant,laikago}_forward_zero.h,
+// what its OpenMPForwardStepper runs: ars_vectorized_environment.h:127-135) — BASELINE.md's "B2, honest best
+// CPU number".  Stateless, so one call per environment from any thread.  Note: the committed
+// Ant artefact is stale w.r.t. the header-only path (1.9e-7 after one step), hence speed baseline only.
+int tdsref_generated_step(const char *name, int n, const double *x, double *y) {
+  const std::string nm(name);
+  if (nm == "ant") {
+    for (int e = 0; e < n; ++e) omp_model_ant_forward_zero_kernel<double>(1, y + (size_t)e * 155, x + (size_t)e * 39);
+    return 0;
+  }
+  if (nm == "laikago") {
+    for (int e = 0; e < n; ++e) omp_model_laikago_forward_zero_kernel<double>(1, y + (size_t)e * 411, x + (size_t)e * 51);
+    return 0;
+  }
+  return -1;
+}
+
 // y[n][output_dim] = reference_step(x[n][input_dim]); y is zero-filled first (the reference's
 // callers hand in zero-initialised vectors, ars_vectorized_environment.h:218-219).
 void tdsref_step(void *h, int n, const double *x, double *y) {

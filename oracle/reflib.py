@@ -40,6 +40,8 @@ def lib():
         L.tdsref_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tdsref_debug.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         L.tdsref_hipstepper_selftest.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        if hasattr(L, "tdsref_generated_step"):
+            L.tdsref_generated_step.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
         if hasattr(L, "tdsref_rb_step"):
             L.tdsref_rb_step.argtypes = [C.POINTER(tds_amd.RbModel), C.c_int, C.c_int, C.c_void_p]
         if hasattr(L, "tdsref_rollout"):
@@ -93,6 +95,16 @@ def rollout(name, x0, params, steps, shift=0.0):
     if rc != 0:
         raise RuntimeError(f"tdsref_rollout({name}) failed: {rc}")
     return tot, cnt, fin
+
+
+def generated_step(name, x, out_dim):
+    """the reference's committed generated kernel omp_model_<name>_forward_zero_kernel (stateless)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros((x.shape[0], out_dim))
+    rc = lib().tdsref_generated_step(name.encode(), x.shape[0], x.ctypes.data, y.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"no generated kernel for {name}")
+    return y
 
 
 def rb_step(model, state, steps=1):
