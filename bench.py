@@ -170,10 +170,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # debugging aid for 1-GPU boxes: TDS_BENCH_ONE_DEVICE=1 TDS_BENCH_BACKEND=gloo runs the N > 1 code
+    # path with every rank on cuda:0 (RCCL refuses two ranks on one device); never used for numbers
+    if os.environ.get("TDS_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("TDS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     m = tds_amd.load_model(args.model)
     n = args.envs_per_gpu
