@@ -222,6 +222,36 @@ __device__ __forceinline__ unsigned scalar_to_bits<float>(float v) {
   return (unsigned)__float_as_int(v);
 }
 
+// 32-lane groups span two 16-lane DPP rows (rows 0|1 and 2|3 of the wavefront).  gfx950's
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second:
+// r[0] = {a.row0, b.row0, a.row2, b.row2}, r[1] = {a.row1, b.row1, a.row3, b.row3} — a VALU move, no
+// LDS round trip (ds_bpermute / __shfl).
+// the partner row's value: lane i of row 0 receives lane i of row 1 and vice versa
+__device__ __forceinline__ int swap_rows_b32(int x, bool upper_row) {
+  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+  return (int)(upper_row ? r[0] : r[1]);
+}
+__device__ __forceinline__ double other_row(double v, bool upper_row) {
+  return __hiloint2double(swap_rows_b32(__double2hiint(v), upper_row), swap_rows_b32(__double2loint(v), upper_row));
+}
+__device__ __forceinline__ float other_row(float v, bool upper_row) {
+  return __int_as_float(swap_rows_b32(__float_as_int(v), upper_row));
+}
+// lane SRC (0..31) of each 32-lane group to all its 32 lanes: row broadcast, then copy that row over its partner
+template <int SRC>
+__device__ __forceinline__ int bcast32_b32(int x) {
+  const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x150 + (SRC & 15), 0xF, 0xF, true);
+  const auto r = __builtin_amdgcn_permlane16_swap(t, t, false, false);
+  return (int)(SRC < 16 ? r[0] : r[1]);
+}
+template <int SRC>
+__device__ __forceinline__ double bcast32(double v) {
+  return __hiloint2double(bcast32_b32<SRC>(__double2hiint(v)), bcast32_b32<SRC>(__double2loint(v)));
+}
+template <int SRC>
+__device__ __forceinline__ float bcast32(float v) {
+  return __int_as_float(bcast32_b32<SRC>(__float_as_int(v)));
+}
 // sum over the G lanes of an environment; every lane receives the total.  Strides 8,4,2,1 are
 // row rotations (DPP row_ror), wider strides go through the LDS crossbar (ds_bpermute).
 template <typename T, int G>
@@ -230,8 +260,12 @@ __device__ __forceinline__ T group_sum(T v) {
   v = dpp_add<0x124>(v);  // row_ror:4
   v = dpp_add<0x122>(v);  // row_ror:2
   v = dpp_add<0x121>(v);  // row_ror:1
+  if constexpr (G == 32) {
+    v += other_row(v, (threadIdx.x & 16) != 0);
+  } else {
 #pragma unroll
-  for (int m = 16; m < G; m <<= 1) v += __shfl_xor(v, m, G);
+    for (int m = 16; m < G; m <<= 1) v += __shfl_xor(v, m, G);
+  }
   return v;
 }
 
@@ -266,6 +300,8 @@ template <typename T, int G, int NDP, int SRC>
 __device__ __forceinline__ T lane_bcast(T v) {
   if constexpr (NDP <= 16)
     return dpp_bcast<SRC & 15>(v);
+  else if constexpr (G == 32)
+    return bcast32<SRC>(v);
   else
     return __shfl(v, SRC, G);
 }
