@@ -1,7 +1,7 @@
 // tds_kernels.hip — the MI355X (gfx950 / CDNA4) step kernel.
 //
 // One launch advances N independent environments by one step of the reference's
-//   PD -> forward_dynamics (ABA) -> integrate_euler_qdd -> World::step (plane contacts +
+//   PD -> forward_dynamics -> integrate_euler_qdd -> World::step (plane contacts +
 //   MLCP / projected Gauss-Seidel) -> integrate_euler -> pack
 // (reference: examples/environments/locomotion_contact_simulation.h:151-304).
 //
@@ -13,20 +13,23 @@
 // read / written by consecutive lanes (env-major records == coalesced for lane-per-component).
 //
 // Formulation (differs from the reference's, results agree to round-off; parity is enforced by
-// tests/ against oracle/ and the golden vectors):
-//   * all spatial quantities are expressed in WORLD coordinates about the world origin, so the
-//     tree sweeps need no 6x6 congruence transforms:  IA_parent += Ia,  pA_parent += pa;
-//     (the reference transforms link-to-parent with dense 6x6x6 products,
-//      src/dynamics/forward_dynamics.hpp:187-189, src/dynamics/mass_matrix.hpp:45-46)
-//   * rigid-body inertias are kept as (I_sym[6], h[3], m) = 10 numbers; only the articulated
-//     inertia needs the full symmetric 6x6 (I[6], H[9], M[6]);
-//   * CRBA composite inertias ride along the ABA backward sweep;
-//   * M = L D L^T (no square roots), B = M^-1 J^T by two triangular solves per constraint row;
-//   * PGS runs on  w = M^-1 J^T x  instead of A = J M^-1 J^T:  delta_i = J_i.w - (J_i.B_i) x_i,
-//     so A (51x51 for Ant) is never formed and the final  qd -= M^-1 J^T p  is simply  qd -= w;
+// tests/ against oracle/ and the golden vectors; DESIGN.md "Reformulation"):
+//   * all spatial quantities are expressed in WORLD coordinates about the world origin, so nothing is
+//     transformed between link frames (the reference transforms link-to-parent with dense 6x6x6
+//     products, src/dynamics/forward_dynamics.hpp:187-189, src/dynamics/mass_matrix.hpp:45-46);
+//   * rigid and composite inertias are (I_sym[6], h[3], m) = 10 numbers; no 6x6 matrix travels;
+//   * forward dynamics goes through the joint-space inertia the contact solve needs anyway:
+//     M = L D L^T (no square roots, in registers), qdd = M^-1 (tau - C); the bias forces C ride on the
+//     composite-inertia (CRBA) sweep — no articulated-body recursion;
+//   * serial chains hand their sweep state from lane to lane with DPP row shifts; the massless
+//     "virtual" base chain is collapsed (prefix-product kinematics, one broadcast of the torso's
+//     composite inertia / force instead of six tree levels);
+//   * constraint rows are stored as z~_r = D^-1/2 L^-1 J_r^T, so A = J M^-1 J^T = Z Z^T is never formed
+//     (51x51 for Ant): PGS runs on u~ = sum_r z~_r x_r, delta_i = z~_i.u~ - G_ii x_i, and the final
+//     qd -= M^-1 J^T p is one back-substitution L^-T D^-1/2 u~;
 //   * rows of separated contacts (distance >= 0) are identically zero in the reference
 //     (keep_all_points_, src/mb_constraint_solver.hpp:285-291) and yield x = 0, so only
-//     penetrating contacts are materialised, in the reference's row order.
+//     penetrating contacts are materialised, in the reference's row order (wave-uniform slots).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
