@@ -81,30 +81,6 @@ __device__ __forceinline__ void sym3_mulv(const T *s, const T *v, T *o) {
   o[1] = y;
   o[2] = z;
 }
-template <typename T>
-__device__ __forceinline__ void mat3_tmulv(const T *m, const T *v, T *o) {  // m^T v
-  const T x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
-  const T y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
-  const T z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
-  o[0] = x;
-  o[1] = y;
-  o[2] = z;
-}
-// [I H; H^T M] v  for the articulated inertia stored as I (sym 6), H (9), M (sym 6)
-template <typename T>
-__device__ __forceinline__ void abi_mulv(const T *I6, const T *H9, const T *M6, const T *v, T *o) {
-  T t3[3];
-  sym3_mulv(I6, v, o);
-  mat3_mulv(H9, v + 3, t3);
-  o[0] += t3[0];
-  o[1] += t3[1];
-  o[2] += t3[2];
-  sym3_mulv(M6, v + 3, o + 3);
-  mat3_tmulv(H9, v, t3);
-  o[3] += t3[0];
-  o[4] += t3[1];
-  o[5] += t3[2];
-}
 // 1/x to full precision: hardware reciprocal estimate + Newton-Raphson (2 steps f64, 1 step f32).
 // ~5 dependent instructions instead of the ~12 of an IEEE division; operands here are pivots /
 // diagonal entries in the normal range, no denormal or infinity handling needed.
@@ -286,18 +262,6 @@ template <int SRC>
 __device__ __forceinline__ float dpp_bcast(float v) {
   const int b = __float_as_int(v);
   return __int_as_float(__builtin_amdgcn_update_dpp(0, b, 0x150 + SRC, 0xF, 0xF, true));
-}
-// lane SRC (of each 16-lane DPP row) to every lane, without the register copy dpp_bcast needs
-template <int SRC>
-__device__ __forceinline__ double dpp_bcast0(double v) {
-  const int l = __double2loint(v), h = __double2hiint(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, l, 0x150 + SRC, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, h, 0x150 + SRC, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-template <int SRC>
-__device__ __forceinline__ float dpp_bcast0(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + SRC, 0xF, 0xF, true));
 }
 template <typename T, int G, int NDP, int SRC>
 __device__ __forceinline__ T lane_bcast(T v) {
