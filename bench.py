@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=0,
                     help="also time the on-device policy rollout with this many policy steps per launch")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: steps whose [obs|reward|done] records travel in one all-gather (1 = every step)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the N > 1 step loop (pipelined record gather) even with one rank: exercises that code path on a 1-GPU box")
     args = ap.parse_args()
@@ -207,28 +209,46 @@ def main():
     amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
     actions = torch.from_numpy(rng.uniform(-amp, amp, (pool, n, adim))).to(tdt).cuda().contiguous()
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
-    # the one exchange of the multi-GPU path: all-gather of [obs | reward | done] per step over RCCL,
-    # double-buffered on a side stream so that the records of step i travel while step i+1 computes
-    # (nothing in the step depends on them; every gather still completes inside the timed region)
+    # the one exchange of the multi-GPU path: all-gather of the [obs | reward | done] records over RCCL.
+    # Nothing in the step depends on the gathered records (per-environment policies run on device; a
+    # learner consumes trajectories), so the records of B consecutive steps travel in ONE all-gather on a
+    # side stream while the next steps compute: at ~23 us per step a collective per step would be bound by
+    # its host-side launch cost, not by xGMI.  Every record still crosses inside the timed region.
     gather = None
     multi = world > 1 or args.force_gather
+    B = max(1, args.gather_every)
     if multi:
-        gather = tds_amd.sharded.PipelinedObsGather(world * n, sim.obs_dim + 2, tdt, f"cuda:{local_rank}")
-        obs2 = [obs, torch.zeros_like(obs)]
+        # records of B consecutive steps travel together: [B*n, obs_dim+2] per rank and exchange
+        gather = tds_amd.sharded.PipelinedObsGather(world * n * B, sim.obs_dim + 2, tdt, f"cuda:{local_rank}")
+        ring = [torch.zeros((B, n, sim.obs_dim + 2), dtype=tdt, device="cuda") for _ in range(gather.slots)]
+    state = {"i": 0}
 
     def one_step(i):
         if multi:
-            slot = i & 1
-            gather.before_reuse(slot)
-            sim.step(actions[i % pool], 1, obs2[slot])
-            gather.submit(obs2[slot], slot)
+            k = state["i"]
+            slot, j = (k // B) % gather.slots, k % B
+            if j == 0:
+                gather.before_reuse(slot)
+            sim.step(actions[i % pool], 1, ring[slot][j])
+            if j == B - 1:
+                gather.submit(ring[slot].view(B * n, -1), slot)
+            state["i"] = k + 1
         else:
             sim.step(actions[i % pool], 1, obs)
 
+    def flush():
+        """exchange a partially filled record block (end of a region) and wait for everything in flight"""
+        if gather is None:
+            return
+        k = state["i"]
+        if k % B:
+            gather.submit(ring[(k // B) % gather.slots].view(B * n, -1), (k // B) % gather.slots)
+            state["i"] = (k // B + 1) * B
+        gather.wait_all()
+
     for i in range(args.warmup):
         one_step(i)
-    if gather is not None:
-        gather.wait_all()
+    flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -246,8 +266,7 @@ def main():
     ev0.record()
     for i in range(K):
         one_step(i)
-    if gather is not None:
-        gather.wait_all()
+    flush()
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -324,7 +343,7 @@ def main():
                                    f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
                        if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
-                       "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(obs|reward|done) per step, overlapped with the next step" if world > 1 else ""),
+                       "parallelism": f"env-shard x{world}" + (f" + RCCL all_gather of the (obs|reward|done) records of every {B} steps, overlapped with the next steps" if world > 1 else ""),
                        "lanes_per_env": sim.kernel_info()["lanes_per_env"],
                        "lds_bytes_per_env": sim.kernel_info()["lds_bytes_per_env"]},
             "roofline": roof, "finite": finite,

@@ -54,16 +54,16 @@ def _worker(rank, world, port, n_global, width, q):
         # the pipelined variant of the bench loop: double-buffered records, gather of step i in flight
         # while step i + 1 is produced
         pg = PipelinedObsGather(n_global, width, torch.float64, "cpu")
-        local2 = [torch.zeros((hi - lo, width), dtype=torch.float64) for _ in range(2)]
-        for step in range(5):
-            slot = step & 1
+        local2 = [torch.zeros((hi - lo, width), dtype=torch.float64) for _ in range(pg.slots)]
+        for step in range(9):
+            slot = step % pg.slots
             pg.before_reuse(slot)
             env = torch.arange(lo, hi, dtype=torch.float64).unsqueeze(1)
             col = torch.arange(width, dtype=torch.float64).unsqueeze(0)
             local2[slot].copy_(env * 1000 + col + step / 10.0)
             pg.submit(local2[slot], slot)
             if step > 0:  # the previous step's records are complete by now or after the wait
-                prev = pg.result((step - 1) & 1)
+                prev = pg.result((step - 1) % pg.slots)
                 env_all = torch.arange(0, n_global, dtype=torch.float64).unsqueeze(1)
                 ok = ok and bool(torch.equal(prev, env_all * 1000 + col + (step - 1) / 10.0))
         pg.wait_all()
@@ -97,14 +97,14 @@ def test_pipelined_gather_side_stream_single_gpu():
     assert torch.cuda.is_available()
     n, w = 4096, 30
     pg = PipelinedObsGather(n, w, torch.float64, "cuda:0")
-    bufs = [torch.zeros((n, w), dtype=torch.float64, device="cuda") for _ in range(2)]
+    bufs = [torch.zeros((n, w), dtype=torch.float64, device="cuda") for _ in range(pg.slots)]
     base = torch.arange(n * w, dtype=torch.float64, device="cuda").reshape(n, w)
     for step in range(20):
-        slot = step & 1
+        slot = step % pg.slots
         pg.before_reuse(slot)
         bufs[slot].copy_(base + step)
         pg.submit(bufs[slot], slot)
         if step > 0:
-            assert torch.equal(pg.result((step - 1) & 1), base + (step - 1))
+            assert torch.equal(pg.result((step - 1) % pg.slots), base + (step - 1))
     pg.wait_all()
     torch.cuda.synchronize()

@@ -70,14 +70,14 @@ class PipelinedObsGather:
 
         g = PipelinedObsGather(n_global, width, dtype, device)
         for i in range(steps):
-            slot = i & 1
+            slot = i % g.slots
             g.before_reuse(slot)              # the producer may overwrite local[slot] again
             produce(local[slot])              # e.g. HipSim.step(actions, 1, local[slot])
             g.submit(local[slot], slot)
         all_records = g.result(slot)          # [n_global, width] of the last submitted step
     """
 
-    def __init__(self, n_global: int, width: int, dtype, device, group=None, slots: int = 2):
+    def __init__(self, n_global: int, width: int, dtype, device, group=None, slots: int = 4):
         import torch
 
         self.torch = torch
@@ -89,6 +89,7 @@ class PipelinedObsGather:
         if self.is_cuda:
             self.stream = torch.cuda.Stream(device=device)
             self._done = [torch.cuda.Event() for _ in range(slots)]
+            self._ready = [torch.cuda.Event() for _ in range(slots)]
             self._pending = [False] * slots
 
     @property
@@ -99,12 +100,12 @@ class PipelinedObsGather:
         torch = self.torch
         g = self.gathers[slot]
         if self.is_cuda:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream())
+            ready = self._ready[slot]
+            ready.record()                    # on the producer's (current) stream
             self.stream.wait_event(ready)
             with torch.cuda.stream(self.stream):
                 g(local)
-                self._done[slot].record(self.stream)
+            self._done[slot].record(self.stream)
             self._pending[slot] = True
         elif g.world > 1 and g.equal:
             self._work[slot] = g.dist.all_gather_into_tensor(g.out, local.contiguous(), group=g.group, async_op=True)
@@ -114,8 +115,12 @@ class PipelinedObsGather:
     def before_reuse(self, slot: int):
         """order the producer (current stream / host) after the gather that last read `local[slot]`"""
         if self.is_cuda:
-            if self._pending[slot]:
+            # a gather that the host can already see finished needs no stream-side wait (each cross-stream
+            # wait costs the producer's stream a few microseconds): with a few slots in flight that is
+            # the normal case
+            if self._pending[slot] and not self._done[slot].query():
                 self.torch.cuda.current_stream().wait_event(self._done[slot])
+            self._pending[slot] = False
         elif self._work[slot] is not None:
             self._work[slot].wait()
             self._work[slot] = None
