@@ -605,6 +605,12 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   const bool lds_children = (cflags & 4) != 0;     // I have children that are not lane + 1
   const int my_slot = isl ? mdl->lc_slot[lsafe] : -1;                        // my (v, a0) side record
   const int par_slot = (isl && parent >= 0) ? mdl->lc_slot[parent] : -1;     // my parent's
+  // PD / joint constants of the link (fetched here with the other lane constants: the PD block right
+  // after the x record arrives must not start with a round trip to L2)
+  const int act_i = isl ? mdl->act_index[lsafe] : -1;
+  const T init_pose_l = mdl->init_pose[lsafe], stiff_l = mdl->stiffness[lsafe], damp_l = mdl->damping[lsafe];
+  const T act_lim = mdl->action_limit;
+  const int step_mode = mdl->step_mode;
   // per-link model constants (joint axis, X_T, rigid inertia).  The straight-line build fetches
   // them HERE, ahead of the x record, so that their L2 latency overlaps the HBM latency of x; the
   // step-loop build re-fetches them per iteration (keeping ~60 VGPRs live across the loop costs more).
@@ -760,16 +766,16 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   // ---- PD controller (locomotion_contact_simulation.h:168-258) or direct torque -------------
   T tau = T(0);
-  if (mdl->step_mode == TDS_STEP_LOCOMOTION) {
-    const int ai = isl ? mdl->act_index[lsafe] : -1;
+  if (step_mode == TDS_STEP_LOCOMOTION) {
+    const int ai = act_i;
     if (ai >= 0) {
       const int var = nq + nd + adim;
       const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
       T a = settling ? T(0) : xr[nq + nd + ai];  // reset settles with zero action
-      const T lim = mdl->action_limit;
+      const T lim = act_lim;
       a = a < lim ? a : lim;       // Algebra::min(clamped_action, ACTION_LIMIT)
       a = a > -lim ? a : -lim;     // Algebra::max(clamped_action, -ACTION_LIMIT)
-      const T q_des = mdl->init_pose[lsafe] + a;
+      const T q_des = init_pose_l + a;
       T f = kp * (q_des - q) + kd * (T(0) - qd);
       f = f > -max_force ? f : -max_force;
       f = f < max_force ? f : max_force;
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     tau = settling ? T(0) : xr[nq + nd + di];
   }
   // joint stiffness / damping (forward_dynamics.hpp:122-123)
-  if (isl) tau -= mdl->stiffness[lsafe] * q + mdl->damping[lsafe] * qd;
+  if (isl) tau -= stiff_l * q + damp_l * qd;
 
   TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
