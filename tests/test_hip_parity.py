@@ -546,3 +546,40 @@ def test_short_root_chains(massless, built):
     err = rel_err(y, y_ref)
     print(f"{massless} massless root links: max rel err {err:.2e}")
     assert err < TOL
+
+
+def test_error_paths_and_edge_sizes(built):
+    """status codes instead of crashes: empty / oversized batches, NULL arguments, unsupported models;
+    and the smallest / a ragged / the largest supported batch shapes"""
+    import ctypes as C
+    torch = _torch()
+    L = hip_backend.lib()
+    m = tds_amd.load_model("ant")
+    h = C.c_void_p()
+    assert L.tds_hip_create(C.byref(m), 0, 0, 0, C.byref(h)) != 0 and not h.value          # empty batch
+    assert L.tds_hip_create(C.byref(m), 8, 99, 0, C.byref(h)) != 0 and not h.value         # no such device
+    assert L.tds_hip_create(C.byref(m), 8, 0, 7, C.byref(h)) != 0 and not h.value          # unknown dtype
+    bad = m.copy()
+    bad.is_floating = 1
+    assert L.tds_hip_create(C.byref(bad), 8, 0, 0, C.byref(h)) != 0 and not h.value        # floating base: N4
+    assert b"floating" in L.tds_hip_last_error()
+    g = np.load(os.path.join(GOLDEN, "ant.npz"))
+    sim = hip_backend.HipSim(m, 5)
+    x = np.ascontiguousarray(g["x"][:7])
+    y = np.zeros((7, m.output_dim))
+    assert L.tds_hip_forward_zero_host(sim.h, 7, x.ctypes.data, y.ctypes.data) != 0        # n > num_envs
+    assert L.tds_hip_forward_zero_host(sim.h, 0, x.ctypes.data, y.ctypes.data) != 0        # n < 1
+    assert L.tds_hip_forward_zero_host(sim.h, 5, None, y.ctypes.data) != 0                 # NULL
+    assert L.tds_hip_step(None, None, 1) != 0
+    assert L.tds_hip_rollout(sim.h, None, 10, C.c_double(0.0), 0, None, None, None) != 0
+    # 1 environment (a single lane group of a single wavefront) and 5 (ragged: 3 idle groups in wave 2)
+    for n in (1, 5):
+        s = hip_backend.HipSim(m, n)
+        yy = s.forward_zero(torch.from_numpy(g["x"][:n]).cuda()).cpu().numpy()
+        assert rel_err(yy, g["y"][:n]) < TOL
+    # a large batch: every environment equal to its golden twin
+    n = 65536 + 3
+    idx = np.arange(n) % g["x"].shape[0]
+    s = hip_backend.HipSim(m, n)
+    yy = s.forward_zero(torch.from_numpy(g["x"][idx]).cuda()).cpu().numpy()
+    assert rel_err(yy, g["y"][idx]) < TOL
