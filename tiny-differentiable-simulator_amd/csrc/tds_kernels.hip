@@ -1152,13 +1152,13 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         mat3_mulv(Rl, pv, po);
         matrix_to_quat(Ro, qo);
         T *o = yo + vbase + 7 * k;
-        o[0] = pl[0] + po[0];
-        o[1] = pl[1] + po[1];
-        o[2] = pl[2] + po[2];
-        o[3] = qo[0];
-        o[4] = qo[1];
-        o[5] = qo[2];
-        o[6] = qo[3];
+        __builtin_nontemporal_store(pl[0] + po[0], &o[0]);
+        __builtin_nontemporal_store(pl[1] + po[1], &o[1]);
+        __builtin_nontemporal_store(pl[2] + po[2], &o[2]);
+        __builtin_nontemporal_store(qo[0], &o[3]);
+        __builtin_nontemporal_store(qo[1], &o[4]);
+        __builtin_nontemporal_store(qo[2], &o[5]);
+        __builtin_nontemporal_store(qo[3], &o[6]);
       }
     }
   }
@@ -1555,17 +1555,17 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   if (last_run) {
     T *const yo = y_out + (size_t)env * out_dim;
     if (di >= 0) {
-      yo[di] = q_new;
-      yo[nq + di] = qd_new;
+      __builtin_nontemporal_store((T)(q_new), &yo[di]);
+      __builtin_nontemporal_store((T)(qd_new), &yo[nq + di]);
     }
     const int nv = mdl->num_visuals;
     int tail = nq + nd;
     if (mdl->pack_visuals) {
       tail += 7 * nv;
-      if (lane == 0) yo[tail] = mdl->base_R[8];  // up_dot_world_z
+      if (lane == 0) __builtin_nontemporal_store((T)(mdl->base_R[8]), &yo[tail]);  // up_dot_world_z
       tail += 1;
     }
-    for (int i = tail + lane; i < out_dim; i += G) yo[i] = T(0);
+    for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((T)(T(0)), &yo[i]);
   }
 
   // ---- N. reward / done of the last normal step
