@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TDS_HIP_ABI_VERSION 1
+#define TDS_HIP_ABI_VERSION 2
 
 #define TDS_MAX_LINKS 32
 #define TDS_MAX_GEOMS 32
@@ -144,7 +144,8 @@ typedef struct tds_model {
   int32_t num_links;
   int32_t dof_q;       /* mb.dof()    */
   int32_t dof_qd;      /* mb.dof_qd() */
-  int32_t is_floating; /* must be 0: floating base is SURVEY §8(f) N4 */
+  int32_t is_floating; /* 1: floating base — q = [quat xyzw | pos | joints] (dof_q = 7 + n), qd = [omega | v | joints]
+                          (multi_body.hpp:324-349, kinematics.hpp:35-62) */
   int32_t num_geoms;
   int32_t num_visuals;
   int32_t action_dim;    /* LOCOMOTION: #PD targets; TAU: dof_qd */
@@ -175,6 +176,10 @@ typedef struct tds_model {
   double reset_noise[TDS_MAX_DOF];
   int32_t settle_steps;
   int32_t pad2_;
+  /* rigid-body inertia of the base link, mb.base_rbi() (multi_body.hpp:78); used only when is_floating */
+  double base_mass;
+  double base_com[3];
+  double base_inertia[9];
   tds_link_t links[TDS_MAX_LINKS];
   tds_geom_t geoms[TDS_MAX_GEOMS];
   tds_visual_t visuals[TDS_MAX_VISUALS];

@@ -74,6 +74,9 @@ int flatten_multibody(const tds::MultiBody<Algebra> &mb, tds_model_t *out) {
   out->is_floating = mb.is_floating() ? 1 : 0;
   copy_mat3<Algebra>(mb.base_X_world().rotation, out->base_X_world_rot);
   copy_vec3<Algebra>(mb.base_X_world().translation, out->base_X_world_trans);
+  out->base_mass = Algebra::to_double(mb.base_rbi().mass);
+  copy_vec3<Algebra>(mb.base_rbi().com, out->base_com);
+  copy_mat3<Algebra>(mb.base_rbi().inertia, out->base_inertia);
   int ng = 0, nv = 0;
   for (size_t g = 0; g < mb.collision_geometries(-1).size(); ++g) {
     if (ng >= TDS_MAX_GEOMS) return -3;

@@ -35,6 +35,10 @@ MODELS = {
     "laikago_soft": dict(ref="laikago", soft=(1e4, 1e2)),           # config 4: cfm/erp from k, d
     "pendulum5_plane": dict(ref="pendulum5.urdf+plane", dt=1e-3),   # sphere contacts on a chain
     "cartpole_plane": dict(ref="cartpole.urdf+plane", dt=1e-3),     # plane-box (8 corner spheres)
+    # floating base: q = [quat | pos | joints], qd = [omega | v | joints]
+    "ant_floating": dict(ref="gym/ant_org.urdf+plane+floating", dt=5e-3),                   # 4 legs on the base
+    "laikago_floating": dict(ref="laikago/laikago_toes_zup.urdf+plane+floating", dt=1e-3),  # 16 links, 18 dof
+    "cube_floating": dict(ref="sphere8cube.urdf+plane+floating", dt=2e-3),                  # a single free body
 }
 
 
@@ -66,6 +70,14 @@ def random_inputs(name, m, n, rng):
         x[:, nq:nq + nd] = rng.uniform(-2, 2, (n, nd))
         x[:, nq + nd:nq + nd + m.action_dim] = rng.uniform(-0.6, 0.6, (n, m.action_dim))
         x[:, -3:] = [15, 0.3, 3] if name.startswith("ant") else [100, 2, 50]
+    elif m.is_floating:
+        quat = rng.normal(size=(n, 4)) * [0.35, 0.35, 0.35, 0.0] + [0, 0, 0, 1.0]
+        x[:, 0:4] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+        x[:, 4:6] = rng.uniform(-1, 1, (n, 2))
+        x[:, 6] = rng.uniform(0.05, 0.7, n)
+        x[:, 7:nq] = rng.uniform(-0.6, 0.6, (n, nq - 7))
+        x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+        x[:, nq + nd:] = rng.uniform(-1, 1, (n, m.action_dim))
     else:
         x[:, :nq] = rng.uniform(-1, 1, (n, nq))
         x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
@@ -84,6 +96,12 @@ def rollout_start(name, m, rng):
         x[2] = 0.48
         x[6:nq] = ip + 0.05 * rng.uniform(-1, 1, nq - 6)
         x[-3:] = [15, 0.3, 3] if name.startswith("ant") else [100, 2, 50]
+    elif m.is_floating:
+        quat = np.array([0.08, -0.05, 0.02, 1.0])
+        x[0:4] = quat / np.linalg.norm(quat)
+        x[6] = 0.55
+        x[7:nq] = rng.uniform(-0.3, 0.3, nq - 7)
+        x[nq:nq + 3] = rng.uniform(-0.5, 0.5, 3)
     else:
         x[:nq] = rng.uniform(-1, 1, nq)
         if name == "pendulum5_plane":
@@ -115,13 +133,17 @@ def rollout_fixture(name, n=24, steps=25, shift=0.5, seed=77):
                 vec_steps=cnt, final_obs=fin)
 
 
-def main():
+def main(only=None):
+    """only: names whose .npz fixture is (re)generated — default all; the model JSONs are always rewritten."""
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     mdir = os.path.join(ROOT, "tiny-differentiable-simulator_amd", "models")
     os.makedirs(mdir, exist_ok=True)
     for idx, name in enumerate(MODELS):
         r, m = make_ref(name)
         tds_amd.save_model(m, os.path.join(mdir, name + ".json"))
+        if only is not None and name not in only:
+            r.close()
+            continue
         rng = np.random.default_rng(1000 + idx)
         n = 48
         x = random_inputs(name, m, n, rng)
@@ -140,7 +162,7 @@ def main():
         traj = np.zeros((T, m.output_dim))
         acts = rng.uniform(-0.4, 0.4, (T, m.action_dim))
         if m.step_mode != tds_amd.TDS_STEP_LOCOMOTION:
-            acts *= 0.0 if name.startswith("pendulum5") else 25.0
+            acts *= 0.0 if name.startswith("pendulum5") else (2.0 if m.is_floating else 25.0)
         for t in range(T):
             xt[nq + nd:nq + nd + m.action_dim] = acts[t]
             traj[t] = r.step(xt)[0]
@@ -152,7 +174,7 @@ def main():
               f"out={m.output_dim} active contacts/state: min {ncs.min()} max {ncs.max()} "
               f"mean {ncs.mean():.1f}")
         r.close()
-    for name in ("ant", "laikago"):
+    for name in ("ant", "laikago") if only is None else ():
         f = rollout_fixture(name)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_rollout.npz"), **f)
         print(f"{name}_rollout: steps taken {f['vec_steps'].min()}..{f['vec_steps'].max()} of {int(f['steps'])}, "
@@ -160,4 +182,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1].split(",") if len(sys.argv) > 1 else None)

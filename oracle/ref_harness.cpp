@@ -77,7 +77,7 @@ struct RefSim {
 
   int input_dim() {
     if (loco()) return loco()->input_dim_with_action_and_variables();
-    return gmb->dof() + gmb->dof_qd() + gmb->dof_qd();
+    return gmb->dof() + gmb->dof_qd() + gmb->dof_actuated();  // == dof_qd for a fixed base, dof_qd - 6 floating
   }
   int num_visuals() {
     int n = 0;
@@ -132,7 +132,7 @@ struct RefSim {
 
 extern "C" {
 
-// name: "ant" | "laikago" | "<file>.urdf" | "<file>.urdf+plane"   (file relative to <ref>/data)
+// name: "ant" | "laikago" | "<file>.urdf" | "<file>.urdf+plane" | "<file>.urdf[+plane]+floating"   (file relative to <ref>/data)
 void *tdsref_create(const char *name_c, const char *reference_root) {
   std::string name(name_c);
   RefSim *s = new RefSim;
@@ -143,7 +143,13 @@ void *tdsref_create(const char *name_c, const char *reference_root) {
     s->laikago = new LaikagoEnv<Alg>(false);
   } else {
     std::string file = name;
-    size_t p = file.find("+plane");
+    bool floating = false;
+    size_t p = file.find("+floating");  // "<file>.urdf[+plane]+floating": MultiBody with a floating base
+    if (p != std::string::npos) {
+      floating = true;
+      file = file.substr(0, p);
+    }
+    p = file.find("+plane");
     if (p != std::string::npos) {
       s->g_plane = true;
       file = file.substr(0, p);
@@ -154,7 +160,7 @@ void *tdsref_create(const char *name_c, const char *reference_root) {
       // plane FIRST, so it is multi_bodies_[0] == mb_a (locomotion_contact_simulation.h:100-123)
       s->cache.construct(root + "/data/plane_implicit.urdf", *s->gworld, false, false);
     }
-    s->gmb = s->cache.construct(root + "/data/" + file, *s->gworld, false, false);
+    s->gmb = s->cache.construct(root + "/data/" + file, *s->gworld, false, floating);
     s->gmb->base_X_world().set_identity();
     s->gworld->default_friction = 1;
     s->gworld->get_mb_constraint_solver()->keep_all_points_ = true;
@@ -211,7 +217,7 @@ int tdsref_flatten(void *h, tds_model_t *out) {
     if (rc) return rc;
     tds_hip::flatten_world<Alg>(*s->gworld, out);
     out->dt = s->g_dt;
-    out->action_dim = s->gmb->dof_qd();
+    out->action_dim = s->gmb->dof_actuated();
     out->input_dim = s->input_dim();
     out->output_dim = s->output_dim();
     out->pack_visuals = 1;

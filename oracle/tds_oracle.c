@@ -274,6 +274,38 @@ static void abi_congruence(const xf_t *X, const abi_t *Ia, abi_t *out) {
 }
 
 /* ---------------------------------------------------------------- per-env scratch */
+/* ref: tiny_matrix3x3.h:539-559 (cofactor inverse) */
+static void m3_inverse(const double *m, double *o) {
+  double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
+  double s = 1.0 / (m[0] * c0 + m[1] * c1 + m[2] * c2);
+  o[0] = c0 * s; o[1] = (m[2] * m[7] - m[1] * m[8]) * s; o[2] = (m[1] * m[5] - m[2] * m[4]) * s;
+  o[3] = c1 * s; o[4] = (m[0] * m[8] - m[2] * m[6]) * s; o[5] = (m[2] * m[3] - m[0] * m[5]) * s;
+  o[6] = c2 * s; o[7] = (m[1] * m[6] - m[0] * m[7]) * s; o[8] = (m[0] * m[4] - m[1] * m[3]) * s;
+}
+
+/* ref: src/math/inertia.hpp:302-329  ArticulatedBodyInertia::inverse() / inv_mul().  NOTE the reference takes
+   C = -H for the lower-left block (exact only while H is skew, i.e. for a single rigid body); restated as is. */
+static void abi_inv_mul(const abi_t *A, const sv_t *f, sv_t *o) {
+  double Ainv[9], C[9], t1[9], t2[9], S[9], D[9], ABD[9], I2[9], H2[9], Ht[9];
+  m3_inverse(A->I, Ainv);
+  for (int k = 0; k < 9; ++k) C[k] = -A->H[k];
+  m3_mul(C, Ainv, t1);
+  m3_mul(t1, A->H, t2);
+  for (int k = 0; k < 9; ++k) S[k] = A->M[k] - t2[k]; /* MCAinvB */
+  m3_inverse(S, D);                                     /* DCAB */
+  m3_mul(Ainv, A->H, t1);
+  m3_mul(t1, D, ABD);                                   /* AinvBDCAB */
+  m3_mul(ABD, C, t1);
+  m3_mul(t1, Ainv, t2);
+  for (int k = 0; k < 9; ++k) { I2[k] = Ainv[k] + t2[k]; H2[k] = -ABD[k]; }
+  m3_transpose(H2, Ht);
+  double a[3], b[3];
+  m3_mulv(I2, f->a, a); m3_mulv(H2, f->l, b);
+  for (int k = 0; k < 3; ++k) o->a[k] = a[k] + b[k];
+  m3_mulv(D, f->l, a); m3_mulv(Ht, f->a, b);
+  for (int k = 0; k < 3; ++k) o->l[k] = a[k] + b[k];
+}
+
 typedef struct {
   xf_t X_J, X_parent, X_world;
   sv_t S, vJ, v, c, a, pA, U;
@@ -289,7 +321,10 @@ typedef struct {
 typedef struct {
   lstate_t L[NL];
   xf_t base_X_world;
-  double q[ND], qd[ND], qdd[ND], tau[ND];
+  /* floating base (multi_body.hpp:66-78): spatial velocity / acceleration, articulated inertia, bias force */
+  sv_t base_v, base_a, base_bias;
+  abi_t base_abi;
+  double q[ND + 1], qd[ND], qdd[ND], tau[ND];
   contact_t cps[NCMAX];
   int n_c;
   double M[ND * ND], Minv[ND * ND];
@@ -350,8 +385,26 @@ static void jcalc(const tds_link_t *l, double q, double qd, int have_qd, lstate_
   }
 }
 
-/* ref: src/dynamics/kinematics.hpp:18-148 (fixed base) */
+/* ref: src/dynamics/kinematics.hpp:18-148 (fixed and floating base) */
 static void forward_kinematics(const tds_model_t *m, scratch_t *s, int have_qd) {
+  if (m->is_floating) { /* :35-62 */
+    quat_to_matrix(s->q, s->base_X_world.r);
+    for (int k = 0; k < 3; ++k) s->base_X_world.t[k] = s->q[4 + k];
+    for (int k = 0; k < 3; ++k) {
+      s->base_v.a[k] = have_qd ? s->qd[k] : 0.0;
+      s->base_v.l[k] = have_qd ? s->qd[3 + k] : 0.0;
+    }
+    abi_from_rbi(m->base_mass, m->base_com, m->base_inertia, &s->base_abi); /* :50 */
+    /* :52-59 gyroscopic force from the "world" inertia tensor R I R^T and the base angular velocity, stored
+       as the top of the base-frame bias force (frames mixed exactly as the reference does) */
+    double Rt[9], RI[9], Iw[9], Iwv[3];
+    m3_transpose(s->base_X_world.r, Rt);
+    m3_mul(s->base_X_world.r, m->base_inertia, RI);
+    m3_mul(RI, Rt, Iw);
+    m3_mulv(Iw, s->base_v.a, Iwv);
+    v3_cross(s->base_v.a, Iwv, s->base_bias.a);
+    s->base_bias.l[0] = s->base_bias.l[1] = s->base_bias.l[2] = 0.0; /* base_applied_force == 0 */
+  }
   for (int i = 0; i < m->num_links; ++i) {
     const tds_link_t *l = &m->links[i];
     lstate_t *L = &s->L[i];
@@ -362,6 +415,11 @@ static void forward_kinematics(const tds_model_t *m, scratch_t *s, int have_qd) 
       xf_mul(&s->L[l->parent].X_world, &L->X_parent, &L->X_world); /* :82 */
       sv_t xv;
       xf_apply_motion(&L->X_parent, &s->L[l->parent].v, &xv); /* :86 */
+      for (int k = 0; k < 3; ++k) { L->v.a[k] = xv.a[k] + L->vJ.a[k]; L->v.l[k] = xv.l[k] + L->vJ.l[k]; }
+    } else if (m->is_floating) {
+      xf_mul(&s->base_X_world, &L->X_parent, &L->X_world); /* :82 with parent_X_world = base_X_world */
+      sv_t xv;
+      xf_apply_motion(&L->X_parent, &s->base_v, &xv); /* :84-87 */
       for (int k = 0; k < 3; ++k) { L->v.a[k] = xv.a[k] + L->vJ.a[k]; L->v.l[k] = xv.l[k] + L->vJ.l[k]; }
     } else {
       xf_mul(&s->base_X_world, &L->X_parent, &L->X_world); /* :92 */
@@ -409,18 +467,25 @@ static void forward_dynamics(const tds_model_t *m, scratch_t *s) {
       pa.a[k] = L->pA.a[k] + Ia_c.a[k] + UuD.a[k];
       pa.l[k] = L->pA.l[k] + Ia_c.l[k] + UuD.l[k];
     }                                           /* :173 */
-    if (l->parent >= 0) {
+    if (l->parent >= 0 || m->is_floating) {
       sv_t dpA;
       abi_t dI;
       xf_apply_force(&L->X_parent, &pa, &dpA); /* :181 */
       abi_congruence(&L->X_parent, &Ia, &dI);  /* :187-189 */
-      lstate_t *P = &s->L[l->parent];
-      for (int k = 0; k < 3; ++k) { P->pA.a[k] += dpA.a[k]; P->pA.l[k] += dpA.l[k]; }
-      for (int k = 0; k < 9; ++k) { P->abi.I[k] += dI.I[k]; P->abi.H[k] += dI.H[k]; P->abi.M[k] += dI.M[k]; }
+      sv_t *PpA = l->parent >= 0 ? &s->L[l->parent].pA : &s->base_bias;   /* :201 / :206 */
+      abi_t *Pabi = l->parent >= 0 ? &s->L[l->parent].abi : &s->base_abi; /* :202 / :207 */
+      for (int k = 0; k < 3; ++k) { PpA->a[k] += dpA.a[k]; PpA->l[k] += dpA.l[k]; }
+      for (int k = 0; k < 9; ++k) { Pabi->I[k] += dI.I[k]; Pabi->H[k] += dI.H[k]; Pabi->M[k] += dI.M[k]; }
     }
   }
-  sv_t a_base; /* :242  base_acceleration = -spatial_gravity (not rotated: rbdl_convention=false) */
-  for (int k = 0; k < 3; ++k) { a_base.a[k] = 0.0; a_base.l[k] = -m->gravity[k]; }
+  sv_t a_base;
+  if (m->is_floating) { /* :232  base_acceleration = -base_abi.inv_mul(base_bias_force) */
+    sv_t r;
+    abi_inv_mul(&s->base_abi, &s->base_bias, &r);
+    for (int k = 0; k < 3; ++k) { a_base.a[k] = -r.a[k]; a_base.l[k] = -r.l[k]; }
+  } else { /* :242  base_acceleration = -spatial_gravity (not rotated: rbdl_convention=false) */
+    for (int k = 0; k < 3; ++k) { a_base.a[k] = 0.0; a_base.l[k] = -m->gravity[k]; }
+  }
   for (int i = 0; i < m->num_links; ++i) { /* :245-302 */
     const tds_link_t *l = &m->links[i];
     lstate_t *L = &s->L[i];
@@ -436,6 +501,12 @@ static void forward_dynamics(const tds_model_t *m, scratch_t *s) {
       for (int k = 0; k < 3; ++k) { L->a.a[k] += L->S.a[k] * qdd; L->a.l[k] += L->S.l[k] * qdd; }
     }
   }
+  if (m->is_floating) { /* :315-319  gravity (WORLD components) is added to the base-frame acceleration */
+    for (int k = 0; k < 3; ++k) {
+      s->qdd[k] = a_base.a[k];
+      s->qdd[3 + k] = a_base.l[k] + m->gravity[k];
+    }
+  }
 }
 
 /* ref: src/dynamics/mass_matrix.hpp:13-127 (fixed base, 1-DoF + fixed joints) */
@@ -446,11 +517,11 @@ static void mass_matrix(const tds_model_t *m, scratch_t *s) {
   for (int i = n - 1; i >= 0; --i) {
     const tds_link_t *l = &m->links[i];
     lstate_t *L = &s->L[i];
-    if (l->parent >= 0) {
+    if (l->parent >= 0 || m->is_floating) {
       abi_t dI;
       abi_congruence(&L->X_parent, &L->abi, &dI); /* :45-46 */
-      lstate_t *P = &s->L[l->parent];
-      for (int k = 0; k < 9; ++k) { P->abi.I[k] += dI.I[k]; P->abi.H[k] += dI.H[k]; P->abi.M[k] += dI.M[k]; }
+      abi_t *P = l->parent >= 0 ? &s->L[l->parent].abi : &s->base_abi; /* :49-53 */
+      for (int k = 0; k < 9; ++k) { P->I[k] += dI.I[k]; P->H[k] += dI.H[k]; P->M[k] += dI.M[k]; }
     }
     if (l->joint_type == TDS_JOINT_FIXED) continue; /* :56 */
     int qd_i = l->qd_index;
@@ -467,6 +538,22 @@ static void mass_matrix(const tds_model_t *m, scratch_t *s) {
       s->M[qd_i * nd + qd_j] = h;
       s->M[qd_j * nd + qd_i] = h;
     }
+    if (m->is_floating) { /* :111-115  force carried into the base frame -> column / row of the base block */
+      xf_apply_force(&s->L[j].X_parent, &Fi, &Fi);
+      for (int k = 0; k < 3; ++k) {
+        s->M[k * nd + qd_i] = s->M[qd_i * nd + k] = Fi.a[k];
+        s->M[(3 + k) * nd + qd_i] = s->M[qd_i * nd + 3 + k] = Fi.l[k];
+      }
+    }
+  }
+  if (m->is_floating) { /* :118-125  composite inertia of the base: [I H; H^T M] */
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        s->M[r * nd + c] = s->base_abi.I[3 * r + c];
+        s->M[r * nd + 3 + c] = s->base_abi.H[3 * r + c];
+        s->M[(3 + r) * nd + c] = s->base_abi.H[3 * c + r];
+        s->M[(3 + r) * nd + 3 + c] = s->base_abi.M[3 * r + c];
+      }
   }
 }
 
@@ -515,6 +602,14 @@ static void point_jacobian(const tds_model_t *m, const scratch_t *s, int link_in
                            const double *point, double *jac /* 3 x nd */) {
   const int nd = m->dof_qd;
   memset(jac, 0, sizeof(double) * 3 * nd);
+  if (m->is_floating) { /* :39-56  base block [ -[r]x | 1 ] with r = point - base position (WORLD axes) */
+    double r[3] = {point[0] - s->base_X_world.t[0], point[1] - s->base_X_world.t[1], point[2] - s->base_X_world.t[2]};
+    double cr[9];
+    m3_cross_matrix(r, cr);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) jac[a * nd + b] = cr[3 * b + a]; /* transpose(cross_matrix(r)) */
+    jac[0 * nd + 3] = jac[1 * nd + 4] = jac[2 * nd + 5] = 1.0;
+  }
   int i = link_index;
   while (i >= 0) {
     const tds_link_t *l = &m->links[i];
@@ -699,7 +794,7 @@ static int resolve_collision(const tds_model_t *m, scratch_t *s, tds_oracle_debu
 static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t *s,
                     tds_oracle_debug_t *dbg) {
   const int nq = m->dof_q, nd = m->dof_qd;
-  if (m->is_floating || m->num_links > NL || nd > ND) return -2;
+  if (m->num_links > NL || nd > ND || nq > ND + 1 || nq != nd + (m->is_floating ? 1 : 0)) return -2;
   if (m->has_plane) {
     int nc = 0;
     for (int g = 0; g < m->num_geoms; ++g)
@@ -733,7 +828,10 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
       s->tau[l->qd_index] = f;
     }
   } else {
-    for (int i = 0; i < nd; ++i) s->tau[i] = x[nq + nd + i];
+    /* tau has dof_actuated entries; get_tau_for_link reads tau[qd_index - 6] on a floating base
+       (multi_body.hpp:557-570): keep it indexed by qd_index here */
+    const int off = m->is_floating ? 6 : 0;
+    for (int i = 0; i < nd - off; ++i) s->tau[off + i] = x[nq + nd + i];
   }
   forward_dynamics(m, s);                                  /* :261 */
   if (dbg && dbg->qdd) memcpy(dbg->qdd, s->qdd, sizeof(double) * nd);
@@ -743,6 +841,8 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
       memcpy(dbg->X_world + 12 * i + 9, s->L[i].X_world.t, 3 * sizeof(double));
     }
   /* integrate_euler_qdd: qd += qdd*dt (integrator.hpp:141-182); qdd = 0 (:194) */
+  if (m->is_floating) /* :152-166 */
+    for (int k = 0; k < 6; ++k) s->qd[k] += s->qdd[k] * m->dt;
   for (int i = 0; i < m->num_links; ++i) {
     const tds_link_t *l = &m->links[i];
     if (l->joint_type != TDS_JOINT_FIXED) s->qd[l->qd_index] += s->qdd[l->qd_index] * m->dt;
@@ -762,6 +862,18 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
     if (rc) return rc;
   }
   /* integrate_euler with qdd == 0: q += qd*dt (integrator.hpp:126-131) */
+  if (m->is_floating) { /* :23-89: quaternion += quat_velocity(q, omega, dt) (tiny_algebra.hpp:604-614), normalise */
+    const double *w = s->qd, h = 0.5 * m->dt;
+    double *b = s->q;
+    double ww = (-b[0] * w[0] - b[1] * w[1] - b[2] * w[2]) * h;
+    double xx = (b[3] * w[0] + b[2] * w[1] - b[1] * w[2]) * h;
+    double yy = (b[3] * w[1] + b[0] * w[2] - b[2] * w[0]) * h;
+    double zz = (b[3] * w[2] + b[1] * w[0] - b[0] * w[1]) * h;
+    b[0] += xx; b[1] += yy; b[2] += zz; b[3] += ww;
+    quat_normalize(b);
+    quat_to_matrix(b, s->base_X_world.r); /* :83 (the translation of base_X_world is NOT refreshed) */
+    for (int k = 0; k < 3; ++k) b[4 + k] += s->qd[3 + k] * m->dt;
+  }
   for (int i = 0; i < m->num_links; ++i) {
     const tds_link_t *l = &m->links[i];
     if (l->joint_type != TDS_JOINT_FIXED) s->q[l->q_index] += s->qd[l->qd_index] * m->dt;

@@ -21,7 +21,7 @@ def lanes_options(m):
     """lane-group widths the library instantiates for this model (G >= links, G >= padded dof;
     G = 64 only for <= 16 dof)"""
     ndp = 8 if m.dof_qd <= 8 else 16 if m.dof_qd <= 16 else 24 if m.dof_qd <= 24 else 32
-    need = max(m.num_links, ndp)
+    need = max(m.num_links + (6 if m.is_floating else 0), ndp)  # (floating base: six pseudo links)
     return [g for g in (16, 32, 64) if g >= need and (g < 64 or ndp <= 16)]
 
 
@@ -65,7 +65,7 @@ def test_golden_rollout_per_step(name, built):
     assert err < TOL
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago_soft", "pendulum5_plane"])
+@pytest.mark.parametrize("name", ["ant", "laikago_soft", "pendulum5_plane", "ant_floating", "laikago_floating"])
 def test_closed_loop_matches_oracle(name, built):
     """device-resident closed loop (tds_hip_step) vs the oracle stepping on the host."""
     torch = _torch()

@@ -192,7 +192,8 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   s->device = device;
   s->dtype = dtype;
   s->elem = dtype == TDS_DTYPE_F64 ? 8 : 4;
-  s->lanes = default_lanes_per_env(model->num_links, model->dof_qd);
+  // (a floating base takes six more lanes: its pseudo links, tds_device_model.h)
+  s->lanes = default_lanes_per_env(model->num_links + (model->is_floating ? 6 : 0), model->dof_qd);
   char why[128];
   size_t msize;
   const void *hsrc;

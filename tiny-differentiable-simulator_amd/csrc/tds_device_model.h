@@ -28,6 +28,12 @@ struct DevModel {
   int num_cp, num_visuals, action_dim, input_dim, output_dim;
   int step_mode, has_plane, pgs_iterations, pack_visuals;
   int num_pairs, reward_mode, settle_steps;
+  // floating base (multi_body.hpp:66-78, kinematics.hpp:35-62): links 0..5 of THIS table are six pseudo links
+  // (3 angular + 3 linear base dofs, the base body's inertia on link 5) in front of the model's own links;
+  // the dofs are numbered joints first (0..nj-1), base last (nj..nj+5), so that the right-looking LDL^T
+  // reaches the base block as the Schur complement of the joints (= the articulated inertia of the base).
+  // The q / qd RECORD keeps the reference's order: q = [quat xyzw | pos | joints], qd = [omega | v | joints].
+  int is_floating, nj;  // nj = number of joint dofs (= dof_qd when the base is fixed)
   T dt, cfm, erp_over_dt, friction, restitution, action_limit;
   T grav[3];       // base acceleration = -grav (forward_dynamics.hpp:242), world frame
   T base_R[9], base_t[3];
@@ -80,9 +86,9 @@ static inline void tds_plane_space(const double *n, double *p, double *q) {
   q[2] = gt ? n[0] * p[1] : a * k;
 }
 
-// Returns TDS_OK or an error code; `why` (>= 128 bytes) receives the reason.
+// `fl`: m is the EXPANDED form of a floating-base model (tds_expand_floating below).
 template <typename T>
-static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) {
+static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *why, const bool fl) {
   memset(d, 0, sizeof(*d));
   why[0] = 0;
 #define TDS_FAIL(code, msg)          \
@@ -93,9 +99,12 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
   } while (0)
   if (m->abi_version != TDS_HIP_ABI_VERSION) TDS_FAIL(TDS_ERR_INVALID_ARG, "model abi_version mismatch");
   if (m->num_links < 1 || m->num_links > TDS_NL) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_links out of range");
-  if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd)
+  if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd + (fl ? 1 : 0) || m->dof_q > TDS_ND)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "dof out of range or dof_q != dof_qd (spherical joints unsupported)");
-  if (m->is_floating) TDS_FAIL(TDS_ERR_UNSUPPORTED, "floating base is not implemented (SURVEY 8f N4)");
+  if (fl && m->reward_mode != TDS_REWARD_NONE)
+    TDS_FAIL(TDS_ERR_UNSUPPORTED, "the Ant / Laikago reward rules read a fixed-base state record");
+  d->is_floating = fl ? 1 : 0;
+  d->nj = fl ? m->dof_qd - 6 : m->dof_qd;
   if (m->num_geoms < 0 || m->num_geoms > TDS_MAX_GEOMS) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_geoms out of range");
   if (m->num_visuals < 0 || m->num_visuals > TDS_NV) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_visuals out of range");
   if (m->step_mode != TDS_STEP_LOCOMOTION && m->step_mode != TDS_STEP_TAU)
@@ -123,8 +132,8 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
   if (m->input_dim < need_in) TDS_FAIL(TDS_ERR_INVALID_ARG, "input_dim too small for [q|qd|action|vars]");
   const int need_out = nq + nd + (m->pack_visuals ? 7 * m->num_visuals + 1 : 0);
   if (m->output_dim < need_out) TDS_FAIL(TDS_ERR_INVALID_ARG, "output_dim too small for [q|qd|visuals|up]");
-  if (m->step_mode == TDS_STEP_TAU && m->action_dim != nd)
-    TDS_FAIL(TDS_ERR_INVALID_ARG, "TAU mode needs action_dim == dof_qd");
+  if (m->step_mode == TDS_STEP_TAU && m->action_dim != d->nj)
+    TDS_FAIL(TDS_ERR_INVALID_ARG, "TAU mode needs action_dim == number of joint dofs (dof_actuated)");
   d->dt = (T)m->dt;
   d->cfm = (T)m->cfm;
   d->erp_over_dt = (T)(m->erp / m->dt);
@@ -136,7 +145,9 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
   for (int r = 0; r < 3; ++r) {
     double g = 0;
     for (int c = 0; c < 3; ++c) g += m->base_X_world_rot[3 * r + c] * m->gravity[c];
-    d->grav[r] = (T)g;
+    // floating base: the WORLD components of gravity are added to the base acceleration as they are
+    // (forward_dynamics.hpp:315-319)
+    d->grav[r] = (T)(fl ? m->gravity[r] : g);
   }
   for (int k = 0; k < 9; ++k) d->base_R[k] = (T)m->base_X_world_rot[k];
   for (int k = 0; k < 3; ++k) d->base_t[k] = (T)m->base_X_world_trans[k];
@@ -166,8 +177,14 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
     d->joint_type[i] = l.joint_type;
     const bool fixed = l.joint_type == TDS_JOINT_FIXED;
     if (!fixed) {
-      if (l.q_index != ndof || l.qd_index != ndof) TDS_FAIL(TDS_ERR_INVALID_ARG, "q/qd indices must be dense in link order");
-      d->dof_link[ndof++] = i;
+      if (fl) {  // internal numbering of the expanded model: checked by tds_expand_floating
+        if (l.qd_index < 0 || l.qd_index >= nd) TDS_FAIL(TDS_ERR_INVALID_ARG, "qd index out of range");
+        d->dof_link[l.qd_index] = i;
+        ++ndof;
+      } else {
+        if (l.q_index != ndof || l.qd_index != ndof) TDS_FAIL(TDS_ERR_INVALID_ARG, "q/qd indices must be dense in link order");
+        d->dof_link[ndof++] = i;
+      }
     }
     d->q_index[i] = fixed ? -1 : l.q_index;
     d->qd_index[i] = fixed ? -1 : l.qd_index;
@@ -226,6 +243,7 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
              m->links[k].joint_type != TDS_JOINT_FIXED)
         ++k;
       if (ok && k >= 1 && m->links[k].joint_type != TDS_JOINT_FIXED) d->root_last = k;
+      if (fl) d->root_last = 5;  // the six pseudo links ARE the root joint (the kernels special-case their kinematics)
     }
   }
   d->num_levels = max_level + 1;
@@ -296,4 +314,76 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
   }
 #undef TDS_FAIL
   return TDS_OK;
+}
+
+// Floating base -> the expanded fixed-layout model the builder above understands: six pseudo links in front
+// (dof nj+k, unit axes, link 5 carries mb.base_rbi()), the model's links shifted by 6 with the base as
+// link 5, joint dofs renumbered 0..nj-1.  Returns a malloc'ed model or NULL (why filled).
+static inline tds_model_t *tds_expand_floating(const tds_model_t *m, char *why) {
+  why[0] = 0;
+  const int nj = m->dof_qd - 6;
+  if (m->num_links < 0 || m->num_links + 6 > TDS_MAX_LINKS || nj < 0 || m->dof_q != m->dof_qd + 1) {
+    strncpy(why, "floating base: needs num_links + 6 <= TDS_MAX_LINKS and dof_q == dof_qd + 1", 127);
+    return nullptr;
+  }
+  tds_model_t *e = (tds_model_t *)malloc(sizeof(tds_model_t));
+  if (!e) return nullptr;
+  memcpy(e, m, sizeof(*e));
+  e->num_links = m->num_links + 6;
+  for (int k = 0; k < 6; ++k) {
+    tds_link_t &L = e->links[k];
+    memset(&L, 0, sizeof(L));
+    L.joint_type = k < 3 ? TDS_JOINT_REVOLUTE_X + k : TDS_JOINT_PRISMATIC_X + (k - 3);
+    L.parent = k - 1;
+    L.q_index = L.qd_index = nj + k;
+    L.X_T_rot[0] = L.X_T_rot[4] = L.X_T_rot[8] = 1.0;
+    L.S[k] = 1.0;
+  }
+  e->links[5].mass = m->base_mass;
+  memcpy(e->links[5].com, m->base_com, sizeof(m->base_com));
+  memcpy(e->links[5].inertia, m->base_inertia, sizeof(m->base_inertia));
+  int ndof = 0;
+  for (int i = 0; i < m->num_links; ++i) {
+    tds_link_t &L = e->links[6 + i];
+    L = m->links[i];
+    if (L.parent >= i || L.parent < -1) {
+      free(e);
+      strncpy(why, "links must be ordered parent-before-child", 127);
+      return nullptr;
+    }
+    L.parent = L.parent < 0 ? 5 : L.parent + 6;
+    if (L.joint_type != TDS_JOINT_FIXED) {
+      // the reference numbers q from 7 and qd from 6 on a floating base (multi_body.hpp:324-349)
+      if (L.qd_index != 6 + ndof || L.q_index != 7 + ndof) {
+        free(e);
+        strncpy(why, "floating base: q/qd indices must be dense in link order from 7 / 6", 127);
+        return nullptr;
+      }
+      L.q_index = L.qd_index = ndof++;
+    }
+  }
+  if (ndof != nj) {
+    free(e);
+    strncpy(why, "dof_qd does not match the joints", 127);
+    return nullptr;
+  }
+  for (int g = 0; g < m->num_geoms && g < TDS_MAX_GEOMS; ++g) e->geoms[g].link = m->geoms[g].link < 0 ? 5 : m->geoms[g].link + 6;
+  for (int v = 0; v < m->num_visuals && v < TDS_MAX_VISUALS; ++v) e->visuals[v].link = m->visuals[v].link + 6;
+  e->pd_start_link = m->pd_start_link + 6;
+  return e;
+}
+
+// Returns TDS_OK or an error code; `why` (>= 128 bytes) receives the reason.
+template <typename T>
+static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) {
+  if (m->abi_version != TDS_HIP_ABI_VERSION) {
+    strncpy(why, "model abi_version mismatch", 127);
+    return TDS_ERR_INVALID_ARG;
+  }
+  if (!m->is_floating) return tds_build_dev_model_impl<T>(m, d, why, false);
+  tds_model_t *e = tds_expand_floating(m, why);
+  if (!e) return TDS_ERR_UNSUPPORTED;
+  const int rc = tds_build_dev_model_impl<T>(e, d, why, true);
+  free(e);
+  return rc;
 }

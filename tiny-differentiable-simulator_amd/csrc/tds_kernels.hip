@@ -64,6 +64,15 @@ __device__ __forceinline__ void mat3_mulv(const T *m, const T *v, T *o) {
   o[1] = y;
   o[2] = z;
 }
+// cofactor inverse (tiny_matrix3x3.h:539-559)
+template <typename T>
+__device__ __forceinline__ void mat3_inverse(const T *m, T *o) {
+  const T c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
+  const T s = T(1) / (m[0] * c0 + m[1] * c1 + m[2] * c2);
+  o[0] = c0 * s; o[1] = (m[2] * m[7] - m[1] * m[8]) * s; o[2] = (m[1] * m[5] - m[2] * m[4]) * s;
+  o[3] = c1 * s; o[4] = (m[0] * m[8] - m[2] * m[6]) * s; o[5] = (m[2] * m[3] - m[0] * m[5]) * s;
+  o[6] = c2 * s; o[7] = (m[1] * m[6] - m[0] * m[7]) * s; o[8] = (m[0] * m[4] - m[1] * m[3]) * s;
+}
 template <typename T>
 __device__ __forceinline__ void mat3_mul(const T *a, const T *b, T *o) {
 #pragma unroll
@@ -596,6 +605,15 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   const int level = isl ? mdl->level[lsafe] : -1;
   const int jt = isl ? mdl->joint_type[lsafe] : TDS_JOINT_FIXED;
   const int di = isl ? mdl->qd_index[lsafe] : -1;  // == q_index (1-DoF joints only)
+  // Floating base (DevModel::is_floating): lanes 0..5 are the base's pseudo links and the dofs are numbered
+  // joints first, base last; the q / qd RECORD keeps the reference's order
+  // q = [quat xyzw | pos | joints], qd = [omega | v | joints]  ->  record indices of this lane's coordinate
+  const bool fl = mdl->is_floating != 0;
+  const int njd = mdl->nj;                       // joint dofs (== nd on a fixed base)
+  const bool froot = fl && isl && li < 6;        // base pseudo link
+  const int qri = fl ? di + 7 : di;              // (not used by the pseudo links)
+  const int qdri = fl ? (di >= njd ? di - njd : di + 6) : di;
+  const int rec_d = fl ? (lane >= njd ? lane - njd : lane + 6) : lane;  // lane == dof role
   // Serial chains (parent == lane - 1, the common case for URDF-derived trees) hand their sweep
   // state from lane to lane with DPP row shifts; only the other parent/child links go through the
   // per-link LDS records (see DESIGN.md "chain hand-over").
@@ -693,11 +711,11 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // q = reset_q + reset_noise * U(-1,1), qd = 0  (ant_environment2.h:124-135)
   auto reset_state = [&]() {
     const unsigned cnt = ctl.reset_count != nullptr ? ctl.reset_count[env] : 0u;
-    if (lane < nd) {
-      const T u01 = (T)tds_uniform01(ctl.seed, (unsigned)env, cnt, (unsigned)lane);
-      xr[lane] = mdl->reset_q[lane] + mdl->reset_noise[lane] * ((u01 - T(0.5)) * T(2));
-      xr[nq + lane] = T(0);
+    for (int i = lane; i < nq; i += G) {
+      const T u01 = (T)tds_uniform01(ctl.seed, (unsigned)env, cnt, (unsigned)i);
+      xr[i] = mdl->reset_q[i] + mdl->reset_noise[i] * ((u01 - T(0.5)) * T(2));
     }
+    for (int i = lane; i < nd; i += G) xr[nq + i] = T(0);
     __builtin_amdgcn_wave_barrier();
     if (lane == 0 && ctl.reset_count != nullptr) ctl.reset_count[env] = cnt + 1u;
   };
@@ -714,16 +732,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     TDS_WAVE_SYNC();
     if (finished0) {
-      if (lane < nd) {
-        if (obs_out != nullptr) {
-          T *const ob = obs_out + (size_t)env * (nq + nd + 2);
-          ob[lane] = lane < 2 ? T(0) : xr[lane];
-          ob[nq + lane] = xr[nq + lane];
-        }
-        if (x_feedback != nullptr) {
-          x_feedback[(size_t)env * in_dim + lane] = xr[lane];
-          x_feedback[(size_t)env * in_dim + nq + lane] = xr[nq + lane];
-        }
+      for (int i = lane; i < nq + nd; i += G) {
+        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? T(0) : xr[i];
+        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = xr[i];
       }
     }
   }
@@ -761,8 +772,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
   }
   const bool do_reward = last_run || (pol && mode == TDS_MODE_RUN);
-  const T q = di >= 0 ? xr[di] : T(0);
-  const T qd = di >= 0 ? xr[nq + di] : T(0);
+  const T q = (di >= 0 && !froot) ? xr[qri] : T(0);
+  const T qd = di >= 0 ? xr[nq + qdri] : T(0);
 
   // ---- PD controller (locomotion_contact_simulation.h:168-258) or direct torque -------------
   T tau = T(0);
@@ -781,7 +792,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       f = f < max_force ? f : max_force;
       tau = f;
     }
-  } else if (di >= 0) {
+  } else if (di >= 0 && di < adim) {  // (adim == joint dofs: the base dofs of a floating base carry no torque)
     tau = settling ? T(0) : xr[nq + nd + di];
   }
   // joint stiffness / damping (forward_dynamics.hpp:122-123)
@@ -865,7 +876,24 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     // inclusive scan with DPP row shifts (3 rounds) instead of rkc+1 tree levels.
     //   (Ra, ta) o (Rb, tb) = (Ra Rb, ta + Ra tb)        (transform.hpp:123-131)
     const bool inch = isl && li <= rkc;
-    if (li == 0) {  // link 0 hangs off the base
+    if (fl) {
+      // floating base (kinematics.hpp:35-47): base_X_world = (quat_to_matrix(q[0..3]), q[4..6]) is the frame
+      // of all six pseudo links; their motion axes are the base frame's own axes (omega, then v)
+      if (inch) {
+        const T qx = xr[0], qy = xr[1], qz = xr[2], qw = xr[3];
+        const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);  // tiny_matrix3x3.h:315-340
+        const T xs = qx * s2, ys = qy * s2, zs = qz * s2;
+        const T wx = qw * xs, wy = qw * ys, wz = qw * zs;
+        const T xx = qx * xs, xy = qx * ys, xz = qx * zs;
+        const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
+        R[0] = T(1) - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+        R[3] = xy + wz; R[4] = T(1) - (xx + zz); R[5] = yz - wx;
+        R[6] = xz - wy; R[7] = yz + wx; R[8] = T(1) - (xx + yy);
+        p[0] = xr[4];
+        p[1] = xr[5];
+        p[2] = xr[6];
+      }
+    } else if (li == 0) {  // link 0 hangs off the base
       mat3_mul(mdl->base_R, Rp, R);
       T r[3];
       mat3_mulv(mdl->base_R, tp, r);
@@ -885,7 +913,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       for (int k = 0; k < 9; ++k) Rq[k] = dpp_shr<D>(R[k]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) pq[k] = dpp_shr<D>(p[k]);
-      if (D <= rkc) {  // wave-uniform
+      if (D <= rkc && !fl) {  // wave-uniform
         T Rn[9], r[3];
         mat3_mul(Rq, R, Rn);
         mat3_mulv(Rq, p, r);
@@ -914,8 +942,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
       for (int k = 0; k < 6; ++k) v[k] += m * dpp_shr<D>(v[k]);
     });
-    // bias accelerations of the chain: prefix sum of cb on top of the base acceleration -gravity
-    if (inch) {
+    // bias accelerations of the chain: prefix sum of cb on top of the base acceleration -gravity.
+    // (floating base: a0 stays zero — the axes move with the base, v x v = 0, and the reference adds gravity
+    //  to the base acceleration AFTER the joint accelerations are known, forward_dynamics.hpp:315-319)
+    if (inch && !fl) {
       bias_accel();
 #pragma unroll
       for (int k = 0; k < 6; ++k) a0[k] = cb[k];
@@ -926,7 +956,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 #pragma unroll
       for (int k = 0; k < 6; ++k) a0[k] += m * dpp_shr<D>(a0[k]);
     });
-    if (inch) {
+    if (inch && !fl) {
       a0[3] -= mdl->grav[0];
       a0[4] -= mdl->grav[1];
       a0[5] -= mdl->grav[2];
@@ -1238,6 +1268,17 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     cross3(v, Iv + 3, fc + 3);
 #pragma unroll
     for (int k = 0; k < 6; ++k) fc[k] += Ia[k];
+    if (fl && li == 5) {
+      // floating base body (kinematics.hpp:52-61): the reference's bias force of the base is ONLY the
+      // gyroscopic torque  w x ((R I R^T) w)  with w = qd[0..2] taken as it is, stored as the top of a
+      // base-frame force vector (no v x* I v, no gravity).  In world coordinates: (R gyro, 0).
+      const T w3[3] = {xr[nq], xr[nq + 1], xr[nq + 2]};
+      T Iww[3], gy[3];
+      mat3_mulv(Iw, w3, Iww);
+      cross3(w3, Iww, gy);
+      mat3_mulv(R, gy, fc);
+      fc[3] = fc[4] = fc[5] = T(0);
+    }
     if (lds_children) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = T(0);
@@ -1358,6 +1399,24 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         s = ((anc >> j) & 1u) ? s : T(0);
         Mr[j] = (!isd && j == d) ? T(1) : s;  // padding rows: identity
       }
+      if (fl) {  // wave-uniform
+        // rows of the base dofs (numbered last): against a joint dof j the composite force is that of the
+        // JOINT's link, M[b][j] = s_b . (Ic_j s_j)   (mass_matrix.hpp:111-115, symmetric counterpart)
+        const bool brow = isd && d >= njd;
+        T sb[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sb[k] = brow ? swd[k * NDs + d] : T(0);
+#pragma unroll
+        for (int j = 0; j < NDP; ++j) {
+          if (j < njd) {
+            const int lj = mdl->dof_link[j];
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += Fs[lj * TDS_S2 + k] * sb[k];
+            Mr[j] = brow ? s : Mr[j];
+          }
+        }
+      }
     }
     TDS_STAMP(6);
     // ---- H. M = L D L^T entirely in registers (replaces the Cholesky inverse,
@@ -1425,13 +1484,85 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         yv = d > k ? yv - Mr[k] * yk : yv;
       });
       T xv = yv * my_inv;
-      // L^T x = D^-1 y with the packed copy of L in LDS
+      const bool jrow = !fl || d < njd;  // (the base rows of a floating base keep a_base in the back substitution)
+      if (fl) {  // wave-uniform
+        // With the joint dofs eliminated, the base rows read  Sigma a_base = rho:  Sigma = L_b D_b L_b^T (the
+        // trailing 6x6 block of the factors) is the articulated inertia of the base and rho = L_b y_b is minus
+        // its bias force.  The reference takes  a_base = -base_abi.inv_mul(base_bias_force)  with ITS block
+        // inverse (inertia.hpp:302-329: lower-left block taken as -H, exact only for a skew H) — restated as is.
+        TDS_WAVE_SYNC();
+        if (d < NDP) rhsx[d] = yv;
+        TDS_WAVE_SYNC();
+        T Lb[6][6], Db[6], yb[6], rho[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          Db[i] = T(1) / dvec[njd + i];
+          yb[i] = rhsx[njd + i];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) Lb[i][j] = j < i ? Lp[((njd + i) * (njd + i - 1)) / 2 + njd + j] : (j == i ? T(1) : T(0));
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          rho[i] = yb[i];
+#pragma unroll
+          for (int j = 0; j < i; ++j) rho[i] += Lb[i][j] * yb[j];
+        }
+        T Sg[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            T a = T(0);
+#pragma unroll
+            for (int m = 0; m <= j; ++m) a += Lb[i][m] * Db[m] * Lb[j][m];
+            Sg[i][j] = Sg[j][i] = a;
+          }
+        T Ai[9], Hb[9], Mb[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            Ai[3 * r + c] = Sg[r][c];
+            Hb[3 * r + c] = Sg[r][3 + c];
+            Mb[3 * r + c] = Sg[3 + r][3 + c];
+          }
+        T Ainv[9], t1[9], t2[9], Sc[9], Dc[9], ABD[9];
+        mat3_inverse(Ai, Ainv);
+        mat3_mul(Hb, Ainv, t1);   // -C Ainv  with C = -H
+        mat3_mul(t1, Hb, t2);     // -C Ainv B
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Sc[k] = Mb[k] + t2[k];  // M - C Ainv B
+        mat3_inverse(Sc, Dc);
+        mat3_mul(Ainv, Hb, t1);
+        mat3_mul(t1, Dc, ABD);    // Ainv B DCAB
+        mat3_mul(ABD, Hb, t1);
+        mat3_mul(t1, Ainv, t2);   // -(AinvBDCAB C Ainv)
+        T I2[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) I2[k] = Ainv[k] - t2[k];
+        // a_base = Q rho:  top = I2 rho_top - ABD rho_bot,  bottom = DCAB rho_bot - ABD^T rho_top
+        T ab[6], u3[3], w3[3];
+        mat3_mulv(I2, rho, u3);
+        mat3_mulv(ABD, rho + 3, w3);
+        ab[0] = u3[0] - w3[0];
+        ab[1] = u3[1] - w3[1];
+        ab[2] = u3[2] - w3[2];
+        mat3_mulv(Dc, rho + 3, u3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ab[3 + c] = u3[c] - (ABD[c] * rho[0] + ABD[3 + c] * rho[1] + ABD[6 + c] * rho[2]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xv = d == njd + i ? ab[i] : xv;
+      }
+      // L^T x = D^-1 y with the packed copy of L in LDS (the base rows of a floating base keep a_base)
       static_for<0, NDP - 1>([&](auto ic) {
         constexpr int k = NDP - 1 - decltype(ic)::value;
         const T xk = lane_bcast<T, G, NDP, k>(xv);
-        if (d < k) xv -= Lp[(k * (k - 1)) / 2 + d] * xk;
+        if (d < k && jrow) xv -= Lp[(k * (k - 1)) / 2 + d] * xk;
       });
-      if (d < nd) xr[nq + d] += xv * dt;
+      if (fl && d >= njd + 3 && d < nd) xv += mdl->grav[d - njd - 3];  // forward_dynamics.hpp:315-319
+      // integrate_euler_qdd; from here on the velocities live in dof order in the column scratch
+      TDS_WAVE_SYNC();
+      if (d < NDP) rhsx[d] = d < nd ? xr[nq + rec_d] + xv * dt : T(0);
     }
     TDS_STAMP(8);
 
@@ -1464,6 +1595,23 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       T sd[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) sd[k] = d < nd ? swd[k * NDs + d] : T(0);
+      if (fl && d >= njd && d < nd) {
+        // the reference's point Jacobian takes the base dofs along WORLD axes about the base origin:
+        // [ -[r]x | 1 ],  r = point - base position   (jacobian.hpp:39-56)
+        const int kb = d - njd;
+        const T pb[3] = {xr[4], xr[5], xr[6]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sd[k] = T(0);
+        if (kb < 3) {
+          const T e[3] = {kb == 0 ? T(1) : T(0), kb == 1 ? T(1) : T(0), kb == 2 ? T(1) : T(0)};
+          sd[0] = e[0];
+          sd[1] = e[1];
+          sd[2] = e[2];
+          cross3(pb, e, sd + 3);
+        } else {
+          sd[kb] = T(1);
+        }
+      }
       T cnv[3], c1v[3], c2v[3];
       cross3(nb, sd, cnv);
       cross3(t1, sd, c1v);
@@ -1506,10 +1654,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     const T cfm = pf_cfm, erp_dt = pf_erp_dt, rest = pf_rest;
     const bool any_slab = nr > ZR;  // wave-uniform
     if (any_slab)
-      tds_row_solve<true, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov, rov,
+      tds_row_solve<true, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, rhsx, cpx, Lp, dvec, zov, rov,
                                      cfm, erp_dt, rest);
     else
-      tds_row_solve<false, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov, rov,
+      tds_row_solve<false, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, rhsx, cpx, Lp, dvec, zov, rov,
                                       cfm, erp_dt, rest);
     TDS_WAVE_SYNC();
     if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1531,11 +1679,11 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         const T wk = lane_bcast<T, G, NDP, k>(w);
         if (d < k) w -= Lp[(k * (k - 1)) / 2 + d] * wk;
       });
-      if (d < nd) xr[nq + d] -= w;
+      if (d < nd) rhsx[d] -= w;
     }
     }  // wave_contacts
     TDS_WAVE_SYNC();
-    if (di >= 0) qd_new = xr[nq + di];
+    if (di >= 0) qd_new = rhsx[di];
   }
 
   TDS_STAMP(12);
@@ -1544,17 +1692,43 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   // carry the state in the LDS record (slot in_dim keeps x_{t-1} for the Ant reward)
   TDS_WAVE_SYNC();
+  T up_z = T(0);  // floating base: base_X_world.rotation(2,2) AFTER the step (integrator.hpp:83)
+  if (froot) {
+    // base coordinates (integrator.hpp:23-89): quaternion += quat_velocity(quat, omega, dt)
+    // (tiny_algebra.hpp:604-614), normalised; position += v dt.  Every pseudo-link lane evaluates the whole
+    // quaternion and stores its own component(s): lanes 0..3 the quaternion, lanes 3..5 also the position.
+    const T h = T(0.5) * dt;
+    const T *const qdv = E + L.dinv + 2 * NDP;  // velocities in dof order (phase F)
+    const T w0 = qdv[njd], w1 = qdv[njd + 1], w2 = qdv[njd + 2];
+    const T b0 = xr[0], b1 = xr[1], b2 = xr[2], b3 = xr[3];
+    T n0 = b0 + (b3 * w0 + b2 * w1 - b1 * w2) * h;
+    T n1 = b1 + (b3 * w1 + b0 * w2 - b2 * w0) * h;
+    T n2 = b2 + (b3 * w2 + b1 * w0 - b0 * w1) * h;
+    T n3 = b3 + (-b0 * w0 - b1 * w1 - b2 * w2) * h;
+    const T ql = sqrt_t<T>(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+    n0 /= ql;
+    n1 /= ql;
+    n2 /= ql;
+    n3 /= ql;
+    up_z = T(1) - (n0 * n0 + n1 * n1) * (T(2) / (n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3));
+    const T pos_new = li >= 3 ? xr[4 + li - 3] + qd_new * dt : T(0);
+    __builtin_amdgcn_wave_barrier();
+    if (li < 4) xr[li] = li == 0 ? n0 : li == 1 ? n1 : li == 2 ? n2 : n3;
+    if (li >= 3) xr[4 + li - 3] = pos_new;
+  }
   if (di == 0) xr[in_dim] = q;
   if (di >= 0) {
-    xr[di] = q_new;
-    xr[nq + di] = qd_new;
+    if (!froot) xr[qri] = q_new;
+    xr[nq + qdri] = qd_new;
   }
   TDS_WAVE_SYNC();
 
   // ---- y record (q, qd, up, zero padding; the visual poses went out in M1) of the last normal step
   if (last_run) {
     T *const yo = y_out + (size_t)env * out_dim;
-    if (di >= 0) {
+    if (fl) {  // the record has one more q than lanes carry coordinates: copy it out as it is
+      for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((T)(xr[i]), &yo[i]);
+    } else if (di >= 0) {
       __builtin_nontemporal_store((T)(q_new), &yo[di]);
       __builtin_nontemporal_store((T)(qd_new), &yo[nq + di]);
     }
@@ -1562,7 +1736,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     int tail = nq + nd;
     if (mdl->pack_visuals) {
       tail += 7 * nv;
-      if (lane == 0) __builtin_nontemporal_store((T)(mdl->base_R[8]), &yo[tail]);  // up_dot_world_z
+      if (lane == 0) __builtin_nontemporal_store((T)(fl ? up_z : mdl->base_R[8]), &yo[tail]);  // up_dot_world_z
       tail += 1;
     }
     for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((T)(T(0)), &yo[i]);
@@ -1606,7 +1780,12 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     // straight-line build: exactly one normal step, no reset -> the environment is finished here;
     // observation (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288) and resident state go
     // out straight from registers
-    if (live && di >= 0) {
+    if (live && fl) {
+      for (int i = lane; i < nq + nd; i += G) {
+        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? T(0) : xr[i];
+        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = xr[i];
+      }
+    } else if (live && di >= 0) {
       if (obs_out != nullptr) {
         T *const ob = obs_out + (size_t)env * (nq + nd + 2);
         ob[di] = di < 2 ? T(0) : q_new;
@@ -1671,15 +1850,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     TDS_WAVE_SYNC();
     // ---- the environment is done with this launch: observation (obs[0] = obs[1] = 0,
     //      ars_vectorized_environment.h:283-288) and resident state
-    if (finished && lane < nd) {
-      if (obs_out != nullptr) {
-        T *const ob = obs_out + (size_t)env * (nq + nd + 2);
-        ob[lane] = lane < 2 ? T(0) : xr[lane];
-        ob[nq + lane] = xr[nq + lane];
-      }
-      if (x_feedback != nullptr) {
-        x_feedback[(size_t)env * in_dim + lane] = xr[lane];
-        x_feedback[(size_t)env * in_dim + nq + lane] = xr[nq + lane];
+    if (finished) {
+      for (int i = lane; i < nq + nd; i += G) {
+        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? T(0) : xr[i];
+        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = xr[i];
       }
     }
   }
@@ -1778,9 +1952,12 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
   const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
   const int key = lanes_per_env * 100 + L.NDP;
   switch (key) {
+#if !defined(TDS_DEBUG_ONLY_3218)  // (register-pressure experiments: compile one instantiation)
     case 1608: TDS_LAUNCH(16, 8); break;
     case 1614: TDS_LAUNCH(16, 14); break;
+#endif
     case 3218: TDS_LAUNCH(32, 18); break;
+#if !defined(TDS_DEBUG_ONLY_3218)
     case 1616: TDS_LAUNCH(16, 16); break;
     case 3208: TDS_LAUNCH(32, 8); break;
     case 3216: TDS_LAUNCH(32, 16); break;
@@ -1788,6 +1965,7 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
     case 3232: TDS_LAUNCH(32, 32); break;
     case 6408: TDS_LAUNCH(64, 8); break;
     case 6416: TDS_LAUNCH(64, 16); break;
+#endif
     default:
       return -1;
   }
@@ -1810,9 +1988,12 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
+#if !defined(TDS_DEBUG_ONLY_3218)  // (register-pressure experiments: compile one instantiation)
     case 1608: TDS_ATTR(16, 8); break;
     case 1614: TDS_ATTR(16, 14); break;
+#endif
     case 3218: TDS_ATTR(32, 18); break;
+#if !defined(TDS_DEBUG_ONLY_3218)
     case 1616: TDS_ATTR(16, 16); break;
     case 3208: TDS_ATTR(32, 8); break;
     case 3216: TDS_ATTR(32, 16); break;
@@ -1820,6 +2001,7 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
     case 3232: TDS_ATTR(32, 32); break;
     case 6408: TDS_ATTR(64, 8); break;
     case 6416: TDS_ATTR(64, 16); break;
+#endif
     default: return -1;
   }
 #undef TDS_ATTR

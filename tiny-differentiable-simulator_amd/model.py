@@ -13,7 +13,7 @@ import ctypes as C
 import json
 import os
 
-TDS_HIP_ABI_VERSION = 1
+TDS_HIP_ABI_VERSION = 2
 TDS_MAX_LINKS = 32
 TDS_MAX_GEOMS = 32
 TDS_MAX_VISUALS = 32
@@ -106,6 +106,9 @@ class Model(C.Structure):
         ("reset_noise", C.c_double * TDS_MAX_DOF),
         ("settle_steps", C.c_int32),
         ("pad2_", C.c_int32),
+        ("base_mass", C.c_double),
+        ("base_com", C.c_double * 3),
+        ("base_inertia", C.c_double * 9),
         ("links", Link * TDS_MAX_LINKS),
         ("geoms", Geom * TDS_MAX_GEOMS),
         ("visuals", Visual * TDS_MAX_VISUALS),
@@ -143,6 +146,7 @@ _SCALARS = [
     "restitution", "action_limit",
 ]
 _VECTORS = ["gravity", "base_X_world_rot", "base_X_world_trans", "plane_normal"]
+_OPTIONAL_VECTORS = ["base_com", "base_inertia"]  # JSON files older than the floating-base fields lack them
 
 
 def _struct_to_dict(s, skip=()):
@@ -175,6 +179,9 @@ def model_to_dict(m: Model) -> dict:
     d = {k: getattr(m, k) for k in _SCALARS}
     for k in _VECTORS:
         d[k] = [float(x) for x in getattr(m, k)]
+    d["base_mass"] = float(m.base_mass)
+    for k in _OPTIONAL_VECTORS:
+        d[k] = [float(x) for x in getattr(m, k)]
     d["name"] = m.name.decode()
     d["initial_poses"] = [float(m.initial_poses[i]) for i in range(m.action_dim)] \
         if m.step_mode == TDS_STEP_LOCOMOTION else []
@@ -194,6 +201,11 @@ def model_from_dict(d: dict) -> Model:
         arr = getattr(m, k)
         for i, x in enumerate(d[k]):
             arr[i] = x
+    m.base_mass = d.get("base_mass", 0.0)
+    for k in _OPTIONAL_VECTORS:
+        arr = getattr(m, k)
+        for i, x in enumerate(d.get(k, [])):
+            arr[i] = x
     m.name = d["name"].encode()
     for i, x in enumerate(d["initial_poses"]):
         m.initial_poses[i] = x
@@ -207,8 +219,8 @@ def model_from_dict(d: dict) -> Model:
         _dict_to_struct(g, m.geoms[i])
     for i, v in enumerate(d["visuals"]):
         _dict_to_struct(v, m.visuals[i])
-    if m.abi_version != TDS_HIP_ABI_VERSION:
-        raise ValueError(f"model blob ABI {m.abi_version} != {TDS_HIP_ABI_VERSION}")
+    # the JSON form is layout-free: fields it lacks stay zero; stamp the blob with the layout we filled
+    m.abi_version = TDS_HIP_ABI_VERSION
     return m
 
 
