@@ -24,7 +24,9 @@ def _rot(rng):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
-def random_tree_model(seed):
+def random_tree_model(seed, floating=False):
+    """floating: the tree hangs off a floating base (random inertia, own collision shapes); links may attach
+    to the base directly (parent -1) anywhere in the list, as in the reference's ant_org.urdf"""
     rng = np.random.default_rng(seed)
     m = tds_amd.Model()
     m.abi_version = tds_amd.TDS_HIP_ABI_VERSION
@@ -32,6 +34,8 @@ def random_tree_model(seed):
     nl = int(rng.integers(3, 23))
     n_virtual = int(rng.integers(0, 6)) if rng.random() < 0.6 else 0     # massless root chain length
     n_virtual = min(n_virtual, nl - 2)
+    if floating:
+        nl, n_virtual = int(rng.integers(1, 21)), 0
     style = rng.integers(0, 3)           # 0: serial chain, 1: DFS-ordered tree, 2: arbitrary parents
     ndof = 0
     # a 6-dof virtual chain must span the motion space: prismatic x, y, z then revolute x, y, z (as URDF loaders build it)
@@ -45,7 +49,7 @@ def random_tree_model(seed):
         elif style == 1:
             l.parent = int(rng.choice([i - 1, i - 1, int(rng.integers(n_virtual, i))]))
         else:
-            l.parent = int(rng.integers(max(n_virtual - 1, 0), i))
+            l.parent = int(rng.integers(-1 if floating else max(n_virtual - 1, 0), i))
         if i < n_virtual:
             jt = virt[i]
         else:
@@ -63,7 +67,8 @@ def random_tree_model(seed):
         for k in range(6):
             l.S[k] = S[k]
         if jt != M.JOINT_FIXED:
-            l.q_index = l.qd_index = ndof
+            l.q_index = ndof + (7 if floating else 0)   # multi_body.hpp:324-349
+            l.qd_index = ndof + (6 if floating else 0)
             ndof += 1
         else:
             l.q_index = l.qd_index = -1
@@ -86,6 +91,16 @@ def random_tree_model(seed):
         l.damping = float(rng.uniform(0, 0.5)) if rng.random() < 0.2 else 0.0
     m.num_links = nl
     m.dof_q = m.dof_qd = m.action_dim = ndof
+    if floating:
+        m.is_floating = 1
+        m.dof_q, m.dof_qd = ndof + 7, ndof + 6
+        m.base_mass = float(rng.uniform(0.5, 3.0))
+        A = rng.normal(size=(3, 3))
+        I = (A @ A.T + 3 * np.eye(3)) * 0.01 * m.base_mass
+        for k in range(9):
+            m.base_inertia[k] = I.flat[k]
+        for k in range(3):
+            m.base_com[k] = float(rng.uniform(-0.05, 0.05))
     # contact geometry: a plane (slightly tilted) and spheres / capsules / boxes on random links
     m.has_plane = 1
     n = np.array([rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), 1.0])
@@ -94,7 +109,7 @@ def random_tree_model(seed):
         m.plane_normal[k] = n[k]
     m.plane_constant = 0.0
     ng, ncp = 0, 0
-    for i in range(n_virtual, nl):
+    for i in range(-1 if floating else n_virtual, nl):
         if rng.random() < 0.6 and ng < tds_amd.TDS_MAX_GEOMS:
             g = m.geoms[ng]
             kind = rng.choice(["sphere", "capsule", "box"], p=[0.6, 0.3, 0.1])
@@ -119,8 +134,8 @@ def random_tree_model(seed):
     m.num_visuals = 0
     m.pack_visuals = 0
     m.pgs_iterations = int(rng.integers(1, 3))
-    m.input_dim = 3 * ndof
-    m.output_dim = 2 * ndof
+    m.input_dim = m.dof_q + m.dof_qd + ndof
+    m.output_dim = m.dof_q + m.dof_qd
     m.dt = 0.005
     for k, v in enumerate((0.0, 0.0, -9.81)):
         m.gravity[k] = v
@@ -159,3 +174,41 @@ def test_random_tree_against_oracle(seed, built):
           f"{m.num_contacts} contact points (<= {active} active), lanes {sim.kernel_info()['lanes_per_env']}: "
           f"max rel err {err:.2e}")
     assert err < 1e-6
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_floating_tree_against_oracle(seed, built):
+    """floating base: random trees on a free base, any base orientation, contacts on base and links"""
+    import torch
+    m, _, style = random_tree_model(500 + seed, floating=True)
+    rng = np.random.default_rng(2000 + seed)
+    n, nq, nd, nj = 24, m.dof_q, m.dof_qd, m.action_dim
+    x = np.zeros((n, m.input_dim))
+    quat = rng.normal(size=(n, 4))
+    x[:, 0:4] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    x[:, 4:6] = rng.uniform(-1, 1, (n, 2))
+    x[:, 6] = rng.uniform(0.0, 0.5, n)
+    x[:, 7:nq] = rng.uniform(-0.6, 0.6, (n, nq - 7))
+    x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+    x[:, nq + nd:] = rng.uniform(-1, 1, (n, nj))
+    try:
+        y_ref = oraclelib.step(m, x)
+    except RuntimeError:
+        pytest.skip("degenerate random model (joint-space inertia not positive definite)")
+    if not np.isfinite(y_ref).all() or np.abs(y_ref).max() > 1e6:
+        pytest.skip("degenerate random model (singular joint-space inertia)")
+    sim = hip_backend.HipSim(m, n)
+    y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = rel_err(y, y_ref)
+    print(f"seed {seed}: floating base + {m.num_links} links (style {style}), {nd} dof, {m.num_contacts} contact points, "
+          f"lanes {sim.kernel_info()['lanes_per_env']}: max rel err {err:.2e}")
+    assert err < 1e-6
+    # several steps inside one launch (the step-loop build) == the same steps one launch at a time
+    xd = torch.from_numpy(x).cuda()
+    sim.x.copy_(xd)
+    for _ in range(3):
+        sim.step(None)
+    y1 = sim.y.clone()
+    sim.x.copy_(xd)
+    sim.step(None, 3)
+    assert rel_err(sim.y.cpu().numpy(), y1.cpu().numpy()) < 1e-9
