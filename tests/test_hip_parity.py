@@ -130,7 +130,7 @@ def test_f32_measured_error(built):
     """float build: measured, reported, and bounded loosely (fp32 parity is doubtful
     through the mass-matrix factorisation; the parity-gated build is f64)."""
     torch = _torch()
-    for name in ("pendulum5", "ant"):
+    for name in ("pendulum5", "ant", "cube_floating"):
         m = tds_amd.load_model(name)
         g = np.load(os.path.join(GOLDEN, name + ".npz"))
         sim = hip_backend.HipSim(m, g["x"].shape[0], dtype="f32")
