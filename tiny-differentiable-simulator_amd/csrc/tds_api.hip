@@ -233,8 +233,9 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     return fail(TDS_ERR_UNSUPPORTED, "model needs more than 160 KiB of LDS per workgroup");
   }
   if (lds_bytes > 64 * 1024) {
-    int e = dtype == TDS_DTYPE_F64 ? tds_kernel_max_dynamic_lds<double>(s->lanes, s->lds.NDP, lds_bytes)
-                                   : tds_kernel_max_dynamic_lds<float>(s->lanes, s->lds.NDP, lds_bytes);
+    const bool fl = model->is_floating != 0;
+    int e = dtype == TDS_DTYPE_F64 ? tds_kernel_max_dynamic_lds<double>(s->lanes, s->lds.NDP, lds_bytes, fl)
+                                   : tds_kernel_max_dynamic_lds<float>(s->lanes, s->lds.NDP, lds_bytes, fl);
     if (e != 0) {
       delete s;
       return fail(TDS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");

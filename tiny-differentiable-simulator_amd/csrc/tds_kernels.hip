@@ -577,7 +577,9 @@ __device__ __forceinline__ double tds_uniform01(unsigned long long seed, unsigne
 // LOOP = false: exactly one normal step per launch, no reset -> straight-line code (the bench /
 // forward_zero path; no loop-carried live ranges).  LOOP = true: the general step loop (substeps,
 // auto / forced reset + settle steps) at the price of ~60 more live registers.
-template <typename T, int G, int NDP, bool PROF, bool LOOP>
+// FL = floating base: a template parameter, not a model flag read at run time — as wave-uniform branches the
+// floating-base blocks cost the fixed-base kernels 5 % (measured: Ant x 4096, 23.3 vs 22.2 us per step).
+template <typename T, int G, int NDP, bool PROF, bool LOOP, bool FL>
 __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const T *x_in, T *__restrict__ y_out,
                                                       const T *__restrict__ actions, T *x_feedback /* may alias x_in */,
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // Floating base (DevModel::is_floating): lanes 0..5 are the base's pseudo links and the dofs are numbered
   // joints first, base last; the q / qd RECORD keeps the reference's order
   // q = [quat xyzw | pos | joints], qd = [omega | v | joints]  ->  record indices of this lane's coordinate
-  const bool fl = mdl->is_floating != 0;
+  constexpr bool fl = FL;
   const int njd = mdl->nj;                       // joint dofs (== nd on a fixed base)
   const bool froot = fl && isl && li < 6;        // base pseudo link
   const int qri = fl ? di + 7 : di;              // (not used by the pseudo links)
@@ -1871,7 +1873,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 // padded dof count = template parameter NDP of the kernel.  Besides the coarse widths (8/16/24/32) the
 // widths of the two benchmark robots are instantiated exactly for their natural lane count
 // (Ant: 14 dof on 16 lanes, Laikago: 18 dof on 32 lanes): LDL^T and the row solves scale with NDP^2.
-#if !defined(TDS_ONLY_F32)
+#if !defined(TDS_ONLY_F32) && !defined(TDS_ONLY_FLOATING)
 int tds_padded_dof(int nd, int lanes) {
   if (lanes == 16 && nd > 8 && nd <= 14) return 14;
   if (lanes == 32 && nd > 16 && nd <= 18) return 18;
@@ -1928,10 +1930,10 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
   return L;
 }
 
-template <typename T>
-int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
-                    const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
-                    hipStream_t stream, const TdsStepCtl &ctl, long long *prof) {
+template <typename T, bool FL>
+int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
+                         const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
+                         hipStream_t stream, const TdsStepCtl &ctl, long long *prof) {
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
   const size_t shmem = (size_t)L.stride * epw * sizeof(T);
@@ -1939,15 +1941,16 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \
     if (prof)                                                                                                \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, true, false>), dim3(blocks), dim3(64), shmem, stream,   \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, true, false, false>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else if (simple)                                                                                         \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, false>), dim3(blocks), dim3(64), shmem, stream,  \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, false, FL>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else                                                                                                     \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, true>), dim3(blocks), dim3(64), shmem, stream,   \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, true, FL>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
   } while (0)
+  if (prof && FL) return -2;  // the phase-stamp build exists for fixed-base models only
   // straight-line kernel when the launch is exactly one normal step without any reset
   const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
   const int key = lanes_per_env * 100 + L.NDP;
@@ -1973,18 +1976,18 @@ int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
   return (int)hipGetLastError();
 }
 
-template <typename T>
-int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
+template <typename T, bool FL>
+int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   hipError_t e = hipSuccess;
 #define TDS_ATTR(GG, NN)                                                                                        \
   do {                                                                                                          \
-    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, false>,                             \
+    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, false, FL>,                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                 \
     if (e == hipSuccess)                                                                                        \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, true>,                            \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, true, FL>,                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
-    if (e == hipSuccess)                                                                                        \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, true, false>,                            \
+    if (e == hipSuccess && !FL)                                                                                 \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, true, false, false>,                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
@@ -2008,15 +2011,29 @@ int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes) {
   return (int)e;
 }
 
-// The file is compiled twice (csrc/Makefile): -DTDS_ONLY_F64 and -DTDS_ONLY_F32 each instantiate one
-// compute dtype, so that the two halves of the kernel set build in parallel.
+// The file is compiled four times (csrc/Makefile): -DTDS_ONLY_F64 / -DTDS_ONLY_F32 pick the compute dtype,
+// -DTDS_ONLY_FIXED / -DTDS_ONLY_FLOATING the base kind, so that the four quarters of the kernel set build in
+// parallel.  (tds_make_lds_layout and tds_padded_dof live in the fixed-base units.)
+#define TDS_INSTANTIATE(TT, FLV)                                                                                       \
+  template int tds_launch_step_impl<TT, FLV>(const DevModel<TT> *, const DevModel<TT> &, const TdsLds &, int, const TT *, \
+                                             TT *, const TT *, TT *, TT *, TT *, int, hipStream_t, const TdsStepCtl &, \
+                                             long long *);                                                             \
+  template int tds_kernel_max_dynamic_lds_impl<TT, FLV>(int, int, int);
 #if !defined(TDS_ONLY_F32)
+#if !defined(TDS_ONLY_FLOATING)
 template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int);
-template int tds_launch_step<double>(const DevModel<double> *, const DevModel<double> &, const TdsLds &, int, const double *, double *, const double *, double *, double *, double *, int, hipStream_t, const TdsStepCtl &, long long *);
-template int tds_kernel_max_dynamic_lds<double>(int, int, int);
+TDS_INSTANTIATE(double, false)
+#endif
+#if !defined(TDS_ONLY_FIXED)
+TDS_INSTANTIATE(double, true)
+#endif
 #endif
 #if !defined(TDS_ONLY_F64)
+#if !defined(TDS_ONLY_FLOATING)
 template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int, int);
-template int tds_launch_step<float>(const DevModel<float> *, const DevModel<float> &, const TdsLds &, int, const float *, float *, const float *, float *, float *, float *, int, hipStream_t, const TdsStepCtl &, long long *);
-template int tds_kernel_max_dynamic_lds<float>(int, int, int);
+TDS_INSTANTIATE(float, false)
+#endif
+#if !defined(TDS_ONLY_FIXED)
+TDS_INSTANTIATE(float, true)
+#endif
 #endif
