@@ -184,6 +184,15 @@ int flatten_locomotion_env(Sim &sim, tds_model_t *out, int reward_mode = TDS_REW
     }
     out->settle_steps = 10;
   }
+  // floating base (laikago_environment2.h:65-77): start orientation and position, joints at initial_poses
+  // without noise, 10 settle steps
+  if (sim.mb_->is_floating() && out->dof_q <= TDS_MAX_DOF) {
+    for (int k = 0; k < 4; ++k) out->reset_q[k] = Algebra::to_double(sim.m_start_base_orientation[k]);
+    for (int k = 0; k < 3; ++k) out->reset_q[4 + k] = Algebra::to_double(sim.m_start_base_position[k]);
+    for (size_t j = 0; j < sim.initial_poses_.size() && 7 + (int)j < out->dof_q; ++j)
+      out->reset_q[7 + j] = Algebra::to_double(sim.initial_poses_[j]);
+    out->settle_steps = 10;
+  }
   out->plane_normal[2] = 1.0;
   rc = flatten_plane<Algebra>(sim.world, *sim.mb_, out->dt, out);
   if (rc) return rc;

@@ -39,6 +39,8 @@ MODELS = {
     "ant_floating": dict(ref="gym/ant_org.urdf+plane+floating", dt=5e-3),                   # 4 legs on the base
     "laikago_floating": dict(ref="laikago/laikago_toes_zup.urdf+plane+floating", dt=1e-3),  # 16 links, 18 dof
     "cube_floating": dict(ref="sphere8cube.urdf+plane+floating", dt=2e-3),                  # a single free body
+    # the ENV step (PD controller, visual poses) on a floating base: LaikagoContactSimulation(floating = true)
+    "laikago_floating_env": dict(ref="laikago_floating_env"),
 }
 
 
@@ -61,7 +63,17 @@ def random_inputs(name, m, n, rng):
     that contacts are both active and inactive."""
     nq, nd = m.dof_q, m.dof_qd
     x = np.zeros((n, m.input_dim))
-    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
+    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and m.is_floating:
+        quat = rng.normal(size=(n, 4)) * [0.3, 0.3, 0.3, 0.0] + [0, 0, 0, 1.0]
+        x[:, 0:4] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+        x[:, 4:6] = rng.uniform(-1, 1, (n, 2))
+        x[:, 6] = rng.uniform(0.1, 0.6, n)
+        ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
+        x[:, 7:nq] = ip + rng.uniform(-0.4, 0.4, (n, nq - 7))
+        x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+        x[:, nq + nd:nq + nd + m.action_dim] = rng.uniform(-0.6, 0.6, (n, m.action_dim))
+        x[:, -3:] = [100, 2, 50]
+    elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
         x[:, 0:2] = rng.uniform(-1, 1, (n, 2))
         x[:, 2] = rng.uniform(0.15, 0.6, n)
         x[:, 3:6] = rng.uniform(-0.6, 0.6, (n, 3))
@@ -91,7 +103,13 @@ def random_inputs(name, m, n, rng):
 def rollout_start(name, m, rng):
     nq, nd = m.dof_q, m.dof_qd
     x = np.zeros(m.input_dim)
-    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
+    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and m.is_floating:
+        ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
+        x[3] = 1.0
+        x[6] = 0.48
+        x[7:nq] = ip + 0.05 * rng.uniform(-1, 1, nq - 7)
+        x[-3:] = [100, 2, 50]
+    elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
         ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
         x[2] = 0.48
         x[6:nq] = ip + 0.05 * rng.uniform(-1, 1, nq - 6)

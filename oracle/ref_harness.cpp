@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,9 @@ struct RefSim {
   // exactly one of the two is used
   AntEnv2<Alg> *ant = nullptr;
   LaikagoEnv<Alg> *laikago = nullptr;
+  // the env step on a FLOATING-base robot: LaikagoContactSimulation constructed with floating = true on
+  // laikago/laikago_toes_zup.urdf (the constructor the reference offers, laikago_environment2.h:36-41)
+  LaikagoContactSimulation<Alg> *lfloat = nullptr;
   // generic model (URDF file from the reference data dir, optional plane)
   UrdfCache<Alg> cache;
   World<Alg> *gworld = nullptr;
@@ -60,16 +64,19 @@ struct RefSim {
   World<Alg> &world() {
     if (ant) return ant->contact_sim.world;
     if (laikago) return laikago->contact_sim.world;
+    if (lfloat) return lfloat->world;
     return *gworld;
   }
   MultiBody<Alg> *mb() {
     if (ant) return ant->contact_sim.mb_;
     if (laikago) return laikago->contact_sim.mb_;
+    if (lfloat) return lfloat->mb_;
     return gmb;
   }
   LocoSim *loco() {
     if (ant) return &ant->contact_sim;
     if (laikago) return &laikago->contact_sim;
+    if (lfloat) return lfloat;
     return nullptr;
   }
   bool has_plane() { return loco() ? true : g_plane; }
@@ -141,6 +148,14 @@ void *tdsref_create(const char *name_c, const char *reference_root) {
     s->ant = new AntEnv2<Alg>(false);
   } else if (name == "laikago") {
     s->laikago = new LaikagoEnv<Alg>(false);
+  } else if (name == "laikago_floating_env") {
+    // urdf_from_file = true: FileUtils::find_file looks under ./data of the working directory
+    char cwd[4096];
+    if (!getcwd(cwd, sizeof(cwd))) cwd[0] = 0;
+    if (chdir(reference_root) != 0) return nullptr;
+    s->lfloat = new LaikagoContactSimulation<Alg>(true, "laikago/laikago_toes_zup.urdf", "",
+                                                  LaikagoContactSimulation<Alg>::get_initial_poses(), true);
+    if (cwd[0] && chdir(cwd) != 0) return nullptr;
   } else {
     std::string file = name;
     bool floating = false;
@@ -172,6 +187,7 @@ void tdsref_destroy(void *h) {
   RefSim *s = (RefSim *)h;
   delete s->ant;
   delete s->laikago;
+  delete s->lfloat;
   delete s->gworld;
   delete s;
 }
@@ -209,6 +225,8 @@ int tdsref_flatten(void *h, tds_model_t *out) {
     rc = tds_hip::flatten_locomotion_env<Alg>(s->ant->contact_sim, out, TDS_REWARD_ANT);
   } else if (s->laikago) {
     rc = tds_hip::flatten_locomotion_env<Alg>(s->laikago->contact_sim, out, TDS_REWARD_LAIKAGO);
+  } else if (s->lfloat) {
+    rc = tds_hip::flatten_locomotion_env<Alg>(*s->lfloat, out, TDS_REWARD_NONE);
   } else {
     memset(out, 0, sizeof(*out));
     out->abi_version = TDS_HIP_ABI_VERSION;

@@ -65,7 +65,8 @@ def test_golden_rollout_per_step(name, built):
     assert err < TOL
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago_soft", "pendulum5_plane", "ant_floating", "laikago_floating"])
+@pytest.mark.parametrize("name", ["ant", "laikago_soft", "pendulum5_plane", "ant_floating", "laikago_floating",
+                                  "laikago_floating_env"])
 def test_closed_loop_matches_oracle(name, built):
     """device-resident closed loop (tds_hip_step) vs the oracle stepping on the host."""
     torch = _torch()
