@@ -297,9 +297,9 @@ def _host_reset(m, x_row, seed, env, count):
     """reset distribution + settle steps, on the host with the oracle"""
     nq, nd = m.dof_q, m.dof_qd
     x = x_row.copy()
-    for j in range(nd):
+    for j in range(nq):  # (nq == nd + 1 on a floating base)
         x[j] = m.reset_q[j] + m.reset_noise[j] * ((_uniform01(seed, env, count, j) - 0.5) * 2.0)
-        x[nq + j] = 0.0
+    x[nq:nq + nd] = 0.0
     x[nq + nd:nq + nd + m.action_dim] = 0.0
     for _ in range(m.settle_steps):
         y = oraclelib.step(m, x)[0]
@@ -307,7 +307,7 @@ def _host_reset(m, x_row, seed, env, count):
     return x[:nq + nd]
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "laikago_floating_env", "ant_floating"])
 def test_substeps_in_kernel_equal_repeated_steps(name, built):
     torch = _torch()
     m = tds_amd.load_model(name)
@@ -330,7 +330,7 @@ def test_substeps_in_kernel_equal_repeated_steps(name, built):
     assert ex < 1e-9 and ey < 1e-9
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "laikago_floating_env"])
 def test_forced_reset_matches_host_emulation(name, built):
     torch = _torch()
     m = tds_amd.load_model(name)
@@ -501,7 +501,7 @@ def test_rollout_equals_stepwise_launches_with_auto_reset(built):
     assert rel_err(sim2.x.cpu().numpy()[:, :od], x_fin[:, :od], 1e-3) < 1e-7
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago", "pendulum5_plane"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "pendulum5_plane", "ant_floating", "laikago_floating_env"])
 @pytest.mark.parametrize("var", ["TDS_HIP_NO_ROOTJOINT", "TDS_HIP_NO_CHAIN"])
 def test_general_tree_paths_still_match(name, var, built):
     """the root-joint / chain hand-over shortcuts are optimisations of the general tree sweeps: with them
