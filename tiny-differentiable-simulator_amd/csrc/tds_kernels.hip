@@ -514,7 +514,10 @@ __device__ __forceinline__ T tds_pgs_sweep(T u, int lane, int NA, int ZR, T mu, 
       xn = min_t<T>(xn, h);   // Algebra::min(x, hi*s)
     }
     if constexpr (FIRST) u += zr * xn; else u += zr * (xn - x_old);
-    if (lane == 0) xs[r] = xn;
+    // every lane of the group holds the same xn and stores it (same address: no bank conflict).  A store
+    // predicated on lane == 0 becomes a branch around the DS write, after which the compiler must drain
+    // lgkmcnt(0) — the LDS write latency then sits on every iteration of this loop.
+    xs[r] = xn;
     if (r == 0) x0 = xn;
     // with a single contact slot row 1 depends on the row just computed (its prefetch is stale)
     sn = NA == 1 ? x0 : sload;
