@@ -463,7 +463,7 @@ __device__ __forceinline__ T tds_pgs(int lane, int NA, int ZR, int OVR, int iter
       xn = max_t<T>(xn, lo);  // Algebra::max(x, lo*s)
       xn = min_t<T>(xn, hi);  // Algebra::min(x, hi*s)
       u += zr * (xn - x_old);
-      if (lane == 0) xs[r] = xn;
+      xs[r] = xn;  // (all lanes of the group, same value: see tds_pgs_sweep)
     }
   }
   return u;
