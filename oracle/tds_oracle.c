@@ -311,6 +311,9 @@ typedef struct {
   sv_t S, vJ, v, c, a, pA, U;
   abi_t abi;
   double D, u;
+  /* spherical joint (link.hpp:168-176: S_3d = [1 0]^T, three angular columns in the link frame) */
+  sv_t U3[3];
+  double invD3[9], u3[3];
 } lstate_t;
 
 typedef struct {
@@ -324,7 +327,7 @@ typedef struct {
   /* floating base (multi_body.hpp:66-78): spatial velocity / acceleration, articulated inertia, bias force */
   sv_t base_v, base_a, base_bias;
   abi_t base_abi;
-  double q[ND + 1], qd[ND], qdd[ND], tau[ND];
+  double q[ND + 1 + NL], qd[ND], qdd[ND], tau[ND]; /* (+1 floating base, +1 per spherical joint) */
   contact_t cps[NCMAX];
   int n_c;
   double M[ND * ND], Minv[ND * ND];
@@ -339,10 +342,18 @@ static void link_xf(const tds_link_t *l, xf_t *x) {
 }
 
 /* ref: src/link.hpp:229-287 (X_J, X_parent) and :289-329 (vJ) */
-static void jcalc(const tds_link_t *l, double q, double qd, int have_qd, lstate_t *s) {
+static void jcalc(const tds_link_t *l, const double *qp, const double *qdp, int have_qd, lstate_t *s) {
   xf_t XT;
   link_xf(l, &XT);
   xf_identity(&s->X_J);
+  if (l->joint_type == TDS_JOINT_SPHERICAL) { /* link.hpp:262-266, :319-321 */
+    quat_to_matrix(qp, s->X_J.r);
+    xf_mul(&XT, &s->X_J, &s->X_parent);
+    for (int k = 0; k < 3; ++k) { s->vJ.a[k] = have_qd ? qdp[k] : 0.0; s->vJ.l[k] = 0.0; }
+    return;
+  }
+  const double q = qp ? qp[0] : 0.0;
+  double qd = qdp ? qdp[0] : 0.0;
   double c = cos(q), sn = sin(q);
   switch (l->joint_type) {
     case TDS_JOINT_PRISMATIC_X: s->X_J.t[0] = q; break;
@@ -408,8 +419,8 @@ static void forward_kinematics(const tds_model_t *m, scratch_t *s, int have_qd) 
   for (int i = 0; i < m->num_links; ++i) {
     const tds_link_t *l = &m->links[i];
     lstate_t *L = &s->L[i];
-    double q = l->q_index >= 0 ? s->q[l->q_index] : 0.0;   /* multi_body.hpp:490-500 */
-    double qd = l->qd_index >= 0 ? s->qd[l->qd_index] : 0.0;
+    const double *q = l->q_index >= 0 ? &s->q[l->q_index] : NULL;   /* multi_body.hpp:490-500 */
+    const double *qd = l->qd_index >= 0 ? &s->qd[l->qd_index] : NULL;
     jcalc(l, q, qd, have_qd, L);
     if (l->parent >= 0) {
       xf_mul(&s->L[l->parent].X_world, &L->X_parent, &L->X_world); /* :82 */
@@ -439,6 +450,58 @@ static void forward_dynamics(const tds_model_t *m, scratch_t *s) {
   for (int i = m->num_links - 1; i >= 0; --i) {
     const tds_link_t *l = &m->links[i];
     lstate_t *L = &s->L[i];
+    if (l->joint_type == TDS_JOINT_SPHERICAL) { /* :56-109 */
+      double D3[9];
+      for (int c = 0; c < 3; ++c) {
+        sv_t e = {{0, 0, 0}, {0, 0, 0}};
+        e.a[c] = 1.0;
+        abi_mul(&L->abi, &e, &L->U3[c]);            /* U_3d = abi * S_3d */
+      }
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) D3[3 * r + c] = L->U3[c].a[r]; /* D_3d = S_3d^T U_3d */
+      /* tau - stiffness * axis_angle(quat) - damping * qd  (:62-76; the loader leaves both at zero) */
+      for (int k = 0; k < 3; ++k)
+        L->u3[k] = s->tau[l->qd_index + k] - l->damping * s->qd[l->qd_index + k] - L->pA.a[k]; /* :79 */
+      if (l->stiffness != 0.0) {
+        const double *qq = &s->q[l->q_index];
+        double qn = sqrt(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2]);
+        double theta = 2.0 * atan2(qn, qq[3]);       /* tiny_algebra.hpp:509-527 */
+        double sc = qn < pow(2.220446049250313e-16, 0.25) ? 1.0 / (0.5 + theta * theta / 48.0) : theta / qn;
+        for (int k = 0; k < 3; ++k) L->u3[k] -= l->stiffness * sc * qq[k];
+      }
+      m3_inverse(D3, L->invD3);                       /* :100 */
+      /* u_dinv_ut = U (U invD)^T  (inertia.hpp:353-368),  UuD = U (invD u) */
+      double w[3];
+      m3_mulv(L->invD3, L->u3, w);
+      abi_t Ia = L->abi;
+      sv_t pa = L->pA;
+      for (int c = 0; c < 3; ++c) {
+        sv_t Ub = {{0, 0, 0}, {0, 0, 0}}; /* column c of U invD */
+        for (int k = 0; k < 3; ++k)
+          for (int j = 0; j < 3; ++j) { Ub.a[j] += L->U3[k].a[j] * L->invD3[3 * k + c]; Ub.l[j] += L->U3[k].l[j] * L->invD3[3 * k + c]; }
+        for (int r = 0; r < 3; ++r)
+          for (int j = 0; j < 3; ++j) {
+            Ia.I[3 * r + j] -= L->U3[c].a[r] * Ub.a[j];
+            Ia.H[3 * r + j] -= L->U3[c].a[r] * Ub.l[j];
+            Ia.M[3 * r + j] -= L->U3[c].l[r] * Ub.l[j];
+          }
+        for (int j = 0; j < 3; ++j) { pa.a[j] += L->U3[c].a[j] * w[c]; pa.l[j] += L->U3[c].l[j] * w[c]; }
+      }
+      sv_t Ia_c;
+      abi_mul(&Ia, &L->c, &Ia_c);
+      for (int k = 0; k < 3; ++k) { pa.a[k] += Ia_c.a[k]; pa.l[k] += Ia_c.l[k]; }
+      if (l->parent >= 0 || m->is_floating) {
+        sv_t dpA;
+        abi_t dI;
+        xf_apply_force(&L->X_parent, &pa, &dpA);
+        abi_congruence(&L->X_parent, &Ia, &dI);
+        sv_t *PpA = l->parent >= 0 ? &s->L[l->parent].pA : &s->base_bias;
+        abi_t *Pabi = l->parent >= 0 ? &s->L[l->parent].abi : &s->base_abi;
+        for (int k = 0; k < 3; ++k) { PpA->a[k] += dpA.a[k]; PpA->l[k] += dpA.l[k]; }
+        for (int k = 0; k < 9; ++k) { Pabi->I[k] += dI.I[k]; Pabi->H[k] += dI.H[k]; Pabi->M[k] += dI.M[k]; }
+      }
+      continue;
+    }
     abi_mul(&L->abi, &L->S, &L->U);           /* :111 */
     L->D = sv_dot(&L->S, &L->U);              /* :115 */
     double tau_val = 0.0;                      /* multi_body.hpp:557-570 */
@@ -493,7 +556,12 @@ static void forward_dynamics(const tds_model_t *m, scratch_t *s) {
     sv_t xa;
     xf_apply_motion(&L->X_parent, ap, &xa);
     for (int k = 0; k < 3; ++k) { L->a.a[k] = xa.a[k] + L->c.a[k]; L->a.l[k] = xa.l[k] + L->c.l[k]; }
-    if (l->qd_index >= 0) {
+    if (l->joint_type == TDS_JOINT_SPHERICAL) { /* :268-283 */
+      double r3[3], qdd3[3];
+      for (int c = 0; c < 3; ++c) r3[c] = L->u3[c] - sv_dot(&L->U3[c], &L->a);
+      m3_mulv(L->invD3, r3, qdd3);
+      for (int c = 0; c < 3; ++c) { s->qdd[l->qd_index + c] = qdd3[c]; L->a.a[c] += qdd3[c]; }
+    } else if (l->qd_index >= 0) {
       double invD = l->joint_type == TDS_JOINT_FIXED ? 0.0 : 1.0 / L->D;
       double Ut_a = sv_dot(&L->U, &L->a);
       double qdd = invD * (L->u - Ut_a);
@@ -524,25 +592,40 @@ static void mass_matrix(const tds_model_t *m, scratch_t *s) {
       for (int k = 0; k < 9; ++k) { P->I[k] += dI.I[k]; P->H[k] += dI.H[k]; P->M[k] += dI.M[k]; }
     }
     if (l->joint_type == TDS_JOINT_FIXED) continue; /* :56 */
-    int qd_i = l->qd_index;
-    sv_t Fi;
-    abi_mul(&L->abi, &L->S, &Fi);              /* :87 */
-    s->M[qd_i * nd + qd_i] = sv_dot(&L->S, &Fi); /* :89 */
-    int j = i;
-    while (m->links[j].parent != -1) {         /* :92-109 */
-      xf_apply_force(&s->L[j].X_parent, &Fi, &Fi);
-      j = m->links[j].parent;
-      if (m->links[j].joint_type == TDS_JOINT_FIXED) continue;
-      int qd_j = m->links[j].qd_index;
-      double h = sv_dot(&Fi, &s->L[j].S);
-      s->M[qd_i * nd + qd_j] = h;
-      s->M[qd_j * nd + qd_i] = h;
-    }
-    if (m->is_floating) { /* :111-115  force carried into the base frame -> column / row of the base block */
-      xf_apply_force(&s->L[j].X_parent, &Fi, &Fi);
-      for (int k = 0; k < 3; ++k) {
-        s->M[k * nd + qd_i] = s->M[qd_i * nd + k] = Fi.a[k];
-        s->M[(3 + k) * nd + qd_i] = s->M[qd_i * nd + 3 + k] = Fi.l[k];
+    const int qd_i = l->qd_index;
+    const int nci = l->joint_type == TDS_JOINT_SPHERICAL ? 3 : 1; /* :58-85 spherical: the same, column by column */
+    for (int ci = 0; ci < nci; ++ci) {
+      sv_t Si = L->S, Fi;
+      if (nci == 3) { memset(&Si, 0, sizeof(Si)); Si.a[ci] = 1.0; }
+      abi_mul(&L->abi, &Si, &Fi);                /* :87 / :59 */
+      if (nci == 3) {
+        for (int c2 = 0; c2 < 3; ++c2) s->M[(qd_i + ci) * nd + qd_i + c2] = Fi.a[c2]; /* S_3d^T Fi */
+      } else {
+        s->M[qd_i * nd + qd_i] = sv_dot(&L->S, &Fi); /* :89 */
+      }
+      int j = i;
+      while (m->links[j].parent != -1) {         /* :92-109 / :63-79 */
+        xf_apply_force(&s->L[j].X_parent, &Fi, &Fi);
+        j = m->links[j].parent;
+        if (m->links[j].joint_type == TDS_JOINT_FIXED) continue;
+        int qd_j = m->links[j].qd_index;
+        if (m->links[j].joint_type == TDS_JOINT_SPHERICAL) {
+          for (int c2 = 0; c2 < 3; ++c2) {
+            s->M[(qd_i + ci) * nd + qd_j + c2] = Fi.a[c2];
+            s->M[(qd_j + c2) * nd + qd_i + ci] = Fi.a[c2];
+          }
+        } else {
+          double h = sv_dot(&Fi, &s->L[j].S);
+          s->M[(qd_i + ci) * nd + qd_j] = h;
+          s->M[qd_j * nd + qd_i + ci] = h;
+        }
+      }
+      if (m->is_floating) { /* :111-115  force carried into the base frame -> column / row of the base block */
+        xf_apply_force(&s->L[j].X_parent, &Fi, &Fi);
+        for (int k = 0; k < 3; ++k) {
+          s->M[k * nd + qd_i + ci] = s->M[(qd_i + ci) * nd + k] = Fi.a[k];
+          s->M[(3 + k) * nd + qd_i + ci] = s->M[(qd_i + ci) * nd + 3 + k] = Fi.l[k];
+        }
       }
     }
   }
@@ -613,7 +696,16 @@ static void point_jacobian(const tds_model_t *m, const scratch_t *s, int link_in
   int i = link_index;
   while (i >= 0) {
     const tds_link_t *l = &m->links[i];
-    if (l->joint_type != TDS_JOINT_FIXED) {
+    if (l->joint_type == TDS_JOINT_SPHERICAL) { /* :65-69: the three columns of S_3d like three revolute axes */
+      for (int c = 0; c < 3; ++c) {
+        sv_t e = {{0, 0, 0}, {0, 0, 0}}, st;
+        e.a[c] = 1.0;
+        xf_apply_inverse_motion(&s->L[i].X_world, &e, &st);
+        double rxw[3];
+        v3_cross(point, st.a, rxw);
+        for (int r = 0; r < 3; ++r) jac[r * nd + l->qd_index + c] = st.l[r] - rxw[r];
+      }
+    } else if (l->joint_type != TDS_JOINT_FIXED) {
       sv_t st;
       xf_apply_inverse_motion(&s->L[i].X_world, &s->L[i].S, &st); /* :74 */
       /* point_tf.apply(st): rotation = I, translation = point (transform.hpp:210-226) */
@@ -794,7 +886,13 @@ static int resolve_collision(const tds_model_t *m, scratch_t *s, tds_oracle_debu
 static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t *s,
                     tds_oracle_debug_t *dbg) {
   const int nq = m->dof_q, nd = m->dof_qd;
-  if (m->num_links > NL || nd > ND || nq > ND + 1 || nq != nd + (m->is_floating ? 1 : 0)) return -2;
+  int nsph = 0;
+  for (int i = 0; i < m->num_links && i < NL; ++i) nsph += m->links[i].joint_type == TDS_JOINT_SPHERICAL;
+  if (m->num_links > NL || nd > ND || nq != nd + (m->is_floating ? 1 : 0) + nsph) return -2;
+  /* floating base + spherical joints: the reference writes the base/joint block of M only one way round
+     (mass_matrix.hpp:80-84) — not restated */
+  if (m->is_floating && nsph) return -2;
+  if (nsph && m->step_mode != TDS_STEP_TAU) return -2; /* the PD block's spherical branch is unused by the configs */
   if (m->has_plane) {
     int nc = 0;
     for (int g = 0; g < m->num_geoms; ++g)
@@ -845,7 +943,9 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
     for (int k = 0; k < 6; ++k) s->qd[k] += s->qdd[k] * m->dt;
   for (int i = 0; i < m->num_links; ++i) {
     const tds_link_t *l = &m->links[i];
-    if (l->joint_type != TDS_JOINT_FIXED) s->qd[l->qd_index] += s->qdd[l->qd_index] * m->dt;
+    const int nc = l->joint_type == TDS_JOINT_SPHERICAL ? 3 : 1; /* :171-174 */
+    if (l->joint_type != TDS_JOINT_FIXED)
+      for (int c = 0; c < nc; ++c) s->qd[l->qd_index + c] += s->qdd[l->qd_index + c] * m->dt;
   }
   if (m->has_plane) {                                      /* world.step (world.hpp:293-366) */
     compute_contacts(m, s);
@@ -876,7 +976,20 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
   }
   for (int i = 0; i < m->num_links; ++i) {
     const tds_link_t *l = &m->links[i];
-    if (l->joint_type != TDS_JOINT_FIXED) s->q[l->q_index] += s->qd[l->qd_index] * m->dt;
+    if (l->joint_type == TDS_JOINT_SPHERICAL) { /* :94-123 */
+      double *w = &s->qd[l->qd_index], *b = &s->q[l->q_index];
+      const double damping = pow(0.995, m->dt * 1000.0); /* MultiBody::joint_damping_ = 0.995 (multi_body.hpp:51) */
+      for (int c = 0; c < 3; ++c) w[c] *= damping;
+      const double h = 0.5 * m->dt; /* quat_velocity_spherical, tiny_algebra.hpp:618-629 */
+      double ww = (-b[0] * w[0] - b[1] * w[1] - b[2] * w[2]) * h;
+      double xx = (b[3] * w[0] + b[1] * w[2] - b[2] * w[1]) * h;
+      double yy = (b[3] * w[1] + b[2] * w[0] - b[0] * w[2]) * h;
+      double zz = (b[3] * w[2] + b[0] * w[1] - b[1] * w[0]) * h;
+      b[0] += xx; b[1] += yy; b[2] += zz; b[3] += ww;
+      quat_normalize(b);
+    } else if (l->joint_type != TDS_JOINT_FIXED) {
+      s->q[l->q_index] += s->qd[l->qd_index] * m->dt;
+    }
   }
   /* pack (:273-303); the rest of y is zero (caller's vector is zero-initialised) */
   int j = 0;
