@@ -41,7 +41,23 @@ MODELS = {
     "cube_floating": dict(ref="sphere8cube.urdf+plane+floating", dt=2e-3),                  # a single free body
     # the ENV step (PD controller, visual poses) on a floating base: LaikagoContactSimulation(floating = true)
     "laikago_floating_env": dict(ref="laikago_floating_env"),
+    # spherical joints: 4 coordinates (quaternion) / 3 velocities per joint
+    "pendulum5_spherical": dict(ref="pendulum5spherical.urdf", dt=1e-3),                          # 5 spherical links in a chain
+    "sphere_spherical": dict(ref="sphere_small_xyzspherical.urdf+plane", dt=2e-3),                  # xyz prismatic + spherical
+    "humanoid_spherical": dict(ref="humanoid_partial_xyz_spherical_fixed.urdf+plane", dt=1e-3),     # + fixed children, 4 shapes
 }
+
+
+def _spherical_links(m):
+    return [i for i in range(m.num_links) if m.links[i].joint_type == tds_amd.model.JOINT_SPHERICAL]
+
+
+def _set_spherical_quats(m, x, rng, spread):
+    """unit quaternions (spread = size of the xyz part before normalisation) for every spherical joint"""
+    for i in _spherical_links(m):
+        qi = m.links[i].q_index
+        quat = rng.normal(size=(x.shape[0], 4)) * [spread, spread, spread, 0.0] + [0, 0, 0, 1.0]
+        x[:, qi:qi + 4] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
 
 
 def make_ref(name):
@@ -90,6 +106,13 @@ def random_inputs(name, m, n, rng):
         x[:, 7:nq] = rng.uniform(-0.6, 0.6, (n, nq - 7))
         x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
         x[:, nq + nd:] = rng.uniform(-1, 1, (n, m.action_dim))
+    elif _spherical_links(m):
+        x[:, :nq] = rng.uniform(-0.3, 0.3, (n, nq))
+        if m.has_plane:
+            x[:, 2] = rng.uniform(-0.05, 0.4, n)     # height of the xyz base: contacts both active and not
+        _set_spherical_quats(m, x, rng, 0.5)
+        x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+        x[:, nq + nd:] = rng.uniform(-1, 1, (n, m.action_dim))
     else:
         x[:, :nq] = rng.uniform(-1, 1, (n, nq))
         x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
@@ -120,6 +143,13 @@ def rollout_start(name, m, rng):
         x[6] = 0.55
         x[7:nq] = rng.uniform(-0.3, 0.3, nq - 7)
         x[nq:nq + 3] = rng.uniform(-0.5, 0.5, 3)
+    elif _spherical_links(m):
+        x[:nq] = rng.uniform(-0.2, 0.2, nq)
+        if m.has_plane:
+            x[2] = 0.3
+        xx = x[None, :].copy()
+        _set_spherical_quats(m, xx, rng, 0.3)
+        x[:] = xx[0]
     else:
         x[:nq] = rng.uniform(-1, 1, nq)
         if name == "pendulum5_plane":
@@ -180,7 +210,7 @@ def main(only=None):
         traj = np.zeros((T, m.output_dim))
         acts = rng.uniform(-0.4, 0.4, (T, m.action_dim))
         if m.step_mode != tds_amd.TDS_STEP_LOCOMOTION:
-            acts *= 0.0 if name.startswith("pendulum5") else (2.0 if m.is_floating else 25.0)
+            acts *= 0.0 if name.startswith("pendulum5") else (2.0 if (m.is_floating or _spherical_links(m)) else 25.0)
         for t in range(T):
             xt[nq + nd:nq + nd + m.action_dim] = acts[t]
             traj[t] = r.step(xt)[0]

@@ -21,7 +21,8 @@ def lanes_options(m):
     """lane-group widths the library instantiates for this model (G >= links, G >= padded dof;
     G = 64 only for <= 16 dof)"""
     ndp = 8 if m.dof_qd <= 8 else 16 if m.dof_qd <= 16 else 24 if m.dof_qd <= 24 else 32
-    need = max(m.num_links + (6 if m.is_floating else 0), ndp)  # (floating base: six pseudo links)
+    nsph = sum(m.links[i].joint_type == tds_amd.model.JOINT_SPHERICAL for i in range(m.num_links))
+    need = max(m.num_links + (6 if m.is_floating else 0) + 2 * nsph, ndp)  # (floating base: six pseudo links; spherical joint: three lanes)
     return [g for g in (16, 32, 64) if g >= need and (g < 64 or ndp <= 16)]
 
 

@@ -193,7 +193,9 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   s->dtype = dtype;
   s->elem = dtype == TDS_DTYPE_F64 ? 8 : 4;
   // (a floating base takes six more lanes: its pseudo links, tds_device_model.h)
-  s->lanes = default_lanes_per_env(model->num_links + (model->is_floating ? 6 : 0), model->dof_qd);
+  int nlanes = model->num_links + (model->is_floating ? 6 : 0);  // + 2 per spherical joint (three lanes)
+  for (int i = 0; i < model->num_links; ++i) nlanes += model->links[i].joint_type == TDS_JOINT_SPHERICAL ? 2 : 0;
+  s->lanes = default_lanes_per_env(nlanes, model->dof_qd);
   char why[128];
   size_t msize;
   const void *hsrc;
@@ -233,9 +235,9 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     return fail(TDS_ERR_UNSUPPORTED, "model needs more than 160 KiB of LDS per workgroup");
   }
   if (lds_bytes > 64 * 1024) {
-    const bool fl = model->is_floating != 0;
-    int e = dtype == TDS_DTYPE_F64 ? tds_kernel_max_dynamic_lds<double>(s->lanes, s->lds.NDP, lds_bytes, fl)
-                                   : tds_kernel_max_dynamic_lds<float>(s->lanes, s->lds.NDP, lds_bytes, fl);
+    const int kind = s->h64.is_floating || s->h32.is_floating ? 1 : (s->h64.num_spherical || s->h32.num_spherical ? 2 : 0);
+    int e = dtype == TDS_DTYPE_F64 ? tds_kernel_max_dynamic_lds<double>(s->lanes, s->lds.NDP, lds_bytes, kind)
+                                   : tds_kernel_max_dynamic_lds<float>(s->lanes, s->lds.NDP, lds_bytes, kind);
     if (e != 0) {
       delete s;
       return fail(TDS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");

@@ -21,6 +21,10 @@
 #define TDS_NCP TDS_MAX_CONTACTS       // 32 contact points
 #define TDS_NV TDS_MAX_VISUALS         // 32
 #define TDS_NPAIR (TDS_NL * 12)        // (link, strict ancestor) pairs
+// internal joint types of the expanded model (never in a tds_model_t handed in by a caller)
+#define TDS_JOINT_SPH0 9   // first lane of a spherical joint: X_J = quat_to_matrix(q[0..3]), axis x
+#define TDS_JOINT_SPH1 10  // second: identity transform, axis y
+#define TDS_JOINT_SPH2 11  // third (the link itself): identity transform, axis z
 
 template <typename T>
 struct DevModel {
@@ -34,6 +38,15 @@ struct DevModel {
   // reaches the base block as the Schur complement of the joints (= the articulated inertia of the base).
   // The q / qd RECORD keeps the reference's order: q = [quat xyzw | pos | joints], qd = [omega | v | joints].
   int is_floating, nj;  // nj = number of joint dofs (= dof_qd when the base is fixed)
+  // spherical joints (link.hpp:168-176,262-266): the link becomes three lanes — two massless pseudo links and
+  // the link itself — that share one frame (quaternion of the joint) and carry the three angular dofs along
+  // that frame's x, y, z; internal joint types TDS_JOINT_SPH0/1/2 below.  num_spherical > 0 selects the
+  // kernels built for them.  Record indices (the q record has 4 coordinates per spherical joint):
+  int num_spherical;
+  int q_rec[TDS_NL];    // index of the link's (first) coordinate in the q record, -1: none
+  int qd_rec[TDS_NL];   // index of the link's velocity in the qd record, -1: none
+  int dof_rec[TDS_ND];  // qd record index of (internal) dof d
+  T sph_damping;        // pow(MultiBody::joint_damping_ = 0.995, 1000 dt)   (integrator.hpp:107-112)
   T dt, cfm, erp_over_dt, friction, restitution, action_limit;
   T grav[3];       // base acceleration = -grav (forward_dynamics.hpp:242), world frame
   T base_R[9], base_t[3];
@@ -86,11 +99,20 @@ static inline void tds_plane_space(const double *n, double *p, double *q) {
   q[2] = gt ? n[0] * p[1] : a * k;
 }
 
-// `fl`: m is the EXPANDED form of a floating-base model (tds_expand_floating below).
+// the expanded form of a model with a floating base and/or spherical joints (tds_expand_model below)
+struct TdsExpanded {
+  tds_model_t m;        // links incl. pseudo links, internal dof numbering in q_index == qd_index
+  int q_rec[TDS_NL], qd_rec[TDS_NL];
+  int num_spherical;
+};
+
+// `ex`: m == &ex->m is an EXPANDED model; NULL: a plain fixed-base model of 1-dof joints.
 template <typename T>
-static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *why, const bool fl) {
+static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *why, const TdsExpanded *ex) {
   memset(d, 0, sizeof(*d));
   why[0] = 0;
+  const bool fl = ex != nullptr && m->is_floating != 0;
+  const int nsph = ex ? ex->num_spherical : 0;
 #define TDS_FAIL(code, msg)          \
   do {                               \
     strncpy(why, msg, 127);          \
@@ -99,8 +121,14 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   } while (0)
   if (m->abi_version != TDS_HIP_ABI_VERSION) TDS_FAIL(TDS_ERR_INVALID_ARG, "model abi_version mismatch");
   if (m->num_links < 1 || m->num_links > TDS_NL) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_links out of range");
-  if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd + (fl ? 1 : 0) || m->dof_q > TDS_ND)
-    TDS_FAIL(TDS_ERR_UNSUPPORTED, "dof out of range or dof_q != dof_qd (spherical joints unsupported)");
+  if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd + (fl ? 1 : 0) + nsph || m->dof_q > TDS_ND)
+    TDS_FAIL(TDS_ERR_UNSUPPORTED, "dof out of range (<= 32 velocities, <= 32 coordinates) or dof_q inconsistent with the joints");
+  if (nsph && m->step_mode != TDS_STEP_TAU)
+    TDS_FAIL(TDS_ERR_UNSUPPORTED, "spherical joints: only the direct-torque step (the PD block's spherical branch is not built)");
+  if (nsph && m->reward_mode != TDS_REWARD_NONE)
+    TDS_FAIL(TDS_ERR_UNSUPPORTED, "the Ant / Laikago reward rules read a 1-dof-joint state record");
+  d->num_spherical = nsph;
+  d->sph_damping = (T)pow(0.995, 1000.0 * m->dt);
   if (fl && m->reward_mode != TDS_REWARD_NONE)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "the Ant / Laikago reward rules read a fixed-base state record");
   d->is_floating = fl ? 1 : 0;
@@ -169,15 +197,18 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   for (int i = 0; i < m->num_links; ++i) {
     const tds_link_t &l = m->links[i];
     if (l.parent >= i || l.parent < -1) TDS_FAIL(TDS_ERR_INVALID_ARG, "links must be ordered parent-before-child");
-    if (l.joint_type == TDS_JOINT_SPHERICAL || l.joint_type < TDS_JOINT_FIXED || l.joint_type > TDS_JOINT_SPHERICAL)
-      TDS_FAIL(TDS_ERR_UNSUPPORTED, "spherical / unknown joint type (SURVEY 8f N4)");
+    const bool sph_lane = ex != nullptr && l.joint_type >= TDS_JOINT_SPH0 && l.joint_type <= TDS_JOINT_SPH2;
+    if (!sph_lane && (l.joint_type == TDS_JOINT_SPHERICAL || l.joint_type < TDS_JOINT_FIXED || l.joint_type > TDS_JOINT_SPHERICAL))
+      TDS_FAIL(TDS_ERR_UNSUPPORTED, "unknown joint type");
+    d->q_rec[i] = ex ? ex->q_rec[i] : (l.joint_type == TDS_JOINT_FIXED ? -1 : l.q_index);
+    d->qd_rec[i] = ex ? ex->qd_rec[i] : (l.joint_type == TDS_JOINT_FIXED ? -1 : l.qd_index);
     d->parent[i] = l.parent;
     d->level[i] = l.parent >= 0 ? d->level[l.parent] + 1 : 0;
     if (d->level[i] > max_level) max_level = d->level[i];
     d->joint_type[i] = l.joint_type;
     const bool fixed = l.joint_type == TDS_JOINT_FIXED;
     if (!fixed) {
-      if (fl) {  // internal numbering of the expanded model: checked by tds_expand_floating
+      if (ex) {  // internal numbering of the expanded model: checked by tds_expand_model
         if (l.qd_index < 0 || l.qd_index >= nd) TDS_FAIL(TDS_ERR_INVALID_ARG, "qd index out of range");
         d->dof_link[l.qd_index] = i;
         ++ndof;
@@ -207,6 +238,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->damping[i] = (T)l.damping;
   }
   if (ndof != nd) TDS_FAIL(TDS_ERR_INVALID_ARG, "dof_qd does not match the joints");
+  for (int dd = 0; dd < nd; ++dd) d->dof_rec[dd] = d->qd_rec[d->dof_link[dd]];
   {
     // TDS_HIP_NO_CHAIN=1 sends every parent/child hand-over through LDS (A/B testing of the two paths)
     const char *nc = getenv("TDS_HIP_NO_CHAIN");
@@ -239,10 +271,15 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
       };
       const bool ok = use_chain && !(nr && nr[0] == '1') && nroots == 1;
       int k = 0;  // first link of the root chain that is not (massless, single child, movable)
+      // (the first two lanes of a spherical joint may END the chain but never lie inside it: their
+      //  velocity-product acceleration is not the chain's prefix sum, see phase C of the kernels)
       while (ok && k < m->num_links - 1 && k < 5 && massless(k) && nchild[k] == 1 && m->links[k + 1].parent == k &&
-             m->links[k].joint_type != TDS_JOINT_FIXED)
+             m->links[k].joint_type != TDS_JOINT_FIXED && m->links[k].joint_type != TDS_JOINT_SPH0 &&
+             m->links[k].joint_type != TDS_JOINT_SPH1)
         ++k;
-      if (ok && k >= 1 && m->links[k].joint_type != TDS_JOINT_FIXED) d->root_last = k;
+      if (ok && k >= 1 && m->links[k].joint_type != TDS_JOINT_FIXED && m->links[k].joint_type != TDS_JOINT_SPH1 &&
+          m->links[k].joint_type != TDS_JOINT_SPH2)
+        d->root_last = k;
       if (fl) d->root_last = 5;  // the six pseudo links ARE the root joint (the kernels special-case their kinematics)
     }
   }
@@ -316,60 +353,112 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   return TDS_OK;
 }
 
-// Floating base -> the expanded fixed-layout model the builder above understands: six pseudo links in front
-// (dof nj+k, unit axes, link 5 carries mb.base_rbi()), the model's links shifted by 6 with the base as
-// link 5, joint dofs renumbered 0..nj-1.  Returns a malloc'ed model or NULL (why filled).
-static inline tds_model_t *tds_expand_floating(const tds_model_t *m, char *why) {
+// Floating base and / or spherical joints -> the expanded model the builder above understands:
+//   * floating base: six pseudo links in front (dof nj+k, unit axes, link 5 carries mb.base_rbi()), the model's
+//     links behind them with the base as link 5, joint dofs renumbered 0..nj-1;
+//   * spherical joint: three lanes SPH0 / SPH1 / SPH2 (the last one is the link: inertia, shapes, children).
+// Returns a malloc'ed TdsExpanded or NULL (why filled).
+static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
   why[0] = 0;
-  const int nj = m->dof_qd - 6;
-  if (m->num_links < 0 || m->num_links + 6 > TDS_MAX_LINKS || nj < 0 || m->dof_q != m->dof_qd + 1) {
-    strncpy(why, "floating base: needs num_links + 6 <= TDS_MAX_LINKS and dof_q == dof_qd + 1", 127);
-    return nullptr;
-  }
-  tds_model_t *e = (tds_model_t *)malloc(sizeof(tds_model_t));
+#define TDS_XFAIL(msg)       \
+  do {                       \
+    strncpy(why, msg, 127);  \
+    why[127] = 0;            \
+    free(e);                 \
+    return nullptr;          \
+  } while (0)
+  TdsExpanded *e = nullptr;
+  if (m->num_links < 0 || m->num_links > TDS_MAX_LINKS) TDS_XFAIL("num_links out of range");
+  const bool fl = m->is_floating != 0;
+  int nsph = 0;
+  for (int i = 0; i < m->num_links; ++i) nsph += m->links[i].joint_type == TDS_JOINT_SPHERICAL;
+  const int base = fl ? 6 : 0;
+  if (fl && nsph) TDS_XFAIL("floating base + spherical joints: the reference fills the base/joint block of M one way only (mass_matrix.hpp:80-84); not built");
+  if (m->num_links + base + 2 * nsph > TDS_MAX_LINKS) TDS_XFAIL("too many links (a floating base takes 6 lanes, a spherical joint 3)");
+  const int nj = m->dof_qd - base;
+  if (nj < 0 || m->dof_q != m->dof_qd + (fl ? 1 : 0) + nsph) TDS_XFAIL("dof_q / dof_qd inconsistent with the base and the joints");
+  e = (TdsExpanded *)malloc(sizeof(TdsExpanded));
   if (!e) return nullptr;
-  memcpy(e, m, sizeof(*e));
-  e->num_links = m->num_links + 6;
-  for (int k = 0; k < 6; ++k) {
-    tds_link_t &L = e->links[k];
+  memcpy(&e->m, m, sizeof(*m));
+  e->num_spherical = nsph;
+  for (int k = 0; k < TDS_NL; ++k) e->q_rec[k] = e->qd_rec[k] = -1;
+  for (int k = 0; k < base; ++k) {
+    tds_link_t &L = e->m.links[k];
     memset(&L, 0, sizeof(L));
     L.joint_type = k < 3 ? TDS_JOINT_REVOLUTE_X + k : TDS_JOINT_PRISMATIC_X + (k - 3);
     L.parent = k - 1;
     L.q_index = L.qd_index = nj + k;
     L.X_T_rot[0] = L.X_T_rot[4] = L.X_T_rot[8] = 1.0;
     L.S[k] = 1.0;
+    e->qd_rec[k] = k;
   }
-  e->links[5].mass = m->base_mass;
-  memcpy(e->links[5].com, m->base_com, sizeof(m->base_com));
-  memcpy(e->links[5].inertia, m->base_inertia, sizeof(m->base_inertia));
-  int ndof = 0;
+  if (fl) {
+    e->m.links[5].mass = m->base_mass;
+    memcpy(e->m.links[5].com, m->base_com, sizeof(m->base_com));
+    memcpy(e->m.links[5].inertia, m->base_inertia, sizeof(m->base_inertia));
+  }
+  int carrier[TDS_MAX_LINKS];  // expanded index of the lane that carries link i (inertia, shapes, children)
+  int nx = base, ndof = 0, nq_rec = fl ? 7 : 0, nqd_rec = base;
   for (int i = 0; i < m->num_links; ++i) {
-    tds_link_t &L = e->links[6 + i];
-    L = m->links[i];
-    if (L.parent >= i || L.parent < -1) {
-      free(e);
-      strncpy(why, "links must be ordered parent-before-child", 127);
-      return nullptr;
-    }
-    L.parent = L.parent < 0 ? 5 : L.parent + 6;
-    if (L.joint_type != TDS_JOINT_FIXED) {
-      // the reference numbers q from 7 and qd from 6 on a floating base (multi_body.hpp:324-349)
-      if (L.qd_index != 6 + ndof || L.q_index != 7 + ndof) {
-        free(e);
-        strncpy(why, "floating base: q/qd indices must be dense in link order from 7 / 6", 127);
-        return nullptr;
+    const tds_link_t &l = m->links[i];
+    if (l.parent >= i || l.parent < -1) TDS_XFAIL("links must be ordered parent-before-child");
+    const int par = l.parent < 0 ? (fl ? 5 : -1) : carrier[l.parent];
+    if (l.joint_type == TDS_JOINT_SPHERICAL) {
+      if (l.q_index != nq_rec || l.qd_index != nqd_rec) TDS_XFAIL("q/qd indices must be dense in link order");
+      if (l.stiffness != 0.0) TDS_XFAIL("spherical joint stiffness (axis-angle spring, forward_dynamics.hpp:70-74) is not built");
+      for (int k = 0; k < 3; ++k) {
+        tds_link_t &L = e->m.links[nx];
+        memset(&L, 0, sizeof(L));
+        L.joint_type = TDS_JOINT_SPH0 + k;
+        L.parent = k == 0 ? par : nx - 1;
+        L.q_index = L.qd_index = ndof++;
+        L.S[k] = 1.0;
+        L.damping = l.damping;
+        L.X_T_rot[0] = L.X_T_rot[4] = L.X_T_rot[8] = 1.0;
+        if (k == 0) {
+          memcpy(L.X_T_rot, l.X_T_rot, sizeof(L.X_T_rot));
+          memcpy(L.X_T_trans, l.X_T_trans, sizeof(L.X_T_trans));
+          e->q_rec[nx] = nq_rec;
+        }
+        if (k == 2) {
+          L.mass = l.mass;
+          memcpy(L.com, l.com, sizeof(L.com));
+          memcpy(L.inertia, l.inertia, sizeof(L.inertia));
+        }
+        e->qd_rec[nx] = nqd_rec + k;
+        ++nx;
       }
-      L.q_index = L.qd_index = ndof++;
+      carrier[i] = nx - 1;
+      nq_rec += 4;
+      nqd_rec += 3;
+    } else {
+      tds_link_t &L = e->m.links[nx];
+      L = l;
+      L.parent = par;
+      if (l.joint_type != TDS_JOINT_FIXED) {
+        // (the reference numbers q from 7 and qd from 6 on a floating base, multi_body.hpp:324-349)
+        if (l.q_index != nq_rec || l.qd_index != nqd_rec) TDS_XFAIL("q/qd indices must be dense in link order");
+        L.q_index = L.qd_index = ndof++;
+        e->q_rec[nx] = nq_rec++;
+        e->qd_rec[nx] = nqd_rec++;
+      }
+      carrier[i] = nx++;
     }
   }
-  if (ndof != nj) {
-    free(e);
-    strncpy(why, "dof_qd does not match the joints", 127);
-    return nullptr;
+  if (ndof != nj) TDS_XFAIL("dof_qd does not match the joints");
+  e->m.num_links = nx;
+  for (int g = 0; g < m->num_geoms && g < TDS_MAX_GEOMS; ++g) {
+    const int lk = m->geoms[g].link;
+    if (lk < -1 || lk >= m->num_links) TDS_XFAIL("geom link out of range");
+    e->m.geoms[g].link = lk < 0 ? (fl ? 5 : -1) : carrier[lk];
   }
-  for (int g = 0; g < m->num_geoms && g < TDS_MAX_GEOMS; ++g) e->geoms[g].link = m->geoms[g].link < 0 ? 5 : m->geoms[g].link + 6;
-  for (int v = 0; v < m->num_visuals && v < TDS_MAX_VISUALS; ++v) e->visuals[v].link = m->visuals[v].link + 6;
-  e->pd_start_link = m->pd_start_link + 6;
+  for (int v = 0; v < m->num_visuals && v < TDS_MAX_VISUALS; ++v) {
+    const int lk = m->visuals[v].link;
+    if (lk < 0 || lk >= m->num_links) TDS_XFAIL("visual link out of range");
+    e->m.visuals[v].link = carrier[lk];
+  }
+  e->m.pd_start_link = m->pd_start_link < m->num_links ? (m->pd_start_link <= 0 ? base : carrier[m->pd_start_link]) : nx;
+#undef TDS_XFAIL
   return e;
 }
 
@@ -380,10 +469,12 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
     strncpy(why, "model abi_version mismatch", 127);
     return TDS_ERR_INVALID_ARG;
   }
-  if (!m->is_floating) return tds_build_dev_model_impl<T>(m, d, why, false);
-  tds_model_t *e = tds_expand_floating(m, why);
+  bool general = m->is_floating != 0;
+  for (int i = 0; i < m->num_links && i < TDS_MAX_LINKS; ++i) general |= m->links[i].joint_type == TDS_JOINT_SPHERICAL;
+  if (!general) return tds_build_dev_model_impl<T>(m, d, why, nullptr);
+  TdsExpanded *e = tds_expand_model(m, why);
   if (!e) return TDS_ERR_UNSUPPORTED;
-  const int rc = tds_build_dev_model_impl<T>(e, d, why, true);
+  const int rc = tds_build_dev_model_impl<T>(&e->m, d, why, e);
   free(e);
   return rc;
 }

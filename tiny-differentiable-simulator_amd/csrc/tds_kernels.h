@@ -48,8 +48,9 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env);
 //   x_feedback (optional) [n_envs][input_dim]  receives the new q, qd (closed-loop stepping)
 //   obs_out    (optional) [n_envs][dof_q+dof_qd+2]  observation | reward | done
 //   ovf        [n_envs][ovrows][NDs+3] scratch slab for surplus constraint rows (NULL iff ovrows == 0)
-// (FL: floating-base kernels; explicit instantiations live in the kernel translation units)
-template <typename T, bool FL>
+// (KIND 0: plain fixed-base kernels, 1: floating base, 2: spherical joints; explicit instantiations live in the
+//  kernel translation units)
+template <typename T, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                          const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
                          hipStream_t stream, const TdsStepCtl &ctl, long long *prof);
@@ -58,18 +59,20 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
                            const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
                            hipStream_t stream, const TdsStepCtl &ctl,
                            long long *prof = nullptr) {  // prof: 14 phase stamps of workgroup 0 (diagnostic)
-  return h_model.is_floating ? tds_launch_step_impl<T, true>(d_model, h_model, L, lanes_per_env, x_in, y_out, actions,
-                                                             x_feedback, obs_out, ovf, n_envs, stream, ctl, prof)
-                             : tds_launch_step_impl<T, false>(d_model, h_model, L, lanes_per_env, x_in, y_out, actions,
-                                                              x_feedback, obs_out, ovf, n_envs, stream, ctl, prof);
+#define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof
+  if (h_model.is_floating) return tds_launch_step_impl<T, 1>(TDS_ARGS);
+  if (h_model.num_spherical) return tds_launch_step_impl<T, 2>(TDS_ARGS);
+  return tds_launch_step_impl<T, 0>(TDS_ARGS);
+#undef TDS_ARGS
 }
 
-template <typename T, bool FL>
+template <typename T, int KIND>
 int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes);
 template <typename T>
-inline int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes, bool floating) {
-  return floating ? tds_kernel_max_dynamic_lds_impl<T, true>(lanes_per_env, ndp, bytes)
-                  : tds_kernel_max_dynamic_lds_impl<T, false>(lanes_per_env, ndp, bytes);
+inline int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes, int kind) {
+  return kind == 1 ? tds_kernel_max_dynamic_lds_impl<T, 1>(lanes_per_env, ndp, bytes)
+         : kind == 2 ? tds_kernel_max_dynamic_lds_impl<T, 2>(lanes_per_env, ndp, bytes)
+                     : tds_kernel_max_dynamic_lds_impl<T, 0>(lanes_per_env, ndp, bytes);
 }
 
 int tds_padded_dof(int nd, int lanes_per_env = 0);

@@ -580,9 +580,10 @@ __device__ __forceinline__ double tds_uniform01(unsigned long long seed, unsigne
 // LOOP = false: exactly one normal step per launch, no reset -> straight-line code (the bench /
 // forward_zero path; no loop-carried live ranges).  LOOP = true: the general step loop (substeps,
 // auto / forced reset + settle steps) at the price of ~60 more live registers.
-// FL = floating base: a template parameter, not a model flag read at run time — as wave-uniform branches the
-// floating-base blocks cost the fixed-base kernels 5 % (measured: Ant x 4096, 23.3 vs 22.2 us per step).
-template <typename T, int G, int NDP, bool PROF, bool LOOP, bool FL>
+// KIND = 0: fixed base, 1-dof joints; 1: floating base; 2: spherical joints (fixed base).  A template parameter,
+// not a model flag read at run time — as wave-uniform branches the floating-base blocks cost the fixed-base
+// kernels 5 % (measured: Ant x 4096, 23.3 vs 22.2 us per step).
+template <typename T, int G, int NDP, bool PROF, bool LOOP, int KIND>
 __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const T *x_in, T *__restrict__ y_out,
                                                       const T *__restrict__ actions, T *x_feedback /* may alias x_in */,
@@ -613,12 +614,17 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // Floating base (DevModel::is_floating): lanes 0..5 are the base's pseudo links and the dofs are numbered
   // joints first, base last; the q / qd RECORD keeps the reference's order
   // q = [quat xyzw | pos | joints], qd = [omega | v | joints]  ->  record indices of this lane's coordinate
-  constexpr bool fl = FL;
+  // Spherical joints (DevModel::num_spherical): three lanes per joint, types TDS_JOINT_SPH0/1/2, one frame; the
+  // q record holds the joint's quaternion (4 coordinates) at q_rec of the first lane.
+  constexpr bool fl = KIND == 1;
+  constexpr bool sph = KIND == 2;
+  constexpr bool gen = KIND != 0;
   const int njd = mdl->nj;                       // joint dofs (== nd on a fixed base)
   const bool froot = fl && isl && li < 6;        // base pseudo link
-  const int qri = fl ? di + 7 : di;              // (not used by the pseudo links)
-  const int qdri = fl ? (di >= njd ? di - njd : di + 6) : di;
-  const int rec_d = fl ? (lane >= njd ? lane - njd : lane + 6) : lane;  // lane == dof role
+  const bool sph_lane = sph && jt >= TDS_JOINT_SPH0;
+  const int qri = gen ? (isl ? mdl->q_rec[lsafe] : -1) : di;    // (-1: this lane owns no coordinate)
+  const int qdri = gen ? (isl ? mdl->qd_rec[lsafe] : -1) : di;
+  const int rec_d = gen ? mdl->dof_rec[lane < nd ? lane : 0] : lane;  // lane == dof role
   // Serial chains (parent == lane - 1, the common case for URDF-derived trees) hand their sweep
   // state from lane to lane with DPP row shifts; only the other parent/child links go through the
   // per-link LDS records (see DESIGN.md "chain hand-over").
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
   }
   const bool do_reward = last_run || (pol && mode == TDS_MODE_RUN);
-  const T q = (di >= 0 && !froot) ? xr[qri] : T(0);
+  const T q = (di >= 0 && (!gen || (qri >= 0 && !sph_lane))) ? xr[gen ? (qri >= 0 ? qri : 0) : qri] : T(0);
   const T qd = di >= 0 ? xr[nq + qdri] : T(0);
 
   // ---- PD controller (locomotion_contact_simulation.h:168-258) or direct torque -------------
@@ -841,6 +847,18 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         RJ[3] = xy + wz; RJ[4] = T(1) - (xx + zz); RJ[5] = yz - wx;
         RJ[6] = xz - wy; RJ[7] = yz + wx; RJ[8] = T(1) - (xx + yy);
       }
+    }
+    if (sph && jt == TDS_JOINT_SPH0) {  // X_J.rotation = quat_to_matrix(q[0..3])  (link.hpp:262-266)
+      const int qb = qri >= 0 ? qri : 0;
+      const T qx = xr[qb], qy = xr[qb + 1], qz = xr[qb + 2], qw = xr[qb + 3];
+      const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+      const T xs = qx * s2, ys = qy * s2, zs = qz * s2;
+      const T wx = qw * xs, wy = qw * ys, wz = qw * zs;
+      const T xx = qx * xs, xy = qx * ys, xz = qx * zs;
+      const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
+      RJ[0] = T(1) - (yy + zz); RJ[1] = xy - wz; RJ[2] = xz + wy;
+      RJ[3] = xy + wz; RJ[4] = T(1) - (xx + zz); RJ[5] = yz - wx;
+      RJ[6] = xz - wy; RJ[7] = yz + wx; RJ[8] = T(1) - (xx + yy);
     }
     mat3_mul(RT, RJ, Rp);  // transform.hpp:123-131
     T r[3];
@@ -1044,6 +1062,36 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         v[k] = vq[k] + vJ[k];
       }
       bias_accel();
+      if (sph && jt >= TDS_JOINT_SPH1) {
+        // the three lanes of a spherical joint are ONE joint: c = v x vJ with vJ = S_3d qd (kinematics.hpp:96-97),
+        // i.e. over the three lanes  v_parent x (vJ_0 + vJ_1 + vJ_2).  As a chain the lanes would add
+        // vJ_0 x vJ_1 + (vJ_0 + vJ_1) x vJ_2 on top: take the earlier lanes' joint velocities (same frame:
+        // axis j = column j of R about the frame origin) out of v before the cross product
+        T vb[6] = {v[0], v[1], v[2], v[3], v[4], v[5]};
+        const int nprev = jt - TDS_JOINT_SPH0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (j < nprev) {
+            const T qj = xr[nq + qdri - nprev + j];
+            const T ax[3] = {R[j] * qj, R[3 + j] * qj, R[6 + j] * qj};
+            T c[3];
+            cross3(p, ax, c);
+            vb[0] -= ax[0];
+            vb[1] -= ax[1];
+            vb[2] -= ax[2];
+            vb[3] -= c[0];
+            vb[4] -= c[1];
+            vb[5] -= c[2];
+          }
+        }
+        cross3(vb, vJ, cb);
+        T c1[3], c2[3];
+        cross3(vb, vJ + 3, c1);
+        cross3(vb + 3, vJ, c2);
+        cb[3] = c1[0] + c2[0];
+        cb[4] = c1[1] + c2[1];
+        cb[5] = c1[2] + c2[2];
+      }
 #pragma unroll
       for (int k = 0; k < 6; ++k) a0[k] = aq[k] + cb[k];
       if (lds_children) {  // children other than lane + 1 read my record
@@ -1721,9 +1769,34 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     if (li < 4) xr[li] = li == 0 ? n0 : li == 1 ? n1 : li == 2 ? n2 : n3;
     if (li >= 3) xr[4 + li - 3] = pos_new;
   }
+  if (sph_lane) {
+    // spherical joint (integrator.hpp:94-123): qd *= pow(joint_damping, 1000 dt), then
+    // quat += quat_velocity_spherical(quat, qd, dt) (tiny_algebra.hpp:618-629), normalised — by the first lane
+    const T damp = mdl->sph_damping;
+    qd_new *= damp;
+    if (jt == TDS_JOINT_SPH0) {
+      const T *const qdv = E + L.dinv + 2 * NDP;  // velocities in dof order (phase F)
+      const T h = T(0.5) * dt;
+      const T w0 = qd_new, w1 = qdv[di + 1] * damp, w2 = qdv[di + 2] * damp;
+      const T b0 = xr[qri], b1 = xr[qri + 1], b2 = xr[qri + 2], b3 = xr[qri + 3];
+      T n0 = b0 + (b3 * w0 + b1 * w2 - b2 * w1) * h;
+      T n1 = b1 + (b3 * w1 + b2 * w0 - b0 * w2) * h;
+      T n2 = b2 + (b3 * w2 + b0 * w1 - b1 * w0) * h;
+      T n3 = b3 + (-b0 * w0 - b1 * w1 - b2 * w2) * h;
+      const T ql = sqrt_t<T>(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+      xr[qri] = n0 / ql;
+      xr[qri + 1] = n1 / ql;
+      xr[qri + 2] = n2 / ql;
+      xr[qri + 3] = n3 / ql;
+    }
+  }
   if (di == 0) xr[in_dim] = q;
   if (di >= 0) {
-    if (!froot) xr[qri] = q_new;
+    if (!gen) {
+      xr[qri] = q_new;
+    } else if (qri >= 0 && !sph_lane) {
+      xr[qri] = q_new;
+    }
     xr[nq + qdri] = qd_new;
   }
   TDS_WAVE_SYNC();
@@ -1731,7 +1804,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // ---- y record (q, qd, up, zero padding; the visual poses went out in M1) of the last normal step
   if (last_run) {
     T *const yo = y_out + (size_t)env * out_dim;
-    if (fl) {  // the record has one more q than lanes carry coordinates: copy it out as it is
+    if (gen) {  // the q record is not one coordinate per lane: copy it out as it is
       for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((T)(xr[i]), &yo[i]);
     } else if (di >= 0) {
       __builtin_nontemporal_store((T)(q_new), &yo[di]);
@@ -1785,7 +1858,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     // straight-line build: exactly one normal step, no reset -> the environment is finished here;
     // observation (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288) and resident state go
     // out straight from registers
-    if (live && fl) {
+    if (live && gen) {
       for (int i = lane; i < nq + nd; i += G) {
         if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? T(0) : xr[i];
         if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = xr[i];
@@ -1876,7 +1949,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 // padded dof count = template parameter NDP of the kernel.  Besides the coarse widths (8/16/24/32) the
 // widths of the two benchmark robots are instantiated exactly for their natural lane count
 // (Ant: 14 dof on 16 lanes, Laikago: 18 dof on 32 lanes): LDL^T and the row solves scale with NDP^2.
-#if !defined(TDS_ONLY_F32) && !defined(TDS_ONLY_FLOATING)
+#if !defined(TDS_ONLY_F32) && (!defined(TDS_ONLY_KIND) || TDS_ONLY_KIND == 0)
 int tds_padded_dof(int nd, int lanes) {
   if (lanes == 16 && nd > 8 && nd <= 14) return 14;
   if (lanes == 32 && nd > 16 && nd <= 18) return 18;
@@ -1933,7 +2006,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
   return L;
 }
 
-template <typename T, bool FL>
+template <typename T, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                          const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
                          hipStream_t stream, const TdsStepCtl &ctl, long long *prof) {
@@ -1944,16 +2017,16 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \
     if (prof)                                                                                                \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, true, false, false>), dim3(blocks), dim3(64), shmem, stream, \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, true, false, 0>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else if (simple)                                                                                         \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, false, FL>), dim3(blocks), dim3(64), shmem, stream, \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, false, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else                                                                                                     \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, true, FL>), dim3(blocks), dim3(64), shmem, stream, \
+      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, true, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
   } while (0)
-  if (prof && FL) return -2;  // the phase-stamp build exists for fixed-base models only
+  if (prof && KIND != 0) return -2;  // the phase-stamp build exists for the plain kernels only
   // straight-line kernel when the launch is exactly one normal step without any reset
   const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
   const int key = lanes_per_env * 100 + L.NDP;
@@ -1979,18 +2052,18 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   return (int)hipGetLastError();
 }
 
-template <typename T, bool FL>
+template <typename T, int KIND>
 int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   hipError_t e = hipSuccess;
 #define TDS_ATTR(GG, NN)                                                                                        \
   do {                                                                                                          \
-    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, false, FL>,                         \
+    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, false, KIND>,                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                 \
     if (e == hipSuccess)                                                                                        \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, true, FL>,                        \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, true, KIND>,                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
-    if (e == hipSuccess && !FL)                                                                                 \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, true, false, false>,                     \
+    if (e == hipSuccess && KIND == 0)                                                                               \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, true, false, 0>,                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
@@ -2014,29 +2087,39 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   return (int)e;
 }
 
-// The file is compiled four times (csrc/Makefile): -DTDS_ONLY_F64 / -DTDS_ONLY_F32 pick the compute dtype,
-// -DTDS_ONLY_FIXED / -DTDS_ONLY_FLOATING the base kind, so that the four quarters of the kernel set build in
-// parallel.  (tds_make_lds_layout and tds_padded_dof live in the fixed-base units.)
-#define TDS_INSTANTIATE(TT, FLV)                                                                                       \
-  template int tds_launch_step_impl<TT, FLV>(const DevModel<TT> *, const DevModel<TT> &, const TdsLds &, int, const TT *, \
-                                             TT *, const TT *, TT *, TT *, TT *, int, hipStream_t, const TdsStepCtl &, \
-                                             long long *);                                                             \
-  template int tds_kernel_max_dynamic_lds_impl<TT, FLV>(int, int, int);
-#if !defined(TDS_ONLY_F32)
-#if !defined(TDS_ONLY_FLOATING)
-template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int);
-TDS_INSTANTIATE(double, false)
+// The file is compiled six times (csrc/Makefile): -DTDS_ONLY_F64 / -DTDS_ONLY_F32 pick the compute dtype,
+// -DTDS_ONLY_KIND=0/1/2 the kernel kind (plain / floating base / spherical joints), so that the parts of the
+// kernel set build in parallel.  (tds_make_lds_layout and tds_padded_dof live in the KIND 0 units.)
+#define TDS_INSTANTIATE(TT, KV)                                                                                        \
+  template int tds_launch_step_impl<TT, KV>(const DevModel<TT> *, const DevModel<TT> &, const TdsLds &, int, const TT *, \
+                                            TT *, const TT *, TT *, TT *, TT *, int, hipStream_t, const TdsStepCtl &,  \
+                                            long long *);                                                              \
+  template int tds_kernel_max_dynamic_lds_impl<TT, KV>(int, int, int);
+#if !defined(TDS_ONLY_KIND)
+#define TDS_ALL_KINDS 1
+#define TDS_ONLY_KIND -1
 #endif
-#if !defined(TDS_ONLY_FIXED)
-TDS_INSTANTIATE(double, true)
+#if !defined(TDS_ONLY_F32)
+#if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
+template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int);
+TDS_INSTANTIATE(double, 0)
+#endif
+#if TDS_ONLY_KIND == 1 || defined(TDS_ALL_KINDS)
+TDS_INSTANTIATE(double, 1)
+#endif
+#if TDS_ONLY_KIND == 2 || defined(TDS_ALL_KINDS)
+TDS_INSTANTIATE(double, 2)
 #endif
 #endif
 #if !defined(TDS_ONLY_F64)
-#if !defined(TDS_ONLY_FLOATING)
+#if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
 template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int, int);
-TDS_INSTANTIATE(float, false)
+TDS_INSTANTIATE(float, 0)
 #endif
-#if !defined(TDS_ONLY_FIXED)
-TDS_INSTANTIATE(float, true)
+#if TDS_ONLY_KIND == 1 || defined(TDS_ALL_KINDS)
+TDS_INSTANTIATE(float, 1)
+#endif
+#if TDS_ONLY_KIND == 2 || defined(TDS_ALL_KINDS)
+TDS_INSTANTIATE(float, 2)
 #endif
 #endif
