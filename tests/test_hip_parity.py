@@ -67,7 +67,7 @@ def test_golden_rollout_per_step(name, built):
 
 
 @pytest.mark.parametrize("name", ["ant", "laikago_soft", "pendulum5_plane", "ant_floating", "laikago_floating",
-                                  "laikago_floating_env"])
+                                  "laikago_floating_env", "sphere_spherical", "humanoid_spherical"])
 def test_closed_loop_matches_oracle(name, built):
     """device-resident closed loop (tds_hip_step) vs the oracle stepping on the host."""
     torch = _torch()
@@ -308,7 +308,8 @@ def _host_reset(m, x_row, seed, env, count):
     return x[:nq + nd]
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago", "laikago_floating_env", "ant_floating"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "laikago_floating_env", "ant_floating", "humanoid_spherical",
+                                  "pendulum5_spherical"])
 def test_substeps_in_kernel_equal_repeated_steps(name, built):
     torch = _torch()
     m = tds_amd.load_model(name)
@@ -502,7 +503,8 @@ def test_rollout_equals_stepwise_launches_with_auto_reset(built):
     assert rel_err(sim2.x.cpu().numpy()[:, :od], x_fin[:, :od], 1e-3) < 1e-7
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago", "pendulum5_plane", "ant_floating", "laikago_floating_env"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "pendulum5_plane", "ant_floating", "laikago_floating_env",
+                                  "sphere_spherical", "humanoid_spherical"])
 @pytest.mark.parametrize("var", ["TDS_HIP_NO_ROOTJOINT", "TDS_HIP_NO_CHAIN"])
 def test_general_tree_paths_still_match(name, var, built):
     """the root-joint / chain hand-over shortcuts are optimisations of the general tree sweeps: with them
@@ -563,8 +565,16 @@ def test_error_paths_and_edge_sizes(built):
     assert L.tds_hip_create(C.byref(m), 8, 0, 7, C.byref(h)) != 0 and not h.value          # unknown dtype
     bad = m.copy()
     bad.is_floating = 1
-    assert L.tds_hip_create(C.byref(bad), 8, 0, 0, C.byref(h)) != 0 and not h.value        # floating base: N4
-    assert b"floating" in L.tds_hip_last_error()
+    assert L.tds_hip_create(C.byref(bad), 8, 0, 0, C.byref(h)) != 0 and not h.value        # floating flag on a fixed-base record
+    assert b"inconsistent" in L.tds_hip_last_error()
+    bad = tds_amd.load_model("ant_floating")
+    bad.links[0].joint_type = tds_amd.model.JOINT_SPHERICAL
+    assert L.tds_hip_create(C.byref(bad), 8, 0, 0, C.byref(h)) != 0 and not h.value        # floating base + spherical joint
+    assert b"spherical" in L.tds_hip_last_error()
+    bad = tds_amd.load_model("pendulum5_spherical")
+    bad.links[2].stiffness = 1.0
+    assert L.tds_hip_create(C.byref(bad), 8, 0, 0, C.byref(h)) != 0 and not h.value        # axis-angle spring of a spherical joint
+    assert b"stiffness" in L.tds_hip_last_error()
     g = np.load(os.path.join(GOLDEN, "ant.npz"))
     sim = hip_backend.HipSim(m, 5)
     x = np.ascontiguousarray(g["x"][:7])

@@ -24,7 +24,7 @@ def _rot(rng):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
-def random_tree_model(seed, floating=False):
+def random_tree_model(seed, floating=False, spherical=False):
     """floating: the tree hangs off a floating base (random inertia, own collision shapes); links may attach
     to the base directly (parent -1) anywhere in the list, as in the reference's ant_org.urdf"""
     rng = np.random.default_rng(seed)
@@ -36,6 +36,10 @@ def random_tree_model(seed, floating=False):
     n_virtual = min(n_virtual, nl - 2)
     if floating:
         nl, n_virtual = int(rng.integers(1, 21)), 0
+    if spherical:       # (a spherical joint takes three lanes and four coordinates)
+        nl = int(rng.integers(2, 12))
+        n_virtual = min(n_virtual, 3, nl - 1)
+    nq_used = 0
     style = rng.integers(0, 3)           # 0: serial chain, 1: DFS-ordered tree, 2: arbitrary parents
     ndof = 0
     # a 6-dof virtual chain must span the motion space: prismatic x, y, z then revolute x, y, z (as URDF loaders build it)
@@ -54,6 +58,8 @@ def random_tree_model(seed, floating=False):
             jt = virt[i]
         else:
             jt = int(rng.integers(0, 8)) if (rng.random() < 0.9 or i == n_virtual) else M.JOINT_FIXED
+            if spherical and (rng.random() < 0.4 or i == n_virtual) and nq_used + 4 <= 30:
+                jt = M.JOINT_SPHERICAL
         l.joint_type = jt
         S = np.zeros(6)
         if jt in (M.JOINT_PRISMATIC_X, M.JOINT_PRISMATIC_Y, M.JOINT_PRISMATIC_Z):
@@ -66,9 +72,14 @@ def random_tree_model(seed, floating=False):
             S[:3] = rng.normal(size=3) * 0.9          # unnormalised on purpose
         for k in range(6):
             l.S[k] = S[k]
-        if jt != M.JOINT_FIXED:
-            l.q_index = ndof + (7 if floating else 0)   # multi_body.hpp:324-349
+        if jt == M.JOINT_SPHERICAL:
+            l.q_index, l.qd_index = nq_used, ndof
+            nq_used += 4
+            ndof += 3
+        elif jt != M.JOINT_FIXED:
+            l.q_index = (nq_used if spherical else ndof) + (7 if floating else 0)   # multi_body.hpp:324-349
             l.qd_index = ndof + (6 if floating else 0)
+            nq_used += 1
             ndof += 1
         else:
             l.q_index = l.qd_index = -1
@@ -87,10 +98,12 @@ def random_tree_model(seed, floating=False):
             c = rng.uniform(-0.1, 0.1, 3)
             for k in range(3):
                 l.com[k] = c[k]
-        l.stiffness = float(rng.uniform(0, 2)) if rng.random() < 0.2 else 0.0
+        l.stiffness = float(rng.uniform(0, 2)) if (rng.random() < 0.2 and jt != M.JOINT_SPHERICAL) else 0.0
         l.damping = float(rng.uniform(0, 0.5)) if rng.random() < 0.2 else 0.0
     m.num_links = nl
     m.dof_q = m.dof_qd = m.action_dim = ndof
+    if spherical:
+        m.dof_q = nq_used
     if floating:
         m.is_floating = 1
         m.dof_q, m.dof_qd = ndof + 7, ndof + 6
@@ -204,6 +217,46 @@ def test_random_floating_tree_against_oracle(seed, built):
           f"lanes {sim.kernel_info()['lanes_per_env']}: max rel err {err:.2e}")
     assert err < 1e-6
     # several steps inside one launch (the step-loop build) == the same steps one launch at a time
+    xd = torch.from_numpy(x).cuda()
+    sim.x.copy_(xd)
+    for _ in range(3):
+        sim.step(None)
+    y1 = sim.y.clone()
+    sim.x.copy_(xd)
+    sim.step(None, 3)
+    assert rel_err(sim.y.cpu().numpy(), y1.cpu().numpy()) < 1e-9
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_spherical_tree_against_oracle(seed, built):
+    """spherical joints mixed with 1-dof and fixed joints in random trees, with and without a
+    massless virtual root chain in front"""
+    import torch
+    m, n_virtual, style = random_tree_model(900 + seed, spherical=True)
+    sph = [i for i in range(m.num_links) if m.links[i].joint_type == M.JOINT_SPHERICAL]
+    rng = np.random.default_rng(3000 + seed)
+    n, nq, nd = 24, m.dof_q, m.dof_qd
+    x = np.zeros((n, m.input_dim))
+    x[:, :nq] = rng.uniform(-0.6, 0.6, (n, nq))
+    if n_virtual >= 3:
+        x[:, 2] = rng.uniform(0.0, 0.4, n)
+    for i in sph:
+        quat = rng.normal(size=(n, 4))
+        x[:, m.links[i].q_index:m.links[i].q_index + 4] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+    x[:, nq + nd:] = rng.uniform(-1, 1, (n, nd))
+    try:
+        y_ref = oraclelib.step(m, x)
+    except RuntimeError:
+        pytest.skip("degenerate random model (joint-space inertia not positive definite)")
+    if not np.isfinite(y_ref).all() or np.abs(y_ref).max() > 1e6:
+        pytest.skip("degenerate random model (singular joint-space inertia)")
+    sim = hip_backend.HipSim(m, n)
+    y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = rel_err(y, y_ref)
+    print(f"seed {seed}: {m.num_links} links ({len(sph)} spherical, {n_virtual} virtual, style {style}), {nd} dof, "
+          f"{m.num_contacts} contact points, lanes {sim.kernel_info()['lanes_per_env']}: max rel err {err:.2e}")
+    assert err < 1e-6
     xd = torch.from_numpy(x).cuda()
     sim.x.copy_(xd)
     for _ in range(3):
