@@ -109,8 +109,8 @@ enum { TDS_DTYPE_F64 = 0, TDS_DTYPE_F32 = 1 };
 typedef struct tds_link {
   int32_t joint_type; /* TDS_JOINT_* */
   int32_t parent;     /* parent link index, -1 = base */
-  int32_t q_index;    /* index into q,  -2 for fixed joints (multi_body.hpp:324-349) */
-  int32_t qd_index;   /* index into qd, -2 for fixed joints */
+  int32_t q_index;    /* index into q,  -2 for fixed joints (multi_body.hpp:324-349); a spherical joint owns 4 */
+  int32_t qd_index;   /* index into qd, -2 for fixed joints; a spherical joint owns 3 */
   double X_T_rot[9];  /* parent link -> joint frame (link.hpp:39) */
   double X_T_trans[3];
   double S[6];        /* motion subspace [angular | linear], NOT normalised (link.hpp:125-193) */
