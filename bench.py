@@ -195,7 +195,12 @@ def main():
     # synthetic inputs: reset-like states, seed 3 (+rank), settle, fresh actions/step
     rng = np.random.default_rng(3 + rank)
     x0 = np.zeros((n, m.input_dim))
-    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
+    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and nq != nd:
+        # floating base / spherical root joint (humanoid): the env's own reset distribution
+        x0[:, :nq] = np.array([m.reset_q[i] for i in range(nq)]) + \
+            np.array([m.reset_noise[i] for i in range(nq)]) * rng.uniform(-1, 1, (n, nq))
+        x0[:, -3:] = [100, 2, 50]
+    elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
         ip = np.array([m.initial_poses[i] for i in range(adim)])
         x0[:, 2] = 0.48
         x0[:, 6:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, nq - 6))

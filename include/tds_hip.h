@@ -37,13 +37,15 @@ extern "C" {
 
 #define TDS_HIP_ABI_VERSION 2
 
-#define TDS_MAX_LINKS 32
+#define TDS_MAX_LINKS 64   /* links of the model as the reference builds it; the kernels take <= 32 lanes: one per
+                              moving link (fixed links are folded into their parents when lanes run short), six for
+                              a floating base, three per spherical joint */
 #define TDS_MAX_GEOMS 32
-#define TDS_MAX_VISUALS 32
+#define TDS_MAX_VISUALS 64
 #define TDS_MAX_ACTIONS 32
 #define TDS_MAX_DOF 32
 /* contact points per environment: sphere 1, capsule 2, box 8 (contact_point.hpp:96-198) */
-#define TDS_MAX_CONTACTS 32
+#define TDS_MAX_CONTACTS 64
 
 /* status codes returned by every tds_hip_* function */
 enum {

@@ -177,7 +177,11 @@ int flatten_locomotion_env(Sim &sim, tds_model_t *out, int reward_mode = TDS_REW
   // initial_poses + 0.05 * U(-1,1), 10 settle steps
   if (!sim.mb_->is_floating() && out->dof_q <= TDS_MAX_DOF) {
     for (int k = 0; k < 3; ++k) out->reset_q[k] = Algebra::to_double(sim.m_start_base_position[k]);
-    const int qoffset = 6;
+    // xyz + xyz-rotation base: six scalars, rotation zero; xyz + spherical base (HumanoidEnv, base_dof_ = 7,
+    // humanoid_environment.h:100-111): identity quaternion (0, 0, 0, 1), joints from coordinate 7
+    const bool spherical_base = sim.mb_->num_links() > 3 && (*sim.mb_)[3].joint_type == tds::JOINT_SPHERICAL;
+    if (spherical_base) out->reset_q[6] = 1.0;
+    const int qoffset = spherical_base ? 7 : 6;
     for (size_t j = 0; j < sim.initial_poses_.size() && qoffset + (int)j < out->dof_q; ++j) {
       out->reset_q[qoffset + j] = Algebra::to_double(sim.initial_poses_[j]);
       out->reset_noise[qoffset + j] = 0.05;

@@ -45,6 +45,9 @@ MODELS = {
     "pendulum5_spherical": dict(ref="pendulum5spherical.urdf", dt=1e-3),                          # 5 spherical links in a chain
     "sphere_spherical": dict(ref="sphere_small_xyzspherical.urdf+plane", dt=2e-3),                  # xyz prismatic + spherical
     "humanoid_spherical": dict(ref="humanoid_partial_xyz_spherical_fixed.urdf+plane", dt=1e-3),     # + fixed children, 4 shapes
+    # HumanoidEnv (humanoid_environment.h): the env step on 37 links (12 of them fixed -> folded into their parents
+    # on the device), xyz + spherical root joint, 21 PD-controlled joints, 27 dof
+    "humanoid": dict(ref="humanoid"),
 }
 
 
@@ -89,6 +92,15 @@ def random_inputs(name, m, n, rng):
         x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
         x[:, nq + nd:nq + nd + m.action_dim] = rng.uniform(-0.6, 0.6, (n, m.action_dim))
         x[:, -3:] = [100, 2, 50]
+    elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and _spherical_links(m):
+        x[:, 0:2] = rng.uniform(-1, 1, (n, 2))
+        x[:, 2] = rng.uniform(0.7, 1.5, n)       # torso height: standing ... lying on the plane
+        _set_spherical_quats(m, x, rng, 0.6)
+        ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
+        x[:, 7:nq] = ip + rng.uniform(-0.5, 0.5, (n, nq - 7))
+        x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+        x[:, nq + nd:nq + nd + m.action_dim] = rng.uniform(-0.6, 0.6, (n, m.action_dim))
+        x[:, -3:] = [100, 2, 50]
     elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
         x[:, 0:2] = rng.uniform(-1, 1, (n, 2))
         x[:, 2] = rng.uniform(0.15, 0.6, n)
@@ -130,6 +142,12 @@ def rollout_start(name, m, rng):
         ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
         x[3] = 1.0
         x[6] = 0.48
+        x[7:nq] = ip + 0.05 * rng.uniform(-1, 1, nq - 7)
+        x[-3:] = [100, 2, 50]
+    elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and _spherical_links(m):
+        ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
+        x[2] = 1.3
+        x[6] = 1.0
         x[7:nq] = ip + 0.05 * rng.uniform(-1, 1, nq - 7)
         x[-3:] = [100, 2, 50]
     elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:

@@ -25,6 +25,7 @@ typedef TinyAlgebra<double, ::TINY::DoubleUtils> Alg;
 
 #include "ant_environment2.h"
 #include "laikago_environment2.h"
+#include "humanoid_environment.h"
 #include "dynamics/mass_matrix.hpp"
 #include "dynamics/jacobian.hpp"
 #include "../ars/ars_vectorized_environment.h"
@@ -54,6 +55,8 @@ struct RefSim {
   // the env step on a FLOATING-base robot: LaikagoContactSimulation constructed with floating = true on
   // laikago/laikago_toes_zup.urdf (the constructor the reference offers, laikago_environment2.h:36-41)
   LaikagoContactSimulation<Alg> *lfloat = nullptr;
+  // HumanoidEnv (humanoid_environment.h:212-232): xyz base + spherical joints, PD with the spherical branch
+  HumanoidEnv<Alg> *humanoid = nullptr;
   // generic model (URDF file from the reference data dir, optional plane)
   UrdfCache<Alg> cache;
   World<Alg> *gworld = nullptr;
@@ -65,18 +68,21 @@ struct RefSim {
     if (ant) return ant->contact_sim.world;
     if (laikago) return laikago->contact_sim.world;
     if (lfloat) return lfloat->world;
+    if (humanoid) return humanoid->contact_sim.world;
     return *gworld;
   }
   MultiBody<Alg> *mb() {
     if (ant) return ant->contact_sim.mb_;
     if (laikago) return laikago->contact_sim.mb_;
     if (lfloat) return lfloat->mb_;
+    if (humanoid) return humanoid->contact_sim.mb_;
     return gmb;
   }
   LocoSim *loco() {
     if (ant) return &ant->contact_sim;
     if (laikago) return &laikago->contact_sim;
     if (lfloat) return lfloat;
+    if (humanoid) return &humanoid->contact_sim;
     return nullptr;
   }
   bool has_plane() { return loco() ? true : g_plane; }
@@ -148,6 +154,8 @@ void *tdsref_create(const char *name_c, const char *reference_root) {
     s->ant = new AntEnv2<Alg>(false);
   } else if (name == "laikago") {
     s->laikago = new LaikagoEnv<Alg>(false);
+  } else if (name == "humanoid") {
+    s->humanoid = new HumanoidEnv<Alg>(false);
   } else if (name == "laikago_floating_env") {
     // urdf_from_file = true: FileUtils::find_file looks under ./data of the working directory
     char cwd[4096];
@@ -188,6 +196,7 @@ void tdsref_destroy(void *h) {
   delete s->ant;
   delete s->laikago;
   delete s->lfloat;
+  delete s->humanoid;
   delete s->gworld;
   delete s;
 }
@@ -227,6 +236,8 @@ int tdsref_flatten(void *h, tds_model_t *out) {
     rc = tds_hip::flatten_locomotion_env<Alg>(s->laikago->contact_sim, out, TDS_REWARD_LAIKAGO);
   } else if (s->lfloat) {
     rc = tds_hip::flatten_locomotion_env<Alg>(*s->lfloat, out, TDS_REWARD_NONE);
+  } else if (s->humanoid) {
+    rc = tds_hip::flatten_locomotion_env<Alg>(s->humanoid->contact_sim, out, TDS_REWARD_NONE);
   } else {
     memset(out, 0, sizeof(*out));
     out->abi_version = TDS_HIP_ABI_VERSION;

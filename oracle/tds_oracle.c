@@ -892,7 +892,12 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
   /* floating base + spherical joints: the reference writes the base/joint block of M only one way round
      (mass_matrix.hpp:80-84) — not restated */
   if (m->is_floating && nsph) return -2;
-  if (nsph && m->step_mode != TDS_STEP_TAU) return -2; /* the PD block's spherical branch is unused by the configs */
+  /* env step: the PD loop starts at link pd_start_link (base_dof_); its spherical branch
+     (locomotion_contact_simulation.h:188-226) is not restated — spherical joints must lie in front of it
+     (HumanoidEnv: base_dof_ = 7, the spherical root joint is link 3) */
+  if (m->step_mode != TDS_STEP_TAU)
+    for (int i = m->pd_start_link > 0 ? m->pd_start_link : 0; i < m->num_links; ++i)
+      if (m->links[i].joint_type == TDS_JOINT_SPHERICAL) return -2;
   if (m->has_plane) {
     int nc = 0;
     for (int g = 0; g < m->num_geoms; ++g)

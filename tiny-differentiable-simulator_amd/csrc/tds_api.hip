@@ -193,13 +193,9 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   s->dtype = dtype;
   s->elem = dtype == TDS_DTYPE_F64 ? 8 : 4;
   // (a floating base takes six more lanes: its pseudo links, tds_device_model.h)
-  int nlanes = model->num_links + (model->is_floating ? 6 : 0);  // + 2 per spherical joint (three lanes)
-  for (int i = 0; i < model->num_links; ++i) nlanes += model->links[i].joint_type == TDS_JOINT_SPHERICAL ? 2 : 0;
-  s->lanes = default_lanes_per_env(nlanes, model->dof_qd);
   char why[128];
   size_t msize;
   const void *hsrc;
-  const int epw = 64 / s->lanes;
   if (dtype == TDS_DTYPE_F64) {
     tds_build_dev_model<double>(model, &s->h64, why);
     msize = sizeof(DevModel<double>);
@@ -209,6 +205,10 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     msize = sizeof(DevModel<float>);
     hsrc = &s->h32;
   }
+  // lanes per environment: the device model's link count (pseudo links of a floating base / of spherical joints
+  // included, folded fixed links excluded) and the padded dof count
+  s->lanes = default_lanes_per_env(dtype == TDS_DTYPE_F64 ? s->h64.num_links : s->h32.num_links, model->dof_qd);
+  const int epw = 64 / s->lanes;
   auto layout = [&](int cap) {
     return dtype == TDS_DTYPE_F64 ? tds_make_lds_layout<double>(s->h64, cap, s->lanes)
                                   : tds_make_lds_layout<float>(s->h32, cap, s->lanes);

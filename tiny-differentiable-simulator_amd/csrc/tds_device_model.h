@@ -16,10 +16,10 @@
 
 #include "tds_hip.h"
 
-#define TDS_NL TDS_MAX_LINKS           // 32
+#define TDS_NL 32                      // lanes of links the kernels take (<= TDS_MAX_LINKS of the blob)
 #define TDS_ND 32                      // max dof
-#define TDS_NCP TDS_MAX_CONTACTS       // 32 contact points
-#define TDS_NV TDS_MAX_VISUALS         // 32
+#define TDS_NCP TDS_MAX_CONTACTS       // 64 contact points
+#define TDS_NV TDS_MAX_VISUALS         // 64
 #define TDS_NPAIR (TDS_NL * 12)        // (link, strict ancestor) pairs
 // internal joint types of the expanded model (never in a tds_model_t handed in by a caller)
 #define TDS_JOINT_SPH0 9   // first lane of a spherical joint: X_J = quat_to_matrix(q[0..3]), axis x
@@ -103,6 +103,7 @@ static inline void tds_plane_space(const double *n, double *p, double *q) {
 struct TdsExpanded {
   tds_model_t m;        // links incl. pseudo links, internal dof numbering in q_index == qd_index
   int q_rec[TDS_NL], qd_rec[TDS_NL];
+  int pd_on[TDS_NL];    // the PD loop of the env step visits this link (locomotion_contact_simulation.h:180-181)
   int num_spherical;
 };
 
@@ -123,8 +124,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   if (m->num_links < 1 || m->num_links > TDS_NL) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_links out of range");
   if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd + (fl ? 1 : 0) + nsph || m->dof_q > TDS_ND)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "dof out of range (<= 32 velocities, <= 32 coordinates) or dof_q inconsistent with the joints");
-  if (nsph && m->step_mode != TDS_STEP_TAU)
-    TDS_FAIL(TDS_ERR_UNSUPPORTED, "spherical joints: only the direct-torque step (the PD block's spherical branch is not built)");
+  // (env step with spherical joints: fine as long as the PD loop does not visit them — checked with pd_on below)
   if (nsph && m->reward_mode != TDS_REWARD_NONE)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "the Ant / Laikago reward rules read a 1-dof-joint state record");
   d->num_spherical = nsph;
@@ -222,7 +222,10 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->anc_dofs[i] = (l.parent >= 0 ? d->anc_dofs[l.parent] : 0u) | (fixed ? 0u : (1u << l.qd_index));
     anc_links[i] = (l.parent >= 0 ? anc_links[l.parent] | (1u << l.parent) : 0u);
     d->act_index[i] = -1;
-    if (m->step_mode == TDS_STEP_LOCOMOTION && i >= m->pd_start_link && !fixed) {
+    const bool pd_here = ex ? ex->pd_on[i] != 0 : i >= m->pd_start_link;
+    if (m->step_mode == TDS_STEP_LOCOMOTION && pd_here && sph_lane)
+      TDS_FAIL(TDS_ERR_UNSUPPORTED, "the PD block's spherical branch (locomotion_contact_simulation.h:188-226) is not built");
+    if (m->step_mode == TDS_STEP_LOCOMOTION && pd_here && !fixed) {
       if (pose_index >= m->action_dim) TDS_FAIL(TDS_ERR_INVALID_ARG, "more PD links than action_dim");
       d->act_index[i] = pose_index;
       d->init_pose[i] = (T)m->initial_poses[pose_index];
@@ -353,10 +356,54 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   return TDS_OK;
 }
 
-// Floating base and / or spherical joints -> the expanded model the builder above understands:
+// ---- small rigid-transform / inertia helpers of the expansion (row-major 3x3, X = (R, t): child frame -> parent) ----
+struct TdsXf { double R[9], t[3]; };
+static inline TdsXf tds_xf_identity() { TdsXf x = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}}; return x; }
+static inline TdsXf tds_xf_make(const double *R, const double *t) { TdsXf x; memcpy(x.R, R, sizeof(x.R)); memcpy(x.t, t, sizeof(x.t)); return x; }
+static inline TdsXf tds_xf_mul(const TdsXf &a, const TdsXf &b) {  // (A*B).R = A.R B.R, .t = A.t + A.R B.t  (transform.hpp:123-131)
+  TdsXf o;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) o.R[3 * r + c] = a.R[3 * r] * b.R[c] + a.R[3 * r + 1] * b.R[3 + c] + a.R[3 * r + 2] * b.R[6 + c];
+    o.t[r] = a.t[r] + a.R[3 * r] * b.t[0] + a.R[3 * r + 1] * b.t[1] + a.R[3 * r + 2] * b.t[2];
+  }
+  return o;
+}
+// rigid body (mass mb, com cb, inertia-about-com Ib, all in frame B) welded to link L at X (B in L's frame)
+static inline void tds_weld_inertia(tds_link_t &L, const TdsXf &X, double mb, const double *cb, const double *Ib) {
+  if (mb == 0.0) {
+    bool zero = true;
+    for (int k = 0; k < 9; ++k) zero &= Ib[k] == 0.0;
+    if (zero) return;
+  }
+  double c2[3], RI[9], I2[9];
+  for (int r = 0; r < 3; ++r) c2[r] = X.t[r] + X.R[3 * r] * cb[0] + X.R[3 * r + 1] * cb[1] + X.R[3 * r + 2] * cb[2];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) RI[3 * r + c] = X.R[3 * r] * Ib[c] + X.R[3 * r + 1] * Ib[3 + c] + X.R[3 * r + 2] * Ib[6 + c];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) I2[3 * r + c] = RI[3 * r] * X.R[3 * c] + RI[3 * r + 1] * X.R[3 * c + 1] + RI[3 * r + 2] * X.R[3 * c + 2];
+  const double ma = L.mass, M = ma + mb;
+  double c[3];
+  for (int k = 0; k < 3; ++k) c[k] = M != 0.0 ? (ma * L.com[k] + mb * c2[k]) / M : 0.0;
+  double I[9];
+  for (int k = 0; k < 9; ++k) I[k] = L.inertia[k] + I2[k];
+  const double da[3] = {L.com[0] - c[0], L.com[1] - c[1], L.com[2] - c[2]}, db[3] = {c2[0] - c[0], c2[1] - c[1], c2[2] - c[2]};
+  const double da2 = da[0] * da[0] + da[1] * da[1] + da[2] * da[2], db2 = db[0] * db[0] + db[1] * db[1] + db[2] * db[2];
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 3; ++cc)
+      I[3 * r + cc] += ma * ((r == cc ? da2 : 0.0) - da[r] * da[cc]) + mb * ((r == cc ? db2 : 0.0) - db[r] * db[cc]);
+  L.mass = M;
+  memcpy(L.com, c, sizeof(c));
+  memcpy(L.inertia, I, sizeof(I));
+}
+
+// Floating base, spherical joints, more links than lanes -> the expanded model the builder above understands:
 //   * floating base: six pseudo links in front (dof nj+k, unit axes, link 5 carries mb.base_rbi()), the model's
 //     links behind them with the base as link 5, joint dofs renumbered 0..nj-1;
-//   * spherical joint: three lanes SPH0 / SPH1 / SPH2 (the last one is the link: inertia, shapes, children).
+//   * spherical joint: three lanes SPH0 / SPH1 / SPH2 (the last one is the link: inertia, shapes, children);
+//   * JOINT_FIXED links below a moving link are FOLDED into it when the model would not fit the 32 lanes otherwise
+//     (or with TDS_HIP_FOLD_FIXED=1): inertia welded on, shapes / visuals / children re-based through the constant
+//     transform.  The reference keeps them as links with 1/D = 0 (forward_dynamics.hpp:153), which is the same
+//     rigid body.
 // Returns a malloc'ed TdsExpanded or NULL (why filled).
 static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
   why[0] = 0;
@@ -370,18 +417,32 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
   TdsExpanded *e = nullptr;
   if (m->num_links < 0 || m->num_links > TDS_MAX_LINKS) TDS_XFAIL("num_links out of range");
   const bool fl = m->is_floating != 0;
-  int nsph = 0;
-  for (int i = 0; i < m->num_links; ++i) nsph += m->links[i].joint_type == TDS_JOINT_SPHERICAL;
+  int nsph = 0, nfixed_foldable = 0;
+  bool moving_above[TDS_MAX_LINKS];  // some ancestor (or the floating base) moves: a fixed link here can be folded
+  for (int i = 0; i < m->num_links; ++i) {
+    const tds_link_t &l = m->links[i];
+    if (l.parent >= i || l.parent < -1) TDS_XFAIL("links must be ordered parent-before-child");
+    nsph += l.joint_type == TDS_JOINT_SPHERICAL;
+    const bool par_moving = l.parent < 0 ? fl : (moving_above[l.parent] || m->links[l.parent].joint_type != TDS_JOINT_FIXED);
+    moving_above[i] = par_moving;
+    nfixed_foldable += (l.joint_type == TDS_JOINT_FIXED && par_moving) ? 1 : 0;
+  }
   const int base = fl ? 6 : 0;
   if (fl && nsph) TDS_XFAIL("floating base + spherical joints: the reference fills the base/joint block of M one way only (mass_matrix.hpp:80-84); not built");
-  if (m->num_links + base + 2 * nsph > TDS_MAX_LINKS) TDS_XFAIL("too many links (a floating base takes 6 lanes, a spherical joint 3)");
+  const char *ff = getenv("TDS_HIP_FOLD_FIXED");
+  const bool fold = (m->num_links + base + 2 * nsph > TDS_NL) || (ff && ff[0] == '1');
+  if (m->num_links + base + 2 * nsph - (fold ? nfixed_foldable : 0) > TDS_NL)
+    TDS_XFAIL("too many links for 32 lanes (one per moving link, 6 for a floating base, 3 per spherical joint)");
   const int nj = m->dof_qd - base;
   if (nj < 0 || m->dof_q != m->dof_qd + (fl ? 1 : 0) + nsph) TDS_XFAIL("dof_q / dof_qd inconsistent with the base and the joints");
   e = (TdsExpanded *)malloc(sizeof(TdsExpanded));
   if (!e) return nullptr;
   memcpy(&e->m, m, sizeof(*m));
   e->num_spherical = nsph;
-  for (int k = 0; k < TDS_NL; ++k) e->q_rec[k] = e->qd_rec[k] = -1;
+  for (int k = 0; k < TDS_NL; ++k) {
+    e->q_rec[k] = e->qd_rec[k] = -1;
+    e->pd_on[k] = 0;
+  }
   for (int k = 0; k < base; ++k) {
     tds_link_t &L = e->m.links[k];
     memset(&L, 0, sizeof(L));
@@ -397,12 +458,23 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
     memcpy(e->m.links[5].com, m->base_com, sizeof(m->base_com));
     memcpy(e->m.links[5].inertia, m->base_inertia, sizeof(m->base_inertia));
   }
-  int carrier[TDS_MAX_LINKS];  // expanded index of the lane that carries link i (inertia, shapes, children)
+  int carrier[TDS_MAX_LINKS];   // expanded index of the lane that carries link i (inertia, shapes, children); -1: base
+  TdsXf xacc[TDS_MAX_LINKS];    // frame of link i in its carrier's frame (identity unless folded)
   int nx = base, ndof = 0, nq_rec = fl ? 7 : 0, nqd_rec = base;
   for (int i = 0; i < m->num_links; ++i) {
     const tds_link_t &l = m->links[i];
-    if (l.parent >= i || l.parent < -1) TDS_XFAIL("links must be ordered parent-before-child");
     const int par = l.parent < 0 ? (fl ? 5 : -1) : carrier[l.parent];
+    const TdsXf xpar = l.parent < 0 ? tds_xf_identity() : xacc[l.parent];   // parent link's frame in ITS carrier
+    const TdsXf xt = tds_xf_mul(xpar, tds_xf_make(l.X_T_rot, l.X_T_trans));  // this link's joint frame in that carrier
+    xacc[i] = tds_xf_identity();
+    if (l.joint_type == TDS_JOINT_FIXED && fold && moving_above[i]) {
+      carrier[i] = par;  // (>= 0: moving_above)
+      xacc[i] = xt;
+      tds_weld_inertia(e->m.links[par], xt, l.mass, l.com, l.inertia);
+      continue;
+    }
+    if (nx + (l.joint_type == TDS_JOINT_SPHERICAL ? 3 : 1) > TDS_NL) TDS_XFAIL("too many links for 32 lanes");
+    const bool pd = m->step_mode == TDS_STEP_LOCOMOTION && i >= m->pd_start_link;
     if (l.joint_type == TDS_JOINT_SPHERICAL) {
       if (l.q_index != nq_rec || l.qd_index != nqd_rec) TDS_XFAIL("q/qd indices must be dense in link order");
       if (l.stiffness != 0.0) TDS_XFAIL("spherical joint stiffness (axis-angle spring, forward_dynamics.hpp:70-74) is not built");
@@ -416,8 +488,8 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
         L.damping = l.damping;
         L.X_T_rot[0] = L.X_T_rot[4] = L.X_T_rot[8] = 1.0;
         if (k == 0) {
-          memcpy(L.X_T_rot, l.X_T_rot, sizeof(L.X_T_rot));
-          memcpy(L.X_T_trans, l.X_T_trans, sizeof(L.X_T_trans));
+          memcpy(L.X_T_rot, xt.R, sizeof(L.X_T_rot));
+          memcpy(L.X_T_trans, xt.t, sizeof(L.X_T_trans));
           e->q_rec[nx] = nq_rec;
         }
         if (k == 2) {
@@ -426,6 +498,7 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
           memcpy(L.inertia, l.inertia, sizeof(L.inertia));
         }
         e->qd_rec[nx] = nqd_rec + k;
+        e->pd_on[nx] = pd;
         ++nx;
       }
       carrier[i] = nx - 1;
@@ -435,6 +508,8 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
       tds_link_t &L = e->m.links[nx];
       L = l;
       L.parent = par;
+      memcpy(L.X_T_rot, xt.R, sizeof(L.X_T_rot));
+      memcpy(L.X_T_trans, xt.t, sizeof(L.X_T_trans));
       if (l.joint_type != TDS_JOINT_FIXED) {
         // (the reference numbers q from 7 and qd from 6 on a floating base, multi_body.hpp:324-349)
         if (l.q_index != nq_rec || l.qd_index != nqd_rec) TDS_XFAIL("q/qd indices must be dense in link order");
@@ -442,6 +517,7 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
         e->q_rec[nx] = nq_rec++;
         e->qd_rec[nx] = nqd_rec++;
       }
+      e->pd_on[nx] = pd;
       carrier[i] = nx++;
     }
   }
@@ -450,14 +526,24 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
   for (int g = 0; g < m->num_geoms && g < TDS_MAX_GEOMS; ++g) {
     const int lk = m->geoms[g].link;
     if (lk < -1 || lk >= m->num_links) TDS_XFAIL("geom link out of range");
-    e->m.geoms[g].link = lk < 0 ? (fl ? 5 : -1) : carrier[lk];
+    tds_geom_t &G = e->m.geoms[g];
+    G.link = lk < 0 ? (fl ? 5 : -1) : carrier[lk];
+    if (lk >= 0) {
+      const TdsXf x = tds_xf_mul(xacc[lk], tds_xf_make(G.X_rot, G.X_trans));
+      memcpy(G.X_rot, x.R, sizeof(G.X_rot));
+      memcpy(G.X_trans, x.t, sizeof(G.X_trans));
+    }
   }
   for (int v = 0; v < m->num_visuals && v < TDS_MAX_VISUALS; ++v) {
     const int lk = m->visuals[v].link;
     if (lk < 0 || lk >= m->num_links) TDS_XFAIL("visual link out of range");
-    e->m.visuals[v].link = carrier[lk];
+    tds_visual_t &V = e->m.visuals[v];
+    V.link = carrier[lk];
+    const TdsXf x = tds_xf_mul(xacc[lk], tds_xf_make(V.X_rot, V.X_trans));
+    memcpy(V.X_rot, x.R, sizeof(V.X_rot));
+    memcpy(V.X_trans, x.t, sizeof(V.X_trans));
   }
-  e->m.pd_start_link = m->pd_start_link < m->num_links ? (m->pd_start_link <= 0 ? base : carrier[m->pd_start_link]) : nx;
+  e->m.pd_start_link = 0;  // (superseded by pd_on)
 #undef TDS_XFAIL
   return e;
 }
@@ -469,7 +555,8 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
     strncpy(why, "model abi_version mismatch", 127);
     return TDS_ERR_INVALID_ARG;
   }
-  bool general = m->is_floating != 0;
+  const char *ffx = getenv("TDS_HIP_FOLD_FIXED");
+  bool general = m->is_floating != 0 || m->num_links > TDS_NL || (ffx && ffx[0] == '1');
   for (int i = 0; i < m->num_links && i < TDS_MAX_LINKS; ++i) general |= m->links[i].joint_type == TDS_JOINT_SPHERICAL;
   if (!general) return tds_build_dev_model_impl<T>(m, d, why, nullptr);
   TdsExpanded *e = tds_expand_model(m, why);

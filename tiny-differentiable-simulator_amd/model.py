@@ -14,12 +14,12 @@ import json
 import os
 
 TDS_HIP_ABI_VERSION = 2
-TDS_MAX_LINKS = 32
+TDS_MAX_LINKS = 64
 TDS_MAX_GEOMS = 32
-TDS_MAX_VISUALS = 32
+TDS_MAX_VISUALS = 64
 TDS_MAX_ACTIONS = 32
 TDS_MAX_DOF = 32
-TDS_MAX_CONTACTS = 32
+TDS_MAX_CONTACTS = 64
 
 TDS_STEP_LOCOMOTION = 0
 TDS_STEP_TAU = 1
