@@ -265,16 +265,17 @@ int tdsref_flatten(void *h, tds_model_t *out) {
 // `steps` env steps of `batch` envs with zero actions; the same rollout through the reference's
 // SerialForwardStepper must agree.  Returns 0 on success; on failure returns non-zero and writes
 // the message (e.g. "no HIP device visible" on a machine without a GPU).
-int tdsref_hipstepper_selftest(int batch, int steps, double *obs0, char *msg, int msg_len) {
-  typedef AntContactSimulation2<Alg> Sim;
+extern "C++" {
+template <typename Sim, typename Env>
+static int hipstepper_selftest(int batch, int steps, int reward_mode, double *obs0, char *msg, int msg_len) {
   typedef VectorizedEnvironment<Alg, Sim> VecEnv;
-  AntEnv2<Alg> env(false);
+  Env env(false);
   VecEnv vec_env(env.contact_sim, batch);
   ARSConfig config;
   config.batch_size = batch;
   config.auto_reset_when_done = false;
   try {
-    tds_hip::HipStepper<Alg, Sim> stepper(env.contact_sim, batch, 0, /*throw_on_error=*/true, TDS_REWARD_ANT);
+    tds_hip::HipStepper<Alg, Sim> stepper(env.contact_sim, batch, 0, /*throw_on_error=*/true, reward_mode);
     vec_env.seed(42);
     auto observations = vec_env.reset(config);
     vec_env.default_stepper_ = &stepper;
@@ -282,7 +283,7 @@ int tdsref_hipstepper_selftest(int batch, int steps, double *obs0, char *msg, in
     std::vector<double> rewards(batch);
     std::vector<bool> dones(batch, false);
     for (int t = 0; t < steps; ++t) vec_env.step(actions, observations, rewards, dones, config);
-    for (size_t k = 0; k < observations[0].size(); ++k) obs0[k] = observations[0][k];
+    for (size_t k = 0; k < observations[0].size() && k < 64; ++k) obs0[k] = observations[0][k];
     VecEnv vec_ref(env.contact_sim, batch);
     vec_ref.seed(42);
     auto obs_ref = vec_ref.reset(config);
@@ -301,6 +302,23 @@ int tdsref_hipstepper_selftest(int batch, int steps, double *obs0, char *msg, in
     snprintf(msg, msg_len, "%s", e.what());
     return 1000;
   }
+}
+}
+
+int tdsref_hipstepper_selftest(int batch, int steps, double *obs0, char *msg, int msg_len) {
+  return hipstepper_selftest<AntContactSimulation2<Alg>, AntEnv2<Alg>>(batch, steps, TDS_REWARD_ANT, obs0, msg, msg_len);
+}
+
+// the same for the other environments of the reference that sit on this path: "ant" | "laikago" | "humanoid"
+int tdsref_hipstepper_selftest_env(const char *env, int batch, int steps, double *obs0, char *msg, int msg_len) {
+  std::string e(env);
+  if (e == "ant") return tdsref_hipstepper_selftest(batch, steps, obs0, msg, msg_len);
+  if (e == "laikago")
+    return hipstepper_selftest<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, TDS_REWARD_LAIKAGO, obs0, msg, msg_len);
+  if (e == "humanoid")
+    return hipstepper_selftest<HumanoidContactSimulation<Alg>, HumanoidEnv<Alg>>(batch, steps, TDS_REWARD_NONE, obs0, msg, msg_len);
+  snprintf(msg, msg_len, "unknown env %s", env);
+  return -1;
 }
 
 // The reference's OWN rollout loop on its header-only CPU path: Worker::rollouts

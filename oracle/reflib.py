@@ -40,6 +40,8 @@ def lib():
         L.tdsref_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tdsref_debug.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         L.tdsref_hipstepper_selftest.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        if hasattr(L, "tdsref_hipstepper_selftest_env"):
+            L.tdsref_hipstepper_selftest_env.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
         if hasattr(L, "tdsref_generated_step"):
             L.tdsref_generated_step.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
         if hasattr(L, "tdsref_rb_step"):
@@ -51,9 +53,9 @@ def lib():
     return _lib
 
 
-def hipstepper_selftest(batch=8, steps=5):
-    """Reference VectorizedEnvironment + tds_hip::HipStepper (include/tds_hip_stepper.hpp).
-    returns (rc, message, obs0)."""
+def hipstepper_selftest(batch=8, steps=5, env="ant"):
+    """Reference VectorizedEnvironment<env> + tds_hip::HipStepper (include/tds_hip_stepper.hpp); env: "ant" |
+    "laikago" | "humanoid".  returns (rc, message, obs0)."""
     obs0 = np.zeros(64)
     msg = C.create_string_buffer(512)
     sys.stdout.flush()
@@ -61,7 +63,7 @@ def hipstepper_selftest(batch=8, steps=5):
     devnull = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull, 1)
     try:
-        rc = lib().tdsref_hipstepper_selftest(batch, steps, obs0.ctypes.data, msg, 512)
+        rc = lib().tdsref_hipstepper_selftest_env(env.encode(), batch, steps, obs0.ctypes.data, msg, 512)
         C.CDLL(None).fflush(None)
     finally:
         os.dup2(saved, 1)

@@ -155,9 +155,10 @@ def test_reference_vecenv_dropin(built):
     import reflib
     if not reflib.available():
         pytest.skip("oracle/_ref/libtds_ref.so not built (needs /root/reference at build time)")
-    rc, msg, obs0 = reflib.hipstepper_selftest(16, 20)
-    print("HipStepper in VectorizedEnvironment:", msg)
-    assert rc == 0, msg
+    for env in ("ant", "laikago", "humanoid"):
+        rc, msg, obs0 = reflib.hipstepper_selftest(16, 20, env)
+        print(f"HipStepper in VectorizedEnvironment<{env}>:", msg)
+        assert rc == 0, (env, msg)
 
 
 @pytest.mark.parametrize("name", ["ant", "laikago"])
