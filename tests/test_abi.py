@@ -78,7 +78,7 @@ def test_no_gpu_fails_loudly(built):
         hip_backend.HipSim(m, 8)
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "humanoid"])
 def test_legacy_shim_exports_reference_symbols(name, built):
     """cuda_model_<env>.so must export exactly what CudaModel<double> dlsym()s
     (reference: examples/ars/ars_train_policy_cuda.cpp:220-229, 345-359)."""
@@ -99,7 +99,7 @@ def test_legacy_shim_exports_reference_symbols(name, built):
     assert (md.output_dim, md.input_dim, md.global_dim) == (m.output_dim, m.input_dim, 0)
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "humanoid"])
 def test_newer_abi_library_exports_reference_symbols(name, built):
     """cudalib_<env>.so must export what CudaLibrary<double> / CudaFunction<double> dlsym()
     (reference: src/utils/cuda/cuda_library.hpp:50-56, cuda_function.hpp:78-99)."""

@@ -161,7 +161,7 @@ def test_reference_vecenv_dropin(built):
         assert rc == 0, (env, msg)
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "humanoid"])
 def test_legacy_forward_zero_library(name, built):
     """dlopen cuda_model_<env>.so the way the reference's CudaModel does and call
     <model>_forward_zero with flat host arrays."""
@@ -182,7 +182,7 @@ def test_legacy_forward_zero_library(name, built):
     assert rel_err(y, g["y"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "humanoid"])
 def test_newer_abi_forward_zero_library(name, built):
     """cudalib_<env>.so driven the way CudaFunction<double>::operator() drives a generated library
     (reference: src/utils/cuda/cuda_function.hpp:117-140): send_global, send_local, then launch."""
