@@ -480,48 +480,55 @@ __device__ __forceinline__ T tds_pgs_sweep(T u, int lane, int NA, int ZR, T mu, 
   constexpr int NDs = NDP + 1;
   const int dcl = lane < NDP ? lane : NDP - 1;  // lanes >= NDP read a valid slot and discard it
   const bool dz = lane < NDP;
-  const int nr = 3 * NA;
   const int last = ZR - 1;
   T zn = Zs[dcl], bn = rws[0], an = rws[ZR], gn = FIRST ? T(0) : rws[2 * ZR], xon = FIRST ? T(0) : xs[0];
-  T sn = T(0), x0 = T(0);
-  for (int r = 0; r < nr; ++r) {
-    const T zr = dz ? zn : T(0);
-    const T br = bn, ar = an, gr = gn, x_old = xon, sdep = sn;
-    // prefetch row r + 1 (index clamped: the loads are unconditional)
-    const int rn = r + 1;
-    const int rl = rn < last ? rn : last;
-    zn = Zs[rl * NDs + dcl];
-    bn = rws[rl];
-    an = rws[ZR + rl];
-    if constexpr (!FIRST) {
-      gn = rws[2 * ZR + rl];
-      xon = xs[rl];
+  T xn = T(0), x_n0 = T(0);
+  // One loop per row kind (normals, tangent 1, tangent 2; NA rows each): the bounds and the row of the limiting
+  // normal impulse are then static per loop instead of selected per row — a lone wavefront issues one
+  // instruction per ~4 cycles whatever its type, so the loop's instruction count IS its latency.
+  // `normal`: bounds [0, 1e5]; otherwise -/+ mu max(x_normal, 0) with x_normal = xs[a] (limit_dependency_,
+  // mb_constraint_solver.hpp:417-436), prefetched one row ahead like the row itself.
+  auto rows = [&](auto normal_c, const int r0) {
+    constexpr bool normal = decltype(normal_c)::value;
+    // (with a single contact slot the normal impulse of THIS sweep comes straight from its register)
+    T sn = normal ? T(0) : (NA == 1 ? x_n0 : xs[0]);
+    for (int a = 0; a < NA; ++a) {
+      const int r = r0 + a;
+      const T zr = dz ? zn : T(0);
+      const T br = bn, ar = an, gr = gn, x_old = xon, sdep = sn;
+      // prefetch row r + 1 (index clamped: the loads are unconditional)
+      const int rl = r + 1 < last ? r + 1 : last;
+      zn = Zs[rl * NDs + dcl];
+      bn = rws[rl];
+      an = rws[ZR + rl];
+      if constexpr (!FIRST) {
+        gn = rws[2 * ZR + rl];
+        xon = xs[rl];
+      }
+      if constexpr (!normal) sn = xs[a + 1 < NA ? a + 1 : a];
+      const T jw = group_sum<T, G>(zr * u);
+      T delta = jw;
+      if constexpr (!FIRST) delta -= gr * x_old;
+      xn = (br - delta) * ar;
+      if constexpr (normal) {
+        xn = max_t<T>(xn, T(0));
+        xn = min_t<T>(xn, T(100000));
+      } else {
+        const T h = mu * (sdep > T(0) ? sdep : T(0));  // where_lt(s, 0, 0, s)
+        xn = max_t<T>(xn, -h);  // Algebra::max(x, lo*s)
+        xn = min_t<T>(xn, h);   // Algebra::min(x, hi*s)
+      }
+      if constexpr (FIRST) u += zr * xn; else u += zr * (xn - x_old);
+      // every lane of the group holds the same xn and stores it (same address: no bank conflict).  A store
+      // predicated on lane == 0 becomes a branch around the DS write, after which the compiler must drain
+      // lgkmcnt(0) — the LDS write latency then sits on every iteration of this loop.
+      xs[r] = xn;
     }
-    // limit_dependency_ (mb_constraint_solver.hpp:417-436): the friction box of row rn scales with the
-    // normal impulse of its contact, row rn - NA (tangent 1) or rn - 2 NA (tangent 2)
-    const int depn = rn - (rn >= NA ? NA : 0) - (rn >= 2 * NA ? NA : 0);
-    const T sload = xs[depn < last ? depn : last];
-    const T jw = group_sum<T, G>(zr * u);
-    T delta = jw;
-    if constexpr (!FIRST) delta -= gr * x_old;
-    T xn = (br - delta) * ar;
-    if (r < NA) {  // wave-uniform: normal row, bounds [0, 1e5]
-      xn = max_t<T>(xn, T(0));
-      xn = min_t<T>(xn, T(100000));
-    } else {       // friction row, bounds -/+ mu max(x_normal, 0)
-      const T h = mu * (sdep > T(0) ? sdep : T(0));  // where_lt(s, 0, 0, s)
-      xn = max_t<T>(xn, -h);  // Algebra::max(x, lo*s)
-      xn = min_t<T>(xn, h);   // Algebra::min(x, hi*s)
-    }
-    if constexpr (FIRST) u += zr * xn; else u += zr * (xn - x_old);
-    // every lane of the group holds the same xn and stores it (same address: no bank conflict).  A store
-    // predicated on lane == 0 becomes a branch around the DS write, after which the compiler must drain
-    // lgkmcnt(0) — the LDS write latency then sits on every iteration of this loop.
-    xs[r] = xn;
-    if (r == 0) x0 = xn;
-    // with a single contact slot row 1 depends on the row just computed (its prefetch is stale)
-    sn = NA == 1 ? x0 : sload;
-  }
+  };
+  rows(std::true_type{}, 0);
+  x_n0 = xn;
+  rows(std::false_type{}, NA);
+  rows(std::false_type{}, 2 * NA);
   return u;
 }
 
