@@ -199,7 +199,7 @@ def main():
         # floating base / spherical root joint (humanoid): the env's own reset distribution
         x0[:, :nq] = np.array([m.reset_q[i] for i in range(nq)]) + \
             np.array([m.reset_noise[i] for i in range(nq)]) * rng.uniform(-1, 1, (n, nq))
-        x0[:, -3:] = [100, 2, 50]
+        x0[:, -3:] = [50, 1.5, 50] if args.model.startswith("humanoid") else [100, 2, 50]
     elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
         ip = np.array([m.initial_poses[i] for i in range(adim)])
         x0[:, 2] = 0.48

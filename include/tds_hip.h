@@ -99,7 +99,10 @@ enum {
   TDS_REWARD_ANT = 1,
   /* reward = x, done = up_dot_world_z < 0.6 || z < 0.2, up from rpy = q[3..5]
      (examples/environments/laikago_environment2.h:130-171) */
-  TDS_REWARD_LAIKAGO = 2
+  TDS_REWARD_LAIKAGO = 2,
+  /* reward = x, done = up_dot_world_z < 0.6 || z < 0.8, up from the quaternion q[3..6] of the spherical root joint
+     (examples/environments/humanoid_environment.h:155-197, fixed-base branch) */
+  TDS_REWARD_HUMANOID = 3
 };
 
 /* scalar type the kernels compute in */

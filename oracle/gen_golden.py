@@ -100,7 +100,7 @@ def random_inputs(name, m, n, rng):
         x[:, 7:nq] = ip + rng.uniform(-0.5, 0.5, (n, nq - 7))
         x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
         x[:, nq + nd:nq + nd + m.action_dim] = rng.uniform(-0.6, 0.6, (n, m.action_dim))
-        x[:, -3:] = [100, 2, 50]
+        x[:, -3:] = [50, 1.5, 50]                # kp, kd, max_force of HumanoidContactSimulation (humanoid_environment.h:73-75)
     elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
         x[:, 0:2] = rng.uniform(-1, 1, (n, 2))
         x[:, 2] = rng.uniform(0.15, 0.6, n)
@@ -149,7 +149,7 @@ def rollout_start(name, m, rng):
         x[2] = 1.3
         x[6] = 1.0
         x[7:nq] = ip + 0.05 * rng.uniform(-1, 1, nq - 7)
-        x[-3:] = [100, 2, 50]
+        x[-3:] = [50, 1.5, 50]
     elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
         ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
         x[2] = 0.48
@@ -189,10 +189,18 @@ def rollout_fixture(name, n=24, steps=25, shift=0.5, seed=77):
     if name == "ant":
         x[::5, 2] -= 0.12          # torso close to the 0.26 threshold
         x[::5, 3] = 0.5
+    elif name == "humanoid":
+        x[::5, 2] = 0.83           # torso close to the 0.8 threshold
+        tilt = np.array([0.47, 0.0, 0.0, 0.883])   # up.z = 1 - 2 (x^2 + y^2) / |q|^2 = 0.56: done from the first step
+        x[::10, 3:7] = tilt / np.linalg.norm(tilt)
     else:
         x[::5, 3] = 0.92           # strongly rolled chassis: up.z drops below 0.6 during the rollout
         x[::10, 3] = 1.0           # ... or is below it from the first step
-    params = rng.normal(0.0, 0.05, (n, adim * od + adim))
+    if name == "humanoid":
+        # (no joint limits, no velocity clamps: a humanoid that has fallen over blows up within tens of steps under
+        #  random policies, and the reference asserts on the NaN — keep the rollout short and the policies small)
+        steps = 12
+    params = rng.normal(0.0, 0.02 if name == "humanoid" else 0.05, (n, adim * od + adim))
     tot, cnt, fin = reflib.rollout(name, x[:, :od], params, steps, shift)
     r.close()
     return dict(x0=x, params=params, steps=np.int32(steps), shift=np.float64(shift), total_rewards=tot,
@@ -240,7 +248,7 @@ def main(only=None):
               f"out={m.output_dim} active contacts/state: min {ncs.min()} max {ncs.max()} "
               f"mean {ncs.mean():.1f}")
         r.close()
-    for name in ("ant", "laikago") if only is None else ():
+    for name in [n for n in ("ant", "laikago", "humanoid") if only is None or n + "_rollout" in only]:
         f = rollout_fixture(name)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_rollout.npz"), **f)
         print(f"{name}_rollout: steps taken {f['vec_steps'].min()}..{f['vec_steps'].max()} of {int(f['steps'])}, "

@@ -237,7 +237,7 @@ int tdsref_flatten(void *h, tds_model_t *out) {
   } else if (s->lfloat) {
     rc = tds_hip::flatten_locomotion_env<Alg>(*s->lfloat, out, TDS_REWARD_NONE);
   } else if (s->humanoid) {
-    rc = tds_hip::flatten_locomotion_env<Alg>(s->humanoid->contact_sim, out, TDS_REWARD_NONE);
+    rc = tds_hip::flatten_locomotion_env<Alg>(s->humanoid->contact_sim, out, TDS_REWARD_HUMANOID);
   } else {
     memset(out, 0, sizeof(*out));
     out->abi_version = TDS_HIP_ABI_VERSION;
@@ -316,7 +316,7 @@ int tdsref_hipstepper_selftest_env(const char *env, int batch, int steps, double
   if (e == "laikago")
     return hipstepper_selftest<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, TDS_REWARD_LAIKAGO, obs0, msg, msg_len);
   if (e == "humanoid")
-    return hipstepper_selftest<HumanoidContactSimulation<Alg>, HumanoidEnv<Alg>>(batch, steps, TDS_REWARD_NONE, obs0, msg, msg_len);
+    return hipstepper_selftest<HumanoidContactSimulation<Alg>, HumanoidEnv<Alg>>(batch, steps, TDS_REWARD_HUMANOID, obs0, msg, msg_len);
   snprintf(msg, msg_len, "unknown env %s", env);
   return -1;
 }
@@ -377,6 +377,9 @@ int tdsref_rollout(const char *name, int batch, int steps, double shift, const d
   if (n == "laikago")
     return ref_rollout<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, shift, x0, params,
                                                                        total_rewards, vec_steps, final_obs);
+  if (n == "humanoid")
+    return ref_rollout<HumanoidContactSimulation<Alg>, HumanoidEnv<Alg>>(batch, steps, shift, x0, params,
+                                                                         total_rewards, vec_steps, final_obs);
   return -1;
 }
 

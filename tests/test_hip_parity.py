@@ -345,7 +345,7 @@ def test_forced_reset_matches_host_emulation(name, built):
     n, seed = 24, 1234
     sim = hip_backend.HipSim(m, n)
     sim.set_auto_reset(False, seed)
-    vars3 = [15, 0.3, 3] if name == "ant" else [100, 2, 50]
+    vars3 = {"ant": [15, 0.3, 3], "humanoid": [50, 1.5, 50]}.get(name, [100, 2, 50])
     sim.x[:, -3:] = torch.tensor(vars3, dtype=torch.float64, device="cuda")
     mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
     mask[::3] = 1
@@ -436,7 +436,7 @@ def _rollout_inputs(name, n, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ant", "laikago"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "humanoid"])
 def test_rollout_matches_reference_worker_loop(name, built):
     """tds_hip_rollout (policy + step + reward/done + return bookkeeping in ONE launch) against the
     reference's own Worker::rollouts / VectorizedEnvironment::policy+step loop run on its header-only

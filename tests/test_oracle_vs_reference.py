@@ -65,7 +65,7 @@ def test_hipstepper_header_compiles_and_fails_loudly_without_gpu(built):
     assert rc != 0 and "no HIP device" in msg
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "humanoid"])
 def test_rollout_fixture_is_the_reference_worker_loop(name, built, gen):
     """tests/golden/<name>_rollout.npz is reproducible from the real reference, and the reference's loop
     (policy, step, reward/done, return bookkeeping) is what an independent numpy restatement on top of
@@ -89,6 +89,11 @@ def test_rollout_fixture_is_the_reference_worker_loop(name, built, gen):
         if name == "ant":                            # ant_environment2.h:75-106
             d = y[:, 2] < 0.26
             rew = np.where(d, 0.0, (y[:, 0] - x[:, 0]) / m.dt)
+        elif name == "humanoid":                     # humanoid_environment.h:155-197
+            qx, qy, qz, qw = y[:, 3], y[:, 4], y[:, 5], y[:, 6]
+            up = 1.0 - 2.0 * (qx * qx + qy * qy) / (qx * qx + qy * qy + qz * qz + qw * qw)
+            d = (up < 0.6) | (y[:, 2] < 0.8)
+            rew = np.where(d, 0.0, y[:, 0])
         else:                                        # laikago_environment2.h:130-171
             up = np.cos(y[:, 3]) * np.cos(y[:, 4])   # R(rpy)(2,2)
             d = (up < 0.6) | (y[:, 2] < 0.2)

@@ -125,8 +125,11 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd + (fl ? 1 : 0) + nsph || m->dof_q > TDS_ND)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "dof out of range (<= 32 velocities, <= 32 coordinates) or dof_q inconsistent with the joints");
   // (env step with spherical joints: fine as long as the PD loop does not visit them — checked with pd_on below)
-  if (nsph && m->reward_mode != TDS_REWARD_NONE)
+  if (nsph && m->reward_mode != TDS_REWARD_NONE && m->reward_mode != TDS_REWARD_HUMANOID)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "the Ant / Laikago reward rules read a 1-dof-joint state record");
+  if (m->reward_mode == TDS_REWARD_HUMANOID &&
+      !(nsph && !fl && m->num_links > 3 && m->links[3].joint_type == TDS_JOINT_SPH0 && ex->q_rec[3] == 3))
+    TDS_FAIL(TDS_ERR_UNSUPPORTED, "the humanoid reward rule needs the xyz + spherical root joint (quaternion at q[3..6])");
   d->num_spherical = nsph;
   d->sph_damping = (T)pow(0.995, 1000.0 * m->dt);
   if (fl && m->reward_mode != TDS_REWARD_NONE)

@@ -1853,6 +1853,14 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       const T up = T(1) - (qx * (qx * s2) + qy * (qy * s2));
       done = (up < T(0.6)) || (xr[2] < T(0.2));
       reward = done ? T(0) : xr[0];
+    } else if (sph && rm == TDS_REWARD_HUMANOID && nq > 6) {
+      // up_dot_world_z = quat_to_matrix(q[3..6])(2,2); done = up < 0.6 || z < 0.8; reward = x
+      // (humanoid_environment.h:172-196, tiny_matrix3x3.h:315-340)
+      const T qx = xr[3], qy = xr[4], qz = xr[5], qw = xr[6];
+      const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+      const T up = T(1) - (qx * (qx * s2) + qy * (qy * s2));
+      done = (up < T(0.6)) || (xr[2] < T(0.8));
+      reward = done ? T(0) : xr[0];
     }
     if (obs_out != nullptr && last_run) {
       T *const ob = obs_out + (size_t)env * (nq + nd + 2);

@@ -23,7 +23,7 @@ TDS_MAX_CONTACTS = 64
 
 TDS_STEP_LOCOMOTION = 0
 TDS_STEP_TAU = 1
-TDS_REWARD_NONE, TDS_REWARD_ANT, TDS_REWARD_LAIKAGO = 0, 1, 2
+TDS_REWARD_NONE, TDS_REWARD_ANT, TDS_REWARD_LAIKAGO, TDS_REWARD_HUMANOID = 0, 1, 2, 3
 TDS_DTYPE_F64 = 0
 TDS_DTYPE_F32 = 1
 
