@@ -29,7 +29,10 @@
 //     qd -= M^-1 J^T p is one back-substitution L^-T D^-1/2 u~;
 //   * rows of separated contacts (distance >= 0) are identically zero in the reference
 //     (keep_all_points_, src/mb_constraint_solver.hpp:285-291) and yield x = 0, so only
-//     penetrating contacts are materialised, in the reference's row order (wave-uniform slots).
+//     penetrating contacts are materialised, in the reference's row order (wave-uniform slots);
+//   * three kernel kinds (template parameter KIND): 0 fixed base with 1-dof joints, 1 floating base (six pseudo
+//     links, the reference's base-frame ABA incl. its block inverse), 2 spherical joints (three lanes per joint);
+//     JOINT_FIXED links may be folded into their parents on the host (tds_device_model.h).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
