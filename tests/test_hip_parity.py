@@ -96,7 +96,7 @@ def test_closed_loop_matches_oracle(name, built):
         sim.x[:, :nq + nd] = torch.from_numpy(x[:, :nq + nd]).cuda()
 
 
-@pytest.mark.parametrize("name", ["ant", "laikago"])
+@pytest.mark.parametrize("name", ["ant", "laikago", "humanoid", "ant_floating", "pendulum5_spherical"])
 def test_full_size_properties(name, built):
     """BASELINE.json sizes (4096 / 8192 envs): size-independent properties —
     (1) permutation equivariance: stepping a shuffled batch == shuffling the stepped batch (bitwise);
