@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=0,
                     help="also time the on-device policy rollout with this many policy steps per launch")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
-    ap.add_argument("--gather-every", type=int, default=8,
+    ap.add_argument("--gather-every", type=int, default=32,
                     help="N > 1: steps whose [obs|reward|done] records travel in one all-gather (1 = every step)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the N > 1 step loop (pipelined record gather) even with one rank: exercises that code path on a 1-GPU box")
