@@ -48,6 +48,12 @@ MODELS = {
     # HumanoidEnv (humanoid_environment.h): the env step on 37 links (12 of them fixed -> folded into their parents
     # on the device), xyz + spherical root joint, 21 PD-controlled joints, 27 dof
     "humanoid": dict(ref="humanoid"),
+    # the PD loop's SPHERICAL branch (locomotion_contact_simulation.h:188-226; no env of the reference reaches it):
+    # HumanoidContactSimulation on data/humanoid_partial_xyz_spherical.urdf with base_dof_ = 3 (the spherical root is
+    # visited: pose_index += 4, torque dropped because its link index is < 4) and on data/pendulum5spherical.urdf with
+    # base_dof_ = 0 (five spherical joints visited, link 4 keeps its euler-angle PD torque)
+    "humanoid_sph_pd": dict(ref="humanoid_sph_pd"),
+    "pendulum5_sph_pd": dict(ref="pendulum5_sph_pd"),
 }
 
 
@@ -92,6 +98,22 @@ def random_inputs(name, m, n, rng):
         x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
         x[:, nq + nd:nq + nd + m.action_dim] = rng.uniform(-0.6, 0.6, (n, m.action_dim))
         x[:, -3:] = [100, 2, 50]
+    elif name in ("humanoid_sph_pd", "pendulum5_sph_pd"):
+        x[:, :nq] = rng.uniform(-0.5, 0.5, (n, nq))
+        if name == "humanoid_sph_pd":
+            x[:, 2] = rng.uniform(0.1, 1.2, n)
+        _set_spherical_quats(m, x, rng, 0.7 if name == "humanoid_sph_pd" else 0.06)
+        if name == "pendulum5_sph_pd":
+            # (the chain lies in the plane z = 0: small angles keep the penetrations shallow; the last joint — the one
+            #  whose PD torque is kept — takes large rotations)
+            quat = rng.normal(size=(n, 4)) * [0.8, 0.8, 0.8, 0.0] + [0, 0, 0, 1.0]
+            x[:, 16:20] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+            x[::7, 16:20] = [0.0, 0.70710678, 0.0, 0.70710678]   # euler y = pi/2: the fi ~ +-1 corner of matrix_to_euler_xyz
+            x[3::7, 16:20] = [0.0, -1.0, 0.0, 1.0]               # ... not normalised
+        x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+        x[:, nq + nd:nq + nd + m.action_dim] = rng.uniform(-0.6, 0.6, (n, m.action_dim))
+        x[:, -3:] = [50, 1.5, 50]
+        x[::3, -3:] = [200, 5.0, 20]             # large gains: the clamp to max_force is active
     elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and _spherical_links(m):
         x[:, 0:2] = rng.uniform(-1, 1, (n, 2))
         x[:, 2] = rng.uniform(0.7, 1.5, n)       # torso height: standing ... lying on the plane
@@ -144,6 +166,14 @@ def rollout_start(name, m, rng):
         x[6] = 0.48
         x[7:nq] = ip + 0.05 * rng.uniform(-1, 1, nq - 7)
         x[-3:] = [100, 2, 50]
+    elif name in ("humanoid_sph_pd", "pendulum5_sph_pd"):
+        x[:nq] = rng.uniform(-0.1, 0.1, nq)
+        if name == "humanoid_sph_pd":
+            x[2] = 1.0
+        xx = x[None, :].copy()
+        _set_spherical_quats(m, xx, rng, 0.2)
+        x[:] = xx[0]
+        x[-3:] = [50, 1.5, 50]
     elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and _spherical_links(m):
         ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
         x[2] = 1.3

@@ -57,6 +57,10 @@ struct RefSim {
   LaikagoContactSimulation<Alg> *lfloat = nullptr;
   // HumanoidEnv (humanoid_environment.h:212-232): xyz base + spherical joints, PD with the spherical branch
   HumanoidEnv<Alg> *humanoid = nullptr;
+  // the PD loop's SPHERICAL branch (locomotion_contact_simulation.h:188-226): no environment of the reference
+  // reaches it (HumanoidEnv skips its only spherical joint with base_dof_ = 7), so the env step is constructed
+  // on URDFs of the reference's data directory whose spherical joints lie behind base_dof_
+  HumanoidContactSimulation<Alg> *sphpd = nullptr;
   // generic model (URDF file from the reference data dir, optional plane)
   UrdfCache<Alg> cache;
   World<Alg> *gworld = nullptr;
@@ -69,6 +73,7 @@ struct RefSim {
     if (laikago) return laikago->contact_sim.world;
     if (lfloat) return lfloat->world;
     if (humanoid) return humanoid->contact_sim.world;
+    if (sphpd) return sphpd->world;
     return *gworld;
   }
   MultiBody<Alg> *mb() {
@@ -76,6 +81,7 @@ struct RefSim {
     if (laikago) return laikago->contact_sim.mb_;
     if (lfloat) return lfloat->mb_;
     if (humanoid) return humanoid->contact_sim.mb_;
+    if (sphpd) return sphpd->mb_;
     return gmb;
   }
   LocoSim *loco() {
@@ -83,6 +89,7 @@ struct RefSim {
     if (laikago) return &laikago->contact_sim;
     if (lfloat) return lfloat;
     if (humanoid) return &humanoid->contact_sim;
+    if (sphpd) return sphpd;
     return nullptr;
   }
   bool has_plane() { return loco() ? true : g_plane; }
@@ -98,6 +105,10 @@ struct RefSim {
     return n;
   }
   int output_dim() {
+    // state_dim() counts num_links * num_visuals scalars for the visual poses (locomotion_contact_simulation.h:75-77)
+    // but 7 are written per visual (:281-299): with fewer than 7 links (pendulum5_sph_pd) the reference would write
+    // past its own output_dim.  For these constructions the record is as long as what the step writes.
+    if (sphpd) return std::max(sphpd->output_dim(), sphpd->mb_->dof() + sphpd->mb_->dof_qd() + 7 * num_visuals() + 1);
     if (loco()) return loco()->output_dim();
     return gmb->dof() + gmb->dof_qd() + 7 * num_visuals() + 1;
   }
@@ -156,6 +167,22 @@ void *tdsref_create(const char *name_c, const char *reference_root) {
     s->laikago = new LaikagoEnv<Alg>(false);
   } else if (name == "humanoid") {
     s->humanoid = new HumanoidEnv<Alg>(false);
+  } else if (name == "humanoid_sph_pd" || name == "pendulum5_sph_pd") {
+    // humanoid_sph_pd : humanoid_partial_xyz_spherical.urdf (xyz prismatic, spherical root = link 3, three revolute
+    //                   joints), base_dof_ = 3: the PD loop visits the spherical joint (pose_index += 4; its torque is
+    //                   NOT stored, link index < 4, :215) and then the revolute joints with pose_index 4, 5, 6
+    // pendulum5_sph_pd: pendulum5spherical.urdf (five spherical joints), base_dof_ = 0: every joint is visited,
+    //                   only link 4 keeps its torque
+    const bool hum = name == "humanoid_sph_pd";
+    char cwd[4096];
+    if (!getcwd(cwd, sizeof(cwd))) cwd[0] = 0;
+    if (chdir(reference_root) != 0) return nullptr;
+    std::vector<double> poses(hum ? 7 : 20, 0.0);
+    if (hum) { poses[4] = 0.1; poses[5] = -0.2; poses[6] = 0.3; }
+    s->sphpd = new HumanoidContactSimulation<Alg>(true, hum ? "humanoid_partial_xyz_spherical.urdf" : "pendulum5spherical.urdf",
+                                                 "", poses, false);
+    s->sphpd->base_dof_ = hum ? 3 : 0;
+    if (cwd[0] && chdir(cwd) != 0) return nullptr;
   } else if (name == "laikago_floating_env") {
     // urdf_from_file = true: FileUtils::find_file looks under ./data of the working directory
     char cwd[4096];
@@ -197,6 +224,7 @@ void tdsref_destroy(void *h) {
   delete s->laikago;
   delete s->lfloat;
   delete s->humanoid;
+  delete s->sphpd;
   delete s->gworld;
   delete s;
 }
@@ -238,6 +266,10 @@ int tdsref_flatten(void *h, tds_model_t *out) {
     rc = tds_hip::flatten_locomotion_env<Alg>(*s->lfloat, out, TDS_REWARD_NONE);
   } else if (s->humanoid) {
     rc = tds_hip::flatten_locomotion_env<Alg>(s->humanoid->contact_sim, out, TDS_REWARD_HUMANOID);
+  } else if (s->sphpd) {
+    rc = tds_hip::flatten_locomotion_env<Alg>(*s->sphpd, out, TDS_REWARD_NONE);
+    out->settle_steps = 0;  // (no reset rule in the reference for these constructions)
+    out->output_dim = s->output_dim();
   } else {
     memset(out, 0, sizeof(*out));
     out->abi_version = TDS_HIP_ABI_VERSION;

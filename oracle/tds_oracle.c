@@ -892,12 +892,6 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
   /* floating base + spherical joints: the reference writes the base/joint block of M only one way round
      (mass_matrix.hpp:80-84) — not restated */
   if (m->is_floating && nsph) return -2;
-  /* env step: the PD loop starts at link pd_start_link (base_dof_); its spherical branch
-     (locomotion_contact_simulation.h:188-226) is not restated — spherical joints must lie in front of it
-     (HumanoidEnv: base_dof_ = 7, the spherical root joint is link 3) */
-  if (m->step_mode != TDS_STEP_TAU)
-    for (int i = m->pd_start_link > 0 ? m->pd_start_link : 0; i < m->num_links; ++i)
-      if (m->links[i].joint_type == TDS_JOINT_SPHERICAL) return -2;
   if (m->has_plane) {
     int nc = 0;
     for (int g = 0; g < m->num_geoms; ++g)
@@ -921,6 +915,29 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
     for (int i = m->pd_start_link; i < m->num_links; ++i) { /* :181-257 */
       const tds_link_t *l = &m->links[i];
       if (l->joint_type == TDS_JOINT_FIXED) continue;
+      if (l->joint_type == TDS_JOINT_SPHERICAL) {          /* :188-226 */
+        /* q_desired = identity, qd_desired = 0; position_error = get_axis_difference_quaternion(q_desired,
+           q_actual) = matrix_to_euler_xyz(quat_to_matrix(inverse(q_desired) * q_actual))
+           (matrix_utils.hpp:77-90; inverse = (-x,-y,-z,w), tiny_quaternion.h:80-82, so the product with
+           the identity is q_actual itself) */
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pe[3];
+        quat_to_matrix(s->q + l->q_index, R);
+        /* matrix_to_euler_xyz (matrix_utils.hpp:18-50); get_matrix_elem(mat, k) = mat(k % 3, k / 3) (:11-16) */
+        const double fi = R[6], e0 = R[0], e1 = R[3], e3 = R[1], e4 = R[4], e5 = R[7], e8 = R[8];
+        const double half_pi = 3.14159265358979323846 / 2.; /* M_PI / 2., tiny_double_utils.h:40 */
+        pe[0] = fi <= 1.0 ? (fi >= -1.0 ? atan2(-e5, e8) : -atan2(e3, e4)) : atan2(e3, e4);
+        pe[1] = fi <= 1.0 ? (fi >= -1.0 ? asin(fi) : -half_pi) : half_pi;
+        pe[2] = fi <= 1.0 ? (fi >= -1.0 ? atan2(-e1, e0) : 0.0) : 0.0;
+        for (int k = 0; k < 3; ++k) {
+          double f = kp * pe[k] + kd * (0.0 - s->qd[l->qd_index + k]); /* :207-208 */
+          if (f < -max_force) f = -max_force;              /* :209-213: min(max(f, -max), max) */
+          if (f > max_force) f = max_force;
+          /* :215-221: the torque is only stored for link indices >= 4 (or on a floating base) */
+          if (m->is_floating || i >= 4) s->tau[l->qd_index + k] = f;
+        }
+        pose_index += 4;                                   /* :223 */
+        continue;
+      }
       double a = x[action_offset + pose_index];
       if (a > m->action_limit) a = m->action_limit;        /* :235-236 */
       if (a < -m->action_limit) a = -m->action_limit;

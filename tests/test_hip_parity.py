@@ -68,7 +68,8 @@ def test_golden_rollout_per_step(name, built):
 
 
 @pytest.mark.parametrize("name", ["ant", "laikago_soft", "pendulum5_plane", "ant_floating", "laikago_floating",
-                                  "laikago_floating_env", "sphere_spherical", "humanoid_spherical", "humanoid"])
+                                  "laikago_floating_env", "sphere_spherical", "humanoid_spherical", "humanoid",
+                                  "humanoid_sph_pd", "pendulum5_sph_pd"])
 def test_closed_loop_matches_oracle(name, built):
     """device-resident closed loop (tds_hip_step) vs the oracle stepping on the host."""
     torch = _torch()

@@ -103,7 +103,9 @@ static inline void tds_plane_space(const double *n, double *p, double *q) {
 struct TdsExpanded {
   tds_model_t m;        // links incl. pseudo links, internal dof numbering in q_index == qd_index
   int q_rec[TDS_NL], qd_rec[TDS_NL];
-  int pd_on[TDS_NL];    // the PD loop of the env step visits this link (locomotion_contact_simulation.h:180-181)
+  int pd_on[TDS_NL];    // the PD loop of the env step visits this link (locomotion_contact_simulation.h:180-181);
+                        // spherical lanes: 2 = its torque is stored (floating base or link index >= 4, :215-221), 1 = dropped
+  int sph_q[TDS_NL];    // spherical lanes: offset of the joint's quaternion in the q record (all three lanes)
   int num_spherical;
 };
 
@@ -124,7 +126,6 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   if (m->num_links < 1 || m->num_links > TDS_NL) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_links out of range");
   if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd + (fl ? 1 : 0) + nsph || m->dof_q > TDS_ND)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "dof out of range (<= 32 velocities, <= 32 coordinates) or dof_q inconsistent with the joints");
-  // (env step with spherical joints: fine as long as the PD loop does not visit them — checked with pd_on below)
   if (nsph && m->reward_mode != TDS_REWARD_NONE && m->reward_mode != TDS_REWARD_HUMANOID)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "the Ant / Laikago reward rules read a 1-dof-joint state record");
   if (m->reward_mode == TDS_REWARD_HUMANOID &&
@@ -226,9 +227,12 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     anc_links[i] = (l.parent >= 0 ? anc_links[l.parent] | (1u << l.parent) : 0u);
     d->act_index[i] = -1;
     const bool pd_here = ex ? ex->pd_on[i] != 0 : i >= m->pd_start_link;
-    if (m->step_mode == TDS_STEP_LOCOMOTION && pd_here && sph_lane)
-      TDS_FAIL(TDS_ERR_UNSUPPORTED, "the PD block's spherical branch (locomotion_contact_simulation.h:188-226) is not built");
-    if (m->step_mode == TDS_STEP_LOCOMOTION && pd_here && !fixed) {
+    if (m->step_mode == TDS_STEP_LOCOMOTION && pd_here && sph_lane) {
+      // the PD block's spherical branch (locomotion_contact_simulation.h:188-226): four pose slots per joint (:223),
+      // no action; lanes whose torque is kept carry the quaternion offset as act_index = -2 - offset
+      if (l.joint_type == TDS_JOINT_SPH0) pose_index += 4;
+      if (ex->pd_on[i] == 2) d->act_index[i] = -2 - ex->sph_q[i];
+    } else if (m->step_mode == TDS_STEP_LOCOMOTION && pd_here && !fixed) {
       if (pose_index >= m->action_dim) TDS_FAIL(TDS_ERR_INVALID_ARG, "more PD links than action_dim");
       d->act_index[i] = pose_index;
       d->init_pose[i] = (T)m->initial_poses[pose_index];
@@ -445,6 +449,7 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
   for (int k = 0; k < TDS_NL; ++k) {
     e->q_rec[k] = e->qd_rec[k] = -1;
     e->pd_on[k] = 0;
+    e->sph_q[k] = -1;
   }
   for (int k = 0; k < base; ++k) {
     tds_link_t &L = e->m.links[k];
@@ -501,7 +506,8 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
           memcpy(L.inertia, l.inertia, sizeof(L.inertia));
         }
         e->qd_rec[nx] = nqd_rec + k;
-        e->pd_on[nx] = pd;
+        e->pd_on[nx] = pd ? ((fl || i >= 4) ? 2 : 1) : 0;
+        e->sph_q[nx] = nq_rec;
         ++nx;
       }
       carrier[i] = nx - 1;

@@ -114,6 +114,18 @@ __device__ __forceinline__ float rcp_full<float>(float d) {
   return __builtin_fmaf(r, e, r);
 }
 template <typename T>
+__device__ __forceinline__ T atan2_t(T y, T x);
+template <>
+__device__ __forceinline__ double atan2_t<double>(double y, double x) { return atan2(y, x); }
+template <>
+__device__ __forceinline__ float atan2_t<float>(float y, float x) { return atan2f(y, x); }
+template <typename T>
+__device__ __forceinline__ T asin_t(T a);
+template <>
+__device__ __forceinline__ double asin_t<double>(double a) { return asin(a); }
+template <>
+__device__ __forceinline__ float asin_t<float>(float a) { return asinf(a); }
+template <typename T>
 __device__ __forceinline__ void sincos_t(T a, T *s, T *c);
 template <>
 __device__ __forceinline__ void sincos_t<double>(double a, double *s, double *c) {
@@ -809,6 +821,40 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       a = a > -lim ? a : -lim;     // Algebra::max(clamped_action, -ACTION_LIMIT)
       const T q_des = init_pose_l + a;
       T f = kp * (q_des - q) + kd * (T(0) - qd);
+      f = f > -max_force ? f : -max_force;
+      f = f < max_force ? f : max_force;
+      tau = f;
+    } else if (sph && ai <= -2) {
+      // spherical branch (locomotion_contact_simulation.h:188-226): q_desired = identity, qd_desired = 0;
+      // position_error = matrix_to_euler_xyz(quat_to_matrix(inverse(identity) * q_actual)) (matrix_utils.hpp:18-90),
+      // lane k of the joint takes component k; the clamped force goes to tau (this lane was kept by the builder:
+      // floating base or link index >= 4, :215-221)
+      const int qo = -2 - ai;
+      const int var = nq + nd + adim;
+      const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
+      const T qx = xr[qo], qy = xr[qo + 1], qz = xr[qo + 2], qw = xr[qo + 3];
+      const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);  // tiny_matrix3x3.h:315-340
+      const T xs = qx * s2, ys = qy * s2, zs = qz * s2;
+      const T wx = qw * xs, wy = qw * ys, wz = qw * zs;
+      const T xx = qx * xs, xy = qx * ys, xz = qx * zs;
+      const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
+      // get_matrix_elem(mat, k) = mat(k % 3, k / 3) (matrix_utils.hpp:11-16)
+      const T e0 = T(1) - (yy + zz), e3 = xy - wz, e1 = xy + wz, e4 = T(1) - (xx + zz);
+      const T fi = xz - wy, e5 = yz + wx, e8 = T(1) - (xx + yy);
+      const bool le = fi <= T(1), ge = fi >= T(-1);
+      const int k = jt - TDS_JOINT_SPH0;
+      T pe;
+      if (k == 1) {
+        pe = le ? (ge ? asin_t<T>(fi) : -T(1.57079632679489661923)) : T(1.57079632679489661923);
+      } else {
+        const bool mid = le && ge;
+        // k == 0: atan2(-e5, e8) | -atan2(e3, e4) | atan2(e3, e4);   k == 2: atan2(-e1, e0) | 0 | 0
+        const T ay = k == 0 ? (mid ? -e5 : e3) : -e1;
+        const T ax = k == 0 ? (mid ? e8 : e4) : e0;
+        const T a = atan2_t<T>(ay, ax);
+        pe = k == 0 ? ((le && !ge) ? -a : a) : (mid ? a : T(0));
+      }
+      T f = kp * pe + kd * (T(0) - qd);
       f = f > -max_force ? f : -max_force;
       f = f < max_force ? f : max_force;
       tau = f;
