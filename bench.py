@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
     ap.add_argument("--gather-every", type=int, default=32,
                     help="N > 1: steps whose [obs|reward|done] records travel in one all-gather (1 = every step)")
+    ap.add_argument("--gather-dtype", choices=["f32", "f64", "same"], default="f32",
+                    help="dtype the [obs | reward | done] records cross xGMI in (the step itself stays in --dtype): "
+                         "f32 = 4 B per scalar as SURVEY 8e sizes the exchange (default), same / f64 = as computed")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the N > 1 step loop (pipelined record gather) even with one rank: exercises that code path on a 1-GPU box")
     args = ap.parse_args()
@@ -230,7 +233,9 @@ def main():
     B = max(1, args.gather_every)
     if multi:
         # records of B consecutive steps travel together: [B*n, obs_dim+2] per rank and exchange
-        gather = tds_amd.sharded.PipelinedObsGather(world * n * B, sim.obs_dim + 2, tdt, f"cuda:{local_rank}")
+        wire = {"f32": torch.float32, "f64": torch.float64, "same": tdt}[args.gather_dtype]
+        gather = tds_amd.sharded.PipelinedObsGather(world * n * B, sim.obs_dim + 2, tdt, f"cuda:{local_rank}",
+                                                    wire_dtype=wire)
         ring = [torch.zeros((B, n, sim.obs_dim + 2), dtype=tdt, device="cuda") for _ in range(gather.slots)]
     state = {"i": 0}
 
@@ -359,7 +364,7 @@ def main():
                                    f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
                        if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
-                       "parallelism": f"env-shard x{world}" + (f" + RCCL all_gather of the (obs|reward|done) records of every {B} steps, overlapped with the next steps" if world > 1 else ""),
+                       "parallelism": f"env-shard x{world}" + (f" + RCCL all_gather of the (obs|reward|done) records of every {B} steps ({'f32' if args.gather_dtype == 'f32' else args.dtype} on the wire), overlapped with the next steps" if world > 1 else ""),
                        "lanes_per_env": sim.kernel_info()["lanes_per_env"],
                        "lds_bytes_per_env": sim.kernel_info()["lds_bytes_per_env"]},
             "roofline": roof, "finite": finite, "nonfinite_envs": bad_envs,

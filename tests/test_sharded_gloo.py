@@ -67,6 +67,20 @@ def _worker(rank, world, port, n_global, width, q):
                 env_all = torch.arange(0, n_global, dtype=torch.float64).unsqueeze(1)
                 ok = ok and bool(torch.equal(prev, env_all * 1000 + col + (step - 1) / 10.0))
         pg.wait_all()
+        # records produced in f64, travelling and arriving as f32 (bench.py --gather-dtype f32): integers < 2^24 are exact
+        pw = PipelinedObsGather(n_global, width, torch.float64, "cpu", wire_dtype=torch.float32)
+        local3 = [torch.zeros((hi - lo, width), dtype=torch.float64) for _ in range(pw.slots)]
+        env_all = torch.arange(0, n_global, dtype=torch.float64).unsqueeze(1)
+        for step in range(7):
+            slot = step % pw.slots
+            pw.before_reuse(slot)
+            local3[slot].copy_(env * 1000 + col + step)
+            pw.submit(local3[slot], slot)
+            if step > 0:
+                prev = pw.result((step - 1) % pw.slots)
+                ok = ok and prev.dtype == torch.float32
+                ok = ok and bool(torch.equal(prev, (env_all * 1000 + col + (step - 1)).to(torch.float32)))
+        pw.wait_all()
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
@@ -107,4 +121,16 @@ def test_pipelined_gather_side_stream_single_gpu():
         if step > 0:
             assert torch.equal(pg.result((step - 1) % pg.slots), base + (step - 1))
     pg.wait_all()
+    torch.cuda.synchronize()
+    # f64 records on an f32 wire: converted on the side stream into a staging buffer
+    pw = PipelinedObsGather(n, w, torch.float64, "cuda:0", wire_dtype=torch.float32)
+    for step in range(20):
+        slot = step % pw.slots
+        pw.before_reuse(slot)
+        bufs[slot].copy_(base + step)
+        pw.submit(bufs[slot], slot)
+        if step > 0:
+            got = pw.result((step - 1) % pw.slots)
+            assert got.dtype == torch.float32 and torch.equal(got, (base + (step - 1)).to(torch.float32))
+    pw.wait_all()
     torch.cuda.synchronize()

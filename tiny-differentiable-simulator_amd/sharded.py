@@ -77,13 +77,22 @@ class PipelinedObsGather:
         all_records = g.result(slot)          # [n_global, width] of the last submitted step
     """
 
-    def __init__(self, n_global: int, width: int, dtype, device, group=None, slots: int = 4):
+    def __init__(self, n_global: int, width: int, dtype, device, group=None, slots: int = 4, wire_dtype=None):
+        """wire_dtype: dtype the records travel and arrive in (default: `dtype`, the producer's).  The step computes
+        and keeps its state in f64; the [obs | reward | done] records a policy / learner consumes can cross xGMI as
+        f32 (SURVEY 8e sizes the exchange at 4 B per scalar): the block is converted into a per-slot staging buffer
+        on the side stream, in front of the all-gather."""
         import torch
 
         self.torch = torch
         self.slots = slots
-        self.gathers = [ObsGather(n_global, width, dtype, device, group) for _ in range(slots)]
+        self.wire_dtype = wire_dtype if wire_dtype is not None else dtype
+        self.gathers = [ObsGather(n_global, width, self.wire_dtype, device, group) for _ in range(slots)]
         self.world = self.gathers[0].world
+        self._stage = None
+        if self.wire_dtype != dtype:
+            self._stage = [torch.zeros((self.gathers[0].local_size, width), dtype=self.wire_dtype, device=device)
+                           for _ in range(slots)]
         self.is_cuda = torch.device(device).type == "cuda"
         self._work = [None] * slots
         if self.is_cuda:
@@ -104,10 +113,17 @@ class PipelinedObsGather:
             ready.record()                    # on the producer's (current) stream
             self.stream.wait_event(ready)
             with torch.cuda.stream(self.stream):
+                if self._stage is not None:
+                    self._stage[slot].copy_(local)    # dtype conversion, on the side stream
+                    local = self._stage[slot]
                 g(local)
             self._done[slot].record(self.stream)
             self._pending[slot] = True
-        elif g.world > 1 and g.equal:
+            return
+        if self._stage is not None:
+            self._stage[slot].copy_(local)
+            local = self._stage[slot]
+        if g.world > 1 and g.equal:
             self._work[slot] = g.dist.all_gather_into_tensor(g.out, local.contiguous(), group=g.group, async_op=True)
         else:
             g(local)
