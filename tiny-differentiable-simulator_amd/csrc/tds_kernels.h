@@ -18,6 +18,8 @@ struct TdsLds {
   int Xw, v;               // phase group 1 (kinematics sweep)   } the three groups alias
   int IA, pA, F, Ic, a;    // phase group 2 (dynamics sweeps)     } each other
   int Z;                   // phase group 3 (constraint rows)     }
+  int in_dim, adim, nqnd;  // record dimensions as kernel arguments: the x record is requested from HBM before anything
+                           // has been read from the model
 };
 
 // what one launch does besides the physics (see the step loop in tds_kernels.hip)

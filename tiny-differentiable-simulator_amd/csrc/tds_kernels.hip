@@ -619,6 +619,18 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   const bool valid = env < n_envs;
   T *const E = sm + grp * L.stride;
 
+  // ---- A0. the x record (and the fresh actions) are requested from HBM first: their latency runs under the
+  //      fetch of the model constants below; dimensions from the kernel arguments, not from the model
+  constexpr int XPL = (96 + G - 1) / G;  // record scalars per lane held in registers (longer records: loop in A)
+  T xpre[XPL];
+#pragma unroll
+  for (int k = 0; k < XPL; ++k) {
+    const int i = lane + k * G;
+    const bool act = actions != nullptr && i >= L.nqnd && i < L.nqnd + L.adim;
+    const T *src = act ? actions + ((size_t)env * L.adim + (i - L.nqnd)) : x_in + ((size_t)env * L.in_dim + i);
+    xpre[k] = (valid && i < L.in_dim) ? *src : T(0);
+  }
+
   const DevModel<T> *mdl = mdl_arg;
   const int nl = mdl->num_links, nq = mdl->dof_q, nd = mdl->dof_qd;
   const int in_dim = mdl->input_dim, out_dim = mdl->output_dim, adim = mdl->action_dim;
@@ -724,9 +736,15 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   TDS_STAMP(0);
   // ---- A. x record -> LDS (coalesced: consecutive lanes, consecutive doubles) ---------------
   T *const xr = E + L.xrec;
-  for (int i = lane; i < in_dim; i += G) xr[i] = valid ? x_in[(size_t)env * in_dim + i] : T(0);
-  if (actions != nullptr && valid)
-    for (int i = lane; i < adim; i += G) xr[nq + nd + i] = actions[(size_t)env * adim + i];
+#pragma unroll
+  for (int k = 0; k < XPL; ++k) {
+    const int i = lane + k * G;
+    if (i < in_dim) xr[i] = xpre[k];
+  }
+  for (int i = lane + XPL * G; i < in_dim; i += G) {
+    const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
+    xr[i] = !valid ? T(0) : act ? actions[(size_t)env * adim + (i - nq - nd)] : x_in[(size_t)env * in_dim + i];
+  }
   TDS_WAVE_SYNC();
 
   // ---- in-kernel step loop: `nsub` normal steps, then (auto / forced reset) the environments that
@@ -2067,6 +2085,9 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
   o = o > g3 ? o : g3;
   o = (o + 1) & ~1;  // keep 16-byte alignment of every env region for T = double
   L.stride = o;
+  L.in_dim = m.input_dim;
+  L.adim = m.action_dim;
+  L.nqnd = m.dof_q + m.dof_qd;
   return L;
 }
 
