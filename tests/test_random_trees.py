@@ -265,3 +265,57 @@ def test_random_spherical_tree_against_oracle(seed, built):
     sim.x.copy_(xd)
     sim.step(None, 3)
     assert rel_err(sim.y.cpu().numpy(), y1.cpu().numpy()) < 1e-9
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_spherical_tree_env_step_against_oracle(seed, built):
+    """the ENV step (PD controller, locomotion_contact_simulation.h:168-258) on random trees with spherical joints:
+    the PD loop starts at a random link, so spherical joints lie in front of it, inside it with a link index < 4
+    (visited: four pose slots, torque dropped) and inside it with an index >= 4 (euler-angle PD torque kept)"""
+    import torch
+    m, n_virtual, style = random_tree_model(1700 + seed, spherical=True)
+    rng = np.random.default_rng(5000 + seed)
+    m.step_mode = tds_amd.TDS_STEP_LOCOMOTION
+    m.pd_start_link = int(rng.integers(0, min(m.num_links, 5)))
+    slots = 0
+    for i in range(m.pd_start_link, m.num_links):
+        jt = m.links[i].joint_type
+        slots += 0 if jt == M.JOINT_FIXED else 4 if jt == M.JOINT_SPHERICAL else 1
+    if slots == 0 or slots > tds_amd.TDS_MAX_ACTIONS:
+        pytest.skip("no PD joint / more pose slots than TDS_MAX_ACTIONS")
+    m.action_dim = slots
+    for k in range(slots):
+        m.initial_poses[k] = float(rng.uniform(-0.3, 0.3))
+    m.action_limit = 0.4
+    for i in range(m.num_links):
+        m.links[i].stiffness = 0.0   # (joint springs stay with the TAU-mode tests)
+    n, nq, nd = 24, m.dof_q, m.dof_qd
+    m.input_dim = nq + nd + slots + 3
+    sph = [i for i in range(m.num_links) if m.links[i].joint_type == M.JOINT_SPHERICAL]
+    x = np.zeros((n, m.input_dim))
+    x[:, :nq] = rng.uniform(-0.6, 0.6, (n, nq))
+    if n_virtual >= 3:
+        x[:, 2] = rng.uniform(0.0, 0.4, n)
+    for i in sph:
+        quat = rng.normal(size=(n, 4))
+        x[:, m.links[i].q_index:m.links[i].q_index + 4] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+    x[:, nq + nd:nq + nd + slots] = rng.uniform(-0.6, 0.6, (n, slots))
+    x[:, -3:] = [20.0, 0.5, 5.0]
+    x[::2, -3:] = [60.0, 1.5, 2.0]       # the clamp to max_force is active
+    try:
+        y_ref = oraclelib.step(m, x)
+    except RuntimeError:
+        pytest.skip("degenerate random model (joint-space inertia not positive definite)")
+    if not np.isfinite(y_ref).all() or np.abs(y_ref).max() > 1e6:
+        pytest.skip("degenerate random model (singular joint-space inertia)")
+    x0 = x.copy()
+    x0[:, -3:] = 0.0
+    acts = np.abs(oraclelib.step(m, x0) - y_ref).max() > 1e-6     # (False: only spherical joints below link 4 in the loop)
+    sim = hip_backend.HipSim(m, n)
+    y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = rel_err(y, y_ref)
+    kept = [i for i in sph if i >= max(m.pd_start_link, 4)]
+    print(f"seed {seed}: {m.num_links} links ({len(sph)} spherical, {len(kept)} with PD torque), PD from link "
+          f"{m.pd_start_link}, {slots} pose slots, {nd} dof, controller acts: {acts}: max rel err {err:.2e}")
+    assert err < 1e-6
