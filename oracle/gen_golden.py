@@ -54,6 +54,13 @@ MODELS = {
     # base_dof_ = 0 (five spherical joints visited, link 4 keeps its euler-angle PD torque)
     "humanoid_sph_pd": dict(ref="humanoid_sph_pd"),
     "pendulum5_sph_pd": dict(ref="pendulum5_sph_pd"),
+    # joint springs / dampers (Link::stiffness / damping; never set by the URDF loader, applied by
+    # forward_dynamics.hpp:62-76 — axis-angle spring of a spherical joint — and :118-123): set on the reference's
+    # links directly.  (link, stiffness, damping)
+    "sphere_spherical_spring": dict(ref="sphere_small_xyzspherical.urdf+plane", dt=2e-3,
+                                    springs=[(3, 0.02, 0.001), (0, 3.0, 0.2), (2, 4.0, 0.1)]),
+    "pendulum5_spherical_spring": dict(ref="pendulum5spherical.urdf", dt=1e-3,
+                                       springs=[(0, 1.5, 0.02), (1, 0.7, 0.0), (2, 0.0, 0.05), (4, 3.0, 0.01)]),
 }
 
 
@@ -74,6 +81,8 @@ def make_ref(name):
     r = reflib.RefSim(spec["ref"])
     if "dt" in spec:
         r.set_dt(spec["dt"])
+    for link, k, d in spec.get("springs", ()):
+        r.set_link_spring(link, k, d)
     m = r.flatten()
     if "soft" in spec:
         m.set_soft_contact(*spec["soft"])

@@ -253,6 +253,16 @@ void tdsref_set_solver(void *h, double cfm, double erp, int pgs_iterations, doub
   s->world().default_restitution = restitution;
 }
 
+// joint spring / damper of one link (Link::stiffness, Link::damping: link.hpp:88-89; the URDF loader leaves them
+// at zero, forward_dynamics.hpp:62-76,118-123 apply them)
+int tdsref_set_link_spring(void *h, int link, double stiffness, double damping) {
+  RefSim *s = (RefSim *)h;
+  if (link < 0 || link >= (int)s->mb()->num_links()) return -1;
+  (*s->mb())[link].stiffness = stiffness;
+  (*s->mb())[link].damping = damping;
+  return 0;
+}
+
 // Flatten the reference's MultiBody + World into the C-ABI blob, through the SAME header a TDS
 // maintainer would use (include/tds_hip_stepper.hpp) — so that header is exercised here.
 int tdsref_flatten(void *h, tds_model_t *out) {

@@ -36,6 +36,8 @@ def lib():
         L.tdsref_set_gravity.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
         L.tdsref_set_solver.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double,
                                         C.c_double]
+        if hasattr(L, "tdsref_set_link_spring"):
+            L.tdsref_set_link_spring.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.tdsref_flatten.argtypes = [C.c_void_p, C.POINTER(tds_amd.Model)]
         L.tdsref_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tdsref_debug.argtypes = [C.c_void_p] + [C.c_void_p] * 7
@@ -154,6 +156,10 @@ class RefSim:
 
     def set_solver(self, cfm, erp, pgs_iterations=1, friction=1.0, restitution=0.0):
         lib().tdsref_set_solver(self.h, cfm, erp, pgs_iterations, friction, restitution)
+
+    def set_link_spring(self, link, stiffness, damping):
+        if lib().tdsref_set_link_spring(self.h, link, stiffness, damping) != 0:
+            raise RuntimeError("tdsref_set_link_spring: no such link")
 
     def flatten(self) -> "tds_amd.Model":
         m = tds_amd.Model()

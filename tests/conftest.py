@@ -11,7 +11,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 MODELS = ["cartpole", "pendulum5", "ant", "laikago", "laikago_soft", "pendulum5_plane", "cartpole_plane",
           "ant_floating", "laikago_floating", "cube_floating", "laikago_floating_env",
           "pendulum5_spherical", "sphere_spherical", "humanoid_spherical", "humanoid",
-          "humanoid_sph_pd", "pendulum5_sph_pd"]
+          "humanoid_sph_pd", "pendulum5_sph_pd", "sphere_spherical_spring", "pendulum5_spherical_spring"]
 
 
 def pytest_configure(config):

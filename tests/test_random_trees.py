@@ -98,7 +98,7 @@ def random_tree_model(seed, floating=False, spherical=False):
             c = rng.uniform(-0.1, 0.1, 3)
             for k in range(3):
                 l.com[k] = c[k]
-        l.stiffness = float(rng.uniform(0, 2)) if (rng.random() < 0.2 and jt != M.JOINT_SPHERICAL) else 0.0
+        l.stiffness = float(rng.uniform(0, 2)) if rng.random() < 0.2 else 0.0   # (spherical: axis-angle spring)
         l.damping = float(rng.uniform(0, 0.5)) if rng.random() < 0.2 else 0.0
     m.num_links = nl
     m.dof_q = m.dof_qd = m.action_dim = ndof

@@ -54,7 +54,9 @@ struct DevModel {
   T nb[3], t1[3], t2[3];  // world_normal_on_b = -n and plane_space(nb)
   // per link ---------------------------------------------------------------------------
   int parent[TDS_NL], level[TDS_NL], joint_type[TDS_NL], q_index[TDS_NL], qd_index[TDS_NL];
-  int act_index[TDS_NL];        // PD pose_index of this link or -1 (locomotion_contact_simulation.h:179-257)
+  int act_index[TDS_NL];        // PD pose_index of this link or -1 (locomotion_contact_simulation.h:179-257);
+                                // -2: lane of a spherical joint whose PD torque is kept (:188-226)
+  int sph_q[TDS_NL];            // lanes of a spherical joint: offset of the joint's quaternion in the q record, else -1
   uint32_t anc_dofs[TDS_NL];    // bit d set: dof d lies on the path base -> link (incl. own)
   // chain hand-over of the tree sweeps (lane == link): bit 0: parent == link - 1 inside one 16-lane
   // DPP row -> sweep state travels by DPP row shift; bit 1: link + 1 is such a child of mine;
@@ -226,12 +228,13 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->anc_dofs[i] = (l.parent >= 0 ? d->anc_dofs[l.parent] : 0u) | (fixed ? 0u : (1u << l.qd_index));
     anc_links[i] = (l.parent >= 0 ? anc_links[l.parent] | (1u << l.parent) : 0u);
     d->act_index[i] = -1;
+    d->sph_q[i] = sph_lane ? ex->sph_q[i] : -1;
     const bool pd_here = ex ? ex->pd_on[i] != 0 : i >= m->pd_start_link;
     if (m->step_mode == TDS_STEP_LOCOMOTION && pd_here && sph_lane) {
       // the PD block's spherical branch (locomotion_contact_simulation.h:188-226): four pose slots per joint (:223),
-      // no action; lanes whose torque is kept carry the quaternion offset as act_index = -2 - offset
+      // no action; lanes whose torque is kept carry act_index = -2
       if (l.joint_type == TDS_JOINT_SPH0) pose_index += 4;
-      if (ex->pd_on[i] == 2) d->act_index[i] = -2 - ex->sph_q[i];
+      if (ex->pd_on[i] == 2) d->act_index[i] = -2;
     } else if (m->step_mode == TDS_STEP_LOCOMOTION && pd_here && !fixed) {
       if (pose_index >= m->action_dim) TDS_FAIL(TDS_ERR_INVALID_ARG, "more PD links than action_dim");
       d->act_index[i] = pose_index;
@@ -485,7 +488,6 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
     const bool pd = m->step_mode == TDS_STEP_LOCOMOTION && i >= m->pd_start_link;
     if (l.joint_type == TDS_JOINT_SPHERICAL) {
       if (l.q_index != nq_rec || l.qd_index != nqd_rec) TDS_XFAIL("q/qd indices must be dense in link order");
-      if (l.stiffness != 0.0) TDS_XFAIL("spherical joint stiffness (axis-angle spring, forward_dynamics.hpp:70-74) is not built");
       for (int k = 0; k < 3; ++k) {
         tds_link_t &L = e->m.links[nx];
         memset(&L, 0, sizeof(L));
@@ -494,6 +496,7 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
         L.q_index = L.qd_index = ndof++;
         L.S[k] = 1.0;
         L.damping = l.damping;
+        L.stiffness = l.stiffness;  // axis-angle spring (forward_dynamics.hpp:70-74): component k on lane k
         L.X_T_rot[0] = L.X_T_rot[4] = L.X_T_rot[8] = 1.0;
         if (k == 0) {
           memcpy(L.X_T_rot, xt.R, sizeof(L.X_T_rot));

@@ -671,6 +671,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   // PD / joint constants of the link (fetched here with the other lane constants: the PD block right
   // after the x record arrives must not start with a round trip to L2)
   const int act_i = isl ? mdl->act_index[lsafe] : -1;
+  const int sphq = (sph && isl) ? mdl->sph_q[lsafe] : -1;
   const T init_pose_l = mdl->init_pose[lsafe], stiff_l = mdl->stiffness[lsafe], damp_l = mdl->damping[lsafe];
   const T act_lim = mdl->action_limit;
   const int step_mode = mdl->step_mode;
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       // position_error = matrix_to_euler_xyz(quat_to_matrix(inverse(identity) * q_actual)) (matrix_utils.hpp:18-90),
       // lane k of the joint takes component k; the clamped force goes to tau (this lane was kept by the builder:
       // floating base or link index >= 4, :215-221)
-      const int qo = -2 - ai;
+      const int qo = sphq;
       const int var = nq + nd + adim;
       const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
       const T qx = xr[qo], qy = xr[qo + 1], qz = xr[qo + 2], qw = xr[qo + 3];
@@ -882,6 +883,18 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   }
   // joint stiffness / damping (forward_dynamics.hpp:122-123)
   if (isl) tau -= stiff_l * q + damp_l * qd;
+  if constexpr (sph) {
+    // spherical joint: tau -= stiffness * quaternion_axis_angle(quat) (forward_dynamics.hpp:70-74,
+    // tiny_algebra.hpp:509-527), component k on lane k (q == 0 on these lanes)
+    if (sphq >= 0 && stiff_l != T(0)) {
+      const T qx = xr[sphq], qy = xr[sphq + 1], qz = xr[sphq + 2], qw = xr[sphq + 3];
+      const T qn = sqrt_t<T>(qx * qx + qy * qy + qz * qz);
+      const T theta = T(2) * atan2_t<T>(qn, qw);
+      // pow(epsilon, 1/4) = 2^-13
+      const T sc = qn < T(1.220703125e-4) ? T(1) / (T(0.5) + theta * theta * (T(1) / T(48))) : theta / qn;
+      tau -= stiff_l * sc * xr[sphq + (jt - TDS_JOINT_SPH0)];
+    }
+  }
 
   TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
