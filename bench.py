@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (16/32/64), 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout-steps", type=int, default=0,
-                    help="also time the on-device policy rollout with this many policy steps per launch")
+                    help="also time the on-device policy rollout (tds_hip_rollout) with this many policy steps per call")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
     ap.add_argument("--gather-every", type=int, default=32,
                     help="N > 1: steps whose [obs|reward|done] records travel in one all-gather (1 = every step)")
@@ -334,7 +334,9 @@ def main():
         dt_r = time.perf_counter() - t1
         rollout = {"value": n * args.rollout_steps * reps / dt_r, "unit": "env-steps/s",
                    "policy_steps_per_launch": args.rollout_steps, "launches": reps,
-                   "what": "linear policy + step + reward/done + return bookkeeping, one launch per rollout"}
+                   "what": "linear policy + step + reward/done + return bookkeeping on device: one launch per rollout "
+                           "(step-loop build), or from two wavefronts per SIMD on one straight-line step launch per "
+                           "step with the policy + bookkeeping kernel in between (tds_hip_rollout picks)"}
     if rank == 0:
         elem = 8 if args.dtype == "f64" else 4
         bytes_per_env_step = (m.input_dim + m.output_dim) * elem  # x record in + y record out

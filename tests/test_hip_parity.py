@@ -437,8 +437,9 @@ def _rollout_inputs(name, n, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["single", "per_step"])
 @pytest.mark.parametrize("name", ["ant", "laikago", "humanoid"])
-def test_rollout_matches_reference_worker_loop(name, built):
+def test_rollout_matches_reference_worker_loop(name, mode, built):
     """tds_hip_rollout (policy + step + reward/done + return bookkeeping in ONE launch) against the
     reference's own Worker::rollouts / VectorizedEnvironment::policy+step loop run on its header-only
     CPU path — committed fixture tests/golden/<name>_rollout.npz (oracle/gen_golden.py), and the live
@@ -457,12 +458,14 @@ def test_rollout_matches_reference_worker_loop(name, built):
     sim = hip_backend.HipSim(m, n)
     sim.x.copy_(torch.from_numpy(x).cuda())
     obs = torch.zeros((n, od + 2), dtype=torch.float64, device="cuda")
-    ret, cnt = sim.rollout(torch.from_numpy(params).cuda(), steps, shift, first_obs_raw=True, obs=obs)
+    # mode: the whole rollout in one launch of the step-loop build / one straight-line step launch per step with
+    # the policy + bookkeeping kernel in between (what tds_hip_rollout picks from 8192 Ant environments on)
+    ret, cnt = sim.rollout(torch.from_numpy(params).cuda(), steps, shift, first_obs_raw=True, obs=obs, mode=mode)
     ret, cnt, ob = ret.cpu().numpy(), cnt.cpu().numpy(), obs.cpu().numpy()
     assert np.array_equal(cnt, cnt_ref)
     err = rel_err(ret, tot_ref, 1e-3)
     ferr = rel_err(ob[:, 2:od], fin_ref[:, 2:], 1e-3)
-    print(f"{name}: return max rel err {err:.2e}, final observation {ferr:.2e}, steps {cnt.min()}..{cnt.max()}")
+    print(f"{name} [{mode}]: return max rel err {err:.2e}, final observation {ferr:.2e}, steps {cnt.min()}..{cnt.max()}")
     assert err < 1e-6 and ferr < 1e-6
     assert (ob[:, :2] == 0).all()
     assert np.array_equal(ob[:, od + 1] != 0, cnt_ref < steps)   # done latch

@@ -64,6 +64,7 @@ struct tds_hip_sim {
   TdsLds lds;
   void *d_x = nullptr, *d_y = nullptr, *d_ovf = nullptr;
   unsigned int *d_reset_count = nullptr;
+  void *d_ro = nullptr;  // scratch of the per-step-launch rollout (actions | records | returns | counts | latches)
   bool auto_reset = false;
   unsigned long long seed = 0x5DEECE66Dull;
   std::vector<double> stage;
@@ -276,6 +277,7 @@ int tds_hip_destroy(tds_hip_sim_t *s) {
   if (s->d_y) (void)hipFree(s->d_y);
   if (s->d_ovf) (void)hipFree(s->d_ovf);
   if (s->d_reset_count) (void)hipFree(s->d_reset_count);
+  if (s->d_ro) (void)hipFree(s->d_ro);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -356,11 +358,109 @@ int tds_hip_forward_zero_host(tds_hip_sim_t *s, int n, const double *x_host, dou
   return download(s, y_host, s->d_y, (size_t)n * s->model.output_dim);
 }
 
+extern "C++" {
+namespace {
+
+// Between two step launches of the per-step-launch rollout: return bookkeeping of the step just taken
+// (Worker::rollouts: a done environment is not counted and, without auto-reset, stays done) and the
+// environment's own linear policy on the new state (VectorizedEnvironment::policy -> NeuralNetwork::compute:
+// one linear layer with bias, identity; obs = [q | qd] with obs[0] = obs[1] = 0,
+// ars_vectorized_environment.h:165-180,283-300).
+template <typename T>
+__global__ void tds_policy_book_kernel(const T *__restrict__ x, int in_dim, int od, int adim,
+                                       const T *__restrict__ policy, T *__restrict__ actions,
+                                       T *__restrict__ rec, T *__restrict__ ret, int *__restrict__ cnt,
+                                       unsigned char *__restrict__ frozen, T shift, int do_book, int do_policy,
+                                       int raw_xy, int n) {
+  // one wavefront per environment; L = 2^k lanes per action, consecutive lanes on consecutive weights
+  const int env = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  const int lane = threadIdx.x & 63;
+  if (env >= n) return;
+  if (do_book && lane == 0) {
+    bool fr = frozen[env] != 0;
+    if (!fr) {
+      const T reward = rec[(size_t)env * (od + 2) + od];
+      if (rec[(size_t)env * (od + 2) + od + 1] != T(0)) {
+        frozen[env] = 1;
+        fr = true;
+      } else {
+        ret[env] += reward - shift;
+        cnt[env] += 1;
+      }
+    }
+    // after the last step the record's done column is the latch ("was done at some step"), as the one-launch
+    // rollout leaves it
+    if (!do_policy) rec[(size_t)env * (od + 2) + od + 1] = fr ? T(1) : T(0);
+  }
+  if (do_policy) {
+    int L = 64;
+    while (L * adim > 64) L >>= 1;  // adim <= TDS_MAX_ACTIONS = 32: L >= 2
+    const int a = lane / L, sub = lane - a * L;
+    const T *const W = policy + (size_t)env * (adim * od + adim);
+    const T *const xe = x + (size_t)env * in_dim;
+    T acc = T(0);
+    if (a < adim)
+      for (int o = sub; o < od; o += L) {
+        const T ob = (o < 2 && !raw_xy) ? T(0) : xe[o];
+        acc += ob * W[a * od + o];
+      }
+    for (int d = 1; d < L; d <<= 1) acc += __shfl_xor(acc, d, 64);
+    if (a < adim && sub == 0) actions[(size_t)env * adim + a] = acc + W[adim * od + a];
+  }
+}
+
+template <typename T>
+int rollout_per_step(tds_hip_sim *s, const void *policy_dev, int n_steps, double shift, int flags,
+                     void *return_sum_dev, int *return_steps_dev, void *obs_dev) {
+  const int n = s->num_envs, adim = s->model.action_dim, od = s->model.dof_q + s->model.dof_qd;
+  const size_t b_act = ((size_t)n * adim * sizeof(T) + 255) & ~(size_t)255;
+  const size_t b_rec = ((size_t)n * (od + 2) * sizeof(T) + 255) & ~(size_t)255;
+  const size_t b_ret = ((size_t)n * sizeof(T) + 255) & ~(size_t)255;
+  const size_t b_cnt = ((size_t)n * sizeof(int) + 255) & ~(size_t)255;
+  const size_t b_frz = ((size_t)n + 255) & ~(size_t)255;
+  if (!s->d_ro && hipMalloc(&s->d_ro, b_act + b_rec + b_ret + b_cnt + b_frz) != hipSuccess)
+    return fail(TDS_ERR_HIP, "hipMalloc (rollout scratch)");
+  char *base = (char *)s->d_ro;
+  T *actions = (T *)base;
+  T *rec = obs_dev ? (T *)obs_dev : (T *)(base + b_act);
+  T *ret = return_sum_dev ? (T *)return_sum_dev : (T *)(base + b_act + b_rec);
+  int *cnt = return_steps_dev ? return_steps_dev : (int *)(base + b_act + b_rec + b_ret);
+  unsigned char *frozen = (unsigned char *)(base + b_act + b_rec + b_ret + b_cnt);
+  if (hipMemsetAsync(ret, 0, (size_t)n * sizeof(T), s->stream) != hipSuccess ||
+      hipMemsetAsync(cnt, 0, (size_t)n * sizeof(int), s->stream) != hipSuccess ||
+      hipMemsetAsync(frozen, 0, (size_t)n, s->stream) != hipSuccess)
+    return fail(TDS_ERR_HIP, "hipMemsetAsync (rollout scratch)");
+  const int threads = 256, blocks = (n + threads / 64 - 1) / (threads / 64);
+  for (int t = 0; t <= n_steps; ++t) {
+    hipLaunchKernelGGL(tds_policy_book_kernel<T>, dim3(blocks), dim3(threads), 0, s->stream, (const T *)s->d_x,
+                       s->model.input_dim, od, adim, (const T *)policy_dev, actions, rec, ret, cnt, frozen,
+                       (T)shift, t > 0 ? 1 : 0, t < n_steps ? 1 : 0, ((flags & 1) && t == 0) ? 1 : 0, n);
+    if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "policy kernel launch");
+    if (t == n_steps) break;
+    const int rc = launch(s, s->d_x, s->d_y, actions, s->d_x, rec, n, 1, TDS_RESET_NONE, nullptr);
+    if (rc != TDS_OK) return rc;
+  }
+  return TDS_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
 int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, double shift, int flags,
                     void *return_sum_dev, int *return_steps_dev, void *obs_dev) {
   if (!s || !policy_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (n_steps < 1) return fail(TDS_ERR_INVALID_ARG, "n_steps < 1");
   if (s->model.action_dim < 1) return fail(TDS_ERR_INVALID_ARG, "model has no actions");
+  // One launch for the whole rollout (the step-loop build: 256 VGPR + AGPR copies, one wavefront per SIMD) or one
+  // launch per step of the straight-line build with the policy + bookkeeping kernel in between: from two
+  // wavefronts per SIMD on (8192 Ant environments) the straight-line build overlaps them and wins.
+  // flags bit 1: force the per-step launches, bit 2: force the single launch.  Auto-reset lives in the step loop.
+  const long waves = ((long)s->num_envs * s->lanes + 63) / 64;
+  const bool per_step = !s->auto_reset && !(flags & 4) && ((flags & 2) || waves >= 2048);
+  if (per_step)
+    return s->dtype == TDS_DTYPE_F64
+               ? rollout_per_step<double>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev)
+               : rollout_per_step<float>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev);
   Rollout ro;
   ro.policy = policy_dev;
   ro.ret_sum = return_sum_dev;

@@ -224,10 +224,12 @@ class HipSim:
             op = C.c_void_p(obs.data_ptr())
         _check(lib().tds_hip_reset(self.h, mp, op))
 
-    def rollout(self, policy, n_steps: int, shift: float = 0.0, first_obs_raw: bool = False, obs=None):
-        """n_steps of { action = W obs + b (per-environment linear policy); step; reward/done } in ONE
-        launch (tds_hip_rollout).  ``policy``: [N, action_dim*obs_dim + action_dim] device tensor in
-        NeuralNetwork parameter order.  Returns (return_sum [N], steps [N] int32) device tensors."""
+    def rollout(self, policy, n_steps: int, shift: float = 0.0, first_obs_raw: bool = False, obs=None, mode=None):
+        """n_steps of { action = W obs + b (per-environment linear policy); step; reward/done } on device
+        (tds_hip_rollout): in ONE launch, or — from two wavefronts per SIMD on, without auto-reset — as one
+        straight-line step launch per step with a small policy + bookkeeping kernel in between
+        (mode "per_step" / "single" forces either).  ``policy``: [N, action_dim*obs_dim + action_dim] device
+        tensor in NeuralNetwork parameter order.  Returns (return_sum [N], steps [N] int32) device tensors."""
         import torch
 
         adim, od = self.model.action_dim, self.obs_dim
@@ -241,7 +243,8 @@ class HipSim:
             assert tuple(obs.shape) == (self.num_envs, od + 2)
             op = C.c_void_p(obs.data_ptr())
         _check(lib().tds_hip_rollout(self.h, C.c_void_p(policy.data_ptr()), int(n_steps), C.c_double(shift),
-                                     1 if first_obs_raw else 0, C.c_void_p(ret.data_ptr()),
+                                     (1 if first_obs_raw else 0) | {None: 0, "per_step": 2, "single": 4}[mode],
+                                     C.c_void_p(ret.data_ptr()),
                                      C.c_void_p(steps.data_ptr()), op))
         return ret, steps
 
