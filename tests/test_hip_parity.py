@@ -373,7 +373,11 @@ def test_forced_reset_matches_host_emulation(name, built):
         assert rel_err(x2[e, :nqd], ref) < TOL
 
 
-def test_auto_reset_inside_step(built):
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_auto_reset_inside_step(split, built, monkeypatch):
+    """split = 0: reset + settle inside the step launch (step-loop build); 1: straight-line step launch followed by
+    a forced-reset launch masked with the done flags (what tds_hip_step_obs picks from two wavefronts per SIMD on)"""
+    monkeypatch.setenv("TDS_HIP_AUTO_RESET_SPLIT", split)
     torch = _torch()
     m = tds_amd.load_model("ant")
     g = np.load(os.path.join(GOLDEN, "ant.npz"))
@@ -472,9 +476,12 @@ def test_rollout_matches_reference_worker_loop(name, mode, built):
 
 
 @pytest.mark.gpu
-def test_rollout_equals_stepwise_launches_with_auto_reset(built):
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_rollout_equals_stepwise_launches_with_auto_reset(split, built, monkeypatch):
     """the same rollout driven step by step from the host (policy in numpy, one launch per step,
-    auto-reset inside the step) must give the same returns / step counts / final state."""
+    auto-reset inside the step — or as the two-launch form, split = 1) must give the same returns / step counts /
+    final state."""
+    monkeypatch.setenv("TDS_HIP_AUTO_RESET_SPLIT", split)
     torch = _torch()
     n, steps, shift, seed = 32, 40, 0.1, 1234
     m, x, params = _rollout_inputs("ant", n, 5)

@@ -64,6 +64,7 @@ struct tds_hip_sim {
   TdsLds lds;
   void *d_x = nullptr, *d_y = nullptr, *d_ovf = nullptr;
   unsigned int *d_reset_count = nullptr;
+  void *d_split = nullptr;  // records + done mask of the two-launch auto-reset step
   void *d_ro = nullptr;  // scratch of the per-step-launch rollout (actions | records | returns | counts | latches)
   bool auto_reset = false;
   unsigned long long seed = 0x5DEECE66Dull;
@@ -278,6 +279,7 @@ int tds_hip_destroy(tds_hip_sim_t *s) {
   if (s->d_ovf) (void)hipFree(s->d_ovf);
   if (s->d_reset_count) (void)hipFree(s->d_reset_count);
   if (s->d_ro) (void)hipFree(s->d_ro);
+  if (s->d_split) (void)hipFree(s->d_split);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -318,9 +320,46 @@ int tds_hip_forward_zero_device(tds_hip_sim_t *s, const void *x_dev, void *y_dev
   return launch(s, x_dev, y_dev, nullptr, nullptr, nullptr, s->num_envs, 1, TDS_RESET_NONE, nullptr);
 }
 
+extern "C++" {
+namespace {
+// done column of the [obs | reward | done] records -> byte mask of tds_hip_reset
+template <typename T>
+__global__ void tds_done_mask_kernel(const T *__restrict__ rec, int width, unsigned char *__restrict__ mask, int n) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env < n) mask[env] = rec[(size_t)env * width + width - 1] != T(0) ? 1 : 0;
+}
+}  // namespace
+}  // extern "C++"
+
 int tds_hip_step_obs(tds_hip_sim_t *s, const void *actions_dev, int substeps, void *obs_dev) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   if (substeps < 1) return fail(TDS_ERR_INVALID_ARG, "substeps must be >= 1");
+  // Auto-reset at large batches: the in-kernel reset needs the step-loop build (one wavefront per SIMD whatever
+  // the batch).  From two wavefronts per SIMD on, a single step is cheaper as the straight-line launch followed by
+  // a forced-reset launch masked with the done flags (idle lane groups leave at once); same random stream
+  // (seed, environment, reset counter), same records.  TDS_HIP_AUTO_RESET_SPLIT=1 / 0 forces / forbids it.
+  if (s->auto_reset && substeps == 1) {
+    const char *e = getenv("TDS_HIP_AUTO_RESET_SPLIT");
+    const long waves = ((long)s->num_envs * s->lanes + 63) / 64;
+    if (e ? e[0] == '1' : waves >= 2048) {
+      const int n = s->num_envs, w = s->model.dof_q + s->model.dof_qd + 2;
+      const size_t b_rec = ((size_t)n * w * s->elem + 255) & ~(size_t)255;
+      if (!s->d_split && hipMalloc(&s->d_split, b_rec + n) != hipSuccess)
+        return fail(TDS_ERR_HIP, "hipMalloc (auto-reset scratch)");
+      void *rec = obs_dev ? obs_dev : s->d_split;
+      unsigned char *mask = (unsigned char *)s->d_split + b_rec;
+      int rc = launch(s, s->d_x, s->d_y, actions_dev, s->d_x, rec, n, 1, TDS_RESET_NONE, nullptr);
+      if (rc != TDS_OK) return rc;
+      if (s->dtype == TDS_DTYPE_F64)
+        hipLaunchKernelGGL(tds_done_mask_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, s->stream,
+                           (const double *)rec, w, mask, n);
+      else
+        hipLaunchKernelGGL(tds_done_mask_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s->stream,
+                           (const float *)rec, w, mask, n);
+      if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "mask kernel launch");
+      return launch(s, s->d_x, s->d_y, nullptr, s->d_x, obs_dev, n, 0, TDS_RESET_FORCED, mask);
+    }
+  }
   // ONE launch: the kernel loops over the substeps (same action) with the state kept in LDS, writes
   // y / reward / done of the last substep and, with auto-reset on, re-initialises + settles the
   // environments that ended with done before it writes their observation and resident state
