@@ -105,8 +105,14 @@ enum {
   TDS_REWARD_HUMANOID = 3
 };
 
-/* scalar type the kernels compute in */
-enum { TDS_DTYPE_F64 = 0, TDS_DTYPE_F32 = 1 };
+/* scalar types: what the kernels compute in / what the records in HBM (x, y, actions, obs, policy) are stored in.
+   F64        double / double — the reference's arithmetic; parity-gated at 1e-6 (measured <= 4e-11 per step)
+   F32        float / float   — pure single precision; measured, NOT gated: the mass-matrix factorisation loses the
+                                1e-6 contract in float (8e-6 without contacts, 1e-3 with), as does the reference's own
+                                TinyAlgebra<float> instantiation (tests/test_f32.py)
+   F64_REC32  double / float  — the reference's FLOAT record ABI (BASELINE config 2; half the bytes per env-step) with
+                                the arithmetic kept in double registers: parity-gated at 1e-6 on float inputs */
+enum { TDS_DTYPE_F64 = 0, TDS_DTYPE_F32 = 1, TDS_DTYPE_F64_REC32 = 2 };
 
 /* All 3x3 matrices are row-major: m[3*r+c].  Transforms are TDS "right-associative":
    X.rot maps child-frame vectors into the parent frame, X.trans is the child origin in the
@@ -180,7 +186,11 @@ typedef struct tds_model {
   double reset_q[TDS_MAX_DOF];
   double reset_noise[TDS_MAX_DOF];
   int32_t settle_steps;
-  int32_t pad2_;
+  /* 1: the observation tds_hip_reset hands out keeps the raw base x, y — what LaikagoContactSimulation::reset and
+     HumanoidContactSimulation::reset return (laikago_environment2.h:63-116); 0: obs[0] = obs[1] = 0 as
+     AntContactSimulation2::reset does (ant_environment2.h:162-163).  The STEP's observation always zeroes them
+     (ars_vectorized_environment.h:283-288).  (Occupies the former padding slot: layout unchanged.) */
+  int32_t reset_obs_raw_xy;
   /* rigid-body inertia of the base link, mb.base_rbi() (multi_body.hpp:78); used only when is_floating */
   double base_mass;
   double base_com[3];
@@ -205,8 +215,9 @@ int tds_hip_device_count(void);
 int tds_hip_model_check(const tds_model_t *model);
 
 /* Create a simulation of num_envs independent copies of `model` on HIP device `device`.
-   dtype = TDS_DTYPE_F64 (parity-gated) or TDS_DTYPE_F32.  Device buffers owned by the
-   handle: x [N][input_dim], y [N][output_dim] (both in the compute dtype). */
+   dtype = TDS_DTYPE_*.  Device buffers owned by the handle: x [N][input_dim], y [N][output_dim] (both in the
+   record dtype).  Every entry point selects the handle's device for the duration of the call and restores the
+   caller's current device: one process may hold handles on several GPUs. */
 int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype,
                    tds_hip_sim_t **out);
 int tds_hip_destroy(tds_hip_sim_t *sim);
@@ -219,6 +230,10 @@ int tds_hip_num_envs(const tds_hip_sim_t *sim);
 int tds_hip_input_dim(const tds_hip_sim_t *sim);
 int tds_hip_output_dim(const tds_hip_sim_t *sim);
 int tds_hip_dtype(const tds_hip_sim_t *sim);
+int tds_hip_device(const tds_hip_sim_t *sim);
+int tds_hip_record_bytes(const tds_hip_sim_t *sim); /* bytes per scalar of the records: 8 (F64) or 4 */
+/* wait for everything enqueued on the handle's stream */
+int tds_hip_sync(tds_hip_sim_t *sim);
 
 /* Device pointers of the resident records, for zero-copy consumers (e.g. a torch tensor
    wrapping them).  Layout: env-major [N][dim], compute dtype. */
@@ -251,6 +266,18 @@ int tds_hip_step(tds_hip_sim_t *sim, const void *actions_dev, int substeps);
    job all-gathers. */
 int tds_hip_step_obs(tds_hip_sim_t *sim, const void *actions_dev, int substeps, void *obs_dev);
 int tds_hip_obs_dim(const tds_hip_sim_t *sim);
+
+/* n_steps closed-loop steps (tds_hip_step_obs with substeps = 1, no auto-reset) per host call, replayed from a
+   captured hipGraph: ONE graph launch instead of n_steps kernel launches, which removes the host-side launch gaps
+   that cost a double-digit share of short runs at ~20 us per step.
+     actions_dev  [action_blocks][N][action_dim] (record dtype) or NULL; step k uses block (first_block + k) % action_blocks
+     obs_dev      optional [N][obs_dim + 2], overwritten by every step (holds the last step's record afterwards)
+   The graph is cached on the handle (keyed by all arguments); _prepare builds it without running anything, so that a
+   timed region holds the launch only.  n_steps <= 4096. */
+int tds_hip_step_many_prepare(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int first_block,
+                              int n_steps, void *obs_dev);
+int tds_hip_step_many(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int first_block, int n_steps,
+                      void *obs_dev);
 
 /* On-device environment reset — replaces the host loop of VectorizedEnvironment::reset / the
    auto-reset branch of VectorizedEnvironment::step (ars_vectorized_environment.h:196-211, 262-277).
@@ -295,6 +322,11 @@ int tds_hip_rollout(tds_hip_sim_t *sim, const void *policy_dev, int n_steps, dou
 /* Blocking convenience with HOST buffers in double, any N <= num_envs:
    H2D(x) -> kernel -> D2H(y), i.e. exactly what the reference's <model>_forward_zero does. */
 int tds_hip_forward_zero_host(tds_hip_sim_t *sim, int n, const double *x_host, double *y_host);
+/* The same call in two halves (F64 records only): _begin enqueues H2D -> kernel -> D2H on the handle's stream and
+   returns, _end waits.  A host that drives several devices enqueues every device's share before it waits
+   (include/tds_hip_stepper.hpp: HipStepper with a device list). */
+int tds_hip_forward_zero_host_begin(tds_hip_sim_t *sim, int n, const double *x_host, double *y_host);
+int tds_hip_forward_zero_host_end(tds_hip_sim_t *sim);
 
 /* The same call split the way the reference's newer generated-library ABI splits it
    (src/utils/cuda/cuda_function.hpp:11-20, 78-99: <fn>_send_local, then <fn>):
@@ -303,8 +335,9 @@ int tds_hip_forward_zero_host(tds_hip_sim_t *sim, int n, const double *x_host, d
 int tds_hip_send_local(tds_hip_sim_t *sim, int n, const double *x_host);
 int tds_hip_forward_zero_fetch(tds_hip_sim_t *sim, int n, double *y_host);
 
-/* Time of the most recent kernel launch sequence measured with HIP events on the handle's
-   stream, in milliseconds (enabled by tds_hip_set_timing(sim, 1); synchronises). */
+/* Duration of the most recent stepping CALL (all of its launches: one for a plain step, two for the split
+   auto-reset step, 2 n + 1 for a per-step-launch rollout, the whole graph for tds_hip_step_many) measured with HIP
+   events on the handle's stream, in milliseconds (enabled by tds_hip_set_timing(sim, 1); synchronises). */
 int tds_hip_set_timing(tds_hip_sim_t *sim, int enable);
 int tds_hip_last_kernel_ms(tds_hip_sim_t *sim, float *ms);
 
@@ -319,6 +352,60 @@ int tds_hip_profile_phases(tds_hip_sim_t *sim, long long *cycles_host, int n);
 /* Static resource usage of the step kernel for this handle (for DESIGN.md / bench). */
 int tds_hip_kernel_info(const tds_hip_sim_t *sim, int *lds_bytes_per_env, int *threads_per_env,
                         int *envs_per_block);
+
+/* ======================================================================================
+ * Multi-GPU: the global batch of environments is cut into equal contiguous shards, one per rank /
+ * GPU (rank r owns environments [r N/G, (r+1) N/G)); each shard is an ordinary tds_hip_sim on its own device, the
+ * model constants are replicated, and there is NO collective inside the step.  The one exchange is an all-gather of
+ * the [obs | reward | done] records, once per policy step, over RCCL / xGMI — called from here (librccl is loaded
+ * with dlopen at first use), on a private communication stream, overlapped with the following steps.  New
+ * functionality: the reference has no multi-device path.
+ *
+ *   one process per GPU:   rank 0: tds_hip_shard_unique_id(id) -> ship the 128 bytes to the other ranks by any
+ *                          means (MPI, a file, torch.distributed) -> every rank: tds_hip_shard_create(..., id, ...)
+ *   one process, G GPUs:   tds_hip_shard_create_all(model, N, G, devices, ...) and tds_hip_shard_group_step
+ *   then per policy step:  tds_hip_shard_step(shard, actions_of_my_shard, substeps)
+ *   consumer:              tds_hip_shard_gathered(shard, consumer_stream, &records, &steps_in_block): the gathered
+ *                          records of the most recently submitted exchange, [world][block][n_local][obs_dim + 2]
+ *                          in the wire dtype (block = 1: [N][obs_dim + 2] in global environment order); the
+ *                          consumer's stream is made to wait for the exchange, the host never blocks.
+ * ====================================================================================== */
+#define TDS_SHARD_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+typedef struct tds_hip_shard tds_hip_shard_t;
+
+/* version of the RCCL library found at run time (ncclGetVersion), 0 if none can be loaded */
+int tds_hip_shard_rccl_version(void);
+int tds_hip_shard_unique_id(void *id_out /* TDS_SHARD_ID_BYTES */);
+/* This rank's shard of `global_envs` environments (a multiple of `world`) on HIP device `device`.
+   dtype: TDS_DTYPE_* of the shard's sim.  wire_dtype: TDS_DTYPE_F32 (4 bytes per scalar on the wire, as SURVEY 8e
+   sizes the exchange; F64 records are converted on the communication stream) or TDS_DTYPE_F64 (as computed).
+   unique_id NULL is allowed for world == 1 only: the "exchange" is then a device copy (no RCCL needed).
+   Collective: every rank of the communicator must call it. */
+int tds_hip_shard_create(const tds_model_t *model, int global_envs, int rank, int world, int device, int dtype,
+                         const void *unique_id, int wire_dtype, tds_hip_shard_t **out);
+/* One process driving n_devices GPUs (ncclCommInitAll): out[i] = shard of rank i on devices[i]. */
+int tds_hip_shard_create_all(const tds_model_t *model, int global_envs, int n_devices, const int *devices, int dtype,
+                             int wire_dtype, tds_hip_shard_t **out /* [n_devices] */);
+int tds_hip_shard_destroy(tds_hip_shard_t *shard);
+/* the shard's simulation: every tds_hip_* call (state upload, reset, auto-reset, streams ...) applies to it */
+tds_hip_sim_t *tds_hip_shard_sim(tds_hip_shard_t *shard);
+int tds_hip_shard_rank(const tds_hip_shard_t *shard);
+int tds_hip_shard_world(const tds_hip_shard_t *shard);
+int tds_hip_shard_local_envs(const tds_hip_shard_t *shard);
+int tds_hip_shard_first_env(const tds_hip_shard_t *shard); /* global index of the shard's first environment */
+int tds_hip_shard_wire_bytes(const tds_hip_shard_t *shard);
+/* Records of `steps_per_exchange` consecutive steps travel in ONE all-gather (default 1 = SURVEY 8e's protocol:
+   one exchange per policy step).  Larger blocks trade observation latency for fewer collectives.  Flushes. */
+int tds_hip_shard_set_block(tds_hip_shard_t *shard, int steps_per_exchange);
+/* One closed-loop step of the shard (tds_hip_step_obs into the ring's record block) and, when the block is complete,
+   its all-gather on the communication stream.  Asynchronous. */
+int tds_hip_shard_step(tds_hip_shard_t *shard, const void *actions_dev, int substeps);
+/* The same for all shards of one process (tds_hip_shard_create_all): the steps are enqueued device by device, the
+   all-gathers go out as one RCCL group. */
+int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const *actions_dev, int substeps);
+/* Exchange a partially filled block, then wait (host) until every exchange in flight has completed. */
+int tds_hip_shard_flush(tds_hip_shard_t *shard);
+int tds_hip_shard_gathered(tds_hip_shard_t *shard, void *consumer_stream, void **records_dev, int *steps_in_block);
 
 /* ======================================================================================
  * Free rigid bodies: World::step for worlds that hold tds::RigidBody

@@ -170,6 +170,9 @@ int flatten_locomotion_env(Sim &sim, tds_model_t *out, int reward_mode = TDS_REW
   out->output_dim = sim.output_dim();
   out->pack_visuals = 1;
   out->reward_mode = reward_mode;
+  // what the environment's own reset() hands out as observation: AntContactSimulation2 zeroes the base x, y
+  // (ant_environment2.h:162-163), Laikago / Humanoid return the state as it is (laikago_environment2.h:63-116)
+  out->reset_obs_raw_xy = (reward_mode == TDS_REWARD_LAIKAGO || reward_mode == TDS_REWARD_HUMANOID) ? 1 : 0;
   out->action_limit = 0.4;  // locomotion_contact_simulation.h:234
   for (size_t i = 0; i < sim.initial_poses_.size(); ++i) out->initial_poses[i] = Algebra::to_double(sim.initial_poses_[i]);
   // reset distribution of the fixed-base locomotion envs (ant_environment2.h:124-135,

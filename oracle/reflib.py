@@ -51,8 +51,34 @@ def lib():
         if hasattr(L, "tdsref_rollout"):
             L.tdsref_rollout.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "tdsref_f32_create"):
+            L.tdsref_f32_create.restype = C.c_void_p
+            L.tdsref_f32_create.argtypes = [C.c_char_p, C.c_char_p, C.c_double]
+            L.tdsref_f32_destroy.argtypes = [C.c_void_p]
+            L.tdsref_f32_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
+
+
+class RefSimF32:
+    """The reference's own FLOAT instantiation (TinyAlgebra<float, FloatUtils>, oracle/ref_harness_f32.cpp) of the
+    step: name "ant" | "laikago" | "<file>.urdf[+plane]".  Host doubles in / out (rounded to float on entry)."""
+
+    def __init__(self, name, in_dim, out_dim, dt=1e-3):
+        self.h = C.c_void_p(lib().tdsref_f32_create(name.encode(), REF_ROOT.encode(), float(dt)))
+        assert self.h, name
+        self.in_dim, self.out_dim = int(in_dim), int(out_dim)
+
+    def step(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.in_dim)
+        y = np.zeros((x.shape[0], self.out_dim))
+        lib().tdsref_f32_step(self.h, x.shape[0], self.in_dim, self.out_dim, x.ctypes.data, y.ctypes.data)
+        return y
+
+    def close(self):
+        if self.h:
+            lib().tdsref_f32_destroy(self.h)
+            self.h = None
 
 
 def hipstepper_selftest(batch=8, steps=5, env="ant"):

@@ -1,0 +1,139 @@
+"""Float records (BASELINE config 2 says "float") — what meets the 1e-6 per-step contract and what does not.
+
+* ``dtype="mixed"`` (TDS_DTYPE_F64_REC32): the reference's FLOAT record ABI (x, y, actions, obs in float: half the
+  bytes per env-step) with the arithmetic in double registers.  Parity-GATED at 1e-6 on float-representable inputs.
+* ``dtype="f32"`` (pure float): measured against the reference's OWN float instantiation
+  (TinyAlgebra<float, FloatUtils>, oracle/ref_harness_f32.cpp -> tests/golden/f32_reference.npz): the reference's
+  float path itself is 8e-6 (pendulum5) ... 4e-3 (Ant) away from its double path, i.e. float ARITHMETIC cannot meet
+  the contract, whoever does it; the pure-float kernels must merely be no worse than the reference's float path.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, MODELS, rel_err
+
+import tds_amd
+import oraclelib
+
+TOL = 1e-6
+F32_MODELS = ["pendulum5", "cartpole", "ant", "laikago", "pendulum5_plane"]
+
+
+def _fixture():
+    return np.load(os.path.join(GOLDEN, "f32_reference.npz"))
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU: the fixture is what the reference computes; the oracle agrees with its double half
+# ------------------------------------------------------------------------------------------------
+def test_f32_fixture_is_the_reference_float_path():
+    reflib = pytest.importorskip("reflib")
+    if not reflib.available() or not hasattr(reflib.lib(), "tdsref_f32_create"):
+        pytest.skip("reference library not built here")
+    import gen_golden_f32 as gen
+
+    f = _fixture()
+    for name, refname in gen.MODELS.items():
+        m = tds_amd.load_model(name)
+        rf = reflib.RefSimF32(refname, m.input_dim, m.output_dim, m.dt)
+        y32 = rf.step(f[name + "_x"])
+        rf.close()
+        assert np.array_equal(y32, f[name + "_y32"]), name
+
+
+@pytest.mark.parametrize("name", F32_MODELS)
+def test_oracle_matches_reference_double_on_float_inputs(name, built):
+    f = _fixture()
+    m = tds_amd.load_model(name)
+    y = oraclelib.step(m, f[name + "_x"])
+    assert rel_err(y, f[name + "_y64"]) < 1e-9
+
+
+def test_reference_float_arithmetic_misses_the_contract():
+    """Known answers (measured on the reference itself): its float path is NOT within 1e-6 of its double path."""
+    f = _fixture()
+    err = {n: rel_err(f[n + "_y32"], f[n + "_y64"]) for n in F32_MODELS}
+    print({k: f"{v:.2e}" for k, v in err.items()})
+    assert 1e-6 < err["pendulum5"] < 1e-4      # 8.3e-6 (config 2's model)
+    assert 1e-4 < err["ant"] < 1e-1            # 3.8e-3 (contacts + 51-row PGS)
+    assert err["cartpole"] < 1e-5              # 7.5e-7
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODELS)
+def test_mixed_records_meet_the_contract(name, built):
+    """float records / double arithmetic, every golden model: HIP (float out) vs the oracle in double on the same
+    float-representable inputs, gated at 1e-6."""
+    torch = _torch()
+    from tds_amd import hip_backend
+
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x32 = g["x"].astype(np.float32)
+    sim = hip_backend.HipSim(m, x32.shape[0], dtype="mixed")
+    assert sim.torch_dtype == torch.float32
+    y = sim.forward_zero(torch.from_numpy(x32).cuda())
+    assert y.dtype == torch.float32
+    y_ref = oraclelib.step(m, x32.astype(np.float64))
+    err = rel_err(y.double().cpu().numpy(), y_ref)
+    print(f"{name} mixed: {err:.3e}")
+    assert err < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n", [("pendulum5", 4096), ("ant", 4096), ("laikago_soft", 8192)])
+def test_mixed_full_size_closed_loop(name, n, built):
+    """BASELINE configs 2 / 3 / 4 at full size with float records: 20 closed-loop steps, EVERY environment compared
+    with the oracle (double) started from the float state the device held before the step (per-step resync)."""
+    torch = _torch()
+    from tds_amd import hip_backend
+
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    rng = np.random.default_rng(11)
+    x0 = g["x"][rng.integers(0, g["x"].shape[0], n)].astype(np.float32)
+    sim = hip_backend.HipSim(m, n, dtype="mixed")
+    sim.x.copy_(torch.from_numpy(x0).cuda())
+    nqd, adim = m.dof_q + m.dof_qd, m.action_dim
+    amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
+    worst = 0.0
+    for t in range(20):
+        a = rng.uniform(-amp, amp, (n, adim)).astype(np.float32)
+        x_before = sim.x.cpu().numpy().astype(np.float64)
+        x_before[:, nqd:nqd + adim] = a
+        sim.step(torch.from_numpy(a).cuda())
+        y_ref = oraclelib.step(m, x_before)
+        y = sim.y.double().cpu().numpy()
+        ok = np.isfinite(y_ref).all(axis=1)
+        worst = max(worst, rel_err(y[ok], y_ref[ok]))
+        assert np.array_equal(sim.x[:, :nqd].cpu().numpy(), sim.y[:, :nqd].cpu().numpy())  # state fed back as written
+    print(f"{name} x{n} mixed closed loop: worst per-step {worst:.3e}")
+    assert worst < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", F32_MODELS)
+def test_pure_f32_is_no_worse_than_the_reference_float_path(name, built):
+    torch = _torch()
+    from tds_amd import hip_backend
+
+    f = _fixture()
+    m = tds_amd.load_model(name)
+    x = f[name + "_x"]
+    sim = hip_backend.HipSim(m, x.shape[0], dtype="f32")
+    y = sim.forward_zero(torch.from_numpy(x).float().cuda()).double().cpu().numpy()
+    e_hip = rel_err(y, f[name + "_y64"])
+    e_ref = rel_err(f[name + "_y32"], f[name + "_y64"])
+    print(f"{name}: HIP f32 vs reference double {e_hip:.3e}; reference float vs reference double {e_ref:.3e}")
+    assert e_hip < 4.0 * e_ref + 1e-6

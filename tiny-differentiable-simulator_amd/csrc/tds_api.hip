@@ -15,27 +15,16 @@
 #include <new>
 #include <vector>
 
-#include "tds_device_model.h"
-#include "tds_hip.h"
-#include "tds_kernels.h"
+#include "tds_api_internal.h"
+
+namespace tds_internal {
+thread_local char g_err[512] = "";
+}
+using namespace tds_internal;
+
+#define HIP_TRY TDS_HIP_TRY
 
 namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, const char *detail = "") {
-  snprintf(g_err, sizeof(g_err), fmt, detail);
-  return code;
-}
-
-#define HIP_TRY(expr)                                                                      \
-  do {                                                                                     \
-    hipError_t e_ = (expr);                                                                \
-    if (e_ != hipSuccess) {                                                                \
-      snprintf(g_err, sizeof(g_err), "%s failed: %s", #expr, hipGetErrorString(e_));       \
-      return TDS_ERR_HIP;                                                                  \
-    }                                                                                      \
-  } while (0)
 
 // lanes per environment: the smallest wave-group that holds every link and every padded dof
 int default_lanes_per_env(int num_links, int dof) {
@@ -51,84 +40,24 @@ int default_lanes_per_env(int num_links, int dof) {
   return need <= 16 ? 16 : (need <= 32 ? 32 : 64);
 }
 
-}  // namespace
-
-struct tds_hip_sim {
-  tds_model_t model;
-  int num_envs = 0, device = 0, dtype = TDS_DTYPE_F64, lanes = 64;
-  size_t elem = 8;
-  hipStream_t stream = nullptr;
-  void *d_model = nullptr;  // DevModel<T>
-  DevModel<double> h64;
-  DevModel<float> h32;
-  TdsLds lds;
-  void *d_x = nullptr, *d_y = nullptr, *d_ovf = nullptr;
-  unsigned int *d_reset_count = nullptr;
-  void *d_split = nullptr;  // records + done mask of the two-launch auto-reset step
-  void *d_ro = nullptr;  // scratch of the per-step-launch rollout (actions | records | returns | counts | latches)
-  bool auto_reset = false;
-  unsigned long long seed = 0x5DEECE66Dull;
-  std::vector<double> stage;
-  bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float last_ms = 0.f;
-  bool have_ms = false;
-
-  int input_dim() const { return model.input_dim; }
-  int output_dim() const { return model.output_dim; }
+// API-level timing (tds_hip_set_timing): ev0 when the entry point starts enqueueing, ev1 after its LAST launch, so
+// that multi-launch forms (auto-reset split, per-step rollout, step_many) report the whole sequence
+struct TimedCall {
+  tds_hip_sim *s;
+  explicit TimedCall(tds_hip_sim *sim) : s(sim) {
+    if (s->timing) (void)hipEventRecord(s->ev0, s->stream);
+  }
+  ~TimedCall() {
+    if (s->timing) {
+      (void)hipEventRecord(s->ev1, s->stream);
+      s->have_ms = true;
+    }
+  }
 };
 
-namespace {
-
-struct Rollout {
-  const void *policy;
-  void *ret_sum;
-  int *ret_steps;
-  double shift;
-  int flags;
-};
-
-int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n, int nsub,
-           int reset_mode, const unsigned char *mask, const Rollout *ro = nullptr) {
-  if (s->timing) (void)hipEventRecord(s->ev0, s->stream);
-  TdsStepCtl ctl;
-  memset(&ctl, 0, sizeof(ctl));
-  if (ro) {
-    ctl.policy = ro->policy;
-    ctl.ret_sum = ro->ret_sum;
-    ctl.ret_steps = ro->ret_steps;
-    ctl.shift = ro->shift;
-    ctl.flags = ro->flags;
-  }
-  ctl.nsub = nsub;
-  ctl.reset_mode = reset_mode;
-  ctl.settle_steps = s->model.settle_steps < 0 ? 0 : s->model.settle_steps;
-  ctl.seed = s->seed;
-  ctl.mask = mask;
-  ctl.reset_count = s->d_reset_count;
-  int rc;
-  if (s->dtype == TDS_DTYPE_F64)
-    rc = tds_launch_step<double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes, (const double *)x,
-                                 (double *)y, (const double *)actions, (double *)fb, (double *)obs,
-                                 (double *)s->d_ovf, n, s->stream, ctl);
-  else
-    rc = tds_launch_step<float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)x,
-                                (float *)y, (const float *)actions, (float *)fb, (float *)obs, (float *)s->d_ovf, n,
-                                s->stream, ctl);
-  if (rc != 0) {
-    snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad lanes_per_env");
-    return TDS_ERR_HIP;
-  }
-  if (s->timing) {
-    (void)hipEventRecord(s->ev1, s->stream);
-    s->have_ms = true;
-  }
-  return TDS_OK;
-}
-
-// host double <-> device compute dtype
+// host double <-> device record dtype
 int upload(tds_hip_sim *s, void *dst, const double *src, size_t count) {
-  if (s->dtype == TDS_DTYPE_F64) {
+  if (s->records_f64()) {
     HIP_TRY(hipMemcpyAsync(dst, src, count * 8, hipMemcpyHostToDevice, s->stream));
   } else {
     std::vector<float> tmp(count);
@@ -139,7 +68,7 @@ int upload(tds_hip_sim *s, void *dst, const double *src, size_t count) {
   return TDS_OK;
 }
 int download(tds_hip_sim *s, double *dst, const void *src, size_t count) {
-  if (s->dtype == TDS_DTYPE_F64) {
+  if (s->records_f64()) {
     HIP_TRY(hipMemcpyAsync(dst, src, count * 8, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   } else {
@@ -151,7 +80,51 @@ int download(tds_hip_sim *s, double *dst, const void *src, size_t count) {
   return TDS_OK;
 }
 
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 }  // namespace
+
+namespace tds_internal {
+
+int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n, int nsub,
+           int reset_mode, const unsigned char *mask, const Rollout *ro, int ctl_flags) {
+  TdsStepCtl ctl;
+  memset(&ctl, 0, sizeof(ctl));
+  if (ro) {
+    ctl.policy = ro->policy;
+    ctl.ret_sum = ro->ret_sum;
+    ctl.ret_steps = ro->ret_steps;
+    ctl.shift = ro->shift;
+    ctl.flags = ro->flags;
+  }
+  ctl.flags |= ctl_flags;
+  ctl.nsub = nsub;
+  ctl.reset_mode = reset_mode;
+  ctl.settle_steps = s->model.settle_steps < 0 ? 0 : s->model.settle_steps;
+  ctl.seed = s->seed;
+  ctl.mask = mask;
+  ctl.reset_count = s->d_reset_count;
+  int rc;
+  if (s->dtype == TDS_DTYPE_F64)
+    rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes,
+                                         (const double *)x, (double *)y, (const double *)actions, (double *)fb,
+                                         (double *)obs, (double *)s->d_ovf, n, s->stream, ctl);
+  else if (s->dtype == TDS_DTYPE_F64_REC32)
+    rc = tds_launch_step<double, float>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes,
+                                        (const float *)x, (float *)y, (const float *)actions, (float *)fb, (float *)obs,
+                                        (double *)s->d_ovf, n, s->stream, ctl);
+  else
+    rc = tds_launch_step<float, float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)x,
+                                       (float *)y, (const float *)actions, (float *)fb, (float *)obs,
+                                       (float *)s->d_ovf, n, s->stream, ctl);
+  if (rc != 0) {
+    snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad lanes_per_env");
+    return TDS_ERR_HIP;
+  }
+  return TDS_OK;
+}
+
+}  // namespace tds_internal
 
 extern "C" {
 
@@ -180,25 +153,28 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   if (!out) return fail(TDS_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
   if (num_envs <= 0) return fail(TDS_ERR_INVALID_ARG, "num_envs must be positive");
-  if (dtype != TDS_DTYPE_F64 && dtype != TDS_DTYPE_F32) return fail(TDS_ERR_INVALID_ARG, "unknown dtype");
+  if (dtype != TDS_DTYPE_F64 && dtype != TDS_DTYPE_F32 && dtype != TDS_DTYPE_F64_REC32)
+    return fail(TDS_ERR_INVALID_ARG, "unknown dtype");
   int rc = tds_hip_model_check(model);
   if (rc != TDS_OK) return rc;
   int ndev = tds_hip_device_count();
   if (ndev <= 0) return fail(TDS_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(TDS_ERR_INVALID_ARG, "device index out of range");
-  HIP_TRY(hipSetDevice(device));
-  tds_hip_sim *s = new (std::nothrow) tds_hip_sim;
+  DeviceGuard guard(device);  // (the caller's current device is restored on return)
+  tds_hip_sim *s = new (std::nothrow) tds_hip_sim();  // value-initialised: both host models start zeroed
   if (!s) return fail(TDS_ERR_INVALID_ARG, "out of host memory");
   s->model = *model;
   s->num_envs = num_envs;
   s->device = device;
   s->dtype = dtype;
   s->elem = dtype == TDS_DTYPE_F64 ? 8 : 4;
+  const bool c64 = dtype != TDS_DTYPE_F32;  // compute scalar (DevModel / LDS / slab): double unless the pure f32 build
+  const size_t celem = c64 ? 8 : 4;
   // (a floating base takes six more lanes: its pseudo links, tds_device_model.h)
   char why[128];
   size_t msize;
   const void *hsrc;
-  if (dtype == TDS_DTYPE_F64) {
+  if (c64) {
     tds_build_dev_model<double>(model, &s->h64, why);
     msize = sizeof(DevModel<double>);
     hsrc = &s->h64;
@@ -209,11 +185,10 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   }
   // lanes per environment: the device model's link count (pseudo links of a floating base / of spherical joints
   // included, folded fixed links excluded) and the padded dof count
-  s->lanes = default_lanes_per_env(dtype == TDS_DTYPE_F64 ? s->h64.num_links : s->h32.num_links, model->dof_qd);
+  s->lanes = default_lanes_per_env(c64 ? s->h64.num_links : s->h32.num_links, model->dof_qd);
   const int epw = 64 / s->lanes;
   auto layout = [&](int cap) {
-    return dtype == TDS_DTYPE_F64 ? tds_make_lds_layout<double>(s->h64, cap, s->lanes)
-                                  : tds_make_lds_layout<float>(s->h32, cap, s->lanes);
+    return c64 ? tds_make_lds_layout<double>(s->h64, cap, s->lanes) : tds_make_lds_layout<float>(s->h32, cap, s->lanes);
   };
   // Contacts whose constraint rows stay in LDS (the surplus goes to a global slab: exact, slower).
   // Default: up to 8, lowered (not below 5) if that is what lets EIGHT workgroups share a CU's 160 KiB,
@@ -225,21 +200,24 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   } else {
     const size_t budget = (160 * 1024) / 8;
     for (int cap = 8; cap >= 5; --cap)
-      if ((size_t)layout(cap).stride * epw * s->elem <= budget) {
+      if ((size_t)layout(cap).stride * epw * celem <= budget) {
         na_cap = cap;
         break;
       }
   }
   s->lds = layout(na_cap);
-  const int lds_bytes = (int)((size_t)s->lds.stride * epw * s->elem);
+  const int lds_bytes = (int)((size_t)s->lds.stride * epw * celem);
   if (lds_bytes > 160 * 1024) {
     delete s;
     return fail(TDS_ERR_UNSUPPORTED, "model needs more than 160 KiB of LDS per workgroup");
   }
   if (lds_bytes > 64 * 1024) {
-    const int kind = s->h64.is_floating || s->h32.is_floating ? 1 : (s->h64.num_spherical || s->h32.num_spherical ? 2 : 0);
-    int e = dtype == TDS_DTYPE_F64 ? tds_kernel_max_dynamic_lds<double>(s->lanes, s->lds.NDP, lds_bytes, kind)
-                                   : tds_kernel_max_dynamic_lds<float>(s->lanes, s->lds.NDP, lds_bytes, kind);
+    const bool is_fl = c64 ? s->h64.is_floating : s->h32.is_floating;
+    const bool is_sph = c64 ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
+    const int kind = is_fl ? 1 : (is_sph ? 2 : 0);
+    int e = dtype == TDS_DTYPE_F64         ? tds_kernel_max_dynamic_lds<double, double>(s->lanes, s->lds.NDP, lds_bytes, kind)
+            : dtype == TDS_DTYPE_F64_REC32 ? tds_kernel_max_dynamic_lds<double, float>(s->lanes, s->lds.NDP, lds_bytes, kind)
+                                           : tds_kernel_max_dynamic_lds<float, float>(s->lanes, s->lds.NDP, lds_bytes, kind);
     if (e != 0) {
       delete s;
       return fail(TDS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -261,9 +239,19 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   CREATE_TRY(hipMemset(s->d_x, 0, (size_t)num_envs * model->input_dim * s->elem));
   CREATE_TRY(hipMemset(s->d_y, 0, (size_t)num_envs * model->output_dim * s->elem));
   if (s->lds.ovrows > 0)
-    CREATE_TRY(hipMalloc(&s->d_ovf, (size_t)num_envs * s->lds.ovrows * (s->lds.NDs + 3) * s->elem));
+    CREATE_TRY(hipMalloc(&s->d_ovf, (size_t)num_envs * s->lds.ovrows * (s->lds.NDs + 3) * celem));
   CREATE_TRY(hipMalloc((void **)&s->d_reset_count, (size_t)num_envs * sizeof(unsigned int)));
   CREATE_TRY(hipMemset(s->d_reset_count, 0, (size_t)num_envs * sizeof(unsigned int)));
+  {
+    // scratch of the multi-launch forms, allocated here (sizes are known) so that no step call ever allocates:
+    // d_split = [obs | reward | done] records + done mask of the two-launch auto-reset step;
+    // d_ro = actions | records | returns | counts | latches of the per-step-launch rollout
+    const size_t n = (size_t)num_envs, w = (size_t)(model->dof_q + model->dof_qd + 2);
+    const size_t adim = (size_t)(model->action_dim > 0 ? model->action_dim : 1);
+    CREATE_TRY(hipMalloc(&s->d_split, align256(n * w * s->elem) + n));
+    CREATE_TRY(hipMalloc(&s->d_ro, align256(n * adim * s->elem) + align256(n * w * s->elem) + align256(n * s->elem) +
+                                       align256(n * sizeof(int)) + align256(n)));
+  }
   CREATE_TRY(hipEventCreate(&s->ev0));
   CREATE_TRY(hipEventCreate(&s->ev1));
 #undef CREATE_TRY
@@ -273,6 +261,9 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
 
 int tds_hip_destroy(tds_hip_sim_t *s) {
   if (!s) return TDS_OK;
+  DeviceGuard guard(s->device);
+  if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+  if (s->graph_stream) (void)hipStreamDestroy(s->graph_stream);
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->d_x) (void)hipFree(s->d_x);
   if (s->d_y) (void)hipFree(s->d_y);
@@ -296,11 +287,14 @@ int tds_hip_num_envs(const tds_hip_sim_t *s) { return s ? s->num_envs : 0; }
 int tds_hip_input_dim(const tds_hip_sim_t *s) { return s ? s->model.input_dim : 0; }
 int tds_hip_output_dim(const tds_hip_sim_t *s) { return s ? s->model.output_dim : 0; }
 int tds_hip_dtype(const tds_hip_sim_t *s) { return s ? s->dtype : -1; }
+int tds_hip_device(const tds_hip_sim_t *s) { return s ? s->device : -1; }
+int tds_hip_record_bytes(const tds_hip_sim_t *s) { return s ? (int)s->elem : 0; }
 void *tds_hip_x_device(tds_hip_sim_t *s) { return s ? s->d_x : nullptr; }
 void *tds_hip_y_device(tds_hip_sim_t *s) { return s ? s->d_y : nullptr; }
 
 int tds_hip_set_inputs(tds_hip_sim_t *s, const double *x_host) {
   if (!s || !x_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard guard(s->device);
   int rc = upload(s, s->d_x, x_host, (size_t)s->num_envs * s->model.input_dim);
   if (rc != TDS_OK) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -308,15 +302,25 @@ int tds_hip_set_inputs(tds_hip_sim_t *s, const double *x_host) {
 }
 int tds_hip_get_inputs(tds_hip_sim_t *s, double *x_host) {
   if (!s || !x_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard guard(s->device);
   return download(s, x_host, s->d_x, (size_t)s->num_envs * s->model.input_dim);
 }
 int tds_hip_get_outputs(tds_hip_sim_t *s, double *y_host) {
   if (!s || !y_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard guard(s->device);
   return download(s, y_host, s->d_y, (size_t)s->num_envs * s->model.output_dim);
+}
+int tds_hip_sync(tds_hip_sim_t *s) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  DeviceGuard guard(s->device);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TDS_OK;
 }
 
 int tds_hip_forward_zero_device(tds_hip_sim_t *s, const void *x_dev, void *y_dev) {
   if (!s || !x_dev || !y_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard guard(s->device);
+  TimedCall timed(s);
   return launch(s, x_dev, y_dev, nullptr, nullptr, nullptr, s->num_envs, 1, TDS_RESET_NONE, nullptr);
 }
 
@@ -328,12 +332,9 @@ __global__ void tds_done_mask_kernel(const T *__restrict__ rec, int width, unsig
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env < n) mask[env] = rec[(size_t)env * width + width - 1] != T(0) ? 1 : 0;
 }
-}  // namespace
-}  // extern "C++"
 
-int tds_hip_step_obs(tds_hip_sim_t *s, const void *actions_dev, int substeps, void *obs_dev) {
-  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
-  if (substeps < 1) return fail(TDS_ERR_INVALID_ARG, "substeps must be >= 1");
+// one closed-loop step incl. the auto-reset forms (device selected, timing handled by the caller)
+int step_obs_impl(tds_hip_sim *s, const void *actions_dev, int substeps, void *obs_dev) {
   // Auto-reset at large batches: the in-kernel reset needs the step-loop build (one wavefront per SIMD whatever
   // the batch).  From two wavefronts per SIMD on, a single step is cheaper as the straight-line launch followed by
   // a forced-reset launch masked with the done flags (idle lane groups leave at once); same random stream
@@ -342,15 +343,13 @@ int tds_hip_step_obs(tds_hip_sim_t *s, const void *actions_dev, int substeps, vo
     const char *e = getenv("TDS_HIP_AUTO_RESET_SPLIT");
     const long waves = ((long)s->num_envs * s->lanes + 63) / 64;
     if (e ? e[0] == '1' : waves >= 2048) {
-      const int n = s->num_envs, w = s->model.dof_q + s->model.dof_qd + 2;
-      const size_t b_rec = ((size_t)n * w * s->elem + 255) & ~(size_t)255;
-      if (!s->d_split && hipMalloc(&s->d_split, b_rec + n) != hipSuccess)
-        return fail(TDS_ERR_HIP, "hipMalloc (auto-reset scratch)");
+      const int n = s->num_envs, w = s->obs_width();
+      const size_t b_rec = align256((size_t)n * w * s->elem);
       void *rec = obs_dev ? obs_dev : s->d_split;
       unsigned char *mask = (unsigned char *)s->d_split + b_rec;
       int rc = launch(s, s->d_x, s->d_y, actions_dev, s->d_x, rec, n, 1, TDS_RESET_NONE, nullptr);
       if (rc != TDS_OK) return rc;
-      if (s->dtype == TDS_DTYPE_F64)
+      if (s->records_f64())
         hipLaunchKernelGGL(tds_done_mask_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, s->stream,
                            (const double *)rec, w, mask, n);
       else
@@ -366,6 +365,91 @@ int tds_hip_step_obs(tds_hip_sim_t *s, const void *actions_dev, int substeps, vo
   return launch(s, s->d_x, s->d_y, actions_dev, s->d_x, obs_dev, s->num_envs, substeps,
                 s->auto_reset ? TDS_RESET_AUTO : TDS_RESET_NONE, nullptr);
 }
+}  // namespace
+}  // extern "C++"
+
+int tds_hip_step_obs(tds_hip_sim_t *s, const void *actions_dev, int substeps, void *obs_dev) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  if (substeps < 1) return fail(TDS_ERR_INVALID_ARG, "substeps must be >= 1");
+  DeviceGuard guard(s->device);
+  TimedCall timed(s);
+  return step_obs_impl(s, actions_dev, substeps, obs_dev);
+}
+
+// K closed-loop steps per host call, replayed from a captured hipGraph (one graph launch instead of K kernel
+// launches: at ~20 us per step the host-side launch gaps are otherwise a double-digit share of short runs).
+extern "C++" {
+namespace {
+int graph_matches(const tds_hip_sim *s, const void *actions, int pool, int first, int n_steps, void *obs) {
+  return s->graph_exec && s->graph_actions == actions && s->graph_pool == pool && s->graph_first == first &&
+         s->graph_steps == n_steps && s->graph_obs == obs;
+}
+int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_steps, void *obs) {
+  if (s->graph_exec) {
+    (void)hipGraphExecDestroy(s->graph_exec);
+    s->graph_exec = nullptr;
+  }
+  if (!s->graph_stream) HIP_TRY(hipStreamCreateWithFlags(&s->graph_stream, hipStreamNonBlocking));
+  // capture on a private stream (the handle's stream may be the NULL stream, which cannot be captured);
+  // the launches are recorded, not executed
+  hipStream_t user = s->stream;
+  s->stream = s->graph_stream;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamBeginCapture(s->graph_stream, hipStreamCaptureModeThreadLocal);
+  int rc = TDS_OK;
+  if (e == hipSuccess) {
+    const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
+    for (int k = 0; k < n_steps && rc == TDS_OK; ++k) {
+      const void *a = actions ? (const char *)actions + (size_t)((first + k) % pool) * blk : nullptr;
+      rc = launch(s, s->d_x, s->d_y, a, s->d_x, obs, s->num_envs, 1, TDS_RESET_NONE, nullptr);
+    }
+    e = hipStreamEndCapture(s->graph_stream, &graph);
+  }
+  s->stream = user;
+  if (e != hipSuccess || rc != TDS_OK || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc == TDS_OK) snprintf(g_err, sizeof(g_err), "graph capture failed: %s", hipGetErrorString(e));
+    return TDS_ERR_HIP;
+  }
+  e = hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    s->graph_exec = nullptr;
+    snprintf(g_err, sizeof(g_err), "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return TDS_ERR_HIP;
+  }
+  s->graph_actions = actions;
+  s->graph_pool = pool;
+  s->graph_first = first;
+  s->graph_steps = n_steps;
+  s->graph_obs = obs;
+  return TDS_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int tds_hip_step_many_prepare(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block,
+                              int n_steps, void *obs_dev) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  if (n_steps < 1 || n_steps > 4096) return fail(TDS_ERR_INVALID_ARG, "n_steps must be in 1..4096");
+  if (actions_dev && action_blocks < 1) return fail(TDS_ERR_INVALID_ARG, "action_blocks must be >= 1");
+  if (s->auto_reset) return fail(TDS_ERR_INVALID_ARG, "step_many replays plain closed-loop steps (auto-reset is off the graph)");
+  DeviceGuard guard(s->device);
+  const int pool = actions_dev ? action_blocks : 1;
+  const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
+  if (graph_matches(s, actions_dev, pool, first, n_steps, obs_dev)) return TDS_OK;
+  return build_graph(s, actions_dev, pool, first, n_steps, obs_dev);
+}
+
+int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block, int n_steps,
+                      void *obs_dev) {
+  int rc = tds_hip_step_many_prepare(s, actions_dev, action_blocks, first_block, n_steps, obs_dev);
+  if (rc != TDS_OK) return rc;
+  DeviceGuard guard(s->device);
+  TimedCall timed(s);
+  HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
+  return TDS_OK;
+}
 
 int tds_hip_set_auto_reset(tds_hip_sim_t *s, int enable, unsigned long long seed) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
@@ -378,7 +462,10 @@ int tds_hip_set_auto_reset(tds_hip_sim_t *s, int enable, unsigned long long seed
 
 int tds_hip_reset(tds_hip_sim_t *s, const unsigned char *mask_dev, void *obs_dev) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
-  return launch(s, s->d_x, s->d_y, nullptr, s->d_x, obs_dev, s->num_envs, 0, TDS_RESET_FORCED, mask_dev);
+  DeviceGuard guard(s->device);
+  TimedCall timed(s);
+  return launch(s, s->d_x, s->d_y, nullptr, s->d_x, obs_dev, s->num_envs, 0, TDS_RESET_FORCED, mask_dev, nullptr,
+                TDS_CTL_RESET_CALL);
 }
 
 int tds_hip_step(tds_hip_sim_t *s, const void *actions_dev, int substeps) {
@@ -390,12 +477,31 @@ int tds_hip_obs_dim(const tds_hip_sim_t *s) { return s ? s->model.dof_q + s->mod
 int tds_hip_forward_zero_host(tds_hip_sim_t *s, int n, const double *x_host, double *y_host) {
   if (!s || !x_host || !y_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (n < 1 || n > s->num_envs) return fail(TDS_ERR_INVALID_ARG, "n out of range");
+  DeviceGuard guard(s->device);
   int rc = upload(s, s->d_x, x_host, (size_t)n * s->model.input_dim);
   if (rc != TDS_OK) return rc;
-  rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n, 1, TDS_RESET_NONE, nullptr);
+  {
+    TimedCall timed(s);
+    rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n, 1, TDS_RESET_NONE, nullptr);
+  }
   if (rc != TDS_OK) return rc;
   return download(s, y_host, s->d_y, (size_t)n * s->model.output_dim);
 }
+
+// the same call in two halves, so that a host that drives several devices (HipStepper with a device list) can
+// enqueue every device's share before it waits for any of them
+int tds_hip_forward_zero_host_begin(tds_hip_sim_t *s, int n, const double *x_host, double *y_host) {
+  if (!s || !x_host || !y_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (n < 1 || n > s->num_envs) return fail(TDS_ERR_INVALID_ARG, "n out of range");
+  if (!s->records_f64()) return fail(TDS_ERR_INVALID_ARG, "begin/end needs f64 records (no host-side conversion)");
+  DeviceGuard guard(s->device);
+  HIP_TRY(hipMemcpyAsync(s->d_x, x_host, (size_t)n * s->model.input_dim * 8, hipMemcpyHostToDevice, s->stream));
+  int rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n, 1, TDS_RESET_NONE, nullptr);
+  if (rc != TDS_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(y_host, s->d_y, (size_t)n * s->model.output_dim * 8, hipMemcpyDeviceToHost, s->stream));
+  return TDS_OK;
+}
+int tds_hip_forward_zero_host_end(tds_hip_sim_t *s) { return tds_hip_sync(s); }
 
 extern "C++" {
 namespace {
@@ -433,7 +539,7 @@ __global__ void tds_policy_book_kernel(const T *__restrict__ x, int in_dim, int 
   }
   if (do_policy) {
     int L = 64;
-    while (L * adim > 64) L >>= 1;  // adim <= TDS_MAX_ACTIONS = 32: L >= 2
+    while (L * adim > 64) L >>= 1;  // 1 <= adim <= TDS_MAX_ACTIONS = 32 (tds_hip_model_check): L >= 2
     const int a = lane / L, sub = lane - a * L;
     const T *const W = policy + (size_t)env * (adim * od + adim);
     const T *const xe = x + (size_t)env * in_dim;
@@ -452,13 +558,10 @@ template <typename T>
 int rollout_per_step(tds_hip_sim *s, const void *policy_dev, int n_steps, double shift, int flags,
                      void *return_sum_dev, int *return_steps_dev, void *obs_dev) {
   const int n = s->num_envs, adim = s->model.action_dim, od = s->model.dof_q + s->model.dof_qd;
-  const size_t b_act = ((size_t)n * adim * sizeof(T) + 255) & ~(size_t)255;
-  const size_t b_rec = ((size_t)n * (od + 2) * sizeof(T) + 255) & ~(size_t)255;
-  const size_t b_ret = ((size_t)n * sizeof(T) + 255) & ~(size_t)255;
-  const size_t b_cnt = ((size_t)n * sizeof(int) + 255) & ~(size_t)255;
-  const size_t b_frz = ((size_t)n + 255) & ~(size_t)255;
-  if (!s->d_ro && hipMalloc(&s->d_ro, b_act + b_rec + b_ret + b_cnt + b_frz) != hipSuccess)
-    return fail(TDS_ERR_HIP, "hipMalloc (rollout scratch)");
+  const size_t b_act = align256((size_t)n * adim * sizeof(T));
+  const size_t b_rec = align256((size_t)n * (od + 2) * sizeof(T));
+  const size_t b_ret = align256((size_t)n * sizeof(T));
+  const size_t b_cnt = align256((size_t)n * sizeof(int));
   char *base = (char *)s->d_ro;
   T *actions = (T *)base;
   T *rec = obs_dev ? (T *)obs_dev : (T *)(base + b_act);
@@ -490,6 +593,8 @@ int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, doubl
   if (!s || !policy_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (n_steps < 1) return fail(TDS_ERR_INVALID_ARG, "n_steps < 1");
   if (s->model.action_dim < 1) return fail(TDS_ERR_INVALID_ARG, "model has no actions");
+  DeviceGuard guard(s->device);
+  TimedCall timed(s);
   // One launch for the whole rollout (the step-loop build: 256 VGPR + AGPR copies, one wavefront per SIMD) or one
   // launch per step of the straight-line build with the policy + bookkeeping kernel in between: from two
   // wavefronts per SIMD on (8192 Ant environments) the straight-line build overlaps them and wins.
@@ -497,7 +602,7 @@ int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, doubl
   const long waves = ((long)s->num_envs * s->lanes + 63) / 64;
   const bool per_step = !s->auto_reset && !(flags & 4) && ((flags & 2) || waves >= 2048);
   if (per_step)
-    return s->dtype == TDS_DTYPE_F64
+    return s->records_f64()
                ? rollout_per_step<double>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev)
                : rollout_per_step<float>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev);
   Rollout ro;
@@ -513,13 +618,19 @@ int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, doubl
 int tds_hip_send_local(tds_hip_sim_t *s, int n, const double *x_host) {
   if (!s || !x_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (n < 1 || n > s->num_envs) return fail(TDS_ERR_INVALID_ARG, "n out of range");
+  DeviceGuard guard(s->device);
   return upload(s, s->d_x, x_host, (size_t)n * s->model.input_dim);
 }
 
 int tds_hip_forward_zero_fetch(tds_hip_sim_t *s, int n, double *y_host) {
   if (!s || !y_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (n < 1 || n > s->num_envs) return fail(TDS_ERR_INVALID_ARG, "n out of range");
-  int rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n, 1, TDS_RESET_NONE, nullptr);
+  DeviceGuard guard(s->device);
+  int rc;
+  {
+    TimedCall timed(s);
+    rc = launch(s, s->d_x, s->d_y, nullptr, nullptr, nullptr, n, 1, TDS_RESET_NONE, nullptr);
+  }
   if (rc != TDS_OK) return rc;
   return download(s, y_host, s->d_y, (size_t)n * s->model.output_dim);
 }
@@ -533,6 +644,7 @@ int tds_hip_set_timing(tds_hip_sim_t *s, int enable) {
 int tds_hip_last_kernel_ms(tds_hip_sim_t *s, float *ms) {
   if (!s || !ms) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (!s->have_ms) return fail(TDS_ERR_INVALID_ARG, "no timed launch recorded");
+  DeviceGuard guard(s->device);
   HIP_TRY(hipEventSynchronize(s->ev1));
   HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
   return TDS_OK;
@@ -541,6 +653,7 @@ int tds_hip_last_kernel_ms(tds_hip_sim_t *s, float *ms) {
 int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   if (!s || !cycles_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (n < TDS_NUM_PHASE_STAMPS) return fail(TDS_ERR_INVALID_ARG, "need room for 14 stamps");
+  DeviceGuard guard(s->device);
   long long *d = nullptr;
   HIP_TRY(hipMalloc(&d, sizeof(long long) * TDS_NUM_PHASE_STAMPS));
   HIP_TRY(hipMemset(d, 0, sizeof(long long) * TDS_NUM_PHASE_STAMPS));
@@ -549,11 +662,17 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   ctl.nsub = 1;
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
-    rc = tds_launch_step<double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes, (const double *)s->d_x,
-                                 (double *)s->d_y, nullptr, nullptr, nullptr, (double *)s->d_ovf, s->num_envs, s->stream, ctl, d);
+    rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes,
+                                         (const double *)s->d_x, (double *)s->d_y, nullptr, nullptr, nullptr,
+                                         (double *)s->d_ovf, s->num_envs, s->stream, ctl, d);
+  else if (s->dtype == TDS_DTYPE_F64_REC32)
+    rc = tds_launch_step<double, float>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes,
+                                        (const float *)s->d_x, (float *)s->d_y, nullptr, nullptr, nullptr,
+                                        (double *)s->d_ovf, s->num_envs, s->stream, ctl, d);
   else
-    rc = tds_launch_step<float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)s->d_x,
-                                (float *)s->d_y, nullptr, nullptr, nullptr, (float *)s->d_ovf, s->num_envs, s->stream, ctl, d);
+    rc = tds_launch_step<float, float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes,
+                                       (const float *)s->d_x, (float *)s->d_y, nullptr, nullptr, nullptr,
+                                       (float *)s->d_ovf, s->num_envs, s->stream, ctl, d);
   if (rc != 0) {
     (void)hipFree(d);
     return fail(TDS_ERR_HIP, "profiling launch failed");
@@ -566,7 +685,7 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
 
 int tds_hip_kernel_info(const tds_hip_sim_t *s, int *lds_bytes_per_env, int *threads_per_env, int *envs_per_block) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
-  if (lds_bytes_per_env) *lds_bytes_per_env = (int)(s->lds.stride * s->elem);
+  if (lds_bytes_per_env) *lds_bytes_per_env = (int)(s->lds.stride * (s->compute_f64() ? 8 : 4));
   if (threads_per_env) *threads_per_env = s->lanes;
   if (envs_per_block) *envs_per_block = 64 / s->lanes;
   return TDS_OK;

@@ -1,0 +1,98 @@
+// tds_api_internal.h — the handle behind tds_hip_sim_t, shared by tds_api.hip (single device) and
+// tds_shard.hip (multi-GPU sharding over RCCL).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "tds_device_model.h"
+#include "tds_hip.h"
+#include "tds_kernels.h"
+
+struct tds_hip_sim {
+  tds_model_t model;
+  int num_envs = 0, device = 0, dtype = TDS_DTYPE_F64, lanes = 64;
+  size_t elem = 8;  // bytes per scalar of the RECORDS in HBM (x, y, actions, obs, policy)
+  hipStream_t stream = nullptr;
+  void *d_model = nullptr;  // DevModel<T>, T = compute scalar
+  DevModel<double> h64;
+  DevModel<float> h32;
+  TdsLds lds;
+  void *d_x = nullptr, *d_y = nullptr, *d_ovf = nullptr;
+  unsigned int *d_reset_count = nullptr;
+  void *d_split = nullptr;  // records + done mask of the two-launch auto-reset step
+  void *d_ro = nullptr;     // scratch of the per-step-launch rollout (actions | records | returns | counts | latches)
+  bool auto_reset = false;
+  unsigned long long seed = 0x5DEECE66Dull;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool have_ms = false;
+  // pre-settled reset pool (tds_hip_set_reset_pool; see tds_api.hip)
+  int pool_depth = 0;
+  void *d_pool = nullptr;            // [depth][N][nq+nd] records
+  unsigned int *d_pool_meta = nullptr;  // [N] consumed count per env | [1] number of pending refills | list
+  hipStream_t pool_stream = nullptr;
+  hipEvent_t *pool_ev = nullptr;     // ring of refill-done events
+  hipEvent_t pool_step_ev = nullptr;
+  long long pool_step = 0;
+  // K-steps-per-launch graph cache (tds_hip_step_many)
+  hipGraphExec_t graph_exec = nullptr;
+  const void *graph_actions = nullptr;
+  void *graph_obs = nullptr;
+  int graph_pool = 0, graph_steps = 0, graph_first = 0;
+  hipStream_t graph_stream = nullptr;
+
+  bool compute_f64() const { return dtype != TDS_DTYPE_F32; }
+  bool records_f64() const { return dtype == TDS_DTYPE_F64; }
+  int obs_width() const { return model.dof_q + model.dof_qd + 2; }
+};
+
+namespace tds_internal {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char *fmt, const char *detail = "") {
+  snprintf(g_err, sizeof(g_err), fmt, detail);
+  return code;
+}
+
+// Every entry point that touches the device selects the handle's device for its duration and puts the caller's
+// device back: a process may hold handles on several GPUs (one per shard) and call them in any order.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) {
+      switched = hipSetDevice(device) == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+struct Rollout {
+  const void *policy;
+  void *ret_sum;
+  int *ret_steps;
+  double shift;
+  int flags;
+};
+
+// enqueue one launch of the step kernel on the handle's stream (device already selected by the caller)
+int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n, int nsub,
+           int reset_mode, const unsigned char *mask, const Rollout *ro = nullptr, int ctl_flags = 0);
+
+}  // namespace tds_internal
+
+#define TDS_HIP_TRY(expr)                                                                                         \
+  do {                                                                                                            \
+    hipError_t e_ = (expr);                                                                                       \
+    if (e_ != hipSuccess) {                                                                                       \
+      snprintf(tds_internal::g_err, sizeof(tds_internal::g_err), "%s failed: %s", #expr, hipGetErrorString(e_)); \
+      return TDS_ERR_HIP;                                                                                         \
+    }                                                                                                             \
+  } while (0)

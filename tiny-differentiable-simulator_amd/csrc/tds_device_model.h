@@ -32,6 +32,7 @@ struct DevModel {
   int num_cp, num_visuals, action_dim, input_dim, output_dim;
   int step_mode, has_plane, pgs_iterations, pack_visuals;
   int num_pairs, reward_mode, settle_steps;
+  int reset_obs_raw_xy;  // observation of a FORCED reset keeps the base x, y (tds_model_t::reset_obs_raw_xy)
   // floating base (multi_body.hpp:66-78, kinematics.hpp:35-62): links 0..5 of THIS table are six pseudo links
   // (3 angular + 3 linear base dofs, the base body's inertia on link 5) in front of the model's own links;
   // the dofs are numbered joints first (0..nj-1), base last (nj..nj+5), so that the right-looking LDL^T
@@ -144,6 +145,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   if (m->step_mode != TDS_STEP_LOCOMOTION && m->step_mode != TDS_STEP_TAU)
     TDS_FAIL(TDS_ERR_INVALID_ARG, "unknown step_mode");
   if (m->pgs_iterations < 1) TDS_FAIL(TDS_ERR_INVALID_ARG, "pgs_iterations < 1");
+  if (m->action_dim < 0 || m->action_dim > TDS_MAX_ACTIONS) TDS_FAIL(TDS_ERR_INVALID_ARG, "action_dim out of range (0..TDS_MAX_ACTIONS)");
   d->num_links = m->num_links;
   d->dof_q = m->dof_q;
   d->dof_qd = m->dof_qd;
@@ -157,6 +159,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   d->pack_visuals = m->pack_visuals;
   d->reward_mode = m->reward_mode;
   d->settle_steps = m->settle_steps < 0 ? 0 : m->settle_steps;
+  d->reset_obs_raw_xy = m->reset_obs_raw_xy != 0;
   for (int k = 0; k < TDS_ND && k < TDS_MAX_DOF; ++k) {
     d->reset_q[k] = (T)m->reset_q[k];
     d->reset_noise[k] = (T)m->reset_noise[k];

@@ -26,6 +26,7 @@ struct TdsLds {
 #define TDS_RESET_NONE 0
 #define TDS_RESET_AUTO 1    // re-initialise + settle the environments whose last step ends with done
 #define TDS_RESET_FORCED 2  // re-initialise + settle the environments selected by mask (NULL = all)
+#define TDS_CTL_RESET_CALL 8
 struct TdsStepCtl {
   int nsub;                   // normal steps in this launch (0 for a pure reset launch)
   int reset_mode;             // TDS_RESET_*
@@ -40,6 +41,8 @@ struct TdsStepCtl {
   int *ret_steps;             // [n_envs]   : number of those steps
   double shift;
   int flags;                  // bit 0: the first step observes the raw base x, y (state fresh from reset())
+                              // TDS_CTL_RESET_CALL: the launch is tds_hip_reset (the environment's own reset():
+                              // its observation keeps the base x, y where the model says so), not an auto-reset
 };
 
 template <typename T>
@@ -52,29 +55,30 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env);
 //   ovf        [n_envs][ovrows][NDs+3] scratch slab for surplus constraint rows (NULL iff ovrows == 0)
 // (KIND 0: plain fixed-base kernels, 1: floating base, 2: spherical joints; explicit instantiations live in the
 //  kernel translation units)
-template <typename T, int KIND>
+template <typename T, typename TR, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
-                         const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
+                         const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
                          hipStream_t stream, const TdsStepCtl &ctl, long long *prof);
-template <typename T>
+// T: compute scalar, TR: record scalar (== T, or float under T = double: "f32 records / f64 arithmetic")
+template <typename T, typename TR>
 inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
-                           const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
+                           const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
                            hipStream_t stream, const TdsStepCtl &ctl,
                            long long *prof = nullptr) {  // prof: 14 phase stamps of workgroup 0 (diagnostic)
 #define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof
-  if (h_model.is_floating) return tds_launch_step_impl<T, 1>(TDS_ARGS);
-  if (h_model.num_spherical) return tds_launch_step_impl<T, 2>(TDS_ARGS);
-  return tds_launch_step_impl<T, 0>(TDS_ARGS);
+  if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
+  if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
+  return tds_launch_step_impl<T, TR, 0>(TDS_ARGS);
 #undef TDS_ARGS
 }
 
-template <typename T, int KIND>
+template <typename T, typename TR, int KIND>
 int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes);
-template <typename T>
+template <typename T, typename TR>
 inline int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes, int kind) {
-  return kind == 1 ? tds_kernel_max_dynamic_lds_impl<T, 1>(lanes_per_env, ndp, bytes)
-         : kind == 2 ? tds_kernel_max_dynamic_lds_impl<T, 2>(lanes_per_env, ndp, bytes)
-                     : tds_kernel_max_dynamic_lds_impl<T, 0>(lanes_per_env, ndp, bytes);
+  return kind == 1 ? tds_kernel_max_dynamic_lds_impl<T, TR, 1>(lanes_per_env, ndp, bytes)
+         : kind == 2 ? tds_kernel_max_dynamic_lds_impl<T, TR, 2>(lanes_per_env, ndp, bytes)
+                     : tds_kernel_max_dynamic_lds_impl<T, TR, 0>(lanes_per_env, ndp, bytes);
 }
 
 int tds_padded_dof(int nd, int lanes_per_env = 0);

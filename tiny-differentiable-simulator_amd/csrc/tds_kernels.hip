@@ -605,11 +605,15 @@ __device__ __forceinline__ double tds_uniform01(unsigned long long seed, unsigne
 // KIND = 0: fixed base, 1-dof joints; 1: floating base; 2: spherical joints (fixed base).  A template parameter,
 // not a model flag read at run time — as wave-uniform branches the floating-base blocks cost the fixed-base
 // kernels 5 % (measured: Ant x 4096, 23.3 vs 22.2 us per step).
-template <typename T, int G, int NDP, bool PROF, bool LOOP, int KIND>
+// T = the scalar the kernel computes in, TR = the scalar of the records in HBM (x, y, actions, obs, policy, returns).
+// TR == T for the f64 and the f32 builds; <T = double, TR = float> is the "f32 records / f64 arithmetic" build:
+// the reference's float ABI (776 B per Ant env-step) with the mass-matrix factorisation kept in double,
+// which is what lets the float record of BASELINE config 2 meet the 1e-6 per-step contract.
+template <typename T, typename TR, int G, int NDP, bool PROF, bool LOOP, int KIND>
 __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
-                                                      const T *x_in, T *__restrict__ y_out,
-                                                      const T *__restrict__ actions, T *x_feedback /* may alias x_in */,
-                                                      T *__restrict__ obs_out, T *ovf, long long *prof, TdsStepCtl ctl, int n_envs) {
+                                                      const TR *x_in, TR *__restrict__ y_out,
+                                                      const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
+                                                      TR *__restrict__ obs_out, T *ovf, long long *prof, TdsStepCtl ctl, int n_envs) {
   extern __shared__ __align__(16) unsigned char tds_smem_raw[];
   T *const sm = reinterpret_cast<T *>(tds_smem_raw);
   constexpr int EPW = 64 / G;
@@ -627,8 +631,8 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   for (int k = 0; k < XPL; ++k) {
     const int i = lane + k * G;
     const bool act = actions != nullptr && i >= L.nqnd && i < L.nqnd + L.adim;
-    const T *src = act ? actions + ((size_t)env * L.adim + (i - L.nqnd)) : x_in + ((size_t)env * L.in_dim + i);
-    xpre[k] = (valid && i < L.in_dim) ? *src : T(0);
+    const TR *src = act ? actions + ((size_t)env * L.adim + (i - L.nqnd)) : x_in + ((size_t)env * L.in_dim + i);
+    xpre[k] = (valid && i < L.in_dim) ? (T)*src : T(0);
   }
 
   const DevModel<T> *mdl = mdl_arg;
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   }
   for (int i = lane + XPL * G; i < in_dim; i += G) {
     const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
-    xr[i] = !valid ? T(0) : act ? actions[(size_t)env * adim + (i - nq - nd)] : x_in[(size_t)env * in_dim + i];
+    xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
   }
   TDS_WAVE_SYNC();
 
@@ -784,9 +788,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     }
     TDS_WAVE_SYNC();
     if (finished0) {
+      const bool raw = (ctl.flags & TDS_CTL_RESET_CALL) != 0 && mdl->reset_obs_raw_xy != 0;
       for (int i = lane; i < nq + nd; i += G) {
-        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? T(0) : xr[i];
-        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = xr[i];
+        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = (TR)((i < 2 && !raw) ? T(0) : xr[i]);
+        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = (TR)xr[i];
       }
     }
   }
@@ -812,11 +817,11 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       const int od = nq + nd;
       const bool raw_xy = (ctl.flags & 1) != 0 && tds_iter == 0;
       if (mode == TDS_MODE_RUN && lane < adim) {
-        const T *const W = (const T *)ctl.policy + (size_t)env * (adim * od + adim);
-        T acc = W[adim * od + lane];
+        const TR *const W = (const TR *)ctl.policy + (size_t)env * (adim * od + adim);
+        T acc = (T)W[adim * od + lane];
         for (int o = 0; o < od; ++o) {
           const T ob = (o < 2 && !raw_xy) ? T(0) : xr[o];
-          acc += ob * W[lane * od + o];
+          acc += ob * (T)W[lane * od + o];
         }
         xr[nq + nd + lane] = acc;
       }
@@ -1294,7 +1299,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   // ---- M1. visual poses of y (they use the PRE-step X_world, locomotion_contact_simulation.h:281-299)
   {
-    T *const yo = y_out + (size_t)env * out_dim;
+    TR *const yo = y_out + (size_t)env * out_dim;
     const int nv = pf_nv;
     const int vbase = nq + nd;
     if (last_run) {  // y describes the last normal step of the launch
@@ -1321,14 +1326,14 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
         mat3_mul(Rl, Rv, Ro);
         mat3_mulv(Rl, pv, po);
         matrix_to_quat(Ro, qo);
-        T *o = yo + vbase + 7 * k;
-        __builtin_nontemporal_store(pl[0] + po[0], &o[0]);
-        __builtin_nontemporal_store(pl[1] + po[1], &o[1]);
-        __builtin_nontemporal_store(pl[2] + po[2], &o[2]);
-        __builtin_nontemporal_store(qo[0], &o[3]);
-        __builtin_nontemporal_store(qo[1], &o[4]);
-        __builtin_nontemporal_store(qo[2], &o[5]);
-        __builtin_nontemporal_store(qo[3], &o[6]);
+        TR *o = yo + vbase + 7 * k;
+        __builtin_nontemporal_store((TR)(pl[0] + po[0]), &o[0]);
+        __builtin_nontemporal_store((TR)(pl[1] + po[1]), &o[1]);
+        __builtin_nontemporal_store((TR)(pl[2] + po[2]), &o[2]);
+        __builtin_nontemporal_store((TR)qo[0], &o[3]);
+        __builtin_nontemporal_store((TR)qo[1], &o[4]);
+        __builtin_nontemporal_store((TR)qo[2], &o[5]);
+        __builtin_nontemporal_store((TR)qo[3], &o[6]);
       }
     }
   }
@@ -1890,21 +1895,21 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 
   // ---- y record (q, qd, up, zero padding; the visual poses went out in M1) of the last normal step
   if (last_run) {
-    T *const yo = y_out + (size_t)env * out_dim;
+    TR *const yo = y_out + (size_t)env * out_dim;
     if (gen) {  // the q record is not one coordinate per lane: copy it out as it is
-      for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((T)(xr[i]), &yo[i]);
+      for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)(xr[i]), &yo[i]);
     } else if (di >= 0) {
-      __builtin_nontemporal_store((T)(q_new), &yo[di]);
-      __builtin_nontemporal_store((T)(qd_new), &yo[nq + di]);
+      __builtin_nontemporal_store((TR)(q_new), &yo[di]);
+      __builtin_nontemporal_store((TR)(qd_new), &yo[nq + di]);
     }
     const int nv = mdl->num_visuals;
     int tail = nq + nd;
     if (mdl->pack_visuals) {
       tail += 7 * nv;
-      if (lane == 0) __builtin_nontemporal_store((T)(fl ? up_z : mdl->base_R[8]), &yo[tail]);  // up_dot_world_z
+      if (lane == 0) __builtin_nontemporal_store((TR)(fl ? up_z : mdl->base_R[8]), &yo[tail]);  // up_dot_world_z
       tail += 1;
     }
-    for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((T)(T(0)), &yo[i]);
+    for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
   }
 
   // ---- N. reward / done of the last normal step
@@ -1943,9 +1948,9 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       reward = done ? T(0) : xr[0];
     }
     if (obs_out != nullptr && last_run) {
-      T *const ob = obs_out + (size_t)env * (nq + nd + 2);
-      ob[nq + nd] = reward;
-      ob[nq + nd + 1] = (done || frozen) ? T(1) : T(0);
+      TR *const ob = obs_out + (size_t)env * (nq + nd + 2);
+      ob[nq + nd] = (TR)reward;
+      ob[nq + nd + 1] = (done || frozen) ? TR(1) : TR(0);
     }
     xr[in_dim + 1] = done ? T(1) : T(0);
   }
@@ -1955,18 +1960,18 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     // out straight from registers
     if (live && gen) {
       for (int i = lane; i < nq + nd; i += G) {
-        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? T(0) : xr[i];
-        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = xr[i];
+        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = (TR)(i < 2 ? T(0) : xr[i]);
+        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = (TR)xr[i];
       }
     } else if (live && di >= 0) {
       if (obs_out != nullptr) {
-        T *const ob = obs_out + (size_t)env * (nq + nd + 2);
-        ob[di] = di < 2 ? T(0) : q_new;
-        ob[nq + di] = qd_new;
+        TR *const ob = obs_out + (size_t)env * (nq + nd + 2);
+        ob[di] = (TR)(di < 2 ? T(0) : q_new);
+        ob[nq + di] = (TR)qd_new;
       }
       if (x_feedback != nullptr) {
-        x_feedback[(size_t)env * in_dim + di] = q_new;
-        x_feedback[(size_t)env * in_dim + nq + di] = qd_new;
+        x_feedback[(size_t)env * in_dim + di] = (TR)q_new;
+        x_feedback[(size_t)env * in_dim + nq + di] = (TR)qd_new;
       }
     }
   } else {
@@ -2017,16 +2022,19 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
       }
     }
     if (finished && pol && lane == 0) {
-      if (ctl.ret_sum != nullptr) ((T *)ctl.ret_sum)[env] = ret;
+      if (ctl.ret_sum != nullptr) ((TR *)ctl.ret_sum)[env] = (TR)ret;
       if (ctl.ret_steps != nullptr) ctl.ret_steps[env] = cnt;
     }
     TDS_WAVE_SYNC();
     // ---- the environment is done with this launch: observation (obs[0] = obs[1] = 0,
     //      ars_vectorized_environment.h:283-288) and resident state
     if (finished) {
+      // (a forced reset hands out what the environment's own reset() returns: only Ant's zeroes the base x, y —
+      //  ant_environment2.h:162-163 vs laikago_environment2.h:63-116; the step always does, ars_vectorized_environment.h:283-288)
+      const bool raw = (ctl.flags & TDS_CTL_RESET_CALL) != 0 && mdl->reset_obs_raw_xy != 0;
       for (int i = lane; i < nq + nd; i += G) {
-        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? T(0) : xr[i];
-        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = xr[i];
+        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = (TR)((i < 2 && !raw) ? T(0) : xr[i]);
+        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = (TR)xr[i];
       }
     }
   }
@@ -2044,7 +2052,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
 // padded dof count = template parameter NDP of the kernel.  Besides the coarse widths (8/16/24/32) the
 // widths of the two benchmark robots are instantiated exactly for their natural lane count
 // (Ant: 14 dof on 16 lanes, Laikago: 18 dof on 32 lanes): LDL^T and the row solves scale with NDP^2.
-#if !defined(TDS_ONLY_F32) && (!defined(TDS_ONLY_KIND) || TDS_ONLY_KIND == 0)
+#if !defined(TDS_ONLY_F32) && !defined(TDS_ONLY_MIX) && (!defined(TDS_ONLY_KIND) || TDS_ONLY_KIND == 0)
 int tds_padded_dof(int nd, int lanes) {
   if (lanes == 16 && nd > 8 && nd <= 14) return 14;
   if (lanes == 32 && nd > 16 && nd <= 18) return 18;
@@ -2104,9 +2112,9 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
   return L;
 }
 
-template <typename T, int KIND>
+template <typename T, typename TR, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
-                         const T *x_in, T *y_out, const T *actions, T *x_feedback, T *obs_out, T *ovf, int n_envs,
+                         const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
                          hipStream_t stream, const TdsStepCtl &ctl, long long *prof) {
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
@@ -2115,13 +2123,13 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \
     if (prof)                                                                                                \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, true, false, 0>), dim3(blocks), dim3(64), shmem, stream, \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, true, false, 0>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else if (simple)                                                                                         \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, false, KIND>), dim3(blocks), dim3(64), shmem, stream, \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, false, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else                                                                                                     \
-      hipLaunchKernelGGL((tds_step_kernel<T, GG, NN, false, true, KIND>), dim3(blocks), dim3(64), shmem, stream, \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, true, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
   } while (0)
   if (prof && KIND != 0) return -2;  // the phase-stamp build exists for the plain kernels only
@@ -2150,18 +2158,18 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   return (int)hipGetLastError();
 }
 
-template <typename T, int KIND>
+template <typename T, typename TR, int KIND>
 int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   hipError_t e = hipSuccess;
 #define TDS_ATTR(GG, NN)                                                                                        \
   do {                                                                                                          \
-    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, false, KIND>,                         \
+    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, false, KIND>,                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                 \
     if (e == hipSuccess)                                                                                        \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, false, true, KIND>,                        \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, true, KIND>,                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
     if (e == hipSuccess && KIND == 0)                                                                               \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, GG, NN, true, false, 0>,                     \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, true, false, 0>,                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
@@ -2185,39 +2193,52 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   return (int)e;
 }
 
-// The file is compiled six times (csrc/Makefile): -DTDS_ONLY_F64 / -DTDS_ONLY_F32 pick the compute dtype,
-// -DTDS_ONLY_KIND=0/1/2 the kernel kind (plain / floating base / spherical joints), so that the parts of the
-// kernel set build in parallel.  (tds_make_lds_layout and tds_padded_dof live in the KIND 0 units.)
-#define TDS_INSTANTIATE(TT, KV)                                                                                        \
-  template int tds_launch_step_impl<TT, KV>(const DevModel<TT> *, const DevModel<TT> &, const TdsLds &, int, const TT *, \
-                                            TT *, const TT *, TT *, TT *, TT *, int, hipStream_t, const TdsStepCtl &,  \
-                                            long long *);                                                              \
-  template int tds_kernel_max_dynamic_lds_impl<TT, KV>(int, int, int);
+// The file is compiled nine times (csrc/Makefile): -DTDS_ONLY_F64 / -DTDS_ONLY_F32 / -DTDS_ONLY_MIX pick the build
+// (compute scalar, record scalar) = (double, double) / (float, float) / (double, float), -DTDS_ONLY_KIND=0/1/2 the
+// kernel kind (plain / floating base / spherical joints), so that the parts of the kernel set build in parallel.
+// (tds_make_lds_layout and tds_padded_dof live in the KIND 0 units.)
+#define TDS_INSTANTIATE(TT, TR, KV)                                                                                     \
+  template int tds_launch_step_impl<TT, TR, KV>(const DevModel<TT> *, const DevModel<TT> &, const TdsLds &, int,       \
+                                                const TR *, TR *, const TR *, TR *, TR *, TT *, int, hipStream_t,     \
+                                                const TdsStepCtl &, long long *);                                      \
+  template int tds_kernel_max_dynamic_lds_impl<TT, TR, KV>(int, int, int);
 #if !defined(TDS_ONLY_KIND)
 #define TDS_ALL_KINDS 1
 #define TDS_ONLY_KIND -1
 #endif
-#if !defined(TDS_ONLY_F32)
+#if !defined(TDS_ONLY_F64) && !defined(TDS_ONLY_F32) && !defined(TDS_ONLY_MIX)
+#define TDS_ONLY_F64 1
+#define TDS_ONLY_F32 1
+#define TDS_ONLY_MIX 1
+#endif
+#if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
+#define TDS_INSTANTIATE_K0(TT, TR) TDS_INSTANTIATE(TT, TR, 0)
+#else
+#define TDS_INSTANTIATE_K0(TT, TR)
+#endif
+#if TDS_ONLY_KIND == 1 || defined(TDS_ALL_KINDS)
+#define TDS_INSTANTIATE_K1(TT, TR) TDS_INSTANTIATE(TT, TR, 1)
+#else
+#define TDS_INSTANTIATE_K1(TT, TR)
+#endif
+#if TDS_ONLY_KIND == 2 || defined(TDS_ALL_KINDS)
+#define TDS_INSTANTIATE_K2(TT, TR) TDS_INSTANTIATE(TT, TR, 2)
+#else
+#define TDS_INSTANTIATE_K2(TT, TR)
+#endif
+#define TDS_INSTANTIATE_KINDS(TT, TR) TDS_INSTANTIATE_K0(TT, TR) TDS_INSTANTIATE_K1(TT, TR) TDS_INSTANTIATE_K2(TT, TR)
+#if defined(TDS_ONLY_F64)
 #if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
 template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int);
-TDS_INSTANTIATE(double, 0)
 #endif
-#if TDS_ONLY_KIND == 1 || defined(TDS_ALL_KINDS)
-TDS_INSTANTIATE(double, 1)
+TDS_INSTANTIATE_KINDS(double, double)
 #endif
-#if TDS_ONLY_KIND == 2 || defined(TDS_ALL_KINDS)
-TDS_INSTANTIATE(double, 2)
+#if defined(TDS_ONLY_MIX)
+TDS_INSTANTIATE_KINDS(double, float)
 #endif
-#endif
-#if !defined(TDS_ONLY_F64)
+#if defined(TDS_ONLY_F32)
 #if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
 template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int, int);
-TDS_INSTANTIATE(float, 0)
 #endif
-#if TDS_ONLY_KIND == 1 || defined(TDS_ALL_KINDS)
-TDS_INSTANTIATE(float, 1)
-#endif
-#if TDS_ONLY_KIND == 2 || defined(TDS_ALL_KINDS)
-TDS_INSTANTIATE(float, 2)
-#endif
+TDS_INSTANTIATE_KINDS(float, float)
 #endif

@@ -1,0 +1,411 @@
+// tds_shard.hip — multi-GPU sharding of the environment batch behind the C ABI (include/tds_hip.h, tds_hip_shard_*).
+//
+// environments are independent, so rank r owns the contiguous block [r N/G, (r+1) N/G) of the global
+// batch on its own GPU — model constants replicated, NO collective inside the step.  The one exchange is an all-gather
+// of the [obs | reward | done] records the step kernel writes, once per policy step, straight over xGMI with RCCL
+// (ncclAllGather; xGMI is a full mesh, so each shard travels once over its own link).  The reference has no analogue
+// (SURVEY §2 "Parallelism strategies": none); the host side stays C/C++ as north_star asks — this file calls librccl
+// directly, no torch.distributed in the data path.
+//
+// Streams.  The step runs on the handle's stream; the exchange on a private communication stream:
+//     step k      : sim stream   — writes the records of step k into ring slot k mod S
+//     gather k    : comm stream  — waits for step k's event, (converts to the wire dtype,) ncclAllGather into the
+//                                  slot's gathered buffer, records the slot's done event
+//     step k + S  : sim stream   — waits for gather k's done event before it overwrites the slot
+// so the exchange of step k overlaps the computation of steps k+1 .. k+S-1, and nothing the step needs ever waits
+// for xGMI (per-environment policies run on device; a learner consumes the gathered records one step late).
+//
+// librccl is loaded with dlopen at first use: a single-GPU host never needs it, and inside a PyTorch process the
+// copy PyTorch already mapped is reused instead of a second one from /opt/rocm.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "tds_api_internal.h"
+
+using namespace tds_internal;
+
+namespace {
+
+struct Rccl {
+  void *handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  bool ok = false;
+};
+
+Rccl *rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.ok ? &r : nullptr;
+  tried = true;
+  const char *names[] = {getenv("TDS_HIP_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  // a copy already mapped into the process (PyTorch's) wins
+  for (const char *n : names)
+    if (n && !r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  for (const char *n : names)
+    if (n && !r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!r.handle) return nullptr;
+#define TDS_SYM(field, name)                                    \
+  r.field = (decltype(r.field))dlsym(r.handle, name);           \
+  if (!r.field) return nullptr
+  TDS_SYM(GetUniqueId, "ncclGetUniqueId");
+  TDS_SYM(CommInitRank, "ncclCommInitRank");
+  TDS_SYM(CommInitAll, "ncclCommInitAll");
+  TDS_SYM(CommDestroy, "ncclCommDestroy");
+  TDS_SYM(AllGather, "ncclAllGather");
+  TDS_SYM(GroupStart, "ncclGroupStart");
+  TDS_SYM(GroupEnd, "ncclGroupEnd");
+  TDS_SYM(GetErrorString, "ncclGetErrorString");
+  TDS_SYM(GetVersion, "ncclGetVersion");
+#undef TDS_SYM
+  r.ok = true;
+  return &r;
+}
+
+#define NCCL_TRY(expr)                                                                        \
+  do {                                                                                        \
+    ncclResult_t r_ = (expr);                                                                 \
+    if (r_ != ncclSuccess) {                                                                  \
+      snprintf(g_err, sizeof(g_err), "%s failed: %s", #expr, rccl()->GetErrorString(r_));     \
+      return TDS_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+constexpr int kSlots = 4;  // record blocks in flight
+
+__global__ void tds_f64_to_f32_kernel(const double *__restrict__ in, float *__restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
+}  // namespace
+
+struct tds_hip_shard {
+  tds_hip_sim *sim = nullptr;
+  int rank = 0, world = 1, n_local = 0, n_global = 0;
+  int wire_bytes = 4;  // bytes per scalar on the wire
+  int block = 1;       // steps whose records travel in one all-gather
+  ncclComm_t comm = nullptr;  // NULL: world == 1 without RCCL (device copy)
+  hipStream_t comm_stream = nullptr;
+  void *rec[kSlots] = {};       // [block][n_local][w]   record dtype: written by the step kernel
+  void *wire[kSlots] = {};      // [block][n_local][w]   wire dtype (== rec when no conversion is needed)
+  void *gathered[kSlots] = {};  // [world][block][n_local][w] wire dtype
+  hipEvent_t ev_step[kSlots] = {}, ev_done[kSlots] = {};
+  bool pending[kSlots] = {};
+  long long steps = 0;  // steps submitted so far
+  int last_slot = -1;   // slot of the most recently submitted exchange
+
+  size_t block_scalars() const { return (size_t)block * n_local * sim->obs_width(); }
+};
+
+namespace {
+
+int alloc_ring(tds_hip_shard *sh) {
+  const size_t rec_b = sh->block_scalars() * sh->sim->elem;
+  const size_t wire_b = sh->block_scalars() * sh->wire_bytes;
+  const bool convert = (int)sh->sim->elem != sh->wire_bytes;
+  for (int i = 0; i < kSlots; ++i) {
+    if (sh->rec[i]) (void)hipFree(sh->rec[i]);
+    if (sh->wire[i] && sh->wire[i] != sh->rec[i]) (void)hipFree(sh->wire[i]);
+    if (sh->gathered[i]) (void)hipFree(sh->gathered[i]);
+    sh->rec[i] = sh->wire[i] = sh->gathered[i] = nullptr;
+    TDS_HIP_TRY(hipMalloc(&sh->rec[i], rec_b));
+    TDS_HIP_TRY(hipMemset(sh->rec[i], 0, rec_b));
+    if (convert)
+      TDS_HIP_TRY(hipMalloc(&sh->wire[i], wire_b));
+    else
+      sh->wire[i] = sh->rec[i];
+    TDS_HIP_TRY(hipMalloc(&sh->gathered[i], wire_b * sh->world));
+    sh->pending[i] = false;
+  }
+  return TDS_OK;
+}
+
+int make_shard(const tds_model_t *model, int global_envs, int rank, int world, int device, int dtype, int wire_dtype,
+               tds_hip_shard **out) {
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return fail(TDS_ERR_INVALID_ARG, "rank / world out of range");
+  if (global_envs < world || global_envs % world != 0)
+    return fail(TDS_ERR_INVALID_ARG, "global_envs must be a positive multiple of world (equal shards: one all-gather)");
+  if (wire_dtype != TDS_DTYPE_F32 && wire_dtype != TDS_DTYPE_F64) return fail(TDS_ERR_INVALID_ARG, "wire dtype: F32 or F64");
+  tds_hip_shard *sh = new (std::nothrow) tds_hip_shard();
+  if (!sh) return fail(TDS_ERR_INVALID_ARG, "out of host memory");
+  sh->rank = rank;
+  sh->world = world;
+  sh->n_global = global_envs;
+  sh->n_local = global_envs / world;
+  int rc = tds_hip_create(model, sh->n_local, device, dtype, &sh->sim);
+  if (rc != TDS_OK) {
+    delete sh;
+    return rc;
+  }
+  sh->wire_bytes = wire_dtype == TDS_DTYPE_F64 ? 8 : 4;
+  if (sh->wire_bytes > (int)sh->sim->elem) sh->wire_bytes = (int)sh->sim->elem;  // never widen on the wire
+  DeviceGuard guard(device);
+  hipError_t e = hipStreamCreateWithFlags(&sh->comm_stream, hipStreamNonBlocking);
+  for (int i = 0; i < kSlots && e == hipSuccess; ++i) {
+    e = hipEventCreateWithFlags(&sh->ev_step[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_done[i], hipEventDisableTiming);
+  }
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "shard stream / event creation failed: %s", hipGetErrorString(e));
+    tds_hip_shard_destroy(sh);
+    return TDS_ERR_HIP;
+  }
+  rc = alloc_ring(sh);
+  if (rc != TDS_OK) {
+    tds_hip_shard_destroy(sh);
+    return rc;
+  }
+  *out = sh;
+  return TDS_OK;
+}
+
+// sim stream: one step of the local shard into the current ring slot
+int shard_step_local(tds_hip_shard *sh, const void *actions_dev, int substeps) {
+  tds_hip_sim *s = sh->sim;
+  const int slot = (int)((sh->steps / sh->block) % kSlots), j = (int)(sh->steps % sh->block);
+  if (j == 0 && sh->pending[slot]) {  // the slot's previous exchange must have read its records
+    TDS_HIP_TRY(hipStreamWaitEvent(s->stream, sh->ev_done[slot], 0));
+    sh->pending[slot] = false;
+  }
+  char *rec = (char *)sh->rec[slot] + (size_t)j * sh->n_local * s->obs_width() * s->elem;
+  int rc = tds_hip_step_obs(s, actions_dev, substeps, rec);
+  if (rc != TDS_OK) return rc;
+  sh->steps++;
+  return TDS_OK;
+}
+
+// comm stream: exchange the block that has just been completed (or a partial one at a flush)
+int shard_submit(tds_hip_shard *sh, int slot) {
+  tds_hip_sim *s = sh->sim;
+  TDS_HIP_TRY(hipEventRecord(sh->ev_step[slot], s->stream));
+  TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, sh->ev_step[slot], 0));
+  const size_t count = sh->block_scalars();
+  if (sh->wire[slot] != sh->rec[slot]) {
+    hipLaunchKernelGGL(tds_f64_to_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, sh->comm_stream,
+                       (const double *)sh->rec[slot], (float *)sh->wire[slot], count);
+    if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "wire conversion launch");
+  }
+  if (sh->comm) {
+    NCCL_TRY(rccl()->AllGather(sh->wire[slot], sh->gathered[slot], count,
+                               sh->wire_bytes == 8 ? ncclFloat64 : ncclFloat32, sh->comm, sh->comm_stream));
+  } else {
+    TDS_HIP_TRY(hipMemcpyAsync(sh->gathered[slot], sh->wire[slot], count * sh->wire_bytes, hipMemcpyDeviceToDevice,
+                               sh->comm_stream));
+  }
+  return TDS_OK;
+}
+int shard_mark_done(tds_hip_shard *sh, int slot) {
+  TDS_HIP_TRY(hipEventRecord(sh->ev_done[slot], sh->comm_stream));
+  sh->pending[slot] = true;
+  sh->last_slot = slot;
+  return TDS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tds_hip_shard_rccl_version(void) {
+  Rccl *r = rccl();
+  int v = 0;
+  if (!r || r->GetVersion(&v) != ncclSuccess) return 0;
+  return v;
+}
+
+int tds_hip_shard_unique_id(void *id_out) {
+  if (!id_out) return fail(TDS_ERR_INVALID_ARG, "id_out is NULL");
+  Rccl *r = rccl();
+  if (!r) return fail(TDS_ERR_UNSUPPORTED, "librccl could not be loaded (set TDS_HIP_RCCL_LIB)");
+  static_assert(sizeof(ncclUniqueId) == TDS_SHARD_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  NCCL_TRY(r->GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return TDS_OK;
+}
+
+int tds_hip_shard_create(const tds_model_t *model, int global_envs, int rank, int world, int device, int dtype,
+                         const void *unique_id, int wire_dtype, tds_hip_shard_t **out) {
+  if (!out) return fail(TDS_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (world > 1 && !unique_id) return fail(TDS_ERR_INVALID_ARG, "world > 1 needs the unique id of tds_hip_shard_unique_id");
+  tds_hip_shard *sh = nullptr;
+  int rc = make_shard(model, global_envs, rank, world, device, dtype, wire_dtype, &sh);
+  if (rc != TDS_OK) return rc;
+  if (unique_id) {
+    Rccl *r = rccl();
+    if (!r) {
+      tds_hip_shard_destroy(sh);
+      return fail(TDS_ERR_UNSUPPORTED, "librccl could not be loaded (set TDS_HIP_RCCL_LIB)");
+    }
+    DeviceGuard guard(device);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t e = r->CommInitRank(&sh->comm, world, id, rank);
+    if (e != ncclSuccess) {
+      snprintf(g_err, sizeof(g_err), "ncclCommInitRank failed: %s", r->GetErrorString(e));
+      sh->comm = nullptr;
+      tds_hip_shard_destroy(sh);
+      return TDS_ERR_HIP;
+    }
+  }
+  *out = sh;
+  return TDS_OK;
+}
+
+int tds_hip_shard_create_all(const tds_model_t *model, int global_envs, int n_devices, const int *devices, int dtype,
+                             int wire_dtype, tds_hip_shard_t **out) {
+  if (!out || !devices || n_devices < 1 || n_devices > 64) return fail(TDS_ERR_INVALID_ARG, "bad device list");
+  for (int i = 0; i < n_devices; ++i) out[i] = nullptr;
+  Rccl *r = rccl();
+  if (!r) return fail(TDS_ERR_UNSUPPORTED, "librccl could not be loaded (set TDS_HIP_RCCL_LIB)");
+  int rc = TDS_OK;
+  for (int i = 0; i < n_devices && rc == TDS_OK; ++i)
+    rc = make_shard(model, global_envs, i, n_devices, devices[i], dtype, wire_dtype, &out[i]);
+  ncclComm_t comms[64];
+  if (rc == TDS_OK) {
+    ncclResult_t e = r->CommInitAll(comms, n_devices, devices);
+    if (e != ncclSuccess) {
+      snprintf(g_err, sizeof(g_err), "ncclCommInitAll failed: %s", r->GetErrorString(e));
+      rc = TDS_ERR_HIP;
+    }
+  }
+  if (rc != TDS_OK) {
+    for (int i = 0; i < n_devices; ++i) {
+      tds_hip_shard_destroy(out[i]);
+      out[i] = nullptr;
+    }
+    return rc;
+  }
+  for (int i = 0; i < n_devices; ++i) out[i]->comm = comms[i];
+  return TDS_OK;
+}
+
+int tds_hip_shard_destroy(tds_hip_shard_t *sh) {
+  if (!sh) return TDS_OK;
+  const int device = sh->sim ? sh->sim->device : 0;
+  {
+    DeviceGuard guard(device);
+    if (sh->comm_stream) (void)hipStreamSynchronize(sh->comm_stream);
+    if (sh->comm && rccl()) (void)rccl()->CommDestroy(sh->comm);
+    for (int i = 0; i < kSlots; ++i) {
+      if (sh->wire[i] && sh->wire[i] != sh->rec[i]) (void)hipFree(sh->wire[i]);
+      if (sh->rec[i]) (void)hipFree(sh->rec[i]);
+      if (sh->gathered[i]) (void)hipFree(sh->gathered[i]);
+      if (sh->ev_step[i]) (void)hipEventDestroy(sh->ev_step[i]);
+      if (sh->ev_done[i]) (void)hipEventDestroy(sh->ev_done[i]);
+    }
+    if (sh->comm_stream) (void)hipStreamDestroy(sh->comm_stream);
+  }
+  if (sh->sim) tds_hip_destroy(sh->sim);
+  delete sh;
+  return TDS_OK;
+}
+
+tds_hip_sim_t *tds_hip_shard_sim(tds_hip_shard_t *sh) { return sh ? sh->sim : nullptr; }
+int tds_hip_shard_rank(const tds_hip_shard_t *sh) { return sh ? sh->rank : -1; }
+int tds_hip_shard_world(const tds_hip_shard_t *sh) { return sh ? sh->world : 0; }
+int tds_hip_shard_local_envs(const tds_hip_shard_t *sh) { return sh ? sh->n_local : 0; }
+int tds_hip_shard_first_env(const tds_hip_shard_t *sh) { return sh ? sh->rank * sh->n_local : 0; }
+int tds_hip_shard_wire_bytes(const tds_hip_shard_t *sh) { return sh ? sh->wire_bytes : 0; }
+
+int tds_hip_shard_set_block(tds_hip_shard_t *sh, int steps_per_exchange) {
+  if (!sh) return fail(TDS_ERR_INVALID_ARG, "shard is NULL");
+  if (steps_per_exchange < 1 || steps_per_exchange > 1024) return fail(TDS_ERR_INVALID_ARG, "steps_per_exchange must be in 1..1024");
+  int rc = tds_hip_shard_flush(sh);
+  if (rc != TDS_OK) return rc;
+  DeviceGuard guard(sh->sim->device);
+  sh->block = steps_per_exchange;
+  sh->steps = 0;
+  sh->last_slot = -1;
+  return alloc_ring(sh);
+}
+
+int tds_hip_shard_step(tds_hip_shard_t *sh, const void *actions_dev, int substeps) {
+  if (!sh) return fail(TDS_ERR_INVALID_ARG, "shard is NULL");
+  DeviceGuard guard(sh->sim->device);
+  const int slot = (int)((sh->steps / sh->block) % kSlots);
+  int rc = shard_step_local(sh, actions_dev, substeps);
+  if (rc != TDS_OK) return rc;
+  if (sh->steps % sh->block != 0) return TDS_OK;  // the block is still filling
+  rc = shard_submit(sh, slot);
+  if (rc != TDS_OK) return rc;
+  return shard_mark_done(sh, slot);
+}
+
+// One process, several devices: every shard steps, then ONE grouped RCCL call carries all their all-gathers
+// (ncclGroupStart / End — issuing them one by one from a single thread would deadlock).
+int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const *actions_dev, int substeps) {
+  if (!shards || n < 1) return fail(TDS_ERR_INVALID_ARG, "no shards");
+  for (int i = 0; i < n; ++i)
+    if (!shards[i] || shards[i]->block != shards[0]->block || shards[i]->steps != shards[0]->steps)
+      return fail(TDS_ERR_INVALID_ARG, "shards of one group must step together");
+  const int slot = (int)((shards[0]->steps / shards[0]->block) % kSlots);
+  for (int i = 0; i < n; ++i) {
+    DeviceGuard guard(shards[i]->sim->device);
+    int rc = shard_step_local(shards[i], actions_dev ? actions_dev[i] : nullptr, substeps);
+    if (rc != TDS_OK) return rc;
+  }
+  if (shards[0]->steps % shards[0]->block != 0) return TDS_OK;
+  Rccl *r = rccl();
+  const bool grouped = r && shards[0]->comm;
+  if (grouped) NCCL_TRY(r->GroupStart());
+  int rc = TDS_OK;
+  for (int i = 0; i < n && rc == TDS_OK; ++i) {
+    DeviceGuard guard(shards[i]->sim->device);
+    rc = shard_submit(shards[i], slot);
+  }
+  if (grouped) {
+    ncclResult_t e = r->GroupEnd();
+    if (e != ncclSuccess && rc == TDS_OK) {
+      snprintf(g_err, sizeof(g_err), "ncclGroupEnd failed: %s", r->GetErrorString(e));
+      rc = TDS_ERR_HIP;
+    }
+  }
+  for (int i = 0; i < n && rc == TDS_OK; ++i) {
+    DeviceGuard guard(shards[i]->sim->device);
+    rc = shard_mark_done(shards[i], slot);
+  }
+  return rc;
+}
+
+int tds_hip_shard_flush(tds_hip_shard_t *sh) {
+  if (!sh) return fail(TDS_ERR_INVALID_ARG, "shard is NULL");
+  DeviceGuard guard(sh->sim->device);
+  if (sh->steps % sh->block != 0) {  // a partially filled block travels as it is (stale tail records included)
+    const int slot = (int)((sh->steps / sh->block) % kSlots);
+    int rc = shard_submit(sh, slot);
+    if (rc == TDS_OK) rc = shard_mark_done(sh, slot);
+    if (rc != TDS_OK) return rc;
+    sh->steps = (sh->steps / sh->block + 1) * sh->block;
+  }
+  TDS_HIP_TRY(hipStreamSynchronize(sh->comm_stream));
+  for (int i = 0; i < kSlots; ++i) sh->pending[i] = false;
+  return TDS_OK;
+}
+
+int tds_hip_shard_gathered(tds_hip_shard_t *sh, void *consumer_stream, void **records_dev, int *steps_in_block) {
+  if (!sh || !records_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (sh->last_slot < 0) return fail(TDS_ERR_INVALID_ARG, "no exchange submitted yet");
+  DeviceGuard guard(sh->sim->device);
+  // the consumer's stream waits for the exchange; the host does not
+  TDS_HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, sh->ev_done[sh->last_slot], 0));
+  *records_dev = sh->gathered[sh->last_slot];
+  if (steps_in_block) *steps_in_block = sh->block;
+  return TDS_OK;
+}
+
+}  // extern "C"

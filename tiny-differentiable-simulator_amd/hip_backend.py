@@ -72,6 +72,26 @@ def lib():
         L.tds_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.tds_hip_profile_phases.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
         L.tds_hip_kernel_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        for f in ("tds_hip_device", "tds_hip_record_bytes", "tds_hip_sync", "tds_hip_forward_zero_host_end"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.tds_hip_forward_zero_host_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        for f in ("tds_hip_step_many_prepare", "tds_hip_step_many"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        # multi-GPU shards (RCCL all-gather of the observation records)
+        L.tds_hip_shard_unique_id.argtypes = [C.c_void_p]
+        L.tds_hip_shard_create.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.POINTER(C.c_void_p)]
+        L.tds_hip_shard_create_all.argtypes = [P, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                               C.POINTER(C.c_void_p)]
+        L.tds_hip_shard_sim.restype = C.c_void_p
+        for f in ("tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
+                  "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes",
+                  "tds_hip_shard_flush"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.tds_hip_shard_set_block.argtypes = [C.c_void_p, C.c_int]
+        L.tds_hip_shard_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.tds_hip_shard_group_step.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int]
+        L.tds_hip_shard_gathered.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -85,6 +105,12 @@ EXPORTED_SYMBOLS = [
     "tds_hip_set_auto_reset", "tds_hip_reset", "tds_hip_rollout",
     "tds_hip_forward_zero_host", "tds_hip_send_local", "tds_hip_forward_zero_fetch",
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
+    "tds_hip_device", "tds_hip_record_bytes", "tds_hip_sync", "tds_hip_forward_zero_host_begin",
+    "tds_hip_forward_zero_host_end", "tds_hip_step_many_prepare", "tds_hip_step_many",
+    "tds_hip_shard_rccl_version", "tds_hip_shard_unique_id", "tds_hip_shard_create", "tds_hip_shard_create_all",
+    "tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
+    "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes", "tds_hip_shard_set_block",
+    "tds_hip_shard_step", "tds_hip_shard_group_step", "tds_hip_shard_flush", "tds_hip_shard_gathered",
     "tds_rb_last_error", "tds_rb_create", "tds_rb_destroy", "tds_rb_set_stream", "tds_rb_state_device",
     "tds_rb_set_state", "tds_rb_get_state", "tds_rb_step",
 ]
@@ -99,15 +125,26 @@ def model_check(m: _model.Model) -> None:
     _check(lib().tds_hip_model_check(C.byref(m)))
 
 
+def dtype_code(dtype) -> int:
+    """"f64": double arithmetic + double records; "mixed": double arithmetic + FLOAT records (the reference's float
+    record ABI, parity-gated); "f32": pure float (measured only)."""
+    if isinstance(dtype, int):
+        return dtype
+    return {"f64": _model.TDS_DTYPE_F64, "float64": _model.TDS_DTYPE_F64, "f32": _model.TDS_DTYPE_F32,
+            "float32": _model.TDS_DTYPE_F32, "mixed": _model.TDS_DTYPE_F64_REC32,
+            "f64r32": _model.TDS_DTYPE_F64_REC32}[dtype]
+
+
 class HipSim:
     """N resident environments of one model on one GPU.
 
     ``x`` / ``y`` are torch views (no copy) of the library-owned env-major records
-    [N, input_dim] / [N, output_dim] in the compute dtype.
+    [N, input_dim] / [N, output_dim] in the RECORD dtype (``torch_dtype``: float64 for "f64", float32 for "mixed"
+    and "f32").
     """
 
     def __init__(self, m: _model.Model, num_envs: int, device: int = 0, dtype: str = "f64",
-                 lanes_per_env: int | None = None, na_cap: int | None = None):
+                 lanes_per_env: int | None = None, na_cap: int | None = None, _handle=None, _owner=None):
         import torch
 
         if not torch.cuda.is_available():
@@ -115,8 +152,17 @@ class HipSim:
         self.model = m.copy()
         self.num_envs = int(num_envs)
         self.device = int(device)
-        self.dtype = _model.TDS_DTYPE_F64 if dtype in ("f64", "float64") else _model.TDS_DTYPE_F32
+        self.dtype = dtype_code(dtype)
         self.torch_dtype = torch.float64 if self.dtype == _model.TDS_DTYPE_F64 else torch.float32
+        self._owner = _owner  # a HipShard owns the handle of its sim
+        if _handle is not None:
+            self.h = _handle
+            self.input_dim = self.model.input_dim
+            self.output_dim = self.model.output_dim
+            self.x = self._wrap(lib().tds_hip_x_device(self.h), (self.num_envs, self.input_dim))
+            self.y = self._wrap(lib().tds_hip_y_device(self.h), (self.num_envs, self.output_dim))
+            self.use_current_stream()
+            return
         if lanes_per_env is not None:
             os.environ["TDS_HIP_LANES_PER_ENV"] = str(lanes_per_env)
         if na_cap is not None:
@@ -143,7 +189,7 @@ class HipSim:
         n = 1
         for s in shape:
             n *= s
-        itemsize = 8 if self.dtype == _model.TDS_DTYPE_F64 else 4
+        itemsize = 8 if getattr(self, "dtype", _model.TDS_DTYPE_F64) == _model.TDS_DTYPE_F64 else 4
         typestr = "<f8" if itemsize == 8 else "<f4"
 
         class _Holder:
@@ -166,7 +212,8 @@ class HipSim:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().tds_hip_destroy(self.h)
+            if getattr(self, "_owner", None) is None:
+                lib().tds_hip_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -174,6 +221,32 @@ class HipSim:
             self.close()
         except Exception:
             pass
+
+    def step_many_prepare(self, actions, n_steps: int, obs=None, first_block: int = 0):
+        """Capture + instantiate the hipGraph of ``n_steps`` closed-loop steps without running anything."""
+        ap, nb, op = self._many_args(actions, obs)
+        _check(lib().tds_hip_step_many_prepare(self.h, ap, nb, int(first_block), int(n_steps), op))
+
+    def step_many(self, actions, n_steps: int, obs=None, first_block: int = 0):
+        """``n_steps`` closed-loop steps as ONE hipGraph launch (tds_hip_step_many): step k takes the action block
+        ``actions[(first_block + k) % len(actions)]`` ([B, N, action_dim] device tensor, or None)."""
+        ap, nb, op = self._many_args(actions, obs)
+        _check(lib().tds_hip_step_many(self.h, ap, nb, int(first_block), int(n_steps), op))
+
+    def _many_args(self, actions, obs):
+        ap, nb, op = None, 1, None
+        if actions is not None:
+            assert actions.is_cuda and actions.dtype == self.torch_dtype and actions.is_contiguous()
+            assert actions.dim() == 3 and tuple(actions.shape[1:]) == (self.num_envs, self.model.action_dim)
+            ap, nb = C.c_void_p(actions.data_ptr()), int(actions.shape[0])
+        if obs is not None:
+            assert obs.is_cuda and obs.dtype == self.torch_dtype and obs.is_contiguous()
+            assert tuple(obs.shape) == (self.num_envs, self.obs_dim + 2)
+            op = C.c_void_p(obs.data_ptr())
+        return ap, nb, op
+
+    def sync(self):
+        _check(lib().tds_hip_sync(self.h))
 
     # -- the hot path -----------------------------------------------------------------------
     def forward_zero(self, x, y=None):
@@ -285,6 +358,96 @@ class HipSim:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _check(lib().tds_hip_kernel_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(lds_bytes_per_env=a.value, lanes_per_env=b.value, envs_per_block=c.value)
+
+
+class HipShard:
+    """This rank's shard of a global batch of environments + the per-policy-step RCCL all-gather of the
+    [obs | reward | done] records (tds_hip_shard_*).  ``sim`` is the shard's HipSim (state upload, reset,
+    auto-reset ... as usual); ``step(actions)`` steps the shard and submits the exchange on the library's
+    communication stream; ``gathered()`` returns the most recently exchanged records as a zero-copy tensor
+    [world, block, n_local, obs_dim + 2] in the wire dtype (the current torch stream waits for the exchange)."""
+
+    def __init__(self, m: _model.Model, global_envs: int, rank: int = 0, world: int = 1, device: int = 0,
+                 dtype: str = "f64", unique_id: bytes | None = None, wire_dtype: str = "f32", block: int = 1):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise TdsHipError("no HIP device visible (the HIP path has no CPU fallback)")
+        self._model = m.copy()
+        h = C.c_void_p()
+        idbuf = None
+        if unique_id is not None:
+            assert len(unique_id) == 128
+            idbuf = C.create_string_buffer(bytes(unique_id), 128)
+        wire = _model.TDS_DTYPE_F64 if wire_dtype in ("f64", "float64") else _model.TDS_DTYPE_F32
+        _check(lib().tds_hip_shard_create(C.byref(self._model), int(global_envs), int(rank), int(world), int(device),
+                                          dtype_code(dtype), idbuf, wire, C.byref(h)))
+        self.h = h
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        self.n_local = lib().tds_hip_shard_local_envs(self.h)
+        self.wire_torch_dtype = torch.float64 if lib().tds_hip_shard_wire_bytes(self.h) == 8 else torch.float32
+        self.sim = HipSim(m, self.n_local, device=device, dtype=dtype,
+                          _handle=C.c_void_p(lib().tds_hip_shard_sim(self.h)), _owner=self)
+        self.block = 1
+        if block != 1:
+            self.set_block(block)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(lib().tds_hip_shard_unique_id(buf))
+        return bytes(buf.raw)
+
+    @staticmethod
+    def rccl_version() -> int:
+        return int(lib().tds_hip_shard_rccl_version())
+
+    def set_block(self, steps_per_exchange: int):
+        _check(lib().tds_hip_shard_set_block(self.h, int(steps_per_exchange)))
+        self.block = int(steps_per_exchange)
+
+    def step(self, actions=None, substeps: int = 1):
+        ap = None
+        if actions is not None:
+            assert actions.is_cuda and actions.dtype == self.sim.torch_dtype and actions.is_contiguous()
+            assert tuple(actions.shape) == (self.n_local, self.sim.model.action_dim)
+            ap = C.c_void_p(actions.data_ptr())
+        _check(lib().tds_hip_shard_step(self.h, ap, int(substeps)))
+
+    def flush(self):
+        _check(lib().tds_hip_shard_flush(self.h))
+
+    def gathered(self):
+        import torch
+
+        ptr, blk = C.c_void_p(), C.c_int()
+        st = torch.cuda.current_stream(self.device)
+        _check(lib().tds_hip_shard_gathered(self.h, C.c_void_p(st.cuda_stream), C.byref(ptr), C.byref(blk)))
+        shape = (self.world, blk.value, self.n_local, self.sim.obs_dim + 2)
+
+        class _Holder:
+            pass
+
+        hld = _Holder()
+        hld.__cuda_array_interface__ = {
+            "shape": shape, "typestr": "<f8" if self.wire_torch_dtype == torch.float64 else "<f4",
+            "data": (int(ptr.value), False), "version": 2, "strides": None,
+        }
+        t = torch.as_tensor(hld, device=f"cuda:{self.device}")
+        t._tds_owner = self
+        return t
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.sim.h = None
+            lib().tds_hip_shard_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class RigidBodySim:

@@ -26,6 +26,7 @@ TDS_STEP_TAU = 1
 TDS_REWARD_NONE, TDS_REWARD_ANT, TDS_REWARD_LAIKAGO, TDS_REWARD_HUMANOID = 0, 1, 2, 3
 TDS_DTYPE_F64 = 0
 TDS_DTYPE_F32 = 1
+TDS_DTYPE_F64_REC32 = 2  # double arithmetic, float records (include/tds_hip.h)
 
 JOINT_FIXED = -1
 JOINT_PRISMATIC_X, JOINT_PRISMATIC_Y, JOINT_PRISMATIC_Z, JOINT_PRISMATIC_AXIS = 0, 1, 2, 3
@@ -105,7 +106,7 @@ class Model(C.Structure):
         ("reset_q", C.c_double * TDS_MAX_DOF),
         ("reset_noise", C.c_double * TDS_MAX_DOF),
         ("settle_steps", C.c_int32),
-        ("pad2_", C.c_int32),
+        ("reset_obs_raw_xy", C.c_int32),
         ("base_mass", C.c_double),
         ("base_com", C.c_double * 3),
         ("base_inertia", C.c_double * 9),
@@ -179,6 +180,7 @@ def model_to_dict(m: Model) -> dict:
     d = {k: getattr(m, k) for k in _SCALARS}
     for k in _VECTORS:
         d[k] = [float(x) for x in getattr(m, k)]
+    d["reset_obs_raw_xy"] = int(m.reset_obs_raw_xy)
     d["base_mass"] = float(m.base_mass)
     for k in _OPTIONAL_VECTORS:
         d[k] = [float(x) for x in getattr(m, k)]
@@ -201,6 +203,7 @@ def model_from_dict(d: dict) -> Model:
         arr = getattr(m, k)
         for i, x in enumerate(d[k]):
             arr[i] = x
+    m.reset_obs_raw_xy = d.get("reset_obs_raw_xy", 0)
     m.base_mass = d.get("base_mass", 0.0)
     for k in _OPTIONAL_VECTORS:
         arr = getattr(m, k)
