@@ -9,8 +9,11 @@ A "step" = one closed-loop environment step of every resident env: fresh action 
 in HBM) -> HIP step kernel (PD, forward dynamics, plane contacts, MLCP/PGS, Euler, record packing) -> new
 state fed back on device, plus the [obs | reward | done] record written by the same launch.
 With N > 1 ranks each GPU owns its own shard of environments (no data-path collective inside
-the step) and the observation records are all-gathered over RCCL once per step, on a side stream,
-overlapped with the next step.
+the step) and the observation records are all-gathered over RCCL ONCE PER POLICY STEP by the
+library's own shard layer (tds_hip_shard_*: librccl called from C, communication stream, overlapped with
+the next step); the 32-steps-per-exchange pipelined form is timed afterwards and reported as a second key.
+At N = 1 the K timed steps are replayed from a captured hipGraph (tds_hip_step_many: one graph launch
+instead of K kernel launches), so that short runs reproduce the steady-state rate.
 
 Prints ONE JSON line on rank 0 (contract in the project brief): value = total env-steps / s
 over all GPUs, plus `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM) and
@@ -132,15 +135,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--model", default="ant")
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "f32-pure"],
+                    help="f64: double arithmetic, double records (the reference's arithmetic; headline).  f32: FLOAT "
+                         "records (x, y, actions, obs) with the arithmetic in double registers — the variant that meets "
+                         "the 1e-6 contract on float records (BASELINE config 2).  f32-pure: float arithmetic "
+                         "(measured only: misses 1e-6, like the reference's own float instantiation)")
+    ap.add_argument("--no-graph", action="store_true", help="N = 1: K eager launches instead of one hipGraph launch")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (16/32/64), 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout-steps", type=int, default=0,
                     help="also time the on-device policy rollout (tds_hip_rollout) with this many policy steps per call")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
-    ap.add_argument("--gather-every", type=int, default=32,
-                    help="N > 1: steps whose [obs|reward|done] records travel in one all-gather (1 = every step)")
-    ap.add_argument("--gather-dtype", choices=["f32", "f64", "same"], default="f32",
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1: steps whose [obs|reward|done] records travel in one all-gather (1 = one exchange "
+                         "per policy step, SURVEY 8e's protocol and the default)")
+    ap.add_argument("--pipelined-block", type=int, default=32,
+                    help="N > 1: also time the pipelined form with this many steps per exchange (0 = skip)")
+    ap.add_argument("--gather-dtype", choices=["f32", "f64"], default="f32",
                     help="dtype the [obs | reward | done] records cross xGMI in (the step itself stays in --dtype): "
                          "f32 = 4 B per scalar as SURVEY 8e sizes the exchange (default), same / f64 = as computed")
     ap.add_argument("--force-gather", action="store_true",
@@ -190,8 +201,28 @@ def main():
 
     m = tds_amd.load_model(args.model)
     n = args.envs_per_gpu
-    sim = hip_backend.HipSim(m, n, device=local_rank, dtype=args.dtype,
-                             lanes_per_env=args.lanes if args.lanes else None)
+    lib_dtype = {"f64": "f64", "f32": "mixed", "f32-pure": "f32"}[args.dtype]
+    multi = world > 1 or args.force_gather
+    shard = None
+    if multi:
+        # the multi-GPU path of the C ABI: this rank's shard + the RCCL all-gather of its records.  Only the 128-byte
+        # ncclUniqueId travels through torch.distributed (rendezvous); the data path is librccl called from C.
+        uid = None
+        if world > 1 or os.environ.get("TDS_BENCH_RCCL_SINGLE", "1") == "1":
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(hip_backend.HipShard.unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(idt, src=0)
+            uid = bytes(idt.cpu().numpy().tobytes())
+        if args.lanes:
+            os.environ["TDS_HIP_LANES_PER_ENV"] = str(args.lanes)
+        shard = hip_backend.HipShard(m, world * n, rank=rank, world=world, device=local_rank, dtype=lib_dtype,
+                                     unique_id=uid, wire_dtype=args.gather_dtype, block=max(1, args.gather_every))
+        sim = shard.sim
+    else:
+        sim = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype,
+                                 lanes_per_env=args.lanes if args.lanes else None)
     tdt = sim.torch_dtype
     nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
 
@@ -223,54 +254,53 @@ def main():
     amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
     actions = torch.from_numpy(rng.uniform(-amp, amp, (pool, n, adim))).to(tdt).cuda().contiguous()
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
-    # the one exchange of the multi-GPU path: all-gather of the [obs | reward | done] records over RCCL.
-    # Nothing in the step depends on the gathered records (per-environment policies run on device; a
-    # learner consumes trajectories), so the records of B consecutive steps travel in ONE all-gather on a
-    # side stream while the next steps compute: at ~23 us per step a collective per step would be bound by
-    # its host-side launch cost, not by xGMI.  Every record still crosses inside the timed region.
-    gather = None
-    multi = world > 1 or args.force_gather
     B = max(1, args.gather_every)
-    if multi:
-        # records of B consecutive steps travel together: [B*n, obs_dim+2] per rank and exchange
-        wire = {"f32": torch.float32, "f64": torch.float64, "same": tdt}[args.gather_dtype]
-        gather = tds_amd.sharded.PipelinedObsGather(world * n * B, sim.obs_dim + 2, tdt, f"cuda:{local_rank}",
-                                                    wire_dtype=wire)
-        ring = [torch.zeros((B, n, sim.obs_dim + 2), dtype=tdt, device="cuda") for _ in range(gather.slots)]
+    use_graph = not multi and not args.no_graph
+    GCH = 1024  # steps per graph launch when K is larger (a multiple of the action pool)
     state = {"i": 0}
 
-    def one_step(i):
+    def run_steps(k_steps):
+        """k_steps closed-loop steps with a fresh action block each; multi: + the per-step record exchange"""
         if multi:
-            k = state["i"]
-            slot, j = (k // B) % gather.slots, k % B
-            if j == 0:
-                gather.before_reuse(slot)
-            sim.step(actions[i % pool], 1, ring[slot][j])
-            if j == B - 1:
-                gather.submit(ring[slot].view(B * n, -1), slot)
-            state["i"] = k + 1
+            for _ in range(k_steps):
+                shard.step(actions[state["i"] % pool], 1)
+                state["i"] += 1
+        elif use_graph:
+            left = k_steps
+            while left > 0:
+                c = left if left <= GCH else GCH
+                if c < GCH and k_steps > GCH:  # remainder of a long run: eager (the graph cache holds one graph)
+                    for _ in range(c):
+                        sim.step(actions[state["i"] % pool], 1, obs)
+                        state["i"] += 1
+                else:
+                    sim.step_many(actions, c, obs, first_block=state["i"] % pool)
+                    state["i"] += c
+                left -= c
         else:
-            sim.step(actions[i % pool], 1, obs)
+            for _ in range(k_steps):
+                sim.step(actions[state["i"] % pool], 1, obs)
+                state["i"] += 1
+
+    def prepare(k_steps):
+        """build the hipGraph of the next run_steps(k_steps) ahead of time (nothing executes)"""
+        if use_graph and k_steps > 0:
+            sim.step_many_prepare(actions, min(k_steps, GCH), obs, first_block=state["i"] % pool)
 
     def flush():
-        """exchange a partially filled record block (end of a region) and wait for everything in flight"""
-        if gather is None:
-            return
-        k = state["i"]
-        if k % B:
-            gather.submit(ring[(k // B) % gather.slots].view(B * n, -1), (k // B) % gather.slots)
-            state["i"] = (k // B + 1) * B
-        gather.wait_all()
+        if multi:
+            shard.flush()
 
-    for i in range(args.warmup):
-        one_step(i)
+    prepare(args.warmup)
+    run_steps(args.warmup)
     flush()
     torch.cuda.synchronize()
+    K = args.steps
+    prepare(K)  # (capture + instantiate only)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
 
-    K = args.steps
     use_events = not args.no_events
     # one HIP event pair brackets the whole timed region on the launch stream (HipSim hands
     # torch.cuda.current_stream() to tds_hip_set_stream): region_ms / K is the average launch
@@ -280,8 +310,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for i in range(K):
-        one_step(i)
+    run_steps(K)
     flush()
     ev1.record()
     torch.cuda.synchronize()
@@ -298,7 +327,7 @@ def main():
     kernel_ms_isolated = None
     if use_events:
         region_ms = ev0.elapsed_time(ev1)
-        if world == 1:
+        if world == 1 and not multi:
             kernel_ms = region_ms / K  # only kernel launches are in the region at N = 1
         ns = min(K, 200)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ns)]
@@ -310,6 +339,31 @@ def main():
         kernel_ms_isolated = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         if kernel_ms is None:
             kernel_ms = kernel_ms_isolated
+
+    # secondary (N > 1): the pipelined exchange — records of `pipelined_block` consecutive steps in one all-gather
+    pipelined = None
+    if multi and args.pipelined_block > 1 and args.pipelined_block != B:
+        shard.set_block(args.pipelined_block)
+        run_steps(2 * args.pipelined_block)
+        flush()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        run_steps(K)
+        flush()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_p = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt_p], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_p = float(t.item())
+        pipelined = {"value": world * n * K / dt_p, "unit": "env-steps/s", "steps_per_exchange": args.pipelined_block,
+                     "what": "same steps, records of 32 consecutive steps per all-gather (observations reach other "
+                             "ranks up to 32 steps late); secondary — the headline value uses one exchange per step"}
+        shard.set_block(B)
 
     # The reference has no joint limits and no velocity clamps: a robot that has fallen over can be driven
     # into a numerical blow-up by the random actions (the CPU reference diverges from the same state the same
@@ -338,7 +392,7 @@ def main():
                            "(step-loop build), or from two wavefronts per SIMD on one straight-line step launch per "
                            "step with the policy + bookkeeping kernel in between (tds_hip_rollout picks)"}
     if rank == 0:
-        elem = 8 if args.dtype == "f64" else 4
+        elem = 8 if args.dtype == "f64" else 4  # bytes per scalar of the records in HBM
         bytes_per_env_step = (m.input_dim + m.output_dim) * elem  # x record in + y record out
         total_steps = world * n * K
         value = total_steps / elapsed
@@ -346,6 +400,7 @@ def main():
         if kernel_ms:
             achieved = n * bytes_per_env_step / (kernel_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(args.model, n, args.dtype)
+            arith = "f32" if args.dtype == "f32-pure" else "f64"
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "tds_step_kernel", "kernel_ms_avg": kernel_ms,
@@ -355,24 +410,35 @@ def main():
                     "algorithmic_flops_per_env_step": ALG_FLOPS.get(args.model),
                     "algorithmic_tflops": (ALG_FLOPS[args.model] * n / (kernel_ms * 1e-3) / 1e12
                                            if args.model in ALG_FLOPS else None),
-                    "valu_peak_tflops_f64": 78.6,
+                    "valu_peak_tflops": 78.6 if arith == "f64" else 157.3,
                     "note": "algorithmic bytes = (input_dim+output_dim)*sizeof(T) per env-step; the path is "
                             "VALU/LDS-latency bound, see DESIGN.md"}
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K,
             "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            # the arithmetic type the path computes in; the record type is in config.records
+            "dtype": "f32" if args.dtype == "f32-pure" else "f64", "data": "synthetic",
             "config": {"workload": f"{args.model} (gym Ant 14-dof + plane, 17 contact points, PGS 1 iter), "
                                    f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
                        if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
+                       "records": "f64" if args.dtype == "f64" else "f32",
+                       "launch": ("hipGraph: %d steps per graph launch" % min(K, GCH)) if use_graph else "one kernel launch per step",
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
-                       "parallelism": f"env-shard x{world}" + (f" + RCCL all_gather of the (obs|reward|done) records of every {B} steps ({'f32' if args.gather_dtype == 'f32' else args.dtype} on the wire), overlapped with the next steps" if world > 1 else ""),
+                       "parallelism": f"env-shard x{world}" + (
+                           f" + one ncclAllGather (librccl from the C ABI, tds_hip_shard_step) of the (obs|reward|done) "
+                           f"records per {'policy step' if B == 1 else str(B) + ' steps'}, "
+                           f"{args.gather_dtype if args.dtype == 'f64' else 'f32'} on the wire (the records are computed "
+                           f"and fed back in {'f64' if args.dtype == 'f64' else 'f32'} on the owning GPU), on a "
+                           f"communication stream, overlapped with the next step" if multi else ""),
                        "lanes_per_env": sim.kernel_info()["lanes_per_env"],
                        "lds_bytes_per_env": sim.kernel_info()["lds_bytes_per_env"]},
             "roofline": roof, "finite": finite, "nonfinite_envs": bad_envs,
         }
         if rollout is not None:
             out["on_device_rollout"] = rollout
+        if pipelined is not None:
+            out["pipelined_gather"] = pipelined
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(args.model, min(n, 4096))
             primary = cb.get("reference") or cb.get("port")

@@ -1,0 +1,192 @@
+"""GPU: the multi-GPU shard layer of the C ABI (tds_hip_shard_*: contiguous environment shards + one RCCL all-gather
+of the [obs | reward | done] records per policy step) and the hipGraph step loop (tds_hip_step_many).
+
+A 1-GPU box exercises the whole path with ONE rank (RCCL communicator of size 1, communication stream, ring of record
+blocks, wire conversion); the 2-rank test runs wherever tds_hip_device_count() >= 2 and skips loudly otherwise.  The
+sharding arithmetic and the N > 1 protocol on CPU are covered by tests/test_sharded_gloo.py (gloo, world_size 2)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+import tds_amd
+from tds_amd import hip_backend
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _start(m, n, seed=5):
+    g = np.load(os.path.join(GOLDEN, "ant.npz"))
+    rng = np.random.default_rng(seed)
+    x = g["x"][rng.integers(0, g["x"].shape[0], n)].copy()
+    acts = rng.uniform(-0.4, 0.4, (6, n, m.action_dim))
+    return x, acts
+
+
+@pytest.mark.parametrize("with_rccl", [False, True])
+@pytest.mark.parametrize("wire", ["f32", "f64"])
+def test_one_rank_shard_equals_plain_stepping(with_rccl, wire, built):
+    torch = _torch()
+    if with_rccl and hip_backend.HipShard.rccl_version() == 0:
+        pytest.skip("librccl cannot be loaded on this machine")
+    m = tds_amd.load_model("ant")
+    n = 256
+    x, acts = _start(m, n)
+    ref = hip_backend.HipSim(m, n)
+    ref.x.copy_(torch.from_numpy(x).cuda())
+    uid = hip_backend.HipShard.unique_id() if with_rccl else None
+    sh = hip_backend.HipShard(m, n, rank=0, world=1, device=0, dtype="f64", unique_id=uid, wire_dtype=wire)
+    sh.sim.x.copy_(torch.from_numpy(x).cuda())
+    obs = torch.zeros((n, ref.obs_dim + 2), dtype=torch.float64, device="cuda")
+    for k in range(6):
+        a = torch.from_numpy(acts[k]).cuda()
+        ref.step(a, 1, obs)
+        sh.step(a)
+        got = sh.gathered()  # (the current stream waits for the exchange)
+        assert tuple(got.shape) == (1, 1, n, ref.obs_dim + 2)
+        want = obs if wire == "f64" else obs.float()
+        assert got.dtype == want.dtype
+        assert torch.equal(got[0, 0], want), k
+    sh.flush()
+    assert torch.equal(sh.sim.x, ref.x) and torch.equal(sh.sim.y, ref.y)
+    sh.close()
+
+
+def test_blocked_exchange_carries_every_step(built):
+    """steps_per_exchange = 4 (the pipelined form): one all-gather carries the records of four consecutive steps"""
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    n = 128
+    x, acts = _start(m, n, seed=8)
+    ref = hip_backend.HipSim(m, n)
+    ref.x.copy_(torch.from_numpy(x).cuda())
+    uid = hip_backend.HipShard.unique_id() if hip_backend.HipShard.rccl_version() else None
+    sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype="f64", block=4)
+    sh.sim.x.copy_(torch.from_numpy(x).cuda())
+    recs = []
+    for k in range(6):
+        a = torch.from_numpy(acts[k]).cuda()
+        o = torch.zeros((n, ref.obs_dim + 2), dtype=torch.float64, device="cuda")
+        ref.step(a, 1, o)
+        recs.append(o)
+        sh.step(a)
+        if k == 3:
+            got = sh.gathered()
+            assert tuple(got.shape) == (1, 4, n, ref.obs_dim + 2)
+            for j in range(4):
+                assert torch.equal(got[0, j], recs[j]), j
+    sh.flush()  # the partial block (steps 4, 5) travels at the flush
+    got = sh.gathered()
+    assert torch.equal(got[0, 0], recs[4]) and torch.equal(got[0, 1], recs[5])
+    sh.close()
+
+
+def test_float_records_travel_unconverted(built):
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    n = 64
+    x, acts = _start(m, n, seed=9)
+    sh = hip_backend.HipShard(m, n, dtype="mixed", wire_dtype="f64")  # (never widened on the wire)
+    assert sh.wire_torch_dtype == torch.float32
+    sh.sim.x.copy_(torch.from_numpy(x).float().cuda())
+    ref = hip_backend.HipSim(m, n, dtype="mixed")
+    ref.x.copy_(torch.from_numpy(x).float().cuda())
+    obs = torch.zeros((n, ref.obs_dim + 2), dtype=torch.float32, device="cuda")
+    a = torch.from_numpy(acts[0]).float().cuda()
+    ref.step(a, 1, obs)
+    sh.step(a)
+    assert torch.equal(sh.gathered()[0, 0], obs)
+    sh.close()
+
+
+def test_two_ranks_one_process_rccl(built):
+    """Two GPUs driven by one process (tds_hip_shard_create_all + tds_hip_shard_group_step): both ranks end up with
+    the records of the whole batch in global environment order."""
+    torch = _torch()
+    L = hip_backend.lib()
+    if L.tds_hip_device_count() < 2:
+        pytest.skip("SKIPPED LOUDLY: this box has %d GPU(s); the 2-rank RCCL exchange needs 2" % L.tds_hip_device_count())
+    m = tds_amd.load_model("ant")
+    n_global = 512
+    x, acts = _start(m, n_global, seed=21)
+    devs = (C.c_int * 2)(0, 1)
+    hs = (C.c_void_p * 2)()
+    rc = L.tds_hip_shard_create_all(C.byref(m), n_global, 2, devs, tds_amd.TDS_DTYPE_F64, tds_amd.TDS_DTYPE_F64, hs)
+    assert rc == 0, L.tds_hip_last_error()
+    half = n_global // 2
+    ref = hip_backend.HipSim(m, n_global)
+    ref.x.copy_(torch.from_numpy(x).cuda())
+    sims = []
+    for r in range(2):
+        assert L.tds_hip_shard_first_env(hs[r]) == r * half
+        s = hip_backend.HipSim(m, half, device=r, _handle=C.c_void_p(L.tds_hip_shard_sim(hs[r])), _owner=object())
+        with torch.cuda.device(r):
+            s.x.copy_(torch.from_numpy(x[r * half:(r + 1) * half]).to(f"cuda:{r}"))
+        sims.append(s)
+    obs = torch.zeros((n_global, ref.obs_dim + 2), dtype=torch.float64, device="cuda:0")
+    for k in range(4):
+        ref.step(torch.from_numpy(acts[k]).cuda(), 1, obs)
+        a_dev = [torch.from_numpy(acts[k][r * half:(r + 1) * half]).to(f"cuda:{r}") for r in range(2)]
+        ap = (C.c_void_p * 2)(a_dev[0].data_ptr(), a_dev[1].data_ptr())
+        assert L.tds_hip_shard_group_step(hs, 2, ap, 1) == 0, L.tds_hip_last_error()
+        for r in range(2):
+            assert L.tds_hip_shard_flush(hs[r]) == 0
+            ptr, blk = C.c_void_p(), C.c_int()
+            assert L.tds_hip_shard_gathered(hs[r], None, C.byref(ptr), C.byref(blk)) == 0
+            with torch.cuda.device(r):
+                host = hip_backend.wrap_device_pointer(ptr.value, (n_global, ref.obs_dim + 2), torch.float64, r).cpu().numpy()
+            assert np.array_equal(host, obs.cpu().numpy()), (k, r)
+    for r in range(2):
+        sims[r].h = None
+        L.tds_hip_shard_destroy(hs[r])
+
+
+def test_create_restores_the_callers_device(built):
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    before = torch.cuda.current_device()
+    sim = hip_backend.HipSim(m, 16, device=0)
+    assert torch.cuda.current_device() == before
+    assert hip_backend.lib().tds_hip_device(sim.h) == 0 and hip_backend.lib().tds_hip_record_bytes(sim.h) == 8
+
+
+@pytest.mark.parametrize("dtype", ["f64", "mixed"])
+def test_step_many_graph_equals_eager_launches(dtype, built):
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    n = 192
+    x, acts = _start(m, n, seed=13)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    a = torch.from_numpy(acts).to(tdt).cuda().contiguous()  # [6, n, adim]
+    eager, graph = hip_backend.HipSim(m, n, dtype=dtype), hip_backend.HipSim(m, n, dtype=dtype)
+    for s in (eager, graph):
+        s.x.copy_(torch.from_numpy(x).to(tdt).cuda())
+    oe = torch.zeros((n, eager.obs_dim + 2), dtype=tdt, device="cuda")
+    og = torch.zeros_like(oe)
+    K = 17
+    for k in range(K):
+        eager.step(a[(2 + k) % 6], 1, oe)
+    graph.step_many_prepare(a, K, og, first_block=2)  # nothing runs
+    assert torch.equal(graph.x, torch.from_numpy(x).to(tdt).cuda())
+    graph.step_many(a, K, og, first_block=2)
+    torch.cuda.synchronize()
+    assert torch.equal(graph.x, eager.x) and torch.equal(graph.y, eager.y) and torch.equal(og, oe)
+    # replay of the cached graph continues from the new state
+    for k in range(K):
+        eager.step(a[(2 + k) % 6], 1, oe)
+    graph.step_many(a, K, og, first_block=2)
+    torch.cuda.synchronize()
+    assert torch.equal(graph.x, eager.x) and torch.equal(og, oe)
+    # timing covers the whole call
+    graph.set_timing(True)
+    graph.step_many(a, K, og, first_block=2)
+    assert graph.last_kernel_ms() > 0.0

@@ -125,6 +125,23 @@ def model_check(m: _model.Model) -> None:
     _check(lib().tds_hip_model_check(C.byref(m)))
 
 
+def wrap_device_pointer(ptr: int, shape, torch_dtype, device: int, owner=None):
+    """zero-copy torch view of library-owned device memory"""
+    import torch
+
+    class _Holder:
+        pass
+
+    hld = _Holder()
+    hld.__cuda_array_interface__ = {
+        "shape": tuple(shape), "typestr": "<f8" if torch_dtype == torch.float64 else "<f4",
+        "data": (int(ptr), False), "version": 2, "strides": None,
+    }
+    t = torch.as_tensor(hld, device=f"cuda:{device}")
+    t._tds_owner = owner
+    return t
+
+
 def dtype_code(dtype) -> int:
     """"f64": double arithmetic + double records; "mixed": double arithmetic + FLOAT records (the reference's float
     record ABI, parity-gated); "f32": pure float (measured only)."""
