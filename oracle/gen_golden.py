@@ -246,6 +246,29 @@ def rollout_fixture(name, n=24, steps=25, shift=0.5, seed=77):
                 vec_steps=cnt, final_obs=fin)
 
 
+def vecenv_fixture(name, n=12, steps=60, seed=91):
+    """VectorizedEnvironment::step of the REAL reference, driven like its Python binding (reflib.vecenv_steps), from
+    settled start states with fresh random actions each step; every 4th environment starts near its termination
+    threshold so that dones and zero rewards occur."""
+    r, m = make_ref(name)
+    rng = np.random.default_rng(seed)
+    od = m.dof_q + m.dof_qd
+    x = np.stack([rollout_start(name, m, rng) for _ in range(n)])
+    for _ in range(10):
+        y = r.step(x)
+        x[:, :od] = y[:, :od]
+    if name == "ant":
+        x[::4, 2] -= 0.1
+        x[::4, 3] = 0.4
+    else:
+        x[::4, 3] = 0.9            # rolled chassis: up.z = cos(0.9) = 0.62, drops below 0.6 within the run
+        x[::8, 3] = 1.0            # ... or is below it from the first step
+    acts = rng.uniform(-0.4, 0.4, (steps, n, m.action_dim))
+    obs, rew, done, vis = reflib.vecenv_steps(name, x[:, :od], acts, m.output_dim)
+    r.close()
+    return dict(x0=x[:, :od], actions=acts, obs=obs, rewards=rew, dones=done, vis=vis[::10], vis_every=np.int32(10))
+
+
 def main(only=None):
     """only: names whose .npz fixture is (re)generated — default all; the model JSONs are always rewritten."""
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
@@ -292,6 +315,11 @@ def main(only=None):
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_rollout.npz"), **f)
         print(f"{name}_rollout: steps taken {f['vec_steps'].min()}..{f['vec_steps'].max()} of {int(f['steps'])}, "
               f"returns {f['total_rewards'].min():.3f}..{f['total_rewards'].max():.3f}")
+    for name in [n for n in ("ant", "laikago") if only is None or n + "_vecenv" in only]:
+        f = vecenv_fixture(name)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_vecenv.npz"), **f)
+        print(f"{name}_vecenv: {f['obs'].shape[0]} steps x {f['obs'].shape[1]} envs, dones per env "
+              f"{f['dones'].sum(axis=0).astype(int).tolist()}")
 
 
 if __name__ == "__main__":

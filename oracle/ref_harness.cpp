@@ -425,6 +425,59 @@ int tdsref_rollout(const char *name, int batch, int steps, double shift, const d
   return -1;
 }
 
+// The reference's vectorised environment driven the way its Python binding drives it
+// (python/pytinydiffsim_includes.h:58-141: VectorizedAntEnv::step / VectorizedLaikagoEnv::step — fresh obs / rewards /
+// dones vectors per call, then VectorizedEnvironment::step, ars_vectorized_environment.h:213-291), serial stepper,
+// auto_reset_when_done = false, from given states instead of reset().  Records what the binding returns per step:
+//   obs [steps][batch][obs_dim], rewards [steps][batch], dones [steps][batch] (1.0 / 0.0),
+//   vis [steps][batch][output_dim] = sim_states_with_graphics_ (visual_world_transforms)
+// (doubles, before the binding's float casts).  Pins tds_amd.VectorizedAntEnv / VectorizedLaikagoEnv.
+extern "C++" {
+template <typename Sim, typename Env>
+static int ref_vecenv_steps(int batch, int steps, const double *x0, const double *actions_in, double *obs_out,
+                            double *rewards_out, double *dones_out, double *vis_out) {
+  typedef VectorizedEnvironment<Alg, Sim> VecEnv;
+  Env env(false);
+  VecEnv vec_env(env.contact_sim, batch);
+  vec_env.default_stepper_ = &vec_env.serial_stepper_;
+  ARSConfig config;
+  config.batch_size = batch;
+  config.auto_reset_when_done = false;
+  const int od = env.contact_sim.input_dim(), adim = env.contact_sim.action_dim(), out = env.contact_sim.output_dim();
+  for (int e = 0; e < batch; ++e) {
+    vec_env.sim_states_[e].assign(env.contact_sim.input_dim_with_action_and_variables(), 0.0);
+    for (int k = 0; k < od; ++k) vec_env.sim_states_[e][k] = x0[(size_t)e * od + k];
+  }
+  std::vector<std::vector<double>> actions(batch, std::vector<double>(adim));
+  for (int t = 0; t < steps; ++t) {
+    std::vector<std::vector<double>> obs(batch, std::vector<double>(od));
+    std::vector<double> rewards(batch);
+    std::vector<bool> dones(batch);
+    for (int e = 0; e < batch; ++e)
+      for (int k = 0; k < adim; ++k) actions[e][k] = actions_in[((size_t)t * batch + e) * adim + k];
+    vec_env.step(actions, obs, rewards, dones, config);
+    for (int e = 0; e < batch; ++e) {
+      for (int k = 0; k < od; ++k) obs_out[((size_t)t * batch + e) * od + k] = obs[e][k];
+      rewards_out[(size_t)t * batch + e] = rewards[e];
+      dones_out[(size_t)t * batch + e] = dones[e] ? 1.0 : 0.0;
+      for (int k = 0; k < out; ++k) vis_out[((size_t)t * batch + e) * out + k] = vec_env.sim_states_with_graphics_[e][k];
+    }
+  }
+  return 0;
+}
+}  // extern "C++"
+
+int tdsref_vecenv_steps(const char *name, int batch, int steps, const double *x0, const double *actions,
+                        double *obs, double *rewards, double *dones, double *vis) {
+  const std::string n(name);
+  if (n == "ant")
+    return ref_vecenv_steps<AntContactSimulation2<Alg>, AntEnv2<Alg>>(batch, steps, x0, actions, obs, rewards, dones, vis);
+  if (n == "laikago")
+    return ref_vecenv_steps<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, x0, actions, obs, rewards,
+                                                                            dones, vis);
+  return -1;
+}
+
 // Free rigid bodies: the reference's World::step on tds::RigidBody objects
 // (world.hpp:293-366, rigid_body.hpp, rb_constraint_solver.hpp) for n worlds described by the same
 // tds_rb_model_t; state[n][num_bodies][13] = position | quaternion xyzw | linear | angular velocity.

@@ -51,6 +51,8 @@ def lib():
         if hasattr(L, "tdsref_rollout"):
             L.tdsref_rollout.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "tdsref_vecenv_steps"):
+            L.tdsref_vecenv_steps.argtypes = [C.c_char_p, C.c_int, C.c_int] + [C.c_void_p] * 6
         if hasattr(L, "tdsref_f32_create"):
             L.tdsref_f32_create.restype = C.c_void_p
             L.tdsref_f32_create.argtypes = [C.c_char_p, C.c_char_p, C.c_double]
@@ -215,3 +217,31 @@ class RefSim:
                                 Xw.ctypes.data)
         return dict(qdd=qdd, M=M, contacts=contacts[:nc], jac=jac[:nc], links=links[:nc],
                     X_world=Xw)
+
+
+def vecenv_steps(name, x0, actions, output_dim):
+    """The reference's VectorizedEnvironment::step driven like its Python binding (auto_reset_when_done = false,
+    serial stepper) from the states x0 [B, obs_dim] with the action sequence actions [T, B, action_dim].
+    returns obs [T, B, obs_dim], rewards [T, B], dones [T, B], visual_world_transforms [T, B, output_dim]."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    actions = np.ascontiguousarray(actions, dtype=np.float64)
+    T, B, _ = actions.shape
+    od = x0.shape[1]
+    obs = np.zeros((T, B, od))
+    rew = np.zeros((T, B))
+    done = np.zeros((T, B))
+    vis = np.zeros((T, B, output_dim))
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    try:
+        rc = lib().tdsref_vecenv_steps(name.encode(), B, T, x0.ctypes.data, actions.ctypes.data, obs.ctypes.data,
+                                       rew.ctypes.data, done.ctypes.data, vis.ctypes.data)
+        C.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
+    assert rc == 0, rc
+    return obs, rew, done, vis

@@ -123,6 +123,69 @@ def test_full_size_properties(name, built):
     assert torch.isfinite(y).all()
 
 
+def _reference_stepper(name, n):
+    """y = f(x) for [n, input_dim] on the host cores: the REAL reference (oracle/_ref/libtds_ref.so travels to the GPU
+    box prebuilt; one simulation object per thread, ctypes releases the GIL) or, where it is absent, the C oracle."""
+    try:
+        import reflib
+        if reflib.available():
+            import threading
+            nth = min(os.cpu_count() or 1, 64, n)
+            sims = [reflib.RefSim(name) for _ in range(nth)]
+            bounds = np.linspace(0, n, nth + 1).astype(int)
+
+            def step(x):
+                y = [None] * nth
+
+                def work(i):
+                    y[i] = sims[i].step(x[bounds[i]:bounds[i + 1]])
+
+                ths = [threading.Thread(target=work, args=(i,)) for i in range(nth)]
+                [t.start() for t in ths]
+                [t.join() for t in ths]
+                return np.concatenate(y)
+
+            return step, "reference (libtds_ref.so, %d threads)" % nth
+    except Exception:
+        pass
+    m = tds_amd.load_model(name)
+    return (lambda x: oraclelib.step(m, x)), "oracle (tds_oracle.c)"
+
+
+def test_full_size_closed_loop_every_env_against_the_reference(built):
+    """BASELINE config 3 at full size: Ant x 4096, 100 closed-loop steps with fresh actions, EVERY environment and
+    every step compared with the reference's own step_forward_original started from the state the device held
+    before the step (per-step resync).  No environment is dropped."""
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    n, steps = 4096, 100
+    ref_step, what = _reference_stepper("ant", n)
+    rng = np.random.default_rng(2024)
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    ip = np.array([m.initial_poses[i] for i in range(adim)])
+    x0 = np.zeros((n, m.input_dim))
+    x0[:, 2] = 0.48
+    x0[:, 6:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
+    x0[:, -3:] = [15, 0.3, 3]
+    sim = hip_backend.HipSim(m, n)
+    sim.x.copy_(torch.from_numpy(x0).cuda())
+    for _ in range(10):
+        sim.step(None)
+    worst, worst_t = 0.0, -1
+    for t in range(steps):
+        a = rng.uniform(-0.4, 0.4, (n, adim))
+        x_before = sim.x.cpu().numpy()
+        x_before[:, nq + nd:nq + nd + adim] = a
+        sim.step(torch.from_numpy(a).cuda())
+        y_ref = ref_step(x_before)
+        assert np.isfinite(y_ref).all()
+        e = rel_err(sim.y.cpu().numpy(), y_ref)
+        if e > worst:
+            worst, worst_t = e, t
+    print(f"ant x{n}, {steps} closed-loop steps, every env, vs {what}: worst per-step rel err {worst:.3e} (step {worst_t})")
+    assert worst < TOL
+
+
 def test_legacy_host_call_and_ragged_n(built):
     """<model>_forward_zero semantics: host buffers in, host buffers out, any n <= N."""
     _torch()

@@ -26,6 +26,19 @@ class VectorizedEnvOutput:
         self.dones = dones
         self.visual_world_transforms = visual_world_transforms
 
+    def dlpack(self) -> dict:
+        """The four outputs as DLPack capsules (zero-copy hand-over to any DLPack consumer:
+        ``torch.from_dlpack``, ``cupy.from_dlpack``, ``jax.dlpack.from_dlpack`` ...)."""
+        from torch.utils.dlpack import to_dlpack
+
+        return {k: to_dlpack(getattr(self, k)) for k in self.__slots__}
+
+    def as_lists(self) -> dict:
+        """The reference binding's own return types — nested Python lists of floats
+        (python/pytinydiffsim_includes.h:51-56: obs / visual_world_transforms list[list[float]], rewards / dones
+        list[float]).  Copies to the host: for drop-in scripts, not for throughput."""
+        return {k: getattr(self, k).float().cpu().tolist() for k in self.__slots__}
+
 
 class VectorizedEnv:
     def __init__(self, model_name: str, num_envs: int, auto_reset_when_done: bool = True, device: int = 0,
@@ -58,6 +71,14 @@ class VectorizedEnv:
 
     def obs_dim(self) -> int:
         return self.sim.obs_dim
+
+    def set_state(self, state):
+        """Overwrite [q | qd] of every environment ([N, obs_dim]; not part of the reference binding, whose only way
+        to a state is reset(): used to start from given states, e.g. in the parity tests)."""
+        import torch
+
+        st = torch.as_tensor(state, dtype=self.sim.torch_dtype, device=self._obs_rec.device)
+        self.sim.x[:, : self.sim.obs_dim] = st
 
     def reset(self):
         """All environments: reset distribution + settle steps on device; returns obs [N, obs_dim]."""
