@@ -217,8 +217,21 @@ def main():
             uid = bytes(idt.cpu().numpy().tobytes())
         if args.lanes:
             os.environ["TDS_HIP_LANES_PER_ENV"] = str(args.lanes)
-        shard = hip_backend.HipShard(m, world * n, rank=rank, world=world, device=local_rank, dtype=lib_dtype,
-                                     unique_id=uid, wire_dtype=args.gather_dtype, block=max(1, args.gather_every))
+        # (RCCL prints a version banner on C stdout when a communicator comes up: keep rank 0's stdout to the one
+        #  JSON line — send C-level stdout to stderr while the communicator is created)
+        import ctypes
+        libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        libc.fflush(None)
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            shard = hip_backend.HipShard(m, world * n, rank=rank, world=world, device=local_rank, dtype=lib_dtype,
+                                         unique_id=uid, wire_dtype=args.gather_dtype, block=max(1, args.gather_every))
+            libc.fflush(None)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         sim = shard.sim
     else:
         sim = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype,
@@ -255,13 +268,20 @@ def main():
     actions = torch.from_numpy(rng.uniform(-amp, amp, (pool, n, adim))).to(tdt).cuda().contiguous()
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
     B = max(1, args.gather_every)
-    use_graph = not multi and not args.no_graph
+    use_graph = not args.no_graph
     GCH = 1024  # steps per graph launch when K is larger (a multiple of the action pool)
     state = {"i": 0}
 
     def run_steps(k_steps):
         """k_steps closed-loop steps with a fresh action block each; multi: + the per-step record exchange"""
-        if multi:
+        if multi and use_graph and k_steps % B == 0:
+            left = k_steps
+            while left > 0:  # (chunks: multiples of the action pool and of the exchange block)
+                c = left if left <= GCH else GCH
+                shard.step_many(actions, c, first_block=state["i"] % pool)
+                state["i"] += c
+                left -= c
+        elif multi:
             for _ in range(k_steps):
                 shard.step(actions[state["i"] % pool], 1)
                 state["i"] += 1
@@ -284,7 +304,10 @@ def main():
 
     def prepare(k_steps):
         """build the hipGraph of the next run_steps(k_steps) ahead of time (nothing executes)"""
-        if use_graph and k_steps > 0:
+        if use_graph and k_steps > 0 and multi:
+            if k_steps % B == 0:
+                shard.step_many(actions, min(k_steps, GCH), first_block=state["i"] % pool, prepare_only=True)
+        elif use_graph and k_steps > 0:
             sim.step_many_prepare(actions, min(k_steps, GCH), obs, first_block=state["i"] % pool)
 
     def flush():
@@ -344,6 +367,7 @@ def main():
     pipelined = None
     if multi and args.pipelined_block > 1 and args.pipelined_block != B:
         shard.set_block(args.pipelined_block)
+        B_saved, B = B, args.pipelined_block
         run_steps(2 * args.pipelined_block)
         flush()
         torch.cuda.synchronize()
@@ -363,6 +387,7 @@ def main():
         pipelined = {"value": world * n * K / dt_p, "unit": "env-steps/s", "steps_per_exchange": args.pipelined_block,
                      "what": "same steps, records of 32 consecutive steps per all-gather (observations reach other "
                              "ranks up to 32 steps late); secondary — the headline value uses one exchange per step"}
+        B = B_saved
         shard.set_block(B)
 
     # The reference has no joint limits and no velocity clamps: a robot that has fallen over can be driven
@@ -423,7 +448,8 @@ def main():
                                    f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
                        if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
                        "records": "f64" if args.dtype == "f64" else "f32",
-                       "launch": ("hipGraph: %d steps per graph launch" % min(K, GCH)) if use_graph else "one kernel launch per step",
+                       "launch": (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else ""))
+                                  if use_graph else "one kernel launch per step"),
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
                        "parallelism": f"env-shard x{world}" + (
                            f" + one ncclAllGather (librccl from the C ABI, tds_hip_shard_step) of the (obs|reward|done) "

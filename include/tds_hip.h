@@ -403,6 +403,17 @@ int tds_hip_shard_step(tds_hip_shard_t *shard, const void *actions_dev, int subs
 /* The same for all shards of one process (tds_hip_shard_create_all): the steps are enqueued device by device, the
    all-gathers go out as one RCCL group. */
 int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const *actions_dev, int substeps);
+/* n_steps steps of the shard INCLUDING their exchanges as one hipGraph launch (the two-stream pattern of
+   tds_hip_shard_step captured once, RCCL all-gathers as graph nodes): one host call per n_steps instead of ~8 per
+   step — the eager form is host-bound at ~20 us per step.  actions_dev [action_blocks][n_local][action_dim], step k
+   uses block (first_block + k) % action_blocks.  n_steps: a multiple of the exchange block, <= 4096.  Collective:
+   every rank makes the same call.  Falls back to eager stepping if the capture is refused (TDS_HIP_SHARD_NO_GRAPH=1
+   forces that). */
+int tds_hip_shard_step_many(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks, int first_block,
+                            int n_steps);
+/* capture + instantiate the graph of the next tds_hip_shard_step_many with the same arguments; nothing executes */
+int tds_hip_shard_step_many_prepare(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks,
+                                    int first_block, int n_steps);
 /* Exchange a partially filled block, then wait (host) until every exchange in flight has completed. */
 int tds_hip_shard_flush(tds_hip_shard_t *shard);
 int tds_hip_shard_gathered(tds_hip_shard_t *shard, void *consumer_stream, void **records_dev, int *steps_in_block);

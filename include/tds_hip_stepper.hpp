@@ -215,22 +215,39 @@ template <typename Algebra, typename Sim>
 struct HipStepper : public VectorizedEnvironment<Algebra, Sim>::CustomForwardDynamicsStepper {
   using Scalar = typename Algebra::Scalar;
   tds_model_t model_;
-  tds_hip_sim_t *sim_ = nullptr;
+  // one simulation per device: device d steps the contiguous block [first_[d], first_[d + 1]) of the batch
+  std::vector<tds_hip_sim_t *> sims_;
+  std::vector<int> first_;
   int batch_size_;
   bool throw_on_error_;
   std::vector<double> in_, out_;
 
   HipStepper(Sim &contact_sim, int batch_size, int device = 0, bool throw_on_error = false,
              int reward_mode = TDS_REWARD_NONE)
+      : HipStepper(contact_sim, batch_size, std::vector<int>(1, device), throw_on_error, reward_mode) {}
+
+  // Several GPUs behind the same plug-in: the batch is cut into equal contiguous blocks, one per entry of `devices`
+  // (an entry may repeat: two handles on one GPU), every call enqueues all devices' shares before it waits for any.
+  HipStepper(Sim &contact_sim, int batch_size, const std::vector<int> &devices, bool throw_on_error = false,
+             int reward_mode = TDS_REWARD_NONE)
       : batch_size_(batch_size), throw_on_error_(throw_on_error) {
+    if (devices.empty() || batch_size < (int)devices.size()) fail("bad device list", TDS_ERR_INVALID_ARG);
     int rc = flatten_locomotion_env<Algebra>(contact_sim, &model_, reward_mode);
     if (rc) fail("flatten_locomotion_env failed", rc);
-    rc = tds_hip_create(&model_, batch_size, device, TDS_DTYPE_F64, &sim_);
-    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    const int nd = (int)devices.size();
+    first_.resize(nd + 1);
+    for (int d = 0; d <= nd; ++d) first_[d] = (int)((long long)batch_size * d / nd);
+    sims_.assign(nd, nullptr);
+    for (int d = 0; d < nd; ++d) {
+      rc = tds_hip_create(&model_, first_[d + 1] - first_[d], devices[d], TDS_DTYPE_F64, &sims_[d]);
+      if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    }
     in_.resize((size_t)batch_size * model_.input_dim);
     out_.resize((size_t)batch_size * model_.output_dim);
   }
-  virtual ~HipStepper() { tds_hip_destroy(sim_); }
+  virtual ~HipStepper() {
+    for (tds_hip_sim_t *s : sims_) tds_hip_destroy(s);
+  }
 
   void fail(const char *what, int rc) {
     std::string msg = std::string("tds_hip: ") + what + " (code " + std::to_string(rc) + ")";
@@ -254,8 +271,19 @@ struct HipStepper : public VectorizedEnvironment<Algebra, Sim>::CustomForwardDyn
       if ((int)thread_inputs[e].size() != in) fail("input record size mismatch", TDS_ERR_INVALID_ARG);
       for (int k = 0; k < in; ++k) in_[(size_t)e * in + k] = Algebra::to_double(thread_inputs[e][k]);
     }
-    int rc = tds_hip_forward_zero_host(sim_, n, in_.data(), out_.data());
-    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    // enqueue every device's share (H2D -> kernel -> D2H on its own stream), then wait for all of them
+    const int nd = (int)sims_.size();
+    for (int d = 0; d < nd; ++d) {
+      const int lo = first_[d] < n ? first_[d] : n, hi = first_[d + 1] < n ? first_[d + 1] : n;
+      if (hi <= lo) continue;
+      int rc = tds_hip_forward_zero_host_begin(sims_[d], hi - lo, in_.data() + (size_t)lo * in, out_.data() + (size_t)lo * od);
+      if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    }
+    for (int d = 0; d < nd; ++d) {
+      if ((first_[d] < n ? first_[d] : n) >= (first_[d + 1] < n ? first_[d + 1] : n)) continue;
+      int rc = tds_hip_forward_zero_host_end(sims_[d]);
+      if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    }
     for (int e = 0; e < n; ++e) {
       if ((int)thread_outputs[e].size() != od) fail("output record size mismatch", TDS_ERR_INVALID_ARG);
       for (int k = 0; k < od; ++k) thread_outputs[e][k] = Algebra::from_double(out_[(size_t)e * od + k]);

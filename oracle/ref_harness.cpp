@@ -309,7 +309,8 @@ int tdsref_flatten(void *h, tds_model_t *out) {
 // the message (e.g. "no HIP device visible" on a machine without a GPU).
 extern "C++" {
 template <typename Sim, typename Env>
-static int hipstepper_selftest(int batch, int steps, int reward_mode, double *obs0, char *msg, int msg_len) {
+static int hipstepper_selftest(int batch, int steps, int reward_mode, double *obs0, char *msg, int msg_len,
+                               const std::vector<int> &devices = std::vector<int>(1, 0)) {
   typedef VectorizedEnvironment<Alg, Sim> VecEnv;
   Env env(false);
   VecEnv vec_env(env.contact_sim, batch);
@@ -317,7 +318,7 @@ static int hipstepper_selftest(int batch, int steps, int reward_mode, double *ob
   config.batch_size = batch;
   config.auto_reset_when_done = false;
   try {
-    tds_hip::HipStepper<Alg, Sim> stepper(env.contact_sim, batch, 0, /*throw_on_error=*/true, reward_mode);
+    tds_hip::HipStepper<Alg, Sim> stepper(env.contact_sim, batch, devices, /*throw_on_error=*/true, reward_mode);
     vec_env.seed(42);
     auto observations = vec_env.reset(config);
     vec_env.default_stepper_ = &stepper;
@@ -361,6 +362,14 @@ int tdsref_hipstepper_selftest_env(const char *env, int batch, int steps, double
     return hipstepper_selftest<HumanoidContactSimulation<Alg>, HumanoidEnv<Alg>>(batch, steps, TDS_REWARD_HUMANOID, obs0, msg, msg_len);
   snprintf(msg, msg_len, "unknown env %s", env);
   return -1;
+}
+
+// HipStepper with a device LIST (one handle per entry; an entry may repeat, so a 1-GPU box exercises the split):
+// Ant, the batch cut into n_devices contiguous blocks
+int tdsref_hipstepper_selftest_devices(int batch, int steps, int n_devices, const int *devices, double *obs0, char *msg,
+                                       int msg_len) {
+  return hipstepper_selftest<AntContactSimulation2<Alg>, AntEnv2<Alg>>(batch, steps, TDS_REWARD_ANT, obs0, msg, msg_len,
+                                                                       std::vector<int>(devices, devices + n_devices));
 }
 
 // The reference's OWN rollout loop on its header-only CPU path: Worker::rollouts

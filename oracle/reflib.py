@@ -102,6 +102,26 @@ def hipstepper_selftest(batch=8, steps=5, env="ant"):
     return rc, msg.value.decode(), obs0
 
 
+def hipstepper_selftest_devices(devices, batch=10, steps=4):
+    """HipStepper constructed with a device list (the batch split over one handle per entry) inside the reference's
+    VectorizedEnvironment<Ant>; returns (rc, message)."""
+    obs0 = np.zeros(64)
+    msg = C.create_string_buffer(512)
+    devs = (C.c_int * len(devices))(*devices)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    try:
+        rc = lib().tdsref_hipstepper_selftest_devices(batch, steps, len(devices), devs, obs0.ctypes.data, msg, 512)
+        C.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
+    return rc, msg.value.decode()
+
+
 def rollout(name, x0, params, steps, shift=0.0):
     """The reference's own rollout loop (Worker::rollouts + VectorizedEnvironment::policy/step, serial
     stepper) from the states x0 [B, dof_q+dof_qd] with per-environment linear policies params [B, P].

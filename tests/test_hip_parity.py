@@ -223,6 +223,13 @@ def test_reference_vecenv_dropin(built):
         rc, msg, obs0 = reflib.hipstepper_selftest(16, 20, env)
         print(f"HipStepper in VectorizedEnvironment<{env}>:", msg)
         assert rc == 0, (env, msg)
+    # the same plug-in over a device LIST: the batch is split over one handle per entry (two handles on GPU 0 here,
+    # GPUs 0 and 1 where the box has them); every share is enqueued before any is waited for
+    ndev = hip_backend.lib().tds_hip_device_count()
+    for devices in ([0, 0], [0, 0, 0], [0, 1] if ndev >= 2 else [0]):
+        rc, msg = reflib.hipstepper_selftest_devices(devices, batch=10, steps=6)
+        print(f"HipStepper over devices {devices}:", msg)
+        assert rc == 0, (devices, msg)
 
 
 @pytest.mark.parametrize("name", ["ant", "laikago", "humanoid"])
@@ -423,7 +430,10 @@ def test_forced_reset_matches_host_emulation(name, built):
             ref = _host_reset(m, x_before[e].cpu().numpy(), seed, e, 0)
             assert rel_err(x_after[e, :nqd], ref) < TOL, e
             o = obs[e].cpu().numpy()
-            assert o[0] == 0 and o[1] == 0 and rel_err(o[2:nqd], ref[2:]) < TOL
+            if m.reset_obs_raw_xy:   # Laikago / Humanoid reset() hands out the state as it is
+                assert rel_err(o[:nqd], ref) < TOL
+            else:                    # AntContactSimulation2::reset zeroes the base x, y
+                assert o[0] == 0 and o[1] == 0 and rel_err(o[2:nqd], ref[2:]) < TOL
             assert o[nqd] == -7.0 and o[nqd + 1] == -7.0  # reward / done untouched
         else:
             assert np.array_equal(x_after[e], x_before[e].cpu().numpy())

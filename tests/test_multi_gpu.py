@@ -190,3 +190,38 @@ def test_step_many_graph_equals_eager_launches(dtype, built):
     graph.set_timing(True)
     graph.step_many(a, K, og, first_block=2)
     assert graph.last_kernel_ms() > 0.0
+
+
+@pytest.mark.parametrize("with_rccl", [False, True])
+def test_shard_step_many_graph_equals_eager_exchange(with_rccl, built):
+    """the two-stream step + all-gather pattern captured into one hipGraph (RCCL all-gathers as graph nodes)"""
+    torch = _torch()
+    if with_rccl and hip_backend.HipShard.rccl_version() == 0:
+        pytest.skip("librccl cannot be loaded on this machine")
+    m = tds_amd.load_model("ant")
+    n = 256
+    x, acts = _start(m, n, seed=31)
+    a = torch.from_numpy(acts).cuda().contiguous()
+    uid = hip_backend.HipShard.unique_id() if with_rccl else None
+    eager = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype="f64")
+    uid2 = hip_backend.HipShard.unique_id() if with_rccl else None
+    graph = hip_backend.HipShard(m, n, unique_id=uid2, wire_dtype="f64")
+    for s in (eager, graph):
+        s.sim.x.copy_(torch.from_numpy(x).cuda())
+    K = 11
+    for rep in range(3):  # first call captures, later calls replay the cached graph
+        for k in range(K):
+            eager.step(a[(1 + k) % 6])
+        if rep == 0:
+            graph.step_many(a, K, first_block=1, prepare_only=True)
+            assert torch.equal(graph.sim.x, torch.from_numpy(x).cuda())
+        graph.step_many(a, K, first_block=1)
+        ge, gg = eager.gathered().clone(), graph.gathered().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(graph.sim.x, eager.sim.x) and torch.equal(gg, ge), rep
+    # eager steps after a graph launch continue the same ring
+    eager.step(a[0])
+    graph.step(a[0])
+    assert torch.equal(graph.gathered(), eager.gathered())
+    eager.close()
+    graph.close()

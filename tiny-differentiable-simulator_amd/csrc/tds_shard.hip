@@ -106,6 +106,11 @@ struct tds_hip_shard {
   bool pending[kSlots] = {};
   long long steps = 0;  // steps submitted so far
   int last_slot = -1;   // slot of the most recently submitted exchange
+  // K steps + their exchanges replayed from one captured hipGraph (tds_hip_shard_step_many)
+  hipGraphExec_t graph_exec = nullptr;
+  hipStream_t graph_stream = nullptr;
+  const void *graph_actions = nullptr;
+  int graph_pool = 0, graph_first = 0, graph_steps = 0, graph_block = 0, graph_slot0 = 0, graph_last_slot = -1;
 
   size_t block_scalars() const { return (size_t)block * n_local * sim->obs_width(); }
 };
@@ -300,6 +305,8 @@ int tds_hip_shard_destroy(tds_hip_shard_t *sh) {
   {
     DeviceGuard guard(device);
     if (sh->comm_stream) (void)hipStreamSynchronize(sh->comm_stream);
+    if (sh->graph_exec) (void)hipGraphExecDestroy(sh->graph_exec);
+    if (sh->graph_stream) (void)hipStreamDestroy(sh->graph_stream);
     if (sh->comm && rccl()) (void)rccl()->CommDestroy(sh->comm);
     for (int i = 0; i < kSlots; ++i) {
       if (sh->wire[i] && sh->wire[i] != sh->rec[i]) (void)hipFree(sh->wire[i]);
@@ -380,6 +387,119 @@ int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const 
     rc = shard_mark_done(shards[i], slot);
   }
   return rc;
+}
+
+// n_steps closed-loop steps of the shard INCLUDING their record exchanges as ONE hipGraph launch.  The two-stream
+// pattern of tds_hip_shard_step (step on the sim stream, all-gather on the communication stream, ring of record
+// blocks) is captured once — the cross-stream events become graph edges, the RCCL all-gathers graph nodes (RCCL
+// supports stream capture) — and replayed; the host then issues one call per n_steps instead of ~8 per step, which
+// is what bounds the eager form at ~20 us per step.  Every rank of the communicator must make the same call.
+// n_steps must be a multiple of the exchange block.  Falls back to eager stepping when the capture is refused.
+static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_blocks, int first_block, int n_steps,
+                      bool run);
+int tds_hip_shard_step_many(tds_hip_shard_t *sh, const void *actions_dev, int action_blocks, int first_block,
+                            int n_steps) {
+  return shard_many(sh, actions_dev, action_blocks, first_block, n_steps, true);
+}
+// capture + instantiate only (nothing executes): keeps the capture out of a timed region
+int tds_hip_shard_step_many_prepare(tds_hip_shard_t *sh, const void *actions_dev, int action_blocks, int first_block,
+                                    int n_steps) {
+  return shard_many(sh, actions_dev, action_blocks, first_block, n_steps, false);
+}
+static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_blocks, int first_block, int n_steps,
+                      bool run) {
+  if (!sh) return fail(TDS_ERR_INVALID_ARG, "shard is NULL");
+  if (n_steps < 1 || n_steps > 4096) return fail(TDS_ERR_INVALID_ARG, "n_steps must be in 1..4096");
+  if (n_steps % sh->block != 0) return fail(TDS_ERR_INVALID_ARG, "n_steps must be a multiple of the exchange block");
+  if (actions_dev && action_blocks < 1) return fail(TDS_ERR_INVALID_ARG, "action_blocks must be >= 1");
+  tds_hip_sim *s = sh->sim;
+  if (s->auto_reset) return fail(TDS_ERR_INVALID_ARG, "step_many replays plain closed-loop steps (auto-reset is off the graph)");
+  DeviceGuard guard(s->device);
+  const int pool = actions_dev ? action_blocks : 1;
+  const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
+  const size_t blk = (size_t)sh->n_local * s->model.action_dim * s->elem;
+  const int slot0 = (int)((sh->steps / sh->block) % kSlots);
+  const bool cached = sh->graph_exec && sh->graph_actions == actions_dev && sh->graph_pool == pool &&
+                      sh->graph_first == first && sh->graph_steps == n_steps && sh->graph_block == sh->block &&
+                      sh->graph_slot0 == slot0;
+  if (!cached && getenv("TDS_HIP_SHARD_NO_GRAPH") == nullptr) {
+    if (sh->graph_exec) {
+      (void)hipGraphExecDestroy(sh->graph_exec);
+      sh->graph_exec = nullptr;
+    }
+    // exchanges in flight belong to the eager timeline: drain them, the capture starts from a clean ring
+    TDS_HIP_TRY(hipStreamSynchronize(sh->comm_stream));
+    for (int i = 0; i < kSlots; ++i) sh->pending[i] = false;
+    if (!sh->graph_stream) TDS_HIP_TRY(hipStreamCreateWithFlags(&sh->graph_stream, hipStreamNonBlocking));
+    hipStream_t user = s->stream;
+    const long long steps0 = sh->steps;
+    const int last0 = sh->last_slot;
+    s->stream = sh->graph_stream;  // capture origin (the handle's own stream may be the NULL stream)
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(sh->graph_stream, hipStreamCaptureModeThreadLocal);
+    int rc = TDS_OK;
+    if (e == hipSuccess) {
+      for (int k = 0; k < n_steps && rc == TDS_OK; ++k) {
+        const void *a = actions_dev ? (const char *)actions_dev + (size_t)((first + k) % pool) * blk : nullptr;
+        const int slot = (int)((sh->steps / sh->block) % kSlots);
+        rc = shard_step_local(sh, a, 1);
+        if (rc == TDS_OK && sh->steps % sh->block == 0) {
+          rc = shard_submit(sh, slot);
+          if (rc == TDS_OK) rc = shard_mark_done(sh, slot);
+        }
+      }
+      // join: the origin stream waits for every exchange of the graph (a capture must end with all forked work
+      // joined; it also makes the graph's completion mean "all records exchanged")
+      for (int i = 0; i < kSlots; ++i)
+        if (sh->pending[i]) {
+          if (rc == TDS_OK && hipStreamWaitEvent(sh->graph_stream, sh->ev_done[i], 0) != hipSuccess) rc = TDS_ERR_HIP;
+          sh->pending[i] = false;
+        }
+      e = hipStreamEndCapture(sh->graph_stream, &graph);
+    }
+    sh->graph_last_slot = sh->last_slot;
+    s->stream = user;
+    sh->steps = steps0;  // (the capture executed nothing)
+    sh->last_slot = last0;
+    if (e == hipSuccess && rc == TDS_OK && graph) {
+      e = hipGraphInstantiate(&sh->graph_exec, graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) sh->graph_exec = nullptr;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    if (sh->graph_exec) {
+      sh->graph_actions = actions_dev;
+      sh->graph_pool = pool;
+      sh->graph_first = first;
+      sh->graph_steps = n_steps;
+      sh->graph_block = sh->block;
+      sh->graph_slot0 = slot0;
+    } else {
+      (void)hipGetLastError();
+      fprintf(stderr, "tds_hip_shard_step_many: graph capture refused (%s) — stepping eagerly\n",
+              e != hipSuccess ? hipGetErrorString(e) : tds_hip_last_error());
+    }
+  }
+  if (!run) return TDS_OK;
+  if (sh->graph_exec && getenv("TDS_HIP_SHARD_NO_GRAPH") == nullptr) {
+    // eager exchanges still in flight must not be overtaken by the graph's reuse of their slots
+    for (int i = 0; i < kSlots; ++i)
+      if (sh->pending[i]) {
+        TDS_HIP_TRY(hipStreamWaitEvent(s->stream, sh->ev_done[i], 0));
+        sh->pending[i] = false;
+      }
+    TDS_HIP_TRY(hipGraphLaunch(sh->graph_exec, s->stream));
+    sh->steps += n_steps;
+    sh->last_slot = sh->graph_last_slot;
+    // consumers of tds_hip_shard_gathered wait on ev_done[last_slot]: re-record it behind the graph
+    TDS_HIP_TRY(hipEventRecord(sh->ev_done[sh->last_slot], s->stream));
+    return TDS_OK;
+  }
+  for (int k = 0; k < n_steps; ++k) {
+    const void *a = actions_dev ? (const char *)actions_dev + (size_t)((first + k) % pool) * blk : nullptr;
+    int rc = tds_hip_shard_step(sh, a, 1);
+    if (rc != TDS_OK) return rc;
+  }
+  return TDS_OK;
 }
 
 int tds_hip_shard_flush(tds_hip_shard_t *sh) {

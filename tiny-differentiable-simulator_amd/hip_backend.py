@@ -90,6 +90,8 @@ def lib():
             getattr(L, f).argtypes = [C.c_void_p]
         L.tds_hip_shard_set_block.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_shard_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.tds_hip_shard_step_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.tds_hip_shard_step_many_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.tds_hip_shard_group_step.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int]
         L.tds_hip_shard_gathered.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         _lib = L
@@ -110,7 +112,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_shard_rccl_version", "tds_hip_shard_unique_id", "tds_hip_shard_create", "tds_hip_shard_create_all",
     "tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
     "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes", "tds_hip_shard_set_block",
-    "tds_hip_shard_step", "tds_hip_shard_group_step", "tds_hip_shard_flush", "tds_hip_shard_gathered",
+    "tds_hip_shard_step", "tds_hip_shard_step_many", "tds_hip_shard_step_many_prepare", "tds_hip_shard_group_step", "tds_hip_shard_flush", "tds_hip_shard_gathered",
     "tds_rb_last_error", "tds_rb_create", "tds_rb_destroy", "tds_rb_set_stream", "tds_rb_state_device",
     "tds_rb_set_state", "tds_rb_get_state", "tds_rb_step",
 ]
@@ -430,6 +432,17 @@ class HipShard:
             assert tuple(actions.shape) == (self.n_local, self.sim.model.action_dim)
             ap = C.c_void_p(actions.data_ptr())
         _check(lib().tds_hip_shard_step(self.h, ap, int(substeps)))
+
+    def step_many(self, actions, n_steps: int, first_block: int = 0, prepare_only: bool = False):
+        """n_steps steps + their exchanges as one hipGraph launch; ``actions`` [B, n_local, action_dim] or None.
+        prepare_only: capture + instantiate the graph, run nothing."""
+        ap, nb = None, 1
+        if actions is not None:
+            assert actions.is_cuda and actions.dtype == self.sim.torch_dtype and actions.is_contiguous()
+            assert actions.dim() == 3 and tuple(actions.shape[1:]) == (self.n_local, self.sim.model.action_dim)
+            ap, nb = C.c_void_p(actions.data_ptr()), int(actions.shape[0])
+        f = lib().tds_hip_shard_step_many_prepare if prepare_only else lib().tds_hip_shard_step_many
+        _check(f(self.h, ap, nb, int(first_block), int(n_steps)))
 
     def flush(self):
         _check(lib().tds_hip_shard_flush(self.h))
