@@ -309,11 +309,9 @@ int tds_hip_reset(tds_hip_sim_t *sim, const unsigned char *mask_dev, void *obs_d
                        environment was not done; return_steps_dev [num_envs] int: their number
                        (total_rewards / vec_steps of Worker::rollouts); either may be NULL
      obs_dev           optional [num_envs][obs_dim + 2]: final observation | last reward | done
-     flags             bit 0: see obs.  The rollout runs as ONE launch of the step-loop kernel or — without
-                       auto-reset and from two wavefronts per SIMD on (8192 Ant environments) — as one launch of
-                       the straight-line step kernel per step with a small policy + bookkeeping kernel in
-                       between (same results to round-off; faster there); bit 1 forces the per-step launches,
-                       bit 2 the single launch.
+     flags             bit 0: see obs.  The rollout runs as ONE launch of the step-loop kernel; bit 1 forces one
+                       launch of the straight-line step kernel per step with a small policy + bookkeeping kernel in
+                       between (same results to round-off; slower at every batch size measured; no auto-reset).
    With tds_hip_set_auto_reset a done environment is re-initialised + settled and keeps collecting;
    without it, it stays done (the state keeps stepping, as under the reference's custom stepper). */
 int tds_hip_rollout(tds_hip_sim_t *sim, const void *policy_dev, int n_steps, double shift, int flags,

@@ -51,6 +51,9 @@ def lib():
         if hasattr(L, "tdsref_rollout"):
             L.tdsref_rollout.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "tdsref_hipstepper_selftest_devices"):
+            L.tdsref_hipstepper_selftest_devices.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p,
+                                                             C.c_char_p, C.c_int]
         if hasattr(L, "tdsref_vecenv_steps"):
             L.tdsref_vecenv_steps.argtypes = [C.c_char_p, C.c_int, C.c_int] + [C.c_void_p] * 6
         if hasattr(L, "tdsref_f32_create"):

@@ -446,10 +446,11 @@ def test_forced_reset_matches_host_emulation(name, built):
         assert rel_err(x2[e, :nqd], ref) < TOL
 
 
-@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("split", ["0", "1", "2"])
 def test_auto_reset_inside_step(split, built, monkeypatch):
     """split = 0: reset + settle inside the step launch (step-loop build); 1: straight-line step launch followed by
-    a forced-reset launch masked with the done flags (what tds_hip_step_obs picks from two wavefronts per SIMD on)"""
+    a forced-reset launch masked with the done flags; 2: the reset pool (pre-settled states copied in by the
+    straight-line kernel — the default)"""
     monkeypatch.setenv("TDS_HIP_AUTO_RESET_SPLIT", split)
     torch = _torch()
     m = tds_amd.load_model("ant")
@@ -549,7 +550,7 @@ def test_rollout_matches_reference_worker_loop(name, mode, built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("split", ["0", "1", "2"])
 def test_rollout_equals_stepwise_launches_with_auto_reset(split, built, monkeypatch):
     """the same rollout driven step by step from the host (policy in numpy, one launch per step,
     auto-reset inside the step — or as the two-launch form, split = 1) must give the same returns / step counts /
@@ -591,6 +592,66 @@ def test_rollout_equals_stepwise_launches_with_auto_reset(split, built, monkeypa
     assert np.array_equal(cnt2.cpu().numpy(), cnt)
     assert rel_err(ret2.cpu().numpy(), tot, 1e-3) < 1e-7
     assert rel_err(sim2.x.cpu().numpy()[:, :od], x_fin[:, :od], 1e-3) < 1e-7
+
+
+@pytest.mark.parametrize("pool_params", [None, ("2", "1", "3"), ("5", "2", "4")])
+@pytest.mark.parametrize("name,dtype", [("ant", "f64"), ("laikago", "f64"), ("ant", "mixed")])
+def test_reset_pool_equals_reset_inside_the_step(name, dtype, pool_params, built, monkeypatch):
+    """The reset pool (default auto-reset form) against the reset inside the step launch, 70 closed-loop steps with
+    MANY resets (environments started at their termination threshold): every step both sims start from the same state
+    (per-step resync), take the same action and must agree on y / obs / reward / done / new state — the fresh
+    environments included: same random stream (seed, env, reset count), same settle steps, whatever the refill
+    schedule (default R / H / W, and tiny rings that wrap within the run)."""
+    torch = _torch()
+    if pool_params is not None:
+        monkeypatch.setenv("TDS_HIP_POOL_EVERY", pool_params[0])
+        monkeypatch.setenv("TDS_HIP_POOL_HOST_LAG", pool_params[1])
+        monkeypatch.setenv("TDS_HIP_POOL_LAG", pool_params[2])
+    m = tds_amd.load_model(name)
+    n, seed, steps = 96, 77, 70
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    od = nq + nd
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    rng = np.random.default_rng(17)
+    x0 = np.zeros((n, m.input_dim))
+    ip = np.array([m.initial_poses[i] for i in range(adim)])
+    x0[:, 2] = 0.48
+    x0[:, 6:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
+    x0[:, -3:] = [15, 0.3, 3] if name == "ant" else [100, 2, 50]
+    if name == "ant":
+        x0[::3, 2] = 0.27      # torso right at the 0.26 threshold: done within a few steps, again after every reset
+        x0[1::3, 3] = 0.6
+    else:
+        x0[::3, 3] = 0.93      # rolled chassis: up.z ~ 0.6
+    pool = hip_backend.HipSim(m, n, dtype=dtype)
+    pool.set_auto_reset(True, seed)
+    pool.x.copy_(torch.from_numpy(x0).to(tdt).cuda())
+    monkeypatch.setenv("TDS_HIP_AUTO_RESET_SPLIT", "0")
+    inl = hip_backend.HipSim(m, n, dtype=dtype)
+    inl.set_auto_reset(True, seed)
+    monkeypatch.delenv("TDS_HIP_AUTO_RESET_SPLIT")
+    op = torch.zeros((n, od + 2), dtype=tdt, device="cuda")
+    oi = torch.zeros_like(op)
+    # mixed (float records): in the pool every settle step is a step on a FLOAT record, the step-loop kernel keeps the
+    # settling state in double LDS — both are float-record trajectories, 1e-7 apart per settle step and amplified by the
+    # contact dynamics over the ten of them; the per-step contract of the mixed build is gated in tests/test_f32.py
+    tol = 1e-6 if dtype == "f64" else 2e-3
+    n_done = np.zeros(n, dtype=int)
+    for t in range(steps):
+        a = torch.from_numpy(rng.uniform(-0.4, 0.4, (n, adim))).to(tdt).cuda()
+        inl.x.copy_(pool.x)            # per-step resync
+        pool.step(a, 1, op)
+        monkeypatch.setenv("TDS_HIP_AUTO_RESET_SPLIT", "0")
+        inl.step(a, 1, oi)
+        monkeypatch.delenv("TDS_HIP_AUTO_RESET_SPLIT")
+        dp, di_ = op[:, od + 1].cpu().numpy() != 0, oi[:, od + 1].cpu().numpy() != 0
+        assert np.array_equal(dp, di_), t
+        n_done += dp
+        assert rel_err(pool.y.double().cpu().numpy(), inl.y.double().cpu().numpy()) < tol, t
+        assert rel_err(op.double().cpu().numpy(), oi.double().cpu().numpy()) < tol, t
+        assert rel_err(pool.x.double().cpu().numpy()[:, :od], inl.x.double().cpu().numpy()[:, :od]) < tol, t
+    print(f"{name} {dtype} pool {pool_params}: resets per env max {n_done.max()}, total {n_done.sum()}")
+    assert n_done.sum() >= 30 and (name != "ant" or n_done.max() >= 3)  # (a reset Laikago stands: one reset each)
 
 
 @pytest.mark.parametrize("name", ["ant", "laikago", "pendulum5_plane", "ant_floating", "laikago_floating_env",

@@ -82,14 +82,24 @@ int download(tds_hip_sim *s, double *dst, const void *src, size_t count) {
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+void pool_free(tds_hip_sim *s);  // (reset pool, defined with the rest of it below)
+
 }  // namespace
 
 namespace tds_internal {
 
 int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n, int nsub,
-           int reset_mode, const unsigned char *mask, const Rollout *ro, int ctl_flags) {
+           int reset_mode, const unsigned char *mask, const Rollout *ro, int ctl_flags, const LaunchOpts *opts) {
   TdsStepCtl ctl;
   memset(&ctl, 0, sizeof(ctl));
+  if (opts && opts->extra) {  // work-list / reset-pool fields of a straight-line launch
+    ctl.pool = opts->extra->pool;
+    ctl.pool_depth = opts->extra->pool_depth;
+    ctl.pool_envs = opts->extra->pool_envs;
+  }
+  const hipStream_t stream = (opts && opts->other_stream) ? opts->stream : s->stream;
+  const TdsLds &lds = (opts && opts->lds) ? *opts->lds : s->lds;
+  void *const ovf = (opts && opts->lds) ? nullptr : s->d_ovf;
   if (ro) {
     ctl.policy = ro->policy;
     ctl.ret_sum = ro->ret_sum;
@@ -106,17 +116,17 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   ctl.reset_count = s->d_reset_count;
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
-    rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes,
+    rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                          (const double *)x, (double *)y, (const double *)actions, (double *)fb,
-                                         (double *)obs, (double *)s->d_ovf, n, s->stream, ctl);
+                                         (double *)obs, (double *)ovf, n, stream, ctl);
   else if (s->dtype == TDS_DTYPE_F64_REC32)
-    rc = tds_launch_step<double, float>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes,
+    rc = tds_launch_step<double, float>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                         (const float *)x, (float *)y, (const float *)actions, (float *)fb, (float *)obs,
-                                        (double *)s->d_ovf, n, s->stream, ctl);
+                                        (double *)ovf, n, stream, ctl);
   else
-    rc = tds_launch_step<float, float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes, (const float *)x,
+    rc = tds_launch_step<float, float>((const DevModel<float> *)s->d_model, s->h32, lds, s->lanes, (const float *)x,
                                        (float *)y, (const float *)actions, (float *)fb, (float *)obs,
-                                       (float *)s->d_ovf, n, s->stream, ctl);
+                                       (float *)ovf, n, stream, ctl);
   if (rc != 0) {
     snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad lanes_per_env");
     return TDS_ERR_HIP;
@@ -262,6 +272,7 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
 int tds_hip_destroy(tds_hip_sim_t *s) {
   if (!s) return TDS_OK;
   DeviceGuard guard(s->device);
+  pool_free(s);
   if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
   if (s->graph_stream) (void)hipStreamDestroy(s->graph_stream);
   if (s->d_model) (void)hipFree(s->d_model);
@@ -324,6 +335,288 @@ int tds_hip_forward_zero_device(tds_hip_sim_t *s, const void *x_dev, void *y_dev
   return launch(s, x_dev, y_dev, nullptr, nullptr, nullptr, s->num_envs, 1, TDS_RESET_NONE, nullptr);
 }
 
+// ======================================================================================================
+// Reset pool — auto_reset_when_done (ars_vectorized_environment.h:262-277) at straight-line speed.
+//
+// The state an environment restarts from is a pure function of (seed, environment, reset count): the reset
+// distribution drawn from the counter-based stream, then settle_steps zero-action steps
+// (ant_environment2.h:109-165).  So it can be computed BEFORE it is needed.  Every environment owns a ring of D
+// pre-settled states in HBM (entry k lives in slot k mod D; valid entries are [count, filled)); the straight-line step
+// kernel turns "done" into a copy of the next entry (tds_kernels.hip, ctl.pool), and consumed entries are replaced in
+// the background on a side stream: every R steps a PASS
+//     plan     one thread per environment: claim the missing entries [filled, count + D) in a work list, write their
+//              reset states into staging records
+//     settle   settle_steps launches of the straight-line step kernel over the staging records (they co-reside with
+//              the main launches: same kernel, two wavefronts per SIMD)
+//     scatter  staging records -> ring slots
+// The grids are exact: the host reads the size of a planned work list H steps after planning it (hipEventQuery,
+// blocking only if the GPU is more than H steps behind the host — it never idles the GPU), then enqueues settle +
+// scatter.  Before step t the step stream waits for pass floor((t - 1 - W) / R).  With D >= R + W an environment can
+// never run out of entries — at most one is consumed per step — so the results are EXACTLY those of resetting inside
+// the step launch (same stream of random numbers, same settle steps), whatever the rate of resets; a burst of resets
+// only makes the step stream wait.
+// ======================================================================================================
+extern "C++" {
+namespace {
+
+struct PoolDist {
+  double q[TDS_MAX_DOF], noise[TDS_MAX_DOF];
+};
+
+__device__ __forceinline__ double pool_uniform01(unsigned long long seed, unsigned env, unsigned count, unsigned j) {
+  // == tds_uniform01 of tds_kernels.hip (splitmix64 finaliser of (seed, env, reset count, coordinate))
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)env << 32) | (unsigned long long)(count * 64u + j + 1u));
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// T: compute scalar of the handle (the reset state is formed in it, as the step-loop kernel does), TR: record scalar
+template <typename T, typename TR>
+__global__ void tds_pool_plan_kernel(const unsigned *__restrict__ count, unsigned *__restrict__ filled, int depth,
+                                     int n, int cap, int *__restrict__ items, TR *__restrict__ stage,
+                                     const TR *__restrict__ x, int in_dim, int nq, int nd, int adim, PoolDist dist,
+                                     unsigned long long seed) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const unsigned c = count[e];
+  unsigned f = filled[e];
+  if (f < c) f = c;  // entries consumed behind the pool's back (forced reset, rollout with auto-reset)
+  const int need = (int)(c + (unsigned)depth - f);
+  if (need <= 0) {
+    filled[e] = f;
+    return;
+  }
+  const int base = atomicAdd(&items[0], need);
+  int take = cap - base;
+  take = take < 0 ? 0 : (take < need ? take : need);
+  for (int j = 0; j < take; ++j) {
+    const unsigned cc = f + (unsigned)j;
+    const int it = base + j;
+    items[1 + it] = e;
+    items[1 + cap + it] = (int)(cc % (unsigned)depth);
+    TR *const xs = stage + (size_t)it * in_dim;
+    for (int i = 0; i < nq; ++i) {
+      const T u01 = (T)pool_uniform01(seed, (unsigned)e, cc, (unsigned)i);
+      xs[i] = (TR)((T)dist.q[i] + (T)dist.noise[i] * ((u01 - T(0.5)) * T(2)));
+    }
+    for (int i = nq; i < nq + nd + adim; ++i) xs[i] = TR(0);  // qd = 0, zero action while settling
+    for (int i = nq + nd + adim; i < in_dim; ++i) xs[i] = x[(size_t)e * in_dim + i];  // kp, kd, max_force of the env
+  }
+  filled[e] = f + (unsigned)take;
+}
+
+template <typename TR>
+__global__ void tds_pool_scatter_kernel(const int *__restrict__ items, int n_items, int cap,
+                                        const TR *__restrict__ stage, int in_dim, int w, TR *__restrict__ pool, int n) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int it = (int)(idx / (size_t)w), i = (int)(idx % (size_t)w);
+  if (it >= n_items) return;
+  const int e = items[1 + it], slot = items[1 + cap + it];
+  pool[((size_t)slot * n + e) * w + i] = stage[(size_t)it * in_dim + i];
+}
+
+int pool_param(const char *name, int dflt) {
+  const char *e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : dflt;
+}
+
+int pool_alloc(tds_hip_sim *s) {
+  if (s->d_pool) return TDS_OK;
+  s->pool_every = pool_param("TDS_HIP_POOL_EVERY", 16);                     // R
+  s->pool_host_lag = pool_param("TDS_HIP_POOL_HOST_LAG", s->pool_every / 2);  // H
+  if (s->pool_host_lag >= s->pool_every) s->pool_host_lag = s->pool_every - 1;
+  if (s->pool_host_lag < 1) s->pool_host_lag = 1;
+  const int settle = s->model.settle_steps > 0 ? s->model.settle_steps : 0;
+  s->pool_lag = pool_param("TDS_HIP_POOL_LAG", s->pool_host_lag + settle + 6);  // W
+  s->pool_depth = s->pool_every + s->pool_lag + 4;                            // D >= R + W (+ slack)
+  const size_t n = (size_t)s->num_envs, w = (size_t)(s->model.dof_q + s->model.dof_qd);
+  s->pool_cap = (int)(n * (size_t)(s->pool_every + 4));
+  TDS_HIP_TRY(hipMalloc(&s->d_pool, (size_t)s->pool_depth * n * w * s->elem));
+  TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_filled, n * sizeof(unsigned)));
+  TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_items, (1 + 2 * (size_t)s->pool_cap) * sizeof(int)));
+  TDS_HIP_TRY(hipHostMalloc((void **)&s->h_pool_nitems, sizeof(int), 0));
+  TDS_HIP_TRY(hipMalloc(&s->d_stage_x, (size_t)s->pool_cap * s->model.input_dim * s->elem));
+  TDS_HIP_TRY(hipStreamCreateWithFlags(&s->pool_stream, hipStreamNonBlocking));
+  for (int i = 0; i < tds_hip_sim::kPoolEvents; ++i)
+    TDS_HIP_TRY(hipEventCreateWithFlags(&s->pool_ev[i], hipEventDisableTiming));
+  TDS_HIP_TRY(hipEventCreateWithFlags(&s->pool_step_ev, hipEventDisableTiming));
+  TDS_HIP_TRY(hipEventCreateWithFlags(&s->pool_plan_ev, hipEventDisableTiming));
+  TDS_HIP_TRY(hipEventCreateWithFlags(&s->pool_sync_ev, hipEventDisableTiming));
+  // LDS layout of the refill launches: every constraint row in LDS, so that they need no scratch slab
+  const int epw = 64 / s->lanes;
+  s->pool_lds = s->compute_f64() ? tds_make_lds_layout<double>(s->h64, 0, s->lanes)
+                                 : tds_make_lds_layout<float>(s->h32, 0, s->lanes);
+  const int lds_bytes = (int)((size_t)s->pool_lds.stride * epw * (s->compute_f64() ? 8 : 4));
+  if (lds_bytes > 160 * 1024) return fail(TDS_ERR_UNSUPPORTED, "reset pool: the refill launches need more than 160 KiB of LDS");
+  if (lds_bytes > 64 * 1024) {
+    const bool is_fl = s->compute_f64() ? s->h64.is_floating : s->h32.is_floating;
+    const bool is_sph = s->compute_f64() ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
+    const int kind = is_fl ? 1 : (is_sph ? 2 : 0);
+    const int e = s->dtype == TDS_DTYPE_F64         ? tds_kernel_max_dynamic_lds<double, double>(s->lanes, s->pool_lds.NDP, lds_bytes, kind)
+                  : s->dtype == TDS_DTYPE_F64_REC32 ? tds_kernel_max_dynamic_lds<double, float>(s->lanes, s->pool_lds.NDP, lds_bytes, kind)
+                                                    : tds_kernel_max_dynamic_lds<float, float>(s->lanes, s->pool_lds.NDP, lds_bytes, kind);
+    if (e != 0) return fail(TDS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (reset pool)");
+  }
+  return TDS_OK;
+}
+
+// pool stream: plan the work list of a pass (after everything the step stream has enqueued so far)
+int pool_plan(tds_hip_sim *s) {
+  TDS_HIP_TRY(hipEventRecord(s->pool_step_ev, s->stream));
+  TDS_HIP_TRY(hipStreamWaitEvent(s->pool_stream, s->pool_step_ev, 0));
+  TDS_HIP_TRY(hipMemsetAsync(s->d_pool_items, 0, sizeof(int), s->pool_stream));
+  PoolDist dist;
+  for (int i = 0; i < TDS_MAX_DOF; ++i) {
+    dist.q[i] = s->model.reset_q[i];
+    dist.noise[i] = s->model.reset_noise[i];
+  }
+  const int n = s->num_envs, nq = s->model.dof_q, nd = s->model.dof_qd;
+  const dim3 grid((n + 127) / 128), block(128);
+#define TDS_PLAN(TT, RR)                                                                                                \
+  hipLaunchKernelGGL((tds_pool_plan_kernel<TT, RR>), grid, block, 0, s->pool_stream, s->d_reset_count, s->d_pool_filled,  \
+                     s->pool_depth, n, s->pool_cap, s->d_pool_items, (RR *)s->d_stage_x, (const RR *)s->d_x,              \
+                     s->model.input_dim, nq, nd, s->model.action_dim, dist, s->seed)
+  if (s->dtype == TDS_DTYPE_F64)
+    TDS_PLAN(double, double);
+  else if (s->dtype == TDS_DTYPE_F64_REC32)
+    TDS_PLAN(double, float);
+  else
+    TDS_PLAN(float, float);
+#undef TDS_PLAN
+  if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "reset pool: plan kernel launch");
+  TDS_HIP_TRY(hipMemcpyAsync(s->h_pool_nitems, s->d_pool_items, sizeof(int), hipMemcpyDeviceToHost, s->pool_stream));
+  TDS_HIP_TRY(hipEventRecord(s->pool_plan_ev, s->pool_stream));
+  return TDS_OK;
+}
+
+// pool stream: settle + scatter the planned work list (its size is known on the host), then signal `done`
+int pool_run(tds_hip_sim *s, hipEvent_t done) {
+  int n_items = *s->h_pool_nitems;
+  if (n_items > s->pool_cap) n_items = s->pool_cap;
+  if (n_items > 0) {
+    LaunchOpts o;
+    o.other_stream = true;
+    o.stream = s->pool_stream;
+    o.lds = &s->pool_lds;
+    for (int k = 0; k < s->model.settle_steps; ++k) {
+      // straight-line step kernel on the staging records: zero action, state fed back in place, no y / obs record
+      const int rc = launch(s, s->d_stage_x, nullptr, nullptr, s->d_stage_x, nullptr, n_items, 1, TDS_RESET_NONE,
+                            nullptr, nullptr, 0, &o);
+      if (rc != TDS_OK) return rc;
+    }
+    const int w = s->model.dof_q + s->model.dof_qd;
+    const size_t total = (size_t)n_items * w;
+    if (s->records_f64())
+      hipLaunchKernelGGL(tds_pool_scatter_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                         s->pool_stream, s->d_pool_items, n_items, s->pool_cap, (const double *)s->d_stage_x,
+                         s->model.input_dim, w, (double *)s->d_pool, s->num_envs);
+    else
+      hipLaunchKernelGGL(tds_pool_scatter_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                         s->pool_stream, s->d_pool_items, n_items, s->pool_cap, (const float *)s->d_stage_x,
+                         s->model.input_dim, w, (float *)s->d_pool, s->num_envs);
+    if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "reset pool: scatter kernel launch");
+  }
+  if (done) TDS_HIP_TRY(hipEventRecord(done, s->pool_stream));
+  return TDS_OK;
+}
+
+// fill every ring completely (first use, new seed, or after resets behind the pool's back); host-synchronous, rare
+int pool_fill(tds_hip_sim *s) {
+  int rc = pool_alloc(s);
+  if (rc != TDS_OK) return rc;
+  if (s->pool_planned) {  // a pass in flight: finish it first
+    TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
+    rc = pool_run(s, nullptr);
+    if (rc != TDS_OK) return rc;
+    s->pool_planned = 0;
+  }
+  if (s->pool_discard) {
+    TDS_HIP_TRY(hipMemsetAsync(s->d_pool_filled, 0, (size_t)s->num_envs * sizeof(unsigned), s->pool_stream));
+    s->pool_discard = false;
+  }
+  for (int guard = 0; guard < 4096; ++guard) {
+    rc = pool_plan(s);
+    if (rc != TDS_OK) return rc;
+    TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
+    if (*s->h_pool_nitems <= 0) break;
+    rc = pool_run(s, nullptr);
+    if (rc != TDS_OK) return rc;
+  }
+  // the step stream continues only after the last scatter
+  TDS_HIP_TRY(hipEventRecord(s->pool_sync_ev, s->pool_stream));
+  TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->pool_sync_ev, 0));
+  s->pool_step = 0;
+  s->pool_waited = 0;
+  s->pool_ready = true;
+  return TDS_OK;
+}
+
+// one auto-reset step through the pool
+int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev) {
+  int rc;
+  if (!s->pool_ready) {
+    rc = pool_fill(s);
+    if (rc != TDS_OK) return rc;
+  }
+  const long long t = ++s->pool_step;
+  const int R = s->pool_every, W = s->pool_lag, H = s->pool_host_lag;
+  // a planned pass goes out as soon as the size of its work list has reached the host (at the latest H steps after
+  // it was planned: then the host waits for the GPU to get there — the step stream still has H steps queued)
+  if (s->pool_planned) {
+    const bool due = t - s->pool_planned_at >= H;
+    if (due) TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
+    if (due || hipEventQuery(s->pool_plan_ev) == hipSuccess) {
+      rc = pool_run(s, s->pool_ev[s->pool_planned % tds_hip_sim::kPoolEvents]);
+      if (rc != TDS_OK) return rc;
+      s->pool_planned = 0;
+    }
+  }
+  // entries this step may consume were produced by passes <= floor((t - 1 - W) / R)
+  const long long jstar = (t - 1 - W) / R;
+  while (t - 1 - W >= R && s->pool_waited < jstar) {
+    ++s->pool_waited;
+    TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->pool_ev[s->pool_waited % tds_hip_sim::kPoolEvents], 0));
+  }
+  TdsStepCtl extra;
+  memset(&extra, 0, sizeof(extra));
+  extra.pool = s->d_pool;
+  extra.pool_depth = s->pool_depth;
+  extra.pool_envs = s->num_envs;
+  LaunchOpts o;
+  o.extra = &extra;
+  rc = launch(s, s->d_x, s->d_y, actions_dev, s->d_x, obs_dev ? obs_dev : s->d_split, s->num_envs, 1, TDS_RESET_NONE,
+              nullptr, nullptr, 0, &o);
+  if (rc != TDS_OK) return rc;
+  if (t % R == 0) {  // pass t / R: plan now, launch when its size is known
+    rc = pool_plan(s);
+    if (rc != TDS_OK) return rc;
+    s->pool_planned = t / R;
+    s->pool_planned_at = t;
+  }
+  return TDS_OK;
+}
+
+void pool_free(tds_hip_sim *s) {
+  if (s->pool_stream) (void)hipStreamSynchronize(s->pool_stream);
+  if (s->d_pool) (void)hipFree(s->d_pool);
+  if (s->d_pool_filled) (void)hipFree(s->d_pool_filled);
+  if (s->d_pool_items) (void)hipFree(s->d_pool_items);
+  if (s->h_pool_nitems) (void)hipHostFree(s->h_pool_nitems);
+  if (s->d_stage_x) (void)hipFree(s->d_stage_x);
+  for (int i = 0; i < tds_hip_sim::kPoolEvents; ++i)
+    if (s->pool_ev[i]) (void)hipEventDestroy(s->pool_ev[i]);
+  if (s->pool_step_ev) (void)hipEventDestroy(s->pool_step_ev);
+  if (s->pool_plan_ev) (void)hipEventDestroy(s->pool_plan_ev);
+  if (s->pool_sync_ev) (void)hipEventDestroy(s->pool_sync_ev);
+  if (s->pool_stream) (void)hipStreamDestroy(s->pool_stream);
+}
+
+}  // namespace
+}  // extern "C++"
+
 extern "C++" {
 namespace {
 // done column of the [obs | reward | done] records -> byte mask of tds_hip_reset
@@ -339,10 +632,15 @@ int step_obs_impl(tds_hip_sim *s, const void *actions_dev, int substeps, void *o
   // the batch).  From two wavefronts per SIMD on, a single step is cheaper as the straight-line launch followed by
   // a forced-reset launch masked with the done flags (idle lane groups leave at once); same random stream
   // (seed, environment, reset counter), same records.  TDS_HIP_AUTO_RESET_SPLIT=1 / 0 forces / forbids it.
+  // Auto-reset: default = the reset pool (straight-line kernel, reset states computed ahead of time, see above).
+  // TDS_HIP_AUTO_RESET_SPLIT=0: reset + settle inside the step launch (step-loop build); =1: straight-line launch
+  // followed by a forced-reset launch masked with the done flags; =2 / unset: pool.  All three draw the same stream
+  // of random numbers (seed, environment, reset counter) and are held to the same host emulation by the tests.
   if (s->auto_reset && substeps == 1) {
     const char *e = getenv("TDS_HIP_AUTO_RESET_SPLIT");
-    const long waves = ((long)s->num_envs * s->lanes + 63) / 64;
-    if (e ? e[0] == '1' : waves >= 2048) {
+    if (!e || e[0] == '2') return pool_step(s, actions_dev, obs_dev);
+    s->pool_ready = false;  // (entries are consumed behind the pool's back)
+    if (e[0] == '1') {
       const int n = s->num_envs, w = s->obs_width();
       const size_t b_rec = align256((size_t)n * w * s->elem);
       void *rec = obs_dev ? obs_dev : s->d_split;
@@ -362,6 +660,7 @@ int step_obs_impl(tds_hip_sim *s, const void *actions_dev, int substeps, void *o
   // ONE launch: the kernel loops over the substeps (same action) with the state kept in LDS, writes
   // y / reward / done of the last substep and, with auto-reset on, re-initialises + settles the
   // environments that ended with done before it writes their observation and resident state
+  if (s->auto_reset) s->pool_ready = false;
   return launch(s, s->d_x, s->d_y, actions_dev, s->d_x, obs_dev, s->num_envs, substeps,
                 s->auto_reset ? TDS_RESET_AUTO : TDS_RESET_NONE, nullptr);
 }
@@ -457,6 +756,8 @@ int tds_hip_set_auto_reset(tds_hip_sim_t *s, int enable, unsigned long long seed
     return fail(TDS_ERR_INVALID_ARG, "auto-reset needs a model with a termination rule (reward_mode)");
   s->auto_reset = enable != 0;
   s->seed = seed;
+  s->pool_ready = false;  // (entries depend on the seed)
+  s->pool_discard = true;
   return TDS_OK;
 }
 
@@ -464,6 +765,7 @@ int tds_hip_reset(tds_hip_sim_t *s, const unsigned char *mask_dev, void *obs_dev
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   DeviceGuard guard(s->device);
   TimedCall timed(s);
+  s->pool_ready = false;  // (a forced reset takes its states straight from the random stream, past the pool)
   return launch(s, s->d_x, s->d_y, nullptr, s->d_x, obs_dev, s->num_envs, 0, TDS_RESET_FORCED, mask_dev, nullptr,
                 TDS_CTL_RESET_CALL);
 }
@@ -595,12 +897,11 @@ int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, doubl
   if (s->model.action_dim < 1) return fail(TDS_ERR_INVALID_ARG, "model has no actions");
   DeviceGuard guard(s->device);
   TimedCall timed(s);
-  // One launch for the whole rollout (the step-loop build: 256 VGPR + AGPR copies, one wavefront per SIMD) or one
-  // launch per step of the straight-line build with the policy + bookkeeping kernel in between: from two
-  // wavefronts per SIMD on (8192 Ant environments) the straight-line build overlaps them and wins.
-  // flags bit 1: force the per-step launches, bit 2: force the single launch.  Auto-reset lives in the step loop.
-  const long waves = ((long)s->num_envs * s->lanes + 63) / 64;
-  const bool per_step = !s->auto_reset && !(flags & 4) && ((flags & 2) || waves >= 2048);
+  // One launch for the whole rollout: the step-loop build, compiled for one or for two wavefronts per SIMD (the
+  // launcher picks by grid size) — faster than per-step launches at every batch size measured
+  // (profiles/r02_rollout_modes.txt).  flags bit 1 forces the other form: one straight-line step launch per step
+  // with a small policy + bookkeeping kernel in between (no auto-reset there).
+  const bool per_step = !s->auto_reset && (flags & 2) != 0;
   if (per_step)
     return s->records_f64()
                ? rollout_per_step<double>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev)
@@ -611,6 +912,7 @@ int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, doubl
   ro.ret_steps = return_steps_dev;
   ro.shift = shift;
   ro.flags = flags;
+  if (s->auto_reset) s->pool_ready = false;
   return launch(s, s->d_x, s->d_y, nullptr, s->d_x, obs_dev, s->num_envs, n_steps,
                 s->auto_reset ? TDS_RESET_AUTO : TDS_RESET_NONE, nullptr, &ro);
 }

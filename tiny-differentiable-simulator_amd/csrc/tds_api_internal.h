@@ -28,14 +28,24 @@ struct tds_hip_sim {
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_ms = false;
-  // pre-settled reset pool (tds_hip_set_reset_pool; see tds_api.hip)
-  int pool_depth = 0;
-  void *d_pool = nullptr;            // [depth][N][nq+nd] records
-  unsigned int *d_pool_meta = nullptr;  // [N] consumed count per env | [1] number of pending refills | list
+  // pre-settled reset pool (auto-reset at straight-line speed; see "reset pool" in tds_api.hip)
+  static constexpr int kPoolEvents = 8;
+  int pool_depth = 0, pool_every = 0, pool_lag = 0, pool_host_lag = 0, pool_cap = 0;  // D, R, W, H, staging capacity
+  void *d_pool = nullptr;                 // [D][N][nq+nd] record dtype: ring of pre-settled reset states per env
+  unsigned int *d_pool_filled = nullptr;  // [N] entries produced so far per env (valid: [count, filled))
+  int *d_pool_items = nullptr;            // [1 + 2 cap]: n_items | item env | item ring slot
+  int *h_pool_nitems = nullptr;           // pinned: n_items of the pass that has been planned
+  void *d_stage_x = nullptr;              // [cap][input_dim] record dtype: the work list's records while they settle
+  TdsLds pool_lds;                        // LDS layout of the refill launches: all constraint rows in LDS
   hipStream_t pool_stream = nullptr;
-  hipEvent_t *pool_ev = nullptr;     // ring of refill-done events
-  hipEvent_t pool_step_ev = nullptr;
-  long long pool_step = 0;
+  hipEvent_t pool_ev[kPoolEvents] = {};   // pass j complete -> pool_ev[j % kPoolEvents]
+  hipEvent_t pool_step_ev = nullptr, pool_plan_ev = nullptr, pool_sync_ev = nullptr;
+  long long pool_step = 0;     // auto-reset steps since the pool was last filled completely
+  long long pool_waited = 0;   // passes the step stream has been made to wait for
+  long long pool_planned = 0;  // pass whose work list has been planned but not launched yet (0: none)
+  long long pool_planned_at = 0;
+  bool pool_ready = false;     // false: fill the pool completely before the next auto-reset step
+  bool pool_discard = true;    // the entries in the rings are void (first use, new seed): start from empty rings
   // K-steps-per-launch graph cache (tds_hip_step_many)
   hipGraphExec_t graph_exec = nullptr;
   const void *graph_actions = nullptr;
@@ -82,9 +92,18 @@ struct Rollout {
   int flags;
 };
 
+// what a launch may override (reset-pool machinery)
+struct LaunchOpts {
+  const TdsStepCtl *extra = nullptr;  // n_dev / pool fields
+  bool other_stream = false;          // launch on `stream` instead of the handle's
+  hipStream_t stream = nullptr;
+  const TdsLds *lds = nullptr;        // LDS layout (the refill launches keep every constraint row in LDS: no slab)
+};
+
 // enqueue one launch of the step kernel on the handle's stream (device already selected by the caller)
 int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n, int nsub,
-           int reset_mode, const unsigned char *mask, const Rollout *ro = nullptr, int ctl_flags = 0);
+           int reset_mode, const unsigned char *mask, const Rollout *ro = nullptr, int ctl_flags = 0,
+           const LaunchOpts *opts = nullptr);
 
 }  // namespace tds_internal
 

@@ -40,6 +40,10 @@ struct TdsStepCtl {
   void *ret_sum;              // [n_envs] T: sum of (reward - shift) over the steps taken while not done
   int *ret_steps;             // [n_envs]   : number of those steps
   double shift;
+  // straight-line launches only:
+  const void *pool;           // != NULL: pre-settled reset states [pool_depth][pool_envs][dof_q + dof_qd] (record
+  int pool_depth, pool_envs;  //          dtype), ring per environment indexed by its reset count; a done environment
+                              //          takes its next state from here (auto-reset without the step loop)
   int flags;                  // bit 0: the first step observes the raw base x, y (state fresh from reset())
                               // TDS_CTL_RESET_CALL: the launch is tds_hip_reset (the environment's own reset():
                               // its observation keeps the base x, y where the model says so), not an auto-reset

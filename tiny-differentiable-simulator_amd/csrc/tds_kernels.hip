@@ -34,6 +34,7 @@
 //     links, the reference's base-frame ABA incl. its block inverse), 2 spherical joints (three lanes per joint);
 //     JOINT_FIXED links may be folded into their parents on the host (tds_device_model.h).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -588,6 +589,21 @@ __device__ __forceinline__ double tds_uniform01(unsigned long long seed, unsigne
   return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// q = reset_q + reset_noise * U(-1,1), qd = 0 into the LDS record of one environment; advances its reset counter
+// (ant_environment2.h:124-135)
+template <typename T, int G>
+__device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, const TdsStepCtl &ctl, int env, int lane,
+                                                int nq, int nd) {
+  const unsigned cnt = ctl.reset_count != nullptr ? ctl.reset_count[env] : 0u;
+  for (int i = lane; i < nq; i += G) {
+    const T u01 = (T)tds_uniform01(ctl.seed, (unsigned)env, cnt, (unsigned)i);
+    xr[i] = mdl->reset_q[i] + mdl->reset_noise[i] * ((u01 - T(0.5)) * T(2));
+  }
+  for (int i = lane; i < nd; i += G) xr[nq + i] = T(0);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0 && ctl.reset_count != nullptr) ctl.reset_count[env] = cnt + 1u;
+}
+
 // TDS_STAMP: phase-boundary timestamps (shader clock) of workgroup 0, PROF builds only
 #define TDS_STAMP(k)                                                        \
   do {                                                                      \
@@ -609,33 +625,111 @@ __device__ __forceinline__ double tds_uniform01(unsigned long long seed, unsigne
 // TR == T for the f64 and the f32 builds; <T = double, TR = float> is the "f32 records / f64 arithmetic" build:
 // the reference's float ABI (776 B per Ant env-step) with the mass-matrix factorisation kept in double,
 // which is what lets the float record of BASELINE config 2 meet the 1e-6 per-step contract.
-template <typename T, typename TR, int G, int NDP, bool PROF, bool LOOP, int KIND>
-__global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
+// LP: 0 = straight-line build, 1 = step-loop build, 2 = step-loop build compiled for two wavefronts per SIMD.
+// The step-loop body needs ~300 registers as the compiler likes it (256 VGPR + ~55 AGPR copies: one wavefront per
+// SIMD, the faster form up to one wavefront per SIMD, i.e. 4096 Ant environments); held to 256 it spills ~55
+// registers to scratch but two wavefronts overlap — measured on MI355X (profiles/r02_rollout_modes.txt): Ant
+// rollouts 2.17e8 vs 2.05e8 env-steps/s at 4096 environments, 2.24e8 vs 3.12e8 at 8192.  The launcher picks by
+// grid size.
+template <typename T, typename TR, int G, int NDP, bool PROF, int LP, int KIND>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LP == 2 ? 2 : 1)))
+void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const TR *x_in, TR *__restrict__ y_out,
                                                       const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
                                                       TR *__restrict__ obs_out, T *ovf, long long *prof, TdsStepCtl ctl, int n_envs) {
+  constexpr bool LOOP = LP != 0;
   extern __shared__ __align__(16) unsigned char tds_smem_raw[];
   T *const sm = reinterpret_cast<T *>(tds_smem_raw);
   constexpr int EPW = 64 / G;
-  const int lane = threadIdx.x & (G - 1);
-  const int grp = threadIdx.x / G;
-  const int env = blockIdx.x * EPW + grp;
-  const bool valid = env < n_envs;
-  T *const E = sm + grp * L.stride;
+  const int lane0 = threadIdx.x & (G - 1);
+  const int grp0 = threadIdx.x / G;
 
   // ---- A0. the x record (and the fresh actions) are requested from HBM first: their latency runs under the
   //      fetch of the model constants below; dimensions from the kernel arguments, not from the model
   constexpr int XPL = (96 + G - 1) / G;  // record scalars per lane held in registers (longer records: loop in A)
   T xpre[XPL];
+  {
+    const int env = blockIdx.x * EPW + grp0;
 #pragma unroll
-  for (int k = 0; k < XPL; ++k) {
-    const int i = lane + k * G;
-    const bool act = actions != nullptr && i >= L.nqnd && i < L.nqnd + L.adim;
-    const TR *src = act ? actions + ((size_t)env * L.adim + (i - L.nqnd)) : x_in + ((size_t)env * L.in_dim + i);
-    xpre[k] = (valid && i < L.in_dim) ? (T)*src : T(0);
+    for (int k = 0; k < XPL; ++k) {
+      const int i = lane0 + k * G;
+      const bool act = actions != nullptr && i >= L.nqnd && i < L.nqnd + L.adim;
+      const TR *src = act ? actions + ((size_t)env * L.adim + (i - L.nqnd)) : x_in + ((size_t)env * L.in_dim + i);
+      xpre[k] = (env < n_envs && i < L.in_dim) ? (T)*src : T(0);
+    }
   }
 
+  // ---- in-kernel step loop (LOOP builds): `nsub` normal steps, then (auto / forced reset) the environments that
+  //      need it are re-initialised and run `settle_steps` zero-action steps — all inside this launch,
+  //      state carried in the LDS record.  mode / left are uniform within a lane group.
+  // Only THESE values are carried from one iteration to the next; everything else — the lane's model constants, the
+  // LDS region pointers, the record dimensions — is re-derived inside the loop body from per-iteration laundered
+  // copies of (lane, group, model pointer), so that the compiler can neither hoist it out of the loop nor keep it
+  // live across the back edge (that cost the step-loop build 256 VGPR + ~155 AGPR copies + ~270 spilled SGPRs).
+  const int nset = (LOOP && ctl.reset_mode != TDS_RESET_NONE) ? ctl.settle_steps : 0;
+  int mode = ((int)(blockIdx.x * EPW + grp0) < n_envs && (!LOOP || ctl.nsub > 0)) ? TDS_MODE_RUN : TDS_MODE_IDLE;
+  int left = LOOP ? ctl.nsub : 1;  // normal steps still to run
+  int sleft = 0;                   // settle steps still to run (mode SETTLE)
+  // rollout mode: return accumulated so far, its step count, "done and not auto-reset" latch
+  const bool pol = LOOP && ctl.policy != nullptr;
+  T ret = T(0);
+  int cnt = 0;
+  bool frozen = false;
+  int tds_iter = 0;
+  (void)tds_iter;
+  if constexpr (LOOP) {
+    // prologue of the step-loop build: x record -> LDS, forced reset of the selected environments
+    const DevModel<T> *mdl = mdl_arg;
+    const int lane = lane0, env = blockIdx.x * EPW + grp0;
+    const bool valid = env < n_envs;
+    const int nq = mdl->dof_q, nd = mdl->dof_qd, in_dim = mdl->input_dim, adim = mdl->action_dim;
+    T *const xr = sm + grp0 * L.stride + L.xrec;
+#pragma unroll
+    for (int k = 0; k < XPL; ++k) {
+      const int i = lane + k * G;
+      if (i < in_dim) xr[i] = xpre[k];
+    }
+    for (int i = lane + XPL * G; i < in_dim; i += G) {
+      const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
+      xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+    }
+    TDS_WAVE_SYNC();
+    bool finished0 = false;  // forced reset with zero settle steps: nothing to simulate
+    if (ctl.reset_mode == TDS_RESET_FORCED && valid && (ctl.mask == nullptr || ctl.mask[env] != 0)) {
+      tds_reset_state<T, G>(xr, mdl, ctl, env, lane, nq, nd);
+      if (nset > 0) {
+        mode = TDS_MODE_SETTLE;
+        sleft = nset;
+      } else {
+        finished0 = true;
+      }
+    }
+    TDS_WAVE_SYNC();
+    if (finished0) {
+      const bool raw = (ctl.flags & TDS_CTL_RESET_CALL) != 0 && mdl->reset_obs_raw_xy != 0;
+      for (int i = lane; i < nq + nd; i += G) {
+        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = (TR)((i < 2 && !raw) ? T(0) : xr[i]);
+        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = (TR)xr[i];
+      }
+    }
+  }
+
+  for (;;) {  // ================================ step loop ================================
+  if constexpr (LOOP) {
+    if (!__any(mode != TDS_MODE_IDLE)) break;
+  }
+  int lane_l = lane0, grp_l = grp0;
   const DevModel<T> *mdl = mdl_arg;
+  // (the 32-dof build is at one wavefront per SIMD whatever is done and fares better with the lane constants
+  //  hoisted into AGPR copies — 256 + 130 registers, no scratch, against 256 + 256 + 876 B of scratch: only the
+  //  model pointer is laundered there)
+  if constexpr (LOOP && NDP < 32) asm volatile("" : "+v"(lane_l), "+v"(grp_l), "+s"(mdl));
+  if constexpr (LOOP && NDP >= 32) asm volatile("" : "+s"(mdl));
+  const int lane = lane_l, grp = grp_l;
+  const int env = blockIdx.x * EPW + grp;
+  const bool valid = env < n_envs;
+  T *const E = sm + grp * L.stride;
+
   const int nl = mdl->num_links, nq = mdl->dof_q, nd = mdl->dof_qd;
   const int in_dim = mdl->input_dim, out_dim = mdl->output_dim, adim = mdl->action_dim;
   constexpr int NDs = NDP + 1;  // odd row stride of every [row][dof] array
@@ -736,75 +830,22 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     pf_iters = md->pgs_iterations;
   };
   if constexpr (!LOOP) load_phase_consts(mdl);
-  int tds_iter = 0;
-  (void)tds_iter;
   TDS_STAMP(0);
   // ---- A. x record -> LDS (coalesced: consecutive lanes, consecutive doubles) ---------------
   T *const xr = E + L.xrec;
+  if constexpr (!LOOP) {  // (the step-loop build did this in its prologue; the state then lives in the LDS record)
 #pragma unroll
-  for (int k = 0; k < XPL; ++k) {
-    const int i = lane + k * G;
-    if (i < in_dim) xr[i] = xpre[k];
-  }
-  for (int i = lane + XPL * G; i < in_dim; i += G) {
-    const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
-    xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
-  }
-  TDS_WAVE_SYNC();
-
-  // ---- in-kernel step loop: `nsub` normal steps, then (auto / forced reset) the environments that
-  //      need it are re-initialised and run `settle_steps` zero-action steps — all inside this launch,
-  //      state carried in the LDS record.  mode / left are uniform within a lane group.
-  const int nset = (LOOP && ctl.reset_mode != TDS_RESET_NONE) ? ctl.settle_steps : 0;
-  int mode = (valid && (!LOOP || ctl.nsub > 0)) ? TDS_MODE_RUN : TDS_MODE_IDLE;
-  int left = LOOP ? ctl.nsub : 1;  // normal steps still to run
-  int sleft = 0;                   // settle steps still to run (mode SETTLE)
-  // rollout mode: return accumulated so far, its step count, "done and not auto-reset" latch
-  const bool pol = LOOP && ctl.policy != nullptr;
-  T ret = T(0);
-  int cnt = 0;
-  bool frozen = false;
-  // q = reset_q + reset_noise * U(-1,1), qd = 0  (ant_environment2.h:124-135)
-  auto reset_state = [&]() {
-    const unsigned cnt = ctl.reset_count != nullptr ? ctl.reset_count[env] : 0u;
-    for (int i = lane; i < nq; i += G) {
-      const T u01 = (T)tds_uniform01(ctl.seed, (unsigned)env, cnt, (unsigned)i);
-      xr[i] = mdl->reset_q[i] + mdl->reset_noise[i] * ((u01 - T(0.5)) * T(2));
+    for (int k = 0; k < XPL; ++k) {
+      const int i = lane + k * G;
+      if (i < in_dim) xr[i] = xpre[k];
     }
-    for (int i = lane; i < nd; i += G) xr[nq + i] = T(0);
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0 && ctl.reset_count != nullptr) ctl.reset_count[env] = cnt + 1u;
-  };
-  if constexpr (LOOP) {
-    bool finished0 = false;  // forced reset with zero settle steps: nothing to simulate
-    if (ctl.reset_mode == TDS_RESET_FORCED && valid && (ctl.mask == nullptr || ctl.mask[env] != 0)) {
-      reset_state();
-      if (nset > 0) {
-        mode = TDS_MODE_SETTLE;
-        sleft = nset;
-      } else {
-        finished0 = true;
-      }
+    for (int i = lane + XPL * G; i < in_dim; i += G) {
+      const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
+      xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
     }
     TDS_WAVE_SYNC();
-    if (finished0) {
-      const bool raw = (ctl.flags & TDS_CTL_RESET_CALL) != 0 && mdl->reset_obs_raw_xy != 0;
-      for (int i = lane; i < nq + nd; i += G) {
-        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = (TR)((i < 2 && !raw) ? T(0) : xr[i]);
-        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = (TR)xr[i];
-      }
-    }
   }
-
-  for (;;) {  // ================================ step loop ================================
-  if constexpr (LOOP) {
-    if (!__any(mode != TDS_MODE_IDLE)) break;
-  }
-  // Launder the model pointer once per iteration: otherwise LICM hoists every model-table load of
-  // the body out of the loop and keeps ~100 VGPRs / ~200 SGPRs of constants live across all phases
-  // (measured: 194 -> 256 VGPR + 73 AGPR + 214 spilled SGPRs).
-  const DevModel<T> *mdl = mdl_arg;
-  if constexpr (LOOP) asm volatile("" : "+s"(mdl));
+  auto reset_state = [&]() { tds_reset_state<T, G>(xr, mdl, ctl, env, lane, nq, nd); };
   const bool live = mode != TDS_MODE_IDLE;
   const bool last_run = mode == TDS_MODE_RUN && left == 1;
   const bool settling = LOOP && mode == TDS_MODE_SETTLE;
@@ -904,7 +945,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
   if constexpr (LOOP) load_link_consts(mdl);
-  if constexpr (LOOP) load_phase_consts(mdl);
+  if constexpr (LOOP && NDP >= 24) load_phase_consts(mdl);
   T Rp[9], tp[3];
   {
     const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
@@ -1216,6 +1257,10 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   TDS_STAMP(3);
   // ---- I. narrowphase right after the kinematics sweep (it only needs X_world), so that the
   //         LDS holding X_world / v can be recycled by the dynamics sweeps
+  // (step-loop build: the constants of the later phases are fetched only now — one L2 round trip per iteration
+  //  instead of ~60 registers held through the kinematics sweep, which is what keeps this build at two
+  //  wavefronts per SIMD)
+  if constexpr (LOOP && NDP < 24) load_phase_consts(mdl);
   T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, ancestor-dof mask (bit pattern)
   const int NCPp = L.NCPp;
   int na = 0;
@@ -1302,7 +1347,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     TR *const yo = y_out + (size_t)env * out_dim;
     const int nv = pf_nv;
     const int vbase = nq + nd;
-    if (last_run) {  // y describes the last normal step of the launch
+    if (last_run && y_out != nullptr) {  // y describes the last normal step of the launch
       for (int k = lane; k < nv; k += G) {
         const bool first = k == lane;  // wave-uniform: visual == lane was prefetched at kernel start
         int lk = pf_vis_link;
@@ -1894,7 +1939,7 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
   TDS_WAVE_SYNC();
 
   // ---- y record (q, qd, up, zero padding; the visual poses went out in M1) of the last normal step
-  if (last_run) {
+  if (last_run && y_out != nullptr) {
     TR *const yo = y_out + (size_t)env * out_dim;
     if (gen) {  // the q record is not one coordinate per lane: copy it out as it is
       for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)(xr[i]), &yo[i]);
@@ -1958,7 +2003,28 @@ __global__ __launch_bounds__(64) void tds_step_kernel(const DevModel<T> *__restr
     // straight-line build: exactly one normal step, no reset -> the environment is finished here;
     // observation (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288) and resident state go
     // out straight from registers
-    if (live && gen) {
+    bool from_pool = false;
+    if (ctl.pool != nullptr) {  // wave-uniform (kernel argument)
+      // auto_reset_when_done (ars_vectorized_environment.h:262-277) without leaving the straight-line kernel: the
+      // reset state of (seed, environment, reset count) — re-initialised AND settled — was computed ahead of time
+      // into the environment's pool ring (tds_api.hip: reset pool); a done environment copies it in.  y, reward and
+      // done describe the terminal step, observation and resident state the fresh environment.
+      TDS_WAVE_SYNC();  // lane 0's done flag
+      from_pool = live && xr[in_dim + 1] != T(0);
+      if (from_pool) {
+        const unsigned c = ctl.reset_count[env];
+        const TR *const src = (const TR *)ctl.pool + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
+        for (int i = lane; i < nq + nd; i += G) {
+          const TR v = src[i];
+          if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? TR(0) : v;
+          if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) ctl.reset_count[env] = c + 1u;
+      }
+    }
+    if (from_pool) {
+    } else if (live && gen) {
       for (int i = lane; i < nq + nd; i += G) {
         if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = (TR)(i < 2 ? T(0) : xr[i]);
         if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = (TR)xr[i];
@@ -2060,6 +2126,12 @@ int tds_padded_dof(int nd, int lanes) {
 }
 #endif
 
+// register-pressure experiments compile ONE (lanes, padded dof) instantiation: -DTDS_DEBUG_ONLY=3218
+#ifndef TDS_DEBUG_ONLY
+#define TDS_DEBUG_ONLY 0
+#endif
+constexpr bool tds_instantiate(int key) { return TDS_DEBUG_ONLY == 0 || TDS_DEBUG_ONLY == key; }
+
 template <typename T>
 TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) {
   TdsLds L;
@@ -2123,34 +2195,36 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \
     if (prof)                                                                                                \
-      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, true, false, 0>), dim3(blocks), dim3(64), shmem, stream, \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, true, 0, 0>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else if (simple)                                                                                         \
-      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, false, KIND>), dim3(blocks), dim3(64), shmem, stream, \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, 0, KIND>), dim3(blocks), dim3(64), shmem, stream, \
+                         d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
+    else if (loop_occ2 && NN < 24)                                                                           \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 2, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else                                                                                                     \
-      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, true, KIND>), dim3(blocks), dim3(64), shmem, stream, \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, 1, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
   } while (0)
   if (prof && KIND != 0) return -2;  // the phase-stamp build exists for the plain kernels only
   // straight-line kernel when the launch is exactly one normal step without any reset
   const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
+  // step-loop build: above one wavefront per SIMD (256 CUs x 4 SIMDs) the two-wavefronts-per-SIMD compilation wins
+  // (TDS_HIP_LOOP_OCC=1 / 2 forces either)
+  static const int loop_force = [] { const char *e = getenv("TDS_HIP_LOOP_OCC"); return e ? atoi(e) : 0; }();
+  // (>= 24 padded dof: the straight-line build is itself at one wavefront per SIMD; the two-wave loop build would
+  //  spill hundreds of registers there)
+  const bool loop_occ2 = L.NDP < 24 && (loop_force == 2 || (loop_force != 1 && blocks >= 1536));
   const int key = lanes_per_env * 100 + L.NDP;
   switch (key) {
-#if !defined(TDS_DEBUG_ONLY_3218)  // (register-pressure experiments: compile one instantiation)
-    case 1608: TDS_LAUNCH(16, 8); break;
-    case 1614: TDS_LAUNCH(16, 14); break;
-#endif
-    case 3218: TDS_LAUNCH(32, 18); break;
-#if !defined(TDS_DEBUG_ONLY_3218)
-    case 1616: TDS_LAUNCH(16, 16); break;
-    case 3208: TDS_LAUNCH(32, 8); break;
-    case 3216: TDS_LAUNCH(32, 16); break;
-    case 3224: TDS_LAUNCH(32, 24); break;
-    case 3232: TDS_LAUNCH(32, 32); break;
-    case 6408: TDS_LAUNCH(64, 8); break;
-    case 6416: TDS_LAUNCH(64, 16); break;
-#endif
+#define TDS_CASE(GG, NN) \
+  case GG * 100 + NN:    \
+    if constexpr (tds_instantiate(GG * 100 + NN)) TDS_LAUNCH(GG, NN); else return -1; \
+    break;
+    TDS_CASE(16, 8) TDS_CASE(16, 14) TDS_CASE(32, 18) TDS_CASE(16, 16) TDS_CASE(32, 8) TDS_CASE(32, 16) TDS_CASE(32, 24)
+    TDS_CASE(32, 32) TDS_CASE(64, 8) TDS_CASE(64, 16)
+#undef TDS_CASE
     default:
       return -1;
   }
@@ -2163,30 +2237,26 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   hipError_t e = hipSuccess;
 #define TDS_ATTR(GG, NN)                                                                                        \
   do {                                                                                                          \
-    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, false, KIND>,                         \
+    e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 0, KIND>,                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                 \
     if (e == hipSuccess)                                                                                        \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, true, KIND>,                        \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 1, KIND>,                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
+    if (e == hipSuccess && NN < 24)                                                                             \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 2, KIND>,        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
     if (e == hipSuccess && KIND == 0)                                                                               \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, true, false, 0>,                     \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, true, 0, 0>,                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
-#if !defined(TDS_DEBUG_ONLY_3218)  // (register-pressure experiments: compile one instantiation)
-    case 1608: TDS_ATTR(16, 8); break;
-    case 1614: TDS_ATTR(16, 14); break;
-#endif
-    case 3218: TDS_ATTR(32, 18); break;
-#if !defined(TDS_DEBUG_ONLY_3218)
-    case 1616: TDS_ATTR(16, 16); break;
-    case 3208: TDS_ATTR(32, 8); break;
-    case 3216: TDS_ATTR(32, 16); break;
-    case 3224: TDS_ATTR(32, 24); break;
-    case 3232: TDS_ATTR(32, 32); break;
-    case 6408: TDS_ATTR(64, 8); break;
-    case 6416: TDS_ATTR(64, 16); break;
-#endif
+#define TDS_CASE(GG, NN) \
+  case GG * 100 + NN:    \
+    if constexpr (tds_instantiate(GG * 100 + NN)) TDS_ATTR(GG, NN); \
+    break;
+    TDS_CASE(16, 8) TDS_CASE(16, 14) TDS_CASE(32, 18) TDS_CASE(16, 16) TDS_CASE(32, 8) TDS_CASE(32, 16) TDS_CASE(32, 24)
+    TDS_CASE(32, 32) TDS_CASE(64, 8) TDS_CASE(64, 16)
+#undef TDS_CASE
     default: return -1;
   }
 #undef TDS_ATTR

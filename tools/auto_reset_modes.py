@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""Runs ON THE GPU BOX: VectorizedAntEnv.step with auto-reset — reset inside the step launch (step-loop build) vs
-straight-line step + masked forced-reset launch (TDS_HIP_AUTO_RESET_SPLIT = 0 / 1 / unset = library's choice)."""
+"""Runs ON THE GPU BOX: VectorizedAntEnv.step with auto_reset_when_done under random actions (~5 % of the environments
+end per step), per batch size and auto-reset form:
+  split=0  reset + settle inside the step launch (step-loop build)
+  split=1  straight-line step launch + forced-reset launch masked with the done flags
+  split=2  reset pool: pre-settled states copied in by the straight-line kernel, refilled on a side stream
+  None     the library's default (= the pool)
+and the same loop with auto-reset OFF (the no-reset rate the pool is held against)."""
 import os
 import sys
 import time
@@ -11,23 +16,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import tds_amd  # noqa: E402
 
+
+def run(n, auto, K=500):
+    env = tds_amd.VectorizedAntEnv(n, auto_reset_when_done=auto, seed=5)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = [(torch.rand((n, 8), dtype=torch.float64, device="cuda", generator=g) - 0.5) * 0.8 for _ in range(16)]
+    for i in range(50):
+        out = env.step(acts[i % 16])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        out = env.step(acts[i % 16])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return n * K / dt, int(out.dones.sum())
+
+
 for n in (4096, 8192, 16384):
-    for split in ("0", "1", None):
+    os.environ.pop("TDS_HIP_AUTO_RESET_SPLIT", None)
+    base, _ = run(n, False)
+    print(f"ant x{n} no auto-reset: {base:.4g} env-steps/s", flush=True)
+    for split in ("0", "1", "2", None):
         if split is None:
             os.environ.pop("TDS_HIP_AUTO_RESET_SPLIT", None)
         else:
             os.environ["TDS_HIP_AUTO_RESET_SPLIT"] = split
-        env = tds_amd.VectorizedAntEnv(n, auto_reset_when_done=True, seed=5)
-        env.reset()
-        g = torch.Generator(device="cuda").manual_seed(1)
-        acts = [(torch.rand((n, 8), dtype=torch.float64, device="cuda", generator=g) - 0.5) * 0.8 for _ in range(16)]
-        for i in range(50):
-            out = env.step(acts[i % 16])
-        torch.cuda.synchronize()
-        K, dones = 500, 0
-        t0 = time.perf_counter()
-        for i in range(K):
-            out = env.step(acts[i % 16])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        print(f"ant x{n} auto-reset split={split}: {n * K / dt:.4g} env-steps/s (last step: {int(out.dones.sum())} done)", flush=True)
+        v, d = run(n, True)
+        print(f"ant x{n} auto-reset split={split}: {v:.4g} env-steps/s = {v / base:.2f} x no-reset (last step: {d} done)", flush=True)
