@@ -48,6 +48,33 @@ def test_golden_single_steps(name, built):
         sim.close()
 
 
+@pytest.mark.parametrize("name", ["cartpole", "pendulum5", "ant", "laikago", "laikago_soft", "pendulum5_plane",
+                                  "cartpole_plane"])
+@pytest.mark.parametrize("w2", ["0", "2"])
+def test_golden_single_steps_both_workgroup_forms(name, w2, built, monkeypatch):
+    """The plain straight-line kernels exist as one-wavefront and as two-wavefront workgroups (main + helper wavefront;
+    the library picks by grid size): both forms, forced, against the golden vectors — and against each other."""
+    torch = _torch()
+    monkeypatch.setenv("TDS_HIP_W2", w2)
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = g["x"].shape[0]
+    sim = hip_backend.HipSim(m, n, dtype="f64")
+    y = sim.forward_zero(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    assert rel_err(y, g["y"]) < TOL
+    # closed loop with the obs record, 30 steps from the trajectory start
+    x0 = np.tile(g["traj_x0"], (n, 1))
+    sim.x.copy_(torch.from_numpy(x0).cuda())
+    obs = torch.zeros((n, sim.obs_dim + 2), dtype=torch.float64, device="cuda")
+    nqd = m.dof_q + m.dof_qd
+    for t in range(30):
+        a = np.tile(g["traj_actions"][t], (n, 1))
+        sim.step(torch.from_numpy(a).cuda().contiguous(), 1, obs)
+        assert rel_err(sim.y.cpu().numpy()[0], g["traj_y"][t]) < 5e-6, t   # (closed loop: errors accumulate)
+        assert torch.equal(sim.x[:, :nqd], sim.y[:, :nqd])
+    assert torch.equal(obs[:, 2:nqd], sim.x[:, 2:nqd])
+
+
 @pytest.mark.parametrize("name", MODELS)
 def test_golden_rollout_per_step(name, built):
     torch = _torch()

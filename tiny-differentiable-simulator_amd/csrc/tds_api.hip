@@ -98,7 +98,12 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     ctl.pool_envs = opts->extra->pool_envs;
   }
   const hipStream_t stream = (opts && opts->other_stream) ? opts->stream : s->stream;
-  const TdsLds &lds = (opts && opts->lds) ? *opts->lds : s->lds;
+  // two-wavefront workgroups: plain straight-line launches whose whole grid is resident at once (the helper wavefront
+  // then fills issue slots that would otherwise idle; beyond that the one-wave form with more workgroups per CU wins)
+  const int n_blocks = (n + (64 / s->lanes) - 1) / (64 / s->lanes);
+  const bool two_waves = s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && nsub == 1 &&
+                         reset_mode == TDS_RESET_NONE && !ro && !(opts && opts->lds);
+  const TdsLds &lds = (opts && opts->lds) ? *opts->lds : (two_waves ? s->lds_w2 : s->lds);
   void *const ovf = (opts && opts->lds) ? nullptr : s->d_ovf;
   if (ro) {
     ctl.policy = ro->policy;
@@ -118,15 +123,15 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                          (const double *)x, (double *)y, (const double *)actions, (double *)fb,
-                                         (double *)obs, (double *)ovf, n, stream, ctl);
+                                         (double *)obs, (double *)ovf, n, stream, ctl, nullptr, two_waves);
   else if (s->dtype == TDS_DTYPE_F64_REC32)
     rc = tds_launch_step<double, float>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                         (const float *)x, (float *)y, (const float *)actions, (float *)fb, (float *)obs,
-                                        (double *)ovf, n, stream, ctl);
+                                        (double *)ovf, n, stream, ctl, nullptr, two_waves);
   else
     rc = tds_launch_step<float, float>((const DevModel<float> *)s->d_model, s->h32, lds, s->lanes, (const float *)x,
                                        (float *)y, (const float *)actions, (float *)fb, (float *)obs,
-                                       (float *)ovf, n, stream, ctl);
+                                       (float *)ovf, n, stream, ctl, nullptr, two_waves);
   if (rc != 0) {
     snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad lanes_per_env");
     return TDS_ERR_HIP;
@@ -216,6 +221,22 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
       }
   }
   s->lds = layout(na_cap);
+  {
+    // two-wavefront workgroups: plain kernels up to 18 padded dof; same row cap (the scratch slab is shared)
+    const bool is_fl = c64 ? s->h64.is_floating : s->h32.is_floating;
+    const bool is_sph = c64 ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
+    const char *e = getenv("TDS_HIP_W2");
+    if (!is_fl && !is_sph && s->lds.NDP < 24 && !(e && e[0] == '0')) {
+      s->lds_w2 = c64 ? tds_make_lds_layout<double>(s->h64, na_cap, s->lanes, true)
+                      : tds_make_lds_layout<float>(s->h32, na_cap, s->lanes, true);
+      const size_t b2 = (size_t)s->lds_w2.stride * epw * celem;
+      const int per_cu = b2 > 0 ? (int)((160 * 1024) / b2) : 0;
+      // 256 CUs; two wavefronts per workgroup, four SIMDs per CU: the form pays while every wavefront is resident
+      // with at most two per SIMD, i.e. up to four workgroups per CU
+      const int wg_per_cu = per_cu < 4 ? per_cu : 4;
+      if (b2 <= 64 * 1024 && wg_per_cu >= 1) s->w2_max_blocks = (e && e[0] == '2') ? (1 << 30) : wg_per_cu * 256;
+    }
+  }
   const int lds_bytes = (int)((size_t)s->lds.stride * epw * celem);
   if (lds_bytes > 160 * 1024) {
     delete s;

@@ -19,6 +19,9 @@ struct tds_hip_sim {
   DevModel<double> h64;
   DevModel<float> h32;
   TdsLds lds;
+  // two-wavefront workgroups (plain kernels, straight-line launches whose whole grid is resident at once)
+  TdsLds lds_w2;
+  int w2_max_blocks = 0;  // 0: not available for this model / dtype
   void *d_x = nullptr, *d_y = nullptr, *d_ovf = nullptr;
   unsigned int *d_reset_count = nullptr;
   void *d_split = nullptr;  // records + done mask of the two-launch auto-reset step

@@ -49,8 +49,10 @@ struct TdsStepCtl {
                               // its observation keeps the base x, y where the model says so), not an auto-reset
 };
 
+// na_cap: contacts whose rows stay in LDS (<= 0: all); w2: the layout of the two-wavefront workgroups (the LDS groups
+// that alias each other in the one-wave layout laid out one after the other, + hand-over slots)
 template <typename T>
-TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env);  // na_cap: contacts whose rows stay in LDS (<=0: all)
+TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, bool w2 = false);
 
 // Enqueue one step  y = f(x)  for n_envs environments on `stream`.
 //   actions    (optional) [n_envs][action_dim] overrides the action slice of x
@@ -62,14 +64,15 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env);
 template <typename T, typename TR, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                          const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
-                         hipStream_t stream, const TdsStepCtl &ctl, long long *prof);
+                         hipStream_t stream, const TdsStepCtl &ctl, long long *prof, bool two_waves);
 // T: compute scalar, TR: record scalar (== T, or float under T = double: "f32 records / f64 arithmetic")
 template <typename T, typename TR>
 inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                            const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
                            hipStream_t stream, const TdsStepCtl &ctl,
-                           long long *prof = nullptr) {  // prof: 14 phase stamps of workgroup 0 (diagnostic)
-#define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof
+                           long long *prof = nullptr,  // prof: 14 phase stamps of workgroup 0 (diagnostic)
+                           bool two_waves = false) {   // L is the w2 layout: launch the two-wavefront form (plain kernels)
+#define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof, two_waves
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
   return tds_launch_step_impl<T, TR, 0>(TDS_ARGS);

@@ -355,7 +355,10 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
 // ------------------------------------------------------------------------------------------
 // per row (lane == row): b_r, forward substitution L z = J_r^T in registers, G_rr = z.D^-1.z,
 // 1/(G_rr + cfm); the row is stored back as z~ = D^-1/2 z so that A_rs = J_r M^-1 J_s^T = z~_r.z~_s
-template <bool SLAB, typename T, int G, int NDP>
+// SPLIT (two-wavefront workgroups, run by the helper wavefront while the main one is still in the forward-dynamics
+// solve): qdv holds the velocities BEFORE integrate_euler_qdd, and the b slot receives only J_r . qd_pre; the main
+// wavefront completes it with the acceleration part afterwards (tds_row_rhs_finish).
+template <bool SLAB, typename T, int G, int NDP, bool SPLIT = false>
 __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, int ZR, int OVR, int NCPp,
                                               T *Zs, T *rws, T *xs, const T *qdv, const T *cpx, const T *Lp,
                                               const T *dvec, volatile T *zov, volatile T *rov, T cfm, T erp_dt,
@@ -389,7 +392,10 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
       for (int k = 0; k < NDP; ++k)
         if (k < nd) vrow += z[k] * qdv[k];
       // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
-      brow = t == 0 ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + a] : vrow;
+      if constexpr (SPLIT)
+        brow = vrow;
+      else
+        brow = t == 0 ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + a] : vrow;
       // column-oriented: once z[j] is final, every later z[k] takes its update independently
 #pragma unroll
       for (int j = 0; j < NDP - 1; ++j) {
@@ -419,6 +425,43 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
       rov[r - ZR] = brow;
       rov[OVR + r - ZR] = ai;
       rov[2 * OVR + r - ZR] = g;
+    }
+  }
+}
+
+// Right-hand sides of the constraint rows after a SPLIT row solve (lane == row).  The velocity the reference uses is
+// the one after integrate_euler_qdd, qd+ = qd + dt qdd with qdd = L^-T D^-1 y (y = L^-1 (tau - C)), hence
+//   J_r . qd+ = J_r . qd + dt z~_r . y~,   y~ = D^-1/2 y   (z~_r = D^-1/2 L^-1 J_r^T is what the row store holds)
+//   b_n = (1 + e) J_r.qd+ - erp dist / dt,   b_t = J_r.qd+        (mb_constraint_solver.hpp:309-372)
+template <bool SLAB, typename T, int G, int NDP>
+__device__ __forceinline__ void tds_row_rhs_finish(int lane, int NA, int na, int ZR, int OVR, int NCPp, const T *Zs,
+                                                   T *rws, const T *cpx, const T *yt, volatile T *zov, volatile T *rov,
+                                                   T dt, T erp_dt, T rest) {
+  constexpr int NDs = NDP + 1;
+  const int nrw = 3 * NA;
+  for (int r = lane; r < nrw; r += G) {
+    const int t = (r >= NA ? 1 : 0) + (r >= 2 * NA ? 1 : 0);
+    const int a = r - t * NA;
+    bool in_lds = true;
+    if constexpr (SLAB) in_lds = r < ZR;
+    if (a < na) {
+      T s = T(0), b0;
+      if (in_lds) {
+#pragma unroll
+        for (int k = 0; k < NDP; ++k) s += Zs[r * NDs + k] * yt[k];
+        b0 = rws[r];
+      } else {
+        volatile T *const Zr = zov + (size_t)(r - ZR) * NDs;
+#pragma unroll
+        for (int k = 0; k < NDP; ++k) s += Zr[k] * yt[k];
+        b0 = rov[r - ZR];
+      }
+      const T vrow = b0 + dt * s;
+      const T b = t == 0 ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + a] : vrow;
+      if (in_lds)
+        rws[r] = b;
+      else
+        rov[r - ZR] = b;
     }
   }
 }
@@ -631,18 +674,34 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
 // registers to scratch but two wavefronts overlap — measured on MI355X (profiles/r02_rollout_modes.txt): Ant
 // rollouts 2.17e8 vs 2.05e8 env-steps/s at 4096 environments, 2.24e8 vs 3.12e8 at 8192.  The launcher picks by
 // grid size.
-template <typename T, typename TR, int G, int NDP, bool PROF, int LP, int KIND>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LP == 2 ? 2 : 1)))
+// W2: TWO wavefronts per workgroup (straight-line build of the plain kernels only; 128 threads).  At the headline size
+// — 4096 Ant environments = 1024 one-wave workgroups = exactly one wavefront per SIMD — the kernel time is the latency
+// of ONE wavefront's dependent instruction stream (a lone wavefront issues an instruction every ~10 cycles).  The
+// phases that depend only on the kinematics sweep — narrowphase, visual poses, Jacobian rows — and the per-row
+// forward substitutions, which depend only on the factorisation, are taken off that stream by a helper wavefront:
+//     wavefront 0:  A load, PD, B jcalc, C kinematics | D inertias, E composite sweep, G mass matrix, H LDL^T |
+//                   F forward dynamics | row right-hand sides, L PGS, M/N integrate + pack
+//     wavefront 1:  (constants)                        | I narrowphase, M1 visual poses, J Jacobian rows        |
+//                   K row solves (forward substitutions) | done
+// with three workgroup barriers at the bars.  The LDS groups that alias each other in the one-wave layout are
+// disjoint here (their lifetimes now overlap), which costs LDS and is why this form is launched only while the whole
+// grid fits the GPU at once (tds_launch_step_impl).
+template <typename T, typename TR, int G, int NDP, bool PROF, int LP, int KIND, bool W2 = false>
+__global__ __launch_bounds__(W2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu((LP == 2 || W2) ? 2 : 1)))
 void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const TR *x_in, TR *__restrict__ y_out,
                                                       const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
                                                       TR *__restrict__ obs_out, T *ovf, long long *prof, TdsStepCtl ctl, int n_envs) {
   constexpr bool LOOP = LP != 0;
+  static_assert(!W2 || (LP == 0 && KIND == 0 && !PROF && NDP < 24), "two-wavefront workgroups: plain straight-line kernels");
   extern __shared__ __align__(16) unsigned char tds_smem_raw[];
   T *const sm = reinterpret_cast<T *>(tds_smem_raw);
   constexpr int EPW = 64 / G;
   const int lane0 = threadIdx.x & (G - 1);
-  const int grp0 = threadIdx.x / G;
+  const int grp0 = (threadIdx.x & 63) / G;
+  // which wavefront of the workgroup (scalar: every branch on it is a uniform branch)
+  const int wv = W2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  const bool main_wave = !W2 || wv == 0;
 
   // ---- A0. the x record (and the fresh actions) are requested from HBM first: their latency runs under the
   //      fetch of the model constants below; dimensions from the kernel arguments, not from the model
@@ -655,7 +714,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       const int i = lane0 + k * G;
       const bool act = actions != nullptr && i >= L.nqnd && i < L.nqnd + L.adim;
       const TR *src = act ? actions + ((size_t)env * L.adim + (i - L.nqnd)) : x_in + ((size_t)env * L.in_dim + i);
-      xpre[k] = (env < n_envs && i < L.in_dim) ? (T)*src : T(0);
+      xpre[k] = (main_wave && env < n_envs && i < L.in_dim) ? (T)*src : T(0);
     }
   }
 
@@ -790,7 +849,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 #pragma unroll
     for (int k = 0; k < 3; ++k) tT[k] = md->X_T[9 + k][lsafe];
   };
-  if constexpr (!LOOP) load_link_consts(mdl);
+  if constexpr (!LOOP) {
+    if (main_wave) load_link_consts(mdl);
+  }
   // The same for the constants of the later phases (first narrowphase pass: contact point == lane,
   // visual == lane, mass-matrix row == lane, contact frame and solver scalars): issued here, their
   // L2 / scalar-cache latency is long gone when the phase starts; fetched where they are used, each
@@ -834,14 +895,16 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // ---- A. x record -> LDS (coalesced: consecutive lanes, consecutive doubles) ---------------
   T *const xr = E + L.xrec;
   if constexpr (!LOOP) {  // (the step-loop build did this in its prologue; the state then lives in the LDS record)
+    if (main_wave) {
 #pragma unroll
-    for (int k = 0; k < XPL; ++k) {
-      const int i = lane + k * G;
-      if (i < in_dim) xr[i] = xpre[k];
-    }
-    for (int i = lane + XPL * G; i < in_dim; i += G) {
-      const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
-      xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+      for (int k = 0; k < XPL; ++k) {
+        const int i = lane + k * G;
+        if (i < in_dim) xr[i] = xpre[k];
+      }
+      for (int i = lane + XPL * G; i < in_dim; i += G) {
+        const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
+        xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+      }
     }
     TDS_WAVE_SYNC();
   }
@@ -870,6 +933,237 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
   }
   const bool do_reward = last_run || (pol && mode == TDS_MODE_RUN);
+  // ---- the phases that a two-wavefront workgroup hands to its helper wavefront, as closures (each derives the LDS
+  //      addresses it needs itself: nothing is kept live for them across the phases in between)
+  const int NCPp = L.NCPp;
+  const int ZR = L.zrows;
+  const int OVR = L.ovrows;  // surplus rows available per environment in the slab
+  // ---- I. narrowphase: penetrating contact points of this lane group, compacted into cpx; returns their number
+  auto phase_I = [&]() -> int {
+    T *const Xw = E + L.Xw;
+    T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, ancestor-dof mask (bit pattern)
+    int na = 0;
+  if (pf_ncp > 0) {
+      const int ncp = pf_ncp;
+      for (int base = 0; base < ncp; base += G) {
+        const int k = base + lane;
+        bool act = false;
+        T Pb[3] = {T(0), T(0), T(0)}, dist = T(0);
+        int lk = -1;
+        unsigned lk_anc = 0u;
+        if (k < ncp) {
+          const bool first = base == 0;  // wave-uniform: the first pass was prefetched at kernel start
+          lk = pf_cp_link;
+          lk_anc = pf_cp_anc;
+          if (!first) {
+            lk = mdl->cp_link[k];
+            lk_anc = mdl->anc_dofs[lk >= 0 ? lk : 0];
+          }
+          T Rl[9], pl[3];
+          if (lk >= 0) {
+  #pragma unroll
+            for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
+  #pragma unroll
+            for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
+          } else {
+  #pragma unroll
+            for (int c = 0; c < 9; ++c) Rl[c] = mdl->base_R[c];
+  #pragma unroll
+            for (int c = 0; c < 3; ++c) pl[c] = mdl->base_t[c];
+          }
+          T loc[3] = {pf_cp_loc[0], pf_cp_loc[1], pf_cp_loc[2]};
+          T rad = pf_cp_rad;
+          if (!first) {
+            loc[0] = mdl->cp_local[0][k];
+            loc[1] = mdl->cp_local[1][k];
+            loc[2] = mdl->cp_local[2][k];
+            rad = mdl->cp_radius[k];
+          }
+          T ctr[3];
+          mat3_mulv(Rl, loc, ctr);
+          ctr[0] += pl[0];
+          ctr[1] += pl[1];
+          ctr[2] += pl[2];
+          const T n[3] = {pf_plane_n[0], pf_plane_n[1], pf_plane_n[2]};
+          // t = -(dot(p, -n) + c);  distance = t - r;  point_on_b = p - r n
+          const T t = -((-dot3(ctr, n)) + pf_plane_c);
+          dist = t - rad;
+          Pb[0] = ctr[0] - rad * n[0];
+          Pb[1] = ctr[1] - rad * n[1];
+          Pb[2] = ctr[2] - rad * n[2];
+          act = live && dist < T(0);  // collision mask, mb_constraint_solver.hpp:285
+        }
+        const unsigned long long bal = __ballot(act);
+        const unsigned long long mine = (G == 64) ? bal : ((bal >> (grp * G)) & ((1ull << (G & 63)) - 1ull));
+        const int pre = __popcll(mine & ((1ull << lane) - 1ull));
+        if (act) {
+          const int slot = na + pre;
+          cpx[0 * NCPp + slot] = Pb[0];
+          cpx[1 * NCPp + slot] = Pb[1];
+          cpx[2 * NCPp + slot] = Pb[2];
+          cpx[3 * NCPp + slot] = dist;
+          cpx[4 * NCPp + slot] = bits_to_scalar<T>(lk >= 0 ? lk_anc : 0u);
+        }
+        na += __popcll(mine);
+      }
+    }
+    return na;
+  };
+  // the largest contact count among the wavefront's environments (wave-uniform)
+  auto wave_max = [&](int n_mine) -> int {
+    int NAv = n_mine;
+#pragma unroll
+    for (int msk = G; msk < 64; msk <<= 1) {
+      const int o = __shfl_xor(NAv, msk, 64);
+      NAv = o > NAv ? o : NAv;
+    }
+    return __builtin_amdgcn_readfirstlane(NAv);
+  };
+  auto phase_M1 = [&]() {
+    T *const Xw = E + L.Xw;
+  // ---- M1. visual poses of y (they use the PRE-step X_world, locomotion_contact_simulation.h:281-299)
+    {
+      TR *const yo = y_out + (size_t)env * out_dim;
+      const int nv = pf_nv;
+      const int vbase = nq + nd;
+      if (last_run && y_out != nullptr) {  // y describes the last normal step of the launch
+        for (int k = lane; k < nv; k += G) {
+          const bool first = k == lane;  // wave-uniform: visual == lane was prefetched at kernel start
+          int lk = pf_vis_link;
+          if (!first) lk = mdl->vis_link[k];
+          T Rl[9], pl[3], Rv[9], pv[3];
+    #pragma unroll
+          for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
+    #pragma unroll
+          for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
+    #pragma unroll
+          for (int c = 0; c < 9; ++c) Rv[c] = pf_vis_X[c];
+    #pragma unroll
+          for (int c = 0; c < 3; ++c) pv[c] = pf_vis_X[9 + c];
+          if (!first) {
+    #pragma unroll
+            for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
+    #pragma unroll
+            for (int c = 0; c < 3; ++c) pv[c] = mdl->vis_X[9 + c][k];
+          }
+          T Ro[9], po[3], qo[4];
+          mat3_mul(Rl, Rv, Ro);
+          mat3_mulv(Rl, pv, po);
+          matrix_to_quat(Ro, qo);
+          TR *o = yo + vbase + 7 * k;
+          __builtin_nontemporal_store((TR)(pl[0] + po[0]), &o[0]);
+          __builtin_nontemporal_store((TR)(pl[1] + po[1]), &o[1]);
+          __builtin_nontemporal_store((TR)(pl[2] + po[2]), &o[2]);
+          __builtin_nontemporal_store((TR)qo[0], &o[3]);
+          __builtin_nontemporal_store((TR)qo[1], &o[4]);
+          __builtin_nontemporal_store((TR)qo[2], &o[5]);
+          __builtin_nontemporal_store((TR)qo[3], &o[6]);
+        }
+      }
+    }
+  };
+  // ---- J. constraint Jacobian rows of the wavefront's contact slots (lane == dof)
+  auto phase_J = [&](const int na, const int NA) {
+    T *const swd = E + L.swd;
+    T *const cpx = E + L.cp;
+    T *const Zs = E + L.Z;
+    volatile T *const zov = (ovf != nullptr && live) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
+    const T nb[3] = {pf_nb[0], pf_nb[1], pf_nb[2]};
+    const T t1[3] = {pf_t1[0], pf_t1[1], pf_t1[2]};
+    const T t2[3] = {pf_t2[0], pf_t2[1], pf_t2[2]};
+    {
+      // column d of the point Jacobian of contact point P: col = s_lin - P x s_ang  (xs.bottom = st.bottom -
+      // point x st.top, jacobian.hpp:56-72); its components along n, t1, t2 are affine in P:
+      //   e . col = e . s_lin + P . (e x s_ang)      -> three FMAs per row instead of a cross and a dot
+      const int d = lane;
+      T sd[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sd[k] = d < nd ? swd[k * NDs + d] : T(0);
+      if (fl && d >= njd && d < nd) {
+        // the reference's point Jacobian takes the base dofs along WORLD axes about the base origin:
+        // [ -[r]x | 1 ],  r = point - base position   (jacobian.hpp:39-56)
+        const int kb = d - njd;
+        const T pb[3] = {xr[4], xr[5], xr[6]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sd[k] = T(0);
+        if (kb < 3) {
+          const T e[3] = {kb == 0 ? T(1) : T(0), kb == 1 ? T(1) : T(0), kb == 2 ? T(1) : T(0)};
+          sd[0] = e[0];
+          sd[1] = e[1];
+          sd[2] = e[2];
+          cross3(pb, e, sd + 3);
+        } else {
+          sd[kb] = T(1);
+        }
+      }
+      T cnv[3], c1v[3], c2v[3];
+      cross3(nb, sd, cnv);
+      cross3(t1, sd, c1v);
+      cross3(t2, sd, c2v);
+      const T cn0 = dot3(nb, sd + 3), c10 = dot3(t1, sd + 3), c20 = dot3(t2, sd + 3);
+      // software pipeline over the wavefront's contact slots: slot a + 1 is fetched while a is written
+      T Pn[3] = {cpx[0], cpx[NCPp], cpx[2 * NCPp]};
+      unsigned mskn = scalar_to_bits<T>(cpx[4 * NCPp]);
+      const int lastc = NCPp - 1;
+      for (int a = 0; a < NA; ++a) {
+        const T P[3] = {Pn[0], Pn[1], Pn[2]};
+        const unsigned msk = mskn;
+        const int an = a + 1 < lastc ? a + 1 : lastc;
+        Pn[0] = cpx[0 * NCPp + an];
+        Pn[1] = cpx[1 * NCPp + an];
+        Pn[2] = cpx[2 * NCPp + an];
+        mskn = scalar_to_bits<T>(cpx[4 * NCPp + an]);
+        if (d < NDP && a < na) {
+          const bool on = d < nd && ((msk >> d) & 1u);
+          const T jn = on ? cn0 + dot3(P, cnv) : T(0);
+          const T j1 = on ? c10 + dot3(P, c1v) : T(0);
+          const T j2 = on ? c20 + dot3(P, c2v) : T(0);
+          const int r0 = a, r1 = NA + a, r2 = 2 * NA + a;
+          if (r0 < ZR) Zs[r0 * NDs + d] = jn; else zov[(r0 - ZR) * NDs + d] = jn;
+          if (r1 < ZR) Zs[r1 * NDs + d] = j1; else zov[(r1 - ZR) * NDs + d] = j1;
+          if (r2 < ZR) Zs[r2 * NDs + d] = j2; else zov[(r2 - ZR) * NDs + d] = j2;
+        }
+      }
+    }
+  };
+
+  if constexpr (W2) {
+    if (wv == 1) {
+      // ================= helper wavefront of a two-wavefront workgroup =================
+      __syncthreads();  // (1) the main wavefront has written the x record, X_world and the motion axes
+      T *const cpx = E + L.cp;
+      T *const Zs = E + L.Z;
+      T *const rws = E + L.rows;
+      T *const xs = E + L.xrow;
+      const int na_h = phase_I();
+      const bool contacts_h = __any(na_h > 0) != 0;
+      const int NA_h = wave_max(na_h);
+      const bool split_ok = 3 * NA_h <= ZR;  // (more rows than the LDS store holds: the main wavefront takes the slab path)
+      if (lane == 0) {  // contact count of the environment / row slots of the wavefront, for the main wavefront
+        xr[in_dim + 2] = bits_to_scalar<T>((unsigned)na_h);
+        xr[in_dim + 3] = bits_to_scalar<T>((unsigned)NA_h);
+      }
+      phase_M1();
+      if (last_run && y_out != nullptr) {  // tail of the y record: up_dot_world_z, zero padding
+        TR *const yo = y_out + (size_t)env * out_dim;
+        int tail = nq + nd;
+        if (mdl->pack_visuals) {
+          tail += 7 * mdl->num_visuals;
+          if (lane == 0) __builtin_nontemporal_store((TR)(mdl->base_R[8]), &yo[tail]);
+          tail += 1;
+        }
+        for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
+      }
+      if (contacts_h && split_ok) phase_J(na_h, NA_h);
+      __syncthreads();  // (2) the factors L, 1/D are in LDS; the rows and the contact list are visible to the main wavefront
+      if (contacts_h && split_ok)
+        tds_row_solve<false, T, G, NDP, true>(lane, NA_h, na_h, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, E + L.Lp,
+                                             E + L.dinv, nullptr, nullptr, pf_cfm, pf_erp_dt, pf_rest);
+      __syncthreads();  // (3) z~ rows and their scalars are final
+      return;
+    }
+  }
+
   const T q = (di >= 0 && (!gen || (qri >= 0 && !sph_lane))) ? xr[gen ? (qri >= 0 ? qri : 0) : qri] : T(0);
   const T qd = di >= 0 ? xr[nq + qdri] : T(0);
 
@@ -1257,132 +1551,29 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   TDS_STAMP(3);
   // ---- I. narrowphase right after the kinematics sweep (it only needs X_world), so that the
   //         LDS holding X_world / v can be recycled by the dynamics sweeps
-  // (step-loop build: the constants of the later phases are fetched only now — one L2 round trip per iteration
-  //  instead of ~60 registers held through the kinematics sweep, which is what keeps this build at two
-  //  wavefronts per SIMD)
-  if constexpr (LOOP && NDP < 24) load_phase_consts(mdl);
-  T *const cpx = E + L.cp;  // [5][NCPp]: point_on_b (3), distance, ancestor-dof mask (bit pattern)
-  const int NCPp = L.NCPp;
-  int na = 0;
-  if (pf_ncp > 0) {
-    const int ncp = pf_ncp;
-    for (int base = 0; base < ncp; base += G) {
-      const int k = base + lane;
-      bool act = false;
-      T Pb[3] = {T(0), T(0), T(0)}, dist = T(0);
-      int lk = -1;
-      unsigned lk_anc = 0u;
-      if (k < ncp) {
-        const bool first = base == 0;  // wave-uniform: the first pass was prefetched at kernel start
-        lk = pf_cp_link;
-        lk_anc = pf_cp_anc;
-        if (!first) {
-          lk = mdl->cp_link[k];
-          lk_anc = mdl->anc_dofs[lk >= 0 ? lk : 0];
-        }
-        T Rl[9], pl[3];
-        if (lk >= 0) {
-#pragma unroll
-          for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
-        } else {
-#pragma unroll
-          for (int c = 0; c < 9; ++c) Rl[c] = mdl->base_R[c];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) pl[c] = mdl->base_t[c];
-        }
-        T loc[3] = {pf_cp_loc[0], pf_cp_loc[1], pf_cp_loc[2]};
-        T rad = pf_cp_rad;
-        if (!first) {
-          loc[0] = mdl->cp_local[0][k];
-          loc[1] = mdl->cp_local[1][k];
-          loc[2] = mdl->cp_local[2][k];
-          rad = mdl->cp_radius[k];
-        }
-        T ctr[3];
-        mat3_mulv(Rl, loc, ctr);
-        ctr[0] += pl[0];
-        ctr[1] += pl[1];
-        ctr[2] += pl[2];
-        const T n[3] = {pf_plane_n[0], pf_plane_n[1], pf_plane_n[2]};
-        // t = -(dot(p, -n) + c);  distance = t - r;  point_on_b = p - r n
-        const T t = -((-dot3(ctr, n)) + pf_plane_c);
-        dist = t - rad;
-        Pb[0] = ctr[0] - rad * n[0];
-        Pb[1] = ctr[1] - rad * n[1];
-        Pb[2] = ctr[2] - rad * n[2];
-        act = live && dist < T(0);  // collision mask, mb_constraint_solver.hpp:285
-      }
-      const unsigned long long bal = __ballot(act);
-      const unsigned long long mine = (G == 64) ? bal : ((bal >> (grp * G)) & ((1ull << (G & 63)) - 1ull));
-      const int pre = __popcll(mine & ((1ull << lane) - 1ull));
-      if (act) {
-        const int slot = na + pre;
-        cpx[0 * NCPp + slot] = Pb[0];
-        cpx[1 * NCPp + slot] = Pb[1];
-        cpx[2 * NCPp + slot] = Pb[2];
-        cpx[3 * NCPp + slot] = dist;
-        cpx[4 * NCPp + slot] = bits_to_scalar<T>(lk >= 0 ? lk_anc : 0u);
-      }
-      na += __popcll(mine);
-    }
+  // ---- I + M1. narrowphase and visual poses right after the kinematics sweep (they only need X_world), so that the
+  //         LDS holding X_world / v can be recycled by the dynamics sweeps.  In a two-wavefront workgroup the helper
+  //         wavefront runs them (and the Jacobian rows) while this one goes on with the dynamics.
+  int na = 0, NA = 0;
+  bool wave_contacts = false;
+  if constexpr (W2) {
+    __syncthreads();  // (1) x record, X_world and the motion axes are in LDS: the helper wavefront starts
+  } else {
+    // (step-loop build: the constants of the later phases are fetched only now — one L2 round trip per iteration
+    //  instead of ~60 registers held through the kinematics sweep, which is what keeps this build at two
+    //  wavefronts per SIMD)
+    if constexpr (LOOP && NDP < 24) load_phase_consts(mdl);
+    na = phase_I();
+    // does any environment of this wavefront have a penetrating contact?  If not, the whole
+    // constraint pipeline (CRBA, LDL^T, rows, PGS) is skipped: with keep_all_points_ the reference
+    // still solves, but every row is identically zero and leaves qd untouched.
+    wave_contacts = __any(na > 0) != 0;
+    // wave-uniform constraint-row layout (see tds_row_solve): NA = the largest contact count among the
+    // wavefront's environments (computed here, long before phase J needs it)
+    NA = wave_max(na);
+    phase_M1();
+    TDS_WAVE_SYNC();  // X_world / v in LDS are dead from here on (their space is reused)
   }
-  // does any environment of this wavefront have a penetrating contact?  If not, the whole
-  // constraint pipeline (CRBA, LDL^T, rows, PGS) is skipped: with keep_all_points_ the reference
-  // still solves, but every row is identically zero and leaves qd untouched.
-  const bool wave_contacts = __any(na > 0) != 0;
-  // wave-uniform constraint-row layout (see tds_row_solve): NA = the largest contact count among the
-  // wavefront's environments (computed here, long before phase J needs it)
-  int NAv = na;
-#pragma unroll
-  for (int msk = G; msk < 64; msk <<= 1) {
-    const int o = __shfl_xor(NAv, msk, 64);
-    NAv = o > NAv ? o : NAv;
-  }
-  const int NA = __builtin_amdgcn_readfirstlane(NAv);
-
-  // ---- M1. visual poses of y (they use the PRE-step X_world, locomotion_contact_simulation.h:281-299)
-  {
-    TR *const yo = y_out + (size_t)env * out_dim;
-    const int nv = pf_nv;
-    const int vbase = nq + nd;
-    if (last_run && y_out != nullptr) {  // y describes the last normal step of the launch
-      for (int k = lane; k < nv; k += G) {
-        const bool first = k == lane;  // wave-uniform: visual == lane was prefetched at kernel start
-        int lk = pf_vis_link;
-        if (!first) lk = mdl->vis_link[k];
-        T Rl[9], pl[3], Rv[9], pv[3];
-  #pragma unroll
-        for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
-  #pragma unroll
-        for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
-  #pragma unroll
-        for (int c = 0; c < 9; ++c) Rv[c] = pf_vis_X[c];
-  #pragma unroll
-        for (int c = 0; c < 3; ++c) pv[c] = pf_vis_X[9 + c];
-        if (!first) {
-  #pragma unroll
-          for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
-  #pragma unroll
-          for (int c = 0; c < 3; ++c) pv[c] = mdl->vis_X[9 + c][k];
-        }
-        T Ro[9], po[3], qo[4];
-        mat3_mul(Rl, Rv, Ro);
-        mat3_mulv(Rl, pv, po);
-        matrix_to_quat(Ro, qo);
-        TR *o = yo + vbase + 7 * k;
-        __builtin_nontemporal_store((TR)(pl[0] + po[0]), &o[0]);
-        __builtin_nontemporal_store((TR)(pl[1] + po[1]), &o[1]);
-        __builtin_nontemporal_store((TR)(pl[2] + po[2]), &o[2]);
-        __builtin_nontemporal_store((TR)qo[0], &o[3]);
-        __builtin_nontemporal_store((TR)qo[1], &o[4]);
-        __builtin_nontemporal_store((TR)qo[2], &o[5]);
-        __builtin_nontemporal_store((TR)qo[3], &o[6]);
-      }
-    }
-  }
-  TDS_WAVE_SYNC();  // X_world / v in LDS are dead from here on (their space is reused)
 
   // ---- D. world-frame rigid inertias and the forces of the "all joint accelerations zero" motion
   //         (kinematics.hpp:96-132, inertia.hpp:121-130).
@@ -1656,6 +1847,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         if (j < lane) Lp[off + j] = Mr[j];
     }
     TDS_STAMP(7);
+    bool split_ok = false;  // two-wavefront workgroup: the helper wavefront does the row solves
+    if constexpr (W2) {
+      __syncthreads();  // (2) L, 1/D are in LDS for the helper wavefront's row solves; its contact list and rows are visible here
+      na = (int)scalar_to_bits<T>(xr[in_dim + 2]);
+      NA = __builtin_amdgcn_readfirstlane((int)scalar_to_bits<T>(xr[in_dim + 3]));
+      wave_contacts = NA > 0;
+      split_ok = 3 * NA <= ZR;
+    }
     // ---- F. forward dynamics: qdd = M^-1 (tau - C) with the factorisation just computed, then
     //         integrate_euler_qdd: qd += qdd dt (integrator.hpp:169-181).  tau - C travels from the link
     //         lanes to the dof lanes through the (now free) column scratch of dvec.
@@ -1674,6 +1873,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         yv = d > k ? yv - Mr[k] * yk : yv;
       });
       T xv = yv * my_inv;
+      if constexpr (W2) {  // y~ = D^-1/2 y for the rows' right-hand sides (tds_row_rhs_finish)
+        if (d < NDP) dvec[3 * NDP + d] = yv * sqrt_t<T>(my_inv);
+      }
       const bool jrow = !fl || d < njd;  // (the base rows of a floating base keep a_base in the back substitution)
       if (fl) {  // wave-uniform
         // With the joint dofs eliminated, the base rows read  Sigma a_base = rho:  Sigma = L_b D_b L_b^T (the
@@ -1757,6 +1959,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     TDS_STAMP(8);
 
     TDS_WAVE_SYNC();  // Z aliases the sweep arrays (f, Ic, F): all of those are dead now
+    if constexpr (W2) __syncthreads();  // (3) the helper wavefront's z~ rows, G_rr and 1 / (G_rr + cfm) are final
     TDS_STAMP(9);
     if (wave_contacts) {
 
@@ -1766,71 +1969,41 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     // contacts keeps the surplus rows (and their scalars) in a global scratch slab — rare, slow,
     // exact.  Sizing LDS for the typical contact count instead of the worst case is what lets four
     // workgroups share a CU.
+    T *const cpx = E + L.cp;
     T *const Zs = E + L.Z;  // [ZR][NDs]: J rows, overwritten in place by z~ = D^-1/2 L^-1 J^T
     T *const rws = E + L.rows;  // [3][ZR]: b | 1/(G+cfm) | G
     T *const xs = E + L.xrow;   // [3 ncp]: the impulses x of ALL rows stay in LDS (read back within the wave)
-    const int ZR = L.zrows;
-    const int OVR = L.ovrows;  // surplus rows available per environment in the slab
     volatile T *const zov = (ovf != nullptr && live) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
     volatile T *const rov = zov != nullptr ? zov + (size_t)OVR * NDs : nullptr;  // [3][OVR]
     const int nr = 3 * NA;
-    const T nb[3] = {pf_nb[0], pf_nb[1], pf_nb[2]};
-    const T t1[3] = {pf_t1[0], pf_t1[1], pf_t1[2]};
-    const T t2[3] = {pf_t2[0], pf_t2[1], pf_t2[2]};
-    {
-      // column d of the point Jacobian of contact point P: col = s_lin - P x s_ang  (xs.bottom = st.bottom -
-      // point x st.top, jacobian.hpp:56-72); its components along n, t1, t2 are affine in P:
-      //   e . col = e . s_lin + P . (e x s_ang)      -> three FMAs per row instead of a cross and a dot
-      const int d = lane;
-      T sd[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) sd[k] = d < nd ? swd[k * NDs + d] : T(0);
-      if (fl && d >= njd && d < nd) {
-        // the reference's point Jacobian takes the base dofs along WORLD axes about the base origin:
-        // [ -[r]x | 1 ],  r = point - base position   (jacobian.hpp:39-56)
-        const int kb = d - njd;
-        const T pb[3] = {xr[4], xr[5], xr[6]};
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sd[k] = T(0);
-        if (kb < 3) {
-          const T e[3] = {kb == 0 ? T(1) : T(0), kb == 1 ? T(1) : T(0), kb == 2 ? T(1) : T(0)};
-          sd[0] = e[0];
-          sd[1] = e[1];
-          sd[2] = e[2];
-          cross3(pb, e, sd + 3);
-        } else {
-          sd[kb] = T(1);
-        }
+    const T cfm = pf_cfm, erp_dt = pf_erp_dt, rest = pf_rest;
+    const bool any_slab = nr > ZR;  // wave-uniform
+    if constexpr (W2) {
+      // Rows and row solves normally came from the helper wavefront.  More rows than the LDS store holds (rare): this
+      // wavefront builds and solves them itself, through the scratch slab — with the SAME split arithmetic, so that
+      // an environment's result does not depend on which path its wavefront-mates forced.
+      if (!split_ok) {
+        phase_J(na, NA);
+        TDS_WAVE_SYNC();
+        if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (any_slab)
+          tds_row_solve<true, T, G, NDP, true>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov,
+                                               rov, cfm, erp_dt, rest);
+        else
+          tds_row_solve<false, T, G, NDP, true>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, Lp, dvec, zov,
+                                                rov, cfm, erp_dt, rest);
+        TDS_WAVE_SYNC();
+        if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       }
-      T cnv[3], c1v[3], c2v[3];
-      cross3(nb, sd, cnv);
-      cross3(t1, sd, c1v);
-      cross3(t2, sd, c2v);
-      const T cn0 = dot3(nb, sd + 3), c10 = dot3(t1, sd + 3), c20 = dot3(t2, sd + 3);
-      // software pipeline over the wavefront's contact slots: slot a + 1 is fetched while a is written
-      T Pn[3] = {cpx[0], cpx[NCPp], cpx[2 * NCPp]};
-      unsigned mskn = scalar_to_bits<T>(cpx[4 * NCPp]);
-      const int lastc = NCPp - 1;
-      for (int a = 0; a < NA; ++a) {
-        const T P[3] = {Pn[0], Pn[1], Pn[2]};
-        const unsigned msk = mskn;
-        const int an = a + 1 < lastc ? a + 1 : lastc;
-        Pn[0] = cpx[0 * NCPp + an];
-        Pn[1] = cpx[1 * NCPp + an];
-        Pn[2] = cpx[2 * NCPp + an];
-        mskn = scalar_to_bits<T>(cpx[4 * NCPp + an]);
-        if (d < NDP && a < na) {
-          const bool on = d < nd && ((msk >> d) & 1u);
-          const T jn = on ? cn0 + dot3(P, cnv) : T(0);
-          const T j1 = on ? c10 + dot3(P, c1v) : T(0);
-          const T j2 = on ? c20 + dot3(P, c2v) : T(0);
-          const int r0 = a, r1 = NA + a, r2 = 2 * NA + a;
-          if (r0 < ZR) Zs[r0 * NDs + d] = jn; else zov[(r0 - ZR) * NDs + d] = jn;
-          if (r1 < ZR) Zs[r1 * NDs + d] = j1; else zov[(r1 - ZR) * NDs + d] = j1;
-          if (r2 < ZR) Zs[r2 * NDs + d] = j2; else zov[(r2 - ZR) * NDs + d] = j2;
-        }
-      }
-    }
+      // complete the right-hand sides with the acceleration part
+      if (any_slab)
+        tds_row_rhs_finish<true, T, G, NDP>(lane, NA, na, ZR, OVR, NCPp, Zs, rws, cpx, dvec + 3 * NDP, zov, rov, dt, erp_dt, rest);
+      else
+        tds_row_rhs_finish<false, T, G, NDP>(lane, NA, na, ZR, OVR, NCPp, Zs, rws, cpx, dvec + 3 * NDP, zov, rov, dt, erp_dt, rest);
+      TDS_WAVE_SYNC();
+      if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    } else {
+    phase_J(na, NA);
     TDS_WAVE_SYNC();
     // surplus rows went through global memory: drain the stores before other lanes load them.
     // (a fence, NOT __syncthreads(): hipcc 7.2 miscompiled the <f64,G=64,NDP=24> kernel when an
@@ -1841,8 +2014,6 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     // ---- K. per row (lane == row): b_r, forward substitution  L z = J_r^T  in registers,
     //         G_rr = z.D^-1.z,  1/(G_rr + cfm);  the row is stored back as z~ = D^-1/2 z so that
     //         A_rs = J_r M^-1 J_s^T = z~_r . z~_s  — one matrix instead of J and M^-1 J^T.
-    const T cfm = pf_cfm, erp_dt = pf_erp_dt, rest = pf_rest;
-    const bool any_slab = nr > ZR;  // wave-uniform
     if (any_slab)
       tds_row_solve<true, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, rhsx, cpx, Lp, dvec, zov, rov,
                                      cfm, erp_dt, rest);
@@ -1851,6 +2022,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                       cfm, erp_dt, rest);
     TDS_WAVE_SYNC();
     if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
     TDS_STAMP(11);
 
     // ---- L. projected Gauss-Seidel (mb_constraint_solver.hpp:101-142) on u~ = sum_r z~_r x_r:
@@ -1947,14 +2119,16 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       __builtin_nontemporal_store((TR)(q_new), &yo[di]);
       __builtin_nontemporal_store((TR)(qd_new), &yo[nq + di]);
     }
-    const int nv = mdl->num_visuals;
-    int tail = nq + nd;
-    if (mdl->pack_visuals) {
-      tail += 7 * nv;
-      if (lane == 0) __builtin_nontemporal_store((TR)(fl ? up_z : mdl->base_R[8]), &yo[tail]);  // up_dot_world_z
-      tail += 1;
+    if constexpr (!W2) {  // (two-wavefront workgroup: the helper wavefront wrote the tail of the record)
+      const int nv = mdl->num_visuals;
+      int tail = nq + nd;
+      if (mdl->pack_visuals) {
+        tail += 7 * nv;
+        if (lane == 0) __builtin_nontemporal_store((TR)(fl ? up_z : mdl->base_R[8]), &yo[tail]);  // up_dot_world_z
+        tail += 1;
+      }
+      for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
     }
-    for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
   }
 
   // ---- N. reward / done of the last normal step
@@ -2133,7 +2307,7 @@ int tds_padded_dof(int nd, int lanes) {
 constexpr bool tds_instantiate(int key) { return TDS_DEBUG_ONLY == 0 || TDS_DEBUG_ONLY == key; }
 
 template <typename T>
-TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) {
+TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, bool w2) {
   TdsLds L;
   memset(&L, 0, sizeof(L));
   const int nl = m.num_links;
@@ -2148,7 +2322,8 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
   L.ovrows = 3 * ncp - L.zrows;    // surplus rows per environment (global scratch slab)
   int o = 0;
   // persistent for the whole step
-  L.xrec = o; o += m.input_dim + 2;  // + x_{t-1} and the done flag of the step loop
+  L.xrec = o; o += m.input_dim + 2 + (w2 ? 2 : 0);  // + x_{t-1} and the done flag of the step loop (+ contact counts
+                                                    //   handed from the helper to the main wavefront)
   // two pairs with disjoint lifetimes share their storage:
   //   swd  (world motion axes per dof: phases C..J)  |  rows (b, 1/(G+cfm), G per constraint row: K..L)
   //   cp   (contact points: phases I..K)             |  xrow (impulses x of all rows: L)
@@ -2161,7 +2336,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
     L.cp = o; L.xrow = o; o += a > b ? a : b;
   }
   L.Lp = o;   o += (ndp * (ndp - 1)) / 2;
-  L.dinv = o; o += 3 * ndp;  // 1/D | sqrt(1/D) | column scratch of the wide LDL^T / rhs exchange
+  L.dinv = o; o += (w2 ? 4 : 3) * ndp;  // 1/D | sqrt(1/D) | column scratch of the wide LDL^T / rhs exchange (| y~)
   // three phase groups share one region:
   //   1. kinematics sweep:   per-link records [X_world(12) | v(6)]              stride TDS_S1
   //   2. composite sweep:    per-link records [f or F(6) | Ic(10)] stride TDS_S2
@@ -2170,9 +2345,11 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
   int g1 = u;
   L.Xw = g1; g1 += TDS_S1 * L.NLp;
   L.v = g1; g1 += TDS_S1 * m.num_lc_slots;
-  int g2 = u;
+  // (two-wavefront workgroups: the helper wavefront reads X_world and writes the rows while the main one sweeps the
+  //  inertias — the three groups are laid out one after the other)
+  int g2 = w2 ? g1 : u;
   L.IA = g2; L.pA = g2; L.F = g2; L.Ic = g2 + 6; L.a = g2; g2 += TDS_S2 * L.NLp;
-  int g3 = u;
+  int g3 = w2 ? g2 : u;
   L.Z = g3; g3 += L.zrows * L.NDs;
   o = g1 > g2 ? g1 : g2;
   o = o > g3 ? o : g3;
@@ -2187,13 +2364,20 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env) 
 template <typename T, typename TR, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                          const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
-                         hipStream_t stream, const TdsStepCtl &ctl, long long *prof) {
+                         hipStream_t stream, const TdsStepCtl &ctl, long long *prof, bool two_waves) {
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
   const size_t shmem = (size_t)L.stride * epw * sizeof(T);
   (void)h_model;
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \
+    if constexpr (KIND == 0 && NN < 24) {                                                                    \
+      if (two_waves && simple && !prof) {                                                                    \
+        hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 0, 0, true>), dim3(blocks), dim3(128), shmem, \
+                           stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
+        break;                                                                                               \
+      }                                                                                                      \
+    }                                                                                                        \
     if (prof)                                                                                                \
       hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, true, 0, 0>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
@@ -2248,6 +2432,9 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
     if (e == hipSuccess && KIND == 0)                                                                               \
       e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, true, 0, 0>,                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
+    if (e == hipSuccess && KIND == 0 && NN < 24)                                                                    \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 0, 0, true>,      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
 #define TDS_CASE(GG, NN) \
@@ -2270,7 +2457,7 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
 #define TDS_INSTANTIATE(TT, TR, KV)                                                                                     \
   template int tds_launch_step_impl<TT, TR, KV>(const DevModel<TT> *, const DevModel<TT> &, const TdsLds &, int,       \
                                                 const TR *, TR *, const TR *, TR *, TR *, TT *, int, hipStream_t,     \
-                                                const TdsStepCtl &, long long *);                                      \
+                                                const TdsStepCtl &, long long *, bool);                                \
   template int tds_kernel_max_dynamic_lds_impl<TT, TR, KV>(int, int, int);
 #if !defined(TDS_ONLY_KIND)
 #define TDS_ALL_KINDS 1
@@ -2299,7 +2486,7 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
 #define TDS_INSTANTIATE_KINDS(TT, TR) TDS_INSTANTIATE_K0(TT, TR) TDS_INSTANTIATE_K1(TT, TR) TDS_INSTANTIATE_K2(TT, TR)
 #if defined(TDS_ONLY_F64)
 #if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
-template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int);
+template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int, bool);
 #endif
 TDS_INSTANTIATE_KINDS(double, double)
 #endif
@@ -2308,7 +2495,7 @@ TDS_INSTANTIATE_KINDS(double, float)
 #endif
 #if defined(TDS_ONLY_F32)
 #if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
-template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int, int);
+template TdsLds tds_make_lds_layout<float>(const DevModel<float> &, int, int, bool);
 #endif
 TDS_INSTANTIATE_KINDS(float, float)
 #endif
