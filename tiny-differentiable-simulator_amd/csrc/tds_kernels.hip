@@ -687,7 +687,8 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
 // disjoint here (their lifetimes now overlap), which costs LDS and is why this form is launched only while the whole
 // grid fits the GPU at once (tds_launch_step_impl).
 template <typename T, typename TR, int G, int NDP, bool PROF, int LP, int KIND, bool W2 = false>
-__global__ __launch_bounds__(W2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu((LP == 2 || W2) ? 2 : 1)))
+__global__ __launch_bounds__(W2 ? 128 : 64)
+__attribute__((amdgpu_waves_per_eu((LP == 2 || W2) ? 2 : 1)))
 void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const TR *x_in, TR *__restrict__ y_out,
                                                       const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
@@ -959,17 +960,23 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
             lk = mdl->cp_link[k];
             lk_anc = mdl->anc_dofs[lk >= 0 ? lk : 0];
           }
+          // (the link's record is read unconditionally — index clamped — and a geometry of the BASE takes the base
+          //  frame as values afterwards: written as "LDS record or model constant" in two branches, the compiler folds
+          //  the two into one FLAT load through a selected pointer — 24 of them on the hot path)
           T Rl[9], pl[3];
-          if (lk >= 0) {
-  #pragma unroll
-            for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
-  #pragma unroll
-            for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
-          } else {
-  #pragma unroll
-            for (int c = 0; c < 9; ++c) Rl[c] = mdl->base_R[c];
-  #pragma unroll
-            for (int c = 0; c < 3; ++c) pl[c] = mdl->base_t[c];
+          {
+            const int lkc = lk >= 0 ? lk : 0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Rl[c] = Xw[lkc * TDS_S1 + c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pl[c] = Xw[lkc * TDS_S1 + 9 + c];
+            if (__any(lk < 0)) {  // wave-uniform, rare: a geometry on the base link
+              const bool on_base = lk < 0;
+#pragma unroll
+              for (int c = 0; c < 9; ++c) Rl[c] = on_base ? mdl->base_R[c] : Rl[c];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) pl[c] = on_base ? mdl->base_t[c] : pl[c];
+            }
           }
           T loc[3] = {pf_cp_loc[0], pf_cp_loc[1], pf_cp_loc[2]};
           T rad = pf_cp_rad;
@@ -1032,18 +1039,18 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           int lk = pf_vis_link;
           if (!first) lk = mdl->vis_link[k];
           T Rl[9], pl[3], Rv[9], pv[3];
-    #pragma unroll
+#pragma unroll
           for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
-    #pragma unroll
+#pragma unroll
           for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
-    #pragma unroll
+#pragma unroll
           for (int c = 0; c < 9; ++c) Rv[c] = pf_vis_X[c];
-    #pragma unroll
+#pragma unroll
           for (int c = 0; c < 3; ++c) pv[c] = pf_vis_X[9 + c];
           if (!first) {
-    #pragma unroll
+#pragma unroll
             for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
-    #pragma unroll
+#pragma unroll
             for (int c = 0; c < 3; ++c) pv[c] = mdl->vis_X[9 + c][k];
           }
           T Ro[9], po[3], qo[4];
@@ -2177,15 +2184,33 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     // straight-line build: exactly one normal step, no reset -> the environment is finished here;
     // observation (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288) and resident state go
     // out straight from registers
-    bool from_pool = false;
-    if (ctl.pool != nullptr) {  // wave-uniform (kernel argument)
+    auto write_state = [&]() {
+      if (live && gen) {
+        for (int i = lane; i < nq + nd; i += G) {
+          if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = (TR)(i < 2 ? T(0) : xr[i]);
+          if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = (TR)xr[i];
+        }
+      } else if (live && di >= 0) {
+        if (obs_out != nullptr) {
+          TR *const ob = obs_out + (size_t)env * (nq + nd + 2);
+          ob[di] = (TR)(di < 2 ? T(0) : q_new);
+          ob[nq + di] = (TR)qd_new;
+        }
+        if (x_feedback != nullptr) {
+          x_feedback[(size_t)env * in_dim + di] = (TR)q_new;
+          x_feedback[(size_t)env * in_dim + nq + di] = (TR)qd_new;
+        }
+      }
+    };
+    if (ctl.pool == nullptr) {  // wave-uniform (kernel argument): the ordinary step — nothing of the pool on its path
+      write_state();
+    } else {
       // auto_reset_when_done (ars_vectorized_environment.h:262-277) without leaving the straight-line kernel: the
       // reset state of (seed, environment, reset count) — re-initialised AND settled — was computed ahead of time
       // into the environment's pool ring (tds_api.hip: reset pool); a done environment copies it in.  y, reward and
       // done describe the terminal step, observation and resident state the fresh environment.
       TDS_WAVE_SYNC();  // lane 0's done flag
-      from_pool = live && xr[in_dim + 1] != T(0);
-      if (from_pool) {
+      if (live && xr[in_dim + 1] != T(0)) {
         const unsigned c = ctl.reset_count[env];
         const TR *const src = (const TR *)ctl.pool + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
         for (int i = lane; i < nq + nd; i += G) {
@@ -2195,23 +2220,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) ctl.reset_count[env] = c + 1u;
-      }
-    }
-    if (from_pool) {
-    } else if (live && gen) {
-      for (int i = lane; i < nq + nd; i += G) {
-        if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = (TR)(i < 2 ? T(0) : xr[i]);
-        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = (TR)xr[i];
-      }
-    } else if (live && di >= 0) {
-      if (obs_out != nullptr) {
-        TR *const ob = obs_out + (size_t)env * (nq + nd + 2);
-        ob[di] = (TR)(di < 2 ? T(0) : q_new);
-        ob[nq + di] = (TR)qd_new;
-      }
-      if (x_feedback != nullptr) {
-        x_feedback[(size_t)env * in_dim + di] = (TR)q_new;
-        x_feedback[(size_t)env * in_dim + nq + di] = (TR)qd_new;
+      } else {
+        write_state();
       }
     }
   } else {

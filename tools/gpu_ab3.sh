@@ -1,0 +1,13 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out/ab3
+for rep in 1 2; do
+for n in 4096 8192; do
+  for t in r1 s1 s2; do
+    (cd ab_$t && TDS_HIP_W2=0 timeout 300 python bench.py --no-cpu-baseline --envs-per-gpu $n 2>/dev/null | tail -1 > ../gpurun_out/ab3/${t}_ant${n}_$rep.json)
+  done
+  TDS_HIP_W2=0 timeout 300 python bench.py --no-cpu-baseline --envs-per-gpu $n 2>/dev/null | tail -1 > gpurun_out/ab3/cur_ant${n}_$rep.json
+done
+done
+for f in gpurun_out/ab3/*.json; do echo "$f: $(python -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('%.4g'%d['value'], '%.3f us'%(d['roofline']['kernel_ms_avg']*1e3))" 2>&1 | tail -1)"; done

@@ -15,12 +15,17 @@ for d in sys.argv[1:]:
         for row in csv.DictReader(open(f)):
             if "tds_step_kernel" not in row["Kernel_Name"]:
                 continue
+            kname = row["Kernel_Name"]
             per[row["Dispatch_Id"]][row["Counter_Name"]] += float(row["Counter_Value"])
             grid = (row.get("Grid_Size"), row.get("Workgroup_Size"), row.get("LDS_Block_Size"))
         for disp in per.values():
             for k, v in disp.items():
                 acc[k].append(v)
 print(f"# mean per dispatch of tds_step_kernel (grid, wg, lds) = {grid}")
+try:
+    print(f"# kernel: {kname[:160]}")
+except NameError:
+    pass
 waves = None
 if "SQ_WAVES" in acc:
     waves = sum(acc["SQ_WAVES"]) / len(acc["SQ_WAVES"])

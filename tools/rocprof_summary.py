@@ -14,5 +14,10 @@ row = db.execute("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr
                  "min(duration), avg(duration), max(duration), count(*) from kernels where name like '%tds_step_kernel%' "
                  "group by name, grid_x").fetchall()
 for r in row:
-    print(f"\n# {r[0][:120]}\n#   grid={r[1]} wg={r[2]} lds_bytes/wg={r[3]} scratch={r[4]} vgpr={r[5]} agpr={r[6]} sgpr={r[7]}"
+    # vgpr_count as rocprofv3 records it is the ALLOCATION in granules of this dispatch (wave64 on the unified 512-entry
+    # file: half the per-lane register count), not the compiler's VGPR count: 120 <-> 240 allocated.  The compiler's
+    # numbers (VGPR / AGPR / scratch / occupancy per instantiation) are in profiles/*kernel_resources*.txt
+    # (tools/kernel_resources.sh, -Rpass-analysis=kernel-resource-usage).
+    print(f"\n# {r[0][:150]}\n#   grid={r[1]} wg={r[2]} lds_bytes/wg={r[3]} scratch={r[4]} "
+          f"rocprof_vgpr_field={r[5]} (x2 = allocated registers per lane) rocprof_agpr_field={r[6]} sgpr={r[7]}"
           f"\n#   duration ns: min={r[8]} avg={r[9]:.0f} max={r[10]} over {r[11]} dispatches")
