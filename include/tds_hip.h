@@ -317,6 +317,20 @@ int tds_hip_reset(tds_hip_sim_t *sim, const unsigned char *mask_dev, void *obs_d
 int tds_hip_rollout(tds_hip_sim_t *sim, const void *policy_dev, int n_steps, double shift, int flags,
                     void *return_sum_dev, int *return_steps_dev, void *obs_dev);
 
+/* tds_hip_rollout plus the by-products Worker::rollouts produces alongside the returns
+   (examples/ars/ars_vectorized_worker.h:88-135), each optional (NULL):
+     stats_dev     [num_envs][obs_dim][3] record dtype, UPDATED in place (zero it for a fresh filter): RunningStat
+                   (examples/ars/running_stat.h, Knuth's recurrence) of every observation component the policy was
+                   evaluated on — (count, mean, S); variance = S / (count - 1).  Pushed every step, done or not.
+     traj_dev      [num_envs][n_steps][output_dim] record dtype + traj_len_dev [num_envs] int: per environment the y
+                   record (sim_states_with_graphics_) of every step taken while not done; a step that ends with done
+                   repeats the previous entry if there is one — the trajectories vector of Worker::rollouts.
+   Asking for either selects the per-step-launch form of the rollout (the bookkeeping kernel between the step
+   launches produces them); auto-reset then goes through the reset pool. */
+int tds_hip_rollout_ex(tds_hip_sim_t *sim, const void *policy_dev, int n_steps, double shift, int flags,
+                       void *return_sum_dev, int *return_steps_dev, void *obs_dev, void *stats_dev, void *traj_dev,
+                       int *traj_len_dev);
+
 /* Blocking convenience with HOST buffers in double, any N <= num_envs:
    H2D(x) -> kernel -> D2H(y), i.e. exactly what the reference's <model>_forward_zero does. */
 int tds_hip_forward_zero_host(tds_hip_sim_t *sim, int n, const double *x_host, double *y_host);

@@ -241,9 +241,15 @@ def rollout_fixture(name, n=24, steps=25, shift=0.5, seed=77):
         steps = 12
     params = rng.normal(0.0, 0.02 if name == "humanoid" else 0.05, (n, adim * od + adim))
     tot, cnt, fin = reflib.rollout(name, x[:, :od], params, steps, shift)
+    out = dict(x0=x, params=params, steps=np.int32(steps), shift=np.float64(shift), total_rewards=tot,
+               vec_steps=cnt, final_obs=fin)
+    if name in ("ant", "laikago"):
+        # by-products of Worker::rollouts: RunningStat of the observations, trajectories (first 6 environments kept)
+        tot2, cnt2, fin2, stats, traj, tlen = reflib.rollout_ex(name, x[:, :od], params, steps, shift, m.output_dim)
+        assert np.array_equal(tot2, tot) and np.array_equal(cnt2, cnt)
+        out.update(obs_stats=stats, traj=traj[:6], traj_len=tlen)
     r.close()
-    return dict(x0=x, params=params, steps=np.int32(steps), shift=np.float64(shift), total_rewards=tot,
-                vec_steps=cnt, final_obs=fin)
+    return out
 
 
 def vecenv_fixture(name, n=12, steps=60, seed=91):

@@ -29,6 +29,7 @@ typedef TinyAlgebra<double, ::TINY::DoubleUtils> Alg;
 #include "dynamics/mass_matrix.hpp"
 #include "dynamics/jacobian.hpp"
 #include "../ars/ars_vectorized_environment.h"
+#include "../ars/running_stat.h"
 
 #include "tds_hip.h"
 #include "tds_hip_stepper.hpp"
@@ -380,9 +381,13 @@ int tdsref_hipstepper_selftest_devices(int batch, int steps, int n_devices, cons
 //   x0 [batch][dof_q + dof_qd], params [batch][action_dim*obs_dim + action_dim],
 //   total_rewards [batch], vec_steps [batch], final_obs [batch][obs_dim]
 extern "C++" {
+// stats (optional) [batch][obs_dim][3] = (NumDataValues, Mean, S = Variance * (n - 1)) of the reference's RunningStat
+// pushed exactly where Worker::rollouts pushes it (ars_vectorized_worker.h:88-110); traj (optional)
+// [batch][steps][output_dim] + traj_len [batch]: the trajectories vector of Worker::rollouts (:118-135)
 template <typename Sim, typename Env>
 static int ref_rollout(int batch, int steps, double shift, const double *x0, const double *params,
-                       double *total_rewards, int *vec_steps, double *final_obs) {
+                       double *total_rewards, int *vec_steps, double *final_obs, double *stats = nullptr,
+                       double *traj = nullptr, int *traj_len = nullptr) {
   typedef VectorizedEnvironment<Alg, Sim> VecEnv;
   Env env(false);
   VecEnv vec_env(env.contact_sim, batch);
@@ -404,20 +409,61 @@ static int ref_rollout(int batch, int steps, double shift, const double *x0, con
   std::vector<double> rewards(batch);
   std::vector<bool> dones(batch, false);
   std::vector<std::vector<double>> actions(batch);
+  std::vector<std::vector<RunningStat>> filters(batch, std::vector<RunningStat>(od));
+  std::vector<std::vector<std::vector<double>>> trajectories(batch);
+  const int out = env.contact_sim.output_dim();
   for (int r = 0; r < steps; ++r) {
     for (int e = 0; e < batch; ++e) actions[e] = vec_env.policy(e, observations[e]);
-    vec_env.step(actions, observations, rewards, dones, config);
     for (int e = 0; e < batch; ++e)
-      if (!dones[e]) {
+      for (int o = 0; o < od; ++o) filters[e][o].Push(observations[e][o]);
+    vec_env.step(actions, observations, rewards, dones, config);
+    for (int e = 0; e < batch; ++e) {
+      if (dones[e]) {
+        const int sz = (int)trajectories[e].size();
+        if (sz) {
+          const auto prev = trajectories[e][sz - 1];
+          trajectories[e].push_back(prev);
+        }
+      } else {
+        trajectories[e].push_back(vec_env.sim_states_with_graphics_[e]);
         total_rewards[e] += rewards[e] - shift;
         vec_steps[e]++;
       }
+    }
   }
+  if (stats)
+    for (int e = 0; e < batch; ++e)
+      for (int o = 0; o < od; ++o) {
+        double *st = stats + ((size_t)e * od + o) * 3;
+        const int nn = filters[e][o].NumDataValues();
+        st[0] = nn;
+        st[1] = filters[e][o].Mean();
+        st[2] = filters[e][o].Variance() * (nn > 1 ? nn - 1 : 0);
+      }
+  if (traj && traj_len)
+    for (int e = 0; e < batch; ++e) {
+      traj_len[e] = (int)trajectories[e].size();
+      for (int t = 0; t < traj_len[e]; ++t)
+        for (int k = 0; k < out; ++k) traj[((size_t)e * steps + t) * out + k] = trajectories[e][t][k];
+    }
   for (int e = 0; e < batch; ++e)
     for (int k = 0; k < od; ++k) final_obs[(size_t)e * od + k] = observations[e][k];
   return 0;
 }
 }  // extern "C++"
+
+int tdsref_rollout_ex(const char *name, int batch, int steps, double shift, const double *x0, const double *params,
+                      double *total_rewards, int *vec_steps, double *final_obs, double *stats, double *traj,
+                      int *traj_len) {
+  const std::string n(name);
+  if (n == "ant")
+    return ref_rollout<AntContactSimulation2<Alg>, AntEnv2<Alg>>(batch, steps, shift, x0, params, total_rewards,
+                                                                 vec_steps, final_obs, stats, traj, traj_len);
+  if (n == "laikago")
+    return ref_rollout<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, shift, x0, params, total_rewards,
+                                                                       vec_steps, final_obs, stats, traj, traj_len);
+  return -1;
+}
 
 int tdsref_rollout(const char *name, int batch, int steps, double shift, const double *x0, const double *params,
                    double *total_rewards, int *vec_steps, double *final_obs) {

@@ -51,6 +51,8 @@ def lib():
         if hasattr(L, "tdsref_rollout"):
             L.tdsref_rollout.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "tdsref_rollout_ex"):
+            L.tdsref_rollout_ex.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 8
         if hasattr(L, "tdsref_hipstepper_selftest_devices"):
             L.tdsref_hipstepper_selftest_devices.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p,
                                                              C.c_char_p, C.c_int]
@@ -268,3 +270,32 @@ def vecenv_steps(name, x0, actions, output_dim):
         os.close(devnull)
     assert rc == 0, rc
     return obs, rew, done, vis
+
+
+def rollout_ex(name, x0, params, steps, shift, output_dim):
+    """reflib.rollout plus the by-products of Worker::rollouts: RunningStat (count, mean, S) per environment and
+    observation component [B, obs_dim, 3], trajectories [B, steps, output_dim] and their lengths [B]."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    b, od = x0.shape
+    tot = np.zeros(b)
+    cnt = np.zeros(b, dtype=np.int32)
+    fin = np.zeros((b, od))
+    stats = np.zeros((b, od, 3))
+    traj = np.zeros((b, steps, output_dim))
+    tlen = np.zeros(b, dtype=np.int32)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    try:
+        rc = lib().tdsref_rollout_ex(name.encode(), b, steps, float(shift), x0.ctypes.data, params.ctypes.data,
+                                     tot.ctypes.data, cnt.ctypes.data, fin.ctypes.data, stats.ctypes.data,
+                                     traj.ctypes.data, tlen.ctypes.data)
+        C.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
+    assert rc == 0, rc
+    return tot, cnt, fin, stats, traj, tlen

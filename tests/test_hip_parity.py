@@ -577,6 +577,42 @@ def test_rollout_matches_reference_worker_loop(name, mode, built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ant", "laikago"])
+def test_rollout_by_products_match_the_reference_worker(name, built):
+    """tds_hip_rollout_ex: the running statistics of the observations and the trajectory records that
+    Worker::rollouts produces alongside the returns (ars_vectorized_worker.h:88-135, running_stat.h) — against the
+    fixture generated from the reference's own loop with its own RunningStat (oracle/ref_harness.cpp: ref_rollout)."""
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + "_rollout.npz"))
+    x, params, steps, shift = g["x0"], g["params"], int(g["steps"]), float(g["shift"])
+    n, od = x.shape[0], m.dof_q + m.dof_qd
+    sim = hip_backend.HipSim(m, n)
+    sim.x.copy_(torch.from_numpy(x).cuda())
+    stats = torch.zeros((n, od, 3), dtype=torch.float64, device="cuda")
+    ret, cnt, traj, tlen = sim.rollout_ex(torch.from_numpy(params).cuda(), steps, shift, first_obs_raw=True,
+                                          stats=stats, want_traj=True)
+    assert np.array_equal(cnt.cpu().numpy(), g["vec_steps"])
+    assert rel_err(ret.cpu().numpy(), g["total_rewards"], 1e-3) < 1e-6
+    st, st_ref = stats.cpu().numpy(), g["obs_stats"]
+    assert np.array_equal(st[:, :, 0], st_ref[:, :, 0]) and (st[:, :, 0] == steps).all()   # pushed every step, done or not
+    calm = np.abs(st_ref[:, :, 1:]).max(axis=(1, 2)) < 1e6  # (a fallen Laikago's blow-up is not a parity question)
+    assert calm.sum() >= n - 4
+    assert rel_err(st[calm][:, :, 1], st_ref[calm][:, :, 1], 1e-3) < 1e-6        # means
+    assert rel_err(st[calm][:, :, 2], st_ref[calm][:, :, 2], 1e-2) < 1e-5        # S = variance (count - 1)
+    tl, tl_ref = tlen.cpu().numpy(), g["traj_len"]
+    assert np.array_equal(tl, tl_ref)
+    tr, tr_ref = traj.cpu().numpy(), g["traj"]
+    for e in range(tr_ref.shape[0]):
+        if tl[e] > 0:   # (done from the first step on: nothing is ever recorded)
+            assert rel_err(tr[e, :tl[e]], tr_ref[e, :tl[e]]) < 1e-6, e
+    # a second call keeps accumulating into the same statistics (the filter persists across rollouts)
+    sim.x.copy_(torch.from_numpy(x).cuda())
+    sim.rollout_ex(torch.from_numpy(params).cuda(), steps, shift, first_obs_raw=True, stats=stats)
+    assert (stats[:, :, 0] == 2 * steps).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("split", ["0", "1", "2"])
 def test_rollout_equals_stepwise_launches_with_auto_reset(split, built, monkeypatch):
     """the same rollout driven step by step from the host (policy in numpy, one launch per step,

@@ -834,31 +834,78 @@ namespace {
 // environment's own linear policy on the new state (VectorizedEnvironment::policy -> NeuralNetwork::compute:
 // one linear layer with bias, identity; obs = [q | qd] with obs[0] = obs[1] = 0,
 // ars_vectorized_environment.h:165-180,283-300).
+// The by-products of Worker::rollouts (examples/ars/ars_vectorized_worker.h:88-135), optional:
+//   stats  [n][od][3] = (count, mean, S) of RunningStat (running_stat.h: Knuth's recurrence) per environment and
+//          observation component, pushed with the observation the policy is evaluated on, every step, done or not
+//          (:88-110; the filter the reference then applies to its local copy never reaches anything);
+//   traj   [n][traj_cap][out_dim] + traj_len [n]: per environment the y record (sim_states_with_graphics_) of every
+//          step taken while not done; a step that ends with done repeats the previous entry, if there is one (:118-135).
+template <typename T>
+struct TdsRolloutExtras {
+  T *stats;
+  T *traj;
+  int *traj_len;
+  const T *y;
+  int out_dim, traj_cap;
+};
+
 template <typename T>
 __global__ void tds_policy_book_kernel(const T *__restrict__ x, int in_dim, int od, int adim,
                                        const T *__restrict__ policy, T *__restrict__ actions,
                                        T *__restrict__ rec, T *__restrict__ ret, int *__restrict__ cnt,
                                        unsigned char *__restrict__ frozen, T shift, int do_book, int do_policy,
-                                       int raw_xy, int n) {
+                                       int raw_xy, int auto_reset, TdsRolloutExtras<T> ex, int n) {
   // one wavefront per environment; L = 2^k lanes per action, consecutive lanes on consecutive weights
   const int env = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
   const int lane = threadIdx.x & 63;
   if (env >= n) return;
-  if (do_book && lane == 0) {
+  if (do_book) {
+    // (all lanes evaluate the flags; lane 0 writes them)
     bool fr = frozen[env] != 0;
-    if (!fr) {
-      const T reward = rec[(size_t)env * (od + 2) + od];
-      if (rec[(size_t)env * (od + 2) + od + 1] != T(0)) {
-        frozen[env] = 1;
-        fr = true;
-      } else {
+    const bool done_now = rec[(size_t)env * (od + 2) + od + 1] != T(0);
+    const T reward = rec[(size_t)env * (od + 2) + od];
+    const bool count_it = !fr && !done_now;
+    if (!fr && done_now && !auto_reset) fr = true;  // without auto-reset the environment stays done
+    if (ex.traj != nullptr) {
+      const int len = ex.traj_len[env];
+      if (len < ex.traj_cap) {
+        T *const dst = ex.traj + ((size_t)env * ex.traj_cap + len) * ex.out_dim;
+        if (!(done_now || fr)) {
+          for (int i = lane; i < ex.out_dim; i += 64) dst[i] = ex.y[(size_t)env * ex.out_dim + i];
+          if (lane == 0) ex.traj_len[env] = len + 1;
+        } else if (len > 0) {
+          for (int i = lane; i < ex.out_dim; i += 64) dst[i] = dst[i - ex.out_dim];
+          if (lane == 0) ex.traj_len[env] = len + 1;
+        }
+      }
+    }
+    if (lane == 0) {
+      if (count_it) {
         ret[env] += reward - shift;
         cnt[env] += 1;
       }
+      frozen[env] = fr ? 1 : 0;
+      // after the last step the record's done column is the latch ("was done at some step"), as the one-launch
+      // rollout leaves it
+      if (!do_policy && !auto_reset) rec[(size_t)env * (od + 2) + od + 1] = fr ? T(1) : T(0);
     }
-    // after the last step the record's done column is the latch ("was done at some step"), as the one-launch
-    // rollout leaves it
-    if (!do_policy) rec[(size_t)env * (od + 2) + od + 1] = fr ? T(1) : T(0);
+  }
+  if (do_policy && ex.stats != nullptr) {
+    for (int o = lane; o < od; o += 64) {
+      const T xo = (o < 2 && !raw_xy) ? T(0) : x[(size_t)env * in_dim + o];
+      T *const st = ex.stats + ((size_t)env * od + o) * 3;
+      const T nn = st[0] + T(1);
+      if (nn == T(1)) {
+        st[1] = xo;
+        st[2] = T(0);
+      } else {
+        const T m_old = st[1];
+        const T m_new = m_old + (xo - m_old) / nn;
+        st[2] = st[2] + (xo - m_old) * (xo - m_new);
+        st[1] = m_new;
+      }
+      st[0] = nn;
+    }
   }
   if (do_policy) {
     int L = 64;
@@ -879,7 +926,8 @@ __global__ void tds_policy_book_kernel(const T *__restrict__ x, int in_dim, int 
 
 template <typename T>
 int rollout_per_step(tds_hip_sim *s, const void *policy_dev, int n_steps, double shift, int flags,
-                     void *return_sum_dev, int *return_steps_dev, void *obs_dev) {
+                     void *return_sum_dev, int *return_steps_dev, void *obs_dev, void *stats_dev, void *traj_dev,
+                     int *traj_len_dev) {
   const int n = s->num_envs, adim = s->model.action_dim, od = s->model.dof_q + s->model.dof_qd;
   const size_t b_act = align256((size_t)n * adim * sizeof(T));
   const size_t b_rec = align256((size_t)n * (od + 2) * sizeof(T));
@@ -895,14 +943,25 @@ int rollout_per_step(tds_hip_sim *s, const void *policy_dev, int n_steps, double
       hipMemsetAsync(cnt, 0, (size_t)n * sizeof(int), s->stream) != hipSuccess ||
       hipMemsetAsync(frozen, 0, (size_t)n, s->stream) != hipSuccess)
     return fail(TDS_ERR_HIP, "hipMemsetAsync (rollout scratch)");
+  TdsRolloutExtras<T> ex;
+  ex.stats = (T *)stats_dev;
+  ex.traj = (T *)traj_dev;
+  ex.traj_len = traj_len_dev;
+  ex.y = (const T *)s->d_y;
+  ex.out_dim = s->model.output_dim;
+  ex.traj_cap = n_steps;
+  if (traj_dev && (!traj_len_dev || hipMemsetAsync(traj_len_dev, 0, (size_t)n * sizeof(int), s->stream) != hipSuccess))
+    return fail(TDS_ERR_INVALID_ARG, "trajectories need a traj_len buffer");
   const int threads = 256, blocks = (n + threads / 64 - 1) / (threads / 64);
   for (int t = 0; t <= n_steps; ++t) {
     hipLaunchKernelGGL(tds_policy_book_kernel<T>, dim3(blocks), dim3(threads), 0, s->stream, (const T *)s->d_x,
                        s->model.input_dim, od, adim, (const T *)policy_dev, actions, rec, ret, cnt, frozen,
-                       (T)shift, t > 0 ? 1 : 0, t < n_steps ? 1 : 0, ((flags & 1) && t == 0) ? 1 : 0, n);
+                       (T)shift, t > 0 ? 1 : 0, t < n_steps ? 1 : 0, ((flags & 1) && t == 0) ? 1 : 0,
+                       s->auto_reset ? 1 : 0, ex, n);
     if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "policy kernel launch");
     if (t == n_steps) break;
-    const int rc = launch(s, s->d_x, s->d_y, actions, s->d_x, rec, n, 1, TDS_RESET_NONE, nullptr);
+    // (plain straight-line step, or — with auto-reset — the step through the reset pool)
+    const int rc = step_obs_impl(s, actions, 1, rec);
     if (rc != TDS_OK) return rc;
   }
   return TDS_OK;
@@ -911,8 +970,9 @@ int rollout_per_step(tds_hip_sim *s, const void *policy_dev, int n_steps, double
 }  // namespace
 }  // extern "C++"
 
-int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, double shift, int flags,
-                    void *return_sum_dev, int *return_steps_dev, void *obs_dev) {
+int tds_hip_rollout_ex(tds_hip_sim_t *s, const void *policy_dev, int n_steps, double shift, int flags,
+                       void *return_sum_dev, int *return_steps_dev, void *obs_dev, void *stats_dev, void *traj_dev,
+                       int *traj_len_dev) {
   if (!s || !policy_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (n_steps < 1) return fail(TDS_ERR_INVALID_ARG, "n_steps < 1");
   if (s->model.action_dim < 1) return fail(TDS_ERR_INVALID_ARG, "model has no actions");
@@ -920,13 +980,17 @@ int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, doubl
   TimedCall timed(s);
   // One launch for the whole rollout: the step-loop build, compiled for one or for two wavefronts per SIMD (the
   // launcher picks by grid size) — faster than per-step launches at every batch size measured
-  // (profiles/r02_rollout_modes.txt).  flags bit 1 forces the other form: one straight-line step launch per step
-  // with a small policy + bookkeeping kernel in between (no auto-reset there).
-  const bool per_step = !s->auto_reset && (flags & 2) != 0;
+  // (profiles/r02a_rollout_modes.txt).  flags bit 1 forces the other form: one straight-line step launch per step
+  // with a small policy + bookkeeping kernel in between; the by-products of Worker::rollouts (running statistics of
+  // the observations, trajectory records) are produced by that bookkeeping kernel, so asking for them selects it.
+  const bool extras = stats_dev != nullptr || traj_dev != nullptr;
+  const bool per_step = extras || (!s->auto_reset && (flags & 2) != 0);
   if (per_step)
     return s->records_f64()
-               ? rollout_per_step<double>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev)
-               : rollout_per_step<float>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev);
+               ? rollout_per_step<double>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev,
+                                          stats_dev, traj_dev, traj_len_dev)
+               : rollout_per_step<float>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev,
+                                         stats_dev, traj_dev, traj_len_dev);
   Rollout ro;
   ro.policy = policy_dev;
   ro.ret_sum = return_sum_dev;
@@ -936,6 +1000,12 @@ int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, doubl
   if (s->auto_reset) s->pool_ready = false;
   return launch(s, s->d_x, s->d_y, nullptr, s->d_x, obs_dev, s->num_envs, n_steps,
                 s->auto_reset ? TDS_RESET_AUTO : TDS_RESET_NONE, nullptr, &ro);
+}
+
+int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, double shift, int flags,
+                    void *return_sum_dev, int *return_steps_dev, void *obs_dev) {
+  return tds_hip_rollout_ex(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev, nullptr,
+                            nullptr, nullptr);
 }
 
 int tds_hip_send_local(tds_hip_sim_t *s, int n, const double *x_host) {

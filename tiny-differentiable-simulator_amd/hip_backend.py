@@ -59,6 +59,7 @@ def lib():
         L.tds_hip_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
         L.tds_hip_forward_zero_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.tds_hip_rollout_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int] + [C.c_void_p] * 6
         L.tds_rb_last_error.restype = C.c_char_p
         L.tds_rb_create.argtypes = [C.POINTER(_model.RbModel), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.tds_rb_destroy.argtypes = [C.c_void_p]
@@ -104,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_input_dim", "tds_hip_output_dim", "tds_hip_dtype", "tds_hip_x_device",
     "tds_hip_y_device", "tds_hip_set_inputs", "tds_hip_get_inputs", "tds_hip_get_outputs",
     "tds_hip_forward_zero_device", "tds_hip_step", "tds_hip_step_obs", "tds_hip_obs_dim",
-    "tds_hip_set_auto_reset", "tds_hip_reset", "tds_hip_rollout",
+    "tds_hip_set_auto_reset", "tds_hip_reset", "tds_hip_rollout", "tds_hip_rollout_ex",
     "tds_hip_forward_zero_host", "tds_hip_send_local", "tds_hip_forward_zero_fetch",
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
     "tds_hip_device", "tds_hip_record_bytes", "tds_hip_sync", "tds_hip_forward_zero_host_begin",
@@ -315,6 +316,33 @@ class HipSim:
             assert tuple(obs.shape) == (self.num_envs, self.obs_dim + 2)
             op = C.c_void_p(obs.data_ptr())
         _check(lib().tds_hip_reset(self.h, mp, op))
+
+    def rollout_ex(self, policy, n_steps: int, shift: float = 0.0, first_obs_raw: bool = False, stats=None,
+                   want_traj: bool = False):
+        """rollout + the by-products of Worker::rollouts (tds_hip_rollout_ex): ``stats`` [N, obs_dim, 3] device tensor
+        of (count, mean, S) updated in place (None: skipped), trajectories [N, n_steps, output_dim] + lengths [N]
+        when ``want_traj``.  Returns (return_sum, steps, traj, traj_len)."""
+        import torch
+
+        adim, od = self.model.action_dim, self.obs_dim
+        assert policy.is_cuda and policy.dtype == self.torch_dtype and policy.is_contiguous()
+        ret = torch.zeros(self.num_envs, dtype=self.torch_dtype, device=policy.device)
+        steps = torch.zeros(self.num_envs, dtype=torch.int32, device=policy.device)
+        sp = None
+        if stats is not None:
+            assert stats.is_cuda and stats.dtype == self.torch_dtype and stats.is_contiguous()
+            assert tuple(stats.shape) == (self.num_envs, od, 3)
+            sp = C.c_void_p(stats.data_ptr())
+        traj = tlen = None
+        tp = lp = None
+        if want_traj:
+            traj = torch.zeros((self.num_envs, n_steps, self.output_dim), dtype=self.torch_dtype, device=policy.device)
+            tlen = torch.zeros(self.num_envs, dtype=torch.int32, device=policy.device)
+            tp, lp = C.c_void_p(traj.data_ptr()), C.c_void_p(tlen.data_ptr())
+        _check(lib().tds_hip_rollout_ex(self.h, C.c_void_p(policy.data_ptr()), int(n_steps), C.c_double(shift),
+                                        1 if first_obs_raw else 0, C.c_void_p(ret.data_ptr()),
+                                        C.c_void_p(steps.data_ptr()), None, sp, tp, lp))
+        return ret, steps, traj, tlen
 
     def rollout(self, policy, n_steps: int, shift: float = 0.0, first_obs_raw: bool = False, obs=None, mode=None):
         """n_steps of { action = W obs + b (per-environment linear policy); step; reward/done } on device
