@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TDS_HIP_ABI_VERSION 2
+#define TDS_HIP_ABI_VERSION 3
 
 #define TDS_MAX_LINKS 64   /* links of the model as the reference builds it; the kernels take <= 32 lanes: one per
                               moving link (fixed links are folded into their parents when lanes run short), six for
@@ -46,6 +46,9 @@ extern "C" {
 #define TDS_MAX_DOF 32
 /* contact points per environment: sphere 1, capsule 2, box 8 (contact_point.hpp:96-198) */
 #define TDS_MAX_CONTACTS 64
+/* contact points between the geometries of TWO articulated bodies of a world (sphere-sphere 1, capsule-sphere 2:
+   contact_point.hpp:43-94, 405-438), per environment */
+#define TDS_MAX_PAIR_CONTACTS 64
 
 /* status codes returned by every tds_hip_* function */
 enum {
@@ -133,7 +136,8 @@ typedef struct tds_link {
 } tds_link_t;
 
 typedef struct tds_geom {
-  int32_t link; /* owning link, -1 = base */
+  int32_t link; /* owning link (index into tds_model_t::links, i.e. global over both bodies of a two-body world);
+                   -1 = base of body A, -2 = base of body B */
   int32_t type; /* TDS_GEOM_SPHERE / CAPSULE / BOX */
   double radius;
   double length;     /* capsule */
@@ -195,6 +199,21 @@ typedef struct tds_model {
   double base_mass;
   double base_com[3];
   double base_inertia[9];
+  /* Worlds with TWO articulated bodies (World::step over multi_bodies_ = [plane,] A, B:
+     src/world.hpp:206-282, 293-366).  num_bodies = 2: links [0, body1_first_link) are body A, the rest body B
+     (parent -1 = the own body's base; q / qd indices dense over both: q = [q_A | q_B], qd = [qd_A | qd_B], in TAU
+     mode x = [q | qd | tau_A | tau_B]); geoms [0, body1_first_geom) belong to A, the rest to B, in the reference's
+     order (base first, then link by link).  Each body is stepped by its own forward dynamics; contacts: each body
+     against the plane (if any), then A against B — sphere-sphere and capsule-sphere in either order, as the
+     reference's dispatcher knows them — solved pair by pair in the reference's order (plane-A, plane-B, A-B) with both
+     Jacobian blocks and both inverse mass matrices (mb_constraint_solver.hpp:191-498).  num_bodies 0 / 1: one body.
+     Fixed bases, 1-dof joints; step_mode TAU. */
+  int32_t num_bodies;
+  int32_t body1_first_link;
+  int32_t body1_first_geom;
+  int32_t pad3_;
+  double body1_base_X_world_rot[9];
+  double body1_base_X_world_trans[3];
   tds_link_t links[TDS_MAX_LINKS];
   tds_geom_t geoms[TDS_MAX_GEOMS];
   tds_visual_t visuals[TDS_MAX_VISUALS];

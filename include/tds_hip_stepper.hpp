@@ -116,6 +116,63 @@ int flatten_multibody(const tds::MultiBody<Algebra> &mb, tds_model_t *out) {
   return 0;
 }
 
+// Body B of a two-body world, appended behind body A (which flatten_multibody put into `out`): links, collision
+// geometry (base geoms: link -2) and visuals with their indices shifted behind A's; q / qd indices dense over both.
+// Fixed bases only.  Returns 0, or a negative code if the blob's capacity is exceeded / the body is unsupported.
+template <typename Algebra>
+int append_second_multibody(const tds::MultiBody<Algebra> &mb, tds_model_t *out) {
+  using namespace detail;
+  if (mb.is_floating() || out->is_floating) return -8;
+  const int l0 = out->num_links, q0 = out->dof_q, d0 = out->dof_qd;
+  const int nl = static_cast<int>(mb.num_links());
+  if (l0 + nl > TDS_MAX_LINKS) return -2;
+  out->num_bodies = 2;
+  out->body1_first_link = l0;
+  out->body1_first_geom = out->num_geoms;
+  copy_mat3<Algebra>(mb.base_X_world().rotation, out->body1_base_X_world_rot);
+  copy_vec3<Algebra>(mb.base_X_world().translation, out->body1_base_X_world_trans);
+  int ng = out->num_geoms, nv = out->num_visuals;
+  for (size_t g = 0; g < mb.collision_geometries(-1).size(); ++g) {
+    if (ng >= TDS_MAX_GEOMS) return -3;
+    fill_geom<Algebra>(mb.collision_geometries(-1)[g], mb.collision_transforms(-1)[g], -2, &out->geoms[ng++]);
+  }
+  for (int i = 0; i < nl; ++i) {
+    const tds::Link<Algebra> &l = mb[i];
+    tds_link_t &L = out->links[l0 + i];
+    memset(&L, 0, sizeof(L));
+    L.joint_type = static_cast<int>(l.joint_type);
+    L.parent = l.parent_index >= 0 ? l0 + l.parent_index : -1;
+    L.q_index = l.q_index >= 0 ? q0 + l.q_index : l.q_index;
+    L.qd_index = l.qd_index >= 0 ? d0 + l.qd_index : l.qd_index;
+    copy_mat3<Algebra>(l.X_T.rotation, L.X_T_rot);
+    copy_vec3<Algebra>(l.X_T.translation, L.X_T_trans);
+    for (int k = 0; k < 6; ++k) L.S[k] = Algebra::to_double(l.S[k]);
+    L.mass = Algebra::to_double(l.rbi.mass);
+    copy_vec3<Algebra>(l.rbi.com, L.com);
+    copy_mat3<Algebra>(l.rbi.inertia, L.inertia);
+    L.stiffness = Algebra::to_double(l.stiffness);
+    L.damping = Algebra::to_double(l.damping);
+    for (size_t g = 0; g < l.collision_geometries.size(); ++g) {
+      if (ng >= TDS_MAX_GEOMS) return -3;
+      fill_geom<Algebra>(l.collision_geometries[g], l.X_collisions[g], l0 + i, &out->geoms[ng++]);
+    }
+    for (size_t v = 0; v < l.X_visuals.size(); ++v) {
+      if (nv >= TDS_MAX_VISUALS) return -4;
+      tds_visual_t &V = out->visuals[nv++];
+      memset(&V, 0, sizeof(V));
+      V.link = l0 + i;
+      copy_mat3<Algebra>(l.X_visuals[v].rotation, V.X_rot);
+      copy_vec3<Algebra>(l.X_visuals[v].translation, V.X_trans);
+    }
+  }
+  out->num_links = l0 + nl;
+  out->dof_q = q0 + mb.dof();
+  out->dof_qd = d0 + mb.dof_qd();
+  out->num_geoms = ng;
+  out->num_visuals = nv;
+  return 0;
+}
+
 // Gravity, contact-solver parameters and default contact material of the World
 // (reference: src/world.hpp:65-71, src/mb_constraint_solver.hpp:59-70).
 template <typename Algebra>

@@ -61,6 +61,12 @@ MODELS = {
                                     springs=[(3, 0.02, 0.001), (0, 3.0, 0.2), (2, 4.0, 0.1)]),
     "pendulum5_spherical_spring": dict(ref="pendulum5spherical.urdf", dt=1e-3,
                                        springs=[(0, 1.5, 0.02), (1, 0.7, 0.0), (2, 0.0, 0.05), (4, 3.0, 0.01)]),
+    # worlds with TWO articulated bodies: contacts between the links of different bodies —
+    # sphere-sphere, capsule-sphere in both argument orders — on top of each body's own dynamics (and plane contacts)
+    "two_pendulums": dict(ref="two:pendulum5.urdf:pendulum5.urdf:0.08:0:0", dt=1e-3),
+    "two_pendulums_plane": dict(ref="two:pendulum5.urdf:pendulum5.urdf:0.08:0:0+plane", dt=1e-3),
+    "two_pendulums_capsule_a": dict(ref="two:pendulum5.urdf:pendulum5.urdf:0.085:0.03:0+capsA", dt=1e-3),
+    "two_pendulums_capsule_b": dict(ref="two:pendulum5.urdf:pendulum5.urdf:0.085:-0.03:0+capsB+plane", dt=1e-3),
 }
 
 
@@ -123,6 +129,17 @@ def random_inputs(name, m, n, rng):
         x[:, nq + nd:nq + nd + m.action_dim] = rng.uniform(-0.6, 0.6, (n, m.action_dim))
         x[:, -3:] = [50, 1.5, 50]
         x[::3, -3:] = [200, 5.0, 20]             # large gains: the clamp to max_force is active
+    elif name.startswith("two_"):
+        # both chains at similar angles (B = A + a little): their spheres / capsules overlap; every fourth state with
+        # independent angles (separated chains).  With the plane (z = 0 through the chains' axes) small angles straddle it.
+        half = nq // 2
+        amp = 0.25 if m.has_plane else 0.9
+        qa = rng.uniform(-amp, amp, (n, half))
+        x[:, :half] = qa
+        x[:, half:nq] = qa + rng.uniform(-0.12, 0.12, (n, half))
+        x[3::4, half:nq] = rng.uniform(-amp, amp, (len(x[3::4]), half))
+        x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+        x[:, nq + nd:] = rng.uniform(-1, 1, (n, nd)) * 0.5
     elif m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and _spherical_links(m):
         x[:, 0:2] = rng.uniform(-1, 1, (n, 2))
         x[:, 2] = rng.uniform(0.7, 1.5, n)       # torso height: standing ... lying on the plane
@@ -194,6 +211,12 @@ def rollout_start(name, m, rng):
         x[2] = 0.48
         x[6:nq] = ip + 0.05 * rng.uniform(-1, 1, nq - 6)
         x[-3:] = [15, 0.3, 3] if name.startswith("ant") else [100, 2, 50]
+    elif name.startswith("two_"):
+        half = nq // 2
+        x[:half] = [0.3, -0.2, 0.1, 0.0, 0.1]
+        x[half:nq] = [0.25, -0.1, 0.05, 0.1, 0.0]
+        if m.has_plane:
+            x[:nq] *= 0.5
     elif m.is_floating:
         quat = np.array([0.08, -0.05, 0.02, 1.0])
         x[0:4] = quat / np.linalg.norm(quat)
@@ -295,6 +318,10 @@ def main(only=None):
         M = np.zeros((n, nd, nd))
         ncs = np.zeros(n, dtype=np.int32)
         for i in range(n):
+            if name.startswith("two_"):
+                r.step(x[i:i + 1])   # (the intermediates of the harness are single-body: count the contacts of a step)
+                ncs[i] = r.last_penetrating_contacts()[-1]   # contacts between the two bodies
+                continue
             d = r.debug(x[i], m)
             qdd[i], M[i] = d["qdd"], d["M"]
             ncs[i] = int((d["contacts"][:, 9] < 0).sum()) if len(d["contacts"]) else 0
@@ -303,7 +330,9 @@ def main(only=None):
         xt = x0.copy()
         traj = np.zeros((T, m.output_dim))
         acts = rng.uniform(-0.4, 0.4, (T, m.action_dim))
-        if m.step_mode != tds_amd.TDS_STEP_LOCOMOTION:
+        if name.startswith("two_"):
+            acts *= 0.5
+        elif m.step_mode != tds_amd.TDS_STEP_LOCOMOTION:
             acts *= 0.0 if name.startswith("pendulum5") else (2.0 if (m.is_floating or _spherical_links(m)) else 25.0)
         for t in range(T):
             xt[nq + nd:nq + nd + m.action_dim] = acts[t]

@@ -66,6 +66,8 @@ struct RefSim {
   UrdfCache<Alg> cache;
   World<Alg> *gworld = nullptr;
   MultiBody<Alg> *gmb = nullptr;
+  // second articulated body of a two-body world ("two:<fileA>:<fileB>:<dx>:<dy>:<dz>[+capsA][+capsB][+plane]")
+  MultiBody<Alg> *gmb2 = nullptr;
   bool g_plane = false;
   double g_dt = 1e-3;
 
@@ -98,11 +100,14 @@ struct RefSim {
 
   int input_dim() {
     if (loco()) return loco()->input_dim_with_action_and_variables();
+    if (gmb2) return gmb->dof() + gmb2->dof() + 2 * (gmb->dof_qd() + gmb2->dof_qd());  // [q | qd | tau] over both
     return gmb->dof() + gmb->dof_qd() + gmb->dof_actuated();  // == dof_qd for a fixed base, dof_qd - 6 floating
   }
   int num_visuals() {
     int n = 0;
     for (const auto &l : *mb()) n += (int)l.X_visuals.size();
+    if (gmb2)
+      for (const auto &l : *gmb2) n += (int)l.X_visuals.size();
     return n;
   }
   int output_dim() {
@@ -111,7 +116,52 @@ struct RefSim {
     // past its own output_dim.  For these constructions the record is as long as what the step writes.
     if (sphpd) return std::max(sphpd->output_dim(), sphpd->mb_->dof() + sphpd->mb_->dof_qd() + 7 * num_visuals() + 1);
     if (loco()) return loco()->output_dim();
+    if (gmb2) return gmb->dof() + gmb2->dof() + gmb->dof_qd() + gmb2->dof_qd() + 7 * num_visuals() + 1;
     return gmb->dof() + gmb->dof_qd() + 7 * num_visuals() + 1;
+  }
+
+  // two-body world: x = [q_A q_B | qd_A qd_B | tau_A tau_B]; the reference's call sequence per body around ONE
+  // World::step (contacts plane-A, plane-B, A-B; resolve_collision pair by pair, world.hpp:293-366):
+  //   forward_dynamics(A), forward_dynamics(B); clear_forces; integrate_euler_qdd(A), (B); world.step;
+  //   integrate_euler(A), (B).   y = [q_A q_B | qd_A qd_B | visual poses of A, then B | base_A.R(2,2)]
+  void two_body_step(const double *x, double *y) {
+    MultiBody<Alg> *bodies[2] = {gmb, gmb2};
+    const int nq = gmb->dof() + gmb2->dof(), nd = gmb->dof_qd() + gmb2->dof_qd();
+    int oq = 0, od = 0;
+    for (MultiBody<Alg> *m : bodies) {
+      m->initialize();
+      for (int i = 0; i < m->dof(); ++i) m->q(i) = x[oq + i];
+      for (int i = 0; i < m->dof_qd(); ++i) m->qd(i) = x[nq + od + i];
+      for (int i = 0; i < m->dof_actuated(); ++i) m->tau(i) = x[nq + nd + od + i];
+      oq += m->dof();
+      od += m->dof_qd();
+    }
+    for (MultiBody<Alg> *m : bodies) {
+      forward_dynamics(*m, gworld->get_gravity());
+      m->clear_forces();
+    }
+    for (MultiBody<Alg> *m : bodies) integrate_euler_qdd(*m, g_dt);
+    gworld->step(g_dt);
+    for (MultiBody<Alg> *m : bodies) integrate_euler(*m, g_dt);
+    int j = 0;
+    for (MultiBody<Alg> *m : bodies)
+      for (int i = 0; i < m->dof(); ++i) y[j++] = m->q(i);
+    for (MultiBody<Alg> *m : bodies)
+      for (int i = 0; i < m->dof_qd(); ++i) y[j++] = m->qd(i);
+    for (MultiBody<Alg> *m : bodies)
+      for (const auto &link : *m)
+        for (size_t v = 0; v < link.X_visuals.size(); ++v) {
+          auto vx = link.X_world * link.X_visuals[v];
+          y[j++] = vx.translation[0];
+          y[j++] = vx.translation[1];
+          y[j++] = vx.translation[2];
+          auto orn = Alg::matrix_to_quat(vx.rotation);
+          y[j++] = orn.x();
+          y[j++] = orn.y();
+          y[j++] = orn.z();
+          y[j++] = orn.w();
+        }
+    y[j++] = gmb->get_world_transform(-1).rotation(2, 2);
   }
 
   // generic step: the reference call sequence with tau given directly.
@@ -192,6 +242,45 @@ void *tdsref_create(const char *name_c, const char *reference_root) {
     s->lfloat = new LaikagoContactSimulation<Alg>(true, "laikago/laikago_toes_zup.urdf", "",
                                                   LaikagoContactSimulation<Alg>::get_initial_poses(), true);
     if (cwd[0] && chdir(cwd) != 0) return nullptr;
+  } else if (name.rfind("two:", 0) == 0) {
+    // "two:<fileA>:<fileB>:<dx>:<dy>:<dz>[+capsA][+capsB][+plane]": two articulated bodies from the reference's data
+    // directory in ONE world, B's base shifted by (dx, dy, dz); +capsX replaces every sphere of body X by a capsule of
+    // the same radius (length 0.16, along the link's local y) so that capsule-sphere pairs occur in both argument orders
+    std::string spec = name.substr(4);
+    const bool capsA = spec.find("+capsA") != std::string::npos, capsB = spec.find("+capsB") != std::string::npos;
+    s->g_plane = spec.find("+plane") != std::string::npos;
+    spec = spec.substr(0, spec.find('+'));
+    std::vector<std::string> tok;
+    size_t a = 0;
+    while (true) {
+      size_t b = spec.find(':', a);
+      tok.push_back(spec.substr(a, b == std::string::npos ? b : b - a));
+      if (b == std::string::npos) break;
+      a = b + 1;
+    }
+    if (tok.size() != 5) return nullptr;
+    std::string root(reference_root);
+    s->gworld = new World<Alg>();
+    if (s->g_plane) s->cache.construct(root + "/data/plane_implicit.urdf", *s->gworld, false, false);
+    s->gmb = s->cache.construct(root + "/data/" + tok[0], *s->gworld, false, false);
+    s->gmb2 = s->cache.construct(root + "/data/" + tok[1], *s->gworld, false, false);
+    s->gmb->base_X_world().set_identity();
+    s->gmb2->base_X_world().set_identity();
+    s->gmb2->base_X_world().translation = Alg::Vector3(atof(tok[2].c_str()), atof(tok[3].c_str()), atof(tok[4].c_str()));
+    auto capsules = [&](MultiBody<Alg> *mb) {
+      for (auto &link : *mb)
+        for (size_t g = 0; g < link.collision_geometries.size(); ++g)
+          if (link.collision_geometries[g]->get_type() == TINY_SPHERE_TYPE) {
+            const double r = ((const Sphere<Alg> *)link.collision_geometries[g])->get_radius();
+            link.collision_geometries[g] = s->gworld->create_capsule(r, 0.16);
+            // capsule axis = local z of the geometry frame: turn it onto the link's y
+            link.X_collisions[g].rotation = Alg::rotation_x_matrix(1.5707963267948966);
+          }
+    };
+    if (capsA) capsules(s->gmb);
+    if (capsB) capsules(s->gmb2);
+    s->gworld->default_friction = 1;
+    s->gworld->get_mb_constraint_solver()->keep_all_points_ = true;
   } else {
     std::string file = name;
     bool floating = false;
@@ -296,6 +385,11 @@ int tdsref_flatten(void *h, tds_model_t *out) {
     out->reward_mode = TDS_REWARD_NONE;
     out->action_limit = 0.4;
     out->plane_normal[2] = 1.0;
+    if (s->gmb2) {
+      rc = tds_hip::append_second_multibody<Alg>(*s->gmb2, out);
+      if (rc) return rc;
+      out->action_dim = s->gmb->dof_actuated() + s->gmb2->dof_actuated();
+    }
     if (s->g_plane) rc = tds_hip::flatten_plane<Alg>(*s->gworld, *s->gmb, s->g_dt, out);
   }
   if (rc) return rc;
@@ -618,10 +712,29 @@ void tdsref_step(void *h, int n, const double *x, double *y) {
     std::fill(yi.begin(), yi.end(), 0.0);
     if (loco)
       loco->step_forward_original(xi, yi);
+    else if (s->gmb2)
+      s->two_body_step(xi.data(), yi.data());
     else
       s->generic_step(xi.data(), yi.data());
     memcpy(y + (size_t)e * out, yi.data(), sizeof(double) * out);
   }
+}
+
+// After a step of a generic world: per body pair of the reference's contact list (world.mb_contacts_, in its order:
+// plane-A, plane-B, A-B for a two-body world with a plane) the number of contacts with distance < 0.  Returns the
+// number of pairs written (<= max_pairs).
+int tdsref_last_penetrating_contacts(void *h, int *counts, int max_pairs) {
+  RefSim *s = (RefSim *)h;
+  const auto &all = s->world().mb_contacts_;
+  int n = 0;
+  for (const auto &pair : all) {
+    if (n >= max_pairs) break;
+    int c = 0;
+    for (const auto &cp : pair)
+      if (cp.distance < 0) ++c;
+    counts[n++] = c;
+  }
+  return n;
 }
 
 // Intermediates for localising a parity failure.  All computed by calling the reference's own

@@ -201,6 +201,13 @@ class RefSim:
             lib().tdsref_destroy(self.h)
             self.h = None
 
+    def last_penetrating_contacts(self):
+        """per body pair of the reference's contact list, contacts with distance < 0 in the last step"""
+        buf = (C.c_int * 8)()
+        lib().tdsref_last_penetrating_contacts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        n = lib().tdsref_last_penetrating_contacts(self.h, buf, 8)
+        return [buf[i] for i in range(n)]
+
     def set_dt(self, dt):
         lib().tdsref_set_dt(self.h, dt)
 

@@ -14,6 +14,10 @@ MODELS = ["cartpole", "pendulum5", "ant", "laikago", "laikago_soft", "pendulum5_
           "humanoid_sph_pd", "pendulum5_sph_pd", "sphere_spherical_spring", "pendulum5_spherical_spring"]
 
 
+# worlds with TWO articulated bodies: fixtures from the real reference (oracle/gen_golden.py)
+TWO_BODY_MODELS = ["two_pendulums", "two_pendulums_plane", "two_pendulums_capsule_a", "two_pendulums_capsule_b"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

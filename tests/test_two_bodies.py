@@ -1,0 +1,93 @@
+"""worlds with TWO articulated bodies — each body's own forward dynamics, contacts of each body with the
+plane, and contacts BETWEEN the bodies (sphere-sphere, capsule-sphere in both argument orders of the reference's
+dispatcher) solved pair by pair with both Jacobian blocks and both inverse mass matrices
+(/root/reference/src/world.hpp:206-282, 293-366; src/contact_point.hpp:43-94, 405-438, 478-495;
+src/mb_constraint_solver.hpp:191-498).  The fixtures are outputs of the REAL reference (oracle/ref_harness.cpp:
+RefSim::two_body_step on two data/pendulum5.urdf chains, oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, TWO_BODY_MODELS, rel_err
+
+import tds_amd
+
+TOL = 1e-6
+
+
+@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+def test_two_body_blob_matches_the_reference_flatten(name, built):
+    """CPU: the committed blob is what include/tds_hip_stepper.hpp flattens from the reference's two MultiBody objects"""
+    reflib = pytest.importorskip("reflib")
+    if not reflib.available():
+        pytest.skip("reference library not built here")
+    import gen_golden as gen
+
+    r, m_ref = gen.make_ref(name)
+    m = tds_amd.load_model(name)
+    assert tds_amd.model_to_dict(m) == tds_amd.model_to_dict(m_ref)
+    assert m.num_bodies == 2 and m.body1_first_link == 5 and m.dof_qd == 10
+    # the fixture is the reference's step on the fixture's inputs
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert rel_err(r.step(g["x"]), g["y"]) < 1e-12
+    assert (g["active_contacts"] > 0).sum() >= 8      # states WITH contacts between the bodies
+    assert (g["active_contacts"] == 0).sum() >= 4     # ... and without
+    r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+def test_two_body_single_steps(name, built):
+    import torch
+    from tds_amd import hip_backend
+
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sim = hip_backend.HipSim(m, g["x"].shape[0], dtype="f64")
+    y = sim.forward_zero(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    touching = g["active_contacts"] > 0
+    e_free = rel_err(y[~touching], g["y"][~touching])
+    e_touch = rel_err(y[touching], g["y"][touching])
+    print(f"{name}: max rel err vs the reference — {int(touching.sum())} states with contacts between the bodies "
+          f"{e_touch:.3e}, {int((~touching).sum())} without {e_free:.3e}")
+    assert e_free < TOL and e_touch < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+def test_two_body_closed_loop_trajectory(name, built):
+    """the fixture's closed-loop trajectory (200 steps of the reference, state fed back), per-step resync"""
+    import torch
+    from tds_amd import hip_backend
+
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    nq, nd = m.dof_q, m.dof_qd
+    T = g["traj_y"].shape[0]
+    x = np.tile(g["traj_x0"], (T, 1))
+    x[1:, :nq + nd] = g["traj_y"][:-1, :nq + nd]            # state before step t = reference state after step t - 1
+    x[:, nq + nd:nq + nd + m.action_dim] = g["traj_actions"]
+    sim = hip_backend.HipSim(m, T, dtype="f64")
+    y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert rel_err(y, g["traj_y"]) < TOL
+
+
+@pytest.mark.gpu
+def test_two_body_mixed_precision_and_slab(built, monkeypatch):
+    """float records (double arithmetic) and the scratch-slab path (one contact's rows in LDS, the rest in the slab)"""
+    import torch
+    from tds_amd import hip_backend
+
+    name = "two_pendulums_plane"
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sim = hip_backend.HipSim(m, g["x"].shape[0], dtype="f64", na_cap=1)
+    y = sim.forward_zero(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    assert rel_err(y, g["y"]) < TOL
+    import oraclelib  # noqa: F401  (kept importable: the C oracle does not restate two-body worlds)
+    x32 = g["x"].astype(np.float32)
+    simf = hip_backend.HipSim(m, x32.shape[0], dtype="mixed")
+    yf = simf.forward_zero(torch.from_numpy(x32).cuda()).double().cpu().numpy()
+    yd = hip_backend.HipSim(m, x32.shape[0], dtype="f64").forward_zero(torch.from_numpy(x32).double().cuda()).cpu().numpy()
+    assert rel_err(yf, yd) < TOL

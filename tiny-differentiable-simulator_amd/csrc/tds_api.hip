@@ -226,7 +226,8 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     const bool is_fl = c64 ? s->h64.is_floating : s->h32.is_floating;
     const bool is_sph = c64 ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
     const char *e = getenv("TDS_HIP_W2");
-    if (!is_fl && !is_sph && s->lds.NDP < 24 && !(e && e[0] == '0')) {
+    const bool is_two_w = c64 ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
+    if (!is_fl && !is_sph && !is_two_w && s->lds.NDP < 24 && !(e && e[0] == '0')) {
       s->lds_w2 = c64 ? tds_make_lds_layout<double>(s->h64, na_cap, s->lanes, true)
                       : tds_make_lds_layout<float>(s->h32, na_cap, s->lanes, true);
       const size_t b2 = (size_t)s->lds_w2.stride * epw * celem;
@@ -245,7 +246,8 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   if (lds_bytes > 64 * 1024) {
     const bool is_fl = c64 ? s->h64.is_floating : s->h32.is_floating;
     const bool is_sph = c64 ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
-    const int kind = is_fl ? 1 : (is_sph ? 2 : 0);
+    const bool is_two = c64 ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
+    const int kind = is_fl ? 1 : (is_sph ? 2 : (is_two ? 3 : 0));
     int e = dtype == TDS_DTYPE_F64         ? tds_kernel_max_dynamic_lds<double, double>(s->lanes, s->lds.NDP, lds_bytes, kind)
             : dtype == TDS_DTYPE_F64_REC32 ? tds_kernel_max_dynamic_lds<double, float>(s->lanes, s->lds.NDP, lds_bytes, kind)
                                            : tds_kernel_max_dynamic_lds<float, float>(s->lanes, s->lds.NDP, lds_bytes, kind);
@@ -475,7 +477,8 @@ int pool_alloc(tds_hip_sim *s) {
   if (lds_bytes > 64 * 1024) {
     const bool is_fl = s->compute_f64() ? s->h64.is_floating : s->h32.is_floating;
     const bool is_sph = s->compute_f64() ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
-    const int kind = is_fl ? 1 : (is_sph ? 2 : 0);
+    const bool is_two = s->compute_f64() ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
+    const int kind = is_fl ? 1 : (is_sph ? 2 : (is_two ? 3 : 0));
     const int e = s->dtype == TDS_DTYPE_F64         ? tds_kernel_max_dynamic_lds<double, double>(s->lanes, s->pool_lds.NDP, lds_bytes, kind)
                   : s->dtype == TDS_DTYPE_F64_REC32 ? tds_kernel_max_dynamic_lds<double, float>(s->lanes, s->pool_lds.NDP, lds_bytes, kind)
                                                     : tds_kernel_max_dynamic_lds<float, float>(s->lanes, s->pool_lds.NDP, lds_bytes, kind);

@@ -21,6 +21,7 @@
 #define TDS_NCP TDS_MAX_CONTACTS       // 64 contact points
 #define TDS_NV TDS_MAX_VISUALS         // 64
 #define TDS_NPAIR (TDS_NL * 12)        // (link, strict ancestor) pairs
+#define TDS_NPC TDS_MAX_PAIR_CONTACTS  // contact points between the two bodies of a two-body world
 // internal joint types of the expanded model (never in a tds_model_t handed in by a caller)
 #define TDS_JOINT_SPH0 9   // first lane of a spherical joint: X_J = quat_to_matrix(q[0..3]), axis x
 #define TDS_JOINT_SPH1 10  // second: identity transform, axis y
@@ -86,6 +87,18 @@ struct DevModel {
   T vis_X[12][TDS_NV];
   // CRBA off-diagonal work list: M[qd(i)][qd(j)] for j a strict ancestor of i, both with a dof
   int16_t pair_i[TDS_NPAIR], pair_j[TDS_NPAIR];
+  // two-body worlds (tds_model_t::num_bodies == 2; kernels of KIND 3) ------------------------------
+  int two_bodies;               // 1: links with body_of_link == 1 hang off the second base
+  int nd_a;                     // dofs 0..nd_a-1 belong to body A, the rest to body B
+  int body_of_link[TDS_NL];
+  T base_R2[9], base_t2[3], grav2[3];
+  // contact points between a geometry of A and a geometry of B, in the reference's order (world.hpp:206-282: geoms
+  // of A outer, geoms of B inner; capsule-sphere: +L/2 end, then -L/2 end).  Each is a pair of spheres:
+  int num_pc;
+  int pc_link_a[TDS_NPC], pc_link_b[TDS_NPC];  // owning links (global index; -1: the body's base)
+  int pc_swap[TDS_NPC];         // 1: the dispatcher ran the pair with swapped arguments (sphere of A, capsule of B:
+                                //    contact_point.hpp:478-495) — same contact, different rounding of the two points
+  T pc_loc_a[3][TDS_NPC], pc_loc_b[3][TDS_NPC], pc_rad_a[TDS_NPC], pc_rad_b[TDS_NPC];
 };
 
 // reference: src/mb_constraint_solver.hpp:506-520 (incl. k = sqrt(a) and p[2] quirks)
@@ -200,6 +213,24 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->t1[k] = (T)t1[k];
     d->t2[k] = (T)t2[k];
   }
+  const bool two = m->num_bodies == 2;
+  if (m->num_bodies > 2 || m->num_bodies < 0) TDS_FAIL(TDS_ERR_UNSUPPORTED, "worlds of more than two articulated bodies");
+  if (two) {
+    if (ex != nullptr || m->is_floating) TDS_FAIL(TDS_ERR_UNSUPPORTED, "two-body worlds: fixed bases and 1-dof joints");
+    if (m->step_mode != TDS_STEP_TAU) TDS_FAIL(TDS_ERR_UNSUPPORTED, "two-body worlds step in TAU mode");
+    if (m->reward_mode != TDS_REWARD_NONE) TDS_FAIL(TDS_ERR_UNSUPPORTED, "two-body worlds carry no reward rule");
+    if (m->body1_first_link < 1 || m->body1_first_link >= m->num_links || m->body1_first_geom < 0 ||
+        m->body1_first_geom > m->num_geoms)
+      TDS_FAIL(TDS_ERR_INVALID_ARG, "body1_first_link / body1_first_geom out of range");
+    d->two_bodies = 1;
+    for (int r = 0; r < 3; ++r) {
+      double g = 0;
+      for (int c = 0; c < 3; ++c) g += m->body1_base_X_world_rot[3 * r + c] * m->gravity[c];
+      d->grav2[r] = (T)g;
+      d->base_t2[r] = (T)m->body1_base_X_world_trans[r];
+    }
+    for (int k = 0; k < 9; ++k) d->base_R2[k] = (T)m->body1_base_X_world_rot[k];
+  }
   // links
   int max_level = 0, pose_index = 0, ndof = 0;
   uint32_t anc_links[TDS_NL];
@@ -212,6 +243,11 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->q_rec[i] = ex ? ex->q_rec[i] : (l.joint_type == TDS_JOINT_FIXED ? -1 : l.q_index);
     d->qd_rec[i] = ex ? ex->qd_rec[i] : (l.joint_type == TDS_JOINT_FIXED ? -1 : l.qd_index);
     d->parent[i] = l.parent;
+    d->body_of_link[i] = (two && i >= m->body1_first_link) ? 1 : 0;
+    if (two && l.parent >= 0 && d->body_of_link[l.parent] != d->body_of_link[i])
+      TDS_FAIL(TDS_ERR_INVALID_ARG, "a link's parent belongs to the other body");
+    if (two && (l.joint_type == TDS_JOINT_SPHERICAL)) TDS_FAIL(TDS_ERR_UNSUPPORTED, "two-body worlds: 1-dof joints");
+    if (two && i == m->body1_first_link) d->nd_a = ndof;
     d->level[i] = l.parent >= 0 ? d->level[l.parent] + 1 : 0;
     if (d->level[i] > max_level) max_level = d->level[i];
     d->joint_type[i] = l.joint_type;
@@ -319,7 +355,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   if (m->has_plane) {
     for (int g = 0; g < m->num_geoms; ++g) {
       const tds_geom_t &G = m->geoms[g];
-      if (G.link < -1 || G.link >= m->num_links) TDS_FAIL(TDS_ERR_INVALID_ARG, "geom link out of range");
+      if (G.link < (two ? -2 : -1) || G.link >= m->num_links) TDS_FAIL(TDS_ERR_INVALID_ARG, "geom link out of range");
       int npts = 0;
       double off[8][3];
       double radius = G.radius;
@@ -358,6 +394,48 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     }
   }
   d->num_cp = ncp;
+  // contact points between the two bodies: every (geometry of A, geometry of B) pair the reference's dispatcher knows
+  int npc = 0;
+  if (two) {
+    auto ends = [&](const tds_geom_t &G, double out[2][3]) {  // sphere centres of the geometry in its link's frame
+      const int n = G.type == TDS_GEOM_CAPSULE ? 2 : 1;
+      for (int e = 0; e < n; ++e) {
+        const double off[3] = {0.0, 0.0, G.type == TDS_GEOM_CAPSULE ? (e == 0 ? 0.5 : -0.5) * G.length : 0.0};
+        for (int r = 0; r < 3; ++r) {
+          double v = G.X_trans[r];
+          for (int c = 0; c < 3; ++c) v += G.X_rot[3 * r + c] * off[c];
+          out[e][r] = v;
+        }
+      }
+      return n;
+    };
+    for (int ga = 0; ga < m->body1_first_geom; ++ga)
+      for (int gb = m->body1_first_geom; gb < m->num_geoms; ++gb) {
+        const tds_geom_t &A = m->geoms[ga], &B = m->geoms[gb];
+        const bool ss = A.type == TDS_GEOM_SPHERE && B.type == TDS_GEOM_SPHERE;
+        const bool cs = A.type == TDS_GEOM_CAPSULE && B.type == TDS_GEOM_SPHERE;   // contact_capsule_sphere
+        const bool sc = A.type == TDS_GEOM_SPHERE && B.type == TDS_GEOM_CAPSULE;   // ... through the dispatcher's swap
+        if (!ss && !cs && !sc) continue;  // (capsule-capsule, boxes, meshes: no function in the dispatcher)
+        if (A.link == -2 || (A.link >= m->body1_first_link) || (B.link >= 0 && B.link < m->body1_first_link) || B.link == -1)
+          TDS_FAIL(TDS_ERR_INVALID_ARG, "geometry listed under the wrong body");
+        double ea[2][3], eb[2][3];
+        const int na = ends(A, ea), nb = ends(B, eb);
+        for (int p = 0; p < (na > nb ? na : nb); ++p) {
+          if (npc >= TDS_NPC) TDS_FAIL(TDS_ERR_UNSUPPORTED, "too many contact points between the two bodies");
+          d->pc_link_a[npc] = A.link;
+          d->pc_link_b[npc] = B.link == -2 ? -1 : B.link;
+          d->pc_swap[npc] = sc ? 1 : 0;
+          d->pc_rad_a[npc] = (T)A.radius;
+          d->pc_rad_b[npc] = (T)B.radius;
+          for (int r = 0; r < 3; ++r) {
+            d->pc_loc_a[r][npc] = (T)ea[na == 2 ? p : 0][r];
+            d->pc_loc_b[r][npc] = (T)eb[nb == 2 ? p : 0][r];
+          }
+          ++npc;
+        }
+      }
+  }
+  d->num_pc = npc;
   for (int v = 0; v < d->num_visuals; ++v) {
     const tds_visual_t &V = m->visuals[v];
     if (V.link < 0 || V.link >= m->num_links) TDS_FAIL(TDS_ERR_INVALID_ARG, "visual link out of range");

@@ -13,6 +13,7 @@
 struct TdsLds {
   int stride;              // scalars per environment
   int NLp, NDP, NDs, NCPp; // links, padded dof (8/14/16/18/24/32), dof row stride (odd), contact-point stride
+  int NPCp, pc;            // two-body worlds: stride / offset of the contact list between the bodies
   int zrows, ovrows;       // constraint rows held in LDS / surplus rows per env in the global slab
   int xrec, swd, cp, Lp, dinv, rows, xrow;  // persistent
   int Xw, v;               // phase group 1 (kinematics sweep)   } the three groups alias
@@ -75,6 +76,7 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
 #define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof, two_waves
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
+  if (h_model.two_bodies) return tds_launch_step_impl<T, TR, 3>(TDS_ARGS);
   return tds_launch_step_impl<T, TR, 0>(TDS_ARGS);
 #undef TDS_ARGS
 }
@@ -85,6 +87,7 @@ template <typename T, typename TR>
 inline int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes, int kind) {
   return kind == 1 ? tds_kernel_max_dynamic_lds_impl<T, TR, 1>(lanes_per_env, ndp, bytes)
          : kind == 2 ? tds_kernel_max_dynamic_lds_impl<T, TR, 2>(lanes_per_env, ndp, bytes)
+         : kind == 3 ? tds_kernel_max_dynamic_lds_impl<T, TR, 3>(lanes_per_env, ndp, bytes)
                      : tds_kernel_max_dynamic_lds_impl<T, TR, 0>(lanes_per_env, ndp, bytes);
 }
 

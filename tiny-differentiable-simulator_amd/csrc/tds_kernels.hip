@@ -306,6 +306,22 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
+// reference: src/mb_constraint_solver.hpp:506-520 (plane_space incl. its k = sqrt(a) and p[2] quirks; the host-side
+// twin for the fixed plane normal is tds_plane_space in tds_device_model.h)
+template <typename T>
+__device__ __forceinline__ void plane_space_dev(const T *n, T *p, T *q) {
+  const T n_sqr = n[2] * n[2];
+  const bool gt = n_sqr > T(0.5);
+  const T a = n[1] * n[1] + (gt ? n_sqr : n[0] * n[0]);
+  const T k = sqrt_t<T>(a);
+  p[0] = gt ? T(0) : -n[1] * k;
+  p[1] = gt ? -n[2] * k : n[0] * k;
+  p[2] = n[1] * k;
+  q[0] = gt ? a * k : -n[2] * p[1];
+  q[1] = gt ? -n[0] * p[2] : n[2] * p[0];
+  q[2] = gt ? n[0] * p[1] : a * k;
+}
+
 // reference: src/math/tiny/tiny_matrix3x3.h:432-465 (getRotation, right-associative build:
 // off-diagonal differences transposed w.r.t. Bullet, w negated)
 template <typename T>
@@ -810,7 +826,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // q record holds the joint's quaternion (4 coordinates) at q_rec of the first lane.
   constexpr bool fl = KIND == 1;
   constexpr bool sph = KIND == 2;
-  constexpr bool gen = KIND != 0;
+  constexpr bool gen = KIND == 1 || KIND == 2;
+  // KIND 3: worlds of TWO articulated bodies (fixed bases, 1-dof joints) in one lane group: the links of body B sit
+  // behind those of body A, the joint-space inertia is block diagonal (the LDL^T and every solve go through as they
+  // are), and a SECOND contact pass handles the contacts between the two bodies (world.hpp:206-282, 293-366).
+  constexpr bool two = KIND == 3;
+  const bool body_b = two && isl && mdl->body_of_link[lsafe] != 0;
   const int njd = mdl->nj;                       // joint dofs (== nd on a fixed base)
   const bool froot = fl && isl && li < 6;        // base pseudo link
   const bool sph_lane = sph && jt >= TDS_JOINT_SPH0;
@@ -970,12 +991,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
             for (int c = 0; c < 9; ++c) Rl[c] = Xw[lkc * TDS_S1 + c];
 #pragma unroll
             for (int c = 0; c < 3; ++c) pl[c] = Xw[lkc * TDS_S1 + 9 + c];
-            if (__any(lk < 0)) {  // wave-uniform, rare: a geometry on the base link
-              const bool on_base = lk < 0;
+            if (__any(lk < 0)) {  // wave-uniform, rare: a geometry on the base link (-2: base of the second body)
+              const bool on_base = lk < 0, b2 = two && lk == -2;
 #pragma unroll
-              for (int c = 0; c < 9; ++c) Rl[c] = on_base ? mdl->base_R[c] : Rl[c];
+              for (int c = 0; c < 9; ++c) Rl[c] = on_base ? (b2 ? mdl->base_R2[c] : mdl->base_R[c]) : Rl[c];
 #pragma unroll
-              for (int c = 0; c < 3; ++c) pl[c] = on_base ? mdl->base_t[c] : pl[c];
+              for (int c = 0; c < 3; ++c) pl[c] = on_base ? (b2 ? mdl->base_t2[c] : mdl->base_t[c]) : pl[c];
             }
           }
           T loc[3] = {pf_cp_loc[0], pf_cp_loc[1], pf_cp_loc[2]};
@@ -1129,6 +1150,144 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           if (r0 < ZR) Zs[r0 * NDs + d] = jn; else zov[(r0 - ZR) * NDs + d] = jn;
           if (r1 < ZR) Zs[r1 * NDs + d] = j1; else zov[(r1 - ZR) * NDs + d] = j1;
           if (r2 < ZR) Zs[r2 * NDs + d] = j2; else zov[(r2 - ZR) * NDs + d] = j2;
+        }
+      }
+    }
+  };
+
+  // ---- two-body worlds (KIND 3): contacts between a geometry of body A and a geometry of body B
+  //      (world.hpp:206-282; contact_sphere_sphere / contact_capsule_sphere, contact_point.hpp:43-94, 405-438; the
+  //      dispatcher's swapped order :478-495).  lane == pair contact point; the penetrating ones are compacted into
+  //      pcx [17][NPCp]: point on A (3) | point on B (3) | normal on B (3) | tangent 1 (3) | tangent 2 (3) | distance |
+  //      dofs on the two paths base -> link (bit pattern).  Returns their number.
+  const int NPCp = L.NPCp;
+  auto phase_I2 = [&]() -> int {
+    int nb2 = 0;
+    if constexpr (two) {
+      T *const Xw = E + L.Xw;
+      T *const pcx = E + L.pc;
+      const int npc = mdl->num_pc;
+      for (int base = 0; base < npc; base += G) {
+        const int k = base + lane;
+        bool act = false;
+        T Pa[3] = {T(0), T(0), T(0)}, Pb[3] = {T(0), T(0), T(0)}, nn[3] = {T(0), T(0), T(0)}, dist = T(0);
+        unsigned msk = 0u;
+        if (k < npc) {
+          const int la = mdl->pc_link_a[k], lb = mdl->pc_link_b[k];
+          msk = (la >= 0 ? mdl->anc_dofs[la] : 0u) | (lb >= 0 ? mdl->anc_dofs[lb] : 0u);
+          T Ra[9], pa[3], Rb[9], pb[3];
+          const int lac = la >= 0 ? la : 0, lbc = lb >= 0 ? lb : 0;
+#pragma unroll
+          for (int c = 0; c < 9; ++c) {
+            Ra[c] = Xw[lac * TDS_S1 + c];
+            Rb[c] = Xw[lbc * TDS_S1 + c];
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            pa[c] = Xw[lac * TDS_S1 + 9 + c];
+            pb[c] = Xw[lbc * TDS_S1 + 9 + c];
+          }
+          if (__any(la < 0 || lb < 0)) {  // wave-uniform, rare: a geometry on a base
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+              Ra[c] = la < 0 ? mdl->base_R[c] : Ra[c];
+              Rb[c] = lb < 0 ? mdl->base_R2[c] : Rb[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              pa[c] = la < 0 ? mdl->base_t[c] : pa[c];
+              pb[c] = lb < 0 ? mdl->base_t2[c] : pb[c];
+            }
+          }
+          const T la3[3] = {mdl->pc_loc_a[0][k], mdl->pc_loc_a[1][k], mdl->pc_loc_a[2][k]};
+          const T lb3[3] = {mdl->pc_loc_b[0][k], mdl->pc_loc_b[1][k], mdl->pc_loc_b[2][k]};
+          const T ra = mdl->pc_rad_a[k], rb = mdl->pc_rad_b[k];
+          T cA[3], cB[3];
+          mat3_mulv(Ra, la3, cA);
+          mat3_mulv(Rb, lb3, cB);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            cA[c] += pa[c];
+            cB[c] += pb[c];
+          }
+          const bool swp = mdl->pc_swap[k] != 0;
+          // contact_sphere_sphere(X, Y): diff = pX - pY, n = diff / |diff|, point_x = pX - rX n, point_y = point_x - dist n;
+          // direct: X = A, Y = B.  Swapped (sphere of A, capsule end of B): X = B's end sphere, Y = A's sphere, and the
+          // dispatcher exchanges the points and negates the normal afterwards.
+          const T *const cX = swp ? cB : cA, *const cY = swp ? cA : cB;
+          const T rX = swp ? rb : ra, rY = swp ? ra : rb;
+          const T diff[3] = {cX[0] - cY[0], cX[1] - cY[1], cX[2] - cY[2]};
+          const T len = sqrt_t<T>(dot3(diff, diff));
+          dist = len - (rX + rY);
+          const T inv = T(1) / len;
+          const T nx[3] = {inv * diff[0], inv * diff[1], inv * diff[2]};
+          const T px[3] = {cX[0] - rX * nx[0], cX[1] - rX * nx[1], cX[2] - rX * nx[2]};
+          const T py[3] = {px[0] - dist * nx[0], px[1] - dist * nx[1], px[2] - dist * nx[2]};
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            Pa[c] = swp ? py[c] : px[c];
+            Pb[c] = swp ? px[c] : py[c];
+            nn[c] = swp ? -nx[c] : nx[c];
+          }
+          act = live && len > T(1e-5) && dist < T(0);  // CONTACT_EPSILON; collision mask, mb_constraint_solver.hpp:285
+        }
+        const unsigned long long bal = __ballot(act);
+        const unsigned long long mine = (G == 64) ? bal : ((bal >> (grp * G)) & ((1ull << (G & 63)) - 1ull));
+        const int pre = __popcll(mine & ((1ull << lane) - 1ull));
+        if (act) {
+          const int slot = nb2 + pre;
+          T t1[3], t2[3];
+          plane_space_dev<T>(nn, t1, t2);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            pcx[(0 + c) * NPCp + slot] = Pa[c];
+            pcx[(3 + c) * NPCp + slot] = Pb[c];
+            pcx[(6 + c) * NPCp + slot] = nn[c];
+            pcx[(9 + c) * NPCp + slot] = t1[c];
+            pcx[(12 + c) * NPCp + slot] = t2[c];
+          }
+          pcx[15 * NPCp + slot] = dist;
+          pcx[16 * NPCp + slot] = bits_to_scalar<T>(msk);
+        }
+        nb2 += __popcll(mine);
+      }
+    }
+    return nb2;
+  };
+  // rows of the contacts between the bodies (lane == dof): the relative velocity is vel_a - vel_b, so a dof of body
+  // A enters with -J_a, a dof of body B with +J_b (mb_constraint_solver.hpp:278-388: rows [J_a | J_b], right-hand
+  // side from J_a qd_a - J_b qd_b, qd_a += M_a^-1 J_a^T p, qd_b -= M_b^-1 J_b^T p); each body's column is taken at
+  // ITS contact point (point_jacobian2(mb_a, link_a, world_point_on_a) / (mb_b, link_b, world_point_on_b))
+  auto phase_J2 = [&](const int nb2, const int NB) {
+    if constexpr (two) {
+      T *const swd = E + L.swd;
+      T *const pcx = E + L.pc;
+      T *const Zs = E + L.Z;
+      volatile T *const zov = (ovf != nullptr && live) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
+      const int d = lane;
+      T sd[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sd[k] = d < nd ? swd[k * NDs + d] : T(0);
+      const bool of_a = d < mdl->nd_a;
+      const T sgn = of_a ? T(-1) : T(1);
+      for (int a = 0; a < NB; ++a) {
+        if (d < NDP && a < nb2) {
+          const int o = of_a ? 0 : 3;
+          const T P[3] = {pcx[(o + 0) * NPCp + a], pcx[(o + 1) * NPCp + a], pcx[(o + 2) * NPCp + a]};
+          const unsigned msk = scalar_to_bits<T>(pcx[16 * NPCp + a]);
+          const bool on = d < nd && ((msk >> d) & 1u);
+          T val[3];
+#pragma unroll
+          for (int e = 0; e < 3; ++e) {
+            const T dir[3] = {pcx[(6 + 3 * e + 0) * NPCp + a], pcx[(6 + 3 * e + 1) * NPCp + a], pcx[(6 + 3 * e + 2) * NPCp + a]};
+            T cr[3];
+            cross3(dir, sd, cr);  // e . col = e . s_lin + P . (e x s_ang)
+            val[e] = on ? sgn * (dot3(dir, sd + 3) + dot3(P, cr)) : T(0);
+          }
+          const int r0 = a, r1 = NB + a, r2 = 2 * NB + a;
+          if (r0 < ZR) Zs[r0 * NDs + d] = val[0]; else zov[(r0 - ZR) * NDs + d] = val[0];
+          if (r1 < ZR) Zs[r1 * NDs + d] = val[1]; else zov[(r1 - ZR) * NDs + d] = val[1];
+          if (r2 < ZR) Zs[r2 * NDs + d] = val[2]; else zov[(r2 - ZR) * NDs + d] = val[2];
         }
       }
     }
@@ -1467,14 +1626,15 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     if (mine) {
       if (parent < 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rq[k] = mdl->base_R[k];
+        for (int k = 0; k < 9; ++k) Rq[k] = body_b ? mdl->base_R2[k] : mdl->base_R[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pq[k] = mdl->base_t[k];
+        for (int k = 0; k < 3; ++k) pq[k] = body_b ? mdl->base_t2[k] : mdl->base_t[k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) vq[k] = aq[k] = T(0);
-        aq[3] = -mdl->grav[0];  // base acceleration = -gravity (forward_dynamics.hpp:237-243)
-        aq[4] = -mdl->grav[1];
-        aq[5] = -mdl->grav[2];
+        // base acceleration = -gravity in the body's own base frame (forward_dynamics.hpp:237-243)
+        aq[3] = body_b ? -mdl->grav2[0] : -mdl->grav[0];
+        aq[4] = body_b ? -mdl->grav2[1] : -mdl->grav[1];
+        aq[5] = body_b ? -mdl->grav2[2] : -mdl->grav[2];
       }
       mat3_mul(Rq, Rp, R);
       T r[3];
@@ -1563,6 +1723,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   //         wavefront runs them (and the Jacobian rows) while this one goes on with the dynamics.
   int na = 0, NA = 0;
   bool wave_contacts = false;
+  int nb_pairs = 0, NB_pairs = 0;  // two-body worlds: penetrating contacts between the bodies (this group / wavefront max)
   if constexpr (W2) {
     __syncthreads();  // (1) x record, X_world and the motion axes are in LDS: the helper wavefront starts
   } else {
@@ -1578,6 +1739,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     // wave-uniform constraint-row layout (see tds_row_solve): NA = the largest contact count among the
     // wavefront's environments (computed here, long before phase J needs it)
     NA = wave_max(na);
+    if constexpr (two) {
+      nb_pairs = phase_I2();
+      NB_pairs = wave_max(nb_pairs);
+    }
     phase_M1();
     TDS_WAVE_SYNC();  // X_world / v in LDS are dead from here on (their space is reused)
   }
@@ -2051,6 +2216,43 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       if (d < nd) rhsx[d] -= w;
     }
     }  // wave_contacts
+    if constexpr (two) {
+      // ---- second contact pass: body A against body B, with the velocities the plane passes left
+      //      (World::step resolves the body pairs one after the other: plane-A, plane-B, A-B; world.hpp:340-352)
+      if (NB_pairs > 0) {
+        TDS_WAVE_SYNC();
+        T *const pcx = E + L.pc;
+        T *const Zs = E + L.Z;
+        T *const rws = E + L.rows;
+        T *const xs = E + L.xrow;
+        volatile T *const zov = (ovf != nullptr && live) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
+        volatile T *const rov = zov != nullptr ? zov + (size_t)OVR * NDs : nullptr;
+        const T cfm = pf_cfm, erp_dt = pf_erp_dt, rest = pf_rest;
+        const bool slab2 = 3 * NB_pairs > ZR;  // wave-uniform
+        phase_J2(nb_pairs, NB_pairs);
+        TDS_WAVE_SYNC();
+        if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        // (the distance of pair contact a sits at pcx[15 NPCp + a]: the row solve reads cpx[3 NCPp + a])
+        if (slab2)
+          tds_row_solve<true, T, G, NDP>(lane, NB_pairs, nb_pairs, nd, ZR, OVR, NPCp, Zs, rws, xs, rhsx, pcx + 12 * NPCp,
+                                         Lp, dvec, zov, rov, cfm, erp_dt, rest);
+        else
+          tds_row_solve<false, T, G, NDP>(lane, NB_pairs, nb_pairs, nd, ZR, OVR, NPCp, Zs, rws, xs, rhsx, pcx + 12 * NPCp,
+                                          Lp, dvec, zov, rov, cfm, erp_dt, rest);
+        TDS_WAVE_SYNC();
+        if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const int d = lane;
+        const T u = slab2 ? tds_pgs<true, T, G, NDP>(lane, NB_pairs, ZR, OVR, pf_iters, pf_mu, Zs, rws, xs, zov, rov)
+                          : tds_pgs_lds<T, G, NDP>(lane, NB_pairs, ZR, pf_iters, pf_mu, Zs, rws, xs);
+        T w = d < NDP ? u * dvec[NDP + d] : T(0);
+        static_for<0, NDP - 1>([&](auto ic) {
+          constexpr int k = NDP - 1 - decltype(ic)::value;
+          const T wk = lane_bcast<T, G, NDP, k>(w);
+          if (d < k) w -= Lp[(k * (k - 1)) / 2 + d] * wk;
+        });
+        if (d < nd) rhsx[d] -= w;
+      }
+    }
     TDS_WAVE_SYNC();
     if (di >= 0) qd_new = rhsx[di];
   }
@@ -2327,9 +2529,13 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   L.NDs = ndp + 1;  // odd row stride: lane == row accesses hit distinct LDS banks
   const int ncp = m.has_plane ? m.num_cp : 0;
   L.NCPp = ncp > 0 ? ncp : 1;
-  if (na_cap <= 0 || na_cap > ncp) na_cap = ncp;
+  // two-body worlds: the contacts between the bodies are a second pass through the same row store
+  const int npc = m.two_bodies ? m.num_pc : 0;
+  L.NPCp = npc > 0 ? npc : 1;
+  const int nct = ncp > npc ? ncp : npc;  // contacts of the larger pass
+  if (na_cap <= 0 || na_cap > nct) na_cap = nct;
   L.zrows = 3 * na_cap;            // constraint rows kept in LDS
-  L.ovrows = 3 * ncp - L.zrows;    // surplus rows per environment (global scratch slab)
+  L.ovrows = 3 * nct - L.zrows;    // surplus rows per environment (global scratch slab)
   int o = 0;
   // persistent for the whole step
   L.xrec = o; o += m.input_dim + 2 + (w2 ? 2 : 0);  // + x_{t-1} and the done flag of the step loop (+ contact counts
@@ -2339,12 +2545,19 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   //   cp   (contact points: phases I..K)             |  xrow (impulses x of all rows: L)
   {
     const int a = 6 * L.NDs, b = 3 * L.zrows;
-    L.swd = o; L.rows = o; o += a > b ? a : b;
+    if (npc > 0) {  // (the second contact pass builds its rows from the motion axes after the first one's row scalars)
+      L.swd = o; o += a;
+      L.rows = o; o += b;
+    } else {
+      L.swd = o; L.rows = o; o += a > b ? a : b;
+    }
   }
   {
-    const int a = ncp ? 5 * L.NCPp : 0, b = 3 * ncp;
+    const int a = ncp ? 5 * L.NCPp : 0, b = 3 * nct;
     L.cp = o; L.xrow = o; o += a > b ? a : b;
   }
+  L.pc = o;
+  if (npc > 0) o += 17 * L.NPCp;  // contact list of the pairs: lives from the narrowphase to the second pass
   L.Lp = o;   o += (ndp * (ndp - 1)) / 2;
   L.dinv = o; o += (w2 ? 4 : 3) * ndp;  // 1/D | sqrt(1/D) | column scratch of the wide LDL^T / rhs exchange (| y~)
   // three phase groups share one region:
@@ -2493,7 +2706,13 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
 #else
 #define TDS_INSTANTIATE_K2(TT, TR)
 #endif
-#define TDS_INSTANTIATE_KINDS(TT, TR) TDS_INSTANTIATE_K0(TT, TR) TDS_INSTANTIATE_K1(TT, TR) TDS_INSTANTIATE_K2(TT, TR)
+#if TDS_ONLY_KIND == 3 || defined(TDS_ALL_KINDS)
+#define TDS_INSTANTIATE_K3(TT, TR) TDS_INSTANTIATE(TT, TR, 3)
+#else
+#define TDS_INSTANTIATE_K3(TT, TR)
+#endif
+#define TDS_INSTANTIATE_KINDS(TT, TR) \
+  TDS_INSTANTIATE_K0(TT, TR) TDS_INSTANTIATE_K1(TT, TR) TDS_INSTANTIATE_K2(TT, TR) TDS_INSTANTIATE_K3(TT, TR)
 #if defined(TDS_ONLY_F64)
 #if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
 template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int, bool);

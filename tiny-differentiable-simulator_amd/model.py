@@ -13,7 +13,7 @@ import ctypes as C
 import json
 import os
 
-TDS_HIP_ABI_VERSION = 2
+TDS_HIP_ABI_VERSION = 3
 TDS_MAX_LINKS = 64
 TDS_MAX_GEOMS = 32
 TDS_MAX_VISUALS = 64
@@ -110,6 +110,12 @@ class Model(C.Structure):
         ("base_mass", C.c_double),
         ("base_com", C.c_double * 3),
         ("base_inertia", C.c_double * 9),
+        ("num_bodies", C.c_int32),
+        ("body1_first_link", C.c_int32),
+        ("body1_first_geom", C.c_int32),
+        ("pad3_", C.c_int32),
+        ("body1_base_X_world_rot", C.c_double * 9),
+        ("body1_base_X_world_trans", C.c_double * 3),
         ("links", Link * TDS_MAX_LINKS),
         ("geoms", Geom * TDS_MAX_GEOMS),
         ("visuals", Visual * TDS_MAX_VISUALS),
@@ -181,6 +187,12 @@ def model_to_dict(m: Model) -> dict:
     for k in _VECTORS:
         d[k] = [float(x) for x in getattr(m, k)]
     d["reset_obs_raw_xy"] = int(m.reset_obs_raw_xy)
+    if m.num_bodies > 1:  # two-body worlds only: the single-body files stay as they are
+        d["num_bodies"] = int(m.num_bodies)
+        d["body1_first_link"] = int(m.body1_first_link)
+        d["body1_first_geom"] = int(m.body1_first_geom)
+        d["body1_base_X_world_rot"] = [float(x) for x in m.body1_base_X_world_rot]
+        d["body1_base_X_world_trans"] = [float(x) for x in m.body1_base_X_world_trans]
     d["base_mass"] = float(m.base_mass)
     for k in _OPTIONAL_VECTORS:
         d[k] = [float(x) for x in getattr(m, k)]
@@ -204,6 +216,13 @@ def model_from_dict(d: dict) -> Model:
         for i, x in enumerate(d[k]):
             arr[i] = x
     m.reset_obs_raw_xy = d.get("reset_obs_raw_xy", 0)
+    m.num_bodies = d.get("num_bodies", 0)
+    m.body1_first_link = d.get("body1_first_link", 0)
+    m.body1_first_geom = d.get("body1_first_geom", 0)
+    for i, x in enumerate(d.get("body1_base_X_world_rot", [])):
+        m.body1_base_X_world_rot[i] = x
+    for i, x in enumerate(d.get("body1_base_X_world_trans", [])):
+        m.body1_base_X_world_trans[i] = x
     m.base_mass = d.get("base_mass", 0.0)
     for k in _OPTIONAL_VECTORS:
         arr = getattr(m, k)
