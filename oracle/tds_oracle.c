@@ -883,8 +883,11 @@ static int resolve_collision(const tds_model_t *m, scratch_t *s, tds_oracle_debu
 
 /* ref: examples/environments/locomotion_contact_simulation.h:151-304 (LOCOMOTION) and
    examples/environments/cartpole_environment.h:71-117 (TAU) */
+static int step_two(const tds_model_t *m, const double *x, double *y);
+
 static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t *s,
                     tds_oracle_debug_t *dbg) {
+  if (m->num_bodies == 2) return step_two(m, x, y); /* worlds with two articulated bodies: below */
   const int nq = m->dof_q, nd = m->dof_qd;
   int nsph = 0;
   for (int i = 0; i < m->num_links && i < NL; ++i) nsph += m->links[i].joint_type == TDS_JOINT_SPHERICAL;
@@ -1032,6 +1035,299 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
     y[j++] = s->base_X_world.r[8];                         /* :301-303 */
   }
   return 0;
+}
+
+/* ================================================================================================
+ * Worlds with TWO articulated bodies (tds_model_t::num_bodies == 2).
+ * ref: src/world.hpp:293-366 (World::step over multi_bodies_ = [plane,] A, B: contacts pair by pair, then
+ * resolve_collision pair by pair in the same order), :206-282 (pair loop), src/contact_point.hpp:43-94
+ * (sphere-sphere), :405-438 (capsule-sphere), :478-495 (the dispatcher's swapped order),
+ * src/mb_constraint_solver.hpp:191-498 (both Jacobian blocks, both inverse mass matrices).
+ * Each body is handled by the single-body functions above on a sub-model of its own.
+ * ================================================================================================ */
+typedef struct {
+  double normal[3], point_a[3], point_b[3], distance;
+  int link_a, link_b;
+} pair_contact_t;
+
+/* body `which` (0 = A, 1 = B) of a two-body blob as a single-body blob of its own */
+static void sub_model(const tds_model_t *m, int which, tds_model_t *o) {
+  const int f = m->body1_first_link, g1 = m->body1_first_geom;
+  int nqa = 0, nda = 0;
+  for (int i = 0; i < f; ++i)
+    if (m->links[i].joint_type != TDS_JOINT_FIXED) { ++nqa; ++nda; }
+  *o = *m;
+  o->num_bodies = 0;
+  o->pack_visuals = 0;
+  o->num_visuals = 0;
+  if (which == 0) {
+    o->num_links = f;
+    o->dof_q = nqa; o->dof_qd = nda;
+    o->num_geoms = g1;
+  } else {
+    o->num_links = m->num_links - f;
+    o->dof_q = m->dof_q - nqa; o->dof_qd = m->dof_qd - nda;
+    memcpy(o->base_X_world_rot, m->body1_base_X_world_rot, sizeof(o->base_X_world_rot));
+    memcpy(o->base_X_world_trans, m->body1_base_X_world_trans, sizeof(o->base_X_world_trans));
+    for (int i = 0; i < o->num_links; ++i) {
+      o->links[i] = m->links[f + i];
+      if (o->links[i].parent >= 0) o->links[i].parent -= f;
+      if (o->links[i].q_index >= 0) o->links[i].q_index -= nqa;
+      if (o->links[i].qd_index >= 0) o->links[i].qd_index -= nda;
+    }
+    o->num_geoms = m->num_geoms - g1;
+    for (int g = 0; g < o->num_geoms; ++g) {
+      o->geoms[g] = m->geoms[g1 + g];
+      o->geoms[g].link = o->geoms[g].link == -2 ? -1 : o->geoms[g].link - f;
+    }
+  }
+  o->action_dim = o->dof_qd;
+}
+
+/* ref: contact_point.hpp:43-94 (non-CppAD branch): at most one contact, emitted when the centres are apart */
+static int pair_sphere_sphere(const double *pa, double ra, const double *pb, double rb, pair_contact_t *c) {
+  double diff[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+  double length = sqrt(v3_dot(diff, diff));
+  double distance = length - (ra + rb);
+  if (!(length > 1e-5)) return 0; /* CONTACT_EPSILON */
+  for (int k = 0; k < 3; ++k) {
+    c->normal[k] = 1.0 / length * diff[k];
+  }
+  for (int k = 0; k < 3; ++k) {
+    c->point_a[k] = pa[k] - ra * c->normal[k];
+    c->point_b[k] = c->point_a[k] - distance * c->normal[k];
+  }
+  c->distance = distance;
+  return 1;
+}
+
+/* world pose of a geometry: position + normalised quaternion (world.hpp:238-245) */
+static void geom_pose(const tds_model_t *mb, const scratch_t *s, const tds_geom_t *G, double *pos, double *orn) {
+  xf_t local, tr;
+  memcpy(local.r, G->X_rot, sizeof(local.r));
+  memcpy(local.t, G->X_trans, sizeof(local.t));
+  const xf_t *Xw = G->link >= 0 ? &s->L[G->link].X_world : &s->base_X_world;
+  (void)mb;
+  xf_mul(Xw, &local, &tr);
+  matrix_to_quat(tr.r, orn);
+  quat_normalize(orn);
+  memcpy(pos, tr.t, 3 * sizeof(double));
+}
+
+/* ref: world.hpp:206-282 for the pair (A, B) */
+static int compute_pair_contacts(const tds_model_t *ma, const scratch_t *sa, const tds_model_t *mb, const scratch_t *sb,
+                                 pair_contact_t *out, int cap) {
+  int n = 0;
+  for (int ga = 0; ga < ma->num_geoms; ++ga) {
+    const tds_geom_t *A = &ma->geoms[ga];
+    double pa[3], qa[4];
+    geom_pose(ma, sa, A, pa, qa);
+    for (int gb = 0; gb < mb->num_geoms; ++gb) {
+      const tds_geom_t *B = &mb->geoms[gb];
+      double pb[3], qb[4];
+      geom_pose(mb, sb, B, pb, qb);
+      pair_contact_t c[2];
+      int nc = 0;
+      if (A->type == TDS_GEOM_SPHERE && B->type == TDS_GEOM_SPHERE) {
+        nc = pair_sphere_sphere(pa, A->radius, pb, B->radius, &c[0]);
+      } else if (A->type == TDS_GEOM_CAPSULE && B->type == TDS_GEOM_SPHERE) { /* contact_point.hpp:405-438 */
+        for (int e = 0; e < 2; ++e) {
+          double off[3] = {0.0, 0.0, (e == 0 ? 0.5 : -0.5) * A->length}, ro[3], pe[3];
+          quat_rotate(qa, off, ro);
+          for (int k = 0; k < 3; ++k) pe[k] = pa[k] + ro[k];
+          nc += pair_sphere_sphere(pe, A->radius, pb, B->radius, &c[nc]);
+        }
+      } else if (A->type == TDS_GEOM_SPHERE && B->type == TDS_GEOM_CAPSULE) { /* :478-495: run swapped, then swap back */
+        for (int e = 0; e < 2; ++e) {
+          double off[3] = {0.0, 0.0, (e == 0 ? 0.5 : -0.5) * B->length}, ro[3], pe[3];
+          quat_rotate(qb, off, ro);
+          for (int k = 0; k < 3; ++k) pe[k] = pb[k] + ro[k];
+          pair_contact_t t;
+          if (pair_sphere_sphere(pe, B->radius, pa, A->radius, &t)) {
+            for (int k = 0; k < 3; ++k) {
+              c[nc].point_a[k] = t.point_b[k];
+              c[nc].point_b[k] = t.point_a[k];
+              c[nc].normal[k] = -t.normal[k];
+            }
+            c[nc].distance = t.distance;
+            ++nc;
+          }
+        }
+      }
+      for (int i = 0; i < nc; ++i) {
+        if (n >= cap) return -1;
+        c[i].link_a = A->link;
+        c[i].link_b = B->link;
+        out[n++] = c[i];
+      }
+    }
+  }
+  return n;
+}
+
+/* ref: mb_constraint_solver.hpp:191-498 with two articulated bodies: rows [J_a | J_b], A = J diag(M_a^-1, M_b^-1) J^T,
+   right-hand side from rel_vel = J_a qd_a - J_b qd_b, qd_a += M_a^-1 J_a^T p, qd_b -= M_b^-1 J_b^T p */
+static int resolve_collision_pair(const tds_model_t *m, const tds_model_t *ma, scratch_t *sa, const tds_model_t *mb,
+                                  scratch_t *sb, const pair_contact_t *cps, int n_c) {
+  const int na = ma->dof_qd, nb = mb->dof_qd, nab = na + nb, nr = 3 * n_c;
+  if (n_c == 0 || nab == 0) return 0;
+  if (nr > NR || nab > ND) return -3;
+  mass_matrix(ma, sa);
+  if (!symmetric_inverse(sa->M, sa->Minv, na)) return -1;
+  mass_matrix(mb, sb);
+  if (!symmetric_inverse(sb->M, sb->Minv, nb)) return -1;
+  static _Thread_local double J[NR * ND], JM[NR * ND], A[NR * NR], b[NR], p[NR], lo[NR], hi[NR];
+  static _Thread_local int dep[NR];
+  memset(J, 0, sizeof(double) * nr * nab);
+  memset(b, 0, sizeof(double) * nr);
+  for (int i = 0; i < n_c; ++i) {
+    const pair_contact_t *cp = &cps[i];
+    const double collision = cp->distance < 0.0 ? 1.0 : 0.0;
+    double ja[3 * ND], jb[3 * ND];
+    point_jacobian(ma, sa, cp->link_a, cp->point_a, ja);
+    point_jacobian(mb, sb, cp->link_b, cp->point_b, jb);
+    double vel_a[3] = {0, 0, 0}, vel_b[3] = {0, 0, 0}, rel_vel[3];
+    for (int r = 0; r < 3; ++r) {
+      for (int d = 0; d < na; ++d) vel_a[r] += ja[r * na + d] * sa->qd[d];
+      for (int d = 0; d < nb; ++d) vel_b[r] += jb[r * nb + d] * sb->qd[d];
+      rel_vel[r] = vel_a[r] - vel_b[r];
+    }
+    double dir[3][3], f1[3], f2[3];
+    plane_space(cp->normal, f1, f2);
+    for (int k = 0; k < 3; ++k) {
+      dir[0][k] = cp->normal[k] * collision;
+      dir[1][k] = f1[k] * collision;
+      dir[2][k] = f2[k] * collision;
+    }
+    const double normal_rel_vel = v3_dot(cp->normal, rel_vel);
+    b[i] = (-(1.0 + m->restitution) * normal_rel_vel - m->erp * cp->distance / m->dt) * collision;
+    b[n_c + i] = -v3_dot(dir[1], rel_vel);
+    b[2 * n_c + i] = -v3_dot(dir[2], rel_vel);
+    for (int e = 0; e < 3; ++e) {
+      double *row = J + (size_t)(e * n_c + i) * nab;
+      for (int d = 0; d < na; ++d) row[d] = ja[d] * dir[e][0] + ja[na + d] * dir[e][1] + ja[2 * na + d] * dir[e][2];
+      for (int d = 0; d < nb; ++d) row[na + d] = jb[d] * dir[e][0] + jb[nb + d] * dir[e][1] + jb[2 * nb + d] * dir[e][2];
+    }
+  }
+  /* lcp_A = jac_con * mass_matrix_inv * jac_con_t with the block-diagonal inverse */
+  for (int i = 0; i < nr; ++i)
+    for (int j = 0; j < nab; ++j) {
+      double sum = 0.0;
+      if (j < na)
+        for (int k = 0; k < na; ++k) sum += J[i * nab + k] * sa->Minv[k * na + j];
+      else
+        for (int k = 0; k < nb; ++k) sum += J[i * nab + na + k] * sb->Minv[k * nb + (j - na)];
+      JM[i * nab + j] = sum;
+    }
+  for (int i = 0; i < nr; ++i)
+    for (int j = 0; j < nr; ++j) {
+      double sum = 0.0;
+      for (int k = 0; k < nab; ++k) sum += JM[i * nab + k] * J[j * nab + k];
+      A[i * nr + j] = sum;
+    }
+  for (int i = 0; i < nr; ++i) A[i * nr + i] += m->cfm;
+  for (int i = 0; i < n_c; ++i) {
+    dep[i] = -1; lo[i] = 0.0; hi[i] = 100000.0;
+    lo[n_c + i] = -m->friction; hi[n_c + i] = m->friction; dep[n_c + i] = i;
+    lo[2 * n_c + i] = -m->friction; hi[2 * n_c + i] = m->friction; dep[2 * n_c + i] = i;
+  }
+  memset(p, 0, sizeof(double) * nr);
+  solve_pgs(A, b, p, nr, m->pgs_iterations, lo, hi, dep);
+  double JtP[ND];
+  for (int d = 0; d < nab; ++d) {
+    double sum = 0.0;
+    for (int i = 0; i < nr; ++i) sum += J[i * nab + d] * p[i];
+    JtP[d] = sum;
+  }
+  for (int d = 0; d < na; ++d) {
+    double sum = 0.0;
+    for (int k = 0; k < na; ++k) sum += sa->Minv[d * na + k] * JtP[k];
+    sa->qd[d] += sum;
+  }
+  for (int d = 0; d < nb; ++d) {
+    double sum = 0.0;
+    for (int k = 0; k < nb; ++k) sum += sb->Minv[d * nb + k] * JtP[na + k];
+    sb->qd[d] -= sum;
+  }
+  return 0;
+}
+
+static int step_two(const tds_model_t *m, const double *x, double *y) {
+  if (m->step_mode != TDS_STEP_TAU || m->is_floating) return -2;
+  tds_model_t *sub = (tds_model_t *)malloc(2 * sizeof(tds_model_t));
+  scratch_t *sc = (scratch_t *)malloc(2 * sizeof(scratch_t));
+  if (!sub || !sc) { free(sub); free(sc); return -4; }
+  sub_model(m, 0, &sub[0]);
+  sub_model(m, 1, &sub[1]);
+  const int nq = m->dof_q, nd = m->dof_qd;
+  int oq = 0, od = 0, rc = 0;
+  for (int b = 0; b < 2 && !rc; ++b) {
+    const tds_model_t *mm = &sub[b];
+    scratch_t *s = &sc[b];
+    if (mm->num_links > NL || mm->dof_qd > ND) { rc = -2; break; }
+    memset(s->q, 0, sizeof(s->q)); memset(s->qd, 0, sizeof(s->qd));
+    memset(s->qdd, 0, sizeof(s->qdd)); memset(s->tau, 0, sizeof(s->tau));
+    memcpy(s->base_X_world.r, mm->base_X_world_rot, sizeof(s->base_X_world.r));
+    memcpy(s->base_X_world.t, mm->base_X_world_trans, sizeof(s->base_X_world.t));
+    for (int i = 0; i < mm->num_links; ++i) {
+      if (mm->links[i].joint_type == TDS_JOINT_SPHERICAL) rc = -2;
+      for (int k = 0; k < 3; ++k) { s->L[i].S.a[k] = mm->links[i].S[k]; s->L[i].S.l[k] = mm->links[i].S[3 + k]; }
+    }
+    for (int i = 0; i < mm->dof_q; ++i) s->q[i] = x[oq + i];
+    for (int i = 0; i < mm->dof_qd; ++i) s->qd[i] = x[nq + od + i];
+    for (int i = 0; i < mm->dof_qd; ++i) s->tau[i] = x[nq + nd + od + i];
+    oq += mm->dof_q;
+    od += mm->dof_qd;
+  }
+  for (int b = 0; b < 2 && !rc; ++b) forward_dynamics(&sub[b], &sc[b]);
+  for (int b = 0; b < 2 && !rc; ++b) /* integrate_euler_qdd */
+    for (int i = 0; i < sub[b].num_links; ++i) {
+      const tds_link_t *l = &sub[b].links[i];
+      if (l->joint_type != TDS_JOINT_FIXED) sc[b].qd[l->qd_index] += sc[b].qdd[l->qd_index] * m->dt;
+    }
+  /* World::step: contacts of every body pair first (world.hpp:321-333), then the pairs are resolved in order */
+  static _Thread_local pair_contact_t pcs[TDS_MAX_PAIR_CONTACTS];
+  int npc = 0;
+  if (!rc) {
+    if (m->has_plane)
+      for (int b = 0; b < 2; ++b) compute_contacts(&sub[b], &sc[b]);
+    npc = compute_pair_contacts(&sub[0], &sc[0], &sub[1], &sc[1], pcs, TDS_MAX_PAIR_CONTACTS);
+    if (npc < 0) rc = -3;
+  }
+  if (!rc && m->has_plane)
+    for (int b = 0; b < 2 && !rc; ++b) rc = resolve_collision(&sub[b], &sc[b], NULL); /* plane-A, plane-B */
+  if (!rc) rc = resolve_collision_pair(m, &sub[0], &sc[0], &sub[1], &sc[1], pcs, npc);    /* A-B */
+  if (!rc) {
+    for (int b = 0; b < 2; ++b) /* integrate_euler */
+      for (int i = 0; i < sub[b].num_links; ++i) {
+        const tds_link_t *l = &sub[b].links[i];
+        if (l->joint_type != TDS_JOINT_FIXED) sc[b].q[l->q_index] += sc[b].qd[l->qd_index] * m->dt;
+      }
+    int j = 0;
+    for (int i = 0; i < m->output_dim; ++i) y[i] = 0.0;
+    for (int b = 0; b < 2; ++b)
+      for (int i = 0; i < sub[b].dof_q; ++i) y[j++] = sc[b].q[i];
+    for (int b = 0; b < 2; ++b)
+      for (int i = 0; i < sub[b].dof_qd; ++i) y[j++] = sc[b].qd[i];
+    if (m->pack_visuals) {
+      for (int v = 0; v < m->num_visuals; ++v) {
+        const tds_visual_t *V = &m->visuals[v];
+        const int b = V->link >= m->body1_first_link ? 1 : 0;
+        const int li = V->link - (b ? m->body1_first_link : 0);
+        xf_t lv, vx;
+        double orn[4];
+        memcpy(lv.r, V->X_rot, sizeof(lv.r)); memcpy(lv.t, V->X_trans, sizeof(lv.t));
+        xf_mul(&sc[b].L[li].X_world, &lv, &vx);
+        y[j++] = vx.t[0]; y[j++] = vx.t[1]; y[j++] = vx.t[2];
+        matrix_to_quat(vx.r, orn);
+        y[j++] = orn[0]; y[j++] = orn[1]; y[j++] = orn[2]; y[j++] = orn[3];
+      }
+      y[j++] = sc[0].base_X_world.r[8];
+    }
+  }
+  free(sub);
+  free(sc);
+  return rc;
 }
 
 int tds_oracle_step_debug(const tds_model_t *model, const double *x, double *y,

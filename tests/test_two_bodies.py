@@ -36,6 +36,53 @@ def test_two_body_blob_matches_the_reference_flatten(name, built):
     r.close()
 
 
+@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+def test_oracle_restates_two_body_worlds(name, built):
+    """CPU: oracle/tds_oracle.c (step_two: per-body sub-models, pair narrowphase, two-sided MLCP) against the committed
+    reference outputs and — where the reference is present — against the live reference on fresh states"""
+    import oraclelib
+
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert rel_err(oraclelib.step(m, g["x"]), g["y"]) < 1e-9
+    reflib = pytest.importorskip("reflib")
+    if reflib.available():
+        import gen_golden as gen
+
+        r, m_ref = gen.make_ref(name)
+        x = gen.random_inputs(name, m_ref, 96, np.random.default_rng(777))
+        assert rel_err(oraclelib.step(m, x), r.step(x)) < 1e-9
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+def test_two_body_fresh_states_against_the_oracle(name, built):
+    """2048 fresh states (touching and separated chains, as the fixture generator draws them) against the C oracle"""
+    import torch
+    import oraclelib
+    from tds_amd import hip_backend
+
+    m = tds_amd.load_model(name)
+    n, nq, nd = 2048, m.dof_q, m.dof_qd
+    rng = np.random.default_rng(4321)
+    half = nq // 2
+    amp = 0.25 if m.has_plane else 0.9
+    x = np.zeros((n, m.input_dim))
+    qa = rng.uniform(-amp, amp, (n, half))
+    x[:, :half] = qa
+    x[:, half:nq] = qa + rng.uniform(-0.12, 0.12, (n, half))
+    x[3::4, half:nq] = rng.uniform(-amp, amp, (len(x[3::4]), half))
+    x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
+    x[:, nq + nd:] = rng.uniform(-0.5, 0.5, (n, nd))
+    sim = hip_backend.HipSim(m, n, dtype="f64")
+    y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+    y_ref = oraclelib.step(m, x)
+    moved = np.abs(y_ref[:, nq:nq + nd] - x[:, nq:nq + nd]).max(axis=1) > 0.05   # (contacts act on most states)
+    print(f"{name}: 2048 fresh states, max rel err vs the oracle {rel_err(y, y_ref):.3e}; {int(moved.sum())} with large velocity changes")
+    assert rel_err(y, y_ref) < TOL
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", TWO_BODY_MODELS)
 def test_two_body_single_steps(name, built):
