@@ -111,6 +111,7 @@ struct tds_hip_shard {
   hipStream_t graph_stream = nullptr;
   const void *graph_actions = nullptr;
   int graph_pool = 0, graph_first = 0, graph_steps = 0, graph_block = 0, graph_slot0 = 0, graph_last_slot = -1;
+  bool comm_warm = false;  // an all-gather has run eagerly on the communicator (connections are up)
 
   size_t block_scalars() const { return (size_t)block * n_local * sim->obs_width(); }
 };
@@ -207,6 +208,8 @@ int shard_submit(tds_hip_shard *sh, int slot) {
   if (sh->comm) {
     NCCL_TRY(rccl()->AllGather(sh->wire[slot], sh->gathered[slot], count,
                                sh->wire_bytes == 8 ? ncclFloat64 : ncclFloat32, sh->comm, sh->comm_stream));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(sh->comm_stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) sh->comm_warm = true;
   } else {
     TDS_HIP_TRY(hipMemcpyAsync(sh->gathered[slot], sh->wire[slot], count * sh->wire_bytes, hipMemcpyDeviceToDevice,
                                sh->comm_stream));
@@ -431,6 +434,14 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
     TDS_HIP_TRY(hipStreamSynchronize(sh->comm_stream));
     for (int i = 0; i < kSlots; ++i) sh->pending[i] = false;
     if (!sh->graph_stream) TDS_HIP_TRY(hipStreamCreateWithFlags(&sh->graph_stream, hipStreamNonBlocking));
+    if (sh->comm && !sh->comm_warm) {
+      // the first collective of a communicator sets up its transport connections between the ranks: that must happen
+      // eagerly, not inside a stream capture — one warm-up all-gather of a (scratch) ring slot, on every rank
+      NCCL_TRY(rccl()->AllGather(sh->wire[0], sh->gathered[0], sh->block_scalars(),
+                                 sh->wire_bytes == 8 ? ncclFloat64 : ncclFloat32, sh->comm, sh->comm_stream));
+      TDS_HIP_TRY(hipStreamSynchronize(sh->comm_stream));
+      sh->comm_warm = true;
+    }
     hipStream_t user = s->stream;
     const long long steps0 = sh->steps;
     const int last0 = sh->last_slot;
