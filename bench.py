@@ -141,6 +141,9 @@ def main():
                          "the 1e-6 contract on float records (BASELINE config 2).  f32-pure: float arithmetic "
                          "(measured only: misses 1e-6, like the reference's own float instantiation)")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: K eager launches instead of one hipGraph launch")
+    ap.add_argument("--chains", default="auto",
+                    help="N = 1, graph launches: environment chains of the graph (tds_hip_step_many in tds_hip.h): a number, "
+                         "'default' (the library's rule) or 'auto' = measured during warm-up (tds_hip_step_many_tune)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (16/32/64), 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout-steps", type=int, default=0,
@@ -314,6 +317,13 @@ def main():
         if multi:
             shard.flush()
 
+    chains = None
+    if use_graph and not multi:
+        if args.chains == "auto":  # 6 x 128 extra untimed steps
+            chains = sim.tune_step_many(actions, 128, obs)
+        elif args.chains != "default":
+            chains = int(args.chains)
+            sim.set_graph_chains(chains)
     prepare(args.warmup)
     run_steps(args.warmup)
     flush()
@@ -448,7 +458,9 @@ def main():
                                    f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
                        if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
                        "records": "f64" if args.dtype == "f64" else "f32",
-                       "launch": (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else ""))
+                       "launch": (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else "")
+                                   + ("" if chains is None else ", the batch as %d independent environment chain%s (%s)" % (
+                                       chains, "" if chains == 1 else "s", "measured at warm-up" if args.chains == "auto" else "--chains")))
                                   if use_graph else "one kernel launch per step"),
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
                        "parallelism": f"env-shard x{world}" + (

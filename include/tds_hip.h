@@ -292,11 +292,24 @@ int tds_hip_obs_dim(const tds_hip_sim_t *sim);
      actions_dev  [action_blocks][N][action_dim] (record dtype) or NULL; step k uses block (first_block + k) % action_blocks
      obs_dev      optional [N][obs_dim + 2], overwritten by every step (holds the last step's record afterwards)
    The graph is cached on the handle (keyed by all arguments); _prepare builds it without running anything, so that a
-   timed region holds the launch only.  n_steps <= 4096. */
+   timed region holds the launch only.  n_steps <= 4096.
+
+   Environment chains.  The environments are independent and the call holds n_steps steps of each, so the batch need
+   not move in lockstep: the library splits it into C contiguous environment ranges ("chains"), captures one linear
+   graph per chain and replays them concurrently on C streams forked from / joined to the handle's stream.  While one
+   chain sits at a kernel boundary (launch latency, workgroup dispatch ramp, the wait for its slowest workgroup: ~3 us
+   of a 20 us Ant x 4096 step) the other chains' workgroups have the compute units to themselves.  Records are bit
+   for bit those of whole-batch launches.  C: tds_hip_set_graph_chains (0 = library default: 2 for models with
+   contact points, 1 otherwise; environment TDS_HIP_GRAPH_CHAINS overrides), or measured on the spot by
+   tds_hip_step_many_tune, which runs probe_steps steps (advancing the simulation) once untimed and once timed for
+   C = 1, 2, 3, keeps the fastest and returns it in *chains. */
 int tds_hip_step_many_prepare(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int first_block,
                               int n_steps, void *obs_dev);
 int tds_hip_step_many(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int first_block, int n_steps,
                       void *obs_dev);
+int tds_hip_set_graph_chains(tds_hip_sim_t *sim, int chains);
+int tds_hip_step_many_tune(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int probe_steps,
+                           void *obs_dev, int *chains);
 
 /* On-device environment reset — replaces the host loop of VectorizedEnvironment::reset / the
    auto-reset branch of VectorizedEnvironment::step (ars_vectorized_environment.h:196-211, 262-277).
@@ -377,7 +390,10 @@ int tds_hip_last_kernel_ms(tds_hip_sim_t *sim, float *ms);
    (A load + PD, B jcalc, C kinematics sweep, I narrowphase + visuals + D inertias, E composite
     inertia / bias force sweep, G mass matrix, H LDL^T, F forward-dynamics solve, (sync), J Jacobian rows,
     K row solves, L PGS, M pack, end).
-   Synchronises the stream. */
+   With n >= 28 and a grid the two-wavefront workgroups serve, THAT form is profiled: 0..13 are the main
+   wavefront's stamps (3 -> 4, 7 -> 8 and 8 -> 9 contain the three workgroup barriers), 14..22 the helper's (start,
+   constants loaded = before barrier 1, after barrier 1, narrowphase, visual poses + y tail, Jacobian rows = before
+   barrier 2, after barrier 2, row solves = before barrier 3, after barrier 3).  Synchronises the stream. */
 int tds_hip_profile_phases(tds_hip_sim_t *sim, long long *cycles_host, int n);
 
 /* Static resource usage of the step kernel for this handle (for DESIGN.md / bench). */

@@ -192,6 +192,53 @@ def test_step_many_graph_equals_eager_launches(dtype, built):
     assert graph.last_kernel_ms() > 0.0
 
 
+@pytest.mark.parametrize("chains,n", [("1", 100), ("3", 100), ("8", 100), ("8", 20), ("2", 2052)])
+def test_step_many_environment_chains_equal_whole_batch_launches(chains, n, built, monkeypatch):
+    """The graph's C environment chains (contiguous ranges, one branch each) leave bit for bit the records of K
+    whole-batch launches, whatever C and however unevenly the workgroups divide (2052 envs: slab for surplus rows
+    in play, one-wavefront / two-wavefront form chosen on the whole batch)."""
+    torch = _torch()
+    monkeypatch.setenv("TDS_HIP_GRAPH_CHAINS", chains)
+    m = tds_amd.load_model("ant")
+    x, acts = _start(m, n, seed=5)
+    a = torch.from_numpy(acts).cuda().contiguous()
+    eager, graph = hip_backend.HipSim(m, n), hip_backend.HipSim(m, n)
+    for s in (eager, graph):
+        s.x.copy_(torch.from_numpy(x).cuda())
+    oe = torch.zeros((n, eager.obs_dim + 2), dtype=torch.float64, device="cuda")
+    og = torch.zeros_like(oe)
+    K = 40
+    for k in range(K):
+        eager.step(a[k % 6], 1, oe)
+    graph.step_many(a, K, og, first_block=0)
+    torch.cuda.synchronize()
+    assert torch.equal(graph.x, eager.x) and torch.equal(graph.y, eager.y) and torch.equal(og, oe)
+
+
+def test_step_many_tune_picks_a_chain_count_and_keeps_the_records(built):
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    n = 512
+    x, acts = _start(m, n, seed=9)
+    a = torch.from_numpy(acts).cuda().contiguous()
+    eager, graph = hip_backend.HipSim(m, n), hip_backend.HipSim(m, n)
+    for s in (eager, graph):
+        s.x.copy_(torch.from_numpy(x).cuda())
+    c = graph.tune_step_many(a, probe_steps=12)  # 6 x 12 steps, every probe from action block 0
+    assert 1 <= c <= 3
+    for rep in range(6):
+        for k in range(12):
+            eager.step(a[k % 6])
+    assert torch.equal(graph.x, eager.x)
+    graph.step_many(a, 30, first_block=1)
+    for k in range(30):
+        eager.step(a[(1 + k) % 6])
+    torch.cuda.synchronize()
+    assert torch.equal(graph.x, eager.x) and torch.equal(graph.y, eager.y)
+    with pytest.raises(Exception):
+        graph.set_graph_chains(9)
+
+
 @pytest.mark.parametrize("with_rccl", [False, True])
 def test_shard_step_many_graph_equals_eager_exchange(with_rccl, built):
     """the two-stream step + all-gather pattern captured into one hipGraph (RCCL all-gathers as graph nodes)"""

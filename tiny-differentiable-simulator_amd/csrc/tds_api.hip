@@ -100,11 +100,25 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   const hipStream_t stream = (opts && opts->other_stream) ? opts->stream : s->stream;
   // two-wavefront workgroups: plain straight-line launches whose whole grid is resident at once (the helper wavefront
   // then fills issue slots that would otherwise idle; beyond that the one-wave form with more workgroups per CU wins)
-  const int n_blocks = (n + (64 / s->lanes) - 1) / (64 / s->lanes);
+  const int n_resident = (opts && opts->env_total > 0) ? opts->env_total : n;
+  const int n_blocks = (n_resident + (64 / s->lanes) - 1) / (64 / s->lanes);
   const bool two_waves = s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && nsub == 1 &&
                          reset_mode == TDS_RESET_NONE && !ro && !(opts && opts->lds);
   const TdsLds &lds = (opts && opts->lds) ? *opts->lds : (two_waves ? s->lds_w2 : s->lds);
-  void *const ovf = (opts && opts->lds) ? nullptr : s->d_ovf;
+  void *ovf = (opts && opts->lds) ? nullptr : s->d_ovf;
+  if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along
+    const size_t e0 = (size_t)opts->env_first, el = s->elem;
+    auto at = [&](const void *p, size_t per_env, size_t bytes) -> void * {
+      return p ? (void *)((const char *)p + e0 * per_env * bytes) : nullptr;
+    };
+    x = at(x, s->model.input_dim, el);
+    y = at(y, s->model.output_dim, el);
+    actions = at(actions, s->model.action_dim, el);
+    fb = at(fb, s->model.input_dim, el);
+    obs = at(obs, s->obs_width(), el);
+    ovf = at(ovf, (size_t)s->lds.ovrows * (s->lds.NDs + 3), s->compute_f64() ? 8 : 4);
+    if (mask || ro) return fail(TDS_ERR_INVALID_ARG, "environment sub-ranges: plain steps only");
+  }
   if (ro) {
     ctl.policy = ro->policy;
     ctl.ret_sum = ro->ret_sum;
@@ -296,8 +310,14 @@ int tds_hip_destroy(tds_hip_sim_t *s) {
   if (!s) return TDS_OK;
   DeviceGuard guard(s->device);
   pool_free(s);
-  if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+  for (int c = 0; c < tds_hip_sim::kMaxChains; ++c)
+    if (s->graph_exec[c]) (void)hipGraphExecDestroy(s->graph_exec[c]);
   if (s->graph_stream) (void)hipStreamDestroy(s->graph_stream);
+  for (int c = 0; c < tds_hip_sim::kMaxChains - 1; ++c) {
+    if (s->graph_chain[c]) (void)hipStreamDestroy(s->graph_chain[c]);
+    if (s->graph_join[c]) (void)hipEventDestroy(s->graph_join[c]);
+  }
+  if (s->graph_fork) (void)hipEventDestroy(s->graph_fork);
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->d_x) (void)hipFree(s->d_x);
   if (s->d_y) (void)hipFree(s->d_y);
@@ -704,48 +724,92 @@ int tds_hip_step_obs(tds_hip_sim_t *s, const void *actions_dev, int substeps, vo
 extern "C++" {
 namespace {
 int graph_matches(const tds_hip_sim *s, const void *actions, int pool, int first, int n_steps, void *obs) {
-  return s->graph_exec && s->graph_actions == actions && s->graph_pool == pool && s->graph_first == first &&
+  return s->graph_exec[0] && s->graph_actions == actions && s->graph_pool == pool && s->graph_first == first &&
          s->graph_steps == n_steps && s->graph_obs == obs;
 }
+// The environments are independent and a step_many call holds K steps of each: enqueue them as C chains (contiguous
+// environment ranges, one stream / graph branch each) instead of K whole-batch launches.  A chain's kernel boundary
+// (launch latency ~1.1 us, workgroup dispatch ramp ~1.4 us, the wait for its slowest workgroup ~1 us: a sixth of a
+// 20 us step, profiles/r02d_*) is then filled by the other chains' workgroups instead of idling the whole GPU.
+int chain_count(const tds_hip_sim *s, int n_steps) {
+  const int epb = 64 / s->lanes, n_blocks = (s->num_envs + epb - 1) / epb;
+  // default: two chains for models with contact points (Ant x 2048 ... 16384: +4 ... +24 %, laikago_soft x 8192 +22 %;
+  // a kernel as short as pendulum5's 11 us loses 15 %: profiles/r02d_graph_chains.txt); four and more chains collapse
+  int c = s->chains_wanted > 0 ? s->chains_wanted : (s->model.num_geoms > 0 && s->model.has_plane ? 2 : 1);
+  if (const char *ce = getenv("TDS_HIP_GRAPH_CHAINS")) c = atoi(ce);
+  if (c > tds_hip_sim::kMaxChains) c = tds_hip_sim::kMaxChains;
+  if (c > n_blocks) c = n_blocks;
+  if (c < 1 || n_steps < 2) c = 1;
+  return c;
+}
+int chain_streams(tds_hip_sim *s, int n_chains) {
+  if (n_chains > 1 && !s->graph_fork) HIP_TRY(hipEventCreateWithFlags(&s->graph_fork, hipEventDisableTiming));
+  for (int c = 1; c < n_chains; ++c) {
+    if (!s->graph_chain[c - 1]) HIP_TRY(hipStreamCreateWithFlags(&s->graph_chain[c - 1], hipStreamNonBlocking));
+    if (!s->graph_join[c - 1]) HIP_TRY(hipEventCreateWithFlags(&s->graph_join[c - 1], hipEventDisableTiming));
+  }
+  return TDS_OK;
+}
+// K steps of chain c of C on `stream`
+int enqueue_chain(tds_hip_sim *s, int c, int C, hipStream_t stream, const void *actions, int pool, int first, int n_steps,
+                  void *obs) {
+  const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
+  const int epb = 64 / s->lanes, n_blocks = (s->num_envs + epb - 1) / epb;
+  const int b0 = (int)((long long)n_blocks * c / C), b1 = (int)((long long)n_blocks * (c + 1) / C);
+  const int e0 = b0 * epb, e1 = (b1 * epb < s->num_envs) ? b1 * epb : s->num_envs;
+  if (e1 <= e0) return TDS_OK;
+  LaunchOpts lo;
+  lo.env_total = s->num_envs;
+  lo.env_first = e0;
+  lo.other_stream = true;
+  lo.stream = stream;
+  for (int k = 0; k < n_steps; ++k) {
+    const void *a = actions ? (const char *)actions + (size_t)((first + k) % pool) * blk : nullptr;
+    const int rc = launch(s, s->d_x, s->d_y, a, s->d_x, obs, e1 - e0, 1, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
+    if (rc != TDS_OK) return rc;
+  }
+  return TDS_OK;
+}
+
+void drop_graphs(tds_hip_sim *s) {
+  for (int c = 0; c < tds_hip_sim::kMaxChains; ++c) {
+    if (s->graph_exec[c]) (void)hipGraphExecDestroy(s->graph_exec[c]);
+    s->graph_exec[c] = nullptr;
+  }
+  s->graph_chains = 0;
+}
+
+// one LINEAR graph per chain (a single graph with parallel branches costs ~2 us more per step than the same chains
+// as independent launches, tools/ubench/two_streams.hip; linear graphs replay at the single-stream rate)
 int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_steps, void *obs) {
-  if (s->graph_exec) {
-    (void)hipGraphExecDestroy(s->graph_exec);
-    s->graph_exec = nullptr;
-  }
+  drop_graphs(s);
   if (!s->graph_stream) HIP_TRY(hipStreamCreateWithFlags(&s->graph_stream, hipStreamNonBlocking));
-  // capture on a private stream (the handle's stream may be the NULL stream, which cannot be captured);
-  // the launches are recorded, not executed
-  hipStream_t user = s->stream;
-  s->stream = s->graph_stream;
-  hipGraph_t graph = nullptr;
-  hipError_t e = hipStreamBeginCapture(s->graph_stream, hipStreamCaptureModeThreadLocal);
-  int rc = TDS_OK;
-  if (e == hipSuccess) {
-    const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
-    for (int k = 0; k < n_steps && rc == TDS_OK; ++k) {
-      const void *a = actions ? (const char *)actions + (size_t)((first + k) % pool) * blk : nullptr;
-      rc = launch(s, s->d_x, s->d_y, a, s->d_x, obs, s->num_envs, 1, TDS_RESET_NONE, nullptr);
+  const int n_chains = chain_count(s, n_steps);
+  int rc = chain_streams(s, n_chains);
+  if (rc != TDS_OK) return rc;
+  for (int c = 0; c < n_chains; ++c) {
+    // capture on a private stream (the handle's stream may be the NULL stream, which cannot be captured);
+    // the launches are recorded, not executed
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(s->graph_stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      rc = enqueue_chain(s, c, n_chains, s->graph_stream, actions, pool, first, n_steps, obs);
+      e = hipStreamEndCapture(s->graph_stream, &graph);
     }
-    e = hipStreamEndCapture(s->graph_stream, &graph);
-  }
-  s->stream = user;
-  if (e != hipSuccess || rc != TDS_OK || !graph) {
+    if (e == hipSuccess && rc == TDS_OK && graph) e = hipGraphInstantiate(&s->graph_exec[c], graph, nullptr, nullptr, 0);
     if (graph) (void)hipGraphDestroy(graph);
-    if (rc == TDS_OK) snprintf(g_err, sizeof(g_err), "graph capture failed: %s", hipGetErrorString(e));
-    return TDS_ERR_HIP;
-  }
-  e = hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (e != hipSuccess) {
-    s->graph_exec = nullptr;
-    snprintf(g_err, sizeof(g_err), "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-    return TDS_ERR_HIP;
+    if (e != hipSuccess || rc != TDS_OK || !s->graph_exec[c]) {
+      if (rc == TDS_OK) snprintf(g_err, sizeof(g_err), "graph capture / instantiation failed: %s", hipGetErrorString(e));
+      drop_graphs(s);
+      return TDS_ERR_HIP;
+    }
   }
   s->graph_actions = actions;
   s->graph_pool = pool;
   s->graph_first = first;
   s->graph_steps = n_steps;
   s->graph_obs = obs;
+  s->graph_chains = n_chains;
   return TDS_OK;
 }
 }  // namespace
@@ -766,12 +830,89 @@ int tds_hip_step_many_prepare(tds_hip_sim_t *s, const void *actions_dev, int act
 
 int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block, int n_steps,
                       void *obs_dev) {
-  int rc = tds_hip_step_many_prepare(s, actions_dev, action_blocks, first_block, n_steps, obs_dev);
-  if (rc != TDS_OK) return rc;
+  const char *em = getenv("TDS_HIP_STEP_MANY_EAGER");  // (diagnostic: the same chains as plain stream launches)
+  const bool eager = em && em[0] == '1';
+  if (!eager) {
+    int rc = tds_hip_step_many_prepare(s, actions_dev, action_blocks, first_block, n_steps, obs_dev);
+    if (rc != TDS_OK) return rc;
+  } else if (!s || n_steps < 1 || s->auto_reset || (actions_dev && action_blocks < 1)) {
+    return fail(TDS_ERR_INVALID_ARG, "step_many: bad arguments");
+  }
   DeviceGuard guard(s->device);
   TimedCall timed(s);
-  HIP_TRY(hipGraphLaunch(s->graph_exec, s->stream));
+  const int pool = actions_dev ? action_blocks : 1;
+  const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
+  const int C = eager ? chain_count(s, n_steps) : s->graph_chains;
+  if (eager) {
+    int rc = chain_streams(s, C);
+    if (rc != TDS_OK) return rc;
+  }
+  // chain 0 runs on the handle's stream, the others on their own streams forked from / joined to it
+  if (C > 1) {
+    HIP_TRY(hipEventRecord(s->graph_fork, s->stream));
+    for (int c = 1; c < C; ++c) HIP_TRY(hipStreamWaitEvent(s->graph_chain[c - 1], s->graph_fork, 0));
+  }
+  if (eager) {
+    for (int k = 0; k < n_steps; ++k)  // (step by step, so that every stream has work from the start)
+      for (int c = 0; c < C; ++c) {
+        const int rc = enqueue_chain(s, c, C, c ? s->graph_chain[c - 1] : s->stream, actions_dev, pool, first + k, 1, obs_dev);
+        if (rc != TDS_OK) return rc;
+      }
+  } else {
+    for (int c = C - 1; c >= 0; --c) HIP_TRY(hipGraphLaunch(s->graph_exec[c], c ? s->graph_chain[c - 1] : s->stream));
+  }
+  for (int c = 1; c < C; ++c) {
+    HIP_TRY(hipEventRecord(s->graph_join[c - 1], s->graph_chain[c - 1]));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->graph_join[c - 1], 0));
+  }
   return TDS_OK;
+}
+
+int tds_hip_set_graph_chains(tds_hip_sim_t *s, int chains) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  if (chains < 0 || chains > tds_hip_sim::kMaxChains) return fail(TDS_ERR_INVALID_ARG, "chains must be in 0..8");
+  if (chains != s->chains_wanted) {
+    DeviceGuard guard(s->device);
+    drop_graphs(s);
+  }
+  s->chains_wanted = chains;
+  return TDS_OK;
+}
+
+int tds_hip_step_many_tune(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int probe_steps, void *obs_dev,
+                           int *chains) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  if (probe_steps < 2 || probe_steps > 4096) return fail(TDS_ERR_INVALID_ARG, "probe_steps must be in 2..4096");
+  DeviceGuard guard(s->device);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  const bool timing = s->timing;
+  s->timing = false;
+  int best = 1, rc = TDS_OK;
+  float best_ms = 0.0f;
+  for (int c = 1; c <= 3 && rc == TDS_OK; ++c) {
+    rc = tds_hip_set_graph_chains(s, c);
+    if (rc == TDS_OK) rc = tds_hip_step_many(s, actions_dev, action_blocks, 0, probe_steps, obs_dev);  // builds, warms up
+    if (rc != TDS_OK) break;
+    hipError_t e = hipEventRecord(e0, s->stream);
+    rc = tds_hip_step_many(s, actions_dev, action_blocks, 0, probe_steps, obs_dev);
+    if (e == hipSuccess) e = hipEventRecord(e1, s->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess) rc = fail(TDS_ERR_HIP, "timing the probe failed: %s", hipGetErrorString(e));
+    if (rc == TDS_OK && (c == 1 || ms < best_ms)) {
+      best = c;
+      best_ms = ms;
+    }
+  }
+  s->timing = timing;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != TDS_OK) return rc;
+  if (chains) *chains = best;
+  return tds_hip_set_graph_chains(s, best);
 }
 
 int tds_hip_set_auto_reset(tds_hip_sim_t *s, int enable, unsigned long long seed) {
@@ -1050,31 +1191,38 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   if (!s || !cycles_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (n < TDS_NUM_PHASE_STAMPS) return fail(TDS_ERR_INVALID_ARG, "need room for 14 stamps");
   DeviceGuard guard(s->device);
+  // room for 2 x 14 stamps and a grid the two-wavefront form serves: profile THAT form (14..: the helper wavefront)
+  const int n_blocks = (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
+  const bool two_waves = n >= 2 * TDS_NUM_PHASE_STAMPS && s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks;
+  // (two-wavefront form: + the 100 MHz wall clock at the first / last stamp of EVERY workgroup, 28 + 2 b + {0, 1})
+  const int ns = two_waves ? 2 * TDS_NUM_PHASE_STAMPS + 2 * n_blocks : TDS_NUM_PHASE_STAMPS;
+  const TdsLds &lds = two_waves ? s->lds_w2 : s->lds;
   long long *d = nullptr;
-  HIP_TRY(hipMalloc(&d, sizeof(long long) * TDS_NUM_PHASE_STAMPS));
-  HIP_TRY(hipMemset(d, 0, sizeof(long long) * TDS_NUM_PHASE_STAMPS));
+  HIP_TRY(hipMalloc(&d, sizeof(long long) * ns));
+  HIP_TRY(hipMemset(d, 0, sizeof(long long) * ns));
   TdsStepCtl ctl;
   memset(&ctl, 0, sizeof(ctl));
   ctl.nsub = 1;
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
-    rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes,
+    rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                          (const double *)s->d_x, (double *)s->d_y, nullptr, nullptr, nullptr,
-                                         (double *)s->d_ovf, s->num_envs, s->stream, ctl, d);
+                                         (double *)s->d_ovf, s->num_envs, s->stream, ctl, d, two_waves);
   else if (s->dtype == TDS_DTYPE_F64_REC32)
-    rc = tds_launch_step<double, float>((const DevModel<double> *)s->d_model, s->h64, s->lds, s->lanes,
+    rc = tds_launch_step<double, float>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                         (const float *)s->d_x, (float *)s->d_y, nullptr, nullptr, nullptr,
-                                        (double *)s->d_ovf, s->num_envs, s->stream, ctl, d);
+                                        (double *)s->d_ovf, s->num_envs, s->stream, ctl, d, two_waves);
   else
-    rc = tds_launch_step<float, float>((const DevModel<float> *)s->d_model, s->h32, s->lds, s->lanes,
+    rc = tds_launch_step<float, float>((const DevModel<float> *)s->d_model, s->h32, lds, s->lanes,
                                        (const float *)s->d_x, (float *)s->d_y, nullptr, nullptr, nullptr,
-                                       (float *)s->d_ovf, s->num_envs, s->stream, ctl, d);
+                                       (float *)s->d_ovf, s->num_envs, s->stream, ctl, d, two_waves);
   if (rc != 0) {
     (void)hipFree(d);
     return fail(TDS_ERR_HIP, "profiling launch failed");
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipMemcpy(cycles_host, d, sizeof(long long) * TDS_NUM_PHASE_STAMPS, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) cycles_host[i] = 0;
+  HIP_TRY(hipMemcpy(cycles_host, d, sizeof(long long) * (ns < n ? ns : n), hipMemcpyDeviceToHost));
   (void)hipFree(d);
   return TDS_OK;
 }

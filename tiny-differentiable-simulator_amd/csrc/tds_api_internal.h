@@ -50,11 +50,17 @@ struct tds_hip_sim {
   bool pool_ready = false;     // false: fill the pool completely before the next auto-reset step
   bool pool_discard = true;    // the entries in the rings are void (first use, new seed): start from empty rings
   // K-steps-per-launch graph cache (tds_hip_step_many)
-  hipGraphExec_t graph_exec = nullptr;
   const void *graph_actions = nullptr;
   void *graph_obs = nullptr;
   int graph_pool = 0, graph_steps = 0, graph_first = 0;
   hipStream_t graph_stream = nullptr;
+  // the graph's environment chains (see build_graph): chain c > 0 is captured on graph_chain[c - 1]
+  static constexpr int kMaxChains = 8;
+  hipGraphExec_t graph_exec[kMaxChains] = {};  // one linear graph per chain
+  hipStream_t graph_chain[kMaxChains - 1] = {};
+  hipEvent_t graph_fork = nullptr, graph_join[kMaxChains - 1] = {};
+  int graph_chains = 0;
+  int chains_wanted = 0;  // tds_hip_set_graph_chains / _tune (0: library default)
 
   bool compute_f64() const { return dtype != TDS_DTYPE_F32; }
   bool records_f64() const { return dtype == TDS_DTYPE_F64; }
@@ -101,6 +107,8 @@ struct LaunchOpts {
   bool other_stream = false;          // launch on `stream` instead of the handle's
   hipStream_t stream = nullptr;
   const TdsLds *lds = nullptr;        // LDS layout (the refill launches keep every constraint row in LDS: no slab)
+  int env_first = 0;                  // this launch serves environments [env_first, env_first + n) of the records
+  int env_total = 0;                  // (> 0: environments of ALL launches resident at the same time, for the form choice)
 };
 
 // enqueue one launch of the step kernel on the handle's stream (device already selected by the caller)

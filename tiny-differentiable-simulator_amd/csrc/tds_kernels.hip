@@ -669,7 +669,16 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
     if (PROF) {                                                             \
       __builtin_amdgcn_sched_barrier(0);                                    \
       __builtin_amdgcn_s_waitcnt(0);                                        \
-      if (blockIdx.x == 0 && threadIdx.x == 0 && tds_iter == 0) prof[k] = (long long)__builtin_amdgcn_s_memtime(); \
+      if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tds_iter == 0)     \
+        prof[(threadIdx.x >> 6) * TDS_NUM_PHASE_STAMPS + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
+      if constexpr (W2 && ((k) == 0 || (k) == 13)) { /* 23..27: wall clock (100 MHz) of workgroup 0, last workgroup */ \
+        if (threadIdx.x == 0 && blockIdx.x == 0) prof[23 + ((k) == 13)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        if (threadIdx.x == 0) prof[28 + 2 * blockIdx.x + ((k) == 13)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {              \
+          prof[25 + ((k) == 13)] = (long long)__builtin_amdgcn_s_memtime(); \
+          if ((k) == 13) prof[27] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        }                                                                   \
+      }                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                    \
     }                                                                       \
   } while (0)
@@ -710,7 +719,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
                                                       TR *__restrict__ obs_out, T *ovf, long long *prof, TdsStepCtl ctl, int n_envs) {
   constexpr bool LOOP = LP != 0;
-  static_assert(!W2 || (LP == 0 && KIND == 0 && !PROF && NDP < 24), "two-wavefront workgroups: plain straight-line kernels");
+  static_assert(!W2 || (LP == 0 && KIND == 0 && NDP < 24), "two-wavefront workgroups: plain straight-line kernels");
   extern __shared__ __align__(16) unsigned char tds_smem_raw[];
   T *const sm = reinterpret_cast<T *>(tds_smem_raw);
   constexpr int EPW = 64 / G;
@@ -1296,7 +1305,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   if constexpr (W2) {
     if (wv == 1) {
       // ================= helper wavefront of a two-wavefront workgroup =================
+      TDS_STAMP(1);
       __syncthreads();  // (1) the main wavefront has written the x record, X_world and the motion axes
+      TDS_STAMP(2);
       T *const cpx = E + L.cp;
       T *const Zs = E + L.Z;
       T *const rws = E + L.rows;
@@ -1309,6 +1320,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         xr[in_dim + 2] = bits_to_scalar<T>((unsigned)na_h);
         xr[in_dim + 3] = bits_to_scalar<T>((unsigned)NA_h);
       }
+      TDS_STAMP(3);
       phase_M1();
       if (last_run && y_out != nullptr) {  // tail of the y record: up_dot_world_z, zero padding
         TR *const yo = y_out + (size_t)env * out_dim;
@@ -1320,12 +1332,17 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         }
         for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
       }
+      TDS_STAMP(4);
       if (contacts_h && split_ok) phase_J(na_h, NA_h);
+      TDS_STAMP(5);
       __syncthreads();  // (2) the factors L, 1/D are in LDS; the rows and the contact list are visible to the main wavefront
+      TDS_STAMP(6);
       if (contacts_h && split_ok)
         tds_row_solve<false, T, G, NDP, true>(lane, NA_h, na_h, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, E + L.Lp,
                                              E + L.dinv, nullptr, nullptr, pf_cfm, pf_erp_dt, pf_rest);
+      TDS_STAMP(7);
       __syncthreads();  // (3) z~ rows and their scalars are final
+      TDS_STAMP(8);
       return;
     }
   }
@@ -2597,6 +2614,11 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
     if constexpr (KIND == 0 && NN < 24) {                                                                    \
       if (two_waves && simple && !prof) {                                                                    \
         hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 0, 0, true>), dim3(blocks), dim3(128), shmem, \
+                           stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
+        break;                                                                                               \
+      }                                                                                                      \
+      if (two_waves && simple && prof) {                                                                     \
+        hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), true, 0, 0, true>), dim3(blocks), dim3(128), shmem, \
                            stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
         break;                                                                                               \
       }                                                                                                      \

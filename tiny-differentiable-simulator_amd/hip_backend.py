@@ -78,6 +78,8 @@ def lib():
         L.tds_hip_forward_zero_host_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         for f in ("tds_hip_step_many_prepare", "tds_hip_step_many"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.tds_hip_set_graph_chains.argtypes = [C.c_void_p, C.c_int]
+        L.tds_hip_step_many_tune.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         # multi-GPU shards (RCCL all-gather of the observation records)
         L.tds_hip_shard_unique_id.argtypes = [C.c_void_p]
         L.tds_hip_shard_create.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -110,6 +112,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
     "tds_hip_device", "tds_hip_record_bytes", "tds_hip_sync", "tds_hip_forward_zero_host_begin",
     "tds_hip_forward_zero_host_end", "tds_hip_step_many_prepare", "tds_hip_step_many",
+    "tds_hip_set_graph_chains", "tds_hip_step_many_tune",
     "tds_hip_shard_rccl_version", "tds_hip_shard_unique_id", "tds_hip_shard_create", "tds_hip_shard_create_all",
     "tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
     "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes", "tds_hip_shard_set_block",
@@ -252,6 +255,18 @@ class HipSim:
         ``actions[(first_block + k) % len(actions)]`` ([B, N, action_dim] device tensor, or None)."""
         ap, nb, op = self._many_args(actions, obs)
         _check(lib().tds_hip_step_many(self.h, ap, nb, int(first_block), int(n_steps), op))
+
+    def set_graph_chains(self, chains: int):
+        """Environment chains of the step_many graphs (0: library default); see tds_hip_step_many in tds_hip.h."""
+        _check(lib().tds_hip_set_graph_chains(self.h, int(chains)))
+
+    def tune_step_many(self, actions, probe_steps: int = 64, obs=None) -> int:
+        """Measure 1, 2 and 3 chains on ``probe_steps`` steps each (the simulation ADVANCES by 6 x probe_steps steps),
+        keep the fastest for later step_many calls and return it."""
+        ap, nb, op = self._many_args(actions, obs)
+        c = C.c_int()
+        _check(lib().tds_hip_step_many_tune(self.h, ap, nb, int(probe_steps), op, C.byref(c)))
+        return c.value
 
     def _many_args(self, actions, obs):
         ap, nb, op = None, 1, None
@@ -400,6 +415,23 @@ class HipSim:
         _check(lib().tds_hip_profile_phases(self.h, buf, 14))
         st = list(buf)
         return {name: st[i + 1] - st[i] for i, name in enumerate(self.PHASES)}
+
+    def profile_phases_two_waves(self):
+        """Raw stamp timelines (shader-clock cycles since the main wavefront's first stamp) of both wavefronts of
+        workgroup 0 in the two-wavefront form; None when that form does not serve this grid."""
+        nb = (self.num_envs + self.kernel_info()["envs_per_block"] - 1) // self.kernel_info()["envs_per_block"]
+        buf = (C.c_longlong * (28 + 2 * nb))()
+        _check(lib().tds_hip_profile_phases(self.h, buf, 28 + 2 * nb))
+        st = list(buf)
+        if st[14] == 0:
+            return None
+        t0 = st[0]
+        # 23, 24: 100 MHz wall clock at workgroup 0's first / last stamp; 25, 26: shader clock at the LAST workgroup's
+        # first / last stamp; 27: wall clock at its last stamp
+        extra = dict(wg0_wall_us=(st[24] - st[23]) / 100.0, last_wg_start=st[25] - t0, last_wg_end=st[26] - t0,
+                     last_wg_end_wall_us=(st[27] - st[23]) / 100.0,
+                     wg_start_us=[(v - st[23]) / 100.0 for v in st[28::2]], wg_end_us=[(v - st[23]) / 100.0 for v in st[29::2]])
+        return [v - t0 for v in st[:14]], [v - t0 for v in st[14:23]], extra
 
     def kernel_info(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()

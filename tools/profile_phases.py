@@ -61,3 +61,28 @@ if m.has_plane:
               f"  wave 0: {wmax[0]}")
     except Exception as e:  # diagnostic only
         print("  (contact statistics unavailable:", e, ")")
+tw = sim.profile_phases_two_waves()
+if tw is not None:
+    MAIN = ["start", "constants loaded", "A load + PD", "B jcalc", "C kinematics  (-> barrier 1)", "D inertias",
+            "E composite sweep", "G mass matrix", "H LDLt  (-> barrier 2)", "F solve  (-> barrier 3)", "after barrier 3",
+            "(sync)", "right-hand sides", "L PGS", "M/N integrate + pack"]
+    HELP = ["start", "constants loaded  (-> barrier 1)", "after barrier 1", "I narrowphase", "M1 visual poses + y tail",
+            "J rows  (-> barrier 2)", "after barrier 2", "K row solves  (-> barrier 3)", "after barrier 3"]
+    print("two-wavefront form, workgroup 0: cycle at which each phase ENDS (0 = the main wavefront's first stamp)")
+    ex = tw[2]
+    print(f"  workgroup 0 first -> last stamp: {tw[0][13]} shader cycles in {ex['wg0_wall_us']:.2f} us of the 100 MHz wall clock"
+          f" = {tw[0][13] / max(ex['wg0_wall_us'], 1e-9):.0f} MHz; last workgroup: starts at cycle {ex['last_wg_start']}, "
+          f"ends at {ex['last_wg_end']} ({ex['last_wg_end_wall_us']:.2f} us after workgroup 0's start)")
+    ws, we = np.array(ex["wg_start_us"]), np.array(ex["wg_end_us"])
+    dur = we - ws
+    print(f"  all {len(ws)} workgroups (100 MHz wall clock, us relative to workgroup 0's first stamp): first start {ws.min():.2f}, "
+          f"last start {ws.max():.2f}, first end {we.min():.2f}, last end {we.max():.2f}; duration min {dur.min():.2f} "
+          f"mean {dur.mean():.2f} max {dur.max():.2f}; span first start -> last end {we.max() - ws.min():.2f}")
+    print("  duration percentiles 5/25/50/75/95/99:", np.round(np.percentile(dur, [5, 25, 50, 75, 95, 99]), 2),
+          " start percentiles:", np.round(np.percentile(ws, [5, 25, 50, 75, 95, 99]), 2))
+    for title, names, st in (("  main wavefront", MAIN[:14], tw[0]), ("  helper wavefront", HELP, tw[1])):
+        print(title)
+        prev = st[0]
+        for k, v in zip(names, st):
+            print(f"    {k:36s} {v:8d}  (+{v - prev})")
+            prev = v
