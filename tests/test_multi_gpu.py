@@ -212,7 +212,12 @@ def test_step_many_environment_chains_equal_whole_batch_launches(chains, n, buil
         eager.step(a[k % 6], 1, oe)
     graph.step_many(a, K, og, first_block=0)
     torch.cuda.synchronize()
-    assert torch.equal(graph.x, eager.x) and torch.equal(graph.y, eager.y) and torch.equal(og, oe)
+
+    def bits(t):  # (random states driven by random actions: a few environments diverge to NaN within 40 steps)
+        return t.view(torch.int64)
+
+    assert torch.equal(bits(graph.x), bits(eager.x)) and torch.equal(bits(graph.y), bits(eager.y))
+    assert torch.equal(bits(og), bits(oe))
 
 
 def test_step_many_tune_picks_a_chain_count_and_keeps_the_records(built):
