@@ -234,12 +234,15 @@ def test_step_many_tune_picks_a_chain_count_and_keeps_the_records(built):
     for rep in range(6):
         for k in range(12):
             eager.step(a[k % 6])
-    assert torch.equal(graph.x, eager.x)
+    def bits(t):  # (random states driven by random actions: a few environments diverge to NaN on the way)
+        return t.view(torch.int64)
+
+    assert torch.equal(bits(graph.x), bits(eager.x))
     graph.step_many(a, 30, first_block=1)
     for k in range(30):
         eager.step(a[(1 + k) % 6])
     torch.cuda.synchronize()
-    assert torch.equal(graph.x, eager.x) and torch.equal(graph.y, eager.y)
+    assert torch.equal(bits(graph.x), bits(eager.x)) and torch.equal(bits(graph.y), bits(eager.y))
     with pytest.raises(Exception):
         graph.set_graph_chains(9)
 

@@ -1203,6 +1203,7 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   TdsStepCtl ctl;
   memset(&ctl, 0, sizeof(ctl));
   ctl.nsub = 1;
+  if (const char *ga = getenv("TDS_GRAM_STAMP_AT")) ctl.flags |= atoi(ga) << 8;  // (stamp 10 inside tds_gram_solve)
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,

@@ -405,8 +405,8 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
       }
       T vrow = T(0);
 #pragma unroll
-      for (int k = 0; k < NDP; ++k)
-        if (k < nd) vrow += z[k] * qdv[k];
+      for (int k = 0; k < NDP; ++k) vrow += z[k] * qdv[k];  // (padding columns k >= nd: z[k] == 0 exactly; a term under
+                                                            //  `if (k < nd)` is a uniform branch with its own LDS round trip)
       // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
       if constexpr (SPLIT)
         brow = vrow;
@@ -633,6 +633,306 @@ __device__ __forceinline__ T tds_pgs_lds(int lane, int NA, int ZR, int iters, T 
   } while (0)
 #endif
 
+// ------------------------------------------------------------------------------------------
+// Gram form of the contact solve on the matrix cores (two-wavefront workgroups, 16 lanes per environment, double).
+//
+// Once the row store holds z~_r = D^-1/2 L^-1 J_r^T (phase K) everything the projected Gauss-Seidel needs is inner
+// products of those rows:  A_rs = z~_r . z~_s  (= J_r M^-1 J_s^T)  and the acceleration part of the right-hand sides
+// z~_r . y~.  v_mfma_f64_4x4x4_4b_f64 computes four independent 4x4x4 products per instruction; its operand map
+// (probed: tools/ubench/mfma_f64_4x4x4.hip) is   A: lane = 16 k + 4 blk + i,  B: lane = 16 k + 4 blk + j,
+// D: lane = 16 i + 4 blk + j   — block blk takes the environment in lane group blk, the operands come straight out of
+// the environments' LDS regions, and [Z~ | y~] [Z~ | y~]^T lands in a per-environment 16 x 16 buffer with ~50 matrix
+// instructions instead of ~12 cross-lane reductions per sweep and 12 more for the right-hand sides.
+// The sweep then runs with lane == row and NO reduction at all: every lane keeps its row's  res_s = sum_r A_sr x_r
+// up to date (one FMA per updated row, the update broadcast by DPP), so the dependent chain per row is
+// sub, mul, max, min, broadcast, fma.  Same iteration as tds_pgs_sweep (mb_constraint_solver.hpp:101-142, rows in the
+// reference's order: normals, tangents 1, tangents 2), different association of the sums.
+// Needs 3 NA <= 15 (rows on 16 lanes, one column left for y~) and every row in LDS.
+// ------------------------------------------------------------------------------------------
+#define TDS_GRAM_STRIDE 17  // odd row stride of the 16 x 16 (+1) buffer
+#define TDS_GRAM_ZEROS (16 * TDS_GRAM_STRIDE)  // 16 zeros behind the buffer: what masked operand lanes read
+// v_max_f64 / v_min_f64 as they are (fmax / fmin would first canonicalise both operands: two more instructions on a
+// path whose instruction count is its latency)
+__device__ __forceinline__ double tds_vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double tds_vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// NA (contact slots of the wavefront) is a template parameter: the tile loops, the row kinds and the DPP sources are
+// then all static and the whole solve is branch-free — every LDS read is issued up front instead of one exposed LDS
+// round trip per uniform branch.
+template <int NDP, int NA>
+__device__ __forceinline__ double tds_gram_solve(double *sm, const TdsLds &L, int lane, int na, int ZR, int NCPp,
+                                                 int iters, double mu, double dt, double erp_dt, double rest,
+                                                 long long *stamp = nullptr, int stamp_at = 0) {
+  using T = double;
+  static_assert(3 * NA <= 15, "rows on 16 lanes, one column left for y~");
+  constexpr int NDs = NDP + 1;
+  constexpr int GS = TDS_GRAM_STRIDE;
+  constexpr int nr = 3 * NA;          // rows 0..nr-1; column nr carries y~
+  constexpr int NTr = (nr + 3) >> 2;  // row tiles
+  constexpr int NTc = (nr + 4) >> 2;  // column tiles (incl. the y~ column)
+  constexpr int NK = (NDP + 3) >> 2;  // k tiles
+  // (diagnostic: one timestamp inside this function, selected by TDS_GRAM_STAMP_AT)
+  auto mark = [&](int at) {
+    if (stamp != nullptr && at == stamp_at) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0);
+      if (blockIdx.x == 0 && threadIdx.x == 0) *stamp = (long long)__builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  const int wl = threadIdx.x & 63;
+  const int grp = wl >> 4;
+  {
+    // ---- [Z~ | y~] [Z~ | y~]^T on the matrix cores
+    const int kq = wl >> 4, blk = (wl >> 2) & 3, ij = wl & 3;
+    const int eb = blk * L.stride;
+    const int zero_at = eb + L.Xw + TDS_GRAM_ZEROS;
+    T op[NTc][NK];
+#pragma unroll
+    for (int t = 0; t < NTc; ++t) {
+      const int c = 4 * t + ij;  // row of [Z~ | y~] this lane feeds in tile t
+      const int at = (c < nr ? eb + L.Z + c * NDs : (c == nr ? eb + L.dinv + 3 * NDP : zero_at)) + kq;
+      const int at_last = (4 * (NK - 1) + kq < NDP) ? at + 4 * (NK - 1) : zero_at;  // (the last k tile may run past NDP)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) op[t][k] = (4 * k + 3 < NDP) ? sm[at + 4 * k] : sm[at_last];
+    }
+    mark(4);
+    const int out = eb + L.Xw + kq * GS + ij;  // D: row 4 I + (lane >> 4), column 4 J + (lane & 3) of block blk
+    T acc[NTr][NTc];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int I = 0; I < NTr; ++I)
+#pragma unroll
+        for (int J = 0; J < NTc; ++J)
+          acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[I][k], op[J][k], k == 0 ? T(0) : acc[I][J], 0, 0, 0);
+    mark(5);
+#pragma unroll
+    for (int I = 0; I < NTr; ++I)
+#pragma unroll
+      for (int J = 0; J < NTc; ++J) sm[out + 4 * I * GS + 4 * J] = acc[I][J];
+  }
+  TDS_WAVE_SYNC();
+  mark(1);
+  // ---- lane == row
+  T *const E = sm + grp * L.stride;
+  const T *const Gm = E + L.Xw;
+  const T *const rws = E + L.rows;
+  const T *const cpx = E + L.cp;
+  const T *const Zs = E + L.Z;
+  const int s = lane;
+  const int t = (s >= NA ? 1 : 0) + (s >= 2 * NA ? 1 : 0);
+  const int a = s - t * NA;
+  const bool row = s < nr && a < na;
+  const int sc = s < nr ? s : 0;
+  T Acol[nr];
+#pragma unroll
+  for (int r = 0; r < nr; ++r) Acol[r] = Gm[s * GS + r];
+  const int dcl = lane < NDP ? lane : NDP - 1;
+  T zc[nr];  // column dcl of Z~ for u~ below (requested now, used after the sweep)
+#pragma unroll
+  for (int r = 0; r < nr; ++r) zc[r] = Zs[r * NDs + dcl];
+  // right-hand side: J_r . qd+ = J_r . qd + dt z~_r . y~ (see tds_row_rhs_finish)
+  const T vrow = rws[sc] + dt * Gm[s * GS + nr];
+  const T dist = cpx[3 * NCPp + (a < NCPp ? a : 0)];
+  const T b = !row ? T(0) : (t == 0 ? (T(1) + rest) * vrow - erp_dt * dist : vrow);
+  const T ar = row ? rws[ZR + sc] : T(0);
+  const T gr = row ? rws[2 * ZR + sc] : T(0);
+  T x = T(0), res = T(0);
+  T lo = T(0), hi = t == 0 ? T(100000) : T(0);
+  mark(2);
+  for (int it = 0; it < iters; ++it) {
+    static_for<0, nr>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      const T delta = it == 0 ? res : res - gr * x;  // sum over the OTHER rows (G_rr x_r taken out again)
+      T xn = (b - delta) * ar;
+      xn = tds_vmax(xn, lo);
+      xn = tds_vmin(xn, hi);
+      const T xnr = dpp_bcast<r>(xn);
+      const T dxr = it == 0 ? xnr : xnr - dpp_bcast<r>(x);
+      res += Acol[r] * dxr;
+      x = s == r ? xn : x;
+      if constexpr (r < NA) {  // a normal row: its impulse bounds the two friction rows of the same contact
+        if (t != 0 && a == r) {
+          const T h = mu * (xnr > T(0) ? xnr : T(0));  // where_lt(s, 0, 0, s)
+          lo = -h;
+          hi = h;
+        }
+      }
+    });
+  }
+  mark(3);
+  // u~ = sum_r z~_r x_r, lane == dof
+  T u = T(0);
+  static_for<0, nr>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    u += zc[r] * dpp_bcast<r>(x);
+  });
+  mark(6);
+  return lane < NDP ? u : T(0);
+}
+
+// ------------------------------------------------------------------------------------------
+// the step kernel
+// ------------------------------------------------------------------------------------------
+// A workgroup is exactly ONE wavefront, and the LDS executes the DS instructions of a wavefront in
+// issue order, so cross-lane hand-offs through LDS need no s_barrier and no s_waitcnt drain:
+// all that is required is that the compiler keeps the program order of the LDS accesses.  A real
+// __syncthreads() would also wait for every outstanding GLOBAL store (the early y writes), which
+// single-wave-per-SIMD occupancy cannot hide.
+#ifdef TDS_FULL_BARRIER
+#define TDS_WAVE_SYNC() __syncthreads()
+#else
+#define TDS_WAVE_SYNC()                                        \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+  } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------
+// Gram form of the contact solve on the matrix cores (two-wavefront workgroups, 16 lanes per environment, double).
+//
+// Once the row store holds z~_r = D^-1/2 L^-1 J_r^T (phase K) everything the projected Gauss-Seidel needs is inner
+// products of those rows:  A_rs = z~_r . z~_s  (= J_r M^-1 J_s^T)  and the acceleration part of the right-hand sides
+// z~_r . y~.  v_mfma_f64_4x4x4_4b_f64 computes four independent 4x4x4 products per instruction; its operand map
+// (probed: tools/ubench/mfma_f64_4x4x4.hip) is   A: lane = 16 k + 4 blk + i,  B: lane = 16 k + 4 blk + j,
+// D: lane = 16 i + 4 blk + j   — block blk takes the environment in lane group blk, the operands come straight out of
+// the environments' LDS regions, and [Z~ | y~] [Z~ | y~]^T lands in a per-environment 16 x 16 buffer with ~50 matrix
+// instructions instead of ~12 cross-lane reductions per sweep and 12 more for the right-hand sides.
+// The sweep then runs with lane == row and NO reduction at all: every lane keeps its row's  res_s = sum_r A_sr x_r
+// up to date (one FMA per updated row, the update broadcast by DPP), so the dependent chain per row is
+// sub, mul, max, min, broadcast, fma.  Same iteration as tds_pgs_sweep (mb_constraint_solver.hpp:101-142, rows in the
+// reference's order: normals, tangents 1, tangents 2), different association of the sums.
+// Needs 3 NA <= 15 (rows on 16 lanes, one column left for y~) and every row in LDS.
+// ------------------------------------------------------------------------------------------
+#define TDS_GRAM_STRIDE 17  // odd row stride of the 16 x 16 (+1) buffer
+#define TDS_GRAM_ZEROS (16 * TDS_GRAM_STRIDE)  // 16 zeros behind the buffer: what masked operand lanes read
+template <int NDP>
+__device__ __forceinline__ double tds_gram_solve(double *sm, const TdsLds &L, int lane, int NA, int na, int ZR, int NCPp,
+                                                 int iters, double mu, double dt, double erp_dt, double rest,
+                                                 long long *stamp = nullptr, int stamp_at = 0) {
+  using T = double;
+  // (diagnostic: one timestamp inside this function, selected by TDS_GRAM_STAMP_AT)
+  auto mark = [&](int at) {
+    if (stamp != nullptr && at == stamp_at) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0);
+      if (blockIdx.x == 0 && threadIdx.x == 0) *stamp = (long long)__builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  constexpr int NDs = NDP + 1;
+  constexpr int GS = TDS_GRAM_STRIDE;
+  const int wl = threadIdx.x & 63;
+  const int grp = wl >> 4;
+  const int nr = 3 * NA;          // rows 0..nr-1; column nr carries y~
+  const int NTr = (nr + 3) >> 2;  // row tiles
+  const int NTc = (nr + 4) >> 2;  // column tiles (incl. the y~ column)
+  {
+    // ---- [Z~ | y~] [Z~ | y~]^T on the matrix cores
+    const int kq = wl >> 4, blk = (wl >> 2) & 3, ij = wl & 3;
+    const int eb = blk * L.stride;
+    const int zero_at = eb + L.Xw + TDS_GRAM_ZEROS;
+    int base[4], base3[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = 4 * t + ij;  // row of [Z~ | y~] this lane feeds in tile t
+      const int at = c < nr ? eb + L.Z + c * NDs : (c == nr ? eb + L.dinv + 3 * NDP : zero_at);
+      base[t] = at + kq;
+      base3[t] = (12 + kq < NDP) ? base[t] : zero_at;  // (k tile 3 runs past the padded dof count)
+    }
+    T op[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < NTc) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (4 * k >= NDP) op[t][k] = T(0);
+          else if (4 * k + 3 < NDP) op[t][k] = sm[base[t] + 4 * k];
+          else op[t][k] = sm[base3[t] + (12 + kq < NDP ? 4 * k : 0)];
+        }
+      }
+    const int out = eb + L.Xw + kq * GS + ij;  // D: row 4 I + (lane >> 4), column 4 J + (lane & 3) of block blk
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+      if (I < NTr) {
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+          if (J < NTc) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (4 * k < NDP) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(op[I][k], op[J][k], acc, 0, 0, 0);
+            sm[out + 4 * I * GS + 4 * J] = acc;
+          }
+      }
+  }
+  TDS_WAVE_SYNC();
+  mark(1);
+  // ---- lane == row
+  T *const E = sm + grp * L.stride;
+  const T *const Gm = E + L.Xw;
+  const T *const rws = E + L.rows;
+  const T *const cpx = E + L.cp;
+  const int s = lane;
+  const int t = (s >= NA ? 1 : 0) + (s >= 2 * NA ? 1 : 0);
+  const int a = s - t * NA;
+  const bool row = s < nr && a < na;
+  const int sc = s < nr ? s : 0;
+  T Acol[15];
+#pragma unroll
+  for (int r = 0; r < 15; ++r) Acol[r] = r < nr ? Gm[s * GS + r] : T(0);
+  // right-hand side: J_r . qd+ = J_r . qd + dt z~_r . y~ (see tds_row_rhs_finish)
+  const T vrow = rws[sc] + dt * Gm[s * GS + nr];
+  const T b = !row ? T(0) : (t == 0 ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + a] : vrow);
+  const T ar = row ? rws[ZR + sc] : T(0);
+  const T gr = row ? rws[2 * ZR + sc] : T(0);
+  T x = T(0), res = T(0);
+  T lo = T(0), hi = t == 0 ? T(100000) : T(0);
+  mark(2);
+  for (int it = 0; it < iters; ++it) {
+    static_for<0, 15>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      if (r < nr) {  // wave-uniform
+        const T delta = res - gr * x;  // sum over the OTHER rows (G_rr x_r taken out again)
+        T xn = (b - delta) * ar;
+        xn = max_t<T>(xn, lo);
+        xn = min_t<T>(xn, hi);
+        const T dxr = dpp_bcast<r>(xn - x);
+        res += Acol[r] * dxr;
+        x = s == r ? xn : x;
+        if (r < NA) {  // a normal row: its impulse bounds the two friction rows of the same contact
+          const T xr_n = dpp_bcast<r>(xn);
+          if (t != 0 && a == r) {
+            const T h = mu * (xr_n > T(0) ? xr_n : T(0));  // where_lt(s, 0, 0, s)
+            lo = -h;
+            hi = h;
+          }
+        }
+      }
+    });
+  }
+  mark(3);
+  // u~ = sum_r z~_r x_r, lane == dof
+  const T *const Zs = E + L.Z;
+  const int dcl = lane < NDP ? lane : NDP - 1;
+  T u = T(0);
+  static_for<0, 15>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r < nr) u += Zs[r * NDs + dcl] * dpp_bcast<r>(x);
+  });
+  return lane < NDP ? u : T(0);
+}
+
+
 // per-group state machine of the in-kernel step loop
 #define TDS_MODE_IDLE 0
 #define TDS_MODE_RUN 1
@@ -713,7 +1013,7 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
 // grid fits the GPU at once (tds_launch_step_impl).
 template <typename T, typename TR, int G, int NDP, bool PROF, int LP, int KIND, bool W2 = false>
 __global__ __launch_bounds__(W2 ? 128 : 64)
-__attribute__((amdgpu_waves_per_eu((LP == 2 || W2) ? 2 : 1)))
+__attribute__((amdgpu_waves_per_eu((LP == 2 || W2 || (LP == 0 && NDP < 24)) ? 2 : 1)))
 void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const TR *x_in, TR *__restrict__ y_out,
                                                       const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
@@ -840,6 +1140,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // behind those of body A, the joint-space inertia is block diagonal (the LDL^T and every solve go through as they
   // are), and a SECOND contact pass handles the contacts between the two bodies (world.hpp:206-282, 293-366).
   constexpr bool two = KIND == 3;
+  // contact solve in Gram form on the matrix cores (tds_gram_solve): two-wavefront workgroups of 16-lane environments
+  constexpr bool GRAM = W2 && G == 16 && NDP <= 16 && std::is_same<T, double>::value;
   const bool body_b = two && isl && mdl->body_of_link[lsafe] != 0;
   const int njd = mdl->nj;                       // joint dofs (== nd on a fixed base)
   const bool froot = fl && isl && li < 6;        // base pseudo link
@@ -1959,15 +2261,33 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       T Fd[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) Fd[k] = isd ? Fs[lk * TDS_S2 + k] : T(0);
+      // Columns j >= nd hold whatever the row store left there; they are deselected by the ancestor mask, so the reads
+      // need no `j < nd` guard.  That matters: a read under a uniform branch is its own LDS round trip, NDP of them in a
+      // row.  Narrow kernels read all NDP x 6 values at once; the wider ones (no registers for that) go three columns per
+      // guarded group.
+      constexpr int GCH = NDP <= 16 ? NDP : 3;
 #pragma unroll
-      for (int j = 0; j < NDP; ++j) {
-        T s = T(0);
-        if (j < nd) {
+      for (int j0 = 0; j0 < NDP; j0 += GCH) {
+        T s[GCH];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) s += Fd[k] * swd[k * NDs + j];
+        for (int jj = 0; jj < GCH; ++jj) s[jj] = T(0);
+        if (NDP <= 16 || j0 < nd) {
+#pragma unroll
+          for (int jj = 0; jj < GCH; ++jj) {
+            if (j0 + jj < NDP) {
+#pragma unroll
+              for (int k = 0; k < 6; ++k) s[jj] += Fd[k] * swd[k * NDs + j0 + jj];
+            }
+          }
         }
-        s = ((anc >> j) & 1u) ? s : T(0);
-        Mr[j] = (!isd && j == d) ? T(1) : s;  // padding rows: identity
+#pragma unroll
+        for (int jj = 0; jj < GCH; ++jj) {
+          const int j = j0 + jj;
+          if (j < NDP) {
+            const T sj = ((anc >> j) & 1u) ? s[jj] : T(0);
+            Mr[j] = (!isd && j == d) ? T(1) : sj;  // padding rows: identity
+          }
+        }
       }
       if (fl) {  // wave-uniform
         // rows of the base dofs (numbered last): against a joint dof j the composite force is that of the
@@ -2039,6 +2359,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     bool split_ok = false;  // two-wavefront workgroup: the helper wavefront does the row solves
     if constexpr (W2) {
       __syncthreads();  // (2) L, 1/D are in LDS for the helper wavefront's row solves; its contact list and rows are visible here
+      if constexpr (GRAM) {  // (the sweep groups' storage is free from here on: zeros for tds_gram_solve's masked lanes)
+        if (L.gram_ok && lane < 16) E[L.Xw + TDS_GRAM_ZEROS + lane] = T(0);
+      }
       na = (int)scalar_to_bits<T>(xr[in_dim + 2]);
       NA = __builtin_amdgcn_readfirstlane((int)scalar_to_bits<T>(xr[in_dim + 3]));
       wave_contacts = NA > 0;
@@ -2056,10 +2379,17 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       const int d = lane;
       T yv = d < NDP ? rhsx[d] : T(0);
       // L y = rhs (L unit lower, row d of it in Mr[0..d-1]), column by column
+      // (the row mask goes into the multiplier ahead of time: the dependent chain per step is broadcast + FMA, no select)
+      //  (narrow kernels only: the wide ones have no registers for a masked copy of the row)
       static_for<0, NDP - 1>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const T yk = lane_bcast<T, G, NDP, k>(yv);
-        yv = d > k ? yv - Mr[k] * yk : yv;
+        if constexpr (NDP <= 16) {
+          const T lm = d > k ? Mr[k] : T(0);
+          yv -= lm * yk;
+        } else {
+          yv = d > k ? yv - Mr[k] * yk : yv;
+        }
       });
       T xv = yv * my_inv;
       if constexpr (W2) {  // y~ = D^-1/2 y for the rows' right-hand sides (tds_row_rhs_finish)
@@ -2135,10 +2465,23 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         for (int i = 0; i < 6; ++i) xv = d == njd + i ? ab[i] : xv;
       }
       // L^T x = D^-1 y with the packed copy of L in LDS (the base rows of a floating base keep a_base)
+      // (column d of L^T requested up front, index clamped: a read under `if (d < k)` is a read inside a branch, and
+      //  every one of the NDP - 1 dependent steps then waits for its own LDS round trip)
+      //  (wide kernels: not the registers for it — they read step by step)
+      constexpr bool PRE = NDP <= 16;
+      T lt[PRE ? NDP - 1 : 1];
+      if constexpr (PRE) {
+#pragma unroll
+        for (int k = 1; k < NDP; ++k) {
+          const T lv = Lp[(k * (k - 1)) / 2 + (d < k ? d : 0)];
+          lt[k - 1] = (d < k && jrow) ? lv : T(0);
+        }
+      }
       static_for<0, NDP - 1>([&](auto ic) {
         constexpr int k = NDP - 1 - decltype(ic)::value;
         const T xk = lane_bcast<T, G, NDP, k>(xv);
-        if (d < k && jrow) xv -= Lp[(k * (k - 1)) / 2 + d] * xk;
+        if constexpr (PRE) xv -= lt[k - 1] * xk;
+        else if (d < k && jrow) xv -= Lp[(k * (k - 1)) / 2 + d] * xk;
       });
       if (fl && d >= njd + 3 && d < nd) xv += mdl->grav[d - njd - 3];  // forward_dynamics.hpp:315-319
       // integrate_euler_qdd; from here on the velocities live in dof order in the column scratch
@@ -2167,6 +2510,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     const int nr = 3 * NA;
     const T cfm = pf_cfm, erp_dt = pf_erp_dt, rest = pf_rest;
     const bool any_slab = nr > ZR;  // wave-uniform
+    bool gram = false;
     if constexpr (W2) {
       // Rows and row solves normally came from the helper wavefront.  More rows than the LDS store holds (rare): this
       // wavefront builds and solves them itself, through the scratch slab — with the SAME split arithmetic, so that
@@ -2184,8 +2528,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         TDS_WAVE_SYNC();
         if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       }
-      // complete the right-hand sides with the acceleration part
-      if (any_slab)
+      if constexpr (GRAM) gram = L.gram_ok && split_ok && NA >= 2 && NA <= 5;  // wave-uniform
+      // complete the right-hand sides with the acceleration part (Gram form: a column of the matrix product)
+      if (gram) {
+      } else if (any_slab)
         tds_row_rhs_finish<true, T, G, NDP>(lane, NA, na, ZR, OVR, NCPp, Zs, rws, cpx, dvec + 3 * NDP, zov, rov, dt, erp_dt, rest);
       else
         tds_row_rhs_finish<false, T, G, NDP>(lane, NA, na, ZR, OVR, NCPp, Zs, rws, cpx, dvec + 3 * NDP, zov, rov, dt, erp_dt, rest);
@@ -2221,14 +2567,41 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       const bool dz = d < NDP;
       const T mu = pf_mu;
       const int iters = pf_iters;
-      const T u = any_slab ? tds_pgs<true, T, G, NDP>(lane, NA, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov)
-                           : tds_pgs_lds<T, G, NDP>(lane, NA, ZR, iters, mu, Zs, rws, xs);
+      T u;
+      if constexpr (GRAM) {
+        long long *const gst = PROF && tds_iter == 0 ? prof + 10 : nullptr;
+        const int gat = ctl.flags >> 8;
+        if (!gram)
+          u = any_slab ? tds_pgs<true, T, G, NDP>(lane, NA, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov)
+                       : tds_pgs_lds<T, G, NDP>(lane, NA, ZR, iters, mu, Zs, rws, xs);
+        else if (NA == 2)
+          u = tds_gram_solve<NDP, 2>(sm, L, lane, na, ZR, NCPp, iters, mu, dt, erp_dt, rest, gst, gat);
+        else if (NA == 3)
+          u = tds_gram_solve<NDP, 3>(sm, L, lane, na, ZR, NCPp, iters, mu, dt, erp_dt, rest, gst, gat);
+        else if (NA == 4)
+          u = tds_gram_solve<NDP, 4>(sm, L, lane, na, ZR, NCPp, iters, mu, dt, erp_dt, rest, gst, gat);
+        else
+          u = tds_gram_solve<NDP, 5>(sm, L, lane, na, ZR, NCPp, iters, mu, dt, erp_dt, rest, gst, gat);
+      } else {
+        u = any_slab ? tds_pgs<true, T, G, NDP>(lane, NA, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov)
+                     : tds_pgs_lds<T, G, NDP>(lane, NA, ZR, iters, mu, Zs, rws, xs);
+      }
       // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
       T w = dz ? u * dvec[NDP + d] : T(0);
+      constexpr bool PRE = NDP <= 16;  // (see phase F)
+      T lt[PRE ? NDP - 1 : 1];
+      if constexpr (PRE) {
+#pragma unroll
+        for (int k = 1; k < NDP; ++k) {
+          const T lv = Lp[(k * (k - 1)) / 2 + (d < k ? d : 0)];
+          lt[k - 1] = d < k ? lv : T(0);
+        }
+      }
       static_for<0, NDP - 1>([&](auto ic) {
         constexpr int k = NDP - 1 - decltype(ic)::value;
         const T wk = lane_bcast<T, G, NDP, k>(w);
-        if (d < k) w -= Lp[(k * (k - 1)) / 2 + d] * wk;
+        if constexpr (PRE) w -= lt[k - 1] * wk;
+        else if (d < k) w -= Lp[(k * (k - 1)) / 2 + d] * wk;
       });
       if (d < nd) rhsx[d] -= w;
     }
@@ -2262,10 +2635,20 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         const T u = slab2 ? tds_pgs<true, T, G, NDP>(lane, NB_pairs, ZR, OVR, pf_iters, pf_mu, Zs, rws, xs, zov, rov)
                           : tds_pgs_lds<T, G, NDP>(lane, NB_pairs, ZR, pf_iters, pf_mu, Zs, rws, xs);
         T w = d < NDP ? u * dvec[NDP + d] : T(0);
+        constexpr bool PRE = NDP <= 16;  // (see phase F)
+        T lt[PRE ? NDP - 1 : 1];
+        if constexpr (PRE) {
+#pragma unroll
+          for (int k = 1; k < NDP; ++k) {
+            const T lv = Lp[(k * (k - 1)) / 2 + (d < k ? d : 0)];
+            lt[k - 1] = d < k ? lv : T(0);
+          }
+        }
         static_for<0, NDP - 1>([&](auto ic) {
           constexpr int k = NDP - 1 - decltype(ic)::value;
           const T wk = lane_bcast<T, G, NDP, k>(w);
-          if (d < k) w -= Lp[(k * (k - 1)) / 2 + d] * wk;
+          if constexpr (PRE) w -= lt[k - 1] * wk;
+          else if (d < k) w -= Lp[(k * (k - 1)) / 2 + d] * wk;
         });
         if (d < nd) rhsx[d] -= w;
       }
@@ -2591,6 +2974,12 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   L.IA = g2; L.pA = g2; L.F = g2; L.Ic = g2 + 6; L.a = g2; g2 += TDS_S2 * L.NLp;
   int g3 = w2 ? g2 : u;
   L.Z = g3; g3 += L.zrows * L.NDs;
+  // Gram form of the contact solve (tds_gram_solve): its 16 x 17 buffer + 16 zeros reuse the two sweep groups
+  // Opt-in (TDS_HIP_GRAM=1): measured 0.4k of 32k cycles better than the z~ sweep at Ant x 4096 (profiles/r02d_gram_mfma.txt),
+  // and an environment's low-order bits then depend on whether its wavefront-mates push NA past 5 (sweep) or not (Gram).
+  const char *ge = getenv("TDS_HIP_GRAM");
+  L.gram_ok = (ge && ge[0] == '1' && w2 && lanes_per_env == 16 && ndp <= 16 && !m.two_bodies &&
+               L.Z - L.Xw >= TDS_GRAM_ZEROS + 16) ? 1 : 0;
   o = g1 > g2 ? g1 : g2;
   o = o > g3 ? o : g3;
   o = (o + 1) & ~1;  // keep 16-byte alignment of every env region for T = double
