@@ -2351,9 +2351,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       dvec[lane] = my_inv;
       dvec[NDP + lane] = sqrt_t<T>(my_inv);
       const int off = (lane * (lane - 1)) / 2;
+      // (row `lane` has `lane` entries: the surplus writes go to this lane's slot of the column scratch, which phase F
+      //  clears next — an address select per entry instead of a branch around each write)
+      T *const dump = dvec + 2 * NDP + lane;
 #pragma unroll
-      for (int j = 0; j < NDP - 1; ++j)
-        if (j < lane) Lp[off + j] = Mr[j];
+      for (int j = 0; j < NDP - 1; ++j) {
+        T *const dst = j < lane ? &Lp[off + j] : dump;
+        *dst = Mr[j];
+      }
     }
     TDS_STAMP(7);
     bool split_ok = false;  // two-wavefront workgroup: the helper wavefront does the row solves
@@ -2477,11 +2482,25 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           lt[k - 1] = (d < k && jrow) ? lv : T(0);
         }
       }
+      // (no registers to hold the whole column: a ring of four reads runs ahead of the dependent chain instead)
+      T ring[4];
+      if constexpr (!PRE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = NDP - 1 - i;
+          ring[i] = k >= 1 ? Lp[(k * (k - 1)) / 2 + (d < k ? d : 0)] : T(0);
+        }
+      }
       static_for<0, NDP - 1>([&](auto ic) {
-        constexpr int k = NDP - 1 - decltype(ic)::value;
+        constexpr int i = decltype(ic)::value;
+        constexpr int k = NDP - 1 - i;
         const T xk = lane_bcast<T, G, NDP, k>(xv);
         if constexpr (PRE) xv -= lt[k - 1] * xk;
-        else if (d < k && jrow) xv -= Lp[(k * (k - 1)) / 2 + d] * xk;
+        else {
+          const T lv = ring[i & 3];
+          if constexpr (k - 4 >= 1) ring[i & 3] = Lp[((k - 4) * (k - 5)) / 2 + (d < k - 4 ? d : 0)];
+          xv -= ((d < k && jrow) ? lv : T(0)) * xk;
+        }
       });
       if (fl && d >= njd + 3 && d < nd) xv += mdl->grav[d - njd - 3];  // forward_dynamics.hpp:315-319
       // integrate_euler_qdd; from here on the velocities live in dof order in the column scratch
@@ -2597,11 +2616,24 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           lt[k - 1] = d < k ? lv : T(0);
         }
       }
+      T ring[4];  // (see phase F)
+      if constexpr (!PRE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = NDP - 1 - i;
+          ring[i] = k >= 1 ? Lp[(k * (k - 1)) / 2 + (d < k ? d : 0)] : T(0);
+        }
+      }
       static_for<0, NDP - 1>([&](auto ic) {
-        constexpr int k = NDP - 1 - decltype(ic)::value;
+        constexpr int i = decltype(ic)::value;
+        constexpr int k = NDP - 1 - i;
         const T wk = lane_bcast<T, G, NDP, k>(w);
         if constexpr (PRE) w -= lt[k - 1] * wk;
-        else if (d < k) w -= Lp[(k * (k - 1)) / 2 + d] * wk;
+        else {
+          const T lv = ring[i & 3];
+          if constexpr (k - 4 >= 1) ring[i & 3] = Lp[((k - 4) * (k - 5)) / 2 + (d < k - 4 ? d : 0)];
+          w -= (d < k ? lv : T(0)) * wk;
+        }
       });
       if (d < nd) rhsx[d] -= w;
     }
@@ -2644,11 +2676,24 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
             lt[k - 1] = d < k ? lv : T(0);
           }
         }
+        T ring[4];  // (see phase F)
+        if constexpr (!PRE) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int k = NDP - 1 - i;
+            ring[i] = k >= 1 ? Lp[(k * (k - 1)) / 2 + (d < k ? d : 0)] : T(0);
+          }
+        }
         static_for<0, NDP - 1>([&](auto ic) {
-          constexpr int k = NDP - 1 - decltype(ic)::value;
+          constexpr int i = decltype(ic)::value;
+          constexpr int k = NDP - 1 - i;
           const T wk = lane_bcast<T, G, NDP, k>(w);
           if constexpr (PRE) w -= lt[k - 1] * wk;
-          else if (d < k) w -= Lp[(k * (k - 1)) / 2 + d] * wk;
+          else {
+            const T lv = ring[i & 3];
+            if constexpr (k - 4 >= 1) ring[i & 3] = Lp[((k - 4) * (k - 5)) / 2 + (d < k - 4 ? d : 0)];
+            w -= (d < k ? lv : T(0)) * wk;
+          }
         });
         if (d < nd) rhsx[d] -= w;
       }
