@@ -433,20 +433,30 @@ def main():
         value = total_steps / elapsed
         roof = None
         if kernel_ms:
+            # environment chains: C launches of n / C environments each are in flight at the same time, every one of
+            # them lasting about one step period (a chain's launches run back to back); the HBM peak is the whole
+            # GPU's, so `achieved` adds up the launches in flight
+            conc = chains if (chains and use_graph and not multi) else 1
             achieved = n * bytes_per_env_step / (kernel_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(args.model, n, args.dtype)
+            traffic, traffic_src = pmc_traffic(args.model, n, args.dtype)  # (measured on whole-batch launches)
+            if traffic is not None:
+                traffic = traffic // conc
             arith = "f32" if args.dtype == "f32-pure" else "f64"
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "tds_step_kernel", "kernel_ms_avg": kernel_ms,
                     "kernel_ms_isolated": kernel_ms_isolated,
-                    "algorithmic_bytes_per_launch": n * bytes_per_env_step,
+                    "algorithmic_bytes_per_launch": n * bytes_per_env_step // conc,
+                    "launches_in_flight": conc,
+                    "achieved_per_launch": achieved / conc,
                     # secondary view: flops of the reference's dense formulation per env-step
                     "algorithmic_flops_per_env_step": ALG_FLOPS.get(args.model),
                     "algorithmic_tflops": (ALG_FLOPS[args.model] * n / (kernel_ms * 1e-3) / 1e12
                                            if args.model in ALG_FLOPS else None),
                     "valu_peak_tflops": 78.6 if arith == "f64" else 157.3,
-                    "note": "algorithmic bytes = (input_dim+output_dim)*sizeof(T) per env-step; the path is "
+                    "note": "algorithmic bytes = (input_dim+output_dim)*sizeof(T) per env-step; achieved = "
+                            "launches_in_flight x algorithmic_bytes_per_launch / kernel_ms_avg (the launches of the "
+                            "environment chains overlap, each lasts about one step period); the path is "
                             "VALU/LDS-latency bound, see DESIGN.md"}
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K,

@@ -39,7 +39,26 @@ for FORM in w2 w1; do
   done
   python tools/pmc_summary.py $W/sq_${FORM}_* > $OUT/${TAG}_ant4096_f64_sq_counters_$FORM.txt 2>&1
 done
-python tools/profile_phases.py ant 4096 > $OUT/${TAG}_ant4096_f64_phases_onewave.txt 2>/dev/null
-python tools/profile_phases.py laikago_soft 8192 > $OUT/${TAG}_laikago_soft8192_f64_phases_onewave.txt 2>/dev/null
+python tools/profile_phases.py ant 4096 > $OUT/${TAG}_ant4096_f64_phases.txt 2>/dev/null
+python tools/profile_phases.py laikago_soft 8192 > $OUT/${TAG}_laikago_soft8192_f64_phases.txt 2>/dev/null
+python tools/w2_tail.py > $OUT/${TAG}_ant4096_f64_workgroup_times.txt 2>/dev/null
+# environment chains of the step_many graphs: throughput by chain count
+{
+  echo "# bench.py --chains C (1000 steps per graph launch), env-steps/s and us per step"
+  for C in "${CONFIGS[@]}" "ant16384_f64|--model ant --envs-per-gpu 16384" "ant2048_f64|--model ant --envs-per-gpu 2048"; do
+    NAME=${C%%|*}; ARGS=${C##*|}
+    for CH in 1 2 3; do
+      python bench.py $ARGS --chains $CH --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-26s chains %d  %.4g  %.2f us' % ('$NAME', $CH, d['value'], 1000*d['ms_per_step']))"
+    done
+  done
+  echo "# TDS_HIP_GRAM=1 (contact solve in Gram form on the f64 matrix cores), ant4096_f64, chains 2 / 1"
+  for CH in 2 1; do
+    TDS_HIP_GRAM=1 python bench.py --chains $CH --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-26s chains %d  %.4g  %.2f us' % ('ant4096_f64 gram', $CH, d['value'], 1000*d['ms_per_step']))"
+  done
+} > $OUT/${TAG}_graph_chains.txt
+# micro-benchmarks (tools/ubench, built in-tree)
+for U in launch_clock kernel_boundary two_streams mfma_f64_4x4x4; do
+  [ -x tools/ubench/$U ] && timeout 120 tools/ubench/$U > $OUT/${TAG}_ubench_$U.txt 2>&1
+done
 for C in "${CONFIGS[@]}"; do NAME=${C%%|*}; echo "== $NAME"; tail -n 4 $OUT/${TAG}_${NAME}_kernel_stats.txt; cat $OUT/${TAG}_${NAME}_pmc_counters.txt; done
 head -30 $OUT/${TAG}_ant4096_f64_sq_counters_w2.txt

@@ -63,9 +63,9 @@ if m.has_plane:
         print("  (contact statistics unavailable:", e, ")")
 tw = sim.profile_phases_two_waves()
 if tw is not None:
-    MAIN = ["start", "constants loaded", "A load + PD", "B jcalc", "C kinematics  (-> barrier 1)", "D inertias",
-            "E composite sweep", "G mass matrix", "H LDLt  (-> barrier 2)", "F solve  (-> barrier 3)", "after barrier 3",
-            "(sync)", "right-hand sides", "L PGS", "M/N integrate + pack"]
+    MAIN = ["start", "A constants, load, PD", "B jcalc", "C kinematics  (-> barrier 1)", "D inertias  (after barrier 1)",
+            "E composite sweep", "G mass matrix", "H LDLt  (-> barrier 2)", "F solve  (after barrier 2; -> barrier 3)",
+            "after barrier 3", "(not stamped in this form)", "right-hand sides", "L contact solve", "M/N integrate + pack"]
     HELP = ["start", "constants loaded  (-> barrier 1)", "after barrier 1", "I narrowphase", "M1 visual poses + y tail",
             "J rows  (-> barrier 2)", "after barrier 2", "K row solves  (-> barrier 3)", "after barrier 3"]
     print("two-wavefront form, workgroup 0: cycle at which each phase ENDS (0 = the main wavefront's first stamp)")
@@ -80,9 +80,11 @@ if tw is not None:
           f"mean {dur.mean():.2f} max {dur.max():.2f}; span first start -> last end {we.max() - ws.min():.2f}")
     print("  duration percentiles 5/25/50/75/95/99:", np.round(np.percentile(dur, [5, 25, 50, 75, 95, 99]), 2),
           " start percentiles:", np.round(np.percentile(ws, [5, 25, 50, 75, 95, 99]), 2))
-    for title, names, st in (("  main wavefront", MAIN[:14], tw[0]), ("  helper wavefront", HELP, tw[1])):
+    for title, names, st in (("  main wavefront", MAIN, tw[0]), ("  helper wavefront", HELP, tw[1])):
         print(title)
         prev = st[0]
         for k, v in zip(names, st):
-            print(f"    {k:36s} {v:8d}  (+{v - prev})")
+            if abs(v) > 10**9:  # (a stamp this form does not take)
+                continue
+            print(f"    {k:42s} {v:8d}  (+{v - prev})")
             prev = v
