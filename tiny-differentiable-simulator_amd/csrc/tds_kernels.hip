@@ -374,11 +374,14 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
 // SPLIT (two-wavefront workgroups, run by the helper wavefront while the main one is still in the forward-dynamics
 // solve): qdv holds the velocities BEFORE integrate_euler_qdd, and the b slot receives only J_r . qd_pre; the main
 // wavefront completes it with the acceleration part afterwards (tds_row_rhs_finish).
+// SPLIT with yt_flag != nullptr: the helper also completes b_r itself, with z~_r still in registers, as soon as the main
+// wavefront has published y~ (flag in LDS, polled: the main wavefront is ~2 k cycles ahead at that point) — same
+// arithmetic as tds_row_rhs_finish, which the main wavefront then skips.
 template <bool SLAB, typename T, int G, int NDP, bool SPLIT = false>
 __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, int ZR, int OVR, int NCPp,
                                               T *Zs, T *rws, T *xs, const T *qdv, const T *cpx, const T *Lp,
                                               const T *dvec, volatile T *zov, volatile T *rov, T cfm, T erp_dt,
-                                              T rest) {
+                                              T rest, const volatile T *yt_flag = nullptr, T dt = T(0)) {
   constexpr int NDs = NDP + 1;
   // ROW LAYOUT (wave-uniform): NA = largest number of penetrating contacts among the wavefront's
   // environments; row a = normal of contact a, NA + a = tangent 1, 2 NA + a = tangent 2.  An environment
@@ -424,7 +427,21 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
         g += z[k] * z[k];
       }
       ai = rcp_full<T>(g + cfm);
-    } else {
+    }
+    if constexpr (SPLIT && !SLAB) {
+      if (yt_flag != nullptr) {  // wave-uniform
+        while (__any(*yt_flag == T(0))) __builtin_amdgcn_s_sleep(1);
+        if (real) {
+          const T *const yt = dvec + 3 * NDP;
+          T s = T(0);
+#pragma unroll
+          for (int k = 0; k < NDP; ++k) s += z[k] * yt[k];
+          const T vrow = brow + dt * s;
+          brow = t == 0 ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + a] : vrow;
+        }
+      }
+    }
+    if (!real) {
 #pragma unroll
       for (int k = 0; k < NDP; ++k) z[k] = T(0);
     }
@@ -1641,7 +1658,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       TDS_STAMP(6);
       if (contacts_h && split_ok)
         tds_row_solve<false, T, G, NDP, true>(lane, NA_h, na_h, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, E + L.Lp,
-                                             E + L.dinv, nullptr, nullptr, pf_cfm, pf_erp_dt, pf_rest);
+                                             E + L.dinv, nullptr, nullptr, pf_cfm, pf_erp_dt, pf_rest,
+                                             L.gram_ok ? nullptr : xr + in_dim + 4, dt);
       TDS_STAMP(7);
       __syncthreads();  // (3) z~ rows and their scalars are final
       TDS_STAMP(8);
@@ -2044,6 +2062,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   bool wave_contacts = false;
   int nb_pairs = 0, NB_pairs = 0;  // two-body worlds: penetrating contacts between the bodies (this group / wavefront max)
   if constexpr (W2) {
+    if (lane == 0) xr[in_dim + 4] = T(0);  // "y~ is published" (phase F), polled by the helper wavefront
     __syncthreads();  // (1) x record, X_world and the motion axes are in LDS: the helper wavefront starts
   } else {
     // (step-loop build: the constants of the later phases are fetched only now — one L2 round trip per iteration
@@ -2397,8 +2416,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         }
       });
       T xv = yv * my_inv;
-      if constexpr (W2) {  // y~ = D^-1/2 y for the rows' right-hand sides (tds_row_rhs_finish)
+      if constexpr (W2) {  // y~ = D^-1/2 y for the rows' right-hand sides (completed by the helper wavefront at the
+                           // end of its row solves — it polls the flag; LDS executes a wavefront's writes in order)
         if (d < NDP) dvec[3 * NDP + d] = yv * sqrt_t<T>(my_inv);
+        TDS_WAVE_SYNC();
+        if (lane == 0) xr[in_dim + 4] = T(1);
       }
       const bool jrow = !fl || d < njd;  // (the base rows of a floating base keep a_base in the back substitution)
       if (fl) {  // wave-uniform
@@ -2549,7 +2571,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       }
       if constexpr (GRAM) gram = L.gram_ok && split_ok && NA >= 2 && NA <= 5;  // wave-uniform
       // complete the right-hand sides with the acceleration part (Gram form: a column of the matrix product)
-      if (gram) {
+      if (gram || (split_ok && !L.gram_ok)) {  // (split_ok: the helper wavefront has completed them)
       } else if (any_slab)
         tds_row_rhs_finish<true, T, G, NDP>(lane, NA, na, ZR, OVR, NCPp, Zs, rws, cpx, dvec + 3 * NDP, zov, rov, dt, erp_dt, rest);
       else
@@ -2983,7 +3005,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   L.ovrows = 3 * nct - L.zrows;    // surplus rows per environment (global scratch slab)
   int o = 0;
   // persistent for the whole step
-  L.xrec = o; o += m.input_dim + 2 + (w2 ? 2 : 0);  // + x_{t-1} and the done flag of the step loop (+ contact counts
+  L.xrec = o; o += m.input_dim + 2 + (w2 ? 4 : 0);  // + x_{t-1} and the done flag of the step loop (+ contact counts
                                                     //   handed from the helper to the main wavefront)
   // two pairs with disjoint lifetimes share their storage:
   //   swd  (world motion axes per dof: phases C..J)  |  rows (b, 1/(G+cfm), G per constraint row: K..L)
