@@ -798,6 +798,10 @@ int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_
     }
     if (e == hipSuccess && rc == TDS_OK && graph) e = hipGraphInstantiate(&s->graph_exec[c], graph, nullptr, nullptr, 0);
     if (graph) (void)hipGraphDestroy(graph);
+    // (device-side copy of the executable graph made now, not by the first launch: a short replay — the 20-step runs of
+    //  a benchmark driver — otherwise pays it inside its timed region)
+    if (e == hipSuccess && rc == TDS_OK && s->graph_exec[c] && getenv("TDS_HIP_NO_GRAPH_UPLOAD") == nullptr)
+      (void)hipGraphUpload(s->graph_exec[c], s->graph_stream);
     if (e != hipSuccess || rc != TDS_OK || !s->graph_exec[c]) {
       if (rc == TDS_OK) snprintf(g_err, sizeof(g_err), "graph capture / instantiation failed: %s", hipGetErrorString(e));
       drop_graphs(s);
