@@ -250,7 +250,12 @@ __device__ __forceinline__ int bcast32_b32(int x) {
 }
 template <int SRC>
 __device__ __forceinline__ double bcast32(double v) {
-  return __hiloint2double(bcast32_b32<SRC>(__double2hiint(v)), bcast32_b32<SRC>(__double2loint(v)));
+  // (one 64-bit row broadcast — row_newbcast is the DPP control the 64-bit ALU takes — then the row swap per half)
+  const double t = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + (SRC & 15), 0xF, 0xF, true);
+  const unsigned tl = (unsigned)__double2loint(t), th = (unsigned)__double2hiint(t);
+  const auto rl = __builtin_amdgcn_permlane16_swap(tl, tl, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(th, th, false, false);
+  return __hiloint2double((int)(SRC < 16 ? rh[0] : rh[1]), (int)(SRC < 16 ? rl[0] : rl[1]));
 }
 template <int SRC>
 __device__ __forceinline__ float bcast32(float v) {
@@ -278,10 +283,8 @@ __device__ __forceinline__ T group_sum(T v) {
 // (a VALU move, no LDS round trip); wider groups go through ds_bpermute.
 template <int SRC>
 __device__ __forceinline__ double dpp_bcast(double v) {
-  const int l = __double2loint(v), h = __double2hiint(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, l, 0x150 + SRC, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, h, 0x150 + SRC, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
+  // row_newbcast is the one DPP control the 64-bit ALU takes (gfx90a on): ONE v_mov_b64_dpp instead of two 32-bit moves
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + SRC, 0xF, 0xF, true);
 }
 template <int SRC>
 __device__ __forceinline__ float dpp_bcast(float v) {
