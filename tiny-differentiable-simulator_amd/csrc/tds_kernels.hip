@@ -204,6 +204,19 @@ template <int D>
 __device__ __forceinline__ float dpp_shr(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xF, 0xF, true));
 }
+// the same shift, lanes without a source (the first D of every row) receive 1 instead of 0 (the low word of 1.0 is 0:
+// only the high word needs a pre-set destination)
+template <int D>
+__device__ __forceinline__ double dpp_shr_one(double v) {
+  const int l = __double2loint(v), h = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, l, 0x110 + D, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0x3FF00000, h, 0x110 + D, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int D>
+__device__ __forceinline__ float dpp_shr_one(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0x3F800000, __float_as_int(v), 0x110 + D, 0xF, 0xF, false));
+}
 // 32 payload bits carried through an LDS slot of the compute scalar (no arithmetic on them)
 template <typename T>
 __device__ __forceinline__ T bits_to_scalar(unsigned b);
@@ -1000,6 +1013,21 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
         }                                                                   \
       }                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                    \
+    }                                                                       \
+  } while (0)
+
+// TDS_PROBE(id): one extra timestamp (slot 10, free in the two-wavefront form) at the probe selected by
+// TDS_GRAM_STAMP_AT=id — for splitting a phase without adding stamps to the record (tools/profile_phases.py)
+#define TDS_PROBE(id)                                                       \
+  do {                                                                      \
+    if (PROF && W2) {                                                       \
+      if ((ctl.flags >> 8) == (id)) {                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        __builtin_amdgcn_s_waitcnt(0);                                      \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tds_iter == 0)           \
+          prof[10] = (long long)__builtin_amdgcn_s_memtime();               \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+      }                                                                     \
     }                                                                       \
   } while (0)
 
@@ -1864,22 +1892,25 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
     static_for<0, 3>([&](auto dc) {
       constexpr int D = 1 << decltype(dc)::value;
-      T Rq[9], pq[3];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Rq[k] = dpp_shr<D>(R[k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) pq[k] = dpp_shr<D>(p[k]);
+      // No selects: the first D lanes of a row have no source and receive the IDENTITY transform (composing with it
+      // is exact), and what the lanes behind the chain pick up does not matter — their R, p are assigned afresh at
+      // their own level from the local transform.
       if (D <= rkc && !fl) {  // wave-uniform
+        T Rq[9], pq[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rq[k] = (k == 0 || k == 4 || k == 8) ? dpp_shr_one<D>(R[k]) : dpp_shr<D>(R[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pq[k] = dpp_shr<D>(p[k]);
         T Rn[9], r[3];
         mat3_mul(Rq, R, Rn);
         mat3_mulv(Rq, p, r);
-        const bool upd = inch && li >= D;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = upd ? Rn[k] : R[k];
+        for (int k = 0; k < 9; ++k) R[k] = Rn[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = upd ? pq[k] + r[k] : p[k];
+        for (int k = 0; k < 3; ++k) p[k] = pq[k] + r[k];
       }
     });
+    TDS_PROBE(11);
     // world motion axes and velocities of the chain: v_i = sum_{j <= i} s_j qd_j (prefix sum)
     if (inch) {
       mat3_mulv(R, Sl, sw);
@@ -1894,10 +1925,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
     static_for<0, 3>([&](auto dc) {
       constexpr int D = 1 << decltype(dc)::value;
-      const T m = (inch && li >= D) ? T(1) : T(0);
+      // (no mask: lanes without a source receive 0, the lanes behind the chain assign v afresh at their level)
 #pragma unroll
-      for (int k = 0; k < 6; ++k) v[k] += m * dpp_shr<D>(v[k]);
+      for (int k = 0; k < 6; ++k) v[k] += dpp_shr<D>(v[k]);
     });
+    TDS_PROBE(12);
     // bias accelerations of the chain: prefix sum of cb on top of the base acceleration -gravity.
     // (floating base: a0 stays zero — the axes move with the base, v x v = 0, and the reference adds gravity
     //  to the base acceleration AFTER the joint accelerations are known, forward_dynamics.hpp:315-319)
@@ -1908,9 +1940,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
     static_for<0, 3>([&](auto dc) {
       constexpr int D = 1 << decltype(dc)::value;
-      const T m = (inch && li >= D) ? T(1) : T(0);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) a0[k] += m * dpp_shr<D>(a0[k]);
+      for (int k = 0; k < 6; ++k) a0[k] += dpp_shr<D>(a0[k]);
     });
     if (inch && !fl) {
       a0[3] -= mdl->grav[0];
@@ -1930,6 +1961,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
     TDS_WAVE_SYNC();
   }
+  TDS_PROBE(13);
   for (int lev = rkc + 1; lev < nlev; ++lev) {
     const bool mine = level == lev;
     const bool by_dpp = mine && chain_child;
@@ -2041,7 +2073,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       }
     }
     if (__any(mine && lds_children)) TDS_WAVE_SYNC();
+    if (lev == rkc + 1) TDS_PROBE(14);
   }
+  TDS_PROBE(15);
   // X_world of the remaining links (narrowphase, visual poses) and the world motion axes per dof
   if (isl && !lds_children) {
 #pragma unroll
