@@ -1966,14 +1966,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     const bool mine = level == lev;
     const bool by_dpp = mine && chain_child;
     const bool by_lds = mine && parent >= 0 && !chain_child;
+    // the parent's record: from lane - 1 by DPP (chain children) or from LDS (the others); no zero-filling — every
+    // lane of the level is served by one of the two or is a root (below), the other lanes discard what they get.
     T Rq[9], pq[3], vq[6], aq[6];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rq[k] = T(0);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) pq[k] = T(0);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) vq[k] = aq[k] = T(0);
-    if (__any(by_dpp)) {  // wave-uniform; the moves themselves run on every lane
+    const bool any_dpp = __any(by_dpp) != 0, any_lds = __any(by_lds) != 0;
+    if (any_dpp) {  // (the moves run on EVERY lane: a DPP source lane must be active)
 #pragma unroll
       for (int k = 0; k < 9; ++k) Rq[k] = dpp_neighbour<false>(R[k]);
 #pragma unroll
@@ -1983,18 +1980,30 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         vq[k] = dpp_neighbour<false>(v[k]);
         aq[k] = dpp_neighbour<false>(a0[k]);
       }
-    }
-    if (by_lds) {
+      if (by_lds) {  // both kinds at one level (the Ant's hips: lane 6 follows the torso in lane 5, the other three do not)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Rq[k] = Xw[parent * TDS_S1 + k];
+        for (int k = 0; k < 9; ++k) Rq[k] = Xw[parent * TDS_S1 + k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) pq[k] = Xw[parent * TDS_S1 + 9 + k];
+        for (int k = 0; k < 3; ++k) pq[k] = Xw[parent * TDS_S1 + 9 + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          vq[k] = va[par_slot * TDS_S1 + k];
+          aq[k] = va[par_slot * TDS_S1 + 6 + k];
+        }
+      }
+    } else {
+      const int pl = by_lds ? parent : 0, ps = by_lds ? par_slot : 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rq[k] = Xw[pl * TDS_S1 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pq[k] = Xw[pl * TDS_S1 + 9 + k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        vq[k] = va[par_slot * TDS_S1 + k];
-        aq[k] = va[par_slot * TDS_S1 + 6 + k];
+        vq[k] = va[ps * TDS_S1 + k];
+        aq[k] = va[ps * TDS_S1 + 6 + k];
       }
     }
+    (void)any_lds;
     if (mine) {
       if (parent < 0) {
 #pragma unroll
