@@ -397,7 +397,8 @@ template <bool SLAB, typename T, int G, int NDP, bool SPLIT = false>
 __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, int ZR, int OVR, int NCPp,
                                               T *Zs, T *rws, T *xs, const T *qdv, const T *cpx, const T *Lp,
                                               const T *dvec, volatile T *zov, volatile T *rov, T cfm, T erp_dt,
-                                              T rest, const volatile T *yt_flag = nullptr, T dt = T(0)) {
+                                              T rest, const volatile T *yt_flag = nullptr, T dt = T(0),
+                                              const volatile T *col_flag = nullptr, const T *Lh = nullptr) {
   constexpr int NDs = NDP + 1;
   // ROW LAYOUT (wave-uniform): NA = largest number of penetrating contacts among the wavefront's
   // environments; row a = normal of contact a, NA + a = tangent 1, 2 NA + a = tangent 2.  An environment
@@ -431,11 +432,26 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
         brow = vrow;
       else
         brow = t == 0 ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + a] : vrow;
-      // column-oriented: once z[j] is final, every later z[k] takes its update independently
+      // column-oriented: once z[j] is final, every later z[k] takes its update independently.
+      // col_flag (two-wavefront workgroups): the main wavefront is still factorising — it raises the flag to 1 when
+      // columns 0 .. NDP/2 - 1 of L are in LDS and to 2 when all of L and D are: the first three quarters of this
+      // substitution run in the shadow of the second half of the LDL^T instead of after it.
 #pragma unroll
       for (int j = 0; j < NDP - 1; ++j) {
+        if constexpr (SPLIT && !SLAB) {
+          if (col_flag != nullptr && (j == 0 || j == NDP / 2)) {  // wave-uniform
+            const T need = j == 0 ? T(1) : T(2);
+            while (__any(*col_flag < need)) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (compile-time order of the LDS reads only)
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
 #pragma unroll
-        for (int k = j + 1; k < NDP; ++k) z[k] -= Lp[(k * (k - 1)) / 2 + j] * z[j];
+        for (int k = j + 1; k < NDP; ++k) {
+          // (two-wavefront pipeline: the first NDP/2 columns arrive early in a row-major copy, stride NDP/2)
+          const T lkj = (SPLIT && !SLAB && Lh != nullptr && j < NDP / 2) ? Lh[k * (NDP / 2) + j] : Lp[(k * (k - 1)) / 2 + j];
+          z[k] -= lkj * z[j];
+        }
       }
 #pragma unroll
       for (int k = 0; k < NDP; ++k) {
@@ -1190,6 +1206,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   constexpr bool two = KIND == 3;
   // contact solve in Gram form on the matrix cores (tds_gram_solve): two-wavefront workgroups of 16-lane environments
   constexpr bool GRAM = W2 && G == 16 && NDP <= 16 && std::is_same<T, double>::value;
+  // two-wavefront workgroups, narrow kernels: no barrier between the LDL^T and the helper's row solves — L reaches the
+  // helper in two halves through LDS flags (tds_row_solve), the contact counts reach this wavefront the same way
+  constexpr bool PIPE = W2 && NDP <= 16;
   const bool body_b = two && isl && mdl->body_of_link[lsafe] != 0;
   const int njd = mdl->nj;                       // joint dofs (== nd on a fixed base)
   const bool froot = fl && isl && li < 6;        // base pseudo link
@@ -1666,9 +1685,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       const bool contacts_h = __any(na_h > 0) != 0;
       const int NA_h = wave_max(na_h);
       const bool split_ok = 3 * NA_h <= ZR;  // (more rows than the LDS store holds: the main wavefront takes the slab path)
-      if (lane == 0) {  // contact count of the environment / row slots of the wavefront, for the main wavefront
-        xr[in_dim + 2] = bits_to_scalar<T>((unsigned)na_h);
-        xr[in_dim + 3] = bits_to_scalar<T>((unsigned)NA_h);
+      if constexpr (!PIPE) {
+        if (lane == 0) {  // contact count of the environment / row slots of the wavefront, for the main wavefront
+          xr[in_dim + 2] = bits_to_scalar<T>((unsigned)na_h);
+          xr[in_dim + 3] = bits_to_scalar<T>((unsigned)NA_h);
+        }
       }
       TDS_STAMP(3);
       phase_M1();
@@ -1685,12 +1706,21 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       TDS_STAMP(4);
       if (contacts_h && split_ok) phase_J(na_h, NA_h);
       TDS_STAMP(5);
-      __syncthreads();  // (2) the factors L, 1/D are in LDS; the rows and the contact list are visible to the main wavefront
+      if constexpr (PIPE) {
+        // (2') contact list and rows are in LDS: the counts double as the "ready" signal the main wavefront polls
+        TDS_WAVE_SYNC();
+        if (lane == 0) xr[in_dim + 2] = bits_to_scalar<T>((unsigned)na_h);
+        TDS_WAVE_SYNC();
+        if (lane == 0) xr[in_dim + 3] = bits_to_scalar<T>((unsigned)NA_h);
+      } else {
+        __syncthreads();  // (2) the factors L, 1/D are in LDS; the rows and the contact list are visible to the main wavefront
+      }
       TDS_STAMP(6);
       if (contacts_h && split_ok)
         tds_row_solve<false, T, G, NDP, true>(lane, NA_h, na_h, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, E + L.Lp,
                                              E + L.dinv, nullptr, nullptr, pf_cfm, pf_erp_dt, pf_rest,
-                                             L.gram_ok ? nullptr : xr + in_dim + 4, dt);
+                                             L.gram_ok ? nullptr : xr + in_dim + 4, dt,
+                                             PIPE ? xr + in_dim + 5 : nullptr, PIPE ? E + L.Lh : nullptr);
       TDS_STAMP(7);
       __syncthreads();  // (3) z~ rows and their scalars are final
       TDS_STAMP(8);
@@ -2108,7 +2138,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   bool wave_contacts = false;
   int nb_pairs = 0, NB_pairs = 0;  // two-body worlds: penetrating contacts between the bodies (this group / wavefront max)
   if constexpr (W2) {
-    if (lane == 0) xr[in_dim + 4] = T(0);  // "y~ is published" (phase F), polled by the helper wavefront
+    if (lane == 0) {
+      xr[in_dim + 4] = T(0);  // "y~ is published" (phase F), polled by the helper wavefront
+      if constexpr (PIPE) {
+        xr[in_dim + 5] = T(0);                               // columns of L published (0, 1 = first half, 2 = all + D)
+        xr[in_dim + 3] = bits_to_scalar<T>(0xFFFFFFFFu);     // the helper's contact counts: not there yet
+      }
+    }
     __syncthreads();  // (1) x record, X_world and the motion axes are in LDS: the helper wavefront starts
   } else {
     // (step-loop build: the constants of the later phases are fetched only now — one L2 round trip per iteration
@@ -2393,6 +2429,18 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         });
         my_inv = lane == k ? inv : my_inv;
         Mr[k] = lane > k ? lr : Mr[k];
+        if constexpr (PIPE && k == NDP / 2 - 1) {
+          // columns 0 .. k of L are final: off they go, every lane its row's first entries at a fixed stride (no
+          // address selects in the middle of the factorisation: it has no registers to spare; entries above the
+          // diagonal are written too and never read)
+          // (volatile stores: kept in program order — data, then flag — without a scheduling barrier in the middle of
+          //  the factorisation)
+          volatile T *const Lh = E + L.Lh + (lane < 16 ? lane : 16) * (NDP / 2);  // (row 16: lanes beyond the rows)
+#pragma unroll
+          for (int j = 0; j <= k; ++j) Lh[j] = Mr[j];
+          // (flag by lane 0, the other lanes hit a scratch slot of their own: an address select, no branch)
+          *(volatile T *)(lane == 0 ? xr + in_dim + 5 : dvec + 2 * NDP + lane) = T(1);
+        }
       } else {
         // wider systems: every lane publishes its column-k entry once, all lanes read the column
         // back as LDS broadcasts (immediate offsets; ds_bpermute needed one address VGPR per source
@@ -2420,15 +2468,26 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       //  clears next — an address select per entry instead of a branch around each write)
       T *const dump = dvec + 2 * NDP + lane;
 #pragma unroll
-      for (int j = 0; j < NDP - 1; ++j) {
+      for (int j = 0; j < NDP - 1; ++j) {  // (all of it: this wavefront's own back substitutions read the packed copy)
         T *const dst = j < lane ? &Lp[off + j] : dump;
         *dst = Mr[j];
       }
     }
+    if constexpr (PIPE) {
+      TDS_WAVE_SYNC();
+      if (lane == 0) xr[in_dim + 5] = T(2);
+    }
     TDS_STAMP(7);
     bool split_ok = false;  // two-wavefront workgroup: the helper wavefront does the row solves
     if constexpr (W2) {
-      __syncthreads();  // (2) L, 1/D are in LDS for the helper wavefront's row solves; its contact list and rows are visible here
+      if constexpr (PIPE) {
+        // (2') no barrier: the helper has long written its contact counts (after its Jacobian rows) — poll them
+        const volatile T *const cnt = xr + in_dim + 3;
+        while (__any(scalar_to_bits<T>(*cnt) == 0xFFFFFFFFu)) __builtin_amdgcn_s_sleep(1);
+        TDS_WAVE_SYNC();
+      } else {
+        __syncthreads();  // (2) L, 1/D are in LDS for the helper wavefront's row solves; its contact list and rows are visible here
+      }
       if constexpr (GRAM) {  // (the sweep groups' storage is free from here on: zeros for tds_gram_solve's masked lanes)
         if (L.gram_ok && lane < 16) E[L.Xw + TDS_GRAM_ZEROS + lane] = T(0);
       }
@@ -3072,6 +3131,8 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   L.pc = o;
   if (npc > 0) o += 17 * L.NPCp;  // contact list of the pairs: lives from the narrowphase to the second pass
   L.Lp = o;   o += (ndp * (ndp - 1)) / 2;
+  L.Lh = o;   // two-wavefront pipeline (narrow kernels): row-major copy of the first ndp/2 columns of L, 16 + 1 rows
+  if (w2 && ndp <= 16) o += 17 * (ndp / 2);  // (+ one row for the lanes of wider groups that own no row)
   L.dinv = o; o += (w2 ? 4 : 3) * ndp;  // 1/D | sqrt(1/D) | column scratch of the wide LDL^T / rhs exchange (| y~)
   // three phase groups share one region:
   //   1. kinematics sweep:   per-link records [X_world(12) | v(6)]              stride TDS_S1
