@@ -67,7 +67,7 @@ if tw is not None:
             "E composite sweep", "G mass matrix", "H LDLt  (-> barrier 2)", "F solve  (after barrier 2; -> barrier 3)",
             "after barrier 3", "(not stamped in this form)", "right-hand sides", "L contact solve", "M/N integrate + pack"]
     HELP = ["start", "constants loaded  (-> barrier 1)", "after barrier 1", "I narrowphase", "M1 visual poses + y tail",
-            "J rows  (-> barrier 2)", "after barrier 2", "K row solves  (-> barrier 3)", "after barrier 3"]
+            "J rows  (-> barrier 2 / counts published)", "after barrier 2 / publishing", "K row solves  (-> barrier 3)", "after barrier 3"]
     print("two-wavefront form, workgroup 0: cycle at which each phase ENDS (0 = the main wavefront's first stamp)")
     ex = tw[2]
     print(f"  workgroup 0 first -> last stamp: {tw[0][13]} shader cycles in {ex['wg0_wall_us']:.2f} us of the 100 MHz wall clock"
