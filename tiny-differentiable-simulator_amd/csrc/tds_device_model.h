@@ -72,6 +72,11 @@ struct DevModel {
   // (root_last+1)-dof joint of link root_last (one small SPD solve) instead of root_last+1 tree
   // levels.  -1: no such chain.
   int root_last;
+  // kinematics only: links 0..kin_chain_last are a serial chain in consecutive lanes (parent of lane i is lane i - 1),
+  // massless or not — their world transforms, velocities and bias accelerations are prefix scans over the lanes (4 DPP
+  // rounds for up to 16 links) instead of one tree level per link; the level loop then starts at kin_lev0, the first
+  // level that holds a link outside the chain.  (>= root_last; a pendulum is all chain.)
+  int kin_chain_last, kin_lev0;
   T X_T[12][TDS_NL];            // rot (row-major 9) | trans (3)
   T S[6][TDS_NL];
   T mass[TDS_NL], com[3][TDS_NL], inertia[9][TDS_NL];
@@ -333,9 +338,20 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
           m->links[k].joint_type != TDS_JOINT_SPH2)
         d->root_last = k;
       if (fl) d->root_last = 5;  // the six pseudo links ARE the root joint (the kernels special-case their kinematics)
+      d->kin_chain_last = d->root_last;
+      const char *nk = getenv("TDS_HIP_NO_KINCHAIN");
+      if (use_chain && !fl && d->num_spherical == 0 && !d->two_bodies && nroots == 1 && !(nk && nk[0] == '1') &&
+          m->num_links > 0 && m->links[0].parent < 0) {
+        int c = 0;
+        while (c + 1 < m->num_links && c + 1 < 16 && m->links[c + 1].parent == c && (d->chain_flags[c + 1] & 1)) ++c;
+        if (c > d->kin_chain_last) d->kin_chain_last = c;
+      }
     }
   }
   d->num_levels = max_level + 1;
+  d->kin_lev0 = d->num_levels;
+  for (int i = d->kin_chain_last + 1; i < m->num_links; ++i)
+    if (d->level[i] < d->kin_lev0) d->kin_lev0 = d->level[i];
   // CRBA pair list
   int np = 0;
   for (int i = 0; i < m->num_links; ++i) {

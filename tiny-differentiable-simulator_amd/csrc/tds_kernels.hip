@@ -1884,10 +1884,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     cb[5] = c1[2] + c2[2];
   };
   const int nlev = mdl->num_levels;
-  const int rkc = mdl->root_last;  // root chain 0..rkc in lanes 0..rkc (see E'): -1 = none
+  const int rkc = mdl->kin_chain_last;  // serial chain 0..rkc from the base in lanes 0..rkc (>= the root joint of E'): -1 = none
   if (rkc >= 0) {
     // The root chain's world transforms are a prefix product of the local ones along consecutive lanes:
-    // inclusive scan with DPP row shifts (3 rounds) instead of rkc+1 tree levels.
+    // inclusive scan with DPP row shifts (ceil(log2(rkc + 1)) <= 4 rounds) instead of rkc+1 tree levels.
     //   (Ra, ta) o (Rb, tb) = (Ra Rb, ta + Ra tb)        (transform.hpp:123-131)
     const bool inch = isl && li <= rkc;
     if (fl) {
@@ -1920,7 +1920,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 #pragma unroll
       for (int k = 0; k < 3; ++k) p[k] = tp[k];
     }
-    static_for<0, 3>([&](auto dc) {
+    static_for<0, 4>([&](auto dc) {
       constexpr int D = 1 << decltype(dc)::value;
       // No selects: the first D lanes of a row have no source and receive the IDENTITY transform (composing with it
       // is exact), and what the lanes behind the chain pick up does not matter — their R, p are assigned afresh at
@@ -1953,11 +1953,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 #pragma unroll
       for (int k = 0; k < 6; ++k) v[k] = vJ[k] = sw[k] * qd;
     }
-    static_for<0, 3>([&](auto dc) {
+    static_for<0, 4>([&](auto dc) {
       constexpr int D = 1 << decltype(dc)::value;
       // (no mask: lanes without a source receive 0, the lanes behind the chain assign v afresh at their level)
+      if (D <= rkc) {  // wave-uniform
 #pragma unroll
-      for (int k = 0; k < 6; ++k) v[k] += dpp_shr<D>(v[k]);
+        for (int k = 0; k < 6; ++k) v[k] += dpp_shr<D>(v[k]);
+      }
     });
     TDS_PROBE(12);
     // bias accelerations of the chain: prefix sum of cb on top of the base acceleration -gravity.
@@ -1968,10 +1970,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 #pragma unroll
       for (int k = 0; k < 6; ++k) a0[k] = cb[k];
     }
-    static_for<0, 3>([&](auto dc) {
+    static_for<0, 4>([&](auto dc) {
       constexpr int D = 1 << decltype(dc)::value;
+      if (D <= rkc) {  // wave-uniform
 #pragma unroll
-      for (int k = 0; k < 6; ++k) a0[k] += dpp_shr<D>(a0[k]);
+        for (int k = 0; k < 6; ++k) a0[k] += dpp_shr<D>(a0[k]);
+      }
     });
     if (inch && !fl) {
       a0[3] -= mdl->grav[0];
@@ -1992,8 +1996,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     TDS_WAVE_SYNC();
   }
   TDS_PROBE(13);
-  for (int lev = rkc + 1; lev < nlev; ++lev) {
-    const bool mine = level == lev;
+  for (int lev = mdl->kin_lev0; lev < nlev; ++lev) {
+    const bool mine = level == lev && li > rkc;  // (the chain's links are done)
     const bool by_dpp = mine && chain_child;
     const bool by_lds = mine && parent >= 0 && !chain_child;
     // the parent's record: from lane - 1 by DPP (chain children) or from LDS (the others); no zero-filling — every
@@ -2112,7 +2116,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       }
     }
     if (__any(mine && lds_children)) TDS_WAVE_SYNC();
-    if (lev == rkc + 1) TDS_PROBE(14);
+    if (lev == mdl->kin_lev0) TDS_PROBE(14);
   }
   TDS_PROBE(15);
   // X_world of the remaining links (narrowphase, visual poses) and the world motion axes per dof
