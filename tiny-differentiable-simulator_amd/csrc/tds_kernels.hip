@@ -192,6 +192,18 @@ __device__ __forceinline__ float dpp_neighbour(float v) {
   constexpr int CTRL = FROM_NEXT ? 0x101 : 0x111;
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+// lane i receives lane i + D of its 16-lane DPP row (row_shl:D), zero where that lane does not exist
+template <int D>
+__device__ __forceinline__ double dpp_shl(double v) {
+  const int l = __double2loint(v), h = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, l, 0x100 + D, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, h, 0x100 + D, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int D>
+__device__ __forceinline__ float dpp_shl(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + D, 0xF, 0xF, true));
+}
 // lane i receives lane i - D of its 16-lane DPP row (row_shr:D), zero where that lane does not exist
 template <int D>
 __device__ __forceinline__ double dpp_shr(double v) {
@@ -2286,7 +2298,22 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   };
   // with a root joint (DevModel::root_last) the massless base chain 0..rk-1 is handled after the loop
   const int rk = mdl->root_last;  // == level of that link; -1: none
-  for (int lev = nlev - 1; lev > rk; --lev) {
+  // A robot that is ONE serial chain (pendulums, the cartpole): the composites are suffix sums along the lanes —
+  // log2 rounds of DPP shifts and one projection for all links at once instead of one level per link
+  const bool pure_chain = rk < 0 && mdl->kin_chain_last == nl - 1 && nl > 1;  // wave-uniform
+  if (pure_chain) {
+    static_for<0, 4>([&](auto dc) {
+      constexpr int D = 1 << decltype(dc)::value;
+      if (D < nl) {  // (lanes that are no links hold zeros)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fc[k] += dpp_shl<D>(fc[k]);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) Ic[k] += dpp_shl<D>(Ic[k]);
+      }
+    });
+    if (isl) project(Ic, fc);
+  }
+  for (int lev = pure_chain ? rk : nlev - 1; lev > rk; --lev) {
     const bool mine = level == lev;
     if (mine && lds_children) {  // what the children other than lane + 1 handed over
 #pragma unroll
