@@ -241,7 +241,10 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     const bool is_sph = c64 ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
     const char *e = getenv("TDS_HIP_W2");
     const bool is_two_w = c64 ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
-    if (!is_fl && !is_sph && !is_two_w && s->lds.NDP < 24 && !(e && e[0] == '0')) {
+    // (a world without contact points leaves the helper wavefront only the visual poses: the one-wave form is then the
+    //  faster one — pendulum5 x 4096: 10.2 vs 10.9 us — unless TDS_HIP_W2=1/2 insists)
+    const bool has_cp = model->has_plane && (c64 ? s->h64.num_cp : s->h32.num_cp) > 0;
+    if (!is_fl && !is_sph && !is_two_w && s->lds.NDP < 24 && !(e && e[0] == '0') && (has_cp || (e && e[0] != '0'))) {
       s->lds_w2 = c64 ? tds_make_lds_layout<double>(s->h64, na_cap, s->lanes, true)
                       : tds_make_lds_layout<float>(s->h32, na_cap, s->lanes, true);
       const size_t b2 = (size_t)s->lds_w2.stride * epw * celem;
