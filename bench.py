@@ -228,13 +228,64 @@ def main():
         libc.fflush(None)
         saved_fd = os.dup(1)
         os.dup2(2, 1)
+        shard_error = None
         try:
             shard = hip_backend.HipShard(m, world * n, rank=rank, world=world, device=local_rank, dtype=lib_dtype,
                                          unique_id=uid, wire_dtype=args.gather_dtype, block=max(1, args.gather_every))
             libc.fflush(None)
+        except Exception as e:  # e.g. librccl refuses the communicator on this node
+            shard_error = repr(e)
         finally:
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+        if world > 1:  # every rank takes the same path
+            flag = torch.tensor([1 if shard_error else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and shard is not None:
+                shard.close()
+                shard = None
+                shard_error = shard_error or "another rank could not create its shard"
+        if shard is None:
+            # Fallback (never on the 1-GPU box; insurance for the multi-GPU run): the same per-step exchange through
+            # torch.distributed (RCCL under it) — tiny-differentiable-simulator_amd/sharded.py, the round-1 driver.
+            print(f"bench.py: tds_hip_shard_create failed ({shard_error}); falling back to the torch.distributed "
+                  f"exchange", file=sys.stderr)
+            from tds_amd.sharded import PipelinedObsGather
+            sim = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype,
+                                     lanes_per_env=args.lanes if args.lanes else None)
+
+            class _TorchShard:
+                def __init__(self):
+                    wd = torch.float32 if (args.gather_dtype == "f32" or lib_dtype != "f64") else torch.float64
+                    self.g = PipelinedObsGather(world * n, sim.obs_dim + 2, sim.torch_dtype, f"cuda:{local_rank}",
+                                                slots=4, wire_dtype=wd)
+                    self.rec = [torch.zeros((n, sim.obs_dim + 2), dtype=sim.torch_dtype, device="cuda") for _ in range(4)]
+                    self.i = 0
+                    self.sim = sim
+
+                def step(self, a, substeps=1):
+                    slot = self.i % 4
+                    self.g.before_reuse(slot)
+                    sim.step(a, substeps, self.rec[slot])
+                    self.g.submit(self.rec[slot], slot)
+                    self.i += 1
+
+                def step_many(self, actions, k, first_block=0, prepare_only=False):
+                    if prepare_only:
+                        return
+                    for j in range(k):
+                        self.step(actions[(first_block + j) % actions.shape[0]], 1)
+
+                def flush(self):
+                    self.g.wait_all()
+
+                def set_block(self, b):
+                    pass
+
+            shard = _TorchShard()
+            torch_fallback = True
+        else:
+            torch_fallback = False
         sim = shard.sim
     else:
         sim = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype,
@@ -471,10 +522,11 @@ def main():
                        "launch": (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else "")
                                    + ("" if chains is None else ", the batch as %d independent environment chain%s (%s)" % (
                                        chains, "" if chains == 1 else "s", "measured at warm-up" if args.chains == "auto" else "--chains")))
-                                  if use_graph else "one kernel launch per step"),
+                                  if (use_graph and not (multi and torch_fallback)) else "one kernel launch per step"),
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
-                       "parallelism": f"env-shard x{world}" + (
-                           f" + one ncclAllGather (librccl from the C ABI, tds_hip_shard_step) of the (obs|reward|done) "
+                       "parallelism": f"env-shard x{world}" + (" [FALLBACK: exchange through torch.distributed, the C-ABI shard "
+                                                                "could not be created] " if (multi and torch_fallback) else "") + (
+                           f" + one {'all_gather_into_tensor (torch.distributed)' if (multi and torch_fallback) else 'ncclAllGather (librccl from the C ABI, tds_hip_shard_step)'} of the (obs|reward|done) "
                            f"records per {'policy step' if B == 1 else str(B) + ' steps'}, "
                            f"{args.gather_dtype if args.dtype == 'f64' else 'f32'} on the wire (the records are computed "
                            f"and fed back in {'f64' if args.dtype == 'f64' else 'f32'} on the owning GPU), on a "
