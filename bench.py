@@ -141,6 +141,10 @@ def main():
                          "the 1e-6 contract on float records (BASELINE config 2).  f32-pure: float arithmetic "
                          "(measured only: misses 1e-6, like the reference's own float instantiation)")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: K eager launches instead of one hipGraph launch")
+    ap.add_argument("--shard-graph", action="store_true",
+                    help="N > 1: replay steps + exchanges from one hipGraph (tds_hip_shard_step_many) instead of eager "
+                         "tds_hip_shard_step calls.  Off by default at N > 1: the RCCL exchange sets the pace there, the "
+                         "host has time for the calls, and a captured collective has never run on more than one rank")
     ap.add_argument("--chains", default="auto",
                     help="N = 1, graph launches: environment chains of the graph (tds_hip_step_many in tds_hip.h): a number, "
                          "'default' (the library's rule) or 'auto' = measured during warm-up (tds_hip_step_many_tune)")
@@ -323,12 +327,13 @@ def main():
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
     B = max(1, args.gather_every)
     use_graph = not args.no_graph
+    shard_graph = use_graph and multi and (world == 1 or args.shard_graph) and not torch_fallback if multi else False
     GCH = 1024  # steps per graph launch when K is larger (a multiple of the action pool)
     state = {"i": 0}
 
     def run_steps(k_steps):
         """k_steps closed-loop steps with a fresh action block each; multi: + the per-step record exchange"""
-        if multi and use_graph and k_steps % B == 0:
+        if multi and shard_graph and k_steps % B == 0:
             left = k_steps
             while left > 0:  # (chunks: multiples of the action pool and of the exchange block)
                 c = left if left <= GCH else GCH
@@ -359,7 +364,7 @@ def main():
     def prepare(k_steps):
         """build the hipGraph of the next run_steps(k_steps) ahead of time (nothing executes)"""
         if use_graph and k_steps > 0 and multi:
-            if k_steps % B == 0:
+            if k_steps % B == 0 and shard_graph:
                 shard.step_many(actions, min(k_steps, GCH), first_block=state["i"] % pool, prepare_only=True)
         elif use_graph and k_steps > 0:
             sim.step_many_prepare(actions, min(k_steps, GCH), obs, first_block=state["i"] % pool)
@@ -522,7 +527,8 @@ def main():
                        "launch": (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else "")
                                    + ("" if chains is None else ", the batch as %d independent environment chain%s (%s)" % (
                                        chains, "" if chains == 1 else "s", "measured at warm-up" if args.chains == "auto" else "--chains")))
-                                  if (use_graph and not (multi and torch_fallback)) else "one kernel launch per step"),
+                                  if (use_graph and (not multi or shard_graph)) else
+                                  ("one tds_hip_shard_step call per step (kernel launch + exchange)" if multi else "one kernel launch per step")),
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
                        "parallelism": f"env-shard x{world}" + (" [FALLBACK: exchange through torch.distributed, the C-ABI shard "
                                                                 "could not be created] " if (multi and torch_fallback) else "") + (
