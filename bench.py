@@ -374,7 +374,8 @@ def main():
             shard.flush()
 
     chains = None
-    if use_graph and not multi:
+    loop_form = use_graph and not multi and sim.step_many_is_loop(min(args.steps, GCH))
+    if use_graph and not multi and not loop_form:
         if args.chains == "auto":  # 6 x 128 extra untimed steps
             chains = sim.tune_step_many(actions, 128, obs)
         elif args.chains != "default":
@@ -524,7 +525,8 @@ def main():
                                    f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
                        if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
                        "records": "f64" if args.dtype == "f64" else "f32",
-                       "launch": (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else "")
+                       "launch": ("one launch of the step-loop kernel per %d steps (world without contact points: state in LDS "
+                                  "across the steps, one action block per step)" % min(K, GCH)) if loop_form else (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else "")
                                    + ("" if chains is None else ", the batch as %d independent environment chain%s (%s)" % (
                                        chains, "" if chains == 1 else "s", "measured at warm-up" if args.chains == "auto" else "--chains")))
                                   if (use_graph and (not multi or shard_graph)) else

@@ -13,6 +13,7 @@ import pytest
 from conftest import GOLDEN
 
 import tds_amd
+from conftest import rel_err
 from tds_amd import hip_backend
 
 pytestmark = pytest.mark.gpu
@@ -218,6 +219,45 @@ def test_step_many_environment_chains_equal_whole_batch_launches(chains, n, buil
 
     assert torch.equal(bits(graph.x), bits(eager.x)) and torch.equal(bits(graph.y), bits(eager.y))
     assert torch.equal(bits(og), bits(oe))
+
+
+@pytest.mark.parametrize("name,dtype", [("pendulum5", "f64"), ("pendulum5", "mixed"), ("cartpole", "f64")])
+def test_step_many_of_a_contact_free_world_is_one_loop_launch(name, dtype, built, monkeypatch):
+    """Worlds without contact points run their K steps as ONE launch of the step-loop build, every step with its own
+    action block (TdsStepCtl::act_pool): same records as K straight-line launches (to round-off: another build), and
+    the forced graph form agrees too."""
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    n = 300
+    rng = np.random.default_rng(21)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    x = np.zeros((n, m.input_dim))
+    x[:, : m.dof_q] = rng.uniform(-0.5, 0.5, (n, m.dof_q))
+    x[:, m.dof_q: m.dof_q + m.dof_qd] = rng.uniform(-0.5, 0.5, (n, m.dof_qd))
+    acts = rng.uniform(-0.3, 0.3, (6, n, m.action_dim))
+    a = torch.from_numpy(acts).to(tdt).cuda().contiguous()
+    K = 37
+    res = {}
+    for form in ("eager", "loop", "graph"):
+        if form == "graph":
+            monkeypatch.setenv("TDS_HIP_STEP_MANY_LOOP", "0")
+        sim = hip_backend.HipSim(m, n, dtype=dtype)
+        sim.x.copy_(torch.from_numpy(x).to(tdt).cuda())
+        obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
+        if form == "eager":
+            for k in range(K):
+                sim.step(a[(4 + k) % 6], 1, obs)
+        else:
+            sim.step_many(a, K, obs, first_block=4)
+        torch.cuda.synchronize()
+        res[form] = (sim.x.double().cpu().numpy(), sim.y.double().cpu().numpy(), obs.double().cpu().numpy())
+    # (float records: K launches round the state to float after every step, the loop keeps it in double in LDS and
+    #  rounds once at the end — per step both are within the contract, the trajectories drift apart at float rounding)
+    tol = 1e-9 if dtype == "f64" else 1e-3
+    for form in ("loop", "graph"):
+        for u, v in zip(res[form], res["eager"]):
+            assert rel_err(u, v) < tol, form
+    assert np.array_equal(res["graph"][0], res["eager"][0])  # (same build, same rounding points: bit for bit)
 
 
 def test_step_many_tune_picks_a_chain_count_and_keeps_the_records(built):

@@ -126,6 +126,12 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     ctl.shift = ro->shift;
     ctl.flags = ro->flags;
   }
+  if (opts && opts->act_pool) {
+    ctl.act_pool = (const char *)opts->act_pool + (size_t)opts->env_first * s->model.action_dim * s->elem;
+    ctl.act_blocks = opts->act_blocks;
+    ctl.act_first = opts->act_first;
+    ctl.act_envs = s->num_envs;
+  }
   ctl.flags |= ctl_flags;
   ctl.nsub = nsub;
   ctl.reset_mode = reset_mode;
@@ -822,6 +828,22 @@ int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_
 }  // namespace
 }  // extern "C++"
 
+extern "C++" {
+namespace {
+// Worlds without contact points (pendulums, the cartpole) have step kernels of ~7 us, of which a kernel boundary is
+// a third and which leave no second wavefront per SIMD for another chain to fill it: their K steps run as ONE launch of
+// the step-loop build instead, every step taking its own action block (TdsStepCtl::act_pool).
+// TDS_HIP_STEP_MANY_LOOP=0 / 1 forbids / forces it.
+bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
+  if (n_steps < 2) return false;
+  if (const char *e = getenv("TDS_HIP_STEP_MANY_LOOP")) return e[0] == '1';
+  const int ncp = s->compute_f64() ? s->h64.num_cp : s->h32.num_cp;
+  const bool two = s->compute_f64() ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
+  return !(s->model.has_plane && ncp > 0) && !two;
+}
+}  // namespace
+}  // extern "C++"
+
 int tds_hip_step_many_prepare(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block,
                               int n_steps, void *obs_dev) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
@@ -831,6 +853,7 @@ int tds_hip_step_many_prepare(tds_hip_sim_t *s, const void *actions_dev, int act
   DeviceGuard guard(s->device);
   const int pool = actions_dev ? action_blocks : 1;
   const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
+  if (step_many_as_loop(s, n_steps)) return TDS_OK;  // (one kernel launch: nothing to build)
   if (graph_matches(s, actions_dev, pool, first, n_steps, obs_dev)) return TDS_OK;
   return build_graph(s, actions_dev, pool, first, n_steps, obs_dev);
 }
@@ -849,6 +872,17 @@ int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_bloc
   TimedCall timed(s);
   const int pool = actions_dev ? action_blocks : 1;
   const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
+  if (!eager && step_many_as_loop(s, n_steps)) {
+    LaunchOpts lo;
+    const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
+    const void *a0 = actions_dev ? (const char *)actions_dev + (size_t)first * blk : nullptr;
+    if (actions_dev) {
+      lo.act_pool = actions_dev;
+      lo.act_blocks = pool;
+      lo.act_first = first;
+    }
+    return launch(s, s->d_x, s->d_y, a0, s->d_x, obs_dev, s->num_envs, n_steps, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
+  }
   const int C = eager ? chain_count(s, n_steps) : s->graph_chains;
   if (eager) {
     int rc = chain_streams(s, C);
@@ -874,6 +908,8 @@ int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_bloc
   }
   return TDS_OK;
 }
+
+int tds_hip_step_many_is_loop(const tds_hip_sim_t *s, int n_steps) { return s && step_many_as_loop(s, n_steps) ? 1 : 0; }
 
 int tds_hip_set_graph_chains(tds_hip_sim_t *s, int chains) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");

@@ -107,6 +107,8 @@ struct LaunchOpts {
   bool other_stream = false;          // launch on `stream` instead of the handle's
   hipStream_t stream = nullptr;
   const TdsLds *lds = nullptr;        // LDS layout (the refill launches keep every constraint row in LDS: no slab)
+  const void *act_pool = nullptr;     // step-loop launch with a different action block per step (TdsStepCtl::act_pool)
+  int act_blocks = 0, act_first = 0;
   int env_first = 0;                  // this launch serves environments [env_first, env_first + n) of the records
   int env_total = 0;                  // (> 0: environments of ALL launches resident at the same time, for the form choice)
 };

@@ -47,6 +47,10 @@ struct TdsStepCtl {
   const void *pool;           // != NULL: pre-settled reset states [pool_depth][pool_envs][dof_q + dof_qd] (record
   int pool_depth, pool_envs;  //          dtype), ring per environment indexed by its reset count; a done environment
                               //          takes its next state from here (auto-reset without the step loop)
+  // step-loop launches only: a different action block per step (tds_hip_step_many as ONE launch)
+  const void *act_pool;       // != NULL: [act_blocks][act_envs][action_dim] (record dtype); step k of the launch takes block
+  int act_blocks, act_first;  //          (act_first + k) % act_blocks (step 0's block is also what `actions` points to)
+  int act_envs;               //          environments per block (= the batch the blocks were laid out for)
   int flags;                  // bit 0: the first step observes the raw base x, y (state fresh from reset())
                               // TDS_CTL_RESET_CALL: the launch is tds_hip_reset (the environment's own reset():
                               // its observation keeps the base x, y where the model says so), not an auto-reset

@@ -1133,6 +1133,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   int sleft = 0;                   // settle steps still to run (mode SETTLE)
   // rollout mode: return accumulated so far, its step count, "done and not auto-reset" latch
   const bool pol = LOOP && ctl.policy != nullptr;
+  // action replay (tds_hip_step_many as one launch): the block of step k + 1 is requested from HBM at the top of step k
+  const bool replay = LOOP && ctl.act_pool != nullptr && ctl.policy == nullptr;
+  T next_act = T(0);
   T ret = T(0);
   int cnt = 0;
   bool frozen = false;
@@ -1325,6 +1328,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   const bool last_run = mode == TDS_MODE_RUN && left == 1;
   const bool settling = LOOP && mode == TDS_MODE_SETTLE;
   if constexpr (LOOP) {
+    if (replay) {  // wave-uniform
+      if (tds_iter > 0 && mode == TDS_MODE_RUN && lane < adim) xr[nq + nd + lane] = next_act;
+      if (valid && lane < adim) {
+        const int blk = (ctl.act_first + tds_iter + 1) % ctl.act_blocks;
+        next_act = (T)((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
+      }
+      TDS_WAVE_SYNC();
+    }
     // ---- rollout mode: action = W obs + b with the environment's own parameters
     //      (VectorizedEnvironment::policy -> NeuralNetwork::compute, one linear layer with bias, identity:
     //       ars_vectorized_environment.h:165-180,293-300; neural_network.hpp:223-262);
