@@ -498,12 +498,17 @@ def main():
             traffic, traffic_src = pmc_traffic(args.model, n, args.dtype)  # (measured on whole-batch launches)
             if traffic is not None:
                 traffic = traffic // conc
+            spl = min(K, GCH) if loop_form else 1  # steps per launch (loop form: one launch = spl steps)
+            if loop_form:
+                # the state stays in LDS across the steps of a launch: per step only the action block is read, the
+                # records are written once per launch — the per-step PMC figures of single-step launches do not apply
+                traffic, traffic_src = None, None
             arith = "f32" if args.dtype == "f32-pure" else "f64"
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "tds_step_kernel", "kernel_ms_avg": kernel_ms,
+                    "kernel": "tds_step_kernel", "kernel_ms_avg": kernel_ms * spl, "steps_per_launch": spl,
                     "kernel_ms_isolated": kernel_ms_isolated,
-                    "algorithmic_bytes_per_launch": n * bytes_per_env_step // conc,
+                    "algorithmic_bytes_per_launch": n * bytes_per_env_step * spl // conc,
                     "launches_in_flight": conc,
                     "achieved_per_launch": achieved / conc,
                     # secondary view: flops of the reference's dense formulation per env-step
