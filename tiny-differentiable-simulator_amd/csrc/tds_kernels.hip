@@ -437,8 +437,11 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
       }
       T vrow = T(0);
 #pragma unroll
-      for (int k = 0; k < NDP; ++k) vrow += z[k] * qdv[k];  // (padding columns k >= nd: z[k] == 0 exactly; a term under
-                                                            //  `if (k < nd)` is a uniform branch with its own LDS round trip)
+      // (padding columns k >= nd: z[k] == 0 exactly, and the velocity slot read for them is a real one (index clamped):
+      //  behind the velocities of the record lie slots nobody writes in the straight-line kernels, and 0 x stale LDS is
+      //  NaN once in a while — seen twice in ~40 suite runs.  A term under `if (k < nd)` would be a uniform branch with
+      //  its own LDS round trip.)
+      for (int k = 0; k < NDP; ++k) vrow += z[k] * qdv[k < nd ? k : 0];
       // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1+e) n.rel_vel - erp dist/dt,  b_t = -t.rel_vel
       if constexpr (SPLIT)
         brow = vrow;
@@ -2481,7 +2484,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 #pragma unroll
           for (int j = 0; j <= k; ++j) Lh[j] = Mr[j];
           // (flag by lane 0, the other lanes hit a scratch slot of their own: an address select, no branch)
-          *(volatile T *)(lane == 0 ? xr + in_dim + 5 : dvec + 2 * NDP + lane) = T(1);
+          *(volatile T *)(lane == 0 ? xr + in_dim + 5 : dvec + 2 * NDP + (lane < NDP ? lane : NDP - 1)) = T(1);
         }
       } else {
         // wider systems: every lane publishes its column-k entry once, all lanes read the column
