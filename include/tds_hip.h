@@ -402,6 +402,13 @@ int tds_hip_last_kernel_ms(tds_hip_sim_t *sim, float *ms);
    barrier 2, after barrier 2, row solves = before barrier 3, after barrier 3).  Synchronises the stream. */
 int tds_hip_profile_phases(tds_hip_sim_t *sim, long long *cycles_host, int n);
 
+/* Test aid: fills the LDS of every compute unit of the handle's device with a byte pattern (0xFF = NaN in every
+   scalar type) by running workgroups that own a whole CU's LDS.  The step kernels never clear LDS, so a read of a slot
+   nobody wrote normally sees benign leftovers; after this call it sees the pattern — a forgotten initialisation or a
+   "0 x whatever" on an unwritten slot shows up as NaN deterministically instead of once in a blue moon
+   (tests/test_hip_parity.py::test_no_step_reads_stale_lds).  Synchronises. */
+int tds_hip_debug_poison_lds(tds_hip_sim_t *sim, int byte_pattern);
+
 /* Static resource usage of the step kernel for this handle (for DESIGN.md / bench). */
 int tds_hip_kernel_info(const tds_hip_sim_t *sim, int *lds_bytes_per_env, int *threads_per_env,
                         int *envs_per_block);

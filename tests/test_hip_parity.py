@@ -48,6 +48,41 @@ def test_golden_single_steps(name, built):
         sim.close()
 
 
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("form", ["default", "w1", "w2", "loop"])
+def test_no_step_reads_stale_lds(name, form, built, monkeypatch):
+    """The kernels never clear LDS: a slot nobody wrote holds leftovers of earlier kernels, normally benign.  With every
+    compute unit's LDS poisoned (all bits set = NaN; then 0x7F.. = huge) before the launch, a read of such a slot that
+    reaches the result — even as 0 x slot — turns it into NaN: golden single steps and a 3-substep launch of the
+    step-loop build must still match."""
+    torch = _torch()
+    if form in ("w1", "w2"):
+        monkeypatch.setenv("TDS_HIP_W2", "0" if form == "w1" else "2")
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x = g["x"]
+    for dtype in ("f64", "mixed"):
+        sim = hip_backend.HipSim(m, x.shape[0], dtype=dtype)
+        xin = x.astype(np.float32).astype(np.float64) if dtype == "mixed" else x
+        xt = torch.from_numpy(xin).to(sim.torch_dtype).cuda()
+        if form != "loop":
+            clean = sim.forward_zero(xt).double().cpu().numpy()
+        else:
+            sim.x.copy_(xt)
+            sim.step(None, 3)
+            clean = sim.y.double().cpu().numpy()
+        for pattern in (0xFF, 0x7F):
+            sim.debug_poison_lds(pattern)
+            if form != "loop":
+                y = sim.forward_zero(xt).double().cpu().numpy()
+            else:
+                sim.x.copy_(xt)
+                sim.step(None, 3)
+                y = sim.y.double().cpu().numpy()
+            same = (y == clean) | (np.isnan(y) & np.isnan(clean))
+            assert same.all(), (name, form, dtype, hex(pattern), int((~same).sum()))
+
+
 @pytest.mark.parametrize("name", ["cartpole", "pendulum5", "ant", "laikago", "laikago_soft", "pendulum5_plane",
                                   "cartpole_plane"])
 @pytest.mark.parametrize("w2", ["0", "2"])

@@ -1271,6 +1271,37 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   return TDS_OK;
 }
 
+extern "C++" {
+namespace {
+__global__ void tds_poison_lds_kernel(unsigned pattern, int words, unsigned *sink) {
+  extern __shared__ unsigned tds_poison_smem[];
+  for (int i = threadIdx.x; i < words; i += blockDim.x) tds_poison_smem[i] = pattern;
+  __syncthreads();
+  // stay resident for a while so that the dispatcher has to give every workgroup its own compute unit
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < 200000) {}
+  if (sink != nullptr && tds_poison_smem[(threadIdx.x * 37) % words] != pattern) sink[0] = 1u;
+}
+}  // namespace
+}  // extern "C++"
+
+int tds_hip_debug_poison_lds(tds_hip_sim_t *s, int byte_pattern) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  DeviceGuard guard(s->device);
+  const int bytes = 160 * 1024;  // one workgroup = all of a CU's LDS
+  HIP_TRY(hipFuncSetAttribute((const void *)tds_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+  const unsigned b = (unsigned)(byte_pattern & 0xFF);
+  const unsigned pattern = b | (b << 8) | (b << 16) | (b << 24);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  hipLaunchKernelGGL(tds_poison_lds_kernel, dim3(prop.multiProcessorCount), dim3(256), bytes, s->stream, pattern,
+                     bytes / 4, (unsigned *)nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TDS_OK;
+}
+
 int tds_hip_kernel_info(const tds_hip_sim_t *s, int *lds_bytes_per_env, int *threads_per_env, int *envs_per_block) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   if (lds_bytes_per_env) *lds_bytes_per_env = (int)(s->lds.stride * (s->compute_f64() ? 8 : 4));

@@ -1460,7 +1460,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       const int vbase = nq + nd;
       if (last_run && y_out != nullptr) {  // y describes the last normal step of the launch
         for (int k = lane; k < nv; k += G) {
-          const bool first = k == lane;  // wave-uniform: visual == lane was prefetched at kernel start
+          const bool first = !LOOP && k == lane;  // wave-uniform: visual == lane was prefetched at kernel start
           int lk = pf_vis_link;
           if (!first) lk = mdl->vis_link[k];
           T Rl[9], pl[3], Rv[9], pv[3];

@@ -80,6 +80,7 @@ def lib():
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.tds_hip_set_graph_chains.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_step_many_is_loop.argtypes = [C.c_void_p, C.c_int]
+        L.tds_hip_debug_poison_lds.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_step_many_tune.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         # multi-GPU shards (RCCL all-gather of the observation records)
         L.tds_hip_shard_unique_id.argtypes = [C.c_void_p]
@@ -113,7 +114,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
     "tds_hip_device", "tds_hip_record_bytes", "tds_hip_sync", "tds_hip_forward_zero_host_begin",
     "tds_hip_forward_zero_host_end", "tds_hip_step_many_prepare", "tds_hip_step_many",
-    "tds_hip_set_graph_chains", "tds_hip_step_many_tune", "tds_hip_step_many_is_loop",
+    "tds_hip_set_graph_chains", "tds_hip_step_many_tune", "tds_hip_step_many_is_loop", "tds_hip_debug_poison_lds",
     "tds_hip_shard_rccl_version", "tds_hip_shard_unique_id", "tds_hip_shard_create", "tds_hip_shard_create_all",
     "tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
     "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes", "tds_hip_shard_set_block",
@@ -256,6 +257,10 @@ class HipSim:
         ``actions[(first_block + k) % len(actions)]`` ([B, N, action_dim] device tensor, or None)."""
         ap, nb, op = self._many_args(actions, obs)
         _check(lib().tds_hip_step_many(self.h, ap, nb, int(first_block), int(n_steps), op))
+
+    def debug_poison_lds(self, byte_pattern: int = 0xFF):
+        """Test aid: every compute unit's LDS filled with the byte pattern (0xFF: NaN in every scalar type)."""
+        _check(lib().tds_hip_debug_poison_lds(self.h, int(byte_pattern)))
 
     def step_many_is_loop(self, n_steps: int) -> bool:
         """True if step_many(n_steps) runs as one launch of the step-loop kernel (worlds without contact points)."""
