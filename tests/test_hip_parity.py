@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, MODELS, rel_err
+from conftest import GOLDEN, MODELS, TWO_BODY_MODELS, rel_err
 
 import tds_amd
 from tds_amd import hip_backend
@@ -48,7 +48,7 @@ def test_golden_single_steps(name, built):
         sim.close()
 
 
-@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("name", MODELS + TWO_BODY_MODELS)
 @pytest.mark.parametrize("form", ["default", "w1", "w2", "loop"])
 def test_no_step_reads_stale_lds(name, form, built, monkeypatch):
     """The kernels never clear LDS: a slot nobody wrote holds leftovers of earlier kernels, normally benign.  With every
