@@ -1,6 +1,8 @@
 #!/bin/bash
+# Runs ON THE GPU BOX: the whole GPU test-suite, then the bench lines of the usual configs and the phase breakdown of
+# the headline kernel -> gpurun_out/suite/ (what was run after every kernel change of round 2).
 export TMPDIR=/tmp
-O=gpurun_out/c24
+O=gpurun_out/suite
 mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; tail -4 $O/pytest.log
 B="timeout 300 python bench.py --no-cpu-baseline"
