@@ -344,7 +344,17 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
           m->num_links > 0 && m->links[0].parent < 0) {
         int c = 0;
         while (c + 1 < m->num_links && c + 1 < 16 && m->links[c + 1].parent == c && (d->chain_flags[c + 1] & 1)) ++c;
-        if (c > d->kin_chain_last) d->kin_chain_last = c;
+        // a longer chain costs scan rounds (ceil(log2(c + 1)), ~0.8 k cycles each) and saves tree levels (~1.7 k each)
+        // only if no link outside it sits at one of its levels: the Ant's and Laikago's first leg would extend the
+        // chain without saving a level (the other legs still need theirs) — Laikago would even pay a fourth round
+        auto cost = [&](int last) {
+          int rounds = 0;
+          while ((1 << rounds) <= last) ++rounds;
+          unsigned levels = 0;  // levels that hold a link outside the chain
+          for (int i = last + 1; i < m->num_links; ++i) levels |= 1u << (d->level[i] & 31);
+          return 800 * rounds + 1700 * __builtin_popcount(levels);
+        };
+        if (c > d->kin_chain_last && cost(c) < cost(d->kin_chain_last)) d->kin_chain_last = c;
       }
     }
   }
