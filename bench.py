@@ -145,6 +145,10 @@ def main():
                     help="N > 1: replay steps + exchanges from one hipGraph (tds_hip_shard_step_many) instead of eager "
                          "tds_hip_shard_step calls.  Off by default at N > 1: the RCCL exchange sets the pace there, the "
                          "host has time for the calls, and a captured collective has never run on more than one rank")
+    ap.add_argument("--step-many-form", choices=["auto", "graph", "loop"], default="auto",
+                    help="N = 1: how tds_hip_step_many runs the K steps — chained hipGraphs of single-step launches, ONE "
+                         "launch of the step-loop kernel, or the library's choice (loop for worlds without contacts and "
+                         "for narrow kernels up to three rounds of workgroups)")
     ap.add_argument("--chains", default="auto",
                     help="N = 1, graph launches: environment chains of the graph (tds_hip_step_many in tds_hip.h): a number, "
                          "'default' (the library's rule) or 'auto' = measured during warm-up (tds_hip_step_many_tune)")
@@ -186,6 +190,8 @@ def main():
                 time.sleep(2.0)
             time.sleep(5.0)
 
+    if args.step_many_form != "auto":
+        os.environ["TDS_HIP_STEP_MANY_LOOP"] = "1" if args.step_many_form == "loop" else "0"
     import tds_amd
     from tds_amd import hip_backend
 
@@ -530,8 +536,8 @@ def main():
                                    f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
                        if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
                        "records": "f64" if args.dtype == "f64" else "f32",
-                       "launch": ("one launch of the step-loop kernel per %d steps (world without contact points: state in LDS "
-                                  "across the steps, one action block per step)" % min(K, GCH)) if loop_form else (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else "")
+                       "launch": ("one launch of the step-loop kernel per %d steps (state in LDS across the steps, one action "
+                                  "block per step; records written once per launch)" % min(K, GCH)) if loop_form else (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else "")
                                    + ("" if chains is None else ", the batch as %d independent environment chain%s (%s)" % (
                                        chains, "" if chains == 1 else "s", "measured at warm-up" if args.chains == "auto" else "--chains")))
                                   if (use_graph and (not multi or shard_graph)) else

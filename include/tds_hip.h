@@ -309,9 +309,11 @@ int tds_hip_step_many(tds_hip_sim_t *sim, const void *actions_dev, int action_bl
                       void *obs_dev);
 int tds_hip_set_graph_chains(tds_hip_sim_t *sim, int chains);
 /* 1 if tds_hip_step_many(sim, ..., n_steps, ...) runs as ONE launch of the step-loop kernel instead of graphs: worlds
-   without contact points (pendulums, the cartpole) — their ~7 us step kernels lose a third to every kernel boundary and
-   leave no second wavefront per SIMD for another chain to fill it.  The state then stays in LDS (in the compute
-   scalar) for the n_steps steps, every step takes its own action block, y / obs / x are written once at the end
+   without contact points (pendulums, the cartpole), and fixed-base kernels up to 16 dof with contacts (the Ant) while
+   the batch is at most three rounds of workgroups (12288 Ant environments).  No kernel boundaries; the state stays in
+   LDS (in the compute scalar) for the n_steps steps, every step takes its own action block, y / obs / x are written
+   once at the end — what the graph form leaves behind too, whose obs_dev is overwritten by every step.  With float
+   records the state is rounded to float once per call instead of once per step.
    (TDS_HIP_STEP_MANY_LOOP=0 / 1 forbids / forces the form). */
 int tds_hip_step_many_is_loop(const tds_hip_sim_t *sim, int n_steps);
 int tds_hip_step_many_tune(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int probe_steps,

@@ -161,8 +161,9 @@ def test_create_restores_the_callers_device(built):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "mixed"])
-def test_step_many_graph_equals_eager_launches(dtype, built):
+def test_step_many_graph_equals_eager_launches(dtype, built, monkeypatch):
     torch = _torch()
+    monkeypatch.setenv("TDS_HIP_STEP_MANY_LOOP", "0")  # (the graph form; the one-launch form: the tests below)
     m = tds_amd.load_model("ant")
     n = 192
     x, acts = _start(m, n, seed=13)
@@ -199,6 +200,7 @@ def test_step_many_environment_chains_equal_whole_batch_launches(chains, n, buil
     whole-batch launches, whatever C and however unevenly the workgroups divide (2052 envs: slab for surplus rows
     in play, one-wavefront / two-wavefront form chosen on the whole batch)."""
     torch = _torch()
+    monkeypatch.setenv("TDS_HIP_STEP_MANY_LOOP", "0")
     monkeypatch.setenv("TDS_HIP_GRAPH_CHAINS", chains)
     m = tds_amd.load_model("ant")
     x, acts = _start(m, n, seed=5)
@@ -260,8 +262,44 @@ def test_step_many_of_a_contact_free_world_is_one_loop_launch(name, dtype, built
     assert np.array_equal(res["graph"][0], res["eager"][0])  # (same build, same rounding points: bit for bit)
 
 
-def test_step_many_tune_picks_a_chain_count_and_keeps_the_records(built):
+@pytest.mark.parametrize("dtype,n", [("f64", 1024), ("mixed", 1024), ("f64", 9000)])
+def test_step_many_of_the_ant_is_one_loop_launch(dtype, n, built, monkeypatch):
+    """Narrow kernels with contacts, up to three rounds of workgroups: the K steps run as ONE launch of the step-loop build
+    (action block per step); against K straight-line launches (another build: to round-off) and against the graphs."""
     torch = _torch()
+    m = tds_amd.load_model("ant")
+    x, acts = _start(m, n, seed=17)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    a = torch.from_numpy(acts).to(tdt).cuda().contiguous()
+    K = 25
+    res = {}
+    for form in ("eager", "loop", "graph"):
+        if form == "graph":
+            monkeypatch.setenv("TDS_HIP_STEP_MANY_LOOP", "0")
+        sim = hip_backend.HipSim(m, n, dtype=dtype)
+        assert sim.step_many_is_loop(K) == (form != "graph")
+        sim.x.copy_(torch.from_numpy(x).to(tdt).cuda())
+        obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
+        if form == "eager":
+            for k in range(K):
+                sim.step(a[(2 + k) % 6], 1, obs)
+        else:
+            sim.step_many(a, K, obs, first_block=2)
+        torch.cuda.synchronize()
+        res[form] = (sim.x.double().cpu().numpy(), sim.y.double().cpu().numpy(), obs.double().cpu().numpy())
+    ok = np.isfinite(res["eager"][0]).all(axis=1) & np.isfinite(res["loop"][0]).all(axis=1)
+    assert ok.sum() > 0.9 * n
+    # (float records: rounded once at the end instead of after every step — the trajectories drift apart at float
+    #  rounding, amplified by 25 steps of contact dynamics)
+    tol = 1e-7 if dtype == "f64" else 5e-2
+    for u, v in zip(res["loop"], res["eager"]):
+        assert rel_err(u[ok], v[ok]) < tol
+    assert np.array_equal(res["graph"][0].view(np.int64), res["eager"][0].view(np.int64))
+
+
+def test_step_many_tune_picks_a_chain_count_and_keeps_the_records(built, monkeypatch):
+    torch = _torch()
+    monkeypatch.setenv("TDS_HIP_STEP_MANY_LOOP", "0")
     m = tds_amd.load_model("ant")
     n = 512
     x, acts = _start(m, n, seed=9)

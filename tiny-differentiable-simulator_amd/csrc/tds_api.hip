@@ -830,16 +830,24 @@ int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_
 
 extern "C++" {
 namespace {
-// Worlds without contact points (pendulums, the cartpole) have step kernels of ~7 us, of which a kernel boundary is
-// a third and which leave no second wavefront per SIMD for another chain to fill it: their K steps run as ONE launch of
-// the step-loop build instead, every step taking its own action block (TdsStepCtl::act_pool).
-// TDS_HIP_STEP_MANY_LOOP=0 / 1 forbids / forces it.
+// K steps as ONE launch of the step-loop build, every step taking its own action block (TdsStepCtl::act_pool): no kernel
+// boundaries at all, the state stays in LDS between the steps.  Always for worlds without contact points (pendulums,
+// the cartpole: ~7 us step kernels of which a boundary is a third), and for narrow kernels with contacts while the
+// batch is at most three rounds of workgroups (see below).  TDS_HIP_STEP_MANY_LOOP=0 / 1 forbids / forces it.
 bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
   if (n_steps < 2) return false;
   if (const char *e = getenv("TDS_HIP_STEP_MANY_LOOP")) return e[0] == '1';
   const int ncp = s->compute_f64() ? s->h64.num_cp : s->h32.num_cp;
   const bool two = s->compute_f64() ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
-  return !(s->model.has_plane && ncp > 0) && !two;
+  if (!(s->model.has_plane && ncp > 0) && !two) return true;
+  // Worlds with contacts, kernels up to 16 dof (their step-loop builds fit the registers: 256 VGPR + 12 AGPR at one
+  // wavefront per SIMD, 52 B of scratch at two): one launch beats the chained graphs up to three rounds of workgroups
+  // (Ant x 2048 / 4096 / 8192: 14.4 / 14.9 / 20.3 us per step against 15.3 / 16.6 / 23.2; x 16384: 39.0 against 36.6).
+  // Wider kernels (Laikago, 18 dof) spill in the loop build and stay with the graphs (66 against 49 us).
+  const bool plain = !two && !(s->compute_f64() ? s->h64.is_floating : s->h32.is_floating) &&
+                     (s->compute_f64() ? s->h64.num_spherical : s->h32.num_spherical) == 0;
+  const int n_blocks = (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
+  return plain && s->lds.NDP <= 16 && n_blocks <= 3072;
 }
 }  // namespace
 }  // extern "C++"
