@@ -128,6 +128,18 @@ def pmc_traffic(model, n, dtype):
         return None, None
 
 
+def pmc_traffic_loop(model, n, dtype, steps_per_launch):
+    """The same for ONE step-loop launch of steps_per_launch steps: measured on a 500-step launch (its traffic is the
+    action block per step plus the records once: linear in the steps to within the records)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            e = json.load(f)[model][str(n)][dtype]["loop"]
+        per_step = 2.0 * e["fetch_kib_per_step"] + e["write_kib_per_step"]
+        return int(per_step * steps_per_launch * 1024), e["source"]
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -507,8 +519,8 @@ def main():
             spl = min(K, GCH) if loop_form else 1  # steps per launch (loop form: one launch = spl steps)
             if loop_form:
                 # the state stays in LDS across the steps of a launch: per step only the action block is read, the
-                # records are written once per launch — the per-step PMC figures of single-step launches do not apply
-                traffic, traffic_src = None, None
+                # records are written once per launch — measured on the step-loop launch itself
+                traffic, traffic_src = pmc_traffic_loop(args.model, n, args.dtype, spl)
             arith = "f32" if args.dtype == "f32-pure" else "f64"
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -27,6 +27,15 @@ for C in "${CONFIGS[@]}"; do
     rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $W/pmc_${NAME}_$i -o p -- python bench.py $ARGS --steps 20 --warmup 5 --no-cpu-baseline --no-graph > $W/pmc_${NAME}_$i.log 2>&1
   done
   python tools/pmc_summary.py $W/pmc_${NAME}_* > $OUT/${TAG}_${NAME}_pmc_counters.txt 2>&1
+  # configs whose K steps run as ONE step-loop launch: HBM traffic of that launch (same two counters, same command as the bench line)
+  if grep -q "step-loop kernel" $OUT/${TAG}_bench_$NAME.json; then
+    i=0
+    for CTRS in "FETCH_SIZE" "WRITE_SIZE"; do
+      i=$((i+1))
+      rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $W/pmcloop_${NAME}_$i -o p -- python bench.py $ARGS --steps 500 --warmup 50 --no-cpu-baseline > $W/pmcloop_${NAME}_$i.log 2>&1
+    done
+    python tools/pmc_loop_summary.py 500 $W/pmcloop_${NAME}_* > $OUT/${TAG}_${NAME}_pmc_counters_loop.txt 2>&1
+  fi
 done
 # SQ counters of the headline kernel (both workgroup forms)
 for FORM in w2 w1; do
@@ -42,20 +51,8 @@ done
 python tools/profile_phases.py ant 4096 > $OUT/${TAG}_ant4096_f64_phases.txt 2>/dev/null
 python tools/profile_phases.py laikago_soft 8192 > $OUT/${TAG}_laikago_soft8192_f64_phases.txt 2>/dev/null
 python tools/w2_tail.py > $OUT/${TAG}_ant4096_f64_workgroup_times.txt 2>/dev/null
-# environment chains of the step_many graphs: throughput by chain count
-{
-  echo "# bench.py --chains C (1000 steps per graph launch), env-steps/s and us per step"
-  for C in "${CONFIGS[@]}" "ant16384_f64|--model ant --envs-per-gpu 16384" "ant2048_f64|--model ant --envs-per-gpu 2048"; do
-    NAME=${C%%|*}; ARGS=${C##*|}
-    for CH in 1 2 3; do
-      python bench.py $ARGS --chains $CH --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-26s chains %d  %.4g  %.2f us' % ('$NAME', $CH, d['value'], 1000*d['ms_per_step']))"
-    done
-  done
-  echo "# TDS_HIP_GRAM=1 (contact solve in Gram form on the f64 matrix cores), ant4096_f64, chains 2 / 1"
-  for CH in 2 1; do
-    TDS_HIP_GRAM=1 python bench.py --chains $CH --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-26s chains %d  %.4g  %.2f us' % ('ant4096_f64 gram', $CH, d['value'], 1000*d['ms_per_step']))"
-  done
-} > $OUT/${TAG}_graph_chains.txt
+# launch forms of tds_hip_step_many: chained graphs by chain count, and the one-launch step-loop form
+bash tools/step_many_forms.sh > $OUT/${TAG}_graph_chains.txt 2>/dev/null
 # micro-benchmarks (tools/ubench, built in-tree)
 for U in launch_clock kernel_boundary two_streams mfma_f64_4x4x4; do
   [ -x tools/ubench/$U ] && timeout 120 tools/ubench/$U > $OUT/${TAG}_ubench_$U.txt 2>&1

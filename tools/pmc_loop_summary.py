@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc CSV output of a run whose timed region is ONE step-loop launch (tds_hip_step_many of K steps): the
+counters of the longest tds_step_kernel dispatch, and per step.
+usage: python tools/pmc_loop_summary.py K <dir> [<dir> ...]"""
+import csv
+import glob
+import os
+import sys
+
+K = int(sys.argv[1])
+best = {}
+for d in sys.argv[2:]:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        per = {}
+        for row in csv.DictReader(open(f)):
+            if "tds_step_kernel" not in row["Kernel_Name"]:
+                continue
+            key = row["Dispatch_Id"]
+            dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            e = per.setdefault(key, {"dur": dur, "name": row["Kernel_Name"], "ctr": {}})
+            e["ctr"][row["Counter_Name"]] = e["ctr"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        if per:
+            top = max(per.values(), key=lambda e: e["dur"])
+            for k, v in top["ctr"].items():
+                best[k] = (v, top["dur"], top["name"])
+print(f"# longest tds_step_kernel dispatch of each pass = the step-loop launch of the {K} timed steps")
+for k in sorted(best):
+    v, dur, name = best[k]
+    print(f"# kernel: {name[:150]}")
+    print(f"{k:28s} {v:14.1f} per launch ({dur / 1000.0:.1f} us)   {v / K:12.3f} per step")
