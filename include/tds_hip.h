@@ -286,7 +286,7 @@ int tds_hip_step(tds_hip_sim_t *sim, const void *actions_dev, int substeps);
 int tds_hip_step_obs(tds_hip_sim_t *sim, const void *actions_dev, int substeps, void *obs_dev);
 int tds_hip_obs_dim(const tds_hip_sim_t *sim);
 
-/* n_steps closed-loop steps (tds_hip_step_obs with substeps = 1, no auto-reset) per host call, replayed from a
+/* n_steps closed-loop steps (tds_hip_step_obs with substeps = 1) per host call, replayed from a
    captured hipGraph: ONE graph launch instead of n_steps kernel launches, which removes the host-side launch gaps
    that cost a double-digit share of short runs at ~20 us per step.
      actions_dev  [action_blocks][N][action_dim] (record dtype) or NULL; step k uses block (first_block + k) % action_blocks
@@ -314,7 +314,13 @@ int tds_hip_set_graph_chains(tds_hip_sim_t *sim, int chains);
    LDS (in the compute scalar) for the n_steps steps, every step takes its own action block, y / obs / x are written
    once at the end — what the graph form leaves behind too, whose obs_dev is overwritten by every step.  With float
    records the state is rounded to float once per call instead of once per step.
-   (TDS_HIP_STEP_MANY_LOOP=0 / 1 forbids / forces the form). */
+   (TDS_HIP_STEP_MANY_LOOP=0 / 1 forbids / forces the form).
+
+   With tds_hip_set_auto_reset on, every one of the n_steps steps resets the environments it ends with done
+   (ars_vectorized_environment.h:262-277), through the reset pool: where _is_loop holds, as step-loop launches of up to
+   128 steps in which a done environment copies its next pre-settled state from its ring into LDS and carries on, the
+   rings being topped up between the launches on a side stream; elsewhere as n_steps single steps.  Same stream of
+   random numbers and same records as n_steps calls of tds_hip_step_obs. */
 int tds_hip_step_many_is_loop(const tds_hip_sim_t *sim, int n_steps);
 int tds_hip_step_many_tune(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int probe_steps,
                            void *obs_dev, int *chains);

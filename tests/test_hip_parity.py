@@ -773,6 +773,66 @@ def test_reset_pool_equals_reset_inside_the_step(name, dtype, pool_params, built
     assert n_done.sum() >= 30 and (name != "ant" or n_done.max() >= 3)  # (a reset Laikago stands: one reset each)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "mixed"])
+@pytest.mark.parametrize("form", ["loop", "loop_chunk16", "loop_short_lists", "single"])
+def test_step_many_with_auto_reset_equals_single_auto_reset_steps(form, dtype, built, monkeypatch):
+    """tds_hip_step_many of a handle with auto-reset on: step-loop launches of up to 128 steps in which a done
+    environment takes its next state from the reset pool (form "loop": the Ant's default), or single steps through the
+    pool (form "single": what wider kernels get) — against calls of tds_hip_step_obs, one per step.  Four calls of 24
+    steps, so that the refill passes behind the launches (plan / run / wait, two launches behind) all come into play."""
+    torch = _torch()
+    monkeypatch.setenv("TDS_HIP_STEP_MANY_LOOP", "0" if form == "single" else "1")
+    if form == "loop_chunk16":        # several launches per call
+        monkeypatch.setenv("TDS_HIP_POOL_CHUNK", "16")
+    m = tds_amd.load_model("ant")
+    n, seed, K, B = 96, 77, 24, 5
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    od = nq + nd
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    rng = np.random.default_rng(23)
+    x0 = np.zeros((n, m.input_dim))
+    ip = np.array([m.initial_poses[i] for i in range(adim)])
+    x0[:, 2] = 0.48
+    x0[:, 6:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
+    x0[:, -3:] = [15, 0.3, 3]
+    x0[::3, 2] = 0.27      # torso right at the 0.26 threshold: done within a few steps, again after every reset
+    x0[1::3, 3] = 0.6
+    many, one = hip_backend.HipSim(m, n, dtype=dtype), hip_backend.HipSim(m, n, dtype=dtype)
+    for sim in (many, one):
+        sim.set_auto_reset(True, seed)
+        sim.x.copy_(torch.from_numpy(x0).to(tdt).cuda())
+    assert many.step_many_is_loop(K) == (form != "single")
+    om = torch.zeros((n, od + 2), dtype=tdt, device="cuda")
+    oo = torch.zeros_like(om)
+    acts = torch.from_numpy(rng.uniform(-0.4, 0.4, (B, n, adim))).to(tdt).cuda().contiguous()
+    # (float records: the step loop rounds the state to float once per launch, single steps once per step)
+    tol = 1e-6 if dtype == "f64" else 5e-2
+    n_done = np.zeros(n, dtype=int)
+    for call in range(4):
+        first = (call * K) % B
+        if form == "loop_short_lists" and call == 0:
+            # refill work lists of 8 entries (read when the pool is set up, in the first call): every pass is cut short
+            # and followed by more
+            monkeypatch.setenv("TDS_HIP_POOL_CAP", "8")
+        many.step_many(acts, K, om, first_block=first)
+        monkeypatch.delenv("TDS_HIP_POOL_CAP", raising=False)
+        for k in range(K):
+            one.step(acts[(first + k) % B], 1, oo)
+            n_done += oo[:, od + 1].cpu().numpy() != 0
+        torch.cuda.synchronize()
+        got = [many.x.double().cpu().numpy()[:, :od], many.y.double().cpu().numpy(), om.double().cpu().numpy()]
+        ref = [one.x.double().cpu().numpy()[:, :od], one.y.double().cpu().numpy(), oo.double().cpu().numpy()]
+        if dtype == "f64":
+            for u, v in zip(got, ref):
+                assert rel_err(u, v) < tol, call
+        else:  # (an environment whose float trajectory crosses the done threshold one step apart is a different one after)
+            close = np.array([rel_err(got[0][e], ref[0][e]) < tol for e in range(n)])
+            assert close.mean() > 0.9, (call, close.mean())
+        one.x.copy_(many.x)  # per-call resync (the reset counters agree as long as the records do)
+    print(f"step_many with auto-reset ({form}, {dtype}): resets per env max {n_done.max()}, total {n_done.sum()}")
+    assert n_done.sum() >= 30 and n_done.max() >= 3
+
+
 @pytest.mark.parametrize("name", ["ant", "laikago", "pendulum5_plane", "ant_floating", "laikago_floating_env",
                                   "sphere_spherical", "humanoid_spherical"])
 @pytest.mark.parametrize("var", ["TDS_HIP_NO_ROOTJOINT", "TDS_HIP_NO_CHAIN"])

@@ -484,8 +484,12 @@ int pool_alloc(tds_hip_sim *s) {
   const int settle = s->model.settle_steps > 0 ? s->model.settle_steps : 0;
   s->pool_lag = pool_param("TDS_HIP_POOL_LAG", s->pool_host_lag + settle + 6);  // W
   s->pool_depth = s->pool_every + s->pool_lag + 4;                            // D >= R + W (+ slack)
+  s->pool_chunk = pool_param("TDS_HIP_POOL_CHUNK", 128);                      // steps per launch of pool_step_many
+  if (s->pool_depth < 2 * s->pool_chunk + 4) s->pool_depth = 2 * s->pool_chunk + 4;  // (D >= 2 x chunk, see pool_step_many)
   const size_t n = (size_t)s->num_envs, w = (size_t)(s->model.dof_q + s->model.dof_qd);
-  s->pool_cap = (int)(n * (size_t)(s->pool_every + 4));
+  // work list of a pass: what R + 4 single steps can consume; pool_step_many, whose two launches could consume more,
+  // carries on with further passes when a list was cut short (more than 24 resets per environment on average)
+  s->pool_cap = pool_param("TDS_HIP_POOL_CAP", (int)(n * (size_t)(s->pool_every + 4 > 24 ? s->pool_every + 4 : 24)));
   TDS_HIP_TRY(hipMalloc(&s->d_pool, (size_t)s->pool_depth * n * w * s->elem));
   TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_filled, n * sizeof(unsigned)));
   TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_items, (1 + 2 * (size_t)s->pool_cap) * sizeof(int)));
@@ -554,10 +558,13 @@ int pool_run(tds_hip_sim *s, hipEvent_t done) {
     o.other_stream = true;
     o.stream = s->pool_stream;
     o.lds = &s->pool_lds;
-    for (int k = 0; k < s->model.settle_steps; ++k) {
-      // straight-line step kernel on the staging records: zero action, state fed back in place, no y / obs record
-      const int rc = launch(s, s->d_stage_x, nullptr, nullptr, s->d_stage_x, nullptr, n_items, 1, TDS_RESET_NONE,
-                            nullptr, nullptr, 0, &o);
+    // straight-line step kernel on the staging records: zero action, state fed back in place, no y / obs record
+    // (TDS_HIP_POOL_SETTLE_LOOP=1: the settle steps as ONE launch of the step-loop build — measured, no gain)
+    const char *sl = getenv("TDS_HIP_POOL_SETTLE_LOOP");
+    const bool one_launch = s->model.settle_steps > 1 && sl && sl[0] == '1';
+    for (int k = 0; k < (one_launch ? 1 : s->model.settle_steps); ++k) {
+      const int rc = launch(s, s->d_stage_x, nullptr, nullptr, s->d_stage_x, nullptr, n_items,
+                            one_launch ? s->model.settle_steps : 1, TDS_RESET_NONE, nullptr, nullptr, 0, &o);
       if (rc != TDS_OK) return rc;
     }
     const int w = s->model.dof_q + s->model.dof_qd;
@@ -610,6 +617,10 @@ int pool_fill(tds_hip_sim *s) {
 // one auto-reset step through the pool
 int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev) {
   int rc;
+  if (s->pool_many) {  // (the step_many form keeps its own pass schedule: start again from full rings)
+    s->pool_many = false;
+    s->pool_ready = false;
+  }
   if (!s->pool_ready) {
     rc = pool_fill(s);
     if (rc != TDS_OK) return rc;
@@ -648,6 +659,80 @@ int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev) {
     if (rc != TDS_OK) return rc;
     s->pool_planned = t / R;
     s->pool_planned_at = t;
+  }
+  return TDS_OK;
+}
+
+// K auto-reset steps as step-loop launches ("chunks") of up to R = pool_chunk steps each (tds_hip_step_many of a handle with auto-reset on):
+// inside a launch a done environment copies its next ring entry into its LDS record and carries on (tds_kernels.hip,
+// pool_r), between the launches the rings are topped up by the same passes as above, on this schedule:
+//     before chunk j   run  the pass planned behind chunk j - 2  (its size reached the host while chunk j - 1 ran)
+//                      plan the pass behind chunk j - 1
+//                      chunk j waits for the pass behind chunk j - 2
+// A chunk consumes at most R entries of a ring and the pass behind chunk j - 2 left D of them, so D >= 2 R entries
+// are never exhausted, and a pass only overwrites slots whose entries were consumed before it was planned: the
+// results are those of resetting inside the step, whatever the rate of resets.  The host never waits for a chunk that
+// is not already followed by another one in the stream.  Measured (tools/auto_reset_modes.py many, Ant, 5 % of the
+// environments done per step = 50 % more environment steps in settling): x 4096 0.76 / 0.88 / 0.93 of the rate without
+// resets for R = 16 / 32 / 96 (the refill launches run beside the chunk in the SIMDs' second wavefront slots), x 8192
+// 0.52 / 0.59 / 0.67 (a chunk holds every CU's LDS: the refill runs between chunks); 0.93 ... 0.99 without resets.
+// The settle steps of a pass as ONE step-loop launch (TDS_HIP_POOL_SETTLE_LOOP=1) are no gain: x 4096 0.74, x 8192 0.67.
+int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int act_first, int n_steps, void *obs_dev) {
+  int rc;
+  if (!s->pool_many) {
+    s->pool_many = true;
+    s->pool_ready = false;
+  }
+  if (!s->pool_ready) {
+    rc = pool_fill(s);
+    if (rc != TDS_OK) return rc;
+    s->pool_many_chunks = 0;
+  }
+  const int R = s->pool_chunk;
+  TdsStepCtl extra;
+  memset(&extra, 0, sizeof(extra));
+  extra.pool = s->d_pool;
+  extra.pool_depth = s->pool_depth;
+  extra.pool_envs = s->num_envs;
+  const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
+  for (int done = 0; done < n_steps;) {
+    const int k = n_steps - done < R ? n_steps - done : R;
+    bool pass = false;
+    if (s->pool_planned) {
+      TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
+      rc = pool_run(s, s->pool_sync_ev);
+      if (rc != TDS_OK) return rc;
+      s->pool_planned = 0;
+      pass = true;
+      while (*s->h_pool_nitems > s->pool_cap) {  // the work list was cut short: the rings must be FULL before the launch
+        rc = pool_plan(s);
+        if (rc != TDS_OK) return rc;
+        TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
+        rc = pool_run(s, s->pool_sync_ev);
+        if (rc != TDS_OK) return rc;
+      }
+    }
+    if (s->pool_many_chunks > 0) {
+      rc = pool_plan(s);
+      if (rc != TDS_OK) return rc;
+      s->pool_planned = 1;
+    }
+    if (pass) TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->pool_sync_ev, 0));
+    LaunchOpts o;
+    o.extra = &extra;
+    const void *a0 = nullptr;
+    if (actions_dev) {
+      const int first = (act_first + done) % act_blocks;
+      a0 = (const char *)actions_dev + (size_t)first * blk;
+      o.act_pool = actions_dev;
+      o.act_blocks = act_blocks;
+      o.act_first = first;
+    }
+    rc = launch(s, s->d_x, s->d_y, a0, s->d_x, obs_dev ? obs_dev : s->d_split, s->num_envs, k, TDS_RESET_NONE, nullptr,
+                nullptr, 0, &o);
+    if (rc != TDS_OK) return rc;
+    ++s->pool_many_chunks;
+    done += k;
   }
   return TDS_OK;
 }
@@ -857,7 +942,7 @@ int tds_hip_step_many_prepare(tds_hip_sim_t *s, const void *actions_dev, int act
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   if (n_steps < 1 || n_steps > 4096) return fail(TDS_ERR_INVALID_ARG, "n_steps must be in 1..4096");
   if (actions_dev && action_blocks < 1) return fail(TDS_ERR_INVALID_ARG, "action_blocks must be >= 1");
-  if (s->auto_reset) return fail(TDS_ERR_INVALID_ARG, "step_many replays plain closed-loop steps (auto-reset is off the graph)");
+  if (s->auto_reset) return TDS_OK;  // (step-loop launches through the reset pool, or single steps: nothing to build)
   DeviceGuard guard(s->device);
   const int pool = actions_dev ? action_blocks : 1;
   const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
@@ -873,13 +958,25 @@ int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_bloc
   if (!eager) {
     int rc = tds_hip_step_many_prepare(s, actions_dev, action_blocks, first_block, n_steps, obs_dev);
     if (rc != TDS_OK) return rc;
-  } else if (!s || n_steps < 1 || s->auto_reset || (actions_dev && action_blocks < 1)) {
+  } else if (!s || n_steps < 1 || (actions_dev && action_blocks < 1)) {
     return fail(TDS_ERR_INVALID_ARG, "step_many: bad arguments");
   }
   DeviceGuard guard(s->device);
   TimedCall timed(s);
   const int pool = actions_dev ? action_blocks : 1;
   const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
+  if (s->auto_reset) {
+    // auto_reset_when_done after every step: step-loop launches that take the fresh states from the reset pool where
+    // the plain call would be one step-loop launch (pool_step_many), else K single steps through the pool
+    if (!eager && step_many_as_loop(s, n_steps)) return pool_step_many(s, actions_dev, pool, first, n_steps, obs_dev);
+    const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
+    for (int k = 0; k < n_steps; ++k) {
+      const void *a = actions_dev ? (const char *)actions_dev + (size_t)((first + k) % pool) * blk : nullptr;
+      const int rc = pool_step(s, a, obs_dev);
+      if (rc != TDS_OK) return rc;
+    }
+    return TDS_OK;
+  }
   if (!eager && step_many_as_loop(s, n_steps)) {
     LaunchOpts lo;
     const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;

@@ -33,7 +33,7 @@ struct tds_hip_sim {
   bool have_ms = false;
   // pre-settled reset pool (auto-reset at straight-line speed; see "reset pool" in tds_api.hip)
   static constexpr int kPoolEvents = 8;
-  int pool_depth = 0, pool_every = 0, pool_lag = 0, pool_host_lag = 0, pool_cap = 0;  // D, R, W, H, staging capacity
+  int pool_depth = 0, pool_every = 0, pool_lag = 0, pool_host_lag = 0, pool_cap = 0, pool_chunk = 0;  // D, R, W, H, staging capacity
   void *d_pool = nullptr;                 // [D][N][nq+nd] record dtype: ring of pre-settled reset states per env
   unsigned int *d_pool_filled = nullptr;  // [N] entries produced so far per env (valid: [count, filled))
   int *d_pool_items = nullptr;            // [1 + 2 cap]: n_items | item env | item ring slot
@@ -47,6 +47,8 @@ struct tds_hip_sim {
   long long pool_waited = 0;   // passes the step stream has been made to wait for
   long long pool_planned = 0;  // pass whose work list has been planned but not launched yet (0: none)
   long long pool_planned_at = 0;
+  bool pool_many = false;      // the pool is on the pass schedule of step_many (pool_step_many), not of single steps
+  long long pool_many_chunks = 0;
   bool pool_ready = false;     // false: fill the pool completely before the next auto-reset step
   bool pool_discard = true;    // the entries in the rings are void (first use, new seed): start from empty rings
   // K-steps-per-launch graph cache (tds_hip_step_many)

@@ -1138,6 +1138,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   const bool pol = LOOP && ctl.policy != nullptr;
   // action replay (tds_hip_step_many as one launch): the block of step k + 1 is requested from HBM at the top of step k
   const bool replay = LOOP && ctl.act_pool != nullptr && ctl.policy == nullptr;
+  // auto-reset inside a replayed step loop: a done environment takes its next pre-settled state from the reset pool
+  // (tds_api.hip: reset pool) and carries on with the following step — the lane groups of a launch stay in lock step
+  const bool pool_r = LOOP && ctl.pool != nullptr && ctl.policy == nullptr;
   T next_act = T(0);
   T ret = T(0);
   int cnt = 0;
@@ -1358,7 +1361,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       TDS_WAVE_SYNC();
     }
   }
-  const bool do_reward = last_run || (pol && mode == TDS_MODE_RUN);
+  const bool do_reward = last_run || ((pol || pool_r) && mode == TDS_MODE_RUN);
   // ---- the phases that a two-wavefront workgroup hands to its helper wavefront, as closures (each derives the LDS
   //      addresses it needs itself: nothing is kept live for them across the phases in between)
   const int NCPp = L.NCPp;
@@ -3066,6 +3069,17 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           }
         }
         reset_now = done_now && auto_r;
+      } else if (pool_r) {
+        // auto_reset_when_done (ars_vectorized_environment.h:262-277) after EVERY step of the loop, through the pool:
+        // entry (reset count mod depth) of the environment's ring is the state reset() + the settle steps lead to
+        if (done_now) {
+          const unsigned c = ctl.reset_count[env];
+          const TR *const src = (const TR *)ctl.pool + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
+          for (int i = lane; i < nq + nd; i += G) xr[i] = (T)src[i];
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) ctl.reset_count[env] = c + 1u;
+        }
+        reset_now = false;
       } else {
         reset_now = left == 0 && done_now && auto_r;
       }

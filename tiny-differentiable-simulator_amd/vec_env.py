@@ -94,6 +94,18 @@ class VectorizedEnv:
         od = self.sim.obs_dim
         return VectorizedEnvOutput(self._obs_rec[:, :od], self._obs_rec[:, od], self._obs_rec[:, od + 1], self.sim.y)
 
+    def step_many(self, action_blocks, n_steps: int, first_block: int = 0) -> VectorizedEnvOutput:
+        """``n_steps`` calls of step() in one host call (tds_hip_step_many): step k takes
+        ``action_blocks[(first_block + k) % len(action_blocks)]`` ([B, N, action_dim] device tensor); with
+        auto_reset_when_done every step resets the environments it ends with done.  Returns the last step's output."""
+        import torch
+
+        a = torch.as_tensor(action_blocks, dtype=self.sim.torch_dtype, device=self._obs_rec.device).contiguous()
+        self.sim.step_many(a, int(n_steps), self._obs_rec, first_block=first_block)
+        od = self.sim.obs_dim
+        return VectorizedEnvOutput(self._obs_rec[:, :od], self._obs_rec[:, od], self._obs_rec[:, od + 1], self.sim.y)
+
+
 
 def VectorizedAntEnv(num_envs: int, auto_reset_when_done: bool = True, **kw) -> VectorizedEnv:
     return VectorizedEnv("ant", num_envs, auto_reset_when_done, **kw)

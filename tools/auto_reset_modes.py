@@ -33,6 +33,32 @@ def run(n, auto, K=500):
     return n * K / dt, int(out.dones.sum())
 
 
+def run_many(n, auto, amp=0.8, K=480, C=96):
+    """the same loop as calls of step_many over C steps each (tds_hip_step_many with auto-reset on: step-loop launches
+    that take the fresh states from the pool, where the plain call is one step-loop launch)"""
+    env = tds_amd.VectorizedAntEnv(n, auto_reset_when_done=auto, seed=5)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = ((torch.rand((16, n, 8), dtype=torch.float64, device="cuda", generator=g) - 0.5) * amp).contiguous()
+    out = env.step_many(acts, C)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K // C):
+        out = env.step_many(acts, C)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return n * (K // C) * C / dt, int(out.dones.sum()), env.sim.step_many_is_loop(C)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "many":
+    for n in (4096, 8192):
+        for amp in (0.8, 0.2):
+            base, _, loop = run_many(n, False, amp)
+            v, d, _ = run_many(n, True, amp)
+            print(f"ant x{n} step_many (loop form: {loop}) actions +-{amp / 2}: no auto-reset {base:.4g}, auto-reset {v:.4g} "
+                  f"env-steps/s = {v / base:.2f} x (last step: {d} done)", flush=True)
+    sys.exit(0)
+
 for n in (4096, 8192, 16384):
     os.environ.pop("TDS_HIP_AUTO_RESET_SPLIT", None)
     base, _ = run(n, False)
