@@ -166,6 +166,9 @@ def main():
                          "'default' (the library's rule) or 'auto' = measured during warm-up (tds_hip_step_many_tune)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (16/32/64), 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--auto-reset", action="store_true",
+                    help="secondary workload (N = 1): auto_reset_when_done on — every step resets the environments it "
+                         "ends with done (reset distribution + settle steps), through the reset pool")
     ap.add_argument("--rollout-steps", type=int, default=0,
                     help="also time the on-device policy rollout (tds_hip_rollout) with this many policy steps per call")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
@@ -339,6 +342,9 @@ def main():
     sim.x.copy_(torch.from_numpy(x0).to(tdt).cuda())
     for _ in range(10):  # 10 settle steps with zero action (ant_environment2.h:137-152)
         sim.step(None)
+    auto_reset = args.auto_reset and not multi and m.step_mode == tds_amd.TDS_STEP_LOCOMOTION
+    if auto_reset:
+        sim.set_auto_reset(True, 5)
     pool = 16
     amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
     actions = torch.from_numpy(rng.uniform(-amp, amp, (pool, n, adim))).to(tdt).cuda().contiguous()
@@ -393,7 +399,7 @@ def main():
 
     chains = None
     loop_form = use_graph and not multi and sim.step_many_is_loop(min(args.steps, GCH))
-    if use_graph and not multi and not loop_form:
+    if use_graph and not multi and not loop_form and not auto_reset:
         if args.chains == "auto":  # 6 x 128 extra untimed steps
             chains = sim.tune_step_many(actions, 128, obs)
         elif args.chains != "default":
@@ -517,7 +523,10 @@ def main():
             if traffic is not None:
                 traffic = traffic // conc
             spl = min(K, GCH) if loop_form else 1  # steps per launch (loop form: one launch = spl steps)
-            if loop_form:
+            if auto_reset:  # (step-loop launches of up to 128 steps, or single steps; the refill launches run beside them)
+                spl = min(K, GCH, 128) if loop_form else 1
+                traffic, traffic_src = None, None
+            elif loop_form:
                 # the state stays in LDS across the steps of a launch: per step only the action block is read, the
                 # records are written once per launch — measured on the step-loop launch itself
                 traffic, traffic_src = pmc_traffic_loop(args.model, n, args.dtype, spl)
@@ -548,7 +557,15 @@ def main():
                                    f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
                        if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
                        "records": "f64" if args.dtype == "f64" else "f32",
-                       "launch": ("one launch of the step-loop kernel per %d steps (state in LDS across the steps, one action "
+                       "auto_reset": ("auto_reset_when_done: every step resets the environments it ends with done "
+                                      "(reset distribution + %d settle steps) through the reset pool; %d of %d environments "
+                                      "done in the last step" % (m.settle_steps, int((obs[:, -1] != 0).sum().item()), n))
+                       if auto_reset else None,
+                       "launch": ("step-loop launches of up to 128 steps, a done environment takes its next pre-settled state "
+                                  "from its ring in HBM; rings refilled by straight-line launches on a side stream") if (auto_reset and loop_form) else
+                                 ("one straight-line launch per step, a done environment takes its next pre-settled state from "
+                                  "its ring in HBM; rings refilled on a side stream") if auto_reset else
+                                 ("one launch of the step-loop kernel per %d steps (state in LDS across the steps, one action "
                                   "block per step; records written once per launch)" % min(K, GCH)) if loop_form else (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else "")
                                    + ("" if chains is None else ", the batch as %d independent environment chain%s (%s)" % (
                                        chains, "" if chains == 1 else "s", "measured at warm-up" if args.chains == "auto" else "--chains")))

@@ -5,7 +5,9 @@ end per step), per batch size and auto-reset form:
   split=1  straight-line step launch + forced-reset launch masked with the done flags
   split=2  reset pool: pre-settled states copied in by the straight-line kernel, refilled on a side stream
   None     the library's default (= the pool)
-and the same loop with auto-reset OFF (the no-reset rate the pool is held against)."""
+and the same loop with auto-reset OFF (the no-reset rate the pool is held against).  Then the same steps as calls of
+step_many over 96 steps each (tds_hip_step_many with auto-reset on), with the random actions at two amplitudes
+(+-0.4: ~5 % of the environments done per step; +-0.1: hardly any).   usage: tools/auto_reset_modes.py [many]"""
 import os
 import sys
 import time
@@ -50,13 +52,17 @@ def run_many(n, auto, amp=0.8, K=480, C=96):
     return n * (K // C) * C / dt, int(out.dones.sum()), env.sim.step_many_is_loop(C)
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "many":
-    for n in (4096, 8192):
+def many_rows(ns):
+    for n in ns:
         for amp in (0.8, 0.2):
             base, _, loop = run_many(n, False, amp)
             v, d, _ = run_many(n, True, amp)
             print(f"ant x{n} step_many (loop form: {loop}) actions +-{amp / 2}: no auto-reset {base:.4g}, auto-reset {v:.4g} "
                   f"env-steps/s = {v / base:.2f} x (last step: {d} done)", flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "many":
+    many_rows((4096, 8192))
     sys.exit(0)
 
 for n in (4096, 8192, 16384):
@@ -70,3 +76,4 @@ for n in (4096, 8192, 16384):
             os.environ["TDS_HIP_AUTO_RESET_SPLIT"] = split
         v, d = run(n, True)
         print(f"ant x{n} auto-reset split={split}: {v:.4g} env-steps/s = {v / base:.2f} x no-reset (last step: {d} done)", flush=True)
+many_rows((4096, 8192, 16384))
