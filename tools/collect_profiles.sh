@@ -37,8 +37,9 @@ for C in "${CONFIGS[@]}"; do
     python tools/pmc_loop_summary.py 500 $W/pmcloop_${NAME}_* > $OUT/${TAG}_${NAME}_pmc_counters_loop.txt 2>&1
   fi
 done
+# (QUICK=1: bench lines, kernel-trace summaries, HBM traffic and phase breakdowns only)
 # SQ counters of the headline kernel (both workgroup forms)
-for FORM in w2 w1; do
+for FORM in $( [ "${QUICK:-0}" = 1 ] || echo w2 w1 ); do
   i=0
   for CTRS in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" \
               "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
@@ -52,10 +53,10 @@ python tools/profile_phases.py ant 4096 > $OUT/${TAG}_ant4096_f64_phases.txt 2>/
 python tools/profile_phases.py laikago_soft 8192 > $OUT/${TAG}_laikago_soft8192_f64_phases.txt 2>/dev/null
 python tools/w2_tail.py > $OUT/${TAG}_ant4096_f64_workgroup_times.txt 2>/dev/null
 # launch forms of tds_hip_step_many: chained graphs by chain count, and the one-launch step-loop form
-bash tools/step_many_forms.sh > $OUT/${TAG}_graph_chains.txt 2>/dev/null
+[ "${QUICK:-0}" = 1 ] || bash tools/step_many_forms.sh > $OUT/${TAG}_graph_chains.txt 2>/dev/null
 # micro-benchmarks (tools/ubench, built in-tree)
-for U in launch_clock kernel_boundary two_streams mfma_f64_4x4x4; do
+for U in $( [ "${QUICK:-0}" = 1 ] || echo launch_clock kernel_boundary two_streams mfma_f64_4x4x4 ); do
   [ -x tools/ubench/$U ] && timeout 120 tools/ubench/$U > $OUT/${TAG}_ubench_$U.txt 2>&1
 done
 for C in "${CONFIGS[@]}"; do NAME=${C%%|*}; echo "== $NAME"; tail -n 4 $OUT/${TAG}_${NAME}_kernel_stats.txt; cat $OUT/${TAG}_${NAME}_pmc_counters.txt; done
-head -30 $OUT/${TAG}_ant4096_f64_sq_counters_w2.txt
+[ "${QUICK:-0}" = 1 ] || head -30 $OUT/${TAG}_ant4096_f64_sq_counters_w2.txt
