@@ -774,7 +774,7 @@ def test_reset_pool_equals_reset_inside_the_step(name, dtype, pool_params, built
 
 
 @pytest.mark.parametrize("dtype", ["f64", "mixed"])
-@pytest.mark.parametrize("form", ["loop", "loop_chunk16", "loop_short_lists", "single"])
+@pytest.mark.parametrize("form", ["loop", "loop_chunk16", "loop_chunk2", "loop_short_lists", "single"])
 def test_step_many_with_auto_reset_equals_single_auto_reset_steps(form, dtype, built, monkeypatch):
     """tds_hip_step_many of a handle with auto-reset on: step-loop launches of up to 128 steps in which a done
     environment takes its next state from the reset pool (form "loop": the Ant's default), or single steps through the
@@ -784,6 +784,8 @@ def test_step_many_with_auto_reset_equals_single_auto_reset_steps(form, dtype, b
     monkeypatch.setenv("TDS_HIP_STEP_MANY_LOOP", "0" if form == "single" else "1")
     if form == "loop_chunk16":        # several launches per call
         monkeypatch.setenv("TDS_HIP_POOL_CHUNK", "16")
+    if form == "loop_chunk2":         # rings of 2 x 2 + 4 = 8 entries: they wrap (up to a dozen resets per environment)
+        monkeypatch.setenv("TDS_HIP_POOL_CHUNK", "2")
     m = tds_amd.load_model("ant")
     n, seed, K, B = 96, 77, 24, 5
     nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
@@ -808,7 +810,7 @@ def test_step_many_with_auto_reset_equals_single_auto_reset_steps(form, dtype, b
     # (float records: the step loop rounds the state to float once per launch, single steps once per step)
     tol = 1e-6 if dtype == "f64" else 5e-2
     n_done = np.zeros(n, dtype=int)
-    for call in range(4):
+    for call in range(6 if form == "loop_chunk2" else 4):
         first = (call * K) % B
         if form == "loop_short_lists" and call == 0:
             # refill work lists of 8 entries (read when the pool is set up, in the first call): every pass is cut short
@@ -830,7 +832,47 @@ def test_step_many_with_auto_reset_equals_single_auto_reset_steps(form, dtype, b
             assert close.mean() > 0.9, (call, close.mean())
         one.x.copy_(many.x)  # per-call resync (the reset counters agree as long as the records do)
     print(f"step_many with auto-reset ({form}, {dtype}): resets per env max {n_done.max()}, total {n_done.sum()}")
-    assert n_done.sum() >= 30 and n_done.max() >= 3
+    assert n_done.sum() >= 30 and n_done.max() >= (9 if form == "loop_chunk2" else 3)
+
+
+def test_single_auto_reset_steps_and_step_many_calls_share_one_pool(built, monkeypatch):
+    """one handle driven by single auto-reset steps and by step_many calls in turn (the pool changes its pass schedule
+    and, the first time, grows its rings) against a handle driven by single steps only"""
+    torch = _torch()
+    monkeypatch.setenv("TDS_HIP_STEP_MANY_LOOP", "1")
+    m = tds_amd.load_model("ant")
+    n, seed, B = 96, 31, 5
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    od = nq + nd
+    rng = np.random.default_rng(29)
+    x0 = np.zeros((n, m.input_dim))
+    x0[:, 2] = 0.48
+    x0[:, 6:nq] = np.array([m.initial_poses[i] for i in range(adim)]) + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
+    x0[:, -3:] = [15, 0.3, 3]
+    x0[::3, 2] = 0.27
+    mixed, one = hip_backend.HipSim(m, n), hip_backend.HipSim(m, n)
+    for sim in (mixed, one):
+        sim.set_auto_reset(True, seed)
+        sim.x.copy_(torch.from_numpy(x0).cuda())
+    om = torch.zeros((n, od + 2), dtype=torch.float64, device="cuda")
+    oo = torch.zeros_like(om)
+    acts = torch.from_numpy(rng.uniform(-0.4, 0.4, (B, n, adim))).cuda().contiguous()
+    t, n_done = 0, 0
+    for seg, K in enumerate((7, 24, 9, 40, 3)):
+        if seg % 2 == 0:
+            for k in range(K):
+                mixed.step(acts[(t + k) % B], 1, om)
+        else:
+            mixed.step_many(acts, K, om, first_block=t % B)
+        for k in range(K):
+            one.step(acts[(t + k) % B], 1, oo)
+            n_done += int((oo[:, od + 1] != 0).sum())
+        t += K
+        torch.cuda.synchronize()
+        assert rel_err(mixed.x.cpu().numpy()[:, :od], one.x.cpu().numpy()[:, :od]) < 1e-6, seg
+        assert rel_err(om.cpu().numpy(), oo.cpu().numpy()) < 1e-6, seg
+        one.x.copy_(mixed.x)
+    assert n_done >= 30
 
 
 @pytest.mark.parametrize("name", ["ant", "laikago", "pendulum5_plane", "ant_floating", "laikago_floating_env",

@@ -475,22 +475,41 @@ int pool_param(const char *name, int dflt) {
   return v > 0 ? v : dflt;
 }
 
-int pool_alloc(tds_hip_sim *s) {
-  if (s->d_pool) return TDS_OK;
+// ring depth D by form: single steps D >= R + W (+ slack); pool_step_many D >= 2 x chunk (+ slack)
+void pool_params(tds_hip_sim *s) {
+  if (s->pool_every > 0) return;
   s->pool_every = pool_param("TDS_HIP_POOL_EVERY", 16);                     // R
   s->pool_host_lag = pool_param("TDS_HIP_POOL_HOST_LAG", s->pool_every / 2);  // H
   if (s->pool_host_lag >= s->pool_every) s->pool_host_lag = s->pool_every - 1;
   if (s->pool_host_lag < 1) s->pool_host_lag = 1;
   const int settle = s->model.settle_steps > 0 ? s->model.settle_steps : 0;
   s->pool_lag = pool_param("TDS_HIP_POOL_LAG", s->pool_host_lag + settle + 6);  // W
-  s->pool_depth = s->pool_every + s->pool_lag + 4;                            // D >= R + W (+ slack)
   s->pool_chunk = pool_param("TDS_HIP_POOL_CHUNK", 128);                      // steps per launch of pool_step_many
-  if (s->pool_depth < 2 * s->pool_chunk + 4) s->pool_depth = 2 * s->pool_chunk + 4;  // (D >= 2 x chunk, see pool_step_many)
+}
+int pool_depth_for(const tds_hip_sim *s, bool many) {
+  return many ? 2 * s->pool_chunk + 4 : s->pool_every + s->pool_lag + 4;
+}
+
+// (first use, or the form now in use needs deeper rings than the one the pool was set up for: the rings start empty)
+int pool_alloc(tds_hip_sim *s) {
+  pool_params(s);
   const size_t n = (size_t)s->num_envs, w = (size_t)(s->model.dof_q + s->model.dof_qd);
+  const int need = pool_depth_for(s, s->pool_many);
+  if (s->d_pool && s->pool_depth >= need) return TDS_OK;
+  if (s->d_pool) {
+    TDS_HIP_TRY(hipStreamSynchronize(s->stream));
+    TDS_HIP_TRY(hipStreamSynchronize(s->pool_stream));
+    TDS_HIP_TRY(hipFree(s->d_pool));
+    s->d_pool = nullptr;
+    s->pool_planned = 0;  // (its work list names slots of the old rings)
+  }
+  s->pool_depth = need;
+  s->pool_discard = true;
+  TDS_HIP_TRY(hipMalloc(&s->d_pool, (size_t)s->pool_depth * n * w * s->elem));
+  if (s->d_pool_filled) return TDS_OK;
   // work list of a pass: what R + 4 single steps can consume; pool_step_many, whose two launches could consume more,
   // carries on with further passes when a list was cut short (more than 24 resets per environment on average)
   s->pool_cap = pool_param("TDS_HIP_POOL_CAP", (int)(n * (size_t)(s->pool_every + 4 > 24 ? s->pool_every + 4 : 24)));
-  TDS_HIP_TRY(hipMalloc(&s->d_pool, (size_t)s->pool_depth * n * w * s->elem));
   TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_filled, n * sizeof(unsigned)));
   TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_items, (1 + 2 * (size_t)s->pool_cap) * sizeof(int)));
   TDS_HIP_TRY(hipHostMalloc((void **)&s->h_pool_nitems, sizeof(int), 0));
