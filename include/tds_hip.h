@@ -317,7 +317,8 @@ int tds_hip_set_graph_chains(tds_hip_sim_t *sim, int chains);
    (TDS_HIP_STEP_MANY_LOOP=0 / 1 forbids / forces the form).
 
    With tds_hip_set_auto_reset on, every one of the n_steps steps resets the environments it ends with done
-   (ars_vectorized_environment.h:262-277), through the reset pool: where _is_loop holds, as step-loop launches of up to
+   (ars_vectorized_environment.h:262-277), through the reset pool: where _is_loop holds (then for the Ant at every
+   batch size: the alternative is single steps, not graphs), as step-loop launches of up to
    128 steps in which a done environment copies its next pre-settled state from its ring into LDS and carries on, the
    rings being topped up between the launches on a side stream; elsewhere as n_steps single steps.  Same stream of
    random numbers and same records as n_steps calls of tds_hip_step_obs. */

@@ -951,7 +951,10 @@ bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
   const bool plain = !two && !(s->compute_f64() ? s->h64.is_floating : s->h32.is_floating) &&
                      (s->compute_f64() ? s->h64.num_spherical : s->h32.num_spherical) == 0;
   const int n_blocks = (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
-  return plain && s->lds.NDP <= 16 && n_blocks <= 3072;
+  // With auto-reset on the alternative is not the chained graphs but single steps through the reset pool: the step-loop
+  // launches (pool_step_many) win at every batch size (Ant x 16384 / 32768 at 5 % resets per step: 2.81e8 / 2.87e8
+  // against 2.29e8 / 2.40e8; with hardly any resets 3.97e8 / 4.07e8 against 3.39e8 / 3.76e8)
+  return plain && s->lds.NDP <= 16 && (n_blocks <= 3072 || s->auto_reset);
 }
 }  // namespace
 }  // extern "C++"

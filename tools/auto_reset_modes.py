@@ -56,8 +56,8 @@ def many_rows(ns):
     for n in ns:
         for amp in (0.8, 0.2):
             base, _, loop = run_many(n, False, amp)
-            v, d, _ = run_many(n, True, amp)
-            print(f"ant x{n} step_many (loop form: {loop}) actions +-{amp / 2}: no auto-reset {base:.4g}, auto-reset {v:.4g} "
+            v, d, loop_ar = run_many(n, True, amp)
+            print(f"ant x{n} step_many (step-loop launches: {loop} without / {loop_ar} with auto-reset) actions +-{amp / 2}: no auto-reset {base:.4g}, auto-reset {v:.4g} "
                   f"env-steps/s = {v / base:.2f} x (last step: {d} done)", flush=True)
 
 
