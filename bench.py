@@ -166,6 +166,10 @@ def main():
                          "'default' (the library's rule) or 'auto' = measured during warm-up (tds_hip_step_many_tune)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (16/32/64), 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spin-up-steps", type=int, default=2000,
+                    help="untimed steps of a SCRATCH handle (same model, same batch, its own state) before the warm-up: a "
+                         "fresh process has run well under a millisecond of kernels by then and a short timed region "
+                         "(--steps 20) would otherwise be measured while the GPU leaves its idle clocks; 0 = off")
     ap.add_argument("--auto-reset", action="store_true",
                     help="secondary workload (N = 1): auto_reset_when_done on — every step resets the environments it "
                          "ends with done (reset distribution + settle steps), through the reset pool")
@@ -405,6 +409,16 @@ def main():
         elif args.chains != "default":
             chains = int(args.chains)
             sim.set_graph_chains(chains)
+    if args.spin_up_steps > 0:
+        scratch = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype,
+                                     lanes_per_env=args.lanes if args.lanes else None)
+        scratch.x.copy_(sim.x)
+        left = args.spin_up_steps
+        while left > 0:
+            c = min(left, 500)
+            scratch.step_many(actions, c)
+            left -= c
+        # (no synchronisation: the warm-up steps below queue up behind it on the same stream)
     prepare(args.warmup)
     run_steps(args.warmup)
     flush()
@@ -571,6 +585,8 @@ def main():
                                        chains, "" if chains == 1 else "s", "measured at warm-up" if args.chains == "auto" else "--chains")))
                                   if (use_graph and (not multi or shard_graph)) else
                                   ("one tds_hip_shard_step call per step (kernel launch + exchange)" if multi else "one kernel launch per step")),
+                       "spin_up": ("%d untimed steps of a scratch handle before the warm-up steps (GPU clocks)" % args.spin_up_steps)
+                       if args.spin_up_steps > 0 else None,
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
                        "parallelism": f"env-shard x{world}" + (" [FALLBACK: exchange through torch.distributed, the C-ABI shard "
                                                                 "could not be created] " if (multi and torch_fallback) else "") + (
