@@ -1,3 +1,6 @@
+"""Runs ON THE GPU BOX: a K-step tds_hip_step_many call (K = 20, 100, 1000; Ant x 4096, one step-loop launch) repeated back
+to back, wall time and HIP-event time, by the way the host waits for it: torch.cuda.synchronize alone, after
+hipStreamSynchronize, after an event wait, after polling the event."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
