@@ -253,8 +253,9 @@ class HipSim:
         _check(lib().tds_hip_step_many_prepare(self.h, ap, nb, int(first_block), int(n_steps), op))
 
     def step_many(self, actions, n_steps: int, obs=None, first_block: int = 0):
-        """``n_steps`` closed-loop steps as ONE hipGraph launch (tds_hip_step_many): step k takes the action block
-        ``actions[(first_block + k) % len(actions)]`` ([B, N, action_dim] device tensor, or None)."""
+        """``n_steps`` closed-loop steps per host call (tds_hip_step_many: chained hipGraphs or one step-loop launch,
+        see step_many_is_loop): step k takes the action block ``actions[(first_block + k) % len(actions)]``
+        ([B, N, action_dim] device tensor, or None).  With auto-reset on, every step resets what it ends with done."""
         ap, nb, op = self._many_args(actions, obs)
         _check(lib().tds_hip_step_many(self.h, ap, nb, int(first_block), int(n_steps), op))
 
@@ -263,7 +264,8 @@ class HipSim:
         _check(lib().tds_hip_debug_poison_lds(self.h, int(byte_pattern)))
 
     def step_many_is_loop(self, n_steps: int) -> bool:
-        """True if step_many(n_steps) runs as one launch of the step-loop kernel (worlds without contact points)."""
+        """True if step_many(n_steps) runs as launches of the step-loop kernel (worlds without contact points; narrow
+        kernels with contacts up to three rounds of workgroups, or at any batch size with auto-reset on)."""
         return bool(lib().tds_hip_step_many_is_loop(self.h, int(n_steps)))
 
     def set_graph_chains(self, chains: int):
