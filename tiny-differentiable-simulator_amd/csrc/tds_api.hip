@@ -424,12 +424,9 @@ __device__ __forceinline__ double pool_uniform01(unsigned long long seed, unsign
   return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// T: compute scalar of the handle (the reset state is formed in it, as the step-loop kernel does), TR: record scalar
-template <typename T, typename TR>
+// one thread per environment: claim the missing entries of its ring in the work list (environment, ring slot, entry)
 __global__ void tds_pool_plan_kernel(const unsigned *__restrict__ count, unsigned *__restrict__ filled, int depth,
-                                     int n, int cap, int *__restrict__ items, TR *__restrict__ stage,
-                                     const TR *__restrict__ x, int in_dim, int nq, int nd, int adim, PoolDist dist,
-                                     unsigned long long seed) {
+                                     int n, int cap, int *__restrict__ items) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const unsigned c = count[e];
@@ -448,15 +445,32 @@ __global__ void tds_pool_plan_kernel(const unsigned *__restrict__ count, unsigne
     const int it = base + j;
     items[1 + it] = e;
     items[1 + cap + it] = (int)(cc % (unsigned)depth);
-    TR *const xs = stage + (size_t)it * in_dim;
-    for (int i = 0; i < nq; ++i) {
-      const T u01 = (T)pool_uniform01(seed, (unsigned)e, cc, (unsigned)i);
-      xs[i] = (TR)((T)dist.q[i] + (T)dist.noise[i] * ((u01 - T(0.5)) * T(2)));
-    }
-    for (int i = nq; i < nq + nd + adim; ++i) xs[i] = TR(0);  // qd = 0, zero action while settling
-    for (int i = nq + nd + adim; i < in_dim; ++i) xs[i] = x[(size_t)e * in_dim + i];  // kp, kd, max_force of the env
+    items[1 + 2 * cap + it] = (int)cc;
   }
   filled[e] = f + (unsigned)take;
+}
+
+// one thread per (work item, record component): the reset state of (seed, environment, entry) into the staging record
+// T: compute scalar of the handle (the reset state is formed in it, as the step-loop kernel does), TR: record scalar
+template <typename T, typename TR>
+__global__ void tds_pool_stage_kernel(const int *__restrict__ items, int n_items, int cap, TR *__restrict__ stage,
+                                      const TR *__restrict__ x, int in_dim, int nq, int nd, int adim, PoolDist dist,
+                                      unsigned long long seed) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int it = (int)(idx / (size_t)in_dim), i = (int)(idx % (size_t)in_dim);
+  if (it >= n_items) return;
+  const int e = items[1 + it];
+  const unsigned cc = (unsigned)items[1 + 2 * cap + it];
+  TR v;
+  if (i < nq) {
+    const T u01 = (T)pool_uniform01(seed, (unsigned)e, cc, (unsigned)i);
+    v = (TR)((T)dist.q[i] + (T)dist.noise[i] * ((u01 - T(0.5)) * T(2)));
+  } else if (i < nq + nd + adim) {
+    v = TR(0);  // qd = 0, zero action while settling
+  } else {
+    v = x[(size_t)e * in_dim + i];  // kp, kd, max_force of the environment
+  }
+  stage[(size_t)it * in_dim + i] = v;
 }
 
 template <typename TR>
@@ -511,7 +525,7 @@ int pool_alloc(tds_hip_sim *s) {
   // carries on with further passes when a list was cut short (more than 24 resets per environment on average)
   s->pool_cap = pool_param("TDS_HIP_POOL_CAP", (int)(n * (size_t)(s->pool_every + 4 > 24 ? s->pool_every + 4 : 24)));
   TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_filled, n * sizeof(unsigned)));
-  TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_items, (1 + 2 * (size_t)s->pool_cap) * sizeof(int)));
+  TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_items, (1 + 3 * (size_t)s->pool_cap) * sizeof(int)));
   TDS_HIP_TRY(hipHostMalloc((void **)&s->h_pool_nitems, sizeof(int), 0));
   TDS_HIP_TRY(hipMalloc(&s->d_stage_x, (size_t)s->pool_cap * s->model.input_dim * s->elem));
   TDS_HIP_TRY(hipStreamCreateWithFlags(&s->pool_stream, hipStreamNonBlocking));
@@ -544,24 +558,9 @@ int pool_plan(tds_hip_sim *s) {
   TDS_HIP_TRY(hipEventRecord(s->pool_step_ev, s->stream));
   TDS_HIP_TRY(hipStreamWaitEvent(s->pool_stream, s->pool_step_ev, 0));
   TDS_HIP_TRY(hipMemsetAsync(s->d_pool_items, 0, sizeof(int), s->pool_stream));
-  PoolDist dist;
-  for (int i = 0; i < TDS_MAX_DOF; ++i) {
-    dist.q[i] = s->model.reset_q[i];
-    dist.noise[i] = s->model.reset_noise[i];
-  }
-  const int n = s->num_envs, nq = s->model.dof_q, nd = s->model.dof_qd;
-  const dim3 grid((n + 127) / 128), block(128);
-#define TDS_PLAN(TT, RR)                                                                                                \
-  hipLaunchKernelGGL((tds_pool_plan_kernel<TT, RR>), grid, block, 0, s->pool_stream, s->d_reset_count, s->d_pool_filled,  \
-                     s->pool_depth, n, s->pool_cap, s->d_pool_items, (RR *)s->d_stage_x, (const RR *)s->d_x,              \
-                     s->model.input_dim, nq, nd, s->model.action_dim, dist, s->seed)
-  if (s->dtype == TDS_DTYPE_F64)
-    TDS_PLAN(double, double);
-  else if (s->dtype == TDS_DTYPE_F64_REC32)
-    TDS_PLAN(double, float);
-  else
-    TDS_PLAN(float, float);
-#undef TDS_PLAN
+  const int n = s->num_envs;
+  hipLaunchKernelGGL(tds_pool_plan_kernel, dim3((n + 127) / 128), dim3(128), 0, s->pool_stream, s->d_reset_count,
+                     s->d_pool_filled, s->pool_depth, n, s->pool_cap, s->d_pool_items);
   if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "reset pool: plan kernel launch");
   TDS_HIP_TRY(hipMemcpyAsync(s->h_pool_nitems, s->d_pool_items, sizeof(int), hipMemcpyDeviceToHost, s->pool_stream));
   TDS_HIP_TRY(hipEventRecord(s->pool_plan_ev, s->pool_stream));
@@ -573,6 +572,27 @@ int pool_run(tds_hip_sim *s, hipEvent_t done) {
   int n_items = *s->h_pool_nitems;
   if (n_items > s->pool_cap) n_items = s->pool_cap;
   if (n_items > 0) {
+    {  // reset states of the work list into the staging records
+      PoolDist dist;
+      for (int i = 0; i < TDS_MAX_DOF; ++i) {
+        dist.q[i] = s->model.reset_q[i];
+        dist.noise[i] = s->model.reset_noise[i];
+      }
+      const int in_dim = s->model.input_dim, nq = s->model.dof_q, nd = s->model.dof_qd;
+      const size_t total = (size_t)n_items * in_dim;
+      const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define TDS_STAGE(TT, RR)                                                                                            \
+  hipLaunchKernelGGL((tds_pool_stage_kernel<TT, RR>), grid, block, 0, s->pool_stream, s->d_pool_items, n_items,         \
+                     s->pool_cap, (RR *)s->d_stage_x, (const RR *)s->d_x, in_dim, nq, nd, s->model.action_dim, dist, s->seed)
+      if (s->dtype == TDS_DTYPE_F64)
+        TDS_STAGE(double, double);
+      else if (s->dtype == TDS_DTYPE_F64_REC32)
+        TDS_STAGE(double, float);
+      else
+        TDS_STAGE(float, float);
+#undef TDS_STAGE
+      if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "reset pool: stage kernel launch");
+    }
     LaunchOpts o;
     o.other_stream = true;
     o.stream = s->pool_stream;
