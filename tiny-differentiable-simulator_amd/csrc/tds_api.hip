@@ -396,8 +396,8 @@ int tds_hip_forward_zero_device(tds_hip_sim_t *s, const void *x_dev, void *y_dev
 // pre-settled states in HBM (entry k lives in slot k mod D; valid entries are [count, filled)); the straight-line step
 // kernel turns "done" into a copy of the next entry (tds_kernels.hip, ctl.pool), and consumed entries are replaced in
 // the background on a side stream: every R steps a PASS
-//     plan     one thread per environment: claim the missing entries [filled, count + D) in a work list, write their
-//              reset states into staging records
+//     plan     one thread per environment: claim the missing entries [filled, count + D) in a work list
+//     stage    one thread per record component: the reset states of the work list into staging records
 //     settle   settle_steps launches of the straight-line step kernel over the staging records (they co-reside with
 //              the main launches: same kernel, two wavefronts per SIMD)
 //     scatter  staging records -> ring slots
