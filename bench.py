@@ -166,7 +166,7 @@ def main():
                          "'default' (the library's rule) or 'auto' = measured during warm-up (tds_hip_step_many_tune)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (16/32/64), 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--spin-up-steps", type=int, default=2000,
+    ap.add_argument("--spin-up-steps", type=int, default=6000,
                     help="untimed steps of a SCRATCH handle (same model, same batch, its own state) before the warm-up: a "
                          "fresh process has run well under a millisecond of kernels by then and a short timed region "
                          "(--steps 20) would otherwise be measured while the GPU leaves its idle clocks; 0 = off")

@@ -477,7 +477,7 @@ int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const 
    step — the eager form is host-bound at ~20 us per step.  actions_dev [action_blocks][n_local][action_dim], step k
    uses block (first_block + k) % action_blocks.  n_steps: a multiple of the exchange block, <= 4096.  Collective:
    every rank makes the same call.  Falls back to eager stepping if the capture is refused (TDS_HIP_SHARD_NO_GRAPH=1
-   forces that). */
+   forces that), and steps eagerly when auto-reset is on (the refill passes of the reset pool are host-driven). */
 int tds_hip_shard_step_many(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks, int first_block,
                             int n_steps);
 /* capture + instantiate the graph of the next tds_hip_shard_step_many with the same arguments; nothing executes */

@@ -358,3 +358,30 @@ def test_shard_step_many_graph_equals_eager_exchange(with_rccl, built):
     assert torch.equal(graph.gathered(), eager.gathered())
     eager.close()
     graph.close()
+
+
+def test_shard_step_many_with_auto_reset_steps_eagerly(built):
+    """with auto-reset on, the K steps of tds_hip_shard_step_many are K auto-reset steps + exchanges (the reset pool's
+    refill passes are host-driven, so nothing is captured): same records as K tds_hip_shard_step calls"""
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    n = 192
+    x, acts = _start(m, n, seed=37)
+    x[::3, 2] = 0.27  # torso at the done threshold: resets within a few steps
+    a = torch.from_numpy(acts).cuda().contiguous()
+    one, many = hip_backend.HipShard(m, n, wire_dtype="f64"), hip_backend.HipShard(m, n, wire_dtype="f64")
+    for s in (one, many):
+        s.sim.set_auto_reset(True, 11)
+        s.sim.x.copy_(torch.from_numpy(x).cuda())
+    K = 30
+    done = 0
+    for k in range(K):
+        one.step(a[(2 + k) % 6])
+        done += int((one.gathered()[0, 0, :, -1] != 0).sum())
+    many.step_many(a, K, first_block=2)
+    torch.cuda.synchronize()
+    assert done > 20
+    assert torch.equal(many.sim.x.view(torch.int64), one.sim.x.view(torch.int64))
+    assert torch.equal(many.gathered().view(torch.int64), one.gathered().view(torch.int64))
+    one.close()
+    many.close()

@@ -416,16 +416,17 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
   if (n_steps % sh->block != 0) return fail(TDS_ERR_INVALID_ARG, "n_steps must be a multiple of the exchange block");
   if (actions_dev && action_blocks < 1) return fail(TDS_ERR_INVALID_ARG, "action_blocks must be >= 1");
   tds_hip_sim *s = sh->sim;
-  if (s->auto_reset) return fail(TDS_ERR_INVALID_ARG, "step_many replays plain closed-loop steps (auto-reset is off the graph)");
   DeviceGuard guard(s->device);
   const int pool = actions_dev ? action_blocks : 1;
   const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
   const size_t blk = (size_t)sh->n_local * s->model.action_dim * s->elem;
   const int slot0 = (int)((sh->steps / sh->block) % kSlots);
+  // (auto-reset: the refill passes of the reset pool are host-driven — stepped eagerly, one exchange per block as ever)
+  const bool eager_only = s->auto_reset || getenv("TDS_HIP_SHARD_NO_GRAPH") != nullptr;
   const bool cached = sh->graph_exec && sh->graph_actions == actions_dev && sh->graph_pool == pool &&
                       sh->graph_first == first && sh->graph_steps == n_steps && sh->graph_block == sh->block &&
                       sh->graph_slot0 == slot0;
-  if (!cached && getenv("TDS_HIP_SHARD_NO_GRAPH") == nullptr) {
+  if (!cached && !eager_only) {
     if (sh->graph_exec) {
       (void)hipGraphExecDestroy(sh->graph_exec);
       sh->graph_exec = nullptr;
@@ -491,7 +492,7 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
     }
   }
   if (!run) return TDS_OK;
-  if (sh->graph_exec && getenv("TDS_HIP_SHARD_NO_GRAPH") == nullptr) {
+  if (sh->graph_exec && !eager_only) {
     // eager exchanges still in flight must not be overtaken by the graph's reuse of their slots
     for (int i = 0; i < kSlots; ++i)
       if (sh->pending[i]) {
