@@ -105,7 +105,7 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   const bool two_waves = s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && nsub == 1 &&
                          reset_mode == TDS_RESET_NONE && !ro && !(opts && opts->lds);
   const TdsLds &lds = (opts && opts->lds) ? *opts->lds : (two_waves ? s->lds_w2 : s->lds);
-  void *ovf = (opts && opts->lds) ? nullptr : s->d_ovf;
+  void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
   if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along
     const size_t e0 = (size_t)opts->env_first, el = s->elem;
     auto at = [&](const void *p, size_t per_env, size_t bytes) -> void * {
@@ -538,6 +538,19 @@ int pool_alloc(tds_hip_sim *s) {
   const int epw = 64 / s->lanes;
   s->pool_lds = s->compute_f64() ? tds_make_lds_layout<double>(s->h64, 0, s->lanes)
                                  : tds_make_lds_layout<float>(s->h32, 0, s->lanes);
+  // The refill launches run with the handle's own layout — 19.8 KB per Ant workgroup, two wavefronts per SIMD — and a
+  // surplus-row slab of their own, sized for a whole work list, where that slab stays under 4 GiB (Ant: 4.6 KB per
+  // entry, 0.46 GB at 4096 environments); otherwise (or with TDS_HIP_POOL_SLAB=0) with every constraint row in LDS
+  // (37.7 KB, one wavefront per SIMD).  Ant x 8192 at 5 % resets per step: single steps 2.21e8 -> 2.73e8, step_many
+  // 2.74e8 -> 3.01e8; x 4096 unchanged (the refill fits beside the steps either way).
+  {
+    const char *ps = getenv("TDS_HIP_POOL_SLAB");
+    const size_t per_env = (size_t)s->lds.ovrows * (s->lds.NDs + 3) * (s->compute_f64() ? 8 : 4);
+    if (!(ps && ps[0] == '0') && per_env > 0 && per_env * (size_t)s->pool_cap <= ((size_t)4 << 30)) {
+      TDS_HIP_TRY(hipMalloc(&s->d_pool_ovf, per_env * (size_t)s->pool_cap));
+      s->pool_lds = s->lds;
+    }
+  }
   const int lds_bytes = (int)((size_t)s->pool_lds.stride * epw * (s->compute_f64() ? 8 : 4));
   if (lds_bytes > 160 * 1024) return fail(TDS_ERR_UNSUPPORTED, "reset pool: the refill launches need more than 160 KiB of LDS");
   if (lds_bytes > 64 * 1024) {
@@ -597,6 +610,7 @@ int pool_run(tds_hip_sim *s, hipEvent_t done) {
     o.other_stream = true;
     o.stream = s->pool_stream;
     o.lds = &s->pool_lds;
+    o.ovf = s->d_pool_ovf;
     // straight-line step kernel on the staging records: zero action, state fed back in place, no y / obs record
     // (TDS_HIP_POOL_SETTLE_LOOP=1: the settle steps as ONE launch of the step-loop build — measured, no gain)
     const char *sl = getenv("TDS_HIP_POOL_SETTLE_LOOP");
@@ -783,6 +797,7 @@ void pool_free(tds_hip_sim *s) {
   if (s->d_pool_items) (void)hipFree(s->d_pool_items);
   if (s->h_pool_nitems) (void)hipHostFree(s->h_pool_nitems);
   if (s->d_stage_x) (void)hipFree(s->d_stage_x);
+  if (s->d_pool_ovf) (void)hipFree(s->d_pool_ovf);
   for (int i = 0; i < tds_hip_sim::kPoolEvents; ++i)
     if (s->pool_ev[i]) (void)hipEventDestroy(s->pool_ev[i]);
   if (s->pool_step_ev) (void)hipEventDestroy(s->pool_step_ev);

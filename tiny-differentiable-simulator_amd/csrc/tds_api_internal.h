@@ -38,6 +38,7 @@ struct tds_hip_sim {
   unsigned int *d_pool_filled = nullptr;  // [N] entries produced so far per env (valid: [count, filled))
   int *d_pool_items = nullptr;            // [1 + 2 cap]: n_items | item env | item ring slot
   int *h_pool_nitems = nullptr;           // pinned: n_items of the pass that has been planned
+  void *d_pool_ovf = nullptr;             // surplus-row slab of the refill launches ([cap] environments; TDS_HIP_POOL_SLAB=0: none)
   void *d_stage_x = nullptr;              // [cap][input_dim] record dtype: the work list's records while they settle
   TdsLds pool_lds;                        // LDS layout of the refill launches: all constraint rows in LDS
   hipStream_t pool_stream = nullptr;
@@ -109,6 +110,7 @@ struct LaunchOpts {
   bool other_stream = false;          // launch on `stream` instead of the handle's
   hipStream_t stream = nullptr;
   const TdsLds *lds = nullptr;        // LDS layout (the refill launches keep every constraint row in LDS: no slab)
+  void *ovf = nullptr;                // ... or a surplus-row slab of the launch's own
   const void *act_pool = nullptr;     // step-loop launch with a different action block per step (TdsStepCtl::act_pool)
   int act_blocks = 0, act_first = 0;
   int env_first = 0;                  // this launch serves environments [env_first, env_first + n) of the records
