@@ -5,15 +5,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one closed-loop environment step of every resident env: fresh action batch (already
-in HBM) -> HIP step kernel (PD, forward dynamics, plane contacts, MLCP/PGS, Euler, record packing) -> new
-state fed back on device, plus the [obs | reward | done] record written by the same launch.
-With N > 1 ranks each GPU owns its own shard of environments (no data-path collective inside
-the step) and the observation records are all-gathered over RCCL ONCE PER POLICY STEP by the
-library's own shard layer (tds_hip_shard_*: librccl called from C, communication stream, overlapped with
-the next step); the 32-steps-per-exchange pipelined form is timed afterwards and reported as a second key.
-At N = 1 the K timed steps are replayed from a captured hipGraph (tds_hip_step_many: one graph launch
-instead of K kernel launches), so that short runs reproduce the steady-state rate.
+A "step" = one closed-loop environment step of every resident env, ALL of step_forward_original's work and of
+VectorizedEnvironment::step's on top of it, EVERY step: fresh action batch (already in HBM) -> PD, forward dynamics,
+plane contacts, MLCP/PGS, Euler -> output packing (q, qd, visual poses, up.z, padding: the y record) + reward / done +
+observation, each step's y record and [obs | reward | done] record stored into its slot of a ring in HBM
+(tds_hip_step_many_rings).  The K timed steps are ONE launch of the step-loop kernel where the library has that form
+(Ant up to three rounds of workgroups, worlds without contacts), chained hipGraphs of single-step launches elsewhere —
+the work per step is the same in both.  The form that skips the records of all but the last step of a launch
+(tds_hip_step_many: a substep-fused figure) is timed afterwards and reported under the secondary key
+"substep_fused", never as `value`.
+With N > 1 ranks each GPU owns its own shard of environments and runs the SAME launches (same rings); the
+[obs | reward | done] ring slots are all-gathered over RCCL ONCE PER POLICY STEP by the library's own
+shard layer (tds_hip_shard_step_many: librccl called from C on a communication stream that follows the running launch's
+per-step progress counter — no host call and no kernel boundary per step).  N = 1 and N > 1 differ by the exchange only.
 
 Prints ONE JSON line on rank 0 (contract in the project brief): value = total env-steps / s
 over all GPUs, plus `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM) and
@@ -140,6 +144,18 @@ def pmc_traffic_loop(model, n, dtype, steps_per_launch):
         return None, None
 
 
+def pmc_traffic_rings(model, n, dtype, steps_per_launch):
+    """HBM bytes of ONE launch of the per-step-record form (tds_hip_step_many_rings): FETCH_SIZE / WRITE_SIZE of the
+    driver's own command (`python bench.py --steps 20 --warmup 5`), per step x the steps of a launch."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            e = json.load(f)[model][str(n)][dtype]["rings"]
+        per_step = 2.0 * e["fetch_kib_per_step"] + e["write_kib_per_step"]
+        return int(per_step * steps_per_launch * 1024), e["source"]
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,11 +168,17 @@ def main():
                          "records (x, y, actions, obs) with the arithmetic in double registers — the variant that meets "
                          "the 1e-6 contract on float records (BASELINE config 2).  f32-pure: float arithmetic "
                          "(measured only: misses 1e-6, like the reference's own float instantiation)")
-    ap.add_argument("--no-graph", action="store_true", help="N = 1: K eager launches instead of one hipGraph launch")
-    ap.add_argument("--shard-graph", action="store_true",
-                    help="N > 1: replay steps + exchanges from one hipGraph (tds_hip_shard_step_many) instead of eager "
-                         "tds_hip_shard_step calls.  Off by default at N > 1: the RCCL exchange sets the pace there, the "
-                         "host has time for the calls, and a captured collective has never run on more than one rank")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="N = 1: K eager single-step launches (tds_hip_step_obs); N > 1: one tds_hip_shard_step call per step")
+    ap.add_argument("--records", choices=["rings", "last"], default="rings",
+                    help="rings (default): every step packs and stores its y and [obs|reward|done] records into ring slots "
+                         "(tds_hip_step_many_rings) — the per-step protocol of the reference's metric loop; last: only the "
+                         "last step of a launch does (tds_hip_step_many: the substep-fused form, secondary)")
+    ap.add_argument("--ring-slots", type=int, default=64, help="slots of the two record rings (a slot is reused that many steps later)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements of the default N = 1 line (substep_fused, one_rank_with_exchange, auto_reset_rate)")
+    ap.add_argument("--shard-eager", action="store_true",
+                    help="N > 1: submit the ring exchange eagerly (TDS_HIP_SHARD_NO_GRAPH=1) instead of one hipGraph per launch")
     ap.add_argument("--step-many-form", choices=["auto", "graph", "loop"], default="auto",
                     help="N = 1: how tds_hip_step_many runs the K steps — chained hipGraphs of single-step launches, ONE "
                          "launch of the step-loop kernel, or the library's choice (loop for worlds without contacts and "
@@ -179,7 +201,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N > 1: steps whose [obs|reward|done] records travel in one all-gather (1 = one exchange "
                          "per policy step, SURVEY 8e's protocol and the default)")
-    ap.add_argument("--pipelined-block", type=int, default=32,
+    ap.add_argument("--pipelined-block", type=int, default=0,
                     help="N > 1: also time the pipelined form with this many steps per exchange (0 = skip)")
     ap.add_argument("--gather-dtype", choices=["f32", "f64"], default="f32",
                     help="dtype the [obs | reward | done] records cross xGMI in (the step itself stays in --dtype): "
@@ -211,6 +233,8 @@ def main():
 
     if args.step_many_form != "auto":
         os.environ["TDS_HIP_STEP_MANY_LOOP"] = "1" if args.step_many_form == "loop" else "0"
+    if args.shard_eager:
+        os.environ["TDS_HIP_SHARD_NO_GRAPH"] = "1"
     import tds_amd
     from tds_amd import hip_backend
 
@@ -355,7 +379,13 @@ def main():
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
     B = max(1, args.gather_every)
     use_graph = not args.no_graph
-    shard_graph = use_graph and multi and (world == 1 or args.shard_graph) and not torch_fallback if multi else False
+    shard_graph = (use_graph and not torch_fallback) if multi else False
+    use_rings = use_graph and not multi and args.records == "rings"
+    RS = max(1, args.ring_slots)
+    obs_ring = y_ring = None
+    if use_rings:  # (at N > 1 the shard layer owns the rings)
+        obs_ring = torch.zeros((RS, n, sim.obs_dim + 2), dtype=tdt, device="cuda")
+        y_ring = torch.zeros((RS, n, m.output_dim), dtype=tdt, device="cuda")
     GCH = 1024  # steps per graph launch when K is larger (a multiple of the action pool)
     state = {"i": 0}
 
@@ -376,7 +406,11 @@ def main():
             left = k_steps
             while left > 0:
                 c = left if left <= GCH else GCH
-                if c < GCH and k_steps > GCH:  # remainder of a long run: eager (the graph cache holds one graph)
+                if use_rings:
+                    sim.step_many_rings(actions, c, obs_ring, y_ring, first_block=state["i"] % pool,
+                                        obs_first=state["i"] % RS, y_first=state["i"] % RS)
+                    state["i"] += c
+                elif c < GCH and k_steps > GCH:  # remainder of a long run: eager (the graph cache holds one graph)
                     for _ in range(c):
                         sim.step(actions[state["i"] % pool], 1, obs)
                         state["i"] += 1
@@ -394,6 +428,9 @@ def main():
         if use_graph and k_steps > 0 and multi:
             if k_steps % B == 0 and shard_graph:
                 shard.step_many(actions, min(k_steps, GCH), first_block=state["i"] % pool, prepare_only=True)
+        elif use_graph and k_steps > 0 and use_rings:
+            sim.step_many_rings(actions, min(k_steps, GCH), obs_ring, y_ring, first_block=state["i"] % pool,
+                                obs_first=state["i"] % RS, y_first=state["i"] % RS, prepare_only=True)
         elif use_graph and k_steps > 0:
             sim.step_many_prepare(actions, min(k_steps, GCH), obs, first_block=state["i"] % pool)
 
@@ -402,7 +439,7 @@ def main():
             shard.flush()
 
     chains = None
-    loop_form = use_graph and not multi and sim.step_many_is_loop(min(args.steps, GCH))
+    loop_form = use_graph and sim.step_many_is_loop(min(args.steps, GCH)) and (not multi or (B == 1 and not torch_fallback))
     if use_graph and not multi and not loop_form and not auto_reset:
         if args.chains == "auto":  # 6 x 128 extra untimed steps
             chains = sim.tune_step_many(actions, 128, obs)
@@ -419,10 +456,42 @@ def main():
             scratch.step_many(actions, c)
             left -= c
         # (no synchronisation: the warm-up steps below queue up behind it on the same stream)
-    prepare(args.warmup)
-    run_steps(args.warmup)
-    flush()
-    torch.cuda.synchronize()
+    shard_form = None
+    if multi and not torch_fallback:
+        # The exchange forms, most to least ambitious: ring exchange behind the step-loop launch (one hipGraph per launch) ->
+        # per-step launches + exchanges from one hipGraph -> one tds_hip_shard_step call per step.  A form that fails
+        # during the warm-up steps (a refused capture falls back inside the library; this catches what it cannot: a
+        # ring wait that timed out, an RCCL error) is dropped on EVERY rank before anything is timed.
+        forms = ["ring", "per-step graph", "per-step eager"] if shard_graph else ["per-step eager"]
+        for f in forms:
+            if f == "per-step graph":
+                os.environ["TDS_HIP_SHARD_RING"] = "0"
+            if f == "per-step eager":
+                shard_graph = False
+            err = 0
+            try:
+                prepare(args.warmup)
+                run_steps(max(args.warmup, 1))
+                flush()
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: exchange form '{f}' failed on rank {rank}: {e!r}", file=sys.stderr)
+                err = 1
+            if world > 1:
+                flag = torch.tensor([err], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                err = int(flag.item())
+            if not err:
+                shard_form = f
+                break
+        if shard_form is None:
+            raise SystemExit("bench.py: no exchange form works on this node")
+        loop_form = loop_form and shard_form == "ring"
+    else:
+        prepare(args.warmup)
+        run_steps(args.warmup)
+        flush()
+        torch.cuda.synchronize()
     K = args.steps
     prepare(K)  # (capture + instantiate only)
     if world > 1:
@@ -504,6 +573,76 @@ def main():
     bad_envs = int((~torch.isfinite(sim.y).all(dim=1)).sum().item())
     finite = bad_envs == 0
 
+    def timed(fn, k_steps):
+        """wall time of fn() bracketed by synchronisations, on this rank (secondary measurements, N = 1)"""
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return n * k_steps / (time.perf_counter() - t1)
+
+    # ---- secondary keys of the default N = 1 line (same model, same batch, same K; each on the state the timed region left)
+    substep_fused = one_rank = auto_rate = None
+    if use_rings and world == 1 and not args.no_secondary and not auto_reset:
+        # (a) the substep-fused form: the same launches WITHOUT per-step records (y / obs of the last step of a launch only)
+        kk = min(K, GCH)
+        sim.step_many(actions, kk, obs)
+        v = timed(lambda: sim.step_many(actions, kk, obs), kk)
+        substep_fused = {"value": v, "unit": "env-steps/s", "steps": kk,
+                         "what": "tds_hip_step_many: the same K steps, output packing and records for the LAST step of a launch "
+                                 "only (batch x substeps per launch; not the per-step protocol, never `value`)"}
+        # (b) one rank through the shard layer: the same launches + the per-step exchange of the obs ring (single-rank
+        #     RCCL communicator): what N > 1 runs, minus the other ranks — the protocol's own cost
+        try:
+            import ctypes
+            libc = ctypes.CDLL(None)
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)  # (RCCL's banner goes to stderr)
+            try:
+                uid = hip_backend.HipShard.unique_id() if hip_backend.HipShard.rccl_version() > 0 else None
+                sh1 = hip_backend.HipShard(m, n, rank=0, world=1, device=local_rank, dtype=lib_dtype, unique_id=uid,
+                                           wire_dtype=args.gather_dtype)
+                libc.fflush(None)
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
+            sh1.sim.x.copy_(sim.x)
+            sh1.step_many(actions, kk)
+            sh1.flush()
+            sh1.step_many(actions, kk, prepare_only=True)
+
+            def go():
+                sh1.step_many(actions, kk)
+                sh1.flush()
+
+            v = timed(go, kk)
+            one_rank = {"value": v, "unit": "env-steps/s", "steps": kk,
+                        "exchange": "ncclAllGather, single-rank communicator" if uid else "device copy (librccl not loadable)",
+                        "what": "tds_hip_shard_step_many on ONE rank: the same step-loop launch and rings + one all-gather of "
+                                "the obs ring slot per policy step on the communication stream (what every rank of an "
+                                "N > 1 run executes)"}
+            sh1.close()
+        except Exception as e:  # noqa: BLE001 - a secondary key must never cost the headline line
+            one_rank = {"error": repr(e)}
+        # (c) auto_reset_when_done on — the loop python/examples/vec_ant.py:16-40 times: every step resets the
+        #     environments it ends with done (reset distribution + settle steps, through the reset pool), records per step
+        if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and m.reward_mode != 0:
+            try:
+                ar = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype, lanes_per_env=args.lanes if args.lanes else None)
+                ar.x.copy_(sim.x)
+                ar.set_auto_reset(True, 5)
+                ar.step_many_rings(actions, max(kk, 64), obs_ring, y_ring)  # (fills the reset pool, first passes)
+                ar.step_many_rings(actions, kk, obs_ring, y_ring)
+                v = timed(lambda: ar.step_many_rings(actions, kk, obs_ring, y_ring), kk)
+                dn = int((obs_ring[(kk - 1) % RS][:, -1] != 0).sum().item())
+                auto_rate = {"value": v, "unit": "env-steps/s", "steps": kk, "done_in_last_step": dn,
+                             "what": "auto_reset_when_done: the same launches with every done environment re-initialised + settled "
+                                     "(%d settle steps) through the reset pool, records per step" % m.settle_steps}
+                ar.close()
+            except Exception as e:  # noqa: BLE001
+                auto_rate = {"error": repr(e)}
+
     # secondary (not the headline): the same environments driven by per-environment linear policies
     # entirely on device, R policy steps per launch (tds_hip_rollout, SURVEY 8f N2)
     rollout = None
@@ -521,13 +660,14 @@ def main():
         rollout = {"value": n * args.rollout_steps * reps / dt_r, "unit": "env-steps/s",
                    "policy_steps_per_launch": args.rollout_steps, "launches": reps,
                    "what": "linear policy + step + reward/done + return bookkeeping on device: one launch per rollout "
-                           "(step-loop build), or from two wavefronts per SIMD on one straight-line step launch per "
-                           "step with the policy + bookkeeping kernel in between (tds_hip_rollout picks)"}
+                           "(step-loop build)"}
     if rank == 0:
         elem = 8 if args.dtype == "f64" else 4  # bytes per scalar of the records in HBM
         bytes_per_env_step = (m.input_dim + m.output_dim) * elem  # x record in + y record out
         total_steps = world * n * K
         value = total_steps / elapsed
+        per_step_records = use_rings or multi or not use_graph  # every step packs + stores its records
+        ring_exchange = multi and not torch_fallback and shard_form == "ring"
         roof = None
         if kernel_ms:
             # environment chains: C launches of n / C environments each are in flight at the same time, every one of
@@ -538,10 +678,14 @@ def main():
             traffic, traffic_src = pmc_traffic(args.model, n, args.dtype)  # (measured on whole-batch launches)
             if traffic is not None:
                 traffic = traffic // conc
-            spl = min(K, GCH) if loop_form else 1  # steps per launch (loop form: one launch = spl steps)
+            spl = (min(K, 64) if multi else min(K, GCH)) if loop_form else 1  # steps per launch (loop form: one launch = spl steps)
             if auto_reset:  # (step-loop launches of up to 128 steps, or single steps; the refill launches run beside them)
                 spl = min(K, GCH, 128) if loop_form else 1
                 traffic, traffic_src = None, None
+            elif loop_form and per_step_records:
+                # every step's y and obs records leave the launch, the state itself stays in LDS: measured on the
+                # driver's own command
+                traffic, traffic_src = pmc_traffic_rings(args.model, n, args.dtype, spl)
             elif loop_form:
                 # the state stays in LDS across the steps of a launch: per step only the action block is read, the
                 # records are written once per launch — measured on the step-loop launch itself
@@ -552,6 +696,7 @@ def main():
                     "kernel": "tds_step_kernel", "kernel_ms_avg": kernel_ms * spl, "steps_per_launch": spl,
                     "kernel_ms_isolated": kernel_ms_isolated,
                     "algorithmic_bytes_per_launch": n * bytes_per_env_step * spl // conc,
+                    "traffic_over_algorithmic": (traffic / (n * bytes_per_env_step * spl // conc)) if traffic else None,
                     "launches_in_flight": conc,
                     "achieved_per_launch": achieved / conc,
                     # secondary view: flops of the reference's dense formulation per env-step
@@ -559,48 +704,77 @@ def main():
                     "algorithmic_tflops": (ALG_FLOPS[args.model] * n / (kernel_ms * 1e-3) / 1e12
                                            if args.model in ALG_FLOPS else None),
                     "valu_peak_tflops": 78.6 if arith == "f64" else 157.3,
-                    "note": "algorithmic bytes = (input_dim+output_dim)*sizeof(T) per env-step; achieved = "
-                            "launches_in_flight x algorithmic_bytes_per_launch / kernel_ms_avg (the launches of the "
-                            "environment chains overlap, each lasts about one step period); the path is "
+                    "note": "algorithmic bytes = (input_dim+output_dim)*sizeof(T) per env-step (SURVEY 8d: one read of the x "
+                            "record + one write of the y record); achieved = launches_in_flight x algorithmic_bytes_per_launch "
+                            "/ kernel_ms_avg; a step-loop launch keeps the state in LDS: per step it reads an action block "
+                            "and writes the y record + the obs record into their ring slots (traffic); the path is "
                             "VALU/LDS-latency bound, see DESIGN.md"}
+        if auto_reset and loop_form:
+            launch = ("step-loop launches of up to 128 steps, per-step records into rings; a done environment takes its next "
+                      "pre-settled state from its ring in HBM; rings refilled by straight-line launches on a side stream")
+        elif auto_reset:
+            launch = ("one straight-line launch per step, a done environment takes its next pre-settled state from its ring in "
+                      "HBM; rings refilled on a side stream")
+        elif multi and ring_exchange:
+            launch = ("one launch of the step-loop kernel per %d steps, EVERY step packing and storing its y record and its "
+                      "[obs | reward | done] record into ring slots; the communication stream follows the launch's per-step "
+                      "progress counter and all-gathers each obs slot (launch + its exchanges = one hipGraph%s)"
+                      % (min(K, 64), "" if os.environ.get("TDS_HIP_SHARD_NO_GRAPH") is None else "; submitted eagerly"))
+        elif loop_form and use_rings:
+            launch = ("one launch of the step-loop kernel per %d steps (state in LDS across the steps, one action block per "
+                      "step), EVERY step running the whole output packing — visual poses, y record, reward / done, "
+                      "observation — and storing its y record and its [obs | reward | done] record into their slots of "
+                      "%d-slot rings in HBM (tds_hip_step_many_rings: per-step records)" % (min(K, GCH), RS))
+        elif loop_form:
+            launch = ("one launch of the step-loop kernel per %d steps (state in LDS across the steps, one action block per step; "
+                      "records written once per launch: substep-fused form)" % min(K, GCH))
+        elif use_graph and (not multi or shard_graph):
+            launch = ("hipGraph: %d single-step launches%s per graph launch, every launch writing its y and [obs | reward | done] "
+                      "records%s" % (min(K, GCH), " + their exchanges" if multi else "", " into ring slots" if use_rings else "")
+                      + ("" if chains is None else ", the batch as %d independent environment chain%s (%s)" % (
+                          chains, "" if chains == 1 else "s", "measured at warm-up" if args.chains == "auto" else "--chains")))
+        else:
+            launch = "one tds_hip_shard_step call per step (kernel launch + exchange)" if multi else "one kernel launch per step"
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K,
             "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             # the arithmetic type the path computes in; the record type is in config.records
             "dtype": "f32" if args.dtype == "f32-pure" else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.model} (gym Ant 14-dof + plane, 17 contact points, PGS 1 iter), "
-                                   f"{n} envs/GPU, dt={m.dt}, closed loop, fresh actions each step"
-                       if args.model == "ant" else f"{args.model}, {n} envs/GPU, dt={m.dt}",
+            "config": {"workload": (f"{args.model} (gym Ant 14-dof + plane, 17 contact points, PGS 1 iter), " if args.model == "ant"
+                                    else f"{args.model}, ") +
+                                   f"{n} envs/GPU, dt={m.dt}; state fed back on device every step; actions: a pool of {pool} "
+                                   f"uniform random action batches resident in HBM, step k takes batch k mod {pool} "
+                                   f"(no policy in the loop)",
                        "records": "f64" if args.dtype == "f64" else "f32",
+                       "per_step_records": bool(per_step_records),
                        "auto_reset": ("auto_reset_when_done: every step resets the environments it ends with done "
                                       "(reset distribution + %d settle steps) through the reset pool; %d of %d environments "
                                       "done in the last step" % (m.settle_steps, int((obs[:, -1] != 0).sum().item()), n))
                        if auto_reset else None,
-                       "launch": ("step-loop launches of up to 128 steps, a done environment takes its next pre-settled state "
-                                  "from its ring in HBM; rings refilled by straight-line launches on a side stream") if (auto_reset and loop_form) else
-                                 ("one straight-line launch per step, a done environment takes its next pre-settled state from "
-                                  "its ring in HBM; rings refilled on a side stream") if auto_reset else
-                                 ("one launch of the step-loop kernel per %d steps (state in LDS across the steps, one action "
-                                  "block per step; records written once per launch)" % min(K, GCH)) if loop_form else (("hipGraph: %d steps%s per graph launch" % (min(K, GCH), " + their exchanges" if multi else "")
-                                   + ("" if chains is None else ", the batch as %d independent environment chain%s (%s)" % (
-                                       chains, "" if chains == 1 else "s", "measured at warm-up" if args.chains == "auto" else "--chains")))
-                                  if (use_graph and (not multi or shard_graph)) else
-                                  ("one tds_hip_shard_step call per step (kernel launch + exchange)" if multi else "one kernel launch per step")),
+                       "launch": launch,
+                       "exchange_form": shard_form,
                        "spin_up": ("%d untimed steps of a scratch handle before the warm-up steps (GPU clocks)" % args.spin_up_steps)
                        if args.spin_up_steps > 0 else None,
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
+                       "steps_per_launch": (min(K, 64) if multi else min(K, GCH)) if loop_form else 1,
                        "parallelism": f"env-shard x{world}" + (" [FALLBACK: exchange through torch.distributed, the C-ABI shard "
                                                                 "could not be created] " if (multi and torch_fallback) else "") + (
-                           f" + one {'all_gather_into_tensor (torch.distributed)' if (multi and torch_fallback) else 'ncclAllGather (librccl from the C ABI, tds_hip_shard_step)'} of the (obs|reward|done) "
+                           f" + one {'all_gather_into_tensor (torch.distributed)' if (multi and torch_fallback) else 'ncclAllGather (librccl from the C ABI, tds_hip_shard_step_many)'} of the (obs|reward|done) "
                            f"records per {'policy step' if B == 1 else str(B) + ' steps'}, "
                            f"{args.gather_dtype if args.dtype == 'f64' else 'f32'} on the wire (the records are computed "
                            f"and fed back in {'f64' if args.dtype == 'f64' else 'f32'} on the owning GPU), on a "
-                           f"communication stream, overlapped with the next step" if multi else ""),
+                           f"communication stream, overlapped with the following steps" if multi else ""),
                        "lanes_per_env": sim.kernel_info()["lanes_per_env"],
                        "lds_bytes_per_env": sim.kernel_info()["lds_bytes_per_env"]},
             "roofline": roof, "finite": finite, "nonfinite_envs": bad_envs,
         }
+        if substep_fused is not None:
+            out["substep_fused"] = substep_fused
+        if one_rank is not None:
+            out["one_rank_with_exchange"] = one_rank
+        if auto_rate is not None:
+            out["auto_reset_rate"] = auto_rate
         if rollout is not None:
             out["on_device_rollout"] = rollout
         if pipelined is not None:

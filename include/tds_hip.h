@@ -323,6 +323,38 @@ int tds_hip_set_graph_chains(tds_hip_sim_t *sim, int chains);
    rings being topped up between the launches on a side stream; elsewhere as n_steps single steps.  Same stream of
    random numbers and same records as n_steps calls of tds_hip_step_obs. */
 int tds_hip_step_many_is_loop(const tds_hip_sim_t *sim, int n_steps);
+
+/* tds_hip_step_many with PER-STEP RECORDS: every one of the n_steps steps produces what one call of the reference's
+   VectorizedEnvironment::step produces (ars_vectorized_environment.h:240-289 on top of step_forward_original's output
+   packing, locomotion_contact_simulation.h:273-303) — the [obs | reward | done] record and, if asked for, the whole y
+   record (q, qd, visual poses, up.z, padding) — and stores it into the step's slot of a caller-owned ring in HBM:
+     obs_ring  [obs_slots][N][obs_dim + 2]   step k of the call -> slot (obs_first + k) % obs_slots
+     y_ring    [y_slots][N][output_dim]      step k of the call -> slot (y_first + k) % y_slots        (either may be NULL)
+   in the record dtype; obs_f32 != 0: the obs ring holds FLOATS whatever the record dtype (the wire format of the
+   multi-GPU exchange).  Where tds_hip_step_many_is_loop holds the n_steps steps are ONE launch of the step-loop kernel
+   that packs and stores the records of every step (non-temporal stores; the state itself never leaves LDS between the
+   steps); elsewhere they are the chained graphs of single-step launches with each launch pointed at its slots.  With
+   auto-reset on, a step that ends with done leaves reward / done of the terminal step and the observation of the fresh
+   environment in its slot, as the reference does.  Afterwards the handle's y record holds the last step's (a device
+   copy of its slot).  This is the form bench.py times: all of step_forward_original's work, every step.
+     progress  optional, step-loop form only: a device counter every workgroup increments once its records of step k
+               are visible device-wide (signalled while step k + 1 runs; not for the last step of the call: stream
+               order covers it) — what tds_hip_shard_step_many polls to exchange slot k while the launch carries on.
+               tds_hip_step_many_rings_blocks = increments per completed step.
+   A slot is overwritten `slots` steps later: the ring's depth is the lag the consumer may have. */
+typedef struct tds_hip_rings {
+  void *obs_ring;
+  int32_t obs_slots, obs_first, obs_f32, pad0_;
+  void *y_ring;
+  int32_t y_slots, y_first;
+  unsigned long long *progress;
+} tds_hip_rings_t;
+int tds_hip_step_many_rings(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int first_block, int n_steps,
+                            const tds_hip_rings_t *rings);
+/* builds the graphs of the next tds_hip_step_many_rings with the same arguments (graph form; a no-op for the loop form) */
+int tds_hip_step_many_rings_prepare(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int first_block,
+                                    int n_steps, const tds_hip_rings_t *rings);
+int tds_hip_step_many_rings_blocks(const tds_hip_sim_t *sim);
 int tds_hip_step_many_tune(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int probe_steps,
                            void *obs_dev, int *chains);
 
@@ -477,12 +509,29 @@ int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const 
    step — the eager form is host-bound at ~20 us per step.  actions_dev [action_blocks][n_local][action_dim], step k
    uses block (first_block + k) % action_blocks.  n_steps: a multiple of the exchange block, <= 4096.  Collective:
    every rank makes the same call.  Falls back to eager stepping if the capture is refused (TDS_HIP_SHARD_NO_GRAPH=1
-   forces that), and steps eagerly when auto-reset is on (the refill passes of the reset pool are host-driven). */
+   forces that), and steps eagerly when auto-reset is on (the refill passes of the reset pool are host-driven).
+
+   RING EXCHANGE.  Where tds_hip_step_many_is_loop holds for the shard's simulation (and the exchange block is 1) the
+   n_steps steps are step-loop launches of up to 64 steps — the very launches of tds_hip_step_many_rings, with the obs
+   ring in the wire dtype and a y ring, i.e. the same work per step as a single GPU does — and the communication stream
+   sends ring slot k as soon as the running launch has counted all its workgroups in for step k (a device counter the
+   stream polls with a one-lane kernel): one ncclAllGather per policy step, no host call per step, no kernel boundary
+   per step.  Each launch + its exchanges is one hipGraph (cached by arguments).  tds_hip_shard_gathered then returns the
+   slot of the last step, [world][n_local][obs_dim + 2].  TDS_HIP_SHARD_RING=0 forces the per-step-launch form. */
 int tds_hip_shard_step_many(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks, int first_block,
                             int n_steps);
 /* capture + instantiate the graph of the next tds_hip_shard_step_many with the same arguments; nothing executes */
 int tds_hip_shard_step_many_prepare(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks,
                                     int first_block, int n_steps);
+/* Introspection of the ring exchange's host arithmetic (no device needed; csrc/tds_shard_plan.h): the step-loop launches
+   ("chunks", up to 64 steps each) a tds_hip_shard_step_many call of n_steps steps is cut into after chunks_done earlier
+   chunks, 6 ints per chunk in out [6 * cap]: ring half | steps | first step of the call | action block of its first
+   step | ring slot of its first step | progress count the communication stream waits for before it sends that slot
+   (n_blocks workgroups per step; 0 = "the launch's completion").  Returns the number of chunks, -1 on bad arguments.
+   tds_hip_shard_gathered_offset: scalar offset of global environment e's record in a gathered block-1 slot. */
+int tds_hip_shard_ring_plan(long long chunks_done, int n_steps, int act_first, int act_blocks, int n_blocks, int *out,
+                            int cap);
+long long tds_hip_shard_gathered_offset(int global_env, int n_local, int width);
 /* Exchange a partially filled block, then wait (host) until every exchange in flight has completed. */
 int tds_hip_shard_flush(tds_hip_shard_t *shard);
 int tds_hip_shard_gathered(tds_hip_shard_t *shard, void *consumer_stream, void **records_dev, int *steps_in_block);

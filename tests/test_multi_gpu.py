@@ -326,9 +326,60 @@ def test_step_many_tune_picks_a_chain_count_and_keeps_the_records(built, monkeyp
 
 
 @pytest.mark.parametrize("with_rccl", [False, True])
-def test_shard_step_many_graph_equals_eager_exchange(with_rccl, built):
-    """the two-stream step + all-gather pattern captured into one hipGraph (RCCL all-gathers as graph nodes)"""
+@pytest.mark.parametrize("submit", ["graph", "eager"])
+@pytest.mark.parametrize("wire", ["f32", "f64"])
+def test_shard_ring_exchange_on_one_rank(with_rccl, submit, wire, built, monkeypatch):
+    """tds_hip_shard_step_many where the K steps are step-loop launches (the Ant): every step's [obs | reward | done]
+    record goes into a ring slot in the wire dtype and is all-gathered as soon as the running launch has counted its
+    workgroups in for that step.  Against the same launches without the exchange (tds_hip_step_many_rings): the gathered
+    records of the last step, the state and the y record, bit for bit; launches of 64 + 11 steps, then a replay."""
     torch = _torch()
+    if with_rccl and hip_backend.HipShard.rccl_version() == 0:
+        pytest.skip("librccl cannot be loaded on this machine")
+    if submit == "eager":
+        monkeypatch.setenv("TDS_HIP_SHARD_NO_GRAPH", "1")
+    m = tds_amd.load_model("ant")
+    n = 1000
+    x, acts = _start(m, n, seed=41)
+    a = torch.from_numpy(acts).cuda().contiguous()
+    uid = hip_backend.HipShard.unique_id() if with_rccl else None
+    sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype=wire)
+    ref = hip_backend.HipSim(m, n)
+    for s in (sh.sim, ref):
+        s.x.copy_(torch.from_numpy(x).cuda())
+    K = 75
+    wdt = torch.float32 if wire == "f32" else torch.float64
+    ring = torch.zeros((K, n, ref.obs_dim + 2), dtype=wdt, device="cuda")
+    assert sh.sim.step_many_is_loop(K)
+    for rep in range(3):
+        if rep == 0:
+            sh.step_many(a, K, first_block=1, prepare_only=True)
+            assert torch.equal(sh.sim.x, torch.from_numpy(x).cuda())
+        sh.step_many(a, K, first_block=1)
+        got = sh.gathered().clone()
+        ref.step_many_rings(a, K, ring, None, first_block=1)
+        sh.flush()
+        torch.cuda.synchronize()
+        assert tuple(got.shape) == (1, 1, n, ref.obs_dim + 2) and got.dtype == wdt
+        assert torch.equal(got[0, 0].view(torch.int32 if wire == "f32" else torch.int64),
+                           ring[-1].view(torch.int32 if wire == "f32" else torch.int64)), rep
+        assert torch.equal(sh.sim.x.view(torch.int64), ref.x.view(torch.int64)), rep
+        assert torch.equal(sh.sim.y.view(torch.int64), ref.y.view(torch.int64)), rep
+    # single eager steps afterwards use the per-step exchange and continue from the same state
+    o = torch.zeros((n, ref.obs_dim + 2), dtype=torch.float64, device="cuda")
+    sh.step(a[0])
+    ref.step(a[0], 1, o)
+    assert torch.equal(sh.gathered()[0, 0].view(torch.int32 if wire == "f32" else torch.int64),
+                       o.to(wdt).view(torch.int32 if wire == "f32" else torch.int64))
+    sh.close()
+
+
+@pytest.mark.parametrize("with_rccl", [False, True])
+def test_shard_step_many_graph_equals_eager_exchange(with_rccl, built, monkeypatch):
+    """the two-stream step + all-gather pattern captured into one hipGraph (RCCL all-gathers as graph nodes): the
+    per-step-launch form (models whose K steps are not one step-loop launch; forced here for the Ant)"""
+    torch = _torch()
+    monkeypatch.setenv("TDS_HIP_SHARD_RING", "0")
     if with_rccl and hip_backend.HipShard.rccl_version() == 0:
         pytest.skip("librccl cannot be loaded on this machine")
     m = tds_amd.load_model("ant")

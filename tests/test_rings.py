@@ -1,0 +1,235 @@
+"""Per-step record rings of the fast launch form (tds_hip_step_many_rings, include/tds_hip.h).
+
+The reference hands out obs / reward / done (and the graphics state y) on EVERY step
+(/root/reference/examples/ars/ars_vectorized_environment.h:240-289,
+ examples/environments/locomotion_contact_simulation.h:273-303).  The step-loop launch keeps the state in LDS across its
+steps; with rings it packs and stores the records of every step.  These tests pin the ring slots
+  * on the REAL reference (oracle/_ref/libtds_ref.so) at BASELINE.json's full sizes, every slot of every environment;
+  * on single-step launches of the same library (every kernel kind, wrap-around rings, float wire format, auto-reset).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import tds_amd
+from tds_amd import hip_backend
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6  # BASELINE.json north_star: relative, per step
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch
+
+
+def _start_state(m, name, n, rng):
+    """reset-like states: the environment's own reset distribution"""
+    nq = m.dof_q
+    x0 = np.zeros((n, m.input_dim))
+    if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
+        ip = np.array([m.initial_poses[i] for i in range(m.action_dim)])
+        x0[:, 2] = 0.48
+        x0[:, 6:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
+        x0[:, -3:] = [15, 0.3, 3] if name.startswith("ant") else [100, 2, 50]
+    else:
+        x0[:, :nq] = rng.uniform(-1, 1, (n, nq))
+    return x0
+
+
+def _reward_done(m, name, q_before, y):
+    """compute_reward_done restated (ant_environment2.h:75-106, laikago_environment2.h:130-171)"""
+    nq = m.dof_q
+    q = y[:, :nq]
+    if m.reward_mode == tds_amd.TDS_REWARD_ANT:
+        done = q[:, 2] < 0.26
+        rew = np.where(done, 0.0, (q[:, 0] - q_before[:, 0]) / m.dt)
+    elif m.reward_mode == tds_amd.TDS_REWARD_LAIKAGO:
+        r, p = q[:, 3], q[:, 4]
+        # up_dot_world_z of quat_from_euler_rpy(roll, pitch, yaw): cos(roll) cos(pitch)
+        up = np.cos(r) * np.cos(p)
+        done = (up < 0.6) | (q[:, 2] < 0.2)
+        rew = np.where(done, 0.0, q[:, 0])
+    else:
+        done = np.zeros(len(q), bool)
+        rew = np.zeros(len(q))
+    return rew, done
+
+
+@pytest.mark.parametrize("name,n,steps,dtype", [("ant", 4096, 20, "f64"), ("pendulum5", 4096, 20, "f64"),
+                                                ("pendulum5", 4096, 20, "mixed"), ("laikago_soft", 8192, 50, "f64")])
+def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtype, built):
+    """BASELINE configs 3 / 2 / 4 at full size through the launch form bench.py times: K steps per call with both
+    rings on; EVERY slot of EVERY environment against the reference's own step started from the state the previous
+    slot holds (per-step resync costs nothing here: the y ring IS the trajectory)."""
+    torch = _torch()
+    from test_hip_parity import _reference_stepper
+
+    m = tds_amd.load_model(name)
+    ref_step, what = _reference_stepper(name, n)
+    rng = np.random.default_rng(77)
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    sim = hip_backend.HipSim(m, n, dtype=dtype)
+    tdt = sim.torch_dtype
+    x0 = _start_state(m, name, n, rng)
+    sim.x.copy_(torch.from_numpy(x0).to(tdt).cuda())
+    for _ in range(10):
+        sim.step(None)
+    amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 1.0
+    act = rng.uniform(-amp, amp, (steps, n, adim))
+    actions = torch.from_numpy(act).to(tdt).cuda().contiguous()
+    obs_ring = torch.full((steps, n, sim.obs_dim + 2), float("nan"), dtype=tdt, device="cuda")
+    y_ring = torch.full((steps, n, m.output_dim), float("nan"), dtype=tdt, device="cuda")
+    x_start = sim.x.cpu().numpy().astype(np.float64)
+    sim.step_many_rings(actions, steps, obs_ring, y_ring)
+    torch.cuda.synchronize()
+    yr = y_ring.cpu().numpy().astype(np.float64)
+    orr = obs_ring.cpu().numpy().astype(np.float64)
+    assert np.isfinite(yr).all() and np.isfinite(orr).all()
+    assert torch.equal(sim.y, y_ring[-1])  # the handle's y record = the last step's
+    tol = TOL if dtype == "f64" else 2e-6  # (float records: the comparison sees the rounding of inputs and outputs)
+    worst = 0.0
+    x = x_start.copy()
+    for k in range(steps):
+        a = actions[k].cpu().numpy().astype(np.float64)
+        x[:, nq + nd:nq + nd + adim] = a
+        y_ref = ref_step(x)
+        assert np.isfinite(y_ref).all()
+        e = rel_err(yr[k], y_ref, floor=1e-3)
+        worst = max(worst, e)
+        assert e < tol, (name, k, e)
+        # the [obs | reward | done] record of the step
+        rew, done = _reward_done(m, name, x[:, :nq], y_ref)
+        ob = y_ref[:, :nq + nd].copy()
+        ob[:, :2] = 0.0
+        assert rel_err(orr[k][:, :nq + nd], ob) < tol, (name, k)
+        if m.reward_mode != tds_amd.TDS_REWARD_NONE:
+            # (an environment within round-off of a termination threshold may fall on either side)
+            edge = np.zeros(n, bool)
+            if m.reward_mode == tds_amd.TDS_REWARD_ANT:
+                edge = np.abs(y_ref[:, 2] - 0.26) < 1e-7
+            if m.reward_mode == tds_amd.TDS_REWARD_LAIKAGO:
+                edge = (np.abs(np.cos(y_ref[:, 3]) * np.cos(y_ref[:, 4]) - 0.6) < 1e-7) | (np.abs(y_ref[:, 2] - 0.2) < 1e-7)
+            assert (orr[k][~edge, -1] == done[~edge]).all(), (name, k)
+            assert rel_err(orr[k][~edge, -2], rew[~edge], floor=1.0) < 10 * tol, (name, k)
+        # resync on the device's own record (its state is what the next step started from)
+        x[:, :nq + nd] = yr[k][:, :nq + nd]
+    print(f"{name} x{n} [{dtype}], {steps} ring slots, every env, vs {what}: worst per-step rel err {worst:.3e} "
+          f"(loop form: {sim.step_many_is_loop(steps)})")
+
+
+RING_MODELS = ["ant", "laikago", "laikago_soft", "pendulum5", "cartpole_plane", "ant_floating", "laikago_floating_env",
+               "humanoid", "pendulum5_spherical", "two_pendulums_plane"]
+
+
+@pytest.mark.parametrize("name", RING_MODELS)
+@pytest.mark.parametrize("dtype", ["f64", "mixed"])
+def test_ring_slots_equal_single_step_records(name, dtype, built):
+    """every kernel kind, both forms (step-loop launch / chained graphs): slot k == what the k-th single-step launch
+    of tds_hip_step_obs leaves in y and in its obs record; rings shorter than the call wrap around."""
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    n, steps, slots = 50, 12, 5
+    rng = np.random.default_rng(5)
+    x = g["x"][rng.integers(0, g["x"].shape[0], n)]
+    adim = m.action_dim
+    sims = [hip_backend.HipSim(m, n, dtype=dtype) for _ in range(2)]
+    tdt = sims[0].torch_dtype
+    for s in sims:
+        s.x.copy_(torch.from_numpy(x).to(tdt).cuda())
+    amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.5
+    actions = torch.from_numpy(rng.uniform(-amp, amp, (4, n, adim))).to(tdt).cuda().contiguous()
+    obs_ring = torch.zeros((slots, n, sims[0].obs_dim + 2), dtype=tdt, device="cuda")
+    y_ring = torch.zeros((steps, n, m.output_dim), dtype=tdt, device="cuda")
+    sims[0].step_many_rings(actions, steps, obs_ring, y_ring, first_block=1, obs_first=3)
+    obs = torch.zeros((n, sims[1].obs_dim + 2), dtype=tdt, device="cuda")
+    loop = sims[0].step_many_is_loop(steps)
+    # graph form: the very same kernels -> bitwise.  Step-loop launch: another compilation of the step (f64: agreement to
+    # round-off, resynchronised every step); with float records it also keeps the state in double across its steps where
+    # single steps round it to float once per step (tds_hip.h) — only the first step is comparable there.
+    def same(a, b, k):
+        if not loop:
+            assert torch.equal(a, b), (name, k)
+        elif dtype == "f64":
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-7, (name, k)
+        elif k == 0:
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6, (name, k)
+        else:
+            assert torch.isfinite(a).all(), (name, k)
+
+    nqd = sims[0].obs_dim
+    for k in range(steps):
+        sims[1].step(actions[(1 + k) % 4], 1, obs)
+        yk, ok = y_ring[k], obs_ring[(3 + k) % slots]
+        if k >= steps - slots:  # (earlier slots of the short ring have been overwritten)
+            same(ok, obs, k)
+        same(yk, sims[1].y, k)
+        if loop and dtype == "f64":  # per-step resync on the ring's own trajectory
+            sims[1].x[:, :nqd] = yk[:, :nqd]
+    if not loop:
+        assert torch.equal(sims[0].x, sims[1].x)
+    assert torch.equal(sims[0].y, y_ring[-1])
+
+
+@pytest.mark.parametrize("name", ["ant", "pendulum5"])
+def test_float_obs_ring_beside_double_records_and_the_progress_counter(name, built):
+    """the wire format of the multi-GPU exchange: a float obs ring written by the step-loop launch of an f64 handle, and
+    the progress counter the exchange polls (one increment per workgroup and completed step, the last step excepted)"""
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    n, steps = 203, 9
+    rng = np.random.default_rng(6)
+    x = g["x"][rng.integers(0, g["x"].shape[0], n)]
+    sim = hip_backend.HipSim(m, n, dtype="f64")
+    if not sim.step_many_is_loop(steps):
+        pytest.skip("graph form")
+    sim2 = hip_backend.HipSim(m, n, dtype="f64")
+    for s in (sim, sim2):
+        s.x.copy_(torch.from_numpy(x).cuda())
+    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (3, n, m.action_dim))).cuda().contiguous()
+    ring32 = torch.zeros((steps, n, sim.obs_dim + 2), dtype=torch.float32, device="cuda")
+    ring64 = torch.zeros((steps, n, sim.obs_dim + 2), dtype=torch.float64, device="cuda")
+    progress = torch.zeros(1, dtype=torch.int64, device="cuda")
+    sim.step_many_rings(actions, steps, ring32, None, progress=progress)
+    sim2.step_many_rings(actions, steps, ring64, None)
+    torch.cuda.synchronize()
+    assert torch.equal(ring32, ring64.to(torch.float32))
+    assert int(progress.item()) == (steps - 1) * sim.rings_blocks()
+    assert torch.equal(sim.x, sim2.x)
+
+
+@pytest.mark.parametrize("name", ["ant", "laikago"])
+def test_rings_with_auto_reset(name, built):
+    """auto_reset_when_done inside the ring form: slot k carries reward / done of the step that ended and the
+    observation of the fresh environment (ars_vectorized_environment.h:262-289) — identical to single auto-reset steps"""
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    n, steps = 256, 40
+    rng = np.random.default_rng(8)
+    x0 = _start_state(m, name, n, rng)
+    x0[: n // 2, 2] = 0.27 if name == "ant" else 0.25  # half of them about to end
+    sims = [hip_backend.HipSim(m, n, dtype="f64") for _ in range(2)]
+    for s in sims:
+        s.x.copy_(torch.from_numpy(x0).cuda())
+        s.set_auto_reset(True, 11)
+    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (8, n, m.action_dim))).cuda().contiguous()
+    obs_ring = torch.zeros((steps, n, sims[0].obs_dim + 2), dtype=torch.float64, device="cuda")
+    y_ring = torch.zeros((steps, n, m.output_dim), dtype=torch.float64, device="cuda")
+    sims[0].step_many_rings(actions, steps, obs_ring, y_ring)
+    obs = torch.zeros((n, sims[1].obs_dim + 2), dtype=torch.float64, device="cuda")
+    dones = 0
+    for k in range(steps):
+        sims[1].step(actions[k % 8], 1, obs)
+        # (step-loop launches and single steps are two compilations of the step: agreement to round-off)
+        assert rel_err(obs_ring[k].cpu().numpy(), obs.cpu().numpy()) < TOL, (name, k)
+        assert rel_err(y_ring[k].cpu().numpy(), sims[1].y.cpu().numpy()) < TOL, (name, k)
+        dones += int((obs[:, -1] != 0).sum().item())
+    assert dones >= n // 4
+    assert rel_err(sims[0].x.cpu().numpy(), sims[1].x.cpu().numpy()) < TOL

@@ -1,0 +1,127 @@
+"""The C shard layer (tds_hip_shard_*, csrc/tds_shard.hip) with TWO RANKS — two processes on the ONE GPU of the test box.
+
+The real RCCL refuses two ranks on one device, so the exchange goes through tests/stub_rccl (a stream-ordered
+all-gather over POSIX shared memory, loaded through TDS_HIP_RCCL_LIB: the shard layer resolves every nccl* symbol with
+dlsym).  Everything else is the product path: rendezvous by unique id, contiguous shards, the ring exchange driven by
+the step-loop launch's progress counter (graph and eager), the per-step-launch form, single eager steps.  What is
+checked: every rank ends up with BOTH shards' records of the last step in global environment order, equal to what each
+shard computes on its own.  (The reference has no multi-device path: SURVEY 8e.)
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+rank, world, mode, name, n_local, steps, idhex, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), sys.argv[7], sys.argv[8]
+sys.path.insert(0, os.environ["TDS_ROOT"])
+import torch
+import tds_amd
+from tds_amd import hip_backend
+m = tds_amd.load_model(name)
+assert hip_backend.HipShard.rccl_version() == 99999, "the stub must be the loaded librccl"
+g = np.load(os.path.join(os.environ["TDS_ROOT"], "tests", "golden", name + ".npz"))
+rng = np.random.default_rng(1234)
+idx = rng.integers(0, g["x"].shape[0], world * n_local)
+xg = g["x"][idx]                                   # the GLOBAL batch, the same on every rank
+ag = rng.uniform(-0.4, 0.4, (4, world * n_local, m.action_dim))
+lo, hi = rank * n_local, (rank + 1) * n_local
+sh = hip_backend.HipShard(m, world * n_local, rank=rank, world=world, device=0, dtype="f64",
+                          unique_id=bytes.fromhex(idhex), wire_dtype="f32")
+sim = sh.sim
+sim.x.copy_(torch.from_numpy(xg[lo:hi]).cuda())
+acts = torch.from_numpy(ag[:, lo:hi]).cuda().contiguous()
+if mode == "single":
+    for k in range(steps):
+        sh.step(acts[k % 4], 1)
+else:
+    done = 0
+    for c in (steps - steps // 3, steps // 3):     # two calls: graphs for two shapes, ring halves carried over
+        if c:
+            sh.step_many(acts, c, first_block=done % 4)
+            done += c
+gat = sh.gathered().clone()
+sh.flush()
+torch.cuda.synchronize()
+# what this shard computes on its own: the same steps on a plain handle
+ref = hip_backend.HipSim(m, n_local, dtype="f64")
+ref.x.copy_(torch.from_numpy(xg[lo:hi]).cuda())
+obs = torch.zeros((n_local, ref.obs_dim + 2), dtype=torch.float64, device="cuda")
+if mode == "single" or not ref.step_many_is_loop(steps) or os.environ.get("TDS_HIP_SHARD_RING") == "0":
+    for k in range(steps):
+        ref.step(acts[k % 4], 1, obs)
+else:
+    ring = torch.zeros((steps, n_local, ref.obs_dim + 2), dtype=torch.float64, device="cuda")
+    ref.step_many_rings(acts, steps, ring, None)
+    obs = ring[-1]
+torch.cuda.synchronize()
+np.savez(out, gathered=gat.cpu().numpy(), local=obs.to(torch.float32).cpu().numpy(), x=sim.x.cpu().numpy(), xref=ref.x.cpu().numpy())
+sh.close()
+'''
+
+
+def _stub(tmp_path_factory):
+    d = tmp_path_factory.mktemp("stub_rccl")
+    so = os.path.join(str(d), "libstub_rccl.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-o", so, os.path.join(ROOT, "tests", "stub_rccl", "stub_rccl.cpp"), "-L/opt/rocm/lib",
+                           "-lamdhip64", "-lrt", "-lpthread"])
+    return so
+
+
+@pytest.fixture(scope="module")
+def stub_lib(tmp_path_factory):
+    return _stub(tmp_path_factory)
+
+
+@pytest.mark.parametrize("mode,name,steps,env", [
+    ("many", "ant", 75, {}),                                   # ring exchange, one hipGraph per step-loop launch
+    ("many", "ant", 75, {"TDS_HIP_SHARD_NO_GRAPH": "1"}),      # ring exchange submitted eagerly
+    ("many", "pendulum5", 30, {}),                             # a world without contacts (always the step-loop form)
+    ("many", "ant", 12, {"TDS_HIP_SHARD_RING": "0"}),          # per-step launches + exchanges from one hipGraph
+    ("many", "laikago", 9, {}),                                # a model whose step_many is not the step-loop form
+    ("single", "ant", 7, {}),                                  # tds_hip_shard_step, one call per step
+])
+def test_two_ranks_on_one_gpu(mode, name, steps, env, built, stub_lib, tmp_path):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world, n_local = 2, 200
+    ident = ("/tds_stub_%d_%s_%d" % (os.getpid(), name, steps)).encode().ljust(128, b"\0")
+    e = dict(os.environ)
+    e.update(env)
+    e["TDS_HIP_RCCL_LIB"] = stub_lib
+    e["TDS_ROOT"] = ROOT
+    e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, "-c", WORKER, str(r), str(world), mode, name, str(n_local), str(steps),
+                               ident.hex(), outs[r]], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace")[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
+    r = [np.load(o) for o in outs]
+    w = r[0]["local"].shape[1]
+    want = np.concatenate([r[0]["local"], r[1]["local"]])  # global environment order = rank order
+    for k in range(world):
+        got = r[k]["gathered"].reshape(-1, w)
+        assert got.shape == want.shape
+        # the records crossed "the wire" as floats; ring form and its reference come from the same step-loop build, the
+        # per-step forms from the same straight-line build: equal bit for bit
+        assert np.array_equal(got, want), (k, np.abs(got - want).max())
+        assert np.array_equal(r[k]["x"], r[k]["xref"])

@@ -103,7 +103,7 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   const int n_resident = (opts && opts->env_total > 0) ? opts->env_total : n;
   const int n_blocks = (n_resident + (64 / s->lanes) - 1) / (64 / s->lanes);
   const bool two_waves = s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && nsub == 1 &&
-                         reset_mode == TDS_RESET_NONE && !ro && !(opts && opts->lds);
+                         reset_mode == TDS_RESET_NONE && !ro && !(opts && opts->lds) && !(opts && opts->rings);
   const TdsLds &lds = (opts && opts->lds) ? *opts->lds : (two_waves ? s->lds_w2 : s->lds);
   void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
   if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along
@@ -131,6 +131,24 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     ctl.act_blocks = opts->act_blocks;
     ctl.act_first = opts->act_first;
     ctl.act_envs = s->num_envs;
+  }
+  if (opts && opts->rings) {  // (step-loop launches: the caller made sure of that)
+    const tds_hip_rings_t &r = *opts->rings;
+    const size_t e0 = (size_t)opts->env_first;
+    if (r.obs_ring) {
+      const size_t ob = r.obs_f32 ? 4 : s->elem;
+      ctl.obs_ring = (char *)r.obs_ring + e0 * s->obs_width() * ob;
+      ctl.obs_slots = r.obs_slots;
+      ctl.obs_first = (r.obs_first + opts->ring_step0) % r.obs_slots;
+      if (r.obs_f32) ctl.ring_flags |= TDS_RING_OBS_F32;
+    }
+    if (r.y_ring) {
+      ctl.y_ring = (char *)r.y_ring + e0 * s->model.output_dim * s->elem;
+      ctl.y_slots = r.y_slots;
+      ctl.y_first = (r.y_first + opts->ring_step0) % r.y_slots;
+    }
+    ctl.ring_envs = s->num_envs;
+    ctl.progress = r.progress;
   }
   ctl.flags |= ctl_flags;
   ctl.nsub = nsub;
@@ -668,7 +686,7 @@ int pool_fill(tds_hip_sim *s) {
 }
 
 // one auto-reset step through the pool
-int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev) {
+int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev, void *y_dev = nullptr) {
   int rc;
   if (s->pool_many) {  // (the step_many form keeps its own pass schedule: start again from full rings)
     s->pool_many = false;
@@ -704,8 +722,8 @@ int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev) {
   extra.pool_envs = s->num_envs;
   LaunchOpts o;
   o.extra = &extra;
-  rc = launch(s, s->d_x, s->d_y, actions_dev, s->d_x, obs_dev ? obs_dev : s->d_split, s->num_envs, 1, TDS_RESET_NONE,
-              nullptr, nullptr, 0, &o);
+  rc = launch(s, s->d_x, y_dev ? y_dev : s->d_y, actions_dev, s->d_x, obs_dev ? obs_dev : s->d_split, s->num_envs, 1,
+              TDS_RESET_NONE, nullptr, nullptr, 0, &o);
   if (rc != TDS_OK) return rc;
   if (t % R == 0) {  // pass t / R: plan now, launch when its size is known
     rc = pool_plan(s);
@@ -730,7 +748,8 @@ int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev) {
 // resets for R = 16 / 32 / 96 (the refill launches run beside the chunk in the SIMDs' second wavefront slots), x 8192
 // 0.52 / 0.59 / 0.67 (a chunk holds every CU's LDS: the refill runs between chunks); 0.93 ... 0.99 without resets.
 // The settle steps of a pass as ONE step-loop launch (TDS_HIP_POOL_SETTLE_LOOP=1) are no gain: x 4096 0.74, x 8192 0.67.
-int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int act_first, int n_steps, void *obs_dev) {
+int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int act_first, int n_steps, void *obs_dev,
+                   const tds_hip_rings_t *rings = nullptr) {
   int rc;
   if (!s->pool_many) {
     s->pool_many = true;
@@ -773,6 +792,8 @@ int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int 
     if (pass) TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->pool_sync_ev, 0));
     LaunchOpts o;
     o.extra = &extra;
+    o.rings = rings;
+    o.ring_step0 = done;
     const void *a0 = nullptr;
     if (actions_dev) {
       const int first = (act_first + done) % act_blocks;
@@ -871,9 +892,17 @@ int tds_hip_step_obs(tds_hip_sim_t *s, const void *actions_dev, int substeps, vo
 // launches: at ~20 us per step the host-side launch gaps are otherwise a double-digit share of short runs).
 extern "C++" {
 namespace {
-int graph_matches(const tds_hip_sim *s, const void *actions, int pool, int first, int n_steps, void *obs) {
+int graph_matches(const tds_hip_sim *s, const void *actions, int pool, int first, int n_steps, void *obs,
+                  const tds_hip_rings_t *rings = nullptr) {
+  tds_hip_rings_t none;
+  memset(&none, 0, sizeof(none));
   return s->graph_exec[0] && s->graph_actions == actions && s->graph_pool == pool && s->graph_first == first &&
-         s->graph_steps == n_steps && s->graph_obs == obs;
+         s->graph_steps == n_steps && s->graph_obs == obs &&
+         memcmp(&s->graph_rings, rings ? rings : &none, sizeof(none)) == 0;
+}
+// slot of a record ring that step k of a call owns
+void *ring_slot(const tds_hip_sim *s, void *ring, int slots, int first, int k, size_t scalars_per_env) {
+  return ring ? (char *)ring + (size_t)((first + k) % slots) * s->num_envs * scalars_per_env * s->elem : nullptr;
 }
 // The environments are independent and a step_many call holds K steps of each: enqueue them as C chains (contiguous
 // environment ranges, one stream / graph branch each) instead of K whole-batch launches.  A chain's kernel boundary
@@ -900,7 +929,7 @@ int chain_streams(tds_hip_sim *s, int n_chains) {
 }
 // K steps of chain c of C on `stream`
 int enqueue_chain(tds_hip_sim *s, int c, int C, hipStream_t stream, const void *actions, int pool, int first, int n_steps,
-                  void *obs) {
+                  void *obs, const tds_hip_rings_t *rings = nullptr) {
   const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
   const int epb = 64 / s->lanes, n_blocks = (s->num_envs + epb - 1) / epb;
   const int b0 = (int)((long long)n_blocks * c / C), b1 = (int)((long long)n_blocks * (c + 1) / C);
@@ -913,7 +942,10 @@ int enqueue_chain(tds_hip_sim *s, int c, int C, hipStream_t stream, const void *
   lo.stream = stream;
   for (int k = 0; k < n_steps; ++k) {
     const void *a = actions ? (const char *)actions + (size_t)((first + k) % pool) * blk : nullptr;
-    const int rc = launch(s, s->d_x, s->d_y, a, s->d_x, obs, e1 - e0, 1, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
+    // (record rings: every launch is pointed at the slots of its step)
+    void *const ob = (rings && rings->obs_ring) ? ring_slot(s, rings->obs_ring, rings->obs_slots, rings->obs_first, k, s->obs_width()) : obs;
+    void *const yk = (rings && rings->y_ring) ? ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, k, s->model.output_dim) : s->d_y;
+    const int rc = launch(s, s->d_x, yk, a, s->d_x, ob, e1 - e0, 1, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
     if (rc != TDS_OK) return rc;
   }
   return TDS_OK;
@@ -929,7 +961,8 @@ void drop_graphs(tds_hip_sim *s) {
 
 // one LINEAR graph per chain (a single graph with parallel branches costs ~2 us more per step than the same chains
 // as independent launches, tools/ubench/two_streams.hip; linear graphs replay at the single-stream rate)
-int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_steps, void *obs) {
+int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_steps, void *obs,
+                const tds_hip_rings_t *rings = nullptr) {
   drop_graphs(s);
   if (!s->graph_stream) HIP_TRY(hipStreamCreateWithFlags(&s->graph_stream, hipStreamNonBlocking));
   const int n_chains = chain_count(s, n_steps);
@@ -941,7 +974,7 @@ int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamBeginCapture(s->graph_stream, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
-      rc = enqueue_chain(s, c, n_chains, s->graph_stream, actions, pool, first, n_steps, obs);
+      rc = enqueue_chain(s, c, n_chains, s->graph_stream, actions, pool, first, n_steps, obs, rings);
       e = hipStreamEndCapture(s->graph_stream, &graph);
     }
     if (e == hipSuccess && rc == TDS_OK && graph) e = hipGraphInstantiate(&s->graph_exec[c], graph, nullptr, nullptr, 0);
@@ -962,6 +995,7 @@ int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_
   s->graph_steps = n_steps;
   s->graph_obs = obs;
   s->graph_chains = n_chains;
+  if (rings) s->graph_rings = *rings; else memset(&s->graph_rings, 0, sizeof(s->graph_rings));
   return TDS_OK;
 }
 }  // namespace
@@ -994,26 +1028,42 @@ bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
 }  // namespace
 }  // extern "C++"
 
-int tds_hip_step_many_prepare(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block,
-                              int n_steps, void *obs_dev) {
+extern "C++" {
+namespace {
+int rings_check(const tds_hip_sim *s, const tds_hip_rings_t *r, int n_steps) {
+  if (!r) return TDS_OK;
+  if (r->obs_ring && (r->obs_slots < 1 || r->obs_first < 0)) return fail(TDS_ERR_INVALID_ARG, "record rings: obs_slots must be >= 1, obs_first >= 0");
+  if (r->y_ring && (r->y_slots < 1 || r->y_first < 0)) return fail(TDS_ERR_INVALID_ARG, "record rings: y_slots must be >= 1, y_first >= 0");
+  const bool loop = step_many_as_loop(s, n_steps) || (n_steps == 1 && step_many_as_loop(s, 2));
+  if (r->progress && !loop) return fail(TDS_ERR_INVALID_ARG, "record rings: a progress counter needs the step-loop form (tds_hip_step_many_is_loop)");
+  if (r->obs_f32 && s->elem == 8 && !loop)
+    return fail(TDS_ERR_INVALID_ARG, "record rings: a float obs ring beside f64 records needs the step-loop form (tds_hip_step_many_is_loop)");
+  return TDS_OK;
+}
+
+int step_many_prepare_impl(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block, int n_steps,
+                           void *obs_dev, const tds_hip_rings_t *rings) {
   if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
   if (n_steps < 1 || n_steps > 4096) return fail(TDS_ERR_INVALID_ARG, "n_steps must be in 1..4096");
   if (actions_dev && action_blocks < 1) return fail(TDS_ERR_INVALID_ARG, "action_blocks must be >= 1");
+  int rc = rings_check(s, rings, n_steps);
+  if (rc != TDS_OK) return rc;
   if (s->auto_reset) return TDS_OK;  // (step-loop launches through the reset pool, or single steps: nothing to build)
   DeviceGuard guard(s->device);
   const int pool = actions_dev ? action_blocks : 1;
   const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
-  if (step_many_as_loop(s, n_steps)) return TDS_OK;  // (one kernel launch: nothing to build)
-  if (graph_matches(s, actions_dev, pool, first, n_steps, obs_dev)) return TDS_OK;
-  return build_graph(s, actions_dev, pool, first, n_steps, obs_dev);
+  // (one kernel launch: nothing to build; with rings a single step is a step-loop launch too where the form exists)
+  if (step_many_as_loop(s, n_steps) || (rings && n_steps == 1 && step_many_as_loop(s, 2))) return TDS_OK;
+  if (graph_matches(s, actions_dev, pool, first, n_steps, obs_dev, rings)) return TDS_OK;
+  return build_graph(s, actions_dev, pool, first, n_steps, obs_dev, rings);
 }
 
-int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block, int n_steps,
-                      void *obs_dev) {
+int step_many_impl(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block, int n_steps,
+                   void *obs_dev, const tds_hip_rings_t *rings) {
   const char *em = getenv("TDS_HIP_STEP_MANY_EAGER");  // (diagnostic: the same chains as plain stream launches)
   const bool eager = em && em[0] == '1';
   if (!eager) {
-    int rc = tds_hip_step_many_prepare(s, actions_dev, action_blocks, first_block, n_steps, obs_dev);
+    int rc = step_many_prepare_impl(s, actions_dev, action_blocks, first_block, n_steps, obs_dev, rings);
     if (rc != TDS_OK) return rc;
   } else if (!s || n_steps < 1 || (actions_dev && action_blocks < 1)) {
     return fail(TDS_ERR_INVALID_ARG, "step_many: bad arguments");
@@ -1022,19 +1072,32 @@ int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_bloc
   TimedCall timed(s);
   const int pool = actions_dev ? action_blocks : 1;
   const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
+  const bool as_loop = !eager && (step_many_as_loop(s, n_steps) || (rings && n_steps == 1 && step_many_as_loop(s, 2)));
+  // the handle's y record holds the last step's record afterwards, rings or not
+  auto y_back = [&]() -> int {
+    if (rings && rings->y_ring)
+      HIP_TRY(hipMemcpyAsync(s->d_y, ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, n_steps - 1, s->model.output_dim),
+                             (size_t)s->num_envs * s->model.output_dim * s->elem, hipMemcpyDeviceToDevice, s->stream));
+    return TDS_OK;
+  };
   if (s->auto_reset) {
     // auto_reset_when_done after every step: step-loop launches that take the fresh states from the reset pool where
     // the plain call would be one step-loop launch (pool_step_many), else K single steps through the pool
-    if (!eager && step_many_as_loop(s, n_steps)) return pool_step_many(s, actions_dev, pool, first, n_steps, obs_dev);
+    if (as_loop) {
+      const int rc = pool_step_many(s, actions_dev, pool, first, n_steps, obs_dev, rings);
+      return rc != TDS_OK ? rc : y_back();
+    }
     const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
     for (int k = 0; k < n_steps; ++k) {
       const void *a = actions_dev ? (const char *)actions_dev + (size_t)((first + k) % pool) * blk : nullptr;
-      const int rc = pool_step(s, a, obs_dev);
+      void *const ob = (rings && rings->obs_ring) ? ring_slot(s, rings->obs_ring, rings->obs_slots, rings->obs_first, k, s->obs_width()) : obs_dev;
+      void *const yk = (rings && rings->y_ring) ? ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, k, s->model.output_dim) : nullptr;
+      const int rc = pool_step(s, a, ob, yk);
       if (rc != TDS_OK) return rc;
     }
-    return TDS_OK;
+    return y_back();
   }
-  if (!eager && step_many_as_loop(s, n_steps)) {
+  if (as_loop) {
     LaunchOpts lo;
     const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
     const void *a0 = actions_dev ? (const char *)actions_dev + (size_t)first * blk : nullptr;
@@ -1043,7 +1106,10 @@ int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_bloc
       lo.act_blocks = pool;
       lo.act_first = first;
     }
-    return launch(s, s->d_x, s->d_y, a0, s->d_x, obs_dev, s->num_envs, n_steps, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
+    lo.rings = rings;
+    // (a single step with rings is a step-loop launch too: the launcher picks that build whenever a ring is set)
+    const int rc = launch(s, s->d_x, s->d_y, a0, s->d_x, obs_dev, s->num_envs, n_steps, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
+    return rc != TDS_OK ? rc : y_back();
   }
   const int C = eager ? chain_count(s, n_steps) : s->graph_chains;
   if (eager) {
@@ -1058,7 +1124,14 @@ int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_bloc
   if (eager) {
     for (int k = 0; k < n_steps; ++k)  // (step by step, so that every stream has work from the start)
       for (int c = 0; c < C; ++c) {
-        const int rc = enqueue_chain(s, c, C, c ? s->graph_chain[c - 1] : s->stream, actions_dev, pool, first + k, 1, obs_dev);
+        tds_hip_rings_t rk;
+        if (rings) {
+          rk = *rings;
+          rk.obs_first = rings->obs_ring ? (rings->obs_first + k) % rings->obs_slots : 0;
+          rk.y_first = rings->y_ring ? (rings->y_first + k) % rings->y_slots : 0;
+        }
+        const int rc = enqueue_chain(s, c, C, c ? s->graph_chain[c - 1] : s->stream, actions_dev, pool, first + k, 1, obs_dev,
+                                     rings ? &rk : nullptr);
         if (rc != TDS_OK) return rc;
       }
   } else {
@@ -1068,7 +1141,35 @@ int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_bloc
     HIP_TRY(hipEventRecord(s->graph_join[c - 1], s->graph_chain[c - 1]));
     HIP_TRY(hipStreamWaitEvent(s->stream, s->graph_join[c - 1], 0));
   }
-  return TDS_OK;
+  return y_back();
+}
+}  // namespace
+}  // extern "C++"
+
+int tds_hip_step_many_prepare(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block,
+                              int n_steps, void *obs_dev) {
+  return step_many_prepare_impl(s, actions_dev, action_blocks, first_block, n_steps, obs_dev, nullptr);
+}
+
+int tds_hip_step_many(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block, int n_steps,
+                      void *obs_dev) {
+  return step_many_impl(s, actions_dev, action_blocks, first_block, n_steps, obs_dev, nullptr);
+}
+
+int tds_hip_step_many_rings_prepare(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block,
+                                    int n_steps, const tds_hip_rings_t *rings) {
+  if (!rings || (!rings->obs_ring && !rings->y_ring)) return fail(TDS_ERR_INVALID_ARG, "record rings: no ring given");
+  return step_many_prepare_impl(s, actions_dev, action_blocks, first_block, n_steps, nullptr, rings);
+}
+
+int tds_hip_step_many_rings(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block, int n_steps,
+                            const tds_hip_rings_t *rings) {
+  if (!rings || (!rings->obs_ring && !rings->y_ring)) return fail(TDS_ERR_INVALID_ARG, "record rings: no ring given");
+  return step_many_impl(s, actions_dev, action_blocks, first_block, n_steps, nullptr, rings);
+}
+
+int tds_hip_step_many_rings_blocks(const tds_hip_sim_t *s) {
+  return s ? (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes) : 0;
 }
 
 int tds_hip_step_many_is_loop(const tds_hip_sim_t *s, int n_steps) { return s && step_many_as_loop(s, n_steps) ? 1 : 0; }

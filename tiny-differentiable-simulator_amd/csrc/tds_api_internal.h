@@ -56,6 +56,7 @@ struct tds_hip_sim {
   const void *graph_actions = nullptr;
   void *graph_obs = nullptr;
   int graph_pool = 0, graph_steps = 0, graph_first = 0;
+  tds_hip_rings_t graph_rings = {};  // record rings the cached graphs write into (all-zero: none)
   hipStream_t graph_stream = nullptr;
   // the graph's environment chains (see build_graph): chain c > 0 is captured on graph_chain[c - 1]
   static constexpr int kMaxChains = 8;
@@ -115,6 +116,10 @@ struct LaunchOpts {
   int act_blocks = 0, act_first = 0;
   int env_first = 0;                  // this launch serves environments [env_first, env_first + n) of the records
   int env_total = 0;                  // (> 0: environments of ALL launches resident at the same time, for the form choice)
+  // step-loop launch with per-step record rings (TdsStepCtl::obs_ring / y_ring / progress); ring_step0: steps of the
+  // call that lie before this launch (the launch's step k owns slot (first + ring_step0 + k) % slots)
+  const tds_hip_rings_t *rings = nullptr;
+  int ring_step0 = 0;
 };
 
 // enqueue one launch of the step kernel on the handle's stream (device already selected by the caller)

@@ -54,7 +54,23 @@ struct TdsStepCtl {
   int flags;                  // bit 0: the first step observes the raw base x, y (state fresh from reset())
                               // TDS_CTL_RESET_CALL: the launch is tds_hip_reset (the environment's own reset():
                               // its observation keeps the base x, y where the model says so), not an auto-reset
+  // step-loop launches only: per-step RECORD RINGS (tds_hip_step_many_rings).  With a ring set, EVERY step of the launch
+  // does the whole output work of step_forward_original + VectorizedEnvironment::step — visual poses, y record,
+  // reward / done, observation (locomotion_contact_simulation.h:273-303, ars_vectorized_environment.h:240-289) — and
+  // stores it into the step's ring slot; step k of the launch owns slot (first + k) % slots.
+  void *obs_ring;             // != NULL: [obs_slots][ring_envs][dof_q + dof_qd + 2]  obs | reward | done
+  void *y_ring;               // != NULL: [y_slots][ring_envs][output_dim]
+  int obs_slots, obs_first;
+  int y_slots, y_first;
+  int ring_envs;              // environments per ring slot (= the batch the rings were laid out for)
+  int ring_flags;             // TDS_RING_OBS_F32: the obs ring holds floats whatever the record dtype (wire format of the
+                              // multi-GPU exchange: the slot is handed to ncclAllGather as it is)
+  // != NULL: every workgroup adds 1 once its records of step k are visible device-wide — signalled from inside step
+  // k + 1 (the stores have long drained by then: no wait on the step's own path), never for the last step of a launch
+  // (kernel completion covers it).  What a communication stream polls to send ring slot k while the launch carries on.
+  unsigned long long *progress;
 };
+#define TDS_RING_OBS_F32 1
 
 // na_cap: contacts whose rows stay in LDS (<= 0: all); w2: the layout of the two-wavefront workgroups (the LDS groups
 // that alias each other in the one-wave layout laid out one after the other, + hand-over slots)

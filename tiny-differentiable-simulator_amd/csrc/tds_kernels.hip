@@ -1141,6 +1141,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // auto-reset inside a replayed step loop: a done environment takes its next pre-settled state from the reset pool
   // (tds_api.hip: reset pool) and carries on with the following step — the lane groups of a launch stay in lock step
   const bool pool_r = LOOP && ctl.pool != nullptr && ctl.policy == nullptr;
+  // per-step record rings (tds_hip_step_many_rings): every step of the launch packs and stores its records
+  const bool ring_o = LOOP && ctl.obs_ring != nullptr;  // wave-uniform (kernel arguments)
+  const bool ring_y = LOOP && ctl.y_ring != nullptr;
   T next_act = T(0);
   T ret = T(0);
   int cnt = 0;
@@ -1361,7 +1364,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       TDS_WAVE_SYNC();
     }
   }
-  const bool do_reward = last_run || ((pol || pool_r) && mode == TDS_MODE_RUN);
+  const bool do_reward = last_run || ((pol || pool_r || ring_o) && mode == TDS_MODE_RUN);
+  // where this step's y record goes, and whether it is packed at all: the handle's y record for the last normal step
+  // of a launch, or — with a y ring — the ring slot of EVERY step
+  const bool pack_y = ring_y ? (valid && mode == TDS_MODE_RUN) : (last_run && y_out != nullptr);
+  TR *const y_step = ring_y ? (TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env) * out_dim
+                            : y_out + (size_t)env * out_dim;
   // ---- the phases that a two-wavefront workgroup hands to its helper wavefront, as closures (each derives the LDS
   //      addresses it needs itself: nothing is kept live for them across the phases in between)
   const int NCPp = L.NCPp;
@@ -1458,10 +1466,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     T *const Xw = E + L.Xw;
   // ---- M1. visual poses of y (they use the PRE-step X_world, locomotion_contact_simulation.h:281-299)
     {
-      TR *const yo = y_out + (size_t)env * out_dim;
+      TR *const yo = y_step;
       const int nv = pf_nv;
       const int vbase = nq + nd;
-      if (last_run && y_out != nullptr) {  // y describes the last normal step of the launch
+      if (pack_y) {  // y describes the last normal step of the launch (y ring: every step its own slot)
         for (int k = lane; k < nv; k += G) {
           const bool first = !LOOP && k == lane;  // wave-uniform: visual == lane was prefetched at kernel start
           int lk = pf_vis_link;
@@ -1722,8 +1730,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       }
       TDS_STAMP(3);
       phase_M1();
-      if (last_run && y_out != nullptr) {  // tail of the y record: up_dot_world_z, zero padding
-        TR *const yo = y_out + (size_t)env * out_dim;
+      if (pack_y) {  // tail of the y record: up_dot_world_z, zero padding
+        TR *const yo = y_step;
         int tail = nq + nd;
         if (mdl->pack_visuals) {
           tail += 7 * mdl->num_visuals;
@@ -2162,6 +2170,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   TDS_WAVE_SYNC();
 
   TDS_STAMP(3);
+  if constexpr (LOOP) {
+    // the ring records of the PREVIOUS step have long left this wavefront: make them visible device-wide and count
+    // this workgroup in (TdsStepCtl::progress; what the exchange of the multi-GPU layer polls, tds_shard.hip)
+    if (ctl.progress != nullptr && tds_iter > 0) {  // wave-uniform
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl.progress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   // ---- I. narrowphase right after the kinematics sweep (it only needs X_world), so that the
   //         LDS holding X_world / v can be recycled by the dynamics sweeps
   // ---- I + M1. narrowphase and visual poses right after the kinematics sweep (they only need X_world), so that the
@@ -2940,8 +2956,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   TDS_WAVE_SYNC();
 
   // ---- y record (q, qd, up, zero padding; the visual poses went out in M1) of the last normal step
-  if (last_run && y_out != nullptr) {
-    TR *const yo = y_out + (size_t)env * out_dim;
+  if (pack_y) {
+    TR *const yo = y_step;
     if (gen) {  // the q record is not one coordinate per lane: copy it out as it is
       for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)(xr[i]), &yo[i]);
     } else if (di >= 0) {
@@ -2999,6 +3015,18 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       TR *const ob = obs_out + (size_t)env * (nq + nd + 2);
       ob[nq + nd] = (TR)reward;
       ob[nq + nd + 1] = (done || frozen) ? TR(1) : TR(0);
+    }
+    if constexpr (LOOP) {
+      if (ring_o) {  // reward / done of THIS step into its ring slot (the observation follows at the end of the step)
+        const size_t at = ((size_t)((ctl.obs_first + tds_iter) % ctl.obs_slots) * ctl.ring_envs + env) * (nq + nd + 2) + nq + nd;
+        if (ctl.ring_flags & TDS_RING_OBS_F32) {
+          __builtin_nontemporal_store((float)reward, (float *)ctl.obs_ring + at);
+          __builtin_nontemporal_store(done ? 1.0f : 0.0f, (float *)ctl.obs_ring + at + 1);
+        } else {
+          __builtin_nontemporal_store((TR)reward, (TR *)ctl.obs_ring + at);
+          __builtin_nontemporal_store(done ? TR(1) : TR(0), (TR *)ctl.obs_ring + at + 1);
+        }
+      }
     }
     xr[in_dim + 1] = done ? T(1) : T(0);
   }
@@ -3109,6 +3137,17 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       if (ctl.ret_steps != nullptr) ctl.ret_steps[env] = cnt;
     }
     TDS_WAVE_SYNC();
+    // ---- per-step observation record (ring): [q | qd] with obs[0] = obs[1] = 0 (ars_vectorized_environment.h:283-288) of
+    //      the state the NEXT step starts from — after an auto-reset through the pool that is the fresh environment,
+    //      while reward / done (written above) describe the step that ended (ars_vectorized_environment.h:262-277)
+    if (ring_o && do_reward && valid) {
+      const size_t at = ((size_t)((ctl.obs_first + tds_iter) % ctl.obs_slots) * ctl.ring_envs + env) * (nq + nd + 2);
+      if (ctl.ring_flags & TDS_RING_OBS_F32) {
+        for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store(i < 2 ? 0.0f : (float)xr[i], (float *)ctl.obs_ring + at + i);
+      } else {
+        for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store(i < 2 ? TR(0) : (TR)xr[i], (TR *)ctl.obs_ring + at + i);
+      }
+    }
     // ---- the environment is done with this launch: observation (obs[0] = obs[1] = 0,
     //      ars_vectorized_environment.h:283-288) and resident state
     if (finished) {
@@ -3260,7 +3299,8 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   } while (0)
   if (prof && KIND != 0) return -2;  // the phase-stamp build exists for the plain kernels only
   // straight-line kernel when the launch is exactly one normal step without any reset
-  const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
+  const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr &&
+                      ctl.obs_ring == nullptr && ctl.y_ring == nullptr;  // (record rings: the step-loop builds write them)
   // step-loop build: above one wavefront per SIMD (256 CUs x 4 SIMDs) the two-wavefronts-per-SIMD compilation wins
   // (TDS_HIP_LOOP_OCC=1 / 2 forces either)
   static const int loop_force = [] { const char *e = getenv("TDS_HIP_LOOP_OCC"); return e ? atoi(e) : 0; }();

@@ -26,6 +26,7 @@
 #include <new>
 
 #include "tds_api_internal.h"
+#include "tds_shard_plan.h"
 
 using namespace tds_internal;
 
@@ -90,6 +91,25 @@ __global__ void tds_f64_to_f32_kernel(const double *__restrict__ in, float *__re
   if (i < n) out[i] = (float)in[i];
 }
 
+// Ring exchange: ONE lane on the communication stream waits until the step-loop launch running on the step stream has
+// counted `target` workgroups in (TdsStepCtl::progress: the records of a step are visible device-wide), then ends — the
+// all-gather of that step's ring slot is the next thing in the stream.  Bounded: after `timeout_ticks` of the 100 MHz
+// clock it raises the error latch and gives up (as does every wait behind it), so that a launch order nobody foresaw
+// costs a wrong exchange that tds_hip_shard_flush reports, never a hung GPU.
+__global__ void tds_ring_wait_kernel(const unsigned long long *progress, unsigned long long target, unsigned *err,
+                                     long long timeout_ticks) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+
 }  // namespace
 
 struct tds_hip_shard {
@@ -112,13 +132,46 @@ struct tds_hip_shard {
   const void *graph_actions = nullptr;
   int graph_pool = 0, graph_first = 0, graph_steps = 0, graph_block = 0, graph_slot0 = 0, graph_last_slot = -1;
   bool comm_warm = false;  // an all-gather has run eagerly on the communicator (connections are up)
+  bool one_process_group = false;  // created by tds_hip_shard_create_all: collectives must be issued as a group
+
+  // ---- ring exchange (tds_hip_shard_step_many where the sim's K steps are ONE step-loop launch): the launch writes
+  //      the [obs | reward | done] record of every step into a slot of `rwire`, in the wire dtype; the communication
+  //      stream sends slot k as soon as the launch has counted every workgroup in for step k
+  void *rwire = nullptr;   // [2 TDS_SHARD_CHUNK][n_local][w]          wire dtype
+  void *rgath = nullptr;   // [2 TDS_SHARD_CHUNK][world][n_local][w]   wire dtype
+  void *ry = nullptr;      // [TDS_SHARD_Y_SLOTS][n_local][output_dim] record dtype: the y records (local, not exchanged)
+  unsigned long long *progress = nullptr;  // [2] one counter per ring half, + the error latch behind them
+  hipEvent_t ev_fork = nullptr, ev_kernel[2] = {}, ev_comm[2] = {};
+  hipEvent_t cap_fork = nullptr, cap_kernel = nullptr, cap_comm = nullptr;  // the same roles inside a stream capture
+  bool comm_pending[2] = {};
+  long long chunks = 0;    // step-loop launches submitted so far
+  void *last_ptr = nullptr;       // gathered records of the most recently submitted exchange ...
+  hipEvent_t last_ev = nullptr;   // ... and the event that says they have arrived
+  int last_block = 1;
+  static constexpr int kRingGraphs = 8;
+  struct RingGraph {
+    hipGraphExec_t exec = nullptr;
+    const void *actions = nullptr;
+    int pool = 0, first = 0, steps = 0, half = 0;
+    long long used = 0;
+  } rgraph[kRingGraphs];
+  long long rgraph_clock = 0;
 
   size_t block_scalars() const { return (size_t)block * n_local * sim->obs_width(); }
+  size_t slot_scalars() const { return (size_t)n_local * sim->obs_width(); }
+  unsigned *wait_err() const { return (unsigned *)(progress + 2); }
 };
 
 namespace {
 
 int alloc_ring(tds_hip_shard *sh) {
+  // (a cached graph's kernel and all-gather nodes point into the rings that are about to be freed)
+  if (sh->graph_exec) {
+    (void)hipGraphExecDestroy(sh->graph_exec);
+    sh->graph_exec = nullptr;
+  }
+  sh->graph_steps = 0;
+  sh->graph_actions = nullptr;
   const size_t rec_b = sh->block_scalars() * sh->sim->elem;
   const size_t wire_b = sh->block_scalars() * sh->wire_bytes;
   const bool convert = (int)sh->sim->elem != sh->wire_bytes;
@@ -220,6 +273,238 @@ int shard_mark_done(tds_hip_shard *sh, int slot) {
   TDS_HIP_TRY(hipEventRecord(sh->ev_done[slot], sh->comm_stream));
   sh->pending[slot] = true;
   sh->last_slot = slot;
+  sh->last_ptr = sh->gathered[slot];
+  sh->last_ev = sh->ev_done[slot];
+  sh->last_block = sh->block;
+  return TDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ring exchange.  Where the shard's K steps are ONE launch of the step-loop kernel (tds_hip_step_many_is_loop: the Ant
+// up to three rounds of workgroups, every world without contacts) there is no kernel boundary per step to hang an
+// exchange on — and none is needed: the launch stores every step's [obs | reward | done] record into a ring slot in the
+// wire dtype (tds_hip_step_many_rings, obs_f32) and counts its workgroups in per step; the communication stream runs
+//     wait(step k counted in)  ->  ncclAllGather(slot k)            k = 0 .. c - 2
+//     wait(launch complete)    ->  ncclAllGather(slot c - 1)
+// beside it.  One exchange per policy step, no host call per step, nothing the step needs ever waits for
+// xGMI.  A call is cut into launches of up to TDS_SHARD_CHUNK steps; the ring holds two of them, launch j + 2 waits
+// for the exchanges of launch j (which used the same half).  N = 1 (tds_hip_step_many_rings alone) and N > 1 (this)
+// run the SAME kernel doing the SAME work per step; the only difference is the exchange.
+// ---------------------------------------------------------------------------------------------------------------
+int ring_alloc(tds_hip_shard *sh) {
+  if (sh->rwire) return TDS_OK;
+  tds_hip_sim *s = sh->sim;
+  const size_t slot_b = sh->slot_scalars() * sh->wire_bytes;
+  TDS_HIP_TRY(hipMalloc(&sh->rwire, 2 * TDS_SHARD_CHUNK * slot_b));
+  TDS_HIP_TRY(hipMemset(sh->rwire, 0, 2 * TDS_SHARD_CHUNK * slot_b));
+  TDS_HIP_TRY(hipMalloc(&sh->rgath, 2 * TDS_SHARD_CHUNK * slot_b * sh->world));
+  TDS_HIP_TRY(hipMalloc(&sh->ry, (size_t)TDS_SHARD_Y_SLOTS * sh->n_local * s->model.output_dim * s->elem));
+  TDS_HIP_TRY(hipMalloc((void **)&sh->progress, 4 * sizeof(unsigned long long)));
+  TDS_HIP_TRY(hipMemset(sh->progress, 0, 4 * sizeof(unsigned long long)));
+  TDS_HIP_TRY(hipEventCreateWithFlags(&sh->ev_fork, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) {
+    TDS_HIP_TRY(hipEventCreateWithFlags(&sh->ev_kernel[i], hipEventDisableTiming));
+    TDS_HIP_TRY(hipEventCreateWithFlags(&sh->ev_comm[i], hipEventDisableTiming));
+  }
+  TDS_HIP_TRY(hipEventCreateWithFlags(&sh->cap_fork, hipEventDisableTiming));
+  TDS_HIP_TRY(hipEventCreateWithFlags(&sh->cap_kernel, hipEventDisableTiming));
+  TDS_HIP_TRY(hipEventCreateWithFlags(&sh->cap_comm, hipEventDisableTiming));
+  return TDS_OK;
+}
+
+void ring_free(tds_hip_shard *sh) {
+  for (auto &g : sh->rgraph)
+    if (g.exec) {
+      (void)hipGraphExecDestroy(g.exec);
+      g.exec = nullptr;
+    }
+  if (sh->rwire) (void)hipFree(sh->rwire);
+  if (sh->rgath) (void)hipFree(sh->rgath);
+  if (sh->ry) (void)hipFree(sh->ry);
+  if (sh->progress) (void)hipFree(sh->progress);
+  if (sh->ev_fork) (void)hipEventDestroy(sh->ev_fork);
+  if (sh->cap_fork) (void)hipEventDestroy(sh->cap_fork);
+  if (sh->cap_kernel) (void)hipEventDestroy(sh->cap_kernel);
+  if (sh->cap_comm) (void)hipEventDestroy(sh->cap_comm);
+  for (int i = 0; i < 2; ++i) {
+    if (sh->ev_kernel[i]) (void)hipEventDestroy(sh->ev_kernel[i]);
+    if (sh->ev_comm[i]) (void)hipEventDestroy(sh->ev_comm[i]);
+  }
+  sh->rwire = sh->rgath = sh->ry = nullptr;
+  sh->progress = nullptr;
+}
+
+bool ring_form(const tds_hip_shard *sh, int n_steps) {
+  const tds_hip_sim *s = sh->sim;
+  if (sh->block != 1 || s->auto_reset) return false;  // (auto-reset: the refill passes of the reset pool are host-driven)
+  if (const char *e = getenv("TDS_HIP_SHARD_RING")) {
+    if (e[0] == '0') return false;
+  }
+  return tds_hip_step_many_is_loop(s, n_steps > 1 ? n_steps : 2) != 0;
+}
+
+// one chunk on the CURRENT streams (sim->stream / comm_stream; under capture both belong to the capture)
+int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRingChunk &ck, bool capturing) {
+  tds_hip_sim *s = sh->sim;
+  const int h = ck.half;
+  const size_t slot_b = sh->slot_scalars() * sh->wire_bytes;
+  // (events recorded inside a capture belong to the capture: it has its own set)
+  const hipEvent_t e_fork = capturing ? sh->cap_fork : sh->ev_fork, e_kernel = capturing ? sh->cap_kernel : sh->ev_kernel[h],
+                   e_comm = capturing ? sh->cap_comm : sh->ev_comm[h];
+  if (!capturing && sh->comm_pending[h]) {  // the exchanges of the launch two back read this half of the ring
+    TDS_HIP_TRY(hipStreamWaitEvent(s->stream, sh->ev_comm[h], 0));
+    sh->comm_pending[h] = false;
+  }
+  TDS_HIP_TRY(hipMemsetAsync(sh->progress + h, 0, sizeof(unsigned long long), s->stream));
+  TDS_HIP_TRY(hipEventRecord(e_fork, s->stream));
+  TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, e_fork, 0));
+  tds_hip_rings_t r;
+  memset(&r, 0, sizeof(r));
+  r.obs_ring = (char *)sh->rwire + (size_t)ck.slot0 * slot_b;
+  r.obs_slots = TDS_SHARD_CHUNK;
+  r.obs_first = 0;
+  r.obs_f32 = (sh->wire_bytes == 4 && s->elem == 8) ? 1 : 0;
+  r.y_ring = sh->ry;
+  r.y_slots = TDS_SHARD_Y_SLOTS;
+  r.y_first = 0;
+  r.progress = sh->progress + h;
+  int rc = tds_hip_step_many_rings(s, actions_dev, pool, ck.act_first, ck.steps, &r);
+  if (rc != TDS_OK) return rc;
+  TDS_HIP_TRY(hipEventRecord(e_kernel, s->stream));
+  const int n_blocks = tds_hip_step_many_rings_blocks(s);
+  static const long long timeout_ticks = [] {
+    const char *e = getenv("TDS_HIP_SHARD_WAIT_MS");
+    return (long long)(e ? atoi(e) : 2000) * 100000ll;  // 100 MHz
+  }();
+  for (int k = 0; k < ck.steps; ++k) {
+    const unsigned long long target = tds_ring_wait_target(k, ck.steps, n_blocks);
+    if (target != 0ull) {
+      hipLaunchKernelGGL(tds_ring_wait_kernel, dim3(1), dim3(64), 0, sh->comm_stream, sh->progress + h, target,
+                         sh->wait_err(), timeout_ticks);
+      if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "ring exchange: wait kernel launch");
+    } else {
+      TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, e_kernel, 0));
+    }
+    const void *src = (const char *)sh->rwire + (size_t)(ck.slot0 + k) * slot_b;
+    void *dst = (char *)sh->rgath + (size_t)(ck.slot0 + k) * slot_b * sh->world;
+    if (sh->comm) {
+      NCCL_TRY(rccl()->AllGather(src, dst, sh->slot_scalars(), sh->wire_bytes == 8 ? ncclFloat64 : ncclFloat32, sh->comm,
+                                 sh->comm_stream));
+      if (!capturing) sh->comm_warm = true;
+    } else {
+      TDS_HIP_TRY(hipMemcpyAsync(dst, src, slot_b, hipMemcpyDeviceToDevice, sh->comm_stream));
+    }
+  }
+  TDS_HIP_TRY(hipEventRecord(e_comm, sh->comm_stream));
+  return TDS_OK;
+}
+
+// bookkeeping after a chunk has been submitted (eagerly or as a graph launch)
+void ring_submitted(tds_hip_shard *sh, const TdsRingChunk &ck) {
+  const size_t slot_b = sh->slot_scalars() * sh->wire_bytes;
+  sh->comm_pending[ck.half] = true;
+  sh->steps += ck.steps;
+  sh->chunks++;
+  sh->last_ptr = (char *)sh->rgath + (size_t)(ck.slot0 + ck.steps - 1) * slot_b * sh->world;
+  sh->last_ev = sh->ev_comm[ck.half];
+  sh->last_block = 1;
+  sh->last_slot = 0;
+}
+
+tds_hip_shard::RingGraph *ring_graph_find(tds_hip_shard *sh, const void *actions, int pool, const TdsRingChunk &ck) {
+  for (auto &g : sh->rgraph)
+    if (g.exec && g.actions == actions && g.pool == pool && g.first == ck.act_first && g.steps == ck.steps && g.half == ck.half)
+      return &g;
+  return nullptr;
+}
+
+// capture one chunk — memset, step-loop launch, waits, all-gathers — into a graph of its own
+tds_hip_shard::RingGraph *ring_graph_build(tds_hip_shard *sh, const void *actions, int pool, const TdsRingChunk &ck) {
+  tds_hip_sim *s = sh->sim;
+  tds_hip_shard::RingGraph *slot = &sh->rgraph[0];
+  for (auto &g : sh->rgraph) {
+    if (!g.exec) {
+      slot = &g;
+      break;
+    }
+    if (g.used < slot->used) slot = &g;
+  }
+  if (slot->exec) {
+    (void)hipGraphExecDestroy(slot->exec);
+    slot->exec = nullptr;
+  }
+  if (!sh->graph_stream && hipStreamCreateWithFlags(&sh->graph_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  hipStream_t user = s->stream;
+  s->stream = sh->graph_stream;  // capture origin (the handle's own stream may be the NULL stream)
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamBeginCapture(sh->graph_stream, hipStreamCaptureModeThreadLocal);
+  int rc = TDS_OK;
+  if (e == hipSuccess) {
+    rc = ring_chunk(sh, actions, pool, ck, true);
+    // join: the graph is complete when the last slot has been exchanged
+    if (rc == TDS_OK && hipStreamWaitEvent(sh->graph_stream, sh->cap_comm, 0) != hipSuccess) rc = TDS_ERR_HIP;
+    e = hipStreamEndCapture(sh->graph_stream, &graph);
+  }
+  s->stream = user;
+  if (e == hipSuccess && rc == TDS_OK && graph) {
+    e = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) slot->exec = nullptr;
+  }
+  if (graph) (void)hipGraphDestroy(graph);
+  if (!slot->exec) {
+    (void)hipGetLastError();
+    fprintf(stderr, "tds_hip_shard_step_many: capture of the ring exchange refused (%s) — submitting it eagerly\n",
+            e != hipSuccess ? hipGetErrorString(e) : tds_hip_last_error());
+    return nullptr;
+  }
+  slot->actions = actions;
+  slot->pool = pool;
+  slot->first = ck.act_first;
+  slot->steps = ck.steps;
+  slot->half = ck.half;
+  return slot;
+}
+
+int ring_many(tds_hip_shard *sh, const void *actions_dev, int pool, int first, int n_steps, bool run) {
+  tds_hip_sim *s = sh->sim;
+  int rc = ring_alloc(sh);
+  if (rc != TDS_OK) return rc;
+  if (sh->comm && !sh->comm_warm) {
+    // the first collective of a communicator sets up its transport connections between the ranks: eagerly, never inside
+    // a stream capture — one warm-up all-gather of a scratch slot, on every rank
+    if (sh->one_process_group)
+      return fail(TDS_ERR_INVALID_ARG, "shards of tds_hip_shard_create_all: call tds_hip_shard_group_step once before "
+                                       "tds_hip_shard_step_many (the first collective must be issued as a group)");
+    NCCL_TRY(rccl()->AllGather(sh->rwire, sh->rgath, sh->slot_scalars(), sh->wire_bytes == 8 ? ncclFloat64 : ncclFloat32,
+                               sh->comm, sh->comm_stream));
+    TDS_HIP_TRY(hipStreamSynchronize(sh->comm_stream));
+    sh->comm_warm = true;
+  }
+  TdsRingChunk plan[4096 / TDS_SHARD_CHUNK + 1];
+  const int nc = tds_ring_plan(sh->chunks, n_steps, first, pool, plan, (int)(sizeof(plan) / sizeof(plan[0])));
+  if (nc < 0) return fail(TDS_ERR_INVALID_ARG, "n_steps too large");
+  const bool want_graph = getenv("TDS_HIP_SHARD_NO_GRAPH") == nullptr;
+  for (int i = 0; i < nc; ++i) {
+    const TdsRingChunk &ck = plan[i];
+    tds_hip_shard::RingGraph *g = want_graph ? ring_graph_find(sh, actions_dev, pool, ck) : nullptr;
+    if (want_graph && !g) g = ring_graph_build(sh, actions_dev, pool, ck);
+    if (!run) continue;  // (prepare: the graphs only)
+    if (g) {
+      for (int h = 0; h < 2; ++h)  // a graph is ordered behind the stream it is launched into: that stream waits for
+        if (sh->comm_pending[h]) {  // whatever the communication stream still has in flight
+          TDS_HIP_TRY(hipStreamWaitEvent(s->stream, sh->ev_comm[h], 0));
+          sh->comm_pending[h] = false;
+        }
+      TDS_HIP_TRY(hipGraphLaunch(g->exec, s->stream));
+      g->used = ++sh->rgraph_clock;
+      // consumers of tds_hip_shard_gathered wait on ev_comm[half]: record it behind the graph (complete = exchanged)
+      TDS_HIP_TRY(hipEventRecord(sh->ev_comm[ck.half], s->stream));
+    } else {
+      rc = ring_chunk(sh, actions_dev, pool, ck, false);
+      if (rc != TDS_OK) return rc;
+    }
+    ring_submitted(sh, ck);
+  }
   return TDS_OK;
 }
 
@@ -298,7 +583,10 @@ int tds_hip_shard_create_all(const tds_model_t *model, int global_envs, int n_de
     }
     return rc;
   }
-  for (int i = 0; i < n_devices; ++i) out[i]->comm = comms[i];
+  for (int i = 0; i < n_devices; ++i) {
+    out[i]->comm = comms[i];
+    out[i]->one_process_group = n_devices > 1;
+  }
   return TDS_OK;
 }
 
@@ -309,6 +597,7 @@ int tds_hip_shard_destroy(tds_hip_shard_t *sh) {
     DeviceGuard guard(device);
     if (sh->comm_stream) (void)hipStreamSynchronize(sh->comm_stream);
     if (sh->graph_exec) (void)hipGraphExecDestroy(sh->graph_exec);
+    ring_free(sh);
     if (sh->graph_stream) (void)hipStreamDestroy(sh->graph_stream);
     if (sh->comm && rccl()) (void)rccl()->CommDestroy(sh->comm);
     for (int i = 0; i < kSlots; ++i) {
@@ -338,9 +627,11 @@ int tds_hip_shard_set_block(tds_hip_shard_t *sh, int steps_per_exchange) {
   int rc = tds_hip_shard_flush(sh);
   if (rc != TDS_OK) return rc;
   DeviceGuard guard(sh->sim->device);
+  if (steps_per_exchange == sh->block) return TDS_OK;  // (nothing to reallocate)
   sh->block = steps_per_exchange;
   sh->steps = 0;
   sh->last_slot = -1;
+  sh->last_ptr = nullptr;
   return alloc_ring(sh);
 }
 
@@ -388,6 +679,7 @@ int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const 
   for (int i = 0; i < n && rc == TDS_OK; ++i) {
     DeviceGuard guard(shards[i]->sim->device);
     rc = shard_mark_done(shards[i], slot);
+    if (grouped) shards[i]->comm_warm = true;
   }
   return rc;
 }
@@ -420,9 +712,29 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
   const int pool = actions_dev ? action_blocks : 1;
   const int first = actions_dev ? ((first_block % pool) + pool) % pool : 0;
   const size_t blk = (size_t)sh->n_local * s->model.action_dim * s->elem;
+  // the K steps as step-loop launches that write a record ring, the exchange of a slot following the launch's own
+  // progress counter: one launch per up to 64 steps instead of one per step (see "Ring exchange" above)
+  if (ring_form(sh, n_steps)) return ring_many(sh, actions_dev, pool, first, n_steps, run);
+  if (sh->comm && !sh->comm_warm && sh->one_process_group)
+    return fail(TDS_ERR_INVALID_ARG, "shards of tds_hip_shard_create_all: call tds_hip_shard_group_step once before "
+                                     "tds_hip_shard_step_many (the first collective must be issued as a group)");
+  const bool eager_only = s->auto_reset || getenv("TDS_HIP_SHARD_NO_GRAPH") != nullptr;
+  if (!eager_only) {
+    if (sh->steps % sh->block != 0) {  // (a partially filled block of eager steps travels first)
+      const int rc = tds_hip_shard_flush(sh);
+      if (rc != TDS_OK) return rc;
+    }
+    // the graph always starts at ring slot 0 (one cached graph serves every call): exchanges of eager steps still in
+    // flight are waited for by the stream the graph goes into, then the step count is realigned to a slot-0 boundary
+    for (int i = 0; i < kSlots; ++i)
+      if (sh->pending[i]) {
+        TDS_HIP_TRY(hipStreamWaitEvent(s->stream, sh->ev_done[i], 0));
+        sh->pending[i] = false;
+      }
+    sh->steps = 0;
+  }
   const int slot0 = (int)((sh->steps / sh->block) % kSlots);
   // (auto-reset: the refill passes of the reset pool are host-driven — stepped eagerly, one exchange per block as ever)
-  const bool eager_only = s->auto_reset || getenv("TDS_HIP_SHARD_NO_GRAPH") != nullptr;
   const bool cached = sh->graph_exec && sh->graph_actions == actions_dev && sh->graph_pool == pool &&
                       sh->graph_first == first && sh->graph_steps == n_steps && sh->graph_block == sh->block &&
                       sh->graph_slot0 == slot0;
@@ -504,6 +816,9 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
     sh->last_slot = sh->graph_last_slot;
     // consumers of tds_hip_shard_gathered wait on ev_done[last_slot]: re-record it behind the graph
     TDS_HIP_TRY(hipEventRecord(sh->ev_done[sh->last_slot], s->stream));
+    sh->last_ptr = sh->gathered[sh->last_slot];
+    sh->last_ev = sh->ev_done[sh->last_slot];
+    sh->last_block = sh->block;
     return TDS_OK;
   }
   for (int k = 0; k < n_steps; ++k) {
@@ -512,6 +827,29 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
     if (rc != TDS_OK) return rc;
   }
   return TDS_OK;
+}
+
+int tds_hip_shard_ring_plan(long long chunks_done, int n_steps, int act_first, int act_blocks, int n_blocks, int *out,
+                            int cap) {
+  if (!out || cap < 1 || n_steps < 1) return -1;
+  TdsRingChunk plan[4096 / TDS_SHARD_CHUNK + 1];
+  if (n_steps > 4096) return -1;
+  const int nc = tds_ring_plan(chunks_done, n_steps, act_first, act_blocks, plan, (int)(sizeof(plan) / sizeof(plan[0])));
+  if (nc < 0 || nc > cap) return -1;
+  for (int i = 0; i < nc; ++i) {
+    out[6 * i + 0] = plan[i].half;
+    out[6 * i + 1] = plan[i].steps;
+    out[6 * i + 2] = plan[i].step0;
+    out[6 * i + 3] = plan[i].act_first;
+    out[6 * i + 4] = plan[i].slot0;
+    // what the communication stream waits for before it sends the chunk's FIRST slot (0: the launch's completion)
+    out[6 * i + 5] = (int)tds_ring_wait_target(0, plan[i].steps, n_blocks);
+  }
+  return nc;
+}
+long long tds_hip_shard_gathered_offset(int global_env, int n_local, int width) {
+  if (global_env < 0 || n_local < 1 || width < 1) return -1;
+  return (long long)tds_gathered_offset(global_env, n_local, width);
 }
 
 int tds_hip_shard_flush(tds_hip_shard_t *sh) {
@@ -524,19 +862,29 @@ int tds_hip_shard_flush(tds_hip_shard_t *sh) {
     if (rc != TDS_OK) return rc;
     sh->steps = (sh->steps / sh->block + 1) * sh->block;
   }
+  TDS_HIP_TRY(hipStreamSynchronize(sh->sim->stream));  // (graph launches of the ring exchange live on the step stream)
   TDS_HIP_TRY(hipStreamSynchronize(sh->comm_stream));
   for (int i = 0; i < kSlots; ++i) sh->pending[i] = false;
+  sh->comm_pending[0] = sh->comm_pending[1] = false;
+  if (sh->progress) {  // a wait of the ring exchange that gave up (see tds_ring_wait_kernel)
+    unsigned err = 0;
+    TDS_HIP_TRY(hipMemcpy(&err, sh->wait_err(), sizeof(err), hipMemcpyDeviceToHost));
+    if (err != 0u) {
+      TDS_HIP_TRY(hipMemset(sh->wait_err(), 0, sizeof(err)));
+      return fail(TDS_ERR_HIP, "ring exchange: a wait for the step-loop launch timed out — gathered records are not valid");
+    }
+  }
   return TDS_OK;
 }
 
 int tds_hip_shard_gathered(tds_hip_shard_t *sh, void *consumer_stream, void **records_dev, int *steps_in_block) {
   if (!sh || !records_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
-  if (sh->last_slot < 0) return fail(TDS_ERR_INVALID_ARG, "no exchange submitted yet");
+  if (!sh->last_ptr) return fail(TDS_ERR_INVALID_ARG, "no exchange submitted yet");
   DeviceGuard guard(sh->sim->device);
   // the consumer's stream waits for the exchange; the host does not
-  TDS_HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, sh->ev_done[sh->last_slot], 0));
-  *records_dev = sh->gathered[sh->last_slot];
-  if (steps_in_block) *steps_in_block = sh->block;
+  TDS_HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, sh->last_ev, 0));
+  *records_dev = sh->last_ptr;
+  if (steps_in_block) *steps_in_block = sh->last_block;
   return TDS_OK;
 }
 

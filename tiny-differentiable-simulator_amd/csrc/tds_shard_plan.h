@@ -1,0 +1,51 @@
+// tds_shard_plan.h — the host arithmetic of the ring exchange of tds_shard.hip, free of HIP: which launches a
+// tds_hip_shard_step_many call is cut into, which ring slots their steps own, what the communication stream waits for
+// before it sends a slot, where a global environment's record lies in a gathered slot.  Kept apart so that it runs (and
+// is tested: tests/test_shard_plan.py, through tds_hip_shard_ring_plan of the C ABI) on a host without a GPU.
+#pragma once
+#include <stddef.h>
+
+// steps per step-loop launch ("chunk") of the ring exchange; the obs ring holds two chunks (one being exchanged while the
+// next one is written)
+#define TDS_SHARD_CHUNK 64
+// slots of the shard's y ring (local records, never exchanged; step k of a chunk owns slot k % TDS_SHARD_Y_SLOTS)
+#define TDS_SHARD_Y_SLOTS 16
+
+struct TdsRingChunk {
+  int half;       // which half of the obs ring the chunk writes (chunk index & 1)
+  int steps;      // steps of the chunk (one step-loop launch)
+  int step0;      // steps of the call that lie before the chunk
+  int act_first;  // action block of the chunk's first step
+  int slot0;      // ring slot of the chunk's first step (= half * TDS_SHARD_CHUNK; step k -> slot0 + k)
+};
+
+// the chunks of one call of n_steps steps, `chunks_done` chunks having been submitted before it; returns their number
+// (-1: more than cap)
+inline int tds_ring_plan(long long chunks_done, int n_steps, int act_first, int act_blocks, TdsRingChunk *out, int cap) {
+  int n = 0;
+  for (int done = 0; done < n_steps; ++n) {
+    if (n >= cap) return -1;
+    const int c = n_steps - done < TDS_SHARD_CHUNK ? n_steps - done : TDS_SHARD_CHUNK;
+    TdsRingChunk &k = out[n];
+    k.half = (int)((chunks_done + n) & 1);
+    k.steps = c;
+    k.step0 = done;
+    k.act_first = act_blocks > 0 ? (act_first + done) % act_blocks : 0;
+    k.slot0 = k.half * TDS_SHARD_CHUNK;
+    done += c;
+  }
+  return n;
+}
+
+// The step-loop launch counts a workgroup in for step k while it runs step k + 1 (TdsStepCtl::progress), never for its
+// last step: slot k of a chunk of c steps may be sent when the chunk's counter has reached (k + 1) * n_blocks (k < c - 1)
+// — or, for k == c - 1, when the launch has completed (returns 0: wait for the launch's event instead).
+inline unsigned long long tds_ring_wait_target(int k, int chunk_steps, int n_blocks) {
+  return k < chunk_steps - 1 ? (unsigned long long)(k + 1) * (unsigned long long)n_blocks : 0ull;
+}
+
+// scalar offset of the record of GLOBAL environment e in a gathered slot [world][n_local][width] (ncclAllGather lays the
+// ranks' blocks out in rank order; rank r owns the environments [r n_local, (r + 1) n_local))
+inline size_t tds_gathered_offset(int e, int n_local, int width) {
+  return ((size_t)(e / n_local) * (size_t)n_local + (size_t)(e % n_local)) * (size_t)width;
+}

@@ -79,6 +79,9 @@ def lib():
         for f in ("tds_hip_step_many_prepare", "tds_hip_step_many"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.tds_hip_set_graph_chains.argtypes = [C.c_void_p, C.c_int]
+        for f in ("tds_hip_step_many_rings", "tds_hip_step_many_rings_prepare"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Rings)]
+        L.tds_hip_step_many_rings_blocks.argtypes = [C.c_void_p]
         L.tds_hip_step_many_is_loop.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_debug_poison_lds.argtypes = [C.c_void_p, C.c_int]
         L.tds_hip_step_many_tune.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
@@ -99,8 +102,18 @@ def lib():
         L.tds_hip_shard_step_many_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.tds_hip_shard_group_step.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int]
         L.tds_hip_shard_gathered.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        L.tds_hip_shard_ring_plan.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.tds_hip_shard_gathered_offset.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.tds_hip_shard_gathered_offset.restype = C.c_longlong
         _lib = L
     return _lib
+
+
+class Rings(C.Structure):
+    """tds_hip_rings_t (include/tds_hip.h): per-step record rings of tds_hip_step_many_rings"""
+    _fields_ = [("obs_ring", C.c_void_p), ("obs_slots", C.c_int32), ("obs_first", C.c_int32), ("obs_f32", C.c_int32),
+                ("pad0_", C.c_int32), ("y_ring", C.c_void_p), ("y_slots", C.c_int32), ("y_first", C.c_int32),
+                ("progress", C.c_void_p)]
 
 
 EXPORTED_SYMBOLS = [
@@ -115,13 +128,27 @@ EXPORTED_SYMBOLS = [
     "tds_hip_device", "tds_hip_record_bytes", "tds_hip_sync", "tds_hip_forward_zero_host_begin",
     "tds_hip_forward_zero_host_end", "tds_hip_step_many_prepare", "tds_hip_step_many",
     "tds_hip_set_graph_chains", "tds_hip_step_many_tune", "tds_hip_step_many_is_loop", "tds_hip_debug_poison_lds",
+    "tds_hip_step_many_rings", "tds_hip_step_many_rings_prepare", "tds_hip_step_many_rings_blocks",
     "tds_hip_shard_rccl_version", "tds_hip_shard_unique_id", "tds_hip_shard_create", "tds_hip_shard_create_all",
     "tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
     "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes", "tds_hip_shard_set_block",
     "tds_hip_shard_step", "tds_hip_shard_step_many", "tds_hip_shard_step_many_prepare", "tds_hip_shard_group_step", "tds_hip_shard_flush", "tds_hip_shard_gathered",
+    "tds_hip_shard_ring_plan", "tds_hip_shard_gathered_offset",
     "tds_rb_last_error", "tds_rb_create", "tds_rb_destroy", "tds_rb_set_stream", "tds_rb_state_device",
     "tds_rb_set_state", "tds_rb_get_state", "tds_rb_step",
 ]
+
+
+def shard_ring_plan(chunks_done: int, n_steps: int, act_first: int = 0, act_blocks: int = 1, n_blocks: int = 1):
+    """the step-loop launches a tds_hip_shard_step_many call is cut into (tds_hip_shard_ring_plan; no device needed):
+    list of dicts half / steps / step0 / act_first / slot0 / first_wait"""
+    cap = 80
+    out = (C.c_int * (6 * cap))()
+    n = lib().tds_hip_shard_ring_plan(int(chunks_done), int(n_steps), int(act_first), int(act_blocks), int(n_blocks), out, cap)
+    if n < 0:
+        raise TdsHipError("tds_hip_shard_ring_plan: bad arguments")
+    keys = ("half", "steps", "step0", "act_first", "slot0", "first_wait")
+    return [dict(zip(keys, out[6 * i:6 * i + 6])) for i in range(n)]
 
 
 def _check(rc):
@@ -258,6 +285,40 @@ class HipSim:
         ([B, N, action_dim] device tensor, or None).  With auto-reset on, every step resets what it ends with done."""
         ap, nb, op = self._many_args(actions, obs)
         _check(lib().tds_hip_step_many(self.h, ap, nb, int(first_block), int(n_steps), op))
+
+    def _rings(self, obs_ring, y_ring, obs_first, y_first, progress=None):
+        import torch
+
+        r = Rings()
+        if obs_ring is not None:
+            assert obs_ring.is_cuda and obs_ring.is_contiguous() and obs_ring.dim() == 3
+            assert tuple(obs_ring.shape[1:]) == (self.num_envs, self.obs_dim + 2)
+            assert obs_ring.dtype in (self.torch_dtype, torch.float32)
+            r.obs_ring, r.obs_slots, r.obs_first = obs_ring.data_ptr(), int(obs_ring.shape[0]), int(obs_first)
+            r.obs_f32 = 1 if (obs_ring.dtype == torch.float32 and self.torch_dtype != torch.float32) else 0
+        if y_ring is not None:
+            assert y_ring.is_cuda and y_ring.is_contiguous() and y_ring.dim() == 3 and y_ring.dtype == self.torch_dtype
+            assert tuple(y_ring.shape[1:]) == (self.num_envs, self.output_dim)
+            r.y_ring, r.y_slots, r.y_first = y_ring.data_ptr(), int(y_ring.shape[0]), int(y_first)
+        if progress is not None:
+            assert progress.is_cuda and progress.dtype == torch.int64 and progress.numel() >= 1
+            r.progress = progress.data_ptr()
+        return r
+
+    def step_many_rings(self, actions, n_steps: int, obs_ring=None, y_ring=None, first_block: int = 0,
+                        obs_first: int = 0, y_first: int = 0, progress=None, prepare_only: bool = False):
+        """``n_steps`` closed-loop steps per host call WITH per-step records (tds_hip_step_many_rings): step k leaves its
+        [obs | reward | done] record in ``obs_ring[(obs_first + k) % len(obs_ring)]`` ([S, N, obs_dim + 2]) and its y
+        record in ``y_ring[(y_first + k) % len(y_ring)]`` ([S', N, output_dim]) — what the reference's
+        VectorizedEnvironment::step hands out every step.  One step-loop launch where step_many_is_loop holds."""
+        ap, nb, _ = self._many_args(actions, None)
+        r = self._rings(obs_ring, y_ring, obs_first, y_first, progress)
+        f = lib().tds_hip_step_many_rings_prepare if prepare_only else lib().tds_hip_step_many_rings
+        _check(f(self.h, ap, nb, int(first_block), int(n_steps), C.byref(r)))
+
+    def rings_blocks(self) -> int:
+        """increments of a rings progress counter per completed step (= workgroups of the step-loop launch)"""
+        return int(lib().tds_hip_step_many_rings_blocks(self.h))
 
     def debug_poison_lds(self, byte_pattern: int = 0xFF):
         """Test aid: every compute unit's LDS filled with the byte pattern (0xFF: NaN in every scalar type)."""
