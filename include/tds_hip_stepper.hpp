@@ -297,7 +297,15 @@ struct HipStepper : public VectorizedEnvironment<Algebra, Sim>::CustomForwardDyn
     sims_.assign(nd, nullptr);
     for (int d = 0; d < nd; ++d) {
       rc = tds_hip_create(&model_, first_[d + 1] - first_[d], devices[d], TDS_DTYPE_F64, &sims_[d]);
-      if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+      if (rc != TDS_OK) {
+        // (a constructor that throws is not followed by its destructor: the handles made so far go first)
+        const std::string why = tds_hip_last_error();
+        for (tds_hip_sim_t *&sp : sims_) {
+          if (sp) tds_hip_destroy(sp);
+          sp = nullptr;
+        }
+        fail(why.c_str(), rc);
+      }
     }
     in_.resize((size_t)batch_size * model_.input_dim);
     out_.resize((size_t)batch_size * model_.output_dim);

@@ -154,30 +154,42 @@ def test_golden_rollout_per_step(name, built):
                                   "laikago_floating_env", "sphere_spherical", "humanoid_spherical", "humanoid",
                                   "humanoid_sph_pd", "pendulum5_sph_pd"])
 def test_closed_loop_matches_oracle(name, built):
-    """device-resident closed loop (tds_hip_step) vs the oracle stepping on the host."""
+    """device-resident closed loop (tds_hip_step) against the reference (libtds_ref.so where the model's URDF is embedded
+    in the reference's headers: Ant, Laikago; the C oracle elsewhere) stepping on the host: EVERY environment, every
+    step, from the state the device held before the step (per-step resync).  Nothing is filtered out: the reference has
+    no joint limits or velocity clamps, so a robot that has fallen over can blow up numerically — relative errors stay
+    meaningful there, and an environment whose reference state leaves the finite range is put back to a fresh state on
+    both sides."""
     torch = _torch()
     m = tds_amd.load_model(name)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     nq, nd = m.dof_q, m.dof_qd
     n, T = 32, 25
+    ref_step, what = _reference_stepper(name, n)
     x = g["x"][:n].copy()
     rng = np.random.default_rng(5)
     sim = hip_backend.HipSim(m, n, dtype="f64")
     sim.x.copy_(torch.from_numpy(x).cuda())
+    restarts = 0
     for t in range(T):
         a = rng.uniform(-0.4, 0.4, (n, m.action_dim))
         sim.step(torch.from_numpy(a).cuda())
         x[:, nq + nd:nq + nd + m.action_dim] = a
-        y = oraclelib.step(m, x)
-        x[:, :nq + nd] = y[:, :nq + nd]
+        y = ref_step(x)
         yd = sim.y.cpu().numpy()
-        # the reference has no joint limits or velocity clamps: a robot that has fallen over can blow up numerically
-        # (the oracle diverges the same way); such environments amplify round-off and are left out of the comparison
-        calm = np.abs(y[:, :nq + nd]).max(axis=1) < 1e3
-        assert calm.sum() >= n // 2
-        assert rel_err(yd[calm], y[calm]) < TOL, (name, t)
-        # keep both on the oracle trajectory so the test measures per-step parity
+        ok = np.isfinite(y).all(axis=1)
+        assert np.isfinite(yd[ok]).all(), (name, t)
+        # (relative to each component's own size down to 1e-3, as everywhere: a blown-up state of 1e8 is held to 1e-6 of
+        #  ITS size, not to an absolute 1e-9)
+        assert rel_err(yd[ok], y[ok]) < TOL, (name, t)
+        x[:, :nq + nd] = y[:, :nq + nd]
+        if not ok.all():  # the reference itself left the finite range: fresh states for those environments
+            bad = np.where(~ok)[0]
+            x[bad] = g["x"][n + (restarts + np.arange(len(bad))) % (g["x"].shape[0] - n)]
+            restarts += len(bad)
+        # the device continues from the reference's trajectory: the test measures per-step parity
         sim.x[:, :nq + nd] = torch.from_numpy(x[:, :nq + nd]).cuda()
+    assert restarts <= n // 4, (name, restarts)
 
 
 @pytest.mark.parametrize("name", ["ant", "laikago", "humanoid", "ant_floating", "pendulum5_spherical"])
@@ -209,12 +221,21 @@ def test_full_size_properties(name, built):
 def _reference_stepper(name, n):
     """y = f(x) for [n, input_dim] on the host cores: the REAL reference (oracle/_ref/libtds_ref.so travels to the GPU
     box prebuilt; one simulation object per thread, ctypes releases the GIL) or, where it is absent, the C oracle."""
+    # constructors the reference library can run WITHOUT /root/reference (URDF embedded in the reference's own headers);
+    # configs built on them: (constructor, apply the model's dt / solver constants)
+    embedded = {"ant": ("ant", False), "laikago": ("laikago", False), "laikago_soft": ("laikago", True)}
     try:
         import reflib
-        if reflib.available():
+        if reflib.available() and name in embedded:
             import threading
             nth = min(os.cpu_count() or 1, 64, n)
-            sims = [reflib.RefSim(name) for _ in range(nth)]
+            ctor, tweak = embedded[name]
+            sims = [reflib.RefSim(ctor) for _ in range(nth)]
+            if tweak:  # (as oracle/gen_golden.py builds the model: spring-damper contact = cfm / erp from k, d)
+                mm = tds_amd.load_model(name)
+                for sref in sims:
+                    sref.set_dt(mm.dt)
+                    sref.set_solver(mm.cfm, mm.erp, mm.pgs_iterations, mm.friction, mm.restitution)
             bounds = np.linspace(0, n, nth + 1).astype(int)
 
             def step(x):

@@ -141,6 +141,10 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
       ctl.obs_slots = r.obs_slots;
       ctl.obs_first = (r.obs_first + opts->ring_step0) % r.obs_slots;
       if (r.obs_f32) ctl.ring_flags |= TDS_RING_OBS_F32;
+      // (how a step's records are made visible to the exchange before its progress count: write-through stores + a
+      //  plain wait, or streaming stores + a release fence — TDS_HIP_RING_NOFENCE=0 / 1)
+      static const bool nofence = [] { const char *e = getenv("TDS_HIP_RING_NOFENCE"); return e ? e[0] == '1' : false; }();
+      if (r.progress && nofence) ctl.ring_flags |= TDS_RING_NOFENCE;
     }
     if (r.y_ring) {
       ctl.y_ring = (char *)r.y_ring + e0 * s->model.output_dim * s->elem;
@@ -379,6 +383,10 @@ int tds_hip_set_inputs(tds_hip_sim_t *s, const double *x_host) {
   int rc = upload(s, s->d_x, x_host, (size_t)s->num_envs * s->model.input_dim);
   if (rc != TDS_OK) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
+  // the pre-settled reset states were settled with the gains (kp, kd, max_force) the records held when they were
+  // staged: new records, new pool
+  s->pool_ready = false;
+  s->pool_discard = true;
   return TDS_OK;
 }
 int tds_hip_get_inputs(tds_hip_sim_t *s, double *x_host) {
@@ -422,9 +430,12 @@ int tds_hip_forward_zero_device(tds_hip_sim_t *s, const void *x_dev, void *y_dev
 // The grids are exact: the host reads the size of a planned work list H steps after planning it (hipEventQuery,
 // blocking only if the GPU is more than H steps behind the host — it never idles the GPU), then enqueues settle +
 // scatter.  Before step t the step stream waits for pass floor((t - 1 - W) / R).  With D >= R + W an environment can
-// never run out of entries — at most one is consumed per step — so the results are EXACTLY those of resetting inside
-// the step launch (same stream of random numbers, same settle steps), whatever the rate of resets; a burst of resets
-// only makes the step stream wait.
+// never run out of entries — at most one is consumed per step — so the results are those of resetting inside the step
+// launch (same stream of random numbers, same settle steps: bit for bit with f64 records; with float records the
+// settle launches round the state to float between the settle steps, the in-kernel reset keeps it in double), whatever
+// the rate of resets; a burst of resets only makes the step stream wait.
+// The entries embed the gains the x records held at staging time: tds_hip_set_inputs discards the pool; a caller that
+// rewrites the gains through the zero-copy x pointer must call tds_hip_set_auto_reset again.
 // ======================================================================================================
 extern "C++" {
 namespace {
@@ -516,6 +527,10 @@ void pool_params(tds_hip_sim *s) {
   if (s->pool_host_lag < 1) s->pool_host_lag = 1;
   const int settle = s->model.settle_steps > 0 ? s->model.settle_steps : 0;
   s->pool_lag = pool_param("TDS_HIP_POOL_LAG", s->pool_host_lag + settle + 6);  // W
+  // (W > H: before step t the step stream waits for the event of pass floor((t - 1 - W) / R), which the host records at
+  //  most H steps after planning that pass — with W <= H it would wait on an event this pass has not recorded yet, i.e.
+  //  not at all, and a done environment could copy a ring slot that has not been refilled)
+  if (s->pool_lag < s->pool_host_lag + 1) s->pool_lag = s->pool_host_lag + 1;
   s->pool_chunk = pool_param("TDS_HIP_POOL_CHUNK", 128);                      // steps per launch of pool_step_many
 }
 int pool_depth_for(const tds_hip_sim *s, bool many) {

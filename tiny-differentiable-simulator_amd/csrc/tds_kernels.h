@@ -71,6 +71,9 @@ struct TdsStepCtl {
   unsigned long long *progress;
 };
 #define TDS_RING_OBS_F32 1
+// the obs ring is written with device-scope write-through stores (sc1) and a step is signalled after a plain
+// s_waitcnt vmcnt(0) — no release fence, whose buffer_wbl2 writes back every dirty line of the L2
+#define TDS_RING_NOFENCE 2
 
 // na_cap: contacts whose rows stay in LDS (<= 0: all); w2: the layout of the two-wavefront workgroups (the LDS groups
 // that alias each other in the one-wave layout laid out one after the other, + hand-over slots)

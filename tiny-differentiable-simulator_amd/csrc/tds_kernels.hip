@@ -1338,12 +1338,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   const bool settling = LOOP && mode == TDS_MODE_SETTLE;
   if constexpr (LOOP) {
     if (replay) {  // wave-uniform
-      if (tds_iter > 0 && mode == TDS_MODE_RUN && lane < adim) xr[nq + nd + lane] = next_act;
+      // the action block of step k + 1 is requested from HBM here, at the top of step k, and moved into the (by then
+      // dead) action slots of the LDS record in the middle of step k (ahead of phase F) — NOT at the top of step k + 1:
+      // on gfx9 loads and stores share one in-order counter, so a wait for this load right behind the record stores
+      // that end a step (y / obs rings) would wait for those stores too: a full HBM write latency per step
       if (valid && lane < adim) {
         const int blk = (ctl.act_first + tds_iter + 1) % ctl.act_blocks;
         next_act = (T)((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
       }
-      TDS_WAVE_SYNC();
     }
     // ---- rollout mode: action = W obs + b with the environment's own parameters
     //      (VectorizedEnvironment::policy -> NeuralNetwork::compute, one linear layer with bias, identity:
@@ -1367,6 +1369,20 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   const bool do_reward = last_run || ((pol || pool_r || ring_o) && mode == TDS_MODE_RUN);
   // where this step's y record goes, and whether it is packed at all: the handle's y record for the last normal step
   // of a launch, or — with a y ring — the ring slot of EVERY step
+  // one scalar into the obs ring: float or record dtype; streaming store, or (TDS_RING_NOFENCE) a device-scope
+  // write-through store that needs no cache write-back to become visible to the exchange
+  auto ring_put = [&](size_t idx, T v) {
+    const int rf = ctl.ring_flags;
+    if (rf & TDS_RING_OBS_F32) {
+      float *const p = (float *)ctl.obs_ring + idx;
+      if (rf & TDS_RING_NOFENCE) __hip_atomic_store(p, (float)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __builtin_nontemporal_store((float)v, p);
+    } else {
+      TR *const p = (TR *)ctl.obs_ring + idx;
+      if (rf & TDS_RING_NOFENCE) __hip_atomic_store(p, (TR)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __builtin_nontemporal_store((TR)v, p);
+    }
+  };
   const bool pack_y = ring_y ? (valid && mode == TDS_MODE_RUN) : (last_run && y_out != nullptr);
   TR *const y_step = ring_y ? (TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env) * out_dim
                             : y_out + (size_t)env * out_dim;
@@ -1769,73 +1785,81 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   const T qd = di >= 0 ? xr[nq + qdri] : T(0);
 
   // ---- PD controller (locomotion_contact_simulation.h:168-258) or direct torque -------------
+  // (a closure, evaluated right here under the latency of the constant loads.  Evaluating it just ahead of phase F, where
+  //  tau is first needed, was tried for the 18-dof kernels, whose 12 B of scratch are tau carried through the sweeps: the
+  //  allocator then spilled 20 B elsewhere — measured with tools/kernel_resources.sh, not kept)
   T tau = T(0);
-  if (step_mode == TDS_STEP_LOCOMOTION) {
-    const int ai = act_i;
-    if (ai >= 0) {
-      const int var = nq + nd + adim;
-      const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
-      T a = settling ? T(0) : xr[nq + nd + ai];  // reset settles with zero action
-      const T lim = act_lim;
-      a = a < lim ? a : lim;       // Algebra::min(clamped_action, ACTION_LIMIT)
-      a = a > -lim ? a : -lim;     // Algebra::max(clamped_action, -ACTION_LIMIT)
-      const T q_des = init_pose_l + a;
-      T f = kp * (q_des - q) + kd * (T(0) - qd);
-      f = f > -max_force ? f : -max_force;
-      f = f < max_force ? f : max_force;
-      tau = f;
-    } else if (sph && ai <= -2) {
-      // spherical branch (locomotion_contact_simulation.h:188-226): q_desired = identity, qd_desired = 0;
-      // position_error = matrix_to_euler_xyz(quat_to_matrix(inverse(identity) * q_actual)) (matrix_utils.hpp:18-90),
-      // lane k of the joint takes component k; the clamped force goes to tau (this lane was kept by the builder:
-      // floating base or link index >= 4, :215-221)
-      const int qo = sphq;
-      const int var = nq + nd + adim;
-      const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
-      const T qx = xr[qo], qy = xr[qo + 1], qz = xr[qo + 2], qw = xr[qo + 3];
-      const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);  // tiny_matrix3x3.h:315-340
-      const T xs = qx * s2, ys = qy * s2, zs = qz * s2;
-      const T wx = qw * xs, wy = qw * ys, wz = qw * zs;
-      const T xx = qx * xs, xy = qx * ys, xz = qx * zs;
-      const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
-      // get_matrix_elem(mat, k) = mat(k % 3, k / 3) (matrix_utils.hpp:11-16)
-      const T e0 = T(1) - (yy + zz), e3 = xy - wz, e1 = xy + wz, e4 = T(1) - (xx + zz);
-      const T fi = xz - wy, e5 = yz + wx, e8 = T(1) - (xx + yy);
-      const bool le = fi <= T(1), ge = fi >= T(-1);
-      const int k = jt - TDS_JOINT_SPH0;
-      T pe;
-      if (k == 1) {
-        pe = le ? (ge ? asin_t<T>(fi) : -T(1.57079632679489661923)) : T(1.57079632679489661923);
-      } else {
-        const bool mid = le && ge;
-        // k == 0: atan2(-e5, e8) | -atan2(e3, e4) | atan2(e3, e4);   k == 2: atan2(-e1, e0) | 0 | 0
-        const T ay = k == 0 ? (mid ? -e5 : e3) : -e1;
-        const T ax = k == 0 ? (mid ? e8 : e4) : e0;
-        const T a = atan2_t<T>(ay, ax);
-        pe = k == 0 ? ((le && !ge) ? -a : a) : (mid ? a : T(0));
+  constexpr bool LATE_PD = false;
+  auto compute_tau = [&]() {
+    if (step_mode == TDS_STEP_LOCOMOTION) {
+      const int ai = act_i;
+      if (ai >= 0) {
+        const int var = nq + nd + adim;
+        const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
+        T a = settling ? T(0) : xr[nq + nd + ai];  // reset settles with zero action
+        const T lim = act_lim;
+        a = a < lim ? a : lim;       // Algebra::min(clamped_action, ACTION_LIMIT)
+        a = a > -lim ? a : -lim;     // Algebra::max(clamped_action, -ACTION_LIMIT)
+        const T q_des = init_pose_l + a;
+        T f = kp * (q_des - q) + kd * (T(0) - qd);
+        f = f > -max_force ? f : -max_force;
+        f = f < max_force ? f : max_force;
+        tau = f;
+      } else if (sph && ai <= -2) {
+        // spherical branch (locomotion_contact_simulation.h:188-226): q_desired = identity, qd_desired = 0;
+        // position_error = matrix_to_euler_xyz(quat_to_matrix(inverse(identity) * q_actual)) (matrix_utils.hpp:18-90),
+        // lane k of the joint takes component k; the clamped force goes to tau (this lane was kept by the builder:
+        // floating base or link index >= 4, :215-221)
+        const int qo = sphq;
+        const int var = nq + nd + adim;
+        const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
+        const T qx = xr[qo], qy = xr[qo + 1], qz = xr[qo + 2], qw = xr[qo + 3];
+        const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);  // tiny_matrix3x3.h:315-340
+        const T xs = qx * s2, ys = qy * s2, zs = qz * s2;
+        const T wx = qw * xs, wy = qw * ys, wz = qw * zs;
+        const T xx = qx * xs, xy = qx * ys, xz = qx * zs;
+        const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
+        // get_matrix_elem(mat, k) = mat(k % 3, k / 3) (matrix_utils.hpp:11-16)
+        const T e0 = T(1) - (yy + zz), e3 = xy - wz, e1 = xy + wz, e4 = T(1) - (xx + zz);
+        const T fi = xz - wy, e5 = yz + wx, e8 = T(1) - (xx + yy);
+        const bool le = fi <= T(1), ge = fi >= T(-1);
+        const int k = jt - TDS_JOINT_SPH0;
+        T pe;
+        if (k == 1) {
+          pe = le ? (ge ? asin_t<T>(fi) : -T(1.57079632679489661923)) : T(1.57079632679489661923);
+        } else {
+          const bool mid = le && ge;
+          // k == 0: atan2(-e5, e8) | -atan2(e3, e4) | atan2(e3, e4);   k == 2: atan2(-e1, e0) | 0 | 0
+          const T ay = k == 0 ? (mid ? -e5 : e3) : -e1;
+          const T ax = k == 0 ? (mid ? e8 : e4) : e0;
+          const T a = atan2_t<T>(ay, ax);
+          pe = k == 0 ? ((le && !ge) ? -a : a) : (mid ? a : T(0));
+        }
+        T f = kp * pe + kd * (T(0) - qd);
+        f = f > -max_force ? f : -max_force;
+        f = f < max_force ? f : max_force;
+        tau = f;
       }
-      T f = kp * pe + kd * (T(0) - qd);
-      f = f > -max_force ? f : -max_force;
-      f = f < max_force ? f : max_force;
-      tau = f;
+    } else if (di >= 0 && di < adim) {  // (adim == joint dofs: the base dofs of a floating base carry no torque)
+      tau = settling ? T(0) : xr[nq + nd + di];
     }
-  } else if (di >= 0 && di < adim) {  // (adim == joint dofs: the base dofs of a floating base carry no torque)
-    tau = settling ? T(0) : xr[nq + nd + di];
-  }
-  // joint stiffness / damping (forward_dynamics.hpp:122-123)
-  if (isl) tau -= stiff_l * q + damp_l * qd;
-  if constexpr (sph) {
-    // spherical joint: tau -= stiffness * quaternion_axis_angle(quat) (forward_dynamics.hpp:70-74,
-    // tiny_algebra.hpp:509-527), component k on lane k (q == 0 on these lanes)
-    if (sphq >= 0 && stiff_l != T(0)) {
-      const T qx = xr[sphq], qy = xr[sphq + 1], qz = xr[sphq + 2], qw = xr[sphq + 3];
-      const T qn = sqrt_t<T>(qx * qx + qy * qy + qz * qz);
-      const T theta = T(2) * atan2_t<T>(qn, qw);
-      // pow(epsilon, 1/4) = 2^-13
-      const T sc = qn < T(1.220703125e-4) ? T(1) / (T(0.5) + theta * theta * (T(1) / T(48))) : theta / qn;
-      tau -= stiff_l * sc * xr[sphq + (jt - TDS_JOINT_SPH0)];
+    // joint stiffness / damping (forward_dynamics.hpp:122-123)
+    if (isl) tau -= stiff_l * q + damp_l * qd;
+    if constexpr (sph) {
+      // spherical joint: tau -= stiffness * quaternion_axis_angle(quat) (forward_dynamics.hpp:70-74,
+      // tiny_algebra.hpp:509-527), component k on lane k (q == 0 on these lanes)
+      if (sphq >= 0 && stiff_l != T(0)) {
+        const T qx = xr[sphq], qy = xr[sphq + 1], qz = xr[sphq + 2], qw = xr[sphq + 3];
+        const T qn = sqrt_t<T>(qx * qx + qy * qy + qz * qz);
+        const T theta = T(2) * atan2_t<T>(qn, qw);
+        // pow(epsilon, 1/4) = 2^-13
+        const T sc = qn < T(1.220703125e-4) ? T(1) / (T(0.5) + theta * theta * (T(1) / T(48))) : theta / qn;
+        tau -= stiff_l * sc * xr[sphq + (jt - TDS_JOINT_SPH0)];
+      }
     }
-  }
+
+  };
+  if constexpr (!LATE_PD) compute_tau();
 
   TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
@@ -2174,7 +2198,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     // the ring records of the PREVIOUS step have long left this wavefront: make them visible device-wide and count
     // this workgroup in (TdsStepCtl::progress; what the exchange of the multi-GPU layer polls, tds_shard.hip)
     if (ctl.progress != nullptr && tds_iter > 0) {  // wave-uniform
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (ctl.ring_flags & TDS_RING_NOFENCE)
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the obs ring's write-through stores have reached the L2 / memory
+      else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl.progress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -2565,6 +2592,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     //         lanes to the dof lanes through the (now free) column scratch of dvec.
     T *const rhsx = dvec + 2 * NDP;
     if (lane < NDP) rhsx[lane] = T(0);
+    if constexpr (LATE_PD) compute_tau();
+    if constexpr (LOOP) {
+      // (action replay: the NEXT step's action block, requested at the top of this step, goes into the action slots of
+      //  the record — nobody reads them any more in this step: the PD block has long turned them into tau)
+      if (replay && mode == TDS_MODE_RUN && lane < adim) xr[nq + nd + lane] = next_act;
+    }
     TDS_WAVE_SYNC();
     if (di >= 0) rhsx[di] = tau - Cb;
     TDS_WAVE_SYNC();
@@ -3019,13 +3052,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     if constexpr (LOOP) {
       if (ring_o) {  // reward / done of THIS step into its ring slot (the observation follows at the end of the step)
         const size_t at = ((size_t)((ctl.obs_first + tds_iter) % ctl.obs_slots) * ctl.ring_envs + env) * (nq + nd + 2) + nq + nd;
-        if (ctl.ring_flags & TDS_RING_OBS_F32) {
-          __builtin_nontemporal_store((float)reward, (float *)ctl.obs_ring + at);
-          __builtin_nontemporal_store(done ? 1.0f : 0.0f, (float *)ctl.obs_ring + at + 1);
-        } else {
-          __builtin_nontemporal_store((TR)reward, (TR *)ctl.obs_ring + at);
-          __builtin_nontemporal_store(done ? TR(1) : TR(0), (TR *)ctl.obs_ring + at + 1);
-        }
+        ring_put(at, reward);
+        ring_put(at + 1, done ? T(1) : T(0));
       }
     }
     xr[in_dim + 1] = done ? T(1) : T(0);
@@ -3142,11 +3170,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     //      while reward / done (written above) describe the step that ended (ars_vectorized_environment.h:262-277)
     if (ring_o && do_reward && valid) {
       const size_t at = ((size_t)((ctl.obs_first + tds_iter) % ctl.obs_slots) * ctl.ring_envs + env) * (nq + nd + 2);
-      if (ctl.ring_flags & TDS_RING_OBS_F32) {
-        for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store(i < 2 ? 0.0f : (float)xr[i], (float *)ctl.obs_ring + at + i);
-      } else {
-        for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store(i < 2 ? TR(0) : (TR)xr[i], (TR *)ctl.obs_ring + at + i);
-      }
+      for (int i = lane; i < nq + nd; i += G) ring_put(at + i, i < 2 ? T(0) : xr[i]);
     }
     // ---- the environment is done with this launch: observation (obs[0] = obs[1] = 0,
     //      ars_vectorized_environment.h:283-288) and resident state

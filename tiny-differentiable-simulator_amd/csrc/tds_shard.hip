@@ -52,7 +52,9 @@ Rccl *rccl() {
   if (tried) return r.ok ? &r : nullptr;
   tried = true;
   const char *names[] = {getenv("TDS_HIP_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-  // a copy already mapped into the process (PyTorch's) wins
+  // an explicitly named library wins (RTLD_LOCAL: its nccl* symbols must not shadow anybody else's) ...
+  if (names[0] && names[0][0]) r.handle = dlopen(names[0], RTLD_NOW | RTLD_LOCAL);
+  // ... then a copy already mapped into the process (PyTorch's)
   for (const char *n : names)
     if (n && !r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
   for (const char *n : names)
