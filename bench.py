@@ -177,8 +177,9 @@ def main():
     ap.add_argument("--ring-slots", type=int, default=64, help="slots of the two record rings (a slot is reused that many steps later)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements of the default N = 1 line (substep_fused, one_rank_with_exchange, auto_reset_rate)")
-    ap.add_argument("--shard-eager", action="store_true",
-                    help="N > 1: submit the ring exchange eagerly (TDS_HIP_SHARD_NO_GRAPH=1) instead of one hipGraph per launch")
+    ap.add_argument("--shard-graph", action="store_true",
+                    help="N > 1: replay each step-loop launch + its exchanges from one hipGraph (TDS_HIP_SHARD_GRAPH=1) instead of "
+                         "submitting the exchange eagerly (the default: faster on ROCm 7)")
     ap.add_argument("--step-many-form", choices=["auto", "graph", "loop"], default="auto",
                     help="N = 1: how tds_hip_step_many runs the K steps — chained hipGraphs of single-step launches, ONE "
                          "launch of the step-loop kernel, or the library's choice (loop for worlds without contacts and "
@@ -233,8 +234,8 @@ def main():
 
     if args.step_many_form != "auto":
         os.environ["TDS_HIP_STEP_MANY_LOOP"] = "1" if args.step_many_form == "loop" else "0"
-    if args.shard_eager:
-        os.environ["TDS_HIP_SHARD_NO_GRAPH"] = "1"
+    if args.shard_graph:
+        os.environ["TDS_HIP_SHARD_GRAPH"] = "1"
     import tds_amd
     from tds_amd import hip_backend
 
@@ -718,8 +719,9 @@ def main():
         elif multi and ring_exchange:
             launch = ("one launch of the step-loop kernel per %d steps, EVERY step packing and storing its y record and its "
                       "[obs | reward | done] record into ring slots; the communication stream follows the launch's per-step "
-                      "progress counter and all-gathers each obs slot (launch + its exchanges = one hipGraph%s)"
-                      % (min(K, 64), "" if os.environ.get("TDS_HIP_SHARD_NO_GRAPH") is None else "; submitted eagerly"))
+                      "progress counter and all-gathers each obs slot (%s)"
+                      % (min(K, 64), "launch + its exchanges = one hipGraph" if os.environ.get("TDS_HIP_SHARD_GRAPH") == "1"
+                         else "exchange submitted eagerly while the launch runs"))
         elif loop_form and use_rings:
             launch = ("one launch of the step-loop kernel per %d steps (state in LDS across the steps, one action block per "
                       "step), EVERY step running the whole output packing — visual poses, y record, reward / done, "

@@ -515,9 +515,11 @@ int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const 
    n_steps steps are step-loop launches of up to 64 steps — the very launches of tds_hip_step_many_rings, with the obs
    ring in the wire dtype and a y ring, i.e. the same work per step as a single GPU does — and the communication stream
    sends ring slot k as soon as the running launch has counted all its workgroups in for step k (a device counter the
-   stream polls with a one-lane kernel): one ncclAllGather per policy step, no host call per step, no kernel boundary
-   per step.  Each launch + its exchanges is one hipGraph (cached by arguments).  tds_hip_shard_gathered then returns the
-   slot of the last step, [world][n_local][obs_dim + 2].  TDS_HIP_SHARD_RING=0 forces the per-step-launch form. */
+   stream polls with a one-lane kernel): one ncclAllGather per policy step, no kernel boundary per step, the host's two
+   calls per step (wait, all-gather) issued while the launch runs.  TDS_HIP_SHARD_GRAPH=1 replays each launch + its
+   exchanges from one hipGraph instead (cached by arguments; slower on ROCm 7: a chain of dependent graph nodes pays a
+   node-to-node latency a stream does not).  tds_hip_shard_gathered then returns the slot of the last step,
+   [world][n_local][obs_dim + 2].  TDS_HIP_SHARD_RING=0 forces the per-step-launch form. */
 int tds_hip_shard_step_many(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks, int first_block,
                             int n_steps);
 /* capture + instantiate the graph of the next tds_hip_shard_step_many with the same arguments; nothing executes */

@@ -336,8 +336,8 @@ def test_shard_ring_exchange_on_one_rank(with_rccl, submit, wire, built, monkeyp
     torch = _torch()
     if with_rccl and hip_backend.HipShard.rccl_version() == 0:
         pytest.skip("librccl cannot be loaded on this machine")
-    if submit == "eager":
-        monkeypatch.setenv("TDS_HIP_SHARD_NO_GRAPH", "1")
+    if submit == "graph":
+        monkeypatch.setenv("TDS_HIP_SHARD_GRAPH", "1")
     m = tds_amd.load_model("ant")
     n = 1000
     x, acts = _start(m, n, seed=41)

@@ -100,14 +100,18 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
         x[:, nq + nd:nq + nd + adim] = a
         y_ref = ref_step(x)
         assert np.isfinite(y_ref).all()
-        e = rel_err(yr[k], y_ref, floor=1e-3)
+        # (float records: the launch keeps the state in DOUBLE across its steps while this comparison restarts the
+        #  reference from the float-rounded record of the previous slot — from the second slot on, components are held to
+        #  the float rounding of the state, 6e-8 of O(1) lever arms, not to 1e-6 of their own (possibly tiny) size)
+        floor = 1e-3 if (dtype == "f64" or k == 0) else 0.1
+        e = rel_err(yr[k], y_ref, floor=floor)
         worst = max(worst, e)
         assert e < tol, (name, k, e)
         # the [obs | reward | done] record of the step
         rew, done = _reward_done(m, name, x[:, :nq], y_ref)
         ob = y_ref[:, :nq + nd].copy()
         ob[:, :2] = 0.0
-        assert rel_err(orr[k][:, :nq + nd], ob) < tol, (name, k)
+        assert rel_err(orr[k][:, :nq + nd], ob, floor=floor) < tol, (name, k)
         if m.reward_mode != tds_amd.TDS_REWARD_NONE:
             # (an environment within round-off of a termination threshold may fall on either side)
             edge = np.zeros(n, bool)
@@ -214,7 +218,10 @@ def test_rings_with_auto_reset(name, built):
     n, steps = 256, 40
     rng = np.random.default_rng(8)
     x0 = _start_state(m, name, n, rng)
-    x0[: n // 2, 2] = 0.27 if name == "ant" else 0.25  # half of them about to end
+    if name == "ant":
+        x0[: n // 2, 2] = 0.27  # half of them about to end (done: z < 0.26)
+    else:
+        x0[: n // 2, 3] = 0.9   # ... rolled over far enough (done: up . z = cos(roll) cos(pitch) < 0.6)
     sims = [hip_backend.HipSim(m, n, dtype="f64") for _ in range(2)]
     for s in sims:
         s.x.copy_(torch.from_numpy(x0).cuda())

@@ -82,8 +82,9 @@ def stub_lib(tmp_path_factory):
 
 
 @pytest.mark.parametrize("mode,name,steps,env", [
-    ("many", "ant", 75, {}),                                   # ring exchange, one hipGraph per step-loop launch
-    ("many", "ant", 75, {"TDS_HIP_SHARD_NO_GRAPH": "1"}),      # ring exchange submitted eagerly
+    ("many", "ant", 75, {}),                                   # ring exchange submitted eagerly (the default)
+    ("many", "ant", 75, {"TDS_HIP_SHARD_GRAPH": "1"}),         # ring exchange, one hipGraph per step-loop launch
+    ("many", "ant", 75, {"TDS_HIP_RING_NOFENCE": "0"}),        # records made visible by a release fence instead of write-through stores
     ("many", "pendulum5", 30, {}),                             # a world without contacts (always the step-loop form)
     ("many", "ant", 12, {"TDS_HIP_SHARD_RING": "0"}),          # per-step launches + exchanges from one hipGraph
     ("many", "laikago", 9, {}),                                # a model whose step_many is not the step-loop form
@@ -123,5 +124,7 @@ def test_two_ranks_on_one_gpu(mode, name, steps, env, built, stub_lib, tmp_path)
         assert got.shape == want.shape
         # the records crossed "the wire" as floats; ring form and its reference come from the same step-loop build, the
         # per-step forms from the same straight-line build: equal bit for bit
-        assert np.array_equal(got, want), (k, np.abs(got - want).max())
-        assert np.array_equal(r[k]["x"], r[k]["xref"])
+        # (random states driven by random actions: a few environments leave the finite range on the way)
+        assert np.array_equal(got, want, equal_nan=True), (k, np.nanmax(np.abs(got - want)))
+        assert np.isfinite(want).mean() > 0.9
+        assert np.array_equal(r[k]["x"], r[k]["xref"], equal_nan=True)

@@ -143,7 +143,9 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
       if (r.obs_f32) ctl.ring_flags |= TDS_RING_OBS_F32;
       // (how a step's records are made visible to the exchange before its progress count: write-through stores + a
       //  plain wait, or streaming stores + a release fence — TDS_HIP_RING_NOFENCE=0 / 1)
-      static const bool nofence = [] { const char *e = getenv("TDS_HIP_RING_NOFENCE"); return e ? e[0] == '1' : false; }();
+      // Default: write-through.  The release fence's buffer_wbl2 writes back every dirty line of the L2 on every step of
+      // every workgroup: + 9 us per 4096-environment step (profiles/r03_ring_exchange_forms.txt).
+      static const bool nofence = [] { const char *e = getenv("TDS_HIP_RING_NOFENCE"); return e ? e[0] == '1' : true; }();
       if (r.progress && nofence) ctl.ring_flags |= TDS_RING_NOFENCE;
     }
     if (r.y_ring) {

@@ -114,6 +114,26 @@ __device__ __forceinline__ float rcp_full<float>(float d) {
   const float e = __builtin_fmaf(-d, r, 1.0f);
   return __builtin_fmaf(r, e, r);
 }
+// 1/sqrt(x): hardware estimate + two Newton-Raphson steps (the estimate is good to ~2^-26 in double, each step squares
+// the error: ~1e-16 after the second).  x > 0 in the normal range (1 + trace of a rotation matrix and its like).
+// sqrt(x) = x * r and c / sqrt(x) = c * r replace an IEEE square root AND an IEEE division (~60 instructions) by ~10.
+template <typename T>
+__device__ __forceinline__ T rsqrt_full(T x);
+template <>
+__device__ __forceinline__ double rsqrt_full<double>(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  r = __builtin_fma(r, __builtin_fma(-hx * r, r, 0.5), r);
+  r = __builtin_fma(r, __builtin_fma(-hx * r, r, 0.5), r);
+  return r;
+}
+template <>
+__device__ __forceinline__ float rsqrt_full<float>(float x) {
+  float r = __builtin_amdgcn_rsqf(x);
+  const float hx = 0.5f * x;
+  r = __builtin_fmaf(r, __builtin_fmaf(-hx * r, r, 0.5f), r);
+  return r;
+}
 template <typename T>
 __device__ __forceinline__ T atan2_t(T y, T x);
 template <>
@@ -368,9 +388,11 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
     } else {
       mii = m[8]; mjj = m[0]; mkk = m[4]; mjk = m[1]; mkj = m[3]; mij = m[6]; mji = m[2]; mik = m[7]; mki = m[5];
     }
-    T s = sqrt_t<T>(((mii - mjj) - mkk) + T(1));
-    const T ti = s * T(0.5);
-    s = T(0.5) / s;
+    // (s = sqrt(a), ti = s / 2, then s = 0.5 / s:  with r = 1 / sqrt(a):  ti = a r / 2,  s = r / 2)
+    const T a_ = ((mii - mjj) - mkk) + T(1);
+    const T r_ = rsqrt_full<T>(a_);
+    const T ti = a_ * r_ * T(0.5);
+    const T s = T(0.5) * r_;
     t3 = (mjk - mkj) * s;
     const T tj = (mij + mji) * s;
     const T tk = (mik + mki) * s;
@@ -378,9 +400,10 @@ __device__ __forceinline__ void matrix_to_quat(const T *m, T *q) {
     else if (i == 1) { t1 = ti; t2 = tj; t0 = tk; }
     else { t2 = ti; t0 = tj; t1 = tk; }
   } else {
-    T s = sqrt_t<T>(trace + T(1));
-    t3 = s * T(0.5);
-    s = T(0.5) / s;
+    const T a_ = trace + T(1);
+    const T r_ = rsqrt_full<T>(a_);
+    t3 = a_ * r_ * T(0.5);
+    const T s = T(0.5) * r_;
     t0 = (m[5] - m[7]) * s;
     t1 = (m[6] - m[2]) * s;
     t2 = (m[1] - m[3]) * s;
@@ -1383,6 +1406,32 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       else __builtin_nontemporal_store((TR)v, p);
     }
   };
+  // Plain kernels (KIND 0) store the END-of-step records of a ring launch — the state part + tail of the y record, the
+  // whole obs record — from the LDS record in the MIDDLE of the following step, behind that step's visual poses: on gfx9
+  // loads and stores drain through ONE in-order counter, so the first wait for a load at the top of a step would also
+  // wait for record stores issued at the end of the step before — a full HBM write latency on every step.  Behind the
+  // visual poses no load is waited for until the next step begins.  (The last step of a launch and environments that
+  // the reset pool re-initialises store at once.)
+  constexpr bool DEFER = LOOP && KIND == 0;
+  auto put_y_state = [&](TR *yo) {  // q | qd | (visual poses: phase M1) | up.z | zero padding, from the LDS record
+    for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)xr[i], &yo[i]);
+    int tail = nq + nd;
+    if (mdl->pack_visuals) {
+      tail += 7 * mdl->num_visuals;
+      if (lane == 0) __builtin_nontemporal_store((TR)(mdl->base_R[8]), &yo[tail]);  // up_dot_world_z (fixed base)
+      tail += 1;
+    }
+    for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
+  };
+  // [q | qd with obs[0] = obs[1] = 0 | reward | done] of ring slot `slot` (ars_vectorized_environment.h:250-289): the
+  // observation from the LDS record as it is NOW, reward / done from their LDS slots (written by the reward block)
+  auto put_obs = [&](int slot) {
+    const size_t at = ((size_t)slot * ctl.ring_envs + env) * (nq + nd + 2);
+    for (int i = lane; i < nq + nd + 2; i += G) {
+      const int src = i < nq + nd ? i : (i == nq + nd ? in_dim + 2 : in_dim + 1);
+      ring_put(at + i, i < 2 ? T(0) : xr[src]);
+    }
+  };
   const bool pack_y = ring_y ? (valid && mode == TDS_MODE_RUN) : (last_run && y_out != nullptr);
   TR *const y_step = ring_y ? (TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env) * out_dim
                             : y_out + (size_t)env * out_dim;
@@ -2194,17 +2243,6 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   TDS_WAVE_SYNC();
 
   TDS_STAMP(3);
-  if constexpr (LOOP) {
-    // the ring records of the PREVIOUS step have long left this wavefront: make them visible device-wide and count
-    // this workgroup in (TdsStepCtl::progress; what the exchange of the multi-GPU layer polls, tds_shard.hip)
-    if (ctl.progress != nullptr && tds_iter > 0) {  // wave-uniform
-      if (ctl.ring_flags & TDS_RING_NOFENCE)
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the obs ring's write-through stores have reached the L2 / memory
-      else
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl.progress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   // ---- I. narrowphase right after the kinematics sweep (it only needs X_world), so that the
   //         LDS holding X_world / v can be recycled by the dynamics sweeps
   // ---- I + M1. narrowphase and visual poses right after the kinematics sweep (they only need X_world), so that the
@@ -2240,6 +2278,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       NB_pairs = wave_max(nb_pairs);
     }
     phase_M1();
+    if constexpr (DEFER) {
+      // the end-of-step records of the PREVIOUS step, from the LDS record (whose state part this step has not touched yet)
+      if ((ring_o || ring_y) && tds_iter > 0 && valid && mode == TDS_MODE_RUN && xr[in_dim + 3] == T(0)) {
+        if (ring_y)
+          put_y_state((TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter - 1) % ctl.y_slots) * ctl.ring_envs + env) * out_dim);
+        if (ring_o) put_obs((ctl.obs_first + tds_iter - 1) % ctl.obs_slots);
+      }
+    }
     TDS_WAVE_SYNC();  // X_world / v in LDS are dead from here on (their space is reused)
   }
 
@@ -2597,6 +2643,16 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       // (action replay: the NEXT step's action block, requested at the top of this step, goes into the action slots of
       //  the record — nobody reads them any more in this step: the PD block has long turned them into tau)
       if (replay && mode == TDS_MODE_RUN && lane < adim) xr[nq + nd + lane] = next_act;
+      // the ring records of the PREVIOUS step left this wavefront half a step ago (behind this step's visual poses):
+      // make them visible device-wide and count this workgroup in (TdsStepCtl::progress — what the exchange of the
+      // multi-GPU layer polls, tds_shard.hip)
+      if (ctl.progress != nullptr && tds_iter > 0) {  // wave-uniform
+        if (ctl.ring_flags & TDS_RING_NOFENCE)
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the obs ring's write-through stores have reached the L2 / memory
+        else
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl.progress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     TDS_WAVE_SYNC();
     if (di >= 0) rhsx[di] = tau - Cb;
@@ -2989,7 +3045,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   TDS_WAVE_SYNC();
 
   // ---- y record (q, qd, up, zero padding; the visual poses went out in M1) of the last normal step
-  if (pack_y) {
+  if (pack_y && !(DEFER && ring_y)) {
     TR *const yo = y_step;
     if (gen) {  // the q record is not one coordinate per lane: copy it out as it is
       for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)(xr[i]), &yo[i]);
@@ -3050,11 +3106,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       ob[nq + nd + 1] = (done || frozen) ? TR(1) : TR(0);
     }
     if constexpr (LOOP) {
-      if (ring_o) {  // reward / done of THIS step into its ring slot (the observation follows at the end of the step)
-        const size_t at = ((size_t)((ctl.obs_first + tds_iter) % ctl.obs_slots) * ctl.ring_envs + env) * (nq + nd + 2) + nq + nd;
-        ring_put(at, reward);
-        ring_put(at + 1, done ? T(1) : T(0));
-      }
+      if (ring_o) xr[in_dim + 2] = reward;  // (the obs record is stored from the LDS record: put_obs)
     }
     xr[in_dim + 1] = done ? T(1) : T(0);
   }
@@ -3106,6 +3158,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     TDS_WAVE_SYNC();
     const bool done_now = do_reward && xr[in_dim + 1] != T(0);
     const bool auto_r = ctl.reset_mode == TDS_RESET_AUTO;
+    // ring records of this step: stored now — the last step of the launch; an environment the pool re-initialises below
+    // (its y record describes the TERMINAL state, which the pool entry is about to overwrite) — or in the middle of the
+    // next step (DEFER, see put_y_state)
+    const bool ring_step = (ring_o || ring_y) && valid && mode == TDS_MODE_RUN;
+    const bool ring_now = ring_step && (!DEFER || last_run || (pool_r && done_now));
+    if constexpr (DEFER) {
+      if (ring_y && ring_now) put_y_state(y_step);
+    }
 
     // ---- mode transition of this lane group
     bool finished = false;
@@ -3168,9 +3228,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     // ---- per-step observation record (ring): [q | qd] with obs[0] = obs[1] = 0 (ars_vectorized_environment.h:283-288) of
     //      the state the NEXT step starts from — after an auto-reset through the pool that is the fresh environment,
     //      while reward / done (written above) describe the step that ended (ars_vectorized_environment.h:262-277)
-    if (ring_o && do_reward && valid) {
-      const size_t at = ((size_t)((ctl.obs_first + tds_iter) % ctl.obs_slots) * ctl.ring_envs + env) * (nq + nd + 2);
-      for (int i = lane; i < nq + nd; i += G) ring_put(at + i, i < 2 ? T(0) : xr[i]);
+    if (ring_o && ring_now) put_obs((ctl.obs_first + tds_iter) % ctl.obs_slots);
+    if constexpr (DEFER) {
+      if (ring_step && lane == 0) xr[in_dim + 3] = ring_now ? T(1) : T(0);  // "the records of this step are out"
     }
     // ---- the environment is done with this launch: observation (obs[0] = obs[1] = 0,
     //      ars_vectorized_environment.h:283-288) and resident state
@@ -3232,8 +3292,9 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   L.ovrows = 3 * nct - L.zrows;    // surplus rows per environment (global scratch slab)
   int o = 0;
   // persistent for the whole step
-  L.xrec = o; o += m.input_dim + 2 + (w2 ? 4 : 0);  // + x_{t-1} and the done flag of the step loop (+ contact counts
-                                                    //   handed from the helper to the main wavefront)
+  L.xrec = o; o += m.input_dim + 4 + (w2 ? 2 : 0);  // + x_{t-1}, the done flag, the reward and the "records are out" flag of
+                                                    //   the step loop (two-wavefront layout: + 2 .. + 5 are the contact counts
+                                                    //   and flags handed between the wavefronts)
   // two pairs with disjoint lifetimes share their storage:
   //   swd  (world motion axes per dof: phases C..J)  |  rows (b, 1/(G+cfm), G per constraint row: K..L)
   //   cp   (contact points: phases I..K)             |  xrow (impulses x of all rows: L)

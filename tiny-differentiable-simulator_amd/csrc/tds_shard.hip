@@ -485,7 +485,12 @@ int ring_many(tds_hip_shard *sh, const void *actions_dev, int pool, int first, i
   TdsRingChunk plan[4096 / TDS_SHARD_CHUNK + 1];
   const int nc = tds_ring_plan(sh->chunks, n_steps, first, pool, plan, (int)(sizeof(plan) / sizeof(plan[0])));
   if (nc < 0) return fail(TDS_ERR_INVALID_ARG, "n_steps too large");
-  const bool want_graph = getenv("TDS_HIP_SHARD_NO_GRAPH") == nullptr;
+  // Submitted eagerly by default: 2 host calls per step (wait kernel, all-gather), issued while the launch runs.  As
+  // ONE hipGraph per launch (TDS_HIP_SHARD_GRAPH=1) the same nodes replay ~10 us per step SLOWER on ROCm 7 — measured,
+  // profiles/r03_ring_exchange_forms.txt: a chain of 128 dependent kernel / copy nodes pays a node-to-node latency the
+  // stream does not.
+  const char *ge = getenv("TDS_HIP_SHARD_GRAPH");
+  const bool want_graph = ge && ge[0] == '1' && getenv("TDS_HIP_SHARD_NO_GRAPH") == nullptr;
   for (int i = 0; i < nc; ++i) {
     const TdsRingChunk &ck = plan[i];
     tds_hip_shard::RingGraph *g = want_graph ? ring_graph_find(sh, actions_dev, pool, ck) : nullptr;

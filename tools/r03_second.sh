@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (round 3, second contact): all ring / shard tests, benches of the per-step-record form, kernel
 # trace of the one-rank ring exchange.
 export TMPDIR=/tmp
-O=gpurun_out/r03b
+O=gpurun_out/r03c
 mkdir -p $O
 timeout 900 python -m pytest tests/test_rings.py -m gpu -q --timeout 300 -s > $O/pytest_rings.log 2>&1; tail -3 $O/pytest_rings.log
 timeout 900 python -m pytest tests/test_shard_two_ranks_one_gpu.py -m gpu -q --timeout 280 > $O/pytest_two.log 2>&1; tail -3 $O/pytest_two.log
@@ -10,14 +10,16 @@ timeout 600 python -m pytest tests/test_multi_gpu.py -m gpu -q --timeout 200 > $
 B="timeout 300 python bench.py --no-cpu-baseline"
 $B --steps 20 --warmup 5 > $O/bench_default20.json 2> $O/bench_default20.err
 $B --steps 1000 --warmup 100 > $O/bench_1000.json 2> $O/bench_1000.err
+$B --steps 1000 --warmup 100 --records last --no-secondary > $O/bench_1000_last.json 2> $O/bench_1000_last.err
 $B --steps 1000 --warmup 100 --force-gather > $O/bench_fg1000.json 2> $O/bench_fg1000.err
-$B --steps 1000 --warmup 100 --force-gather --shard-eager > $O/bench_fg1000_eager.json 2> $O/bench_fg1000_eager.err
-TDS_BENCH_RCCL_SINGLE=0 $B --steps 1000 --warmup 100 --force-gather > $O/bench_fg1000_copy.json 2> $O/bench_fg1000_copy.err
-TDS_BENCH_RCCL_SINGLE=0 $B --steps 1000 --warmup 100 --force-gather --shard-eager > $O/bench_fg1000_copy_eager.json 2> $O/bench_fg1000_copy_eager.err
-TDS_HIP_RING_NOFENCE=1 $B --steps 1000 --warmup 100 --force-gather --shard-eager > $O/bench_fg1000_nofence_eager.json 2> $O/bench_fg1000_nofence_eager.err
-TDS_HIP_RING_NOFENCE=1 TDS_BENCH_RCCL_SINGLE=0 $B --steps 1000 --warmup 100 --force-gather > $O/bench_fg1000_nofence_copy.json 2> $O/bench_fg1000_nofence_copy.err
-for V in fg fg_eager; do
-  EX=$( [ $V = fg_eager ] && echo --shard-eager )
+$B --steps 20 --warmup 5 --force-gather > $O/bench_fg20.json 2> $O/bench_fg20.err
+$B --steps 1000 --warmup 100 --force-gather --shard-graph > $O/bench_fg1000_graph.json 2> $O/bench_fg1000_graph.err
+TDS_HIP_RING_NOFENCE=0 $B --steps 1000 --warmup 100 --force-gather > $O/bench_fg1000_fence.json 2> $O/bench_fg1000_fence.err
+$B --steps 500 --warmup 50 --envs-per-gpu 8192 > $O/bench_8192.json 2> $O/bench_8192.err
+$B --steps 500 --warmup 50 --model laikago_soft --envs-per-gpu 8192 --no-secondary > $O/bench_laikago.json 2> $O/bench_laikago.err
+$B --steps 500 --warmup 50 --model pendulum5 --dtype f32 --no-secondary > $O/bench_pendulum5.json 2> $O/bench_pendulum5.err
+for V in fg; do
+  EX=
   rocprofv3 --kernel-trace --stats -d $O/kt_$V -o k -- python bench.py --no-cpu-baseline --steps 192 --warmup 64 --force-gather --spin-up-steps 0 $EX > $O/kt_$V.log 2>&1
   DB=$(ls $O/kt_$V/*.db $O/kt_$V/*/*.db 2>/dev/null | head -1)
   python tools/rocprof_summary.py "$DB" > $O/kt_${V}_stats.txt 2>&1
