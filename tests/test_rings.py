@@ -221,7 +221,7 @@ def test_rings_with_auto_reset(name, built):
     if name == "ant":
         x0[: n // 2, 2] = 0.27  # half of them about to end (done: z < 0.26)
     else:
-        x0[: n // 2, 3] = 0.9   # ... rolled over far enough (done: up . z = cos(roll) cos(pitch) < 0.6)
+        x0[: n // 2, 3] = 1.05  # ... rolled over far enough (done: up . z = cos(roll) cos(pitch) < 0.6)
     sims = [hip_backend.HipSim(m, n, dtype="f64") for _ in range(2)]
     for s in sims:
         s.x.copy_(torch.from_numpy(x0).cuda())

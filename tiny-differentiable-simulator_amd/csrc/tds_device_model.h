@@ -77,6 +77,14 @@ struct DevModel {
   // rounds for up to 16 links) instead of one tree level per link; the level loop then starts at kin_lev0, the first
   // level that holds a link outside the chain.  (>= root_last; a pendulum is all chain.)
   int kin_chain_last, kin_lev0;
+  // The root chain of the URDF-derived fixed-base robots in closed form: links 0..5 = prismatic X, Y, Z, revolute X, Y, Z
+  // with identity X_T (the Ant, Laikago: Appendix A of SURVEY.md), links 0..4 massless without shapes or visuals.
+  // World transform, motion axes, velocity and bias acceleration of link 5 then follow from six broadcasts of
+  // (q, sin q, cos q, qd) without any scan over the chain.  0: no; 1: yes (the base frame's rotation is the identity too).
+  int euler_root;
+  // 1: link i carries dof i for every link (lane == link == dof: the Ant; not Laikago, whose fixed toes own no dof) —
+  // per-link results that feed per-dof computations then stay in the lane's registers instead of crossing through LDS
+  int dof_identity;
   T X_T[12][TDS_NL];            // rot (row-major 9) | trans (3)
   T S[6][TDS_NL];
   T mass[TDS_NL], com[3][TDS_NL], inertia[9][TDS_NL];
@@ -358,6 +366,33 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
       }
     }
   }
+  d->euler_root = 0;
+  {
+    const char *ne = getenv("TDS_HIP_NO_EULERROOT");
+    bool ok = !(ne && ne[0] == '1') && !fl && d->num_spherical == 0 && !d->two_bodies && d->root_last == 5 &&
+              d->kin_chain_last == 5 && m->num_links > 6;
+    static const int want[6] = {TDS_JOINT_PRISMATIC_X, TDS_JOINT_PRISMATIC_Y, TDS_JOINT_PRISMATIC_Z,
+                                TDS_JOINT_REVOLUTE_X,  TDS_JOINT_REVOLUTE_Y,  TDS_JOINT_REVOLUTE_Z};
+    for (int i = 0; ok && i < 6; ++i) {
+      const tds_link_t &l = m->links[i];
+      ok = l.joint_type == want[i] && l.parent == i - 1 && l.qd_index == i && l.q_index == i;
+      for (int c = 0; ok && c < 9; ++c) ok = l.X_T_rot[c] == ((c == 0 || c == 4 || c == 8) ? 1.0 : 0.0);
+      for (int c = 0; ok && c < 3; ++c) ok = l.X_T_trans[c] == 0.0;
+      for (int c = 0; ok && c < 6; ++c) ok = l.S[c] == ((c == (i < 3 ? 3 + i : i - 3)) ? 1.0 : 0.0);
+      ok = ok && l.stiffness == 0.0 && l.damping == 0.0;
+    }
+    // (the closed form leaves links 0..4 without a world transform of their own: nothing may hang on them)
+    for (int g = 0; ok && g < m->num_geoms; ++g) ok = !(m->geoms[g].link >= 0 && m->geoms[g].link < 5);
+    for (int v = 0; ok && v < m->num_visuals; ++v) ok = !(m->visuals[v].link >= 0 && m->visuals[v].link < 5);
+    if (ok) {
+      bool ident = true;
+      for (int c = 0; c < 9; ++c) ident = ident && m->base_X_world_rot[c] == ((c == 0 || c == 4 || c == 8) ? 1.0 : 0.0);
+      d->euler_root = ident ? 1 : 0;  // (a rotated base frame: the general scan)
+    }
+  }
+  d->dof_identity = (!fl && d->num_spherical == 0 && !d->two_bodies && m->num_links == m->dof_qd) ? 1 : 0;
+  for (int i = 0; i < m->num_links && d->dof_identity; ++i)
+    if (m->links[i].qd_index != i) d->dof_identity = 0;
   d->num_levels = max_level + 1;
   d->kin_lev0 = d->num_levels;
   for (int i = d->kin_chain_last + 1; i < m->num_links; ++i)

@@ -1536,7 +1536,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       const int vbase = nq + nd;
       if (pack_y) {  // y describes the last normal step of the launch (y ring: every step its own slot)
         for (int k = lane; k < nv; k += G) {
-          const bool first = !LOOP && k == lane;  // wave-uniform: visual == lane was prefetched at kernel start
+          // wave-uniform: visual == lane was prefetched — at kernel start (straight-line builds), or just ahead of the
+          // narrowphase of THIS iteration (step-loop builds below 24 dof: load_phase_consts); the wider step-loop builds
+          // fetch their phase constants at the top of the iteration and read the visuals here
+          // (not the two-wavefronts-per-SIMD step-loop build: carrying 24 more registers through the narrowphase costs it
+          //  116 B of scratch)
+          const bool first = (!LOOP || (NDP < 24 && LP != 2)) && k == lane;
           int lk = pf_vis_link;
           if (!first) lk = mdl->vis_link[k];
           T Rl[9], pl[3], Rv[9], pv[3];
@@ -1915,6 +1920,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   if constexpr (LOOP) load_link_consts(mdl);
   if constexpr (LOOP && NDP >= 24) load_phase_consts(mdl);
   T Rp[9], tp[3];
+  T sn, cs;  // sin / cos of the lane's joint angle (half angle for REVOLUTE_AXIS); phase C's closed-form root chain uses them
   {
     const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
     const bool pris = jt >= TDS_JOINT_PRISMATIC_X && jt <= TDS_JOINT_PRISMATIC_AXIS;
@@ -1925,7 +1931,6 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       tJ[1] = Sl[4] * q;
       tJ[2] = Sl[5] * q;
     }
-    T sn, cs;
     sincos_t<T>(jt == TDS_JOINT_REVOLUTE_AXIS ? q * T(0.5) : q, &sn, &cs);
     if (rev) {
       if (jt == TDS_JOINT_REVOLUTE_X) {  // tiny_matrix3x3.h:218-234
@@ -1995,7 +2000,103 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   };
   const int nlev = mdl->num_levels;
   const int rkc = mdl->kin_chain_last;  // serial chain 0..rkc from the base in lanes 0..rkc (>= the root joint of E'): -1 = none
-  if (rkc >= 0) {
+  const int eul = KIND == 0 ? mdl->euler_root : 0;  // wave-uniform
+  if (eul != 0) {
+    // ---- The root chain in CLOSED FORM (DevModel::euler_root: links 0..5 = prismatic X, Y, Z, revolute X, Y, Z with
+    //      identity X_T — the free motion of the URDF-derived fixed-base robots, the Ant and Laikago).  The chain's six
+    //      transforms are  trans(q0, q1, q2) Rx(q3) Ry(q4) Rz(q5);  world pose, motion axis, velocity and bias
+    //      acceleration of link 5 (the torso / chassis: the only link of the chain with mass, shapes and children) follow
+    //      from 15 lane broadcasts of (q, sin q, cos q, qd) and ~200 independent multiply-adds on every lane — instead of
+    //      nine dependent rounds of DPP scans (three 3x3 products deep each) that a lone wavefront sat through at ~10
+    //      cycles per instruction.  Same quantities as kinematics.hpp:64-97 produces link by link, other association.
+    const T q0 = lane_bcast<T, G, NDP, 0>(q), q1 = lane_bcast<T, G, NDP, 1>(q), q2 = lane_bcast<T, G, NDP, 2>(q);
+    const T sx = lane_bcast<T, G, NDP, 3>(sn), cx = lane_bcast<T, G, NDP, 3>(cs);
+    const T sy = lane_bcast<T, G, NDP, 4>(sn), cy = lane_bcast<T, G, NDP, 4>(cs);
+    const T sz = lane_bcast<T, G, NDP, 5>(sn), cz = lane_bcast<T, G, NDP, 5>(cs);
+    // R5 = Rx Ry Rz, revolute axes a3 = e_x, a4 = Rx e_y, a5 = Rx Ry e_z, all through the point P = base + (q0, q1, q2)
+    // (base frame == world frame: the host sets euler_root only then — the prismatic axes are the unit vectors, a3 = e_x)
+    R[0] = cy * cz;                 R[1] = -cy * sz;                R[2] = sy;
+    R[3] = sx * sy * cz + cx * sz;  R[4] = cx * cz - sx * sy * sz;  R[5] = -sx * cy;
+    R[6] = sx * sz - cx * sy * cz;  R[7] = cx * sy * sz + sx * cz;  R[8] = cx * cy;
+    const T P[3] = {q0 + mdl->base_t[0], q1 + mdl->base_t[1], q2 + mdl->base_t[2]};
+    const T A3[3] = {T(1), T(0), T(0)}, A4[3] = {T(0), cx, sx}, A5[3] = {sy, -sx * cy, cx * cy};
+    const T C0[3] = {T(1), T(0), T(0)}, C1[3] = {T(0), T(1), T(0)}, C2[3] = {T(0), T(0), T(1)};
+    p[0] = P[0]; p[1] = P[1]; p[2] = P[2];
+    // this lane's world motion axis: s = (0 | column) for the prismatic links, (A | P x A) for the revolute ones
+    {
+      const bool pr = li < 3;
+      T ang[3], lin[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ang[k] = pr ? T(0) : (li == 3 ? A3[k] : (li == 4 ? A4[k] : A5[k]));
+        lin[k] = li == 0 ? C0[k] : (li == 1 ? C1[k] : C2[k]);
+      }
+      T c[3];
+      cross3(P, ang, c);
+      const bool inch6 = isl && li <= 5;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        sw[k] = inch6 ? ang[k] : T(0);
+        sw[3 + k] = inch6 ? (pr ? lin[k] : c[k]) : T(0);
+      }
+    }
+    // link 5: v = (W5 | U + P x W5),  a0 = sum_j crm(v_j) vJ_j - g  with  v_j = (W_j | U + P x W_j),  vJ_j = (J_j | P x J_j),
+    // J_j = A_j qd_j, W_3 = J_3, W_4 = W_3 + J_4, W_5 = W_4 + J_5  (the prismatic joints contribute nothing: no rotation yet)
+    // (scheduling fence: the pose / axis part above is done before the velocity part starts — interleaved, the two
+    //  parts' temporaries together cost the narrow kernels their last free registers)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const T d0 = lane_bcast<T, G, NDP, 0>(qd), d1 = lane_bcast<T, G, NDP, 1>(qd), d2 = lane_bcast<T, G, NDP, 2>(qd);
+      const T d3 = lane_bcast<T, G, NDP, 3>(qd), d4 = lane_bcast<T, G, NDP, 4>(qd), d5 = lane_bcast<T, G, NDP, 5>(qd);
+      const T U[3] = {d0, d1, d2};
+      const T J3[3] = {A3[0] * d3, A3[1] * d3, A3[2] * d3}, J4[3] = {A4[0] * d4, A4[1] * d4, A4[2] * d4},
+              J5[3] = {A5[0] * d5, A5[1] * d5, A5[2] * d5};
+      const T W4[3] = {J3[0] + J4[0], J3[1] + J4[1], J3[2] + J4[2]};
+      const T W5[3] = {W4[0] + J5[0], W4[1] + J5[1], W4[2] + J5[2]};
+      T pJ3[3], pJ4[3], pJ5[3];
+      cross3(P, J3, pJ3);
+      cross3(P, J4, pJ4);
+      cross3(P, J5, pJ5);
+      const T pW4[3] = {pJ3[0] + pJ4[0], pJ3[1] + pJ4[1], pJ3[2] + pJ4[2]};
+      const T pW5[3] = {pW4[0] + pJ5[0], pW4[1] + pJ5[1], pW4[2] + pJ5[2]};
+      const T V3[3] = {U[0] + pJ3[0], U[1] + pJ3[1], U[2] + pJ3[2]};
+      const T V4[3] = {U[0] + pW4[0], U[1] + pW4[1], U[2] + pW4[2]};
+      const T V5[3] = {U[0] + pW5[0], U[1] + pW5[1], U[2] + pW5[2]};
+      // crm(v) vJ = (w x wJ | w x vJ_lin + v_lin x wJ)
+      T a45[3], a55[3], t1[3], t2[3], l3[3], l4[3], l5[3];
+      cross3(J3, J4, a45);   // W4 x J4 = J3 x J4
+      cross3(W4, J5, a55);   // W5 x J5 = W4 x J5
+      cross3(J3, pJ3, t1);
+      cross3(V3, J3, t2);
+      l3[0] = t1[0] + t2[0]; l3[1] = t1[1] + t2[1]; l3[2] = t1[2] + t2[2];
+      cross3(W4, pJ4, t1);
+      cross3(V4, J4, t2);
+      l4[0] = t1[0] + t2[0]; l4[1] = t1[1] + t2[1]; l4[2] = t1[2] + t2[2];
+      cross3(W5, pJ5, t1);
+      cross3(V5, J5, t2);
+      l5[0] = t1[0] + t2[0]; l5[1] = t1[1] + t2[1]; l5[2] = t1[2] + t2[2];
+      const bool torso = isl && li == 5;  // (links 0..4: massless, v = a0 = 0 keeps their zero inertia's products finite)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        v[k] = torso ? W5[k] : T(0);
+        v[3 + k] = torso ? V5[k] : T(0);
+        a0[k] = torso ? a45[k] + a55[k] : T(0);
+        a0[3 + k] = torso ? (l3[k] + l4[k] + l5[k]) - mdl->grav[k] : T(0);
+      }
+    }
+    if (isl && li <= 5 && lds_children) {  // children other than lane + 1 read my record (link 5: the hips)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Xw[li * TDS_S1 + 9 + k] = p[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        va[my_slot * TDS_S1 + k] = v[k];
+        va[my_slot * TDS_S1 + 6 + k] = a0[k];
+      }
+    }
+    TDS_WAVE_SYNC();
+  } else if (rkc >= 0) {
     // The root chain's world transforms are a prefix product of the local ones along consecutive lanes:
     // inclusive scan with DPP row shifts (ceil(log2(rkc + 1)) <= 4 rounds) instead of rkc+1 tree levels.
     //   (Ra, ta) o (Rb, tb) = (Ra Rb, ta + Ra tb)        (transform.hpp:123-131)
@@ -2428,14 +2529,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       for (int k = 0; k < 10; ++k) Ic[k] += Ics[li * TDS_S2 + k];
     }
     const bool to_lds = mine && parent >= 0 && !chain_child;
-    if (mine) {
-      project(Ic, fc);
-      if (to_lds) {
+    // (the projection F = Ic s, C = s . f is NOT done level by level: nothing in the sweep needs it, so every lane
+    //  projects its finished composite once, behind the sweep — two projections fewer on the dependent chain)
+    if (to_lds) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&pAs[parent * TDS_S2 + k], fc[k]);
+      for (int k = 0; k < 6; ++k) atomicAdd(&pAs[parent * TDS_S2 + k], fc[k]);
 #pragma unroll
-        for (int k = 0; k < 10; ++k) atomicAdd(&Ics[parent * TDS_S2 + k], Ic[k]);
-      }
+      for (int k = 0; k < 10; ++k) atomicAdd(&Ics[parent * TDS_S2 + k], Ic[k]);
     }
     if (__any(mine && chain_child)) {  // wave-uniform: lane i takes over from its child in lane i + 1
       // (select by multiplication: one FMA instead of two 32-bit selects and an add per value)
@@ -2451,29 +2551,44 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   //      force of link rk pass through them unchanged: F_i = Ic_rk s_i, C_i = s_i . f_rk for i <= rk,
   //      all at once instead of rk+1 more levels
   if (rk >= 0) {  // wave-uniform
-    if (li == rk) {
-      if (lds_children) {
+    if (li == rk && lds_children) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) fc[k] += pAs[li * TDS_S2 + k];
+      for (int k = 0; k < 6; ++k) fc[k] += pAs[li * TDS_S2 + k];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) Ic[k] += Ics[li * TDS_S2 + k];
+      for (int k = 0; k < 10; ++k) Ic[k] += Ics[li * TDS_S2 + k];
+    }
+    if (rk == 5) {
+      // the usual six-link base chain: link 5's totals reach lanes 0..4 by a DPP broadcast (their own composites are
+      // zero: massless links) — no LDS round trip
+      const bool take = isl && li < 5;
+      static_for<0, 6>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const T b = lane_bcast<T, G, NDP, 5>(fc[k]);
+        fc[k] = take ? b : fc[k];
+      });
+      static_for<0, 10>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const T b = lane_bcast<T, G, NDP, 5>(Ic[k]);
+        Ic[k] = take ? b : Ic[k];
+      });
+    } else {
+      if (li == rk) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = fc[k];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) Ics[li * TDS_S2 + k] = Ic[k];
       }
+      TDS_WAVE_SYNC();
+      if (isl && li < rk) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pAs[li * TDS_S2 + k] = fc[k];
+        for (int k = 0; k < 10; ++k) Ic[k] = Ics[rk * TDS_S2 + k];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) Ics[li * TDS_S2 + k] = Ic[k];
+        for (int k = 0; k < 6; ++k) fc[k] = pAs[rk * TDS_S2 + k];
+      }
+      TDS_WAVE_SYNC();
     }
-    TDS_WAVE_SYNC();
-    if (isl && li <= rk) {
-      T Icr[10], fr[6];
-#pragma unroll
-      for (int k = 0; k < 10; ++k) Icr[k] = Ics[rk * TDS_S2 + k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) fr[k] = pAs[rk * TDS_S2 + k];
-      project(Icr, fr);
-    }
-    TDS_WAVE_SYNC();
   }
+  if (!pure_chain && isl) project(Ic, fc);
 
   TDS_STAMP(5);
   T qd_new = qd;
@@ -2485,11 +2600,15 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     T *const Fs = E + L.F;      // (= pA slot of the link records)
     T *const Lp = E + L.Lp;     // strictly-lower L packed row-major: L[r][j] at r(r-1)/2 + j
     T *const dvec = E + L.dinv; // [3][NDP]: 1/D_k | sqrt(1/D_k) | column scratch (NDP > 16)
-    if (isl) {
+    // lane == link == dof for every link (DevModel::dof_identity: the Ant): F, tau - C stay in the lane's registers
+    const bool didn = !gen && !two && mdl->dof_identity != 0;  // wave-uniform
+    if (!didn) {
+      if (isl) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Fs[li * TDS_S2 + k] = Fc[k];
+        for (int k = 0; k < 6; ++k) Fs[li * TDS_S2 + k] = Fc[k];
+      }
+      TDS_WAVE_SYNC();
     }
-    TDS_WAVE_SYNC();
     T Mr[NDP];
     {
       const int d = lane;
@@ -2497,8 +2616,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       const int lk = isd ? pf_dof_link : 0;
       const unsigned anc = isd ? pf_anc : 0u;
       T Fd[6];
+      if (didn) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Fd[k] = isd ? Fs[lk * TDS_S2 + k] : T(0);
+        for (int k = 0; k < 6; ++k) Fd[k] = isd ? Fc[k] : T(0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Fd[k] = isd ? Fs[lk * TDS_S2 + k] : T(0);
+      }
       // Columns j >= nd hold whatever the row store left there; they are deselected by the ancestor mask, so the reads
       // need no `j < nd` guard.  That matters: a read under a uniform branch is its own LDS round trip, NDP of them in a
       // row.  Narrow kernels read all NDP x 6 values at once; the wider ones (no registers for that) go three columns per
@@ -2655,11 +2779,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       }
     }
     TDS_WAVE_SYNC();
-    if (di >= 0) rhsx[di] = tau - Cb;
-    TDS_WAVE_SYNC();
+    if (!didn) {
+      if (di >= 0) rhsx[di] = tau - Cb;
+      TDS_WAVE_SYNC();
+    }
     {
       const int d = lane;
-      T yv = d < NDP ? rhsx[d] : T(0);
+      T yv = didn ? (d < nd ? tau - Cb : T(0)) : (d < NDP ? rhsx[d] : T(0));
       // L y = rhs (L unit lower, row d of it in Mr[0..d-1]), column by column
       // (the row mask goes into the multiplier ahead of time: the dependent chain per step is broadcast + FMA, no select)
       //  (narrow kernels only: the wide ones have no registers for a masked copy of the row)
