@@ -102,8 +102,14 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   // then fills issue slots that would otherwise idle; beyond that the one-wave form with more workgroups per CU wins)
   const int n_resident = (opts && opts->env_total > 0) ? opts->env_total : n;
   const int n_blocks = (n_resident + (64 / s->lanes) - 1) / (64 / s->lanes);
-  const bool two_waves = s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && nsub == 1 &&
-                         reset_mode == TDS_RESET_NONE && !ro && !(opts && opts->lds) && !(opts && opts->rings);
+  // ... straight-line launches; and step-loop launches of plain steps (no policy, no reset, no reset pool): there the
+  // helper wavefront loops along and is also the RECORDER of per-step rings (TDS_HIP_LOOP_W2=0: the one-wave loop build)
+  static const bool loop_w2 = [] { const char *e = getenv("TDS_HIP_LOOP_W2"); return !(e && e[0] == '0'); }();
+  const bool w2_fits = s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && reset_mode == TDS_RESET_NONE && !ro &&
+                       !(opts && opts->lds);
+  const bool is_loop_launch = nsub > 1 || (opts && opts->rings);
+  const bool two_waves = w2_fits && (is_loop_launch ? (loop_w2 && !(opts && opts->extra) && s->lds_w2.NDP <= 16)
+                                                    : !(opts && opts->rings));
   const TdsLds &lds = (opts && opts->lds) ? *opts->lds : (two_waves ? s->lds_w2 : s->lds);
   void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
   if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along

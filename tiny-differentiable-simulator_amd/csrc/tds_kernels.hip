@@ -1121,7 +1121,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
                                                       TR *__restrict__ obs_out, T *ovf, long long *prof, TdsStepCtl ctl, int n_envs) {
   constexpr bool LOOP = LP != 0;
-  static_assert(!W2 || (LP == 0 && KIND == 0 && NDP < 24), "two-wavefront workgroups: plain straight-line kernels");
+  static_assert(!W2 || ((LP == 0 || LP == 1) && KIND == 0 && NDP < 24),
+                "two-wavefront workgroups: plain kernels, straight-line or step-loop");
+  // LDS slots behind the x record (xr[in_dim + ...]): 0 x_{t-1}, 1 done; two-wavefront layout: 2, 3 contact counts, 4 "y~ is
+  // published", 5 columns of L published; then (step-loop builds with record rings) the step's reward and "its records are out"
+  constexpr int RW_SLOT = W2 ? 6 : 2, OUT_SLOT = W2 ? 7 : 3;
   extern __shared__ __align__(16) unsigned char tds_smem_raw[];
   T *const sm = reinterpret_cast<T *>(tds_smem_raw);
   constexpr int EPW = 64 / G;
@@ -1180,14 +1184,16 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     const bool valid = env < n_envs;
     const int nq = mdl->dof_q, nd = mdl->dof_qd, in_dim = mdl->input_dim, adim = mdl->action_dim;
     T *const xr = sm + grp0 * L.stride + L.xrec;
+    if (main_wave) {  // (a helper wavefront first touches the record behind barrier (1) of the first step)
 #pragma unroll
-    for (int k = 0; k < XPL; ++k) {
-      const int i = lane + k * G;
-      if (i < in_dim) xr[i] = xpre[k];
-    }
-    for (int i = lane + XPL * G; i < in_dim; i += G) {
-      const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
-      xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+      for (int k = 0; k < XPL; ++k) {
+        const int i = lane + k * G;
+        if (i < in_dim) xr[i] = xpre[k];
+      }
+      for (int i = lane + XPL * G; i < in_dim; i += G) {
+        const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
+        xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+      }
     }
     TDS_WAVE_SYNC();
     bool finished0 = false;  // forced reset with zero settle steps: nothing to simulate
@@ -1252,7 +1258,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // are), and a SECOND contact pass handles the contacts between the two bodies (world.hpp:206-282, 293-366).
   constexpr bool two = KIND == 3;
   // contact solve in Gram form on the matrix cores (tds_gram_solve): two-wavefront workgroups of 16-lane environments
-  constexpr bool GRAM = W2 && G == 16 && NDP <= 16 && std::is_same<T, double>::value;
+  constexpr bool GRAM = W2 && !LOOP && G == 16 && NDP <= 16 && std::is_same<T, double>::value;  // (opt-in; straight-line form only)
   // two-wavefront workgroups, narrow kernels: no barrier between the LDL^T and the helper's row solves — L reaches the
   // helper in two halves through LDS flags (tds_row_solve), the contact counts reach this wavefront the same way
   constexpr bool PIPE = W2 && NDP <= 16;
@@ -1428,8 +1434,29 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   auto put_obs = [&](int slot) {
     const size_t at = ((size_t)slot * ctl.ring_envs + env) * (nq + nd + 2);
     for (int i = lane; i < nq + nd + 2; i += G) {
-      const int src = i < nq + nd ? i : (i == nq + nd ? in_dim + 2 : in_dim + 1);
+      const int src = i < nq + nd ? i : (i == nq + nd ? in_dim + RW_SLOT : in_dim + 1);
       ring_put(at + i, i < 2 ? T(0) : xr[src]);
+    }
+  };
+  // the end-of-step records of the PREVIOUS step, from the LDS record (whose state part this step has not touched yet)
+  auto flush_prev_records = [&]() {
+    if constexpr (DEFER) {
+      if ((ring_o || ring_y) && tds_iter > 0 && valid && mode == TDS_MODE_RUN && xr[in_dim + OUT_SLOT] == T(0)) {
+        if (ring_y)
+          put_y_state((TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter - 1) % ctl.y_slots) * ctl.ring_envs + env) * out_dim);
+        if (ring_o) put_obs((ctl.obs_first + tds_iter - 1) % ctl.obs_slots);
+      }
+    }
+  };
+  // the previous step's records are visible device-wide: count this workgroup in (TdsStepCtl::progress — what the exchange
+  // of the multi-GPU layer polls, tds_shard.hip).  Called by the wavefront that stored them, half a step later.
+  auto signal_progress = [&]() {
+    if (ctl.progress != nullptr && tds_iter > 0) {  // wave-uniform
+      if (ctl.ring_flags & TDS_RING_NOFENCE)
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the obs ring's write-through stores have reached the L2 / memory
+      else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctl.progress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   const bool pack_y = ring_y ? (valid && mode == TDS_MODE_RUN) : (last_run && y_out != nullptr);
@@ -1781,6 +1808,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   if constexpr (W2) {
     if (wv == 1) {
       // ================= helper wavefront of a two-wavefront workgroup =================
+      // (step-loop build: the helper loops along, step by step; besides the contact pipeline it is the RECORDER — visual
+      //  poses, and from the LDS record the previous step's y state + obs record — so that per-step records cost the main
+      //  wavefront's dependent chain nothing but the reward block)
+      if constexpr (LOOP) load_phase_consts(mdl);
       TDS_STAMP(1);
       __syncthreads();  // (1) the main wavefront has written the x record, X_world and the motion axes
       TDS_STAMP(2);
@@ -1800,7 +1831,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       }
       TDS_STAMP(3);
       phase_M1();
-      if (pack_y) {  // tail of the y record: up_dot_world_z, zero padding
+      flush_prev_records();
+      if (pack_y && !(DEFER && ring_y)) {  // tail of the y record: up_dot_world_z, zero padding
         TR *const yo = y_step;
         int tail = nq + nd;
         if (mdl->pack_visuals) {
@@ -1829,9 +1861,17 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                              L.gram_ok ? nullptr : xr + in_dim + 4, dt,
                                              PIPE ? xr + in_dim + 5 : nullptr, PIPE ? E + L.Lh : nullptr);
       TDS_STAMP(7);
+      if constexpr (LOOP) signal_progress();  // (the records this wavefront stored behind the visual poses)
       __syncthreads();  // (3) z~ rows and their scalars are final
       TDS_STAMP(8);
-      return;
+      if constexpr (LOOP) {
+        // the same bookkeeping the main wavefront does for a plain / replayed step (these launches have no settle steps)
+        if (mode == TDS_MODE_RUN && --left == 0) mode = TDS_MODE_IDLE;
+        ++tds_iter;
+        continue;
+      } else {
+        return;
+      }
     }
   }
 
@@ -2361,6 +2401,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       }
     }
     __syncthreads();  // (1) x record, X_world and the motion axes are in LDS: the helper wavefront starts
+    if constexpr (LOOP) load_phase_consts(mdl);
   } else {
     // (step-loop build: the constants of the later phases are fetched only now — one L2 round trip per iteration
     //  instead of ~60 registers held through the kinematics sweep, which is what keeps this build at two
@@ -2379,14 +2420,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       NB_pairs = wave_max(nb_pairs);
     }
     phase_M1();
-    if constexpr (DEFER) {
-      // the end-of-step records of the PREVIOUS step, from the LDS record (whose state part this step has not touched yet)
-      if ((ring_o || ring_y) && tds_iter > 0 && valid && mode == TDS_MODE_RUN && xr[in_dim + 3] == T(0)) {
-        if (ring_y)
-          put_y_state((TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter - 1) % ctl.y_slots) * ctl.ring_envs + env) * out_dim);
-        if (ring_o) put_obs((ctl.obs_first + tds_iter - 1) % ctl.obs_slots);
-      }
-    }
+    flush_prev_records();
     TDS_WAVE_SYNC();  // X_world / v in LDS are dead from here on (their space is reused)
   }
 
@@ -2767,16 +2801,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       // (action replay: the NEXT step's action block, requested at the top of this step, goes into the action slots of
       //  the record — nobody reads them any more in this step: the PD block has long turned them into tau)
       if (replay && mode == TDS_MODE_RUN && lane < adim) xr[nq + nd + lane] = next_act;
-      // the ring records of the PREVIOUS step left this wavefront half a step ago (behind this step's visual poses):
-      // make them visible device-wide and count this workgroup in (TdsStepCtl::progress — what the exchange of the
-      // multi-GPU layer polls, tds_shard.hip)
-      if (ctl.progress != nullptr && tds_iter > 0) {  // wave-uniform
-        if (ctl.ring_flags & TDS_RING_NOFENCE)
-          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the obs ring's write-through stores have reached the L2 / memory
-        else
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl.progress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      // the ring records of the PREVIOUS step left this wavefront half a step ago (behind this step's visual poses)
+      if constexpr (!W2) signal_progress();
     }
     TDS_WAVE_SYNC();
     if (!didn) {
@@ -3232,7 +3258,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       ob[nq + nd + 1] = (done || frozen) ? TR(1) : TR(0);
     }
     if constexpr (LOOP) {
-      if (ring_o) xr[in_dim + 2] = reward;  // (the obs record is stored from the LDS record: put_obs)
+      if (ring_o) xr[in_dim + RW_SLOT] = reward;  // (the obs record is stored from the LDS record: put_obs)
     }
     xr[in_dim + 1] = done ? T(1) : T(0);
   }
@@ -3356,7 +3382,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     //      while reward / done (written above) describe the step that ended (ars_vectorized_environment.h:262-277)
     if (ring_o && ring_now) put_obs((ctl.obs_first + tds_iter) % ctl.obs_slots);
     if constexpr (DEFER) {
-      if (ring_step && lane == 0) xr[in_dim + 3] = ring_now ? T(1) : T(0);  // "the records of this step are out"
+      if (ring_step && lane == 0) xr[in_dim + OUT_SLOT] = ring_now ? T(1) : T(0);  // "the records of this step are out"
     }
     // ---- the environment is done with this launch: observation (obs[0] = obs[1] = 0,
     //      ars_vectorized_environment.h:283-288) and resident state
@@ -3418,7 +3444,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   L.ovrows = 3 * nct - L.zrows;    // surplus rows per environment (global scratch slab)
   int o = 0;
   // persistent for the whole step
-  L.xrec = o; o += m.input_dim + 4 + (w2 ? 2 : 0);  // + x_{t-1}, the done flag, the reward and the "records are out" flag of
+  L.xrec = o; o += m.input_dim + 4 + (w2 ? 4 : 0);  // + x_{t-1}, the done flag, the reward and the "records are out" flag of
                                                     //   the step loop (two-wavefront layout: + 2 .. + 5 are the contact counts
                                                     //   and flags handed between the wavefronts)
   // two pairs with disjoint lifetimes share their storage:
@@ -3495,6 +3521,13 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
         break;                                                                                               \
       }                                                                                                      \
     }                                                                                                        \
+    if constexpr (KIND == 0 && NN < 24) {                                                                    \
+      if (two_waves && !simple && !prof) {                                                                   \
+        hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 1, 0, true>), dim3(blocks), dim3(128), shmem, \
+                           stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
+        break;                                                                                               \
+      }                                                                                                      \
+    }                                                                                                        \
     if (prof)                                                                                                \
       hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, true, 0, 0>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
@@ -3552,6 +3585,9 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
     if (e == hipSuccess && KIND == 0 && NN < 24)                                                                    \
       e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 0, 0, true>,      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
+    if (e == hipSuccess && KIND == 0 && NN < 24)                                                                    \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 1, 0, true>,      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
