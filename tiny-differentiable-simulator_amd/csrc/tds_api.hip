@@ -108,7 +108,16 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   const bool w2_fits = s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && reset_mode == TDS_RESET_NONE && !ro &&
                        !(opts && opts->lds);
   const bool is_loop_launch = nsub > 1 || (opts && opts->rings);
-  const bool two_waves = w2_fits && (is_loop_launch ? (loop_w2 && !(opts && opts->extra) && s->lds_w2.NDP <= 16)
+  // (TDS_HIP_LOOP_W2=2: not for launches that take reset states from the pool)
+  static const bool loop_w2_pool = [] { const char *e = getenv("TDS_HIP_LOOP_W2"); return !(e && e[0] == '2'); }();
+  // (a launch whose ring slots are exchanged while it runs — rings->progress — stays with the ONE-wave loop build: two
+  //  wavefronts of 256 registers per SIMD leave no register for anybody else, and the exchange's kernels — the one-lane
+  //  wait, RCCL's all-gather — would not get onto a compute unit before the launch ends; the one-wave build holds 296 of a
+  //  SIMD's 512.  Measured, profiles/r03_ring_exchange_forms.txt: the first wait of a 64-step launch returned after 86 %
+  //  of it.)
+  const bool exchanged = opts && opts->rings && opts->rings->progress;
+  const bool two_waves = w2_fits && (is_loop_launch ? (loop_w2 && !exchanged && (loop_w2_pool || !(opts && opts->extra)) &&
+                                                       s->lds_w2.NDP <= 16)
                                                     : !(opts && opts->rings));
   const TdsLds &lds = (opts && opts->lds) ? *opts->lds : (two_waves ? s->lds_w2 : s->lds);
   void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
