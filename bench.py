@@ -145,13 +145,15 @@ def pmc_traffic_loop(model, n, dtype, steps_per_launch):
 
 
 def pmc_traffic_rings(model, n, dtype, steps_per_launch):
-    """HBM bytes of ONE launch of the per-step-record form (tds_hip_step_many_rings): FETCH_SIZE / WRITE_SIZE of the
-    driver's own command (`python bench.py --steps 20 --warmup 5`), per step x the steps of a launch."""
+    """HBM bytes of ONE launch of the per-step-record form (tds_hip_step_many_rings): FETCH_SIZE of the whole launch (the x
+    records, the model, the action pool once — it stays cache-resident) doubled per the guide's gfx950 correction, plus
+    WRITE_SIZE per step x the steps of the launch — from the committed PMC passes of the driver's own command
+    (`python bench.py --steps 20 --warmup 5`: "short") and of a long launch."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             e = json.load(f)[model][str(n)][dtype]["rings"]
-        per_step = 2.0 * e["fetch_kib_per_step"] + e["write_kib_per_step"]
-        return int(per_step * steps_per_launch * 1024), e["source"]
+        w = e["write_kib_per_step_short" if steps_per_launch <= 64 else "write_kib_per_step_long"]
+        return int((2.0 * e["fetch_kib_per_launch"] + w * steps_per_launch) * 1024), e["source"]
     except Exception:
         return None, None
 
@@ -375,7 +377,11 @@ def main():
     if auto_reset:
         sim.set_auto_reset(True, 5)
     pool = 16
-    amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
+    # action amplitude: +-0.4 rad (the reference's ACTION_LIMIT) for the Ant; +-0.1 for the legged robots that can fall over
+    # (Laikago, humanoid): the reference has no joint limits, a fallen robot driven by +-0.4 random actions blows up
+    # numerically within ~1000 steps (tools/laikago_stability.py: 0 / 0 / 6 / 25 of 8192 non-finite after 600 / 800 / 1000 /
+    # 1200 steps at +-0.4, none at +-0.1) — the metric loop of the reference would have reset it long before
+    amp = (0.4 if args.model.startswith("ant") else 0.1) if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
     actions = torch.from_numpy(rng.uniform(-amp, amp, (pool, n, adim))).to(tdt).cuda().contiguous()
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
     B = max(1, args.gather_every)
@@ -746,7 +752,7 @@ def main():
             "config": {"workload": (f"{args.model} (gym Ant 14-dof + plane, 17 contact points, PGS 1 iter), " if args.model == "ant"
                                     else f"{args.model}, ") +
                                    f"{n} envs/GPU, dt={m.dt}; state fed back on device every step; actions: a pool of {pool} "
-                                   f"uniform random action batches resident in HBM, step k takes batch k mod {pool} "
+                                   f"uniform random (+-{amp}) action batches resident in HBM, step k takes batch k mod {pool} "
                                    f"(no policy in the loop)",
                        "records": "f64" if args.dtype == "f64" else "f32",
                        "per_step_records": bool(per_step_records),
