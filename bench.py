@@ -469,7 +469,10 @@ def main():
         # per-step launches + exchanges from one hipGraph -> one tds_hip_shard_step call per step.  A form that fails
         # during the warm-up steps (a refused capture falls back inside the library; this catches what it cannot: a
         # ring wait that timed out, an RCCL error) is dropped on EVERY rank before anything is timed.
-        forms = ["ring", "per-step graph", "per-step eager"] if shard_graph else ["per-step eager"]
+        # (at N > 1 the hipGraph form of the per-step launches is left out: collectives captured into a graph have never
+        #  run on more than one rank, and a capture that hangs has no timeout — the plain stream-ordered form is the
+        #  conservative fallback there)
+        forms = (["ring", "per-step graph", "per-step eager"] if world == 1 else ["ring", "per-step eager"]) if shard_graph else ["per-step eager"]
         for f in forms:
             if f == "per-step graph":
                 os.environ["TDS_HIP_SHARD_RING"] = "0"

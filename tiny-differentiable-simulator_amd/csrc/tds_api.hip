@@ -1115,10 +1115,8 @@ int step_many_impl(tds_hip_sim_t *s, const void *actions_dev, int action_blocks,
   if (s->auto_reset) {
     // auto_reset_when_done after every step: step-loop launches that take the fresh states from the reset pool where
     // the plain call would be one step-loop launch (pool_step_many), else K single steps through the pool
-    if (as_loop) {
-      const int rc = pool_step_many(s, actions_dev, pool, first, n_steps, obs_dev, rings);
-      return rc != TDS_OK ? rc : y_back();
-    }
+    if (as_loop)  // (the step-loop launches write the last step's y record into d_y themselves)
+      return pool_step_many(s, actions_dev, pool, first, n_steps, obs_dev, rings);
     const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
     for (int k = 0; k < n_steps; ++k) {
       const void *a = actions_dev ? (const char *)actions_dev + (size_t)((first + k) % pool) * blk : nullptr;
@@ -1140,8 +1138,8 @@ int step_many_impl(tds_hip_sim_t *s, const void *actions_dev, int action_blocks,
     }
     lo.rings = rings;
     // (a single step with rings is a step-loop launch too: the launcher picks that build whenever a ring is set)
-    const int rc = launch(s, s->d_x, s->d_y, a0, s->d_x, obs_dev, s->num_envs, n_steps, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
-    return rc != TDS_OK ? rc : y_back();
+    // (no copy of the last y slot behind the launch: the step-loop kernel writes the last step's record into d_y as well)
+    return launch(s, s->d_x, s->d_y, a0, s->d_x, obs_dev, s->num_envs, n_steps, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
   }
   const int C = eager ? chain_count(s, n_steps) : s->graph_chains;
   if (eager) {

@@ -1598,6 +1598,20 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           __builtin_nontemporal_store((TR)qo[1], &o[4]);
           __builtin_nontemporal_store((TR)qo[2], &o[5]);
           __builtin_nontemporal_store((TR)qo[3], &o[6]);
+          if constexpr (LOOP) {
+            // (the LAST step of a launch with a y ring also leaves its record in the handle's y record: what a device
+            //  copy of the ring slot behind the launch used to do, at the price of a dispatch per call)
+            if (ring_y && last_run && y_out != nullptr) {  // wave-uniform
+              TR *o2 = y_out + (size_t)env * out_dim + vbase + 7 * k;
+              o2[0] = (TR)(pl[0] + po[0]);
+              o2[1] = (TR)(pl[1] + po[1]);
+              o2[2] = (TR)(pl[2] + po[2]);
+              o2[3] = (TR)qo[0];
+              o2[4] = (TR)qo[1];
+              o2[5] = (TR)qo[2];
+              o2[6] = (TR)qo[3];
+            }
+          }
         }
       }
     }
@@ -3197,8 +3211,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   TDS_WAVE_SYNC();
 
   // ---- y record (q, qd, up, zero padding; the visual poses went out in M1) of the last normal step
+  const int n_y_targets = (LOOP && !DEFER && ring_y && pack_y && last_run && y_out != nullptr) ? 2 : 1;
+  for (int yt_i = 0; yt_i < n_y_targets; ++yt_i)
   if (pack_y && !(DEFER && ring_y)) {
-    TR *const yo = y_step;
+    TR *const yo = yt_i == 0 ? y_step : y_out + (size_t)env * out_dim;
     if (gen) {  // the q record is not one coordinate per lane: copy it out as it is
       for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)(xr[i]), &yo[i]);
     } else if (di >= 0) {
@@ -3317,6 +3333,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     const bool ring_now = ring_step && (!DEFER || last_run || (pool_r && done_now));
     if constexpr (DEFER) {
       if (ring_y && ring_now) put_y_state(y_step);
+      if (ring_y && ring_step && last_run && y_out != nullptr) put_y_state(y_out + (size_t)env * out_dim);
     }
 
     // ---- mode transition of this lane group
