@@ -357,7 +357,9 @@ def test_shard_ring_exchange_on_one_rank(with_rccl, submit, wire, built, monkeyp
             assert torch.equal(sh.sim.x, torch.from_numpy(x).cuda())
         sh.step_many(a, K, first_block=1)
         got = sh.gathered().clone()
-        ref.step_many_rings(a, K, ring, None, first_block=1)
+        # (a launch whose slots are exchanged while it runs uses the one-wave step-loop build; so does one that is handed a
+        #  progress counter — the same build on both sides: bit for bit)
+        ref.step_many_rings(a, K, ring, None, first_block=1, progress=torch.zeros(1, dtype=torch.int64, device="cuda"))
         sh.flush()
         torch.cuda.synchronize()
         assert tuple(got.shape) == (1, 1, n, ref.obs_dim + 2) and got.dtype == wdt

@@ -202,7 +202,8 @@ def test_float_obs_ring_beside_double_records_and_the_progress_counter(name, bui
     ring64 = torch.zeros((steps, n, sim.obs_dim + 2), dtype=torch.float64, device="cuda")
     progress = torch.zeros(1, dtype=torch.int64, device="cuda")
     sim.step_many_rings(actions, steps, ring32, None, progress=progress)
-    sim2.step_many_rings(actions, steps, ring64, None)
+    # (a progress counter selects the one-wave step-loop build; both launches get one, so that they are the same build)
+    sim2.step_many_rings(actions, steps, ring64, None, progress=torch.zeros(1, dtype=torch.int64, device="cuda"))
     torch.cuda.synchronize()
     assert torch.equal(ring32, ring64.to(torch.float32))
     assert int(progress.item()) == (steps - 1) * sim.rings_blocks()
