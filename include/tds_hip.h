@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TDS_HIP_ABI_VERSION 3
+#define TDS_HIP_ABI_VERSION 4
 
 #define TDS_MAX_LINKS 64   /* links of the model as the reference builds it; the kernels take <= 32 lanes: one per
                               moving link (fixed links are folded into their parents when lanes run short), six for
@@ -46,9 +46,11 @@ extern "C" {
 #define TDS_MAX_DOF 32
 /* contact points per environment: sphere 1, capsule 2, box 8 (contact_point.hpp:96-198) */
 #define TDS_MAX_CONTACTS 64
-/* contact points between the geometries of TWO articulated bodies of a world (sphere-sphere 1, capsule-sphere 2:
-   contact_point.hpp:43-94, 405-438), per environment */
-#define TDS_MAX_PAIR_CONTACTS 64
+/* articulated bodies of one world (World::multi_bodies_ without the plane; src/world.hpp:206-282 pairs them all) */
+#define TDS_MAX_BODIES 4
+/* contact points between the geometries of the articulated bodies of a world, summed over all body pairs
+   (sphere-sphere 1, capsule-sphere 2: contact_point.hpp:43-94, 405-438), per environment */
+#define TDS_MAX_PAIR_CONTACTS 160
 
 /* status codes returned by every tds_hip_* function */
 enum {
@@ -136,8 +138,8 @@ typedef struct tds_link {
 } tds_link_t;
 
 typedef struct tds_geom {
-  int32_t link; /* owning link (index into tds_model_t::links, i.e. global over both bodies of a two-body world);
-                   -1 = base of body A, -2 = base of body B */
+  int32_t link; /* owning link (index into tds_model_t::links, i.e. global over all bodies of a multi-body world);
+                   -1 - b = base of body b (-1 for a single body) */
   int32_t type; /* TDS_GEOM_SPHERE / CAPSULE / BOX */
   double radius;
   double length;     /* capsule */
@@ -152,6 +154,19 @@ typedef struct tds_visual {
   double X_rot[9]; /* X_visual (link.hpp:78-79) */
   double X_trans[3];
 } tds_visual_t;
+
+/* body b >= 1 of a world with several articulated bodies (tds_model_t::bodies) */
+typedef struct tds_body {
+  int32_t first_link;  /* index of the body's first link in tds_model_t::links */
+  int32_t first_geom;  /* index of the body's first geometry in tds_model_t::geoms */
+  int32_t is_floating; /* multi_body.hpp:66-78 */
+  int32_t pad_;
+  double base_X_world_rot[9];
+  double base_X_world_trans[3];
+  double base_mass; /* mb.base_rbi(), used only when is_floating */
+  double base_com[3];
+  double base_inertia[9];
+} tds_body_t;
 
 typedef struct tds_model {
   int32_t abi_version; /* TDS_HIP_ABI_VERSION */
@@ -199,21 +214,21 @@ typedef struct tds_model {
   double base_mass;
   double base_com[3];
   double base_inertia[9];
-  /* Worlds with TWO articulated bodies (World::step over multi_bodies_ = [plane,] A, B:
-     src/world.hpp:206-282, 293-366).  num_bodies = 2: links [0, body1_first_link) are body A, the rest body B
-     (parent -1 = the own body's base; q / qd indices dense over both: q = [q_A | q_B], qd = [qd_A | qd_B], in TAU
-     mode x = [q | qd | tau_A | tau_B]); geoms [0, body1_first_geom) belong to A, the rest to B, in the reference's
-     order (base first, then link by link).  Each body is stepped by its own forward dynamics; contacts: each body
-     against the plane (if any), then A against B — sphere-sphere and capsule-sphere in either order, as the
-     reference's dispatcher knows them — solved pair by pair in the reference's order (plane-A, plane-B, A-B) with both
-     Jacobian blocks and both inverse mass matrices (mb_constraint_solver.hpp:191-498).  num_bodies 0 / 1: one body.
-     Fixed bases, 1-dof joints; step_mode TAU. */
+  /* Worlds with SEVERAL articulated bodies (World::step over multi_bodies_ = [plane,] body 0, 1, ...:
+     src/world.hpp:206-282, 293-366).  num_bodies = B in 2..TDS_MAX_BODIES: body 0 is described by the fields above
+     (base frame, is_floating, base inertia) and owns links [0, bodies[1].first_link) and geoms [0, bodies[1].first_geom);
+     body b >= 1 is bodies[b] and owns links / geoms from its first_link / first_geom up to those of body b + 1 (or the
+     end).  A link's parent is -1 (its own body's base) or a link of the same body; q / qd indices are dense over all
+     bodies: q = [q_0 | q_1 | ...], qd = [qd_0 | qd_1 | ...] (a floating body's share is [quat xyzw | pos | joints] /
+     [omega | v | joints]), in TAU mode x = [q | qd | tau_0 | tau_1 | ...] with dof_actuated entries per body; a geometry
+     on the base of body b has link = -1 - b; geoms in the reference's order (base first, then link by link).  Each body is
+     stepped by its own forward dynamics; contacts: every body against the plane (if any), then every pair of bodies
+     i < j in the reference's order — sphere-sphere and capsule-sphere in either order, as the reference's dispatcher
+     knows them — solved pair by pair (plane-0, plane-1, ..., 0-1, 0-2, ..., 1-2, ...) with both Jacobian blocks and both
+     inverse mass matrices (mb_constraint_solver.hpp:191-498).  num_bodies 0 / 1: one body.  1-dof joints; step_mode TAU. */
   int32_t num_bodies;
-  int32_t body1_first_link;
-  int32_t body1_first_geom;
-  int32_t pad3_;
-  double body1_base_X_world_rot[9];
-  double body1_base_X_world_trans[3];
+  int32_t pad3_[3];
+  tds_body_t bodies[TDS_MAX_BODIES]; /* entries 1 .. num_bodies - 1 (entry 0 is not read) */
   tds_link_t links[TDS_MAX_LINKS];
   tds_geom_t geoms[TDS_MAX_GEOMS];
   tds_visual_t visuals[TDS_MAX_VISUALS];

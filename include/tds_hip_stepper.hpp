@@ -116,25 +116,33 @@ int flatten_multibody(const tds::MultiBody<Algebra> &mb, tds_model_t *out) {
   return 0;
 }
 
-// Body B of a two-body world, appended behind body A (which flatten_multibody put into `out`): links, collision
-// geometry (base geoms: link -2) and visuals with their indices shifted behind A's; q / qd indices dense over both.
-// Fixed bases only.  Returns 0, or a negative code if the blob's capacity is exceeded / the body is unsupported.
+// The next articulated body of a world with several of them, appended behind the bodies already in `out` (the first
+// one put there by flatten_multibody): links, collision geometry (base geoms: link -1 - b) and visuals with their
+// indices shifted behind the earlier bodies'; q / qd indices dense over all bodies.  Returns 0, or a negative code if
+// the blob's capacity is exceeded.
 template <typename Algebra>
-int append_second_multibody(const tds::MultiBody<Algebra> &mb, tds_model_t *out) {
+int append_multibody(const tds::MultiBody<Algebra> &mb, tds_model_t *out) {
   using namespace detail;
-  if (mb.is_floating() || out->is_floating) return -8;
   const int l0 = out->num_links, q0 = out->dof_q, d0 = out->dof_qd;
   const int nl = static_cast<int>(mb.num_links());
   if (l0 + nl > TDS_MAX_LINKS) return -2;
-  out->num_bodies = 2;
-  out->body1_first_link = l0;
-  out->body1_first_geom = out->num_geoms;
-  copy_mat3<Algebra>(mb.base_X_world().rotation, out->body1_base_X_world_rot);
-  copy_vec3<Algebra>(mb.base_X_world().translation, out->body1_base_X_world_trans);
+  const int b = out->num_bodies < 2 ? 1 : out->num_bodies;
+  if (b >= TDS_MAX_BODIES) return -8;
+  out->num_bodies = b + 1;
+  tds_body_t &B = out->bodies[b];
+  memset(&B, 0, sizeof(B));
+  B.first_link = l0;
+  B.first_geom = out->num_geoms;
+  B.is_floating = mb.is_floating() ? 1 : 0;
+  copy_mat3<Algebra>(mb.base_X_world().rotation, B.base_X_world_rot);
+  copy_vec3<Algebra>(mb.base_X_world().translation, B.base_X_world_trans);
+  B.base_mass = Algebra::to_double(mb.base_rbi().mass);
+  copy_vec3<Algebra>(mb.base_rbi().com, B.base_com);
+  copy_mat3<Algebra>(mb.base_rbi().inertia, B.base_inertia);
   int ng = out->num_geoms, nv = out->num_visuals;
   for (size_t g = 0; g < mb.collision_geometries(-1).size(); ++g) {
     if (ng >= TDS_MAX_GEOMS) return -3;
-    fill_geom<Algebra>(mb.collision_geometries(-1)[g], mb.collision_transforms(-1)[g], -2, &out->geoms[ng++]);
+    fill_geom<Algebra>(mb.collision_geometries(-1)[g], mb.collision_transforms(-1)[g], -1 - b, &out->geoms[ng++]);
   }
   for (int i = 0; i < nl; ++i) {
     const tds::Link<Algebra> &l = mb[i];

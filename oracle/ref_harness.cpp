@@ -66,8 +66,9 @@ struct RefSim {
   UrdfCache<Alg> cache;
   World<Alg> *gworld = nullptr;
   MultiBody<Alg> *gmb = nullptr;
-  // second articulated body of a two-body world ("two:<fileA>:<fileB>:<dx>:<dy>:<dz>[+capsA][+capsB][+plane]")
-  MultiBody<Alg> *gmb2 = nullptr;
+  // all articulated bodies of a world with several of them, gmb first
+  // ("two:<fileA>:<fileB>:<dx>:<dy>:<dz>[+capsA][+capsB][+plane]", "multi:<file>@x,y,z[/caps][/floating]:...[+plane]")
+  std::vector<MultiBody<Alg> *> gbodies;
   bool g_plane = false;
   double g_dt = 1e-3;
 
@@ -100,14 +101,18 @@ struct RefSim {
 
   int input_dim() {
     if (loco()) return loco()->input_dim_with_action_and_variables();
-    if (gmb2) return gmb->dof() + gmb2->dof() + 2 * (gmb->dof_qd() + gmb2->dof_qd());  // [q | qd | tau] over both
+    if (!gbodies.empty()) {  // [q | qd | tau] over all bodies
+      int n = 0;
+      for (MultiBody<Alg> *m : gbodies) n += m->dof() + m->dof_qd() + m->dof_actuated();
+      return n;
+    }
     return gmb->dof() + gmb->dof_qd() + gmb->dof_actuated();  // == dof_qd for a fixed base, dof_qd - 6 floating
   }
   int num_visuals() {
     int n = 0;
     for (const auto &l : *mb()) n += (int)l.X_visuals.size();
-    if (gmb2)
-      for (const auto &l : *gmb2) n += (int)l.X_visuals.size();
+    for (size_t b = 1; b < gbodies.size(); ++b)
+      for (const auto &l : *gbodies[b]) n += (int)l.X_visuals.size();
     return n;
   }
   int output_dim() {
@@ -116,25 +121,32 @@ struct RefSim {
     // past its own output_dim.  For these constructions the record is as long as what the step writes.
     if (sphpd) return std::max(sphpd->output_dim(), sphpd->mb_->dof() + sphpd->mb_->dof_qd() + 7 * num_visuals() + 1);
     if (loco()) return loco()->output_dim();
-    if (gmb2) return gmb->dof() + gmb2->dof() + gmb->dof_qd() + gmb2->dof_qd() + 7 * num_visuals() + 1;
+    if (!gbodies.empty()) {
+      int n = 7 * num_visuals() + 1;
+      for (MultiBody<Alg> *m : gbodies) n += m->dof() + m->dof_qd();
+      return n;
+    }
     return gmb->dof() + gmb->dof_qd() + 7 * num_visuals() + 1;
   }
 
-  // two-body world: x = [q_A q_B | qd_A qd_B | tau_A tau_B]; the reference's call sequence per body around ONE
-  // World::step (contacts plane-A, plane-B, A-B; resolve_collision pair by pair, world.hpp:293-366):
-  //   forward_dynamics(A), forward_dynamics(B); clear_forces; integrate_euler_qdd(A), (B); world.step;
-  //   integrate_euler(A), (B).   y = [q_A q_B | qd_A qd_B | visual poses of A, then B | base_A.R(2,2)]
-  void two_body_step(const double *x, double *y) {
-    MultiBody<Alg> *bodies[2] = {gmb, gmb2};
-    const int nq = gmb->dof() + gmb2->dof(), nd = gmb->dof_qd() + gmb2->dof_qd();
-    int oq = 0, od = 0;
+  // world of several articulated bodies: x = [q_0 q_1 .. | qd_0 qd_1 .. | tau_0 tau_1 ..]; the reference's call sequence
+  // per body around ONE World::step (contacts plane-0, plane-1, .., 0-1, 0-2, .., 1-2, ..; resolve_collision pair by
+  // pair, world.hpp:293-366):
+  //   forward_dynamics(b) for all b; clear_forces; integrate_euler_qdd(b); world.step; integrate_euler(b).
+  //   y = [q_0 q_1 .. | qd_0 qd_1 .. | visual poses body by body | base_0.R(2,2)]
+  void multi_body_step(const double *x, double *y) {
+    const std::vector<MultiBody<Alg> *> &bodies = gbodies;
+    int nq = 0, nd = 0;
+    for (MultiBody<Alg> *m : bodies) { nq += m->dof(); nd += m->dof_qd(); }
+    int oq = 0, od = 0, ot = 0;
     for (MultiBody<Alg> *m : bodies) {
       m->initialize();
       for (int i = 0; i < m->dof(); ++i) m->q(i) = x[oq + i];
       for (int i = 0; i < m->dof_qd(); ++i) m->qd(i) = x[nq + od + i];
-      for (int i = 0; i < m->dof_actuated(); ++i) m->tau(i) = x[nq + nd + od + i];
+      for (int i = 0; i < m->dof_actuated(); ++i) m->tau(i) = x[nq + nd + ot + i];
       oq += m->dof();
       od += m->dof_qd();
+      ot += m->dof_actuated();
     }
     for (MultiBody<Alg> *m : bodies) {
       forward_dynamics(*m, gworld->get_gravity());
@@ -205,6 +217,19 @@ struct RefSim {
 
 }  // namespace
 
+// replaces every sphere of a body by a capsule of the same radius (length 0.16, along the link's local y) so that
+// capsule-sphere pairs occur in both argument orders of the dispatcher
+static void sphere_to_capsules(RefSim *s, MultiBody<Alg> *mb) {
+  for (auto &link : *mb)
+    for (size_t g = 0; g < link.collision_geometries.size(); ++g)
+      if (link.collision_geometries[g]->get_type() == TINY_SPHERE_TYPE) {
+        const double r = ((const Sphere<Alg> *)link.collision_geometries[g])->get_radius();
+        link.collision_geometries[g] = s->gworld->create_capsule(r, 0.16);
+        // capsule axis = local z of the geometry frame: turn it onto the link's y
+        link.X_collisions[g].rotation = Alg::rotation_x_matrix(1.5707963267948966);
+      }
+}
+
 extern "C" {
 
 // name: "ant" | "laikago" | "<file>.urdf" | "<file>.urdf+plane" | "<file>.urdf[+plane]+floating"   (file relative to <ref>/data)
@@ -242,6 +267,38 @@ void *tdsref_create(const char *name_c, const char *reference_root) {
     s->lfloat = new LaikagoContactSimulation<Alg>(true, "laikago/laikago_toes_zup.urdf", "",
                                                   LaikagoContactSimulation<Alg>::get_initial_poses(), true);
     if (cwd[0] && chdir(cwd) != 0) return nullptr;
+  } else if (name.rfind("multi:", 0) == 0) {
+    // "multi:<file>@x,y,z[/caps][/floating]:<file>@x,y,z...[+plane]": up to TDS_MAX_BODIES articulated bodies from the
+    // reference's data directory in ONE world, each base at (x, y, z); /caps: spheres -> capsules (see above);
+    // /floating: MultiBody with a floating base (its pose then comes from q, the position given here is not used)
+    std::string spec = name.substr(6);
+    s->g_plane = spec.find("+plane") != std::string::npos;
+    spec = spec.substr(0, spec.find('+'));
+    std::string root(reference_root);
+    s->gworld = new World<Alg>();
+    if (s->g_plane) s->cache.construct(root + "/data/plane_implicit.urdf", *s->gworld, false, false);
+    size_t a = 0;
+    while (a <= spec.size()) {
+      size_t b = spec.find(':', a);
+      std::string item = spec.substr(a, b == std::string::npos ? b : b - a);
+      const bool caps = item.find("/caps") != std::string::npos, floating = item.find("/floating") != std::string::npos;
+      item = item.substr(0, item.find('/'));
+      const size_t at = item.find('@');
+      if (at == std::string::npos) return nullptr;
+      double pos[3] = {0, 0, 0};
+      if (sscanf(item.c_str() + at + 1, "%lf,%lf,%lf", &pos[0], &pos[1], &pos[2]) != 3) return nullptr;
+      MultiBody<Alg> *mb = s->cache.construct(root + "/data/" + item.substr(0, at), *s->gworld, false, floating);
+      mb->base_X_world().set_identity();
+      mb->base_X_world().translation = Alg::Vector3(pos[0], pos[1], pos[2]);
+      if (caps) sphere_to_capsules(s, mb);
+      s->gbodies.push_back(mb);
+      if (b == std::string::npos) break;
+      a = b + 1;
+    }
+    if (s->gbodies.size() < 2 || s->gbodies.size() > TDS_MAX_BODIES) return nullptr;
+    s->gmb = s->gbodies[0];
+    s->gworld->default_friction = 1;
+    s->gworld->get_mb_constraint_solver()->keep_all_points_ = true;
   } else if (name.rfind("two:", 0) == 0) {
     // "two:<fileA>:<fileB>:<dx>:<dy>:<dz>[+capsA][+capsB][+plane]": two articulated bodies from the reference's data
     // directory in ONE world, B's base shifted by (dx, dy, dz); +capsX replaces every sphere of body X by a capsule of
@@ -263,22 +320,13 @@ void *tdsref_create(const char *name_c, const char *reference_root) {
     s->gworld = new World<Alg>();
     if (s->g_plane) s->cache.construct(root + "/data/plane_implicit.urdf", *s->gworld, false, false);
     s->gmb = s->cache.construct(root + "/data/" + tok[0], *s->gworld, false, false);
-    s->gmb2 = s->cache.construct(root + "/data/" + tok[1], *s->gworld, false, false);
+    MultiBody<Alg> *gmb2 = s->cache.construct(root + "/data/" + tok[1], *s->gworld, false, false);
+    s->gbodies = {s->gmb, gmb2};
     s->gmb->base_X_world().set_identity();
-    s->gmb2->base_X_world().set_identity();
-    s->gmb2->base_X_world().translation = Alg::Vector3(atof(tok[2].c_str()), atof(tok[3].c_str()), atof(tok[4].c_str()));
-    auto capsules = [&](MultiBody<Alg> *mb) {
-      for (auto &link : *mb)
-        for (size_t g = 0; g < link.collision_geometries.size(); ++g)
-          if (link.collision_geometries[g]->get_type() == TINY_SPHERE_TYPE) {
-            const double r = ((const Sphere<Alg> *)link.collision_geometries[g])->get_radius();
-            link.collision_geometries[g] = s->gworld->create_capsule(r, 0.16);
-            // capsule axis = local z of the geometry frame: turn it onto the link's y
-            link.X_collisions[g].rotation = Alg::rotation_x_matrix(1.5707963267948966);
-          }
-    };
-    if (capsA) capsules(s->gmb);
-    if (capsB) capsules(s->gmb2);
+    gmb2->base_X_world().set_identity();
+    gmb2->base_X_world().translation = Alg::Vector3(atof(tok[2].c_str()), atof(tok[3].c_str()), atof(tok[4].c_str()));
+    if (capsA) sphere_to_capsules(s, s->gmb);
+    if (capsB) sphere_to_capsules(s, gmb2);
     s->gworld->default_friction = 1;
     s->gworld->get_mb_constraint_solver()->keep_all_points_ = true;
   } else {
@@ -385,10 +433,10 @@ int tdsref_flatten(void *h, tds_model_t *out) {
     out->reward_mode = TDS_REWARD_NONE;
     out->action_limit = 0.4;
     out->plane_normal[2] = 1.0;
-    if (s->gmb2) {
-      rc = tds_hip::append_second_multibody<Alg>(*s->gmb2, out);
+    for (size_t b = 1; b < s->gbodies.size(); ++b) {
+      rc = tds_hip::append_multibody<Alg>(*s->gbodies[b], out);
       if (rc) return rc;
-      out->action_dim = s->gmb->dof_actuated() + s->gmb2->dof_actuated();
+      out->action_dim += s->gbodies[b]->dof_actuated();
     }
     if (s->g_plane) rc = tds_hip::flatten_plane<Alg>(*s->gworld, *s->gmb, s->g_dt, out);
   }
@@ -712,8 +760,8 @@ void tdsref_step(void *h, int n, const double *x, double *y) {
     std::fill(yi.begin(), yi.end(), 0.0);
     if (loco)
       loco->step_forward_original(xi, yi);
-    else if (s->gmb2)
-      s->two_body_step(xi.data(), yi.data());
+    else if (!s->gbodies.empty())
+      s->multi_body_step(xi.data(), yi.data());
     else
       s->generic_step(xi.data(), yi.data());
     memcpy(y + (size_t)e * out, yi.data(), sizeof(double) * out);

@@ -203,9 +203,9 @@ class RefSim:
 
     def last_penetrating_contacts(self):
         """per body pair of the reference's contact list, contacts with distance < 0 in the last step"""
-        buf = (C.c_int * 8)()
+        buf = (C.c_int * 16)()
         lib().tdsref_last_penetrating_contacts.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
-        n = lib().tdsref_last_penetrating_contacts(self.h, buf, 8)
+        n = lib().tdsref_last_penetrating_contacts(self.h, buf, 16)
         return [buf[i] for i in range(n)]
 
     def set_dt(self, dt):

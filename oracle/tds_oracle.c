@@ -881,13 +881,58 @@ static int resolve_collision(const tds_model_t *m, scratch_t *s, tds_oracle_debu
   return 0;
 }
 
+/* integrate_euler_qdd: qd += qdd*dt (integrator.hpp:141-182); qdd = 0 (:194) */
+static void integrate_euler_qdd(const tds_model_t *m, scratch_t *s) {
+  if (m->is_floating) /* :152-166 */
+    for (int k = 0; k < 6; ++k) s->qd[k] += s->qdd[k] * m->dt;
+  for (int i = 0; i < m->num_links; ++i) {
+    const tds_link_t *l = &m->links[i];
+    const int nc = l->joint_type == TDS_JOINT_SPHERICAL ? 3 : 1; /* :171-174 */
+    if (l->joint_type != TDS_JOINT_FIXED)
+      for (int c = 0; c < nc; ++c) s->qd[l->qd_index + c] += s->qdd[l->qd_index + c] * m->dt;
+  }
+}
+
+static void integrate_euler(const tds_model_t *m, scratch_t *s) {
+  /* integrate_euler with qdd == 0: q += qd*dt (integrator.hpp:126-131) */
+  if (m->is_floating) { /* :23-89: quaternion += quat_velocity(q, omega, dt) (tiny_algebra.hpp:604-614), normalise */
+    const double *w = s->qd, h = 0.5 * m->dt;
+    double *b = s->q;
+    double ww = (-b[0] * w[0] - b[1] * w[1] - b[2] * w[2]) * h;
+    double xx = (b[3] * w[0] + b[2] * w[1] - b[1] * w[2]) * h;
+    double yy = (b[3] * w[1] + b[0] * w[2] - b[2] * w[0]) * h;
+    double zz = (b[3] * w[2] + b[1] * w[0] - b[0] * w[1]) * h;
+    b[0] += xx; b[1] += yy; b[2] += zz; b[3] += ww;
+    quat_normalize(b);
+    quat_to_matrix(b, s->base_X_world.r); /* :83 (the translation of base_X_world is NOT refreshed) */
+    for (int k = 0; k < 3; ++k) b[4 + k] += s->qd[3 + k] * m->dt;
+  }
+  for (int i = 0; i < m->num_links; ++i) {
+    const tds_link_t *l = &m->links[i];
+    if (l->joint_type == TDS_JOINT_SPHERICAL) { /* :94-123 */
+      double *w = &s->qd[l->qd_index], *b = &s->q[l->q_index];
+      const double damping = pow(0.995, m->dt * 1000.0); /* MultiBody::joint_damping_ = 0.995 (multi_body.hpp:51) */
+      for (int c = 0; c < 3; ++c) w[c] *= damping;
+      const double h = 0.5 * m->dt; /* quat_velocity_spherical, tiny_algebra.hpp:618-629 */
+      double ww = (-b[0] * w[0] - b[1] * w[1] - b[2] * w[2]) * h;
+      double xx = (b[3] * w[0] + b[1] * w[2] - b[2] * w[1]) * h;
+      double yy = (b[3] * w[1] + b[2] * w[0] - b[0] * w[2]) * h;
+      double zz = (b[3] * w[2] + b[0] * w[1] - b[1] * w[0]) * h;
+      b[0] += xx; b[1] += yy; b[2] += zz; b[3] += ww;
+      quat_normalize(b);
+    } else if (l->joint_type != TDS_JOINT_FIXED) {
+      s->q[l->q_index] += s->qd[l->qd_index] * m->dt;
+    }
+  }
+}
+
+static int step_multi(const tds_model_t *m, const double *x, double *y);
+
 /* ref: examples/environments/locomotion_contact_simulation.h:151-304 (LOCOMOTION) and
    examples/environments/cartpole_environment.h:71-117 (TAU) */
-static int step_two(const tds_model_t *m, const double *x, double *y);
-
 static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t *s,
                     tds_oracle_debug_t *dbg) {
-  if (m->num_bodies == 2) return step_two(m, x, y); /* worlds with two articulated bodies: below */
+  if (m->num_bodies >= 2) return step_multi(m, x, y); /* worlds with several articulated bodies: below */
   const int nq = m->dof_q, nd = m->dof_qd;
   int nsph = 0;
   for (int i = 0; i < m->num_links && i < NL; ++i) nsph += m->links[i].joint_type == TDS_JOINT_SPHERICAL;
@@ -963,15 +1008,7 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
       memcpy(dbg->X_world + 12 * i, s->L[i].X_world.r, 9 * sizeof(double));
       memcpy(dbg->X_world + 12 * i + 9, s->L[i].X_world.t, 3 * sizeof(double));
     }
-  /* integrate_euler_qdd: qd += qdd*dt (integrator.hpp:141-182); qdd = 0 (:194) */
-  if (m->is_floating) /* :152-166 */
-    for (int k = 0; k < 6; ++k) s->qd[k] += s->qdd[k] * m->dt;
-  for (int i = 0; i < m->num_links; ++i) {
-    const tds_link_t *l = &m->links[i];
-    const int nc = l->joint_type == TDS_JOINT_SPHERICAL ? 3 : 1; /* :171-174 */
-    if (l->joint_type != TDS_JOINT_FIXED)
-      for (int c = 0; c < nc; ++c) s->qd[l->qd_index + c] += s->qdd[l->qd_index + c] * m->dt;
-  }
+  integrate_euler_qdd(m, s);
   if (m->has_plane) {                                      /* world.step (world.hpp:293-366) */
     compute_contacts(m, s);
     if (dbg) {
@@ -986,36 +1023,7 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
     int rc = resolve_collision(m, s, dbg);
     if (rc) return rc;
   }
-  /* integrate_euler with qdd == 0: q += qd*dt (integrator.hpp:126-131) */
-  if (m->is_floating) { /* :23-89: quaternion += quat_velocity(q, omega, dt) (tiny_algebra.hpp:604-614), normalise */
-    const double *w = s->qd, h = 0.5 * m->dt;
-    double *b = s->q;
-    double ww = (-b[0] * w[0] - b[1] * w[1] - b[2] * w[2]) * h;
-    double xx = (b[3] * w[0] + b[2] * w[1] - b[1] * w[2]) * h;
-    double yy = (b[3] * w[1] + b[0] * w[2] - b[2] * w[0]) * h;
-    double zz = (b[3] * w[2] + b[1] * w[0] - b[0] * w[1]) * h;
-    b[0] += xx; b[1] += yy; b[2] += zz; b[3] += ww;
-    quat_normalize(b);
-    quat_to_matrix(b, s->base_X_world.r); /* :83 (the translation of base_X_world is NOT refreshed) */
-    for (int k = 0; k < 3; ++k) b[4 + k] += s->qd[3 + k] * m->dt;
-  }
-  for (int i = 0; i < m->num_links; ++i) {
-    const tds_link_t *l = &m->links[i];
-    if (l->joint_type == TDS_JOINT_SPHERICAL) { /* :94-123 */
-      double *w = &s->qd[l->qd_index], *b = &s->q[l->q_index];
-      const double damping = pow(0.995, m->dt * 1000.0); /* MultiBody::joint_damping_ = 0.995 (multi_body.hpp:51) */
-      for (int c = 0; c < 3; ++c) w[c] *= damping;
-      const double h = 0.5 * m->dt; /* quat_velocity_spherical, tiny_algebra.hpp:618-629 */
-      double ww = (-b[0] * w[0] - b[1] * w[1] - b[2] * w[2]) * h;
-      double xx = (b[3] * w[0] + b[1] * w[2] - b[2] * w[1]) * h;
-      double yy = (b[3] * w[1] + b[2] * w[0] - b[0] * w[2]) * h;
-      double zz = (b[3] * w[2] + b[0] * w[1] - b[1] * w[0]) * h;
-      b[0] += xx; b[1] += yy; b[2] += zz; b[3] += ww;
-      quat_normalize(b);
-    } else if (l->joint_type != TDS_JOINT_FIXED) {
-      s->q[l->q_index] += s->qd[l->qd_index] * m->dt;
-    }
-  }
+  integrate_euler(m, s);
   /* pack (:273-303); the rest of y is zero (caller's vector is zero-initialised) */
   int j = 0;
   for (int i = 0; i < m->output_dim; ++i) y[i] = 0.0;
@@ -1038,9 +1046,9 @@ static int step_one(const tds_model_t *m, const double *x, double *y, scratch_t 
 }
 
 /* ================================================================================================
- * Worlds with TWO articulated bodies (tds_model_t::num_bodies == 2).
- * ref: src/world.hpp:293-366 (World::step over multi_bodies_ = [plane,] A, B: contacts pair by pair, then
- * resolve_collision pair by pair in the same order), :206-282 (pair loop), src/contact_point.hpp:43-94
+ * Worlds with SEVERAL articulated bodies (tds_model_t::num_bodies in 2..TDS_MAX_BODIES).
+ * ref: src/world.hpp:293-366 (World::step over multi_bodies_ = [plane,] body 0, 1, ...: contacts pair by pair, then
+ * resolve_collision pair by pair in the same order), :206-282 (pair loop over all i < j), src/contact_point.hpp:43-94
  * (sphere-sphere), :405-438 (capsule-sphere), :478-495 (the dispatcher's swapped order),
  * src/mb_constraint_solver.hpp:191-498 (both Jacobian blocks, both inverse mass matrices).
  * Each body is handled by the single-body functions above on a sub-model of its own.
@@ -1050,38 +1058,54 @@ typedef struct {
   int link_a, link_b;
 } pair_contact_t;
 
-/* body `which` (0 = A, 1 = B) of a two-body blob as a single-body blob of its own */
+/* body `which` of a multi-body blob as a single-body blob of its own */
 static void sub_model(const tds_model_t *m, int which, tds_model_t *o) {
-  const int f = m->body1_first_link, g1 = m->body1_first_geom;
-  int nqa = 0, nda = 0;
-  for (int i = 0; i < f; ++i)
-    if (m->links[i].joint_type != TDS_JOINT_FIXED) { ++nqa; ++nda; }
+  const int B = m->num_bodies;
+  const int f = which == 0 ? 0 : m->bodies[which].first_link;
+  const int fe = which + 1 < B ? m->bodies[which + 1].first_link : m->num_links;
+  const int g0 = which == 0 ? 0 : m->bodies[which].first_geom;
+  const int ge = which + 1 < B ? m->bodies[which + 1].first_geom : m->num_geoms;
+  /* first q / qd index of the body: everything the earlier bodies own (floating: 7 / 6 base coordinates,
+     multi_body.hpp:324-349) */
+  int q0 = 0, d0 = 0;
+  for (int b = 0; b < which; ++b) {
+    const int lb = b == 0 ? 0 : m->bodies[b].first_link, le = m->bodies[b + 1].first_link;
+    if (b == 0 ? m->is_floating : m->bodies[b].is_floating) { q0 += 7; d0 += 6; }
+    for (int i = lb; i < le; ++i)
+      if (m->links[i].joint_type == TDS_JOINT_SPHERICAL) { q0 += 4; d0 += 3; }
+      else if (m->links[i].joint_type != TDS_JOINT_FIXED) { ++q0; ++d0; }
+  }
   *o = *m;
   o->num_bodies = 0;
   o->pack_visuals = 0;
   o->num_visuals = 0;
-  if (which == 0) {
-    o->num_links = f;
-    o->dof_q = nqa; o->dof_qd = nda;
-    o->num_geoms = g1;
-  } else {
-    o->num_links = m->num_links - f;
-    o->dof_q = m->dof_q - nqa; o->dof_qd = m->dof_qd - nda;
-    memcpy(o->base_X_world_rot, m->body1_base_X_world_rot, sizeof(o->base_X_world_rot));
-    memcpy(o->base_X_world_trans, m->body1_base_X_world_trans, sizeof(o->base_X_world_trans));
-    for (int i = 0; i < o->num_links; ++i) {
-      o->links[i] = m->links[f + i];
-      if (o->links[i].parent >= 0) o->links[i].parent -= f;
-      if (o->links[i].q_index >= 0) o->links[i].q_index -= nqa;
-      if (o->links[i].qd_index >= 0) o->links[i].qd_index -= nda;
-    }
-    o->num_geoms = m->num_geoms - g1;
-    for (int g = 0; g < o->num_geoms; ++g) {
-      o->geoms[g] = m->geoms[g1 + g];
-      o->geoms[g].link = o->geoms[g].link == -2 ? -1 : o->geoms[g].link - f;
-    }
+  if (which > 0) {
+    const tds_body_t *bd = &m->bodies[which];
+    o->is_floating = bd->is_floating;
+    memcpy(o->base_X_world_rot, bd->base_X_world_rot, sizeof(o->base_X_world_rot));
+    memcpy(o->base_X_world_trans, bd->base_X_world_trans, sizeof(o->base_X_world_trans));
+    o->base_mass = bd->base_mass;
+    memcpy(o->base_com, bd->base_com, sizeof(o->base_com));
+    memcpy(o->base_inertia, bd->base_inertia, sizeof(o->base_inertia));
   }
-  o->action_dim = o->dof_qd;
+  o->num_links = fe - f;
+  int nq = o->is_floating ? 7 : 0, nd = o->is_floating ? 6 : 0;
+  for (int i = 0; i < o->num_links; ++i) {
+    o->links[i] = m->links[f + i];
+    if (o->links[i].parent >= 0) o->links[i].parent -= f;
+    if (o->links[i].q_index >= 0) o->links[i].q_index -= q0;
+    if (o->links[i].qd_index >= 0) o->links[i].qd_index -= d0;
+    if (o->links[i].joint_type == TDS_JOINT_SPHERICAL) { nq += 4; nd += 3; }
+    else if (o->links[i].joint_type != TDS_JOINT_FIXED) { ++nq; ++nd; }
+  }
+  o->dof_q = nq;
+  o->dof_qd = nd;
+  o->num_geoms = ge - g0;
+  for (int g = 0; g < o->num_geoms; ++g) {
+    o->geoms[g] = m->geoms[g0 + g];
+    o->geoms[g].link = o->geoms[g].link < 0 ? -1 : o->geoms[g].link - f;
+  }
+  o->action_dim = nd - (o->is_floating ? 6 : 0); /* dof_actuated */
 }
 
 /* ref: contact_point.hpp:43-94 (non-CppAD branch): at most one contact, emitted when the centres are apart */
@@ -1252,16 +1276,16 @@ static int resolve_collision_pair(const tds_model_t *m, const tds_model_t *ma, s
   return 0;
 }
 
-static int step_two(const tds_model_t *m, const double *x, double *y) {
-  if (m->step_mode != TDS_STEP_TAU || m->is_floating) return -2;
-  tds_model_t *sub = (tds_model_t *)malloc(2 * sizeof(tds_model_t));
-  scratch_t *sc = (scratch_t *)malloc(2 * sizeof(scratch_t));
+static int step_multi(const tds_model_t *m, const double *x, double *y) {
+  const int B = m->num_bodies;
+  if (m->step_mode != TDS_STEP_TAU || B > TDS_MAX_BODIES) return -2;
+  tds_model_t *sub = (tds_model_t *)malloc(B * sizeof(tds_model_t));
+  scratch_t *sc = (scratch_t *)malloc(B * sizeof(scratch_t));
   if (!sub || !sc) { free(sub); free(sc); return -4; }
-  sub_model(m, 0, &sub[0]);
-  sub_model(m, 1, &sub[1]);
+  for (int b = 0; b < B; ++b) sub_model(m, b, &sub[b]);
   const int nq = m->dof_q, nd = m->dof_qd;
-  int oq = 0, od = 0, rc = 0;
-  for (int b = 0; b < 2 && !rc; ++b) {
+  int oq = 0, od = 0, ot = 0, rc = 0;
+  for (int b = 0; b < B && !rc; ++b) {
     const tds_model_t *mm = &sub[b];
     scratch_t *s = &sc[b];
     if (mm->num_links > NL || mm->dof_qd > ND) { rc = -2; break; }
@@ -1275,45 +1299,49 @@ static int step_two(const tds_model_t *m, const double *x, double *y) {
     }
     for (int i = 0; i < mm->dof_q; ++i) s->q[i] = x[oq + i];
     for (int i = 0; i < mm->dof_qd; ++i) s->qd[i] = x[nq + od + i];
-    for (int i = 0; i < mm->dof_qd; ++i) s->tau[i] = x[nq + nd + od + i];
+    /* tau has dof_actuated entries per body; kept indexed by qd_index (multi_body.hpp:557-570) */
+    const int off = mm->is_floating ? 6 : 0;
+    for (int i = 0; i < mm->action_dim; ++i) s->tau[off + i] = x[nq + nd + ot + i];
     oq += mm->dof_q;
     od += mm->dof_qd;
+    ot += mm->action_dim;
   }
-  for (int b = 0; b < 2 && !rc; ++b) forward_dynamics(&sub[b], &sc[b]);
-  for (int b = 0; b < 2 && !rc; ++b) /* integrate_euler_qdd */
-    for (int i = 0; i < sub[b].num_links; ++i) {
-      const tds_link_t *l = &sub[b].links[i];
-      if (l->joint_type != TDS_JOINT_FIXED) sc[b].qd[l->qd_index] += sc[b].qdd[l->qd_index] * m->dt;
-    }
-  /* World::step: contacts of every body pair first (world.hpp:321-333), then the pairs are resolved in order */
+  for (int b = 0; b < B && !rc; ++b) forward_dynamics(&sub[b], &sc[b]);
+  for (int b = 0; b < B && !rc; ++b) integrate_euler_qdd(&sub[b], &sc[b]);
+  /* World::step: contacts of every body pair first (world.hpp:321-333), then the pairs are resolved in order:
+     multi_bodies_ = [plane,] body 0, 1, ...: plane-0, plane-1, ..., 0-1, 0-2, ..., 1-2, ... */
   static _Thread_local pair_contact_t pcs[TDS_MAX_PAIR_CONTACTS];
-  int npc = 0;
+  int np[TDS_MAX_BODIES * TDS_MAX_BODIES], p0[TDS_MAX_BODIES * TDS_MAX_BODIES], npc = 0, npairs = 0;
   if (!rc) {
     if (m->has_plane)
-      for (int b = 0; b < 2; ++b) compute_contacts(&sub[b], &sc[b]);
-    npc = compute_pair_contacts(&sub[0], &sc[0], &sub[1], &sc[1], pcs, TDS_MAX_PAIR_CONTACTS);
-    if (npc < 0) rc = -3;
+      for (int b = 0; b < B; ++b) compute_contacts(&sub[b], &sc[b]);
+    for (int i = 0; i < B && !rc; ++i)
+      for (int j = i + 1; j < B && !rc; ++j) {
+        const int n = compute_pair_contacts(&sub[i], &sc[i], &sub[j], &sc[j], pcs + npc, TDS_MAX_PAIR_CONTACTS - npc);
+        if (n < 0) { rc = -3; break; }
+        p0[npairs] = npc; np[npairs++] = n;
+        npc += n;
+      }
   }
   if (!rc && m->has_plane)
-    for (int b = 0; b < 2 && !rc; ++b) rc = resolve_collision(&sub[b], &sc[b], NULL); /* plane-A, plane-B */
-  if (!rc) rc = resolve_collision_pair(m, &sub[0], &sc[0], &sub[1], &sc[1], pcs, npc);    /* A-B */
+    for (int b = 0; b < B && !rc; ++b) rc = resolve_collision(&sub[b], &sc[b], NULL); /* plane-0, plane-1, ... */
+  for (int i = 0, p = 0; i < B && !rc; ++i)
+    for (int j = i + 1; j < B && !rc; ++j, ++p)
+      rc = resolve_collision_pair(m, &sub[i], &sc[i], &sub[j], &sc[j], pcs + p0[p], np[p]);
   if (!rc) {
-    for (int b = 0; b < 2; ++b) /* integrate_euler */
-      for (int i = 0; i < sub[b].num_links; ++i) {
-        const tds_link_t *l = &sub[b].links[i];
-        if (l->joint_type != TDS_JOINT_FIXED) sc[b].q[l->q_index] += sc[b].qd[l->qd_index] * m->dt;
-      }
+    for (int b = 0; b < B; ++b) integrate_euler(&sub[b], &sc[b]);
     int j = 0;
     for (int i = 0; i < m->output_dim; ++i) y[i] = 0.0;
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < B; ++b)
       for (int i = 0; i < sub[b].dof_q; ++i) y[j++] = sc[b].q[i];
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < B; ++b)
       for (int i = 0; i < sub[b].dof_qd; ++i) y[j++] = sc[b].qd[i];
     if (m->pack_visuals) {
       for (int v = 0; v < m->num_visuals; ++v) {
         const tds_visual_t *V = &m->visuals[v];
-        const int b = V->link >= m->body1_first_link ? 1 : 0;
-        const int li = V->link - (b ? m->body1_first_link : 0);
+        int b = 0;
+        while (b + 1 < B && V->link >= m->bodies[b + 1].first_link) ++b;
+        const int li = V->link - (b ? m->bodies[b].first_link : 0);
         xf_t lv, vx;
         double orn[4];
         memcpy(lv.r, V->X_rot, sizeof(lv.r)); memcpy(lv.t, V->X_trans, sizeof(lv.t));

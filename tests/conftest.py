@@ -16,6 +16,10 @@ MODELS = ["cartpole", "pendulum5", "ant", "laikago", "laikago_soft", "pendulum5_
 
 # worlds with TWO articulated bodies: fixtures from the real reference (oracle/gen_golden.py)
 TWO_BODY_MODELS = ["two_pendulums", "two_pendulums_plane", "two_pendulums_capsule_a", "two_pendulums_capsule_b"]
+# ... with THREE / FOUR bodies (every pair i < j is a contact pass of its own, world.hpp:206-282)
+MULTI_BODY_MODELS = TWO_BODY_MODELS + ["three_pendulums", "three_pendulums_plane", "four_pendulums"]
+# ... with FLOATING bases among the bodies
+FLOATING_MULTI_BODY_MODELS = ["two_cubes_floating", "pendulum_and_cube"]
 
 
 def pytest_configure(config):

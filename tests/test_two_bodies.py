@@ -1,22 +1,22 @@
-"""worlds with TWO articulated bodies — each body's own forward dynamics, contacts of each body with the
-plane, and contacts BETWEEN the bodies (sphere-sphere, capsule-sphere in both argument orders of the reference's
-dispatcher) solved pair by pair with both Jacobian blocks and both inverse mass matrices
-(/root/reference/src/world.hpp:206-282, 293-366; src/contact_point.hpp:43-94, 405-438, 478-495;
+"""worlds with SEVERAL articulated bodies (two, three, four) — each body's own forward dynamics, contacts
+of each body with the plane, and contacts BETWEEN the bodies (sphere-sphere, capsule-sphere in both argument orders of
+the reference's dispatcher) solved body pair by body pair, in the reference's order, with both Jacobian blocks and both
+inverse mass matrices (/root/reference/src/world.hpp:206-282, 293-366; src/contact_point.hpp:43-94, 405-438, 478-495;
 src/mb_constraint_solver.hpp:191-498).  The fixtures are outputs of the REAL reference (oracle/ref_harness.cpp:
-RefSim::two_body_step on two data/pendulum5.urdf chains, oracle/gen_golden.py)."""
+RefSim::multi_body_step on data/pendulum5.urdf chains and data/sphere8cube.urdf free bodies, oracle/gen_golden.py)."""
 import os
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, TWO_BODY_MODELS, rel_err
+from conftest import FLOATING_MULTI_BODY_MODELS, GOLDEN, MULTI_BODY_MODELS, rel_err
 
 import tds_amd
 
 TOL = 1e-6
 
 
-@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+@pytest.mark.parametrize("name", MULTI_BODY_MODELS)
 def test_two_body_blob_matches_the_reference_flatten(name, built):
     """CPU: the committed blob is what include/tds_hip_stepper.hpp flattens from the reference's two MultiBody objects"""
     reflib = pytest.importorskip("reflib")
@@ -27,16 +27,18 @@ def test_two_body_blob_matches_the_reference_flatten(name, built):
     r, m_ref = gen.make_ref(name)
     m = tds_amd.load_model(name)
     assert tds_amd.model_to_dict(m) == tds_amd.model_to_dict(m_ref)
-    assert m.num_bodies == 2 and m.body1_first_link == 5 and m.dof_qd == 10
+    nb = {"two": 2, "three": 3, "four": 4}[name.split("_")[0]]
+    assert m.num_bodies == nb and [m.bodies[b].first_link for b in range(1, nb)] == [5 * b for b in range(1, nb)]
+    assert m.dof_qd == 5 * nb and len(m.body_table()) == nb
     # the fixture is the reference's step on the fixture's inputs
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     assert rel_err(r.step(g["x"]), g["y"]) < 1e-12
     assert (g["active_contacts"] > 0).sum() >= 8      # states WITH contacts between the bodies
-    assert (g["active_contacts"] == 0).sum() >= 4     # ... and without
+    assert (g["active_contacts"] == 0).sum() >= (4 if nb == 2 else 2)     # ... and without
     r.close()
 
 
-@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+@pytest.mark.parametrize("name", MULTI_BODY_MODELS)
 def test_oracle_restates_two_body_worlds(name, built):
     """CPU: oracle/tds_oracle.c (step_two: per-body sub-models, pair narrowphase, two-sided MLCP) against the committed
     reference outputs and — where the reference is present — against the live reference on fresh states"""
@@ -56,7 +58,7 @@ def test_oracle_restates_two_body_worlds(name, built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+@pytest.mark.parametrize("name", MULTI_BODY_MODELS)
 def test_two_body_fresh_states_against_the_oracle(name, built):
     """2048 fresh states (touching and separated chains, as the fixture generator draws them) against the C oracle"""
     import torch
@@ -66,13 +68,15 @@ def test_two_body_fresh_states_against_the_oracle(name, built):
     m = tds_amd.load_model(name)
     n, nq, nd = 2048, m.dof_q, m.dof_qd
     rng = np.random.default_rng(4321)
-    half = nq // 2
+    bt = m.body_table()
+    half = bt[0]["q"][1]
     amp = 0.25 if m.has_plane else 0.9
     x = np.zeros((n, m.input_dim))
     qa = rng.uniform(-amp, amp, (n, half))
     x[:, :half] = qa
-    x[:, half:nq] = qa + rng.uniform(-0.12, 0.12, (n, half))
-    x[3::4, half:nq] = rng.uniform(-amp, amp, (len(x[3::4]), half))
+    for b in bt[1:]:   # the other chains close to the first: their spheres / capsules overlap; every fourth state apart
+        x[:, b["q"][0]:b["q"][1]] = qa + rng.uniform(-0.12, 0.12, (n, half))
+        x[3::4, b["q"][0]:b["q"][1]] = rng.uniform(-amp, amp, (len(x[3::4]), half))
     x[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
     x[:, nq + nd:] = rng.uniform(-0.5, 0.5, (n, nd))
     sim = hip_backend.HipSim(m, n, dtype="f64")
@@ -84,7 +88,7 @@ def test_two_body_fresh_states_against_the_oracle(name, built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+@pytest.mark.parametrize("name", MULTI_BODY_MODELS)
 def test_two_body_single_steps(name, built):
     import torch
     from tds_amd import hip_backend
@@ -102,7 +106,7 @@ def test_two_body_single_steps(name, built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", TWO_BODY_MODELS)
+@pytest.mark.parametrize("name", MULTI_BODY_MODELS)
 def test_two_body_closed_loop_trajectory(name, built):
     """the fixture's closed-loop trajectory (200 steps of the reference, state fed back), per-step resync"""
     import torch
@@ -138,3 +142,33 @@ def test_two_body_mixed_precision_and_slab(built, monkeypatch):
     yf = simf.forward_zero(torch.from_numpy(x32).cuda()).double().cpu().numpy()
     yd = hip_backend.HipSim(m, x32.shape[0], dtype="f64").forward_zero(torch.from_numpy(x32).double().cuda()).cpu().numpy()
     assert rel_err(yf, yd) < TOL
+
+
+@pytest.mark.parametrize("name", FLOATING_MULTI_BODY_MODELS)
+def test_oracle_restates_multi_body_worlds_with_floating_bases(name, built):
+    """CPU: free bodies among the articulated bodies of a world (two sphere8cube.urdf cubes stacked on the plane; a
+    pendulum5.urdf chain and a free cube) — the oracle's sub-model per body carries the floating base through the
+    single-body functions; against the committed outputs of the REAL reference (single steps, closed-loop trajectory)
+    and, where it is present, the live reference"""
+    import oraclelib
+
+    m = tds_amd.load_model(name)
+    assert any(b["floating"] for b in m.body_table())
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert (g["active_contacts"] > 0).sum() >= 8
+    assert rel_err(oraclelib.step(m, g["x"]), g["y"]) < 1e-9
+    nq, nd = m.dof_q, m.dof_qd
+    T = g["traj_y"].shape[0]
+    x = np.tile(g["traj_x0"], (T, 1))
+    x[1:, :nq + nd] = g["traj_y"][:-1, :nq + nd]
+    x[:, nq + nd:nq + nd + m.action_dim] = g["traj_actions"]
+    assert rel_err(oraclelib.step(m, x), g["traj_y"]) < 1e-9
+    reflib = pytest.importorskip("reflib")
+    if reflib.available():
+        import gen_golden as gen
+
+        r, m_ref = gen.make_ref(name)
+        assert tds_amd.model_to_dict(m) == tds_amd.model_to_dict(m_ref)
+        xr = gen.random_inputs(name, m_ref, 96, np.random.default_rng(778))
+        assert rel_err(oraclelib.step(m, xr), r.step(xr)) < 1e-9
+        r.close()

@@ -285,7 +285,7 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     const bool is_fl = c64 ? s->h64.is_floating : s->h32.is_floating;
     const bool is_sph = c64 ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
     const char *e = getenv("TDS_HIP_W2");
-    const bool is_two_w = c64 ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
+    const bool is_two_w = c64 ? s->h64.num_bodies >= 2 : s->h32.num_bodies >= 2;
     // (a world without contact points leaves the helper wavefront only the visual poses: the one-wave form is then the
     //  faster one — pendulum5 x 4096: 10.2 vs 10.9 us — unless TDS_HIP_W2=1/2 insists)
     const bool has_cp = model->has_plane && (c64 ? s->h64.num_cp : s->h32.num_cp) > 0;
@@ -308,7 +308,7 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   if (lds_bytes > 64 * 1024) {
     const bool is_fl = c64 ? s->h64.is_floating : s->h32.is_floating;
     const bool is_sph = c64 ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
-    const bool is_two = c64 ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
+    const bool is_two = c64 ? s->h64.num_bodies >= 2 : s->h32.num_bodies >= 2;
     const int kind = is_fl ? 1 : (is_sph ? 2 : (is_two ? 3 : 0));
     int e = dtype == TDS_DTYPE_F64         ? tds_kernel_max_dynamic_lds<double, double>(s->lanes, s->lds.NDP, lds_bytes, kind)
             : dtype == TDS_DTYPE_F64_REC32 ? tds_kernel_max_dynamic_lds<double, float>(s->lanes, s->lds.NDP, lds_bytes, kind)
@@ -606,7 +606,7 @@ int pool_alloc(tds_hip_sim *s) {
   if (lds_bytes > 64 * 1024) {
     const bool is_fl = s->compute_f64() ? s->h64.is_floating : s->h32.is_floating;
     const bool is_sph = s->compute_f64() ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
-    const bool is_two = s->compute_f64() ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
+    const bool is_two = s->compute_f64() ? s->h64.num_bodies >= 2 : s->h32.num_bodies >= 2;
     const int kind = is_fl ? 1 : (is_sph ? 2 : (is_two ? 3 : 0));
     const int e = s->dtype == TDS_DTYPE_F64         ? tds_kernel_max_dynamic_lds<double, double>(s->lanes, s->pool_lds.NDP, lds_bytes, kind)
                   : s->dtype == TDS_DTYPE_F64_REC32 ? tds_kernel_max_dynamic_lds<double, float>(s->lanes, s->pool_lds.NDP, lds_bytes, kind)
@@ -1043,7 +1043,7 @@ bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
   if (n_steps < 2) return false;
   if (const char *e = getenv("TDS_HIP_STEP_MANY_LOOP")) return e[0] == '1';
   const int ncp = s->compute_f64() ? s->h64.num_cp : s->h32.num_cp;
-  const bool two = s->compute_f64() ? s->h64.two_bodies != 0 : s->h32.two_bodies != 0;
+  const bool two = s->compute_f64() ? s->h64.num_bodies >= 2 : s->h32.num_bodies >= 2;
   if (!(s->model.has_plane && ncp > 0) && !two) return true;
   // Worlds with contacts, kernels up to 16 dof (their step-loop builds fit the registers: 256 VGPR + 12 AGPR at one
   // wavefront per SIMD, 52 B of scratch at two): one launch beats the chained graphs up to three rounds of workgroups

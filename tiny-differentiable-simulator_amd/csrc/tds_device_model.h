@@ -21,7 +21,9 @@
 #define TDS_NCP TDS_MAX_CONTACTS       // 64 contact points
 #define TDS_NV TDS_MAX_VISUALS         // 64
 #define TDS_NPAIR (TDS_NL * 12)        // (link, strict ancestor) pairs
-#define TDS_NPC TDS_MAX_PAIR_CONTACTS  // contact points between the two bodies of a two-body world
+#define TDS_NPC TDS_MAX_PAIR_CONTACTS  // contact points between the bodies of a multi-body world (all pairs)
+#define TDS_NB TDS_MAX_BODIES          // articulated bodies of a world
+#define TDS_NBP ((TDS_NB * (TDS_NB - 1)) / 2)  // body pairs i < j
 // internal joint types of the expanded model (never in a tds_model_t handed in by a caller)
 #define TDS_JOINT_SPH0 9   // first lane of a spherical joint: X_J = quat_to_matrix(q[0..3]), axis x
 #define TDS_JOINT_SPH1 10  // second: identity transform, axis y
@@ -100,13 +102,16 @@ struct DevModel {
   T vis_X[12][TDS_NV];
   // CRBA off-diagonal work list: M[qd(i)][qd(j)] for j a strict ancestor of i, both with a dof
   int16_t pair_i[TDS_NPAIR], pair_j[TDS_NPAIR];
-  // two-body worlds (tds_model_t::num_bodies == 2; kernels of KIND 3) ------------------------------
-  int two_bodies;               // 1: links with body_of_link == 1 hang off the second base
-  int nd_a;                     // dofs 0..nd_a-1 belong to body A, the rest to body B
+  // multi-body worlds (tds_model_t::num_bodies >= 2; kernels of KIND 3) ------------------------------
+  int num_bodies;               // >= 2: links with body_of_link == b hang off the base of body b; 0: one body
+  int body_dof0[TDS_NB + 1];    // dofs body_dof0[b] .. body_dof0[b + 1] - 1 belong to body b
   int body_of_link[TDS_NL];
-  T base_R2[9], base_t2[3], grav2[3];
-  // contact points between a geometry of A and a geometry of B, in the reference's order (world.hpp:206-282: geoms
-  // of A outer, geoms of B inner; capsule-sphere: +L/2 end, then -L/2 end).  Each is a pair of spheres:
+  T base_Rb[TDS_NB][9], base_tb[TDS_NB][3], gravb[TDS_NB][3];  // per body (entry 0 repeats base_R, base_t, grav)
+  // body pairs a < b in the reference's order (world.hpp:212-216: 0-1, 0-2, .., 1-2, ..); each is a contact pass of its
+  // own; the contact points of pair p are pc[pair_pc0[p] .. pair_pc0[p + 1] - 1]
+  int num_bpairs, bpair_a[TDS_NBP], bpair_b[TDS_NBP], bpair_pc0[TDS_NBP + 1];
+  // contact points between a geometry of body a and a geometry of body b, in the reference's order (world.hpp:206-282:
+  // geoms of a outer, geoms of b inner; capsule-sphere: +L/2 end, then -L/2 end).  Each is a pair of spheres:
   int num_pc;
   int pc_link_a[TDS_NPC], pc_link_b[TDS_NPC];  // owning links (global index; -1: the body's base)
   int pc_swap[TDS_NPC];         // 1: the dispatcher ran the pair with swapped arguments (sphere of A, capsule of B:
@@ -226,23 +231,37 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->t1[k] = (T)t1[k];
     d->t2[k] = (T)t2[k];
   }
-  const bool two = m->num_bodies == 2;
-  if (m->num_bodies > 2 || m->num_bodies < 0) TDS_FAIL(TDS_ERR_UNSUPPORTED, "worlds of more than two articulated bodies");
+  const int NBod = m->num_bodies;
+  const bool two = NBod >= 2;  // a world of several articulated bodies
+  if (NBod > TDS_NB || NBod < 0) TDS_FAIL(TDS_ERR_UNSUPPORTED, "worlds of more than TDS_MAX_BODIES articulated bodies");
+  int body_l0[TDS_NB + 1] = {0}, body_g0[TDS_NB + 1] = {0};  // first link / geom of each body (+ end)
   if (two) {
-    if (ex != nullptr || m->is_floating) TDS_FAIL(TDS_ERR_UNSUPPORTED, "two-body worlds: fixed bases and 1-dof joints");
-    if (m->step_mode != TDS_STEP_TAU) TDS_FAIL(TDS_ERR_UNSUPPORTED, "two-body worlds step in TAU mode");
-    if (m->reward_mode != TDS_REWARD_NONE) TDS_FAIL(TDS_ERR_UNSUPPORTED, "two-body worlds carry no reward rule");
-    if (m->body1_first_link < 1 || m->body1_first_link >= m->num_links || m->body1_first_geom < 0 ||
-        m->body1_first_geom > m->num_geoms)
-      TDS_FAIL(TDS_ERR_INVALID_ARG, "body1_first_link / body1_first_geom out of range");
-    d->two_bodies = 1;
-    for (int r = 0; r < 3; ++r) {
-      double g = 0;
-      for (int c = 0; c < 3; ++c) g += m->body1_base_X_world_rot[3 * r + c] * m->gravity[c];
-      d->grav2[r] = (T)g;
-      d->base_t2[r] = (T)m->body1_base_X_world_trans[r];
+    if (ex != nullptr || m->is_floating) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds: fixed bases and 1-dof joints");
+    if (m->step_mode != TDS_STEP_TAU) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds step in TAU mode");
+    if (m->reward_mode != TDS_REWARD_NONE) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds carry no reward rule");
+    d->num_bodies = NBod;
+    for (int b = 1; b < NBod; ++b) {
+      const tds_body_t &B = m->bodies[b];
+      if (B.is_floating) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds: fixed bases and 1-dof joints");
+      if (B.first_link <= body_l0[b - 1] || B.first_link >= m->num_links || B.first_geom < body_g0[b - 1] ||
+          B.first_geom > m->num_geoms)
+        TDS_FAIL(TDS_ERR_INVALID_ARG, "bodies[].first_link / first_geom out of range or not ascending");
+      body_l0[b] = B.first_link;
+      body_g0[b] = B.first_geom;
     }
-    for (int k = 0; k < 9; ++k) d->base_R2[k] = (T)m->body1_base_X_world_rot[k];
+    body_l0[NBod] = m->num_links;
+    body_g0[NBod] = m->num_geoms;
+    for (int b = 0; b < NBod; ++b) {
+      const double *R = b == 0 ? m->base_X_world_rot : m->bodies[b].base_X_world_rot;
+      const double *t = b == 0 ? m->base_X_world_trans : m->bodies[b].base_X_world_trans;
+      for (int r = 0; r < 3; ++r) {
+        double g = 0;
+        for (int c = 0; c < 3; ++c) g += R[3 * r + c] * m->gravity[c];
+        d->gravb[b][r] = (T)g;
+        d->base_tb[b][r] = (T)t[r];
+      }
+      for (int k = 0; k < 9; ++k) d->base_Rb[b][k] = (T)R[k];
+    }
   }
   // links
   int max_level = 0, pose_index = 0, ndof = 0;
@@ -256,11 +275,15 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->q_rec[i] = ex ? ex->q_rec[i] : (l.joint_type == TDS_JOINT_FIXED ? -1 : l.q_index);
     d->qd_rec[i] = ex ? ex->qd_rec[i] : (l.joint_type == TDS_JOINT_FIXED ? -1 : l.qd_index);
     d->parent[i] = l.parent;
-    d->body_of_link[i] = (two && i >= m->body1_first_link) ? 1 : 0;
+    {
+      int bo = 0;
+      while (two && bo + 1 < NBod && i >= body_l0[bo + 1]) ++bo;
+      d->body_of_link[i] = bo;
+      if (two && i == body_l0[bo]) d->body_dof0[bo] = ndof;
+    }
     if (two && l.parent >= 0 && d->body_of_link[l.parent] != d->body_of_link[i])
-      TDS_FAIL(TDS_ERR_INVALID_ARG, "a link's parent belongs to the other body");
-    if (two && (l.joint_type == TDS_JOINT_SPHERICAL)) TDS_FAIL(TDS_ERR_UNSUPPORTED, "two-body worlds: 1-dof joints");
-    if (two && i == m->body1_first_link) d->nd_a = ndof;
+      TDS_FAIL(TDS_ERR_INVALID_ARG, "a link's parent belongs to another body");
+    if (two && (l.joint_type == TDS_JOINT_SPHERICAL)) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds: 1-dof joints");
     d->level[i] = l.parent >= 0 ? d->level[l.parent] + 1 : 0;
     if (d->level[i] > max_level) max_level = d->level[i];
     d->joint_type[i] = l.joint_type;
@@ -303,6 +326,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->damping[i] = (T)l.damping;
   }
   if (ndof != nd) TDS_FAIL(TDS_ERR_INVALID_ARG, "dof_qd does not match the joints");
+  if (two) d->body_dof0[NBod] = ndof;
   for (int dd = 0; dd < nd; ++dd) d->dof_rec[dd] = d->qd_rec[d->dof_link[dd]];
   {
     // TDS_HIP_NO_CHAIN=1 sends every parent/child hand-over through LDS (A/B testing of the two paths)
@@ -348,7 +372,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
       if (fl) d->root_last = 5;  // the six pseudo links ARE the root joint (the kernels special-case their kinematics)
       d->kin_chain_last = d->root_last;
       const char *nk = getenv("TDS_HIP_NO_KINCHAIN");
-      if (use_chain && !fl && d->num_spherical == 0 && !d->two_bodies && nroots == 1 && !(nk && nk[0] == '1') &&
+      if (use_chain && !fl && d->num_spherical == 0 && d->num_bodies < 2 && nroots == 1 && !(nk && nk[0] == '1') &&
           m->num_links > 0 && m->links[0].parent < 0) {
         int c = 0;
         while (c + 1 < m->num_links && c + 1 < 16 && m->links[c + 1].parent == c && (d->chain_flags[c + 1] & 1)) ++c;
@@ -369,7 +393,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   d->euler_root = 0;
   {
     const char *ne = getenv("TDS_HIP_NO_EULERROOT");
-    bool ok = !(ne && ne[0] == '1') && !fl && d->num_spherical == 0 && !d->two_bodies && d->root_last == 5 &&
+    bool ok = !(ne && ne[0] == '1') && !fl && d->num_spherical == 0 && d->num_bodies < 2 && d->root_last == 5 &&
               d->kin_chain_last == 5 && m->num_links > 6;
     static const int want[6] = {TDS_JOINT_PRISMATIC_X, TDS_JOINT_PRISMATIC_Y, TDS_JOINT_PRISMATIC_Z,
                                 TDS_JOINT_REVOLUTE_X,  TDS_JOINT_REVOLUTE_Y,  TDS_JOINT_REVOLUTE_Z};
@@ -390,7 +414,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
       d->euler_root = ident ? 1 : 0;  // (a rotated base frame: the general scan)
     }
   }
-  d->dof_identity = (!fl && d->num_spherical == 0 && !d->two_bodies && m->num_links == m->dof_qd) ? 1 : 0;
+  d->dof_identity = (!fl && d->num_spherical == 0 && d->num_bodies < 2 && m->num_links == m->dof_qd) ? 1 : 0;
   for (int i = 0; i < m->num_links && d->dof_identity; ++i)
     if (m->links[i].qd_index != i) d->dof_identity = 0;
   d->num_levels = max_level + 1;
@@ -416,7 +440,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   if (m->has_plane) {
     for (int g = 0; g < m->num_geoms; ++g) {
       const tds_geom_t &G = m->geoms[g];
-      if (G.link < (two ? -2 : -1) || G.link >= m->num_links) TDS_FAIL(TDS_ERR_INVALID_ARG, "geom link out of range");
+      if (G.link < (two ? -NBod : -1) || G.link >= m->num_links) TDS_FAIL(TDS_ERR_INVALID_ARG, "geom link out of range");
       int npts = 0;
       double off[8][3];
       double radius = G.radius;
@@ -470,31 +494,43 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
       }
       return n;
     };
-    for (int ga = 0; ga < m->body1_first_geom; ++ga)
-      for (int gb = m->body1_first_geom; gb < m->num_geoms; ++gb) {
-        const tds_geom_t &A = m->geoms[ga], &B = m->geoms[gb];
-        const bool ss = A.type == TDS_GEOM_SPHERE && B.type == TDS_GEOM_SPHERE;
-        const bool cs = A.type == TDS_GEOM_CAPSULE && B.type == TDS_GEOM_SPHERE;   // contact_capsule_sphere
-        const bool sc = A.type == TDS_GEOM_SPHERE && B.type == TDS_GEOM_CAPSULE;   // ... through the dispatcher's swap
-        if (!ss && !cs && !sc) continue;  // (capsule-capsule, boxes, meshes: no function in the dispatcher)
-        if (A.link == -2 || (A.link >= m->body1_first_link) || (B.link >= 0 && B.link < m->body1_first_link) || B.link == -1)
-          TDS_FAIL(TDS_ERR_INVALID_ARG, "geometry listed under the wrong body");
-        double ea[2][3], eb[2][3];
-        const int na = ends(A, ea), nb = ends(B, eb);
-        for (int p = 0; p < (na > nb ? na : nb); ++p) {
-          if (npc >= TDS_NPC) TDS_FAIL(TDS_ERR_UNSUPPORTED, "too many contact points between the two bodies");
-          d->pc_link_a[npc] = A.link;
-          d->pc_link_b[npc] = B.link == -2 ? -1 : B.link;
-          d->pc_swap[npc] = sc ? 1 : 0;
-          d->pc_rad_a[npc] = (T)A.radius;
-          d->pc_rad_b[npc] = (T)B.radius;
-          for (int r = 0; r < 3; ++r) {
-            d->pc_loc_a[r][npc] = (T)ea[na == 2 ? p : 0][r];
-            d->pc_loc_b[r][npc] = (T)eb[nb == 2 ? p : 0][r];
+    int np = 0;
+    for (int ba = 0; ba < NBod; ++ba)
+      for (int bb = ba + 1; bb < NBod; ++bb) {
+        d->bpair_a[np] = ba;
+        d->bpair_b[np] = bb;
+        d->bpair_pc0[np] = npc;
+        for (int ga = body_g0[ba]; ga < body_g0[ba + 1]; ++ga)
+          for (int gb = body_g0[bb]; gb < body_g0[bb + 1]; ++gb) {
+            const tds_geom_t &A = m->geoms[ga], &B = m->geoms[gb];
+            const bool ss = A.type == TDS_GEOM_SPHERE && B.type == TDS_GEOM_SPHERE;
+            const bool cs = A.type == TDS_GEOM_CAPSULE && B.type == TDS_GEOM_SPHERE;   // contact_capsule_sphere
+            const bool sc = A.type == TDS_GEOM_SPHERE && B.type == TDS_GEOM_CAPSULE;   // ... through the dispatcher's swap
+            if (!ss && !cs && !sc) continue;  // (capsule-capsule, boxes, meshes: no function in the dispatcher)
+            auto owned = [&](const tds_geom_t &G, int b) {
+              return G.link < 0 ? G.link == -1 - b : (G.link >= body_l0[b] && G.link < body_l0[b + 1]);
+            };
+            if (!owned(A, ba) || !owned(B, bb)) TDS_FAIL(TDS_ERR_INVALID_ARG, "geometry listed under the wrong body");
+            double ea[2][3], eb[2][3];
+            const int na = ends(A, ea), nb = ends(B, eb);
+            for (int p = 0; p < (na > nb ? na : nb); ++p) {
+              if (npc >= TDS_NPC) TDS_FAIL(TDS_ERR_UNSUPPORTED, "too many contact points between the bodies");
+              d->pc_link_a[npc] = A.link < 0 ? -1 : A.link;
+              d->pc_link_b[npc] = B.link < 0 ? -1 : B.link;
+              d->pc_swap[npc] = sc ? 1 : 0;
+              d->pc_rad_a[npc] = (T)A.radius;
+              d->pc_rad_b[npc] = (T)B.radius;
+              for (int r = 0; r < 3; ++r) {
+                d->pc_loc_a[r][npc] = (T)ea[na == 2 ? p : 0][r];
+                d->pc_loc_b[r][npc] = (T)eb[nb == 2 ? p : 0][r];
+              }
+              ++npc;
+            }
           }
-          ++npc;
-        }
+        ++np;
       }
+    d->num_bpairs = np;
+    d->bpair_pc0[np] = npc;
   }
   d->num_pc = npc;
   for (int v = 0; v < d->num_visuals; ++v) {

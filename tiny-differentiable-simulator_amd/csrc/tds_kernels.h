@@ -101,7 +101,7 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
 #define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof, two_waves
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
-  if (h_model.two_bodies) return tds_launch_step_impl<T, TR, 3>(TDS_ARGS);
+  if (h_model.num_bodies >= 2) return tds_launch_step_impl<T, TR, 3>(TDS_ARGS);
   return tds_launch_step_impl<T, TR, 0>(TDS_ARGS);
 #undef TDS_ARGS
 }

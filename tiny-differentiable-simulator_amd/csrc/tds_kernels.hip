@@ -1253,16 +1253,17 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   constexpr bool fl = KIND == 1;
   constexpr bool sph = KIND == 2;
   constexpr bool gen = KIND == 1 || KIND == 2;
-  // KIND 3: worlds of TWO articulated bodies (fixed bases, 1-dof joints) in one lane group: the links of body B sit
-  // behind those of body A, the joint-space inertia is block diagonal (the LDL^T and every solve go through as they
-  // are), and a SECOND contact pass handles the contacts between the two bodies (world.hpp:206-282, 293-366).
+  // KIND 3: worlds of SEVERAL articulated bodies (<= TDS_MAX_BODIES; fixed bases, 1-dof joints) in one lane group: the
+  // links of body b + 1 sit behind those of body b, the joint-space inertia is block diagonal (the LDL^T and every solve
+  // go through as they are), and one MORE contact pass per body pair a < b handles the contacts between the bodies, in
+  // the reference's order (world.hpp:206-282, 293-366).
   constexpr bool two = KIND == 3;
   // contact solve in Gram form on the matrix cores (tds_gram_solve): two-wavefront workgroups of 16-lane environments
   constexpr bool GRAM = W2 && !LOOP && G == 16 && NDP <= 16 && std::is_same<T, double>::value;  // (opt-in; straight-line form only)
   // two-wavefront workgroups, narrow kernels: no barrier between the LDL^T and the helper's row solves — L reaches the
   // helper in two halves through LDS flags (tds_row_solve), the contact counts reach this wavefront the same way
   constexpr bool PIPE = W2 && NDP <= 16;
-  const bool body_b = two && isl && mdl->body_of_link[lsafe] != 0;
+  const int bod = (two && isl) ? mdl->body_of_link[lsafe] : 0;  // my link's body
   const int njd = mdl->nj;                       // joint dofs (== nd on a fixed base)
   const bool froot = fl && isl && li < 6;        // base pseudo link
   const bool sph_lane = sph && jt >= TDS_JOINT_SPH0;
@@ -1498,12 +1499,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
             for (int c = 0; c < 9; ++c) Rl[c] = Xw[lkc * TDS_S1 + c];
 #pragma unroll
             for (int c = 0; c < 3; ++c) pl[c] = Xw[lkc * TDS_S1 + 9 + c];
-            if (__any(lk < 0)) {  // wave-uniform, rare: a geometry on the base link (-2: base of the second body)
-              const bool on_base = lk < 0, b2 = two && lk == -2;
+            if (__any(lk < 0)) {  // wave-uniform, rare: a geometry on a base link (-1 - b: base of body b)
+              const bool on_base = lk < 0;
+              const int bl = (two && on_base) ? -1 - lk : 0;
 #pragma unroll
-              for (int c = 0; c < 9; ++c) Rl[c] = on_base ? (b2 ? mdl->base_R2[c] : mdl->base_R[c]) : Rl[c];
+              for (int c = 0; c < 9; ++c) Rl[c] = on_base ? (two ? mdl->base_Rb[bl][c] : mdl->base_R[c]) : Rl[c];
 #pragma unroll
-              for (int c = 0; c < 3; ++c) pl[c] = on_base ? (b2 ? mdl->base_t2[c] : mdl->base_t[c]) : pl[c];
+              for (int c = 0; c < 3; ++c) pl[c] = on_base ? (two ? mdl->base_tb[bl][c] : mdl->base_t[c]) : pl[c];
             }
           }
           T loc[3] = {pf_cp_loc[0], pf_cp_loc[1], pf_cp_loc[2]};
@@ -1681,19 +1683,25 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
   };
 
-  // ---- two-body worlds (KIND 3): contacts between a geometry of body A and a geometry of body B
-  //      (world.hpp:206-282; contact_sphere_sphere / contact_capsule_sphere, contact_point.hpp:43-94, 405-438; the
+  // ---- multi-body worlds (KIND 3): contacts between a geometry of body A and a geometry of body B, body pair by body
+  //      pair (world.hpp:206-282; contact_sphere_sphere / contact_capsule_sphere, contact_point.hpp:43-94, 405-438; the
   //      dispatcher's swapped order :478-495).  lane == pair contact point; the penetrating ones are compacted into
   //      pcx [17][NPCp]: point on A (3) | point on B (3) | normal on B (3) | tangent 1 (3) | tangent 2 (3) | distance |
-  //      dofs on the two paths base -> link (bit pattern).  Returns their number.
+  //      dofs on the two paths base -> link (bit pattern); the pairs' contacts one behind the other.  Returns their
+  //      numbers, eight bits per body pair.
   const int NPCp = L.NPCp;
-  auto phase_I2 = [&]() -> int {
-    int nb2 = 0;
+  auto phase_I2 = [&]() -> unsigned long long {
+    unsigned long long cnts = 0ull;
     if constexpr (two) {
       T *const Xw = E + L.Xw;
       T *const pcx = E + L.pc;
-      const int npc = mdl->num_pc;
-      for (int base = 0; base < npc; base += G) {
+      int nb_all = 0;  // slots taken by the earlier pairs
+      const int nbp = mdl->num_bpairs;
+      for (int pr = 0; pr < nbp; ++pr) {
+      const int pc0 = mdl->bpair_pc0[pr], npc = mdl->bpair_pc0[pr + 1];
+      const int bd_a = mdl->bpair_a[pr], bd_b = mdl->bpair_b[pr];
+      int nb2 = 0;
+      for (int base = pc0; base < npc; base += G) {
         const int k = base + lane;
         bool act = false;
         T Pa[3] = {T(0), T(0), T(0)}, Pb[3] = {T(0), T(0), T(0)}, nn[3] = {T(0), T(0), T(0)}, dist = T(0);
@@ -1716,13 +1724,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           if (__any(la < 0 || lb < 0)) {  // wave-uniform, rare: a geometry on a base
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-              Ra[c] = la < 0 ? mdl->base_R[c] : Ra[c];
-              Rb[c] = lb < 0 ? mdl->base_R2[c] : Rb[c];
+              Ra[c] = la < 0 ? mdl->base_Rb[bd_a][c] : Ra[c];
+              Rb[c] = lb < 0 ? mdl->base_Rb[bd_b][c] : Rb[c];
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              pa[c] = la < 0 ? mdl->base_t[c] : pa[c];
-              pb[c] = lb < 0 ? mdl->base_t2[c] : pb[c];
+              pa[c] = la < 0 ? mdl->base_tb[bd_a][c] : pa[c];
+              pb[c] = lb < 0 ? mdl->base_tb[bd_b][c] : pb[c];
             }
           }
           const T la3[3] = {mdl->pc_loc_a[0][k], mdl->pc_loc_a[1][k], mdl->pc_loc_a[2][k]};
@@ -1761,7 +1769,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         const unsigned long long mine = (G == 64) ? bal : ((bal >> (grp * G)) & ((1ull << (G & 63)) - 1ull));
         const int pre = __popcll(mine & ((1ull << lane) - 1ull));
         if (act) {
-          const int slot = nb2 + pre;
+          const int slot = nb_all + nb2 + pre;
           T t1[3], t2[3];
           plane_space_dev<T>(nn, t1, t2);
 #pragma unroll
@@ -1777,24 +1785,28 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         }
         nb2 += __popcll(mine);
       }
+      cnts |= (unsigned long long)nb2 << (8 * pr);
+      nb_all += nb2;
+      }
     }
-    return nb2;
+    return cnts;
   };
   // rows of the contacts between the bodies (lane == dof): the relative velocity is vel_a - vel_b, so a dof of body
   // A enters with -J_a, a dof of body B with +J_b (mb_constraint_solver.hpp:278-388: rows [J_a | J_b], right-hand
   // side from J_a qd_a - J_b qd_b, qd_a += M_a^-1 J_a^T p, qd_b -= M_b^-1 J_b^T p); each body's column is taken at
   // ITS contact point (point_jacobian2(mb_a, link_a, world_point_on_a) / (mb_b, link_b, world_point_on_b))
-  auto phase_J2 = [&](const int nb2, const int NB) {
+  auto phase_J2 = [&](const int pr, const int off, const int nb2, const int NB) {
     if constexpr (two) {
       T *const swd = E + L.swd;
-      T *const pcx = E + L.pc;
+      T *const pcx = E + L.pc + off;  // (the pair's contacts sit behind those of the earlier pairs)
       T *const Zs = E + L.Z;
       volatile T *const zov = (ovf != nullptr && live) ? ovf + (size_t)env * OVR * (NDs + 3) : nullptr;
       const int d = lane;
       T sd[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) sd[k] = d < nd ? swd[k * NDs + d] : T(0);
-      const bool of_a = d < mdl->nd_a;
+      const int bd_a = mdl->bpair_a[pr];
+      const bool of_a = d >= mdl->body_dof0[bd_a] && d < mdl->body_dof0[bd_a + 1];  // (a dof of a third body: masked out)
       const T sgn = of_a ? T(-1) : T(1);
       for (int a = 0; a < NB; ++a) {
         if (d < NDP && a < nb2) {
@@ -2306,15 +2318,15 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     if (mine) {
       if (parent < 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rq[k] = body_b ? mdl->base_R2[k] : mdl->base_R[k];
+        for (int k = 0; k < 9; ++k) Rq[k] = two ? mdl->base_Rb[bod][k] : mdl->base_R[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pq[k] = body_b ? mdl->base_t2[k] : mdl->base_t[k];
+        for (int k = 0; k < 3; ++k) pq[k] = two ? mdl->base_tb[bod][k] : mdl->base_t[k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) vq[k] = aq[k] = T(0);
         // base acceleration = -gravity in the body's own base frame (forward_dynamics.hpp:237-243)
-        aq[3] = body_b ? -mdl->grav2[0] : -mdl->grav[0];
-        aq[4] = body_b ? -mdl->grav2[1] : -mdl->grav[1];
-        aq[5] = body_b ? -mdl->grav2[2] : -mdl->grav[2];
+        aq[3] = two ? -mdl->gravb[bod][0] : -mdl->grav[0];
+        aq[4] = two ? -mdl->gravb[bod][1] : -mdl->grav[1];
+        aq[5] = two ? -mdl->gravb[bod][2] : -mdl->grav[2];
       }
       mat3_mul(Rq, Rp, R);
       T r[3];
@@ -2405,7 +2417,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   //         wavefront runs them (and the Jacobian rows) while this one goes on with the dynamics.
   int na = 0, NA = 0;
   bool wave_contacts = false;
-  int nb_pairs = 0, NB_pairs = 0;  // two-body worlds: penetrating contacts between the bodies (this group / wavefront max)
+  unsigned long long pair_cnts = 0ull;  // multi-body worlds: penetrating contacts between the bodies, 8 bits per body pair
+  bool any_pairs = false;               // ... any in this wavefront
   if constexpr (W2) {
     if (lane == 0) {
       xr[in_dim + 4] = T(0);  // "y~ is published" (phase F), polled by the helper wavefront
@@ -2430,8 +2443,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     // wavefront's environments (computed here, long before phase J needs it)
     NA = wave_max(na);
     if constexpr (two) {
-      nb_pairs = phase_I2();
-      NB_pairs = wave_max(nb_pairs);
+      pair_cnts = phase_I2();
+      any_pairs = __any(pair_cnts != 0ull) != 0;
     }
     phase_M1();
     flush_prev_records();
@@ -3085,11 +3098,18 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
     }  // wave_contacts
     if constexpr (two) {
-      // ---- second contact pass: body A against body B, with the velocities the plane passes left
-      //      (World::step resolves the body pairs one after the other: plane-A, plane-B, A-B; world.hpp:340-352)
+      // ---- further contact passes: body a against body b for every pair a < b, each with the velocities the earlier
+      //      passes left (World::step resolves the body pairs one after the other: plane-0, plane-1, .., 0-1, 0-2, ..,
+      //      1-2, ..; world.hpp:340-352)
+      int pair_off = 0;
+      for (int pr = 0; any_pairs && pr < mdl->num_bpairs; ++pr) {
+      const int nb_pairs = (int)((pair_cnts >> (8 * pr)) & 255ull);
+      const int NB_pairs = wave_max(nb_pairs);
+      const int my_off = pair_off;
+      pair_off += nb_pairs;
       if (NB_pairs > 0) {
         TDS_WAVE_SYNC();
-        T *const pcx = E + L.pc;
+        T *const pcx = E + L.pc + my_off;
         T *const Zs = E + L.Z;
         T *const rws = E + L.rows;
         T *const xs = E + L.xrow;
@@ -3097,7 +3117,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         volatile T *const rov = zov != nullptr ? zov + (size_t)OVR * NDs : nullptr;
         const T cfm = pf_cfm, erp_dt = pf_erp_dt, rest = pf_rest;
         const bool slab2 = 3 * NB_pairs > ZR;  // wave-uniform
-        phase_J2(nb_pairs, NB_pairs);
+        phase_J2(pr, my_off, nb_pairs, NB_pairs);
         TDS_WAVE_SYNC();
         if (OVR > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         // (the distance of pair contact a sits at pcx[15 NPCp + a]: the row solve reads cpx[3 NCPp + a])
@@ -3143,6 +3163,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         });
         if (d < nd) rhsx[d] -= w;
       }
+      }  // body pairs
     }
     TDS_WAVE_SYNC();
     if (di >= 0) qd_new = rhsx[di];
@@ -3453,7 +3474,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   const int ncp = m.has_plane ? m.num_cp : 0;
   L.NCPp = ncp > 0 ? ncp : 1;
   // two-body worlds: the contacts between the bodies are a second pass through the same row store
-  const int npc = m.two_bodies ? m.num_pc : 0;
+  const int npc = m.num_bodies >= 2 ? m.num_pc : 0;
   L.NPCp = npc > 0 ? npc : 1;
   const int nct = ncp > npc ? ncp : npc;  // contacts of the larger pass
   if (na_cap <= 0 || na_cap > nct) na_cap = nct;
@@ -3504,7 +3525,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   // Opt-in (TDS_HIP_GRAM=1): measured 0.4k of 32k cycles better than the z~ sweep at Ant x 4096 (profiles/r02d_gram_mfma.txt),
   // and an environment's low-order bits then depend on whether its wavefront-mates push NA past 5 (sweep) or not (Gram).
   const char *ge = getenv("TDS_HIP_GRAM");
-  L.gram_ok = (ge && ge[0] == '1' && w2 && lanes_per_env == 16 && ndp <= 16 && !m.two_bodies &&
+  L.gram_ok = (ge && ge[0] == '1' && w2 && lanes_per_env == 16 && ndp <= 16 && m.num_bodies < 2 &&
                L.Z - L.Xw >= TDS_GRAM_ZEROS + 16) ? 1 : 0;
   o = g1 > g2 ? g1 : g2;
   o = o > g3 ? o : g3;

@@ -13,13 +13,14 @@ import ctypes as C
 import json
 import os
 
-TDS_HIP_ABI_VERSION = 3
+TDS_HIP_ABI_VERSION = 4
 TDS_MAX_LINKS = 64
 TDS_MAX_GEOMS = 32
 TDS_MAX_VISUALS = 64
 TDS_MAX_ACTIONS = 32
 TDS_MAX_DOF = 32
 TDS_MAX_CONTACTS = 64
+TDS_MAX_BODIES = 4
 
 TDS_STEP_LOCOMOTION = 0
 TDS_STEP_TAU = 1
@@ -73,6 +74,21 @@ class Visual(C.Structure):
     ]
 
 
+class Body(C.Structure):
+    """body b >= 1 of a world with several articulated bodies (tds_body_t)"""
+    _fields_ = [
+        ("first_link", C.c_int32),
+        ("first_geom", C.c_int32),
+        ("is_floating", C.c_int32),
+        ("pad_", C.c_int32),
+        ("base_X_world_rot", C.c_double * 9),
+        ("base_X_world_trans", C.c_double * 3),
+        ("base_mass", C.c_double),
+        ("base_com", C.c_double * 3),
+        ("base_inertia", C.c_double * 9),
+    ]
+
+
 class Model(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32),
@@ -111,11 +127,8 @@ class Model(C.Structure):
         ("base_com", C.c_double * 3),
         ("base_inertia", C.c_double * 9),
         ("num_bodies", C.c_int32),
-        ("body1_first_link", C.c_int32),
-        ("body1_first_geom", C.c_int32),
-        ("pad3_", C.c_int32),
-        ("body1_base_X_world_rot", C.c_double * 9),
-        ("body1_base_X_world_trans", C.c_double * 3),
+        ("pad3_", C.c_int32 * 3),
+        ("bodies", Body * TDS_MAX_BODIES),
         ("links", Link * TDS_MAX_LINKS),
         ("geoms", Geom * TDS_MAX_GEOMS),
         ("visuals", Visual * TDS_MAX_VISUALS),
@@ -137,6 +150,26 @@ class Model(C.Structure):
             t = self.geoms[g].type
             n += {GEOM_SPHERE: 1, GEOM_CAPSULE: 2, GEOM_BOX: 8}.get(t, 0)
         return n if self.has_plane else 0
+
+    def body_table(self):
+        """per articulated body of the world: dict(links=(l0, l1), geoms=(g0, g1), q=(q0, q1), qd=(d0, d1),
+        tau=(t0, t1), floating) — index ranges into the link / geom tables and the q | qd | tau parts of the records
+        (one entry for a single-body model)"""
+        B = max(1, self.num_bodies)
+        out, q, d, t = [], 0, 0, 0
+        for b in range(B):
+            l0 = 0 if b == 0 else self.bodies[b].first_link
+            l1 = self.bodies[b + 1].first_link if b + 1 < B else self.num_links
+            g0 = 0 if b == 0 else self.bodies[b].first_geom
+            g1 = self.bodies[b + 1].first_geom if b + 1 < B else self.num_geoms
+            fl = bool(self.is_floating if b == 0 else self.bodies[b].is_floating)
+            nj = sum(3 if self.links[i].joint_type == JOINT_SPHERICAL else 1
+                     for i in range(l0, l1) if self.links[i].joint_type != JOINT_FIXED)
+            nsph = sum(1 for i in range(l0, l1) if self.links[i].joint_type == JOINT_SPHERICAL)
+            nq, nd = nj + nsph + (7 if fl else 0), nj + (6 if fl else 0)
+            out.append(dict(links=(l0, l1), geoms=(g0, g1), q=(q, q + nq), qd=(d, d + nd), tau=(t, t + nj), floating=fl))
+            q, d, t = q + nq, d + nd, t + nj
+        return out
 
     def set_soft_contact(self, stiffness: float, damping: float) -> None:
         """cfm/erp from a contact stiffness/damping pair — the only "spring-damper" contact
@@ -187,12 +220,9 @@ def model_to_dict(m: Model) -> dict:
     for k in _VECTORS:
         d[k] = [float(x) for x in getattr(m, k)]
     d["reset_obs_raw_xy"] = int(m.reset_obs_raw_xy)
-    if m.num_bodies > 1:  # two-body worlds only: the single-body files stay as they are
+    if m.num_bodies > 1:  # multi-body worlds only: the single-body files stay as they are
         d["num_bodies"] = int(m.num_bodies)
-        d["body1_first_link"] = int(m.body1_first_link)
-        d["body1_first_geom"] = int(m.body1_first_geom)
-        d["body1_base_X_world_rot"] = [float(x) for x in m.body1_base_X_world_rot]
-        d["body1_base_X_world_trans"] = [float(x) for x in m.body1_base_X_world_trans]
+        d["bodies"] = [_struct_to_dict(m.bodies[b]) for b in range(1, m.num_bodies)]   # (body 0: the model's own fields)
     d["base_mass"] = float(m.base_mass)
     for k in _OPTIONAL_VECTORS:
         d[k] = [float(x) for x in getattr(m, k)]
@@ -217,12 +247,8 @@ def model_from_dict(d: dict) -> Model:
             arr[i] = x
     m.reset_obs_raw_xy = d.get("reset_obs_raw_xy", 0)
     m.num_bodies = d.get("num_bodies", 0)
-    m.body1_first_link = d.get("body1_first_link", 0)
-    m.body1_first_geom = d.get("body1_first_geom", 0)
-    for i, x in enumerate(d.get("body1_base_X_world_rot", [])):
-        m.body1_base_X_world_rot[i] = x
-    for i, x in enumerate(d.get("body1_base_X_world_trans", [])):
-        m.body1_base_X_world_trans[i] = x
+    for b, bd in enumerate(d.get("bodies", [])):
+        _dict_to_struct(bd, m.bodies[b + 1])
     m.base_mass = d.get("base_mass", 0.0)
     for k in _OPTIONAL_VECTORS:
         arr = getattr(m, k)
