@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, MODELS, MULTI_BODY_MODELS, rel_err
+from conftest import FLOATING_MULTI_BODY_MODELS, GOLDEN, MODELS, MULTI_BODY_MODELS, rel_err
 
 import tds_amd
 from tds_amd import hip_backend
@@ -48,7 +48,7 @@ def test_golden_single_steps(name, built):
         sim.close()
 
 
-@pytest.mark.parametrize("name", MODELS + MULTI_BODY_MODELS)
+@pytest.mark.parametrize("name", MODELS + MULTI_BODY_MODELS + FLOATING_MULTI_BODY_MODELS)
 @pytest.mark.parametrize("form", ["default", "w1", "w2", "loop"])
 def test_no_step_reads_stale_lds(name, form, built, monkeypatch):
     """The kernels never clear LDS: a slot nobody wrote holds leftovers of earlier kernels, normally benign.  With every
@@ -83,7 +83,7 @@ def test_no_step_reads_stale_lds(name, form, built, monkeypatch):
             assert same.all(), (name, form, dtype, hex(pattern), int((~same).sum()))
 
 
-@pytest.mark.parametrize("name", MODELS + MULTI_BODY_MODELS)
+@pytest.mark.parametrize("name", MODELS + MULTI_BODY_MODELS + FLOATING_MULTI_BODY_MODELS)
 def test_launches_are_repeatable_bit_for_bit(name, built):
     """The same launch from the same state, twelve times: straight-line step, 2- and 3-substep launches of the step-loop
     build (whatever is stale in a register or in LDS differs from run to run; the cartpole's first visual pose came

@@ -172,3 +172,63 @@ def test_oracle_restates_multi_body_worlds_with_floating_bases(name, built):
         xr = gen.random_inputs(name, m_ref, 96, np.random.default_rng(778))
         assert rel_err(oraclelib.step(m, xr), r.step(xr)) < 1e-9
         r.close()
+
+
+def _floating_multi_states(name, m, n, rng):
+    """states as the fixture generator draws them (oracle/gen_golden.py: random_inputs), without the reference"""
+    import gen_golden as gen
+
+    return gen.random_inputs(name, m, n, rng)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FLOATING_MULTI_BODY_MODELS)
+def test_floating_multi_body_single_steps_and_trajectory(name, built):
+    """GPU (kernels of KIND 4): the reference's own single steps and its 100 / 200-step closed-loop trajectory (per-step
+    resync), double and float records"""
+    import torch
+    from tds_amd import hip_backend
+
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sim = hip_backend.HipSim(m, g["x"].shape[0], dtype="f64")
+    y = sim.forward_zero(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    touching = g["active_contacts"] > 0
+    e_free, e_touch = rel_err(y[~touching], g["y"][~touching]), rel_err(y[touching], g["y"][touching])
+    print(f"{name}: max rel err vs the reference — {int(touching.sum())} states with contacts between the bodies "
+          f"{e_touch:.3e}, {int((~touching).sum())} without {e_free:.3e}")
+    assert e_free < TOL and e_touch < TOL
+    nq, nd = m.dof_q, m.dof_qd
+    T = g["traj_y"].shape[0]
+    x = np.tile(g["traj_x0"], (T, 1))
+    x[1:, :nq + nd] = g["traj_y"][:-1, :nq + nd]
+    x[:, nq + nd:nq + nd + m.action_dim] = g["traj_actions"]
+    simt = hip_backend.HipSim(m, T, dtype="f64")
+    yt = simt.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert rel_err(yt, g["traj_y"]) < TOL
+    x32 = g["x"].astype(np.float32)
+    yf = hip_backend.HipSim(m, x32.shape[0], dtype="mixed").forward_zero(torch.from_numpy(x32).cuda()).double().cpu().numpy()
+    yd = sim.forward_zero(torch.from_numpy(x32).double().cuda()).cpu().numpy()
+    assert rel_err(yf, yd, floor=1e-6 * max(1.0, np.abs(yd).max())) < 1e-4 or rel_err(yf, yd) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FLOATING_MULTI_BODY_MODELS)
+def test_floating_multi_body_fresh_states_and_closed_loop_against_the_oracle(name, built):
+    """2048 fresh states against the C oracle, then 40 closed-loop steps of all of them with per-step resync"""
+    import torch
+    import oraclelib
+    from tds_amd import hip_backend
+
+    m = tds_amd.load_model(name)
+    n, nq, nd = 2048, m.dof_q, m.dof_qd
+    x = _floating_multi_states(name, m, n, np.random.default_rng(97531))
+    sim = hip_backend.HipSim(m, n, dtype="f64")
+    worst = 0.0
+    for t in range(40):
+        y = sim.forward_zero(torch.from_numpy(x).cuda()).cpu().numpy()
+        y_ref = oraclelib.step(m, x)
+        worst = max(worst, rel_err(y, y_ref))
+        assert rel_err(y, y_ref) < TOL, (name, t)
+        x[:, :nq + nd] = y_ref[:, :nq + nd]
+    print(f"{name}: 2048 states x 40 closed-loop steps, worst per-step rel err vs the oracle {worst:.3e}")

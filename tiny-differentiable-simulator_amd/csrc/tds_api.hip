@@ -309,7 +309,8 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     const bool is_fl = c64 ? s->h64.is_floating : s->h32.is_floating;
     const bool is_sph = c64 ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
     const bool is_two = c64 ? s->h64.num_bodies >= 2 : s->h32.num_bodies >= 2;
-    const int kind = is_fl ? 1 : (is_sph ? 2 : (is_two ? 3 : 0));
+    const bool is_mfl = c64 ? s->h64.multi_floating != 0 : s->h32.multi_floating != 0;
+    const int kind = is_fl ? 1 : (is_sph ? 2 : (is_two ? (is_mfl ? 4 : 3) : 0));
     int e = dtype == TDS_DTYPE_F64         ? tds_kernel_max_dynamic_lds<double, double>(s->lanes, s->lds.NDP, lds_bytes, kind)
             : dtype == TDS_DTYPE_F64_REC32 ? tds_kernel_max_dynamic_lds<double, float>(s->lanes, s->lds.NDP, lds_bytes, kind)
                                            : tds_kernel_max_dynamic_lds<float, float>(s->lanes, s->lds.NDP, lds_bytes, kind);
@@ -607,7 +608,8 @@ int pool_alloc(tds_hip_sim *s) {
     const bool is_fl = s->compute_f64() ? s->h64.is_floating : s->h32.is_floating;
     const bool is_sph = s->compute_f64() ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
     const bool is_two = s->compute_f64() ? s->h64.num_bodies >= 2 : s->h32.num_bodies >= 2;
-    const int kind = is_fl ? 1 : (is_sph ? 2 : (is_two ? 3 : 0));
+    const bool is_mfl = s->compute_f64() ? s->h64.multi_floating != 0 : s->h32.multi_floating != 0;
+    const int kind = is_fl ? 1 : (is_sph ? 2 : (is_two ? (is_mfl ? 4 : 3) : 0));
     const int e = s->dtype == TDS_DTYPE_F64         ? tds_kernel_max_dynamic_lds<double, double>(s->lanes, s->pool_lds.NDP, lds_bytes, kind)
                   : s->dtype == TDS_DTYPE_F64_REC32 ? tds_kernel_max_dynamic_lds<double, float>(s->lanes, s->pool_lds.NDP, lds_bytes, kind)
                                                     : tds_kernel_max_dynamic_lds<float, float>(s->lanes, s->pool_lds.NDP, lds_bytes, kind);

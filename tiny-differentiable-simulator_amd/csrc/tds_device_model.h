@@ -110,6 +110,16 @@ struct DevModel {
   // body pairs a < b in the reference's order (world.hpp:212-216: 0-1, 0-2, .., 1-2, ..); each is a contact pass of its
   // own; the contact points of pair p are pc[pair_pc0[p] .. pair_pc0[p + 1] - 1]
   int num_bpairs, bpair_a[TDS_NBP], bpair_b[TDS_NBP], bpair_pc0[TDS_NBP + 1];
+  // ... with FLOATING bases among the bodies (kernels of KIND 4): a floating body's six pseudo links sit in front of its
+  // links, its dofs are numbered joints first, base last (see is_floating above), body by body
+  int multi_floating;           // 1: some body of the world has a floating base
+  int fb_k[TDS_NL];             // lane is pseudo link k = 0..5 of a floating body's base; -1: an ordinary link
+  int fb_q[TDS_NL];             // pseudo links: index of the body's quaternion in the q record (position at + 4)
+  int tau_rec[TDS_NL];          // TAU mode: index of the link's torque within the action part of the record, -1: none
+  int dof_body[TDS_ND];         // body of dof d
+  int dof_joint0[TDS_ND];       // first (joint) dof of that body
+  int dof_base0[TDS_ND];        // first of the six base dofs of that body; -1: its base is fixed
+  int dof_fbq[TDS_ND];          // d is a BASE dof: index of the body's quaternion in the q record; else -1
   // contact points between a geometry of body a and a geometry of body b, in the reference's order (world.hpp:206-282:
   // geoms of a outer, geoms of b inner; capsule-sphere: +L/2 end, then -L/2 end).  Each is a pair of spheres:
   int num_pc;
@@ -141,6 +151,10 @@ struct TdsExpanded {
                         // spherical lanes: 2 = its torque is stored (floating base or link index >= 4, :215-221), 1 = dropped
   int sph_q[TDS_NL];    // spherical lanes: offset of the joint's quaternion in the q record (all three lanes)
   int num_spherical;
+  // worlds of several bodies with floating bases among them (tds_expand_multibody):
+  int multi;            // 1: expanded by tds_expand_multibody
+  int body_fl[TDS_NB];  // body b has a floating base
+  int fb_k[TDS_NL], fb_q[TDS_NL], tau_rec[TDS_NL];   // see DevModel
 };
 
 // `ex`: m == &ex->m is an EXPANDED model; NULL: a plain fixed-base model of 1-dof joints.
@@ -148,17 +162,21 @@ template <typename T>
 static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *why, const TdsExpanded *ex) {
   memset(d, 0, sizeof(*d));
   why[0] = 0;
-  const bool fl = ex != nullptr && m->is_floating != 0;
+  const bool exm = ex != nullptr && ex->multi != 0;  // several bodies, floating bases among them
+  const bool fl = ex != nullptr && !exm && m->is_floating != 0;
   const int nsph = ex ? ex->num_spherical : 0;
+  int nflb = 0;  // floating bodies of a multi-body world
+  for (int b = 0; exm && b < m->num_bodies && b < TDS_NB; ++b) nflb += ex->body_fl[b] ? 1 : 0;
 #define TDS_FAIL(code, msg)          \
   do {                               \
     strncpy(why, msg, 127);          \
     why[127] = 0;                    \
     return code;                     \
   } while (0)
+  auto fixed_joint = [](const tds_link_t &l) { return l.joint_type == TDS_JOINT_FIXED; };
   if (m->abi_version != TDS_HIP_ABI_VERSION) TDS_FAIL(TDS_ERR_INVALID_ARG, "model abi_version mismatch");
   if (m->num_links < 1 || m->num_links > TDS_NL) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_links out of range");
-  if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd + (fl ? 1 : 0) + nsph || m->dof_q > TDS_ND)
+  if (m->dof_qd < 1 || m->dof_qd > TDS_ND || m->dof_q != m->dof_qd + (fl ? 1 : 0) + nflb + nsph || m->dof_q > TDS_ND)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "dof out of range (<= 32 velocities, <= 32 coordinates) or dof_q inconsistent with the joints");
   if (nsph && m->reward_mode != TDS_REWARD_NONE && m->reward_mode != TDS_REWARD_HUMANOID)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "the Ant / Laikago reward rules read a 1-dof-joint state record");
@@ -170,7 +188,8 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   if (fl && m->reward_mode != TDS_REWARD_NONE)
     TDS_FAIL(TDS_ERR_UNSUPPORTED, "the Ant / Laikago reward rules read a fixed-base state record");
   d->is_floating = fl ? 1 : 0;
-  d->nj = fl ? m->dof_qd - 6 : m->dof_qd;
+  d->nj = fl ? m->dof_qd - 6 : m->dof_qd - 6 * nflb;
+  d->multi_floating = exm ? 1 : 0;
   if (m->num_geoms < 0 || m->num_geoms > TDS_MAX_GEOMS) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_geoms out of range");
   if (m->num_visuals < 0 || m->num_visuals > TDS_NV) TDS_FAIL(TDS_ERR_INVALID_ARG, "num_visuals out of range");
   if (m->step_mode != TDS_STEP_LOCOMOTION && m->step_mode != TDS_STEP_TAU)
@@ -236,13 +255,14 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   if (NBod > TDS_NB || NBod < 0) TDS_FAIL(TDS_ERR_UNSUPPORTED, "worlds of more than TDS_MAX_BODIES articulated bodies");
   int body_l0[TDS_NB + 1] = {0}, body_g0[TDS_NB + 1] = {0};  // first link / geom of each body (+ end)
   if (two) {
-    if (ex != nullptr || m->is_floating) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds: fixed bases and 1-dof joints");
+    if ((ex != nullptr && !exm) || (!exm && m->is_floating))
+      TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds: 1-dof joints (floating bases through tds_expand_multibody)");
     if (m->step_mode != TDS_STEP_TAU) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds step in TAU mode");
     if (m->reward_mode != TDS_REWARD_NONE) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds carry no reward rule");
     d->num_bodies = NBod;
     for (int b = 1; b < NBod; ++b) {
       const tds_body_t &B = m->bodies[b];
-      if (B.is_floating) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds: fixed bases and 1-dof joints");
+      if (B.is_floating && !exm) TDS_FAIL(TDS_ERR_UNSUPPORTED, "multi-body worlds: a floating base needs the expanded model");
       if (B.first_link <= body_l0[b - 1] || B.first_link >= m->num_links || B.first_geom < body_g0[b - 1] ||
           B.first_geom > m->num_geoms)
         TDS_FAIL(TDS_ERR_INVALID_ARG, "bodies[].first_link / first_geom out of range or not ascending");
@@ -257,7 +277,9 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
       for (int r = 0; r < 3; ++r) {
         double g = 0;
         for (int c = 0; c < 3; ++c) g += R[3 * r + c] * m->gravity[c];
-        d->gravb[b][r] = (T)g;
+        // (a floating body: the WORLD components of gravity, added to its base acceleration as they are,
+        //  forward_dynamics.hpp:315-319)
+        d->gravb[b][r] = (T)((exm && ex->body_fl[b]) ? m->gravity[r] : g);
         d->base_tb[b][r] = (T)t[r];
       }
       for (int k = 0; k < 9; ++k) d->base_Rb[b][k] = (T)R[k];
@@ -304,6 +326,9 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     anc_links[i] = (l.parent >= 0 ? anc_links[l.parent] | (1u << l.parent) : 0u);
     d->act_index[i] = -1;
     d->sph_q[i] = sph_lane ? ex->sph_q[i] : -1;
+    d->fb_k[i] = exm ? ex->fb_k[i] : -1;
+    d->fb_q[i] = exm ? ex->fb_q[i] : -1;
+    d->tau_rec[i] = exm ? ex->tau_rec[i] : (fixed_joint(l) ? -1 : l.qd_index);
     const bool pd_here = ex ? ex->pd_on[i] != 0 : i >= m->pd_start_link;
     if (m->step_mode == TDS_STEP_LOCOMOTION && pd_here && sph_lane) {
       // the PD block's spherical branch (locomotion_contact_simulation.h:188-226): four pose slots per joint (:223),
@@ -327,6 +352,19 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   }
   if (ndof != nd) TDS_FAIL(TDS_ERR_INVALID_ARG, "dof_qd does not match the joints");
   if (two) d->body_dof0[NBod] = ndof;
+  for (int dd = 0; dd < TDS_ND; ++dd) d->dof_base0[dd] = d->dof_fbq[dd] = -1;
+  if (two) {
+    for (int b = 0; b < NBod; ++b) {
+      const bool bf = exm && ex->body_fl[b];
+      for (int dd = d->body_dof0[b]; dd < d->body_dof0[b + 1]; ++dd) {
+        d->dof_body[dd] = b;
+        d->dof_joint0[dd] = d->body_dof0[b];
+        d->dof_base0[dd] = bf ? d->body_dof0[b + 1] - 6 : -1;
+        const int lk = d->dof_link[dd];
+        d->dof_fbq[dd] = (bf && d->fb_k[lk] >= 0) ? d->fb_q[lk] : -1;
+      }
+    }
+  }
   for (int dd = 0; dd < nd; ++dd) d->dof_rec[dd] = d->qd_rec[d->dof_link[dd]];
   {
     // TDS_HIP_NO_CHAIN=1 sends every parent/child hand-over through LDS (A/B testing of the two paths)
@@ -627,10 +665,12 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
   if (!e) return nullptr;
   memcpy(&e->m, m, sizeof(*m));
   e->num_spherical = nsph;
+  e->multi = 0;
+  for (int k = 0; k < TDS_NB; ++k) e->body_fl[k] = 0;
   for (int k = 0; k < TDS_NL; ++k) {
     e->q_rec[k] = e->qd_rec[k] = -1;
     e->pd_on[k] = 0;
-    e->sph_q[k] = -1;
+    e->sph_q[k] = e->fb_k[k] = e->fb_q[k] = e->tau_rec[k] = -1;
   }
   for (int k = 0; k < base; ++k) {
     tds_link_t &L = e->m.links[k];
@@ -738,12 +778,125 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
   return e;
 }
 
+// A world of several articulated bodies with floating bases among them -> the expanded model: body by body, the six
+// pseudo links of a floating base (see tds_expand_model) in front of the body's links; internal dofs numbered per body
+// joints first, base last, the bodies one behind the other (a block-diagonal joint-space inertia whose blocks each end
+// in their base's 6 x 6).  Fixed links are kept as links, spherical joints are not taken.
+// Returns a malloc'ed TdsExpanded or NULL (why filled).
+static inline TdsExpanded *tds_expand_multibody(const tds_model_t *m, char *why) {
+  why[0] = 0;
+#define TDS_XFAIL(msg)       \
+  do {                       \
+    strncpy(why, msg, 127);  \
+    why[127] = 0;            \
+    free(e);                 \
+    return nullptr;          \
+  } while (0)
+  TdsExpanded *e = nullptr;
+  const int B = m->num_bodies;
+  if (B < 2 || B > TDS_NB) TDS_XFAIL("num_bodies out of range");
+  if (m->num_links < 0 || m->num_links > TDS_MAX_LINKS) TDS_XFAIL("num_links out of range");
+  e = (TdsExpanded *)malloc(sizeof(TdsExpanded));
+  if (!e) return nullptr;
+  memcpy(&e->m, m, sizeof(*m));
+  e->num_spherical = 0;
+  e->multi = 1;
+  for (int k = 0; k < TDS_NL; ++k) {
+    e->q_rec[k] = e->qd_rec[k] = -1;
+    e->pd_on[k] = 0;
+    e->sph_q[k] = e->fb_k[k] = e->fb_q[k] = e->tau_rec[k] = -1;
+  }
+  int carrier[TDS_MAX_LINKS], base_lane[TDS_NB];
+  int nx = 0, ndof = 0, nq_rec = 0, nqd_rec = 0, ntau = 0;
+  for (int b = 0; b < B; ++b) {
+    const int l0 = b == 0 ? 0 : m->bodies[b].first_link, l1 = b + 1 < B ? m->bodies[b + 1].first_link : m->num_links;
+    if (l0 < 0 || l1 < l0 || l1 > m->num_links) TDS_XFAIL("bodies[].first_link out of range or not ascending");
+    const bool fl = (b == 0 ? m->is_floating : m->bodies[b].is_floating) != 0;
+    e->body_fl[b] = fl ? 1 : 0;
+    int nj = 0;
+    for (int i = l0; i < l1; ++i) {
+      if (m->links[i].joint_type == TDS_JOINT_SPHERICAL) TDS_XFAIL("multi-body worlds: 1-dof joints");
+      nj += m->links[i].joint_type != TDS_JOINT_FIXED;
+    }
+    if (nx + (fl ? 6 : 0) + (l1 - l0) > TDS_NL) TDS_XFAIL("too many links for 32 lanes (one per link, 6 per floating base)");
+    if (!fl && l1 == l0) TDS_XFAIL("a body with a fixed base and no links");
+    if (b > 0) e->m.bodies[b].first_link = nx;  // (expanded index)
+    base_lane[b] = fl ? nx + 5 : -1;
+    if (fl) {
+      const int bd = ndof + nj;  // the base's six dofs follow the body's joints
+      for (int k = 0; k < 6; ++k) {
+        tds_link_t &L = e->m.links[nx];
+        memset(&L, 0, sizeof(L));
+        L.joint_type = k < 3 ? TDS_JOINT_REVOLUTE_X + k : TDS_JOINT_PRISMATIC_X + (k - 3);
+        L.parent = k == 0 ? -1 : nx - 1;
+        L.q_index = L.qd_index = bd + k;
+        L.X_T_rot[0] = L.X_T_rot[4] = L.X_T_rot[8] = 1.0;
+        L.S[k] = 1.0;
+        e->qd_rec[nx] = nqd_rec + k;
+        e->fb_k[nx] = k;
+        e->fb_q[nx] = nq_rec;
+        ++nx;
+      }
+      tds_link_t &L5 = e->m.links[nx - 1];
+      L5.mass = b == 0 ? m->base_mass : m->bodies[b].base_mass;
+      memcpy(L5.com, b == 0 ? m->base_com : m->bodies[b].base_com, sizeof(L5.com));
+      memcpy(L5.inertia, b == 0 ? m->base_inertia : m->bodies[b].base_inertia, sizeof(L5.inertia));
+      nq_rec += 7;   // [quat xyzw | pos], then the joints (multi_body.hpp:324-349)
+      nqd_rec += 6;  // [omega | v]
+    }
+    for (int i = l0; i < l1; ++i) {
+      const tds_link_t &l = m->links[i];
+      if (l.parent >= i || l.parent < -1 || (l.parent >= 0 && l.parent < l0))
+        TDS_XFAIL("links must be ordered parent-before-child within their body");
+      tds_link_t &L = e->m.links[nx];
+      L = l;
+      L.parent = l.parent < 0 ? base_lane[b] : carrier[l.parent];
+      if (l.joint_type != TDS_JOINT_FIXED) {
+        if (l.q_index != nq_rec || l.qd_index != nqd_rec) TDS_XFAIL("q/qd indices must be dense in link order over all bodies");
+        L.q_index = L.qd_index = ndof++;
+        e->q_rec[nx] = nq_rec++;
+        e->qd_rec[nx] = nqd_rec++;
+        e->tau_rec[nx] = ntau++;
+      }
+      carrier[i] = nx++;
+    }
+    if (fl) ndof += 6;
+  }
+  if (ndof != m->dof_qd || nq_rec != m->dof_q || nqd_rec != m->dof_qd) TDS_XFAIL("dof_q / dof_qd inconsistent with the bases and the joints");
+  e->m.num_links = nx;
+  e->m.is_floating = 0;  // (per body: body_fl)
+  for (int g = 0; g < m->num_geoms && g < TDS_MAX_GEOMS; ++g) {
+    const int lk = m->geoms[g].link;
+    if (lk < -B || lk >= m->num_links) TDS_XFAIL("geom link out of range");
+    e->m.geoms[g].link = lk < 0 ? (base_lane[-1 - lk] >= 0 ? base_lane[-1 - lk] : lk) : carrier[lk];
+  }
+  for (int v = 0; v < m->num_visuals && v < TDS_MAX_VISUALS; ++v) {
+    const int lk = m->visuals[v].link;
+    if (lk < 0 || lk >= m->num_links) TDS_XFAIL("visual link out of range");
+    e->m.visuals[v].link = carrier[lk];
+  }
+  e->m.pd_start_link = 0;
+#undef TDS_XFAIL
+  return e;
+}
+
 // Returns TDS_OK or an error code; `why` (>= 128 bytes) receives the reason.
 template <typename T>
 static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) {
   if (m->abi_version != TDS_HIP_ABI_VERSION) {
     strncpy(why, "model abi_version mismatch", 127);
     return TDS_ERR_INVALID_ARG;
+  }
+  if (m->num_bodies >= 2 && m->num_bodies <= TDS_NB) {
+    bool any_fl = m->is_floating != 0;
+    for (int b = 1; b < m->num_bodies; ++b) any_fl |= m->bodies[b].is_floating != 0;
+    if (any_fl) {
+      TdsExpanded *e = tds_expand_multibody(m, why);
+      if (!e) return TDS_ERR_UNSUPPORTED;
+      const int rc = tds_build_dev_model_impl<T>(&e->m, d, why, e);
+      free(e);
+      return rc;
+    }
   }
   const char *ffx = getenv("TDS_HIP_FOLD_FIXED");
   bool general = m->is_floating != 0 || m->num_links > TDS_NL || (ffx && ffx[0] == '1');

@@ -85,8 +85,8 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
 //   x_feedback (optional) [n_envs][input_dim]  receives the new q, qd (closed-loop stepping)
 //   obs_out    (optional) [n_envs][dof_q+dof_qd+2]  observation | reward | done
 //   ovf        [n_envs][ovrows][NDs+3] scratch slab for surplus constraint rows (NULL iff ovrows == 0)
-// (KIND 0: plain fixed-base kernels, 1: floating base, 2: spherical joints; explicit instantiations live in the
-//  kernel translation units)
+// (KIND 0: plain fixed-base kernels, 1: floating base, 2: spherical joints, 3: worlds of several articulated bodies,
+//  4: ... with floating bases among them; explicit instantiations live in the kernel translation units)
 template <typename T, typename TR, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                          const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
@@ -101,6 +101,7 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
 #define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof, two_waves
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
+  if (h_model.num_bodies >= 2 && h_model.multi_floating) return tds_launch_step_impl<T, TR, 4>(TDS_ARGS);
   if (h_model.num_bodies >= 2) return tds_launch_step_impl<T, TR, 3>(TDS_ARGS);
   return tds_launch_step_impl<T, TR, 0>(TDS_ARGS);
 #undef TDS_ARGS
@@ -113,6 +114,7 @@ inline int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes, int
   return kind == 1 ? tds_kernel_max_dynamic_lds_impl<T, TR, 1>(lanes_per_env, ndp, bytes)
          : kind == 2 ? tds_kernel_max_dynamic_lds_impl<T, TR, 2>(lanes_per_env, ndp, bytes)
          : kind == 3 ? tds_kernel_max_dynamic_lds_impl<T, TR, 3>(lanes_per_env, ndp, bytes)
+         : kind == 4 ? tds_kernel_max_dynamic_lds_impl<T, TR, 4>(lanes_per_env, ndp, bytes)
                      : tds_kernel_max_dynamic_lds_impl<T, TR, 0>(lanes_per_env, ndp, bytes);
 }
 

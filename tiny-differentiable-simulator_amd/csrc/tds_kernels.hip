@@ -1252,12 +1252,16 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // q record holds the joint's quaternion (4 coordinates) at q_rec of the first lane.
   constexpr bool fl = KIND == 1;
   constexpr bool sph = KIND == 2;
-  constexpr bool gen = KIND == 1 || KIND == 2;
+  constexpr bool gen = KIND == 1 || KIND == 2 || KIND == 4;  // (the q / qd records are addressed through index tables)
   // KIND 3: worlds of SEVERAL articulated bodies (<= TDS_MAX_BODIES; fixed bases, 1-dof joints) in one lane group: the
   // links of body b + 1 sit behind those of body b, the joint-space inertia is block diagonal (the LDL^T and every solve
   // go through as they are), and one MORE contact pass per body pair a < b handles the contacts between the bodies, in
   // the reference's order (world.hpp:206-282, 293-366).
-  constexpr bool two = KIND == 3;
+  // KIND 4: ... with FLOATING bases among the bodies: a floating body's six pseudo links (see KIND 1) sit in front of
+  // its links, its dofs are numbered joints first, base last, so that every diagonal block of the factorisation ends in
+  // its base's 6 x 6 Schur complement; the floating-base quirks of the reference are applied body by body.
+  constexpr bool flm = KIND == 4;
+  constexpr bool two = KIND == 3 || KIND == 4;
   // contact solve in Gram form on the matrix cores (tds_gram_solve): two-wavefront workgroups of 16-lane environments
   constexpr bool GRAM = W2 && !LOOP && G == 16 && NDP <= 16 && std::is_same<T, double>::value;  // (opt-in; straight-line form only)
   // two-wavefront workgroups, narrow kernels: no barrier between the LDL^T and the helper's row solves — L reaches the
@@ -1265,7 +1269,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   constexpr bool PIPE = W2 && NDP <= 16;
   const int bod = (two && isl) ? mdl->body_of_link[lsafe] : 0;  // my link's body
   const int njd = mdl->nj;                       // joint dofs (== nd on a fixed base)
-  const bool froot = fl && isl && li < 6;        // base pseudo link
+  const int fbk = (flm && isl) ? mdl->fb_k[lsafe] : (fl && isl && li < 6 ? li : -1);  // pseudo link k of a floating base
+  const int fbq = (flm && isl) ? mdl->fb_q[lsafe] : 0;  // ... its body's quaternion in the q record (position at + 4)
+  const bool froot = fbk >= 0;                   // base pseudo link
+  // lane == dof role: the first of the six base dofs of my dof's body (-1: its base is fixed), whether my dof is one of
+  // them, and where that body's quaternion sits in the q record
+  const int dbase0 = flm ? (lane < nd ? mdl->dof_base0[lane] : -1) : (fl ? njd : -1);
+  const int dfbq = flm ? (lane < nd ? mdl->dof_fbq[lane] : -1) : 0;
+  const bool bdof = flm ? dfbq >= 0 : (fl && lane >= njd && lane < nd);
   const bool sph_lane = sph && jt >= TDS_JOINT_SPH0;
   const int qri = gen ? (isl ? mdl->q_rec[lsafe] : -1) : di;    // (-1: this lane owns no coordinate)
   const int qdri = gen ? (isl ? mdl->qd_rec[lsafe] : -1) : di;
@@ -1635,11 +1646,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       T sd[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) sd[k] = d < nd ? swd[k * NDs + d] : T(0);
-      if (fl && d >= njd && d < nd) {
+      if ((fl || flm) && bdof) {
         // the reference's point Jacobian takes the base dofs along WORLD axes about the base origin:
         // [ -[r]x | 1 ],  r = point - base position   (jacobian.hpp:39-56)
-        const int kb = d - njd;
-        const T pb[3] = {xr[4], xr[5], xr[6]};
+        const int kb = d - dbase0;
+        const T pb[3] = {xr[dfbq + 4], xr[dfbq + 5], xr[dfbq + 6]};
 #pragma unroll
         for (int k = 0; k < 6; ++k) sd[k] = T(0);
         if (kb < 3) {
@@ -1805,6 +1816,21 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       T sd[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) sd[k] = d < nd ? swd[k * NDs + d] : T(0);
+      if (flm && bdof) {  // base dofs of a floating body: WORLD axes about the base origin (see phase J)
+        const int kb = d - dbase0;
+        const T pb[3] = {xr[dfbq + 4], xr[dfbq + 5], xr[dfbq + 6]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sd[k] = T(0);
+        if (kb < 3) {
+          const T e[3] = {kb == 0 ? T(1) : T(0), kb == 1 ? T(1) : T(0), kb == 2 ? T(1) : T(0)};
+          sd[0] = e[0];
+          sd[1] = e[1];
+          sd[2] = e[2];
+          cross3(pb, e, sd + 3);
+        } else {
+          sd[kb] = T(1);
+        }
+      }
       const int bd_a = mdl->bpair_a[pr];
       const bool of_a = d >= mdl->body_dof0[bd_a] && d < mdl->body_dof0[bd_a + 1];  // (a dof of a third body: masked out)
       const T sgn = of_a ? T(-1) : T(1);
@@ -1960,6 +1986,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         f = f < max_force ? f : max_force;
         tau = f;
       }
+    } else if (flm) {  // (torques of the joints of all bodies, one behind the other; base dofs carry none)
+      const int ti = isl ? mdl->tau_rec[lsafe] : -1;
+      if (ti >= 0) tau = settling ? T(0) : xr[nq + nd + ti];
     } else if (di >= 0 && di < adim) {  // (adim == joint dofs: the base dofs of a floating base carry no torque)
       tau = settling ? T(0) : xr[nq + nd + di];
     }
@@ -2327,6 +2356,23 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         aq[3] = two ? -mdl->gravb[bod][0] : -mdl->grav[0];
         aq[4] = two ? -mdl->gravb[bod][1] : -mdl->grav[1];
         aq[5] = two ? -mdl->gravb[bod][2] : -mdl->grav[2];
+        if (flm && fbk == 0) {
+          // floating base (kinematics.hpp:35-47): base_X_world = (quat_to_matrix(q[0..3]), q[4..6]) of the body's own
+          // share of the q record; it is the frame of all six pseudo links (identity joint transforms behind this one)
+          const T qx = xr[fbq], qy = xr[fbq + 1], qz = xr[fbq + 2], qw = xr[fbq + 3];
+          const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);  // tiny_matrix3x3.h:315-340
+          const T xs = qx * s2, ys = qy * s2, zs = qz * s2;
+          const T wx = qw * xs, wy = qw * ys, wz = qw * zs;
+          const T xx = qx * xs, xy = qx * ys, xz = qx * zs;
+          const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
+          Rq[0] = T(1) - (yy + zz); Rq[1] = xy - wz; Rq[2] = xz + wy;
+          Rq[3] = xy + wz; Rq[4] = T(1) - (xx + zz); Rq[5] = yz - wx;
+          Rq[6] = xz - wy; Rq[7] = yz + wx; Rq[8] = T(1) - (xx + yy);
+          pq[0] = xr[fbq + 4];
+          pq[1] = xr[fbq + 5];
+          pq[2] = xr[fbq + 6];
+          aq[3] = aq[4] = aq[5] = T(0);  // (gravity reaches a floating base after the solve, forward_dynamics.hpp:315-319)
+        }
       }
       mat3_mul(Rq, Rp, R);
       T r[3];
@@ -2380,6 +2426,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) a0[k] = aq[k] + cb[k];
+      if (flm && fbk >= 0) {
+        // (pseudo links of a floating base: the axes move with the base — no velocity-product acceleration, see KIND 1)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a0[k] = T(0);
+      }
       if (lds_children) {  // children other than lane + 1 read my record
 #pragma unroll
         for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
@@ -2525,11 +2576,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     cross3(v, Iv + 3, fc + 3);
 #pragma unroll
     for (int k = 0; k < 6; ++k) fc[k] += Ia[k];
-    if (fl && li == 5) {
+    if ((fl || flm) && fbk == 5) {
       // floating base body (kinematics.hpp:52-61): the reference's bias force of the base is ONLY the
       // gyroscopic torque  w x ((R I R^T) w)  with w = qd[0..2] taken as it is, stored as the top of a
       // base-frame force vector (no v x* I v, no gravity).  In world coordinates: (R gyro, 0).
-      const T w3[3] = {xr[nq], xr[nq + 1], xr[nq + 2]};
+      const int wq = flm ? nq + qdri - 5 : nq;  // (the body's [omega | v] share of the qd record)
+      const T w3[3] = {xr[wq], xr[wq + 1], xr[wq + 2]};
       T Iww[3], gy[3];
       mat3_mulv(Iw, w3, Iww);
       cross3(w3, Iww, gy);
@@ -2712,6 +2764,25 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           }
         }
       }
+      if constexpr (flm) {
+        // rows of the base dofs of a floating body (numbered behind the body's joints): against a joint dof j of the
+        // same body the composite force is that of the JOINT's link (see KIND 1 below)
+        const bool brow = isd && bdof;
+        const int jlo = isd ? mdl->dof_joint0[d] : 0;
+        T sb[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sb[k] = brow ? swd[k * NDs + d] : T(0);
+#pragma unroll
+        for (int j = 0; j < NDP; ++j) {
+          if (j < nd) {
+            const int lj = mdl->dof_link[j];
+            T s = T(0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += Fs[lj * TDS_S2 + k] * sb[k];
+            Mr[j] = (brow && j >= jlo && j < dbase0) ? s : Mr[j];
+          }
+        }
+      }
       if (fl) {  // wave-uniform
         // rows of the base dofs (numbered last): against a joint dof j the composite force is that of the
         // JOINT's link, M[b][j] = s_b . (Ic_j s_j)   (mass_matrix.hpp:111-115, symmetric counterpart)
@@ -2859,8 +2930,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         TDS_WAVE_SYNC();
         if (lane == 0) xr[in_dim + 4] = T(1);
       }
-      const bool jrow = !fl || d < njd;  // (the base rows of a floating base keep a_base in the back substitution)
-      if (fl) {  // wave-uniform
+      const bool jrow = fl ? d < njd : !bdof;  // (the base rows of a floating base keep a_base in the back substitution)
+      if (fl || flm) {  // wave-uniform
+        // (KIND 4: every lane works on the base block of ITS dof's body; lanes of fixed-base bodies compute on block 0
+        //  and discard)
+        const int njd = dbase0 >= 0 ? dbase0 : 0;
+        const bool has_base = dbase0 >= 0;
         // With the joint dofs eliminated, the base rows read  Sigma a_base = rho:  Sigma = L_b D_b L_b^T (the
         // trailing 6x6 block of the factors) is the articulated inertia of the base and rho = L_b y_b is minus
         // its bias force.  The reference takes  a_base = -base_abi.inv_mul(base_bias_force)  with ITS block
@@ -2926,7 +3001,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 #pragma unroll
         for (int c = 0; c < 3; ++c) ab[3 + c] = u3[c] - (ABD[c] * rho[0] + ABD[3 + c] * rho[1] + ABD[6 + c] * rho[2]);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) xv = d == njd + i ? ab[i] : xv;
+        for (int i = 0; i < 6; ++i) xv = (has_base && d == njd + i) ? ab[i] : xv;
       }
       // L^T x = D^-1 y with the packed copy of L in LDS (the base rows of a floating base keep a_base)
       // (column d of L^T requested up front, index clamped: a read under `if (d < k)` is a read inside a branch, and
@@ -2962,6 +3037,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         }
       });
       if (fl && d >= njd + 3 && d < nd) xv += mdl->grav[d - njd - 3];  // forward_dynamics.hpp:315-319
+      if (flm && bdof && d >= dbase0 + 3) xv += mdl->gravb[mdl->dof_body[d]][d - dbase0 - 3];
       // integrate_euler_qdd; from here on the velocities live in dof order in the column scratch
       TDS_WAVE_SYNC();
       if (d < NDP) rhsx[d] = d < nd ? xr[nq + rec_d] + xv * dt : T(0);
@@ -3182,8 +3258,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     // quaternion and stores its own component(s): lanes 0..3 the quaternion, lanes 3..5 also the position.
     const T h = T(0.5) * dt;
     const T *const qdv = E + L.dinv + 2 * NDP;  // velocities in dof order (phase F)
-    const T w0 = qdv[njd], w1 = qdv[njd + 1], w2 = qdv[njd + 2];
-    const T b0 = xr[0], b1 = xr[1], b2 = xr[2], b3 = xr[3];
+    const int wb = flm ? di - fbk : njd;  // first base dof of my body
+    const int qb = flm ? fbq : 0;         // its quaternion in the q record
+    const T w0 = qdv[wb], w1 = qdv[wb + 1], w2 = qdv[wb + 2];
+    const T b0 = xr[qb], b1 = xr[qb + 1], b2 = xr[qb + 2], b3 = xr[qb + 3];
     T n0 = b0 + (b3 * w0 + b2 * w1 - b1 * w2) * h;
     T n1 = b1 + (b3 * w1 + b0 * w2 - b2 * w0) * h;
     T n2 = b2 + (b3 * w2 + b1 * w0 - b0 * w1) * h;
@@ -3194,10 +3272,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     n2 /= ql;
     n3 /= ql;
     up_z = T(1) - (n0 * n0 + n1 * n1) * (T(2) / (n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3));
-    const T pos_new = li >= 3 ? xr[4 + li - 3] + qd_new * dt : T(0);
+    const T pos_new = fbk >= 3 ? xr[qb + 4 + fbk - 3] + qd_new * dt : T(0);
     __builtin_amdgcn_wave_barrier();
-    if (li < 4) xr[li] = li == 0 ? n0 : li == 1 ? n1 : li == 2 ? n2 : n3;
-    if (li >= 3) xr[4 + li - 3] = pos_new;
+    if (fbk < 4) xr[qb + fbk] = fbk == 0 ? n0 : fbk == 1 ? n1 : fbk == 2 ? n2 : n3;
+    if (fbk >= 3) xr[qb + 4 + fbk - 3] = pos_new;
   }
   if (sph_lane) {
     // spherical joint (integrator.hpp:94-123): qd *= pow(joint_damping, 1000 dt), then
@@ -3247,7 +3325,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       int tail = nq + nd;
       if (mdl->pack_visuals) {
         tail += 7 * nv;
-        if (lane == 0) __builtin_nontemporal_store((TR)(fl ? up_z : mdl->base_R[8]), &yo[tail]);  // up_dot_world_z
+        // up_dot_world_z (of body 0; lane 0 is its first pseudo link when its base floats)
+        if (lane == 0) __builtin_nontemporal_store((TR)((fl || (flm && fbk == 0)) ? up_z : (two ? mdl->base_Rb[0][8] : mdl->base_R[8])), &yo[tail]);
         tail += 1;
       }
       for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
@@ -3642,9 +3721,10 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   return (int)e;
 }
 
-// The file is compiled nine times (csrc/Makefile): -DTDS_ONLY_F64 / -DTDS_ONLY_F32 / -DTDS_ONLY_MIX pick the build
-// (compute scalar, record scalar) = (double, double) / (float, float) / (double, float), -DTDS_ONLY_KIND=0/1/2 the
-// kernel kind (plain / floating base / spherical joints), so that the parts of the kernel set build in parallel.
+// The file is compiled fifteen times (csrc/Makefile): -DTDS_ONLY_F64 / -DTDS_ONLY_F32 / -DTDS_ONLY_MIX pick the build
+// (compute scalar, record scalar) = (double, double) / (float, float) / (double, float), -DTDS_ONLY_KIND=0..4 the
+// kernel kind (plain / floating base / spherical joints / several bodies / several bodies with floating bases), so
+// that the parts of the kernel set build in parallel.
 // (tds_make_lds_layout and tds_padded_dof live in the KIND 0 units.)
 #define TDS_INSTANTIATE(TT, TR, KV)                                                                                     \
   template int tds_launch_step_impl<TT, TR, KV>(const DevModel<TT> *, const DevModel<TT> &, const TdsLds &, int,       \
@@ -3680,8 +3760,14 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
 #else
 #define TDS_INSTANTIATE_K3(TT, TR)
 #endif
+#if TDS_ONLY_KIND == 4 || defined(TDS_ALL_KINDS)
+#define TDS_INSTANTIATE_K4(TT, TR) TDS_INSTANTIATE(TT, TR, 4)
+#else
+#define TDS_INSTANTIATE_K4(TT, TR)
+#endif
 #define TDS_INSTANTIATE_KINDS(TT, TR) \
-  TDS_INSTANTIATE_K0(TT, TR) TDS_INSTANTIATE_K1(TT, TR) TDS_INSTANTIATE_K2(TT, TR) TDS_INSTANTIATE_K3(TT, TR)
+  TDS_INSTANTIATE_K0(TT, TR) TDS_INSTANTIATE_K1(TT, TR) TDS_INSTANTIATE_K2(TT, TR) TDS_INSTANTIATE_K3(TT, TR) \
+  TDS_INSTANTIATE_K4(TT, TR)
 #if defined(TDS_ONLY_F64)
 #if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
 template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int, bool);
