@@ -425,6 +425,33 @@ int tds_hip_rollout_ex(tds_hip_sim_t *sim, const void *policy_dev, int n_steps, 
                        void *return_sum_dev, int *return_steps_dev, void *obs_dev, void *stats_dev, void *traj_dev,
                        int *traj_len_dev);
 
+/* Policies with hidden layers (the reference's NeuralNetworkSpecification / NeuralNetwork::compute,
+   src/math/neural_network.hpp:93-160, 223-300 — the vectorised ARS environment builds one linear layer and keeps its
+   two ReLU layers commented out, examples/ars/ars_vectorized_environment.h:170-178).  num_layers entries, the input
+   included: layer_sizes[0] = obs_dim = dof_q + dof_qd, layer_sizes[num_layers - 1] = action_dim, each
+   <= TDS_NN_MAX_UNITS; activations[i - 1] (TDS_NN_ACT_*) is applied to layer i >= 1; use_bias[i] != 0 gives layer i a
+   bias (use_bias[0]: a bias added to the observation, set_input_dim).  Afterwards the policy_dev argument of
+   tds_hip_rollout(_ex) holds, per environment, tds_hip_policy_num_parameters() scalars in NeuralNetwork parameter order
+   (set_parameters, :406-415): all weights layer by layer, each row-major [unit of layer i][unit of layer i - 1], then all
+   biases layer by layer — and rollouts run as one straight-line step launch per step with the network evaluated by a
+   kernel of its own in between (one wavefront per environment, activations in LDS).  num_layers = 0 restores the
+   default (the linear policy inside the step-loop launch). */
+enum {
+  TDS_NN_ACT_IDENTITY = -1,
+  TDS_NN_ACT_TANH = 0,
+  TDS_NN_ACT_SIN = 1,
+  TDS_NN_ACT_RELU = 2,
+  TDS_NN_ACT_SOFT_RELU = 3,
+  TDS_NN_ACT_ELU = 4,
+  TDS_NN_ACT_SIGMOID = 5,
+  TDS_NN_ACT_SOFTSIGN = 6
+};
+#define TDS_NN_MAX_LAYERS 8
+#define TDS_NN_MAX_UNITS 256
+int tds_hip_set_policy_network(tds_hip_sim_t *sim, int num_layers, const int *layer_sizes, const int *activations,
+                               const int *use_bias);
+int tds_hip_policy_num_parameters(const tds_hip_sim_t *sim);
+
 /* Blocking convenience with HOST buffers in double, any N <= num_envs:
    H2D(x) -> kernel -> D2H(y), i.e. exactly what the reference's <model>_forward_zero does. */
 int tds_hip_forward_zero_host(tds_hip_sim_t *sim, int n, const double *x_host, double *y_host);

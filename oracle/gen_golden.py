@@ -343,6 +343,48 @@ def rollout_fixture(name, n=24, steps=25, shift=0.5, seed=77):
     return out
 
 
+# hidden layers for the policy network fixture: the two ReLU layers the reference's vectorised environment keeps commented
+# out (ars_vectorized_environment.h:175-176), and a second network that exercises the other activations and the input bias
+NN_ACT = dict(identity=-1, tanh=0, sin=1, relu=2, soft_relu=3, elu=4, sigmoid=5, softsign=6)
+NETWORKS = {
+    "relu_32_64": lambda od, adim: ([od, 32, 64, adim], [NN_ACT["relu"], NN_ACT["relu"], NN_ACT["identity"]],
+                                    [False, True, True, True]),
+    "mixed": lambda od, adim: ([od, 24, 20, 16, 12, 10, 9, adim],
+                               [NN_ACT["tanh"], NN_ACT["sin"], NN_ACT["soft_relu"], NN_ACT["elu"], NN_ACT["sigmoid"],
+                                NN_ACT["softsign"], NN_ACT["identity"]],
+                               [True, True, False, True, True, False, True, True]),
+}
+
+
+def nn_num_parameters(units, bias):
+    return sum(units[i - 1] * units[i] for i in range(1, len(units))) + sum(u for u, b in zip(units, bias) if b)
+
+
+def rollout_nn_fixture(name="ant", n=24, steps=25, shift=0.5, seed=79):
+    """Worker::rollouts of the REAL reference with a policy NETWORK per environment (reflib.rollout(network=...)): for
+    each entry of NETWORKS the parameters, returns, step counts and final observations"""
+    r, m = make_ref(name)
+    rng = np.random.default_rng(seed)
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    od = nq + nd
+    x = np.stack([rollout_start(name, m, rng) for _ in range(n)])
+    for _ in range(10):
+        y = r.step(x)
+        x[:, :od] = y[:, :od]
+    x[::5, 2] -= 0.12
+    x[::5, 3] = 0.5
+    out = dict(x0=x, steps=np.int32(steps), shift=np.float64(shift))
+    for key, mk in NETWORKS.items():
+        units, acts, bias = mk(od, adim)
+        params = rng.normal(0.0, 0.25, (n, nn_num_parameters(units, bias)))
+        tot, cnt, fin = reflib.rollout(name, x[:, :od], params, steps, shift, network=(units, acts, bias))
+        out.update({key + "_units": np.array(units, dtype=np.int32), key + "_acts": np.array(acts, dtype=np.int32),
+                    key + "_bias": np.array(bias, dtype=np.int32), key + "_params": params, key + "_total_rewards": tot,
+                    key + "_vec_steps": cnt, key + "_final_obs": fin})
+    r.close()
+    return out
+
+
 def vecenv_fixture(name, n=12, steps=60, seed=91):
     """VectorizedEnvironment::step of the REAL reference, driven like its Python binding (reflib.vecenv_steps), from
     settled start states with fresh random actions each step; every 4th environment starts near its termination
@@ -419,6 +461,12 @@ def main(only=None):
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_rollout.npz"), **f)
         print(f"{name}_rollout: steps taken {f['vec_steps'].min()}..{f['vec_steps'].max()} of {int(f['steps'])}, "
               f"returns {f['total_rewards'].min():.3f}..{f['total_rewards'].max():.3f}")
+    if only is None or "ant_rollout_nn" in only:
+        f = rollout_nn_fixture("ant")
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ant_rollout_nn.npz"), **f)
+        for key in NETWORKS:
+            print(f"ant_rollout_nn[{key}]: steps taken {f[key + '_vec_steps'].min()}..{f[key + '_vec_steps'].max()}, "
+                  f"returns {f[key + '_total_rewards'].min():.3f}..{f[key + '_total_rewards'].max():.3f}")
     for name in [n for n in ("ant", "laikago") if only is None or n + "_vecenv" in only]:
         f = vecenv_fixture(name)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_vecenv.npz"), **f)

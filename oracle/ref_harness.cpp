@@ -526,10 +526,13 @@ extern "C++" {
 // stats (optional) [batch][obs_dim][3] = (NumDataValues, Mean, S = Variance * (n - 1)) of the reference's RunningStat
 // pushed exactly where Worker::rollouts pushes it (ars_vectorized_worker.h:88-110); traj (optional)
 // [batch][steps][output_dim] + traj_len [batch]: the trajectories vector of Worker::rollouts (:118-135)
+// nn (optional): {num_layers, units[num_layers], activations[num_layers - 1], use_bias[num_layers]} — every environment's
+// network is rebuilt with these layers through the reference's own NeuralNetworkSpecification calls (the hidden ReLU
+// layers the reference keeps commented out, ars_vectorized_environment.h:175-176); params then holds num_parameters() per env
 template <typename Sim, typename Env>
 static int ref_rollout(int batch, int steps, double shift, const double *x0, const double *params,
                        double *total_rewards, int *vec_steps, double *final_obs, double *stats = nullptr,
-                       double *traj = nullptr, int *traj_len = nullptr) {
+                       double *traj = nullptr, int *traj_len = nullptr, const int *nn = nullptr) {
   typedef VectorizedEnvironment<Alg, Sim> VecEnv;
   Env env(false);
   VecEnv vec_env(env.contact_sim, batch);
@@ -538,7 +541,19 @@ static int ref_rollout(int batch, int steps, double shift, const double *x0, con
   config.batch_size = batch;
   config.auto_reset_when_done = false;
   const int od = env.contact_sim.input_dim();
-  const int np = env.contact_sim.action_dim() * od + env.contact_sim.action_dim();
+  int np = env.contact_sim.action_dim() * od + env.contact_sim.action_dim();
+  if (nn) {
+    const int nl = nn[0];
+    const int *units = nn + 1, *acts = nn + 1 + nl, *bias = nn + 1 + nl + (nl - 1);
+    if (units[0] != od || units[nl - 1] != env.contact_sim.action_dim()) return -2;
+    for (int e = 0; e < batch; ++e) {
+      tds::NeuralNetwork<Alg> net;
+      net.set_input_dim(units[0], bias[0] != 0);
+      for (int i = 1; i < nl; ++i) net.add_linear_layer((tds::NeuralNetworkActivation)acts[i - 1], units[i], bias[i] != 0);
+      vec_env.neural_networks_[e] = net;
+    }
+    np = vec_env.neural_networks_[0].num_parameters();
+  }
   std::vector<std::vector<double>> observations(batch);
   for (int e = 0; e < batch; ++e) {
     vec_env.sim_states_[e].assign(env.contact_sim.input_dim_with_action_and_variables(), 0.0);
@@ -604,6 +619,19 @@ int tdsref_rollout_ex(const char *name, int batch, int steps, double shift, cons
   if (n == "laikago")
     return ref_rollout<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, shift, x0, params, total_rewards,
                                                                        vec_steps, final_obs, stats, traj, traj_len);
+  return -1;
+}
+
+// the rollout with a policy NETWORK per environment: nn = {num_layers, units.., activations.., use_bias..} (see ref_rollout)
+int tdsref_rollout_nn(const char *name, int batch, int steps, double shift, const double *x0, const double *params,
+                      const int *nn, double *total_rewards, int *vec_steps, double *final_obs) {
+  const std::string n(name);
+  if (n == "ant")
+    return ref_rollout<AntContactSimulation2<Alg>, AntEnv2<Alg>>(batch, steps, shift, x0, params, total_rewards,
+                                                                 vec_steps, final_obs, nullptr, nullptr, nullptr, nn);
+  if (n == "laikago")
+    return ref_rollout<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, shift, x0, params, total_rewards,
+                                                                       vec_steps, final_obs, nullptr, nullptr, nullptr, nn);
   return -1;
 }
 

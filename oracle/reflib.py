@@ -127,9 +127,10 @@ def hipstepper_selftest_devices(devices, batch=10, steps=4):
     return rc, msg.value.decode()
 
 
-def rollout(name, x0, params, steps, shift=0.0):
+def rollout(name, x0, params, steps, shift=0.0, network=None):
     """The reference's own rollout loop (Worker::rollouts + VectorizedEnvironment::policy/step, serial
-    stepper) from the states x0 [B, dof_q+dof_qd] with per-environment linear policies params [B, P].
+    stepper) from the states x0 [B, dof_q+dof_qd] with per-environment linear policies params [B, P] — or, with
+    network = (layer_sizes, activations, use_bias), the reference's NeuralNetwork with those layers per environment.
     returns (total_rewards [B], vec_steps [B] int32, final_obs [B, obs_dim])."""
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     params = np.ascontiguousarray(params, dtype=np.float64)
@@ -142,8 +143,16 @@ def rollout(name, x0, params, steps, shift=0.0):
     devnull = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull, 1)
     try:
-        rc = lib().tdsref_rollout(name.encode(), b, int(steps), float(shift), x0.ctypes.data, params.ctypes.data,
-                                  tot.ctypes.data, cnt.ctypes.data, fin.ctypes.data)
+        if network is not None:
+            units, acts, bias = network
+            assert len(acts) == len(units) - 1 and len(bias) == len(units)
+            nn = np.array([len(units)] + list(units) + list(acts) + [1 if v else 0 for v in bias], dtype=np.int32)
+            lib().tdsref_rollout_nn.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 6
+            rc = lib().tdsref_rollout_nn(name.encode(), b, int(steps), float(shift), x0.ctypes.data, params.ctypes.data,
+                                         nn.ctypes.data, tot.ctypes.data, cnt.ctypes.data, fin.ctypes.data)
+        else:
+            rc = lib().tdsref_rollout(name.encode(), b, int(steps), float(shift), x0.ctypes.data, params.ctypes.data,
+                                      tot.ctypes.data, cnt.ctypes.data, fin.ctypes.data)
         C.CDLL(None).fflush(None)
     finally:
         os.dup2(saved, 1)

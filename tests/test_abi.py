@@ -32,14 +32,14 @@ def test_struct_layout_matches_c(built):
     """sizeof(tds_model_t) as seen by C must equal the ctypes mirror."""
     import subprocess
     import tempfile
-    src = '#include <stdio.h>\n#include "tds_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu",sizeof(tds_model_t),sizeof(tds_link_t),sizeof(tds_geom_t),sizeof(tds_visual_t),sizeof(tds_rb_model_t),sizeof(tds_rb_body_t));return 0;}'
+    src = '#include <stdio.h>\n#include "tds_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu",sizeof(tds_model_t),sizeof(tds_link_t),sizeof(tds_geom_t),sizeof(tds_visual_t),sizeof(tds_rb_model_t),sizeof(tds_rb_body_t),sizeof(tds_body_t));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         out = subprocess.check_output([os.path.join(d, "s")]).decode().split()
     assert [int(v) for v in out] == [C.sizeof(tds_amd.Model), C.sizeof(tds_amd.model.Link),
                                      C.sizeof(tds_amd.model.Geom), C.sizeof(tds_amd.model.Visual),
-                                     C.sizeof(tds_amd.RbModel), C.sizeof(tds_amd.RbBody)]
+                                     C.sizeof(tds_amd.RbModel), C.sizeof(tds_amd.RbBody), C.sizeof(tds_amd.model.Body)]
 
 
 @pytest.mark.parametrize("name", MODELS)

@@ -661,6 +661,50 @@ def test_rollout_matches_reference_worker_loop(name, mode, built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("net", ["relu_32_64", "mixed"])
+def test_rollout_with_a_policy_network_matches_the_reference_worker_loop(net, built):
+    """tds_hip_set_policy_network + tds_hip_rollout: a NeuralNetwork with hidden layers per environment (the two ReLU
+    layers the reference's vectorised environment keeps commented out, ars_vectorized_environment.h:175-176; a second
+    network through tanh / sin / soft_relu / elu / sigmoid / softsign with an input bias and bias-free layers,
+    src/math/neural_network.hpp:223-300) against the reference's own Worker::rollouts loop with the same layers —
+    committed fixture tests/golden/ant_rollout_nn.npz (oracle/gen_golden.py: rollout_nn_fixture)."""
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    g = np.load(os.path.join(GOLDEN, "ant_rollout_nn.npz"))
+    x, steps, shift = g["x0"], int(g["steps"]), float(g["shift"])
+    units, acts, bias = g[net + "_units"].tolist(), g[net + "_acts"].tolist(), g[net + "_bias"].tolist()
+    params, tot_ref, cnt_ref, fin_ref = g[net + "_params"], g[net + "_total_rewards"], g[net + "_vec_steps"], g[net + "_final_obs"]
+    n, od = x.shape[0], m.dof_q + m.dof_qd
+    import reflib
+    if reflib.available():
+        tot_live, cnt_live, _ = reflib.rollout("ant", x[:, :od], params, steps, shift, network=(units, acts, bias))
+        assert np.array_equal(cnt_live, cnt_ref) and rel_err(tot_live, tot_ref) < 1e-9
+    assert 0 < (cnt_ref < steps).sum() < n
+    sim = hip_backend.HipSim(m, n)
+    assert sim.policy_num_parameters == m.action_dim * od + m.action_dim
+    assert sim.set_policy_network(units, acts, bias) == params.shape[1]
+    sim.x.copy_(torch.from_numpy(x).cuda())
+    obs = torch.zeros((n, od + 2), dtype=torch.float64, device="cuda")
+    ret, cnt = sim.rollout(torch.from_numpy(params).cuda(), steps, shift, first_obs_raw=True, obs=obs)
+    ret, cnt, ob = ret.cpu().numpy(), cnt.cpu().numpy(), obs.cpu().numpy()
+    assert np.array_equal(cnt, cnt_ref)
+    err = rel_err(ret, tot_ref, 1e-3)
+    ferr = rel_err(ob[:, 2:od], fin_ref[:, 2:], 1e-3)
+    print(f"ant, policy network {net} {units}: return max rel err {err:.2e}, final observation {ferr:.2e}, steps {cnt.min()}..{cnt.max()}")
+    assert err < 1e-6 and ferr < 1e-6
+    assert np.array_equal(ob[:, od + 1] != 0, cnt_ref < steps)
+    # back to the default linear policy: the linear fixture still holds
+    sim.set_policy_network(None)
+    gl = np.load(os.path.join(GOLDEN, "ant_rollout.npz"))
+    sim2 = hip_backend.HipSim(m, gl["x0"].shape[0])
+    sim2.set_policy_network(units, acts, bias)
+    sim2.set_policy_network(None)
+    sim2.x.copy_(torch.from_numpy(gl["x0"]).cuda())
+    ret2, cnt2 = sim2.rollout(torch.from_numpy(gl["params"]).cuda(), int(gl["steps"]), float(gl["shift"]), first_obs_raw=True)
+    assert np.array_equal(cnt2.cpu().numpy(), gl["vec_steps"]) and rel_err(ret2.cpu().numpy(), gl["total_rewards"], 1e-3) < 1e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["ant", "laikago"])
 def test_rollout_by_products_match_the_reference_worker(name, built):
     """tds_hip_rollout_ex: the running statistics of the observations and the trajectory records that

@@ -1336,7 +1336,8 @@ __global__ void tds_policy_book_kernel(const T *__restrict__ x, int in_dim, int 
                                        const T *__restrict__ policy, T *__restrict__ actions,
                                        T *__restrict__ rec, T *__restrict__ ret, int *__restrict__ cnt,
                                        unsigned char *__restrict__ frozen, T shift, int do_book, int do_policy,
-                                       int raw_xy, int auto_reset, TdsRolloutExtras<T> ex, int n) {
+                                       int raw_xy, int auto_reset, TdsRolloutExtras<T> ex, int n,
+                                       int linear_policy = 1) {  // 0: the actions come from tds_policy_mlp_kernel
   // one wavefront per environment; L = 2^k lanes per action, consecutive lanes on consecutive weights
   const int env = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
   const int lane = threadIdx.x & 63;
@@ -1389,7 +1390,7 @@ __global__ void tds_policy_book_kernel(const T *__restrict__ x, int in_dim, int 
       st[0] = nn;
     }
   }
-  if (do_policy) {
+  if (do_policy && linear_policy) {
     int L = 64;
     while (L * adim > 64) L >>= 1;  // 1 <= adim <= TDS_MAX_ACTIONS = 32 (tds_hip_model_check): L >= 2
     const int a = lane / L, sub = lane - a * L;
@@ -1404,6 +1405,61 @@ __global__ void tds_policy_book_kernel(const T *__restrict__ x, int in_dim, int 
     for (int d = 1; d < L; d <<= 1) acc += __shfl_xor(acc, d, 64);
     if (a < adim && sub == 0) actions[(size_t)env * adim + a] = acc + W[adim * od + a];
   }
+}
+
+// The environment's own policy NETWORK on the new state (NeuralNetwork::compute, src/math/neural_network.hpp:223-300):
+// one wavefront per environment, the activations of two consecutive layers in LDS, the lanes split a unit's dot product
+// (consecutive lanes on consecutive weights of its row) and reduce it with shuffles.
+struct TdsNN {
+  int n, units[TDS_NN_MAX_LAYERS], act[TDS_NN_MAX_LAYERS], bias[TDS_NN_MAX_LAYERS], nw, nb;
+};
+
+template <typename T>
+__global__ void tds_policy_mlp_kernel(const T *__restrict__ x, int in_dim, const T *__restrict__ policy,
+                                      T *__restrict__ actions, TdsNN nn, int raw_xy, int n) {
+  __shared__ T buf[2][TDS_NN_MAX_UNITS];
+  const int env = blockIdx.x, lane = threadIdx.x;  // (64 threads per block)
+  if (env >= n) return;
+  const T *const W = policy + (size_t)env * (nn.nw + nn.nb);
+  const T *const Bs = W + nn.nw;
+  int wi = 0, bi = 0, cur = 0;
+  for (int o = lane; o < nn.units[0]; o += 64) {
+    // obs = [q | qd] with obs[0] = obs[1] = 0 (ars_vectorized_environment.h:283-288); the input layer's bias (:251-255)
+    T v = (o < 2 && !raw_xy) ? T(0) : x[(size_t)env * in_dim + o];
+    if (nn.bias[0]) v += Bs[o];
+    buf[0][o] = v;
+  }
+  if (nn.bias[0]) bi += nn.units[0];
+  __syncthreads();
+  for (int i = 1; i < nn.n; ++i) {
+    const int P = nn.units[i - 1], Cn = nn.units[i], act = nn.act[i - 1];
+    const T *const prev = buf[cur];
+    T *const out = buf[cur ^ 1];
+    for (int ci = 0; ci < Cn; ++ci) {
+      T acc = T(0);
+      for (int pi = lane; pi < P; pi += 64) acc += prev[pi] * W[wi + ci * P + pi];
+      for (int d = 1; d < 64; d <<= 1) acc += __shfl_xor(acc, d, 64);
+      if (lane == 0) {
+        T v = acc + (nn.bias[i] ? Bs[bi + ci] : T(0));
+        switch (act) {  // :267-294
+          case TDS_NN_ACT_TANH: v = tanh(v); break;
+          case TDS_NN_ACT_SIN: v = sin(v); break;
+          case TDS_NN_ACT_RELU: v = v > T(0) ? v : T(0); break;
+          case TDS_NN_ACT_SOFT_RELU: v = log(T(1) + exp(v)); break;
+          case TDS_NN_ACT_ELU: v = v >= T(0) ? v : exp(v) - T(1); break;
+          case TDS_NN_ACT_SIGMOID: { const T e = exp(v); v = e / (e + T(1)); break; }
+          case TDS_NN_ACT_SOFTSIGN: v = v / (T(1) + (v < T(0) ? -v : v)); break;
+          default: break;
+        }
+        out[ci] = v;
+      }
+    }
+    wi += P * Cn;
+    if (nn.bias[i]) bi += Cn;
+    cur ^= 1;
+    __syncthreads();
+  }
+  for (int a = lane; a < nn.units[nn.n - 1]; a += 64) actions[(size_t)env * nn.units[nn.n - 1] + a] = buf[cur][a];
 }
 
 template <typename T>
@@ -1439,8 +1495,22 @@ int rollout_per_step(tds_hip_sim *s, const void *policy_dev, int n_steps, double
     hipLaunchKernelGGL(tds_policy_book_kernel<T>, dim3(blocks), dim3(threads), 0, s->stream, (const T *)s->d_x,
                        s->model.input_dim, od, adim, (const T *)policy_dev, actions, rec, ret, cnt, frozen,
                        (T)shift, t > 0 ? 1 : 0, t < n_steps ? 1 : 0, ((flags & 1) && t == 0) ? 1 : 0,
-                       s->auto_reset ? 1 : 0, ex, n);
+                       s->auto_reset ? 1 : 0, ex, n, s->nn_layers > 0 ? 0 : 1);
     if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "policy kernel launch");
+    if (s->nn_layers > 0 && t < n_steps) {
+      TdsNN nn;
+      nn.n = s->nn_layers;
+      for (int i = 0; i < TDS_NN_MAX_LAYERS; ++i) {
+        nn.units[i] = s->nn_units[i];
+        nn.act[i] = s->nn_act[i];
+        nn.bias[i] = s->nn_bias[i];
+      }
+      nn.nw = s->nn_weights;
+      nn.nb = s->nn_biases;
+      hipLaunchKernelGGL(tds_policy_mlp_kernel<T>, dim3(n), dim3(64), 0, s->stream, (const T *)s->d_x, s->model.input_dim,
+                         (const T *)policy_dev, actions, nn, ((flags & 1) && t == 0) ? 1 : 0, n);
+      if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "policy network kernel launch");
+    }
     if (t == n_steps) break;
     // (plain straight-line step, or — with auto-reset — the step through the reset pool)
     const int rc = step_obs_impl(s, actions, 1, rec);
@@ -1466,7 +1536,7 @@ int tds_hip_rollout_ex(tds_hip_sim_t *s, const void *policy_dev, int n_steps, do
   // with a small policy + bookkeeping kernel in between; the by-products of Worker::rollouts (running statistics of
   // the observations, trajectory records) are produced by that bookkeeping kernel, so asking for them selects it.
   const bool extras = stats_dev != nullptr || traj_dev != nullptr;
-  const bool per_step = extras || (!s->auto_reset && (flags & 2) != 0);
+  const bool per_step = extras || (!s->auto_reset && (flags & 2) != 0) || s->nn_layers > 0;
   if (per_step)
     return s->records_f64()
                ? rollout_per_step<double>(s, policy_dev, n_steps, shift, flags, return_sum_dev, return_steps_dev, obs_dev,
@@ -1482,6 +1552,43 @@ int tds_hip_rollout_ex(tds_hip_sim_t *s, const void *policy_dev, int n_steps, do
   if (s->auto_reset) s->pool_ready = false;
   return launch(s, s->d_x, s->d_y, nullptr, s->d_x, obs_dev, s->num_envs, n_steps,
                 s->auto_reset ? TDS_RESET_AUTO : TDS_RESET_NONE, nullptr, &ro);
+}
+
+int tds_hip_set_policy_network(tds_hip_sim_t *s, int num_layers, const int *layer_sizes, const int *activations,
+                               const int *use_bias) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  if (num_layers == 0) {
+    s->nn_layers = 0;
+    return TDS_OK;
+  }
+  if (num_layers < 2 || num_layers > TDS_NN_MAX_LAYERS) return fail(TDS_ERR_INVALID_ARG, "num_layers must be 0 or 2..TDS_NN_MAX_LAYERS");
+  if (!layer_sizes || !activations || !use_bias) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (layer_sizes[0] != s->model.dof_q + s->model.dof_qd) return fail(TDS_ERR_INVALID_ARG, "layer_sizes[0] must be the observation size dof_q + dof_qd");
+  if (layer_sizes[num_layers - 1] != s->model.action_dim) return fail(TDS_ERR_INVALID_ARG, "the last layer must have action_dim units");
+  int nw = 0, nb = 0;
+  for (int i = 0; i < num_layers; ++i) {
+    if (layer_sizes[i] < 1 || layer_sizes[i] > TDS_NN_MAX_UNITS) return fail(TDS_ERR_INVALID_ARG, "layer size out of range (1..TDS_NN_MAX_UNITS)");
+    if (i > 0 && (activations[i - 1] < TDS_NN_ACT_IDENTITY || activations[i - 1] > TDS_NN_ACT_SOFTSIGN))
+      return fail(TDS_ERR_INVALID_ARG, "unknown activation");
+    if (i > 0) nw += layer_sizes[i - 1] * layer_sizes[i];
+    nb += use_bias[i] ? layer_sizes[i] : 0;
+  }
+  s->nn_layers = num_layers;
+  for (int i = 0; i < TDS_NN_MAX_LAYERS; ++i) {
+    s->nn_units[i] = i < num_layers ? layer_sizes[i] : 0;
+    s->nn_bias[i] = (i < num_layers && use_bias[i]) ? 1 : 0;
+  }
+  // (nn_act[i - 1] belongs to layer i, as in the reference's activations_ vector)
+  for (int i = 0; i < TDS_NN_MAX_LAYERS; ++i) s->nn_act[i] = i + 1 < num_layers ? activations[i] : TDS_NN_ACT_IDENTITY;
+  s->nn_weights = nw;
+  s->nn_biases = nb;
+  return TDS_OK;
+}
+
+int tds_hip_policy_num_parameters(const tds_hip_sim_t *s) {
+  if (!s) return -1;
+  if (s->nn_layers > 0) return s->nn_weights + s->nn_biases;
+  return s->model.action_dim * (s->model.dof_q + s->model.dof_qd) + s->model.action_dim;
 }
 
 int tds_hip_rollout(tds_hip_sim_t *s, const void *policy_dev, int n_steps, double shift, int flags,

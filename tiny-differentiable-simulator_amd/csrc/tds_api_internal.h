@@ -28,6 +28,9 @@ struct tds_hip_sim {
   void *d_ro = nullptr;     // scratch of the per-step-launch rollout (actions | records | returns | counts | latches)
   bool auto_reset = false;
   unsigned long long seed = 0x5DEECE66Dull;
+  // policy network of the rollouts (tds_hip_set_policy_network); nn_layers == 0: the default linear policy
+  int nn_layers = 0, nn_units[TDS_NN_MAX_LAYERS] = {0}, nn_act[TDS_NN_MAX_LAYERS] = {0}, nn_bias[TDS_NN_MAX_LAYERS] = {0};
+  int nn_weights = 0, nn_biases = 0;
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_ms = false;

@@ -123,6 +123,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_y_device", "tds_hip_set_inputs", "tds_hip_get_inputs", "tds_hip_get_outputs",
     "tds_hip_forward_zero_device", "tds_hip_step", "tds_hip_step_obs", "tds_hip_obs_dim",
     "tds_hip_set_auto_reset", "tds_hip_reset", "tds_hip_rollout", "tds_hip_rollout_ex",
+    "tds_hip_set_policy_network", "tds_hip_policy_num_parameters",
     "tds_hip_forward_zero_host", "tds_hip_send_local", "tds_hip_forward_zero_fetch",
     "tds_hip_set_timing", "tds_hip_last_kernel_ms", "tds_hip_kernel_info", "tds_hip_profile_phases",
     "tds_hip_device", "tds_hip_record_bytes", "tds_hip_sync", "tds_hip_forward_zero_host_begin",
@@ -405,6 +406,26 @@ class HipSim:
             op = C.c_void_p(obs.data_ptr())
         _check(lib().tds_hip_reset(self.h, mp, op))
 
+    def set_policy_network(self, layer_sizes=None, activations=None, use_bias=None):
+        """the policy NETWORK of the rollouts (tds_hip_set_policy_network; the reference's NeuralNetworkSpecification):
+        layer_sizes incl. the input (obs_dim) and output (action_dim) layers, activations[i - 1] (TDS_NN_ACT_*: -1
+        identity, 0 tanh, 1 sin, 2 relu, 3 soft_relu, 4 elu, 5 sigmoid, 6 softsign) for layer i >= 1, use_bias per layer;
+        None restores the default linear policy.  Returns the number of parameters per environment."""
+        if layer_sizes is None:
+            _check(lib().tds_hip_set_policy_network(self.h, 0, None, None, None))
+        else:
+            n = len(layer_sizes)
+            assert len(activations) == n - 1 and len(use_bias) == n
+            arr = lambda v: (C.c_int * len(v))(*[int(a) for a in v])
+            lib().tds_hip_set_policy_network.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            _check(lib().tds_hip_set_policy_network(self.h, n, arr(layer_sizes), arr(activations), arr(use_bias)))
+        return self.policy_num_parameters
+
+    @property
+    def policy_num_parameters(self) -> int:
+        lib().tds_hip_policy_num_parameters.argtypes = [C.c_void_p]
+        return int(lib().tds_hip_policy_num_parameters(self.h))
+
     def rollout_ex(self, policy, n_steps: int, shift: float = 0.0, first_obs_raw: bool = False, stats=None,
                    want_traj: bool = False):
         """rollout + the by-products of Worker::rollouts (tds_hip_rollout_ex): ``stats`` [N, obs_dim, 3] device tensor
@@ -442,7 +463,7 @@ class HipSim:
 
         adim, od = self.model.action_dim, self.obs_dim
         assert policy.is_cuda and policy.dtype == self.torch_dtype and policy.is_contiguous()
-        assert tuple(policy.shape) == (self.num_envs, adim * od + adim)
+        assert tuple(policy.shape) == (self.num_envs, self.policy_num_parameters)
         ret = torch.zeros(self.num_envs, dtype=self.torch_dtype, device=policy.device)
         steps = torch.zeros(self.num_envs, dtype=torch.int32, device=policy.device)
         op = None
