@@ -21,6 +21,7 @@ struct TdsLds {
   int Z;                   // phase group 3 (constraint rows)     }
   int gram_ok;             // two-wavefront layout: the sweep groups hold the Gram buffer of tds_gram_solve
   int Lh;                  // two-wavefront layout: early copy of the first NDP/2 columns of L (tds_row_solve)
+  int tau;                 // 18-dof kernels: per-link slot that keeps the generalised force from the PD block to phase F
   int in_dim, adim, nqnd;  // record dimensions as kernel arguments: the x record is requested from HBM before anything
                            // has been read from the model
 };

@@ -40,6 +40,15 @@
 
 #include "tds_device_model.h"
 #include "tds_kernels.h"
+// two-wavefront workgroups of the narrow kernels: the generalised force of the PD block waits in LDS for phase F
+// (0: carried in registers)
+#ifndef TDS_PARK_W2
+#define TDS_PARK_W2 1
+#endif
+#ifndef TDS_PARK_LOOP
+#define TDS_PARK_LOOP 0
+#endif
+
 
 namespace {
 
@@ -2009,6 +2018,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 
   };
   if constexpr (!LATE_PD) compute_tau();
+  // 18-dof straight-line kernels (Laikago): tau would be the one value carried in registers from here through every
+  // sweep to phase F — it waits in LDS instead (a slot of its own per link)
+  constexpr bool PARK_TAU = (!LOOP && ((!W2 && NDP > 16 && NDP < 24) || (W2 && NDP <= 16 && TDS_PARK_W2))) ||
+                            (LOOP && W2 && NDP <= 16 && TDS_PARK_LOOP);
+  if constexpr (PARK_TAU) {
+    if (isl) E[L.tau + li] = tau;
+  }
 
   TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
@@ -2904,12 +2920,20 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
     TDS_WAVE_SYNC();
     if (!didn) {
-      if (di >= 0) rhsx[di] = tau - Cb;
+      if constexpr (PARK_TAU) {
+        if (di >= 0) rhsx[di] = E[L.tau + li] - Cb;
+      } else {
+        if (di >= 0) rhsx[di] = tau - Cb;
+      }
       TDS_WAVE_SYNC();
     }
     {
       const int d = lane;
-      T yv = didn ? (d < nd ? tau - Cb : T(0)) : (d < NDP ? rhsx[d] : T(0));
+      T tau_f = tau;
+      if constexpr (PARK_TAU) {
+        if (didn) tau_f = E[L.tau + (lane < nl ? lane : 0)];
+      }
+      T yv = didn ? (d < nd ? tau_f - Cb : T(0)) : (d < NDP ? rhsx[d] : T(0));
       // L y = rhs (L unit lower, row d of it in Mr[0..d-1]), column by column
       // (the row mask goes into the multiplier ahead of time: the dependent chain per step is broadcast + FMA, no select)
       //  (narrow kernels only: the wide ones have no registers for a masked copy of the row)
@@ -3586,6 +3610,8 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   L.Lh = o;   // two-wavefront pipeline (narrow kernels): row-major copy of the first ndp/2 columns of L, 16 + 1 rows
   if (w2 && ndp <= 16) o += 17 * (ndp / 2);  // (+ one row for the lanes of wider groups that own no row)
   L.dinv = o; o += (w2 ? 4 : 3) * ndp;  // 1/D | sqrt(1/D) | column scratch of the wide LDL^T / rhs exchange (| y~)
+  L.tau = o;
+  if ((ndp > 16 && ndp < 24) || (w2 && ndp <= 16 && TDS_PARK_W2)) o += nl;  // (the generalised forces wait here from the PD block to phase F)
   // three phase groups share one region:
   //   1. kinematics sweep:   per-link records [X_world(12) | v(6)]              stride TDS_S1
   //   2. composite sweep:    per-link records [f or F(6) | Ic(10)] stride TDS_S2
