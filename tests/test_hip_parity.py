@@ -497,7 +497,8 @@ def _host_reset(m, x_row, seed, env, count):
 
 
 @pytest.mark.parametrize("name", ["ant", "laikago", "laikago_floating_env", "ant_floating", "humanoid_spherical",
-                                  "pendulum5_spherical", "humanoid"])
+                                  "pendulum5_spherical", "humanoid", "two_pendulums_plane", "three_pendulums_plane",
+                                  "four_pendulums", "two_cubes_floating", "pendulum_and_cube"])
 def test_substeps_in_kernel_equal_repeated_steps(name, built):
     torch = _torch()
     m = tds_amd.load_model(name)
