@@ -50,6 +50,7 @@
 #endif
 
 
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
