@@ -84,6 +84,10 @@ struct DevModel {
   // World transform, motion axes, velocity and bias acceleration of link 5 then follow from six broadcasts of
   // (q, sin q, cos q, qd) without any scan over the chain.  0: no; 1: yes (the base frame's rotation is the identity too).
   int euler_root;
+  // ... and behind it nothing but serial chains of equal length leg_len = 2 or 4 in consecutive lanes, every one hanging
+  // off link 5 (the Ant's hip + ankle, Laikago's hip + upper + lower + toe): their kinematics is one segmented prefix scan
+  // over the lanes (log2(leg_len) rounds of DPP shifts) instead of leg_len tree levels.  0: no.
+  int leg_len;
   // 1: link i carries dof i for every link (lane == link == dof: the Ant; not Laikago, whose fixed toes own no dof) —
   // per-link results that feed per-dof computations then stay in the lane's registers instead of crossing through LDS
   int dof_identity;
@@ -450,6 +454,22 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
       bool ident = true;
       for (int c = 0; c < 9; ++c) ident = ident && m->base_X_world_rot[c] == ((c == 0 || c == 4 || c == 8) ? 1.0 : 0.0);
       d->euler_root = ident ? 1 : 0;  // (a rotated base frame: the general scan)
+    }
+    d->leg_len = 0;
+    const char *nls = getenv("TDS_HIP_NO_LEGSCAN");
+    // (double arithmetic only: in the pure float build the re-associated products of the scan cost Laikago a quarter of
+    //  a digit — 4.7e-4 against 3.5e-4 of the level loop, the reference's own float path: 1.1e-4; tests/test_f32.py)
+    if (d->euler_root && sizeof(T) == 8 && !(nls && nls[0] == '1')) {
+      const int nleg = m->num_links - 6;
+      for (int len = 4; len >= 2 && d->leg_len == 0; len >>= 1) {
+        if (nleg < len || nleg % len != 0) continue;
+        bool legs = true;
+        for (int i = 6; legs && i < m->num_links; ++i) {
+          const int j = (i - 6) % len;
+          legs = m->links[i].parent == (j == 0 ? 5 : i - 1);
+        }
+        if (legs) d->leg_len = len;
+      }
     }
   }
   d->dof_identity = (!fl && d->num_spherical == 0 && d->num_bodies < 2 && m->num_links == m->dof_qd) ? 1 : 0;

@@ -246,6 +246,33 @@ template <int D>
 __device__ __forceinline__ float dpp_shr(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xF, 0xF, true));
 }
+// lane i receives lane i - D, rows of 16 lanes or not: G == 16 (an environment is one DPP row): row_shr:D; wider lane
+// groups: wave_shr:1 (gfx9: shifts across the whole wavefront), D times.  What the first D lanes receive is garbage.
+template <int D, int G>
+__device__ __forceinline__ double seg_shr(double v) {
+  if constexpr (G == 16) {
+    return dpp_shr<D>(v);
+  } else {
+    int l = __double2loint(v), h = __double2hiint(v);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      l = __builtin_amdgcn_update_dpp(0, l, 0x138, 0xF, 0xF, true);
+      h = __builtin_amdgcn_update_dpp(0, h, 0x138, 0xF, 0xF, true);
+    }
+    return __hiloint2double(h, l);
+  }
+}
+template <int D, int G>
+__device__ __forceinline__ float seg_shr(float v) {
+  if constexpr (G == 16) {
+    return dpp_shr<D>(v);
+  } else {
+    int b = __float_as_int(v);
+#pragma unroll
+    for (int i = 0; i < D; ++i) b = __builtin_amdgcn_update_dpp(0, b, 0x138, 0xF, 0xF, true);
+    return __int_as_float(b);
+  }
+}
 // the same shift, lanes without a source (the first D of every row) receive 1 instead of 0 (the low word of 1.0 is 0:
 // only the high word needs a pre-set destination)
 template <int D>
@@ -2113,6 +2140,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   const int nlev = mdl->num_levels;
   const int rkc = mdl->kin_chain_last;  // serial chain 0..rkc from the base in lanes 0..rkc (>= the root joint of E'): -1 = none
   const int eul = KIND == 0 ? mdl->euler_root : 0;  // wave-uniform
+  const int leg_len = KIND == 0 ? mdl->leg_len : 0;  // wave-uniform: the links behind the root chain are chains of this length
   if (eul != 0) {
     // ---- The root chain in CLOSED FORM (DevModel::euler_root: links 0..5 = prismatic X, Y, Z, revolute X, Y, Z with
     //      identity X_T — the free motion of the URDF-derived fixed-base robots, the Ant and Laikago).  The chain's six
@@ -2187,13 +2215,113 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       cross3(W5, pJ5, t1);
       cross3(V5, J5, t2);
       l5[0] = t1[0] + t2[0]; l5[1] = t1[1] + t2[1]; l5[2] = t1[2] + t2[2];
-      const bool torso = isl && li == 5;  // (links 0..4: massless, v = a0 = 0 keeps their zero inertia's products finite)
+      // (links 0..4: massless, v = a0 = 0 keeps their zero inertia's products finite; with the leg scan below the lanes
+      //  of the legs start from the torso's velocity and bias acceleration: their chains hang off it)
+      const bool torso = isl && (li == 5 || (leg_len != 0 && li > 5));
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         v[k] = torso ? W5[k] : T(0);
         v[3 + k] = torso ? V5[k] : T(0);
         a0[k] = torso ? a45[k] + a55[k] : T(0);
         a0[3 + k] = torso ? (l3[k] + l4[k] + l5[k]) - mdl->grav[k] : T(0);
+      }
+    }
+    if (leg_len != 0) {
+      // ---- The legs as ONE segmented prefix scan: every link behind the torso sits in a serial chain of leg_len
+      //      consecutive lanes that hangs off the torso (DevModel::leg_len).  Chain-local prefix products of the joint
+      //      transforms (log2(leg_len) rounds of lane shifts), one composition with the torso's pose — which the closed
+      //      form above left on EVERY lane —, then prefix sums of the joint velocities and of the velocity-product
+      //      accelerations on top of the torso's: the same X_world, s, v, a0 the level loop produces link by link
+      //      (kinematics.hpp:64-97), leg_len tree levels and their LDS hand-over from the torso shorter.
+      const bool leg = isl && li > 5;
+      const int jpos = leg ? ((li - 6) & (leg_len - 1)) : 0;  // my position in my chain
+      T Rl[9], pl[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rl[k] = Rp[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pl[k] = tp[k];
+      static_for<0, 2>([&](auto dc) {
+        constexpr int D = 1 << decltype(dc)::value;
+        if (D < leg_len) {  // wave-uniform
+          const bool take = jpos >= D;
+          T Rq[9], pq[3];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const T sh = seg_shr<D, G>(Rl[k]);
+            Rq[k] = take ? sh : ((k == 0 || k == 4 || k == 8) ? T(1) : T(0));
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const T sh = seg_shr<D, G>(pl[k]);
+            pq[k] = take ? sh : T(0);
+          }
+          T Rn[9], r[3];
+          mat3_mul(Rq, Rl, Rn);
+          mat3_mulv(Rq, pl, r);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rl[k] = Rn[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pl[k] = pq[k] + r[k];
+        }
+      });
+      {
+        // into the world: X = X_torso o X_chain  (R, p hold the torso's pose on every lane)
+        T Rn[9], r[3];
+        mat3_mul(R, Rl, Rn);
+        mat3_mulv(R, pl, r);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = leg ? Rn[k] : R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = leg ? p[k] + r[k] : p[k];
+      }
+      if (leg) {
+        // s = X_world.apply_inverse(S) = (R w, R v + p x (R w))   (transform.hpp:232-243)
+        mat3_mulv(R, Sl, sw);
+        mat3_mulv(R, Sl + 3, sw + 3);
+        T c[3];
+        cross3(p, sw, c);
+        sw[3] += c[0];
+        sw[4] += c[1];
+        sw[5] += c[2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vJ[k] = sw[k] * qd;
+      }
+      {
+        T pre[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pre[k] = leg ? vJ[k] : T(0);
+        static_for<0, 2>([&](auto dc) {
+          constexpr int D = 1 << decltype(dc)::value;
+          if (D < leg_len) {  // wave-uniform
+            const bool take = jpos >= D;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              const T sh = seg_shr<D, G>(pre[k]);
+              pre[k] += take ? sh : T(0);
+            }
+          }
+        });
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = leg ? v[k] + pre[k] : v[k];
+      }
+      if (leg) bias_accel();
+      {
+        T pre[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pre[k] = leg ? cb[k] : T(0);
+        static_for<0, 2>([&](auto dc) {
+          constexpr int D = 1 << decltype(dc)::value;
+          if (D < leg_len) {  // wave-uniform
+            const bool take = jpos >= D;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              const T sh = seg_shr<D, G>(pre[k]);
+              pre[k] += take ? sh : T(0);
+            }
+          }
+        });
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a0[k] = leg ? a0[k] + pre[k] : a0[k];
       }
     }
     if (isl && li <= 5 && lds_children) {  // children other than lane + 1 read my record (link 5: the hips)
@@ -2319,7 +2447,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     TDS_WAVE_SYNC();
   }
   TDS_PROBE(13);
-  for (int lev = mdl->kin_lev0; lev < nlev; ++lev) {
+  for (int lev = leg_len != 0 ? nlev : mdl->kin_lev0; lev < nlev; ++lev) {  // (leg scan: every link is done)
     const bool mine = level == lev && li > rkc;  // (the chain's links are done)
     const bool by_dpp = mine && chain_child;
     const bool by_lds = mine && parent >= 0 && !chain_child;
@@ -2465,7 +2593,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   }
   TDS_PROBE(15);
   // X_world of the remaining links (narrowphase, visual poses) and the world motion axes per dof
-  if (isl && !lds_children) {
+  // (leg scan: no leg link has written its record yet, whatever its children — a chain that crosses a DPP row marks the
+  //  link in front of the crossing as a parent of LDS children for the later sweeps)
+  if (isl && (!lds_children || (leg_len != 0 && li > 5))) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) Xw[li * TDS_S1 + k] = R[k];
 #pragma unroll
