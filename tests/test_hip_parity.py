@@ -705,6 +705,24 @@ def test_rollout_with_a_policy_network_matches_the_reference_worker_loop(net, bu
     assert np.array_equal(cnt2.cpu().numpy(), gl["vec_steps"]) and rel_err(ret2.cpu().numpy(), gl["total_rewards"], 1e-3) < 1e-6
 
 
+def test_policy_network_arguments_are_checked(built):
+    """tds_hip_set_policy_network refuses specifications the reference's NeuralNetwork could not be driven with here: a
+    first layer that is not the observation, a last layer that is not the action, too many / too wide layers, an unknown
+    activation — and leaves the handle on its previous policy"""
+    m = tds_amd.load_model("ant")
+    od, adim = m.dof_q + m.dof_qd, m.action_dim
+    sim = hip_backend.HipSim(m, 8)
+    linear = adim * od + adim
+    for units, acts, bias in [([od + 1, adim], [-1], [0, 1]), ([od, 16, adim + 1], [2, -1], [0, 1, 1]),
+                              ([od] + [8] * 8 + [adim], [2] * 8 + [-1], [0] + [1] * 9), ([od, 257, adim], [2, -1], [0, 1, 1]),
+                              ([od, 16, adim], [7, -1], [0, 1, 1]), ([od], [], [0])]:
+        with pytest.raises(hip_backend.TdsHipError):
+            sim.set_policy_network(units, acts, bias)
+        assert sim.policy_num_parameters == linear
+    assert sim.set_policy_network([od, 16, adim], [0, -1], [1, 0, 1]) == od * 16 + 16 * adim + od + adim
+    assert sim.set_policy_network(None) == linear
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["ant", "laikago"])
 def test_rollout_by_products_match_the_reference_worker(name, built):
