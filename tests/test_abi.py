@@ -123,3 +123,34 @@ def test_newer_abi_library_exports_reference_symbols(name, built):
     m = tds_amd.load_model(name)
     assert (md.output_dim, md.local_input_dim, md.global_input_dim, md.accumulated_output) == \
         (m.output_dim, m.input_dim, 0, False)
+
+
+def test_model_check_on_multi_body_worlds(built):
+    """CPU: the multi-body blobs pass (fixed and floating bases; kernels of kind 3 / 4), malformed ones are refused with
+    a reason"""
+    for name in ["three_pendulums_plane", "four_pendulums", "two_cubes_floating", "pendulum_and_cube"]:
+        hip_backend.model_check(tds_amd.load_model(name))
+    m = tds_amd.load_model("three_pendulums")
+    m.bodies[2].first_link = m.bodies[1].first_link - 1          # not ascending
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.model_check(m)
+    m = tds_amd.load_model("three_pendulums")
+    m.links[7].parent = 2                                        # a link of body 1 hanging off a link of body 0
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.model_check(m)
+    m = tds_amd.load_model("three_pendulums")
+    m.num_bodies = 5                                             # more than TDS_MAX_BODIES
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.model_check(m)
+    m = tds_amd.load_model("pendulum_and_cube")
+    m.links[2].joint_type = tds_amd.model.JOINT_SPHERICAL        # spherical joints are not taken in multi-body worlds
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.model_check(m)
+    m = tds_amd.load_model("two_cubes_floating")
+    m.dof_q -= 1                                                 # dof_q inconsistent with two floating bases
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.model_check(m)
+    m = tds_amd.load_model("two_pendulums")
+    m.geoms[0].link = 7                                          # a geometry of body 0 listed on a link of body 1
+    with pytest.raises(hip_backend.TdsHipError):
+        hip_backend.model_check(m)
