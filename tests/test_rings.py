@@ -62,7 +62,8 @@ def _reward_done(m, name, q_before, y):
 
 
 @pytest.mark.parametrize("name,n,steps,dtype", [("ant", 4096, 20, "f64"), ("pendulum5", 4096, 20, "f64"),
-                                                ("pendulum5", 4096, 20, "mixed"), ("laikago_soft", 8192, 50, "f64")])
+                                                ("pendulum5", 4096, 20, "mixed"), ("laikago_soft", 8192, 50, "f64"),
+                                                ("ant", 8192, 20, "f64")])   # (config 5's per-GPU share: the one-wave loop build)
 def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtype, built):
     """BASELINE configs 3 / 2 / 4 at full size through the launch form bench.py times: K steps per call with both
     rings on; EVERY slot of EVERY environment against the reference's own step started from the state the previous
