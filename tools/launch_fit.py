@@ -13,10 +13,15 @@ model, n = (sys.argv[1] if len(sys.argv) > 1 else "ant"), int(sys.argv[2]) if le
 m = tds_amd.load_model(model)
 rng = np.random.default_rng(3)
 nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
-x0 = np.zeros((n, m.input_dim)); x0[:, 2] = 0.48
-x0[:, 6:nq] = np.array([m.initial_poses[i] for i in range(adim)]) + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
-x0[:, -3:] = [15, 0.3, 3] if model == "ant" else [100, 2, 50]
-a = torch.from_numpy(rng.uniform(-0.4, 0.4, (16, n, adim))).cuda().contiguous()
+x0 = np.zeros((n, m.input_dim))
+loco = m.step_mode == tds_amd.TDS_STEP_LOCOMOTION
+if loco:
+    x0[:, 2] = 0.48
+    x0[:, 6:nq] = np.array([m.initial_poses[i] for i in range(adim)]) + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
+    x0[:, -3:] = [15, 0.3, 3] if model == "ant" else [100, 2, 50]
+else:
+    x0[:, :nq] = rng.uniform(-1, 1, (n, nq))
+a = torch.from_numpy(rng.uniform(-0.4, 0.4, (16, n, adim)) * (1.0 if loco else 0.0)).cuda().contiguous()
 sim = hip_backend.HipSim(m, n)
 sim.x.copy_(torch.from_numpy(x0).cuda())
 S = 64
