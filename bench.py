@@ -177,6 +177,10 @@ def main():
                          "(tds_hip_step_many_rings) — the per-step protocol of the reference's metric loop; last: only the "
                          "last step of a launch does (tds_hip_step_many: the substep-fused form, secondary)")
     ap.add_argument("--ring-slots", type=int, default=64, help="slots of the two record rings (a slot is reused that many steps later)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="library option for every handle of this run (tds_hip_default_option), e.g. loop_w2=0, shard_wait=1")
+    ap.add_argument("--y-stride", default="line", choices=["line", "packed"],
+                    help="record stride of the y ring: padded to whole 128-byte lines (default) or output_dim")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements of the default N = 1 line (substep_fused, one_rank_with_exchange, auto_reset_rate)")
     ap.add_argument("--shard-graph", action="store_true",
@@ -234,12 +238,18 @@ def main():
                 time.sleep(2.0)
             time.sleep(5.0)
 
-    if args.step_many_form != "auto":
-        os.environ["TDS_HIP_STEP_MANY_LOOP"] = "1" if args.step_many_form == "loop" else "0"
-    if args.shard_graph:
-        os.environ["TDS_HIP_SHARD_GRAPH"] = "1"
     import tds_amd
     from tds_amd import hip_backend
+
+    # library options of every handle this run creates (tds_hip_default_option: the option table of csrc/tds_options.h;
+    # environment variables TDS_HIP_<KEY> remain the defaults underneath)
+    if args.step_many_form != "auto":
+        hip_backend.default_option("step_many_loop", 1 if args.step_many_form == "loop" else 0)
+    if args.shard_graph:
+        hip_backend.default_option("shard_graph", 1)
+    for kv in args.option:
+        k, _, v = kv.partition("=")
+        hip_backend.default_option(k, int(v))
 
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
@@ -275,7 +285,7 @@ def main():
                 dist.broadcast(idt, src=0)
             uid = bytes(idt.cpu().numpy().tobytes())
         if args.lanes:
-            os.environ["TDS_HIP_LANES_PER_ENV"] = str(args.lanes)
+            hip_backend.default_option("lanes_per_env", args.lanes)
         # (RCCL prints a version banner on C stdout when a communicator comes up: keep rank 0's stdout to the one
         #  JSON line — send C-level stdout to stderr while the communicator is created)
         import ctypes
@@ -392,7 +402,11 @@ def main():
     obs_ring = y_ring = None
     if use_rings:  # (at N > 1 the shard layer owns the rings)
         obs_ring = torch.zeros((RS, n, sim.obs_dim + 2), dtype=tdt, device="cuda")
-        y_ring = torch.zeros((RS, n, m.output_dim), dtype=tdt, device="cuda")
+        # y records on 128-byte line boundaries (tds_hip_rings_t::y_stride; Ant f64: 160 scalars instead of 155): the
+        # launch then writes whole lines only — the payload is unchanged
+        per_line = 128 // (8 if tdt == torch.float64 else 4)
+        y_str = -(-m.output_dim // per_line) * per_line if args.y_stride == "line" else m.output_dim
+        y_ring = torch.zeros((RS, n, y_str), dtype=tdt, device="cuda")
     GCH = 1024  # steps per graph launch when K is larger (a multiple of the action pool)
     state = {"i": 0}
 
@@ -475,7 +489,7 @@ def main():
         forms = (["ring", "per-step graph", "per-step eager"] if world == 1 else ["ring", "per-step eager"]) if shard_graph else ["per-step eager"]
         for f in forms:
             if f == "per-step graph":
-                os.environ["TDS_HIP_SHARD_RING"] = "0"
+                shard.sim.set_option("shard_ring", 0)
             if f == "per-step eager":
                 shard_graph = False
             err = 0
@@ -627,11 +641,17 @@ def main():
                 sh1.flush()
 
             v = timed(go, kk)
+            xo = {k: sh1.sim.get_option(k) for k in ("exchange_w2", "shard_wait", "shard_inplace", "shard_register")}
             one_rank = {"value": v, "unit": "env-steps/s", "steps": kk,
                         "exchange": "ncclAllGather, single-rank communicator" if uid else "device copy (librccl not loadable)",
-                        "what": "tds_hip_shard_step_many on ONE rank: the same step-loop launch and rings + one all-gather of "
-                                "the obs ring slot per policy step on the communication stream (what every rank of an "
-                                "N > 1 run executes)"}
+                        "build": "two-wavefront step-loop build (exchange_w2 = 1)" if xo["exchange_w2"] == 1
+                                 else "one-wave step-loop build (leaves 216 of a SIMD's 512 registers to the exchange's kernels)",
+                        "wait": "hipStreamWaitValue64" if xo["shard_wait"] == 1 else "one-lane wait kernel (bounded)",
+                        "in_place": xo["shard_inplace"] != 0,
+                        "what": "tds_hip_shard_step_many on ONE rank: step-loop launches of <= 64 steps storing every step's "
+                                "[obs | reward | done] record straight into this rank's block of the gathered buffer + one "
+                                "(in-place) all-gather of that slot per policy step on the communication stream, which "
+                                "follows the launch's progress counter (what every rank of an N > 1 run executes)"}
             sh1.close()
         except Exception as e:  # noqa: BLE001 - a secondary key must never cost the headline line
             one_rank = {"error": repr(e)}
@@ -729,7 +749,7 @@ def main():
             launch = ("one launch of the step-loop kernel per %d steps, EVERY step packing and storing its y record and its "
                       "[obs | reward | done] record into ring slots; the communication stream follows the launch's per-step "
                       "progress counter and all-gathers each obs slot (%s)"
-                      % (min(K, 64), "launch + its exchanges = one hipGraph" if os.environ.get("TDS_HIP_SHARD_GRAPH") == "1"
+                      % (min(K, 64), "launch + its exchanges = one hipGraph" if args.shard_graph
                          else "exchange submitted eagerly while the launch runs"))
         elif loop_form and use_rings:
             launch = ("one launch of the step-loop kernel per %d steps (state in LDS across the steps, one action block per "
@@ -783,6 +803,8 @@ def main():
         if substep_fused is not None:
             out["substep_fused"] = substep_fused
         if one_rank is not None:
+            if "value" in one_rank:
+                one_rank["ratio_to_value"] = one_rank["value"] / value
             out["one_rank_with_exchange"] = one_rank
         if auto_rate is not None:
             out["auto_reset_rate"] = auto_rate

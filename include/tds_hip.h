@@ -29,13 +29,14 @@
 #ifndef TDS_HIP_H
 #define TDS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define TDS_HIP_ABI_VERSION 4
+#define TDS_HIP_ABI_VERSION 5
 
 #define TDS_MAX_LINKS 64   /* links of the model as the reference builds it; the kernels take <= 32 lanes: one per
                               moving link (fixed links are folded into their parents when lanes run short), six for
@@ -301,6 +302,25 @@ int tds_hip_step(tds_hip_sim_t *sim, const void *actions_dev, int substeps);
 int tds_hip_step_obs(tds_hip_sim_t *sim, const void *actions_dev, int substeps, void *obs_dev);
 int tds_hip_obs_dim(const tds_hip_sim_t *sim);
 
+/* The same step for a caller whose actions and observations are HOST arrays of doubles — the signature the reference's
+   VectorizedEnvironment::step works on (ars_vectorized_environment.h:213-291) — with the STATE resident on the device:
+   per call only actions_host [N][action_dim] travel up and obs_host [N][obs_dim + 2] = [obs | reward | done]
+   (and y_host [N][output_dim] = sim_states_with_graphics_, optional) travel down, through pinned staging memory owned
+   by the handle.  Blocking.  With tds_hip_set_auto_reset on, done environments are reset inside the call.
+   tds_hip_reset_host: tds_hip_reset with a host mask ([N] bytes, NULL = all) and the observations back on the host.
+   tds_hip_set_states: overwrite [q | qd] of every environment from qqd_host [N][dof_q + dof_qd] (actions and the PD
+   variables of the x records stay) — how a caller that resets with the REFERENCE's own reset() hands the states over.
+   Used by tds_hip::VectorizedEnv (include/tds_hip_stepper.hpp). */
+int tds_hip_step_host(tds_hip_sim_t *sim, const double *actions_host, int substeps, double *obs_host, double *y_host);
+int tds_hip_reset_host(tds_hip_sim_t *sim, const unsigned char *mask_host, double *obs_host);
+int tds_hip_set_states(tds_hip_sim_t *sim, const double *qqd_host);
+/* Device memory on the handle's device for callers without HIP headers (action pools, record rings, policies handed to
+   tds_hip_step_many_rings / tds_hip_rollout): alloc zero-fills; upload / download block on the handle's stream. */
+int tds_hip_device_alloc(tds_hip_sim_t *sim, size_t bytes, void **out);
+int tds_hip_device_free(tds_hip_sim_t *sim, void *ptr);
+int tds_hip_device_upload(tds_hip_sim_t *sim, void *dst_dev, const void *src_host, size_t bytes);
+int tds_hip_device_download(tds_hip_sim_t *sim, void *dst_host, const void *src_dev, size_t bytes);
+
 /* n_steps closed-loop steps (tds_hip_step_obs with substeps = 1) per host call, replayed from a
    captured hipGraph: ONE graph launch instead of n_steps kernel launches, which removes the host-side launch gaps
    that cost a double-digit share of short runs at ~20 us per step.
@@ -323,6 +343,24 @@ int tds_hip_step_many_prepare(tds_hip_sim_t *sim, const void *actions_dev, int a
 int tds_hip_step_many(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int first_block, int n_steps,
                       void *obs_dev);
 int tds_hip_set_graph_chains(tds_hip_sim_t *sim, int chains);
+
+/* Run-time options.  Every switch of the library — kernel forms, launch forms, reset-pool geometry, exchange forms — is a
+   named integer option (table: csrc/tds_options.h; tds_hip_option_count / _name enumerate it).  When a handle is
+   CREATED each option takes, in this order: the value of tds_hip_default_option in this process, the environment
+   variable TDS_HIP_<KEY> (upper case), or "unset" = the library's own rule.  The handle keeps that snapshot; afterwards
+   only tds_hip_set_option changes it — the environment is never read while a handle is in use and nothing is latched
+   per process, so one process can hold handles with different forms (how the tests select kernel builds).
+   Create-time options (lanes_per_env, na_cap, w2, gram, no_chain, no_rootjoint, no_kinchain, no_eulerroot, no_legscan,
+   fold_fixed) shape the device model / LDS layout: tds_hip_set_option refuses them, set them with
+   tds_hip_default_option before tds_hip_create.  Setting an option that cached graphs or the reset pool depend on
+   drops those (they are rebuilt by the next call).  The options of a shard are those of its sim handle
+   (tds_hip_shard_sim).  Unknown key: TDS_ERR_INVALID_ARG. */
+int tds_hip_default_option(const char *key, long long value);
+int tds_hip_set_option(tds_hip_sim_t *sim, const char *key, long long value);
+/* *is_set (optional) = 0: the option is unset (library rule), *value = 0 */
+int tds_hip_get_option(const tds_hip_sim_t *sim, const char *key, long long *value, int *is_set);
+int tds_hip_option_count(void);
+const char *tds_hip_option_name(int index);
 /* 1 if tds_hip_step_many(sim, ..., n_steps, ...) runs as ONE launch of the step-loop kernel instead of graphs: worlds
    without contact points (pendulums, the cartpole), and fixed-base kernels up to 16 dof with contacts (the Ant) while
    the batch is at most three rounds of workgroups (12288 Ant environments).  No kernel boundaries; the state stays in
@@ -344,7 +382,7 @@ int tds_hip_step_many_is_loop(const tds_hip_sim_t *sim, int n_steps);
    packing, locomotion_contact_simulation.h:273-303) — the [obs | reward | done] record and, if asked for, the whole y
    record (q, qd, visual poses, up.z, padding) — and stores it into the step's slot of a caller-owned ring in HBM:
      obs_ring  [obs_slots][N][obs_dim + 2]   step k of the call -> slot (obs_first + k) % obs_slots
-     y_ring    [y_slots][N][output_dim]      step k of the call -> slot (y_first + k) % y_slots        (either may be NULL)
+     y_ring    [y_slots][N][y_stride]        step k of the call -> slot (y_first + k) % y_slots        (either may be NULL)
    in the record dtype; obs_f32 != 0: the obs ring holds FLOATS whatever the record dtype (the wire format of the
    multi-GPU exchange).  Where tds_hip_step_many_is_loop holds the n_steps steps are ONE launch of the step-loop kernel
    that packs and stores the records of every step (non-temporal stores; the state itself never leaves LDS between the
@@ -352,17 +390,29 @@ int tds_hip_step_many_is_loop(const tds_hip_sim_t *sim, int n_steps);
    auto-reset on, a step that ends with done leaves reward / done of the terminal step and the observation of the fresh
    environment in its slot, as the reference does.  Afterwards the handle's y record holds the last step's (a device
    copy of its slot).  This is the form bench.py times: all of step_forward_original's work, every step.
-     progress  optional, step-loop form only: a device counter every workgroup increments once its records of step k
-               are visible device-wide (signalled while step k + 1 runs; not for the last step of the call: stream
-               order covers it) — what tds_hip_shard_step_many polls to exchange slot k while the launch carries on.
+     progress  optional, step-loop form only, not with auto-reset (those calls are cut into several launches): a device
+               counter every workgroup increments once its OBS-RING record of step k is visible device-wide (signalled
+               while step k + 1 runs; not for the last step of the call: stream order covers it) — what
+               tds_hip_shard_step_many polls to exchange slot k while the launch carries on.  It covers the obs ring
+               only: the y ring is written with streaming stores that become visible to other agents at the end of the
+               launch (nothing exchanges y records; read them behind the launch in stream order).
                tds_hip_step_many_rings_blocks = increments per completed step.
+     y_stride  scalars between consecutive y records of the y ring (0: output_dim, i.e. packed).  A stride that is a
+               multiple of the 128-byte line (Ant, f64: 160 instead of 155) lets every record start on a line boundary:
+               the ring launch then writes whole lines only (measured: HBM write traffic per step down to the payload).
+     obs_slot_envs  see the field.
    A slot is overwritten `slots` steps later: the ring's depth is the lag the consumer may have. */
 typedef struct tds_hip_rings {
   void *obs_ring;
-  int32_t obs_slots, obs_first, obs_f32, pad0_;
+  int32_t obs_slots, obs_first, obs_f32, y_stride;
   void *y_ring;
   int32_t y_slots, y_first;
   unsigned long long *progress;
+  int32_t obs_slot_envs; /* environments per SLOT of the obs ring (0: the handle's own N).  Larger than N: a slot laid out
+                            for the environments of all ranks of a multi-GPU run — obs_ring then points at this rank's
+                            block of slot 0, and the launch stores its records straight into the receive buffer of an
+                            in-place all-gather (no copy of the local block on any rank) */
+  int32_t pad1_;
 } tds_hip_rings_t;
 int tds_hip_step_many_rings(tds_hip_sim_t *sim, const void *actions_dev, int action_blocks, int first_block, int n_steps,
                             const tds_hip_rings_t *rings);

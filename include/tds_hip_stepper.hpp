@@ -17,7 +17,9 @@
 #pragma once
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -361,6 +363,238 @@ struct HipStepper : public VectorizedEnvironment<Algebra, Sim>::CustomForwardDyn
       if ((int)thread_outputs[e].size() != od) fail("output record size mismatch", TDS_ERR_INVALID_ARG);
       for (int k = 0; k < od; ++k) thread_outputs[e][k] = Algebra::from_double(out_[(size_t)e * od + k]);
     }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tds_hip::VectorizedEnv<Algebra, Sim> — the reference's VectorizedEnvironment (examples/ars/ars_vectorized_environment.h:
+// 141-300) with the environments RESIDENT on the GPU.  Same public surface — the members Worker<> touches
+// (neural_networks_, observation_dim_, sim_states_with_graphics_), seed(), reset(config), step(actions, observations,
+// rewards, dones, config), policy(), init_neural_network() — so that the reference's own rollout loop compiles against it
+// unchanged:   Worker<tds_hip::VectorizedEnv<Alg, Sim>> worker(env, ...)   (examples/ars/ars_vectorized_worker.h:9-160).
+//
+// Where HipStepper (above) replaces the STEPPER — and therefore moves every state record to the device and back on every
+// step (268 us per step at 4096 Ant environments) — this class replaces the ENVIRONMENT: state, PD control, physics,
+// reward / done and auto-reset live on the device (tds_hip_step_obs); step() moves only what its signature names, the
+// actions up and [obs | reward | done] down (+ the y records while fetch_graphics_ is set: Worker::rollouts reads
+// sim_states_with_graphics_ every step).  No H2D / D2H of state.  Beyond the reference's surface, for callers that keep
+// actions / policies on the device too (no HIP headers needed, the buffers come from tds_hip_device_alloc):
+//   step_many_device   K steps per call with per-step record rings (tds_hip_step_many_rings) — the 2e8 env-steps/s path
+//   rollouts_on_device Worker::rollouts in one call, the environments' own linear policies evaluated on the device
+// Copies of the object share the device state (Worker<> keeps its environment BY VALUE).
+//
+// reset().  Default: on the device (tds_hip_reset / tds_hip_set_auto_reset: the reset distribution of the model blob and
+// the settle steps, counter-based random stream — NOT std::rand's).  host_reset_ = true: through the reference's own
+// contact_sim.reset() on the host, state uploaded afterwards — the std::rand stream and therefore the trajectories of
+// the reference, environment for environment (what the parity test runs); auto_reset_when_done then resets done
+// environments on the host as well.
+// A done environment keeps stepping (as under the reference's CudaStepper, which ignores `dones`); without
+// auto_reset_when_done its reward reads 0 and `done` stays set, as in VectorizedEnvironment::step.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename Algebra, typename Sim>
+struct VectorizedEnv {
+  using Scalar = typename Algebra::Scalar;
+  struct Handle {
+    tds_hip_sim_t *h = nullptr;
+    ~Handle() {
+      if (h) tds_hip_destroy(h);
+    }
+  };
+
+  Sim &contact_sim;
+  std::vector<std::vector<Scalar>> sim_states_;                           // [q | qd] mirror (refreshed with the y records)
+  std::vector<std::vector<Scalar>> sim_states_with_action_and_variables;  // (surface parity; the device builds its own)
+  std::vector<std::vector<Scalar>> sim_states_with_graphics_;             // y record of the last step per environment
+  std::vector<tds::NeuralNetwork<Algebra>> neural_networks_;
+  int observation_dim_{0};
+  bool host_reset_ = false;     // resets through contact_sim.reset() on the host (the reference's std::rand stream)
+  bool fetch_graphics_ = true;  // step() also brings the y records down (sim_states_with_graphics_, sim_states_)
+  bool throw_on_error_ = true;
+
+  VectorizedEnv(Sim &sim, int batch_size, int reward_mode, int device = 0, int dtype = TDS_DTYPE_F64)
+      : contact_sim(sim), batch_size_(batch_size), handle_(std::make_shared<Handle>()) {
+    int rc = flatten_locomotion_env<Algebra>(contact_sim, &model_, reward_mode);
+    if (rc) fail("flatten_locomotion_env failed", rc);
+    rc = tds_hip_create(&model_, batch_size, device, dtype, &handle_->h);
+    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    observation_dim_ = contact_sim.input_dim();
+    od_ = observation_dim_;
+    neural_networks_.resize(batch_size);
+    sim_states_.resize(batch_size);
+    sim_states_with_action_and_variables.resize(batch_size);
+    sim_states_with_graphics_.resize(batch_size);
+    for (int e = 0; e < batch_size; ++e) {  // the policy VectorizedEnvironment builds (:165-180)
+      neural_networks_[e].set_input_dim(observation_dim_, false);
+      neural_networks_[e].add_linear_layer(tds::NN_ACT_IDENTITY, sim.action_dim(), true);
+    }
+    act_.resize((size_t)batch_size * model_.action_dim);
+    rec_.resize((size_t)batch_size * (od_ + 2));
+    y_.resize((size_t)batch_size * model_.output_dim);
+    // the x records carry kp, kd, max_force in their last slots (prepare_sim_state_with_action_and_variables,
+    // locomotion_contact_simulation.h:138-148): filled once, resident from then on
+    std::vector<double> x((size_t)batch_size * model_.input_dim, 0.0);
+    std::vector<Scalar> v(contact_sim.input_dim_with_action_and_variables(), Scalar(0)), zero_act(sim.action_dim(), Scalar(0));
+    contact_sim.prepare_sim_state_with_action_and_variables(v, zero_act);
+    for (int e = 0; e < batch_size; ++e)
+      for (int k = 0; k < model_.input_dim; ++k) x[(size_t)e * model_.input_dim + k] = Algebra::to_double(v[k]);
+    rc = tds_hip_set_inputs(handle_->h, x.data());
+    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+  }
+  virtual ~VectorizedEnv() {}
+
+  tds_hip_sim_t *handle() const { return handle_->h; }
+  const tds_model_t &model() const { return model_; }
+
+  void init_neural_network(int index, const std::vector<double> &x) { neural_networks_[index].set_parameters(x); }
+
+  void seed(long long int s) {
+    std::srand(s);  // (host_reset_: the stream contact_sim.reset() draws from, as in the reference)
+    seed_ = (unsigned long long)s;
+    auto_reset_set_ = -1;
+  }
+
+  std::vector<std::vector<double>> reset(const ARSConfig &config) {
+    check_batch(config);
+    std::vector<std::vector<double>> observations(batch_size_);
+    if (host_reset_) {
+      std::vector<double> qqd((size_t)batch_size_ * od_);
+      for (int e = 0; e < batch_size_; ++e) {
+        sim_states_[e].resize(0);
+        sim_states_[e].resize(contact_sim.input_dim_with_action_and_variables(), Scalar(0));
+        observations[e].resize(contact_sim.input_dim());
+        contact_sim.reset(sim_states_[e], observations[e]);
+        for (int k = 0; k < od_; ++k) qqd[(size_t)e * od_ + k] = Algebra::to_double(sim_states_[e][k]);
+      }
+      const int rc = tds_hip_set_states(handle_->h, qqd.data());
+      if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+      return observations;
+    }
+    apply_auto_reset(config);
+    const int rc = tds_hip_reset_host(handle_->h, nullptr, rec_.data());
+    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    for (int e = 0; e < batch_size_; ++e) observations[e].assign(rec_.begin() + (size_t)e * (od_ + 2), rec_.begin() + (size_t)e * (od_ + 2) + od_);
+    return observations;
+  }
+
+  void step(std::vector<std::vector<double>> &actions, std::vector<std::vector<double>> &observations,
+            std::vector<double> &rewards, std::vector<bool> &dones, const ARSConfig &config) {
+    check_batch(config);
+    apply_auto_reset(config);
+    const int adim = model_.action_dim, out = model_.output_dim;
+    for (int e = 0; e < batch_size_; ++e) {
+      if ((int)actions[e].size() < adim) fail("action vector too short", TDS_ERR_INVALID_ARG);
+      for (int k = 0; k < adim; ++k) act_[(size_t)e * adim + k] = actions[e][k];
+    }
+    const bool want_y = fetch_graphics_ || (host_reset_ && config.auto_reset_when_done);
+    const int rc = tds_hip_step_host(handle_->h, act_.data(), 1, rec_.data(), want_y ? y_.data() : nullptr);
+    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    bool any_host_reset = false;
+    for (int e = 0; e < batch_size_; ++e) {
+      const double *r = rec_.data() + (size_t)e * (od_ + 2);
+      if (want_y) {
+        sim_states_with_graphics_[e].assign(y_.begin() + (size_t)e * out, y_.begin() + (size_t)(e + 1) * out);
+        sim_states_[e].assign(y_.begin() + (size_t)e * out, y_.begin() + (size_t)e * out + od_);
+      }
+      observations[e].assign(r, r + od_);  // (obs[0] = obs[1] = 0: the kernel's record, :283-288)
+      if (!dones[e] || config.auto_reset_when_done) {
+        rewards[e] = r[od_];
+        const bool done = r[od_ + 1] != 0.0;
+        if (done && config.auto_reset_when_done && host_reset_) {
+          sim_states_[e].resize(0);
+          sim_states_[e].resize(contact_sim.input_dim_with_action_and_variables(), Scalar(0));
+          observations[e].resize(contact_sim.input_dim());
+          contact_sim.reset(sim_states_[e], observations[e]);
+          sim_states_[e].resize(od_);
+          any_host_reset = true;
+        }
+        dones[e] = done;
+      } else {
+        rewards[e] = 0;
+      }
+    }
+    if (any_host_reset) {  // (parity mode: the fresh states of the environments the host has just reset go up)
+      std::vector<double> qqd((size_t)batch_size_ * od_);
+      for (int e = 0; e < batch_size_; ++e)
+        for (int k = 0; k < od_; ++k) qqd[(size_t)e * od_ + k] = Algebra::to_double(sim_states_[e][k]);
+      const int rc2 = tds_hip_set_states(handle_->h, qqd.data());
+      if (rc2 != TDS_OK) fail(tds_hip_last_error(), rc2);
+    }
+  }
+
+  inline const std::vector<double> policy(int index, const std::vector<double> &obs) {
+    std::vector<double> action(neural_networks_[index].input_dim(), Scalar(0));
+    neural_networks_[index].compute(obs, action);
+    return action;
+  }
+
+  // ---- beyond the reference's surface: nothing but the call crosses PCIe --------------------------------------------
+  // K closed-loop steps in ONE call, step k taking block (first_block + k) % action_blocks of an action pool in device
+  // memory ([action_blocks][N][action_dim] doubles, tds_hip_device_alloc + tds_hip_device_upload), every step leaving its
+  // [obs | reward | done] and y records in the rings (tds_hip_step_many_rings).  Asynchronous; tds_hip_sync(handle()).
+  void step_many_device(const void *actions_dev, int action_blocks, int first_block, int n_steps, const tds_hip_rings_t &rings,
+                        const ARSConfig &config) {
+    apply_auto_reset(config);
+    const int rc = tds_hip_step_many_rings(handle_->h, actions_dev, action_blocks, first_block, n_steps, &rings);
+    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+  }
+  // Worker::rollouts (ars_vectorized_worker.h:51-140) as ONE device call: reset, then rollout_length times { the
+  // environment's own policy (neural_networks_[e]: the linear layer with bias), step, reward / done, return bookkeeping }.
+  void rollouts_on_device(double shift, int rollout_length, std::vector<double> &total_rewards, std::vector<int> &vec_steps,
+                          const ARSConfig &config) {
+    check_batch(config);
+    apply_auto_reset(config);
+    const int np = neural_networks_[0].num_parameters();
+    std::vector<double> params((size_t)batch_size_ * np);
+    for (int e = 0; e < batch_size_; ++e) {
+      // (NeuralNetwork parameter order, neural_network.hpp:406-415: all weights, then all biases)
+      const auto &W = neural_networks_[e].weights;
+      const auto &B = neural_networks_[e].biases;
+      size_t i = 0;
+      for (size_t k = 0; k < W.size(); ++k) params[(size_t)e * np + i++] = W[k];
+      for (size_t k = 0; k < B.size(); ++k) params[(size_t)e * np + i++] = B[k];
+    }
+    void *pol = nullptr, *ret = nullptr, *cnt = nullptr;
+    auto chk = [&](int rc) {
+      if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    };
+    chk(tds_hip_device_alloc(handle_->h, params.size() * 8, &pol));
+    chk(tds_hip_device_alloc(handle_->h, (size_t)batch_size_ * 8, &ret));
+    chk(tds_hip_device_alloc(handle_->h, (size_t)batch_size_ * sizeof(int), &cnt));
+    chk(tds_hip_device_upload(handle_->h, pol, params.data(), params.size() * 8));
+    chk(tds_hip_reset(handle_->h, nullptr, nullptr));
+    chk(tds_hip_rollout(handle_->h, pol, rollout_length, shift, /*first step sees the raw base x, y*/ 1, ret, (int *)cnt, nullptr));
+    total_rewards.resize(batch_size_);
+    vec_steps.resize(batch_size_);
+    chk(tds_hip_device_download(handle_->h, total_rewards.data(), ret, (size_t)batch_size_ * 8));
+    chk(tds_hip_device_download(handle_->h, vec_steps.data(), cnt, (size_t)batch_size_ * sizeof(int)));
+    tds_hip_device_free(handle_->h, pol);
+    tds_hip_device_free(handle_->h, ret);
+    tds_hip_device_free(handle_->h, cnt);
+  }
+
+ private:
+  tds_model_t model_;
+  int batch_size_ = 0, od_ = 0, auto_reset_set_ = -1;
+  unsigned long long seed_ = 0x5DEECE66Dull;
+  std::shared_ptr<Handle> handle_;
+  std::vector<double> act_, rec_, y_;
+
+  void check_batch(const ARSConfig &config) {
+    if (config.batch_size != batch_size_) fail("config.batch_size differs from the environment's batch", TDS_ERR_INVALID_ARG);
+  }
+  // auto_reset_when_done travels in the config of every call (as in the reference): forwarded when it changes
+  void apply_auto_reset(const ARSConfig &config) {
+    const int want = (config.auto_reset_when_done && !host_reset_) ? 1 : 0;
+    if (want == auto_reset_set_) return;
+    const int rc = tds_hip_set_auto_reset(handle_->h, want, seed_);
+    if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
+    auto_reset_set_ = want;
+  }
+  void fail(const char *what, int rc) {
+    std::string msg = std::string("tds_hip::VectorizedEnv: ") + what + " (code " + std::to_string(rc) + ")";
+    if (throw_on_error_) throw std::runtime_error(msg);
+    fprintf(stderr, "%s\n", msg.c_str());
+    exit(rc);
   }
 };
 #endif  // ARS_VECTORIZED_ENVIRONMENT_H

@@ -30,6 +30,12 @@ typedef TinyAlgebra<double, ::TINY::DoubleUtils> Alg;
 #include "dynamics/jacobian.hpp"
 #include "../ars/ars_vectorized_environment.h"
 #include "../ars/running_stat.h"
+#include "../ars/shared_noise_table.h"
+// what the reference's training programs define ahead of ars_vectorized_worker.h (ars_train_policy_cuda.cpp:58, 164-169)
+struct PolicyParams {};
+static void visualize_trajectories(std::vector<std::vector<std::vector<double>>> &, int, bool, int) {}
+#include "../ars/ars_vectorized_worker.h"
+#include <chrono>
 
 #include "tds_hip.h"
 #include "tds_hip_stepper.hpp"
@@ -700,6 +706,169 @@ int tdsref_vecenv_steps(const char *name, int batch, int steps, const double *x0
   if (n == "laikago")
     return ref_vecenv_steps<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, x0, actions, obs, rewards,
                                                                             dones, vis);
+  return -1;
+}
+
+// The reference's OWN rollout loop — Worker<Env>::rollouts, examples/ars/ars_vectorized_worker.h:51-140, compiled from
+// the unmodified header — instantiated twice: on the reference's VectorizedEnvironment (serial CPU stepper) and on
+// tds_hip::VectorizedEnv (include/tds_hip_stepper.hpp: the environments resident on the GPU).  Same seed, same policy
+// parameters per environment; tds_hip::VectorizedEnv resets through the reference's contact_sim.reset() (host_reset_:
+// the same std::rand stream), so both loops walk the same trajectories.  Returns both sets of results:
+//   total_rewards / vec_steps [2][batch] (0: reference, 1: HIP), traj_last [2][batch][output_dim] = the last entry of
+//   every environment's trajectory, traj_len [2][batch].  auto_reset: ARSConfig::auto_reset_when_done.
+extern "C++" {
+template <typename Sim, typename Env>
+static int vecenv_hip_worker(int batch, int steps, double shift, int seed, int auto_reset, int reward_mode, const double *params,
+                             double *total_rewards, int *vec_steps, double *traj_last, int *traj_len, char *msg, int msg_len) {
+  typedef VectorizedEnvironment<Alg, Sim> RefEnv;
+  typedef tds_hip::VectorizedEnv<Alg, Sim> HipEnv;
+  ARSConfig config;
+  config.batch_size = batch;
+  config.auto_reset_when_done = auto_reset != 0;
+  config.env_seed = seed;
+  const std::vector<double> deltas(4096, 0.0);
+  const PolicyParams pp;
+  try {
+    Env env(false);
+    const int out = env.contact_sim.output_dim();
+    const int np = env.contact_sim.action_dim() * env.contact_sim.input_dim() + env.contact_sim.action_dim();
+    for (int which = 0; which < 2; ++which) {
+      std::vector<double> tr(batch, 0.0);
+      std::vector<int> vs(batch, 0);
+      std::vector<std::vector<std::vector<double>>> trajectories(batch);
+      if (which == 0) {
+        RefEnv vec_env(env.contact_sim, batch);
+        vec_env.default_stepper_ = &vec_env.serial_stepper_;
+        for (int e = 0; e < batch; ++e)
+          vec_env.init_neural_network(e, std::vector<double>(params + (size_t)e * np, params + (size_t)(e + 1) * np));
+        Worker<RefEnv> worker(vec_env, np, pp, deltas, config);  // (seeds the environment: std::srand(env_seed))
+        worker.rollouts(shift, steps, tr, vs, trajectories);
+      } else {
+        HipEnv vec_env(env.contact_sim, batch, reward_mode);
+        vec_env.host_reset_ = true;
+        for (int e = 0; e < batch; ++e)
+          vec_env.init_neural_network(e, std::vector<double>(params + (size_t)e * np, params + (size_t)(e + 1) * np));
+        Worker<HipEnv> worker(vec_env, np, pp, deltas, config);
+        worker.rollouts(shift, steps, tr, vs, trajectories);
+      }
+      for (int e = 0; e < batch; ++e) {
+        total_rewards[(size_t)which * batch + e] = tr[e];
+        vec_steps[(size_t)which * batch + e] = vs[e];
+        traj_len[(size_t)which * batch + e] = (int)trajectories[e].size();
+        for (int k = 0; k < out; ++k)
+          traj_last[((size_t)which * batch + e) * out + k] = trajectories[e].empty() ? 0.0 : trajectories[e].back()[k];
+      }
+    }
+    snprintf(msg, msg_len, "ok");
+    return 0;
+  } catch (const std::exception &e) {
+    snprintf(msg, msg_len, "%s", e.what());
+    return 1000;
+  }
+}
+
+// Throughput of tds_hip::VectorizedEnv driven from C++ (no Python, no torch): environment steps per second of
+//   rates[0]  step(actions, observations, rewards, dones, config) — the reference's signature: actions up, records down
+//   rates[1]  the same with fetch_graphics_ = false (no y records down)
+//   rates[2]  step_many_device: K steps per call, per-step records into device rings, actions from a device pool
+//   rates[3]  rollouts_on_device (reset + K policy steps, the linear policies evaluated on the device)
+template <typename Sim, typename Env>
+static int vecenv_hip_bench(int batch, int steps, int reward_mode, double amp, double *rates, char *msg, int msg_len) {
+  typedef tds_hip::VectorizedEnv<Alg, Sim> HipEnv;
+  ARSConfig config;
+  config.batch_size = batch;
+  config.auto_reset_when_done = false;
+  try {
+    Env env(false);
+    HipEnv ve(env.contact_sim, batch, reward_mode);
+    const int adim = env.contact_sim.action_dim(), od = env.contact_sim.input_dim(), out = env.contact_sim.output_dim();
+    ve.seed(7);
+    auto observations = ve.reset(config);
+    std::vector<std::vector<double>> actions(batch, std::vector<double>(adim, 0.0));
+    std::srand(11);
+    for (int e = 0; e < batch; ++e)
+      for (int k = 0; k < adim; ++k) actions[e][k] = amp * ((std::rand() * 2.0 / RAND_MAX) - 1.0);
+    std::vector<double> rewards(batch);
+    std::vector<bool> dones(batch, false);
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (int mode = 0; mode < 2; ++mode) {
+      ve.fetch_graphics_ = mode == 0;
+      const int k_host = steps < 200 ? steps : 200;
+      for (int t = 0; t < 5; ++t) ve.step(actions, observations, rewards, dones, config);
+      const double t0 = now();
+      for (int t = 0; t < k_host; ++t) ve.step(actions, observations, rewards, dones, config);
+      rates[mode] = (double)batch * k_host / (now() - t0);
+    }
+    {
+      const int pool = 16, slots = 64;
+      std::vector<double> ap((size_t)pool * batch * adim);
+      for (double &v : ap) v = amp * ((std::rand() * 2.0 / RAND_MAX) - 1.0);
+      void *d_act = nullptr, *d_obs = nullptr, *d_y = nullptr;
+      const int per_line = 16, ystr = (out + per_line - 1) / per_line * per_line;
+      tds_hip_sim_t *h = ve.handle();
+      if (tds_hip_device_alloc(h, ap.size() * 8, &d_act) || tds_hip_device_alloc(h, (size_t)slots * batch * (od + 2) * 8, &d_obs) ||
+          tds_hip_device_alloc(h, (size_t)slots * batch * ystr * 8, &d_y) || tds_hip_device_upload(h, d_act, ap.data(), ap.size() * 8))
+        throw std::runtime_error(tds_hip_last_error());
+      tds_hip_rings_t r;
+      memset(&r, 0, sizeof(r));
+      r.obs_ring = d_obs;
+      r.obs_slots = slots;
+      r.y_ring = d_y;
+      r.y_slots = slots;
+      r.y_stride = ystr;
+      ve.step_many_device(d_act, pool, 0, steps, r, config);
+      tds_hip_sync(h);
+      const double t0 = now();
+      ve.step_many_device(d_act, pool, 0, steps, r, config);
+      tds_hip_sync(h);
+      rates[2] = (double)batch * steps / (now() - t0);
+      tds_hip_device_free(h, d_act);
+      tds_hip_device_free(h, d_obs);
+      tds_hip_device_free(h, d_y);
+    }
+    {
+      std::vector<double> tr;
+      std::vector<int> vs;
+      const int np = adim * od + adim;
+      for (int e = 0; e < batch; ++e) {
+        std::vector<double> w(np);
+        for (double &v : w) v = 0.05 * ((std::rand() * 2.0 / RAND_MAX) - 1.0);
+        ve.init_neural_network(e, w);
+      }
+      ve.rollouts_on_device(0.0, steps, tr, vs, config);
+      const double t0 = now();
+      ve.rollouts_on_device(0.0, steps, tr, vs, config);
+      rates[3] = (double)batch * steps / (now() - t0);
+    }
+    snprintf(msg, msg_len, "ok");
+    return 0;
+  } catch (const std::exception &e) {
+    snprintf(msg, msg_len, "%s", e.what());
+    return 1000;
+  }
+}
+}  // extern "C++"
+
+int tdsref_vecenv_hip_worker(const char *name, int batch, int steps, double shift, int seed, int auto_reset, const double *params,
+                             double *total_rewards, int *vec_steps, double *traj_last, int *traj_len, char *msg, int msg_len) {
+  const std::string n(name);
+  if (n == "ant")
+    return vecenv_hip_worker<AntContactSimulation2<Alg>, AntEnv2<Alg>>(batch, steps, shift, seed, auto_reset, TDS_REWARD_ANT, params,
+                                                                       total_rewards, vec_steps, traj_last, traj_len, msg, msg_len);
+  if (n == "laikago")
+    return vecenv_hip_worker<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, shift, seed, auto_reset, TDS_REWARD_LAIKAGO,
+                                                                             params, total_rewards, vec_steps, traj_last, traj_len,
+                                                                             msg, msg_len);
+  snprintf(msg, msg_len, "unknown env %s", name);
+  return -1;
+}
+int tdsref_vecenv_hip_bench(const char *name, int batch, int steps, double *rates, char *msg, int msg_len) {
+  const std::string n(name);
+  if (n == "ant")
+    return vecenv_hip_bench<AntContactSimulation2<Alg>, AntEnv2<Alg>>(batch, steps, TDS_REWARD_ANT, 0.4, rates, msg, msg_len);
+  if (n == "laikago")
+    return vecenv_hip_bench<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, TDS_REWARD_LAIKAGO, 0.1, rates, msg, msg_len);
+  snprintf(msg, msg_len, "unknown env %s", name);
   return -1;
 }
 

@@ -58,6 +58,10 @@ def lib():
                                                              C.c_char_p, C.c_int]
         if hasattr(L, "tdsref_vecenv_steps"):
             L.tdsref_vecenv_steps.argtypes = [C.c_char_p, C.c_int, C.c_int] + [C.c_void_p] * 6
+        if hasattr(L, "tdsref_vecenv_hip_worker"):
+            L.tdsref_vecenv_hip_worker.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int] + \
+                [C.c_void_p] * 5 + [C.c_char_p, C.c_int]
+            L.tdsref_vecenv_hip_bench.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
         if hasattr(L, "tdsref_f32_create"):
             L.tdsref_f32_create.restype = C.c_void_p
             L.tdsref_f32_create.argtypes = [C.c_char_p, C.c_char_p, C.c_double]
@@ -315,3 +319,34 @@ def rollout_ex(name, x0, params, steps, shift, output_dim):
         os.close(devnull)
     assert rc == 0, rc
     return tot, cnt, fin, stats, traj, tlen
+
+
+def vecenv_hip_worker(name, batch, steps, params, output_dim, shift=0.0, seed=12345, auto_reset=False):
+    """The reference's Worker<Env>::rollouts (ars_vectorized_worker.h:51-140, unmodified header) instantiated on the
+    reference's VectorizedEnvironment (CPU, serial stepper) AND on tds_hip::VectorizedEnv (environments resident on
+    the GPU, include/tds_hip_stepper.hpp), same seed / policies.  Returns a dict of [2, batch, ...] arrays: index 0
+    the reference, index 1 the HIP class."""
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    tr = np.zeros((2, batch))
+    vs = np.zeros((2, batch), dtype=np.int32)
+    last = np.zeros((2, batch, output_dim))
+    tl = np.zeros((2, batch), dtype=np.int32)
+    msg = C.create_string_buffer(512)
+    rc = lib().tdsref_vecenv_hip_worker(name.encode(), int(batch), int(steps), float(shift), int(seed), int(bool(auto_reset)),
+                                        params.ctypes.data, tr.ctypes.data, vs.ctypes.data, last.ctypes.data, tl.ctypes.data,
+                                        msg, 512)
+    if rc != 0:
+        raise RuntimeError(f"tdsref_vecenv_hip_worker: {rc} {msg.value.decode()}")
+    return {"total_rewards": tr, "vec_steps": vs, "traj_last": last, "traj_len": tl}
+
+
+def vecenv_hip_bench(name, batch, steps):
+    """env-steps/s of tds_hip::VectorizedEnv driven from C++: step() with / without the y records, step_many_device
+    (per-step records into device rings), rollouts_on_device"""
+    rates = np.zeros(4)
+    msg = C.create_string_buffer(512)
+    rc = lib().tdsref_vecenv_hip_bench(name.encode(), int(batch), int(steps), rates.ctypes.data, msg, 512)
+    if rc != 0:
+        raise RuntimeError(f"tdsref_vecenv_hip_bench: {rc} {msg.value.decode()}")
+    return {"step_host_vectors": rates[0], "step_host_vectors_no_graphics": rates[1], "step_many_device": rates[2],
+            "rollouts_on_device": rates[3]}

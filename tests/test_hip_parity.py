@@ -56,13 +56,12 @@ def test_no_step_reads_stale_lds(name, form, built, monkeypatch):
     reaches the result — even as 0 x slot — turns it into NaN: golden single steps and a 3-substep launch of the
     step-loop build must still match."""
     torch = _torch()
-    if form in ("w1", "w2"):
-        monkeypatch.setenv("TDS_HIP_W2", "0" if form == "w1" else "2")
+    opts = {"w2": 0 if form == "w1" else 2} if form in ("w1", "w2") else None  # (handle options, not the environment)
     m = tds_amd.load_model(name)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     x = g["x"]
     for dtype in ("f64", "mixed"):
-        sim = hip_backend.HipSim(m, x.shape[0], dtype=dtype)
+        sim = hip_backend.HipSim(m, x.shape[0], dtype=dtype, options=opts)
         xin = x.astype(np.float32).astype(np.float64) if dtype == "mixed" else x
         xt = torch.from_numpy(xin).to(sim.torch_dtype).cuda()
         if form != "loop":
@@ -111,11 +110,10 @@ def test_golden_single_steps_both_workgroup_forms(name, w2, built, monkeypatch):
     """The plain straight-line kernels exist as one-wavefront and as two-wavefront workgroups (main + helper wavefront;
     the library picks by grid size): both forms, forced, against the golden vectors — and against each other."""
     torch = _torch()
-    monkeypatch.setenv("TDS_HIP_W2", w2)
     m = tds_amd.load_model(name)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     n = g["x"].shape[0]
-    sim = hip_backend.HipSim(m, n, dtype="f64")
+    sim = hip_backend.HipSim(m, n, dtype="f64", options={"w2": int(w2)})
     y = sim.forward_zero(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
     assert rel_err(y, g["y"]) < TOL
     # closed loop with the obs record, 30 steps from the trajectory start
@@ -836,10 +834,8 @@ def test_reset_pool_equals_reset_inside_the_step(name, dtype, pool_params, built
     pool = hip_backend.HipSim(m, n, dtype=dtype)
     pool.set_auto_reset(True, seed)
     pool.x.copy_(torch.from_numpy(x0).to(tdt).cuda())
-    monkeypatch.setenv("TDS_HIP_AUTO_RESET_SPLIT", "0")
-    inl = hip_backend.HipSim(m, n, dtype=dtype)
+    inl = hip_backend.HipSim(m, n, dtype=dtype, options={"auto_reset_split": 0})  # reset + settle inside the step launch
     inl.set_auto_reset(True, seed)
-    monkeypatch.delenv("TDS_HIP_AUTO_RESET_SPLIT")
     op = torch.zeros((n, od + 2), dtype=tdt, device="cuda")
     oi = torch.zeros_like(op)
     # mixed (float records): in the pool every settle step is a step on a FLOAT record, the step-loop kernel keeps the
@@ -851,9 +847,7 @@ def test_reset_pool_equals_reset_inside_the_step(name, dtype, pool_params, built
         a = torch.from_numpy(rng.uniform(-0.4, 0.4, (n, adim))).to(tdt).cuda()
         inl.x.copy_(pool.x)            # per-step resync
         pool.step(a, 1, op)
-        monkeypatch.setenv("TDS_HIP_AUTO_RESET_SPLIT", "0")
         inl.step(a, 1, oi)
-        monkeypatch.delenv("TDS_HIP_AUTO_RESET_SPLIT")
         dp, di_ = op[:, od + 1].cpu().numpy() != 0, oi[:, od + 1].cpu().numpy() != 0
         assert np.array_equal(dp, di_), t
         n_done += dp
@@ -906,9 +900,9 @@ def test_step_many_with_auto_reset_equals_single_auto_reset_steps(form, dtype, b
         if form == "loop_short_lists" and call == 0:
             # refill work lists of 8 entries (read when the pool is set up, in the first call): every pass is cut short
             # and followed by more
-            monkeypatch.setenv("TDS_HIP_POOL_CAP", "8")
+            many.set_option("pool_cap", 8)
+            assert many.get_option("pool_cap") == 8 and one.get_option("pool_cap") is None
         many.step_many(acts, K, om, first_block=first)
-        monkeypatch.delenv("TDS_HIP_POOL_CAP", raising=False)
         for k in range(K):
             one.step(acts[(first + k) % B], 1, oo)
             n_done += oo[:, od + 1].cpu().numpy() != 0

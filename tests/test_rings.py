@@ -61,13 +61,21 @@ def _reward_done(m, name, q_before, y):
     return rew, done
 
 
-@pytest.mark.parametrize("name,n,steps,dtype", [("ant", 4096, 20, "f64"), ("pendulum5", 4096, 20, "f64"),
-                                                ("pendulum5", 4096, 20, "mixed"), ("laikago_soft", 8192, 50, "f64"),
-                                                ("ant", 8192, 20, "f64")])   # (config 5's per-GPU share: the one-wave loop build)
-def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtype, built):
+@pytest.mark.parametrize("name,n,steps,dtype,form", [
+    ("ant", 4096, 20, "f64", "default"), ("pendulum5", 4096, 20, "f64", "default"), ("pendulum5", 4096, 20, "mixed", "default"),
+    ("laikago_soft", 8192, 50, "f64", "default"),
+    ("ant", 8192, 20, "f64", "default"),       # config 5's per-GPU share: the one-wave loop build
+    # the builds a MULTI-GPU run launches (tds_hip_shard_step_many): a progress counter attached -> the one-wave loop
+    # build with write-through record stores; the same with the two-wavefront build kept (option exchange_w2); the obs
+    # ring laid out for two ranks (in-place all-gather: obs_slot_envs); y records on 128-byte lines (y_stride)
+    ("ant", 4096, 20, "f64", "exchange"), ("ant", 4096, 20, "f64", "exchange_w2"), ("ant", 4096, 20, "f64", "exchange_inplace"),
+    ("ant", 4096, 20, "f64", "padded"), ("laikago_soft", 8192, 20, "f64", "padded"),
+    ("ant", 4096, 20, "f64", "one_wave")])
+def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtype, form, built):
     """BASELINE configs 3 / 2 / 4 at full size through the launch form bench.py times: K steps per call with both
     rings on; EVERY slot of EVERY environment against the reference's own step started from the state the previous
-    slot holds (per-step resync costs nothing here: the y ring IS the trajectory)."""
+    slot holds (per-step resync costs nothing here: the y ring IS the trajectory).  `form` walks through every build of
+    the step-loop kernel a run can meet — selected per HANDLE (tds_hip_set_option), several of them in one process."""
     torch = _torch()
     from test_hip_parity import _reference_stepper
 
@@ -75,7 +83,8 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
     ref_step, what = _reference_stepper(name, n)
     rng = np.random.default_rng(77)
     nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
-    sim = hip_backend.HipSim(m, n, dtype=dtype)
+    opts = {"exchange_w2": 1} if form == "exchange_w2" else ({"loop_w2": 0} if form == "one_wave" else None)
+    sim = hip_backend.HipSim(m, n, dtype=dtype, options=opts)
     tdt = sim.torch_dtype
     x0 = _start_state(m, name, n, rng)
     sim.x.copy_(torch.from_numpy(x0).to(tdt).cuda())
@@ -84,15 +93,43 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
     amp = 0.4 if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 1.0
     act = rng.uniform(-amp, amp, (steps, n, adim))
     actions = torch.from_numpy(act).to(tdt).cuda().contiguous()
-    obs_ring = torch.full((steps, n, sim.obs_dim + 2), float("nan"), dtype=tdt, device="cuda")
-    y_ring = torch.full((steps, n, m.output_dim), float("nan"), dtype=tdt, device="cuda")
+    ow = sim.obs_dim + 2
+    ystr = m.output_dim if form != "padded" else -(-m.output_dim // 16) * 16
+    obs_envs = 2 * n if form == "exchange_inplace" else n  # (this "rank" owns the SECOND block of every slot)
+    obs_ring = torch.full((steps, obs_envs, ow), float("nan"), dtype=tdt, device="cuda")
+    y_ring = torch.full((steps, n, ystr), float("nan"), dtype=tdt, device="cuda")
     x_start = sim.x.cpu().numpy().astype(np.float64)
-    sim.step_many_rings(actions, steps, obs_ring, y_ring)
+    progress = torch.zeros(1, dtype=torch.int64, device="cuda") if form.startswith("exchange") else None
+    if form == "exchange_inplace":
+        r = sim._rings(None, y_ring, 0, 0, progress)
+        r.obs_ring, r.obs_slots, r.obs_first, r.obs_slot_envs = obs_ring[0, n:].data_ptr(), steps, 0, obs_envs
+        sim.step_many_rings_raw(actions, steps, r)
+    else:
+        sim.step_many_rings(actions, steps, obs_ring, y_ring, progress=progress)
     torch.cuda.synchronize()
-    yr = y_ring.cpu().numpy().astype(np.float64)
+    if progress is not None:  # every workgroup counts itself in once per step but the last
+        assert int(progress.item()) == (steps - 1) * sim.rings_blocks()
+    if form == "exchange_inplace":
+        assert torch.isnan(obs_ring[:, :n]).all()  # (the other rank's blocks are untouched)
+        obs_ring = obs_ring[:, n:]
+    yr = y_ring.cpu().numpy().astype(np.float64)[:, :, :m.output_dim]
+    if form == "padded":  # the padding is zero-filled: whole lines written
+        assert (y_ring[:, :, m.output_dim:] == 0).all()
     orr = obs_ring.cpu().numpy().astype(np.float64)
     assert np.isfinite(yr).all() and np.isfinite(orr).all()
-    assert torch.equal(sim.y, y_ring[-1])  # the handle's y record = the last step's
+    assert torch.equal(sim.y, y_ring[-1][:, :m.output_dim])  # the handle's y record = the last step's
+    # float records: the launch keeps the state in DOUBLE across its steps.  The reference is therefore restarted from
+    # the double state of a lock-step f64 handle (same double arithmetic, double records) — not from the float-rounded
+    # record of the previous slot — and every slot is held to the float contract with the ordinary floor.
+    yr_state = yr
+    if dtype == "mixed":
+        sim64 = hip_backend.HipSim(m, n, dtype="f64", options=opts)
+        sim64.x.copy_(torch.from_numpy(x_start).cuda())
+        y64 = torch.zeros((steps, n, m.output_dim), dtype=torch.float64, device="cuda")
+        sim64.step_many_rings(actions.double().contiguous(), steps, None, y64)
+        torch.cuda.synchronize()
+        yr_state = y64.cpu().numpy()
+        assert rel_err(yr, yr_state) < 2e-6  # (the float records ARE the rounded double trajectory)
     tol = TOL if dtype == "f64" else 2e-6  # (float records: the comparison sees the rounding of inputs and outputs)
     worst = 0.0
     x = x_start.copy()
@@ -101,10 +138,7 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
         x[:, nq + nd:nq + nd + adim] = a
         y_ref = ref_step(x)
         assert np.isfinite(y_ref).all()
-        # (float records: the launch keeps the state in DOUBLE across its steps while this comparison restarts the
-        #  reference from the float-rounded record of the previous slot — from the second slot on, components are held to
-        #  the float rounding of the state, 6e-8 of O(1) lever arms, not to 1e-6 of their own (possibly tiny) size)
-        floor = 1e-3 if (dtype == "f64" or k == 0) else 0.1
+        floor = 1e-3
         e = rel_err(yr[k], y_ref, floor=floor)
         worst = max(worst, e)
         assert e < tol, (name, k, e)
@@ -122,9 +156,9 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
                 edge = (np.abs(np.cos(y_ref[:, 3]) * np.cos(y_ref[:, 4]) - 0.6) < 1e-7) | (np.abs(y_ref[:, 2] - 0.2) < 1e-7)
             assert (orr[k][~edge, -1] == done[~edge]).all(), (name, k)
             assert rel_err(orr[k][~edge, -2], rew[~edge], floor=1.0) < 10 * tol, (name, k)
-        # resync on the device's own record (its state is what the next step started from)
-        x[:, :nq + nd] = yr[k][:, :nq + nd]
-    print(f"{name} x{n} [{dtype}], {steps} ring slots, every env, vs {what}: worst per-step rel err {worst:.3e} "
+        # resync on the device's own (double) state: what the next step started from
+        x[:, :nq + nd] = yr_state[k][:, :nq + nd]
+    print(f"{name} x{n} [{dtype}, {form}], {steps} ring slots, every env, vs {what}: worst per-step rel err {worst:.3e} "
           f"(loop form: {sim.step_many_is_loop(steps)})")
 
 

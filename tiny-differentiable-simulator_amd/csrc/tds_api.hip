@@ -29,8 +29,8 @@ namespace {
 // lanes per environment: the smallest wave-group that holds every link and every padded dof
 int default_lanes_per_env(int num_links, int dof) {
   const int need = num_links > tds_padded_dof(dof) ? num_links : tds_padded_dof(dof);
-  const char *env = getenv("TDS_HIP_LANES_PER_ENV");
-  int g = env ? atoi(env) : 0;
+  const long long g_opt = tds_opt_now(TDS_OPT_LANES_PER_ENV);
+  const int g = g_opt == TDS_OPT_UNSET ? 0 : (int)g_opt;
   // 64 lanes per environment is only instantiated for systems of <= 16 dof: the <G=64, NDP>=24>
   // build was miscompiled by hipcc 7.2 under its register pressure (caught by the golden tests),
   // and it is never the fast choice anyway.
@@ -83,6 +83,8 @@ int download(tds_hip_sim *s, double *dst, const void *src, size_t count) {
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 void pool_free(tds_hip_sim *s);  // (reset pool, defined with the rest of it below)
+void pool_reset(tds_hip_sim *s);  // ... and back to "no pool yet" (an option that shapes the pool has changed)
+void drop_graphs(tds_hip_sim *s);
 
 }  // namespace
 
@@ -103,23 +105,27 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   const int n_resident = (opts && opts->env_total > 0) ? opts->env_total : n;
   const int n_blocks = (n_resident + (64 / s->lanes) - 1) / (64 / s->lanes);
   // ... straight-line launches; and step-loop launches of plain steps (no policy, no reset, no reset pool): there the
-  // helper wavefront loops along and is also the RECORDER of per-step rings (TDS_HIP_LOOP_W2=0: the one-wave loop build)
-  static const bool loop_w2 = [] { const char *e = getenv("TDS_HIP_LOOP_W2"); return !(e && e[0] == '0'); }();
+  // helper wavefront loops along and is also the RECORDER of per-step rings (option loop_w2 = 0: the one-wave loop build)
+  const bool loop_w2 = s->opt.get(TDS_OPT_LOOP_W2, 1) != 0;
   const bool w2_fits = s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && reset_mode == TDS_RESET_NONE && !ro &&
                        !(opts && opts->lds);
   const bool is_loop_launch = nsub > 1 || (opts && opts->rings);
-  // (TDS_HIP_LOOP_W2=2: not for launches that take reset states from the pool)
-  static const bool loop_w2_pool = [] { const char *e = getenv("TDS_HIP_LOOP_W2"); return !(e && e[0] == '2'); }();
+  // (loop_w2 = 2: not for launches that take reset states from the pool)
+  const bool loop_w2_pool = s->opt.get(TDS_OPT_LOOP_W2, 1) != 2;
   // (a launch whose ring slots are exchanged while it runs — rings->progress — stays with the ONE-wave loop build: two
   //  wavefronts of 256 registers per SIMD leave no register for anybody else, and the exchange's kernels — the one-lane
   //  wait, RCCL's all-gather — would not get onto a compute unit before the launch ends; the one-wave build holds 296 of a
   //  SIMD's 512.  Measured, profiles/r03_ring_exchange_forms.txt: the first wait of a 64-step launch returned after 86 %
   //  of it.)
-  const bool exchanged = opts && opts->rings && opts->rings->progress;
+  //  Option exchange_w2 = 1 keeps the two-wavefront build under the exchange all the same — right when the exchange needs
+  //  no compute unit while the launch runs (tests pin THIS build on the reference too).
+  const bool exchanged = opts && opts->rings && opts->rings->progress && !s->opt.flag(TDS_OPT_EXCHANGE_W2);
   const bool two_waves = w2_fits && (is_loop_launch ? (loop_w2 && !exchanged && (loop_w2_pool || !(opts && opts->extra)) &&
                                                        s->lds_w2.NDP <= 16)
                                                     : !(opts && opts->rings));
   const TdsLds &lds = (opts && opts->lds) ? *opts->lds : (two_waves ? s->lds_w2 : s->lds);
+  const long long occ = s->opt.get(TDS_OPT_LOOP_OCC, 0);
+  const int form = (two_waves ? TDS_FORM_W2 : 0) | (occ == 1 ? TDS_FORM_LOOP_OCC1 : (occ == 2 ? TDS_FORM_LOOP_OCC2 : 0));
   void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
   if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along
     const size_t e0 = (size_t)opts->env_first, el = s->elem;
@@ -127,7 +133,7 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
       return p ? (void *)((const char *)p + e0 * per_env * bytes) : nullptr;
     };
     x = at(x, s->model.input_dim, el);
-    y = at(y, s->model.output_dim, el);
+    y = at(y, (opts->y_stride > 0 ? opts->y_stride : s->model.output_dim), el);
     actions = at(actions, s->model.action_dim, el);
     fb = at(fb, s->model.input_dim, el);
     obs = at(obs, s->obs_width(), el);
@@ -154,23 +160,26 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
       const size_t ob = r.obs_f32 ? 4 : s->elem;
       ctl.obs_ring = (char *)r.obs_ring + e0 * s->obs_width() * ob;
       ctl.obs_slots = r.obs_slots;
+      ctl.obs_envs = r.obs_slot_envs > 0 ? r.obs_slot_envs : s->num_envs;
       ctl.obs_first = (r.obs_first + opts->ring_step0) % r.obs_slots;
       if (r.obs_f32) ctl.ring_flags |= TDS_RING_OBS_F32;
       // (how a step's records are made visible to the exchange before its progress count: write-through stores + a
       //  plain wait, or streaming stores + a release fence — TDS_HIP_RING_NOFENCE=0 / 1)
       // Default: write-through.  The release fence's buffer_wbl2 writes back every dirty line of the L2 on every step of
       // every workgroup: + 9 us per 4096-environment step (profiles/r03_ring_exchange_forms.txt).
-      static const bool nofence = [] { const char *e = getenv("TDS_HIP_RING_NOFENCE"); return e ? e[0] == '1' : true; }();
+      const bool nofence = s->opt.get(TDS_OPT_RING_NOFENCE, 1) == 1;
       if (r.progress && nofence) ctl.ring_flags |= TDS_RING_NOFENCE;
     }
     if (r.y_ring) {
-      ctl.y_ring = (char *)r.y_ring + e0 * s->model.output_dim * s->elem;
+      ctl.y_stride = r.y_stride > 0 ? r.y_stride : s->model.output_dim;
+      ctl.y_ring = (char *)r.y_ring + e0 * ctl.y_stride * s->elem;
       ctl.y_slots = r.y_slots;
       ctl.y_first = (r.y_first + opts->ring_step0) % r.y_slots;
     }
     ctl.ring_envs = s->num_envs;
     ctl.progress = r.progress;
   }
+  if (opts && !opts->rings && opts->y_stride > 0) ctl.y_stride = opts->y_stride;
   ctl.flags |= ctl_flags;
   ctl.nsub = nsub;
   ctl.reset_mode = reset_mode;
@@ -182,15 +191,15 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                          (const double *)x, (double *)y, (const double *)actions, (double *)fb,
-                                         (double *)obs, (double *)ovf, n, stream, ctl, nullptr, two_waves);
+                                         (double *)obs, (double *)ovf, n, stream, ctl, nullptr, form);
   else if (s->dtype == TDS_DTYPE_F64_REC32)
     rc = tds_launch_step<double, float>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                         (const float *)x, (float *)y, (const float *)actions, (float *)fb, (float *)obs,
-                                        (double *)ovf, n, stream, ctl, nullptr, two_waves);
+                                        (double *)ovf, n, stream, ctl, nullptr, form);
   else
     rc = tds_launch_step<float, float>((const DevModel<float> *)s->d_model, s->h32, lds, s->lanes, (const float *)x,
                                        (float *)y, (const float *)actions, (float *)fb, (float *)obs,
-                                       (float *)ovf, n, stream, ctl, nullptr, two_waves);
+                                       (float *)ovf, n, stream, ctl, nullptr, form);
   if (rc != 0) {
     snprintf(g_err, sizeof(g_err), "kernel launch failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "bad lanes_per_env");
     return TDS_ERR_HIP;
@@ -210,6 +219,46 @@ int tds_hip_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+int tds_hip_default_option(const char *key, long long value) {
+  const int k = tds_opt_find(key);
+  if (k < 0) return fail(TDS_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
+  tds_opt_overrides().v[k] = value;
+  return TDS_OK;
+}
+int tds_hip_set_option(tds_hip_sim_t *s, const char *key, long long value) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  const int k = tds_opt_find(key);
+  if (k < 0) return fail(TDS_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
+  if (tds_opt_rows()[k].create_time)
+    return fail(TDS_ERR_INVALID_ARG, "option '%s' is fixed when a handle is created: tds_hip_default_option before tds_hip_create", key);
+  if (s->opt.v[k] == value) return TDS_OK;
+  // (cached graphs / a pool laid out for the old value must not outlive it)
+  if (k == TDS_OPT_GRAPH_CHAINS || k == TDS_OPT_STEP_MANY_LOOP || k == TDS_OPT_LOOP_W2 || k == TDS_OPT_LOOP_OCC ||
+      k == TDS_OPT_NO_GRAPH_UPLOAD) {
+    DeviceGuard guard(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    drop_graphs(s);
+  }
+  if (k == TDS_OPT_POOL_EVERY || k == TDS_OPT_POOL_HOST_LAG || k == TDS_OPT_POOL_LAG || k == TDS_OPT_POOL_CHUNK ||
+      k == TDS_OPT_POOL_CAP || k == TDS_OPT_POOL_SLAB) {
+    DeviceGuard guard(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    pool_reset(s);
+  }
+  s->opt.v[k] = value;
+  return TDS_OK;
+}
+int tds_hip_get_option(const tds_hip_sim_t *s, const char *key, long long *value, int *is_set) {
+  if (!s || !value) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  const int k = tds_opt_find(key);
+  if (k < 0) return fail(TDS_ERR_INVALID_ARG, "unknown option '%s'", key ? key : "(null)");
+  *value = s->opt.v[k] == TDS_OPT_UNSET ? 0 : s->opt.v[k];
+  if (is_set) *is_set = s->opt.v[k] != TDS_OPT_UNSET;
+  return TDS_OK;
+}
+int tds_hip_option_count(void) { return TDS_OPT_COUNT; }
+const char *tds_hip_option_name(int index) { return (index >= 0 && index < TDS_OPT_COUNT) ? tds_opt_rows()[index].key : nullptr; }
 
 int tds_hip_model_check(const tds_model_t *model) {
   if (!model) return fail(TDS_ERR_INVALID_ARG, "model is NULL");
@@ -237,6 +286,7 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   DeviceGuard guard(device);  // (the caller's current device is restored on return)
   tds_hip_sim *s = new (std::nothrow) tds_hip_sim();  // value-initialised: both host models start zeroed
   if (!s) return fail(TDS_ERR_INVALID_ARG, "out of host memory");
+  s->opt = tds_opt_snapshot();  // (override > environment > library default; the environment is not read again)
   s->model = *model;
   s->num_envs = num_envs;
   s->device = device;
@@ -269,8 +319,8 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   // i.e. two wavefronts per SIMD, which hides most of the instruction-stream latency once the batch
   // provides them (Ant f64: 6 -> 19.8 KiB per workgroup).  TDS_HIP_NA_CAP overrides.
   int na_cap = 8;
-  if (const char *e = getenv("TDS_HIP_NA_CAP")) {
-    na_cap = atoi(e);
+  if (s->opt.is_set(TDS_OPT_NA_CAP)) {
+    na_cap = (int)s->opt.v[TDS_OPT_NA_CAP];
   } else {
     const size_t budget = (160 * 1024) / 8;
     for (int cap = 8; cap >= 5; --cap)
@@ -284,12 +334,14 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     // two-wavefront workgroups: plain kernels up to 18 padded dof; same row cap (the scratch slab is shared)
     const bool is_fl = c64 ? s->h64.is_floating : s->h32.is_floating;
     const bool is_sph = c64 ? s->h64.num_spherical != 0 : s->h32.num_spherical != 0;
-    const char *e = getenv("TDS_HIP_W2");
+    // (option w2: 0 never, 2 at any grid size, any other value: also for worlds without contact points)
+    const bool w2_set = s->opt.is_set(TDS_OPT_W2);
+    const long long w2_opt = s->opt.get(TDS_OPT_W2, 1);
     const bool is_two_w = c64 ? s->h64.num_bodies >= 2 : s->h32.num_bodies >= 2;
     // (a world without contact points leaves the helper wavefront only the visual poses: the one-wave form is then the
     //  faster one — pendulum5 x 4096: 10.2 vs 10.9 us — unless TDS_HIP_W2=1/2 insists)
     const bool has_cp = model->has_plane && (c64 ? s->h64.num_cp : s->h32.num_cp) > 0;
-    if (!is_fl && !is_sph && !is_two_w && s->lds.NDP < 24 && !(e && e[0] == '0') && (has_cp || (e && e[0] != '0'))) {
+    if (!is_fl && !is_sph && !is_two_w && s->lds.NDP < 24 && w2_opt != 0 && (has_cp || w2_set)) {
       s->lds_w2 = c64 ? tds_make_lds_layout<double>(s->h64, na_cap, s->lanes, true)
                       : tds_make_lds_layout<float>(s->h32, na_cap, s->lanes, true);
       const size_t b2 = (size_t)s->lds_w2.stride * epw * celem;
@@ -297,7 +349,7 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
       // 256 CUs; two wavefronts per workgroup, four SIMDs per CU: the form pays while every wavefront is resident
       // with at most two per SIMD, i.e. up to four workgroups per CU
       const int wg_per_cu = per_cu < 4 ? per_cu : 4;
-      if (b2 <= 64 * 1024 && wg_per_cu >= 1) s->w2_max_blocks = (e && e[0] == '2') ? (1 << 30) : wg_per_cu * 256;
+      if (b2 <= 64 * 1024 && wg_per_cu >= 1) s->w2_max_blocks = w2_opt == 2 ? (1 << 30) : wg_per_cu * 256;
     }
   }
   const int lds_bytes = (int)((size_t)s->lds.stride * epw * celem);
@@ -376,6 +428,9 @@ int tds_hip_destroy(tds_hip_sim_t *s) {
   if (s->d_split) (void)hipFree(s->d_split);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->h_stage) (void)hipHostFree(s->h_stage);
+  if (s->d_stage_act) (void)hipFree(s->d_stage_act);
+  if (s->d_stage_obs) (void)hipFree(s->d_stage_obs);
   delete s;
   return TDS_OK;
 }
@@ -530,26 +585,25 @@ __global__ void tds_pool_scatter_kernel(const int *__restrict__ items, int n_ite
   pool[((size_t)slot * n + e) * w + i] = stage[(size_t)it * in_dim + i];
 }
 
-int pool_param(const char *name, int dflt) {
-  const char *e = getenv(name);
-  const int v = e ? atoi(e) : 0;
+int pool_param(const tds_hip_sim *s, int key, int dflt) {
+  const int v = (int)s->opt.get(key, 0);
   return v > 0 ? v : dflt;
 }
 
 // ring depth D by form: single steps D >= R + W (+ slack); pool_step_many D >= 2 x chunk (+ slack)
 void pool_params(tds_hip_sim *s) {
   if (s->pool_every > 0) return;
-  s->pool_every = pool_param("TDS_HIP_POOL_EVERY", 16);                     // R
-  s->pool_host_lag = pool_param("TDS_HIP_POOL_HOST_LAG", s->pool_every / 2);  // H
+  s->pool_every = pool_param(s, TDS_OPT_POOL_EVERY, 16);                     // R
+  s->pool_host_lag = pool_param(s, TDS_OPT_POOL_HOST_LAG, s->pool_every / 2);  // H
   if (s->pool_host_lag >= s->pool_every) s->pool_host_lag = s->pool_every - 1;
   if (s->pool_host_lag < 1) s->pool_host_lag = 1;
   const int settle = s->model.settle_steps > 0 ? s->model.settle_steps : 0;
-  s->pool_lag = pool_param("TDS_HIP_POOL_LAG", s->pool_host_lag + settle + 6);  // W
+  s->pool_lag = pool_param(s, TDS_OPT_POOL_LAG, s->pool_host_lag + settle + 6);  // W
   // (W > H: before step t the step stream waits for the event of pass floor((t - 1 - W) / R), which the host records at
   //  most H steps after planning that pass — with W <= H it would wait on an event this pass has not recorded yet, i.e.
   //  not at all, and a done environment could copy a ring slot that has not been refilled)
   if (s->pool_lag < s->pool_host_lag + 1) s->pool_lag = s->pool_host_lag + 1;
-  s->pool_chunk = pool_param("TDS_HIP_POOL_CHUNK", 128);                      // steps per launch of pool_step_many
+  s->pool_chunk = pool_param(s, TDS_OPT_POOL_CHUNK, 128);                      // steps per launch of pool_step_many
 }
 int pool_depth_for(const tds_hip_sim *s, bool many) {
   return many ? 2 * s->pool_chunk + 4 : s->pool_every + s->pool_lag + 4;
@@ -574,7 +628,7 @@ int pool_alloc(tds_hip_sim *s) {
   if (s->d_pool_filled) return TDS_OK;
   // work list of a pass: what R + 4 single steps can consume; pool_step_many, whose two launches could consume more,
   // carries on with further passes when a list was cut short (more than 24 resets per environment on average)
-  s->pool_cap = pool_param("TDS_HIP_POOL_CAP", (int)(n * (size_t)(s->pool_every + 4 > 24 ? s->pool_every + 4 : 24)));
+  s->pool_cap = pool_param(s, TDS_OPT_POOL_CAP, (int)(n * (size_t)(s->pool_every + 4 > 24 ? s->pool_every + 4 : 24)));
   TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_filled, n * sizeof(unsigned)));
   TDS_HIP_TRY(hipMalloc((void **)&s->d_pool_items, (1 + 3 * (size_t)s->pool_cap) * sizeof(int)));
   TDS_HIP_TRY(hipHostMalloc((void **)&s->h_pool_nitems, sizeof(int), 0));
@@ -595,9 +649,8 @@ int pool_alloc(tds_hip_sim *s) {
   // (37.7 KB, one wavefront per SIMD).  Ant x 8192 at 5 % resets per step: single steps 2.21e8 -> 2.73e8, step_many
   // 2.74e8 -> 3.01e8; x 4096 unchanged (the refill fits beside the steps either way).
   {
-    const char *ps = getenv("TDS_HIP_POOL_SLAB");
     const size_t per_env = (size_t)s->lds.ovrows * (s->lds.NDs + 3) * (s->compute_f64() ? 8 : 4);
-    if (!(ps && ps[0] == '0') && per_env > 0 && per_env * (size_t)s->pool_cap <= ((size_t)4 << 30)) {
+    if (s->opt.get(TDS_OPT_POOL_SLAB, 1) != 0 && per_env > 0 && per_env * (size_t)s->pool_cap <= ((size_t)4 << 30)) {
       TDS_HIP_TRY(hipMalloc(&s->d_pool_ovf, per_env * (size_t)s->pool_cap));
       s->pool_lds = s->lds;
     }
@@ -665,8 +718,7 @@ int pool_run(tds_hip_sim *s, hipEvent_t done) {
     o.ovf = s->d_pool_ovf;
     // straight-line step kernel on the staging records: zero action, state fed back in place, no y / obs record
     // (TDS_HIP_POOL_SETTLE_LOOP=1: the settle steps as ONE launch of the step-loop build — measured, no gain)
-    const char *sl = getenv("TDS_HIP_POOL_SETTLE_LOOP");
-    const bool one_launch = s->model.settle_steps > 1 && sl && sl[0] == '1';
+    const bool one_launch = s->model.settle_steps > 1 && s->opt.get(TDS_OPT_POOL_SETTLE_LOOP, 0) == 1;
     for (int k = 0; k < (one_launch ? 1 : s->model.settle_steps); ++k) {
       const int rc = launch(s, s->d_stage_x, nullptr, nullptr, s->d_stage_x, nullptr, n_items,
                             one_launch ? s->model.settle_steps : 1, TDS_RESET_NONE, nullptr, nullptr, 0, &o);
@@ -720,7 +772,7 @@ int pool_fill(tds_hip_sim *s) {
 }
 
 // one auto-reset step through the pool
-int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev, void *y_dev = nullptr) {
+int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev, void *y_dev = nullptr, int y_stride = 0) {
   int rc;
   if (s->pool_many) {  // (the step_many form keeps its own pass schedule: start again from full rings)
     s->pool_many = false;
@@ -756,6 +808,7 @@ int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev, void *y_de
   extra.pool_envs = s->num_envs;
   LaunchOpts o;
   o.extra = &extra;
+  o.y_stride = y_dev ? y_stride : 0;
   rc = launch(s, s->d_x, y_dev ? y_dev : s->d_y, actions_dev, s->d_x, obs_dev ? obs_dev : s->d_split, s->num_envs, 1,
               TDS_RESET_NONE, nullptr, nullptr, 0, &o);
   if (rc != TDS_OK) return rc;
@@ -860,6 +913,21 @@ void pool_free(tds_hip_sim *s) {
   if (s->pool_sync_ev) (void)hipEventDestroy(s->pool_sync_ev);
   if (s->pool_stream) (void)hipStreamDestroy(s->pool_stream);
 }
+void pool_reset(tds_hip_sim *s) {
+  pool_free(s);
+  s->d_pool = s->d_stage_x = s->d_pool_ovf = nullptr;
+  s->d_pool_filled = nullptr;
+  s->d_pool_items = nullptr;
+  s->h_pool_nitems = nullptr;
+  for (int i = 0; i < tds_hip_sim::kPoolEvents; ++i) s->pool_ev[i] = nullptr;
+  s->pool_step_ev = s->pool_plan_ev = s->pool_sync_ev = nullptr;
+  s->pool_stream = nullptr;
+  s->pool_depth = s->pool_every = s->pool_lag = s->pool_host_lag = s->pool_cap = s->pool_chunk = 0;
+  s->pool_step = s->pool_waited = s->pool_planned = s->pool_planned_at = s->pool_many_chunks = 0;
+  s->pool_many = false;
+  s->pool_ready = false;
+  s->pool_discard = true;
+}
 
 }  // namespace
 }  // extern "C++"
@@ -884,10 +952,10 @@ int step_obs_impl(tds_hip_sim *s, const void *actions_dev, int substeps, void *o
   // followed by a forced-reset launch masked with the done flags; =2 / unset: pool.  All three draw the same stream
   // of random numbers (seed, environment, reset counter) and are held to the same host emulation by the tests.
   if (s->auto_reset && substeps == 1) {
-    const char *e = getenv("TDS_HIP_AUTO_RESET_SPLIT");
-    if (!e || e[0] == '2') return pool_step(s, actions_dev, obs_dev);
+    const long long split = s->opt.get(TDS_OPT_AUTO_RESET_SPLIT, 2);
+    if (split == 2) return pool_step(s, actions_dev, obs_dev);
     s->pool_ready = false;  // (entries are consumed behind the pool's back)
-    if (e[0] == '1') {
+    if (split == 1) {
       const int n = s->num_envs, w = s->obs_width();
       const size_t b_rec = align256((size_t)n * w * s->elem);
       void *rec = obs_dev ? obs_dev : s->d_split;
@@ -938,6 +1006,10 @@ int graph_matches(const tds_hip_sim *s, const void *actions, int pool, int first
 void *ring_slot(const tds_hip_sim *s, void *ring, int slots, int first, int k, size_t scalars_per_env) {
   return ring ? (char *)ring + (size_t)((first + k) % slots) * s->num_envs * scalars_per_env * s->elem : nullptr;
 }
+// scalars between consecutive records of a y ring (tds_hip_rings_t::y_stride; 0: packed)
+size_t y_width(const tds_hip_sim *s, const tds_hip_rings_t *r) {
+  return (r && r->y_stride > 0) ? (size_t)r->y_stride : (size_t)s->model.output_dim;
+}
 // The environments are independent and a step_many call holds K steps of each: enqueue them as C chains (contiguous
 // environment ranges, one stream / graph branch each) instead of K whole-batch launches.  A chain's kernel boundary
 // (launch latency ~1.1 us, workgroup dispatch ramp ~1.4 us, the wait for its slowest workgroup ~1 us: a sixth of a
@@ -947,7 +1019,7 @@ int chain_count(const tds_hip_sim *s, int n_steps) {
   // default: two chains for models with contact points (Ant x 2048 ... 16384: +4 ... +24 %, laikago_soft x 8192 +22 %;
   // a kernel as short as pendulum5's 11 us loses 15 %: profiles/r02d_graph_chains.txt); four and more chains collapse
   int c = s->chains_wanted > 0 ? s->chains_wanted : (s->model.num_geoms > 0 && s->model.has_plane ? 2 : 1);
-  if (const char *ce = getenv("TDS_HIP_GRAPH_CHAINS")) c = atoi(ce);
+  if (s->opt.is_set(TDS_OPT_GRAPH_CHAINS)) c = (int)s->opt.v[TDS_OPT_GRAPH_CHAINS];
   if (c > tds_hip_sim::kMaxChains) c = tds_hip_sim::kMaxChains;
   if (c > n_blocks) c = n_blocks;
   if (c < 1 || n_steps < 2) c = 1;
@@ -978,7 +1050,8 @@ int enqueue_chain(tds_hip_sim *s, int c, int C, hipStream_t stream, const void *
     const void *a = actions ? (const char *)actions + (size_t)((first + k) % pool) * blk : nullptr;
     // (record rings: every launch is pointed at the slots of its step)
     void *const ob = (rings && rings->obs_ring) ? ring_slot(s, rings->obs_ring, rings->obs_slots, rings->obs_first, k, s->obs_width()) : obs;
-    void *const yk = (rings && rings->y_ring) ? ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, k, s->model.output_dim) : s->d_y;
+    void *const yk = (rings && rings->y_ring) ? ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, k, y_width(s, rings)) : s->d_y;
+    lo.y_stride = (rings && rings->y_ring && rings->y_stride > 0) ? rings->y_stride : 0;
     const int rc = launch(s, s->d_x, yk, a, s->d_x, ob, e1 - e0, 1, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
     if (rc != TDS_OK) return rc;
   }
@@ -1015,7 +1088,7 @@ int build_graph(tds_hip_sim *s, const void *actions, int pool, int first, int n_
     if (graph) (void)hipGraphDestroy(graph);
     // (device-side copy of the executable graph made now, not by the first launch: a short replay — the 20-step runs of
     //  a benchmark driver — otherwise pays it inside its timed region)
-    if (e == hipSuccess && rc == TDS_OK && s->graph_exec[c] && getenv("TDS_HIP_NO_GRAPH_UPLOAD") == nullptr)
+    if (e == hipSuccess && rc == TDS_OK && s->graph_exec[c] && !s->opt.flag(TDS_OPT_NO_GRAPH_UPLOAD))
       (void)hipGraphUpload(s->graph_exec[c], s->graph_stream);
     if (e != hipSuccess || rc != TDS_OK || !s->graph_exec[c]) {
       if (rc == TDS_OK) snprintf(g_err, sizeof(g_err), "graph capture / instantiation failed: %s", hipGetErrorString(e));
@@ -1043,7 +1116,7 @@ namespace {
 // batch is at most three rounds of workgroups (see below).  TDS_HIP_STEP_MANY_LOOP=0 / 1 forbids / forces it.
 bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
   if (n_steps < 2) return false;
-  if (const char *e = getenv("TDS_HIP_STEP_MANY_LOOP")) return e[0] == '1';
+  if (s->opt.is_set(TDS_OPT_STEP_MANY_LOOP)) return s->opt.v[TDS_OPT_STEP_MANY_LOOP] == 1;
   const int ncp = s->compute_f64() ? s->h64.num_cp : s->h32.num_cp;
   const bool two = s->compute_f64() ? s->h64.num_bodies >= 2 : s->h32.num_bodies >= 2;
   if (!(s->model.has_plane && ncp > 0) && !two) return true;
@@ -1068,7 +1141,15 @@ int rings_check(const tds_hip_sim *s, const tds_hip_rings_t *r, int n_steps) {
   if (!r) return TDS_OK;
   if (r->obs_ring && (r->obs_slots < 1 || r->obs_first < 0)) return fail(TDS_ERR_INVALID_ARG, "record rings: obs_slots must be >= 1, obs_first >= 0");
   if (r->y_ring && (r->y_slots < 1 || r->y_first < 0)) return fail(TDS_ERR_INVALID_ARG, "record rings: y_slots must be >= 1, y_first >= 0");
+  if (r->y_stride != 0 && r->y_stride < s->model.output_dim)
+    return fail(TDS_ERR_INVALID_ARG, "record rings: y_stride must be 0 (packed) or >= output_dim");
+  // (a call with auto-reset on is cut into several launches, none of which signals its last step: the counter would fall
+  //  one workgroup count behind per launch)
+  if (r->progress && s->auto_reset)
+    return fail(TDS_ERR_INVALID_ARG, "record rings: a progress counter cannot be combined with auto-reset");
   const bool loop = step_many_as_loop(s, n_steps) || (n_steps == 1 && step_many_as_loop(s, 2));
+  if (r->obs_slot_envs != 0 && (r->obs_slot_envs < s->num_envs || !loop))
+    return fail(TDS_ERR_INVALID_ARG, "record rings: obs_slot_envs must be 0 or >= num_envs, step-loop form only");
   if (r->progress && !loop) return fail(TDS_ERR_INVALID_ARG, "record rings: a progress counter needs the step-loop form (tds_hip_step_many_is_loop)");
   if (r->obs_f32 && s->elem == 8 && !loop)
     return fail(TDS_ERR_INVALID_ARG, "record rings: a float obs ring beside f64 records needs the step-loop form (tds_hip_step_many_is_loop)");
@@ -1094,8 +1175,7 @@ int step_many_prepare_impl(tds_hip_sim_t *s, const void *actions_dev, int action
 
 int step_many_impl(tds_hip_sim_t *s, const void *actions_dev, int action_blocks, int first_block, int n_steps,
                    void *obs_dev, const tds_hip_rings_t *rings) {
-  const char *em = getenv("TDS_HIP_STEP_MANY_EAGER");  // (diagnostic: the same chains as plain stream launches)
-  const bool eager = em && em[0] == '1';
+  const bool eager = s && s->opt.get(TDS_OPT_STEP_MANY_EAGER, 0) == 1;  // (diagnostic: the same chains as plain stream launches)
   if (!eager) {
     int rc = step_many_prepare_impl(s, actions_dev, action_blocks, first_block, n_steps, obs_dev, rings);
     if (rc != TDS_OK) return rc;
@@ -1109,9 +1189,11 @@ int step_many_impl(tds_hip_sim_t *s, const void *actions_dev, int action_blocks,
   const bool as_loop = !eager && (step_many_as_loop(s, n_steps) || (rings && n_steps == 1 && step_many_as_loop(s, 2)));
   // the handle's y record holds the last step's record afterwards, rings or not
   auto y_back = [&]() -> int {
-    if (rings && rings->y_ring)
-      HIP_TRY(hipMemcpyAsync(s->d_y, ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, n_steps - 1, s->model.output_dim),
-                             (size_t)s->num_envs * s->model.output_dim * s->elem, hipMemcpyDeviceToDevice, s->stream));
+    if (rings && rings->y_ring) {
+      const size_t row = (size_t)s->model.output_dim * s->elem;
+      HIP_TRY(hipMemcpy2DAsync(s->d_y, row, ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, n_steps - 1, y_width(s, rings)),
+                               y_width(s, rings) * s->elem, row, (size_t)s->num_envs, hipMemcpyDeviceToDevice, s->stream));
+    }
     return TDS_OK;
   };
   if (s->auto_reset) {
@@ -1123,8 +1205,8 @@ int step_many_impl(tds_hip_sim_t *s, const void *actions_dev, int action_blocks,
     for (int k = 0; k < n_steps; ++k) {
       const void *a = actions_dev ? (const char *)actions_dev + (size_t)((first + k) % pool) * blk : nullptr;
       void *const ob = (rings && rings->obs_ring) ? ring_slot(s, rings->obs_ring, rings->obs_slots, rings->obs_first, k, s->obs_width()) : obs_dev;
-      void *const yk = (rings && rings->y_ring) ? ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, k, s->model.output_dim) : nullptr;
-      const int rc = pool_step(s, a, ob, yk);
+      void *const yk = (rings && rings->y_ring) ? ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, k, y_width(s, rings)) : nullptr;
+      const int rc = pool_step(s, a, ob, yk, (rings && rings->y_ring && rings->y_stride > 0) ? rings->y_stride : 0);
       if (rc != TDS_OK) return rc;
     }
     return y_back();
@@ -1275,6 +1357,129 @@ int tds_hip_reset(tds_hip_sim_t *s, const unsigned char *mask_dev, void *obs_dev
 
 int tds_hip_step(tds_hip_sim_t *s, const void *actions_dev, int substeps) {
   return tds_hip_step_obs(s, actions_dev, substeps, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Host-vector entry points for a plain C / C++ caller without HIP headers (include/tds_hip_stepper.hpp:
+// tds_hip::VectorizedEnv): the STATE stays resident on the device; per call only the actions travel up and the
+// [obs | reward | done] records (and, if asked for, the y records) travel down, through pinned staging memory.
+// ------------------------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+int stage_alloc(tds_hip_sim *s) {
+  if (s->h_stage) return TDS_OK;
+  const size_t n = (size_t)s->num_envs;
+  const size_t b_act = align256(n * s->model.action_dim * s->elem), b_obs = align256(n * s->obs_width() * s->elem),
+               b_y = align256(n * s->model.output_dim * s->elem);
+  HIP_TRY(hipHostMalloc(&s->h_stage, b_act + b_obs + b_y, hipHostMallocDefault));
+  s->h_stage_bytes = b_act + b_obs + b_y;
+  HIP_TRY(hipMalloc(&s->d_stage_act, b_act));
+  HIP_TRY(hipMalloc(&s->d_stage_obs, b_obs));
+  HIP_TRY(hipMemset(s->d_stage_obs, 0, b_obs));
+  return TDS_OK;
+}
+// records of the record dtype in pinned memory -> host doubles
+void widen(const tds_hip_sim *s, const void *src, double *dst, size_t count) {
+  if (s->records_f64()) memcpy(dst, src, count * 8);
+  else for (size_t i = 0; i < count; ++i) dst[i] = (double)((const float *)src)[i];
+}
+}  // namespace
+}  // extern "C++"
+
+int tds_hip_step_host(tds_hip_sim_t *s, const double *actions_host, int substeps, double *obs_host, double *y_host) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  if (substeps < 1) return fail(TDS_ERR_INVALID_ARG, "substeps must be >= 1");
+  DeviceGuard guard(s->device);
+  int rc = stage_alloc(s);
+  if (rc != TDS_OK) return rc;
+  const size_t n = (size_t)s->num_envs, na = n * s->model.action_dim, no = n * s->obs_width(), ny = n * s->model.output_dim;
+  const size_t b_act = align256(na * s->elem), b_obs = align256(no * s->elem);
+  char *const h_act = (char *)s->h_stage, *const h_obs = h_act + b_act, *const h_y = h_obs + b_obs;
+  if (actions_host) {
+    if (s->records_f64()) memcpy(h_act, actions_host, na * 8);
+    else for (size_t i = 0; i < na; ++i) ((float *)h_act)[i] = (float)actions_host[i];
+    HIP_TRY(hipMemcpyAsync(s->d_stage_act, h_act, na * s->elem, hipMemcpyHostToDevice, s->stream));
+  }
+  {
+    TimedCall timed(s);
+    rc = step_obs_impl(s, actions_host ? s->d_stage_act : nullptr, substeps, s->d_stage_obs);
+  }
+  if (rc != TDS_OK) return rc;
+  if (obs_host) HIP_TRY(hipMemcpyAsync(h_obs, s->d_stage_obs, no * s->elem, hipMemcpyDeviceToHost, s->stream));
+  if (y_host) HIP_TRY(hipMemcpyAsync(h_y, s->d_y, ny * s->elem, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (obs_host) widen(s, h_obs, obs_host, no);
+  if (y_host) widen(s, h_y, y_host, ny);
+  return TDS_OK;
+}
+
+int tds_hip_reset_host(tds_hip_sim_t *s, const unsigned char *mask_host, double *obs_host) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  DeviceGuard guard(s->device);
+  int rc = stage_alloc(s);
+  if (rc != TDS_OK) return rc;
+  const size_t n = (size_t)s->num_envs, no = n * s->obs_width();
+  const size_t b_act = align256(n * s->model.action_dim * s->elem);
+  char *const h_obs = (char *)s->h_stage + b_act;
+  unsigned char *mask_dev = nullptr;
+  if (mask_host) {  // (the action staging buffer doubles as the mask: a reset takes no action)
+    memcpy(s->h_stage, mask_host, n);
+    HIP_TRY(hipMemcpyAsync(s->d_stage_act, s->h_stage, n, hipMemcpyHostToDevice, s->stream));
+    mask_dev = (unsigned char *)s->d_stage_act;
+  }
+  rc = tds_hip_reset(s, mask_dev, s->d_stage_obs);
+  if (rc != TDS_OK) return rc;
+  if (obs_host) HIP_TRY(hipMemcpyAsync(h_obs, s->d_stage_obs, no * s->elem, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (obs_host) widen(s, h_obs, obs_host, no);
+  return TDS_OK;
+}
+
+int tds_hip_set_states(tds_hip_sim_t *s, const double *qqd_host) {
+  if (!s || !qqd_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard guard(s->device);
+  const int w = s->model.dof_q + s->model.dof_qd, in = s->model.input_dim;
+  const size_t n = (size_t)s->num_envs;
+  // strided: only the [q | qd] columns of the x records change (actions and the PD variables stay as they are)
+  if (s->records_f64()) {
+    HIP_TRY(hipMemcpy2DAsync(s->d_x, (size_t)in * 8, qqd_host, (size_t)w * 8, (size_t)w * 8, n, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  } else {
+    std::vector<float> tmp(n * w);
+    for (size_t i = 0; i < n * w; ++i) tmp[i] = (float)qqd_host[i];
+    HIP_TRY(hipMemcpy2DAsync(s->d_x, (size_t)in * 4, tmp.data(), (size_t)w * 4, (size_t)w * 4, n, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  s->pool_ready = false;  // (see tds_hip_set_inputs)
+  return TDS_OK;
+}
+
+int tds_hip_device_alloc(tds_hip_sim_t *s, size_t bytes, void **out) {
+  if (!s || !out) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard guard(s->device);
+  HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+  HIP_TRY(hipMemset(*out, 0, bytes ? bytes : 1));
+  return TDS_OK;
+}
+int tds_hip_device_free(tds_hip_sim_t *s, void *p) {
+  if (!s) return fail(TDS_ERR_INVALID_ARG, "sim is NULL");
+  DeviceGuard guard(s->device);
+  if (p) HIP_TRY(hipFree(p));
+  return TDS_OK;
+}
+int tds_hip_device_upload(tds_hip_sim_t *s, void *dst_dev, const void *src_host, size_t bytes) {
+  if (!s || !dst_dev || !src_host) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard guard(s->device);
+  HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TDS_OK;
+}
+int tds_hip_device_download(tds_hip_sim_t *s, void *dst_host, const void *src_dev, size_t bytes) {
+  if (!s || !dst_host || !src_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  DeviceGuard guard(s->device);
+  HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TDS_OK;
 }
 
 int tds_hip_obs_dim(const tds_hip_sim_t *s) { return s ? s->model.dof_q + s->model.dof_qd : 0; }
@@ -1648,20 +1853,20 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   TdsStepCtl ctl;
   memset(&ctl, 0, sizeof(ctl));
   ctl.nsub = 1;
-  if (const char *ga = getenv("TDS_GRAM_STAMP_AT")) ctl.flags |= atoi(ga) << 8;  // (stamp 10 inside tds_gram_solve)
+  if (s->opt.is_set(TDS_OPT_GRAM_STAMP_AT)) ctl.flags |= (int)s->opt.v[TDS_OPT_GRAM_STAMP_AT] << 8;  // (stamp 10 inside tds_gram_solve)
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                          (const double *)s->d_x, (double *)s->d_y, nullptr, nullptr, nullptr,
-                                         (double *)s->d_ovf, s->num_envs, s->stream, ctl, d, two_waves);
+                                         (double *)s->d_ovf, s->num_envs, s->stream, ctl, d, two_waves ? TDS_FORM_W2 : 0);
   else if (s->dtype == TDS_DTYPE_F64_REC32)
     rc = tds_launch_step<double, float>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                         (const float *)s->d_x, (float *)s->d_y, nullptr, nullptr, nullptr,
-                                        (double *)s->d_ovf, s->num_envs, s->stream, ctl, d, two_waves);
+                                        (double *)s->d_ovf, s->num_envs, s->stream, ctl, d, two_waves ? TDS_FORM_W2 : 0);
   else
     rc = tds_launch_step<float, float>((const DevModel<float> *)s->d_model, s->h32, lds, s->lanes,
                                        (const float *)s->d_x, (float *)s->d_y, nullptr, nullptr, nullptr,
-                                       (float *)s->d_ovf, s->num_envs, s->stream, ctl, d, two_waves);
+                                       (float *)s->d_ovf, s->num_envs, s->stream, ctl, d, two_waves ? TDS_FORM_W2 : 0);
   if (rc != 0) {
     (void)hipFree(d);
     return fail(TDS_ERR_HIP, "profiling launch failed");

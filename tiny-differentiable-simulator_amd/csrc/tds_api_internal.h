@@ -13,6 +13,7 @@
 struct tds_hip_sim {
   tds_model_t model;
   int num_envs = 0, device = 0, dtype = TDS_DTYPE_F64, lanes = 64;
+  TdsOptions opt;  // this handle's options (tds_options.h): snapshot at creation, tds_hip_set_option afterwards
   size_t elem = 8;  // bytes per scalar of the RECORDS in HBM (x, y, actions, obs, policy)
   hipStream_t stream = nullptr;
   void *d_model = nullptr;  // DevModel<T>, T = compute scalar
@@ -31,6 +32,9 @@ struct tds_hip_sim {
   // policy network of the rollouts (tds_hip_set_policy_network); nn_layers == 0: the default linear policy
   int nn_layers = 0, nn_units[TDS_NN_MAX_LAYERS] = {0}, nn_act[TDS_NN_MAX_LAYERS] = {0}, nn_bias[TDS_NN_MAX_LAYERS] = {0};
   int nn_weights = 0, nn_biases = 0;
+  // pinned staging of the host-vector entry points (tds_hip_step_host / tds_hip_reset_host): actions up, records down
+  void *h_stage = nullptr, *d_stage_act = nullptr, *d_stage_obs = nullptr;
+  size_t h_stage_bytes = 0;
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_ms = false;
@@ -123,6 +127,7 @@ struct LaunchOpts {
   // call that lie before this launch (the launch's step k owns slot (first + ring_step0 + k) % slots)
   const tds_hip_rings_t *rings = nullptr;
   int ring_step0 = 0;
+  int y_stride = 0;                   // straight-line launch whose `y` is a slot of a strided y ring: scalars per record (0: packed)
 };
 
 // enqueue one launch of the step kernel on the handle's stream (device already selected by the caller)

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "tds_hip.h"
+#include "tds_options.h"
 
 #define TDS_NL 32                      // lanes of links the kernels take (<= TDS_MAX_LINKS of the blob)
 #define TDS_ND 32                      // max dof
@@ -372,8 +373,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   for (int dd = 0; dd < nd; ++dd) d->dof_rec[dd] = d->qd_rec[d->dof_link[dd]];
   {
     // TDS_HIP_NO_CHAIN=1 sends every parent/child hand-over through LDS (A/B testing of the two paths)
-    const char *nc = getenv("TDS_HIP_NO_CHAIN");
-    const bool use_chain = !(nc && nc[0] == '1');
+    const bool use_chain = !tds_opt_now_flag(TDS_OPT_NO_CHAIN);
     for (int i = 0; i < m->num_links; ++i) {
       const int par = m->links[i].parent;
       if (par < 0) continue;
@@ -387,7 +387,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     for (int i = 0; i < m->num_links; ++i) d->lc_slot[i] = (d->chain_flags[i] & 4) ? d->num_lc_slots++ : -1;
     d->root_last = -1;
     {
-      const char *nr = getenv("TDS_HIP_NO_ROOTJOINT");
+      const bool no_rootjoint = tds_opt_now_flag(TDS_OPT_NO_ROOTJOINT);
       int nchild[TDS_NL] = {0}, nroots = 0;
       for (int i = 0; i < m->num_links; ++i) {
         if (m->links[i].parent >= 0) nchild[m->links[i].parent]++;
@@ -400,7 +400,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
           if (l.inertia[c] != 0.0) return false;
         return true;
       };
-      const bool ok = use_chain && !(nr && nr[0] == '1') && nroots == 1;
+      const bool ok = use_chain && !no_rootjoint && nroots == 1;
       int k = 0;  // first link of the root chain that is not (massless, single child, movable)
       // (the first two lanes of a spherical joint may END the chain but never lie inside it: their
       //  velocity-product acceleration is not the chain's prefix sum, see phase C of the kernels)
@@ -413,8 +413,8 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
         d->root_last = k;
       if (fl) d->root_last = 5;  // the six pseudo links ARE the root joint (the kernels special-case their kinematics)
       d->kin_chain_last = d->root_last;
-      const char *nk = getenv("TDS_HIP_NO_KINCHAIN");
-      if (use_chain && !fl && d->num_spherical == 0 && d->num_bodies < 2 && nroots == 1 && !(nk && nk[0] == '1') &&
+      const bool no_kinchain = tds_opt_now_flag(TDS_OPT_NO_KINCHAIN);
+      if (use_chain && !fl && d->num_spherical == 0 && d->num_bodies < 2 && nroots == 1 && !no_kinchain &&
           m->num_links > 0 && m->links[0].parent < 0) {
         int c = 0;
         while (c + 1 < m->num_links && c + 1 < 16 && m->links[c + 1].parent == c && (d->chain_flags[c + 1] & 1)) ++c;
@@ -434,8 +434,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
   }
   d->euler_root = 0;
   {
-    const char *ne = getenv("TDS_HIP_NO_EULERROOT");
-    bool ok = !(ne && ne[0] == '1') && !fl && d->num_spherical == 0 && d->num_bodies < 2 && d->root_last == 5 &&
+    bool ok = !tds_opt_now_flag(TDS_OPT_NO_EULERROOT) && !fl && d->num_spherical == 0 && d->num_bodies < 2 && d->root_last == 5 &&
               d->kin_chain_last == 5 && m->num_links > 6;
     static const int want[6] = {TDS_JOINT_PRISMATIC_X, TDS_JOINT_PRISMATIC_Y, TDS_JOINT_PRISMATIC_Z,
                                 TDS_JOINT_REVOLUTE_X,  TDS_JOINT_REVOLUTE_Y,  TDS_JOINT_REVOLUTE_Z};
@@ -456,10 +455,9 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
       d->euler_root = ident ? 1 : 0;  // (a rotated base frame: the general scan)
     }
     d->leg_len = 0;
-    const char *nls = getenv("TDS_HIP_NO_LEGSCAN");
     // (double arithmetic only: in the pure float build the re-associated products of the scan cost Laikago a quarter of
     //  a digit — 4.7e-4 against 3.5e-4 of the level loop, the reference's own float path: 1.1e-4; tests/test_f32.py)
-    if (d->euler_root && sizeof(T) == 8 && !(nls && nls[0] == '1')) {
+    if (d->euler_root && sizeof(T) == 8 && !tds_opt_now_flag(TDS_OPT_NO_LEGSCAN)) {
       const int nleg = m->num_links - 6;
       for (int len = 4; len >= 2 && d->leg_len == 0; len >>= 1) {
         if (nleg < len || nleg % len != 0) continue;
@@ -675,8 +673,7 @@ static inline TdsExpanded *tds_expand_model(const tds_model_t *m, char *why) {
   }
   const int base = fl ? 6 : 0;
   if (fl && nsph) TDS_XFAIL("floating base + spherical joints: the reference fills the base/joint block of M one way only (mass_matrix.hpp:80-84); not built");
-  const char *ff = getenv("TDS_HIP_FOLD_FIXED");
-  const bool fold = (m->num_links + base + 2 * nsph > TDS_NL) || (ff && ff[0] == '1');
+  const bool fold = (m->num_links + base + 2 * nsph > TDS_NL) || tds_opt_now_flag(TDS_OPT_FOLD_FIXED);
   if (m->num_links + base + 2 * nsph - (fold ? nfixed_foldable : 0) > TDS_NL)
     TDS_XFAIL("too many links for 32 lanes (one per moving link, 6 for a floating base, 3 per spherical joint)");
   const int nj = m->dof_qd - base;
@@ -918,8 +915,7 @@ static int tds_build_dev_model(const tds_model_t *m, DevModel<T> *d, char *why) 
       return rc;
     }
   }
-  const char *ffx = getenv("TDS_HIP_FOLD_FIXED");
-  bool general = m->is_floating != 0 || m->num_links > TDS_NL || (ffx && ffx[0] == '1');
+  bool general = m->is_floating != 0 || m->num_links > TDS_NL || tds_opt_now_flag(TDS_OPT_FOLD_FIXED);
   for (int i = 0; i < m->num_links && i < TDS_MAX_LINKS; ++i) general |= m->links[i].joint_type == TDS_JOINT_SPHERICAL;
   if (!general) return tds_build_dev_model_impl<T>(m, d, why, nullptr);
   TdsExpanded *e = tds_expand_model(m, why);

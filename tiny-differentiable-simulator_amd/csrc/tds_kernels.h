@@ -64,6 +64,8 @@ struct TdsStepCtl {
   int obs_slots, obs_first;
   int y_slots, y_first;
   int ring_envs;              // environments per ring slot (= the batch the rings were laid out for)
+  int y_stride;               // scalars between consecutive records of the y ring (0: output_dim)
+  int obs_envs;               // environments per slot of the obs ring (>= ring_envs: a slot laid out for all ranks)
   int ring_flags;             // TDS_RING_OBS_F32: the obs ring holds floats whatever the record dtype (wire format of the
                               // multi-GPU exchange: the slot is handed to ncclAllGather as it is)
   // != NULL: every workgroup adds 1 once its records of step k are visible device-wide — signalled from inside step
@@ -75,6 +77,11 @@ struct TdsStepCtl {
 // the obs ring is written with device-scope write-through stores (sc1) and a step is signalled after a plain
 // s_waitcnt vmcnt(0) — no release fence, whose buffer_wbl2 writes back every dirty line of the L2
 #define TDS_RING_NOFENCE 2
+
+// which build of the step kernel a launch takes (tds_launch_step's `form`)
+#define TDS_FORM_W2 1         // L is the w2 layout: launch the two-wavefront form (plain kernels)
+#define TDS_FORM_LOOP_OCC1 2  // step-loop build: the one-wavefront-per-SIMD compilation whatever the grid
+#define TDS_FORM_LOOP_OCC2 4  // ... the two-wavefronts-per-SIMD compilation whatever the grid
 
 // na_cap: contacts whose rows stay in LDS (<= 0: all); w2: the layout of the two-wavefront workgroups (the LDS groups
 // that alias each other in the one-wave layout laid out one after the other, + hand-over slots)
@@ -91,15 +98,15 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
 template <typename T, typename TR, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                          const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
-                         hipStream_t stream, const TdsStepCtl &ctl, long long *prof, bool two_waves);
+                         hipStream_t stream, const TdsStepCtl &ctl, long long *prof, int form);
 // T: compute scalar, TR: record scalar (== T, or float under T = double: "f32 records / f64 arithmetic")
 template <typename T, typename TR>
 inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                            const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
                            hipStream_t stream, const TdsStepCtl &ctl,
                            long long *prof = nullptr,  // prof: 14 phase stamps of workgroup 0 (diagnostic)
-                           bool two_waves = false) {   // L is the w2 layout: launch the two-wavefront form (plain kernels)
-#define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof, two_waves
+                           int form = 0) {   // TDS_FORM_*: which build of the kernel
+#define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof, form
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
   if (h_model.num_bodies >= 2 && h_model.multi_floating) return tds_launch_step_impl<T, TR, 4>(TDS_ARGS);

@@ -1494,7 +1494,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // visual poses no load is waited for until the next step begins.  (The last step of a launch and environments that
   // the reset pool re-initialises store at once.)
   constexpr bool DEFER = LOOP && KIND == 0;
-  auto put_y_state = [&](TR *yo) {  // q | qd | (visual poses: phase M1) | up.z | zero padding, from the LDS record
+  // (a y RING may have a record stride beyond output_dim — TdsStepCtl::y_stride, records on 128-byte line boundaries: the
+  //  zero padding then runs to the stride, so that a record's last line is written whole)
+  //  (straight-line launches pointed at a ring slot — the graph form of tds_hip_step_many_rings — take the stride for y_out)
+  const int ystr = ((LOOP ? ring_y : true) && ctl.y_stride > 0) ? ctl.y_stride : out_dim;
+  auto put_y_state = [&](TR *yo, int yend) {  // q | qd | (visual poses: phase M1) | up.z | zero padding, from the LDS record
     for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)xr[i], &yo[i]);
     int tail = nq + nd;
     if (mdl->pack_visuals) {
@@ -1502,12 +1506,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       if (lane == 0) __builtin_nontemporal_store((TR)(mdl->base_R[8]), &yo[tail]);  // up_dot_world_z (fixed base)
       tail += 1;
     }
-    for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
+    for (int i = tail + lane; i < yend; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
   };
   // [q | qd with obs[0] = obs[1] = 0 | reward | done] of ring slot `slot` (ars_vectorized_environment.h:250-289): the
   // observation from the LDS record as it is NOW, reward / done from their LDS slots (written by the reward block)
   auto put_obs = [&](int slot) {
-    const size_t at = ((size_t)slot * ctl.ring_envs + env) * (nq + nd + 2);
+    const size_t at = ((size_t)slot * ctl.obs_envs + env) * (nq + nd + 2);
     for (int i = lane; i < nq + nd + 2; i += G) {
       const int src = i < nq + nd ? i : (i == nq + nd ? in_dim + RW_SLOT : in_dim + 1);
       ring_put(at + i, i < 2 ? T(0) : xr[src]);
@@ -1518,7 +1522,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     if constexpr (DEFER) {
       if ((ring_o || ring_y) && tds_iter > 0 && valid && mode == TDS_MODE_RUN && xr[in_dim + OUT_SLOT] == T(0)) {
         if (ring_y)
-          put_y_state((TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter - 1) % ctl.y_slots) * ctl.ring_envs + env) * out_dim);
+          put_y_state((TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter - 1) % ctl.y_slots) * ctl.ring_envs + env) * ystr, ystr);
         if (ring_o) put_obs((ctl.obs_first + tds_iter - 1) % ctl.obs_slots);
       }
     }
@@ -1535,8 +1539,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
   };
   const bool pack_y = ring_y ? (valid && mode == TDS_MODE_RUN) : (last_run && y_out != nullptr);
-  TR *const y_step = ring_y ? (TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env) * out_dim
-                            : y_out + (size_t)env * out_dim;
+  TR *const y_step = ring_y ? (TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env) * ystr
+                            : y_out + (size_t)env * (LOOP ? out_dim : ystr);
   // ---- the phases that a two-wavefront workgroup hands to its helper wavefront, as closures (each derives the LDS
   //      addresses it needs itself: nothing is kept live for them across the phases in between)
   const int NCPp = L.NCPp;
@@ -1955,7 +1959,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           if (lane == 0) __builtin_nontemporal_store((TR)(mdl->base_R[8]), &yo[tail]);
           tail += 1;
         }
-        for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
+        for (int i = tail + lane; i < ystr; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
       }
       TDS_STAMP(4);
       if (contacts_h && split_ok) phase_J(na_h, NA_h);
@@ -3536,7 +3540,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         if (lane == 0) __builtin_nontemporal_store((TR)((fl || (flm && fbk == 0)) ? up_z : (two ? mdl->base_Rb[0][8] : mdl->base_R[8])), &yo[tail]);
         tail += 1;
       }
-      for (int i = tail + lane; i < out_dim; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
+      const int yend = yt_i == 0 ? ystr : out_dim;
+      for (int i = tail + lane; i < yend; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
     }
   }
 
@@ -3639,8 +3644,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     const bool ring_step = (ring_o || ring_y) && valid && mode == TDS_MODE_RUN;
     const bool ring_now = ring_step && (!DEFER || last_run || (pool_r && done_now));
     if constexpr (DEFER) {
-      if (ring_y && ring_now) put_y_state(y_step);
-      if (ring_y && ring_step && last_run && y_out != nullptr) put_y_state(y_out + (size_t)env * out_dim);
+      if (ring_y && ring_now) put_y_state(y_step, ystr);
+      if (ring_y && ring_step && last_run && y_out != nullptr) put_y_state(y_out + (size_t)env * out_dim, out_dim);
     }
 
     // ---- mode transition of this lane group
@@ -3812,8 +3817,7 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
   // Gram form of the contact solve (tds_gram_solve): its 16 x 17 buffer + 16 zeros reuse the two sweep groups
   // Opt-in (TDS_HIP_GRAM=1): measured 0.4k of 32k cycles better than the z~ sweep at Ant x 4096 (profiles/r02d_gram_mfma.txt),
   // and an environment's low-order bits then depend on whether its wavefront-mates push NA past 5 (sweep) or not (Gram).
-  const char *ge = getenv("TDS_HIP_GRAM");
-  L.gram_ok = (ge && ge[0] == '1' && w2 && lanes_per_env == 16 && ndp <= 16 && m.num_bodies < 2 &&
+  L.gram_ok = (tds_opt_now_flag(TDS_OPT_GRAM) && w2 && lanes_per_env == 16 && ndp <= 16 && m.num_bodies < 2 &&
                L.Z - L.Xw >= TDS_GRAM_ZEROS + 16) ? 1 : 0;
   o = g1 > g2 ? g1 : g2;
   o = o > g3 ? o : g3;
@@ -3828,7 +3832,8 @@ TdsLds tds_make_lds_layout(const DevModel<T> &m, int na_cap, int lanes_per_env, 
 template <typename T, typename TR, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                          const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
-                         hipStream_t stream, const TdsStepCtl &ctl, long long *prof, bool two_waves) {
+                         hipStream_t stream, const TdsStepCtl &ctl, long long *prof, int form) {
+  const bool two_waves = (form & TDS_FORM_W2) != 0;
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
   const size_t shmem = (size_t)L.stride * epw * sizeof(T);
@@ -3872,8 +3877,8 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr &&
                       ctl.obs_ring == nullptr && ctl.y_ring == nullptr;  // (record rings: the step-loop builds write them)
   // step-loop build: above one wavefront per SIMD (256 CUs x 4 SIMDs) the two-wavefronts-per-SIMD compilation wins
-  // (TDS_HIP_LOOP_OCC=1 / 2 forces either)
-  static const int loop_force = [] { const char *e = getenv("TDS_HIP_LOOP_OCC"); return e ? atoi(e) : 0; }();
+  // (option loop_occ = 1 / 2 forces either: TDS_FORM_LOOP_OCC*)
+  const int loop_force = (form & TDS_FORM_LOOP_OCC2) ? 2 : ((form & TDS_FORM_LOOP_OCC1) ? 1 : 0);
   // (>= 24 padded dof: the straight-line build is itself at one wavefront per SIMD; the two-wave loop build would
   //  spill hundreds of registers there)
   const bool loop_occ2 = L.NDP < 24 && (loop_force == 2 || (loop_force != 1 && blocks >= 1536));
@@ -3938,7 +3943,7 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
 #define TDS_INSTANTIATE(TT, TR, KV)                                                                                     \
   template int tds_launch_step_impl<TT, TR, KV>(const DevModel<TT> *, const DevModel<TT> &, const TdsLds &, int,       \
                                                 const TR *, TR *, const TR *, TR *, TR *, TT *, int, hipStream_t,     \
-                                                const TdsStepCtl &, long long *, bool);                                \
+                                                const TdsStepCtl &, long long *, int);                                 \
   template int tds_kernel_max_dynamic_lds_impl<TT, TR, KV>(int, int, int);
 #if !defined(TDS_ONLY_KIND)
 #define TDS_ALL_KINDS 1

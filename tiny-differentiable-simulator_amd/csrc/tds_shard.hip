@@ -43,6 +43,9 @@ struct Rccl {
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;
+  // optional (RCCL >= 2.19): user-buffer registration
+  ncclResult_t (*CommRegister)(const ncclComm_t, void *, size_t, void **) = nullptr;
+  ncclResult_t (*CommDeregister)(const ncclComm_t, void *) = nullptr;
   bool ok = false;
 };
 
@@ -73,6 +76,8 @@ Rccl *rccl() {
   TDS_SYM(GetErrorString, "ncclGetErrorString");
   TDS_SYM(GetVersion, "ncclGetVersion");
 #undef TDS_SYM
+  r.CommRegister = (decltype(r.CommRegister))dlsym(r.handle, "ncclCommRegister");
+  r.CommDeregister = (decltype(r.CommDeregister))dlsym(r.handle, "ncclCommDeregister");
   r.ok = true;
   return &r;
 }
@@ -99,13 +104,15 @@ __global__ void tds_f64_to_f32_kernel(const double *__restrict__ in, float *__re
 // clock it raises the error latch and gives up (as does every wait behind it), so that a launch order nobody foresaw
 // costs a wrong exchange that tds_hip_shard_flush reports, never a hung GPU.
 __global__ void tds_ring_wait_kernel(const unsigned long long *progress, unsigned long long target, unsigned *err,
-                                     long long timeout_ticks) {
+                                     long long timeout_ticks, unsigned *host_latch) {
   if (threadIdx.x != 0) return;
   const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
   while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
       __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (pinned host word: the next host call of the shard sees the failure without a device round trip)
+      if (host_latch) __hip_atomic_store(host_latch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
     __builtin_amdgcn_s_sleep(16);
@@ -139,11 +146,20 @@ struct tds_hip_shard {
   // ---- ring exchange (tds_hip_shard_step_many where the sim's K steps are ONE step-loop launch): the launch writes
   //      the [obs | reward | done] record of every step into a slot of `rwire`, in the wire dtype; the communication
   //      stream sends slot k as soon as the launch has counted every workgroup in for step k
-  void *rwire = nullptr;   // [2 TDS_SHARD_CHUNK][n_local][w]          wire dtype
+  void *rwire = nullptr;   // [2 TDS_SHARD_CHUNK][n_local][w]          wire dtype (NULL with the in-place exchange)
   void *rgath = nullptr;   // [2 TDS_SHARD_CHUNK][world][n_local][w]   wire dtype
-  void *ry = nullptr;      // [TDS_SHARD_Y_SLOTS][n_local][output_dim] record dtype: the y records (local, not exchanged)
-  unsigned long long *progress = nullptr;  // [2] one counter per ring half, + the error latch behind them
-  hipEvent_t ev_fork = nullptr, ev_kernel[2] = {}, ev_comm[2] = {};
+  void *ry = nullptr;      // [TDS_SHARD_Y_SLOTS][n_local][y_stride]   record dtype: the y records (local, not exchanged)
+  int ry_stride = 0;       // scalars per y record in `ry` (padded to whole 128-byte lines; option y_stride)
+  bool inplace = false;    // the launch stores its records into ITS block of rgath; the all-gather is in place
+  void *reg_handle = nullptr;  // ncclCommRegister handle of rgath
+  // one counter per ring half, + the error latch behind them.  The counters are NEVER reset: a launch of c steps adds
+  // (c - 1) n_blocks, the host keeps the running base of each half (prog_base) — no memset between launches
+  unsigned long long *progress = nullptr;
+  unsigned long long prog_base[2] = {0ull, 0ull};
+  unsigned *host_latch = nullptr;  // pinned: raised by a wait that gave up (checked by every later call of the shard)
+  bool wait_value = false;         // the waits are hipStreamWaitValue64 commands instead of wait kernels
+  bool ring_ready = false;         // ring_alloc has completed (a failed allocation is undone as a whole)
+  hipEvent_t ev_kernel[2] = {}, ev_comm[2] = {};
   hipEvent_t cap_fork = nullptr, cap_kernel = nullptr, cap_comm = nullptr;  // the same roles inside a stream capture
   bool comm_pending[2] = {};
   long long chunks = 0;    // step-loop launches submitted so far
@@ -293,17 +309,35 @@ int shard_mark_done(tds_hip_shard *sh, int slot) {
 // for the exchanges of launch j (which used the same half).  N = 1 (tds_hip_step_many_rings alone) and N > 1 (this)
 // run the SAME kernel doing the SAME work per step; the only difference is the exchange.
 // ---------------------------------------------------------------------------------------------------------------
-int ring_alloc(tds_hip_shard *sh) {
-  if (sh->rwire) return TDS_OK;
+void ring_free(tds_hip_shard *sh);
+
+int ring_alloc_impl(tds_hip_shard *sh) {
   tds_hip_sim *s = sh->sim;
   const size_t slot_b = sh->slot_scalars() * sh->wire_bytes;
-  TDS_HIP_TRY(hipMalloc(&sh->rwire, 2 * TDS_SHARD_CHUNK * slot_b));
-  TDS_HIP_TRY(hipMemset(sh->rwire, 0, 2 * TDS_SHARD_CHUNK * slot_b));
+  // In-place exchange (default): the gathered buffer is the only copy — the step-loop launch stores the records of step k
+  // into THIS rank's block of slot k (tds_hip_rings_t::obs_slot_envs = world n_local), ncclAllGather runs with
+  // sendbuff == recvbuff + rank * count.  On one rank nothing is left to move at all; on G ranks the local block is
+  // neither copied nor sent to itself.  (option shard_inplace = 0: separate send ring, as in round 3)
+  sh->inplace = s->opt.get(TDS_OPT_SHARD_INPLACE, 1) != 0;
+  if (!sh->inplace) {
+    TDS_HIP_TRY(hipMalloc(&sh->rwire, 2 * TDS_SHARD_CHUNK * slot_b));
+    TDS_HIP_TRY(hipMemset(sh->rwire, 0, 2 * TDS_SHARD_CHUNK * slot_b));
+  }
   TDS_HIP_TRY(hipMalloc(&sh->rgath, 2 * TDS_SHARD_CHUNK * slot_b * sh->world));
-  TDS_HIP_TRY(hipMalloc(&sh->ry, (size_t)TDS_SHARD_Y_SLOTS * sh->n_local * s->model.output_dim * s->elem));
+  TDS_HIP_TRY(hipMemset(sh->rgath, 0, 2 * TDS_SHARD_CHUNK * slot_b * sh->world));
+  // y records on 128-byte line boundaries (the launch then writes whole lines only)
+  {
+    const int per_line = 128 / (int)s->elem;
+    int ys = (s->model.output_dim + per_line - 1) / per_line * per_line;
+    if (s->opt.is_set(TDS_OPT_Y_STRIDE) && s->opt.v[TDS_OPT_Y_STRIDE] >= s->model.output_dim) ys = (int)s->opt.v[TDS_OPT_Y_STRIDE];
+    sh->ry_stride = ys;
+  }
+  TDS_HIP_TRY(hipMalloc(&sh->ry, (size_t)TDS_SHARD_Y_SLOTS * sh->n_local * sh->ry_stride * s->elem));
   TDS_HIP_TRY(hipMalloc((void **)&sh->progress, 4 * sizeof(unsigned long long)));
   TDS_HIP_TRY(hipMemset(sh->progress, 0, 4 * sizeof(unsigned long long)));
-  TDS_HIP_TRY(hipEventCreateWithFlags(&sh->ev_fork, hipEventDisableTiming));
+  sh->prog_base[0] = sh->prog_base[1] = 0ull;
+  TDS_HIP_TRY(hipHostMalloc((void **)&sh->host_latch, sizeof(unsigned), hipHostMallocMapped));
+  *sh->host_latch = 0u;
   for (int i = 0; i < 2; ++i) {
     TDS_HIP_TRY(hipEventCreateWithFlags(&sh->ev_kernel[i], hipEventDisableTiming));
     TDS_HIP_TRY(hipEventCreateWithFlags(&sh->ev_comm[i], hipEventDisableTiming));
@@ -311,6 +345,31 @@ int ring_alloc(tds_hip_shard *sh) {
   TDS_HIP_TRY(hipEventCreateWithFlags(&sh->cap_fork, hipEventDisableTiming));
   TDS_HIP_TRY(hipEventCreateWithFlags(&sh->cap_kernel, hipEventDisableTiming));
   TDS_HIP_TRY(hipEventCreateWithFlags(&sh->cap_comm, hipEventDisableTiming));
+  // how the communication stream follows the counter: a one-lane wait kernel of our own (bounded: it gives up after
+  // shard_wait_ms and raises the latch), or — option shard_wait = 1 — a hipStreamWaitValue64 command.  Measured
+  // (profiles/r04_ubench_wait_value.txt, r04_ring_exchange_forms.txt): on ROCm 7.2 the latter is ALSO a one-wave kernel
+  // (__amd_rocclr_streamOpsWait in the trace), not a command-processor wait — it needs a wavefront slot just the same,
+  // has no timeout, and follows only counters in DEVICE memory at speed (signal / host memory: 700 us per step).
+  sh->wait_value = false;
+  if (s->opt.get(TDS_OPT_SHARD_WAIT, 0) == 1) {
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, s->device) == hipSuccess && can) sh->wait_value = true;
+  }
+  // user-buffer registration of the receive ring (RCCL >= 2.19; harmless where the transport ignores it)
+  if (sh->comm && s->opt.get(TDS_OPT_SHARD_REGISTER, 1) != 0 && rccl() && rccl()->CommRegister) {
+    if (rccl()->CommRegister(sh->comm, sh->rgath, 2 * TDS_SHARD_CHUNK * slot_b * sh->world, &sh->reg_handle) != ncclSuccess)
+      sh->reg_handle = nullptr;  // (not fatal: the collective works on unregistered buffers)
+  }
+  return TDS_OK;
+}
+int ring_alloc(tds_hip_shard *sh) {
+  if (sh->ring_ready) return TDS_OK;
+  const int rc = ring_alloc_impl(sh);
+  if (rc != TDS_OK) {
+    ring_free(sh);  // a partial allocation is undone: the next call starts from nothing instead of dereferencing NULL
+    return rc;
+  }
+  sh->ring_ready = true;
   return TDS_OK;
 }
 
@@ -320,28 +379,32 @@ void ring_free(tds_hip_shard *sh) {
       (void)hipGraphExecDestroy(g.exec);
       g.exec = nullptr;
     }
+  if (sh->reg_handle && sh->comm && rccl() && rccl()->CommDeregister) (void)rccl()->CommDeregister(sh->comm, sh->reg_handle);
+  sh->reg_handle = nullptr;
   if (sh->rwire) (void)hipFree(sh->rwire);
   if (sh->rgath) (void)hipFree(sh->rgath);
   if (sh->ry) (void)hipFree(sh->ry);
   if (sh->progress) (void)hipFree(sh->progress);
-  if (sh->ev_fork) (void)hipEventDestroy(sh->ev_fork);
+  if (sh->host_latch) (void)hipHostFree(sh->host_latch);
   if (sh->cap_fork) (void)hipEventDestroy(sh->cap_fork);
   if (sh->cap_kernel) (void)hipEventDestroy(sh->cap_kernel);
   if (sh->cap_comm) (void)hipEventDestroy(sh->cap_comm);
   for (int i = 0; i < 2; ++i) {
     if (sh->ev_kernel[i]) (void)hipEventDestroy(sh->ev_kernel[i]);
     if (sh->ev_comm[i]) (void)hipEventDestroy(sh->ev_comm[i]);
+    sh->ev_kernel[i] = sh->ev_comm[i] = nullptr;
   }
+  sh->cap_fork = sh->cap_kernel = sh->cap_comm = nullptr;
   sh->rwire = sh->rgath = sh->ry = nullptr;
   sh->progress = nullptr;
+  sh->host_latch = nullptr;
+  sh->ring_ready = false;
 }
 
 bool ring_form(const tds_hip_shard *sh, int n_steps) {
   const tds_hip_sim *s = sh->sim;
   if (sh->block != 1 || s->auto_reset) return false;  // (auto-reset: the refill passes of the reset pool are host-driven)
-  if (const char *e = getenv("TDS_HIP_SHARD_RING")) {
-    if (e[0] == '0') return false;
-  }
+  if (s->opt.get(TDS_OPT_SHARD_RING, 1) == 0) return false;
   return tds_hip_step_many_is_loop(s, n_steps > 1 ? n_steps : 2) != 0;
 }
 
@@ -351,53 +414,71 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
   const int h = ck.half;
   const size_t slot_b = sh->slot_scalars() * sh->wire_bytes;
   // (events recorded inside a capture belong to the capture: it has its own set)
-  const hipEvent_t e_fork = capturing ? sh->cap_fork : sh->ev_fork, e_kernel = capturing ? sh->cap_kernel : sh->ev_kernel[h],
-                   e_comm = capturing ? sh->cap_comm : sh->ev_comm[h];
+  const hipEvent_t e_kernel = capturing ? sh->cap_kernel : sh->ev_kernel[h], e_comm = capturing ? sh->cap_comm : sh->ev_comm[h];
   if (!capturing && sh->comm_pending[h]) {  // the exchanges of the launch two back read this half of the ring
     TDS_HIP_TRY(hipStreamWaitEvent(s->stream, sh->ev_comm[h], 0));
     sh->comm_pending[h] = false;
   }
-  TDS_HIP_TRY(hipMemsetAsync(sh->progress + h, 0, sizeof(unsigned long long), s->stream));
-  TDS_HIP_TRY(hipEventRecord(e_fork, s->stream));
-  TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, e_fork, 0));
+  // The counters are never reset in the eager form: the waits of this launch target base + (k + 1) n_blocks, which no
+  // earlier launch can have reached — no fill kernel, no fork event between the two streams (round 3 had both per
+  // launch).  A captured chunk must replay with fixed targets: it zeroes its counter first, and forks the communication
+  // stream off the capture's origin.
+  unsigned long long base = sh->prog_base[h];
+  if (capturing) {
+    TDS_HIP_TRY(hipMemsetAsync(sh->progress + h, 0, sizeof(unsigned long long), s->stream));
+    TDS_HIP_TRY(hipEventRecord(sh->cap_fork, s->stream));
+    TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, sh->cap_fork, 0));
+    base = 0ull;
+  }
   tds_hip_rings_t r;
   memset(&r, 0, sizeof(r));
-  r.obs_ring = (char *)sh->rwire + (size_t)ck.slot0 * slot_b;
+  if (sh->inplace) {  // slot k of the chunk = this rank's block of gathered slot slot0 + k
+    r.obs_ring = (char *)sh->rgath + ((size_t)ck.slot0 * sh->world + sh->rank) * slot_b;
+    r.obs_slot_envs = sh->world * sh->n_local;
+  } else {
+    r.obs_ring = (char *)sh->rwire + (size_t)ck.slot0 * slot_b;
+  }
   r.obs_slots = TDS_SHARD_CHUNK;
   r.obs_first = 0;
   r.obs_f32 = (sh->wire_bytes == 4 && s->elem == 8) ? 1 : 0;
   r.y_ring = sh->ry;
   r.y_slots = TDS_SHARD_Y_SLOTS;
   r.y_first = 0;
+  r.y_stride = sh->ry_stride;
   r.progress = sh->progress + h;
   int rc = tds_hip_step_many_rings(s, actions_dev, pool, ck.act_first, ck.steps, &r);
   if (rc != TDS_OK) return rc;
   TDS_HIP_TRY(hipEventRecord(e_kernel, s->stream));
   const int n_blocks = tds_hip_step_many_rings_blocks(s);
-  static const long long timeout_ticks = [] {
-    const char *e = getenv("TDS_HIP_SHARD_WAIT_MS");
-    return (long long)(e ? atoi(e) : 2000) * 100000ll;  // 100 MHz
-  }();
+  const long long timeout_ticks = s->opt.get(TDS_OPT_SHARD_WAIT_MS, 2000) * 100000ll;  // 100 MHz
+  const bool nothing_to_move = sh->inplace && sh->world == 1 && !sh->comm;
   for (int k = 0; k < ck.steps; ++k) {
-    const unsigned long long target = tds_ring_wait_target(k, ck.steps, n_blocks);
-    if (target != 0ull) {
-      hipLaunchKernelGGL(tds_ring_wait_kernel, dim3(1), dim3(64), 0, sh->comm_stream, sh->progress + h, target,
-                         sh->wait_err(), timeout_ticks);
-      if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "ring exchange: wait kernel launch");
-    } else {
+    const unsigned long long rel = tds_ring_wait_target(k, ck.steps, n_blocks);
+    if (rel == 0ull) {
       TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, e_kernel, 0));
+    } else if (nothing_to_move) {
+      continue;  // (one rank without a communicator, records already where the gather would put them: the slot is
+                 //  complete when the launch is — nothing follows the counter)
+    } else if (sh->wait_value && !capturing) {
+      TDS_HIP_TRY(hipStreamWaitValue64(sh->comm_stream, sh->progress + h, base + rel, hipStreamWaitValueGte, ~0ull));
+    } else {
+      hipLaunchKernelGGL(tds_ring_wait_kernel, dim3(1), dim3(64), 0, sh->comm_stream, sh->progress + h, base + rel,
+                         sh->wait_err(), timeout_ticks, sh->host_latch);
+      if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "ring exchange: wait kernel launch");
     }
-    const void *src = (const char *)sh->rwire + (size_t)(ck.slot0 + k) * slot_b;
-    void *dst = (char *)sh->rgath + (size_t)(ck.slot0 + k) * slot_b * sh->world;
+    char *const dst = (char *)sh->rgath + (size_t)(ck.slot0 + k) * slot_b * sh->world;
+    const void *src = sh->inplace ? (const void *)(dst + (size_t)sh->rank * slot_b)
+                                  : (const void *)((const char *)sh->rwire + (size_t)(ck.slot0 + k) * slot_b);
     if (sh->comm) {
       NCCL_TRY(rccl()->AllGather(src, dst, sh->slot_scalars(), sh->wire_bytes == 8 ? ncclFloat64 : ncclFloat32, sh->comm,
                                  sh->comm_stream));
       if (!capturing) sh->comm_warm = true;
-    } else {
+    } else if (!sh->inplace) {
       TDS_HIP_TRY(hipMemcpyAsync(dst, src, slot_b, hipMemcpyDeviceToDevice, sh->comm_stream));
     }
   }
   TDS_HIP_TRY(hipEventRecord(e_comm, sh->comm_stream));
+  if (!capturing) sh->prog_base[h] = base + (unsigned long long)(ck.steps - 1) * (unsigned long long)n_blocks;
   return TDS_OK;
 }
 
@@ -467,9 +548,20 @@ tds_hip_shard::RingGraph *ring_graph_build(tds_hip_shard *sh, const void *action
   return slot;
 }
 
+// a wait of the ring exchange that gave up (tds_ring_wait_kernel raised the pinned latch): the all-gathers behind it sent
+// slots that may not have been written — every later call of the shard fails until tds_hip_shard_flush has reported it
+int ring_latched(const tds_hip_shard *sh) {
+  if (sh->host_latch && *(volatile unsigned *)sh->host_latch != 0u)
+    return fail(TDS_ERR_HIP, "ring exchange: a wait for the step-loop launch timed out — gathered records are not valid "
+                             "(tds_hip_shard_flush clears the condition)");
+  return TDS_OK;
+}
+
 int ring_many(tds_hip_shard *sh, const void *actions_dev, int pool, int first, int n_steps, bool run) {
   tds_hip_sim *s = sh->sim;
   int rc = ring_alloc(sh);
+  if (rc != TDS_OK) return rc;
+  rc = ring_latched(sh);
   if (rc != TDS_OK) return rc;
   if (sh->comm && !sh->comm_warm) {
     // the first collective of a communicator sets up its transport connections between the ranks: eagerly, never inside
@@ -477,8 +569,13 @@ int ring_many(tds_hip_shard *sh, const void *actions_dev, int pool, int first, i
     if (sh->one_process_group)
       return fail(TDS_ERR_INVALID_ARG, "shards of tds_hip_shard_create_all: call tds_hip_shard_group_step once before "
                                        "tds_hip_shard_step_many (the first collective must be issued as a group)");
-    NCCL_TRY(rccl()->AllGather(sh->rwire, sh->rgath, sh->slot_scalars(), sh->wire_bytes == 8 ? ncclFloat64 : ncclFloat32,
-                               sh->comm, sh->comm_stream));
+    // (slot 0 of the ring; in place: this rank's block of it)
+    {
+      const size_t slot_b0 = sh->slot_scalars() * sh->wire_bytes;
+      const void *src0 = sh->inplace ? (const void *)((const char *)sh->rgath + (size_t)sh->rank * slot_b0) : (const void *)sh->rwire;
+      NCCL_TRY(rccl()->AllGather(src0, sh->rgath, sh->slot_scalars(), sh->wire_bytes == 8 ? ncclFloat64 : ncclFloat32,
+                                 sh->comm, sh->comm_stream));
+    }
     TDS_HIP_TRY(hipStreamSynchronize(sh->comm_stream));
     sh->comm_warm = true;
   }
@@ -489,8 +586,7 @@ int ring_many(tds_hip_shard *sh, const void *actions_dev, int pool, int first, i
   // ONE hipGraph per launch (TDS_HIP_SHARD_GRAPH=1) the same nodes replay ~10 us per step SLOWER on ROCm 7 — measured,
   // profiles/r03_ring_exchange_forms.txt: a chain of 128 dependent kernel / copy nodes pays a node-to-node latency the
   // stream does not.
-  const char *ge = getenv("TDS_HIP_SHARD_GRAPH");
-  const bool want_graph = ge && ge[0] == '1' && getenv("TDS_HIP_SHARD_NO_GRAPH") == nullptr;
+  const bool want_graph = s->opt.get(TDS_OPT_SHARD_GRAPH, 0) == 1 && !s->opt.flag(TDS_OPT_SHARD_NO_GRAPH);
   for (int i = 0; i < nc; ++i) {
     const TdsRingChunk &ck = plan[i];
     tds_hip_shard::RingGraph *g = want_graph ? ring_graph_find(sh, actions_dev, pool, ck) : nullptr;
@@ -504,6 +600,8 @@ int ring_many(tds_hip_shard *sh, const void *actions_dev, int pool, int first, i
         }
       TDS_HIP_TRY(hipGraphLaunch(g->exec, s->stream));
       g->used = ++sh->rgraph_clock;
+      // (the captured chunk zeroes its counter and leaves it at (steps - 1) n_blocks)
+      sh->prog_base[ck.half] = (unsigned long long)(ck.steps - 1) * (unsigned long long)tds_hip_step_many_rings_blocks(s);
       // consumers of tds_hip_shard_gathered wait on ev_comm[half]: record it behind the graph (complete = exchanged)
       TDS_HIP_TRY(hipEventRecord(sh->ev_comm[ck.half], s->stream));
     } else {
@@ -725,7 +823,7 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
   if (sh->comm && !sh->comm_warm && sh->one_process_group)
     return fail(TDS_ERR_INVALID_ARG, "shards of tds_hip_shard_create_all: call tds_hip_shard_group_step once before "
                                      "tds_hip_shard_step_many (the first collective must be issued as a group)");
-  const bool eager_only = s->auto_reset || getenv("TDS_HIP_SHARD_NO_GRAPH") != nullptr;
+  const bool eager_only = s->auto_reset || s->opt.flag(TDS_OPT_SHARD_NO_GRAPH);
   if (!eager_only) {
     if (sh->steps % sh->block != 0) {  // (a partially filled block of eager steps travels first)
       const int rc = tds_hip_shard_flush(sh);
@@ -765,6 +863,9 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
     hipStream_t user = s->stream;
     const long long steps0 = sh->steps;
     const int last0 = sh->last_slot;
+    void *const last_ptr0 = sh->last_ptr;  // (shard_mark_done inside the capture sets these to events recorded in the
+    const hipEvent_t last_ev0 = sh->last_ev;  //  capture only: nothing a consumer may wait on)
+    const int last_block0 = sh->last_block;
     s->stream = sh->graph_stream;  // capture origin (the handle's own stream may be the NULL stream)
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamBeginCapture(sh->graph_stream, hipStreamCaptureModeThreadLocal);
@@ -792,6 +893,9 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
     s->stream = user;
     sh->steps = steps0;  // (the capture executed nothing)
     sh->last_slot = last0;
+    sh->last_ptr = last_ptr0;
+    sh->last_ev = last_ev0;
+    sh->last_block = last_block0;
     if (e == hipSuccess && rc == TDS_OK && graph) {
       e = hipGraphInstantiate(&sh->graph_exec, graph, nullptr, nullptr, 0);
       if (e != hipSuccess) sh->graph_exec = nullptr;
@@ -876,8 +980,9 @@ int tds_hip_shard_flush(tds_hip_shard_t *sh) {
   if (sh->progress) {  // a wait of the ring exchange that gave up (see tds_ring_wait_kernel)
     unsigned err = 0;
     TDS_HIP_TRY(hipMemcpy(&err, sh->wait_err(), sizeof(err), hipMemcpyDeviceToHost));
-    if (err != 0u) {
+    if (err != 0u || (sh->host_latch && *(volatile unsigned *)sh->host_latch != 0u)) {
       TDS_HIP_TRY(hipMemset(sh->wait_err(), 0, sizeof(err)));
+      if (sh->host_latch) *(volatile unsigned *)sh->host_latch = 0u;
       return fail(TDS_ERR_HIP, "ring exchange: a wait for the step-loop launch timed out — gathered records are not valid");
     }
   }
@@ -887,6 +992,10 @@ int tds_hip_shard_flush(tds_hip_shard_t *sh) {
 int tds_hip_shard_gathered(tds_hip_shard_t *sh, void *consumer_stream, void **records_dev, int *steps_in_block) {
   if (!sh || !records_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
   if (!sh->last_ptr) return fail(TDS_ERR_INVALID_ARG, "no exchange submitted yet");
+  {
+    const int rc = ring_latched(sh);
+    if (rc != TDS_OK) return rc;
+  }
   DeviceGuard guard(sh->sim->device);
   // the consumer's stream waits for the exchange; the host does not
   TDS_HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, sh->last_ev, 0));

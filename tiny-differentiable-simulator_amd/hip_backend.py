@@ -105,6 +105,11 @@ def lib():
         L.tds_hip_shard_ring_plan.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
         L.tds_hip_shard_gathered_offset.argtypes = [C.c_int, C.c_int, C.c_int]
         L.tds_hip_shard_gathered_offset.restype = C.c_longlong
+        L.tds_hip_default_option.argtypes = [C.c_char_p, C.c_longlong]
+        L.tds_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+        L.tds_hip_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+        L.tds_hip_option_name.argtypes = [C.c_int]
+        L.tds_hip_option_name.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -112,8 +117,8 @@ def lib():
 class Rings(C.Structure):
     """tds_hip_rings_t (include/tds_hip.h): per-step record rings of tds_hip_step_many_rings"""
     _fields_ = [("obs_ring", C.c_void_p), ("obs_slots", C.c_int32), ("obs_first", C.c_int32), ("obs_f32", C.c_int32),
-                ("pad0_", C.c_int32), ("y_ring", C.c_void_p), ("y_slots", C.c_int32), ("y_first", C.c_int32),
-                ("progress", C.c_void_p)]
+                ("y_stride", C.c_int32), ("y_ring", C.c_void_p), ("y_slots", C.c_int32), ("y_first", C.c_int32),
+                ("progress", C.c_void_p), ("obs_slot_envs", C.c_int32), ("pad1_", C.c_int32)]
 
 
 EXPORTED_SYMBOLS = [
@@ -130,6 +135,9 @@ EXPORTED_SYMBOLS = [
     "tds_hip_forward_zero_host_end", "tds_hip_step_many_prepare", "tds_hip_step_many",
     "tds_hip_set_graph_chains", "tds_hip_step_many_tune", "tds_hip_step_many_is_loop", "tds_hip_debug_poison_lds",
     "tds_hip_step_many_rings", "tds_hip_step_many_rings_prepare", "tds_hip_step_many_rings_blocks",
+    "tds_hip_default_option", "tds_hip_set_option", "tds_hip_get_option", "tds_hip_option_count", "tds_hip_option_name",
+    "tds_hip_step_host", "tds_hip_reset_host", "tds_hip_set_states", "tds_hip_device_alloc", "tds_hip_device_free",
+    "tds_hip_device_upload", "tds_hip_device_download",
     "tds_hip_shard_rccl_version", "tds_hip_shard_unique_id", "tds_hip_shard_create", "tds_hip_shard_create_all",
     "tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
     "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes", "tds_hip_shard_set_block",
@@ -150,6 +158,35 @@ def shard_ring_plan(chunks_done: int, n_steps: int, act_first: int = 0, act_bloc
         raise TdsHipError("tds_hip_shard_ring_plan: bad arguments")
     keys = ("half", "steps", "step0", "act_first", "slot0", "first_wait")
     return [dict(zip(keys, out[6 * i:6 * i + 6])) for i in range(n)]
+
+
+def default_option(key: str, value) -> None:
+    """process-wide default of a library option for handles created from now on (tds_hip_default_option;
+    None: back to "unset" = environment variable TDS_HIP_<KEY>, else the library's own rule)"""
+    v = -(1 << 63) if value is None else int(value)
+    _check(lib().tds_hip_default_option(key.encode(), v))
+
+
+def option_names():
+    L = lib()
+    return [L.tds_hip_option_name(i).decode() for i in range(L.tds_hip_option_count())]
+
+
+class default_options:
+    """``with default_options(w2=0, no_chain=1): sim = HipSim(...)`` — create-time options for the handles made inside"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            default_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            default_option(k, None)
+        return False
 
 
 def _check(rc):
@@ -197,7 +234,8 @@ class HipSim:
     """
 
     def __init__(self, m: _model.Model, num_envs: int, device: int = 0, dtype: str = "f64",
-                 lanes_per_env: int | None = None, na_cap: int | None = None, _handle=None, _owner=None):
+                 lanes_per_env: int | None = None, na_cap: int | None = None, _handle=None, _owner=None,
+                 options: dict | None = None):
         import torch
 
         if not torch.cuda.is_available():
@@ -216,19 +254,23 @@ class HipSim:
             self.y = self._wrap(lib().tds_hip_y_device(self.h), (self.num_envs, self.output_dim))
             self.use_current_stream()
             return
+        create_opts = {}
         if lanes_per_env is not None:
-            os.environ["TDS_HIP_LANES_PER_ENV"] = str(lanes_per_env)
+            create_opts["lanes_per_env"] = lanes_per_env
         if na_cap is not None:
-            os.environ["TDS_HIP_NA_CAP"] = str(na_cap)
+            create_opts["na_cap"] = na_cap
+        if options:  # create-time options go through the process defaults, run-time ones are set on the new handle
+            ct = ("lanes_per_env", "na_cap", "w2", "gram", "no_chain", "no_rootjoint", "no_kinchain", "no_eulerroot",
+                  "no_legscan", "fold_fixed")
+            create_opts.update({k: v for k, v in options.items() if k in ct})
         h = C.c_void_p()
-        try:
+        with default_options(**create_opts):
             _check(lib().tds_hip_create(C.byref(self.model), self.num_envs, self.device, self.dtype, C.byref(h)))
-        finally:
-            if lanes_per_env is not None:
-                os.environ.pop("TDS_HIP_LANES_PER_ENV", None)
-            if na_cap is not None:
-                os.environ.pop("TDS_HIP_NA_CAP", None)
         self.h = h
+        if options:
+            for k, v in options.items():
+                if k not in create_opts:
+                    self.set_option(k, v)
         self.input_dim = self.model.input_dim
         self.output_dim = self.model.output_dim
         self.x = self._wrap(lib().tds_hip_x_device(self.h), (self.num_envs, self.input_dim))
@@ -256,6 +298,16 @@ class HipSim:
         t = torch.as_tensor(hld, device=f"cuda:{self.device}")
         t._tds_owner = self  # keep the handle alive as long as the view lives
         return t
+
+    def set_option(self, key: str, value) -> None:
+        """run-time option of this handle (tds_hip_set_option; csrc/tds_options.h lists the keys)"""
+        _check(lib().tds_hip_set_option(self.h, key.encode(), -(1 << 63) if value is None else int(value)))
+
+    def get_option(self, key: str):
+        """the option's value, or None while it is unset (library rule)"""
+        v, st = C.c_longlong(0), C.c_int(0)
+        _check(lib().tds_hip_get_option(self.h, key.encode(), C.byref(v), C.byref(st)))
+        return int(v.value) if st.value else None
 
     def use_current_stream(self):
         import torch
@@ -299,8 +351,10 @@ class HipSim:
             r.obs_f32 = 1 if (obs_ring.dtype == torch.float32 and self.torch_dtype != torch.float32) else 0
         if y_ring is not None:
             assert y_ring.is_cuda and y_ring.is_contiguous() and y_ring.dim() == 3 and y_ring.dtype == self.torch_dtype
-            assert tuple(y_ring.shape[1:]) == (self.num_envs, self.output_dim)
+            # (a last dimension beyond output_dim: a padded record stride, tds_hip_rings_t::y_stride)
+            assert int(y_ring.shape[1]) == self.num_envs and int(y_ring.shape[2]) >= self.output_dim
             r.y_ring, r.y_slots, r.y_first = y_ring.data_ptr(), int(y_ring.shape[0]), int(y_first)
+            r.y_stride = int(y_ring.shape[2]) if int(y_ring.shape[2]) != self.output_dim else 0
         if progress is not None:
             assert progress.is_cuda and progress.dtype == torch.int64 and progress.numel() >= 1
             r.progress = progress.data_ptr()
@@ -316,6 +370,11 @@ class HipSim:
         r = self._rings(obs_ring, y_ring, obs_first, y_first, progress)
         f = lib().tds_hip_step_many_rings_prepare if prepare_only else lib().tds_hip_step_many_rings
         _check(f(self.h, ap, nb, int(first_block), int(n_steps), C.byref(r)))
+
+    def step_many_rings_raw(self, actions, n_steps: int, rings: "Rings", first_block: int = 0):
+        """tds_hip_step_many_rings with a hand-filled tds_hip_rings_t (obs_slot_envs, strides ...)"""
+        ap, nb, _ = self._many_args(actions, None)
+        _check(lib().tds_hip_step_many_rings(self.h, ap, nb, int(first_block), int(n_steps), C.byref(rings)))
 
     def rings_blocks(self) -> int:
         """increments of a rings progress counter per completed step (= workgroups of the step-loop launch)"""
@@ -541,7 +600,8 @@ class HipShard:
     [world, block, n_local, obs_dim + 2] in the wire dtype (the current torch stream waits for the exchange)."""
 
     def __init__(self, m: _model.Model, global_envs: int, rank: int = 0, world: int = 1, device: int = 0,
-                 dtype: str = "f64", unique_id: bytes | None = None, wire_dtype: str = "f32", block: int = 1):
+                 dtype: str = "f64", unique_id: bytes | None = None, wire_dtype: str = "f32", block: int = 1,
+                 options: dict | None = None):
         import torch
 
         if not torch.cuda.is_available():
@@ -562,6 +622,8 @@ class HipShard:
         self.sim = HipSim(m, self.n_local, device=device, dtype=dtype,
                           _handle=C.c_void_p(lib().tds_hip_shard_sim(self.h)), _owner=self)
         self.block = 1
+        for k, v in (options or {}).items():  # (run-time options of the shard live in its sim handle)
+            self.sim.set_option(k, v)
         if block != 1:
             self.set_block(block)
 

@@ -13,7 +13,7 @@ import ctypes as C
 import json
 import os
 
-TDS_HIP_ABI_VERSION = 4
+TDS_HIP_ABI_VERSION = 5
 TDS_MAX_LINKS = 64
 TDS_MAX_GEOMS = 32
 TDS_MAX_VISUALS = 64
