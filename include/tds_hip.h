@@ -535,6 +535,16 @@ int tds_hip_last_kernel_ms(tds_hip_sim_t *sim, float *ms);
    barrier 2, after barrier 2, row solves = before barrier 3, after barrier 3).  Synchronises the stream. */
 int tds_hip_profile_phases(tds_hip_sim_t *sim, long long *cycles_host, int n);
 
+/* Host-side counterpart of the reference's SubmitProfileTiming hook (src/base.hpp:39; World::submit_profile_timing,
+   world.hpp:82-86, called around "compute multi body contacts", "solve constraints", "integrate" ..., and
+   MultiBodyConstraintSolver's "inverse_mass_matrix_a", "lcpA", "solve_pgs", mb_constraint_solver.hpp:225-439): runs ONE
+   step of the resident state with the instrumented kernel build and calls fn(zone, microseconds, user) once per zone —
+   the reference's zone names where a phase group of the kernel corresponds to one, "forward_dynamics/..." and
+   "solve constraints/..." sub-zones for the kernel's own phases, "step" for the whole.  Durations are those of workgroup
+   0's instruction stream (shader clock / the device's clock rate).  Synchronises the stream. */
+typedef void (*tds_hip_profile_zone_fn)(const char *zone, double microseconds, void *user);
+int tds_hip_profile_zones(tds_hip_sim_t *sim, tds_hip_profile_zone_fn fn, void *user);
+
 /* Test aid: fills the LDS of every compute unit of the handle's device with a byte pattern (0xFF = NaN in every
    scalar type) by running workgroups that own a whole CU's LDS.  The step kernels never clear LDS, so a read of a slot
    nobody wrote normally sees benign leftovers; after this call it sees the pattern — a forgotten initialisation or a

@@ -58,3 +58,22 @@ def test_options_are_per_handle_and_the_environment_is_only_a_default(built, mon
         ys.append(ring.cpu().numpy())
     assert __import__("conftest").rel_err(ys[0], ys[1]) < 1e-9
     assert w1.get_option("loop_w2") == 0 and w2.get_option("loop_w2") is None
+
+
+@pytest.mark.gpu
+def test_profile_zones_callback_reports_the_reference_zones(built):
+    """tds_hip_profile_zones: the host-side counterpart of the reference's SubmitProfileTiming hook
+    (/root/reference/src/base.hpp:39, world.hpp:82-86, mb_constraint_solver.hpp:225-439)"""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    m = tds_amd.load_model("ant")
+    sim = hip_backend.HipSim(m, 256)
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "ant.npz"))
+    sim.x.copy_(torch.from_numpy(np.resize(g["x"], (256, m.input_dim))).cuda())
+    z = sim.profile_zones()
+    for name in ("compute multi body contacts", "solve constraints", "integrate", "inverse_mass_matrix_a", "lcpA", "solve_pgs",
+                 "forward_dynamics", "step"):
+        assert name in z and z[name] > 0, (name, z)
+    assert z["step"] >= z["solve constraints"] + z["forward_dynamics"] and z["step"] < 1000.0

@@ -1878,6 +1878,41 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   return TDS_OK;
 }
 
+// The reference's profiling hook (src/base.hpp:39 SubmitProfileTiming, called at the start of a zone with its name and
+// at its end with NULL: world.hpp:82-86, 293-366; mb_constraint_solver.hpp:225-247, 396-411, 439, 547-551) cannot be called
+// from inside a kernel.  Its host-side counterpart: ONE step of the handle's state with the instrumented kernel build
+// (tds_hip_profile_phases, one-wavefront form: workgroup 0's dependent chain), then the zones reported one after the
+// other — a zone of the reference where a phase group corresponds to one (same names), the kernel's own phases otherwise.
+int tds_hip_profile_zones(tds_hip_sim_t *s, tds_hip_profile_zone_fn fn, void *user) {
+  if (!s || !fn) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  long long st[TDS_NUM_PHASE_STAMPS];
+  const int rc = tds_hip_profile_phases(s, st, TDS_NUM_PHASE_STAMPS);
+  if (rc != TDS_OK) return rc;
+  int khz = 0;
+  {
+    DeviceGuard guard(s->device);
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, s->device) != hipSuccess || khz <= 0) khz = 2400000;
+  }
+  const double us_per_cycle = 1e3 / (double)khz;
+  auto zone = [&](const char *name, int from, int to) { fn(name, (double)(st[to] - st[from]) * us_per_cycle, user); };
+  // stamps: 0 start | 1 A | 2 B | 3 C | 4 I + M1 + D | 5 E | 6 G | 7 H | 8 F | 9 (sync) | 10 J | 11 K | 12 L | 13 M / N
+  zone("forward_dynamics", 0, 8);                     // env step ahead of World::step: PD, kinematics, M = LDL^T, qdd, integrate_euler_qdd
+  zone("forward_dynamics/load + PD", 0, 1);
+  zone("forward_dynamics/jcalc", 1, 2);
+  zone("forward_dynamics/forward_kinematics", 2, 3);
+  zone("compute multi body contacts", 3, 4);          // world.hpp:324 (+ visual poses and link inertias: same stamp interval)
+  zone("forward_dynamics/composite sweep", 4, 5);
+  zone("inverse_mass_matrix_a", 5, 7);                // mb_constraint_solver.hpp:225 (mass-matrix rows + LDL^T)
+  zone("forward_dynamics/solve", 7, 8);
+  zone("solve constraints", 9, 12);                   // world.hpp:335
+  zone("solve constraints/jacobian rows", 9, 10);
+  zone("lcpA", 10, 11);                               // mb_constraint_solver.hpp:396 (here: the rows z~ = D^-1/2 L^-1 J^T; A is never formed)
+  zone("solve_pgs", 11, 12);                          // mb_constraint_solver.hpp:439
+  zone("integrate", 12, 13);                          // world.hpp:360 (+ output packing, reward / done)
+  zone("step", 0, 13);
+  return TDS_OK;
+}
+
 extern "C++" {
 namespace {
 __global__ void tds_poison_lds_kernel(unsigned pattern, int words, unsigned *sink) {

@@ -1197,6 +1197,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // which wavefront of the workgroup (scalar: every branch on it is a uniform branch)
   const int wv = W2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   const bool main_wave = !W2 || wv == 0;
+#ifdef TDS_X_SETPRIO
+  // experiment: the main wavefront is the workgroup's critical path, the helper has slack — where a main and a helper
+  // wavefront (of different workgroups) share a SIMD, the arbiter should issue the main one first
+  if constexpr (W2) {
+    if (wv == 0) __builtin_amdgcn_s_setprio(TDS_X_SETPRIO);
+  }
+#endif
 
   // ---- A0. the x record (and the fresh actions) are requested from HBM first: their latency runs under the
   //      fetch of the model constants below; dimensions from the kernel arguments, not from the model

@@ -136,7 +136,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_set_graph_chains", "tds_hip_step_many_tune", "tds_hip_step_many_is_loop", "tds_hip_debug_poison_lds",
     "tds_hip_step_many_rings", "tds_hip_step_many_rings_prepare", "tds_hip_step_many_rings_blocks",
     "tds_hip_default_option", "tds_hip_set_option", "tds_hip_get_option", "tds_hip_option_count", "tds_hip_option_name",
-    "tds_hip_step_host", "tds_hip_reset_host", "tds_hip_set_states", "tds_hip_device_alloc", "tds_hip_device_free",
+    "tds_hip_profile_zones", "tds_hip_step_host", "tds_hip_reset_host", "tds_hip_set_states", "tds_hip_device_alloc", "tds_hip_device_free",
     "tds_hip_device_upload", "tds_hip_device_download",
     "tds_hip_shard_rccl_version", "tds_hip_shard_unique_id", "tds_hip_shard_create", "tds_hip_shard_create_all",
     "tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
@@ -371,10 +371,41 @@ class HipSim:
         f = lib().tds_hip_step_many_rings_prepare if prepare_only else lib().tds_hip_step_many_rings
         _check(f(self.h, ap, nb, int(first_block), int(n_steps), C.byref(r)))
 
+    def prepared_step_many_rings(self, actions, n_steps: int, obs_ring=None, y_ring=None, first_block: int = 0,
+                                 obs_first: int = 0, y_first: int = 0):
+        """step_many_rings with every argument marshalled NOW: returns a callable whose body is the one C call (a
+        20-step timed region is 0.3 ms — tens of microseconds of Python argument checking inside it are a tenth of it).
+        Builds the graphs of the graph form as well (tds_hip_step_many_rings_prepare)."""
+        ap, nb, _ = self._many_args(actions, None)
+        r = self._rings(obs_ring, y_ring, obs_first, y_first, None)
+        L, h, fb, ns, rr = lib(), self.h, int(first_block), int(n_steps), C.byref(r)
+        _check(L.tds_hip_step_many_rings_prepare(h, ap, nb, fb, ns, rr))
+        keep = (actions, obs_ring, y_ring, r)  # (the tensors and the struct must outlive the callable)
+
+        def call(_f=L.tds_hip_step_many_rings, _keep=keep):
+            if _f(h, ap, nb, fb, ns, rr) != TDS_OK:
+                _check(-1)
+
+        return call
+
     def step_many_rings_raw(self, actions, n_steps: int, rings: "Rings", first_block: int = 0):
         """tds_hip_step_many_rings with a hand-filled tds_hip_rings_t (obs_slot_envs, strides ...)"""
         ap, nb, _ = self._many_args(actions, None)
         _check(lib().tds_hip_step_many_rings(self.h, ap, nb, int(first_block), int(n_steps), C.byref(rings)))
+
+    def profile_zones(self) -> dict:
+        """one instrumented step, reported through the SubmitProfileTiming-shaped callback (tds_hip_profile_zones):
+        {zone name: microseconds}"""
+        out = {}
+        FN = C.CFUNCTYPE(None, C.c_char_p, C.c_double, C.c_void_p)
+
+        def cb(name, us, _user):
+            out[name.decode()] = float(us)
+
+        f = FN(cb)
+        lib().tds_hip_profile_zones.argtypes = [C.c_void_p, FN, C.c_void_p]
+        _check(lib().tds_hip_profile_zones(self.h, f, None))
+        return out
 
     def rings_blocks(self) -> int:
         """increments of a rings progress counter per completed step (= workgroups of the step-loop launch)"""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One rank through the ring exchange (tds_hip_shard_step_many), nothing else: for rocprofv3 --kernel-trace.
-usage: python tools/trace_ring_exchange.py [rccl=1] [n=4096] [chunks=4]"""
+usage: python tools/trace_ring_exchange.py [rccl=1] [n=4096] [chunks=4] [key=value ...]   (library options of the shard)"""
 import os
 import sys
 
@@ -23,7 +23,8 @@ x0[:, 2] = 0.48
 x0[:, 6:m.dof_q] = ip + 0.05 * rng.uniform(-1, 1, (n, m.dof_q - 6))
 x0[:, -3:] = [15, 0.3, 3]
 uid = hip_backend.HipShard.unique_id() if rccl else None
-sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype="f32")
+opts = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[4:] if "=" in a}
+sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype="f32", options=opts)
 sh.sim.x.copy_(torch.from_numpy(x0).cuda())
 acts = torch.from_numpy(rng.uniform(-0.4, 0.4, (16, n, m.action_dim))).cuda().contiguous()
 for _ in range(chunks):
