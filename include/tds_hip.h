@@ -390,13 +390,16 @@ int tds_hip_step_many_is_loop(const tds_hip_sim_t *sim, int n_steps);
    auto-reset on, a step that ends with done leaves reward / done of the terminal step and the observation of the fresh
    environment in its slot, as the reference does.  Afterwards the handle's y record holds the last step's (a device
    copy of its slot).  This is the form bench.py times: all of step_forward_original's work, every step.
-     progress  optional, step-loop form only, not with auto-reset (those calls are cut into several launches): a device
-               counter every workgroup increments once its OBS-RING record of step k is visible device-wide (signalled
-               while step k + 1 runs; not for the last step of the call: stream order covers it) — what
-               tds_hip_shard_step_many polls to exchange slot k while the launch carries on.  It covers the obs ring
+     progress  optional, step-loop form only, not with auto-reset (those calls are cut into several launches): an array
+               of obs_slots device counters, one per slot of the obs ring.  Every workgroup adds 1 to the counter of
+               step k's slot once its OBS-RING record of that step is visible device-wide (signalled while step k + 1
+               runs; not for the last step of the call: stream order covers it): the slot's counter has grown by
+               tds_hip_step_many_rings_blocks exactly when EVERY workgroup has stored that step — what
+               tds_hip_shard_step_many polls to exchange slot k while the launch carries on (a single running total
+               would be reached by the average workgroup while the slowest is steps behind).  It covers the obs ring
                only: the y ring is written with streaming stores that become visible to other agents at the end of the
                launch (nothing exchanges y records; read them behind the launch in stream order).
-               tds_hip_step_many_rings_blocks = increments per completed step.
+               tds_hip_step_many_rings_blocks = increments of a slot's counter per use of the slot.
      y_stride  scalars between consecutive y records of the y ring (0: output_dim, i.e. packed).  A stride that is a
                multiple of the 128-byte line (Ant, f64: 160 instead of 155) lets every record start on a line boundary:
                the ring launch then writes whole lines only (measured: HBM write traffic per step down to the payload).
@@ -639,6 +642,10 @@ long long tds_hip_shard_gathered_offset(int global_env, int n_local, int width);
 /* Exchange a partially filled block, then wait (host) until every exchange in flight has completed. */
 int tds_hip_shard_flush(tds_hip_shard_t *shard);
 int tds_hip_shard_gathered(tds_hip_shard_t *shard, void *consumer_stream, void **records_dev, int *steps_in_block);
+/* Ring exchange only: the gathered records [world][n_local][obs_dim + 2] of the step `steps_back` steps before the most
+   recently submitted one (0: what tds_hip_shard_gathered returns), as long as it lies inside the most recently submitted
+   step-loop launch (its slots are still in the ring); the consumer's stream waits for that launch's exchanges. */
+int tds_hip_shard_gathered_step(tds_hip_shard_t *shard, int steps_back, void *consumer_stream, void **records_dev);
 
 /* ======================================================================================
  * Free rigid bodies: World::step for worlds that hold tds::RigidBody

@@ -359,7 +359,7 @@ def test_shard_ring_exchange_on_one_rank(with_rccl, submit, wire, built, monkeyp
         got = sh.gathered().clone()
         # (a launch whose slots are exchanged while it runs uses the one-wave step-loop build; so does one that is handed a
         #  progress counter — the same build on both sides: bit for bit)
-        ref.step_many_rings(a, K, ring, None, first_block=1, progress=torch.zeros(1, dtype=torch.int64, device="cuda"))
+        ref.step_many_rings(a, K, ring, None, first_block=1, progress=torch.zeros(K, dtype=torch.int64, device="cuda"))
         sh.flush()
         torch.cuda.synchronize()
         assert tuple(got.shape) == (1, 1, n, ref.obs_dim + 2) and got.dtype == wdt
@@ -438,3 +438,36 @@ def test_shard_step_many_with_auto_reset_steps_eagerly(built):
     assert torch.equal(many.gathered().view(torch.int64), one.gathered().view(torch.int64))
     one.close()
     many.close()
+
+
+@pytest.mark.parametrize("build", ["one_wave", "two_wave"])
+def test_ring_exchange_sends_a_slot_only_when_the_slowest_workgroup_has_stored_it(build, built):
+    """The workgroups of a step-loop launch run at their own pace: here half of the environments fly (no contact: their
+    wavefronts skip the whole constraint pipeline and run far ahead), the other half stand on the ground.  The exchange of
+    step k follows the counter of step k's OWN ring slot (tds_hip_rings_t::progress[slot]), which is complete only when
+    every workgroup has stored that step — every intermediate slot the communication stream copied while the launch was
+    running must hold the final records (round 3 followed one running total per launch: reached by the AVERAGE
+    workgroup).  shard_inplace = 0 + no communicator: the exchange of a slot is a device copy made at the moment its wait
+    fires, i.e. a snapshot of what had been stored by then."""
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    n, K = 4096, 64
+    x, acts = _start(m, n, seed=3)
+    x[: n // 2, 2] = 6.0  # the first half of the batch starts 6 m above the plane: airborne for the whole launch
+    a = torch.from_numpy(acts).cuda().contiguous()
+    opts = {"shard_inplace": 0, "exchange_w2": 1 if build == "two_wave" else 0}
+    sh = hip_backend.HipShard(m, n, unique_id=None, wire_dtype="f64", options=opts)
+    ref = hip_backend.HipSim(m, n, options={"exchange_w2": opts["exchange_w2"]})
+    for s in (sh.sim, ref):
+        s.x.copy_(torch.from_numpy(x).cuda())
+    ring = torch.zeros((K, n, ref.obs_dim + 2), dtype=torch.float64, device="cuda")
+    ref.step_many_rings(a, K, ring, None, first_block=2, progress=torch.zeros(K, dtype=torch.int64, device="cuda"))
+    sh.step_many(a, K, first_block=2)
+    sh.flush()
+    torch.cuda.synchronize()
+    for back in range(K):
+        got = sh.gathered_step(back)
+        assert torch.equal(got[0].view(torch.int64), ring[K - 1 - back].view(torch.int64)), (build, K - 1 - back)
+    # (the airborne half did stay airborne, i.e. the two halves did run at different paces)
+    assert float(ref.x[: n // 2, 2].min()) > 1.0
+    sh.close()

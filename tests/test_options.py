@@ -45,7 +45,7 @@ def test_options_are_per_handle_and_the_environment_is_only_a_default(built, mon
     # two handles with different step-loop builds in ONE process: same records to round-off
     g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "ant.npz"))
     n = 64
-    x = torch.from_numpy(g["x"][:n]).cuda()
+    x = torch.from_numpy(np.resize(g["x"], (n, m.input_dim))).cuda()
     act = torch.from_numpy(np.random.default_rng(0).uniform(-0.4, 0.4, (4, n, m.action_dim))).cuda().contiguous()
     w2 = hip_backend.HipSim(m, n)
     w1 = hip_backend.HipSim(m, n, options={"loop_w2": 0})

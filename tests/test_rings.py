@@ -99,16 +99,17 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
     obs_ring = torch.full((steps, obs_envs, ow), float("nan"), dtype=tdt, device="cuda")
     y_ring = torch.full((steps, n, ystr), float("nan"), dtype=tdt, device="cuda")
     x_start = sim.x.cpu().numpy().astype(np.float64)
-    progress = torch.zeros(1, dtype=torch.int64, device="cuda") if form.startswith("exchange") else None
+    progress = torch.zeros(steps, dtype=torch.int64, device="cuda") if form.startswith("exchange") else None  # one per slot
     if form == "exchange_inplace":
-        r = sim._rings(None, y_ring, 0, 0, progress)
+        r = sim._rings(None, y_ring, 0, 0, None)
         r.obs_ring, r.obs_slots, r.obs_first, r.obs_slot_envs = obs_ring[0, n:].data_ptr(), steps, 0, obs_envs
+        r.progress = progress.data_ptr()
         sim.step_many_rings_raw(actions, steps, r)
     else:
         sim.step_many_rings(actions, steps, obs_ring, y_ring, progress=progress)
     torch.cuda.synchronize()
-    if progress is not None:  # every workgroup counts itself in once per step but the last
-        assert int(progress.item()) == (steps - 1) * sim.rings_blocks()
+    if progress is not None:  # every workgroup counts itself in on the slot's own counter, once per step but the last
+        assert (progress[:-1] == sim.rings_blocks()).all() and int(progress[-1].item()) == 0
     if form == "exchange_inplace":
         assert torch.isnan(obs_ring[:, :n]).all()  # (the other rank's blocks are untouched)
         obs_ring = obs_ring[:, n:]
@@ -219,7 +220,8 @@ def test_ring_slots_equal_single_step_records(name, dtype, built):
 @pytest.mark.parametrize("name", ["ant", "pendulum5"])
 def test_float_obs_ring_beside_double_records_and_the_progress_counter(name, built):
     """the wire format of the multi-GPU exchange: a float obs ring written by the step-loop launch of an f64 handle, and
-    the progress counter the exchange polls (one increment per workgroup and completed step, the last step excepted)"""
+    the progress counters the exchange polls (per ring slot: one increment per workgroup and completed step, the last step
+    excepted)"""
     torch = _torch()
     m = tds_amd.load_model(name)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
@@ -235,13 +237,13 @@ def test_float_obs_ring_beside_double_records_and_the_progress_counter(name, bui
     actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (3, n, m.action_dim))).cuda().contiguous()
     ring32 = torch.zeros((steps, n, sim.obs_dim + 2), dtype=torch.float32, device="cuda")
     ring64 = torch.zeros((steps, n, sim.obs_dim + 2), dtype=torch.float64, device="cuda")
-    progress = torch.zeros(1, dtype=torch.int64, device="cuda")
+    progress = torch.zeros(ring32.shape[0], dtype=torch.int64, device="cuda")  # one counter per ring slot
     sim.step_many_rings(actions, steps, ring32, None, progress=progress)
     # (a progress counter selects the one-wave step-loop build; both launches get one, so that they are the same build)
-    sim2.step_many_rings(actions, steps, ring64, None, progress=torch.zeros(1, dtype=torch.int64, device="cuda"))
+    sim2.step_many_rings(actions, steps, ring64, None, progress=torch.zeros(ring64.shape[0], dtype=torch.int64, device="cuda"))
     torch.cuda.synchronize()
     assert torch.equal(ring32, ring64.to(torch.float32))
-    assert int(progress.item()) == (steps - 1) * sim.rings_blocks()
+    assert int(progress.sum().item()) == (steps - 1) * sim.rings_blocks()
     assert torch.equal(sim.x, sim2.x)
 
 

@@ -60,7 +60,7 @@ if mode == "single" or not ref.step_many_is_loop(steps) or os.environ.get("TDS_H
 else:
     ring = torch.zeros((steps, n_local, ref.obs_dim + 2), dtype=torch.float64, device="cuda")
     # (a progress counter selects the one-wave step-loop build, the one exchange launches use: same build, same bits)
-    ref.step_many_rings(acts, steps, ring, None, progress=torch.zeros(1, dtype=torch.int64, device="cuda"))
+    ref.step_many_rings(acts, steps, ring, None, progress=torch.zeros(steps, dtype=torch.int64, device="cuda"))
     obs = ring[-1]
 torch.cuda.synchronize()
 np.savez(out, gathered=gat.cpu().numpy(), local=obs.to(torch.float32).cpu().numpy(), x=sim.x.cpu().numpy(), xref=ref.x.cpu().numpy())

@@ -94,6 +94,7 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
            int reset_mode, const unsigned char *mask, const Rollout *ro, int ctl_flags, const LaunchOpts *opts) {
   TdsStepCtl ctl;
   memset(&ctl, 0, sizeof(ctl));
+  bool y_stride_set = false;
   if (opts && opts->extra) {  // work-list / reset-pool fields of a straight-line launch
     ctl.pool = opts->extra->pool;
     ctl.pool_depth = opts->extra->pool_depth;
@@ -169,10 +170,12 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
       // every workgroup: + 9 us per 4096-environment step (profiles/r03_ring_exchange_forms.txt).
       const bool nofence = s->opt.get(TDS_OPT_RING_NOFENCE, 1) == 1;
       if (r.progress && nofence) ctl.ring_flags |= TDS_RING_NOFENCE;
+      if (r.progress && s->opt.get(TDS_OPT_RING_SIGNAL_LATE, 0) == 1) ctl.ring_flags |= TDS_RING_SIGNAL_LATE;
     }
     if (r.y_ring) {
       ctl.y_stride = r.y_stride > 0 ? r.y_stride : s->model.output_dim;
       ctl.y_ring = (char *)r.y_ring + e0 * ctl.y_stride * s->elem;
+      y_stride_set = true;
       ctl.y_slots = r.y_slots;
       ctl.y_first = (r.y_first + opts->ring_step0) % r.y_slots;
     }
@@ -180,6 +183,7 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     ctl.progress = r.progress;
   }
   if (opts && !opts->rings && opts->y_stride > 0) ctl.y_stride = opts->y_stride;
+  else if (!y_stride_set) ctl.y_stride = s->model.output_dim;  // (the kernels read the stride as it is: never 0)
   ctl.flags |= ctl_flags;
   ctl.nsub = nsub;
   ctl.reset_mode = reset_mode;
@@ -767,6 +771,7 @@ int pool_fill(tds_hip_sim *s) {
   TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->pool_sync_ev, 0));
   s->pool_step = 0;
   s->pool_waited = 0;
+  s->pool_run_pending = false;  // (the wait above covers every pass issued before it: the pool stream is in order)
   s->pool_ready = true;
   return TDS_OK;
 }
@@ -856,27 +861,19 @@ int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int 
   const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
   for (int done = 0; done < n_steps;) {
     const int k = n_steps - done < R ? n_steps - done : R;
-    bool pass = false;
-    if (s->pool_planned) {
-      TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
-      rc = pool_run(s, s->pool_sync_ev);
-      if (rc != TDS_OK) return rc;
-      s->pool_planned = 0;
-      pass = true;
-      while (*s->h_pool_nitems > s->pool_cap) {  // the work list was cut short: the rings must be FULL before the launch
-        rc = pool_plan(s);
-        if (rc != TDS_OK) return rc;
-        TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
-        rc = pool_run(s, s->pool_sync_ev);
-        if (rc != TDS_OK) return rc;
-      }
+    // Order of the host calls (round 4): the chunk goes out FIRST, the refill pass behind the previous chunk afterwards,
+    // beside it on the pool stream.  Round 3 issued the pass (plan sync, stage, settle launches, scatter: ~17 runtime
+    // calls) in front of the chunk: ~100 us of host time during which a caller that synchronises between calls — a
+    // 20-step benchmark region — left the GPU idle (auto-reset rate 0.80 of the plain rate at 20 steps per call).
+    //     chunk j     waits for the pass issued behind chunk j - 1 (planned behind chunk j - 2: rings full up to there)
+    //     then        run the pass planned behind chunk j - 1, plan the one behind chunk j
+    // A chunk consumes at most R entries of a ring and starts with everything refilled that was consumed before the
+    // chunk in front of it: D >= R + slack entries cannot run dry; a pass only overwrites slots consumed before it was
+    // planned.  Results are those of resetting inside the step, whatever the rate of resets.
+    if (s->pool_run_pending) {
+      TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->pool_sync_ev, 0));
+      s->pool_run_pending = false;
     }
-    if (s->pool_many_chunks > 0) {
-      rc = pool_plan(s);
-      if (rc != TDS_OK) return rc;
-      s->pool_planned = 1;
-    }
-    if (pass) TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->pool_sync_ev, 0));
     LaunchOpts o;
     o.extra = &extra;
     o.rings = rings;
@@ -894,6 +891,23 @@ int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int 
     if (rc != TDS_OK) return rc;
     ++s->pool_many_chunks;
     done += k;
+    if (s->pool_planned) {  // the pass planned behind the chunk before this one: its size has long reached the host
+      TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
+      rc = pool_run(s, s->pool_sync_ev);
+      if (rc != TDS_OK) return rc;
+      s->pool_planned = 0;
+      s->pool_run_pending = true;
+      while (*s->h_pool_nitems > s->pool_cap) {  // the work list was cut short: the rings must be FULL before the next launch
+        rc = pool_plan(s);                       // (planned behind the chunk just launched: the host waits for it here)
+        if (rc != TDS_OK) return rc;
+        TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
+        rc = pool_run(s, s->pool_sync_ev);
+        if (rc != TDS_OK) return rc;
+      }
+    }
+    rc = pool_plan(s);  // what this chunk and the ones before it have consumed: run behind the NEXT chunk's launch
+    if (rc != TDS_OK) return rc;
+    s->pool_planned = 1;
   }
   return TDS_OK;
 }
@@ -1853,6 +1867,7 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   TdsStepCtl ctl;
   memset(&ctl, 0, sizeof(ctl));
   ctl.nsub = 1;
+  ctl.y_stride = s->model.output_dim;
   if (s->opt.is_set(TDS_OPT_GRAM_STAMP_AT)) ctl.flags |= (int)s->opt.v[TDS_OPT_GRAM_STAMP_AT] << 8;  // (stamp 10 inside tds_gram_solve)
   int rc;
   if (s->dtype == TDS_DTYPE_F64)

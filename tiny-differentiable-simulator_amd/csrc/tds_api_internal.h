@@ -56,6 +56,7 @@ struct tds_hip_sim {
   long long pool_planned = 0;  // pass whose work list has been planned but not launched yet (0: none)
   long long pool_planned_at = 0;
   bool pool_many = false;      // the pool is on the pass schedule of step_many (pool_step_many), not of single steps
+  bool pool_run_pending = false;  // ... a pass has been issued on the pool stream that the next chunk must wait for (pool_sync_ev)
   long long pool_many_chunks = 0;
   bool pool_ready = false;     // false: fill the pool completely before the next auto-reset step
   bool pool_discard = true;    // the entries in the rings are void (first use, new seed): start from empty rings

@@ -68,15 +68,20 @@ struct TdsStepCtl {
   int obs_envs;               // environments per slot of the obs ring (>= ring_envs: a slot laid out for all ranks)
   int ring_flags;             // TDS_RING_OBS_F32: the obs ring holds floats whatever the record dtype (wire format of the
                               // multi-GPU exchange: the slot is handed to ncclAllGather as it is)
-  // != NULL: every workgroup adds 1 once its records of step k are visible device-wide — signalled from inside step
-  // k + 1 (the stores have long drained by then: no wait on the step's own path), never for the last step of a launch
-  // (kernel completion covers it).  What a communication stream polls to send ring slot k while the launch carries on.
+  // != NULL: [obs_slots] counters, one per slot of the obs ring: every workgroup adds 1 to the counter of step k's slot
+  // once its records of that step are visible device-wide — signalled from inside step k + 1 (the stores have long
+  // drained by then: no wait on the step's own path), never for the last step of a launch (kernel completion covers
+  // it).  What a communication stream polls to send ring slot k while the launch carries on.
   unsigned long long *progress;
 };
 #define TDS_RING_OBS_F32 1
 // the obs ring is written with device-scope write-through stores (sc1) and a step is signalled after a plain
 // s_waitcnt vmcnt(0) — no release fence, whose buffer_wbl2 writes back every dirty line of the L2
 #define TDS_RING_NOFENCE 2
+// two-wavefront step-loop build: the helper wavefront counts the records of step k in at the top of its iteration k + 2,
+// where it waits for the main wavefront's kinematics anyway (instead of in the middle of iteration k + 1, where its wait
+// for the stores' acknowledgement sits in front of the workgroup barrier the main wavefront arrives at next)
+#define TDS_RING_SIGNAL_LATE 4
 
 // which build of the step kernel a launch takes (tds_launch_step's `form`)
 #define TDS_FORM_W2 1         // L is the w2 layout: launch the two-wavefront form (plain kernels)

@@ -1504,7 +1504,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // (a y RING may have a record stride beyond output_dim — TdsStepCtl::y_stride, records on 128-byte line boundaries: the
   //  zero padding then runs to the stride, so that a record's last line is written whole)
   //  (straight-line launches pointed at a ring slot — the graph form of tds_hip_step_many_rings — take the stride for y_out)
-  const int ystr = ((LOOP ? ring_y : true) && ctl.y_stride > 0) ? ctl.y_stride : out_dim;
+  //  (the host sets ctl.y_stride on EVERY launch — output_dim where nothing else was asked for: no select here)
+  const int ystr = ctl.y_stride;
   auto put_y_state = [&](TR *yo, int yend) {  // q | qd | (visual poses: phase M1) | up.z | zero padding, from the LDS record
     for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)xr[i], &yo[i]);
     int tail = nq + nd;
@@ -1536,13 +1537,19 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   };
   // the previous step's records are visible device-wide: count this workgroup in (TdsStepCtl::progress — what the exchange
   // of the multi-GPU layer polls, tds_shard.hip).  Called by the wavefront that stored them, half a step later.
-  auto signal_progress = [&]() {
-    if (ctl.progress != nullptr && tds_iter > 0) {  // wave-uniform
+  // One counter PER RING SLOT (progress[slot]): the workgroups of a launch run at their own pace — a wavefront whose
+  // environments carry more contacts falls steps behind the others over a long launch — so a single running total says
+  // nothing about the slowest workgroup; the slot's own counter reaches (uses of the slot) x (workgroups) exactly when
+  // EVERY workgroup has stored its records of that step.
+  auto signal_progress = [&](int back = 1) {  // counts in the records of step tds_iter - back
+    if (ctl.progress != nullptr && tds_iter >= back) {  // wave-uniform
       if (ctl.ring_flags & TDS_RING_NOFENCE)
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the obs ring's write-through stores have reached the L2 / memory
       else
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctl.progress, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int pslot = (ctl.obs_first + tds_iter - back) % ctl.obs_slots;
+      if ((threadIdx.x & 63) == 0)
+        __hip_atomic_fetch_add(ctl.progress + pslot, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   const bool pack_y = ring_y ? (valid && mode == TDS_MODE_RUN) : (last_run && y_out != nullptr);
@@ -1939,6 +1946,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       //  wavefront's dependent chain nothing but the reward block)
       if constexpr (LOOP) load_phase_consts(mdl);
       TDS_STAMP(1);
+      if constexpr (LOOP) {  // (TDS_RING_SIGNAL_LATE: the records stored in the iteration before this one)
+        if (ctl.ring_flags & TDS_RING_SIGNAL_LATE) signal_progress(2);
+      }
       __syncthreads();  // (1) the main wavefront has written the x record, X_world and the motion axes
       TDS_STAMP(2);
       T *const cpx = E + L.cp;
@@ -1987,7 +1997,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                              L.gram_ok ? nullptr : xr + in_dim + 4, dt,
                                              PIPE ? xr + in_dim + 5 : nullptr, PIPE ? E + L.Lh : nullptr);
       TDS_STAMP(7);
-      if constexpr (LOOP) signal_progress();  // (the records this wavefront stored behind the visual poses)
+      if constexpr (LOOP) {  // (the records this wavefront stored behind the visual poses)
+        if (!(ctl.ring_flags & TDS_RING_SIGNAL_LATE) || last_run) signal_progress();
+      }
       __syncthreads();  // (3) z~ rows and their scalars are final
       TDS_STAMP(8);
       if constexpr (LOOP) {

@@ -49,6 +49,8 @@ enum TdsOptKey {
   TDS_OPT_SHARD_WAIT,         // how the communication stream follows the progress counter: 0 wait kernel, 1 hipStreamWaitValue64 (default where supported)
   TDS_OPT_SHARD_INPLACE,      // 1 (default): the launch stores its records straight into its own block of the gathered buffer (in-place all-gather)
   TDS_OPT_SHARD_REGISTER,     // 1 (default): ncclCommRegister the ring buffers where librccl offers it
+  TDS_OPT_SHARD_CHUNK,        // steps per step-loop launch of the ring exchange (default 64; read when the ring is first used)
+  TDS_OPT_RING_SIGNAL_LATE,   // experiment: 1 = the helper wavefront counts a step in at the top of its NEXT iteration
   TDS_OPT_COUNT
 };
 
@@ -97,6 +99,8 @@ inline const TdsOptRow *tds_opt_rows() {
       {"shard_wait", false, "TDS_HIP_SHARD_WAIT"},
       {"shard_inplace", false, "TDS_HIP_SHARD_INPLACE"},
       {"shard_register", false, "TDS_HIP_SHARD_REGISTER"},
+      {"shard_chunk", false, "TDS_HIP_SHARD_CHUNK"},
+      {"ring_signal_late", false, "TDS_HIP_RING_SIGNAL_LATE"},
   };
   return rows;
 }

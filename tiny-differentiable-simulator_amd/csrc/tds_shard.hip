@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <new>
+#include <vector>
 
 #include "tds_api_internal.h"
 #include "tds_shard_plan.h"
@@ -152,13 +153,15 @@ struct tds_hip_shard {
   int ry_stride = 0;       // scalars per y record in `ry` (padded to whole 128-byte lines; option y_stride)
   bool inplace = false;    // the launch stores its records into ITS block of rgath; the all-gather is in place
   void *reg_handle = nullptr;  // ncclCommRegister handle of rgath
-  // one counter per ring half, + the error latch behind them.  The counters are NEVER reset: a launch of c steps adds
-  // (c - 1) n_blocks, the host keeps the running base of each half (prog_base) — no memset between launches
+  // one counter per RING SLOT (2 chunk of them), + the error latch behind them.  The counters are NEVER reset: every use
+  // of a slot adds n_blocks to its counter, the host keeps the number of uses (slot_uses) — no memset between launches
   unsigned long long *progress = nullptr;
-  unsigned long long prog_base[2] = {0ull, 0ull};
+  std::vector<unsigned long long> slot_uses;
   unsigned *host_latch = nullptr;  // pinned: raised by a wait that gave up (checked by every later call of the shard)
   bool wait_value = false;         // the waits are hipStreamWaitValue64 commands instead of wait kernels
   bool ring_ready = false;         // ring_alloc has completed (a failed allocation is undone as a whole)
+  int chunk = TDS_SHARD_CHUNK;     // steps per step-loop launch of the ring exchange (option shard_chunk, read at ring_alloc)
+  int last_ring_slot0 = -1, last_ring_steps = 0, last_ring_half = 0;  // the most recently submitted launch of the ring exchange
   hipEvent_t ev_kernel[2] = {}, ev_comm[2] = {};
   hipEvent_t cap_fork = nullptr, cap_kernel = nullptr, cap_comm = nullptr;  // the same roles inside a stream capture
   bool comm_pending[2] = {};
@@ -177,7 +180,7 @@ struct tds_hip_shard {
 
   size_t block_scalars() const { return (size_t)block * n_local * sim->obs_width(); }
   size_t slot_scalars() const { return (size_t)n_local * sim->obs_width(); }
-  unsigned *wait_err() const { return (unsigned *)(progress + 2); }
+  unsigned *wait_err() const { return (unsigned *)(progress + 2 * (size_t)chunk); }
 };
 
 namespace {
@@ -319,12 +322,17 @@ int ring_alloc_impl(tds_hip_shard *sh) {
   // sendbuff == recvbuff + rank * count.  On one rank nothing is left to move at all; on G ranks the local block is
   // neither copied nor sent to itself.  (option shard_inplace = 0: separate send ring, as in round 3)
   sh->inplace = s->opt.get(TDS_OPT_SHARD_INPLACE, 1) != 0;
-  if (!sh->inplace) {
-    TDS_HIP_TRY(hipMalloc(&sh->rwire, 2 * TDS_SHARD_CHUNK * slot_b));
-    TDS_HIP_TRY(hipMemset(sh->rwire, 0, 2 * TDS_SHARD_CHUNK * slot_b));
+  {
+    long long c = s->opt.get(TDS_OPT_SHARD_CHUNK, TDS_SHARD_CHUNK);
+    sh->chunk = (int)(c < 8 ? 8 : (c > TDS_SHARD_CHUNK_MAX ? TDS_SHARD_CHUNK_MAX : c));
   }
-  TDS_HIP_TRY(hipMalloc(&sh->rgath, 2 * TDS_SHARD_CHUNK * slot_b * sh->world));
-  TDS_HIP_TRY(hipMemset(sh->rgath, 0, 2 * TDS_SHARD_CHUNK * slot_b * sh->world));
+  const size_t ring_slots = 2 * (size_t)sh->chunk;
+  if (!sh->inplace) {
+    TDS_HIP_TRY(hipMalloc(&sh->rwire, ring_slots * slot_b));
+    TDS_HIP_TRY(hipMemset(sh->rwire, 0, ring_slots * slot_b));
+  }
+  TDS_HIP_TRY(hipMalloc(&sh->rgath, ring_slots * slot_b * sh->world));
+  TDS_HIP_TRY(hipMemset(sh->rgath, 0, ring_slots * slot_b * sh->world));
   // y records on 128-byte line boundaries (the launch then writes whole lines only)
   {
     const int per_line = 128 / (int)s->elem;
@@ -333,9 +341,9 @@ int ring_alloc_impl(tds_hip_shard *sh) {
     sh->ry_stride = ys;
   }
   TDS_HIP_TRY(hipMalloc(&sh->ry, (size_t)TDS_SHARD_Y_SLOTS * sh->n_local * sh->ry_stride * s->elem));
-  TDS_HIP_TRY(hipMalloc((void **)&sh->progress, 4 * sizeof(unsigned long long)));
-  TDS_HIP_TRY(hipMemset(sh->progress, 0, 4 * sizeof(unsigned long long)));
-  sh->prog_base[0] = sh->prog_base[1] = 0ull;
+  TDS_HIP_TRY(hipMalloc((void **)&sh->progress, (ring_slots + 2) * sizeof(unsigned long long)));
+  TDS_HIP_TRY(hipMemset(sh->progress, 0, (ring_slots + 2) * sizeof(unsigned long long)));
+  sh->slot_uses.assign(ring_slots, 0ull);
   TDS_HIP_TRY(hipHostMalloc((void **)&sh->host_latch, sizeof(unsigned), hipHostMallocMapped));
   *sh->host_latch = 0u;
   for (int i = 0; i < 2; ++i) {
@@ -357,7 +365,7 @@ int ring_alloc_impl(tds_hip_shard *sh) {
   }
   // user-buffer registration of the receive ring (RCCL >= 2.19; harmless where the transport ignores it)
   if (sh->comm && s->opt.get(TDS_OPT_SHARD_REGISTER, 1) != 0 && rccl() && rccl()->CommRegister) {
-    if (rccl()->CommRegister(sh->comm, sh->rgath, 2 * TDS_SHARD_CHUNK * slot_b * sh->world, &sh->reg_handle) != ncclSuccess)
+    if (rccl()->CommRegister(sh->comm, sh->rgath, ring_slots * slot_b * sh->world, &sh->reg_handle) != ncclSuccess)
       sh->reg_handle = nullptr;  // (not fatal: the collective works on unregistered buffers)
   }
   return TDS_OK;
@@ -419,16 +427,15 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
     TDS_HIP_TRY(hipStreamWaitEvent(s->stream, sh->ev_comm[h], 0));
     sh->comm_pending[h] = false;
   }
-  // The counters are never reset in the eager form: the waits of this launch target base + (k + 1) n_blocks, which no
-  // earlier launch can have reached — no fill kernel, no fork event between the two streams (round 3 had both per
-  // launch).  A captured chunk must replay with fixed targets: it zeroes its counter first, and forks the communication
-  // stream off the capture's origin.
-  unsigned long long base = sh->prog_base[h];
+  // The counters are never reset in the eager form: the wait for step k targets (uses of its slot so far + 1) n_blocks,
+  // which no earlier launch can have reached — no fill kernel, no fork event between the two streams (round 3 had both
+  // per launch).  A captured chunk must replay with fixed targets: it zeroes its half's counters first, and forks the
+  // communication stream off the capture's origin.
+  unsigned long long *const counters = sh->progress + ck.slot0;  // (the kernel's slot k of this launch = ring slot slot0 + k)
   if (capturing) {
-    TDS_HIP_TRY(hipMemsetAsync(sh->progress + h, 0, sizeof(unsigned long long), s->stream));
+    TDS_HIP_TRY(hipMemsetAsync(counters, 0, (size_t)sh->chunk * sizeof(unsigned long long), s->stream));
     TDS_HIP_TRY(hipEventRecord(sh->cap_fork, s->stream));
     TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, sh->cap_fork, 0));
-    base = 0ull;
   }
   tds_hip_rings_t r;
   memset(&r, 0, sizeof(r));
@@ -438,14 +445,14 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
   } else {
     r.obs_ring = (char *)sh->rwire + (size_t)ck.slot0 * slot_b;
   }
-  r.obs_slots = TDS_SHARD_CHUNK;
+  r.obs_slots = sh->chunk;
   r.obs_first = 0;
   r.obs_f32 = (sh->wire_bytes == 4 && s->elem == 8) ? 1 : 0;
   r.y_ring = sh->ry;
   r.y_slots = TDS_SHARD_Y_SLOTS;
   r.y_first = 0;
   r.y_stride = sh->ry_stride;
-  r.progress = sh->progress + h;
+  r.progress = counters;
   int rc = tds_hip_step_many_rings(s, actions_dev, pool, ck.act_first, ck.steps, &r);
   if (rc != TDS_OK) return rc;
   TDS_HIP_TRY(hipEventRecord(e_kernel, s->stream));
@@ -460,9 +467,11 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
       continue;  // (one rank without a communicator, records already where the gather would put them: the slot is
                  //  complete when the launch is — nothing follows the counter)
     } else if (sh->wait_value && !capturing) {
-      TDS_HIP_TRY(hipStreamWaitValue64(sh->comm_stream, sh->progress + h, base + rel, hipStreamWaitValueGte, ~0ull));
+      const unsigned long long target = sh->slot_uses[ck.slot0 + k] * (unsigned long long)n_blocks + rel;
+      TDS_HIP_TRY(hipStreamWaitValue64(sh->comm_stream, counters + k, target, hipStreamWaitValueGte, ~0ull));
     } else {
-      hipLaunchKernelGGL(tds_ring_wait_kernel, dim3(1), dim3(64), 0, sh->comm_stream, sh->progress + h, base + rel,
+      const unsigned long long target = (capturing ? 0ull : sh->slot_uses[ck.slot0 + k] * (unsigned long long)n_blocks) + rel;
+      hipLaunchKernelGGL(tds_ring_wait_kernel, dim3(1), dim3(64), 0, sh->comm_stream, counters + k, target,
                          sh->wait_err(), timeout_ticks, sh->host_latch);
       if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "ring exchange: wait kernel launch");
     }
@@ -478,7 +487,8 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
     }
   }
   TDS_HIP_TRY(hipEventRecord(e_comm, sh->comm_stream));
-  if (!capturing) sh->prog_base[h] = base + (unsigned long long)(ck.steps - 1) * (unsigned long long)n_blocks;
+  if (!capturing)
+    for (int k = 0; k + 1 < ck.steps; ++k) sh->slot_uses[ck.slot0 + k]++;
   return TDS_OK;
 }
 
@@ -492,6 +502,9 @@ void ring_submitted(tds_hip_shard *sh, const TdsRingChunk &ck) {
   sh->last_ev = sh->ev_comm[ck.half];
   sh->last_block = 1;
   sh->last_slot = 0;
+  sh->last_ring_slot0 = ck.slot0;
+  sh->last_ring_steps = ck.steps;
+  sh->last_ring_half = ck.half;
 }
 
 tds_hip_shard::RingGraph *ring_graph_find(tds_hip_shard *sh, const void *actions, int pool, const TdsRingChunk &ck) {
@@ -579,8 +592,8 @@ int ring_many(tds_hip_shard *sh, const void *actions_dev, int pool, int first, i
     TDS_HIP_TRY(hipStreamSynchronize(sh->comm_stream));
     sh->comm_warm = true;
   }
-  TdsRingChunk plan[4096 / TDS_SHARD_CHUNK + 1];
-  const int nc = tds_ring_plan(sh->chunks, n_steps, first, pool, plan, (int)(sizeof(plan) / sizeof(plan[0])));
+  TdsRingChunk plan[4096 / 8 + 1];
+  const int nc = tds_ring_plan(sh->chunks, n_steps, first, pool, plan, (int)(sizeof(plan) / sizeof(plan[0])), sh->chunk);
   if (nc < 0) return fail(TDS_ERR_INVALID_ARG, "n_steps too large");
   // Submitted eagerly by default: 2 host calls per step (wait kernel, all-gather), issued while the launch runs.  As
   // ONE hipGraph per launch (TDS_HIP_SHARD_GRAPH=1) the same nodes replay ~10 us per step SLOWER on ROCm 7 — measured,
@@ -600,8 +613,8 @@ int ring_many(tds_hip_shard *sh, const void *actions_dev, int pool, int first, i
         }
       TDS_HIP_TRY(hipGraphLaunch(g->exec, s->stream));
       g->used = ++sh->rgraph_clock;
-      // (the captured chunk zeroes its counter and leaves it at (steps - 1) n_blocks)
-      sh->prog_base[ck.half] = (unsigned long long)(ck.steps - 1) * (unsigned long long)tds_hip_step_many_rings_blocks(s);
+      // (the captured chunk zeroes its half's counters and leaves n_blocks in those of its steps but the last)
+      for (int k = 0; k < sh->chunk; ++k) sh->slot_uses[ck.slot0 + k] = k + 1 < ck.steps ? 1ull : 0ull;
       // consumers of tds_hip_shard_gathered wait on ev_comm[half]: record it behind the graph (complete = exchanged)
       TDS_HIP_TRY(hipEventRecord(sh->ev_comm[ck.half], s->stream));
     } else {
@@ -986,6 +999,23 @@ int tds_hip_shard_flush(tds_hip_shard_t *sh) {
       return fail(TDS_ERR_HIP, "ring exchange: a wait for the step-loop launch timed out — gathered records are not valid");
     }
   }
+  return TDS_OK;
+}
+
+int tds_hip_shard_gathered_step(tds_hip_shard_t *sh, int steps_back, void *consumer_stream, void **records_dev) {
+  if (!sh || !records_dev) return fail(TDS_ERR_INVALID_ARG, "NULL argument");
+  if (sh->last_ring_slot0 < 0 || !sh->rgath || sh->last_ptr < sh->rgath)
+    return fail(TDS_ERR_INVALID_ARG, "the most recent exchange was not a ring exchange");
+  if (steps_back < 0 || steps_back >= sh->last_ring_steps)
+    return fail(TDS_ERR_INVALID_ARG, "steps_back must lie inside the most recently submitted launch");
+  {
+    const int rc = ring_latched(sh);
+    if (rc != TDS_OK) return rc;
+  }
+  DeviceGuard guard(sh->sim->device);
+  TDS_HIP_TRY(hipStreamWaitEvent((hipStream_t)consumer_stream, sh->ev_comm[sh->last_ring_half], 0));
+  const size_t slot_b = sh->slot_scalars() * sh->wire_bytes;
+  *records_dev = (char *)sh->rgath + (size_t)(sh->last_ring_slot0 + sh->last_ring_steps - 1 - steps_back) * slot_b * sh->world;
   return TDS_OK;
 }
 

@@ -6,8 +6,11 @@
 #include <stddef.h>
 
 // steps per step-loop launch ("chunk") of the ring exchange; the obs ring holds two chunks (one being exchanged while the
-// next one is written)
+// next one is written).  Default; a shard's option shard_chunk (8 .. 1024) overrides it: a launch costs ~15 us before / after
+// its steps plus the gap to the next one, 0.3 us per step at 64 steps; the ring grows with it (world x 0.49 MB per slot at
+// 4096 Ant environments per rank)
 #define TDS_SHARD_CHUNK 64
+#define TDS_SHARD_CHUNK_MAX 1024
 // slots of the shard's y ring (local records, never exchanged; step k of a chunk owns slot k % TDS_SHARD_Y_SLOTS)
 #define TDS_SHARD_Y_SLOTS 16
 
@@ -21,27 +24,31 @@ struct TdsRingChunk {
 
 // the chunks of one call of n_steps steps, `chunks_done` chunks having been submitted before it; returns their number
 // (-1: more than cap)
-inline int tds_ring_plan(long long chunks_done, int n_steps, int act_first, int act_blocks, TdsRingChunk *out, int cap) {
+inline int tds_ring_plan(long long chunks_done, int n_steps, int act_first, int act_blocks, TdsRingChunk *out, int cap,
+                         int chunk = TDS_SHARD_CHUNK) {
   int n = 0;
   for (int done = 0; done < n_steps; ++n) {
     if (n >= cap) return -1;
-    const int c = n_steps - done < TDS_SHARD_CHUNK ? n_steps - done : TDS_SHARD_CHUNK;
+    const int c = n_steps - done < chunk ? n_steps - done : chunk;
     TdsRingChunk &k = out[n];
     k.half = (int)((chunks_done + n) & 1);
     k.steps = c;
     k.step0 = done;
     k.act_first = act_blocks > 0 ? (act_first + done) % act_blocks : 0;
-    k.slot0 = k.half * TDS_SHARD_CHUNK;
+    k.slot0 = k.half * chunk;
     done += c;
   }
   return n;
 }
 
-// The step-loop launch counts a workgroup in for step k while it runs step k + 1 (TdsStepCtl::progress), never for its
-// last step: slot k of a chunk of c steps may be sent when the chunk's counter has reached (k + 1) * n_blocks (k < c - 1)
-// — or, for k == c - 1, when the launch has completed (returns 0: wait for the launch's event instead).
+// The step-loop launch counts a workgroup in for step k — on the counter of step k's OWN ring slot — while it runs step
+// k + 1 (TdsStepCtl::progress), never for its last step: slot k of a chunk of c steps may be sent when the slot's counter
+// has grown by n_blocks since the slot was last used (k < c - 1) — every workgroup has then stored that step's records,
+// however far apart the workgroups of the launch have drifted — or, for k == c - 1, when the launch has completed
+// (returns 0: wait for the launch's event instead).  (Round 3 kept ONE running total per launch and waited for
+// (k + 1) * n_blocks: met as soon as the AVERAGE workgroup had passed step k, not the slowest one.)
 inline unsigned long long tds_ring_wait_target(int k, int chunk_steps, int n_blocks) {
-  return k < chunk_steps - 1 ? (unsigned long long)(k + 1) * (unsigned long long)n_blocks : 0ull;
+  return k < chunk_steps - 1 ? (unsigned long long)n_blocks : 0ull;
 }
 
 // scalar offset of the record of GLOBAL environment e in a gathered slot [world][n_local][width] (ncclAllGather lays the

@@ -141,7 +141,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_shard_rccl_version", "tds_hip_shard_unique_id", "tds_hip_shard_create", "tds_hip_shard_create_all",
     "tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
     "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes", "tds_hip_shard_set_block",
-    "tds_hip_shard_step", "tds_hip_shard_step_many", "tds_hip_shard_step_many_prepare", "tds_hip_shard_group_step", "tds_hip_shard_flush", "tds_hip_shard_gathered",
+    "tds_hip_shard_step", "tds_hip_shard_step_many", "tds_hip_shard_step_many_prepare", "tds_hip_shard_group_step", "tds_hip_shard_flush", "tds_hip_shard_gathered", "tds_hip_shard_gathered_step",
     "tds_hip_shard_ring_plan", "tds_hip_shard_gathered_offset",
     "tds_rb_last_error", "tds_rb_create", "tds_rb_destroy", "tds_rb_set_stream", "tds_rb_state_device",
     "tds_rb_set_state", "tds_rb_get_state", "tds_rb_step",
@@ -356,7 +356,9 @@ class HipSim:
             r.y_ring, r.y_slots, r.y_first = y_ring.data_ptr(), int(y_ring.shape[0]), int(y_first)
             r.y_stride = int(y_ring.shape[2]) if int(y_ring.shape[2]) != self.output_dim else 0
         if progress is not None:
-            assert progress.is_cuda and progress.dtype == torch.int64 and progress.numel() >= 1
+            # (one counter per slot of the obs ring, tds_hip_rings_t::progress)
+            assert progress.is_cuda and progress.dtype == torch.int64 and obs_ring is not None
+            assert progress.numel() >= int(obs_ring.shape[0])
             r.progress = progress.data_ptr()
         return r
 
@@ -713,6 +715,18 @@ class HipShard:
         t = torch.as_tensor(hld, device=f"cuda:{self.device}")
         t._tds_owner = self
         return t
+
+    def gathered_step(self, steps_back: int):
+        """ring exchange: gathered records [world, n_local, obs_dim + 2] of the step ``steps_back`` before the most recently
+        submitted one, while it is still in the ring (tds_hip_shard_gathered_step)"""
+        import torch
+
+        ptr = C.c_void_p()
+        st = torch.cuda.current_stream(self.device)
+        lib().tds_hip_shard_gathered_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        _check(lib().tds_hip_shard_gathered_step(self.h, int(steps_back), C.c_void_p(st.cuda_stream), C.byref(ptr)))
+        return wrap_device_pointer(ptr.value, (self.world, self.n_local, self.sim.obs_dim + 2), self.wire_torch_dtype,
+                                   self.device, owner=self)
 
     def close(self):
         if getattr(self, "h", None):
