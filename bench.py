@@ -478,6 +478,7 @@ def main():
             left -= c
         # (no synchronisation: the warm-up steps below queue up behind it on the same stream)
     shard_form = None
+    exchange_tune = None
     if multi and not torch_fallback:
         # The exchange forms, most to least ambitious: ring exchange behind the step-loop launch (one hipGraph per launch) ->
         # per-step launches + exchanges from one hipGraph -> one tds_hip_shard_step call per step.  A form that fails
@@ -511,6 +512,36 @@ def main():
         if shard_form is None:
             raise SystemExit("bench.py: no exchange form works on this node")
         loop_form = loop_form and shard_form == "ring"
+        # Which build of the step-loop kernel runs under the ring exchange (library option exchange_w2): the two-wavefront
+        # build N = 1 takes (the default: 0.93 of the N = 1 rate on one rank) fills every SIMD's register file, so RCCL's
+        # all-gather kernels reach a compute unit only between launches; the one-wave build leaves them 216 registers per
+        # SIMD and pays 13 % of the step rate for it.  Which one is faster with REAL peers depends on what the all-gathers
+        # cost on the node: both are timed here (untimed warm-up, 2 x 512 steps, the slowest rank counts) and the faster
+        # one is kept on every rank.  --option exchange_w2=... pins it; on one rank only TDS_BENCH_TUNE_EXCHANGE=1 runs it.
+        if (shard_form == "ring" and (world > 1 or os.environ.get("TDS_BENCH_TUNE_EXCHANGE") == "1")
+                and not any(kv.startswith("exchange_w2=") for kv in args.option)):
+            tuned = {}
+            for w2 in (1, 0):
+                shard.sim.set_option("exchange_w2", w2)
+                run_steps(64)
+                flush()
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                tt = time.perf_counter()
+                run_steps(512)
+                flush()
+                torch.cuda.synchronize()
+                dt_ = time.perf_counter() - tt
+                if world > 1:
+                    tdt_ = torch.tensor([dt_], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tdt_, op=dist.ReduceOp.MAX)
+                    dt_ = float(tdt_.item())
+                tuned[w2] = dt_ / 512 * 1e6
+            keep = 1 if tuned[1] <= tuned[0] else 0
+            shard.sim.set_option("exchange_w2", keep)
+            exchange_tune = {"two_wavefront_build_us_per_step": tuned[1], "one_wave_build_us_per_step": tuned[0],
+                             "kept": "two-wavefront build (the N = 1 kernel)" if keep else "one-wave build"}
     else:
         prepare(args.warmup)
         run_steps(args.warmup)
@@ -658,7 +689,7 @@ def main():
                                  else "one-wave step-loop build (leaves 216 of a SIMD's 512 registers to the exchange's kernels)",
                         "wait": "hipStreamWaitValue64" if xo["shard_wait"] == 1 else "one-lane wait kernel (bounded)",
                         "in_place": xo["shard_inplace"] != 0,
-                        "what": "tds_hip_shard_step_many on ONE rank: step-loop launches of <= 64 steps storing every step's "
+                        "what": "tds_hip_shard_step_many on ONE rank: step-loop launches of <= 256 steps storing every step's "
                                 "[obs | reward | done] record straight into this rank's block of the gathered buffer + one "
                                 "(in-place) all-gather of that slot per policy step on the communication stream, which "
                                 "follows the launch's progress counter (what every rank of an N > 1 run executes)"}
@@ -794,7 +825,7 @@ def main():
                                       "done in the last step" % (m.settle_steps, int((obs[:, -1] != 0).sum().item()), n))
                        if auto_reset else None,
                        "launch": launch,
-                       "exchange_form": shard_form,
+                       "exchange_form": shard_form, "exchange_tune": exchange_tune,
                        "spin_up": ("%d untimed steps of a scratch handle before the warm-up steps (GPU clocks)" % args.spin_up_steps)
                        if args.spin_up_steps > 0 else None,
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,

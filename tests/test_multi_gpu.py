@@ -343,7 +343,7 @@ def test_shard_ring_exchange_on_one_rank(with_rccl, submit, wire, built, monkeyp
     x, acts = _start(m, n, seed=41)
     a = torch.from_numpy(acts).cuda().contiguous()
     uid = hip_backend.HipShard.unique_id() if with_rccl else None
-    sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype=wire)
+    sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype=wire, options={"shard_chunk": 64})  # (default: 256 steps per launch)
     ref = hip_backend.HipSim(m, n)
     for s in (sh.sim, ref):
         s.x.copy_(torch.from_numpy(x).cuda())
@@ -357,8 +357,8 @@ def test_shard_ring_exchange_on_one_rank(with_rccl, submit, wire, built, monkeyp
             assert torch.equal(sh.sim.x, torch.from_numpy(x).cuda())
         sh.step_many(a, K, first_block=1)
         got = sh.gathered().clone()
-        # (a launch whose slots are exchanged while it runs uses the one-wave step-loop build; so does one that is handed a
-        #  progress counter — the same build on both sides: bit for bit)
+        # (a launch that is handed a progress counter takes the build option exchange_w2 names — since round 4 the
+        #  two-wavefront build, the one N = 1 runs — on both sides: bit for bit)
         ref.step_many_rings(a, K, ring, None, first_block=1, progress=torch.zeros(K, dtype=torch.int64, device="cuda"))
         sh.flush()
         torch.cuda.synchronize()

@@ -65,8 +65,8 @@ def _reward_done(m, name, q_before, y):
     ("ant", 4096, 20, "f64", "default"), ("pendulum5", 4096, 20, "f64", "default"), ("pendulum5", 4096, 20, "mixed", "default"),
     ("laikago_soft", 8192, 50, "f64", "default"),
     ("ant", 8192, 20, "f64", "default"),       # config 5's per-GPU share: the one-wave loop build
-    # the builds a MULTI-GPU run launches (tds_hip_shard_step_many): a progress counter attached -> the one-wave loop
-    # build with write-through record stores; the same with the two-wavefront build kept (option exchange_w2); the obs
+    # the builds a MULTI-GPU run launches (tds_hip_shard_step_many): a progress counter attached -> write-through record
+    # stores, in the one-wave loop build (option exchange_w2 = 0) and in the two-wavefront build (the default); the obs
     # ring laid out for two ranks (in-place all-gather: obs_slot_envs); y records on 128-byte lines (y_stride)
     ("ant", 4096, 20, "f64", "exchange"), ("ant", 4096, 20, "f64", "exchange_w2"), ("ant", 4096, 20, "f64", "exchange_inplace"),
     ("ant", 4096, 20, "f64", "padded"), ("laikago_soft", 8192, 20, "f64", "padded"),
@@ -83,7 +83,10 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
     ref_step, what = _reference_stepper(name, n)
     rng = np.random.default_rng(77)
     nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
-    opts = {"exchange_w2": 1} if form == "exchange_w2" else ({"loop_w2": 0} if form == "one_wave" else None)
+    # ("exchange": the ONE-wave build under a progress counter, round 3's default, still an option; "exchange_w2" and
+    #  "exchange_inplace": the two-wavefront build — the default since round 4, what N = 1 runs)
+    opts = {"exchange_w2": 1} if form == "exchange_w2" else ({"exchange_w2": 0} if form == "exchange" else
+                                                               ({"loop_w2": 0} if form == "one_wave" else None))
     sim = hip_backend.HipSim(m, n, dtype=dtype, options=opts)
     tdt = sim.torch_dtype
     x0 = _start_state(m, name, n, rng)

@@ -34,7 +34,7 @@ xg = g["x"][idx]                                   # the GLOBAL batch, the same 
 ag = rng.uniform(-0.4, 0.4, (4, world * n_local, m.action_dim))
 lo, hi = rank * n_local, (rank + 1) * n_local
 sh = hip_backend.HipShard(m, world * n_local, rank=rank, world=world, device=0, dtype="f64",
-                          unique_id=bytes.fromhex(idhex), wire_dtype="f32")
+                          unique_id=bytes.fromhex(idhex), wire_dtype="f32", options={"shard_chunk": 64})
 sim = sh.sim
 sim.x.copy_(torch.from_numpy(xg[lo:hi]).cuda())
 acts = torch.from_numpy(ag[:, lo:hi]).cuda().contiguous()
@@ -59,7 +59,7 @@ if mode == "single" or not ref.step_many_is_loop(steps) or os.environ.get("TDS_H
         ref.step(acts[k % 4], 1, obs)
 else:
     ring = torch.zeros((steps, n_local, ref.obs_dim + 2), dtype=torch.float64, device="cuda")
-    # (a progress counter selects the one-wave step-loop build, the one exchange launches use: same build, same bits)
+    # (a progress counter selects the build option exchange_w2 names, the one exchange launches use: same build, same bits)
     ref.step_many_rings(acts, steps, ring, None, progress=torch.zeros(steps, dtype=torch.int64, device="cuda"))
     obs = ring[-1]
 torch.cuda.synchronize()

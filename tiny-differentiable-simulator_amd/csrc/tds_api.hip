@@ -113,14 +113,16 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   const bool is_loop_launch = nsub > 1 || (opts && opts->rings);
   // (loop_w2 = 2: not for launches that take reset states from the pool)
   const bool loop_w2_pool = s->opt.get(TDS_OPT_LOOP_W2, 1) != 2;
-  // (a launch whose ring slots are exchanged while it runs — rings->progress — stays with the ONE-wave loop build: two
-  //  wavefronts of 256 registers per SIMD leave no register for anybody else, and the exchange's kernels — the one-lane
-  //  wait, RCCL's all-gather — would not get onto a compute unit before the launch ends; the one-wave build holds 296 of a
-  //  SIMD's 512.  Measured, profiles/r03_ring_exchange_forms.txt: the first wait of a 64-step launch returned after 86 %
-  //  of it.)
-  //  Option exchange_w2 = 1 keeps the two-wavefront build under the exchange all the same — right when the exchange needs
-  //  no compute unit while the launch runs (tests pin THIS build on the reference too).
-  const bool exchanged = opts && opts->rings && opts->rings->progress && !s->opt.flag(TDS_OPT_EXCHANGE_W2);
+  // A launch whose ring slots are exchanged while it runs (rings->progress) takes the SAME two-wavefront build an N = 1
+  // launch takes (round 4: every rank of an N > 1 run executes the N = 1 kernel).  Round 3 dropped such launches to the
+  // one-wave loop build — two wavefronts of 256 registers per SIMD leave no register for anybody else, and the exchange's
+  // kernels (the one-lane wait, RCCL's all-gather) get onto a compute unit only when a workgroup of the launch retires
+  // (profiles/r03_ring_exchange_forms.txt: the first wait of a 64-step launch returned after 86 % of it) — at the price of
+  // 13 % of the step rate before a byte travelled.  Measured on one rank (profiles/r04_same_box_ab_and_exchange_forms.txt):
+  // two-wavefront build + 256-step launches 14.9 us per step (0.935 of the N = 1 rate), one-wave build 18.6.
+  // Option exchange_w2 = 0 brings the one-wave build back (bench.py times both forms in its warm-up at N > 1 and keeps the
+  // faster one on every rank); the tests pin BOTH builds on the reference.
+  const bool exchanged = opts && opts->rings && opts->rings->progress && s->opt.get(TDS_OPT_EXCHANGE_W2, 1) == 0;
   const bool two_waves = w2_fits && (is_loop_launch ? (loop_w2 && !exchanged && (loop_w2_pool || !(opts && opts->extra)) &&
                                                        s->lds_w2.NDP <= 16)
                                                     : !(opts && opts->rings));

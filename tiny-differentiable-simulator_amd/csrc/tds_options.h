@@ -25,7 +25,7 @@ enum TdsOptKey {
   // ---- run-time rows (may change between calls of a handle)
   TDS_OPT_LOOP_W2,            // step-loop launches: 0 one-wave build, 1 (default) two-wavefront build where it fits, 2 ... not with the reset pool
   TDS_OPT_LOOP_OCC,           // step-loop build: 1 / 2 wavefronts per SIMD forced (unset: by grid size)
-  TDS_OPT_EXCHANGE_W2,        // launches whose ring slots are exchanged while they run (rings->progress): 1 two-wavefront build, 0 / unset one-wave build
+  TDS_OPT_EXCHANGE_W2,        // launches whose ring slots are exchanged while they run (rings->progress): 1 / unset the two-wavefront build N = 1 takes, 0 the one-wave build
   TDS_OPT_RING_NOFENCE,       // 1 (default): write-through record stores + plain wait; 0: release fence per step
   TDS_OPT_POOL_SLAB,          // 0: refill launches keep every constraint row in LDS
   TDS_OPT_POOL_SETTLE_LOOP,   // 1: the settle steps of a refill pass as one step-loop launch
@@ -49,7 +49,7 @@ enum TdsOptKey {
   TDS_OPT_SHARD_WAIT,         // how the communication stream follows the progress counter: 0 wait kernel, 1 hipStreamWaitValue64 (default where supported)
   TDS_OPT_SHARD_INPLACE,      // 1 (default): the launch stores its records straight into its own block of the gathered buffer (in-place all-gather)
   TDS_OPT_SHARD_REGISTER,     // 1 (default): ncclCommRegister the ring buffers where librccl offers it
-  TDS_OPT_SHARD_CHUNK,        // steps per step-loop launch of the ring exchange (default 64; read when the ring is first used)
+  TDS_OPT_SHARD_CHUNK,        // steps per step-loop launch of the ring exchange (default 256; read when the ring is first used)
   TDS_OPT_RING_SIGNAL_LATE,   // experiment: 1 = the helper wavefront counts a step in at the top of its NEXT iteration
   TDS_OPT_COUNT
 };

@@ -160,7 +160,7 @@ struct tds_hip_shard {
   unsigned *host_latch = nullptr;  // pinned: raised by a wait that gave up (checked by every later call of the shard)
   bool wait_value = false;         // the waits are hipStreamWaitValue64 commands instead of wait kernels
   bool ring_ready = false;         // ring_alloc has completed (a failed allocation is undone as a whole)
-  int chunk = TDS_SHARD_CHUNK;     // steps per step-loop launch of the ring exchange (option shard_chunk, read at ring_alloc)
+  int chunk = TDS_SHARD_CHUNK_DEFAULT;  // steps per step-loop launch of the ring exchange (option shard_chunk, read at ring_alloc)
   int last_ring_slot0 = -1, last_ring_steps = 0, last_ring_half = 0;  // the most recently submitted launch of the ring exchange
   hipEvent_t ev_kernel[2] = {}, ev_comm[2] = {};
   hipEvent_t cap_fork = nullptr, cap_kernel = nullptr, cap_comm = nullptr;  // the same roles inside a stream capture
@@ -323,7 +323,7 @@ int ring_alloc_impl(tds_hip_shard *sh) {
   // neither copied nor sent to itself.  (option shard_inplace = 0: separate send ring, as in round 3)
   sh->inplace = s->opt.get(TDS_OPT_SHARD_INPLACE, 1) != 0;
   {
-    long long c = s->opt.get(TDS_OPT_SHARD_CHUNK, TDS_SHARD_CHUNK);
+    long long c = s->opt.get(TDS_OPT_SHARD_CHUNK, TDS_SHARD_CHUNK_DEFAULT);
     sh->chunk = (int)(c < 8 ? 8 : (c > TDS_SHARD_CHUNK_MAX ? TDS_SHARD_CHUNK_MAX : c));
   }
   const size_t ring_slots = 2 * (size_t)sh->chunk;
@@ -368,6 +368,12 @@ int ring_alloc_impl(tds_hip_shard *sh) {
     if (rccl()->CommRegister(sh->comm, sh->rgath, ring_slots * slot_b * sh->world, &sh->reg_handle) != ncclSuccess)
       sh->reg_handle = nullptr;  // (not fatal: the collective works on unregistered buffers)
   }
+  // The memsets above are commands of the NULL stream; the communication stream is a non-blocking stream, which the NULL
+  // stream does not order: behind a long launch of the caller's they are still pending when the first wait of the
+  // exchange starts polling — a recycled allocation then shows it the counters of an earlier ring and it sends its slot
+  // at once (tests/test_multi_gpu.py: ..._only_when_the_slowest_workgroup_has_stored_it, zeros in one slot).  Once per
+  // shard: the ring exists — zeroed — before anything of the exchange is enqueued.
+  TDS_HIP_TRY(hipDeviceSynchronize());
   return TDS_OK;
 }
 int ring_alloc(tds_hip_shard *sh) {

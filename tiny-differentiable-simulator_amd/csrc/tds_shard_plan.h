@@ -11,6 +11,11 @@
 // 4096 Ant environments per rank)
 #define TDS_SHARD_CHUNK 64
 #define TDS_SHARD_CHUNK_MAX 1024
+// what a shard takes where the option is not set: measured on one rank (profiles/r04_same_box_ab_and_exchange_forms.txt,
+// Ant x 4096, two-wavefront build under the exchange): 64-step launches 17.3 us per step, 256-step launches 15.1 — the
+// launch's fixed ~15 us and the gap to the next one are paid once per chunk; the ring then holds 2 x 256 slots (8 ranks, f32
+// wire: 2 GB of 288)
+#define TDS_SHARD_CHUNK_DEFAULT 256
 // slots of the shard's y ring (local records, never exchanged; step k of a chunk owns slot k % TDS_SHARD_Y_SLOTS)
 #define TDS_SHARD_Y_SLOTS 16
 
