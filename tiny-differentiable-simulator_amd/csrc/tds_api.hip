@@ -88,6 +88,27 @@ void drop_graphs(tds_hip_sim *s);
 
 }  // namespace
 
+// experiment slots (tds_kernels.h): weak — NULL unless tools/build_alt.sh linked a slot's translation unit in
+extern "C" {
+#define TDS_ALT_DECL(k)                                                                                                  \
+  __attribute__((weak)) int tds_alt_launch_##k(const void *, const void *, const TdsLds *, int, const void *, void *,    \
+                                               const void *, void *, void *, void *, int, hipStream_t,                   \
+                                               const TdsStepCtl *, int, int *);
+TDS_ALT_DECL(1) TDS_ALT_DECL(2) TDS_ALT_DECL(3) TDS_ALT_DECL(4) TDS_ALT_DECL(5) TDS_ALT_DECL(6)
+#undef TDS_ALT_DECL
+}
+static tds_alt_launch_fn tds_alt_slot(int k) {
+  switch (k) {
+    case 1: return tds_alt_launch_1;
+    case 2: return tds_alt_launch_2;
+    case 3: return tds_alt_launch_3;
+    case 4: return tds_alt_launch_4;
+    case 5: return tds_alt_launch_5;
+    case 6: return tds_alt_launch_6;
+    default: return nullptr;
+  }
+}
+
 namespace tds_internal {
 
 int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb, void *obs, int n, int nsub,
@@ -194,7 +215,16 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   ctl.mask = mask;
   ctl.reset_count = s->d_reset_count;
   int rc;
-  if (s->dtype == TDS_DTYPE_F64)
+  const long long alt = s->opt.get(TDS_OPT_ALT_BUILD, 0);
+  if (alt != 0) {  // an experiment slot (tds_kernels.h): f64 plain kernels of the one instantiation the slot was built for
+    tds_alt_launch_fn fn = alt >= 1 && alt <= TDS_ALT_SLOTS ? tds_alt_slot((int)alt) : nullptr;
+    int key = 0;
+    if (fn) (void)fn(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, &key);
+    const bool plain = !s->h64.is_floating && !s->h64.num_spherical && s->h64.num_bodies < 2;
+    if (!fn || s->dtype != TDS_DTYPE_F64 || !plain || key != s->lanes * 100 + lds.NDP)
+      return fail(TDS_ERR_UNSUPPORTED, "option alt_build: no such experiment slot in this library for this handle's kernels");
+    rc = fn(s->d_model, &s->h64, &lds, s->lanes, x, y, actions, fb, obs, ovf, n, stream, &ctl, form, nullptr);
+  } else if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,
                                          (const double *)x, (double *)y, (const double *)actions, (double *)fb,
                                          (double *)obs, (double *)ovf, n, stream, ctl, nullptr, form);

@@ -88,6 +88,23 @@ struct TdsStepCtl {
 #define TDS_FORM_LOOP_OCC1 2  // step-loop build: the one-wavefront-per-SIMD compilation whatever the grid
 #define TDS_FORM_LOOP_OCC2 4  // ... the two-wavefronts-per-SIMD compilation whatever the grid
 
+// EXPERIMENT SLOTS (tools/build_alt.sh): the kernel sources compiled once more — other compiler flags, -DTDS_X_... source
+// switches — as a small extra translation unit holding ONE (lanes, padded dof) instantiation of the f64 / KIND 0 kernels,
+// linked into the SAME library under other names (-DTDS_ALT=k) and chosen per handle with the run-time option alt_build = k.
+// Same-box A/B of a kernel experiment then costs one more object of ~0.5 MB instead of a second 55 MB library on the way
+// to the GPU box.  The default build has no slot: the weak entry points of tds_api.hip are NULL and the option is refused.
+#ifdef TDS_ALT
+#define TDS_ALT_PASTE2(a, b) a##b
+#define TDS_ALT_PASTE(a, b) TDS_ALT_PASTE2(a, b)
+#define tds_launch_step_impl TDS_ALT_PASTE(tds_launch_step_impl_alt, TDS_ALT)
+#define tds_kernel_max_dynamic_lds_impl TDS_ALT_PASTE(tds_kernel_max_dynamic_lds_impl_alt, TDS_ALT)
+#endif
+#define TDS_ALT_SLOTS 6
+// what a slot's translation unit exports (tds_kernels.hip, bottom; extern "C", looked up weakly by tds_api.hip)
+typedef int (*tds_alt_launch_fn)(const void *d_model, const void *h_model, const TdsLds *L, int lanes_per_env, const void *x_in,
+                                 void *y_out, const void *actions, void *x_feedback, void *obs_out, void *ovf, int n_envs,
+                                 hipStream_t stream, const TdsStepCtl *ctl, int form, int *lanes_ndp_key);
+
 // na_cap: contacts whose rows stay in LDS (<= 0: all); w2: the layout of the two-wavefront workgroups (the LDS groups
 // that alias each other in the one-wave layout laid out one after the other, + hand-over slots)
 template <typename T>

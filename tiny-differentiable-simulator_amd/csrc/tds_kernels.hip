@@ -1197,13 +1197,16 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // which wavefront of the workgroup (scalar: every branch on it is a uniform branch)
   const int wv = W2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   const bool main_wave = !W2 || wv == 0;
-#ifdef TDS_X_SETPRIO
-  // experiment: the main wavefront is the workgroup's critical path, the helper has slack — where a main and a helper
-  // wavefront (of different workgroups) share a SIMD, the arbiter should issue the main one first
-  if constexpr (W2) {
-    if (wv == 0) __builtin_amdgcn_s_setprio(TDS_X_SETPRIO);
-  }
+  // The main wavefront is the workgroup's critical path, the helper has slack: where a main and a helper wavefront (of
+  // different workgroups: one of each per SIMD when 1024 two-wave workgroups are resident) share a SIMD, the arbiter
+  // issues the main one first.  Measured (same process, experiment slots, profiles/r04_ab_slots_ant4096.txt): Ant x 4096
+  // ring launches 14.01 -> 13.72 us per step (priority 3; -DTDS_MAIN_PRIO=0 leaves the default arbitration).
+#ifndef TDS_MAIN_PRIO
+#define TDS_MAIN_PRIO 3
 #endif
+  if constexpr (W2 && TDS_MAIN_PRIO > 0) {
+    if (wv == 0) __builtin_amdgcn_s_setprio(TDS_MAIN_PRIO);
+  }
 
   // ---- A0. the x record (and the fresh actions) are requested from HBM first: their latency runs under the
   //      fetch of the model constants below; dimensions from the kernel arguments, not from the model
@@ -3758,7 +3761,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 // padded dof count = template parameter NDP of the kernel.  Besides the coarse widths (8/16/24/32) the
 // widths of the two benchmark robots are instantiated exactly for their natural lane count
 // (Ant: 14 dof on 16 lanes, Laikago: 18 dof on 32 lanes): LDL^T and the row solves scale with NDP^2.
-#if !defined(TDS_ONLY_F32) && !defined(TDS_ONLY_MIX) && (!defined(TDS_ONLY_KIND) || TDS_ONLY_KIND == 0)
+#if !defined(TDS_ONLY_F32) && !defined(TDS_ONLY_MIX) && (!defined(TDS_ONLY_KIND) || TDS_ONLY_KIND == 0) && !defined(TDS_ALT)
 int tds_padded_dof(int nd, int lanes) {
   if (lanes == 16 && nd > 8 && nd <= 14) return 14;
   if (lanes == 32 && nd > 16 && nd <= 18) return 18;
@@ -3900,7 +3903,11 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   const int loop_force = (form & TDS_FORM_LOOP_OCC2) ? 2 : ((form & TDS_FORM_LOOP_OCC1) ? 1 : 0);
   // (>= 24 padded dof: the straight-line build is itself at one wavefront per SIMD; the two-wave loop build would
   //  spill hundreds of registers there)
-  const bool loop_occ2 = L.NDP < 24 && (loop_force == 2 || (loop_force != 1 && blocks >= 1536));
+  // (round 4: compiled without MachineLICM the two-wavefronts-per-SIMD compilation of the kernels up to 14 padded dof
+  //  holds no scratch — 245 VGPR — and is taken at ANY grid size: the one-wavefront-per-SIMD compilation (256 VGPR + 20
+  //  AGPR copies) buys nothing there any more, and its <double, double, 16, 8> instantiation does not terminate when
+  //  built without the pass — profiles/r04_diag_loop_hang.txt; option loop_occ = 1 still selects it)
+  const bool loop_occ2 = L.NDP < 24 && (loop_force == 2 || (loop_force != 1 && (blocks >= 1536 || L.NDP < 16)));
   const int key = lanes_per_env * 100 + L.NDP;
   switch (key) {
 #define TDS_CASE(GG, NN) \
@@ -4002,10 +4009,24 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   TDS_INSTANTIATE_K0(TT, TR) TDS_INSTANTIATE_K1(TT, TR) TDS_INSTANTIATE_K2(TT, TR) TDS_INSTANTIATE_K3(TT, TR) \
   TDS_INSTANTIATE_K4(TT, TR)
 #if defined(TDS_ONLY_F64)
-#if TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)
+#if (TDS_ONLY_KIND == 0 || defined(TDS_ALL_KINDS)) && !defined(TDS_ALT)
 template TdsLds tds_make_lds_layout<double>(const DevModel<double> &, int, int, bool);
 #endif
 TDS_INSTANTIATE_KINDS(double, double)
+#endif
+#ifdef TDS_ALT
+// the slot's entry point (tds_kernels.h: EXPERIMENT SLOTS); *lanes_ndp_key = the one instantiation this unit holds
+extern "C" int TDS_ALT_PASTE(tds_alt_launch_, TDS_ALT)(const void *d_model, const void *h_model, const TdsLds *L,
+                                                       int lanes_per_env, const void *x_in, void *y_out, const void *actions,
+                                                       void *x_feedback, void *obs_out, void *ovf, int n_envs,
+                                                       hipStream_t stream, const TdsStepCtl *ctl, int form, int *lanes_ndp_key) {
+  if (lanes_ndp_key) *lanes_ndp_key = TDS_DEBUG_ONLY;
+  if (!d_model) return 0;  // (query only)
+  return tds_launch_step_impl<double, double, 0>((const DevModel<double> *)d_model, *(const DevModel<double> *)h_model, *L,
+                                                 lanes_per_env, (const double *)x_in, (double *)y_out, (const double *)actions,
+                                                 (double *)x_feedback, (double *)obs_out, (double *)ovf, n_envs, stream, *ctl,
+                                                 nullptr, form);
+}
 #endif
 #if defined(TDS_ONLY_MIX)
 TDS_INSTANTIATE_KINDS(double, float)

@@ -51,6 +51,7 @@ enum TdsOptKey {
   TDS_OPT_SHARD_REGISTER,     // 1 (default): ncclCommRegister the ring buffers where librccl offers it
   TDS_OPT_SHARD_CHUNK,        // steps per step-loop launch of the ring exchange (default 256; read when the ring is first used)
   TDS_OPT_RING_SIGNAL_LATE,   // experiment: 1 = the helper wavefront counts a step in at the top of its NEXT iteration
+  TDS_OPT_ALT_BUILD,          // experiment slot k (1 .. TDS_ALT_SLOTS) of the library, where it was linked in (tds_kernels.h); f64 plain kernels
   TDS_OPT_COUNT
 };
 
@@ -101,6 +102,7 @@ inline const TdsOptRow *tds_opt_rows() {
       {"shard_register", false, "TDS_HIP_SHARD_REGISTER"},
       {"shard_chunk", false, "TDS_HIP_SHARD_CHUNK"},
       {"ring_signal_late", false, "TDS_HIP_RING_SIGNAL_LATE"},
+      {"alt_build", false, "TDS_HIP_ALT_BUILD"},
   };
   return rows;
 }
