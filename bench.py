@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=0,
                     help="also time the on-device policy rollout (tds_hip_rollout) with this many policy steps per call")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
+    ap.add_argument("--stream", choices=["own", "default"], default="default",
+                    help="own: everything runs on a stream of its own (torch.cuda.Stream) instead of the NULL stream")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N > 1: steps whose [obs|reward|done] records travel in one all-gather (1 = one exchange "
                          "per policy step, SURVEY 8e's protocol and the default)")
@@ -260,6 +262,8 @@ def main():
     if os.environ.get("TDS_BENCH_ONE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if args.stream == "own":
+        torch.cuda.set_stream(torch.cuda.Stream())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("TDS_BENCH_BACKEND", "nccl")
@@ -467,6 +471,7 @@ def main():
         elif args.chains != "default":
             chains = int(args.chains)
             sim.set_graph_chains(chains)
+    scratch = None
     if args.spin_up_steps > 0:
         scratch = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype,
                                      lanes_per_env=args.lanes if args.lanes else None)
@@ -557,6 +562,16 @@ def main():
                                                  obs_first=state["i"] % RS, y_first=state["i"] % RS)
     if world > 1:
         dist.barrier()
+    # The host has spent milliseconds marshalling the timed call while the GPU sat idle: a short launch of the scratch handle
+    # right in front of the synchronisation that opens the region keeps the clocks where the spin-up left them (the same
+    # 20-step launch repeated back to back in one process takes 300 us, after an idle gap 350: profiles/
+    # r04_bench_20_step_harness_cost.txt, tools/ab_slots.py).  Untimed, its own state, named in config.spin_up.
+    if scratch is not None:
+        scratch.step_many(actions, 256)
+        evw = torch.cuda.Event()
+        evw.record()
+        while not evw.query():
+            pass
     torch.cuda.synchronize()
 
     use_events = not args.no_events
@@ -826,7 +841,8 @@ def main():
                        if auto_reset else None,
                        "launch": launch,
                        "exchange_form": shard_form, "exchange_tune": exchange_tune,
-                       "spin_up": ("%d untimed steps of a scratch handle before the warm-up steps (GPU clocks)" % args.spin_up_steps)
+                       "spin_up": ("%d untimed steps of a scratch handle before the warm-up steps and 256 more right in front of the "
+                                   "synchronisation that opens the timed region (GPU clocks)" % args.spin_up_steps)
                        if args.spin_up_steps > 0 else None,
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
                        "steps_per_launch": (min(K, 64) if multi else min(K, GCH)) if loop_form else 1,

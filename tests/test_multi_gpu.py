@@ -468,6 +468,9 @@ def test_ring_exchange_sends_a_slot_only_when_the_slowest_workgroup_has_stored_i
     for back in range(K):
         got = sh.gathered_step(back)
         assert torch.equal(got[0].view(torch.int64), ring[K - 1 - back].view(torch.int64)), (build, K - 1 - back)
-    # (the airborne half did stay airborne, i.e. the two halves did run at different paces)
-    assert float(ref.x[: n // 2, 2].min()) > 1.0
+    # (the airborne half did stay airborne, i.e. the two halves did run at different paces; a handful of the golden start
+    #  states — large joint velocities, no joint limits — go non-finite in free flight within 50 steps, in the reference's
+    #  own arithmetic too: they are compared bit for bit above like every other record and left out here)
+    z = ref.x[: n // 2, 2]
+    assert int(torch.isfinite(z).sum()) > n // 2 - 32 and float(z[torch.isfinite(z)].min()) > 1.0
     sh.close()

@@ -386,6 +386,15 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
       // with at most two per SIMD, i.e. up to four workgroups per CU
       const int wg_per_cu = per_cu < 4 ? per_cu : 4;
       if (b2 <= 64 * 1024 && wg_per_cu >= 1) s->w2_max_blocks = w2_opt == 2 ? (1 << 30) : wg_per_cu * 256;
+      // the workgroup's constant table of the step-loop launches (TdsLds::cw): as many rows as the LDS left over by
+      // wg_per_cu workgroups holds — never at the price of a workgroup per CU (LDS is granted in 512-byte units)
+      for (const int rows : {TDS_CW_ROWS, TDS_CW_LANE}) {
+        const size_t with = ((b2 + (size_t)rows * s->lanes * celem + 511) / 512) * 512;
+        if (wg_per_cu >= 1 && with <= 64 * 1024 && (size_t)wg_per_cu * with <= 160 * 1024) {
+          s->lds_w2.cw = rows;
+          break;
+        }
+      }
     }
   }
   const int lds_bytes = (int)((size_t)s->lds.stride * epw * celem);

@@ -1178,7 +1178,10 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
 // grid fits the GPU at once (tds_launch_step_impl).
 template <typename T, typename TR, int G, int NDP, bool PROF, int LP, int KIND, bool W2 = false>
 __global__ __launch_bounds__(W2 ? 128 : 64)
-__attribute__((amdgpu_waves_per_eu((LP == 2 || W2 || (LP == 0 && NDP < 24)) ? 2 : 1)))
+#ifndef TDS_X_WAVES_STRAIGHT  // (experiment: wavefronts per SIMD the straight-line one-wave builds are compiled for)
+#define TDS_X_WAVES_STRAIGHT 2
+#endif
+__attribute__((amdgpu_waves_per_eu((LP == 0 && !W2 && NDP < 24) ? TDS_X_WAVES_STRAIGHT : ((LP == 2 || W2) ? 2 : 1))))
 void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const TR *x_in, TR *__restrict__ y_out,
                                                       const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
@@ -1257,6 +1260,41 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     const bool valid = env < n_envs;
     const int nq = mdl->dof_q, nd = mdl->dof_qd, in_dim = mdl->input_dim, adim = mdl->action_dim;
     T *const xr = sm + grp0 * L.stride + L.xrec;
+    // The lane's model constants are re-derived inside every iteration BY DESIGN (see above: nothing but the loop state may
+    // stay live across the back edge) — which made every iteration begin with a round trip to L2 for the lane's small
+    // constants (in front of the PD block) and another one for X_T (in front of jcalc).  Two-wavefront step-loop launches
+    // keep them in a table of the WORKGROUP in LDS instead (TdsLds::cw rows of [G] scalars behind the environments'
+    // regions, filled here once per launch by the first lane group; the host grants the rows only where they do not cost a
+    // workgroup per CU).  Measured (experiment slots, same process: profiles/r04_ab_slots3_lds_consts.txt): Ant x 4096 ring
+    // launches 13.66 -> 13.46 (small constants) -> 13.08 us per step (+ X_T); mass / centre of mass / inertia / motion axis
+    // on top change nothing (they are consumed phases later: their latency was hidden already).
+    if constexpr (W2 && KIND == 0) {
+      if (L.cw != 0) {  // wave-uniform (kernel argument)
+        T *const CW = sm + EPW * L.stride;
+        if (main_wave && grp0 == 0) {
+          const int ls = lane < mdl->num_links ? lane : 0;
+          const bool il = lane < mdl->num_links;
+          CW[0 * G + lane] = mdl->init_pose[ls];
+          CW[1 * G + lane] = mdl->stiffness[ls];
+          CW[2 * G + lane] = mdl->damping[ls];
+          const int par = il ? mdl->parent[ls] : -1, lev = il ? mdl->level[ls] : -1;
+          const int jtt = il ? mdl->joint_type[ls] : TDS_JOINT_FIXED, dii = il ? mdl->qd_index[ls] : -1;
+          const int cfl = il ? mdl->chain_flags[ls] : 0, msl = il ? mdl->lc_slot[ls] : -1;
+          const int psl = (il && par >= 0) ? mdl->lc_slot[par] : -1, aci = il ? mdl->act_index[ls] : -1;
+          const unsigned lo = (unsigned)((par + 1) & 255) | ((unsigned)((lev + 1) & 255) << 8) | ((unsigned)(jtt & 255) << 16) |
+                              ((unsigned)((dii + 1) & 255) << 24);
+          const unsigned hi = (unsigned)(cfl & 255) | ((unsigned)((msl + 1) & 255) << 8) | ((unsigned)((psl + 1) & 255) << 16) |
+                              ((unsigned)((aci + 1) & 255) << 24);
+          CW[3 * G + lane] = bits_to_scalar<T>(lo);
+          CW[4 * G + lane] = bits_to_scalar<T>(hi);
+          if (L.cw >= TDS_CW_ROWS) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) CW[(TDS_CW_LANE + k) * G + lane] = mdl->X_T[k][ls];
+          }
+        }
+        __syncthreads();
+      }
+    }
     if (main_wave) {  // (a helper wavefront first touches the record behind barrier (1) of the first step)
 #pragma unroll
       for (int k = 0; k < XPL; ++k) {
@@ -1314,10 +1352,24 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   const int li = lane;
   const bool isl = li < nl;
   const int lsafe = isl ? li : 0;
-  const int parent = isl ? mdl->parent[lsafe] : -1;
-  const int level = isl ? mdl->level[lsafe] : -1;
-  const int jt = isl ? mdl->joint_type[lsafe] : TDS_JOINT_FIXED;
-  const int di = isl ? mdl->qd_index[lsafe] : -1;  // == q_index (1-DoF joints only)
+  // (two-wavefront step-loop launches: from the workgroup's constant table in LDS where the host granted one, see the prologue)
+  const bool cwt = LOOP && W2 && KIND == 0 && L.cw != 0;  // wave-uniform
+  const T *const CW = sm + EPW * L.stride;
+  int parent, level, jt, di;
+  unsigned cw_hi = 0u;
+  if (cwt) {
+    const unsigned cw_lo = scalar_to_bits<T>(CW[3 * G + lane]);
+    cw_hi = scalar_to_bits<T>(CW[4 * G + lane]);
+    parent = (int)(cw_lo & 255u) - 1;
+    level = (int)((cw_lo >> 8) & 255u) - 1;
+    jt = (int)((cw_lo >> 16) & 255u);
+    di = (int)(cw_lo >> 24) - 1;
+  } else {
+    parent = isl ? mdl->parent[lsafe] : -1;
+    level = isl ? mdl->level[lsafe] : -1;
+    jt = isl ? mdl->joint_type[lsafe] : TDS_JOINT_FIXED;
+    di = isl ? mdl->qd_index[lsafe] : -1;  // == q_index (1-DoF joints only)
+  }
   // Floating base (DevModel::is_floating): lanes 0..5 are the base's pseudo links and the dofs are numbered
   // joints first, base last; the q / qd RECORD keeps the reference's order
   // q = [quat xyzw | pos | joints], qd = [omega | v | joints]  ->  record indices of this lane's coordinate
@@ -1357,17 +1409,31 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // Serial chains (parent == lane - 1, the common case for URDF-derived trees) hand their sweep
   // state from lane to lane with DPP row shifts; only the other parent/child links go through the
   // per-link LDS records (see DESIGN.md "chain hand-over").
-  const int cflags = isl ? mdl->chain_flags[lsafe] : 0;
+  int cflags, my_slot, par_slot, act_i;  // chain flags; my (v, a0) side record, my parent's; my action
+  T init_pose_l, stiff_l, damp_l;
+  if (cwt) {
+    cflags = (int)(cw_hi & 255u);
+    my_slot = (int)((cw_hi >> 8) & 255u) - 1;
+    par_slot = (int)((cw_hi >> 16) & 255u) - 1;
+    act_i = (int)(cw_hi >> 24) - 1;
+    init_pose_l = CW[0 * G + lane];
+    stiff_l = CW[1 * G + lane];
+    damp_l = CW[2 * G + lane];
+  } else {
+    cflags = isl ? mdl->chain_flags[lsafe] : 0;
+    my_slot = isl ? mdl->lc_slot[lsafe] : -1;
+    par_slot = (isl && parent >= 0) ? mdl->lc_slot[parent] : -1;
+    act_i = isl ? mdl->act_index[lsafe] : -1;
+    init_pose_l = mdl->init_pose[lsafe];
+    stiff_l = mdl->stiffness[lsafe];
+    damp_l = mdl->damping[lsafe];
+  }
   const bool chain_child = (cflags & 1) != 0;      // my parent is lane - 1
   const bool has_chain_child = (cflags & 2) != 0;  // lane + 1 is my child and hands over by DPP
   const bool lds_children = (cflags & 4) != 0;     // I have children that are not lane + 1
-  const int my_slot = isl ? mdl->lc_slot[lsafe] : -1;                        // my (v, a0) side record
-  const int par_slot = (isl && parent >= 0) ? mdl->lc_slot[parent] : -1;     // my parent's
   // PD / joint constants of the link (fetched here with the other lane constants: the PD block right
   // after the x record arrives must not start with a round trip to L2)
-  const int act_i = isl ? mdl->act_index[lsafe] : -1;
   const int sphq = (sph && isl) ? mdl->sph_q[lsafe] : -1;
-  const T init_pose_l = mdl->init_pose[lsafe], stiff_l = mdl->stiffness[lsafe], damp_l = mdl->damping[lsafe];
   const T act_lim = mdl->action_limit;
   const int step_mode = mdl->step_mode;
   // per-link model constants (joint axis, X_T, rigid inertia).  The straight-line build fetches
@@ -1375,6 +1441,20 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // step-loop build re-fetches them per iteration (keeping ~60 VGPRs live across the loop costs more).
   T Sl[6], mass_l, com_l[3], Il[9], RT[9], tT[3];
   auto load_link_consts = [&](const DevModel<T> *md) {
+    if (cwt && L.cw >= TDS_CW_ROWS) {  // (X_T from the workgroup's table; the rest is consumed phases later)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Sl[k] = md->S[k][lsafe];
+      mass_l = md->mass[lsafe];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) com_l[k] = md->com[k][lsafe];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Il[k] = md->inertia[k][lsafe];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) RT[k] = CW[(TDS_CW_LANE + k) * G + lane];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tT[k] = CW[(TDS_CW_LANE + 9 + k) * G + lane];
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) Sl[k] = md->S[k][lsafe];
     mass_l = md->mass[lsafe];
@@ -1390,6 +1470,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   if constexpr (!LOOP) {
     if (main_wave) load_link_consts(mdl);
   }
+#ifdef TDS_X_EARLY_CONSTS
+  // experiment: the step-loop build requests the link constants HERE as well, at the top of the iteration, so that their
+  // round trip runs under the PD block instead of in front of jcalc
+  else {
+    if (main_wave) load_link_consts(mdl);
+  }
+#endif
   // The same for the constants of the later phases (first narrowphase pass: contact point == lane,
   // visual == lane, mass-matrix row == lane, contact frame and solver scalars): issued here, their
   // L2 / scalar-cache latency is long gone when the phase starts; fetched where they are used, each
@@ -2108,7 +2195,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 
   TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
+#ifndef TDS_X_EARLY_CONSTS
   if constexpr (LOOP) load_link_consts(mdl);
+#endif
   if constexpr (LOOP && NDP >= 24) load_phase_consts(mdl);
   T Rp[9], tp[3];
   T sn, cs;  // sin / cos of the lane's joint angle (half angle for REVOLUTE_AXIS); phase C's closed-form root chain uses them
@@ -3858,7 +3947,8 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   const bool two_waves = (form & TDS_FORM_W2) != 0;
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
-  const size_t shmem = (size_t)L.stride * epw * sizeof(T);
+  // (+ the workgroup's constant table of the two-wavefront step-loop launches, TdsLds::cw)
+  const size_t shmem = (size_t)L.stride * epw * sizeof(T) + (two_waves ? (size_t)L.cw * lanes_per_env * sizeof(T) : 0);
   (void)h_model;
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \

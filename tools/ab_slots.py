@@ -33,15 +33,14 @@ n = args.envs
 rng = np.random.default_rng(0)
 x0 = np.zeros((n, m.input_dim))
 nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
-if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:
+if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION:  # (bench.py's start state)
     ip = np.array([m.initial_poses[i] for i in range(adim)])
-    x0[:, 2] = 0.48 if args.model == "ant" else 0.5
-    x0[:, nq - adim:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, adim))
-    g = np.load(os.path.join(ROOT, "tests", "golden", args.model + ".npz"))
-    x0[:, nq + nd + adim:] = g["x"][0, nq + nd + adim:]
+    x0[:, 2] = 0.48
+    x0[:, 6:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
+    x0[:, -3:] = [15, 0.3, 3] if args.model.startswith("ant") else [100, 2, 50]
 else:
     x0[:, :nq] = rng.uniform(-1, 1, (n, nq))
-amp = 0.4 if args.model == "ant" else 0.1
+amp = 0.4 if args.model.startswith("ant") else 0.1
 acts = torch.from_numpy(rng.uniform(-amp, amp, (16, n, adim))).cuda().contiguous()
 base_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.opt}
 RS = 64
@@ -78,13 +77,20 @@ for k, (s, obs, yr) in sims.items():
     print(f"slot {k}: 40 steps, max rel difference to slot {slots[0]}: {d:.3e}, finite {bool(np.isfinite(y).all())}")
 # spin-up (clocks)
 for k, (s, obs, yr) in sims.items():
-    s.step_many_rings(acts, 1000, obs, yr)
+    s.step_many_rings(acts, args.steps, obs, yr)
 torch.cuda.synchronize()
+# (every timed launch runs right behind the SAME conditioning launch — 256 steps of the first slot's handle: a launch that
+#  follows a slow one inherits its clocks, up to 10 % at these kernel sizes; the order of the slots rotates from repetition
+#  to repetition)
+cond = sims[slots[0]][0].prepared_step_many_rings(acts, 256, sims[slots[0]][1], sims[slots[0]][2])
 for K in (args.steps, args.short):
     calls = {k: s.prepared_step_many_rings(acts, K, obs, yr) for k, (s, obs, yr) in sims.items()}
     t = {k: [] for k in sims}
+    order = list(sims)
     for rep in range(args.reps + 1):
-        for k in sims:
+        order = order[1:] + order[:1]
+        for k in order:
+            cond()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             calls[k]()
