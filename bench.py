@@ -654,7 +654,14 @@ def main():
     finite = bad_envs == 0
 
     def timed(fn, k_steps):
-        """wall time of fn() bracketed by synchronisations, on this rank (secondary measurements, N = 1)"""
+        """wall time of fn() bracketed by synchronisations, on this rank (secondary measurements, N = 1); like the timed
+        region of `value`, right behind 256 untimed steps of the scratch handle (GPU clocks)"""
+        if scratch is not None:
+            scratch.step_many(actions, 256)
+            evs = torch.cuda.Event()
+            evs.record()
+            while not evs.query():
+                pass
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         fn()
@@ -706,8 +713,9 @@ def main():
                         "in_place": xo["shard_inplace"] != 0,
                         "what": "tds_hip_shard_step_many on ONE rank: step-loop launches of <= 256 steps storing every step's "
                                 "[obs | reward | done] record straight into this rank's block of the gathered buffer + one "
-                                "(in-place) all-gather of that slot per policy step on the communication stream, which "
-                                "follows the launch's progress counter (what every rank of an N > 1 run executes)"}
+                                "(in-place) all-gather of that slot per policy step on the communication stream — behind the "
+                                "launch as one RCCL group under the two-wavefront build (the N = 1 kernel), beside it following "
+                                "the slots' progress counters under the one-wave build (what every rank of an N > 1 run executes)"}
             sh1.close()
         except Exception as e:  # noqa: BLE001 - a secondary key must never cost the headline line
             one_rank = {"error": repr(e)}

@@ -617,21 +617,30 @@ int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const 
    forces that), and steps eagerly when auto-reset is on (the refill passes of the reset pool are host-driven).
 
    RING EXCHANGE.  Where tds_hip_step_many_is_loop holds for the shard's simulation (and the exchange block is 1) the
-   n_steps steps are step-loop launches of up to 64 steps — the very launches of tds_hip_step_many_rings, with the obs
-   ring in the wire dtype and a y ring, i.e. the same work per step as a single GPU does — and the communication stream
-   sends ring slot k as soon as the running launch has counted all its workgroups in for step k (a device counter the
-   stream polls with a one-lane kernel): one ncclAllGather per policy step, no kernel boundary per step, the host's two
-   calls per step (wait, all-gather) issued while the launch runs.  TDS_HIP_SHARD_GRAPH=1 replays each launch + its
-   exchanges from one hipGraph instead (cached by arguments; slower on ROCm 7: a chain of dependent graph nodes pays a
-   node-to-node latency a stream does not).  tds_hip_shard_gathered then returns the slot of the last step,
-   [world][n_local][obs_dim + 2].  TDS_HIP_SHARD_RING=0 forces the per-step-launch form. */
+   n_steps steps are step-loop launches of up to 256 steps (option shard_chunk) — the very launches of
+   tds_hip_step_many_rings, storing every step's record straight into this rank's block of that step's gathered slot (in-
+   place all-gather; the obs ring in the wire dtype) and a y ring, i.e. the same work per step as a single GPU does — with
+   one ncclAllGather per policy step on the communication stream, no kernel boundary per step, nothing the step needs
+   waiting for the exchange.  WHEN a slot travels depends on the build of the launch (option exchange_w2):
+     1 (default)  the two-wavefront build N = 1 runs: it fills every SIMD's register file, so nothing of the exchange
+                  could run beside it — the launch runs exactly as at N = 1 and the communication stream sends its slots
+                  as ONE RCCL group as soon as it has completed (beside the NEXT launch; launch j + 2 waits for the
+                  exchanges of launch j);
+     0            the one-wave build: every workgroup counts itself in on the slot's own device counter once its records
+                  of step k are visible device-wide, and the communication stream — one bounded one-lane wait kernel (or
+                  hipStreamWaitValue64: option shard_wait) + one all-gather per step — sends slot k while the launch runs
+                  step k + 1, as soon as the SLOWEST workgroup has stored it.
+   Option shard_graph = 1 replays each launch + its exchanges from one hipGraph instead (cached by arguments; slower on
+   ROCm 7: a chain of dependent graph nodes pays a node-to-node latency a stream does not).  tds_hip_shard_gathered then
+   returns the slot of the last step, [world][n_local][obs_dim + 2].  Option shard_ring = 0 forces the per-step-launch
+   form. */
 int tds_hip_shard_step_many(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks, int first_block,
                             int n_steps);
 /* capture + instantiate the graph of the next tds_hip_shard_step_many with the same arguments; nothing executes */
 int tds_hip_shard_step_many_prepare(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks,
                                     int first_block, int n_steps);
 /* Introspection of the ring exchange's host arithmetic (no device needed; csrc/tds_shard_plan.h): the step-loop launches
-   ("chunks", up to 64 steps each) a tds_hip_shard_step_many call of n_steps steps is cut into after chunks_done earlier
+   ("chunks", here of up to 64 steps each; a shard takes its option shard_chunk, default 256) a tds_hip_shard_step_many call of n_steps steps is cut into after chunks_done earlier
    chunks, 6 ints per chunk in out [6 * cap]: ring half | steps | first step of the call | action block of its first
    step | ring slot of its first step | progress count the communication stream waits for before it sends that slot
    (n_blocks workgroups per step; 0 = "the launch's completion").  Returns the number of chunks, -1 on bad arguments.

@@ -388,12 +388,27 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
       if (b2 <= 64 * 1024 && wg_per_cu >= 1) s->w2_max_blocks = w2_opt == 2 ? (1 << 30) : wg_per_cu * 256;
       // the workgroup's constant table of the step-loop launches (TdsLds::cw): as many rows as the LDS left over by
       // wg_per_cu workgroups holds — never at the price of a workgroup per CU (LDS is granted in 512-byte units)
-      for (const int rows : {TDS_CW_ROWS, TDS_CW_LANE}) {
+      for (const int rows : {TDS_CW_LANE(celem) + TDS_CW_XT, TDS_CW_LANE(celem)}) {
         const size_t with = ((b2 + (size_t)rows * s->lanes * celem + 511) / 512) * 512;
         if (wg_per_cu >= 1 && with <= 64 * 1024 && (size_t)wg_per_cu * with <= 160 * 1024) {
           s->lds_w2.cw = rows;
           break;
         }
+      }
+    }
+  }
+  // ... and of the one-wave step-loop launches: out of what the workgroups of the form's occupancy leave over (two
+  // wavefronts per SIMD = eight one-wave workgroups per CU below 24 padded dof, four from there on)
+  {
+    const bool plain = c64 ? (!s->h64.is_floating && !s->h64.num_spherical && s->h64.num_bodies < 2)
+                           : (!s->h32.is_floating && !s->h32.num_spherical && s->h32.num_bodies < 2);
+    const size_t b1 = (size_t)s->lds.stride * epw * celem;
+    const size_t per_cu = s->lds.NDP < 24 ? 8 : 4;
+    for (const int rows : {TDS_CW_LANE(celem) + TDS_CW_XT, TDS_CW_LANE(celem)}) {
+      const size_t with = ((b1 + (size_t)rows * s->lanes * celem + 511) / 512) * 512;
+      if (plain && with <= 64 * 1024 && per_cu * with <= 160 * 1024) {
+        s->lds.cw = rows;
+        break;
       }
     }
   }

@@ -24,12 +24,14 @@ struct TdsLds {
   int tau;                 // 18-dof kernels: per-link slot that keeps the generalised force from the PD block to phase F
   int in_dim, adim, nqnd;  // record dimensions as kernel arguments: the x record is requested from HBM before anything
                            // has been read from the model
-  int cw;                  // two-wavefront layout, step-loop launches: rows ([G] scalars each) of the WORKGROUP's constant
-                           // table behind the environments' regions (0: none; TDS_CW_LANE: the lane's small constants;
-                           // TDS_CW_ROWS: + X_T) — what every iteration of the step loop would otherwise re-fetch from L2
+  int cw;                  // step-loop launches of the plain kernels: rows ([G] scalars each) of the WORKGROUP's constant
+                           // table behind the environments' regions (0: none; TDS_CW_LANE(bytes per scalar): the lane's
+                           // small constants; + TDS_CW_XT: + X_T) — what every iteration of the step loop would otherwise
+                           // re-fetch from L2
 };
-#define TDS_CW_LANE 5   // init_pose | stiffness | damping | packed small integers (two rows)
-#define TDS_CW_ROWS 17  // ... + X_T (rotation 9, translation 3)
+// init_pose | stiffness | damping | packed small integers (one 8-byte row, or two 4-byte rows)
+#define TDS_CW_LANE(scalar_bytes) ((scalar_bytes) == 8 ? 4 : 5)
+#define TDS_CW_XT 12  // X_T: rotation 9, translation 3
 
 // what one launch does besides the physics (see the step loop in tds_kernels.hip)
 #define TDS_RESET_NONE 0

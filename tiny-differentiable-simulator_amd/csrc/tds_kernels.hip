@@ -1262,14 +1262,15 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     T *const xr = sm + grp0 * L.stride + L.xrec;
     // The lane's model constants are re-derived inside every iteration BY DESIGN (see above: nothing but the loop state may
     // stay live across the back edge) — which made every iteration begin with a round trip to L2 for the lane's small
-    // constants (in front of the PD block) and another one for X_T (in front of jcalc).  Two-wavefront step-loop launches
+    // constants (in front of the PD block) and another one for X_T (in front of jcalc).  Step-loop launches of the plain kernels
     // keep them in a table of the WORKGROUP in LDS instead (TdsLds::cw rows of [G] scalars behind the environments'
     // regions, filled here once per launch by the first lane group; the host grants the rows only where they do not cost a
     // workgroup per CU).  Measured (experiment slots, same process: profiles/r04_ab_slots3_lds_consts.txt): Ant x 4096 ring
     // launches 13.66 -> 13.46 (small constants) -> 13.08 us per step (+ X_T); mass / centre of mass / inertia / motion axis
     // on top change nothing (they are consumed phases later: their latency was hidden already).
-    if constexpr (W2 && KIND == 0) {
+    if constexpr (KIND == 0) {
       if (L.cw != 0) {  // wave-uniform (kernel argument)
+        constexpr int CWL = TDS_CW_LANE(sizeof(T));
         T *const CW = sm + EPW * L.stride;
         if (main_wave && grp0 == 0) {
           const int ls = lane < mdl->num_links ? lane : 0;
@@ -1285,14 +1286,19 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                               ((unsigned)((dii + 1) & 255) << 24);
           const unsigned hi = (unsigned)(cfl & 255) | ((unsigned)((msl + 1) & 255) << 8) | ((unsigned)((psl + 1) & 255) << 16) |
                               ((unsigned)((aci + 1) & 255) << 24);
-          CW[3 * G + lane] = bits_to_scalar<T>(lo);
-          CW[4 * G + lane] = bits_to_scalar<T>(hi);
-          if (L.cw >= TDS_CW_ROWS) {
+          if constexpr (sizeof(T) == 8) {
+            CW[3 * G + lane] = (T)__hiloint2double((int)hi, (int)lo);
+          } else {
+            CW[3 * G + lane] = bits_to_scalar<T>(lo);
+            CW[4 * G + lane] = bits_to_scalar<T>(hi);
+          }
+          if (L.cw >= CWL + TDS_CW_XT) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) CW[(TDS_CW_LANE + k) * G + lane] = mdl->X_T[k][ls];
+            for (int k = 0; k < 12; ++k) CW[(CWL + k) * G + lane] = mdl->X_T[k][ls];
           }
         }
-        __syncthreads();
+        if constexpr (W2) __syncthreads();
+        else TDS_WAVE_SYNC();
       }
     }
     if (main_wave) {  // (a helper wavefront first touches the record behind barrier (1) of the first step)
@@ -1352,14 +1358,22 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   const int li = lane;
   const bool isl = li < nl;
   const int lsafe = isl ? li : 0;
-  // (two-wavefront step-loop launches: from the workgroup's constant table in LDS where the host granted one, see the prologue)
-  const bool cwt = LOOP && W2 && KIND == 0 && L.cw != 0;  // wave-uniform
+  // (step-loop launches: from the workgroup's constant table in LDS where the host granted one, see the prologue)
+  const bool cwt = LOOP && KIND == 0 && L.cw != 0;  // wave-uniform
+  constexpr int CWL = TDS_CW_LANE(sizeof(T));
   const T *const CW = sm + EPW * L.stride;
   int parent, level, jt, di;
   unsigned cw_hi = 0u;
   if (cwt) {
-    const unsigned cw_lo = scalar_to_bits<T>(CW[3 * G + lane]);
-    cw_hi = scalar_to_bits<T>(CW[4 * G + lane]);
+    unsigned cw_lo;
+    if constexpr (sizeof(T) == 8) {
+      const double pk = (double)CW[3 * G + lane];
+      cw_lo = (unsigned)__double2loint(pk);
+      cw_hi = (unsigned)__double2hiint(pk);
+    } else {
+      cw_lo = scalar_to_bits<T>(CW[3 * G + lane]);
+      cw_hi = scalar_to_bits<T>(CW[4 * G + lane]);
+    }
     parent = (int)(cw_lo & 255u) - 1;
     level = (int)((cw_lo >> 8) & 255u) - 1;
     jt = (int)((cw_lo >> 16) & 255u);
@@ -1441,7 +1455,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // step-loop build re-fetches them per iteration (keeping ~60 VGPRs live across the loop costs more).
   T Sl[6], mass_l, com_l[3], Il[9], RT[9], tT[3];
   auto load_link_consts = [&](const DevModel<T> *md) {
-    if (cwt && L.cw >= TDS_CW_ROWS) {  // (X_T from the workgroup's table; the rest is consumed phases later)
+    if (cwt && L.cw >= CWL + TDS_CW_XT) {  // (X_T from the workgroup's table; the rest is consumed phases later)
 #pragma unroll
       for (int k = 0; k < 6; ++k) Sl[k] = md->S[k][lsafe];
       mass_l = md->mass[lsafe];
@@ -1450,9 +1464,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 #pragma unroll
       for (int k = 0; k < 9; ++k) Il[k] = md->inertia[k][lsafe];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) RT[k] = CW[(TDS_CW_LANE + k) * G + lane];
+      for (int k = 0; k < 9; ++k) RT[k] = CW[(CWL + k) * G + lane];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) tT[k] = CW[(TDS_CW_LANE + 9 + k) * G + lane];
+      for (int k = 0; k < 3; ++k) tT[k] = CW[(CWL + 9 + k) * G + lane];
       return;
     }
 #pragma unroll
@@ -3947,8 +3961,8 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   const bool two_waves = (form & TDS_FORM_W2) != 0;
   const int epw = 64 / lanes_per_env;
   const int blocks = (n_envs + epw - 1) / epw;
-  // (+ the workgroup's constant table of the two-wavefront step-loop launches, TdsLds::cw)
-  const size_t shmem = (size_t)L.stride * epw * sizeof(T) + (two_waves ? (size_t)L.cw * lanes_per_env * sizeof(T) : 0);
+  // (+ the workgroup's constant table of the step-loop launches, TdsLds::cw)
+  const size_t shmem = (size_t)L.stride * epw * sizeof(T) + (size_t)L.cw * lanes_per_env * sizeof(T);
   (void)h_model;
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \

@@ -458,11 +458,45 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
   r.y_slots = TDS_SHARD_Y_SLOTS;
   r.y_first = 0;
   r.y_stride = sh->ry_stride;
-  r.progress = counters;
+  // Which build the launch takes decides how its slots are exchanged.  The one-wave build (option exchange_w2 = 0) leaves
+  // the exchange's kernels room beside it: the communication stream follows the slots' counters and sends slot k while
+  // the launch runs step k + 1.  The two-wavefront build (the default: the kernel N = 1 runs) fills every SIMD's register
+  // file — a wait or an all-gather gets onto a compute unit only when the launch retires, so per-slot waits buy nothing
+  // and cost a kernel each (measured on one rank: 15.6 against 13.8 us per step, profiles/
+  // r04_one_rank_exchange_with_table.txt): the launch then runs exactly as at N = 1 — no progress counter, streaming
+  // stores — and the communication stream waits for its completion ONCE and sends the launch's slots as one RCCL group.
+  const int n_blocks = tds_hip_step_many_rings_blocks(s);
+  const bool after_launch = s->opt.get(TDS_OPT_EXCHANGE_W2, 1) != 0 && s->opt.get(TDS_OPT_LOOP_W2, 1) != 0 &&
+                            s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && s->lds_w2.NDP <= 16;
+  r.progress = after_launch ? nullptr : counters;
   int rc = tds_hip_step_many_rings(s, actions_dev, pool, ck.act_first, ck.steps, &r);
   if (rc != TDS_OK) return rc;
   TDS_HIP_TRY(hipEventRecord(e_kernel, s->stream));
-  const int n_blocks = tds_hip_step_many_rings_blocks(s);
+  if (after_launch) {
+    TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, e_kernel, 0));
+    if (sh->comm) {
+      NCCL_TRY(rccl()->GroupStart());
+      for (int k = 0; k < ck.steps; ++k) {
+        char *const dst = (char *)sh->rgath + (size_t)(ck.slot0 + k) * slot_b * sh->world;
+        const void *src = sh->inplace ? (const void *)(dst + (size_t)sh->rank * slot_b)
+                                      : (const void *)((const char *)sh->rwire + (size_t)(ck.slot0 + k) * slot_b);
+        const ncclResult_t gr = rccl()->AllGather(src, dst, sh->slot_scalars(), sh->wire_bytes == 8 ? ncclFloat64 : ncclFloat32,
+                                                  sh->comm, sh->comm_stream);
+        if (gr != ncclSuccess) {
+          (void)rccl()->GroupEnd();
+          snprintf(g_err, sizeof(g_err), "ncclAllGather (ring exchange, grouped) failed: %s", rccl()->GetErrorString(gr));
+          return TDS_ERR_HIP;
+        }
+      }
+      NCCL_TRY(rccl()->GroupEnd());
+      if (!capturing) sh->comm_warm = true;
+    } else if (!sh->inplace) {  // (one rank, no communicator: the launch's slots are contiguous in both rings)
+      TDS_HIP_TRY(hipMemcpyAsync((char *)sh->rgath + (size_t)ck.slot0 * slot_b, (const char *)sh->rwire + (size_t)ck.slot0 * slot_b,
+                                 (size_t)ck.steps * slot_b, hipMemcpyDeviceToDevice, sh->comm_stream));
+    }
+    TDS_HIP_TRY(hipEventRecord(e_comm, sh->comm_stream));
+    return TDS_OK;
+  }
   const long long timeout_ticks = s->opt.get(TDS_OPT_SHARD_WAIT_MS, 2000) * 100000ll;  // 100 MHz
   const bool nothing_to_move = sh->inplace && sh->world == 1 && !sh->comm;
   for (int k = 0; k < ck.steps; ++k) {
