@@ -281,3 +281,66 @@ def test_rings_with_auto_reset(name, built):
         dones += int((obs[:, -1] != 0).sum().item())
     assert dones >= n // 4
     assert rel_err(sims[0].x.cpu().numpy(), sims[1].x.cpu().numpy()) < TOL
+
+
+def test_rings_with_auto_reset_against_the_reference_at_full_size(built):
+    """Config 3's size through the form bench.py's auto_reset_rate times: Ant x 4096, auto_reset_when_done, 20 steps as
+    step-loop launches through the reset pool with both rings on.  The host replays the reference's loop environment by
+    environment — its own step (libtds_ref.so), compute_reward_done (ant_environment2.h:75-106) and, for an environment that
+    ends a step with done, reset() + the ten settle steps (ant_environment2.h:109-165; the device's counter-based random
+    stream, restated in test_hip_parity._host_reset) — and every slot of both rings must agree: reward / done of the step
+    that ended, the observation of the FRESH environment, the y record of the terminal state
+    (ars_vectorized_environment.h:262-289)."""
+    torch = _torch()
+    from test_hip_parity import _host_reset, _reference_stepper
+
+    name, n, steps, seed = "ant", 4096, 20, 23
+    m = tds_amd.load_model(name)
+    ref_step, what = _reference_stepper(name, n)
+    rng = np.random.default_rng(99)
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    x0 = _start_state(m, name, n, rng)
+    sim = hip_backend.HipSim(m, n, dtype="f64")
+    sim.x.copy_(torch.from_numpy(x0).cuda())
+    for _ in range(10):
+        sim.step(None)
+    # a tenth of the batch starts just above the termination height: resets in every one of the 20 steps
+    xs = sim.x.cpu().numpy().copy()
+    low = rng.permutation(n)[: n // 10]
+    xs[low, 2] = 0.262 + 0.02 * rng.uniform(0, 1, len(low))
+    sim.x.copy_(torch.from_numpy(xs).cuda())
+    sim.set_auto_reset(True, seed)
+    act = rng.uniform(-0.4, 0.4, (steps, n, adim))
+    actions = torch.from_numpy(act).cuda().contiguous()
+    obs_ring = torch.full((steps, n, sim.obs_dim + 2), float("nan"), dtype=torch.float64, device="cuda")
+    y_ring = torch.full((steps, n, m.output_dim), float("nan"), dtype=torch.float64, device="cuda")
+    sim.step_many_rings(actions, steps, obs_ring, y_ring)
+    torch.cuda.synchronize()
+    orr, yr = obs_ring.cpu().numpy(), y_ring.cpu().numpy()
+    assert np.isfinite(orr).all() and np.isfinite(yr).all()
+    x = xs.copy()
+    count = np.zeros(n, dtype=np.int64)  # resets of the environment so far = its position in the random stream
+    resets = 0
+    for k in range(steps):
+        x[:, nq + nd:nq + nd + adim] = act[k]
+        y_ref = ref_step(x)
+        rew, done = _reward_done(m, name, x[:, :nq], y_ref)
+        edge = np.abs(y_ref[:, 2] - 0.26) < 1e-7  # (within round-off of the threshold: either side)
+        assert rel_err(yr[k], y_ref) < TOL, k
+        got_done = orr[k][:, -1] != 0
+        assert (got_done[~edge] == done[~edge]).all(), k
+        assert rel_err(orr[k][~edge, -2], rew[~edge], floor=1.0) < 10 * TOL, k
+        nxt = y_ref[:, :nq + nd].copy()
+        for e in np.where(got_done)[0]:  # (the device's decision where the reference sits on the threshold)
+            nxt[e] = _host_reset(m, x[e], seed, int(e), int(count[e]))
+            count[e] += 1
+            resets += 1
+        ob = nxt.copy()
+        ob[:, :2] = 0.0
+        assert rel_err(orr[k][:, :nq + nd], ob) < TOL, k
+        # resync on the device's own state: what its next step started from
+        x[:, :nq + nd] = np.where(got_done[:, None], orr[k][:, :nq + nd], yr[k][:, :nq + nd])
+        x[got_done, :2] = nxt[got_done, :2]  # (the observation zeroes the base x, y; the state keeps them)
+    assert resets >= n // 10, resets
+    assert rel_err(sim.x.cpu().numpy()[:, :nq + nd], x[:, :nq + nd]) < TOL
+    print(f"ant x{n}, auto-reset ring form, {steps} slots, {resets} resets, every env, vs {what} + host reset: ok")
