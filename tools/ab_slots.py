@@ -82,7 +82,12 @@ torch.cuda.synchronize()
 # (every timed launch runs right behind the SAME conditioning launch — 256 steps of the first slot's handle: a launch that
 #  follows a slow one inherits its clocks, up to 10 % at these kernel sizes; the order of the slots rotates from repetition
 #  to repetition)
-cond = sims[slots[0]][0].prepared_step_many_rings(acts, 256, sims[slots[0]][1], sims[slots[0]][2])
+# (a handle of its own: a graph-form model keeps ONE graph per handle — alternating 256- and K-step calls on a timed handle
+#  would re-instantiate its graph inside the timed region)
+cs = hip_backend.HipSim(m, n, dtype="f64", options=dict(base_opts))
+cs.x.copy_(sims[slots[0]][0].x)
+cobs, cyr = torch.zeros_like(sims[slots[0]][1]), torch.zeros_like(sims[slots[0]][2])
+cond = cs.prepared_step_many_rings(acts, 256, cobs, cyr)
 for K in (args.steps, args.short):
     calls = {k: s.prepared_step_many_rings(acts, K, obs, yr) for k, (s, obs, yr) in sims.items()}
     t = {k: [] for k in sims}
