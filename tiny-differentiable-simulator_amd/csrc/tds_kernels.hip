@@ -1178,10 +1178,7 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
 // grid fits the GPU at once (tds_launch_step_impl).
 template <typename T, typename TR, int G, int NDP, bool PROF, int LP, int KIND, bool W2 = false>
 __global__ __launch_bounds__(W2 ? 128 : 64)
-#ifndef TDS_X_WAVES_STRAIGHT  // (experiment: wavefronts per SIMD the straight-line one-wave builds are compiled for)
-#define TDS_X_WAVES_STRAIGHT 2
-#endif
-__attribute__((amdgpu_waves_per_eu((LP == 0 && !W2 && NDP < 24) ? TDS_X_WAVES_STRAIGHT : ((LP == 2 || W2) ? 2 : 1))))
+__attribute__((amdgpu_waves_per_eu((LP == 2 || W2 || (LP == 0 && NDP < 24)) ? 2 : 1)))
 void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
                                                       const TR *x_in, TR *__restrict__ y_out,
                                                       const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
@@ -1333,29 +1330,6 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
   }
 
-#ifdef TDS_X_HOIST_SCALARS
-  // experiment: the model's UNIFORM scalars are read once, ahead of the loop, and stay in SGPRs (or their spill lanes) —
-  // the laundered model pointer made every iteration re-read them from the scalar cache, each read in front of a
-  // s_waitcnt lgkmcnt(0) that also waits for the LDS
-  struct {
-    int nl, nq, nd, in_dim, out_dim, adim, njd, step_mode, nlev, rkc, eul, leg_len, rk, didn;
-    T dt, act_lim, bt[3], gr[3];
-  } UH;
-  UH.nl = mdl_arg->num_links; UH.nq = mdl_arg->dof_q; UH.nd = mdl_arg->dof_qd; UH.in_dim = mdl_arg->input_dim;
-  UH.out_dim = mdl_arg->output_dim; UH.adim = mdl_arg->action_dim; UH.njd = mdl_arg->nj; UH.step_mode = mdl_arg->step_mode;
-  UH.nlev = mdl_arg->num_levels; UH.rkc = mdl_arg->kin_chain_last; UH.eul = mdl_arg->euler_root; UH.leg_len = mdl_arg->leg_len;
-  UH.rk = mdl_arg->root_last; UH.didn = mdl_arg->dof_identity;
-  UH.dt = mdl_arg->dt; UH.act_lim = mdl_arg->action_limit;
-  for (int k = 0; k < 3; ++k) { UH.bt[k] = mdl_arg->base_t[k]; UH.gr[k] = mdl_arg->grav[k]; }
-// (TDS_X_HOIST_SCALARS = 1: all of them; 2: the integers; 3: only the flags that steer uniform branches; 4: flags + reals)
-#define TDS_UH(field, expr) (LOOP ? UH.field : (expr))
-#define TDS_UHD(field, expr) ((LOOP && (TDS_X_HOIST_SCALARS == 1 || TDS_X_HOIST_SCALARS == 4)) ? UH.field : (expr))
-#define TDS_UHI(field, expr) ((LOOP && TDS_X_HOIST_SCALARS <= 2) ? UH.field : (expr))
-#else
-#define TDS_UH(field, expr) (expr)
-#define TDS_UHD(field, expr) (expr)
-#define TDS_UHI(field, expr) (expr)
-#endif
   for (;;) {  // ================================ step loop ================================
   if constexpr (LOOP) {
     if (!__any(mode != TDS_MODE_IDLE)) break;
@@ -1372,10 +1346,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   const bool valid = env < n_envs;
   T *const E = sm + grp * L.stride;
 
-  const int nl = TDS_UHI(nl, mdl->num_links), nq = TDS_UHI(nq, mdl->dof_q), nd = TDS_UHI(nd, mdl->dof_qd);
-  const int in_dim = TDS_UHI(in_dim, mdl->input_dim), out_dim = TDS_UHI(out_dim, mdl->output_dim), adim = TDS_UHI(adim, mdl->action_dim);
+  const int nl = mdl->num_links, nq = mdl->dof_q, nd = mdl->dof_qd;
+  const int in_dim = mdl->input_dim, out_dim = mdl->output_dim, adim = mdl->action_dim;
   constexpr int NDs = NDP + 1;  // odd row stride of every [row][dof] array
-  const T dt = TDS_UHD(dt, mdl->dt);
+  const T dt = mdl->dt;
 
   // ---- lane == link: constants -------------------------------------------------------------
   const int li = lane;
@@ -1430,7 +1404,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // helper in two halves through LDS flags (tds_row_solve), the contact counts reach this wavefront the same way
   constexpr bool PIPE = W2 && NDP <= 16;
   const int bod = (two && isl) ? mdl->body_of_link[lsafe] : 0;  // my link's body
-  const int njd = TDS_UHI(njd, mdl->nj);          // joint dofs (== nd on a fixed base)
+  const int njd = mdl->nj;          // joint dofs (== nd on a fixed base)
   const int fbk = (flm && isl) ? mdl->fb_k[lsafe] : (fl && isl && li < 6 ? li : -1);  // pseudo link k of a floating base
   const int fbq = (flm && isl) ? mdl->fb_q[lsafe] : 0;  // ... its body's quaternion in the q record (position at + 4)
   const bool froot = fbk >= 0;                   // base pseudo link
@@ -1471,8 +1445,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // PD / joint constants of the link (fetched here with the other lane constants: the PD block right
   // after the x record arrives must not start with a round trip to L2)
   const int sphq = (sph && isl) ? mdl->sph_q[lsafe] : -1;
-  const T act_lim = TDS_UHD(act_lim, mdl->action_limit);
-  const int step_mode = TDS_UHI(step_mode, mdl->step_mode);
+  const T act_lim = mdl->action_limit;
+  const int step_mode = mdl->step_mode;
   // per-link model constants (joint axis, X_T, rigid inertia).  The straight-line build fetches
   // them HERE, ahead of the x record, so that their L2 latency overlaps the HBM latency of x; the
   // step-loop build re-fetches them per iteration (keeping ~60 VGPRs live across the loop costs more).
@@ -1507,13 +1481,6 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   if constexpr (!LOOP) {
     if (main_wave) load_link_consts(mdl);
   }
-#ifdef TDS_X_EARLY_CONSTS
-  // experiment: the step-loop build requests the link constants HERE as well, at the top of the iteration, so that their
-  // round trip runs under the PD block instead of in front of jcalc
-  else {
-    if (main_wave) load_link_consts(mdl);
-  }
-#endif
   // The same for the constants of the later phases (first narrowphase pass: contact point == lane,
   // visual == lane, mass-matrix row == lane, contact frame and solver scalars): issued here, their
   // L2 / scalar-cache latency is long gone when the phase starts; fetched where they are used, each
@@ -2232,9 +2199,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
 
   TDS_STAMP(1);
   // ---- B. jcalc: X_parent = X_T * X_J(q)   (link.hpp:229-287) -------------------------------
-#ifndef TDS_X_EARLY_CONSTS
   if constexpr (LOOP) load_link_consts(mdl);
-#endif
   if constexpr (LOOP && NDP >= 24) load_phase_consts(mdl);
   T Rp[9], tp[3];
   T sn, cs;  // sin / cos of the lane's joint angle (half angle for REVOLUTE_AXIS); phase C's closed-form root chain uses them
@@ -2315,10 +2280,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     cb[4] = c1[1] + c2[1];
     cb[5] = c1[2] + c2[2];
   };
-  const int nlev = TDS_UH(nlev, mdl->num_levels);
-  const int rkc = TDS_UH(rkc, mdl->kin_chain_last);  // serial chain 0..rkc from the base in lanes 0..rkc (>= the root joint of E'): -1 = none
-  const int eul = KIND == 0 ? TDS_UH(eul, mdl->euler_root) : 0;  // wave-uniform
-  const int leg_len = KIND == 0 ? TDS_UH(leg_len, mdl->leg_len) : 0;  // wave-uniform: the links behind the root chain are chains of this length
+  const int nlev = mdl->num_levels;
+  const int rkc = mdl->kin_chain_last;  // serial chain 0..rkc from the base in lanes 0..rkc (>= the root joint of E'): -1 = none
+  const int eul = KIND == 0 ? mdl->euler_root : 0;  // wave-uniform
+  const int leg_len = KIND == 0 ? mdl->leg_len : 0;  // wave-uniform: the links behind the root chain are chains of this length
   if (eul != 0) {
     // ---- The root chain in CLOSED FORM (DevModel::euler_root: links 0..5 = prismatic X, Y, Z, revolute X, Y, Z with
     //      identity X_T — the free motion of the URDF-derived fixed-base robots, the Ant and Laikago).  The chain's six
@@ -2336,7 +2301,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     R[0] = cy * cz;                 R[1] = -cy * sz;                R[2] = sy;
     R[3] = sx * sy * cz + cx * sz;  R[4] = cx * cz - sx * sy * sz;  R[5] = -sx * cy;
     R[6] = sx * sz - cx * sy * cz;  R[7] = cx * sy * sz + sx * cz;  R[8] = cx * cy;
-    const T P[3] = {q0 + TDS_UHD(bt[0], mdl->base_t[0]), q1 + TDS_UHD(bt[1], mdl->base_t[1]), q2 + TDS_UHD(bt[2], mdl->base_t[2])};
+    const T P[3] = {q0 + mdl->base_t[0], q1 + mdl->base_t[1], q2 + mdl->base_t[2]};
     const T A3[3] = {T(1), T(0), T(0)}, A4[3] = {T(0), cx, sx}, A5[3] = {sy, -sx * cy, cx * cy};
     const T C0[3] = {T(1), T(0), T(0)}, C1[3] = {T(0), T(1), T(0)}, C2[3] = {T(0), T(0), T(1)};
     p[0] = P[0]; p[1] = P[1]; p[2] = P[2];
@@ -2401,7 +2366,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         v[k] = torso ? W5[k] : T(0);
         v[3 + k] = torso ? V5[k] : T(0);
         a0[k] = torso ? a45[k] + a55[k] : T(0);
-        a0[3 + k] = torso ? (l3[k] + l4[k] + l5[k]) - TDS_UHD(gr[k], mdl->grav[k]) : T(0);
+        a0[3 + k] = torso ? (l3[k] + l4[k] + l5[k]) - mdl->grav[k] : T(0);
       }
     }
     if (leg_len != 0) {
@@ -2942,7 +2907,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     Cb = dot3(sw, fx) + dot3(sw + 3, fx + 3);
   };
   // with a root joint (DevModel::root_last) the massless base chain 0..rk-1 is handled after the loop
-  const int rk = TDS_UH(rk, mdl->root_last);  // == level of that link; -1: none
+  const int rk = mdl->root_last;  // == level of that link; -1: none
   // A robot that is ONE serial chain (pendulums, the cartpole): the composites are suffix sums along the lanes —
   // log2 rounds of DPP shifts and one projection for all links at once instead of one level per link
   const bool pure_chain = rk < 0 && mdl->kin_chain_last == nl - 1 && nl > 1;  // wave-uniform
@@ -3065,7 +3030,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     T *const Lp = E + L.Lp;     // strictly-lower L packed row-major: L[r][j] at r(r-1)/2 + j
     T *const dvec = E + L.dinv; // [3][NDP]: 1/D_k | sqrt(1/D_k) | column scratch (NDP > 16)
     // lane == link == dof for every link (DevModel::dof_identity: the Ant): F, tau - C stay in the lane's registers
-    const bool didn = !gen && !two && TDS_UH(didn, mdl->dof_identity) != 0;  // wave-uniform
+    const bool didn = !gen && !two && mdl->dof_identity != 0;  // wave-uniform
     if (!didn) {
       if (isl) {
 #pragma unroll
