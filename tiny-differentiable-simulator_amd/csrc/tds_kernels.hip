@@ -1439,6 +1439,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     stiff_l = mdl->stiffness[lsafe];
     damp_l = mdl->damping[lsafe];
   }
+  if constexpr (W2 && LOOP) {
+    if (main_wave && tds_iter > 0) {  // the helper has read X_world of the previous step (its late visual poses, see there)
+      const volatile T *const pf = sm + grp * L.stride + L.xrec + in_dim + 4;
+      while (__any(*pf != T(2))) __builtin_amdgcn_s_sleep(1);
+    }
+  }
   const bool chain_child = (cflags & 1) != 0;      // my parent is lane - 1
   const bool has_chain_child = (cflags & 2) != 0;  // lane + 1 is my child and hands over by DPP
   const bool lds_children = (cflags & 4) != 0;     // I have children that are not lane + 1
@@ -1742,11 +1748,23 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     }
     return __builtin_amdgcn_readfirstlane(NAv);
   };
-  auto phase_M1 = [&]() {
+  auto phase_M1 = [&](const bool late = false) {  // (late: not behind the narrowphase — the prefetched visual is gone)
     T *const Xw = E + L.Xw;
   // ---- M1. visual poses of y (they use the PRE-step X_world, locomotion_contact_simulation.h:281-299)
     {
-      TR *const yo = y_step;
+      // (late: the record's address is derived again, from a laundered copy of the environment index — carried from the
+      //  top of the iteration through the narrowphase, the rows and the row solves it costs the build its last registers)
+      int env_l = env;
+      const T *Xw_l = Xw;
+      if (late) {
+        int lane_2 = lane0, grp_2 = grp0;
+        asm volatile("" : "+v"(lane_2), "+v"(grp_2));
+        env_l = blockIdx.x * EPW + grp_2;
+        Xw_l = sm + grp_2 * L.stride + L.Xw;
+      }
+      TR *const yo = !late ? y_step
+                           : (ring_y ? (TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env_l) * ystr
+                                     : y_out + (size_t)env_l * (LOOP ? out_dim : ystr));
       const int nv = pf_nv;
       const int vbase = nq + nd;
       if (pack_y) {  // y describes the last normal step of the launch (y ring: every step its own slot)
@@ -1756,14 +1774,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           // fetch their phase constants at the top of the iteration and read the visuals here
           // (not the two-wavefronts-per-SIMD step-loop build: carrying 24 more registers through the narrowphase costs it
           //  116 B of scratch)
-          const bool first = (!LOOP || (NDP < 24 && LP != 2)) && k == lane;
+          const bool first = !late && (!LOOP || (NDP < 24 && LP != 2)) && k == lane;
           int lk = pf_vis_link;
           if (!first) lk = mdl->vis_link[k];
           T Rl[9], pl[3], Rv[9], pv[3];
 #pragma unroll
-          for (int c = 0; c < 9; ++c) Rl[c] = Xw[lk * TDS_S1 + c];
+          for (int c = 0; c < 9; ++c) Rl[c] = Xw_l[lk * TDS_S1 + c];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) pl[c] = Xw[lk * TDS_S1 + 9 + c];
+          for (int c = 0; c < 3; ++c) pl[c] = Xw_l[lk * TDS_S1 + 9 + c];
 #pragma unroll
           for (int c = 0; c < 9; ++c) Rv[c] = pf_vis_X[c];
 #pragma unroll
@@ -1790,7 +1808,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
             // (the LAST step of a launch with a y ring also leaves its record in the handle's y record: what a device
             //  copy of the ring slot behind the launch used to do, at the price of a dispatch per call)
             if (ring_y && last_run && y_out != nullptr) {  // wave-uniform
-              TR *o2 = y_out + (size_t)env * out_dim + vbase + 7 * k;
+              TR *o2 = y_out + (size_t)env_l * out_dim + vbase + 7 * k;
               o2[0] = (TR)(pl[0] + po[0]);
               o2[1] = (TR)(pl[1] + po[1]);
               o2[2] = (TR)(pl[2] + po[2]);
@@ -2060,7 +2078,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         }
       }
       TDS_STAMP(3);
-      phase_M1();
+      // (the visual poses go out behind barrier (3), in this wavefront's idle tail — see there)
       flush_prev_records();
       if (pack_y && !(DEFER && ring_y)) {  // tail of the y record: up_dot_world_z, zero padding
         TR *const yo = y_step;
@@ -2085,17 +2103,37 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         __syncthreads();  // (2) the factors L, 1/D are in LDS; the rows and the contact list are visible to the main wavefront
       }
       TDS_STAMP(6);
+      // (the row solves end at barrier (3), where the main wavefront arrives from its forward-dynamics solve: from here to
+      //  the barrier the helper is as critical as the main wavefront it shares its SIMD with — same priority.  Measured,
+      //  profiles/r04_ab_slots7_helper_priority.txt: 13.37 -> 13.21 us per step; the main wavefront was waiting ~2 k cycles
+      //  at barrier (3) once it had priority everywhere, profiles/r04f_ant4096_f64_phases.txt.  From the Jacobian rows or
+      //  the narrowphase on instead: 12.99 / 13.29 against 12.71, no priorities at all 13.58,
+      //  profiles/r04_ab_slots9_helper_from.txt)
+      if constexpr (TDS_MAIN_PRIO > 0) __builtin_amdgcn_s_setprio(TDS_MAIN_PRIO);
       if (contacts_h && split_ok)
         tds_row_solve<false, T, G, NDP, true>(lane, NA_h, na_h, nd, ZR, OVR, NCPp, Zs, rws, xs, xr + nq, cpx, E + L.Lp,
                                              E + L.dinv, nullptr, nullptr, pf_cfm, pf_erp_dt, pf_rest,
                                              L.gram_ok ? nullptr : xr + in_dim + 4, dt,
                                              PIPE ? xr + in_dim + 5 : nullptr, PIPE ? E + L.Lh : nullptr);
       TDS_STAMP(7);
+      if constexpr (TDS_MAIN_PRIO > 0) __builtin_amdgcn_s_setprio(0);
       if constexpr (LOOP) {  // (the records this wavefront stored behind the visual poses)
         if (!(ctl.ring_flags & TDS_RING_SIGNAL_LATE) || last_run) signal_progress();
       }
       __syncthreads();  // (3) z~ rows and their scalars are final
       TDS_STAMP(8);
+      // The visual poses of this step go out HERE, in the helper's idle tail, not between the narrowphase
+      // and the Jacobian rows: with the main wavefront at priority the helper's I -> M1 -> J -> K had become the longer
+      // path to barrier (3) (profiles/r04f_ant4096_f64_phases.txt: the main wavefront waited 2.1 k cycles there).  X_world
+      // stays in LDS until the main wavefront's next kinematics sweep; in the step-loop builds the main wavefront makes sure
+      // of that with the flag below at the top of its next iteration (normally long set).  Measured with the priority above
+      // (profiles/r04_ab_slots8_m1_late.txt): 13.40 -> 12.86 us per step.  (Round 3 had tried this move without the
+      // priorities: no gain — the helper was not the critical path then.)
+      phase_M1(true);
+      if constexpr (LOOP) {
+        TDS_WAVE_SYNC();
+        if (lane == 0) xr[in_dim + 4] = T(2);  // "poses are out" (the slot of the y~ flag, free until the next barrier (1))
+      }
       if constexpr (LOOP) {
         // the same bookkeeping the main wavefront does for a plain / replayed step (these launches have no settle steps)
         if (mode == TDS_MODE_RUN && --left == 0) mode = TDS_MODE_IDLE;

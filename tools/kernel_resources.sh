@@ -1,14 +1,15 @@
 #!/bin/bash
 # Compiler-reported resources of every step-kernel instantiation (no GPU needed):
 #   tools/kernel_resources.sh [f64|mix|f32] [kind] > profiles/rNN_kernel_resources_<build>_k<kind>.txt
-# VGPR / AGPR / scratch / occupancy per instantiation from -Rpass-analysis=kernel-resource-usage.
+# VGPR / AGPR / scratch / occupancy per instantiation from -Rpass-analysis=kernel-resource-usage, compiled with the
+# Makefile's KFLAGS (TDS_KFLAGS= overrides them, TDS_EXTRA_FLAGS adds to them).
 set -e
 BUILD=${1:-f64}; KIND=${2:-0}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CS=$ROOT/tiny-differentiable-simulator_amd/csrc
 DEF=$(echo $BUILD | tr a-z A-Z)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$CS -DTDS_ONLY_$DEF -DTDS_ONLY_KIND=$KIND \
-  $TDS_EXTRA_FLAGS -Rpass-analysis=kernel-resource-usage -c -o /dev/null $CS/tds_kernels.hip 2>&1 | python3 -c '
+  ${TDS_KFLAGS--mllvm -disable-machine-licm} $TDS_EXTRA_FLAGS -Rpass-analysis=kernel-resource-usage -c -o /dev/null $CS/tds_kernels.hip 2>&1 | python3 -c '
 import re,sys
 cur=None; rows=[]
 for line in sys.stdin:
