@@ -83,7 +83,8 @@ def stub_lib(tmp_path_factory):
 
 
 @pytest.mark.parametrize("mode,name,steps,env", [
-    ("many", "ant", 75, {}),                                   # ring exchange submitted eagerly (the default)
+    ("many", "ant", 75, {}),                                   # ring exchange submitted eagerly (the default: two-wavefront build, slots sent behind the launch as one group)
+    ("many", "ant", 75, {"TDS_HIP_EXCHANGE_W2": "0"}),         # ... the one-wave build: per-slot counters, a slot sent while the launch runs
     ("many", "ant", 75, {"TDS_HIP_SHARD_GRAPH": "1"}),         # ring exchange, one hipGraph per step-loop launch
     ("many", "ant", 75, {"TDS_HIP_RING_NOFENCE": "0"}),        # records made visible by a release fence instead of write-through stores
     ("many", "pendulum5", 30, {}),                             # a world without contacts (always the step-loop form)
