@@ -153,7 +153,11 @@ def pmc_traffic_rings(model, n, dtype, steps_per_launch):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             e = json.load(f)[model][str(n)][dtype]["rings"]
         w = e["write_kib_per_step_short" if steps_per_launch <= 64 else "write_kib_per_step_long"]
-        return int((2.0 * e["fetch_kib_per_launch"] + w * steps_per_launch) * 1024), e["source"]
+        fetch = e["fetch_kib_per_launch"]
+        # (write-back record stores: a long launch also fetches — partial lines the L2 completes before it writes them back)
+        if steps_per_launch > 64 and "fetch_kib_per_step_long" in e:
+            fetch = e["fetch_kib_per_step_long"] * steps_per_launch
+        return int((2.0 * fetch + w * steps_per_launch) * 1024), e["source"]
     except Exception:
         return None, None
 

@@ -385,7 +385,7 @@ int tds_hip_step_many_is_loop(const tds_hip_sim_t *sim, int n_steps);
      y_ring    [y_slots][N][y_stride]        step k of the call -> slot (y_first + k) % y_slots        (either may be NULL)
    in the record dtype; obs_f32 != 0: the obs ring holds FLOATS whatever the record dtype (the wire format of the
    multi-GPU exchange).  Where tds_hip_step_many_is_loop holds the n_steps steps are ONE launch of the step-loop kernel
-   that packs and stores the records of every step (non-temporal stores; the state itself never leaves LDS between the
+   that packs and stores the records of every step (write-back stores; the state itself never leaves LDS between the
    steps); elsewhere they are the chained graphs of single-step launches with each launch pointed at its slots.  With
    auto-reset on, a step that ends with done leaves reward / done of the terminal step and the observation of the fresh
    environment in its slot, as the reference does.  Afterwards the handle's y record holds the last step's (a device
@@ -397,7 +397,7 @@ int tds_hip_step_many_is_loop(const tds_hip_sim_t *sim, int n_steps);
                tds_hip_step_many_rings_blocks exactly when EVERY workgroup has stored that step — what
                tds_hip_shard_step_many polls to exchange slot k while the launch carries on (a single running total
                would be reached by the average workgroup while the slowest is steps behind).  It covers the obs ring
-               only: the y ring is written with streaming stores that become visible to other agents at the end of the
+               only: the y ring is written with ordinary stores that become visible to other agents at the end of the
                launch (nothing exchanges y records; read them behind the launch in stream order).
                tds_hip_step_many_rings_blocks = increments of a slot's counter per use of the slot.
      y_stride  scalars between consecutive y records of the y ring (0: output_dim, i.e. packed).  A stride that is a

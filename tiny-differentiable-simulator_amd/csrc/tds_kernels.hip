@@ -56,6 +56,18 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // small fixed-size algebra on registers (everything fully unrolled; no runtime-indexed arrays)
 // ------------------------------------------------------------------------------------------
+// Record stores (y records, obs records, visual poses) are ORDINARY write-back stores.  Until round 4 they were streaming
+// (non-temporal) stores: a record's lines are not written in one go — the line that holds the end of the state and the first
+// visual pose is written in two halves half a step apart, the obs ring's 240-byte records share lines between workgroups —
+// and a streamed partial line leaves the L2 before its other half arrives: HBM write traffic 7.68 MB per Ant x 4096 step for
+// 6.23 MB of payload.  Write-back stores let the halves meet in the L2: 6.08 MB per step, traffic / algorithmic bytes 1.24 ->
+// 1.02 at 1000 steps and 1.34 -> 1.09 on the 20-step command, for +0.7 % of step time
+// (profiles/r04_ab_slots11_plain_stores.txt; -DTDS_STREAMING_STORES brings the streaming stores back).
+#ifdef TDS_STREAMING_STORES
+#define TDS_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define TDS_NT_STORE(v, p) (*(p) = (v))
+#endif
 template <typename T>
 __device__ __forceinline__ void cross3(const T *a, const T *b, T *o) {
   const T x = a[1] * b[2] - a[2] * b[1];
@@ -1587,11 +1599,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     if (rf & TDS_RING_OBS_F32) {
       float *const p = (float *)ctl.obs_ring + idx;
       if (rf & TDS_RING_NOFENCE) __hip_atomic_store(p, (float)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else __builtin_nontemporal_store((float)v, p);
+      else TDS_NT_STORE((float)v, p);
     } else {
       TR *const p = (TR *)ctl.obs_ring + idx;
       if (rf & TDS_RING_NOFENCE) __hip_atomic_store(p, (TR)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else __builtin_nontemporal_store((TR)v, p);
+      else TDS_NT_STORE((TR)v, p);
     }
   };
   // Plain kernels (KIND 0) store the END-of-step records of a ring launch — the state part + tail of the y record, the
@@ -1607,14 +1619,14 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   //  (the host sets ctl.y_stride on EVERY launch — output_dim where nothing else was asked for: no select here)
   const int ystr = ctl.y_stride;
   auto put_y_state = [&](TR *yo, int yend) {  // q | qd | (visual poses: phase M1) | up.z | zero padding, from the LDS record
-    for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)xr[i], &yo[i]);
+    for (int i = lane; i < nq + nd; i += G) TDS_NT_STORE((TR)xr[i], &yo[i]);
     int tail = nq + nd;
     if (mdl->pack_visuals) {
       tail += 7 * mdl->num_visuals;
-      if (lane == 0) __builtin_nontemporal_store((TR)(mdl->base_R[8]), &yo[tail]);  // up_dot_world_z (fixed base)
+      if (lane == 0) TDS_NT_STORE((TR)(mdl->base_R[8]), &yo[tail]);  // up_dot_world_z (fixed base)
       tail += 1;
     }
-    for (int i = tail + lane; i < yend; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
+    for (int i = tail + lane; i < yend; i += G) TDS_NT_STORE((TR)(0), &yo[i]);
   };
   // [q | qd with obs[0] = obs[1] = 0 | reward | done] of ring slot `slot` (ars_vectorized_environment.h:250-289): the
   // observation from the LDS record as it is NOW, reward / done from their LDS slots (written by the reward block)
@@ -1797,13 +1809,13 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           mat3_mulv(Rl, pv, po);
           matrix_to_quat(Ro, qo);
           TR *o = yo + vbase + 7 * k;
-          __builtin_nontemporal_store((TR)(pl[0] + po[0]), &o[0]);
-          __builtin_nontemporal_store((TR)(pl[1] + po[1]), &o[1]);
-          __builtin_nontemporal_store((TR)(pl[2] + po[2]), &o[2]);
-          __builtin_nontemporal_store((TR)qo[0], &o[3]);
-          __builtin_nontemporal_store((TR)qo[1], &o[4]);
-          __builtin_nontemporal_store((TR)qo[2], &o[5]);
-          __builtin_nontemporal_store((TR)qo[3], &o[6]);
+          TDS_NT_STORE((TR)(pl[0] + po[0]), &o[0]);
+          TDS_NT_STORE((TR)(pl[1] + po[1]), &o[1]);
+          TDS_NT_STORE((TR)(pl[2] + po[2]), &o[2]);
+          TDS_NT_STORE((TR)qo[0], &o[3]);
+          TDS_NT_STORE((TR)qo[1], &o[4]);
+          TDS_NT_STORE((TR)qo[2], &o[5]);
+          TDS_NT_STORE((TR)qo[3], &o[6]);
           if constexpr (LOOP) {
             // (the LAST step of a launch with a y ring also leaves its record in the handle's y record: what a device
             //  copy of the ring slot behind the launch used to do, at the price of a dispatch per call)
@@ -2085,10 +2097,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         int tail = nq + nd;
         if (mdl->pack_visuals) {
           tail += 7 * mdl->num_visuals;
-          if (lane == 0) __builtin_nontemporal_store((TR)(mdl->base_R[8]), &yo[tail]);
+          if (lane == 0) TDS_NT_STORE((TR)(mdl->base_R[8]), &yo[tail]);
           tail += 1;
         }
-        for (int i = tail + lane; i < ystr; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
+        for (int i = tail + lane; i < ystr; i += G) TDS_NT_STORE((TR)(0), &yo[i]);
       }
       TDS_STAMP(4);
       if (contacts_h && split_ok) phase_J(na_h, NA_h);
@@ -3677,10 +3689,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   if (pack_y && !(DEFER && ring_y)) {
     TR *const yo = yt_i == 0 ? y_step : y_out + (size_t)env * out_dim;
     if (gen) {  // the q record is not one coordinate per lane: copy it out as it is
-      for (int i = lane; i < nq + nd; i += G) __builtin_nontemporal_store((TR)(xr[i]), &yo[i]);
+      for (int i = lane; i < nq + nd; i += G) TDS_NT_STORE((TR)(xr[i]), &yo[i]);
     } else if (di >= 0) {
-      __builtin_nontemporal_store((TR)(q_new), &yo[di]);
-      __builtin_nontemporal_store((TR)(qd_new), &yo[nq + di]);
+      TDS_NT_STORE((TR)(q_new), &yo[di]);
+      TDS_NT_STORE((TR)(qd_new), &yo[nq + di]);
     }
     if constexpr (!W2) {  // (two-wavefront workgroup: the helper wavefront wrote the tail of the record)
       const int nv = mdl->num_visuals;
@@ -3688,11 +3700,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       if (mdl->pack_visuals) {
         tail += 7 * nv;
         // up_dot_world_z (of body 0; lane 0 is its first pseudo link when its base floats)
-        if (lane == 0) __builtin_nontemporal_store((TR)((fl || (flm && fbk == 0)) ? up_z : (two ? mdl->base_Rb[0][8] : mdl->base_R[8])), &yo[tail]);
+        if (lane == 0) TDS_NT_STORE((TR)((fl || (flm && fbk == 0)) ? up_z : (two ? mdl->base_Rb[0][8] : mdl->base_R[8])), &yo[tail]);
         tail += 1;
       }
       const int yend = yt_i == 0 ? ystr : out_dim;
-      for (int i = tail + lane; i < yend; i += G) __builtin_nontemporal_store((TR)(0), &yo[i]);
+      for (int i = tail + lane; i < yend; i += G) TDS_NT_STORE((TR)(0), &yo[i]);
     }
   }
 
