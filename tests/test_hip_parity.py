@@ -48,6 +48,22 @@ def test_golden_single_steps(name, built):
         sim.close()
 
 
+def test_gram_form_of_the_contact_solve_matches_the_golden_steps(built):
+    """Option gram = 1 (opt-in): the two-wavefront straight-line Ant kernel solves the contacts in Gram form on the f64 matrix
+    cores; its buffer takes X_world's place behind barrier (2), so the helper wavefront packs the visual poses BEFORE the
+    rows there (everywhere else: behind barrier (3)).  Golden single steps incl. the visual poses of the y record."""
+    torch = _torch()
+    m = tds_amd.load_model("ant")
+    g = np.load(os.path.join(GOLDEN, "ant.npz"))
+    for opts in ({"gram": 1}, {"gram": 1, "w2": 2}):
+        sim = hip_backend.HipSim(m, g["x"].shape[0], dtype="f64", options=opts)
+        for _ in range(3):  # (repeated: a race with the helper's pose packing would show as run-to-run differences)
+            y = sim.forward_zero(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+            err = rel_err(y, g["y"])
+            assert err < TOL, (opts, err)
+        sim.close()
+
+
 @pytest.mark.parametrize("name", MODELS + MULTI_BODY_MODELS + FLOATING_MULTI_BODY_MODELS)
 @pytest.mark.parametrize("form", ["default", "w1", "w2", "loop"])
 def test_no_step_reads_stale_lds(name, form, built, monkeypatch):

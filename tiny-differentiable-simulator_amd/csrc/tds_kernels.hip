@@ -2090,7 +2090,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
         }
       }
       TDS_STAMP(3);
-      // (the visual poses go out behind barrier (3), in this wavefront's idle tail — see there)
+      // (the visual poses go out behind barrier (3), in this wavefront's idle tail — see there; not with the Gram form of
+      //  the contact solve, whose buffer takes X_world's place behind barrier (2))
+      if constexpr (!LOOP) {
+        if (L.gram_ok) phase_M1();
+      }
       flush_prev_records();
       if (pack_y && !(DEFER && ring_y)) {  // tail of the y record: up_dot_world_z, zero padding
         TR *const yo = y_step;
@@ -2141,7 +2145,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
       // of that with the flag below at the top of its next iteration (normally long set).  Measured with the priority above
       // (profiles/r04_ab_slots8_m1_late.txt): 13.40 -> 12.86 us per step.  (Round 3 had tried this move without the
       // priorities: no gain — the helper was not the critical path then.)
-      phase_M1(true);
+      if (LOOP || !L.gram_ok) phase_M1(true);
       if constexpr (LOOP) {
         TDS_WAVE_SYNC();
         if (lane == 0) xr[in_dim + 4] = T(2);  // "poses are out" (the slot of the y~ flag, free until the next barrier (1))
