@@ -77,3 +77,23 @@ def test_profile_zones_callback_reports_the_reference_zones(built):
                  "forward_dynamics", "step"):
         assert name in z and z[name] > 0, (name, z)
     assert z["step"] >= z["solve constraints"] + z["forward_dynamics"] and z["step"] < 1000.0
+
+
+@pytest.mark.gpu
+def test_an_experiment_slot_that_is_not_linked_in_is_refused(built):
+    """option alt_build = k selects experiment slot k of the library (csrc/tds_kernels.h, tools/build_alt.sh); the production
+    library carries none: a launch must fail loudly, never fall back to the library's own kernels"""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    m = tds_amd.load_model("ant")
+    sim = hip_backend.HipSim(m, 64)
+    sim.step(None)  # (the library's own kernels)
+    sim.set_option("alt_build", 1)
+    if hip_backend.lib_has_symbol("tds_alt_launch_1"):
+        pytest.skip("this library was linked with experiment slots (tools/build_alt.sh)")
+    with pytest.raises(hip_backend.TdsHipError):
+        sim.step(None)
+    sim.set_option("alt_build", None)
+    sim.step(None)

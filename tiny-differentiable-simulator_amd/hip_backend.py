@@ -148,6 +148,11 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+def lib_has_symbol(name: str) -> bool:
+    """whether libtds_hip.so exports `name` (e.g. the entry point of an experiment slot, tools/build_alt.sh)"""
+    return hasattr(lib(), name)
+
+
 def shard_ring_plan(chunks_done: int, n_steps: int, act_first: int = 0, act_blocks: int = 1, n_blocks: int = 1):
     """the step-loop launches a tds_hip_shard_step_many call is cut into (tds_hip_shard_ring_plan; no device needed):
     list of dicts half / steps / step0 / act_first / slot0 / first_wait"""
