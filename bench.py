@@ -525,7 +525,7 @@ def main():
         # build N = 1 takes (the default: 0.93 of the N = 1 rate on one rank) fills every SIMD's register file, so RCCL's
         # all-gather kernels reach a compute unit only between launches; the one-wave build leaves them 216 registers per
         # SIMD and pays 13 % of the step rate for it.  Which one is faster with REAL peers depends on what the all-gathers
-        # cost on the node: both are timed here (untimed warm-up, 2 x 512 steps, the slowest rank counts) and the faster
+        # cost on the node: both are timed here (untimed warm-up, 2 x ~512 steps in regions of the timed shape, the slowest rank counts) and the faster
         # one is kept on every rank.  --option exchange_w2=... pins it; on one rank only TDS_BENCH_TUNE_EXCHANGE=1 runs it.
         if (shard_form == "ring" and (world > 1 or os.environ.get("TDS_BENCH_TUNE_EXCHANGE") == "1")
                 and not any(kv.startswith("exchange_w2=") for kv in args.option)):
@@ -537,16 +537,21 @@ def main():
                 torch.cuda.synchronize()
                 if world > 1:
                     dist.barrier()
+                # (in regions of the shape that will be timed: K steps + the wait for their exchanges — a 20-step region sees
+                #  the exchanges of ONE launch behind it, a 1000-step region sees them overlap the next launches)
+                kt = min(max(args.steps, 1), 512)
+                reps_t = max(1, 512 // kt)
                 tt = time.perf_counter()
-                run_steps(512)
-                flush()
+                for _ in range(reps_t):
+                    run_steps(kt)
+                    flush()
                 torch.cuda.synchronize()
                 dt_ = time.perf_counter() - tt
                 if world > 1:
                     tdt_ = torch.tensor([dt_], dtype=torch.float64, device="cuda")
                     dist.all_reduce(tdt_, op=dist.ReduceOp.MAX)
                     dt_ = float(tdt_.item())
-                tuned[w2] = dt_ / 512 * 1e6
+                tuned[w2] = dt_ / (kt * reps_t) * 1e6
             keep = 1 if tuned[1] <= tuned[0] else 0
             shard.sim.set_option("exchange_w2", keep)
             exchange_tune = {"two_wavefront_build_us_per_step": tuned[1], "one_wave_build_us_per_step": tuned[0],
