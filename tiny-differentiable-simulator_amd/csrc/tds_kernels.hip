@@ -607,6 +607,82 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
   }
 }
 
+// The row solve of 32-lane groups with TWO lanes per constraint row: lane r (DPP row 0 of the group) keeps the even
+// components z[0], z[2], ... of row r, lane 16 + r (DPP row 1) the odd ones.  The column-oriented substitution needs the
+// pivot z[j] on both — one v_permlane16_swap pair per step — and every lane then updates only ITS components: half the
+// multiply-adds per lane and, what matters, half the LDS reads of L per wavefront (the 18-dof kernels' row solves are bound
+// by the LDS bandwidth of eight wavefronts per CU reading all 153 entries of L each).  Rows of ONE pass
+// (3 NA <= 16), every row in LDS, one-wave form; same arithmetic per component as tds_row_solve, the sums over the
+// components (J.qd, G_rr) in two halves.
+template <typename T, int NDP>
+__device__ __forceinline__ void tds_row_solve_half(int lane, int NA, int na, int nd, int ZR, int NCPp, T *Zs, T *rws,
+                                                   const T *qdv, const T *cpx, const T *Lp, const T *dvec, T cfm, T erp_dt,
+                                                   T rest) {
+  constexpr int NDs = NDP + 1;
+  constexpr int NH = (NDP + 1) / 2;  // components per lane
+  const bool upper = (threadIdx.x & 16) != 0;
+  const int p = upper ? 1 : 0;       // parity of this lane's components: k = 2 i + p
+  const int r = lane & 15;
+  const int nrw = 3 * NA;
+  const bool rowl = r < nrw;
+  const int rc = rowl ? r : 0;
+  const int t = (rc >= NA ? 1 : 0) + (rc >= 2 * NA ? 1 : 0);
+  const int a = rc - t * NA;
+  const bool real = rowl && a < na;
+  T z[NH];
+  T vpart = T(0);
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int k = 2 * i + p;
+    const int kc = k < NDP ? k : NDP - 1;  // (odd NDP: the last odd slot does not exist — NDP is even here, kept general)
+    const T v = Zs[rc * NDs + kc];
+    z[i] = (real && k < NDP) ? v : T(0);
+    vpart += z[i] * qdv[kc < nd ? kc : 0];
+  }
+  const T vrow = vpart + other_row(vpart, upper);
+  const T brow = t == 0 ? (T(1) + rest) * vrow - erp_dt * cpx[3 * NCPp + a] : vrow;
+  // column j: the pivot z[j] to both lanes of the row, then every component k > j of this lane
+  static_for<0, NDP - 1>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const T mine = z[j / 2];
+    const T theirs = other_row(mine, upper);
+    const T zj = (p == (j & 1)) ? mine : theirs;
+    static_for<0, NH>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      // k = 2 i + p > j:  2 i > j for both parities; 2 i == j only for the odd lane (k = j + 1); else neither
+      if constexpr (2 * i + 1 > j) {
+        const int k = 2 * i + p;
+        const int kc = k < NDP ? k : NDP - 1;
+        const T l = Lp[(kc * (kc - 1)) / 2 + j];
+        const bool on = (2 * i > j || p == 1) && k < NDP;
+        z[i] -= (on ? l : T(0)) * zj;
+      }
+    });
+  });
+  T gpart = T(0);
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int k = 2 * i + p;
+    const int kc = k < NDP ? k : NDP - 1;
+    z[i] *= dvec[NDP + kc];
+    gpart += z[i] * z[i];
+  }
+  const T g = gpart + other_row(gpart, upper);
+  const T ai = real ? rcp_full<T>(g + cfm) : T(0);
+  if (rowl) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int k = 2 * i + p;
+      if (k < NDP) Zs[rc * NDs + k] = z[i];
+    }
+    if (!upper) {
+      rws[rc] = real ? brow : T(0);
+      rws[ZR + rc] = ai;
+      rws[2 * ZR + rc] = real ? g : T(0);
+    }
+  }
+}
+
 // Right-hand sides of the constraint rows after a SPLIT row solve (lane == row).  The velocity the reference uses is
 // the one after integrate_euler_qdd, qd+ = qd + dt qdd with qdd = L^-T D^-1 y (y = L^-1 (tau - C)), hence
 //   J_r . qd+ = J_r . qd + dt z~_r . y~,   y~ = D^-1/2 y   (z~_r = D^-1/2 L^-1 J_r^T is what the row store holds)
@@ -3484,6 +3560,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     if (any_slab)
       tds_row_solve<true, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, rhsx, cpx, Lp, dvec, zov, rov,
                                      cfm, erp_dt, rest);
+    // (18-dof kernels, rows of one pass: two lanes per row — measured, profiles/r04_ab_slots14_laikago_row_half.txt:
+    //  laikago_soft x 8192 48.2 -> 47.1 us per step)
+    else if (G == 32 && NDP > 16 && NDP < 24 && 3 * NA <= 16 && 3 * NA <= ZR)  // wave-uniform
+      tds_row_solve_half<T, NDP>(lane, NA, na, nd, ZR, NCPp, Zs, rws, rhsx, cpx, Lp, dvec, cfm, erp_dt, rest);
     else
       tds_row_solve<false, T, G, NDP>(lane, NA, na, nd, ZR, OVR, NCPp, Zs, rws, xs, rhsx, cpx, Lp, dvec, zov, rov,
                                       cfm, erp_dt, rest);

@@ -64,10 +64,12 @@ for k in slots:
         sims[k] = (s, obs, yr)
     except Exception as e:  # noqa: BLE001
         print(f"slot {k}: not usable ({e})")
-# parity of the slots among themselves: 40 steps from the same state
+# parity of the slots among themselves: 40 steps from the same SETTLED state (the first slot's, after its 10 settle + 64
+# steps: robots on the ground, contacts in play)
 ref = None
+xs_common = sims[slots[0]][0].x.clone()
 for k, (s, obs, yr) in sims.items():
-    s.x.copy_(torch.from_numpy(x0).cuda())
+    s.x.copy_(xs_common)
     s.step_many_rings(acts, 40, obs, yr)
     torch.cuda.synchronize()
     y = yr[39][:, :m.output_dim].cpu().numpy()
