@@ -3796,6 +3796,15 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   //         (ars_vectorized_environment.h:250-289; ant_environment2.h:75-106;
   //          laikago_environment2.h:130-171)
   T reward = T(0);  // (lane 0)
+  // (Laikago's reward takes the sine and cosine of three half angles: lanes 0..2 evaluate one each, side by side, instead
+  //  of lane 0 running the three evaluations in a row with the other lanes of the wavefront waiting — same function, same
+  //  arguments, same bits)
+  T rw_s0 = T(0), rw_c0 = T(1), rw_s1 = T(0), rw_c1 = T(1), rw_s2 = T(0), rw_c2 = T(1);
+  if (mdl->reward_mode == TDS_REWARD_LAIKAGO && nq > 5 && (last_run || pol || pool_r || ring_o)) {
+    sincos_t<T>(lane < 3 ? xr[3 + lane] * T(0.5) : T(0), &rw_s0, &rw_c0);
+    rw_s1 = dpp_bcast<1>(rw_s0), rw_c1 = dpp_bcast<1>(rw_c0);
+    rw_s2 = dpp_bcast<2>(rw_s0), rw_c2 = dpp_bcast<2>(rw_c0);
+  }
   if (do_reward && lane == 0) {
     bool done = false;
     const int rm = mdl->reward_mode;
@@ -3806,10 +3815,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     } else if (rm == TDS_REWARD_LAIKAGO && nq > 5) {
       // up_dot_world_z = quat_to_matrix(quat_from_euler_rpy(q[3..5]))(2,2)
       // (tiny_quaternion.h set_euler_rpy, tiny_matrix3x3.h:315-340)
-      T sp, cp, st, ct, ss, cs2;
-      sincos_t<T>(xr[3] * T(0.5), &sp, &cp);
-      sincos_t<T>(xr[4] * T(0.5), &st, &ct);
-      sincos_t<T>(xr[5] * T(0.5), &ss, &cs2);
+      const T sp = rw_s0, cp = rw_c0, st = rw_s1, ct = rw_c1, ss = rw_s2, cs2 = rw_c2;
       const T qx = sp * ct * cs2 - cp * st * ss;
       const T qy = cp * st * cs2 + sp * ct * ss;
       const T qz = cp * ct * ss - sp * st * cs2;
