@@ -361,21 +361,33 @@ __device__ __forceinline__ double other_row(double v, bool upper_row) {
 __device__ __forceinline__ float other_row(float v, bool upper_row) {
   return __int_as_float(swap_rows_b32(__float_as_int(v), upper_row));
 }
-// lane SRC (0..31) of each 32-lane group to all its 32 lanes: row broadcast, then copy that row over its partner
+// lane SRC (0..31) of each 32-lane group to all its 32 lanes.  A source in the group's FIRST row: row broadcast, then
+// lane 15 of rows 0 / 2 into every lane of rows 1 / 3 (row_bcast:15 under row mask 0b1010) — two moves per 32 bits.  A
+// source in the SECOND row has no DPP control that reaches back: row broadcast, then that row copied over its partner
+// with a row swap (v_permlane16_swap and the copies its two-operand form needs).
 template <int SRC>
 __device__ __forceinline__ int bcast32_b32(int x) {
-  const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x150 + (SRC & 15), 0xF, 0xF, true);
-  const auto r = __builtin_amdgcn_permlane16_swap(t, t, false, false);
-  return (int)(SRC < 16 ? r[0] : r[1]);
+  const int t = __builtin_amdgcn_update_dpp(0, x, 0x150 + (SRC & 15), 0xF, 0xF, true);
+  if constexpr (SRC < 16) {
+    return __builtin_amdgcn_update_dpp(t, t, 0x142, 0xA, 0xF, false);
+  } else {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)t, (unsigned)t, false, false);
+    return (int)r[1];
+  }
 }
 template <int SRC>
 __device__ __forceinline__ double bcast32(double v) {
-  // (one 64-bit row broadcast — row_newbcast is the DPP control the 64-bit ALU takes — then the row swap per half)
+  // (one 64-bit row broadcast — row_newbcast is the DPP control the 64-bit ALU takes — then the second step per half)
   const double t = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + (SRC & 15), 0xF, 0xF, true);
-  const unsigned tl = (unsigned)__double2loint(t), th = (unsigned)__double2hiint(t);
-  const auto rl = __builtin_amdgcn_permlane16_swap(tl, tl, false, false);
-  const auto rh = __builtin_amdgcn_permlane16_swap(th, th, false, false);
-  return __hiloint2double((int)(SRC < 16 ? rh[0] : rh[1]), (int)(SRC < 16 ? rl[0] : rl[1]));
+  const int l = __double2loint(t), h = __double2hiint(t);
+  if constexpr (SRC < 16) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(h, h, 0x142, 0xA, 0xF, false),
+                            __builtin_amdgcn_update_dpp(l, l, 0x142, 0xA, 0xF, false));
+  } else {
+    const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)l, (unsigned)l, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap((unsigned)h, (unsigned)h, false, false);
+    return __hiloint2double((int)rh[1], (int)rl[1]);
+  }
 }
 template <int SRC>
 __device__ __forceinline__ float bcast32(float v) {
