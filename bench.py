@@ -15,9 +15,11 @@ the work per step is the same in both.  The form that skips the records of all b
 (tds_hip_step_many: a substep-fused figure) is timed afterwards and reported under the secondary key
 "substep_fused", never as `value`.
 With N > 1 ranks each GPU owns its own shard of environments and runs the SAME launches (same rings); the
-[obs | reward | done] ring slots are all-gathered over RCCL ONCE PER POLICY STEP by the library's own
-shard layer (tds_hip_shard_step_many: librccl called from C on a communication stream that follows the running launch's
-per-step progress counter — no host call and no kernel boundary per step).  N = 1 and N > 1 differ by the exchange only.
+[obs | reward | done] records of every policy step reach every rank through the library's own shard layer
+(tds_hip_shard_step_many): by default the step-loop launch itself stores each record into the gathered ring of EVERY rank
+(IPC-mapped peer memory over xGMI: no collective, no host call and no kernel boundary per step), else librccl's all-gather
+called from C.  N = 1 and N > 1 run the same kernel and differ by the exchange only.  --gpus 8 runs BASELINE config 5
+(8192 environments per GPU = 65 536) as `value` and the 4096-per-GPU line beside it (`envs_4096_per_gpu`).
 
 Prints ONE JSON line on rank 0 (contract in the project brief): value = total env-steps / s
 over all GPUs, plus `roofline` (algorithmic bytes / measured kernel time vs 8 TB/s HBM) and
@@ -167,7 +169,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--envs-per-gpu", type=int, default=0,
+                    help="environments per GPU; 0 (default): BASELINE.json's configurations — 4096 (config 3, the one the "
+                         "metric is quoted on) at 1 / 2 / 4 GPUs, 8192 at 8 GPUs (config 5: 65 536 environments sharded "
+                         "8 x), where the 4096-per-GPU line is reported beside it under `envs_4096_per_gpu`")
     ap.add_argument("--model", default="ant")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32", "f32-pure"],
                     help="f64: double arithmetic, double records (the reference's arithmetic; headline).  f32: FLOAT "
@@ -276,90 +281,83 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # BASELINE.json: config 3 (Ant x 4096 on one GPU) is the configuration the metric is quoted on; config 5 is "65 536
+    # environments sharded 8 x" = 8192 per GPU.  --gpus 8 therefore runs config 5 as `value` and the 4096-per-GPU line — the
+    # weak-scaling partner of the N = 1 / 2 / 4 runs — beside it under `envs_4096_per_gpu` (same ranks, same flow).
+    config5 = args.envs_per_gpu == 0 and world == 8 and args.model == "ant"
+    n = args.envs_per_gpu if args.envs_per_gpu > 0 else (8192 if config5 else 4096)
+    out = run(args, n, rank, local_rank, world, secondary=True, config5=config5)
+    if config5 and not args.no_secondary:
+        second = run(args, 4096, rank, local_rank, world, secondary=False, config5=False)
+        if rank == 0:
+            out["envs_4096_per_gpu"] = {k: second[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")}
+            out["envs_4096_per_gpu"]["workload"] = second["config"]["workload"]
+            out["envs_4096_per_gpu"]["exchange_form"] = second["config"]["exchange_form"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run(args, n, rank, local_rank, world, secondary, config5):
+    """one measurement at n environments per GPU; returns the JSON record on rank 0 (None elsewhere)"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import tds_amd
+    from tds_amd import hip_backend
+
     m = tds_amd.load_model(args.model)
-    n = args.envs_per_gpu
     lib_dtype = {"f64": "f64", "f32": "mixed", "f32-pure": "f32"}[args.dtype]
     multi = world > 1 or args.force_gather
     shard = None
     if multi:
-        # the multi-GPU path of the C ABI: this rank's shard + the RCCL all-gather of its records.  Only the 128-byte
-        # ncclUniqueId travels through torch.distributed (rendezvous); the data path is librccl called from C.
-        uid = None
-        if world > 1 or os.environ.get("TDS_BENCH_RCCL_SINGLE", "1") == "1":
-            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(hip_backend.HipShard.unique_id()), dtype=torch.uint8))
-            if world > 1:
-                dist.broadcast(idt, src=0)
-            uid = bytes(idt.cpu().numpy().tobytes())
+        # the multi-GPU path of the C ABI: this rank's shard + the exchange of its records.  Only the 128-byte ncclUniqueId
+        # travels through torch.distributed (rendezvous); the data path is the library's own (peer stores over IPC-mapped
+        # rings, or librccl called from C).  There is NO other path under `value`: if the shard cannot be created the run
+        # fails on every rank.
         if args.lanes:
             hip_backend.default_option("lanes_per_env", args.lanes)
-        # (RCCL prints a version banner on C stdout when a communicator comes up: keep rank 0's stdout to the one
-        #  JSON line — send C-level stdout to stderr while the communicator is created)
-        import ctypes
-        libc = ctypes.CDLL(None)
-        sys.stdout.flush()
-        libc.fflush(None)
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        shard_error = None
-        try:
-            shard = hip_backend.HipShard(m, world * n, rank=rank, world=world, device=local_rank, dtype=lib_dtype,
-                                         unique_id=uid, wire_dtype=args.gather_dtype, block=max(1, args.gather_every))
+
+        def create_shard(options):
+            uid = None
+            if world > 1 or os.environ.get("TDS_BENCH_RCCL_SINGLE", "1") == "1":
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(hip_backend.HipShard.unique_id()), dtype=torch.uint8))
+                if world > 1:
+                    dist.broadcast(idt, src=0)
+                uid = bytes(idt.cpu().numpy().tobytes())
+            # (RCCL prints a version banner on C stdout when a communicator comes up: keep rank 0's stdout to the one
+            #  JSON line — send C-level stdout to stderr while the communicator is created)
+            import ctypes
+            libc = ctypes.CDLL(None)
+            sys.stdout.flush()
             libc.fflush(None)
-        except Exception as e:  # e.g. librccl refuses the communicator on this node
-            shard_error = repr(e)
-        finally:
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
-        if world > 1:  # every rank takes the same path
-            flag = torch.tensor([1 if shard_error else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()) and shard is not None:
-                shard.close()
-                shard = None
-                shard_error = shard_error or "another rank could not create its shard"
-        if shard is None:
-            # Fallback (never on the 1-GPU box; insurance for the multi-GPU run): the same per-step exchange through
-            # torch.distributed (RCCL under it) — tiny-differentiable-simulator_amd/sharded.py, the round-1 driver.
-            print(f"bench.py: tds_hip_shard_create failed ({shard_error}); falling back to the torch.distributed "
-                  f"exchange", file=sys.stderr)
-            from tds_amd.sharded import PipelinedObsGather
-            sim = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype,
-                                     lanes_per_env=args.lanes if args.lanes else None)
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            err, sh = None, None
+            try:
+                sh = hip_backend.HipShard(m, world * n, rank=rank, world=world, device=local_rank, dtype=lib_dtype,
+                                          unique_id=uid, wire_dtype=args.gather_dtype, block=max(1, args.gather_every),
+                                          options=options)
+                libc.fflush(None)
+            except Exception as e:  # e.g. librccl refuses the communicator on this node
+                err = repr(e)
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
+            if world > 1:  # every rank takes the same path
+                flag = torch.tensor([1 if err else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if int(flag.item()):
+                    err = err or "another rank could not create its shard"
+            if err:
+                raise SystemExit(f"bench.py: tds_hip_shard_create failed on rank {rank}: {err} (no fallback under `value`)")
+            return sh
 
-            class _TorchShard:
-                def __init__(self):
-                    wd = torch.float32 if (args.gather_dtype == "f32" or lib_dtype != "f64") else torch.float64
-                    self.g = PipelinedObsGather(world * n, sim.obs_dim + 2, sim.torch_dtype, f"cuda:{local_rank}",
-                                                slots=4, wire_dtype=wd)
-                    self.rec = [torch.zeros((n, sim.obs_dim + 2), dtype=sim.torch_dtype, device="cuda") for _ in range(4)]
-                    self.i = 0
-                    self.sim = sim
-
-                def step(self, a, substeps=1):
-                    slot = self.i % 4
-                    self.g.before_reuse(slot)
-                    sim.step(a, substeps, self.rec[slot])
-                    self.g.submit(self.rec[slot], slot)
-                    self.i += 1
-
-                def step_many(self, actions, k, first_block=0, prepare_only=False):
-                    if prepare_only:
-                        return
-                    for j in range(k):
-                        self.step(actions[(first_block + j) % actions.shape[0]], 1)
-
-                def flush(self):
-                    self.g.wait_all()
-
-                def set_block(self, b):
-                    pass
-
-            shard = _TorchShard()
-            torch_fallback = True
-        else:
-            torch_fallback = False
+        shard = create_shard(None)
         sim = shard.sim
     else:
         sim = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype,
@@ -388,9 +386,12 @@ def main():
         x0[:, 7:nq] = rng.uniform(-0.3, 0.3, (n, nq - 7))
     else:
         x0[:, :nq] = rng.uniform(-1, 1, (n, nq))
-    sim.x.copy_(torch.from_numpy(x0).to(tdt).cuda())
-    for _ in range(10):  # 10 settle steps with zero action (ant_environment2.h:137-152)
-        sim.step(None)
+    def init_state(target):
+        target.x.copy_(torch.from_numpy(x0).to(tdt).cuda())
+        for _ in range(10):  # 10 settle steps with zero action (ant_environment2.h:137-152)
+            target.step(None)
+
+    init_state(sim)
     auto_reset = args.auto_reset and not multi and m.step_mode == tds_amd.TDS_STEP_LOCOMOTION
     if auto_reset:
         sim.set_auto_reset(True, 5)
@@ -404,7 +405,7 @@ def main():
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
     B = max(1, args.gather_every)
     use_graph = not args.no_graph
-    shard_graph = (use_graph and not torch_fallback) if multi else False
+    shard_graph = use_graph if multi else False
     use_rings = use_graph and not multi and args.records == "rings"
     RS = max(1, args.ring_slots)
     obs_ring = y_ring = None
@@ -468,7 +469,7 @@ def main():
             shard.flush()
 
     chains = None
-    loop_form = use_graph and sim.step_many_is_loop(min(args.steps, GCH)) and (not multi or (B == 1 and not torch_fallback))
+    loop_form = use_graph and sim.step_many_is_loop(min(args.steps, GCH)) and (not multi or B == 1)
     if use_graph and not multi and not loop_form and not auto_reset:
         if args.chains == "auto":  # 6 x 128 extra untimed steps
             chains = sim.tune_step_many(actions, 128, obs)
@@ -487,29 +488,37 @@ def main():
             left -= c
         # (no synchronisation: the warm-up steps below queue up behind it on the same stream)
     shard_form = None
-    exchange_tune = None
-    if multi and not torch_fallback:
-        # The exchange forms, most to least ambitious: ring exchange behind the step-loop launch (one hipGraph per launch) ->
-        # per-step launches + exchanges from one hipGraph -> one tds_hip_shard_step call per step.  A form that fails
-        # during the warm-up steps (a refused capture falls back inside the library; this catches what it cannot: a
-        # ring wait that timed out, an RCCL error) is dropped on EVERY rank before anything is timed.
-        # (at N > 1 the hipGraph form of the per-step launches is left out: collectives captured into a graph have never
-        #  run on more than one rank, and a capture that hangs has no timeout — the plain stream-ordered form is the
-        #  conservative fallback there)
-        forms = (["ring", "per-step graph", "per-step eager"] if world == 1 else ["ring", "per-step eager"]) if shard_graph else ["per-step eager"]
-        for f in forms:
-            if f == "per-step graph":
-                shard.sim.set_option("shard_ring", 0)
-            if f == "per-step eager":
-                shard_graph = False
+    exchange_form = None
+    if multi:
+        # The exchange forms, most to least ambitious:
+        #   ring / peer stores   the step-loop launch (the N = 1 kernel) stores every record on every rank itself (IPC-mapped
+        #                        rings): no collective, no host call per step — the library's default
+        #   ring / RCCL          the same launches, the slots sent with ncclAllGather (shard re-created with shard_peer = 0)
+        #   per-step eager       one tds_hip_shard_step call per step (kernel launch + ncclAllGather)
+        # A form that fails during the warm-up steps on ANY rank (a wait that timed out, an RCCL error; a set-up that cannot
+        # be made falls back inside the library) is dropped on EVERY rank before anything is timed.  No timing decides
+        # anything here: every rank runs the library's default build of the kernel.
+        forms = [("ring", None), ("ring", {"shard_peer": 0}), ("per-step eager", None)] if shard_graph else [("per-step eager", None)]
+        current_opts = None
+        for f, fopts in forms:
             err = 0
             try:
+                if fopts != current_opts and fopts is not None:  # (options that shape the ring: a new shard)
+                    shard.close()
+                    shard = create_shard(fopts)
+                    sim = shard.sim
+                    init_state(sim)
+                    current_opts = fopts
+                if f == "per-step eager":
+                    shard_graph = False
                 prepare(args.warmup)
                 run_steps(max(args.warmup, 1))
                 flush()
                 torch.cuda.synchronize()
+            except SystemExit:
+                raise
             except Exception as e:  # noqa: BLE001
-                print(f"bench.py: exchange form '{f}' failed on rank {rank}: {e!r}", file=sys.stderr)
+                print(f"bench.py: exchange form '{f}' {fopts or ''} failed on rank {rank}: {e!r}", file=sys.stderr)
                 err = 1
             if world > 1:
                 flag = torch.tensor([err], dtype=torch.int32, device="cuda")
@@ -520,42 +529,8 @@ def main():
                 break
         if shard_form is None:
             raise SystemExit("bench.py: no exchange form works on this node")
+        exchange_form = shard.exchange_form()
         loop_form = loop_form and shard_form == "ring"
-        # Which build of the step-loop kernel runs under the ring exchange (library option exchange_w2): the two-wavefront
-        # build N = 1 takes (the default: 0.93 of the N = 1 rate on one rank) fills every SIMD's register file, so RCCL's
-        # all-gather kernels reach a compute unit only between launches; the one-wave build leaves them 216 registers per
-        # SIMD and pays 13 % of the step rate for it.  Which one is faster with REAL peers depends on what the all-gathers
-        # cost on the node: both are timed here (untimed warm-up, 2 x ~512 steps in regions of the timed shape, the slowest rank counts) and the faster
-        # one is kept on every rank.  --option exchange_w2=... pins it; on one rank only TDS_BENCH_TUNE_EXCHANGE=1 runs it.
-        if (shard_form == "ring" and (world > 1 or os.environ.get("TDS_BENCH_TUNE_EXCHANGE") == "1")
-                and not any(kv.startswith("exchange_w2=") for kv in args.option)):
-            tuned = {}
-            for w2 in (1, 0):
-                shard.sim.set_option("exchange_w2", w2)
-                run_steps(64)
-                flush()
-                torch.cuda.synchronize()
-                if world > 1:
-                    dist.barrier()
-                # (in regions of the shape that will be timed: K steps + the wait for their exchanges — a 20-step region sees
-                #  the exchanges of ONE launch behind it, a 1000-step region sees them overlap the next launches)
-                kt = min(max(args.steps, 1), 512)
-                reps_t = max(1, 512 // kt)
-                tt = time.perf_counter()
-                for _ in range(reps_t):
-                    run_steps(kt)
-                    flush()
-                torch.cuda.synchronize()
-                dt_ = time.perf_counter() - tt
-                if world > 1:
-                    tdt_ = torch.tensor([dt_], dtype=torch.float64, device="cuda")
-                    dist.all_reduce(tdt_, op=dist.ReduceOp.MAX)
-                    dt_ = float(tdt_.item())
-                tuned[w2] = dt_ / (kt * reps_t) * 1e6
-            keep = 1 if tuned[1] <= tuned[0] else 0
-            shard.sim.set_option("exchange_w2", keep)
-            exchange_tune = {"two_wavefront_build_us_per_step": tuned[1], "one_wave_build_us_per_step": tuned[0],
-                             "kept": "two-wavefront build (the N = 1 kernel)" if keep else "one-wave build"}
     else:
         prepare(args.warmup)
         run_steps(args.warmup)
@@ -678,8 +653,36 @@ def main():
         return n * k_steps / (time.perf_counter() - t1)
 
     # ---- secondary keys of the default N = 1 line (same model, same batch, same K; each on the state the timed region left)
-    substep_fused = one_rank = auto_rate = None
-    if use_rings and world == 1 and not args.no_secondary and not auto_reset:
+    substep_fused = one_rank = one_rank_7 = auto_rate = None
+    steady = None
+    if use_rings and world == 1 and not args.no_secondary and not auto_reset and secondary and loop_form:
+        # (0) the steady state ("steady-state over >= 1000 steps after 100 warm-up steps"): the same form, the same
+        #     rings, 100 untimed + 1000 timed steps as ONE launch, bracketed by a HIP event pair on the launch stream
+        sim.step_many_rings(actions, 100, obs_ring, y_ring, first_block=state["i"] % pool, obs_first=state["i"] % RS, y_first=state["i"] % RS)
+        state["i"] += 100
+        call = sim.prepared_step_many_rings(actions, 1000, obs_ring, y_ring, first_block=state["i"] % pool,
+                                            obs_first=state["i"] % RS, y_first=state["i"] % RS)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        e0.record()
+        call()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t1
+        state["i"] += 1000
+        ms = e0.elapsed_time(e1)
+        bpes = (m.input_dim + m.output_dim) * (8 if args.dtype == "f64" else 4)
+        ach = n * bpes / (ms / 1000 * 1e-3) / 1e9
+        tr, tr_src = pmc_traffic_rings(args.model, n, args.dtype, 1000)
+        steady = {"value": n * 1000 / wall, "unit": "env-steps/s", "steps": 1000, "warmup": 100, "ms_per_step": wall,
+                  "kernel_ms_avg": ms, "steps_per_launch": 1000, "us_per_step_kernel": ms,
+                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                               "traffic": tr, "traffic_source": tr_src,
+                               "traffic_over_algorithmic": (tr / (n * bpes * 1000)) if tr else None},
+                  "what": "the same launches and rings as `value`, 1000 steps in ONE launch after 100 warm-up steps; value from "
+                          "the wall clock around the call, kernel_ms_avg from a HIP event pair on the launch stream"}
+    if use_rings and world == 1 and not args.no_secondary and not auto_reset and secondary:
         # (a) the substep-fused form: the same launches WITHOUT per-step records (y / obs of the last step of a launch only)
         kk = min(K, GCH)
         sim.step_many(actions, kk, obs)
@@ -687,9 +690,11 @@ def main():
         substep_fused = {"value": v, "unit": "env-steps/s", "steps": kk,
                          "what": "tds_hip_step_many: the same K steps, output packing and records for the LAST step of a launch "
                                  "only (batch x substeps per launch; not the per-step protocol, never `value`)"}
-        # (b) one rank through the shard layer: the same launches + the per-step exchange of the obs ring (single-rank
-        #     RCCL communicator): what N > 1 runs, minus the other ranks — the protocol's own cost
-        try:
+        # (b) one rank through the shard layer (tds_hip_shard_step_many): what every rank of an N > 1 run executes, minus
+        #     the other ranks — the protocol's own cost.  Default form: the peer-store exchange (on one rank: the arrival
+        #     counters and this rank's own flags); and once more with SEVEN scratch rings of this GPU's own standing in for
+        #     the peers of an 8-GPU run (option shard_peer_loopback): every store an 8-rank run issues, HBM instead of xGMI.
+        def one_rank_line(options, label):
             import ctypes
             libc = ctypes.CDLL(None)
             sys.stdout.flush()
@@ -698,7 +703,7 @@ def main():
             try:
                 uid = hip_backend.HipShard.unique_id() if hip_backend.HipShard.rccl_version() > 0 else None
                 sh1 = hip_backend.HipShard(m, n, rank=0, world=1, device=local_rank, dtype=lib_dtype, unique_id=uid,
-                                           wire_dtype=args.gather_dtype)
+                                           wire_dtype=args.gather_dtype, options=options)
                 libc.fflush(None)
             finally:
                 os.dup2(saved_fd, 1)
@@ -713,21 +718,28 @@ def main():
                 sh1.flush()
 
             v = timed(go, kk)
-            xo = {k: sh1.sim.get_option(k) for k in ("exchange_w2", "shard_wait", "shard_inplace", "shard_register")}
-            one_rank = {"value": v, "unit": "env-steps/s", "steps": kk,
-                        "exchange": "ncclAllGather, single-rank communicator" if uid else "device copy (librccl not loadable)",
-                        "build": "two-wavefront step-loop build (exchange_w2 = 1)" if xo["exchange_w2"] == 1
-                                 else "one-wave step-loop build (leaves 216 of a SIMD's 512 registers to the exchange's kernels)",
-                        "wait": "hipStreamWaitValue64" if xo["shard_wait"] == 1 else "one-lane wait kernel (bounded)",
-                        "in_place": xo["shard_inplace"] != 0,
-                        "what": "tds_hip_shard_step_many on ONE rank: step-loop launches of <= 256 steps storing every step's "
-                                "[obs | reward | done] record straight into this rank's block of the gathered buffer + one "
-                                "(in-place) all-gather of that slot per policy step on the communication stream — behind the "
-                                "launch as one RCCL group under the two-wavefront build (the N = 1 kernel), beside it following "
-                                "the slots' progress counters under the one-wave build (what every rank of an N > 1 run executes)"}
+            form = sh1.exchange_form()
+            rec = {"value": v, "unit": "env-steps/s", "steps": kk, "exchange_form": form, "peers": sh1.peer_count(),
+                   "communicator": "single-rank RCCL communicator" if uid else "none (librccl not loadable)",
+                   "what": label}
             sh1.close()
+            return rec
+
+        try:
+            one_rank = one_rank_line(None, "tds_hip_shard_step_many on ONE rank, library defaults: step-loop launches (the N = 1 "
+                                           "two-wavefront kernel) of <= 256 steps storing every step's [obs | reward | done] record "
+                                           "straight into this rank's block of the gathered slot and raising the slot's flag when "
+                                           "the last workgroup has stored it; a one-wave arrival check per launch on the "
+                                           "communication stream (what every rank of an N > 1 run executes, minus the peers)")
         except Exception as e:  # noqa: BLE001 - a secondary key must never cost the headline line
             one_rank = {"error": repr(e)}
+        try:
+            one_rank_7 = one_rank_line({"shard_peer_loopback": 7},
+                                       "the same with seven scratch rings of this GPU standing in for the peers of an 8-GPU run: "
+                                       "the kernel issues every store it issues on eight ranks (7 x 120 B per environment and "
+                                       "step on the float wire), into HBM instead of over xGMI")
+        except Exception as e:  # noqa: BLE001
+            one_rank_7 = {"error": repr(e)}
         # (c) auto_reset_when_done on — the loop python/examples/vec_ant.py:16-40 times: every step resets the
         #     environments it ends with done (reset distribution + settle steps, through the reset pool), records per step
         if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and m.reward_mode != 0:
@@ -770,7 +782,7 @@ def main():
         total_steps = world * n * K
         value = total_steps / elapsed
         per_step_records = use_rings or multi or not use_graph  # every step packs + stores its records
-        ring_exchange = multi and not torch_fallback and shard_form == "ring"
+        ring_exchange = multi and shard_form == "ring"
         roof = None
         if kernel_ms:
             # environment chains: C launches of n / C environments each are in flight at the same time, every one of
@@ -781,7 +793,7 @@ def main():
             traffic, traffic_src = pmc_traffic(args.model, n, args.dtype)  # (measured on whole-batch launches)
             if traffic is not None:
                 traffic = traffic // conc
-            spl = (min(K, 64) if multi else min(K, GCH)) if loop_form else 1  # steps per launch (loop form: one launch = spl steps)
+            spl = (min(K, 256) if multi else min(K, GCH)) if loop_form else 1  # steps per launch (loop form: one launch = spl steps)
             if auto_reset:  # (step-loop launches of up to 128 steps, or single steps; the refill launches run beside them)
                 spl = min(K, GCH, 128) if loop_form else 1
                 traffic, traffic_src = None, None
@@ -819,11 +831,14 @@ def main():
             launch = ("one straight-line launch per step, a done environment takes its next pre-settled state from its ring in "
                       "HBM; rings refilled on a side stream")
         elif multi and ring_exchange:
+            how = {"peer_stores": "the launch stores each record into its block of the gathered slot on EVERY rank (IPC-mapped "
+                                  "rings, system-scope stores over xGMI) and raises the slot's flags when its last workgroup has "
+                                  "stored it: no collective, the transfer of step k lies inside step k + 1",
+                   "rccl_group_after_launch": "the launch's slots are all-gathered as ONE RCCL group behind it",
+                   "rccl_per_slot": "the communication stream follows the slots' progress counters and all-gathers each slot "
+                                    "beside the launch"}.get(exchange_form, str(exchange_form))
             launch = ("one launch of the step-loop kernel per %d steps, EVERY step packing and storing its y record and its "
-                      "[obs | reward | done] record into ring slots; the communication stream follows the launch's per-step "
-                      "progress counter and all-gathers each obs slot (%s)"
-                      % (min(K, 64), "launch + its exchanges = one hipGraph" if args.shard_graph
-                         else "exchange submitted eagerly while the launch runs"))
+                      "[obs | reward | done] record into ring slots; %s" % (min(K, 256), how))
         elif loop_form and use_rings:
             launch = ("one launch of the step-loop kernel per %d steps (state in LDS across the steps, one action block per "
                       "step), EVERY step running the whole output packing — visual poses, y record, reward / done, "
@@ -845,8 +860,10 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             # the arithmetic type the path computes in; the record type is in config.records
             "dtype": "f32" if args.dtype == "f32-pure" else "f64", "data": "synthetic",
-            "config": {"workload": (f"{args.model} (gym Ant 14-dof + plane, 17 contact points, PGS 1 iter), " if args.model == "ant"
-                                    else f"{args.model}, ") +
+            "config": {"workload": (("BASELINE config 5: " if config5 else "") +
+                                    (f"{args.model} (gym Ant 14-dof + plane, 17 contact points, PGS 1 iter), " if args.model == "ant"
+                                     else f"{args.model}, ")) +
+                                   (f"{world * n} envs sharded {world} x = " if multi and world > 1 else "") +
                                    f"{n} envs/GPU, dt={m.dt}; state fed back on device every step; actions: a pool of {pool} "
                                    f"uniform random (+-{amp}) action batches resident in HBM, step k takes batch k mod {pool} "
                                    f"(no policy in the loop)",
@@ -857,44 +874,49 @@ def main():
                                       "done in the last step" % (m.settle_steps, int((obs[:, -1] != 0).sum().item()), n))
                        if auto_reset else None,
                        "launch": launch,
-                       "exchange_form": shard_form, "exchange_tune": exchange_tune,
+                       "exchange_form": ("%s / %s" % (shard_form, exchange_form)) if multi else None,
+                       "peers": shard.peer_count() if multi else None,
                        "spin_up": ("%d untimed steps of a scratch handle before the warm-up steps and 256 more right in front of the "
                                    "synchronisation that opens the timed region (GPU clocks)" % args.spin_up_steps)
                        if args.spin_up_steps > 0 else None,
                        "envs_per_gpu": n, "global_envs": world * n, "substeps_per_launch": 1,
-                       "steps_per_launch": (min(K, 64) if multi else min(K, GCH)) if loop_form else 1,
-                       "parallelism": f"env-shard x{world}" + (" [FALLBACK: exchange through torch.distributed, the C-ABI shard "
-                                                                "could not be created] " if (multi and torch_fallback) else "") + (
-                           f" + one {'all_gather_into_tensor (torch.distributed)' if (multi and torch_fallback) else 'ncclAllGather (librccl from the C ABI, tds_hip_shard_step_many)'} of the (obs|reward|done) "
-                           f"records per {'policy step' if B == 1 else str(B) + ' steps'}, "
-                           f"{args.gather_dtype if args.dtype == 'f64' else 'f32'} on the wire (the records are computed "
-                           f"and fed back in {'f64' if args.dtype == 'f64' else 'f32'} on the owning GPU), on a "
-                           f"communication stream, overlapped with the following steps" if multi else ""),
+                       "steps_per_launch": (min(K, 256) if multi else min(K, GCH)) if loop_form else 1,
+                       "parallelism": f"env-shard x{world}" + (
+                           f" + one exchange of the (obs|reward|done) records per {'policy step' if B == 1 else str(B) + ' steps'} "
+                           f"({'peer stores into IPC-mapped gathered rings, no collective' if exchange_form == 'peer_stores' else 'ncclAllGather, librccl called from the C ABI'}; "
+                           f"tds_hip_shard_step_many), {args.gather_dtype if args.dtype == 'f64' else 'f32'} on the wire (the records are "
+                           f"computed and fed back in {'f64' if args.dtype == 'f64' else 'f32'} on the owning GPU), overlapped with "
+                           f"the following steps" if multi else ""),
                        "lanes_per_env": sim.kernel_info()["lanes_per_env"],
                        "lds_bytes_per_env": sim.kernel_info()["lds_bytes_per_env"]},
             "roofline": roof, "finite": finite, "nonfinite_envs": bad_envs,
         }
         if substep_fused is not None:
             out["substep_fused"] = substep_fused
+        if steady is not None:
+            out["steady_state_1000"] = steady
         if one_rank is not None:
             if "value" in one_rank:
                 one_rank["ratio_to_value"] = one_rank["value"] / value
             out["one_rank_with_exchange"] = one_rank
+        if one_rank_7 is not None:
+            if "value" in one_rank_7:
+                one_rank_7["ratio_to_value"] = one_rank_7["value"] / value
+            out["one_rank_with_exchange_7_loopback_peers"] = one_rank_7
         if auto_rate is not None:
             out["auto_reset_rate"] = auto_rate
         if rollout is not None:
             out["on_device_rollout"] = rollout
         if pipelined is not None:
             out["pipelined_gather"] = pipelined
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and secondary:
             cb = cpu_baseline(args.model, min(n, 4096))
             primary = cb.get("reference") or cb.get("port")
             out["cpu_baseline"] = primary
             out["cpu_baseline_port"] = cb.get("port")
             out["cpu_baseline_generated"] = cb.get("generated")
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

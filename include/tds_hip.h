@@ -630,12 +630,37 @@ int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const 
                   of step k are visible device-wide, and the communication stream — one bounded one-lane wait kernel (or
                   hipStreamWaitValue64: option shard_wait) + one all-gather per step — sends slot k while the launch runs
                   step k + 1, as soon as the SLOWEST workgroup has stored it.
+   PEER-STORE EXCHANGE (round 5; option shard_peer, default on where every rank can set it up).  The all-gather without a
+   collective: at the first tds_hip_shard_step_many every rank maps the other ranks' gathered rings and flag arrays into its
+   address space (hipIpcGetMemHandle / hipIpcOpenMemHandle, the handles exchanged once over the communicator; a token round
+   trip over the mapped memory checks the mapping) and from then on the step-loop launch itself — the N = 1 two-wavefront
+   build — stores every step's record into its own block of the slot on EVERY rank (system-scope write-through stores over
+   xGMI, issued by the helper wavefront that stores the record anyway) and raises the slot's flag on every rank when its
+   last workgroup has stored it.  The transfer of step k lies inside step k + 1 of the same launch; no kernel of the
+   exchange needs a compute unit beside the launch, no host call per step.  Around a LAUNCH: a one-wave credit kernel in
+   front of it (ranks drift apart by at most one launch: launch m waits until every peer has started launch m - 1) and a
+   one-wave arrival check behind it on the communication stream (what tds_hip_shard_gathered / _flush wait for).  If IPC
+   cannot be set up on ANY rank, every rank uses the RCCL forms above (shard_peer = 2: an error instead; = 0: never
+   tried).  Option exchange_fields = 1 sends only [reward | done] to the peers (8 instead of 120 bytes per Ant
+   environment and step on the float wire: for runs whose policy lives on the device, tds_hip_rollout).
+   tds_hip_shard_exchange_form tells which form the most recent call ran.
    Option shard_graph = 1 replays each launch + its exchanges from one hipGraph instead (cached by arguments; slower on
    ROCm 7: a chain of dependent graph nodes pays a node-to-node latency a stream does not).  tds_hip_shard_gathered then
    returns the slot of the last step, [world][n_local][obs_dim + 2].  Option shard_ring = 0 forces the per-step-launch
    form. */
 int tds_hip_shard_step_many(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks, int first_block,
                             int n_steps);
+/* which exchange the most recent tds_hip_shard_step / _step_many of the shard ran (0: none yet) */
+enum {
+  TDS_EXCHANGE_NONE = 0,
+  TDS_EXCHANGE_RCCL_PER_STEP = 1,     /* one kernel launch + one ncclAllGather per step (eager or from one hipGraph) */
+  TDS_EXCHANGE_RCCL_AFTER_LAUNCH = 2, /* ring exchange, two-wavefront build: the launch's slots as ONE RCCL group behind it */
+  TDS_EXCHANGE_RCCL_PER_SLOT = 3,     /* ring exchange, one-wave build: wait kernel + ncclAllGather per slot beside the launch */
+  TDS_EXCHANGE_PEER_STORES = 4        /* ring exchange by peer stores: no collective, the launch writes every rank's ring */
+};
+int tds_hip_shard_exchange_form(const tds_hip_shard_t *shard);
+/* ranks this shard stores its records to under the peer-store exchange (0 on one rank; -1: the exchange is not in use) */
+int tds_hip_shard_peer_count(const tds_hip_shard_t *shard);
 /* capture + instantiate the graph of the next tds_hip_shard_step_many with the same arguments; nothing executes */
 int tds_hip_shard_step_many_prepare(tds_hip_shard_t *shard, const void *actions_dev, int action_blocks,
                                     int first_block, int n_steps);

@@ -505,6 +505,11 @@ struct VectorizedEnv {
           observations[e].resize(contact_sim.input_dim());
           contact_sim.reset(sim_states_[e], observations[e]);
           sim_states_[e].resize(od_);
+          // (the reference then OVERWRITES the observation reset() wrote: observations = sim_states_ resized to input_dim
+          //  with [0] = [1] = 0, ars_vectorized_environment.h:282-288 — a reset pose with non-zero base x, y shows the
+          //  difference)
+          observations[e].assign(sim_states_[e].begin(), sim_states_[e].begin() + od_);
+          if (od_ > 1) observations[e][0] = observations[e][1] = 0.;
           any_host_reset = true;
         }
         dones[e] = done;
@@ -553,23 +558,30 @@ struct VectorizedEnv {
       for (size_t k = 0; k < W.size(); ++k) params[(size_t)e * np + i++] = W[k];
       for (size_t k = 0; k < B.size(); ++k) params[(size_t)e * np + i++] = B[k];
     }
-    void *pol = nullptr, *ret = nullptr, *cnt = nullptr;
+    // (the three device buffers are released on every way out, fail() throwing included)
+    struct DeviceBuffer {
+      tds_hip_sim_t *h;
+      void *p = nullptr;
+      explicit DeviceBuffer(tds_hip_sim_t *handle) : h(handle) {}
+      ~DeviceBuffer() {
+        if (p) tds_hip_device_free(h, p);
+      }
+      DeviceBuffer(const DeviceBuffer &) = delete;
+      DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    } pol(handle_->h), ret(handle_->h), cnt(handle_->h);
     auto chk = [&](int rc) {
       if (rc != TDS_OK) fail(tds_hip_last_error(), rc);
     };
-    chk(tds_hip_device_alloc(handle_->h, params.size() * 8, &pol));
-    chk(tds_hip_device_alloc(handle_->h, (size_t)batch_size_ * 8, &ret));
-    chk(tds_hip_device_alloc(handle_->h, (size_t)batch_size_ * sizeof(int), &cnt));
-    chk(tds_hip_device_upload(handle_->h, pol, params.data(), params.size() * 8));
+    chk(tds_hip_device_alloc(handle_->h, params.size() * 8, &pol.p));
+    chk(tds_hip_device_alloc(handle_->h, (size_t)batch_size_ * 8, &ret.p));
+    chk(tds_hip_device_alloc(handle_->h, (size_t)batch_size_ * sizeof(int), &cnt.p));
+    chk(tds_hip_device_upload(handle_->h, pol.p, params.data(), params.size() * 8));
     chk(tds_hip_reset(handle_->h, nullptr, nullptr));
-    chk(tds_hip_rollout(handle_->h, pol, rollout_length, shift, /*first step sees the raw base x, y*/ 1, ret, (int *)cnt, nullptr));
+    chk(tds_hip_rollout(handle_->h, pol.p, rollout_length, shift, /*first step sees the raw base x, y*/ 1, ret.p, (int *)cnt.p, nullptr));
     total_rewards.resize(batch_size_);
     vec_steps.resize(batch_size_);
-    chk(tds_hip_device_download(handle_->h, total_rewards.data(), ret, (size_t)batch_size_ * 8));
-    chk(tds_hip_device_download(handle_->h, vec_steps.data(), cnt, (size_t)batch_size_ * sizeof(int)));
-    tds_hip_device_free(handle_->h, pol);
-    tds_hip_device_free(handle_->h, ret);
-    tds_hip_device_free(handle_->h, cnt);
+    chk(tds_hip_device_download(handle_->h, total_rewards.data(), ret.p, (size_t)batch_size_ * 8));
+    chk(tds_hip_device_download(handle_->h, vec_steps.data(), cnt.p, (size_t)batch_size_ * sizeof(int)));
   }
 
  private:

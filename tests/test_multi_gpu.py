@@ -343,7 +343,8 @@ def test_shard_ring_exchange_on_one_rank(with_rccl, submit, wire, built, monkeyp
     x, acts = _start(m, n, seed=41)
     a = torch.from_numpy(acts).cuda().contiguous()
     uid = hip_backend.HipShard.unique_id() if with_rccl else None
-    sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype=wire, options={"shard_chunk": 64})  # (default: 256 steps per launch)
+    # (default: 256 steps per launch; shard_peer = 0: the RCCL forms of the exchange — the default, peer stores, has its own tests below)
+    sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype=wire, options={"shard_chunk": 64, "shard_peer": 0})
     ref = hip_backend.HipSim(m, n)
     for s in (sh.sim, ref):
         s.x.copy_(torch.from_numpy(x).cuda())
@@ -473,4 +474,109 @@ def test_ring_exchange_sends_a_slot_only_when_the_slowest_workgroup_has_stored_i
     #  own arithmetic too: they are compared bit for bit above like every other record and left out here)
     z = ref.x[: n // 2, 2]
     assert int(torch.isfinite(z).sum()) > n // 2 - 32 and float(z[torch.isfinite(z)].min()) > 1.0
+    sh.close()
+
+
+@pytest.mark.parametrize("with_rccl,wire,loopback,fields", [
+    (False, "f32", 0, 0), (True, "f32", 0, 0), (False, "f64", 3, 0), (True, "f32", 7, 0), (False, "f32", 2, 1)])
+def test_shard_peer_store_exchange_on_one_rank(with_rccl, wire, loopback, fields, built):
+    """The DEFAULT ring exchange (round 5): the step-loop launch stores every step's record into the gathered slot itself —
+    on every rank; here on the one rank there is, plus `loopback` scratch rings of its own standing in for peers, so that the
+    kernel executes exactly what it executes on loopback + 1 GPUs — and raises the slot's flags when its last workgroup has
+    stored it.  EVERY slot of the most recent launch (tds_hip_shard_gathered_step), the state and the y record, bit for bit
+    against the same launches without any exchange; launches of 64 + 11 steps, three calls (both ring halves, reuse)."""
+    torch = _torch()
+    if with_rccl and hip_backend.HipShard.rccl_version() == 0:
+        pytest.skip("librccl cannot be loaded on this machine")
+    m = tds_amd.load_model("ant")
+    n = 1000
+    x, acts = _start(m, n, seed=43)
+    a = torch.from_numpy(acts).cuda().contiguous()
+    uid = hip_backend.HipShard.unique_id() if with_rccl else None
+    sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype=wire,
+                              options={"shard_chunk": 64, "shard_peer": 2, "shard_peer_loopback": loopback, "exchange_fields": fields})
+    ref = hip_backend.HipSim(m, n)
+    for s in (sh.sim, ref):
+        s.x.copy_(torch.from_numpy(x).cuda())
+    K = 75
+    wdt = torch.float32 if wire == "f32" else torch.float64
+    idt = torch.int32 if wire == "f32" else torch.int64
+    ring = torch.zeros((K, n, ref.obs_dim + 2), dtype=wdt, device="cuda")
+    for rep in range(3):
+        sh.step_many(a, K, first_block=1 + rep)
+        assert sh.exchange_form() == "peer_stores" and sh.peer_count() == loopback
+        ref.step_many_rings(a, K, ring, None, first_block=1 + rep)
+        torch.cuda.synchronize()
+        last = K - 64  # steps of the most recently submitted launch
+        for back in range(last):
+            got = sh.gathered_step(back)
+            assert tuple(got.shape) == (1, n, ref.obs_dim + 2) and got.dtype == wdt
+            assert torch.equal(got[0].view(idt), ring[K - 1 - back].view(idt)), (rep, back)
+        assert torch.equal(sh.gathered()[0, 0].view(idt), ring[-1].view(idt))
+        sh.flush()
+        assert torch.equal(sh.sim.x.view(torch.int64), ref.x.view(torch.int64)), rep
+        assert torch.equal(sh.sim.y.view(torch.int64), ref.y.view(torch.int64)), rep
+    # an option that shapes the ring is refused once the ring exists (it would be ignored silently)
+    with pytest.raises(Exception):
+        sh.sim.set_option("shard_chunk", 128)
+    sh.close()
+
+
+@pytest.mark.parametrize("form", ["peer_stores", "peer_stores_7_loopback", "rccl_group_after_launch", "rccl_per_slot"])
+def test_shard_step_many_every_gathered_slot_against_the_reference(form, built):
+    """What an N > 1 run executes by default — tds_hip_shard_step_many, ring exchange — pinned on the REFERENCE
+    (oracle/_ref/libtds_ref.so) at BASELINE config 3's size: every environment of every gathered slot of an Ant x 4096 x 20
+    call against the reference's own step + compute_reward_done started from the state the slot before it holds (a lock-step
+    plain handle provides that state: its y ring is the trajectory, and the shard's records must equal its records bit for
+    bit).  One rank (a 1-GPU box); the forms differ in the kernel build and in how records become visible."""
+    torch = _torch()
+    from test_hip_parity import _reference_stepper
+    from test_rings import _reward_done, _start_state
+
+    m = tds_amd.load_model("ant")
+    n, steps = 4096, 20
+    ref_step, what = _reference_stepper("ant", n)
+    rng = np.random.default_rng(78)
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    opts = {"peer_stores": {"shard_peer": 2}, "peer_stores_7_loopback": {"shard_peer": 2, "shard_peer_loopback": 7},
+            "rccl_group_after_launch": {"shard_peer": 0}, "rccl_per_slot": {"shard_peer": 0, "exchange_w2": 0}}[form]
+    uid = hip_backend.HipShard.unique_id() if (form.startswith("rccl") and hip_backend.HipShard.rccl_version() != 0) else None
+    sh = hip_backend.HipShard(m, n, unique_id=uid, wire_dtype="f64", options=opts)
+    plain = hip_backend.HipSim(m, n, options={"exchange_w2": opts.get("exchange_w2", 1)})
+    x0 = _start_state(m, "ant", n, rng)
+    for s in (sh.sim, plain):
+        s.x.copy_(torch.from_numpy(x0).cuda())
+        for _ in range(10):
+            s.step(None)
+    act = rng.uniform(-0.4, 0.4, (steps, n, adim))
+    actions = torch.from_numpy(act).cuda().contiguous()
+    x_start = plain.x.cpu().numpy()
+    y_ring = torch.zeros((steps, n, m.output_dim), dtype=torch.float64, device="cuda")
+    o_ring = torch.zeros((steps, n, plain.obs_dim + 2), dtype=torch.float64, device="cuda")
+    prog = torch.zeros(steps, dtype=torch.int64, device="cuda") if form == "rccl_per_slot" else None
+    plain.step_many_rings(actions, steps, o_ring, y_ring, progress=prog)
+    sh.step_many(actions, steps)
+    assert sh.exchange_form() == form.replace("_7_loopback", "")
+    slots = [sh.gathered_step(steps - 1 - k)[0].clone() for k in range(steps)]
+    sh.flush()
+    torch.cuda.synchronize()
+    yr = y_ring.cpu().numpy()
+    x = x_start.copy()
+    worst = 0.0
+    for k in range(steps):
+        assert torch.equal(slots[k].view(torch.int64), o_ring[k].view(torch.int64)), (form, k)
+        got = slots[k].cpu().numpy()
+        x[:, nq + nd:nq + nd + adim] = act[k]
+        y_ref = ref_step(x)
+        rew, done = _reward_done(m, "ant", x[:, :nq], y_ref)
+        ob = y_ref[:, :nq + nd].copy()
+        ob[:, :2] = 0.0
+        e = rel_err(got[:, :nq + nd], ob, floor=1e-3)
+        worst = max(worst, e)
+        assert e < 1e-6, (form, k, e)
+        edge = np.abs(y_ref[:, 2] - 0.26) < 1e-7
+        assert (got[~edge, -1] == done[~edge]).all(), (form, k)
+        assert rel_err(got[~edge, -2], rew[~edge], floor=1.0) < 1e-5, (form, k)
+        x[:, :nq + nd] = yr[k][:, :nq + nd]
+    print(f"ant x{n}, tds_hip_shard_step_many [{form}], {steps} gathered slots, every env, vs {what}: worst {worst:.3e}")
     sh.close()

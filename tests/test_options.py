@@ -97,3 +97,71 @@ def test_an_experiment_slot_that_is_not_linked_in_is_refused(built):
         sim.step(None)
     sim.set_option("alt_build", None)
     sim.step(None)
+
+
+WATCHDOG_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["TDS_ROOT"])
+import torch
+import tds_amd
+from tds_amd import hip_backend
+name = sys.argv[1]
+m = tds_amd.load_model(name)
+g = np.load(os.path.join(os.environ["TDS_ROOT"], "tests", "golden", name + ".npz"))
+n = 4096
+x = torch.from_numpy(np.resize(g["x"], (n, m.input_dim))).cuda()
+act = torch.zeros((4, n, m.action_dim), dtype=torch.float64, device="cuda")
+# every step-loop launch form a caller can reach for an 8-dof model: library default, both forced compilations
+for occ in (None, 2, 1):
+    sim = hip_backend.HipSim(m, n)
+    sim.x.copy_(x)
+    refused = False
+    try:
+        if occ is not None:
+            sim.set_option("loop_occ", occ)
+        sim.step_many(act, 50)
+        torch.cuda.synchronize()
+    except hip_backend.TdsHipError:
+        refused = True
+    assert refused == (occ == 1), (name, occ, refused)
+    if not refused:
+        assert torch.isfinite(sim.x).all()
+# ... and as the process default (the environment variable of round 4's report): refused at the launch, not hung
+with hip_backend.default_options(loop_occ=1):
+    sim = hip_backend.HipSim(m, n)
+    sim.x.copy_(x)
+    try:
+        sim.step_many(act, 50)
+        torch.cuda.synchronize()
+        raise SystemExit("loop_occ = 1 was not refused")
+    except hip_backend.TdsHipError:
+        pass
+print("ok")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cartpole", "pendulum5"])
+def test_step_loop_launches_of_the_8_dof_kernels_terminate(name, built):
+    """Round 4's advisor finding: built without MachineLICM (csrc/Makefile KFLAGS) the one-wavefront-per-SIMD compilation of
+    the step loop of <double, double, 16, 8> never terminated (profiles/r04_diag_loop_hang.txt) and option loop_occ = 1 could
+    still launch it.  That compilation is no longer instantiated below 14 padded dof and the option is refused there; this
+    test runs every reachable step-loop form of the two 8-dof BASELINE models (configs 1, 2) under a watchdog."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TDS_ROOT=root)
+    p = subprocess.Popen([sys.executable, "-c", WATCHDOG_WORKER, name], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        out, _ = p.communicate(timeout=180)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        pytest.fail(f"{name}: a step-loop launch did not terminate within the watchdog's 180 s")
+    assert p.returncode == 0 and b"ok" in out, out.decode(errors="replace")[-2000:]

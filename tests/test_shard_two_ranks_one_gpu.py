@@ -48,6 +48,12 @@ else:
             sh.step_many(acts, c, first_block=done % 4)
             done += c
 gat = sh.gathered().clone()
+form = sh.exchange_form()
+# ring exchange: EVERY slot of the most recently submitted launch, not only the last one
+backs = []
+if mode != "single" and form in ("peer_stores", "rccl_group_after_launch", "rccl_per_slot"):
+    last = steps // 3 if steps // 3 else steps
+    backs = [sh.gathered_step(b).clone() for b in range(min(last, 64))]
 sh.flush()
 torch.cuda.synchronize()
 # what this shard computes on its own: the same steps on a plain handle
@@ -63,7 +69,12 @@ else:
     ref.step_many_rings(acts, steps, ring, None, progress=torch.zeros(steps, dtype=torch.int64, device="cuda"))
     obs = ring[-1]
 torch.cuda.synchronize()
-np.savez(out, gathered=gat.cpu().numpy(), local=obs.to(torch.float32).cpu().numpy(), x=sim.x.cpu().numpy(), xref=ref.x.cpu().numpy())
+extra = {}
+if backs:
+    extra["backs"] = torch.stack(backs).cpu().numpy()                         # [b][world][n_local][w] float
+    extra["local_backs"] = torch.stack([ring[steps - 1 - b] for b in range(len(backs))]).to(torch.float32).cpu().numpy()
+np.savez(out, gathered=gat.cpu().numpy(), local=obs.to(torch.float32).cpu().numpy(), x=sim.x.cpu().numpy(), xref=ref.x.cpu().numpy(),
+         form=np.array(form), peers=np.array(sh.peer_count()), **extra)
 sh.close()
 '''
 
@@ -82,17 +93,26 @@ def stub_lib(tmp_path_factory):
     return _stub(tmp_path_factory)
 
 
-@pytest.mark.parametrize("mode,name,steps,env", [
-    ("many", "ant", 75, {}),                                   # ring exchange submitted eagerly (the default: two-wavefront build, slots sent behind the launch as one group)
-    ("many", "ant", 75, {"TDS_HIP_EXCHANGE_W2": "0"}),         # ... the one-wave build: per-slot counters, a slot sent while the launch runs
-    ("many", "ant", 75, {"TDS_HIP_SHARD_GRAPH": "1"}),         # ring exchange, one hipGraph per step-loop launch
-    ("many", "ant", 75, {"TDS_HIP_RING_NOFENCE": "0"}),        # records made visible by a release fence instead of write-through stores
-    ("many", "pendulum5", 30, {}),                             # a world without contacts (always the step-loop form)
-    ("many", "ant", 12, {"TDS_HIP_SHARD_RING": "0"}),          # per-step launches + exchanges from one hipGraph
-    ("many", "laikago", 9, {}),                                # a model whose step_many is not the step-loop form
-    ("single", "ant", 7, {}),                                  # tds_hip_shard_step, one call per step
+RCCL = {"TDS_HIP_SHARD_PEER": "0"}  # the forms of the exchange that go through ncclAllGather (here: the stub)
+
+
+@pytest.mark.parametrize("mode,name,steps,env,want_form", [
+    # PEER STORES (the default): each process maps the other's gathered ring and flag array through hipIpcOpenMemHandle — real
+    # IPC between two processes, here onto the one GPU — and its step-loop launch stores every record on both "ranks"
+    ("many", "ant", 75, {"TDS_HIP_SHARD_PEER": "2"}, "peer_stores"),
+    ("many", "ant", 75, {}, "peer_stores"),
+    ("many", "ant", 75, {"TDS_HIP_EXCHANGE_FIELDS": "1"}, "peer_stores"),   # only [reward | done] travel to the peer
+    ("many", "pendulum5", 30, {}, "peer_stores"),                           # a world without contacts (one-wave step-loop build)
+    ("many", "ant", 75, dict(RCCL), "rccl_group_after_launch"),             # ring exchange, two-wavefront build, slots sent behind the launch as one group
+    ("many", "ant", 75, dict(RCCL, TDS_HIP_EXCHANGE_W2="0"), "rccl_per_slot"),  # ... the one-wave build: per-slot counters, a slot sent while the launch runs
+    ("many", "ant", 75, dict(RCCL, TDS_HIP_SHARD_GRAPH="1"), "rccl_group_after_launch"),  # ring exchange, one hipGraph per step-loop launch
+    ("many", "ant", 75, dict(RCCL, TDS_HIP_RING_NOFENCE="0", TDS_HIP_EXCHANGE_W2="0"), "rccl_per_slot"),  # records made visible by a release fence instead of write-through stores
+    ("many", "pendulum5", 30, dict(RCCL), "rccl_per_slot"),                 # a world without contacts through RCCL
+    ("many", "ant", 12, {"TDS_HIP_SHARD_RING": "0"}, "rccl_per_step"),      # per-step launches + exchanges from one hipGraph
+    ("many", "laikago", 9, {}, "rccl_per_step"),                            # a model whose step_many is not the step-loop form
+    ("single", "ant", 7, {}, "rccl_per_step"),                              # tds_hip_shard_step, one call per step
 ])
-def test_two_ranks_on_one_gpu(mode, name, steps, env, built, stub_lib, tmp_path):
+def test_two_ranks_on_one_gpu(mode, name, steps, env, want_form, built, stub_lib, tmp_path):
     import torch
 
     if not torch.cuda.is_available():
@@ -121,9 +141,22 @@ def test_two_ranks_on_one_gpu(mode, name, steps, env, built, stub_lib, tmp_path)
     r = [np.load(o) for o in outs]
     w = r[0]["local"].shape[1]
     want = np.concatenate([r[0]["local"], r[1]["local"]])  # global environment order = rank order
+    rd_only = env.get("TDS_HIP_EXCHANGE_FIELDS") == "1"
     for k in range(world):
+        assert str(r[k]["form"]) == want_form, (k, str(r[k]["form"]), logs[k])
+        assert int(r[k]["peers"]) == (1 if want_form == "peer_stores" else -1)
         got = r[k]["gathered"].reshape(-1, w)
         assert got.shape == want.shape
+        if rd_only:  # the OTHER rank's block carries [reward | done] only (its observation columns are never written)
+            other = slice((1 - k) * n_local, (2 - k) * n_local)
+            assert np.array_equal(got[other, -2:], want[other, -2:], equal_nan=True) and (got[other, :-2] == 0).all()
+            got[other, :-2] = want[other, :-2]
+        if "backs" in r[k].files:  # every slot of the last launch, both ranks' blocks
+            lb = np.concatenate([r[0]["local_backs"], r[1]["local_backs"]], axis=1)  # [b][world n_local][w]
+            gb = r[k]["backs"].reshape(lb.shape).copy()
+            if rd_only:
+                gb[:, other, :-2] = lb[:, other, :-2]
+            assert np.array_equal(gb, lb, equal_nan=True), k
         # the records crossed "the wire" as floats; ring form and its reference come from the same step-loop build, the
         # per-step forms from the same straight-line build: equal bit for bit
         # (random states driven by random actions: a few environments leave the finite range on the way)

@@ -149,6 +149,12 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
                                                     : !(opts && opts->rings));
   const TdsLds &lds = (opts && opts->lds) ? *opts->lds : (two_waves ? s->lds_w2 : s->lds);
   const long long occ = s->opt.get(TDS_OPT_LOOP_OCC, 0);
+  // (the one-wavefront-per-SIMD compilation of the step loop does not exist below 14 padded dof: built without
+  //  MachineLICM its <double, double, 16, 8> instantiation never terminated — profiles/r04_diag_loop_hang.txt — and the
+  //  two-wavefront compilation holds no scratch there, so nothing is lost; asked for by option, the launch is refused
+  //  instead of falling back silently)
+  if (occ == 1 && lds.NDP < 14 && !two_waves && (nsub != 1 || reset_mode != TDS_RESET_NONE || ro || (opts && opts->rings)))
+    return fail(TDS_ERR_UNSUPPORTED, "option loop_occ = 1: no one-wavefront-per-SIMD step-loop build below 14 padded dof");
   const int form = (two_waves ? TDS_FORM_W2 : 0) | (occ == 1 ? TDS_FORM_LOOP_OCC1 : (occ == 2 ? TDS_FORM_LOOP_OCC2 : 0));
   void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
   if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along
@@ -204,6 +210,24 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     }
     ctl.ring_envs = s->num_envs;
     ctl.progress = r.progress;
+    if (s->peer_launch && r.obs_ring) {  // peer-store exchange (tds_shard.hip): the launch counts EVERY step in on arrival counters
+      const TdsPeerLaunch &pl = *s->peer_launch;
+      ctl.progress = nullptr;
+      ctl.peer_ring = pl.rings;
+      ctl.peer_flags = pl.flags;
+      ctl.peer_arrive = pl.arrive;
+      ctl.peer_off = pl.ring_off + (long long)(e0 * s->obs_width() * (r.obs_f32 ? 4 : s->elem));
+      ctl.peer_epoch = pl.epoch;
+      ctl.n_peers = pl.n_peers;
+      ctl.peer_flag_off = pl.flag_off;
+      ctl.peer_flag_stride = pl.flag_stride;
+      if (pl.reward_done_only) ctl.ring_flags |= TDS_RING_PEER_REWARD_DONE;
+      // this rank's own block: write-through stores, visible device-wide when the slot's flag is raised (a consumer may read a
+      // slot before the launch has completed); counted in at the top of the helper wavefront's NEXT iteration, where it
+      // waits for the kinematics anyway — the acknowledgements of stores that crossed xGMI have had a whole step by then
+      ctl.ring_flags |= TDS_RING_NOFENCE;
+      if (s->opt.get(TDS_OPT_RING_SIGNAL_LATE, 1) == 1) ctl.ring_flags |= TDS_RING_SIGNAL_LATE;
+    }
   }
   if (opts && !opts->rings && opts->y_stride > 0) ctl.y_stride = opts->y_stride;
   else if (!y_stride_set) ctl.y_stride = s->model.output_dim;  // (the kernels read the stride as it is: never 0)
@@ -269,9 +293,19 @@ int tds_hip_set_option(tds_hip_sim_t *s, const char *key, long long value) {
   if (tds_opt_rows()[k].create_time)
     return fail(TDS_ERR_INVALID_ARG, "option '%s' is fixed when a handle is created: tds_hip_default_option before tds_hip_create", key);
   if (s->opt.v[k] == value) return TDS_OK;
-  // (cached graphs / a pool laid out for the old value must not outlive it)
+  if (k == TDS_OPT_LOOP_OCC && value == 1 && s->lds.NDP < 14)
+    return fail(TDS_ERR_UNSUPPORTED, "option loop_occ = 1: no one-wavefront-per-SIMD step-loop build below 14 padded dof");
+  // options that shape the shard layer's ring are read ONCE, when the ring is first used: afterwards a new value would be
+  // ignored silently — refused instead (set them before the first tds_hip_shard_step_many, or with tds_hip_default_option)
+  if (s->shard_ring_shaped && (k == TDS_OPT_SHARD_CHUNK || k == TDS_OPT_SHARD_INPLACE || k == TDS_OPT_SHARD_WAIT ||
+                               k == TDS_OPT_SHARD_REGISTER || k == TDS_OPT_Y_STRIDE || k == TDS_OPT_SHARD_PEER ||
+                               k == TDS_OPT_EXCHANGE_FIELDS))
+    return fail(TDS_ERR_INVALID_ARG, "option '%s' shapes the shard's ring, which exists already: set it before the first "
+                                     "tds_hip_shard_step_many", key);
+  // (cached graphs / a pool laid out for the old value must not outlive it; alt_build: the cached step_many graphs
+  //  replay the kernel of the build that was current when they were captured)
   if (k == TDS_OPT_GRAPH_CHAINS || k == TDS_OPT_STEP_MANY_LOOP || k == TDS_OPT_LOOP_W2 || k == TDS_OPT_LOOP_OCC ||
-      k == TDS_OPT_NO_GRAPH_UPLOAD) {
+      k == TDS_OPT_NO_GRAPH_UPLOAD || k == TDS_OPT_ALT_BUILD) {
     DeviceGuard guard(s->device);
     (void)hipStreamSynchronize(s->stream);
     drop_graphs(s);
@@ -1217,6 +1251,9 @@ int rings_check(const tds_hip_sim *s, const tds_hip_rings_t *r, int n_steps) {
   //  one workgroup count behind per launch)
   if (r->progress && s->auto_reset)
     return fail(TDS_ERR_INVALID_ARG, "record rings: a progress counter cannot be combined with auto-reset");
+  // (one counter per slot of the OBS ring: without that ring the device would index the counters modulo zero)
+  if (r->progress && (!r->obs_ring || r->obs_slots < 1))
+    return fail(TDS_ERR_INVALID_ARG, "record rings: a progress counter needs an obs ring (one counter per obs slot)");
   const bool loop = step_many_as_loop(s, n_steps) || (n_steps == 1 && step_many_as_loop(s, 2));
   if (r->obs_slot_envs != 0 && (r->obs_slot_envs < s->num_envs || !loop))
     return fail(TDS_ERR_INVALID_ARG, "record rings: obs_slot_envs must be 0 or >= num_envs, step-loop form only");
@@ -1436,16 +1473,33 @@ int tds_hip_step(tds_hip_sim_t *s, const void *actions_dev, int substeps) {
 // ------------------------------------------------------------------------------------------------------
 extern "C++" {
 namespace {
+// bytes of the action staging region: the actions of a step, or the [N]-byte mask of tds_hip_reset_host, whichever is
+// larger (models without actions — free bodies — still reset through a mask)
+size_t stage_act_bytes(const tds_hip_sim *s) {
+  const size_t n = (size_t)s->num_envs, a = n * s->model.action_dim * s->elem;
+  return align256(a > n ? a : n);
+}
 int stage_alloc(tds_hip_sim *s) {
-  if (s->h_stage) return TDS_OK;
+  if (s->stage_ready) return TDS_OK;
   const size_t n = (size_t)s->num_envs;
-  const size_t b_act = align256(n * s->model.action_dim * s->elem), b_obs = align256(n * s->obs_width() * s->elem),
+  const size_t b_act = stage_act_bytes(s), b_obs = align256(n * s->obs_width() * s->elem),
                b_y = align256(n * s->model.output_dim * s->elem);
-  HIP_TRY(hipHostMalloc(&s->h_stage, b_act + b_obs + b_y, hipHostMallocDefault));
+  // all or nothing: a partial allocation is undone, and readiness is a flag set last (a later call then starts over
+  // instead of running with NULL device staging)
+  hipError_t e = hipHostMalloc(&s->h_stage, b_act + b_obs + b_y, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(&s->d_stage_act, b_act);
+  if (e == hipSuccess) e = hipMalloc(&s->d_stage_obs, b_obs);
+  if (e == hipSuccess) e = hipMemset(s->d_stage_obs, 0, b_obs);
+  if (e != hipSuccess) {
+    if (s->h_stage) (void)hipHostFree(s->h_stage);
+    if (s->d_stage_act) (void)hipFree(s->d_stage_act);
+    if (s->d_stage_obs) (void)hipFree(s->d_stage_obs);
+    s->h_stage = s->d_stage_act = s->d_stage_obs = nullptr;
+    snprintf(g_err, sizeof(g_err), "staging buffers of the host-vector entry points: %s", hipGetErrorString(e));
+    return TDS_ERR_HIP;
+  }
   s->h_stage_bytes = b_act + b_obs + b_y;
-  HIP_TRY(hipMalloc(&s->d_stage_act, b_act));
-  HIP_TRY(hipMalloc(&s->d_stage_obs, b_obs));
-  HIP_TRY(hipMemset(s->d_stage_obs, 0, b_obs));
+  s->stage_ready = true;
   return TDS_OK;
 }
 // records of the record dtype in pinned memory -> host doubles
@@ -1463,7 +1517,7 @@ int tds_hip_step_host(tds_hip_sim_t *s, const double *actions_host, int substeps
   int rc = stage_alloc(s);
   if (rc != TDS_OK) return rc;
   const size_t n = (size_t)s->num_envs, na = n * s->model.action_dim, no = n * s->obs_width(), ny = n * s->model.output_dim;
-  const size_t b_act = align256(na * s->elem), b_obs = align256(no * s->elem);
+  const size_t b_act = stage_act_bytes(s), b_obs = align256(no * s->elem);
   char *const h_act = (char *)s->h_stage, *const h_obs = h_act + b_act, *const h_y = h_obs + b_obs;
   if (actions_host) {
     if (s->records_f64()) memcpy(h_act, actions_host, na * 8);
@@ -1489,7 +1543,7 @@ int tds_hip_reset_host(tds_hip_sim_t *s, const unsigned char *mask_host, double 
   int rc = stage_alloc(s);
   if (rc != TDS_OK) return rc;
   const size_t n = (size_t)s->num_envs, no = n * s->obs_width();
-  const size_t b_act = align256(n * s->model.action_dim * s->elem);
+  const size_t b_act = stage_act_bytes(s);
   char *const h_obs = (char *)s->h_stage + b_act;
   unsigned char *mask_dev = nullptr;
   if (mask_host) {  // (the action staging buffer doubles as the mask: a reset takes no action)

@@ -10,6 +10,18 @@
 #include "tds_hip.h"
 #include "tds_kernels.h"
 
+// Peer-store exchange of ONE step-loop launch (tds_shard.hip sets tds_hip_sim::peer_launch around its call of
+// tds_hip_step_many_rings; launch() copies it into TdsStepCtl::peer_*).  Library-internal: not part of the C ABI.
+struct TdsPeerLaunch {
+  const void *const *rings;          // device array [n_peers]: the peers' gathered rings as mapped in this process
+  unsigned long long *const *flags;  // device array [n_peers + 1]: the peers' flag arrays, this rank's own last
+  unsigned int *arrive;              // arrival counters of the launch's slots (slot 0 of the launch first)
+  long long ring_off;                // bytes from a ring's base to this rank's block of the launch's slot 0
+  unsigned long long epoch;          // the launch's sequence number
+  int n_peers, flag_off, flag_stride;
+  int reward_done_only;              // option exchange_fields = 1
+};
+
 struct tds_hip_sim {
   tds_model_t model;
   int num_envs = 0, device = 0, dtype = TDS_DTYPE_F64, lanes = 64;
@@ -35,6 +47,9 @@ struct tds_hip_sim {
   // pinned staging of the host-vector entry points (tds_hip_step_host / tds_hip_reset_host): actions up, records down
   void *h_stage = nullptr, *d_stage_act = nullptr, *d_stage_obs = nullptr;
   size_t h_stage_bytes = 0;
+  bool stage_ready = false;        // the three staging buffers exist (set last by stage_alloc: all or nothing)
+  const TdsPeerLaunch *peer_launch = nullptr;  // != NULL: the next ring launch is a peer-store exchange launch (see above)
+  bool shard_ring_shaped = false;  // a shard layer has laid out its ring from this handle's options (tds_shard.hip: ring_alloc)
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_ms = false;

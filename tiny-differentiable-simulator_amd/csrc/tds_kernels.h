@@ -80,6 +80,21 @@ struct TdsStepCtl {
   // drained by then: no wait on the step's own path), never for the last step of a launch (kernel completion covers
   // it).  What a communication stream polls to send ring slot k while the launch carries on.
   unsigned long long *progress;
+  // PEER-STORE EXCHANGE (tds_shard.hip, round 5): the multi-GPU exchange without a collective.  The wavefront that stores a
+  // step's [obs | reward | done] record into this rank's block of the gathered slot stores it into the SAME place of every
+  // peer's gathered ring as well (peer memory mapped through hipIpcOpenMemHandle, system-scope write-through stores over
+  // xGMI), and the workgroup that completes a slot — the last of the grid to count itself in on the slot's arrival counter —
+  // raises the slot's flag on every rank (its own included) to the launch's sequence number.  No kernel of the exchange
+  // ever needs a compute unit while the launch runs; the data movement of step k lies inside step k + 1.
+  // peer_arrive != NULL selects it (then progress == NULL); EVERY step of the launch is signalled, the last one included.
+  const void *const *peer_ring;     // [n_peers] device array: base of peer p's gathered ring as mapped in this process
+  unsigned long long *const *peer_flags;  // [n_peers + 1]: peer p's flag array [slots][world]; the last entry is this rank's own
+  unsigned int *peer_arrive;        // [obs_slots] arrival counters of this launch's slots (wrap at the grid size: atomicInc)
+  long long peer_off;               // bytes from a ring's base to THIS rank's block of the launch's slot 0
+  unsigned long long peer_epoch;    // the launch's sequence number (what a completed slot's flags are raised to)
+  int n_peers;                      // ranks other than this one (0: one rank — the counters and the own flags only)
+  int peer_flag_off;                // flag index of this rank in the launch's slot 0: slot0 * world + rank
+  int peer_flag_stride;             // flags per slot (= world)
 };
 #define TDS_RING_OBS_F32 1
 // the obs ring is written with device-scope write-through stores (sc1) and a step is signalled after a plain
@@ -89,6 +104,12 @@ struct TdsStepCtl {
 // where it waits for the main wavefront's kinematics anyway (instead of in the middle of iteration k + 1, where its wait
 // for the stores' acknowledgement sits in front of the workgroup barrier the main wavefront arrives at next)
 #define TDS_RING_SIGNAL_LATE 4
+// peer-store exchange: only [reward | done] of a record travel to the peers (option exchange_fields = 1: 8 of 120 bytes per
+// Ant environment on a float wire — for runs whose policy lives on the device, SURVEY 8f N2: "removes the obs gather except
+// for logging"); this rank's own block still receives the whole record
+#define TDS_RING_PEER_REWARD_DONE 8
+// upper bound of the peers of a rank (ranks of one node - 1)
+#define TDS_MAX_PEERS 15
 
 // which build of the step kernel a launch takes (tds_launch_step's `form`)
 #define TDS_FORM_W2 1         // L is the w2 layout: launch the two-wavefront form (plain kernels)

@@ -1718,11 +1718,28 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   };
   // [q | qd with obs[0] = obs[1] = 0 | reward | done] of ring slot `slot` (ars_vectorized_environment.h:250-289): the
   // observation from the LDS record as it is NOW, reward / done from their LDS slots (written by the reward block)
+  // Peer-store exchange (TdsStepCtl::peer_arrive): the same scalar goes into the same place of every peer's gathered ring —
+  // system-scope write-through stores into memory mapped from the other ranks (over xGMI) — by the wavefront that stores
+  // the record anyway (the helper wavefront of a two-wavefront workgroup: off the step's dependent chain).
   auto put_obs = [&](int slot) {
     const size_t at = ((size_t)slot * ctl.obs_envs + env) * (nq + nd + 2);
+    const int np = (LOOP && ctl.peer_arrive != nullptr) ? ctl.n_peers : 0;  // wave-uniform (kernel arguments)
+    const bool rd_only = (ctl.ring_flags & TDS_RING_PEER_REWARD_DONE) != 0;
     for (int i = lane; i < nq + nd + 2; i += G) {
       const int src = i < nq + nd ? i : (i == nq + nd ? in_dim + RW_SLOT : in_dim + 1);
-      ring_put(at + i, i < 2 ? T(0) : xr[src]);
+      const T v = i < 2 ? T(0) : xr[src];
+      ring_put(at + i, v);
+      if constexpr (LOOP) {
+        if (np > 0 && (i >= nq + nd || !rd_only)) {
+          for (int pr = 0; pr < np; ++pr) {
+            char *const pb = (char *)ctl.peer_ring[pr] + ctl.peer_off;
+            if (ctl.ring_flags & TDS_RING_OBS_F32)
+              __hip_atomic_store((float *)pb + (at + i), (float)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else
+              __hip_atomic_store((TR *)pb + (at + i), (TR)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+      }
     }
   };
   // the end-of-step records of the PREVIOUS step, from the LDS record (whose state part this step has not touched yet)
@@ -1741,7 +1758,30 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // environments carry more contacts falls steps behind the others over a long launch — so a single running total says
   // nothing about the slowest workgroup; the slot's own counter reaches (uses of the slot) x (workgroups) exactly when
   // EVERY workgroup has stored its records of that step.
+  // Peer-store exchange: this workgroup's records of ring slot `pslot` are out — acknowledged by the memory they went to,
+  // this rank's and the peers' — so it counts itself in on the slot's arrival counter (wrapping at the grid size: never
+  // reset); the workgroup that completes the slot raises the slot's flag of THIS rank on every rank, its own included, to
+  // the launch's sequence number.  Every store of every workgroup was acknowledged before that workgroup's count, and the
+  // flag stores are issued after the last count returned: a rank that sees the flag sees the records.
+  auto peer_signal = [&](int pslot) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned last = gridDim.x - 1u;
+      const unsigned old = atomicInc(ctl.peer_arrive + pslot, last);
+      if (old == last) {
+        const size_t fi = (size_t)ctl.peer_flag_off + (size_t)pslot * (size_t)ctl.peer_flag_stride;
+        for (int pr = 0; pr <= ctl.n_peers; ++pr)
+          __hip_atomic_store(ctl.peer_flags[pr] + fi, ctl.peer_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  };
   auto signal_progress = [&](int back = 1) {  // counts in the records of step tds_iter - back
+    if constexpr (LOOP) {
+      if (ctl.peer_arrive != nullptr) {  // wave-uniform
+        if (tds_iter >= back) peer_signal((ctl.obs_first + tds_iter - back) % ctl.obs_slots);
+        return;
+      }
+    }
     if (ctl.progress != nullptr && tds_iter >= back) {  // wave-uniform
       if (ctl.ring_flags & TDS_RING_NOFENCE)
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the obs ring's write-through stores have reached the L2 / memory
@@ -3975,6 +4015,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     //      the state the NEXT step starts from — after an auto-reset through the pool that is the fresh environment,
     //      while reward / done (written above) describe the step that ended (ars_vectorized_environment.h:262-277)
     if (ring_o && ring_now) put_obs((ctl.obs_first + tds_iter) % ctl.obs_slots);
+    // (peer-store exchange: EVERY step of the launch is counted in — the last one here, by the wavefront that has just stored
+    //  it; kernel completion would tell this rank, not the peers)
+    if (ring_o && ctl.peer_arrive != nullptr && __any(last_run)) peer_signal((ctl.obs_first + tds_iter) % ctl.obs_slots);
     if constexpr (DEFER) {
       if (ring_step && lane == 0) xr[in_dim + OUT_SLOT] = ring_now ? T(1) : T(0);  // "the records of this step are out"
     }
@@ -4134,9 +4177,11 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
     else if (loop_occ2 && NN < 24)                                                                           \
       hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 2, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
-    else                                                                                                     \
-      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, 1, KIND>), dim3(blocks), dim3(64), shmem, stream, \
+    else if constexpr (NN >= 14)                                                                             \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN >= 14 ? NN : 32), false, 1, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
+    else                                                                                                     \
+      return -3; /* (no one-wavefront-per-SIMD step-loop build below 14 padded dof: see loop_occ2) */        \
   } while (0)
   if (prof && KIND != 0) return -2;  // the phase-stamp build exists for the plain kernels only
   // straight-line kernel when the launch is exactly one normal step without any reset
@@ -4150,8 +4195,10 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   // (round 4: compiled without MachineLICM the two-wavefronts-per-SIMD compilation of the kernels up to 14 padded dof
   //  holds no scratch — 245 VGPR — and is taken at ANY grid size: the one-wavefront-per-SIMD compilation (256 VGPR + 20
   //  AGPR copies) buys nothing there any more, and its <double, double, 16, 8> instantiation does not terminate when
-  //  built without the pass — profiles/r04_diag_loop_hang.txt; option loop_occ = 1 still selects it)
-  const bool loop_occ2 = L.NDP < 24 && (loop_force == 2 || (loop_force != 1 && (blocks >= 1536 || L.NDP < 16)));
+  //  built without the pass — profiles/r04_diag_loop_hang.txt.  Round 5: that compilation is no longer INSTANTIATED
+  //  below 14 padded dof — nothing can launch it; option loop_occ = 1 is refused there by tds_api.hip: launch(),
+  //  TDS_ERR_UNSUPPORTED, and tests/test_options.py runs the 8-dof loop launches under a watchdog)
+  const bool loop_occ2 = L.NDP < 24 && (loop_force == 2 || L.NDP < 14 || (loop_force != 1 && (blocks >= 1536 || L.NDP < 16)));
   const int key = lanes_per_env * 100 + L.NDP;
   switch (key) {
 #define TDS_CASE(GG, NN) \
@@ -4175,8 +4222,8 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   do {                                                                                                          \
     e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 0, KIND>,                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                 \
-    if (e == hipSuccess)                                                                                        \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 1, KIND>,                        \
+    if (e == hipSuccess && NN >= 14)                                                                            \
+      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN >= 14 ? NN : 32), false, 1, KIND>,      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
     if (e == hipSuccess && NN < 24)                                                                             \
       e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 2, KIND>,        \

@@ -52,6 +52,9 @@ enum TdsOptKey {
   TDS_OPT_SHARD_CHUNK,        // steps per step-loop launch of the ring exchange (default 256; read when the ring is first used)
   TDS_OPT_RING_SIGNAL_LATE,   // experiment: 1 = the helper wavefront counts a step in at the top of its NEXT iteration
   TDS_OPT_ALT_BUILD,          // experiment slot k (1 .. TDS_ALT_SLOTS) of the library, where it was linked in (tds_kernels.h); f64 plain kernels
+  TDS_OPT_SHARD_PEER,         // ring exchange by PEER STORES (the step kernel writes its records into the other ranks' gathered rings, IPC-mapped): unset / 1 where it can be set up on every rank (else the RCCL all-gather), 0 never, 2 required (error instead of the fallback)
+  TDS_OPT_EXCHANGE_FIELDS,    // peer-store exchange: 0 / unset the whole [obs | reward | done] record travels, 1 only [reward | done]
+  TDS_OPT_SHARD_PEER_LOOPBACK,  // diagnostic: k extra "peers" mapped onto scratch rings of this rank's own GPU (the kernel-side cost of k peers, measurable on one GPU)
   TDS_OPT_COUNT
 };
 
@@ -103,6 +106,9 @@ inline const TdsOptRow *tds_opt_rows() {
       {"shard_chunk", false, "TDS_HIP_SHARD_CHUNK"},
       {"ring_signal_late", false, "TDS_HIP_RING_SIGNAL_LATE"},
       {"alt_build", false, "TDS_HIP_ALT_BUILD"},
+      {"shard_peer", false, "TDS_HIP_SHARD_PEER"},
+      {"exchange_fields", false, "TDS_HIP_EXCHANGE_FIELDS"},
+      {"shard_peer_loopback", false, "TDS_HIP_SHARD_PEER_LOOPBACK"},
   };
   return rows;
 }

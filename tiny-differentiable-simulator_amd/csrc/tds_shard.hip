@@ -22,6 +22,7 @@
 #include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <new>
 #include <vector>
@@ -120,6 +121,63 @@ __global__ void tds_ring_wait_kernel(const unsigned long long *progress, unsigne
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Peer-store exchange (round 5): the all-gather without a collective.  Every rank maps the other ranks' gathered rings and
+// flag arrays into its address space (hipIpcGetMemHandle / hipIpcOpenMemHandle, handles exchanged once over the
+// communicator); the step-loop launch stores each [obs | reward | done] record into its own block of the slot on EVERY
+// rank and raises the slot's flag on every rank when its last workgroup has stored it (tds_kernels.hip: put_obs,
+// peer_signal).  What is left for the streams are three one-wavefront kernels per LAUNCH (not per step), none of which
+// runs beside the launch it belongs to:
+//   credit   (step stream, in front of launch m) publishes "this rank has started launch m" on every rank and waits until
+//            every peer has started launch m - 1: the half of the ring launch m writes holds the records of launch m - 2,
+//            which are out of contract on a rank that has submitted launch m - 1 (tds_hip_shard_gathered_step: "inside the
+//            most recently submitted launch") — ranks may drift apart by one launch, never by a ring;
+//   arrived  (communication stream, behind launch m) waits until every slot of launch m carries every rank's flag: what
+//            tds_hip_shard_gathered / _flush wait for.  Nothing of the step stream waits for it.
+// All waits are bounded (option shard_wait_ms) and raise the same latch as the waits of the RCCL form.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool tds_wait_ge(const unsigned long long *p, unsigned long long target, unsigned *err,
+                                            long long t0, long long timeout_ticks, unsigned *host_latch) {
+  while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (host_latch) __hip_atomic_store(host_latch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(32);
+  }
+  return true;
+}
+
+// flags: [n_peers + 1] device table of flag arrays (the peers', then this rank's own); credit_off: index of credit[0]
+__global__ void tds_peer_credit_kernel(unsigned long long *const *flags, int n_peers, long long credit_off, int rank,
+                                       int world, unsigned long long seq, unsigned *err, long long timeout_ticks,
+                                       unsigned *host_latch) {
+  const int lane = threadIdx.x;
+  if (lane <= n_peers)
+    __hip_atomic_store(flags[lane] + credit_off + rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (seq > 1ull && lane < world && lane != rank) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    (void)tds_wait_ge(flags[n_peers] + credit_off + lane, seq - 1ull, err, t0, timeout_ticks, host_latch);
+  }
+}
+
+__global__ void tds_peer_arrived_kernel(const unsigned long long *flags, int n, unsigned long long seq, unsigned *err,
+                                        long long timeout_ticks, unsigned *host_latch) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (!tds_wait_ge(flags + i, seq, err, t0, timeout_ticks, host_latch)) return;
+}
+
+// set-up check: a token into slot `rank` of the test row of every peer's flag array (and this rank's own)
+__global__ void tds_peer_token_kernel(unsigned long long *const *flags, int n_peers, long long test_off, int rank,
+                                      unsigned long long token) {
+  const int lane = threadIdx.x;
+  if (lane <= n_peers)
+    __hip_atomic_store(flags[lane] + test_off + rank, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 
 struct tds_hip_shard {
@@ -178,6 +236,22 @@ struct tds_hip_shard {
   } rgraph[kRingGraphs];
   long long rgraph_clock = 0;
 
+  // ---- peer-store exchange (see the kernels above)
+  bool peer_mode = false;        // the ring exchange goes through peer stores (decided once, in ring_alloc, by ALL ranks together)
+  int n_peers = 0;               // ranks other than this one (+ loopback "peers": scratch rings of this rank's own)
+  int n_real_peers = 0;
+  unsigned long long *pflags = nullptr;  // [ring slots][world] arrival flags | credit[world] | test[world]  (uncached where offered)
+  unsigned int *parrive = nullptr;       // [ring slots] arrival counters of this rank's own launches
+  void *peer_ring_map[TDS_MAX_PEERS] = {};   // the peers' rgath / pflags as mapped here (hipIpcOpenMemHandle), peer order =
+  void *peer_flag_map[TDS_MAX_PEERS] = {};   //   rank order without this rank
+  bool peer_opened[TDS_MAX_PEERS] = {};      // (mapped through IPC: closed in ring_free; loopback rings are hipFree'd)
+  void *d_peer_tab = nullptr;    // device: [n_peers] ring bases | [n_peers + 1] flag arrays (own last)
+  bool reward_done_only = false;
+  int exchange_form = 0;         // what the most recent tds_hip_shard_step_many ran: TDS_EXCHANGE_*
+
+  size_t flag_count() const { return 2 * (size_t)chunk * world; }
+  size_t credit_off() const { return flag_count(); }
+  size_t test_off() const { return flag_count() + world; }
   size_t block_scalars() const { return (size_t)block * n_local * sim->obs_width(); }
   size_t slot_scalars() const { return (size_t)n_local * sim->obs_width(); }
   unsigned *wait_err() const { return (unsigned *)(progress + 2 * (size_t)chunk); }
@@ -314,6 +388,218 @@ int shard_mark_done(tds_hip_shard *sh, int slot) {
 // ---------------------------------------------------------------------------------------------------------------
 void ring_free(tds_hip_shard *sh);
 
+// bytes all-gathered over the communicator (ncclInt8): one record per rank
+struct PeerHello {
+  int ok;
+  int pad_;
+  hipIpcMemHandle_t ring, flags;
+};
+
+int comm_all_gather_bytes(tds_hip_shard *sh, const void *mine, void *all, size_t bytes) {
+  if (sh->world == 1 || !sh->comm) {
+    memcpy(all, mine, bytes);
+    return TDS_OK;
+  }
+  void *d_send = nullptr, *d_recv = nullptr;
+  TDS_HIP_TRY(hipMalloc(&d_send, bytes));
+  TDS_HIP_TRY(hipMalloc(&d_recv, bytes * sh->world));
+  int rc = TDS_OK;
+  hipError_t e = hipMemcpyAsync(d_send, mine, bytes, hipMemcpyHostToDevice, sh->comm_stream);
+  if (e == hipSuccess) {
+    const ncclResult_t r = rccl()->AllGather(d_send, d_recv, bytes, ncclInt8, sh->comm, sh->comm_stream);
+    if (r != ncclSuccess) {
+      snprintf(g_err, sizeof(g_err), "ncclAllGather (peer-store set-up) failed: %s", rccl()->GetErrorString(r));
+      rc = TDS_ERR_HIP;
+    } else {
+      sh->comm_warm = true;
+    }
+  }
+  if (e == hipSuccess && rc == TDS_OK) e = hipMemcpyAsync(all, d_recv, bytes * sh->world, hipMemcpyDeviceToHost, sh->comm_stream);
+  if (e == hipSuccess && rc == TDS_OK) e = hipStreamSynchronize(sh->comm_stream);
+  (void)hipFree(d_send);
+  (void)hipFree(d_recv);
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "peer-store set-up: %s", hipGetErrorString(e));
+    return TDS_ERR_HIP;
+  }
+  return rc;
+}
+
+void peer_unmap(tds_hip_shard *sh) {
+  for (int i = 0; i < TDS_MAX_PEERS; ++i) {
+    if (sh->peer_opened[i]) {
+      if (sh->peer_ring_map[i]) (void)hipIpcCloseMemHandle(sh->peer_ring_map[i]);
+      if (sh->peer_flag_map[i]) (void)hipIpcCloseMemHandle(sh->peer_flag_map[i]);
+    } else {  // (loopback "peers": scratch allocations of this rank's own)
+      if (sh->peer_ring_map[i]) (void)hipFree(sh->peer_ring_map[i]);
+      if (sh->peer_flag_map[i]) (void)hipFree(sh->peer_flag_map[i]);
+    }
+    sh->peer_ring_map[i] = sh->peer_flag_map[i] = nullptr;
+    sh->peer_opened[i] = false;
+  }
+  sh->n_peers = sh->n_real_peers = 0;
+}
+
+// Decide — all ranks together — whether the ring exchange goes through peer stores, and set it up: flag / counter arrays,
+// the peers' rings and flag arrays mapped through IPC, a token round trip over the mapped memory as a check that what was
+// mapped is what the peers read.  Any failure on any rank (no IPC between the devices, a container without dmabuf IPC, a
+// token that never arrives) leaves EVERY rank on the RCCL all-gather (option shard_peer = 2: an error instead).
+int peer_setup(tds_hip_shard *sh, size_t ring_slots, size_t slot_b) {
+  tds_hip_sim *s = sh->sim;
+  const long long want = s->opt.get(TDS_OPT_SHARD_PEER, 1);
+  sh->peer_mode = false;
+  sh->reward_done_only = s->opt.get(TDS_OPT_EXCHANGE_FIELDS, 0) == 1;
+  const int loopback = (int)s->opt.get(TDS_OPT_SHARD_PEER_LOOPBACK, 0);
+  const bool possible = want != 0 && sh->inplace && !sh->one_process_group && sh->world - 1 + (loopback > 0 ? loopback : 0) <= TDS_MAX_PEERS &&
+                        (sh->world == 1 || sh->comm != nullptr);
+  // own arrays first (every rank allocates them: the set-up below is a collective either way)
+  const size_t n_flags = sh->flag_count() + 2 * (size_t)sh->world;
+  {
+    void *pf = nullptr;
+    // fine-grained / uncached device memory where the runtime offers it: a flag written by another GPU must never be served
+    // from this GPU's L2
+    if (hipExtMallocWithFlags(&pf, n_flags * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      pf = nullptr;
+      TDS_HIP_TRY(hipMalloc(&pf, n_flags * sizeof(unsigned long long)));
+    }
+    sh->pflags = (unsigned long long *)pf;
+    TDS_HIP_TRY(hipMemset(sh->pflags, 0, n_flags * sizeof(unsigned long long)));
+    TDS_HIP_TRY(hipMalloc((void **)&sh->parrive, ring_slots * sizeof(unsigned int)));
+    TDS_HIP_TRY(hipMemset(sh->parrive, 0, ring_slots * sizeof(unsigned int)));
+    TDS_HIP_TRY(hipDeviceSynchronize());
+  }
+  if (sh->world > 1 && !sh->comm) return TDS_OK;  // (no communicator, several ranks: nothing collective can be set up)
+  bool ok = possible;
+  char why[160] = "";
+  std::vector<PeerHello> all((size_t)sh->world);
+  PeerHello mine;
+  memset(&mine, 0, sizeof(mine));
+  if (ok && sh->world > 1) {
+    hipError_t e = hipIpcGetMemHandle(&mine.ring, sh->rgath);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&mine.flags, sh->pflags);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      ok = false;
+      snprintf(why, sizeof(why), "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    }
+  }
+  mine.ok = ok ? 1 : 0;
+  if (sh->world > 1) {  // (collective: every rank of the communicator is here, whatever its own verdict)
+    const int rc = comm_all_gather_bytes(sh, &mine, all.data(), sizeof(PeerHello));
+    if (rc != TDS_OK) return rc;
+    for (int r = 0; r < sh->world; ++r) ok = ok && all[(size_t)r].ok != 0;
+  }
+  // map the peers (rank order without this rank)
+  int np = 0;
+  if (ok) {
+    for (int r = 0; r < sh->world && ok; ++r) {
+      if (r == sh->rank) continue;
+      void *pr = nullptr, *pf = nullptr;
+      hipError_t e = hipIpcOpenMemHandle(&pr, all[(size_t)r].ring, hipIpcMemLazyEnablePeerAccess);
+      if (e == hipSuccess) e = hipIpcOpenMemHandle(&pf, all[(size_t)r].flags, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (pr) (void)hipIpcCloseMemHandle(pr);
+        ok = false;
+        snprintf(why, sizeof(why), "hipIpcOpenMemHandle (rank %d): %s", r, hipGetErrorString(e));
+        break;
+      }
+      sh->peer_ring_map[np] = pr;
+      sh->peer_flag_map[np] = pf;
+      sh->peer_opened[np] = true;
+      ++np;
+    }
+  }
+  sh->n_real_peers = ok ? np : 0;
+  for (int k = 0; ok && k < loopback; ++k) {  // diagnostic: scratch rings of this rank's own as further "peers"
+    void *pr = nullptr, *pf = nullptr;
+    hipError_t e = hipMalloc(&pr, ring_slots * slot_b * sh->world);
+    if (e == hipSuccess) e = hipMalloc(&pf, n_flags * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(pf, 0, n_flags * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      if (pr) (void)hipFree(pr);
+      if (pf) (void)hipFree(pf);
+      ok = false;
+      snprintf(why, sizeof(why), "loopback ring: %s", hipGetErrorString(e));
+      break;
+    }
+    sh->peer_ring_map[np] = pr;
+    sh->peer_flag_map[np] = pf;
+    sh->peer_opened[np] = false;
+    ++np;
+  }
+  sh->n_peers = ok ? np : 0;
+  // device table: [np] ring bases | [np + 1] flag arrays, this rank's own last
+  if (ok) {
+    std::vector<void *> tab((size_t)(2 * np + 1));
+    for (int i = 0; i < np; ++i) {
+      tab[(size_t)i] = sh->peer_ring_map[i];
+      tab[(size_t)(np + i)] = sh->peer_flag_map[i];
+    }
+    tab[(size_t)(2 * np)] = sh->pflags;
+    hipError_t e = hipMalloc(&sh->d_peer_tab, tab.size() * sizeof(void *));
+    if (e == hipSuccess) e = hipMemcpy(sh->d_peer_tab, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      ok = false;
+      snprintf(why, sizeof(why), "peer table: %s", hipGetErrorString(e));
+    }
+  }
+  // token round trip: every rank writes (token base + its rank) into its slot of the test row on every rank, then waits
+  // for the tokens of all ranks in its own test row
+  if (ok && sh->world > 1) {
+    const unsigned long long token = 0x7D5000000000ull + (unsigned long long)sh->rank + 1ull;
+    unsigned long long *const *ftab = (unsigned long long *const *)((void **)sh->d_peer_tab + np);
+    hipLaunchKernelGGL(tds_peer_token_kernel, dim3(1), dim3(64), 0, sh->comm_stream, ftab, np, (long long)sh->test_off(), sh->rank, token);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(sh->comm_stream);
+    std::vector<unsigned long long> got((size_t)sh->world);
+    const long long wait_ms = s->opt.get(TDS_OPT_SHARD_WAIT_MS, 2000);
+    bool seen = false;
+    for (long long t = 0; e == hipSuccess && t < wait_ms + 1000 && !seen; ++t) {  // (the peers may still be mapping: their set-up time counts)
+      e = hipMemcpy(got.data(), sh->pflags + sh->test_off(), got.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      seen = true;
+      for (int r = 0; r < sh->world; ++r) seen = seen && got[(size_t)r] == 0x7D5000000000ull + (unsigned long long)r + 1ull;
+      if (!seen) {
+        struct timespec ts = {0, 1000000};
+        nanosleep(&ts, nullptr);
+      }
+    }
+    if (e != hipSuccess || !seen) {
+      (void)hipGetLastError();
+      ok = false;
+      snprintf(why, sizeof(why), "token round trip over the mapped memory failed%s%s", e != hipSuccess ? ": " : "",
+               e != hipSuccess ? hipGetErrorString(e) : "");
+    }
+  }
+  // the verdict, all ranks together (a rank that failed late must take the others with it)
+  if (sh->world > 1) {
+    PeerHello v;
+    memset(&v, 0, sizeof(v));
+    v.ok = ok ? 1 : 0;
+    const int rc = comm_all_gather_bytes(sh, &v, all.data(), sizeof(PeerHello));
+    if (rc != TDS_OK) return rc;
+    for (int r = 0; r < sh->world; ++r) ok = ok && all[(size_t)r].ok != 0;
+  }
+  if (!ok) {
+    peer_unmap(sh);
+    if (sh->d_peer_tab) (void)hipFree(sh->d_peer_tab);
+    sh->d_peer_tab = nullptr;
+    if (want == 2) {
+      snprintf(g_err, sizeof(g_err), "option shard_peer = 2: the peer-store exchange could not be set up on every rank (%s)",
+               why[0] ? why : (possible ? "another rank failed" : "not available for this shard"));
+      return TDS_ERR_UNSUPPORTED;
+    }
+    if (possible && why[0])
+      fprintf(stderr, "tds_hip_shard (rank %d): peer-store exchange not available (%s) — RCCL all-gather instead\n", sh->rank, why);
+    return TDS_OK;
+  }
+  sh->peer_mode = true;
+  return TDS_OK;
+}
+
 int ring_alloc_impl(tds_hip_shard *sh) {
   tds_hip_sim *s = sh->sim;
   const size_t slot_b = sh->slot_scalars() * sh->wire_bytes;
@@ -368,6 +654,12 @@ int ring_alloc_impl(tds_hip_shard *sh) {
     if (rccl()->CommRegister(sh->comm, sh->rgath, ring_slots * slot_b * sh->world, &sh->reg_handle) != ncclSuccess)
       sh->reg_handle = nullptr;  // (not fatal: the collective works on unregistered buffers)
   }
+  // peer-store exchange: decided here, once, by all ranks together (a collective when the shard has a communicator)
+  {
+    const int rc = peer_setup(sh, ring_slots, slot_b);
+    if (rc != TDS_OK) return rc;
+  }
+  s->shard_ring_shaped = true;  // (tds_hip_set_option refuses the options read above from now on)
   // The memsets above are commands of the NULL stream; the communication stream is a non-blocking stream, which the NULL
   // stream does not order: behind a long launch of the caller's they are still pending when the first wait of the
   // exchange starts polling — a recycled allocation then shows it the counters of an earlier ring and it sends its slot
@@ -395,6 +687,14 @@ void ring_free(tds_hip_shard *sh) {
     }
   if (sh->reg_handle && sh->comm && rccl() && rccl()->CommDeregister) (void)rccl()->CommDeregister(sh->comm, sh->reg_handle);
   sh->reg_handle = nullptr;
+  peer_unmap(sh);
+  if (sh->d_peer_tab) (void)hipFree(sh->d_peer_tab);
+  if (sh->pflags) (void)hipFree(sh->pflags);
+  if (sh->parrive) (void)hipFree(sh->parrive);
+  sh->d_peer_tab = nullptr;
+  sh->pflags = nullptr;
+  sh->parrive = nullptr;
+  sh->peer_mode = false;
   if (sh->rwire) (void)hipFree(sh->rwire);
   if (sh->rgath) (void)hipFree(sh->rgath);
   if (sh->ry) (void)hipFree(sh->ry);
@@ -429,7 +729,9 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
   const size_t slot_b = sh->slot_scalars() * sh->wire_bytes;
   // (events recorded inside a capture belong to the capture: it has its own set)
   const hipEvent_t e_kernel = capturing ? sh->cap_kernel : sh->ev_kernel[h], e_comm = capturing ? sh->cap_comm : sh->ev_comm[h];
-  if (!capturing && sh->comm_pending[h]) {  // the exchanges of the launch two back read this half of the ring
+  // (peer-store exchange: nothing of the communication stream reads this rank's ring — the credit kernel in front of the
+  //  launch is what keeps the ranks within a ring half of each other)
+  if (!capturing && sh->comm_pending[h] && !sh->peer_mode) {  // the exchanges of the launch two back read this half of the ring
     TDS_HIP_TRY(hipStreamWaitEvent(s->stream, sh->ev_comm[h], 0));
     sh->comm_pending[h] = false;
   }
@@ -465,6 +767,43 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
   // and cost a kernel each (measured on one rank: 15.6 against 13.8 us per step, profiles/
   // r04_one_rank_exchange_with_table.txt): the launch then runs exactly as at N = 1 — no progress counter, streaming
   // stores — and the communication stream waits for its completion ONCE and sends the launch's slots as one RCCL group.
+  if (sh->peer_mode && !capturing) {
+    // PEER-STORE EXCHANGE: the launch is the N = 1 launch (two-wavefront build, no progress counter polled by anybody) whose
+    // recorder stores every record on every rank; see the kernels at the top of the file for the three small kernels around it
+    const unsigned long long seq = (unsigned long long)sh->chunks + 1ull;  // the same on every rank: all make the same calls
+    const long long timeout_ticks = s->opt.get(TDS_OPT_SHARD_WAIT_MS, 2000) * 100000ll;  // 100 MHz
+    const int np = sh->n_peers;
+    unsigned long long *const *ftab = (unsigned long long *const *)((void **)sh->d_peer_tab + np);
+    if (sh->n_real_peers > 0) {
+      hipLaunchKernelGGL(tds_peer_credit_kernel, dim3(1), dim3(64), 0, s->stream, ftab, np, (long long)sh->credit_off(), sh->rank,
+                         sh->world, seq, sh->wait_err(), timeout_ticks, sh->host_latch);
+      if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "peer-store exchange: credit kernel launch");
+    }
+    TdsPeerLaunch pl;
+    pl.rings = (const void *const *)sh->d_peer_tab;
+    pl.flags = ftab;
+    pl.arrive = sh->parrive + ck.slot0;
+    pl.ring_off = (long long)(((size_t)ck.slot0 * sh->world + sh->rank) * slot_b);
+    pl.epoch = seq;
+    pl.n_peers = np;
+    pl.flag_off = ck.slot0 * sh->world + sh->rank;
+    pl.flag_stride = sh->world;
+    pl.reward_done_only = sh->reward_done_only ? 1 : 0;
+    r.progress = nullptr;
+    s->peer_launch = &pl;
+    const int rc = tds_hip_step_many_rings(s, actions_dev, pool, ck.act_first, ck.steps, &r);
+    s->peer_launch = nullptr;
+    if (rc != TDS_OK) return rc;
+    TDS_HIP_TRY(hipEventRecord(e_kernel, s->stream));
+    TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, e_kernel, 0));
+    hipLaunchKernelGGL(tds_peer_arrived_kernel, dim3(1), dim3(64), 0, sh->comm_stream,
+                       (const unsigned long long *)(sh->pflags + (size_t)ck.slot0 * sh->world), ck.steps * sh->world, seq,
+                       sh->wait_err(), timeout_ticks, sh->host_latch);
+    if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "peer-store exchange: arrival kernel launch");
+    TDS_HIP_TRY(hipEventRecord(e_comm, sh->comm_stream));
+    sh->exchange_form = TDS_EXCHANGE_PEER_STORES;
+    return TDS_OK;
+  }
   const int n_blocks = tds_hip_step_many_rings_blocks(s);
   const bool after_launch = s->opt.get(TDS_OPT_EXCHANGE_W2, 1) != 0 && s->opt.get(TDS_OPT_LOOP_W2, 1) != 0 &&
                             s->w2_max_blocks > 0 && n_blocks <= s->w2_max_blocks && s->lds_w2.NDP <= 16;
@@ -495,8 +834,10 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
                                  (size_t)ck.steps * slot_b, hipMemcpyDeviceToDevice, sh->comm_stream));
     }
     TDS_HIP_TRY(hipEventRecord(e_comm, sh->comm_stream));
+    sh->exchange_form = TDS_EXCHANGE_RCCL_AFTER_LAUNCH;
     return TDS_OK;
   }
+  sh->exchange_form = TDS_EXCHANGE_RCCL_PER_SLOT;
   const long long timeout_ticks = s->opt.get(TDS_OPT_SHARD_WAIT_MS, 2000) * 100000ll;  // 100 MHz
   const bool nothing_to_move = sh->inplace && sh->world == 1 && !sh->comm;
   for (int k = 0; k < ck.steps; ++k) {
@@ -639,7 +980,8 @@ int ring_many(tds_hip_shard *sh, const void *actions_dev, int pool, int first, i
   // ONE hipGraph per launch (TDS_HIP_SHARD_GRAPH=1) the same nodes replay ~10 us per step SLOWER on ROCm 7 — measured,
   // profiles/r03_ring_exchange_forms.txt: a chain of 128 dependent kernel / copy nodes pays a node-to-node latency the
   // stream does not.
-  const bool want_graph = s->opt.get(TDS_OPT_SHARD_GRAPH, 0) == 1 && !s->opt.flag(TDS_OPT_SHARD_NO_GRAPH);
+  // (peer-store exchange: a launch carries its sequence number — three small kernels per launch need no graph either)
+  const bool want_graph = s->opt.get(TDS_OPT_SHARD_GRAPH, 0) == 1 && !s->opt.flag(TDS_OPT_SHARD_NO_GRAPH) && !sh->peer_mode;
   for (int i = 0; i < nc; ++i) {
     const TdsRingChunk &ck = plan[i];
     tds_hip_shard::RingGraph *g = want_graph ? ring_graph_find(sh, actions_dev, pool, ck) : nullptr;
@@ -779,6 +1121,9 @@ int tds_hip_shard_local_envs(const tds_hip_shard_t *sh) { return sh ? sh->n_loca
 int tds_hip_shard_first_env(const tds_hip_shard_t *sh) { return sh ? sh->rank * sh->n_local : 0; }
 int tds_hip_shard_wire_bytes(const tds_hip_shard_t *sh) { return sh ? sh->wire_bytes : 0; }
 
+int tds_hip_shard_exchange_form(const tds_hip_shard_t *sh) { return sh ? sh->exchange_form : 0; }
+int tds_hip_shard_peer_count(const tds_hip_shard_t *sh) { return (sh && sh->peer_mode) ? sh->n_peers : -1; }
+
 int tds_hip_shard_set_block(tds_hip_shard_t *sh, int steps_per_exchange) {
   if (!sh) return fail(TDS_ERR_INVALID_ARG, "shard is NULL");
   if (steps_per_exchange < 1 || steps_per_exchange > 1024) return fail(TDS_ERR_INVALID_ARG, "steps_per_exchange must be in 1..1024");
@@ -802,6 +1147,7 @@ int tds_hip_shard_step(tds_hip_shard_t *sh, const void *actions_dev, int substep
   if (sh->steps % sh->block != 0) return TDS_OK;  // the block is still filling
   rc = shard_submit(sh, slot);
   if (rc != TDS_OK) return rc;
+  sh->exchange_form = TDS_EXCHANGE_RCCL_PER_STEP;
   return shard_mark_done(sh, slot);
 }
 
@@ -976,6 +1322,7 @@ static int shard_many(tds_hip_shard_t *sh, const void *actions_dev, int action_b
         sh->pending[i] = false;
       }
     TDS_HIP_TRY(hipGraphLaunch(sh->graph_exec, s->stream));
+    sh->exchange_form = TDS_EXCHANGE_RCCL_PER_STEP;
     sh->steps += n_steps;
     sh->last_slot = sh->graph_last_slot;
     // consumers of tds_hip_shard_gathered wait on ev_done[last_slot]: re-record it behind the graph

@@ -142,7 +142,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_shard_destroy", "tds_hip_shard_sim", "tds_hip_shard_rank", "tds_hip_shard_world",
     "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes", "tds_hip_shard_set_block",
     "tds_hip_shard_step", "tds_hip_shard_step_many", "tds_hip_shard_step_many_prepare", "tds_hip_shard_group_step", "tds_hip_shard_flush", "tds_hip_shard_gathered", "tds_hip_shard_gathered_step",
-    "tds_hip_shard_ring_plan", "tds_hip_shard_gathered_offset",
+    "tds_hip_shard_ring_plan", "tds_hip_shard_gathered_offset", "tds_hip_shard_exchange_form", "tds_hip_shard_peer_count",
     "tds_rb_last_error", "tds_rb_create", "tds_rb_destroy", "tds_rb_set_stream", "tds_rb_state_device",
     "tds_rb_set_state", "tds_rb_get_state", "tds_rb_step",
 ]
@@ -700,6 +700,18 @@ class HipShard:
 
     def flush(self):
         _check(lib().tds_hip_shard_flush(self.h))
+
+    EXCHANGE_FORMS = {0: "none", 1: "rccl_per_step", 2: "rccl_group_after_launch", 3: "rccl_per_slot", 4: "peer_stores"}
+
+    def exchange_form(self) -> str:
+        """which exchange the most recent step / step_many ran (tds_hip_shard_exchange_form)"""
+        lib().tds_hip_shard_exchange_form.argtypes = [C.c_void_p]
+        return self.EXCHANGE_FORMS.get(int(lib().tds_hip_shard_exchange_form(self.h)), "?")
+
+    def peer_count(self) -> int:
+        """ranks this shard stores its records to under the peer-store exchange; -1: not in use"""
+        lib().tds_hip_shard_peer_count.argtypes = [C.c_void_p]
+        return int(lib().tds_hip_shard_peer_count(self.h))
 
     def gathered(self):
         import torch
