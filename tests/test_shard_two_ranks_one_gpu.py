@@ -102,6 +102,8 @@ RCCL = {"TDS_HIP_SHARD_PEER": "0"}  # the forms of the exchange that go through 
     ("many", "ant", 75, {"TDS_HIP_SHARD_PEER": "2"}, "peer_stores"),
     ("many", "ant", 75, {}, "peer_stores"),
     ("many", "ant", 75, {"TDS_HIP_EXCHANGE_FIELDS": "1"}, "peer_stores"),   # only [reward | done] travel to the peer
+    ("many", "ant", 75, {"_n_local": "201"}, "peer_stores"),                # a ragged last wavefront: lane-per-component stores instead of whole rows
+    ("many", "ant", 75, {"_n_local": "201", "TDS_HIP_EXCHANGE_FIELDS": "1"}, "peer_stores"),
     ("many", "pendulum5", 30, {}, "peer_stores"),                           # a world without contacts (one-wave step-loop build)
     ("many", "ant", 75, dict(RCCL), "rccl_group_after_launch"),             # ring exchange, two-wavefront build, slots sent behind the launch as one group
     ("many", "ant", 75, dict(RCCL, TDS_HIP_EXCHANGE_W2="0"), "rccl_per_slot"),  # ... the one-wave build: per-slot counters, a slot sent while the launch runs
@@ -117,7 +119,8 @@ def test_two_ranks_on_one_gpu(mode, name, steps, env, want_form, built, stub_lib
 
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    world, n_local = 2, 200
+    world, n_local = 2, int(env.get("_n_local", 200))
+    env = {k: v for k, v in env.items() if not k.startswith("_")}
     ident = ("/tds_stub_%d_%s_%d" % (os.getpid(), name, steps)).encode().ljust(128, b"\0")
     e = dict(os.environ)
     e.update(env)

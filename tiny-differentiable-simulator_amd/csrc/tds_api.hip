@@ -222,6 +222,12 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
       ctl.peer_flag_off = pl.flag_off;
       ctl.peer_flag_stride = pl.flag_stride;
       if (pl.reward_done_only) ctl.ring_flags |= TDS_RING_PEER_REWARD_DONE;
+      {  // a wavefront's records as one row of 8-byte units (put_obs_wide): every stride a multiple of 8 bytes
+        const size_t wb = r.obs_f32 ? 4 : s->elem, w = (size_t)s->obs_width(), epw = (size_t)(64 / s->lanes);
+        if ((epw * w * wb) % 8 == 0 && ((size_t)ctl.obs_envs * w * wb) % 8 == 0 && ((size_t)(uintptr_t)ctl.obs_ring) % 8 == 0 &&
+            (size_t)ctl.peer_off % 8 == 0 && (size_t)n % epw == 0 && pl.wide_ok)
+          ctl.ring_flags |= TDS_RING_WIDE;
+      }
       // this rank's own block: write-through stores, visible device-wide when the slot's flag is raised (a consumer may read a
       // slot before the launch has completed); counted in at the top of the helper wavefront's NEXT iteration, where it
       // waits for the kinematics anyway — the acknowledgements of stores that crossed xGMI have had a whole step by then

@@ -20,6 +20,7 @@ struct TdsPeerLaunch {
   unsigned long long epoch;          // the launch's sequence number
   int n_peers, flag_off, flag_stride;
   int reward_done_only;              // option exchange_fields = 1
+  int wide_ok;                       // the rings table is padded to a multiple of four entries (put_obs_wide may read past n_peers)
 };
 
 struct tds_hip_sim {

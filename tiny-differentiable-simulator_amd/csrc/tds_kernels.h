@@ -108,6 +108,10 @@ struct TdsStepCtl {
 // Ant environment on a float wire — for runs whose policy lives on the device, SURVEY 8f N2: "removes the obs gather except
 // for logging"); this rank's own block still receives the whole record
 #define TDS_RING_PEER_REWARD_DONE 8
+// peer-store exchange: every stride of the obs ring (record row of a wavefront, slot, rank block, peer offset) is a multiple
+// of 8 bytes — a wavefront's records may leave as one row of 8-byte units (tds_kernels.hip: put_obs_wide); the peer table is
+// padded to a multiple of four entries
+#define TDS_RING_WIDE 16
 // upper bound of the peers of a rank (ranks of one node - 1)
 #define TDS_MAX_PEERS 15
 

@@ -45,6 +45,10 @@
 #ifndef TDS_PARK_W2
 #define TDS_PARK_W2 1
 #endif
+// scope of the peer-store exchange's stores into the other ranks' rings (experiments on one GPU may lower it)
+#ifndef TDS_PEER_SCOPE
+#define TDS_PEER_SCOPE __HIP_MEMORY_SCOPE_SYSTEM
+#endif
 #ifndef TDS_PARK_LOOP
 #define TDS_PARK_LOOP 0
 #endif
@@ -1183,6 +1187,44 @@ __device__ __forceinline__ double tds_gram_solve(double *sm, const TdsLds &L, in
 }
 
 
+// The by-value kernel arguments L (LDS layout) and ctl (what the launch does) as the STEP-LOOP builds read them.  Taken
+// from the function parameters, every field the loop body uses — and every boolean derived from one — is loop-invariant:
+// the compiler loads them all in front of the loop and keeps them live across it, ~60 kernel-argument dwords and ~40
+// uniform conditions (two SGPRs each) against 102 SGPRs, i.e. 190 - 230 SGPR spills into VGPR lanes, v_readlane reloads all
+// through an issue-bound loop body and, past 192, VGPRs lost to holding them (round 4's review, "What's weak" 3).  The step
+// loop therefore re-derives the kernel-argument segment pointer per iteration from a laundered copy — as it does for the
+// lane, the lane group and the model pointer — and reads the two structs THROUGH it (constant address space: scalar
+// loads, hit the scalar cache), so that a field lives from its first use in an iteration to its last.  The straight-line
+// builds keep the parameters.  (The mirror struct below has the kernel's parameter list, hence the segment's layout.)
+#define TDS_AS4 __attribute__((address_space(4)))
+template <typename T, typename TR>
+struct TdsKernArgs {
+  const DevModel<T> *mdl;
+  TdsLds L;
+  const TR *x_in;
+  TR *y_out;
+  const TR *actions;
+  TR *x_feedback;
+  TR *obs_out;
+  T *ovf;
+  long long *prof;
+  TdsStepCtl ctl;
+  int n_envs;
+};
+template <bool LOOP, typename S>
+struct TdsKaRef {
+  using type = const S &;
+  static __device__ __forceinline__ type get(const S &param, const TDS_AS4 char *) { return param; }
+};
+template <typename S>
+struct TdsKaRef<true, S> {
+  using type = const TDS_AS4 S &;
+  static __device__ __forceinline__ type get(const S &, const TDS_AS4 char *at) { return *(const TDS_AS4 S *)at; }
+};
+#ifndef TDS_KA_RELOAD
+#define TDS_KA_RELOAD 1
+#endif
+
 // per-group state machine of the in-kernel step loop
 #define TDS_MODE_IDLE 0
 #define TDS_MODE_RUN 1
@@ -1200,8 +1242,8 @@ __device__ __forceinline__ double tds_uniform01(unsigned long long seed, unsigne
 
 // q = reset_q + reset_noise * U(-1,1), qd = 0 into the LDS record of one environment; advances its reset counter
 // (ant_environment2.h:124-135)
-template <typename T, int G>
-__device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, const TdsStepCtl &ctl, int env, int lane,
+template <typename T, int G, typename CTL>
+__device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, const CTL &ctl, int env, int lane,
                                                 int nq, int nd) {
   const unsigned cnt = ctl.reset_count != nullptr ? ctl.reset_count[env] : 0u;
   for (int i = lane; i < nq; i += G) {
@@ -1279,11 +1321,14 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
 template <typename T, typename TR, int G, int NDP, bool PROF, int LP, int KIND, bool W2 = false>
 __global__ __launch_bounds__(W2 ? 128 : 64)
 __attribute__((amdgpu_waves_per_eu((LP == 2 || W2 || (LP == 0 && NDP < 24)) ? 2 : 1)))
-void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
+void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
                                                       const TR *x_in, TR *__restrict__ y_out,
                                                       const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
-                                                      TR *__restrict__ obs_out, T *ovf, long long *prof, TdsStepCtl ctl, int n_envs) {
+                                                      TR *__restrict__ obs_out, T *ovf, long long *prof, TdsStepCtl ctl_arg, int n_envs) {
   constexpr bool LOOP = LP != 0;
+  // (in front of the step loop the parameters themselves; inside it: see TdsKaRef)
+  const TdsLds &L = L_arg;
+  const TdsStepCtl &ctl = ctl_arg;
   static_assert(!W2 || ((LP == 0 || LP == 1) && KIND == 0 && NDP < 24),
                 "two-wavefront workgroups: plain kernels, straight-line or step-loop");
   // LDS slots behind the x record (xr[in_dim + ...]): 0 x_{t-1}, 1 done; two-wavefront layout: 2, 3 contact counts, 4 "y~ is
@@ -1335,15 +1380,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   int left = LOOP ? ctl.nsub : 1;  // normal steps still to run
   int sleft = 0;                   // settle steps still to run (mode SETTLE)
   // rollout mode: return accumulated so far, its step count, "done and not auto-reset" latch
-  const bool pol = LOOP && ctl.policy != nullptr;
-  // action replay (tds_hip_step_many as one launch): the block of step k + 1 is requested from HBM at the top of step k
-  const bool replay = LOOP && ctl.act_pool != nullptr && ctl.policy == nullptr;
-  // auto-reset inside a replayed step loop: a done environment takes its next pre-settled state from the reset pool
-  // (tds_api.hip: reset pool) and carries on with the following step — the lane groups of a launch stay in lock step
-  const bool pool_r = LOOP && ctl.pool != nullptr && ctl.policy == nullptr;
-  // per-step record rings (tds_hip_step_many_rings): every step of the launch packs and stores its records
-  const bool ring_o = LOOP && ctl.obs_ring != nullptr;  // wave-uniform (kernel arguments)
-  const bool ring_y = LOOP && ctl.y_ring != nullptr;
+  // (pol: rollout mode.  replay: action replay — tds_hip_step_many as one launch: the block of step k + 1 is requested from
+  //  HBM at the top of step k.  pool_r: auto-reset inside a replayed step loop: a done environment takes its next
+  //  pre-settled state from the reset pool (tds_api.hip: reset pool) and carries on with the following step — the lane
+  //  groups of a launch stay in lock step.  ring_o / ring_y: per-step record rings (tds_hip_step_many_rings): every step of
+  //  the launch packs and stores its records.  All of them are derived inside the loop body, per iteration.)
   T next_act = T(0);
   T ret = T(0);
   int cnt = 0;
@@ -1442,6 +1483,20 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   if constexpr (LOOP && NDP < 32) asm volatile("" : "+v"(lane_l), "+v"(grp_l), "+s"(mdl));
   if constexpr (LOOP && NDP >= 32) asm volatile("" : "+s"(mdl));
   const int lane = lane_l, grp = grp_l;
+  // ---- the kernel arguments of this iteration (step-loop builds: read through a laundered segment pointer, see TdsKaRef)
+  constexpr bool KA = LOOP && TDS_KA_RELOAD != 0;
+  const TDS_AS4 char *ka_seg = (const TDS_AS4 char *)__builtin_amdgcn_kernarg_segment_ptr();
+  if constexpr (KA) asm volatile("" : "+s"(ka_seg));
+  using TdsKA = TdsKernArgs<T, TR>;
+  typename TdsKaRef<KA, TdsLds>::type L = TdsKaRef<KA, TdsLds>::get(L_arg, ka_seg + __builtin_offsetof(TdsKA, L));
+  typename TdsKaRef<KA, TdsStepCtl>::type ctl = TdsKaRef<KA, TdsStepCtl>::get(ctl_arg, ka_seg + __builtin_offsetof(TdsKA, ctl));
+  // (the launch-wide conditions, from THIS iteration's arguments — shadowing the prologue's)
+  const int nset = (LOOP && ctl.reset_mode != TDS_RESET_NONE) ? ctl.settle_steps : 0;
+  const bool pol = LOOP && ctl.policy != nullptr;
+  const bool replay = LOOP && ctl.act_pool != nullptr && ctl.policy == nullptr;
+  const bool pool_r = LOOP && ctl.pool != nullptr && ctl.policy == nullptr;
+  const bool ring_o = LOOP && ctl.obs_ring != nullptr;  // wave-uniform (kernel arguments)
+  const bool ring_y = LOOP && ctl.y_ring != nullptr;
   const int env = blockIdx.x * EPW + grp;
   const bool valid = env < n_envs;
   T *const E = sm + grp * L.stride;
@@ -1734,10 +1789,76 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
           for (int pr = 0; pr < np; ++pr) {
             char *const pb = (char *)ctl.peer_ring[pr] + ctl.peer_off;
             if (ctl.ring_flags & TDS_RING_OBS_F32)
-              __hip_atomic_store((float *)pb + (at + i), (float)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store((float *)pb + (at + i), (float)v, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
             else
-              __hip_atomic_store((TR *)pb + (at + i), (TR)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store((TR *)pb + (at + i), (TR)v, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
           }
+        }
+      }
+    }
+  };
+  // Peer-store exchange, the whole WAVEFRONT'S records as one burst (TDS_RING_WIDE: every stride of the ring is a multiple
+  // of 8 bytes).  The EPW environments of a wavefront own consecutive records of a slot: EPW x (nq + nd + 2) scalars in a
+  // row (Ant, float wire: 480 bytes).  Lane-per-component stores cut that row into 2 EPW pieces of 64 / 56 bytes per
+  // destination; here every lane takes 8 bytes of the row — read from the environments' LDS records, converted once — and
+  // the row goes out with ONE 8-byte-per-lane store instruction per destination (two on a double wire), whole and in order:
+  // what a write-through store into another GPU's memory wants to look like on the fabric.  Destinations: this rank's own
+  // block (device scope), then every peer's (system scope), the table's pointers fetched four at a time.
+  auto put_obs_wide = [&](int slot) {
+    const int w = nq + nd + 2;
+    const int wl = threadIdx.x & 63;
+    const size_t row0 = ((size_t)slot * ctl.obs_envs + (size_t)blockIdx.x * EPW) * (size_t)w;  // first scalar of the wavefront's row
+    const bool f32w = (ctl.ring_flags & TDS_RING_OBS_F32) != 0 || sizeof(TR) == 4;
+    const bool rd_only = (ctl.ring_flags & TDS_RING_PEER_REWARD_DONE) != 0;
+    const int per_unit = f32w ? 2 : 1;                 // scalars per 8-byte unit
+    const int n_units = (EPW * w) / per_unit;
+    const int np = ctl.n_peers;
+    const unsigned long long *const *tab = (const unsigned long long *const *)ctl.peer_ring;
+    for (int u0 = 0; u0 < n_units; u0 += 64) {  // (one pass on a float wire up to 128 scalars per wavefront)
+      const int u = u0 + wl;
+      const bool on = u < n_units;
+      unsigned long long bits = 0ull;
+      bool tail = true;  // this unit holds only [reward | done] columns
+      {
+        unsigned lo = 0u, hi = 0u;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (c < per_unit) {
+            int f = on ? u * per_unit + c : 0;
+            int e = 0;
+#pragma unroll
+            for (int k = 1; k < EPW; ++k) e += f >= k * w ? 1 : 0;
+            const int i = f - e * w;
+            const int src = i < nq + nd ? i : (i == nq + nd ? in_dim + RW_SLOT : in_dim + 1);
+            const T v = i < 2 ? T(0) : sm[e * L.stride + L.xrec + src];
+            tail = tail && i >= nq + nd;
+            if (f32w) {
+              const unsigned b = (unsigned)__float_as_int((float)v);
+              if (c == 0) lo = b; else hi = b;
+            } else {
+              const double dv = (double)v;
+              lo = (unsigned)__double2loint(dv);
+              hi = (unsigned)__double2hiint(dv);
+            }
+          }
+        }
+        bits = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+      }
+      const size_t unit_at = row0 / per_unit + (size_t)u;  // (row0 is a multiple of per_unit: TDS_RING_WIDE)
+      if (on) __hip_atomic_store((unsigned long long *)ctl.obs_ring + unit_at, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool to_peers = on && (!rd_only || tail);
+      for (int p0 = 0; p0 < np; p0 += 4) {  // (the table is padded to a multiple of four entries)
+        const unsigned long long *const b0 = tab[p0], *const b1 = tab[p0 + 1], *const b2 = tab[p0 + 2], *const b3 = tab[p0 + 3];
+        const size_t po = (size_t)ctl.peer_off / 8 + unit_at;
+#ifdef TDS_X_PEER_NOSTORE  // (experiment: everything but the peers' stores themselves)
+        if (to_peers && po == ~(size_t)0) {
+#else
+        if (to_peers) {
+#endif
+          __hip_atomic_store((unsigned long long *)b0 + po, bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
+          if (p0 + 1 < np) __hip_atomic_store((unsigned long long *)b1 + po, bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
+          if (p0 + 2 < np) __hip_atomic_store((unsigned long long *)b2 + po, bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
+          if (p0 + 3 < np) __hip_atomic_store((unsigned long long *)b3 + po, bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
         }
       }
     }
@@ -1745,10 +1866,17 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
   // the end-of-step records of the PREVIOUS step, from the LDS record (whose state part this step has not touched yet)
   auto flush_prev_records = [&]() {
     if constexpr (DEFER) {
-      if ((ring_o || ring_y) && tds_iter > 0 && valid && mode == TDS_MODE_RUN && xr[in_dim + OUT_SLOT] == T(0)) {
-        if (ring_y)
+      if ((ring_o || ring_y) && tds_iter > 0) {  // wave-uniform
+        const bool mine = valid && mode == TDS_MODE_RUN && xr[in_dim + OUT_SLOT] == T(0);
+        if (ring_y && mine)
           put_y_state((TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter - 1) % ctl.y_slots) * ctl.ring_envs + env) * ystr, ystr);
-        if (ring_o) put_obs((ctl.obs_first + tds_iter - 1) % ctl.obs_slots);
+        if (ring_o) {
+          // (peer-store exchange: the wavefront's records as one burst where all of its environments store this step)
+          if (ctl.peer_arrive != nullptr && (ctl.ring_flags & TDS_RING_WIDE) != 0 && __all(mine))
+            put_obs_wide((ctl.obs_first + tds_iter - 1) % ctl.obs_slots);
+          else if (mine)
+            put_obs((ctl.obs_first + tds_iter - 1) % ctl.obs_slots);
+        }
       }
     }
   };
@@ -4014,7 +4142,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L,
     // ---- per-step observation record (ring): [q | qd] with obs[0] = obs[1] = 0 (ars_vectorized_environment.h:283-288) of
     //      the state the NEXT step starts from — after an auto-reset through the pool that is the fresh environment,
     //      while reward / done (written above) describe the step that ended (ars_vectorized_environment.h:262-277)
-    if (ring_o && ring_now) put_obs((ctl.obs_first + tds_iter) % ctl.obs_slots);
+    if (ring_o) {
+      if (ctl.peer_arrive != nullptr && (ctl.ring_flags & TDS_RING_WIDE) != 0 && __all(ring_now))
+        put_obs_wide((ctl.obs_first + tds_iter) % ctl.obs_slots);
+      else if (ring_now)
+        put_obs((ctl.obs_first + tds_iter) % ctl.obs_slots);
+    }
     // (peer-store exchange: EVERY step of the launch is counted in — the last one here, by the wavefront that has just stored
     //  it; kernel completion would tell this rank, not the peers)
     if (ring_o && ctl.peer_arrive != nullptr && __any(last_run)) peer_signal((ctl.obs_first + tds_iter) % ctl.obs_slots);

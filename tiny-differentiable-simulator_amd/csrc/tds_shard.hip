@@ -531,14 +531,14 @@ int peer_setup(tds_hip_shard *sh, size_t ring_slots, size_t slot_b) {
     ++np;
   }
   sh->n_peers = ok ? np : 0;
-  // device table: [np] ring bases | [np + 1] flag arrays, this rank's own last
+  // device table: [np4] ring bases (padded to a multiple of four entries: the wide store fetches them four at a time) |
+  // [np + 1] flag arrays, this rank's own last
+  const int np4 = (np + 3) / 4 * 4;
   if (ok) {
-    std::vector<void *> tab((size_t)(2 * np + 1));
-    for (int i = 0; i < np; ++i) {
-      tab[(size_t)i] = sh->peer_ring_map[i];
-      tab[(size_t)(np + i)] = sh->peer_flag_map[i];
-    }
-    tab[(size_t)(2 * np)] = sh->pflags;
+    std::vector<void *> tab((size_t)(np4 + np + 1));
+    for (int i = 0; i < np4; ++i) tab[(size_t)i] = np > 0 ? sh->peer_ring_map[i < np ? i : np - 1] : nullptr;
+    for (int i = 0; i < np; ++i) tab[(size_t)(np4 + i)] = sh->peer_flag_map[i];
+    tab[(size_t)(np4 + np)] = sh->pflags;
     hipError_t e = hipMalloc(&sh->d_peer_tab, tab.size() * sizeof(void *));
     if (e == hipSuccess) e = hipMemcpy(sh->d_peer_tab, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -551,7 +551,7 @@ int peer_setup(tds_hip_shard *sh, size_t ring_slots, size_t slot_b) {
   // for the tokens of all ranks in its own test row
   if (ok && sh->world > 1) {
     const unsigned long long token = 0x7D5000000000ull + (unsigned long long)sh->rank + 1ull;
-    unsigned long long *const *ftab = (unsigned long long *const *)((void **)sh->d_peer_tab + np);
+    unsigned long long *const *ftab = (unsigned long long *const *)((void **)sh->d_peer_tab + np4);
     hipLaunchKernelGGL(tds_peer_token_kernel, dim3(1), dim3(64), 0, sh->comm_stream, ftab, np, (long long)sh->test_off(), sh->rank, token);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(sh->comm_stream);
@@ -773,7 +773,7 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
     const unsigned long long seq = (unsigned long long)sh->chunks + 1ull;  // the same on every rank: all make the same calls
     const long long timeout_ticks = s->opt.get(TDS_OPT_SHARD_WAIT_MS, 2000) * 100000ll;  // 100 MHz
     const int np = sh->n_peers;
-    unsigned long long *const *ftab = (unsigned long long *const *)((void **)sh->d_peer_tab + np);
+    unsigned long long *const *ftab = (unsigned long long *const *)((void **)sh->d_peer_tab + (np + 3) / 4 * 4);
     if (sh->n_real_peers > 0) {
       hipLaunchKernelGGL(tds_peer_credit_kernel, dim3(1), dim3(64), 0, s->stream, ftab, np, (long long)sh->credit_off(), sh->rank,
                          sh->world, seq, sh->wait_err(), timeout_ticks, sh->host_latch);
@@ -789,6 +789,7 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
     pl.flag_off = ck.slot0 * sh->world + sh->rank;
     pl.flag_stride = sh->world;
     pl.reward_done_only = sh->reward_done_only ? 1 : 0;
+    pl.wide_ok = 1;
     r.progress = nullptr;
     s->peer_launch = &pl;
     const int rc = tds_hip_step_many_rings(s, actions_dev, pool, ck.act_first, ck.steps, &r);
@@ -796,10 +797,12 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
     if (rc != TDS_OK) return rc;
     TDS_HIP_TRY(hipEventRecord(e_kernel, s->stream));
     TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, e_kernel, 0));
-    hipLaunchKernelGGL(tds_peer_arrived_kernel, dim3(1), dim3(64), 0, sh->comm_stream,
-                       (const unsigned long long *)(sh->pflags + (size_t)ck.slot0 * sh->world), ck.steps * sh->world, seq,
-                       sh->wait_err(), timeout_ticks, sh->host_latch);
-    if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "peer-store exchange: arrival kernel launch");
+    if (sh->n_real_peers > 0) {  // (one rank: the launch's completion IS the arrival of everything anybody stores here)
+      hipLaunchKernelGGL(tds_peer_arrived_kernel, dim3(1), dim3(64), 0, sh->comm_stream,
+                         (const unsigned long long *)(sh->pflags + (size_t)ck.slot0 * sh->world), ck.steps * sh->world, seq,
+                         sh->wait_err(), timeout_ticks, sh->host_latch);
+      if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "peer-store exchange: arrival kernel launch");
+    }
     TDS_HIP_TRY(hipEventRecord(e_comm, sh->comm_stream));
     sh->exchange_form = TDS_EXCHANGE_PEER_STORES;
     return TDS_OK;
@@ -1378,8 +1381,9 @@ int tds_hip_shard_flush(tds_hip_shard_t *sh) {
   for (int i = 0; i < kSlots; ++i) sh->pending[i] = false;
   sh->comm_pending[0] = sh->comm_pending[1] = false;
   if (sh->progress) {  // a wait of the ring exchange that gave up (see tds_ring_wait_kernel)
+    // (every wait that gives up also raises the pinned host word: no device round trip on the good path)
     unsigned err = 0;
-    TDS_HIP_TRY(hipMemcpy(&err, sh->wait_err(), sizeof(err), hipMemcpyDeviceToHost));
+    if (!sh->host_latch) TDS_HIP_TRY(hipMemcpy(&err, sh->wait_err(), sizeof(err), hipMemcpyDeviceToHost));
     if (err != 0u || (sh->host_latch && *(volatile unsigned *)sh->host_latch != 0u)) {
       TDS_HIP_TRY(hipMemset(sh->wait_err(), 0, sizeof(err)));
       if (sh->host_latch) *(volatile unsigned *)sh->host_latch = 0u;
