@@ -559,6 +559,14 @@ int tds_hip_debug_poison_lds(tds_hip_sim_t *sim, int byte_pattern);
 int tds_hip_kernel_info(const tds_hip_sim_t *sim, int *lds_bytes_per_env, int *threads_per_env,
                         int *envs_per_block);
 
+/* Which kernel a plain single step of this handle runs (tds_hip_step / _step_obs with substeps = 1, tds_hip_forward_zero_*,
+   the launches of the tds_hip_step_many graphs): 0 the general kernel (csrc/tds_kernels.hip: lanes per environment as
+   tds_hip_kernel_info reports), 1 the 16-lane kernel of the star-shaped legged robots (csrc/tds_quad.hip: a root body on the
+   reference's six virtual links + four legs of three 1-dof joints and a fixed toe — Laikago, BASELINE config 4; create-time
+   option quad = 0 keeps such a model on the general kernel).  Optional outputs: that kernel's lanes and LDS bytes per
+   environment. */
+int tds_hip_single_step_kernel(const tds_hip_sim_t *sim, int *lanes_per_env, int *lds_bytes_per_env);
+
 /* ======================================================================================
  * Multi-GPU: the global batch of environments is cut into equal contiguous shards, one per rank /
  * GPU (rank r owns environments [r N/G, (r+1) N/G)); each shard is an ordinary tds_hip_sim on its own device, the

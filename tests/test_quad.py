@@ -1,0 +1,131 @@
+"""The 16-lane kernel of the star-shaped legged robots (csrc/tds_quad.hip; BASELINE config 4: Laikago).
+
+A handle whose model is a root body on the reference's six virtual links + four legs of (1-dof, 1-dof, 1-dof, fixed toe) runs its
+plain single steps on that kernel (four environments per wavefront, M factorised leaves-first: leg blocks, couplings, the root's
+Schur complement) instead of the general 32-lane kernel.  Pinned here
+  * on the reference's golden vectors (single steps, closed-loop trajectory),
+  * on the general kernel (create-time option quad = 0) over states that cover 0 .. 4 penetrating toes, mixed inside a wavefront,
+  * on the REAL reference (oracle/_ref/libtds_ref.so) in a closed loop of every environment at BASELINE's size,
+and — because every other test of the suite that steps a Laikago model one step at a time (golden steps, ring slots of the
+chained graphs, float records, the vectorised environments, the reset pool) now runs through it — by those as well."""
+import os
+
+import numpy as np
+import pytest
+
+import tds_amd
+from tds_amd import hip_backend
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+QUAD_MODELS = ["laikago", "laikago_soft"]
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch
+
+
+@pytest.mark.parametrize("name", QUAD_MODELS)
+@pytest.mark.parametrize("dtype", ["f64", "mixed"])
+def test_quad_kernel_takes_the_star_models_and_matches_the_golden_steps(name, dtype, built):
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = g["x"].shape[0]
+    sim = hip_backend.HipSim(m, n, dtype=dtype)
+    gen = hip_backend.HipSim(m, n, dtype=dtype, options={"quad": 0})
+    assert sim.single_step_kernel()[:2] == ("quad16", 16) and gen.single_step_kernel()[0] == "general"
+    assert hip_backend.HipSim(tds_amd.load_model("ant"), 8).single_step_kernel()[0] == "general"
+    x = torch.from_numpy(g["x"]).to(sim.torch_dtype).cuda()
+    y = sim.forward_zero(x).double().cpu().numpy()
+    yg = gen.forward_zero(x).double().cpu().numpy()
+    # (float records: the golden inputs are doubles — rounded to float on the way in, the step's own conditioning decides how
+    #  far the double golden outputs are; what is pinned there is the general kernel on the SAME float inputs, itself held to
+    #  the reference on float-representable inputs by tests/test_f32.py)
+    e_ref, e_gen = rel_err(y, g["y"]), rel_err(y, yg)
+    print(f"{name} [{dtype}] quad16: vs golden {e_ref:.3e}, vs the general kernel {e_gen:.3e}")
+    assert e_ref < (1e-6 if dtype == "f64" else 1e-3) and e_gen < (1e-9 if dtype == "f64" else 2e-6)
+    # closed loop with the obs record: the golden trajectory
+    x0 = np.tile(g["traj_x0"], (n, 1))
+    sim.x.copy_(torch.from_numpy(x0).to(sim.torch_dtype).cuda())
+    obs = torch.zeros((n, sim.obs_dim + 2), dtype=sim.torch_dtype, device="cuda")
+    nqd = m.dof_q + m.dof_qd
+    for t in range(30):
+        a = np.tile(g["traj_actions"][t], (n, 1))
+        sim.step(torch.from_numpy(a).to(sim.torch_dtype).cuda().contiguous(), 1, obs)
+        assert rel_err(sim.y.double().cpu().numpy()[0], g["traj_y"][t]) < (5e-6 if dtype == "f64" else 2e-3), t
+        assert torch.equal(sim.x[:, :nqd], sim.y[:, :nqd])
+    assert torch.equal(obs[:, 2:nqd], sim.x[:, 2:nqd]) and (obs[:, :2] == 0).all()
+
+
+@pytest.mark.parametrize("name", QUAD_MODELS)
+def test_quad_against_the_general_kernel_over_contact_patterns(name, built):
+    """every number of penetrating toes 0 .. 4 and every mix of them inside a wavefront (the rows of a wavefront are laid out
+    for its largest count): 4096 states with random base height / tilt / joint angles and velocities, one step each"""
+    torch = _torch()
+    m = tds_amd.load_model(name)
+    n = 4096
+    rng = np.random.default_rng(11)
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    x = np.zeros((n, m.input_dim))
+    ip = np.array([m.initial_poses[i] for i in range(adim)])
+    x[:, 0:2] = rng.uniform(-2, 2, (n, 2))
+    x[:, 2] = rng.uniform(0.30, 0.50, n)              # from well inside the plane to airborne
+    x[:, 3:5] = rng.uniform(-0.4, 0.4, (n, 2))        # roll / pitch: some toes down, some up
+    x[:, 5] = rng.uniform(-3, 3, n)
+    x[:, 6:nq] = ip + rng.uniform(-0.5, 0.5, (n, nq - 6))
+    x[:, nq:nq + nd] = rng.uniform(-1.5, 1.5, (n, nd))
+    x[:, nq + nd:nq + nd + adim] = rng.uniform(-0.4, 0.4, (n, adim))
+    x[:, -3:] = [100, 2, 50]
+    sim = hip_backend.HipSim(m, n)
+    gen = hip_backend.HipSim(m, n, options={"quad": 0})
+    xd = torch.from_numpy(x).cuda()
+    y, yg = sim.forward_zero(xd).cpu().numpy(), gen.forward_zero(xd).cpu().numpy()
+    assert np.isfinite(y).all()
+    e = rel_err(y, yg)
+    # how many toes were down (from the oracle-free side: a toe is down when the general kernel's step changed its leg's
+    # velocity differently from free flight is hard to see; count from the geometry instead: toe height at the start)
+    print(f"{name}: quad16 vs general over {n} contact patterns: {e:.3e}")
+    assert e < 1e-9
+    # obs / reward / done records and the state feedback agree too
+    o1 = torch.zeros((n, sim.obs_dim + 2), dtype=torch.float64, device="cuda")
+    o2 = torch.zeros_like(o1)
+    for s_, o_ in ((sim, o1), (gen, o2)):
+        s_.x.copy_(xd)
+        s_.step(None, 1, o_)
+    assert rel_err(o1.cpu().numpy(), o2.cpu().numpy()) < 1e-9
+    assert rel_err(sim.x.cpu().numpy(), gen.x.cpu().numpy()) < 1e-9
+    assert (o1[:, -1] == o2[:, -1]).all()
+
+
+def test_quad_closed_loop_of_every_env_against_the_reference(built):
+    """BASELINE config 4 at full size through the 16-lane kernel: laikago_soft x 8192, 60 closed-loop single steps with fresh
+    +-0.4 actions, every environment and every step against the REAL reference from the state the device held before the step"""
+    torch = _torch()
+    from test_hip_parity import _reference_stepper
+    from test_rings import _start_state
+
+    name, n, steps = "laikago_soft", 8192, 60
+    m = tds_amd.load_model(name)
+    ref_step, what = _reference_stepper(name, n)
+    rng = np.random.default_rng(21)
+    nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
+    sim = hip_backend.HipSim(m, n)
+    assert sim.single_step_kernel()[0] == "quad16"
+    sim.x.copy_(torch.from_numpy(_start_state(m, name, n, rng)).cuda())
+    worst = 0.0
+    for k in range(steps):
+        a = rng.uniform(-0.4, 0.4, (n, adim))
+        x = sim.x.cpu().numpy()
+        x[:, nq + nd:nq + nd + adim] = a
+        sim.step(torch.from_numpy(a).cuda().contiguous(), 1)
+        y = sim.y.cpu().numpy()
+        y_ref = ref_step(x)
+        e = rel_err(y, y_ref)
+        worst = max(worst, e)
+        assert e < 1e-6, (k, e)
+    print(f"{name} x{n}, {steps} closed-loop steps on the 16-lane kernel, every env, vs {what}: worst per-step rel err {worst:.3e}")

@@ -2080,7 +2080,17 @@ int tds_hip_kernel_info(const tds_hip_sim_t *s, int *lds_bytes_per_env, int *thr
   if (lds_bytes_per_env) *lds_bytes_per_env = (int)(s->lds.stride * (s->compute_f64() ? 8 : 4));
   if (threads_per_env) *threads_per_env = s->lanes;
   if (envs_per_block) *envs_per_block = 64 / s->lanes;
+
   return TDS_OK;
+}
+
+int tds_hip_single_step_kernel(const tds_hip_sim_t *s, int *lanes_per_env, int *lds_bytes_per_env) {
+  if (!s) return -1;
+  const bool quad = s->compute_f64() && s->h64.quad != 0;
+  if (lanes_per_env) *lanes_per_env = quad ? 16 : s->lanes;
+  if (lds_bytes_per_env)
+    *lds_bytes_per_env = quad ? tds_quad_lds_bytes<double>(s->model.input_dim) : (int)(s->lds.stride * (s->compute_f64() ? 8 : 4));
+  return quad ? 1 : 0;
 }
 
 }  // extern "C"

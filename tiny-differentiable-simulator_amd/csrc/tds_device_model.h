@@ -92,6 +92,11 @@ struct DevModel {
   // 1: link i carries dof i for every link (lane == link == dof: the Ant; not Laikago, whose fixed toes own no dof) —
   // per-link results that feed per-dof computations then stay in the lane's registers instead of crossing through LDS
   int dof_identity;
+  // 1: the model is the STAR the 16-lane kernel of tds_quad.hip is built for: the closed-form root chain (euler_root), behind
+  // it exactly four legs of four links each in consecutive lanes — three 1-dof joints and a FIXED toe —, plane contacts
+  // on the toes only (one sphere each, in leg order), visuals on links 5 .. 21 in link order, unactuated root links without
+  // joint springs.  Laikago (BASELINE config 4) is one; option quad = 0 keeps such a model on the general kernel.
+  int quad;
   T X_T[12][TDS_NL];            // rot (row-major 9) | trans (3)
   T S[6][TDS_NL];
   T mass[TDS_NL], com[3][TDS_NL], inertia[9][TDS_NL];
@@ -595,6 +600,28 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->vis_link[v] = V.link;
     for (int k = 0; k < 9; ++k) d->vis_X[k][v] = (T)V.X_rot[k];
     for (int k = 0; k < 3; ++k) d->vis_X[9 + k][v] = (T)V.X_trans[k];
+  }
+  // the STAR of tds_quad.hip (see DevModel::quad): root chain in closed form + four legs of (1-dof, 1-dof, 1-dof, fixed)
+  d->quad = 0;
+  if (d->euler_root && sizeof(T) == 8 && m->num_links == 22 && m->dof_qd == 18 && m->dof_q == 18 && m->has_plane &&
+      ncp == 4 && tds_opt_now(TDS_OPT_QUAD) != 0) {
+    bool ok = true;
+    for (int k = 0; ok && k < 4; ++k) {
+      for (int j = 0; ok && j < 4; ++j) {
+        const int i = 6 + 4 * k + j;
+        const tds_link_t &l = m->links[i];
+        ok = l.parent == (j == 0 ? 5 : i - 1);
+        if (j < 3)
+          ok = ok && l.joint_type >= TDS_JOINT_PRISMATIC_X && l.joint_type <= TDS_JOINT_REVOLUTE_AXIS && l.qd_index == 6 + 3 * k + j &&
+               l.q_index == 6 + 3 * k + j;
+        else
+          ok = ok && l.joint_type == TDS_JOINT_FIXED;
+      }
+      ok = ok && d->cp_link[k] == 9 + 4 * k;
+    }
+    ok = ok && (d->num_visuals == 0 || d->num_visuals == 17);
+    for (int v = 0; ok && v < d->num_visuals; ++v) ok = d->vis_link[v] == 5 + v;
+    d->quad = ok ? 1 : 0;
   }
 #undef TDS_FAIL
   return TDS_OK;

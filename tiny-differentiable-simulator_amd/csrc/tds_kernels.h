@@ -153,6 +153,18 @@ template <typename T, typename TR, int KIND>
 int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
                          const TR *x_in, TR *y_out, const TR *actions, TR *x_feedback, TR *obs_out, T *ovf, int n_envs,
                          hipStream_t stream, const TdsStepCtl &ctl, long long *prof, int form);
+// the 16-lane kernel of the star-shaped legged robots (tds_quad.hip; DevModel::quad): one straight-line step per launch
+template <typename T, typename TR>
+int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
+                    TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl);
+template <typename T>
+int tds_quad_lds_bytes(int input_dim);
+// what tds_launch_step hands to it: exactly one plain step, no rings, no profile stamps
+inline bool tds_quad_takes(int quad, const TdsStepCtl &ctl, const long long *prof) {
+  return quad != 0 && prof == nullptr && ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr &&
+         ctl.obs_ring == nullptr && ctl.y_ring == nullptr;
+}
+
 // T: compute scalar, TR: record scalar (== T, or float under T = double: "f32 records / f64 arithmetic")
 template <typename T, typename TR>
 inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
@@ -161,6 +173,8 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
                            long long *prof = nullptr,  // prof: 14 phase stamps of workgroup 0 (diagnostic)
                            int form = 0) {   // TDS_FORM_*: which build of the kernel
 #define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof, form
+  if (tds_quad_takes(h_model.quad, ctl, prof))
+    return tds_launch_quad<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl);
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
   if (h_model.num_bodies >= 2 && h_model.multi_floating) return tds_launch_step_impl<T, TR, 4>(TDS_ARGS);

@@ -1,0 +1,977 @@
+// tds_quad.hip — the step kernel of the LEGGED robots on 16 lanes per environment (round 5; BASELINE config 4: Laikago).
+//
+// The general kernel (tds_kernels.hip) gives an environment as many lanes as it has links and dofs: Laikago's 22 links /
+// 18 dofs take a 32-lane group — two environments per wavefront — and its dense register LDL^T, its row solves and its
+// forward-dynamics solve read all 153 entries of L although the robot is a STAR: a root body on the reference's six
+// "virtual" links (prismatic x, y, z, revolute x, y, z: tds_device_model.h euler_root) and four legs that are serial
+// chains of four links (hip, upper, lower, fixed toe: leg_len == 4) with nothing between them but the root.  Round 4's
+// counts said 58 % of that kernel's VALU stream moves data and that it is issue-bound: the lever is instructions per
+// environment.  This kernel is built for the star:
+//
+//   * 16 lanes per environment = the 16 leg links, one QUAD of lanes per leg (lane = 4 leg + position in the chain);
+//     four environments per wavefront.  The root chain needs no lane: pose, motion axes, velocity and bias
+//     acceleration of the root body in closed form from (q0..5, qd0..5) on every lane (the formulas of the general
+//     kernel's phase C); its rigid inertia redundantly on every lane; the composite of the legs reaches it by two row
+//     rotations.
+//   * M in LEAVES-FIRST order [leg 0 | leg 1 | leg 2 | leg 3 | root]: four independent 3 x 3 leg blocks B_l, their
+//     6-column couplings C_l to the root and the root's 6 x 6 block — 21 of the dense 171 entries per leg row instead of 18.
+//     LDL^T: every lane of a quad factorises its leg's 3 x 3 block (values gathered by quad broadcasts: DPP moves, no LDS),
+//     the coupling rows L_c = C D^-1 follow inside the quad, the root's Schur complement S = R - sum_l L_c D L_c^T is
+//     formed lane-parallel (21 entries on 16 lanes, two passes over an LDS copy of L_c) and factorised redundantly on every
+//     lane in registers.  Forward dynamics qdd = M^-1 (tau - C) and the final qd -= M^-1 J^T p are quad-local
+//     substitutions plus six 16-lane sums.
+//   * a toe's constraint row touches its own leg's three dofs and the root's six: z~ = D^-1/2 L^-1 J^T costs 9 + 18 + 15
+//     multiply-adds per row (dense: 153), the rows are stored 9 wide, and the Gauss-Seidel sweep keeps the root part of
+//     u~ on every lane.  Contact points are the toes' own lanes: the narrowphase reads no LDS at all.
+//
+// Same arithmetic contract as the general kernel — the reference's env step (locomotion_contact_simulation.h:151-304) to
+// round-off, the same quirks (contacts from pre-step transforms with post-integration velocities, plane_space's k,
+// unnormalised REVOLUTE_AXIS axes, visual poses that lag q by one step) — pinned by the same tests: a handle takes this
+// kernel when its model is such a star (DevModel::quad, tds_device_model.h) and option quad is not 0; option quad = 0
+// keeps the general kernel, and tests/test_quad.py holds the two against each other and against the reference.
+//
+// Straight-line form: one step per launch (what the chained hipGraphs of tds_hip_step_many replay), incl. the reset
+// pool's "done environment takes its next pre-settled state" tail.  Reference files as in tds_kernels.hip.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "tds_device_model.h"
+#include "tds_kernels.h"
+#include "tds_lanes.h"
+
+namespace {
+
+// value of lane K of each QUAD of lanes, delivered to the four lanes of the quad (DPP quad_perm: a VALU move)
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v) {
+  constexpr int CTRL = K * 0x55;
+  const int l = __double2loint(v), h = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, l, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, h, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xF, 0xF, true));
+}
+
+#define QUAD_SYNC()                                            \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+  } while (0)
+
+// LDS per environment, in scalars of T (odd strides where lanes index rows)
+struct QuadLds {
+  static constexpr int LCW = 13;                  // [16 lanes][Lc(6) | W(6)] + pad
+  static constexpr int ZW = 9;                    // a constraint row: 3 leg entries | 6 root entries
+  // offsets are computed at run time from input_dim (see quad_layout)
+};
+
+struct QuadOff {
+  int lcw, legf, swl, qdp, S, ax, Z, rws, xs, cp, stride;
+};
+__host__ __device__ inline QuadOff quad_layout(int in_dim) {
+  QuadOff o;
+  int at = in_dim + 4;
+  at = (at + 1) & ~1;
+  o.lcw = at;  at += 16 * QuadLds::LCW;   // L_c and W = L_c D of every leg-dof lane
+  o.legf = at; at += 4 * 9 + 1;            // per leg: l10 l20 l21 | 1/d (3) | sqrt(1/d) (3)
+  o.swl = at;  at += 16 * 7;               // world motion axis of every leg lane (6, stride 7)
+  o.qdp = at;  at += 16 + 6;               // velocities after integrate_euler_qdd: leg lanes | root
+  o.S = at;    at += 21 + 1;               // Schur complement of the root block
+  o.ax = at;   at += 6 * 7;                // the six root motion axes (stride 7)
+  o.Z = at;    at += 12 * QuadLds::ZW;     // constraint rows z~
+  o.rws = at;  at += 4 * 12;               // per row: b | 1 / (G + cfm) | G | leg of the row's contact
+  o.xs = at;   at += 12;                   // impulses
+  o.cp = at;   at += 5 * 4;                // contact list: point (3) | distance | leg, per slot
+  o.stride = (at + 1) & ~1;
+  return o;
+}
+
+template <typename T, typename TR>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__restrict__ y_out,
+                     const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */, TR *__restrict__ obs_out,
+                     TdsStepCtl ctl, int n_envs, QuadOff O) {
+  extern __shared__ __align__(16) unsigned char tds_quad_smem[];
+  T *const sm = reinterpret_cast<T *>(tds_quad_smem);
+  const int lane = threadIdx.x & 15;
+  const int grp = (threadIdx.x & 63) >> 4;
+  const int env = blockIdx.x * 4 + grp;
+  const bool valid = env < n_envs;
+  T *const E = sm + grp * O.stride;
+  T *const xr = E;
+  const int leg = lane >> 2, pos = lane & 3;
+  const int li = 6 + lane;            // my link
+  const bool dofl = pos < 3;          // my link carries a dof (the toe's joint is fixed)
+  const int dq = 6 + 3 * leg + pos;   // ... this one, in the q / qd records (nq == nd == 18)
+  constexpr int nq = 18, nd = 18;
+  const int in_dim = mdl->input_dim, adim = mdl->action_dim;
+  const T dt = mdl->dt;
+
+  // ---- A. x record -> LDS (coalesced), fresh actions over the action slice
+  for (int i = lane; i < in_dim; i += 16) {
+    const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
+    xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+  }
+  // lane constants (issued under the latency of the record)
+  const int jt = mdl->joint_type[li];
+  const int act_i = mdl->act_index[li];
+  const T init_pose_l = mdl->init_pose[li], stiff_l = mdl->stiffness[li], damp_l = mdl->damping[li];
+  T Sl[6], RT[9], tT[3], Il[9], com_l[3];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Sl[k] = mdl->S[k][li];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) RT[k] = mdl->X_T[k][li];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tT[k] = mdl->X_T[9 + k][li];
+  const T mass_l = mdl->mass[li];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) com_l[k] = mdl->com[k][li];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Il[k] = mdl->inertia[k][li];
+  const T act_lim = mdl->action_limit;
+  QUAD_SYNC();
+  const T q = dofl ? xr[dq] : T(0);
+  const T qd = dofl ? xr[nq + dq] : T(0);
+
+  // ---- PD controller (locomotion_contact_simulation.h:168-258) or direct torque; joint stiffness / damping
+  T tau = T(0);
+  if (mdl->step_mode == TDS_STEP_LOCOMOTION) {
+    if (act_i >= 0) {
+      const int var = nq + nd + adim;
+      const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
+      T a = xr[nq + nd + act_i];
+      a = a < act_lim ? a : act_lim;
+      a = a > -act_lim ? a : -act_lim;
+      const T q_des = init_pose_l + a;
+      T f = kp * (q_des - q) + kd * (T(0) - qd);
+      f = f > -max_force ? f : -max_force;
+      f = f < max_force ? f : max_force;
+      tau = f;
+    }
+  } else if (dofl && dq < adim) {
+    tau = xr[nq + nd + dq];
+  }
+  tau -= stiff_l * q + damp_l * qd;
+
+  // ---- B. jcalc (link.hpp:229-287); the toe lanes of legs 0..2 — fixed joints, no angle of their own — take the root's
+  //         three angles: their sines and cosines reach every lane by one row broadcast each
+  T Rp[9], tp[3], sn, cs;
+  {
+    const T ang = dofl ? (jt == TDS_JOINT_REVOLUTE_AXIS ? q * T(0.5) : q) : xr[3 + (leg < 3 ? leg : 0)];
+    sincos_t<T>(ang, &sn, &cs);
+    const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
+    const bool pris = jt >= TDS_JOINT_PRISMATIC_X && jt <= TDS_JOINT_PRISMATIC_AXIS;
+    T RJ[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+    T tJ[3] = {T(0), T(0), T(0)};
+    if (pris) {
+      tJ[0] = Sl[3] * q;
+      tJ[1] = Sl[4] * q;
+      tJ[2] = Sl[5] * q;
+    }
+    if (rev) {
+      if (jt == TDS_JOINT_REVOLUTE_X) {
+        RJ[4] = cs; RJ[5] = -sn; RJ[7] = sn; RJ[8] = cs;
+      } else if (jt == TDS_JOINT_REVOLUTE_Y) {
+        RJ[0] = cs; RJ[2] = sn; RJ[6] = -sn; RJ[8] = cs;
+      } else if (jt == TDS_JOINT_REVOLUTE_Z) {
+        RJ[0] = cs; RJ[1] = -sn; RJ[3] = sn; RJ[4] = cs;
+      } else {  // axis-angle quaternion with the UNNORMALISED axis (link.hpp:256-261)
+        const T d = sqrt_t<T>(Sl[0] * Sl[0] + Sl[1] * Sl[1] + Sl[2] * Sl[2]);
+        const T sh = sn / d;
+        const T qx = Sl[0] * sh, qy = Sl[1] * sh, qz = Sl[2] * sh, qw = cs;
+        const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+        const T xs = qx * s2, ys = qy * s2, zs = qz * s2;
+        const T wx = qw * xs, wy = qw * ys, wz = qw * zs;
+        const T xx = qx * xs, xy = qx * ys, xz = qx * zs;
+        const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
+        RJ[0] = T(1) - (yy + zz); RJ[1] = xy - wz; RJ[2] = xz + wy;
+        RJ[3] = xy + wz; RJ[4] = T(1) - (xx + zz); RJ[5] = yz - wx;
+        RJ[6] = xz - wy; RJ[7] = yz + wx; RJ[8] = T(1) - (xx + yy);
+      }
+    }
+    mat3_mul(RT, RJ, Rp);
+    T r[3];
+    mat3_mulv(RT, tJ, r);
+    tp[0] = tT[0] + r[0];
+    tp[1] = tT[1] + r[1];
+    tp[2] = tT[2] + r[2];
+  }
+
+  // ---- C. the root chain in closed form (kinematics.hpp:64-97; see tds_kernels.hip phase C: same formulas), on every lane
+  const T q0 = xr[0], q1 = xr[1], q2 = xr[2];
+  const T sx = dpp_bcast<3>(sn), cx = dpp_bcast<3>(cs);
+  const T sy = dpp_bcast<7>(sn), cy = dpp_bcast<7>(cs);
+  const T sz = dpp_bcast<11>(sn), cz = dpp_bcast<11>(cs);
+  T R5[9];  // the root body's rotation
+  R5[0] = cy * cz;                 R5[1] = -cy * sz;                R5[2] = sy;
+  R5[3] = sx * sy * cz + cx * sz;  R5[4] = cx * cz - sx * sy * sz;  R5[5] = -sx * cy;
+  R5[6] = sx * sz - cx * sy * cz;  R5[7] = cx * sy * sz + sx * cz;  R5[8] = cx * cy;
+  const T P[3] = {q0 + mdl->base_t[0], q1 + mdl->base_t[1], q2 + mdl->base_t[2]};
+  const T A3[3] = {T(1), T(0), T(0)}, A4[3] = {T(0), cx, sx}, A5[3] = {sy, -sx * cy, cx * cy};
+  // the six root motion axes (angular | linear): prismatic e_x, e_y, e_z; revolute (A | P x A)
+  T pA3[3], pA4[3], pA5[3];
+  cross3(P, A3, pA3);
+  cross3(P, A4, pA4);
+  cross3(P, A5, pA5);
+  T v5[6], a5[6];  // velocity and bias acceleration (a0) of the root body
+  {
+    const T d0 = xr[nq + 0], d1 = xr[nq + 1], d2 = xr[nq + 2], d3 = xr[nq + 3], d4 = xr[nq + 4], d5 = xr[nq + 5];
+    const T U[3] = {d0, d1, d2};
+    const T J3[3] = {A3[0] * d3, A3[1] * d3, A3[2] * d3}, J4[3] = {A4[0] * d4, A4[1] * d4, A4[2] * d4},
+            J5[3] = {A5[0] * d5, A5[1] * d5, A5[2] * d5};
+    const T W4[3] = {J3[0] + J4[0], J3[1] + J4[1], J3[2] + J4[2]};
+    const T W5[3] = {W4[0] + J5[0], W4[1] + J5[1], W4[2] + J5[2]};
+    T pJ3[3], pJ4[3], pJ5[3];
+    cross3(P, J3, pJ3);
+    cross3(P, J4, pJ4);
+    cross3(P, J5, pJ5);
+    const T pW4[3] = {pJ3[0] + pJ4[0], pJ3[1] + pJ4[1], pJ3[2] + pJ4[2]};
+    const T pW5[3] = {pW4[0] + pJ5[0], pW4[1] + pJ5[1], pW4[2] + pJ5[2]};
+    const T V3[3] = {U[0] + pJ3[0], U[1] + pJ3[1], U[2] + pJ3[2]};
+    const T V4[3] = {U[0] + pW4[0], U[1] + pW4[1], U[2] + pW4[2]};
+    const T V5[3] = {U[0] + pW5[0], U[1] + pW5[1], U[2] + pW5[2]};
+    T a45[3], a55[3], t1[3], t2[3], l3[3], l4[3], l5[3];
+    cross3(J3, J4, a45);
+    cross3(W4, J5, a55);
+    cross3(J3, pJ3, t1);
+    cross3(V3, J3, t2);
+    l3[0] = t1[0] + t2[0]; l3[1] = t1[1] + t2[1]; l3[2] = t1[2] + t2[2];
+    cross3(W4, pJ4, t1);
+    cross3(V4, J4, t2);
+    l4[0] = t1[0] + t2[0]; l4[1] = t1[1] + t2[1]; l4[2] = t1[2] + t2[2];
+    cross3(W5, pJ5, t1);
+    cross3(V5, J5, t2);
+    l5[0] = t1[0] + t2[0]; l5[1] = t1[1] + t2[1]; l5[2] = t1[2] + t2[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      v5[k] = W5[k];
+      v5[3 + k] = V5[k];
+      a5[k] = a45[k] + a55[k];
+      a5[3 + k] = (l3[k] + l4[k] + l5[k]) - mdl->grav[k];
+    }
+  }
+  // ---- the legs: one segmented prefix scan along each quad (chain-local products of the joint transforms, then the
+  //      root's pose in front; prefix sums of the joint velocities and of the velocity-product accelerations)
+  T R[9], p[3], sw[6], vJ[6], v[6], a0[6];
+  {
+    T Rl[9], pl[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rl[k] = Rp[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pl[k] = tp[k];
+    static_for<0, 2>([&](auto dc) {
+      constexpr int D = 1 << decltype(dc)::value;
+      const bool take = pos >= D;
+      T Rq[9], pq[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const T sh = dpp_shr<D>(Rl[k]);
+        Rq[k] = take ? sh : ((k == 0 || k == 4 || k == 8) ? T(1) : T(0));
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const T sh = dpp_shr<D>(pl[k]);
+        pq[k] = take ? sh : T(0);
+      }
+      T Rn[9], r[3];
+      mat3_mul(Rq, Rl, Rn);
+      mat3_mulv(Rq, pl, r);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rl[k] = Rn[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pl[k] = pq[k] + r[k];
+    });
+    T r[3];
+    mat3_mul(R5, Rl, R);
+    mat3_mulv(R5, pl, r);
+    p[0] = P[0] + r[0];
+    p[1] = P[1] + r[1];
+    p[2] = P[2] + r[2];
+    // s = X_world.apply_inverse(S) = (R w, R v + p x (R w))   (transform.hpp:232-243)
+    mat3_mulv(R, Sl, sw);
+    mat3_mulv(R, Sl + 3, sw + 3);
+    T c[3];
+    cross3(p, sw, c);
+    sw[3] += c[0];
+    sw[4] += c[1];
+    sw[5] += c[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vJ[k] = sw[k] * qd;
+    T pre[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pre[k] = vJ[k];
+    static_for<0, 2>([&](auto dc) {
+      constexpr int D = 1 << decltype(dc)::value;
+      const bool take = pos >= D;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const T sh = dpp_shr<D>(pre[k]);
+        pre[k] += take ? sh : T(0);
+      }
+    });
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = v5[k] + pre[k];
+    // cb = v x vJ (kinematics.hpp:96-99)
+    T cb[6];
+    cross3(v, vJ, cb);
+    T c1[3], c2[3];
+    cross3(v, vJ + 3, c1);
+    cross3(v + 3, vJ, c2);
+    cb[3] = c1[0] + c2[0];
+    cb[4] = c1[1] + c2[1];
+    cb[5] = c1[2] + c2[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pre[k] = cb[k];
+    static_for<0, 2>([&](auto dc) {
+      constexpr int D = 1 << decltype(dc)::value;
+      const bool take = pos >= D;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const T sh = dpp_shr<D>(pre[k]);
+        pre[k] += take ? sh : T(0);
+      }
+    });
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a0[k] = a5[k] + pre[k];
+  }
+  // my world motion axis, for the rows of the contacts (lane-dependent reads in phase J)
+  {
+    T *const swl = E + O.swl;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) swl[lane * 7 + k] = sw[k];
+  }
+
+  // ---- I. narrowphase: the contact points are the toes' own lanes (plane x sphere, contact_point.hpp:96-131)
+  const T nb[3] = {mdl->nb[0], mdl->nb[1], mdl->nb[2]};
+  const T t1v[3] = {mdl->t1[0], mdl->t1[1], mdl->t1[2]};
+  const T t2v[3] = {mdl->t2[0], mdl->t2[1], mdl->t2[2]};
+  int na = 0;
+  {
+    T *const cpx = E + O.cp;
+    const T rad = mdl->cp_radius[leg];
+    const T loc[3] = {mdl->cp_local[0][leg], mdl->cp_local[1][leg], mdl->cp_local[2][leg]};
+    T ctr[3];
+    mat3_mulv(R, loc, ctr);
+    ctr[0] += p[0];
+    ctr[1] += p[1];
+    ctr[2] += p[2];
+    const T n[3] = {mdl->plane_n[0], mdl->plane_n[1], mdl->plane_n[2]};
+    const T t = -((-dot3(ctr, n)) + mdl->plane_c);
+    const T dist = t - rad;
+    const bool act = valid && pos == 3 && dist < T(0);
+    const unsigned long long bal = __ballot(act);
+    const unsigned mine = (unsigned)((bal >> (grp * 16)) & 0xFFFFull);
+    const int pre = __popc(mine & ((1u << lane) - 1u));
+    if (act) {
+      cpx[0 * 4 + pre] = ctr[0] - rad * n[0];
+      cpx[1 * 4 + pre] = ctr[1] - rad * n[1];
+      cpx[2 * 4 + pre] = ctr[2] - rad * n[2];
+      cpx[3 * 4 + pre] = dist;
+      cpx[4 * 4 + pre] = (T)leg;
+    }
+    na = __popc(mine);
+  }
+  int NA = na;
+#pragma unroll
+  for (int msk = 16; msk < 64; msk <<= 1) {
+    const int o = __shfl_xor(NA, msk, 64);
+    NA = o > NA ? o : NA;
+  }
+  NA = __builtin_amdgcn_readfirstlane(NA);
+
+  // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
+  //          my link's (DevModel::quad checks the order); visual 0 — the root body's — goes out on the toe lane of leg 3
+  const int ystr = ctl.y_stride;
+  TR *const yo = y_out != nullptr ? y_out + (size_t)env * ystr : nullptr;
+  const int nv = mdl->num_visuals;
+  if (valid && yo != nullptr && nv > 0) {
+    auto pose_out = [&](const T *Rl, const T *pl, int k) {
+      T Rv[9], pv[3], Ro[9], po[3], qo[4];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pv[c] = mdl->vis_X[9 + c][k];
+      mat3_mul(Rl, Rv, Ro);
+      mat3_mulv(Rl, pv, po);
+      matrix_to_quat(Ro, qo);
+      TR *o = yo + (nq + nd) + 7 * k;
+      o[0] = (TR)(pl[0] + po[0]);
+      o[1] = (TR)(pl[1] + po[1]);
+      o[2] = (TR)(pl[2] + po[2]);
+      o[3] = (TR)qo[0];
+      o[4] = (TR)qo[1];
+      o[5] = (TR)qo[2];
+      o[6] = (TR)qo[3];
+    };
+    pose_out(R, p, 1 + lane);
+    if (lane == 15) pose_out(R5, P, 0);
+  }
+
+  // ---- D. world-frame rigid inertia and bias force of my link, and (redundantly on every lane) of the root body
+  //         (kinematics.hpp:96-132, inertia.hpp:121-130): I = (Isym 6 | h 3 | m), f = I a0 + v x* I v
+  auto rigid = [&](const T *Rl, const T *pl, T m, const T *com, const T *Ib, const T *vl, const T *al, T *Ic, T *fc) {
+    T cw[3];
+    mat3_mulv(Rl, com, cw);
+    cw[0] += pl[0];
+    cw[1] += pl[1];
+    cw[2] += pl[2];
+    T RI[9], Iw[9];
+    mat3_mul(Rl, Ib, RI);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Iw[3 * r + c] = RI[3 * r] * Rl[3 * c] + RI[3 * r + 1] * Rl[3 * c + 1] + RI[3 * r + 2] * Rl[3 * c + 2];
+    const T c2 = dot3(cw, cw);
+    Ic[0] = Iw[0] + m * (c2 - cw[0] * cw[0]);
+    Ic[1] = T(0.5) * (Iw[1] + Iw[3]) - m * cw[0] * cw[1];
+    Ic[2] = T(0.5) * (Iw[2] + Iw[6]) - m * cw[0] * cw[2];
+    Ic[3] = Iw[4] + m * (c2 - cw[1] * cw[1]);
+    Ic[4] = T(0.5) * (Iw[5] + Iw[7]) - m * cw[1] * cw[2];
+    Ic[5] = Iw[8] + m * (c2 - cw[2] * cw[2]);
+    Ic[6] = m * cw[0];
+    Ic[7] = m * cw[1];
+    Ic[8] = m * cw[2];
+    Ic[9] = m;
+    const T *const h = Ic + 6;
+    T Iv[6], Ia[6], t3[3];
+    sym3_mulv(Ic, vl, Iv);
+    cross3(h, vl + 3, t3);
+    Iv[0] += t3[0];
+    Iv[1] += t3[1];
+    Iv[2] += t3[2];
+    cross3(h, vl, t3);
+    Iv[3] = m * vl[3] - t3[0];
+    Iv[4] = m * vl[4] - t3[1];
+    Iv[5] = m * vl[5] - t3[2];
+    sym3_mulv(Ic, al, Ia);
+    cross3(h, al + 3, t3);
+    Ia[0] += t3[0];
+    Ia[1] += t3[1];
+    Ia[2] += t3[2];
+    cross3(h, al, t3);
+    Ia[3] = m * al[3] - t3[0];
+    Ia[4] = m * al[4] - t3[1];
+    Ia[5] = m * al[5] - t3[2];
+    T u3[3];
+    cross3(vl, Iv, fc);
+    cross3(vl + 3, Iv + 3, u3);
+    fc[0] += u3[0];
+    fc[1] += u3[1];
+    fc[2] += u3[2];
+    cross3(vl, Iv + 3, fc + 3);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fc[k] += Ia[k];
+  };
+  T Ic[10], fc[6];
+  rigid(R, p, mass_l, com_l, Il, v, a0, Ic, fc);
+  T It[10], ft[6];  // the root body's; below: + the legs' composites = the whole robot's
+  {
+    const T com5[3] = {mdl->com[0][5], mdl->com[1][5], mdl->com[2][5]};
+    T I5[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) I5[k] = mdl->inertia[k][5];
+    rigid(R5, P, mdl->mass[5], com5, I5, v5, a5, It, ft);
+  }
+
+  // ---- E. composite inertia / bias force (CRBA, mass_matrix.hpp:39-56): suffix sums along every quad; the chain heads'
+  //         totals reach the root by two row rotations and come back to every lane by a quad broadcast
+  static_for<0, 2>([&](auto dc) {
+    constexpr int D = 1 << decltype(dc)::value;
+    const T recv = (pos + D < 4) ? T(1) : T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fc[k] += recv * dpp_shl<D>(fc[k]);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) Ic[k] += recv * dpp_shl<D>(Ic[k]);
+  });
+  {
+    const T head = pos == 0 ? T(1) : T(0);
+    auto legs_total = [&](T x) -> T {
+      T s = head * x;
+      s = dpp_add<0x124>(s);  // row_ror:4
+      s = dpp_add<0x128>(s);  // row_ror:8   (lanes of position 0 now hold the sum over the four legs)
+      return quad_bcast<0>(s);
+    };
+#pragma unroll
+    for (int k = 0; k < 10; ++k) It[k] += legs_total(Ic[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ft[k] += legs_total(fc[k]);
+  }
+  // F = Ic s, C = s . f of my dof
+  auto times_inertia = [&](const T *I, const T *s, T *F) {  // (I w + h x v, m v - h x w)
+    T t3[3];
+    sym3_mulv(I, s, F);
+    cross3(I + 6, s + 3, t3);
+    F[0] += t3[0];
+    F[1] += t3[1];
+    F[2] += t3[2];
+    cross3(I + 6, s, t3);
+    F[3] = I[9] * s[3] - t3[0];
+    F[4] = I[9] * s[4] - t3[1];
+    F[5] = I[9] * s[5] - t3[2];
+  };
+  auto dot6 = [&](const T *a, const T *b) -> T { return dot3(a, b) + dot3(a + 3, b + 3); };
+  T Fc[6];
+  times_inertia(Ic, sw, Fc);
+  const T Cb = dot6(sw, fc);
+  // the six root axes, as (angular | linear)
+  const T ax0[6] = {T(0), T(0), T(0), T(1), T(0), T(0)}, ax1[6] = {T(0), T(0), T(0), T(0), T(1), T(0)},
+          ax2[6] = {T(0), T(0), T(0), T(0), T(0), T(1)};
+  const T ax3[6] = {A3[0], A3[1], A3[2], pA3[0], pA3[1], pA3[2]}, ax4[6] = {A4[0], A4[1], A4[2], pA4[0], pA4[1], pA4[2]},
+          ax5[6] = {A5[0], A5[1], A5[2], pA5[0], pA5[1], pA5[2]};
+  const T *const axr[6] = {ax0, ax1, ax2, ax3, ax4, ax5};
+  T Cr[6];  // bias forces of the root dofs
+#pragma unroll
+  for (int r = 0; r < 6; ++r) Cr[r] = dot6(axr[r], ft);
+
+  // ---- G. M in leaves-first order.  My row of my leg's 3 x 3 block (entries against the dofs in front of me in the
+  //         chain: M[i][j] = F_i . s_j for j an ancestor of i, mass_matrix.hpp:87-109) and my coupling to the root dofs
+  T Bm[3], Cc[6];
+  {
+    T s0[6], s1[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      s0[k] = quad_bcast<0>(sw[k]);
+      s1[k] = quad_bcast<1>(sw[k]);
+    }
+    Bm[0] = dot6(Fc, s0);
+    Bm[1] = dot6(Fc, s1);
+    Bm[2] = dot6(Fc, sw);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) Cc[r] = dofl ? dot6(Fc, axr[r]) : T(0);
+  }
+  // ---- H. LDL^T.  The leg block: its six entries to every lane of the quad, factorised there
+  T l10, l20, l21, id0, id1, id2;
+  {
+    const T b00 = quad_bcast<0>(Bm[0]);
+    const T b10 = quad_bcast<1>(Bm[0]), b11 = quad_bcast<1>(Bm[1]);
+    const T b20 = quad_bcast<2>(Bm[0]), b21 = quad_bcast<2>(Bm[1]), b22 = quad_bcast<2>(Bm[2]);
+    id0 = rcp_full<T>(b00);
+    l10 = b10 * id0;
+    l20 = b20 * id0;
+    const T d1 = b11 - l10 * b10;
+    id1 = rcp_full<T>(d1);
+    const T u21 = b21 - l20 * b10;  // = l21 d1
+    l21 = u21 * id1;
+    const T d2 = b22 - l20 * b20 - l21 * u21;
+    id2 = rcp_full<T>(d2);
+  }
+  const T my_id = pos == 0 ? id0 : (pos == 1 ? id1 : id2);
+  // the coupling rows: W_a = C_a - sum_{a' < a} L[a][a'] W_a', L_c = W / d
+  T W[6], Lc[6];
+  {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) W[r] = Cc[r];
+    const T m1 = pos == 1 ? l10 : (pos == 2 ? l20 : T(0));
+#pragma unroll
+    for (int r = 0; r < 6; ++r) W[r] -= m1 * quad_bcast<0>(W[r]);
+    const T m2 = pos == 2 ? l21 : T(0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) W[r] -= m2 * quad_bcast<1>(W[r]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      W[r] = dofl ? W[r] : T(0);
+      Lc[r] = W[r] * my_id;
+    }
+  }
+  {
+    T *const lcw = E + O.lcw + lane * QuadLds::LCW;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      lcw[r] = Lc[r];
+      lcw[6 + r] = W[r];
+    }
+    if (pos == 0) {
+      T *const lf = E + O.legf + leg * 9;
+      lf[0] = l10; lf[1] = l20; lf[2] = l21;
+      lf[3] = id0; lf[4] = id1; lf[5] = id2;
+      lf[6] = sqrt_t<T>(id0); lf[7] = sqrt_t<T>(id1); lf[8] = sqrt_t<T>(id2);
+    }
+    // the six root axes for the lane-parallel root block (every lane the same values to the same slots)
+    T *const axl = E + O.ax;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) axl[r * 7 + k] = axr[r][k];
+  }
+  QUAD_SYNC();
+  // the root's Schur complement S[r][r'] = s_r . (It s_r') - sum_lanes L_c[r] W[r'], entry e = r (r + 1) / 2 + r' on lane
+  // e (two passes: 21 entries, 16 lanes)
+  {
+    const T *const lcw = E + O.lcw;
+    const T *const axl = E + O.ax;
+    T *const Sl_ = E + O.S;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      int e = lane + 16 * pass;
+      e = e < 21 ? e : 20;
+      int r = 0;
+#pragma unroll
+      for (int k = 1; k < 6; ++k) r += e >= (k * (k + 1)) / 2 ? 1 : 0;
+      const int rp = e - (r * (r + 1)) / 2;
+      T sr[6], srp[6], Fr[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        sr[k] = axl[r * 7 + k];
+        srp[k] = axl[rp * 7 + k];
+      }
+      times_inertia(It, srp, Fr);
+      T acc = dot6(sr, Fr);
+#pragma unroll
+      for (int l = 0; l < 16; ++l) acc -= lcw[l * QuadLds::LCW + r] * lcw[l * QuadLds::LCW + 6 + rp];
+      Sl_[e] = acc;
+    }
+  }
+  QUAD_SYNC();
+  // ... factorised redundantly on every lane: Ls (strictly lower, row-major packed), 1 / D
+  T Ls[15], ids[6];
+  {
+    const T *const Sl_ = E + O.S;
+    T Sm[21];
+#pragma unroll
+    for (int e = 0; e < 21; ++e) Sm[e] = Sl_[e];
+    // right-looking on the packed lower triangle: S(r, c) at r (r + 1) / 2 + c
+    static_for<0, 6>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const T inv = rcp_full<T>(Sm[(k * (k + 1)) / 2 + k]);
+      ids[k] = inv;
+      T col[6];
+      static_for<k + 1, 6>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        col[r] = Sm[(r * (r + 1)) / 2 + k];           // S(r, k) before scaling
+        Ls[(r * (r - 1)) / 2 + k] = col[r] * inv;     // L(r, k)
+      });
+      static_for<k + 1, 6>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        static_for<k + 1, r + 1>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          Sm[(r * (r + 1)) / 2 + c] -= Ls[(r * (r - 1)) / 2 + k] * col[c];
+        });
+      });
+    });
+  }
+
+  // the two substitutions with the factors, used three times (forward dynamics, contact impulse)
+  //   leaves-first system  [B  C^T; C  R] = L D L^T,  unknown (x_leg on the dof lanes, x_root[6] on every lane)
+  auto solve = [&](T b_leg, const T *b_root, T &x_leg, T *x_root) {
+    // forward: legs, quad-local
+    T y = b_leg;
+    {
+      const T m1 = pos == 1 ? l10 : (pos == 2 ? l20 : T(0));
+      y -= m1 * quad_bcast<0>(y);
+      const T m2 = pos == 2 ? l21 : T(0);
+      y -= m2 * quad_bcast<1>(y);
+      y = dofl ? y : T(0);
+    }
+    // root: y_r = b_r - sum_lanes L_c[r] y, then the root block's own forward substitution
+    T yr[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) yr[r] = b_root[r] - group_sum<T, 16>(Lc[r] * y);
+    static_for<1, 6>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      static_for<0, r>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        yr[r] -= Ls[(r * (r - 1)) / 2 + c] * yr[c];
+      });
+    });
+    // diagonal, backward: root first
+#pragma unroll
+    for (int r = 0; r < 6; ++r) x_root[r] = yr[r] * ids[r];
+    static_for<0, 5>([&](auto ic) {
+      constexpr int r = 4 - decltype(ic)::value;
+      static_for<r + 1, 6>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        x_root[r] -= Ls[(c * (c - 1)) / 2 + r] * x_root[c];
+      });
+    });
+    // legs: x = y / d - L_c . x_root - sum_{a'' > a} L[a''][a] x_a''
+    T x = y * my_id;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) x -= Lc[r] * x_root[r];
+    {
+      const T x2 = quad_bcast<2>(x);
+      x -= (pos == 1 ? l21 : (pos == 0 ? l20 : T(0))) * x2;
+      const T x1 = quad_bcast<1>(x);
+      x -= (pos == 0 ? l10 : T(0)) * x1;
+    }
+    x_leg = dofl ? x : T(0);
+  };
+
+  // ---- F. forward dynamics qdd = M^-1 (tau - C), integrate_euler_qdd (integrator.hpp:169-181)
+  T qd_new, qdr_new[6];
+  {
+    T br[6], xl, xrt[6];
+    // (the root links are unactuated; their joint stiffness / damping is zero: DevModel::quad)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) br[r] = -Cr[r];
+    solve(dofl ? tau - Cb : T(0), br, xl, xrt);
+    qd_new = qd + xl * dt;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) qdr_new[r] = xr[nq + r] + xrt[r] * dt;
+  }
+
+  // ---- J, K, L. contacts: rows of the penetrating toes (wave-uniform slots: NA = the largest count among the wavefront's
+  //      environments; rows a: normals, NA + a: tangents 1, 2 NA + a: tangents 2, the reference's order under compaction)
+  if (NA > 0) {
+    T *const qdp = E + O.qdp;
+    qdp[lane] = qd_new;
+    QUAD_SYNC();
+    const T *const cpx = E + O.cp;
+    const T *const swl = E + O.swl;
+    const T *const lcw = E + O.lcw;
+    T *const Zs = E + O.Z;
+    T *const rws = E + O.rws;  // [4][12]: b | 1 / (G + cfm) | G | leg
+    T *const xs = E + O.xs;
+    const int nr = 3 * NA;
+    const T cfm = mdl->cfm, erp_dt = mdl->erp_over_dt, rest = mdl->restitution, mu = mdl->friction;
+    {
+      // lane == row
+      const int r = lane < nr ? lane : 0;
+      const int t = (r >= NA ? 1 : 0) + (r >= 2 * NA ? 1 : 0);
+      const int a = r - t * NA;
+      const bool real = lane < nr && a < na;
+      const int ac = a < 4 ? a : 0;
+      const T Pc[3] = {cpx[0 * 4 + ac], cpx[1 * 4 + ac], cpx[2 * 4 + ac]};
+      const T dist = cpx[3 * 4 + ac];
+      const int cl = real ? (int)cpx[4 * 4 + ac] : 0;  // the leg of the row's contact
+      const T e[3] = {t == 0 ? nb[0] : (t == 1 ? t1v[0] : t2v[0]), t == 0 ? nb[1] : (t == 1 ? t1v[1] : t2v[1]),
+                      t == 0 ? nb[2] : (t == 1 ? t1v[2] : t2v[2])};
+      // column of the point Jacobian along e: e . s_lin + P . (e x s_ang)   (jacobian.hpp:56-72)
+      auto jcol = [&](const T *s) -> T {
+        T c[3];
+        cross3(e, s, c);
+        return dot3(e, s + 3) + dot3(Pc, c);
+      };
+      T z[3], zr[6];
+      T vrow = T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        T s[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s[c] = swl[(4 * cl + k) * 7 + c];
+        z[k] = jcol(s);
+        vrow += z[k] * qdp[4 * cl + k];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) {
+        zr[rr] = jcol(axr[rr]);
+        vrow += zr[rr] * qdr_new[rr];
+      }
+      // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1 + e) n.rel_vel - erp dist / dt,  b_t = -t.rel_vel
+      const T brow = t == 0 ? (T(1) + rest) * vrow - erp_dt * dist : vrow;
+      // forward substitution L z = J^T, leaves first: the contact's leg, then the root rows
+      const T *const lf = E + O.legf + cl * 9;
+      const T c10 = lf[0], c20 = lf[1], c21 = lf[2];
+      z[1] -= c10 * z[0];
+      z[2] -= c20 * z[0] + c21 * z[1];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) zr[rr] -= lcw[(4 * cl + k) * QuadLds::LCW + rr] * z[k];
+      }
+      static_for<1, 6>([&](auto rc) {
+        constexpr int rr = decltype(rc)::value;
+        static_for<0, rr>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          zr[rr] -= Ls[(rr * (rr - 1)) / 2 + c] * zr[c];
+        });
+      });
+      // z~ = D^-1/2 z, G = z~ . z~
+      T g = T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        z[k] *= lf[6 + k];
+        g += z[k] * z[k];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) {
+        zr[rr] *= sqrt_t<T>(ids[rr]);
+        g += zr[rr] * zr[rr];
+      }
+      const T ai = real ? rcp_full<T>(g + cfm) : T(0);
+      if (lane < nr) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Zs[lane * QuadLds::ZW + k] = real ? z[k] : T(0);
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) Zs[lane * QuadLds::ZW + 3 + rr] = real ? zr[rr] : T(0);
+        rws[0 * 12 + lane] = real ? brow : T(0);
+        rws[1 * 12 + lane] = ai;
+        rws[2 * 12 + lane] = real ? g : T(0);
+        rws[3 * 12 + lane] = (T)cl;
+      }
+    }
+    QUAD_SYNC();
+    // projected Gauss-Seidel (mb_constraint_solver.hpp:101-142) on u~ = sum_r z~_r x_r: the leg part on the dof lanes, the
+    // root part on every lane
+    T u = T(0), ur[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    const int iters = mdl->pgs_iterations;
+    const T my_leg = (T)leg;
+    for (int it = 0; it < iters; ++it) {
+      for (int r = 0; r < nr; ++r) {
+        const bool is_n = r < NA;
+        const int dep = r - (r >= NA ? NA : 0) - (r >= 2 * NA ? NA : 0);
+        const T zl = (dofl && rws[3 * 12 + r] == my_leg) ? Zs[r * QuadLds::ZW + pos] : T(0);
+        T zrr[6];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) zrr[rr] = Zs[r * QuadLds::ZW + 3 + rr];
+        const T br = rws[0 * 12 + r], ar = rws[1 * 12 + r], gr = rws[2 * 12 + r];
+        const T x_old = it > 0 ? xs[r] : T(0);
+        const T sdep = is_n ? T(0) : xs[dep];
+        T jw = group_sum<T, 16>(zl * u);
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) jw += zrr[rr] * ur[rr];
+        const T delta = jw - gr * x_old;
+        T xn = (br - delta) * ar;
+        const T sc = sdep < T(0) ? T(0) : sdep;  // where_lt(s, 0, 0, s)
+        const T lo = is_n ? T(0) : -mu * sc;
+        const T hi = is_n ? T(100000) : mu * sc;
+        xn = max_t<T>(xn, lo);
+        xn = min_t<T>(xn, hi);
+        const T dx = xn - x_old;
+        u += zl * dx;
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) ur[rr] += zrr[rr] * dx;
+        xs[r] = xn;
+        QUAD_SYNC();
+      }
+    }
+    // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
+    {
+      T w = dofl ? u * sqrt_t<T>(my_id) : T(0);
+      T wr[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) wr[r] = ur[r] * sqrt_t<T>(ids[r]);
+      static_for<0, 5>([&](auto ic) {
+        constexpr int r = 4 - decltype(ic)::value;
+        static_for<r + 1, 6>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          wr[r] -= Ls[(c * (c - 1)) / 2 + r] * wr[c];
+        });
+      });
+#pragma unroll
+      for (int r = 0; r < 6; ++r) w -= Lc[r] * wr[r];
+      {
+        const T w2 = quad_bcast<2>(w);
+        w -= (pos == 1 ? l21 : (pos == 0 ? l20 : T(0))) * w2;
+        const T w1 = quad_bcast<1>(w);
+        w -= (pos == 0 ? l10 : T(0)) * w1;
+      }
+      qd_new -= dofl ? w : T(0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) qdr_new[r] -= wr[r];
+    }
+  }
+
+  // ---- M. integrate_euler: q += qd dt (integrator.hpp:126-131); the new state into the LDS record
+  QUAD_SYNC();
+  {
+    const T q_old0 = xr[0];
+    // root coordinates: lane r < 6 stores root value r
+    T qr_sel = qdr_new[0];
+#pragma unroll
+    for (int r = 1; r < 6; ++r) qr_sel = lane == r ? qdr_new[r] : qr_sel;
+    const T qn_root = xr[lane < 6 ? lane : 0] + qr_sel * dt;
+    QUAD_SYNC();
+    if (lane < 6) {
+      xr[lane] = qn_root;
+      xr[nq + lane] = qr_sel;
+    }
+    if (dofl) {
+      xr[dq] = q + qd_new * dt;
+      xr[nq + dq] = qd_new;
+    }
+    if (lane == 0) xr[in_dim] = q_old0;  // x_{t-1} (the Ant's reward reads it; kept for the record's sake)
+  }
+  QUAD_SYNC();
+  // ---- y record: q | qd | (visual poses: M1) | up.z | zero padding
+  if (valid && yo != nullptr) {
+    for (int i = lane; i < nq + nd; i += 16) yo[i] = (TR)xr[i];
+    int tail = nq + nd;
+    if (mdl->pack_visuals) {
+      tail += 7 * nv;
+      if (lane == 0) yo[tail] = (TR)(mdl->base_R[8]);  // up_dot_world_z (fixed base)
+      tail += 1;
+    }
+    for (int i = tail + lane; i < ystr; i += 16) yo[i] = TR(0);
+  }
+  // ---- N. reward / done (laikago_environment2.h:130-171; ant_environment2.h:75-106)
+  {
+    T rs = T(0), rc = T(1);
+    sincos_t<T>(lane < 3 ? xr[3 + lane] * T(0.5) : T(0), &rs, &rc);
+    const T s1 = dpp_bcast<1>(rs), c1 = dpp_bcast<1>(rc), s2 = dpp_bcast<2>(rs), c2 = dpp_bcast<2>(rc);
+    if (lane == 0) {
+      bool done = false;
+      T reward = T(0);
+      const int rm = mdl->reward_mode;
+      if (rm == TDS_REWARD_ANT) {
+        const T vel_x = (xr[0] - xr[in_dim]) / dt;
+        done = xr[2] < T(0.26);
+        reward = done ? T(0) : vel_x;
+      } else if (rm == TDS_REWARD_LAIKAGO) {
+        const T sp = rs, cp = rc, st = s1, ct = c1, ss = s2, cs2 = c2;
+        const T qx = sp * ct * cs2 - cp * st * ss;
+        const T qy = cp * st * cs2 + sp * ct * ss;
+        const T qz = cp * ct * ss - sp * st * cs2;
+        const T qw = cp * ct * cs2 + sp * st * ss;
+        const T sq = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+        const T up = T(1) - (qx * (qx * sq) + qy * (qy * sq));
+        done = (up < T(0.6)) || (xr[2] < T(0.2));
+        reward = done ? T(0) : xr[0];
+      }
+      if (obs_out != nullptr && valid) {
+        TR *const ob = obs_out + (size_t)env * (nq + nd + 2);
+        ob[nq + nd] = (TR)reward;
+        ob[nq + nd + 1] = done ? TR(1) : TR(0);
+      }
+      xr[in_dim + 1] = done ? T(1) : T(0);
+    }
+  }
+  QUAD_SYNC();
+  // ---- observation (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288) and resident state; with the reset pool
+  //      (ctl.pool) a done environment takes its next pre-settled state instead (ars_vectorized_environment.h:262-277)
+  if (valid) {
+    const TR *src = nullptr;
+    if (ctl.pool != nullptr && xr[in_dim + 1] != T(0)) {
+      const unsigned c = ctl.reset_count[env];
+      src = (const TR *)ctl.pool + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
+    }
+    for (int i = lane; i < nq + nd; i += 16) {
+      const TR vv = src != nullptr ? src[i] : (TR)xr[i];
+      if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? TR(0) : vv;
+      if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = vv;
+    }
+    if (src != nullptr) {
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) ctl.reset_count[env] = ctl.reset_count[env] + 1u;
+    }
+  }
+}
+
+}  // namespace
+
+// LDS bytes of one environment of the quadruped kernel
+template <typename T>
+int tds_quad_lds_bytes(int input_dim) {
+  return quad_layout(input_dim).stride * (int)sizeof(T);
+}
+template int tds_quad_lds_bytes<double>(int);
+template int tds_quad_lds_bytes<float>(int);
+
+template <typename T, typename TR>
+int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
+                    TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl) {
+  const QuadOff O = quad_layout(h_model.input_dim);
+  const int blocks = (n_envs + 3) / 4;
+  const size_t shmem = (size_t)O.stride * 4 * sizeof(T);
+  hipLaunchKernelGGL((tds_quad_kernel<T, TR>), dim3(blocks), dim3(64), shmem, stream, d_model, x_in, y_out, actions, x_feedback,
+                     obs_out, ctl, n_envs, O);
+  return (int)hipGetLastError();
+}
+template int tds_launch_quad<double, double>(const DevModel<double> *, const DevModel<double> &, const double *, double *,
+                                             const double *, double *, double *, int, hipStream_t, const TdsStepCtl &);
+template int tds_launch_quad<double, float>(const DevModel<double> *, const DevModel<double> &, const float *, float *,
+                                            const float *, float *, float *, int, hipStream_t, const TdsStepCtl &);
+template int tds_launch_quad<float, float>(const DevModel<float> *, const DevModel<float> &, const float *, float *,
+                                           const float *, float *, float *, int, hipStream_t, const TdsStepCtl &);

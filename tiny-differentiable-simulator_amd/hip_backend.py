@@ -143,6 +143,7 @@ EXPORTED_SYMBOLS = [
     "tds_hip_shard_local_envs", "tds_hip_shard_first_env", "tds_hip_shard_wire_bytes", "tds_hip_shard_set_block",
     "tds_hip_shard_step", "tds_hip_shard_step_many", "tds_hip_shard_step_many_prepare", "tds_hip_shard_group_step", "tds_hip_shard_flush", "tds_hip_shard_gathered", "tds_hip_shard_gathered_step",
     "tds_hip_shard_ring_plan", "tds_hip_shard_gathered_offset", "tds_hip_shard_exchange_form", "tds_hip_shard_peer_count",
+    "tds_hip_single_step_kernel",
     "tds_rb_last_error", "tds_rb_create", "tds_rb_destroy", "tds_rb_set_stream", "tds_rb_state_device",
     "tds_rb_set_state", "tds_rb_get_state", "tds_rb_step",
 ]
@@ -266,7 +267,7 @@ class HipSim:
             create_opts["na_cap"] = na_cap
         if options:  # create-time options go through the process defaults, run-time ones are set on the new handle
             ct = ("lanes_per_env", "na_cap", "w2", "gram", "no_chain", "no_rootjoint", "no_kinchain", "no_eulerroot",
-                  "no_legscan", "fold_fixed")
+                  "no_legscan", "fold_fixed", "quad")
             create_opts.update({k: v for k, v in options.items() if k in ct})
         h = C.c_void_p()
         with default_options(**create_opts):
@@ -623,6 +624,13 @@ class HipSim:
                      last_wg_end_wall_us=(st[27] - st[23]) / 100.0,
                      wg_start_us=[(v - st[23]) / 100.0 for v in st[28::2]], wg_end_us=[(v - st[23]) / 100.0 for v in st[29::2]])
         return [v - t0 for v in st[:14]], [v - t0 for v in st[14:23]], extra
+
+    def single_step_kernel(self):
+        """which kernel a plain single step runs: ("general" | "quad16", lanes per environment, LDS bytes per environment)"""
+        a, b = C.c_int(), C.c_int()
+        lib().tds_hip_single_step_kernel.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        k = lib().tds_hip_single_step_kernel(self.h, C.byref(a), C.byref(b))
+        return ("quad16" if k == 1 else "general"), a.value, b.value
 
     def kernel_info(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
