@@ -380,7 +380,10 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
     const int o = __shfl_xor(NA, msk, 64);
     NA = o > NA ? o : NA;
   }
-  NA = __builtin_amdgcn_readfirstlane(NA);
+  // (every toe gets its row slots as soon as ANY toe of the wavefront is down: an environment's row -> lane assignment is
+  //  then fixed — lane = 4 t + leg order — and its result cannot depend on its wavefront-mates' contact counts, bit for bit;
+  //  a standing robot has its four toes down anyway)
+  NA = __builtin_amdgcn_readfirstlane(NA) > 0 ? 4 : 0;
 
   // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
   //          my link's (DevModel::quad checks the order); visual 0 — the root body's — goes out on the toe lane of leg 3
@@ -489,9 +492,13 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
   {
     const T head = pos == 0 ? T(1) : T(0);
     auto legs_total = [&](T x) -> T {
+      // (rotation by 8 FIRST: legs l and l + 2 then hold the same pair sum, and the second round adds the same two pair
+      //  sums on every leg — IEEE addition is commutative, not associative: with 4 before 8 the legs' totals differed in
+      //  the last bit, and with them everything "redundant on every lane" behind this line: an environment's result then
+      //  depended on which lane solved its constraint rows, i.e. on its wavefront-mates' contact counts)
       T s = head * x;
-      s = dpp_add<0x124>(s);  // row_ror:4
-      s = dpp_add<0x128>(s);  // row_ror:8   (lanes of position 0 now hold the sum over the four legs)
+      s = dpp_add<0x128>(s);  // row_ror:8
+      s = dpp_add<0x124>(s);  // row_ror:4   (lanes of position 0 now hold the sum over the four legs)
       return quad_bcast<0>(s);
     };
 #pragma unroll
