@@ -380,10 +380,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
     const int o = __shfl_xor(NA, msk, 64);
     NA = o > NA ? o : NA;
   }
-  // (every toe gets its row slots as soon as ANY toe of the wavefront is down: an environment's row -> lane assignment is
-  //  then fixed — lane = 4 t + leg order — and its result cannot depend on its wavefront-mates' contact counts, bit for bit;
-  //  a standing robot has its four toes down anyway)
-  NA = __builtin_amdgcn_readfirstlane(NA) > 0 ? 4 : 0;
+  NA = __builtin_amdgcn_readfirstlane(NA);
 
   // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
   //          my link's (DevModel::quad checks the order); visual 0 — the root body's — goes out on the toe lane of leg 3
@@ -734,11 +731,13 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
     const int nr = 3 * NA;
     const T cfm = mdl->cfm, erp_dt = mdl->erp_over_dt, rest = mdl->restitution, mu = mdl->friction;
     {
-      // lane == row
-      const int r = lane < nr ? lane : 0;
-      const int t = (r >= NA ? 1 : 0) + (r >= 2 * NA ? 1 : 0);
-      const int a = r - t * NA;
-      const bool real = lane < nr && a < na;
+      // lane == row, CONTACT-major: lane 3 a + t solves row t (normal, tangent 1, tangent 2) of contact slot a and stores it
+      // at index 3 a + t — an assignment that does not depend on NA, i.e. on the wavefront-mates' contact counts (with the
+      // kind-major index t NA + a of the sweep's order an environment's rows moved to other lanes when a mate had more
+      // contacts: bit-level differences, caught by the permutation test of tests/test_hip_parity.py)
+      const int a = (lane * 11) >> 5;  // lane / 3 for lane < 16
+      const int t = lane - 3 * a;
+      const bool real = a < na;        // (lanes 12 .. 15: a == 4, never real)
       const int ac = a < 4 ? a : 0;
       const T Pc[3] = {cpx[0 * 4 + ac], cpx[1 * 4 + ac], cpx[2 * 4 + ac]};
       const T dist = cpx[3 * 4 + ac];
@@ -798,7 +797,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
         g += zr[rr] * zr[rr];
       }
       const T ai = real ? rcp_full<T>(g + cfm) : T(0);
-      if (lane < nr) {
+      if (lane < 12) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) Zs[lane * QuadLds::ZW + k] = real ? z[k] : T(0);
 #pragma unroll
@@ -816,9 +815,13 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
     const int iters = mdl->pgs_iterations;
     const T my_leg = (T)leg;
     for (int it = 0; it < iters; ++it) {
-      for (int r = 0; r < nr; ++r) {
-        const bool is_n = r < NA;
-        const int dep = r - (r >= NA ? NA : 0) - (r >= 2 * NA ? NA : 0);
+      // the reference's row order: normals, tangents 1, tangents 2, each by contact (rows live at 3 a + t)
+      for (int rr_ = 0; rr_ < nr; ++rr_) {
+        const int tk = (rr_ >= NA ? 1 : 0) + (rr_ >= 2 * NA ? 1 : 0);
+        const int ak = rr_ - tk * NA;
+        const int r = 3 * ak + tk;
+        const bool is_n = tk == 0;
+        const int dep = 3 * ak;
         const T zl = (dofl && rws[3 * 12 + r] == my_leg) ? Zs[r * QuadLds::ZW + pos] : T(0);
         T zrr[6];
 #pragma unroll
