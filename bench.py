@@ -211,6 +211,10 @@ def main():
     ap.add_argument("--auto-reset", action="store_true",
                     help="secondary workload (N = 1): auto_reset_when_done on — every step resets the environments it "
                          "ends with done (reset distribution + settle steps), through the reset pool")
+    ap.add_argument("--action-amp", type=float, default=-1.0,
+                    help="amplitude of the uniform random actions; default: 0.4 (the reference's ACTION_LIMIT, SURVEY 8d) for the "
+                         "Ant and for every model when --auto-reset is on (fallen robots are reset, as in the reference's metric "
+                         "loop), 0.1 for the legged robots that can fall over when nothing resets them")
     ap.add_argument("--rollout-steps", type=int, default=0,
                     help="also time the on-device policy rollout (tds_hip_rollout) with this many policy steps per call")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (pure wall clock)")
@@ -400,7 +404,9 @@ def run(args, n, rank, local_rank, world, secondary, config5):
     # (Laikago, humanoid): the reference has no joint limits, a fallen robot driven by +-0.4 random actions blows up
     # numerically within ~1000 steps (tools/laikago_stability.py: 0 / 0 / 6 / 25 of 8192 non-finite after 600 / 800 / 1000 /
     # 1200 steps at +-0.4, none at +-0.1) — the metric loop of the reference would have reset it long before
-    amp = (0.4 if args.model.startswith("ant") else 0.1) if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
+    amp = (0.4 if (args.model.startswith("ant") or auto_reset) else 0.1) if m.step_mode == tds_amd.TDS_STEP_LOCOMOTION else 0.0
+    if args.action_amp >= 0:
+        amp = args.action_amp
     actions = torch.from_numpy(rng.uniform(-amp, amp, (pool, n, adim))).to(tdt).cuda().contiguous()
     obs = torch.zeros((n, sim.obs_dim + 2), dtype=tdt, device="cuda")
     B = max(1, args.gather_every)
