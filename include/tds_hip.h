@@ -362,8 +362,10 @@ int tds_hip_get_option(const tds_hip_sim_t *sim, const char *key, long long *val
 int tds_hip_option_count(void);
 const char *tds_hip_option_name(int index);
 /* 1 if tds_hip_step_many(sim, ..., n_steps, ...) runs as ONE launch of the step-loop kernel instead of graphs: worlds
-   without contact points (pendulums, the cartpole), and fixed-base kernels up to 16 dof with contacts (the Ant) while
-   the batch is at most three rounds of workgroups (12288 Ant environments).  No kernel boundaries; the state stays in
+   without contact points (pendulums, the cartpole), fixed-base kernels up to 16 dof with contacts (the Ant) while
+   the batch is at most three rounds of workgroups (12288 Ant environments); the star-shaped legged robots of
+   tds_hip_single_step_kernel (Laikago) take their 16-lane kernel's own step-loop form when auto-reset is on (or option
+   step_many_loop = 1), the chained graphs of its straight-line form otherwise.  No kernel boundaries; the state stays in
    LDS (in the compute scalar) for the n_steps steps, every step takes its own action block, y / obs / x are written
    once at the end — what the graph form leaves behind too, whose obs_dev is overwritten by every step.  With float
    records the state is rounded to float once per call instead of once per step.

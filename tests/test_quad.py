@@ -129,3 +129,100 @@ def test_quad_closed_loop_of_every_env_against_the_reference(built):
         worst = max(worst, e)
         assert e < 1e-6, (k, e)
     print(f"{name} x{n}, {steps} closed-loop steps on the 16-lane kernel, every env, vs {what}: worst per-step rel err {worst:.3e}")
+
+
+@pytest.mark.parametrize("dtype", ["f64", "mixed"])
+def test_quad_step_loop_form_equals_single_steps(dtype, built):
+    """K steps as ONE launch of the 16-lane kernel's step-loop form (tds_hip_step_many_rings: state in LDS, a fresh action block
+    per step, every step's y and obs records into ring slots that wrap around) against the same K steps as single launches
+    of its straight-line form: every slot, the state and the handle's y record."""
+    torch = _torch()
+    name = "laikago_soft"
+    m = tds_amd.load_model(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n, steps, slots = 2000, 24, 7
+    rng = np.random.default_rng(6)
+    x = g["x"][rng.integers(0, g["x"].shape[0], n)]
+    a = hip_backend.HipSim(m, n, dtype=dtype, options={"step_many_loop": 1})  # (without resets the library's own choice is the graphs)
+    b = hip_backend.HipSim(m, n, dtype=dtype)
+    assert a.step_many_is_loop(steps) and not b.step_many_is_loop(steps) and a.single_step_kernel()[0] == "quad16"
+    tdt = a.torch_dtype
+    for s_ in (a, b):
+        s_.x.copy_(torch.from_numpy(x).to(tdt).cuda())
+    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (5, n, m.action_dim))).to(tdt).cuda().contiguous()
+    obs_ring = torch.zeros((slots, n, a.obs_dim + 2), dtype=tdt, device="cuda")
+    y_ring = torch.zeros((steps, n, m.output_dim), dtype=tdt, device="cuda")
+    a.step_many_rings(actions, steps, obs_ring, y_ring, first_block=2, obs_first=4)
+    obs = torch.zeros((n, b.obs_dim + 2), dtype=tdt, device="cuda")
+    tol = 1e-9 if dtype == "f64" else 2e-6
+    nqd = m.dof_q + m.dof_qd
+    if dtype != "f64":
+        # float records: the launch keeps the state in DOUBLE between its steps — its records are the rounded trajectory of the
+        # same launch with double records (single steps would round the state to float after every step: another trajectory)
+        a64 = hip_backend.HipSim(m, n, dtype="f64", options={"step_many_loop": 1})
+        a64.x.copy_(a.x.double() * 0 + torch.from_numpy(x).to(tdt).cuda().double())
+        y64 = torch.zeros((steps, n, m.output_dim), dtype=torch.float64, device="cuda")
+        o64 = torch.zeros((slots, n, a.obs_dim + 2), dtype=torch.float64, device="cuda")
+        a64.step_many_rings(actions.double().contiguous(), steps, o64, y64, first_block=2, obs_first=4)
+        assert rel_err(y_ring.double().cpu().numpy(), y64.cpu().numpy()) < tol
+        assert rel_err(obs_ring.double().cpu().numpy(), o64.cpu().numpy()) < tol
+        assert torch.equal(a.y, y_ring[-1])
+        return
+    for k in range(steps):
+        b.step(actions[(2 + k) % 5], 1, obs)
+        assert rel_err(y_ring[k].double().cpu().numpy(), b.y.double().cpu().numpy()) < tol, k
+        if k >= steps - slots:
+            assert rel_err(obs_ring[(4 + k) % slots].double().cpu().numpy(), obs.double().cpu().numpy()) < tol, k
+    assert rel_err(a.x.double().cpu().numpy(), b.x.double().cpu().numpy()) < tol
+    assert torch.equal(a.y, y_ring[-1])
+    # without rings: the last step's records only (tds_hip_step_many), and substeps with one action (tds_hip_step_obs)
+    for s_ in (a, b):
+        s_.x.copy_(torch.from_numpy(x).to(tdt).cuda())
+    o2 = torch.zeros_like(obs)
+    a.step_many(actions, 9, o2, first_block=1)
+    for k in range(9):
+        if dtype != "f64" and k > 0:
+            pass  # (no per-step record to resync on: compared loosely below)
+        b.step(actions[(1 + k) % 5], 1, obs)
+    lo = 1e-9 if dtype == "f64" else 1e-3
+    assert rel_err(a.x.double().cpu().numpy(), b.x.double().cpu().numpy()) < lo and rel_err(o2.double().cpu().numpy(), obs.double().cpu().numpy()) < lo
+    for s_ in (a, b):
+        s_.x.copy_(torch.from_numpy(x).to(tdt).cuda())
+    a.step(actions[0], 4, o2)
+    for k in range(4):
+        b.step(actions[0], 1, obs)
+    assert rel_err(a.x.double().cpu().numpy(), b.x.double().cpu().numpy()) < lo and rel_err(o2.double().cpu().numpy(), obs.double().cpu().numpy()) < lo
+
+
+def test_quad_step_loop_with_auto_reset_equals_single_steps(built):
+    """auto_reset_when_done inside the 16-lane kernel's step loop (a done environment takes its next pre-settled state from the
+    reset pool and carries on) against single auto-reset steps through the same pool: same random stream, same records —
+    a third of the environments start tilted past the termination threshold, so resets happen from the first step on."""
+    torch = _torch()
+    name = "laikago_soft"
+    m = tds_amd.load_model(name)
+    n, steps = 1024, 40
+    rng = np.random.default_rng(8)
+    from test_rings import _start_state
+
+    x = _start_state(m, name, n, rng)
+    x[: n // 3, 3] = rng.uniform(1.0, 1.3, n // 3)  # roll: up . z < 0.6 -> done
+    a = hip_backend.HipSim(m, n)
+    b = hip_backend.HipSim(m, n)
+    for s_ in (a, b):
+        s_.x.copy_(torch.from_numpy(x).cuda())
+        s_.set_auto_reset(True, 99)
+    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (4, n, m.action_dim))).cuda().contiguous()
+    obs_ring = torch.zeros((steps, n, a.obs_dim + 2), dtype=torch.float64, device="cuda")
+    y_ring = torch.zeros((steps, n, m.output_dim), dtype=torch.float64, device="cuda")
+    a.step_many_rings(actions, steps, obs_ring, y_ring)
+    obs = torch.zeros((n, b.obs_dim + 2), dtype=torch.float64, device="cuda")
+    dones = 0
+    for k in range(steps):
+        b.step(actions[k % 4], 1, obs)
+        dones += int((obs[:, -1] != 0).sum().item())
+        assert (obs_ring[k][:, -1] == obs[:, -1]).all(), k
+        assert rel_err(obs_ring[k].cpu().numpy(), obs.cpu().numpy()) < 1e-9, k
+        assert rel_err(y_ring[k].cpu().numpy(), b.y.cpu().numpy()) < 1e-9, k
+    assert dones >= n // 3
+    assert rel_err(a.x.cpu().numpy(), b.x.cpu().numpy()) < 1e-9

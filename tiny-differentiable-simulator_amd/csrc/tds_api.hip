@@ -1236,6 +1236,13 @@ bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
   // Wider kernels (Laikago, 18 dof) spill in the loop build and stay with the graphs (66 against 49 us).
   const bool plain = !two && !(s->compute_f64() ? s->h64.is_floating : s->h32.is_floating) &&
                      (s->compute_f64() ? s->h64.num_spherical : s->h32.num_spherical) == 0;
+  // the star-shaped legged robots (tds_quad.hip: 246 VGPR, no scratch in its step-loop form): with auto-reset on, the
+  // step-loop form — reset-pool entries taken inside the loop: 2.41e8 at laikago_soft x 8192 against 2.15e8 for single steps
+  // through the pool.  Without resets the chained graphs of its straight-line form are still faster (27 against 35 us per
+  // step, profiles/r05_quad_forms.txt: every iteration of the loop form re-fetches the lane constants from L2 and waits for
+  // the previous step's record stores with them — a constant table in LDS and an action prefetch are what it needs);
+  // option step_many_loop = 1 forces the loop form
+  if (s->compute_f64() && s->h64.quad) return s->auto_reset;
   const int n_blocks = (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
   // With auto-reset on the alternative is not the chained graphs but single steps through the reset pool: the step-loop
   // launches (pool_step_many) win at every batch size (Ant x 16384 / 32768 at 5 % resets per step: 2.81e8 / 2.87e8

@@ -159,10 +159,12 @@ int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
                     TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl);
 template <typename T>
 int tds_quad_lds_bytes(int input_dim);
-// what tds_launch_step hands to it: exactly one plain step, no rings, no profile stamps
+// what tds_launch_step hands to it: plain steps — one per launch, or K of them with action replay, record rings and
+// reset-pool entries taken in the loop (tds_hip_step_many / _rings) —, no in-kernel reset, no policy, no exchange launch
+// (progress counters / peer stores), no profile stamps
 inline bool tds_quad_takes(int quad, const TdsStepCtl &ctl, const long long *prof) {
-  return quad != 0 && prof == nullptr && ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr &&
-         ctl.obs_ring == nullptr && ctl.y_ring == nullptr;
+  return quad != 0 && prof == nullptr && ctl.nsub >= 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr &&
+         ctl.progress == nullptr && ctl.peer_arrive == nullptr;
 }
 
 // T: compute scalar, TR: record scalar (== T, or float under T = double: "f32 records / f64 arithmetic")

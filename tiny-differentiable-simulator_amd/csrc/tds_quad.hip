@@ -30,8 +30,11 @@
 // kernel when its model is such a star (DevModel::quad, tds_device_model.h) and option quad is not 0; option quad = 0
 // keeps the general kernel, and tests/test_quad.py holds the two against each other and against the reference.
 //
-// Straight-line form: one step per launch (what the chained hipGraphs of tds_hip_step_many replay), incl. the reset
-// pool's "done environment takes its next pre-settled state" tail.  Reference files as in tds_kernels.hip.
+// Two forms (template parameter LOOP): one step per launch, and K steps per launch with the state in LDS, a fresh action block
+// per step, per-step record rings and the reset pool's "done environment takes its next pre-settled state" inside the loop —
+// what tds_hip_step_many / _rings run for this model.  In-kernel reset + settle, substeps with one action, on-device
+// rollouts and the exchange launches of the multi-GPU layer stay with the general kernel.  Reference files as in
+// tds_kernels.hip.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -71,6 +74,28 @@ struct QuadLds {
 struct QuadOff {
   int lcw, legf, swl, qdp, S, ax, Z, rws, xs, cp, stride;
 };
+// the kernel's parameter list as a struct: the layout of its kernel-argument segment (see TdsKernArgs in tds_kernels.hip)
+struct QuadKernArgs {
+  const void *mdl, *x_in;
+  void *y_out;
+  const void *actions;
+  void *x_feedback, *obs_out;
+  TdsStepCtl ctl;
+  int n_envs;
+  QuadOff O;
+};
+template <bool LOOP>
+struct QuadCtlRef {
+  using type = const TdsStepCtl &;
+  static __device__ __forceinline__ type get(const TdsStepCtl &param, const __attribute__((address_space(4))) char *) { return param; }
+};
+template <>
+struct QuadCtlRef<true> {
+  using type = const __attribute__((address_space(4))) TdsStepCtl &;
+  static __device__ __forceinline__ type get(const TdsStepCtl &, const __attribute__((address_space(4))) char *at) {
+    return *(const __attribute__((address_space(4))) TdsStepCtl *)at;
+  }
+};
 __host__ __device__ inline QuadOff quad_layout(int in_dim) {
   QuadOff o;
   int at = in_dim + 4;
@@ -89,15 +114,40 @@ __host__ __device__ inline QuadOff quad_layout(int in_dim) {
   return o;
 }
 
-template <typename T, typename TR>
+// LOOP = false: one step per launch.  LOOP = true: ctl.nsub steps in ONE launch with the state in the LDS record between them
+// (tds_hip_step_many / _rings for this model): a fresh action block per step (ctl.act_pool), every step's y and
+// [obs | reward | done] records into ring slots (ctl.y_ring / obs_ring) — or the last step's only —, a done environment
+// taking its next pre-settled state from the reset pool inside the loop (ctl.pool).  As in the general kernel's step-loop
+// builds nothing but the loop state lives across an iteration: the model pointer and the kernel-argument segment are
+// laundered per iteration, so the lane constants and the ctl fields are loaded where an iteration uses them.
+template <typename T, typename TR, bool LOOP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
-void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__restrict__ y_out,
+void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
                      const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */, TR *__restrict__ obs_out,
-                     TdsStepCtl ctl, int n_envs, QuadOff O) {
+                     TdsStepCtl ctl_arg, int n_envs, QuadOff O) {
   extern __shared__ __align__(16) unsigned char tds_quad_smem[];
   T *const sm = reinterpret_cast<T *>(tds_quad_smem);
-  const int lane = threadIdx.x & 15;
-  const int grp = (threadIdx.x & 63) >> 4;
+  constexpr int nq = 18, nd = 18;
+  {
+    // ---- A. x record -> LDS (coalesced), fresh actions over the action slice
+    const int lane = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4, env = blockIdx.x * 4 + grp;
+    const bool valid = env < n_envs;
+    T *const xr = sm + grp * O.stride;
+    const int in_dim = mdl_arg->input_dim, adim = mdl_arg->action_dim;
+    for (int i = lane; i < in_dim; i += 16) {
+      const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
+      xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+    }
+  }
+  const int nsteps = LOOP ? ctl_arg.nsub : 1;
+  for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
+  // (nothing but `it` lives across an iteration: lane, model pointer and kernel-argument segment are laundered)
+  const DevModel<T> *mdl = mdl_arg;
+  const __attribute__((address_space(4))) char *ka_seg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+  int tid = threadIdx.x;
+  if constexpr (LOOP) asm volatile("" : "+s"(mdl), "+s"(ka_seg), "+v"(tid));
+  const int lane = tid & 15;
+  const int grp = (tid & 63) >> 4;
   const int env = blockIdx.x * 4 + grp;
   const bool valid = env < n_envs;
   T *const E = sm + grp * O.stride;
@@ -106,31 +156,29 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
   const int li = 6 + lane;            // my link
   const bool dofl = pos < 3;          // my link carries a dof (the toe's joint is fixed)
   const int dq = 6 + 3 * leg + pos;   // ... this one, in the q / qd records (nq == nd == 18)
-  constexpr int nq = 18, nd = 18;
   const int in_dim = mdl->input_dim, adim = mdl->action_dim;
+  // (kernel-argument segment: mdl 0 | x_in 8 | y_out 16 | actions 24 | x_feedback 32 | obs_out 40 | ctl 48: see QuadKernArgs)
+  typename QuadCtlRef<LOOP>::type ctl = QuadCtlRef<LOOP>::get(ctl_arg, ka_seg + __builtin_offsetof(QuadKernArgs, ctl));
   const T dt = mdl->dt;
-
-  // ---- A. x record -> LDS (coalesced), fresh actions over the action slice
-  for (int i = lane; i < in_dim; i += 16) {
-    const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
-    xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+  const bool last = it == nsteps - 1;
+  if constexpr (LOOP) {
+    // the action block of this step (step 0's came in with the record): block (act_first + it) % act_blocks of the pool
+    if (it > 0 && ctl.act_pool != nullptr) {  // wave-uniform
+      const int blk = (ctl.act_first + it) % ctl.act_blocks;
+      if (valid && lane < adim) xr[nq + nd + lane] = (T)((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
+    }
   }
   // lane constants (issued under the latency of the record)
   const int jt = mdl->joint_type[li];
   const int act_i = mdl->act_index[li];
   const T init_pose_l = mdl->init_pose[li], stiff_l = mdl->stiffness[li], damp_l = mdl->damping[li];
-  T Sl[6], RT[9], tT[3], Il[9], com_l[3];
+  T Sl[6], RT[9], tT[3];
 #pragma unroll
   for (int k = 0; k < 6; ++k) Sl[k] = mdl->S[k][li];
 #pragma unroll
   for (int k = 0; k < 9; ++k) RT[k] = mdl->X_T[k][li];
 #pragma unroll
   for (int k = 0; k < 3; ++k) tT[k] = mdl->X_T[9 + k][li];
-  const T mass_l = mdl->mass[li];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) com_l[k] = mdl->com[k][li];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) Il[k] = mdl->inertia[k][li];
   const T act_lim = mdl->action_limit;
   QUAD_SYNC();
   const T q = dofl ? xr[dq] : T(0);
@@ -344,72 +392,6 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
     for (int k = 0; k < 6; ++k) swl[lane * 7 + k] = sw[k];
   }
 
-  // ---- I. narrowphase: the contact points are the toes' own lanes (plane x sphere, contact_point.hpp:96-131)
-  const T nb[3] = {mdl->nb[0], mdl->nb[1], mdl->nb[2]};
-  const T t1v[3] = {mdl->t1[0], mdl->t1[1], mdl->t1[2]};
-  const T t2v[3] = {mdl->t2[0], mdl->t2[1], mdl->t2[2]};
-  int na = 0;
-  {
-    T *const cpx = E + O.cp;
-    const T rad = mdl->cp_radius[leg];
-    const T loc[3] = {mdl->cp_local[0][leg], mdl->cp_local[1][leg], mdl->cp_local[2][leg]};
-    T ctr[3];
-    mat3_mulv(R, loc, ctr);
-    ctr[0] += p[0];
-    ctr[1] += p[1];
-    ctr[2] += p[2];
-    const T n[3] = {mdl->plane_n[0], mdl->plane_n[1], mdl->plane_n[2]};
-    const T t = -((-dot3(ctr, n)) + mdl->plane_c);
-    const T dist = t - rad;
-    const bool act = valid && pos == 3 && dist < T(0);
-    const unsigned long long bal = __ballot(act);
-    const unsigned mine = (unsigned)((bal >> (grp * 16)) & 0xFFFFull);
-    const int pre = __popc(mine & ((1u << lane) - 1u));
-    if (act) {
-      cpx[0 * 4 + pre] = ctr[0] - rad * n[0];
-      cpx[1 * 4 + pre] = ctr[1] - rad * n[1];
-      cpx[2 * 4 + pre] = ctr[2] - rad * n[2];
-      cpx[3 * 4 + pre] = dist;
-      cpx[4 * 4 + pre] = (T)leg;
-    }
-    na = __popc(mine);
-  }
-  int NA = na;
-#pragma unroll
-  for (int msk = 16; msk < 64; msk <<= 1) {
-    const int o = __shfl_xor(NA, msk, 64);
-    NA = o > NA ? o : NA;
-  }
-  NA = __builtin_amdgcn_readfirstlane(NA);
-
-  // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
-  //          my link's (DevModel::quad checks the order); visual 0 — the root body's — goes out on the toe lane of leg 3
-  const int ystr = ctl.y_stride;
-  TR *const yo = y_out != nullptr ? y_out + (size_t)env * ystr : nullptr;
-  const int nv = mdl->num_visuals;
-  if (valid && yo != nullptr && nv > 0) {
-    auto pose_out = [&](const T *Rl, const T *pl, int k) {
-      T Rv[9], pv[3], Ro[9], po[3], qo[4];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) Rv[c] = mdl->vis_X[c][k];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) pv[c] = mdl->vis_X[9 + c][k];
-      mat3_mul(Rl, Rv, Ro);
-      mat3_mulv(Rl, pv, po);
-      matrix_to_quat(Ro, qo);
-      TR *o = yo + (nq + nd) + 7 * k;
-      o[0] = (TR)(pl[0] + po[0]);
-      o[1] = (TR)(pl[1] + po[1]);
-      o[2] = (TR)(pl[2] + po[2]);
-      o[3] = (TR)qo[0];
-      o[4] = (TR)qo[1];
-      o[5] = (TR)qo[2];
-      o[6] = (TR)qo[3];
-    };
-    pose_out(R, p, 1 + lane);
-    if (lane == 15) pose_out(R5, P, 0);
-  }
-
   // ---- D. world-frame rigid inertia and bias force of my link, and (redundantly on every lane) of the root body
   //         (kinematics.hpp:96-132, inertia.hpp:121-130): I = (Isym 6 | h 3 | m), f = I a0 + v x* I v
   auto rigid = [&](const T *Rl, const T *pl, T m, const T *com, const T *Ib, const T *vl, const T *al, T *Ic, T *fc) {
@@ -465,15 +447,115 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
 #pragma unroll
     for (int k = 0; k < 6; ++k) fc[k] += Ia[k];
   };
+  // ---- I. narrowphase: the contact points are the toes' own lanes (plane x sphere, contact_point.hpp:96-131)
+  int na = 0;
+  {
+    T *const cpx = E + O.cp;
+    const T rad = mdl->cp_radius[leg];
+    const T loc[3] = {mdl->cp_local[0][leg], mdl->cp_local[1][leg], mdl->cp_local[2][leg]};
+    T ctr[3];
+    mat3_mulv(R, loc, ctr);
+    ctr[0] += p[0];
+    ctr[1] += p[1];
+    ctr[2] += p[2];
+    const T n[3] = {mdl->plane_n[0], mdl->plane_n[1], mdl->plane_n[2]};
+    const T t = -((-dot3(ctr, n)) + mdl->plane_c);
+    const T dist = t - rad;
+    const bool act = valid && pos == 3 && dist < T(0);
+    const unsigned long long bal = __ballot(act);
+    const unsigned mine = (unsigned)((bal >> (grp * 16)) & 0xFFFFull);
+    const int pre = __popc(mine & ((1u << lane) - 1u));
+    if (act) {
+      cpx[0 * 4 + pre] = ctr[0] - rad * n[0];
+      cpx[1 * 4 + pre] = ctr[1] - rad * n[1];
+      cpx[2 * 4 + pre] = ctr[2] - rad * n[2];
+      cpx[3 * 4 + pre] = dist;
+      cpx[4 * 4 + pre] = (T)leg;
+    }
+    na = __popc(mine);
+  }
+  int NA = na;
+#pragma unroll
+  for (int msk = 16; msk < 64; msk <<= 1) {
+    const int o = __shfl_xor(NA, msk, 64);
+    NA = o > NA ? o : NA;
+  }
+  NA = __builtin_amdgcn_readfirstlane(NA);
+
+  // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
+  //          my link's (DevModel::quad checks the order); visual 0 — the root body's — goes out on the toe lane of leg 3
+  // where this step's y record goes: the slot of a y ring (every step of a step-loop launch), else the handle's y record
+  // (the last step); the last step of a ring launch leaves its record in the handle's y record as well
+  const int ystr = ctl.y_stride;
+  const int out_dim = mdl->output_dim;
+  TR *yo = nullptr, *yo2 = nullptr;
+  int yend = ystr, yend2 = out_dim;
+  if (LOOP && ctl.y_ring != nullptr) {
+    yo = (TR *)ctl.y_ring + ((size_t)((ctl.y_first + it) % ctl.y_slots) * ctl.ring_envs + env) * ystr;
+    if (last && y_out != nullptr) yo2 = y_out + (size_t)env * out_dim;
+  } else if (last && y_out != nullptr) {
+    yo = y_out + (size_t)env * (LOOP ? out_dim : ystr);
+    yend = LOOP ? out_dim : ystr;
+  }
+  const int nv = mdl->num_visuals;
+  if (valid && yo != nullptr && nv > 0) {
+    const DevModel<T> *md3 = mdl;  // (see the rigid inertia above: the visuals' constants are fetched where they are used)
+    asm volatile("" : "+s"(md3));
+    auto pose_out = [&](const T *Rl, const T *pl, int k) {
+      T Rv[9], pv[3], Ro[9], po[3], qo[4];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) Rv[c] = md3->vis_X[c][k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pv[c] = md3->vis_X[9 + c][k];
+      mat3_mul(Rl, Rv, Ro);
+      mat3_mulv(Rl, pv, po);
+      matrix_to_quat(Ro, qo);
+      TR *o = yo + (nq + nd) + 7 * k;
+      o[0] = (TR)(pl[0] + po[0]);
+      o[1] = (TR)(pl[1] + po[1]);
+      o[2] = (TR)(pl[2] + po[2]);
+      o[3] = (TR)qo[0];
+      o[4] = (TR)qo[1];
+      o[5] = (TR)qo[2];
+      o[6] = (TR)qo[3];
+      if (yo2 != nullptr) {
+        TR *o2 = yo2 + (nq + nd) + 7 * k;
+        o2[0] = (TR)(pl[0] + po[0]);
+        o2[1] = (TR)(pl[1] + po[1]);
+        o2[2] = (TR)(pl[2] + po[2]);
+        o2[3] = (TR)qo[0];
+        o2[4] = (TR)qo[1];
+        o2[5] = (TR)qo[2];
+        o2[6] = (TR)qo[3];
+      }
+    };
+    pose_out(R, p, 1 + lane);
+    if (lane == 15) pose_out(R5, P, 0);
+  }
+
   T Ic[10], fc[6];
-  rigid(R, p, mass_l, com_l, Il, v, a0, Ic, fc);
+  {
+    // (my link's rigid inertia is fetched HERE, through a pointer laundered at this point: requested at the top of the step
+    //  "under the latency of the record" the scheduler kept 13 values alive — or spilled — through the kinematics)
+    const DevModel<T> *md2 = mdl;
+    asm volatile("" : "+s"(md2));
+    T Il[9], com_l[3];
+    const T mass_l = md2->mass[li];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) com_l[k] = md2->com[k][li];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Il[k] = md2->inertia[k][li];
+    rigid(R, p, mass_l, com_l, Il, v, a0, Ic, fc);
+  }
   T It[10], ft[6];  // the root body's; below: + the legs' composites = the whole robot's
   {
-    const T com5[3] = {mdl->com[0][5], mdl->com[1][5], mdl->com[2][5]};
+    const DevModel<T> *md4 = mdl;
+    asm volatile("" : "+s"(md4));
+    const T com5[3] = {md4->com[0][5], md4->com[1][5], md4->com[2][5]};
     T I5[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) I5[k] = mdl->inertia[k][5];
-    rigid(R5, P, mdl->mass[5], com5, I5, v5, a5, It, ft);
+    for (int k = 0; k < 9; ++k) I5[k] = md4->inertia[k][5];
+    rigid(R5, P, md4->mass[5], com5, I5, v5, a5, It, ft);
   }
 
   // ---- E. composite inertia / bias force (CRBA, mass_matrix.hpp:39-56): suffix sums along every quad; the chain heads'
@@ -729,7 +811,12 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
     T *const rws = E + O.rws;  // [4][12]: b | 1 / (G + cfm) | G | leg
     T *const xs = E + O.xs;
     const int nr = 3 * NA;
-    const T cfm = mdl->cfm, erp_dt = mdl->erp_over_dt, rest = mdl->restitution, mu = mdl->friction;
+    const DevModel<T> *md5 = mdl;  // (the contact frame and the solver's scalars are fetched here, not at the top of the step)
+    asm volatile("" : "+s"(md5));
+    const T nb[3] = {md5->nb[0], md5->nb[1], md5->nb[2]};
+    const T t1v[3] = {md5->t1[0], md5->t1[1], md5->t1[2]};
+    const T t2v[3] = {md5->t2[0], md5->t2[1], md5->t2[2]};
+    const T cfm = md5->cfm, erp_dt = md5->erp_over_dt, rest = md5->restitution, mu = md5->friction;
     {
       // lane == row, CONTACT-major: lane 3 a + t solves row t (normal, tangent 1, tangent 2) of contact slot a and stores it
       // at index 3 a + t — an assignment that does not depend on NA, i.e. on the wavefront-mates' contact counts (with the
@@ -812,7 +899,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
     // projected Gauss-Seidel (mb_constraint_solver.hpp:101-142) on u~ = sum_r z~_r x_r: the leg part on the dof lanes, the
     // root part on every lane
     T u = T(0), ur[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-    const int iters = mdl->pgs_iterations;
+    const int iters = md5->pgs_iterations;
     const T my_leg = (T)leg;
     for (int it = 0; it < iters; ++it) {
       // the reference's row order: normals, tangents 1, tangents 2, each by contact (rows live at 3 a + t)
@@ -897,14 +984,18 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
   QUAD_SYNC();
   // ---- y record: q | qd | (visual poses: M1) | up.z | zero padding
   if (valid && yo != nullptr) {
-    for (int i = lane; i < nq + nd; i += 16) yo[i] = (TR)xr[i];
-    int tail = nq + nd;
-    if (mdl->pack_visuals) {
-      tail += 7 * nv;
-      if (lane == 0) yo[tail] = (TR)(mdl->base_R[8]);  // up_dot_world_z (fixed base)
-      tail += 1;
-    }
-    for (int i = tail + lane; i < ystr; i += 16) yo[i] = TR(0);
+    auto y_state = [&](TR *y, int end) {
+      for (int i = lane; i < nq + nd; i += 16) y[i] = (TR)xr[i];
+      int tail = nq + nd;
+      if (mdl->pack_visuals) {
+        tail += 7 * nv;
+        if (lane == 0) y[tail] = (TR)(mdl->base_R[8]);  // up_dot_world_z (fixed base)
+        tail += 1;
+      }
+      for (int i = tail + lane; i < end; i += 16) y[i] = TR(0);
+    };
+    y_state(yo, yend);
+    if (yo2 != nullptr) y_state(yo2, yend2);
   }
   // ---- N. reward / done (laikago_environment2.h:130-171; ant_environment2.h:75-106)
   {
@@ -930,33 +1021,54 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl, const TR *x_in, TR *__
         done = (up < T(0.6)) || (xr[2] < T(0.2));
         reward = done ? T(0) : xr[0];
       }
-      if (obs_out != nullptr && valid) {
-        TR *const ob = obs_out + (size_t)env * (nq + nd + 2);
-        ob[nq + nd] = (TR)reward;
-        ob[nq + nd + 1] = done ? TR(1) : TR(0);
-      }
       xr[in_dim + 1] = done ? T(1) : T(0);
+      xr[in_dim + 2] = reward;
     }
   }
   QUAD_SYNC();
-  // ---- observation (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288) and resident state; with the reset pool
-  //      (ctl.pool) a done environment takes its next pre-settled state instead (ars_vectorized_environment.h:262-277)
+  // ---- auto_reset_when_done through the reset pool (ctl.pool; ars_vectorized_environment.h:262-277): a done environment
+  //      takes its next pre-settled state — y, reward and done describe the terminal step, the observation and the state
+  //      the fresh environment
+  if (ctl.pool != nullptr && valid && xr[in_dim + 1] != T(0)) {
+    const unsigned c = ctl.reset_count[env];
+    const TR *const src = (const TR *)ctl.pool + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
+    T v0 = T(0), v1 = T(0), v2 = T(0);
+    if (lane < nq + nd) v0 = (T)src[lane];
+    if (lane + 16 < nq + nd) v1 = (T)src[lane + 16];
+    if (lane + 32 < nq + nd) v2 = (T)src[lane + 32];
+    QUAD_SYNC();
+    if (lane < nq + nd) xr[lane] = v0;
+    if (lane + 16 < nq + nd) xr[lane + 16] = v1;
+    if (lane + 32 < nq + nd) xr[lane + 32] = v2;
+    if (lane == 0) ctl.reset_count[env] = c + 1u;
+  }
+  QUAD_SYNC();
+  // ---- [obs | reward | done] record (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288): the slot of an obs ring
+  //      (every step of a step-loop launch; floats on the multi-GPU wire format) and / or the caller's record (last step)
   if (valid) {
-    const TR *src = nullptr;
-    if (ctl.pool != nullptr && xr[in_dim + 1] != T(0)) {
-      const unsigned c = ctl.reset_count[env];
-      src = (const TR *)ctl.pool + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
+    const int w = nq + nd + 2;
+    if (LOOP && ctl.obs_ring != nullptr) {
+      const size_t at = ((size_t)((ctl.obs_first + it) % ctl.obs_slots) * ctl.obs_envs + env) * w;
+      for (int i = lane; i < w; i += 16) {
+        const T vv = i < 2 ? T(0) : xr[i < nq + nd ? i : (i == nq + nd ? in_dim + 2 : in_dim + 1)];
+        if (ctl.ring_flags & TDS_RING_OBS_F32) ((float *)ctl.obs_ring)[at + i] = (float)vv;
+        else ((TR *)ctl.obs_ring)[at + i] = (TR)vv;
+      }
     }
-    for (int i = lane; i < nq + nd; i += 16) {
-      const TR vv = src != nullptr ? src[i] : (TR)xr[i];
-      if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? TR(0) : vv;
-      if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = vv;
-    }
-    if (src != nullptr) {
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) ctl.reset_count[env] = ctl.reset_count[env] + 1u;
+    if (last) {
+      for (int i = lane; i < nq + nd; i += 16) {
+        const TR vv = (TR)xr[i];
+        if (obs_out != nullptr) obs_out[(size_t)env * w + i] = i < 2 ? TR(0) : vv;
+        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = vv;
+      }
+      if (lane == 0 && obs_out != nullptr) {
+        obs_out[(size_t)env * w + nq + nd] = (TR)xr[in_dim + 2];
+        obs_out[(size_t)env * w + nq + nd + 1] = (TR)xr[in_dim + 1];
+      }
     }
   }
+  if constexpr (LOOP) QUAD_SYNC();
+  }  // ================================ end of the step loop ================================
 }
 
 }  // namespace
@@ -975,8 +1087,13 @@ int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
   const QuadOff O = quad_layout(h_model.input_dim);
   const int blocks = (n_envs + 3) / 4;
   const size_t shmem = (size_t)O.stride * 4 * sizeof(T);
-  hipLaunchKernelGGL((tds_quad_kernel<T, TR>), dim3(blocks), dim3(64), shmem, stream, d_model, x_in, y_out, actions, x_feedback,
-                     obs_out, ctl, n_envs, O);
+  // one plain step without rings: the straight-line form; K steps, record rings: the step-loop form
+  if (ctl.nsub == 1 && ctl.obs_ring == nullptr && ctl.y_ring == nullptr)
+    hipLaunchKernelGGL((tds_quad_kernel<T, TR, false>), dim3(blocks), dim3(64), shmem, stream, d_model, x_in, y_out, actions,
+                       x_feedback, obs_out, ctl, n_envs, O);
+  else
+    hipLaunchKernelGGL((tds_quad_kernel<T, TR, true>), dim3(blocks), dim3(64), shmem, stream, d_model, x_in, y_out, actions,
+                       x_feedback, obs_out, ctl, n_envs, O);
   return (int)hipGetLastError();
 }
 template int tds_launch_quad<double, double>(const DevModel<double> *, const DevModel<double> &, const double *, double *,

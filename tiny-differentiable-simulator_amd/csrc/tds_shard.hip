@@ -719,6 +719,9 @@ bool ring_form(const tds_hip_shard *sh, int n_steps) {
   const tds_hip_sim *s = sh->sim;
   if (sh->block != 1 || s->auto_reset) return false;  // (auto-reset: the refill passes of the reset pool are host-driven)
   if (s->opt.get(TDS_OPT_SHARD_RING, 1) == 0) return false;
+  // (the 16-lane kernel of the legged robots has a step-loop form, but not the exchange's part of it — progress counters,
+  //  peer stores: their shards keep the per-step launches, which run on that kernel's straight-line form)
+  if (s->compute_f64() && s->h64.quad) return false;
   return tds_hip_step_many_is_loop(s, n_steps > 1 ? n_steps : 2) != 0;
 }
 
