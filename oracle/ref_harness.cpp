@@ -767,6 +767,80 @@ static int vecenv_hip_worker(int batch, int steps, double shift, int seed, int a
   }
 }
 
+// The two classes in LOCK STEP, re-synchronised after every step: both are reset from the same std::rand stream, then per
+// step { actions = the environment's policy on the REFERENCE's observation; reference.step; hip.step (same std::rand
+// seed in front of each, so host resets of auto_reset_when_done draw the same poses); compare observations, rewards, dones
+// and the y records of EVERY environment; hip state := reference state (tds_hip_set_states) }.  Without the resync two
+// chaotic contact trajectories drift apart and only aggregate agreement can be asserted (vecenv_hip_worker above); with it
+// each step of each environment is a one-step comparison from identical inputs, so a per-environment bound holds.
+//   worst [batch] = the largest |hip - ref| / max(1, |ref|) of an environment over all steps and all compared values,
+//   counts[0] = done flags that differ, counts[1] = host resets the reference made, counts[2] = values compared.
+template <typename Sim, typename Env>
+static int vecenv_hip_lockstep(int batch, int steps, int seed, int auto_reset, int reward_mode, const double *params, double *worst,
+                               long long *counts, char *msg, int msg_len) {
+  typedef VectorizedEnvironment<Alg, Sim> RefEnv;
+  typedef tds_hip::VectorizedEnv<Alg, Sim> HipEnv;
+  ARSConfig config;
+  config.batch_size = batch;
+  config.auto_reset_when_done = auto_reset != 0;
+  try {
+    Env env(false);
+    const int od = env.contact_sim.input_dim(), out = env.contact_sim.output_dim();
+    const int np = env.contact_sim.action_dim() * od + env.contact_sim.action_dim();
+    RefEnv ref(env.contact_sim, batch);
+    ref.default_stepper_ = &ref.serial_stepper_;
+    HipEnv hip(env.contact_sim, batch, reward_mode);
+    hip.host_reset_ = true;
+    for (int e = 0; e < batch; ++e) {
+      const std::vector<double> w(params + (size_t)e * np, params + (size_t)(e + 1) * np);
+      ref.init_neural_network(e, w);
+      hip.init_neural_network(e, w);
+    }
+    std::srand(seed);
+    auto obs_r = ref.reset(config);
+    std::srand(seed);
+    auto obs_h = hip.reset(config);
+    std::vector<double> rew_r(batch, 0.0), rew_h(batch, 0.0);
+    std::vector<bool> done_r(batch, false), done_h(batch, false);
+    std::vector<std::vector<double>> actions(batch);
+    std::vector<double> qqd((size_t)batch * od);
+    counts[0] = counts[1] = counts[2] = 0;
+    for (int e = 0; e < batch; ++e) worst[e] = 0.0;
+    auto cmp = [&](int e, double a, double b) {
+      const double d = std::fabs(a - b) / std::max(1.0, std::fabs(b));
+      if (!(d <= worst[e])) worst[e] = std::isfinite(d) ? d : 1e300;
+      ++counts[2];
+    };
+    for (int e = 0; e < batch; ++e)
+      for (int k = 0; k < od; ++k) cmp(e, obs_h[e][k], obs_r[e][k]);
+    for (int t = 0; t < steps; ++t) {
+      for (int e = 0; e < batch; ++e) actions[e] = ref.policy(e, obs_r[e]);
+      std::vector<std::vector<double>> act_h = actions;
+      std::srand(seed + 7919 * (t + 1));
+      ref.step(actions, obs_r, rew_r, done_r, config);
+      std::srand(seed + 7919 * (t + 1));
+      hip.step(act_h, obs_h, rew_h, done_h, config);
+      for (int e = 0; e < batch; ++e) {
+        for (int k = 0; k < od; ++k) cmp(e, obs_h[e][k], obs_r[e][k]);
+        cmp(e, rew_h[e], rew_r[e]);
+        if (done_h[e] != done_r[e]) ++counts[0];
+        if (done_r[e] && config.auto_reset_when_done) ++counts[1];
+        // (the y record of the step; after a host reset sim_states_ holds the fresh pose, also compared through it)
+        for (int k = 0; k < out; ++k) cmp(e, hip.sim_states_with_graphics_[e][k], ref.sim_states_with_graphics_[e][k]);
+        for (int k = 0; k < od; ++k) cmp(e, hip.sim_states_[e][k], ref.sim_states_[e][k]);
+        done_h[e] = done_r[e];
+        for (int k = 0; k < od; ++k) qqd[(size_t)e * od + k] = ref.sim_states_[e][k];
+      }
+      if (tds_hip_set_states(hip.handle(), qqd.data()) != TDS_OK) throw std::runtime_error(tds_hip_last_error());
+    }
+    snprintf(msg, msg_len, "ok");
+    return 0;
+  } catch (const std::exception &e) {
+    snprintf(msg, msg_len, "%s", e.what());
+    return 1000;
+  }
+}
+
 // Throughput of tds_hip::VectorizedEnv driven from C++ (no Python, no torch): environment steps per second of
 //   rates[0]  step(actions, observations, rewards, dones, config) — the reference's signature: actions up, records down
 //   rates[1]  the same with fetch_graphics_ = false (no y records down)
@@ -859,6 +933,18 @@ int tdsref_vecenv_hip_worker(const char *name, int batch, int steps, double shif
     return vecenv_hip_worker<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, shift, seed, auto_reset, TDS_REWARD_LAIKAGO,
                                                                              params, total_rewards, vec_steps, traj_last, traj_len,
                                                                              msg, msg_len);
+  snprintf(msg, msg_len, "unknown env %s", name);
+  return -1;
+}
+int tdsref_vecenv_hip_lockstep(const char *name, int batch, int steps, int seed, int auto_reset, const double *params, double *worst,
+                               long long *counts, char *msg, int msg_len) {
+  const std::string n(name);
+  if (n == "ant")
+    return vecenv_hip_lockstep<AntContactSimulation2<Alg>, AntEnv2<Alg>>(batch, steps, seed, auto_reset, TDS_REWARD_ANT, params, worst,
+                                                                         counts, msg, msg_len);
+  if (n == "laikago")
+    return vecenv_hip_lockstep<LaikagoContactSimulation<Alg>, LaikagoEnv<Alg>>(batch, steps, seed, auto_reset, TDS_REWARD_LAIKAGO,
+                                                                               params, worst, counts, msg, msg_len);
   snprintf(msg, msg_len, "unknown env %s", name);
   return -1;
 }

@@ -62,6 +62,9 @@ def lib():
             L.tdsref_vecenv_hip_worker.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int] + \
                 [C.c_void_p] * 5 + [C.c_char_p, C.c_int]
             L.tdsref_vecenv_hip_bench.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        if hasattr(L, "tdsref_vecenv_hip_lockstep"):
+            L.tdsref_vecenv_hip_lockstep.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + \
+                [C.c_char_p, C.c_int]
         if hasattr(L, "tdsref_f32_create"):
             L.tdsref_f32_create.restype = C.c_void_p
             L.tdsref_f32_create.argtypes = [C.c_char_p, C.c_char_p, C.c_double]
@@ -338,6 +341,21 @@ def vecenv_hip_worker(name, batch, steps, params, output_dim, shift=0.0, seed=12
     if rc != 0:
         raise RuntimeError(f"tdsref_vecenv_hip_worker: {rc} {msg.value.decode()}")
     return {"total_rewards": tr, "vec_steps": vs, "traj_last": last, "traj_len": tl}
+
+
+def vecenv_hip_lockstep(name, batch, steps, params, seed=12345, auto_reset=False):
+    """The reference's VectorizedEnvironment and tds_hip::VectorizedEnv stepped in lock step under the environments' own
+    linear policies, the HIP class's state re-synchronised to the reference's after every step: per environment the
+    largest |hip - ref| / max(1, |ref|) over every observation, reward, y record and state of every step."""
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    worst = np.zeros(batch)
+    counts = np.zeros(3, dtype=np.int64)
+    msg = C.create_string_buffer(512)
+    rc = lib().tdsref_vecenv_hip_lockstep(name.encode(), int(batch), int(steps), int(seed), int(bool(auto_reset)),
+                                          params.ctypes.data, worst.ctypes.data, counts.ctypes.data, msg, 512)
+    if rc != 0:
+        raise RuntimeError(f"tdsref_vecenv_hip_lockstep: {rc} {msg.value.decode()}")
+    return {"worst": worst, "done_mismatches": int(counts[0]), "host_resets": int(counts[1]), "values_compared": int(counts[2])}
 
 
 def vecenv_hip_bench(name, batch, steps):

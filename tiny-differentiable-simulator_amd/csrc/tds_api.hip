@@ -924,18 +924,50 @@ int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev, void *y_de
 
 // K auto-reset steps as step-loop launches ("chunks") of up to R = pool_chunk steps each (tds_hip_step_many of a handle with auto-reset on):
 // inside a launch a done environment copies its next ring entry into its LDS record and carries on (tds_kernels.hip,
-// pool_r), between the launches the rings are topped up by the same passes as above, on this schedule:
-//     before chunk j   run  the pass planned behind chunk j - 2  (its size reached the host while chunk j - 1 ran)
-//                      plan the pass behind chunk j - 1
-//                      chunk j waits for the pass behind chunk j - 2
-// A chunk consumes at most R entries of a ring and the pass behind chunk j - 2 left D of them, so D >= 2 R entries
-// are never exhausted, and a pass only overwrites slots whose entries were consumed before it was planned: the
-// results are those of resetting inside the step, whatever the rate of resets.  The host never waits for a chunk that
-// is not already followed by another one in the stream.  Measured (tools/auto_reset_modes.py many, Ant, 5 % of the
-// environments done per step = 50 % more environment steps in settling): x 4096 0.76 / 0.88 / 0.93 of the rate without
-// resets for R = 16 / 32 / 96 (the refill launches run beside the chunk in the SIMDs' second wavefront slots), x 8192
-// 0.52 / 0.59 / 0.67 (a chunk holds every CU's LDS: the refill runs between chunks); 0.93 ... 0.99 without resets.
-// The settle steps of a pass as ONE step-loop launch (TDS_HIP_POOL_SETTLE_LOOP=1) are no gain: x 4096 0.74, x 8192 0.67.
+// pool_r), between the launches the rings are topped up by the same passes as above.
+//
+// Schedule (round 5).  The two-wavefront step-loop launch holds every wave slot of the GPU (two 256-register wavefronts
+// per SIMD), so a refill pass cannot run BESIDE a chunk any more: it runs between two chunks, and it takes ten settle
+// launches one after the other (~12 us each however few environments they settle).  A pass per call — round 4's
+// schedule — therefore cost a 20-step call 130 us on top of its 317 us (profiles/r05_ant4096_f64_default_dispatches.txt:
+// auto-reset rate 0.73 of the plain rate).  Now a pass is planned only when R steps have been launched since the last
+// snapshot, across calls: the same ten settle launches then settle R x (done per step) environments instead of
+// 20 x (done per step), i.e. the GPU-wide latency of a pass is paid once per R steps, and the host never blocks on a plan
+// behind the chunk it has just launched unless the rings would otherwise run dry:
+//     total    steps launched since the rings were filled
+//     visible  value of `total` at the snapshot of the newest pass the NEXT launch waits for
+//     before a launch of k steps:  total + k - visible > D - 4  ->  bring a newer pass in first (plan if none is, wait
+//                                  for its size, run it): an environment consumes at most one entry per step, so
+//                                  D entries cannot run dry
+//     after it:                    a planned pass whose size has reached the host (always, if the caller synchronised
+//                                  since; otherwise only between the chunks of one call) is run behind the launch;
+//                                  with none planned and total - (last snapshot) >= R, plan one
+// A pass only overwrites slots whose entries were consumed before it was planned: the results are those of resetting
+// inside the step, whatever the rate of resets and however the calls are cut (tests/test_auto_reset.py).
+int pool_make_visible(tds_hip_sim *s) {  // the planned pass (planned here if there is none): size to the host, run it
+  int rc;
+  if (!s->pool_planned) {
+    rc = pool_plan(s);
+    if (rc != TDS_OK) return rc;
+    s->pool_planned = 1;
+    s->pool_snap_planned = s->pool_total;
+  }
+  TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
+  rc = pool_run(s, s->pool_sync_ev);
+  if (rc != TDS_OK) return rc;
+  s->pool_planned = 0;
+  s->pool_run_pending = true;
+  const long long snap = s->pool_snap_planned;
+  while (*s->h_pool_nitems > s->pool_cap) {  // the work list was cut short: the rings must be FULL up to the snapshot
+    rc = pool_plan(s);
+    if (rc != TDS_OK) return rc;
+    TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
+    rc = pool_run(s, s->pool_sync_ev);
+    if (rc != TDS_OK) return rc;
+  }
+  s->pool_snap_visible = snap;
+  return TDS_OK;
+}
 int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int act_first, int n_steps, void *obs_dev,
                    const tds_hip_rings_t *rings = nullptr) {
   int rc;
@@ -947,6 +979,7 @@ int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int 
     rc = pool_fill(s);
     if (rc != TDS_OK) return rc;
     s->pool_many_chunks = 0;
+    s->pool_total = s->pool_snap_visible = s->pool_snap_planned = 0;
   }
   const int R = s->pool_chunk;
   TdsStepCtl extra;
@@ -957,15 +990,10 @@ int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int 
   const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
   for (int done = 0; done < n_steps;) {
     const int k = n_steps - done < R ? n_steps - done : R;
-    // Order of the host calls (round 4): the chunk goes out FIRST, the refill pass behind the previous chunk afterwards,
-    // beside it on the pool stream.  Round 3 issued the pass (plan sync, stage, settle launches, scatter: ~17 runtime
-    // calls) in front of the chunk: ~100 us of host time during which a caller that synchronises between calls — a
-    // 20-step benchmark region — left the GPU idle (auto-reset rate 0.80 of the plain rate at 20 steps per call).
-    //     chunk j     waits for the pass issued behind chunk j - 1 (planned behind chunk j - 2: rings full up to there)
-    //     then        run the pass planned behind chunk j - 1, plan the one behind chunk j
-    // A chunk consumes at most R entries of a ring and starts with everything refilled that was consumed before the
-    // chunk in front of it: D >= R + slack entries cannot run dry; a pass only overwrites slots consumed before it was
-    // planned.  Results are those of resetting inside the step, whatever the rate of resets.
+    if (s->pool_total + k - s->pool_snap_visible > (long long)s->pool_depth - 4) {
+      rc = pool_make_visible(s);
+      if (rc != TDS_OK) return rc;
+    }
     if (s->pool_run_pending) {
       TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->pool_sync_ev, 0));
       s->pool_run_pending = false;
@@ -986,24 +1014,20 @@ int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int 
                 nullptr, 0, &o);
     if (rc != TDS_OK) return rc;
     ++s->pool_many_chunks;
+    s->pool_total += k;
     done += k;
-    if (s->pool_planned) {  // the pass planned behind the chunk before this one: its size has long reached the host
-      TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
-      rc = pool_run(s, s->pool_sync_ev);
+    // (between the chunks of one call the host waits for the size — the chunk just launched keeps the GPU busy meanwhile;
+    //  behind the last chunk of a call it only looks: a caller that synchronises between calls finds it there next time)
+    if (s->pool_planned && (done < n_steps || hipEventQuery(s->pool_plan_ev) == hipSuccess)) {
+      rc = pool_make_visible(s);
       if (rc != TDS_OK) return rc;
-      s->pool_planned = 0;
-      s->pool_run_pending = true;
-      while (*s->h_pool_nitems > s->pool_cap) {  // the work list was cut short: the rings must be FULL before the next launch
-        rc = pool_plan(s);                       // (planned behind the chunk just launched: the host waits for it here)
-        if (rc != TDS_OK) return rc;
-        TDS_HIP_TRY(hipEventSynchronize(s->pool_plan_ev));
-        rc = pool_run(s, s->pool_sync_ev);
-        if (rc != TDS_OK) return rc;
-      }
     }
-    rc = pool_plan(s);  // what this chunk and the ones before it have consumed: run behind the NEXT chunk's launch
-    if (rc != TDS_OK) return rc;
-    s->pool_planned = 1;
+    if (!s->pool_planned && s->pool_total - s->pool_snap_visible >= R) {
+      rc = pool_plan(s);  // what the launches so far have consumed
+      if (rc != TDS_OK) return rc;
+      s->pool_planned = 1;
+      s->pool_snap_planned = s->pool_total;
+    }
   }
   return TDS_OK;
 }

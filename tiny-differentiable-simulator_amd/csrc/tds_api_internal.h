@@ -74,6 +74,7 @@ struct tds_hip_sim {
   bool pool_many = false;      // the pool is on the pass schedule of step_many (pool_step_many), not of single steps
   bool pool_run_pending = false;  // ... a pass has been issued on the pool stream that the next chunk must wait for (pool_sync_ev)
   long long pool_many_chunks = 0;
+  long long pool_total = 0, pool_snap_visible = 0, pool_snap_planned = 0;  // pool_step_many: steps launched / snapshots of the passes
   bool pool_ready = false;     // false: fill the pool completely before the next auto-reset step
   bool pool_discard = true;    // the entries in the rings are void (first use, new seed): start from empty rings
   // K-steps-per-launch graph cache (tds_hip_step_many)

@@ -84,6 +84,24 @@ struct QuadKernArgs {
   int n_envs;
   QuadOff O;
 };
+// The model constants of a step-loop launch, in LDS: filled once per launch, behind the environments' regions.  Read from L2
+// through a laundered model pointer — what keeps a step-loop body at its register budget — every iteration began with a
+// round trip per group of constants, and the first of them also waited for the previous step's record stores (loads and
+// stores share one in-order counter on gfx9): 35.2 us per laikago_soft x 8192 step against 27.2 for the chained graphs
+// of the straight-line form (profiles/r05_quad_forms.txt).  The straight-line form reads the model directly.
+template <typename T>
+struct QuadTable {
+  T S[6][16], X_T[12][16], mass[16], com[3][16], inertia[9][16], init_pose[16], stiffness[16], damping[16];
+  int joint_type[16], act_index[16];
+  T mass5, com5[3], inertia5[9];
+  T cp_radius[4], cp_local[3][4];
+  T vis_X[12][17];
+  T dt, action_limit, base_t[3], grav[3], plane_n[3], plane_c, nb[3], t1[3], t2[3], cfm, erp_over_dt, restitution, friction, base_R8;
+  int input_dim, action_dim, num_visuals, step_mode, reward_mode, pgs_iterations, pack_visuals, output_dim;
+};
+// constant `tab` of the table in a step-loop launch, `glob` of the model otherwise
+#define QC(tab, glob) (LOOP ? (CT->tab) : (mdl->glob))
+
 template <bool LOOP>
 struct QuadCtlRef {
   using type = const TdsStepCtl &;
@@ -139,7 +157,72 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
     }
   }
+  QuadTable<T> *const CT = reinterpret_cast<QuadTable<T> *>(sm + 4 * O.stride);  // (step-loop launches only)
+  if constexpr (LOOP) {
+    const DevModel<T> *const md = mdl_arg;
+    const int t = threadIdx.x & 63;
+    if (t < 16) {
+      const int l = 6 + t;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) CT->S[k][t] = md->S[k][l];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) CT->X_T[k][t] = md->X_T[k][l];
+      CT->mass[t] = md->mass[l];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) CT->com[k][t] = md->com[k][l];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) CT->inertia[k][t] = md->inertia[k][l];
+      CT->init_pose[t] = md->init_pose[l];
+      CT->stiffness[t] = md->stiffness[l];
+      CT->damping[t] = md->damping[l];
+      CT->joint_type[t] = md->joint_type[l];
+      CT->act_index[t] = md->act_index[l];
+    } else if (t < 20) {
+      const int k = t - 16;
+      CT->cp_radius[k] = md->cp_radius[k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) CT->cp_local[c][k] = md->cp_local[c][k];
+    } else if (t == 20) {
+      CT->mass5 = md->mass[5];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) CT->com5[k] = md->com[k][5];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) CT->inertia5[k] = md->inertia[k][5];
+    } else if (t == 21) {
+      CT->dt = md->dt;
+      CT->action_limit = md->action_limit;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        CT->base_t[k] = md->base_t[k];
+        CT->grav[k] = md->grav[k];
+        CT->plane_n[k] = md->plane_n[k];
+        CT->nb[k] = md->nb[k];
+        CT->t1[k] = md->t1[k];
+        CT->t2[k] = md->t2[k];
+      }
+      CT->plane_c = md->plane_c;
+      CT->cfm = md->cfm;
+      CT->erp_over_dt = md->erp_over_dt;
+      CT->restitution = md->restitution;
+      CT->friction = md->friction;
+      CT->base_R8 = md->base_R[8];
+      CT->input_dim = md->input_dim;
+      CT->action_dim = md->action_dim;
+      CT->num_visuals = md->num_visuals;
+      CT->step_mode = md->step_mode;
+      CT->reward_mode = md->reward_mode;
+      CT->pgs_iterations = md->pgs_iterations;
+      CT->pack_visuals = md->pack_visuals;
+      CT->output_dim = md->output_dim;
+    }
+    for (int i = t; i < 12 * 17; i += 64) {
+      const int c = i / 17, k = i - 17 * c;
+      CT->vis_X[c][k] = k < md->num_visuals ? md->vis_X[c][k] : T(0);
+    }
+    QUAD_SYNC();
+  }
   const int nsteps = LOOP ? ctl_arg.nsub : 1;
+  T next_act = T(0);  // (step-loop form: the action block of the NEXT step, requested a step ahead)
   for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
   // (nothing but `it` lives across an iteration: lane, model pointer and kernel-argument segment are laundered)
   const DevModel<T> *mdl = mdl_arg;
@@ -156,37 +239,41 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   const int li = 6 + lane;            // my link
   const bool dofl = pos < 3;          // my link carries a dof (the toe's joint is fixed)
   const int dq = 6 + 3 * leg + pos;   // ... this one, in the q / qd records (nq == nd == 18)
-  const int in_dim = mdl->input_dim, adim = mdl->action_dim;
+  const int in_dim = QC(input_dim, input_dim), adim = QC(action_dim, action_dim);
   // (kernel-argument segment: mdl 0 | x_in 8 | y_out 16 | actions 24 | x_feedback 32 | obs_out 40 | ctl 48: see QuadKernArgs)
   typename QuadCtlRef<LOOP>::type ctl = QuadCtlRef<LOOP>::get(ctl_arg, ka_seg + __builtin_offsetof(QuadKernArgs, ctl));
-  const T dt = mdl->dt;
+  const T dt = QC(dt, dt);
   const bool last = it == nsteps - 1;
   if constexpr (LOOP) {
-    // the action block of this step (step 0's came in with the record): block (act_first + it) % act_blocks of the pool
-    if (it > 0 && ctl.act_pool != nullptr) {  // wave-uniform
-      const int blk = (ctl.act_first + it) % ctl.act_blocks;
-      if (valid && lane < adim) xr[nq + nd + lane] = (T)((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
+    // the action block of this step (step 0's came in with the record) was requested at the top of the step before; the
+    // next step's — block (act_first + it + 1) % act_blocks of the pool — is requested now: no step waits for HBM
+    if (ctl.act_pool != nullptr) {  // wave-uniform
+      if (it > 0 && lane < adim) xr[nq + nd + lane] = next_act;
+      if (it + 1 < nsteps && valid && lane < adim) {
+        const int blk = (ctl.act_first + it + 1) % ctl.act_blocks;
+        next_act = (T)((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
+      }
     }
   }
   // lane constants (issued under the latency of the record)
-  const int jt = mdl->joint_type[li];
-  const int act_i = mdl->act_index[li];
-  const T init_pose_l = mdl->init_pose[li], stiff_l = mdl->stiffness[li], damp_l = mdl->damping[li];
+  const int jt = QC(joint_type[lane], joint_type[li]);
+  const int act_i = QC(act_index[lane], act_index[li]);
+  const T init_pose_l = QC(init_pose[lane], init_pose[li]), stiff_l = QC(stiffness[lane], stiffness[li]), damp_l = QC(damping[lane], damping[li]);
   T Sl[6], RT[9], tT[3];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) Sl[k] = mdl->S[k][li];
+  for (int k = 0; k < 6; ++k) Sl[k] = QC(S[k][lane], S[k][li]);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) RT[k] = mdl->X_T[k][li];
+  for (int k = 0; k < 9; ++k) RT[k] = QC(X_T[k][lane], X_T[k][li]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) tT[k] = mdl->X_T[9 + k][li];
-  const T act_lim = mdl->action_limit;
+  for (int k = 0; k < 3; ++k) tT[k] = QC(X_T[9 + k][lane], X_T[9 + k][li]);
+  const T act_lim = QC(action_limit, action_limit);
   QUAD_SYNC();
   const T q = dofl ? xr[dq] : T(0);
   const T qd = dofl ? xr[nq + dq] : T(0);
 
   // ---- PD controller (locomotion_contact_simulation.h:168-258) or direct torque; joint stiffness / damping
   T tau = T(0);
-  if (mdl->step_mode == TDS_STEP_LOCOMOTION) {
+  if (QC(step_mode, step_mode) == TDS_STEP_LOCOMOTION) {
     if (act_i >= 0) {
       const int var = nq + nd + adim;
       const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
@@ -257,7 +344,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   R5[0] = cy * cz;                 R5[1] = -cy * sz;                R5[2] = sy;
   R5[3] = sx * sy * cz + cx * sz;  R5[4] = cx * cz - sx * sy * sz;  R5[5] = -sx * cy;
   R5[6] = sx * sz - cx * sy * cz;  R5[7] = cx * sy * sz + sx * cz;  R5[8] = cx * cy;
-  const T P[3] = {q0 + mdl->base_t[0], q1 + mdl->base_t[1], q2 + mdl->base_t[2]};
+  const T P[3] = {q0 + QC(base_t[0], base_t[0]), q1 + QC(base_t[1], base_t[1]), q2 + QC(base_t[2], base_t[2])};
   const T A3[3] = {T(1), T(0), T(0)}, A4[3] = {T(0), cx, sx}, A5[3] = {sy, -sx * cy, cx * cy};
   // the six root motion axes (angular | linear): prismatic e_x, e_y, e_z; revolute (A | P x A)
   T pA3[3], pA4[3], pA5[3];
@@ -298,7 +385,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       v5[k] = W5[k];
       v5[3 + k] = V5[k];
       a5[k] = a45[k] + a55[k];
-      a5[3 + k] = (l3[k] + l4[k] + l5[k]) - mdl->grav[k];
+      a5[3 + k] = (l3[k] + l4[k] + l5[k]) - QC(grav[k], grav[k]);
     }
   }
   // ---- the legs: one segmented prefix scan along each quad (chain-local products of the joint transforms, then the
@@ -451,15 +538,15 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   int na = 0;
   {
     T *const cpx = E + O.cp;
-    const T rad = mdl->cp_radius[leg];
-    const T loc[3] = {mdl->cp_local[0][leg], mdl->cp_local[1][leg], mdl->cp_local[2][leg]};
+    const T rad = QC(cp_radius[leg], cp_radius[leg]);
+    const T loc[3] = {QC(cp_local[0][leg], cp_local[0][leg]), QC(cp_local[1][leg], cp_local[1][leg]), QC(cp_local[2][leg], cp_local[2][leg])};
     T ctr[3];
     mat3_mulv(R, loc, ctr);
     ctr[0] += p[0];
     ctr[1] += p[1];
     ctr[2] += p[2];
-    const T n[3] = {mdl->plane_n[0], mdl->plane_n[1], mdl->plane_n[2]};
-    const T t = -((-dot3(ctr, n)) + mdl->plane_c);
+    const T n[3] = {QC(plane_n[0], plane_n[0]), QC(plane_n[1], plane_n[1]), QC(plane_n[2], plane_n[2])};
+    const T t = -((-dot3(ctr, n)) + QC(plane_c, plane_c));
     const T dist = t - rad;
     const bool act = valid && pos == 3 && dist < T(0);
     const unsigned long long bal = __ballot(act);
@@ -487,7 +574,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   // where this step's y record goes: the slot of a y ring (every step of a step-loop launch), else the handle's y record
   // (the last step); the last step of a ring launch leaves its record in the handle's y record as well
   const int ystr = ctl.y_stride;
-  const int out_dim = mdl->output_dim;
+  const int out_dim = QC(output_dim, output_dim);
   TR *yo = nullptr, *yo2 = nullptr;
   int yend = ystr, yend2 = out_dim;
   if (LOOP && ctl.y_ring != nullptr) {
@@ -497,16 +584,16 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     yo = y_out + (size_t)env * (LOOP ? out_dim : ystr);
     yend = LOOP ? out_dim : ystr;
   }
-  const int nv = mdl->num_visuals;
+  const int nv = QC(num_visuals, num_visuals);
   if (valid && yo != nullptr && nv > 0) {
     const DevModel<T> *md3 = mdl;  // (see the rigid inertia above: the visuals' constants are fetched where they are used)
     asm volatile("" : "+s"(md3));
     auto pose_out = [&](const T *Rl, const T *pl, int k) {
       T Rv[9], pv[3], Ro[9], po[3], qo[4];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) Rv[c] = md3->vis_X[c][k];
+      for (int c = 0; c < 9; ++c) Rv[c] = LOOP ? CT->vis_X[c][k] : md3->vis_X[c][k];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) pv[c] = md3->vis_X[9 + c][k];
+      for (int c = 0; c < 3; ++c) pv[c] = LOOP ? CT->vis_X[9 + c][k] : md3->vis_X[9 + c][k];
       mat3_mul(Rl, Rv, Ro);
       mat3_mulv(Rl, pv, po);
       matrix_to_quat(Ro, qo);
@@ -540,22 +627,22 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     const DevModel<T> *md2 = mdl;
     asm volatile("" : "+s"(md2));
     T Il[9], com_l[3];
-    const T mass_l = md2->mass[li];
+    const T mass_l = LOOP ? CT->mass[lane] : md2->mass[li];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) com_l[k] = md2->com[k][li];
+    for (int k = 0; k < 3; ++k) com_l[k] = LOOP ? CT->com[k][lane] : md2->com[k][li];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Il[k] = md2->inertia[k][li];
+    for (int k = 0; k < 9; ++k) Il[k] = LOOP ? CT->inertia[k][lane] : md2->inertia[k][li];
     rigid(R, p, mass_l, com_l, Il, v, a0, Ic, fc);
   }
   T It[10], ft[6];  // the root body's; below: + the legs' composites = the whole robot's
   {
     const DevModel<T> *md4 = mdl;
     asm volatile("" : "+s"(md4));
-    const T com5[3] = {md4->com[0][5], md4->com[1][5], md4->com[2][5]};
+    const T com5[3] = {LOOP ? CT->com5[0] : md4->com[0][5], LOOP ? CT->com5[1] : md4->com[1][5], LOOP ? CT->com5[2] : md4->com[2][5]};
     T I5[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) I5[k] = md4->inertia[k][5];
-    rigid(R5, P, md4->mass[5], com5, I5, v5, a5, It, ft);
+    for (int k = 0; k < 9; ++k) I5[k] = LOOP ? CT->inertia5[k] : md4->inertia[k][5];
+    rigid(R5, P, LOOP ? CT->mass5 : md4->mass[5], com5, I5, v5, a5, It, ft);
   }
 
   // ---- E. composite inertia / bias force (CRBA, mass_matrix.hpp:39-56): suffix sums along every quad; the chain heads'
@@ -813,10 +900,10 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     const int nr = 3 * NA;
     const DevModel<T> *md5 = mdl;  // (the contact frame and the solver's scalars are fetched here, not at the top of the step)
     asm volatile("" : "+s"(md5));
-    const T nb[3] = {md5->nb[0], md5->nb[1], md5->nb[2]};
-    const T t1v[3] = {md5->t1[0], md5->t1[1], md5->t1[2]};
-    const T t2v[3] = {md5->t2[0], md5->t2[1], md5->t2[2]};
-    const T cfm = md5->cfm, erp_dt = md5->erp_over_dt, rest = md5->restitution, mu = md5->friction;
+    const T nb[3] = {LOOP ? CT->nb[0] : md5->nb[0], LOOP ? CT->nb[1] : md5->nb[1], LOOP ? CT->nb[2] : md5->nb[2]};
+    const T t1v[3] = {LOOP ? CT->t1[0] : md5->t1[0], LOOP ? CT->t1[1] : md5->t1[1], LOOP ? CT->t1[2] : md5->t1[2]};
+    const T t2v[3] = {LOOP ? CT->t2[0] : md5->t2[0], LOOP ? CT->t2[1] : md5->t2[1], LOOP ? CT->t2[2] : md5->t2[2]};
+    const T cfm = LOOP ? CT->cfm : md5->cfm, erp_dt = LOOP ? CT->erp_over_dt : md5->erp_over_dt, rest = LOOP ? CT->restitution : md5->restitution, mu = LOOP ? CT->friction : md5->friction;
     {
       // lane == row, CONTACT-major: lane 3 a + t solves row t (normal, tangent 1, tangent 2) of contact slot a and stores it
       // at index 3 a + t — an assignment that does not depend on NA, i.e. on the wavefront-mates' contact counts (with the
@@ -899,7 +986,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     // projected Gauss-Seidel (mb_constraint_solver.hpp:101-142) on u~ = sum_r z~_r x_r: the leg part on the dof lanes, the
     // root part on every lane
     T u = T(0), ur[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-    const int iters = md5->pgs_iterations;
+    const int iters = LOOP ? CT->pgs_iterations : md5->pgs_iterations;
     const T my_leg = (T)leg;
     for (int it = 0; it < iters; ++it) {
       // the reference's row order: normals, tangents 1, tangents 2, each by contact (rows live at 3 a + t)
@@ -987,9 +1074,9 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     auto y_state = [&](TR *y, int end) {
       for (int i = lane; i < nq + nd; i += 16) y[i] = (TR)xr[i];
       int tail = nq + nd;
-      if (mdl->pack_visuals) {
+      if (QC(pack_visuals, pack_visuals)) {
         tail += 7 * nv;
-        if (lane == 0) y[tail] = (TR)(mdl->base_R[8]);  // up_dot_world_z (fixed base)
+        if (lane == 0) y[tail] = (TR)(QC(base_R8, base_R[8]));  // up_dot_world_z (fixed base)
         tail += 1;
       }
       for (int i = tail + lane; i < end; i += 16) y[i] = TR(0);
@@ -1005,7 +1092,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     if (lane == 0) {
       bool done = false;
       T reward = T(0);
-      const int rm = mdl->reward_mode;
+      const int rm = QC(reward_mode, reward_mode);
       if (rm == TDS_REWARD_ANT) {
         const T vel_x = (xr[0] - xr[in_dim]) / dt;
         done = xr[2] < T(0.26);
@@ -1086,9 +1173,11 @@ int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
                     TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl) {
   const QuadOff O = quad_layout(h_model.input_dim);
   const int blocks = (n_envs + 3) / 4;
-  const size_t shmem = (size_t)O.stride * 4 * sizeof(T);
+  // (+ the constant table of a step-loop launch behind the four environments' regions)
+  const bool one_step = ctl.nsub == 1 && ctl.obs_ring == nullptr && ctl.y_ring == nullptr;
+  const size_t shmem = (size_t)O.stride * 4 * sizeof(T) + (one_step ? 0 : sizeof(QuadTable<T>));
   // one plain step without rings: the straight-line form; K steps, record rings: the step-loop form
-  if (ctl.nsub == 1 && ctl.obs_ring == nullptr && ctl.y_ring == nullptr)
+  if (one_step)
     hipLaunchKernelGGL((tds_quad_kernel<T, TR, false>), dim3(blocks), dim3(64), shmem, stream, d_model, x_in, y_out, actions,
                        x_feedback, obs_out, ctl, n_envs, O);
   else

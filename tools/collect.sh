@@ -87,7 +87,7 @@ exchange)
   python tools/rocprof_timeline.py "$DB" 60 > $P/${TAG}_one_rank_exchange_timeline.txt 2>&1
   rm -rf $O/kt_fg ;;
 tworank)
-  bash tools/two_rank_peer_trace.sh $TAG ;;
+  bash tools/two_rank_peer_trace.sh $TAG $TAG ;;
 phases)
   python tools/profile_phases.py ant 4096 > $P/${TAG}_ant4096_f64_phases.txt 2>/dev/null
   python tools/profile_phases.py laikago_soft 8192 > $P/${TAG}_laikago_soft8192_f64_phases.txt 2>/dev/null
