@@ -817,8 +817,9 @@ int pool_run(tds_hip_sim *s, hipEvent_t done) {
     o.lds = &s->pool_lds;
     o.ovf = s->d_pool_ovf;
     // straight-line step kernel on the staging records: zero action, state fed back in place, no y / obs record
-    // (TDS_HIP_POOL_SETTLE_LOOP=1: the settle steps as ONE launch of the step-loop build — measured, no gain)
-    const bool one_launch = s->model.settle_steps > 1 && s->opt.get(TDS_OPT_POOL_SETTLE_LOOP, 0) == 1;
+    // (the settle steps as ONE launch of the step-loop build; option pool_settle_loop = 0: one straight-line launch per
+    //  settle step — round 4's form, from when the passes ran beside the chunks)
+    const bool one_launch = s->model.settle_steps > 1 && s->opt.get(TDS_OPT_POOL_SETTLE_LOOP, 1) == 1;
     for (int k = 0; k < (one_launch ? 1 : s->model.settle_steps); ++k) {
       const int rc = launch(s, s->d_stage_x, nullptr, nullptr, s->d_stage_x, nullptr, n_items,
                             one_launch ? s->model.settle_steps : 1, TDS_RESET_NONE, nullptr, nullptr, 0, &o);
@@ -981,7 +982,6 @@ int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int 
     s->pool_many_chunks = 0;
     s->pool_total = s->pool_snap_visible = s->pool_snap_planned = 0;
   }
-  const int R = s->pool_chunk;
   TdsStepCtl extra;
   memset(&extra, 0, sizeof(extra));
   extra.pool = s->d_pool;
@@ -989,6 +989,7 @@ int pool_step_many(tds_hip_sim *s, const void *actions_dev, int act_blocks, int 
   extra.pool_envs = s->num_envs;
   const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
   for (int done = 0; done < n_steps;) {
+    const int R = s->pool_chunk;
     const int k = n_steps - done < R ? n_steps - done : R;
     if (s->pool_total + k - s->pool_snap_visible > (long long)s->pool_depth - 4) {
       rc = pool_make_visible(s);

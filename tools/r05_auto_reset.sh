@@ -22,7 +22,7 @@ PY
 {
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/driver.json 2> $O/driver.err; line $O/driver.json "driver line"
 timeout 300 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-secondary > $O/plain.json 2> $O/plain.err; line $O/plain.json "plain 1000"
-for A in "" "--option pool_settle_loop=1" "--option pool_chunk=96" "--option pool_chunk=96 --option pool_settle_loop=1" "--option pool_chunk=64" "--option pool_chunk=256"; do
+for A in "" "--option pool_settle_loop=0" "--option pool_chunk=128" "--option pool_chunk=128 --option pool_settle_loop=0"; do
   timeout 300 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-secondary --auto-reset $A > $O/ar.json 2> $O/ar.err; line $O/ar.json "auto-reset 1000 $A"
 done
 } 2>&1 | tee $P/${TAG}_auto_reset_lines.txt
@@ -34,7 +34,7 @@ con = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
 st = "start" if "start" in cols else "start_timestamp"
 en = "end" if "end" in cols else "end_timestamp"
-rows = con.execute(f"select name, {st}, {en}, grid_size_x from kernels order by {st}").fetchall() if "grid_size_x" in cols else \
+rows = con.execute(f"select name, {st}, {en}, grid_x from kernels order by {st}").fetchall() if "grid_x" in cols else \
        [r + (0,) for r in con.execute(f"select name, {st}, {en} from kernels order by {st}").fetchall()]
 # the last 1000-step call: from the 8th-last step-loop launch (LP = 1 build, > 1 ms) to the end
 big = [i for i, r in enumerate(rows) if "tds_step_kernel" in r[0] and (r[2] - r[1]) > 8e5]
@@ -45,7 +45,7 @@ print("# start us | duration us | grid | kernel")
 prev_end = t0
 agg = {}
 for n, a, b, g in rows[i0:]:
-    k = n.split("(")[0].replace("void (anonymous namespace)::", "")[:70]
+    k = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
     print("%10.1f  %9.1f  %8d  %s" % ((a - t0) / 1e3, (b - a) / 1e3, g, k))
     agg[k.split("<")[0]] = agg.get(k.split("<")[0], 0) + (b - a) / 1e3
 print("# totals by kernel (us):", {k: round(v, 1) for k, v in agg.items()})

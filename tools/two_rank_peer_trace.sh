@@ -49,7 +49,7 @@ for db in sorted(glob.glob(O + "/kt_*/**/*.db", recursive=True)):
     c = collections.Counter()
     t = collections.Counter()
     for n, a, b in rows:
-        k = n.split("(")[0].split("<")[0][-48:]
+        k = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0][-48:]
         c[k] += 1
         t[k] += (b - a)
     print("\n%s: %d dispatches" % ("/".join(db.split("/")[-2:]), len(rows)))
@@ -60,9 +60,9 @@ for db in sorted(glob.glob(O + "/kt_*/**/*.db", recursive=True)):
     # the last step-loop launch and what surrounds it
     idx = [i for i, r in enumerate(rows) if "tds_step_kernel" in r[0]]
     if idx:
-        i = idx[-1]
+        i = max(idx, key=lambda j: rows[j][2] - rows[j][1])  # the longest one = the step-loop launch of the timed steps
         t0 = rows[i][1]
-        print("   around the last step-loop launch:")
-        for n, a, b in rows[max(0, i - 2):i + 3]:
-            print("     %+10.1f us  dur %9.1f us  %s" % ((a - t0) / 1e3, (b - a) / 1e3, n.split("(")[0][-70:]))
+        print("   around the step-loop launch of the timed steps (the longest tds_step_kernel dispatch):")
+        for n, a, b in rows[max(0, i - 3):i + 4]:
+            print("     %+10.1f us  dur %9.1f us  %s" % ((a - t0) / 1e3, (b - a) / 1e3, n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]))
 PY
