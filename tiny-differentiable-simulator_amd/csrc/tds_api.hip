@@ -97,6 +97,7 @@ extern "C" {
 TDS_ALT_DECL(1) TDS_ALT_DECL(2) TDS_ALT_DECL(3) TDS_ALT_DECL(4) TDS_ALT_DECL(5) TDS_ALT_DECL(6)
 #undef TDS_ALT_DECL
 }
+int tds_quad_loop_workgroup_bytes(int input_dim);  // (tds_quad.hip: LDS of one workgroup of its step-loop form)
 static tds_alt_launch_fn tds_alt_slot(int k) {
   switch (k) {
     case 1: return tds_alt_launch_1;
@@ -1261,13 +1262,17 @@ bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
   // Wider kernels (Laikago, 18 dof) spill in the loop build and stay with the graphs (66 against 49 us).
   const bool plain = !two && !(s->compute_f64() ? s->h64.is_floating : s->h32.is_floating) &&
                      (s->compute_f64() ? s->h64.num_spherical : s->h32.num_spherical) == 0;
-  // the star-shaped legged robots (tds_quad.hip: 246 VGPR, no scratch in its step-loop form): with auto-reset on, the
-  // step-loop form — reset-pool entries taken inside the loop: 2.41e8 at laikago_soft x 8192 against 2.15e8 for single steps
-  // through the pool.  Without resets the chained graphs of its straight-line form are still faster (27 against 35 us per
-  // step, profiles/r05_quad_forms.txt: every iteration of the loop form re-fetches the lane constants from L2 and waits for
-  // the previous step's record stores with them — a constant table in LDS and an action prefetch are what it needs);
-  // option step_many_loop = 1 forces the loop form
-  if (s->compute_f64() && s->h64.quad) return s->auto_reset;
+  // the star-shaped legged robots (tds_quad.hip; 248 VGPR, no scratch in its step-loop form): the step-loop form while
+  // EVERY workgroup of the launch is resident at once — its constant table costs LDS: six workgroups per compute unit
+  // instead of the straight-line form's eight — and the chained graphs (single steps through the reset pool with
+  // auto-reset on) beyond that, where the loop form would run its workgroups in two rounds of all the steps each.
+  // laikago_soft (tools/quad_occupancy_sweep.sh, us per step, loop / graphs): x 4096 13.4 / 20.8, x 6144 18.3 / 23.2,
+  // x 8192 32.5 / 24.7; with auto-reset: 13.2 / 21.0, 17.8 / 25.8, 30.9 / 27.4.  Option step_many_loop = 0 / 1 forces a form.
+  if (s->compute_f64() && s->h64.quad) {
+    const int per_cu = (160 * 1024) / tds_quad_loop_workgroup_bytes(s->model.input_dim);
+    const int resident = 256 * (per_cu < 8 ? per_cu : 8);
+    return (s->num_envs + 3) / 4 <= resident;
+  }
   const int n_blocks = (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
   // With auto-reset on the alternative is not the chained graphs but single steps through the reset pool: the step-loop
   // launches (pool_step_many) win at every batch size (Ant x 16384 / 32768 at 5 % resets per step: 2.81e8 / 2.87e8

@@ -774,6 +774,11 @@ struct TdsKaRef<true, S> {
   using type = const TDS_AS4 S &;
   static __device__ __forceinline__ type get(const S &, const TDS_AS4 char *at) { return *(const TDS_AS4 S *)at; }
 };
+template <bool ON, typename P>
+__device__ __forceinline__ P tds_ka_val(P param, const TDS_AS4 char *at) {  // a pointer / scalar parameter, by value
+  if constexpr (ON) return *(const TDS_AS4 P *)at;
+  else return param;
+}
 #ifndef TDS_KA_RELOAD
 #define TDS_KA_RELOAD 1
 #endif
@@ -1043,6 +1048,27 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
   using TdsKA = TdsKernArgs<T, TR>;
   typename TdsKaRef<KA, TdsLds>::type L = TdsKaRef<KA, TdsLds>::get(L_arg, ka_seg + __builtin_offsetof(TdsKA, L));
   typename TdsKaRef<KA, TdsStepCtl>::type ctl = TdsKaRef<KA, TdsStepCtl>::get(ctl_arg, ka_seg + __builtin_offsetof(TdsKA, ctl));
+  // (likewise the pointer parameters and the environment count: taken from the parameters, every `!= nullptr` of the loop body
+  //  is a launch-invariant condition the compiler evaluates in front of the loop and keeps — two SGPRs each — in lanes of a
+  //  spill register: 48 SGPR spills, 97 v_readlane per iteration in the headline build.  -DTDS_KA_PTRS=0: the parameters)
+#ifndef TDS_KA_PTRS
+#define TDS_KA_PTRS 1
+#endif
+  constexpr bool KP = KA && TDS_KA_PTRS != 0;
+  const TR *const ka_x_in = tds_ka_val<KP, const TR *>(x_in, ka_seg + __builtin_offsetof(TdsKA, x_in));
+  TR *const ka_y_out = tds_ka_val<KP, TR *>(y_out, ka_seg + __builtin_offsetof(TdsKA, y_out));
+  const TR *const ka_actions = tds_ka_val<KP, const TR *>(actions, ka_seg + __builtin_offsetof(TdsKA, actions));
+  TR *const ka_x_feedback = tds_ka_val<KP, TR *>(x_feedback, ka_seg + __builtin_offsetof(TdsKA, x_feedback));
+  TR *const ka_obs_out = tds_ka_val<KP, TR *>(obs_out, ka_seg + __builtin_offsetof(TdsKA, obs_out));
+  T *const ka_ovf = tds_ka_val<KP, T *>(ovf, ka_seg + __builtin_offsetof(TdsKA, ovf));
+  const int ka_n_envs = tds_ka_val<KP, int>(n_envs, ka_seg + __builtin_offsetof(TdsKA, n_envs));
+  const TR *const x_in = ka_x_in;
+  TR *__restrict__ const y_out = ka_y_out;
+  const TR *__restrict__ const actions = ka_actions;
+  TR *const x_feedback = ka_x_feedback;
+  TR *__restrict__ const obs_out = ka_obs_out;
+  T *const ovf = ka_ovf;
+  const int n_envs = ka_n_envs;
   // (the launch-wide conditions, from THIS iteration's arguments — shadowing the prologue's)
   const int nset = (LOOP && ctl.reset_mode != TDS_RESET_NONE) ? ctl.settle_steps : 0;
   const bool pol = LOOP && ctl.policy != nullptr;
@@ -1147,10 +1173,26 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
     stiff_l = mdl->stiffness[lsafe];
     damp_l = mdl->damping[lsafe];
   }
+  // Top of a step of a two-wavefront step loop, BOTH wavefronts: barrier (0).  The main wavefront arrives from its
+  // integration (the LDS record holds the state, reward and done flag of the step before), the helper — long waiting — from
+  // its late visual poses (it has read X_world of the step before: the main wavefront's kinematics sweep may overwrite it).
+  // Behind it the helper stores the END-of-step records of the step before (flush_prev_records) while the main wavefront
+  // runs A - C, in what used to be the helper's idle wait for barrier (1) — not between its narrowphase and its Jacobian
+  // rows, where every store instruction lengthened its path to barrier (2): with the records also going to seven peers
+  // (the peer-store exchange of an 8-GPU run) that was 12 % of the step (profiles/r05_peer_store_cost_one_gpu.txt).
+  // Round 4's form (-DTDS_FLUSH_EARLY=0): no barrier, the main wavefront polls the helper's "poses are out" flag.
+  // (lgkmcnt only: neither wavefront waits for its outstanding global stores here)
+#ifndef TDS_FLUSH_EARLY
+#define TDS_FLUSH_EARLY 1
+#endif
   if constexpr (W2 && LOOP) {
-    if (main_wave && tds_iter > 0) {  // the helper has read X_world of the previous step (its late visual poses, see there)
-      const volatile T *const pf = sm + grp * L.stride + L.xrec + in_dim + 4;
-      while (__any(*pf != T(2))) __builtin_amdgcn_s_sleep(1);
+    if constexpr (TDS_FLUSH_EARLY != 0) {
+      if (tds_iter > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      if (main_wave && tds_iter > 0) {  // the helper has read X_world of the previous step (its late visual poses, see there)
+        const volatile T *const pf = sm + grp * L.stride + L.xrec + in_dim + 4;
+        while (__any(*pf != T(2))) __builtin_amdgcn_s_sleep(1);
+      }
     }
   }
   const bool chain_child = (cflags & 1) != 0;      // my parent is lane - 1
@@ -1882,6 +1924,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       if constexpr (LOOP) {  // (TDS_RING_SIGNAL_LATE: the records stored in the iteration before this one)
         if (ctl.ring_flags & TDS_RING_SIGNAL_LATE) signal_progress(2);
       }
+      if constexpr (LOOP && TDS_FLUSH_EARLY != 0) flush_prev_records();  // (behind barrier (0): see there)
       __syncthreads();  // (1) the main wavefront has written the x record, X_world and the motion axes
       TDS_STAMP(2);
       T *const cpx = E + L.cp;
@@ -1904,7 +1947,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       if constexpr (!LOOP) {
         if (L.gram_ok) phase_M1();
       }
-      flush_prev_records();
+      if constexpr (!(LOOP && TDS_FLUSH_EARLY != 0)) flush_prev_records();
       if (pack_y && !(DEFER && ring_y)) {  // tail of the y record: up_dot_world_z, zero padding
         TR *const yo = y_step;
         int tail = nq + nd;

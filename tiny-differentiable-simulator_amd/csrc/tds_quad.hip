@@ -118,9 +118,9 @@ __host__ __device__ inline QuadOff quad_layout(int in_dim) {
   QuadOff o;
   int at = in_dim + 4;
   at = (at + 1) & ~1;
-  o.lcw = at;  at += 16 * QuadLds::LCW;   // L_c and W = L_c D of every leg-dof lane
+  o.lcw = at;  at += 12 * QuadLds::LCW;   // L_c and W = L_c D of the 12 leg-dof lanes (slot 3 leg + position)
   o.legf = at; at += 4 * 9 + 1;            // per leg: l10 l20 l21 | 1/d (3) | sqrt(1/d) (3)
-  o.swl = at;  at += 16 * 7;               // world motion axis of every leg lane (6, stride 7)
+  o.swl = at;  at += 12 * 7;               // world motion axis of the 12 leg-dof lanes (6, stride 7; slot 3 leg + position)
   o.qdp = at;  at += 16 + 6;               // velocities after integrate_euler_qdd: leg lanes | root
   o.S = at;    at += 21 + 1;               // Schur complement of the root block
   o.ax = at;   at += 6 * 7;                // the six root motion axes (stride 7)
@@ -245,10 +245,10 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   const T dt = QC(dt, dt);
   const bool last = it == nsteps - 1;
   if constexpr (LOOP) {
-    // the action block of this step (step 0's came in with the record) was requested at the top of the step before; the
+    // the action block of this step (step 0's came in with the record) was requested at the top of the step before and
+    // moved into the record's action slots at the END of that step, in front of its record stores (see phase M); the
     // next step's — block (act_first + it + 1) % act_blocks of the pool — is requested now: no step waits for HBM
     if (ctl.act_pool != nullptr) {  // wave-uniform
-      if (it > 0 && lane < adim) xr[nq + nd + lane] = next_act;
       if (it + 1 < nsteps && valid && lane < adim) {
         const int blk = (ctl.act_first + it + 1) % ctl.act_blocks;
         next_act = (T)((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
@@ -476,7 +476,9 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   {
     T *const swl = E + O.swl;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) swl[lane * 7 + k] = sw[k];
+    for (int k = 0; k < 6; ++k) {
+      if (dofl) swl[(3 * leg + pos) * 7 + k] = sw[k];
+    }
   }
 
   // ---- D. world-frame rigid inertia and bias force of my link, and (redundantly on every lane) of the root body
@@ -750,11 +752,17 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     }
   }
   {
-    T *const lcw = E + O.lcw + lane * QuadLds::LCW;
+    // (the toe lanes — fixed joints — have L_c = W = 0: no slot.  Twelve slots instead of sixteen, here and for the motion
+    //  axes, are what brings a workgroup's four environments under 20 KB of LDS: EIGHT workgroups per compute unit, so
+    //  that the 2048 workgroups of config 4 are resident at once — at seven per CU the last 256 ran behind the others,
+    //  28.5 us per step against 24.8 for 7168 environments, tools/quad_occupancy_sweep.sh)
+    T *const lcw = E + O.lcw + (3 * leg + pos) * QuadLds::LCW;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      lcw[r] = Lc[r];
-      lcw[6 + r] = W[r];
+      if (dofl) {
+        lcw[r] = Lc[r];
+        lcw[6 + r] = W[r];
+      }
     }
     if (pos == 0) {
       T *const lf = E + O.legf + leg * 9;
@@ -793,7 +801,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       times_inertia(It, srp, Fr);
       T acc = dot6(sr, Fr);
 #pragma unroll
-      for (int l = 0; l < 16; ++l) acc -= lcw[l * QuadLds::LCW + r] * lcw[l * QuadLds::LCW + 6 + rp];
+      for (int l = 0; l < 12; ++l) acc -= lcw[l * QuadLds::LCW + r] * lcw[l * QuadLds::LCW + 6 + rp];
       Sl_[e] = acc;
     }
   }
@@ -930,7 +938,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       for (int k = 0; k < 3; ++k) {
         T s[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) s[c] = swl[(4 * cl + k) * 7 + c];
+        for (int c = 0; c < 6; ++c) s[c] = swl[(3 * cl + k) * 7 + c];
         z[k] = jcol(s);
         vrow += z[k] * qdp[4 * cl + k];
       }
@@ -949,7 +957,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) zr[rr] -= lcw[(4 * cl + k) * QuadLds::LCW + rr] * z[k];
+        for (int rr = 0; rr < 6; ++rr) zr[rr] -= lcw[(3 * cl + k) * QuadLds::LCW + rr] * z[k];
       }
       static_for<1, 6>([&](auto rc) {
         constexpr int rr = decltype(rc)::value;
@@ -1068,6 +1076,13 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     }
     if (lane == 0) xr[in_dim] = q_old0;  // x_{t-1} (the Ant's reward reads it; kept for the record's sake)
   }
+  if constexpr (LOOP) {
+    // The next step's actions into the record's action slots (dead since the PD block) HERE, in front of this step's record
+    // stores — not at the top of the next step: loads and stores return through one in-order counter on gfx9 and the
+    // record stores sit in loops, so a wait for this load behind them is a wait for every one of them (vmcnt(0)): a full
+    // HBM write latency per step — what kept the step-loop form 2.7 us per step behind the single-step graphs.
+    if (ctl.act_pool != nullptr && !last && lane < adim) xr[nq + nd + lane] = next_act;
+  }
   QUAD_SYNC();
   // ---- y record: q | qd | (visual poses: M1) | up.z | zero padding
   if (valid && yo != nullptr) {
@@ -1166,6 +1181,10 @@ int tds_quad_lds_bytes(int input_dim) {
   return quad_layout(input_dim).stride * (int)sizeof(T);
 }
 template int tds_quad_lds_bytes<double>(int);
+// LDS bytes of one WORKGROUP (four environments) of a step-loop launch: the environments' regions + the constant table
+int tds_quad_loop_workgroup_bytes(int input_dim) {
+  return quad_layout(input_dim).stride * 4 * (int)sizeof(double) + (int)sizeof(QuadTable<double>);
+}
 template int tds_quad_lds_bytes<float>(int);
 
 template <typename T, typename TR>

@@ -3,9 +3,9 @@
 # no peer stores at all — experiment slots of tools/build_alt.sh 1614 "-DTDS_PEER_SCOPE=__HIP_MEMORY_SCOPE_AGENT" "-DTDS_X_PEER_NOSTORE"
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/r05c
+O=gpurun_out/${1:-r05c}
 mkdir -p $O
-for alt in 0 1 2; do
+for alt in ${ALTS:-0 1 2}; do
   OPT=""; [ $alt != 0 ] && OPT="--option alt_build=$alt"
   timeout 300 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline $OPT > $O/bench_alt$alt.json 2> $O/bench_alt$alt.err
   python3 - $O/bench_alt$alt.json $alt <<'P'
