@@ -143,8 +143,10 @@ def test_quad_step_loop_form_equals_single_steps(dtype, built):
     n, steps, slots = 2000, 24, 7
     rng = np.random.default_rng(6)
     x = g["x"][rng.integers(0, g["x"].shape[0], n)]
-    a = hip_backend.HipSim(m, n, dtype=dtype, options={"step_many_loop": 1})  # (without resets the library's own choice is the graphs)
-    b = hip_backend.HipSim(m, n, dtype=dtype)
+    # (the library's own choice: the step-loop form while every workgroup is resident at once — up to 6144 environments —
+    #  and the graphs of single steps beyond; both forced here)
+    a = hip_backend.HipSim(m, n, dtype=dtype, options={"step_many_loop": 1})
+    b = hip_backend.HipSim(m, n, dtype=dtype, options={"step_many_loop": 0})
     assert a.step_many_is_loop(steps) and not b.step_many_is_loop(steps) and a.single_step_kernel()[0] == "quad16"
     tdt = a.torch_dtype
     for s_ in (a, b):

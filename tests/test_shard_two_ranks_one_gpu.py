@@ -60,7 +60,9 @@ torch.cuda.synchronize()
 ref = hip_backend.HipSim(m, n_local, dtype="f64")
 ref.x.copy_(torch.from_numpy(xg[lo:hi]).cuda())
 obs = torch.zeros((n_local, ref.obs_dim + 2), dtype=torch.float64, device="cuda")
-if mode == "single" or not ref.step_many_is_loop(steps) or os.environ.get("TDS_HIP_SHARD_RING") == "0":
+# (bitwise comparison: the plain handle takes the form the shard took — single steps where the shard exchanges per step,
+#  e.g. the 16-lane quadruped kernel, whose step-loop compilation rounds differently from its straight-line one)
+if mode == "single" or form == "rccl_per_step" or not ref.step_many_is_loop(steps) or os.environ.get("TDS_HIP_SHARD_RING") == "0":
     for k in range(steps):
         ref.step(acts[k % 4], 1, obs)
 else:
