@@ -89,13 +89,25 @@ struct TdsStepCtl {
   // peer_arrive != NULL selects it (then progress == NULL); EVERY step of the launch is signalled, the last one included.
   const void *const *peer_ring;     // [n_peers] device array: base of peer p's gathered ring as mapped in this process
   unsigned long long *const *peer_flags;  // [n_peers + 1]: peer p's flag array [slots][world]; the last entry is this rank's own
-  unsigned int *peer_arrive;        // [obs_slots] arrival counters of this launch's slots (wrap at the grid size: atomicInc)
+  unsigned int *peer_arrive;        // [obs_slots][TDS_PEER_ARRIVE_STRIDE] arrival counters of this launch's slots: TDS_PEER_SUB
+                                    // first-level counters + one second-level counter per slot, a 128-byte line each
+                                    // (all wrap at their own count: atomicInc, never reset) — see peer_signal
   long long peer_off;               // bytes from a ring's base to THIS rank's block of the launch's slot 0
   unsigned long long peer_epoch;    // the launch's sequence number (what a completed slot's flags are raised to)
   int n_peers;                      // ranks other than this one (0: one rank — the counters and the own flags only)
   int peer_flag_off;                // flag index of this rank in the launch's slot 0: slot0 * world + rank
   int peer_flag_stride;             // flags per slot (= world)
 };
+// arrival counting of the peer-store exchange: workgroup b counts itself in on first-level counter b mod TDS_PEER_SUB of
+// the slot, the workgroup that completes a first-level counter on the slot's second-level counter.  One counter for the
+// whole grid — round 5's first form — serialised 1024 returning atomics on one address at the end of every launch
+// (device-scope atomics of eight XCDs meet at the memory side): + 35 us per launch whatever its length
+// (tools/call_overhead_trace.sh).  The host allocates the full stride whatever TDS_PEER_SUB a kernel was built with.
+#ifndef TDS_PEER_SUB
+#define TDS_PEER_SUB 32
+#endif
+#define TDS_PEER_LINE 32  /* unsigned ints per counter: one 128-byte line each */
+#define TDS_PEER_ARRIVE_STRIDE ((32 + 1) * TDS_PEER_LINE)
 #define TDS_RING_OBS_F32 1
 // the obs ring is written with device-scope write-through stores (sc1) and a step is signalled after a plain
 // s_waitcnt vmcnt(0) — no release fence, whose buffer_wbl2 writes back every dirty line of the L2

@@ -1185,9 +1185,15 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
 #ifndef TDS_FLUSH_EARLY
 #define TDS_FLUSH_EARLY 1
 #endif
+// (-DTDS_SIGNAL_IN_TAIL=1, experiment: the helper's barrier (0) behind its count-in of the step before last, so that the wait
+//  for store acknowledgements and the atomics' round trips falls into its idle tail instead of the A - C window — measured
+//  same process, one rank through the shard layer: 13.24 against 12.96 us per step at 256 steps per launch: not kept)
+#ifndef TDS_SIGNAL_IN_TAIL
+#define TDS_SIGNAL_IN_TAIL 0
+#endif
   if constexpr (W2 && LOOP) {
     if constexpr (TDS_FLUSH_EARLY != 0) {
-      if (tds_iter > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tds_iter > 0 && (main_wave || TDS_SIGNAL_IN_TAIL == 0)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
       if (main_wave && tds_iter > 0) {  // the helper has read X_world of the previous step (its late visual poses, see there)
         const volatile T *const pf = sm + grp * L.stride + L.xrec + in_dim + 4;
@@ -1482,19 +1488,26 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
   // nothing about the slowest workgroup; the slot's own counter reaches (uses of the slot) x (workgroups) exactly when
   // EVERY workgroup has stored its records of that step.
   // Peer-store exchange: this workgroup's records of ring slot `pslot` are out — acknowledged by the memory they went to,
-  // this rank's and the peers' — so it counts itself in on the slot's arrival counter (wrapping at the grid size: never
-  // reset); the workgroup that completes the slot raises the slot's flag of THIS rank on every rank, its own included, to
-  // the launch's sequence number.  Every store of every workgroup was acknowledged before that workgroup's count, and the
+  // this rank's and the peers' — so it counts itself in on the slot's arrival counters (two levels, each wrapping at its own
+  // count: never reset); the workgroup that completes the slot raises the slot's flag of THIS rank on every rank, its own
+  // included, to the launch's sequence number.  Every store of every workgroup was acknowledged before that workgroup's count, and the
   // flag stores are issued after the last count returned: a rank that sees the flag sees the records.
   auto peer_signal = [&](int pslot) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     if ((threadIdx.x & 63) == 0) {
-      const unsigned last = gridDim.x - 1u;
-      const unsigned old = atomicInc(ctl.peer_arrive + pslot, last);
-      if (old == last) {
-        const size_t fi = (size_t)ctl.peer_flag_off + (size_t)pslot * (size_t)ctl.peer_flag_stride;
-        for (int pr = 0; pr <= ctl.n_peers; ++pr)
-          __hip_atomic_store(ctl.peer_flags[pr] + fi, ctl.peer_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // two levels (tds_kernels.h: TDS_PEER_SUB): workgroup b on first-level counter b mod SUB, whoever completes one on
+      // the second level; every counter wraps at its own count and lives on a line of its own
+      constexpr unsigned SUB = TDS_PEER_SUB;
+      const unsigned g = gridDim.x, j = blockIdx.x % SUB;
+      const unsigned n1 = (g - j + SUB - 1u) / SUB;  // workgroups that count on first-level counter j
+      const unsigned n2 = g < SUB ? g : SUB;          // first-level counters in use
+      unsigned *const base = ctl.peer_arrive + (size_t)pslot * TDS_PEER_ARRIVE_STRIDE;
+      if (atomicInc(base + j * TDS_PEER_LINE, n1 - 1u) == n1 - 1u) {
+        if (atomicInc(base + 32 * TDS_PEER_LINE, n2 - 1u) == n2 - 1u) {
+          const size_t fi = (size_t)ctl.peer_flag_off + (size_t)pslot * (size_t)ctl.peer_flag_stride;
+          for (int pr = 0; pr <= ctl.n_peers; ++pr)
+            __hip_atomic_store(ctl.peer_flags[pr] + fi, ctl.peer_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
   };
@@ -1923,6 +1936,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       TDS_STAMP(1);
       if constexpr (LOOP) {  // (TDS_RING_SIGNAL_LATE: the records stored in the iteration before this one)
         if (ctl.ring_flags & TDS_RING_SIGNAL_LATE) signal_progress(2);
+      }
+      if constexpr (LOOP && TDS_FLUSH_EARLY != 0 && TDS_SIGNAL_IN_TAIL != 0) {
+        if (tds_iter > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier (0), the helper's side
       }
       if constexpr (LOOP && TDS_FLUSH_EARLY != 0) flush_prev_records();  // (behind barrier (0): see there)
       __syncthreads();  // (1) the main wavefront has written the x record, X_world and the motion axes

@@ -241,7 +241,7 @@ struct tds_hip_shard {
   int n_peers = 0;               // ranks other than this one (+ loopback "peers": scratch rings of this rank's own)
   int n_real_peers = 0;
   unsigned long long *pflags = nullptr;  // [ring slots][world] arrival flags | credit[world] | test[world]  (uncached where offered)
-  unsigned int *parrive = nullptr;       // [ring slots] arrival counters of this rank's own launches
+  unsigned int *parrive = nullptr;       // [ring slots][TDS_PEER_ARRIVE_STRIDE] arrival counters of this rank's own launches
   void *peer_ring_map[TDS_MAX_PEERS] = {};   // the peers' rgath / pflags as mapped here (hipIpcOpenMemHandle), peer order =
   void *peer_flag_map[TDS_MAX_PEERS] = {};   //   rank order without this rank
   bool peer_opened[TDS_MAX_PEERS] = {};      // (mapped through IPC: closed in ring_free; loopback rings are hipFree'd)
@@ -465,8 +465,8 @@ int peer_setup(tds_hip_shard *sh, size_t ring_slots, size_t slot_b) {
     }
     sh->pflags = (unsigned long long *)pf;
     TDS_HIP_TRY(hipMemset(sh->pflags, 0, n_flags * sizeof(unsigned long long)));
-    TDS_HIP_TRY(hipMalloc((void **)&sh->parrive, ring_slots * sizeof(unsigned int)));
-    TDS_HIP_TRY(hipMemset(sh->parrive, 0, ring_slots * sizeof(unsigned int)));
+    TDS_HIP_TRY(hipMalloc((void **)&sh->parrive, ring_slots * TDS_PEER_ARRIVE_STRIDE * sizeof(unsigned int)));
+    TDS_HIP_TRY(hipMemset(sh->parrive, 0, ring_slots * TDS_PEER_ARRIVE_STRIDE * sizeof(unsigned int)));
     TDS_HIP_TRY(hipDeviceSynchronize());
   }
   if (sh->world > 1 && !sh->comm) return TDS_OK;  // (no communicator, several ranks: nothing collective can be set up)
@@ -785,7 +785,7 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
     TdsPeerLaunch pl;
     pl.rings = (const void *const *)sh->d_peer_tab;
     pl.flags = ftab;
-    pl.arrive = sh->parrive + ck.slot0;
+    pl.arrive = sh->parrive + (size_t)ck.slot0 * TDS_PEER_ARRIVE_STRIDE;
     pl.ring_off = (long long)(((size_t)ck.slot0 * sh->world + sh->rank) * slot_b);
     pl.epoch = seq;
     pl.n_peers = np;
