@@ -72,12 +72,50 @@ namespace {
 // SPLIT with yt_flag != nullptr: the helper also completes b_r itself, with z~_r still in registers, as soon as the main
 // wavefront has published y~ (flag in LDS, polled: the main wavefront is ~2 k cycles ahead at that point) — same
 // arithmetic as tds_row_rhs_finish, which the main wavefront then skips.
+// LDS flags between the two wavefronts of a workgroup.  Through a `volatile T *` (generic address space: the address-space
+// inference leaves volatile accesses alone) every one of them was a FLAT instruction with sc0 sc1 and an `s_waitcnt vmcnt(0)`
+// of its own — eight flat stores + waits in the middle of the main wavefront's LDL^T (the hand-over of the first half of L),
+// a flat load + wait per poll.  These go to the LDS address space explicitly: ds_read / ds_write, lgkmcnt only.
+// (-DTDS_LDS_FLAGS=0: round 4's volatile generic pointers)
+#ifndef TDS_LDS_FLAGS
+#define TDS_LDS_FLAGS 1
+#endif
+#ifndef TDS_LDS_PUBLISH
+#define TDS_LDS_PUBLISH 1
+#endif
+#define TDS_AS3 __attribute__((address_space(3)))
+// A pointer that was LOADED (a field of the kernel-argument structs read through the laundered segment pointer, an entry of a
+// pointer table) has no address space the compiler could know: its accesses are FLAT instructions — both counters, out of
+// order with the DS instructions, and a flat LOAD (the action block requested a step ahead) holds the next LDS wait until it
+// has returned from memory.  tds_global() says "global memory" (an assumption `neither LDS nor scratch`, which the
+// address-space inference pass turns into address space 1 for every access derived from the pointer).  -DTDS_RINGS_GLOBAL=0: the loaded pointers as they are.
+#ifndef TDS_RINGS_GLOBAL
+#define TDS_RINGS_GLOBAL 1
+#endif
+template <typename P>
+__device__ __forceinline__ P *tds_global(P *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (TDS_RINGS_GLOBAL != 0)
+    __builtin_assume(!__builtin_amdgcn_is_shared((const void *)p) && !__builtin_amdgcn_is_private((const void *)p));
+#endif
+  return p;
+}
+template <int WHO = 1, typename T>
+__device__ __forceinline__ T tds_lds_poll(const T *p) {  // WHO: 1 the main wavefront's polls, 2 the helper's
+  if constexpr ((TDS_LDS_FLAGS & WHO) != 0) return *(const volatile TDS_AS3 T *)p;
+  else return *(const volatile T *)p;
+}
+template <typename T>
+__device__ __forceinline__ void tds_lds_flag(T *p, T v) {
+  if constexpr (TDS_LDS_PUBLISH != 0) *(volatile TDS_AS3 T *)p = v;
+  else *(volatile T *)p = v;
+}
 template <bool SLAB, typename T, int G, int NDP, bool SPLIT = false>
 __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, int ZR, int OVR, int NCPp,
                                               T *Zs, T *rws, T *xs, const T *qdv, const T *cpx, const T *Lp,
                                               const T *dvec, volatile T *zov, volatile T *rov, T cfm, T erp_dt,
-                                              T rest, const volatile T *yt_flag = nullptr, T dt = T(0),
-                                              const volatile T *col_flag = nullptr, const T *Lh = nullptr) {
+                                              T rest, const T *yt_flag = nullptr, T dt = T(0),
+                                              const T *col_flag = nullptr, const T *Lh = nullptr) {
   constexpr int NDs = NDP + 1;
   // ROW LAYOUT (wave-uniform): NA = largest number of penetrating contacts among the wavefront's
   // environments; row a = normal of contact a, NA + a = tangent 1, 2 NA + a = tangent 2.  An environment
@@ -123,7 +161,7 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
         if constexpr (SPLIT && !SLAB) {
           if (col_flag != nullptr && (j == 0 || j == NDP / 2)) {  // wave-uniform
             const T need = j == 0 ? T(1) : T(2);
-            while (__any(*col_flag < need)) __builtin_amdgcn_s_sleep(1);
+            while (__any(tds_lds_poll<2>(col_flag) < need)) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (compile-time order of the LDS reads only)
             __builtin_amdgcn_wave_barrier();
           }
@@ -144,7 +182,7 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
     }
     if constexpr (SPLIT && !SLAB) {
       if (yt_flag != nullptr) {  // wave-uniform
-        while (__any(*yt_flag == T(0))) __builtin_amdgcn_s_sleep(1);
+        while (__any(tds_lds_poll<2>(yt_flag) == T(0))) __builtin_amdgcn_s_sleep(1);
         if (real) {
           const T *const yt = dvec + 3 * NDP;
           T s = T(0);
@@ -1034,12 +1072,35 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
     if (!__any(mode != TDS_MODE_IDLE)) break;
   }
   int lane_l = lane0, grp_l = grp0;
-  const DevModel<T> *mdl = mdl_arg;
+  // (the model pointer is laundered as a GLOBAL-address-space pointer: laundered as a generic one — round 4 — the address
+  //  space was lost with the provenance and every model constant of a step-loop build came in through a FLAT load, which
+  //  counts on vmcnt AND lgkmcnt and returns out of order with the DS instructions: every LDS wait behind one became
+  //  lgkmcnt(0).  -DTDS_MDL_GLOBAL=0: the generic pointer)
+#ifndef TDS_MDL_GLOBAL
+#define TDS_MDL_GLOBAL 1
+#endif
+  // (TDS_MDL_GLOBAL = 2: the CONSTANT address space — the model is read-only for the kernel — so that loads at uniform
+  //  addresses through the laundered pointer are scalar loads again (the header fields every iteration starts with: as
+  //  vector loads a round trip to L2 at the top of every step), as they are in the straight-line builds, whose pointer is the
+  //  `const __restrict__` kernel argument itself)
+#if TDS_MDL_GLOBAL == 2
+#define TDS_MDL_AS 4
+#else
+#define TDS_MDL_AS 1
+#endif
+  const __attribute__((address_space(TDS_MDL_AS))) DevModel<T> *mdl_g = (const __attribute__((address_space(TDS_MDL_AS))) DevModel<T> *)mdl_arg;
+  const DevModel<T> *mdl_f = mdl_arg;
   // (the 32-dof build is at one wavefront per SIMD whatever is done and fares better with the lane constants
   //  hoisted into AGPR copies — 256 + 130 registers, no scratch, against 256 + 256 + 876 B of scratch: only the
   //  model pointer is laundered there)
-  if constexpr (LOOP && NDP < 32) asm volatile("" : "+v"(lane_l), "+v"(grp_l), "+s"(mdl));
-  if constexpr (LOOP && NDP >= 32) asm volatile("" : "+s"(mdl));
+  if constexpr (TDS_MDL_GLOBAL != 0) {
+    if constexpr (LOOP && NDP < 32) asm volatile("" : "+v"(lane_l), "+v"(grp_l), "+s"(mdl_g));
+    if constexpr (LOOP && NDP >= 32) asm volatile("" : "+s"(mdl_g));
+  } else {
+    if constexpr (LOOP && NDP < 32) asm volatile("" : "+v"(lane_l), "+v"(grp_l), "+s"(mdl_f));
+    if constexpr (LOOP && NDP >= 32) asm volatile("" : "+s"(mdl_f));
+  }
+  const DevModel<T> *const mdl = TDS_MDL_GLOBAL != 0 ? (const DevModel<T> *)mdl_g : mdl_f;
   const int lane = lane_l, grp = grp_l;
   // ---- the kernel arguments of this iteration (step-loop builds: read through a laundered segment pointer, see TdsKaRef)
   constexpr bool KA = LOOP && TDS_KA_RELOAD != 0;
@@ -1062,12 +1123,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
   TR *const ka_obs_out = tds_ka_val<KP, TR *>(obs_out, ka_seg + __builtin_offsetof(TdsKA, obs_out));
   T *const ka_ovf = tds_ka_val<KP, T *>(ovf, ka_seg + __builtin_offsetof(TdsKA, ovf));
   const int ka_n_envs = tds_ka_val<KP, int>(n_envs, ka_seg + __builtin_offsetof(TdsKA, n_envs));
-  const TR *const x_in = ka_x_in;
-  TR *__restrict__ const y_out = ka_y_out;
-  const TR *__restrict__ const actions = ka_actions;
-  TR *const x_feedback = ka_x_feedback;
-  TR *__restrict__ const obs_out = ka_obs_out;
-  T *const ovf = ka_ovf;
+  const TR *const x_in = tds_global(ka_x_in);
+  TR *__restrict__ const y_out = tds_global(ka_y_out);
+  const TR *__restrict__ const actions = tds_global(ka_actions);
+  TR *const x_feedback = tds_global(ka_x_feedback);
+  TR *__restrict__ const obs_out = tds_global(ka_obs_out);
+  T *const ovf = tds_global(ka_ovf);
   const int n_envs = ka_n_envs;
   // (the launch-wide conditions, from THIS iteration's arguments — shadowing the prologue's)
   const int nset = (LOOP && ctl.reset_mode != TDS_RESET_NONE) ? ctl.settle_steps : 0;
@@ -1093,17 +1154,27 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
   const bool cwt = LOOP && KIND == 0 && L.cw != 0;  // wave-uniform
   constexpr int CWL = TDS_CW_LANE(sizeof(T));
   const T *const CW = sm + EPW * L.stride;
+  // (read through an LDS-address-space pointer: as generic pointers the compiler merged "table or model" into ONE flat load
+  //  through a selected pointer — table reads that went the flat path, out of order with the DS instructions)
+#ifndef TDS_CW_LDS
+#define TDS_CW_LDS 1
+#endif
+#if TDS_CW_LDS
+  const TDS_AS3 T *const CWl = (const TDS_AS3 T *)CW;
+#else
+  const T *const CWl = CW;
+#endif
   int parent, level, jt, di;
   unsigned cw_hi = 0u;
   if (cwt) {
     unsigned cw_lo;
     if constexpr (sizeof(T) == 8) {
-      const double pk = (double)CW[3 * G + lane];
+      const double pk = (double)CWl[3 * G + lane];
       cw_lo = (unsigned)__double2loint(pk);
       cw_hi = (unsigned)__double2hiint(pk);
     } else {
-      cw_lo = scalar_to_bits<T>(CW[3 * G + lane]);
-      cw_hi = scalar_to_bits<T>(CW[4 * G + lane]);
+      cw_lo = scalar_to_bits<T>(CWl[3 * G + lane]);
+      cw_hi = scalar_to_bits<T>(CWl[4 * G + lane]);
     }
     parent = (int)(cw_lo & 255u) - 1;
     level = (int)((cw_lo >> 8) & 255u) - 1;
@@ -1161,9 +1232,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
     my_slot = (int)((cw_hi >> 8) & 255u) - 1;
     par_slot = (int)((cw_hi >> 16) & 255u) - 1;
     act_i = (int)(cw_hi >> 24) - 1;
-    init_pose_l = CW[0 * G + lane];
-    stiff_l = CW[1 * G + lane];
-    damp_l = CW[2 * G + lane];
+    init_pose_l = CWl[0 * G + lane];
+    stiff_l = CWl[1 * G + lane];
+    damp_l = CWl[2 * G + lane];
   } else {
     cflags = isl ? mdl->chain_flags[lsafe] : 0;
     my_slot = isl ? mdl->lc_slot[lsafe] : -1;
@@ -1196,8 +1267,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       if (tds_iter > 0 && (main_wave || TDS_SIGNAL_IN_TAIL == 0)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
       if (main_wave && tds_iter > 0) {  // the helper has read X_world of the previous step (its late visual poses, see there)
-        const volatile T *const pf = sm + grp * L.stride + L.xrec + in_dim + 4;
-        while (__any(*pf != T(2))) __builtin_amdgcn_s_sleep(1);
+        const T *const pf = sm + grp * L.stride + L.xrec + in_dim + 4;
+        while (__any(tds_lds_poll(pf) != T(2))) __builtin_amdgcn_s_sleep(1);
       }
     }
   }
@@ -1223,9 +1294,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
 #pragma unroll
       for (int k = 0; k < 9; ++k) Il[k] = md->inertia[k][lsafe];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) RT[k] = CW[(CWL + k) * G + lane];
+      for (int k = 0; k < 9; ++k) RT[k] = CWl[(CWL + k) * G + lane];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) tT[k] = CW[(CWL + 9 + k) * G + lane];
+      for (int k = 0; k < 3; ++k) tT[k] = CWl[(CWL + 9 + k) * G + lane];
       return;
     }
 #pragma unroll
@@ -1311,7 +1382,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       // that end a step (y / obs rings) would wait for those stores too: a full HBM write latency per step
       if (valid && lane < adim) {
         const int blk = (ctl.act_first + tds_iter + 1) % ctl.act_blocks;
-        next_act = (T)((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
+        next_act = (T)tds_global((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
       }
     }
     // ---- rollout mode: action = W obs + b with the environment's own parameters
@@ -1341,11 +1412,11 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
   auto ring_put = [&](size_t idx, T v) {
     const int rf = ctl.ring_flags;
     if (rf & TDS_RING_OBS_F32) {
-      float *const p = (float *)ctl.obs_ring + idx;
+      float *const p = tds_global((float *)ctl.obs_ring) + idx;
       if (rf & TDS_RING_NOFENCE) __hip_atomic_store(p, (float)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else TDS_NT_STORE((float)v, p);
     } else {
-      TR *const p = (TR *)ctl.obs_ring + idx;
+      TR *const p = tds_global((TR *)ctl.obs_ring) + idx;
       if (rf & TDS_RING_NOFENCE) __hip_atomic_store(p, (TR)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else TDS_NT_STORE((TR)v, p);
     }
@@ -1414,7 +1485,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
     const int per_unit = f32w ? 2 : 1;                 // scalars per 8-byte unit
     const int n_units = (EPW * w) / per_unit;
     const int np = ctl.n_peers;
-    const unsigned long long *const *tab = (const unsigned long long *const *)ctl.peer_ring;
+    const unsigned long long *const *tab = tds_global((const unsigned long long *const *)ctl.peer_ring);
     for (int u0 = 0; u0 < n_units; u0 += 64) {  // (one pass on a float wire up to 128 scalars per wavefront)
       const int u = u0 + wl;
       const bool on = u < n_units;
@@ -1446,10 +1517,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
         bits = ((unsigned long long)hi << 32) | (unsigned long long)lo;
       }
       const size_t unit_at = row0 / per_unit + (size_t)u;  // (row0 is a multiple of per_unit: TDS_RING_WIDE)
-      if (on) __hip_atomic_store((unsigned long long *)ctl.obs_ring + unit_at, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (on) __hip_atomic_store(tds_global((unsigned long long *)ctl.obs_ring) + unit_at, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool to_peers = on && (!rd_only || tail);
       for (int p0 = 0; p0 < np; p0 += 4) {  // (the table is padded to a multiple of four entries)
-        const unsigned long long *const b0 = tab[p0], *const b1 = tab[p0 + 1], *const b2 = tab[p0 + 2], *const b3 = tab[p0 + 3];
+        const unsigned long long *const b0 = tds_global(tab[p0]), *const b1 = tds_global(tab[p0 + 1]), *const b2 = tds_global(tab[p0 + 2]), *const b3 = tds_global(tab[p0 + 3]);
         const size_t po = (size_t)ctl.peer_off / 8 + unit_at;
 #ifdef TDS_X_PEER_NOSTORE  // (experiment: everything but the peers' stores themselves)
         if (to_peers && po == ~(size_t)0) {
@@ -1470,7 +1541,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       if ((ring_o || ring_y) && tds_iter > 0) {  // wave-uniform
         const bool mine = valid && mode == TDS_MODE_RUN && xr[in_dim + OUT_SLOT] == T(0);
         if (ring_y && mine)
-          put_y_state((TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter - 1) % ctl.y_slots) * ctl.ring_envs + env) * ystr, ystr);
+          put_y_state(tds_global((TR *)ctl.y_ring) + ((size_t)((ctl.y_first + tds_iter - 1) % ctl.y_slots) * ctl.ring_envs + env) * ystr, ystr);
         if (ring_o) {
           // (peer-store exchange: the wavefront's records as one burst where all of its environments store this step)
           if (ctl.peer_arrive != nullptr && (ctl.ring_flags & TDS_RING_WIDE) != 0 && __all(mine))
@@ -1529,7 +1600,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
     }
   };
   const bool pack_y = ring_y ? (valid && mode == TDS_MODE_RUN) : (last_run && y_out != nullptr);
-  TR *const y_step = ring_y ? (TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env) * ystr
+  TR *const y_step = ring_y ? tds_global((TR *)ctl.y_ring) + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env) * ystr
                             : y_out + (size_t)env * (LOOP ? out_dim : ystr);
   // ---- the phases that a two-wavefront workgroup hands to its helper wavefront, as closures (each derives the LDS
   //      addresses it needs itself: nothing is kept live for them across the phases in between)
@@ -1639,7 +1710,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
         Xw_l = sm + grp_2 * L.stride + L.Xw;
       }
       TR *const yo = !late ? y_step
-                           : (ring_y ? (TR *)ctl.y_ring + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env_l) * ystr
+                           : (ring_y ? tds_global((TR *)ctl.y_ring) + ((size_t)((ctl.y_first + tds_iter) % ctl.y_slots) * ctl.ring_envs + env_l) * ystr
                                      : y_out + (size_t)env_l * (LOOP ? out_dim : ystr));
       const int nv = pf_nv;
       const int vbase = nq + nd;
@@ -3066,11 +3137,21 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
           // diagonal are written too and never read)
           // (volatile stores: kept in program order — data, then flag — without a scheduling barrier in the middle of
           //  the factorisation)
-          volatile T *const Lh = E + L.Lh + (lane < 16 ? lane : 16) * (NDP / 2);  // (row 16: lanes beyond the rows)
+          if constexpr (TDS_LDS_PUBLISH != 0) {
+            // (volatile stores into the LDS address space: kept in program order — data, then flag — without a scheduling
+            //  barrier in the middle of the factorisation, as ds_write instructions)
+            volatile TDS_AS3 T *const Lh = (volatile TDS_AS3 T *)(E + L.Lh + (lane < 16 ? lane : 16) * (NDP / 2));  // (row 16: lanes beyond the rows)
 #pragma unroll
-          for (int j = 0; j <= k; ++j) Lh[j] = Mr[j];
-          // (flag by lane 0, the other lanes hit a scratch slot of their own: an address select, no branch)
-          *(volatile T *)(lane == 0 ? xr + in_dim + 5 : dvec + 2 * NDP + (lane < NDP ? lane : NDP - 1)) = T(1);
+            for (int j = 0; j <= k; ++j) Lh[j] = Mr[j];
+            // (flag by lane 0, the other lanes hit a scratch slot of their own: an address select, no branch)
+            *(volatile TDS_AS3 T *)(lane == 0 ? xr + in_dim + 5 : dvec + 2 * NDP + (lane < NDP ? lane : NDP - 1)) = T(1);
+          } else {
+            volatile T *const Lh = E + L.Lh + (lane < 16 ? lane : 16) * (NDP / 2);  // (row 16: lanes beyond the rows)
+#pragma unroll
+            for (int j = 0; j <= k; ++j) Lh[j] = Mr[j];
+            // (flag by lane 0, the other lanes hit a scratch slot of their own: an address select, no branch)
+            *(volatile T *)(lane == 0 ? xr + in_dim + 5 : dvec + 2 * NDP + (lane < NDP ? lane : NDP - 1)) = T(1);
+          }
         }
       } else {
         // wider systems: every lane publishes its column-k entry once, all lanes read the column
@@ -3113,8 +3194,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
     if constexpr (W2) {
       if constexpr (PIPE) {
         // (2') no barrier: the helper has long written its contact counts (after its Jacobian rows) — poll them
-        const volatile T *const cnt = xr + in_dim + 3;
-        while (__any(scalar_to_bits<T>(*cnt) == 0xFFFFFFFFu)) __builtin_amdgcn_s_sleep(1);
+        const T *const cnt = xr + in_dim + 3;
+        while (__any(scalar_to_bits<T>(tds_lds_poll(cnt)) == 0xFFFFFFFFu)) __builtin_amdgcn_s_sleep(1);
         TDS_WAVE_SYNC();
       } else {
         __syncthreads();  // (2) L, 1/D are in LDS for the helper wavefront's row solves; its contact list and rows are visible here
@@ -3667,7 +3748,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       TDS_WAVE_SYNC();  // lane 0's done flag
       if (live && xr[in_dim + 1] != T(0)) {
         const unsigned c = ctl.reset_count[env];
-        const TR *const src = (const TR *)ctl.pool + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
+        const TR *const src = tds_global((const TR *)ctl.pool) + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
         for (int i = lane; i < nq + nd; i += G) {
           const TR v = src[i];
           if (obs_out != nullptr) obs_out[(size_t)env * (nq + nd + 2) + i] = i < 2 ? TR(0) : v;
@@ -3716,7 +3797,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
         // entry (reset count mod depth) of the environment's ring is the state reset() + the settle steps lead to
         if (done_now) {
           const unsigned c = ctl.reset_count[env];
-          const TR *const src = (const TR *)ctl.pool + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
+          const TR *const src = tds_global((const TR *)ctl.pool) + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
           for (int i = lane; i < nq + nd; i += G) xr[i] = (T)src[i];
           __builtin_amdgcn_wave_barrier();
           if (lane == 0) ctl.reset_count[env] = c + 1u;

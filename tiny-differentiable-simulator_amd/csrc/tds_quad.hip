@@ -58,6 +58,15 @@ __device__ __forceinline__ float quad_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xF, 0xF, true));
 }
 
+// launder a model pointer WITHOUT losing its address space (laundered as a generic pointer every access behind it is a FLAT
+// load: both counters, out of order with the DS instructions — see tds_kernels.hip)
+#define QUAD_LAUNDER_MODEL(dst, src)                                                                                    \
+  const DevModel<T> *dst;                                                                                               \
+  {                                                                                                                     \
+    const __attribute__((address_space(1))) DevModel<T> *g_ = (const __attribute__((address_space(1))) DevModel<T> *)(src); \
+    asm volatile("" : "+s"(g_));                                                                                        \
+    dst = (const DevModel<T> *)g_;                                                                                      \
+  }
 #define QUAD_SYNC()                                            \
   do {                                                         \
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     \
@@ -225,10 +234,11 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   T next_act = T(0);  // (step-loop form: the action block of the NEXT step, requested a step ahead)
   for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
   // (nothing but `it` lives across an iteration: lane, model pointer and kernel-argument segment are laundered)
-  const DevModel<T> *mdl = mdl_arg;
+  const __attribute__((address_space(1))) DevModel<T> *mdl_g = (const __attribute__((address_space(1))) DevModel<T> *)mdl_arg;
   const __attribute__((address_space(4))) char *ka_seg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
   int tid = threadIdx.x;
-  if constexpr (LOOP) asm volatile("" : "+s"(mdl), "+s"(ka_seg), "+v"(tid));
+  if constexpr (LOOP) asm volatile("" : "+s"(mdl_g), "+s"(ka_seg), "+v"(tid));
+  const DevModel<T> *const mdl = (const DevModel<T> *)mdl_g;
   const int lane = tid & 15;
   const int grp = (tid & 63) >> 4;
   const int env = blockIdx.x * 4 + grp;
@@ -588,8 +598,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   }
   const int nv = QC(num_visuals, num_visuals);
   if (valid && yo != nullptr && nv > 0) {
-    const DevModel<T> *md3 = mdl;  // (see the rigid inertia above: the visuals' constants are fetched where they are used)
-    asm volatile("" : "+s"(md3));
+    QUAD_LAUNDER_MODEL(md3, mdl)  // (see the rigid inertia above: the visuals' constants are fetched where they are used)
     auto pose_out = [&](const T *Rl, const T *pl, int k) {
       T Rv[9], pv[3], Ro[9], po[3], qo[4];
 #pragma unroll
@@ -626,8 +635,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   {
     // (my link's rigid inertia is fetched HERE, through a pointer laundered at this point: requested at the top of the step
     //  "under the latency of the record" the scheduler kept 13 values alive — or spilled — through the kinematics)
-    const DevModel<T> *md2 = mdl;
-    asm volatile("" : "+s"(md2));
+    QUAD_LAUNDER_MODEL(md2, mdl)
     T Il[9], com_l[3];
     const T mass_l = LOOP ? CT->mass[lane] : md2->mass[li];
 #pragma unroll
@@ -638,8 +646,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   }
   T It[10], ft[6];  // the root body's; below: + the legs' composites = the whole robot's
   {
-    const DevModel<T> *md4 = mdl;
-    asm volatile("" : "+s"(md4));
+    QUAD_LAUNDER_MODEL(md4, mdl)
     const T com5[3] = {LOOP ? CT->com5[0] : md4->com[0][5], LOOP ? CT->com5[1] : md4->com[1][5], LOOP ? CT->com5[2] : md4->com[2][5]};
     T I5[9];
 #pragma unroll
@@ -906,8 +913,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     T *const rws = E + O.rws;  // [4][12]: b | 1 / (G + cfm) | G | leg
     T *const xs = E + O.xs;
     const int nr = 3 * NA;
-    const DevModel<T> *md5 = mdl;  // (the contact frame and the solver's scalars are fetched here, not at the top of the step)
-    asm volatile("" : "+s"(md5));
+    QUAD_LAUNDER_MODEL(md5, mdl)  // (the contact frame and the solver's scalars are fetched here, not at the top of the step)
     const T nb[3] = {LOOP ? CT->nb[0] : md5->nb[0], LOOP ? CT->nb[1] : md5->nb[1], LOOP ? CT->nb[2] : md5->nb[2]};
     const T t1v[3] = {LOOP ? CT->t1[0] : md5->t1[0], LOOP ? CT->t1[1] : md5->t1[1], LOOP ? CT->t1[2] : md5->t1[2]};
     const T t2v[3] = {LOOP ? CT->t2[0] : md5->t2[0], LOOP ? CT->t2[1] : md5->t2[1], LOOP ? CT->t2[2] : md5->t2[2]};
