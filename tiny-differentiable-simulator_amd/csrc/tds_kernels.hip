@@ -103,6 +103,13 @@ __device__ __forceinline__ P *tds_global(P *p) {
 template <int WHO = 1, typename T>
 __device__ __forceinline__ T tds_lds_poll(const T *p) {  // WHO: 1 the main wavefront's polls, 2 the helper's
   if constexpr ((TDS_LDS_FLAGS & WHO) != 0) return *(const volatile TDS_AS3 T *)p;
+  else if constexpr ((TDS_LDS_FLAGS & (WHO << 2)) != 0) {  // (bits 4 / 8: the DS read spelled out)
+    const unsigned a = (unsigned)(unsigned long long)(const TDS_AS3 T *)p;
+    T v;
+    if constexpr (sizeof(T) == 8) asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+  }
   else return *(const volatile T *)p;
 }
 template <typename T>
@@ -1075,9 +1082,10 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
   // (the model pointer is laundered as a GLOBAL-address-space pointer: laundered as a generic one — round 4 — the address
   //  space was lost with the provenance and every model constant of a step-loop build came in through a FLAT load, which
   //  counts on vmcnt AND lgkmcnt and returns out of order with the DS instructions: every LDS wait behind one became
-  //  lgkmcnt(0).  -DTDS_MDL_GLOBAL=0: the generic pointer)
+  //  lgkmcnt(0).  -DTDS_MDL_GLOBAL=0: the generic pointer, 1: global, 2 (default): constant address space, see below;
+  //  same-process A/B, Ant x 4096 / x 8192, us per step: 12.10 / 21.02 -> 12.04 / 20.56 -> 11.58 / 19.91)
 #ifndef TDS_MDL_GLOBAL
-#define TDS_MDL_GLOBAL 1
+#define TDS_MDL_GLOBAL 2
 #endif
   // (TDS_MDL_GLOBAL = 2: the CONSTANT address space — the model is read-only for the kernel — so that loads at uniform
   //  addresses through the laundered pointer are scalar loads again (the header fields every iteration starts with: as

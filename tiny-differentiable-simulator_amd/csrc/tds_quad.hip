@@ -60,10 +60,14 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 // launder a model pointer WITHOUT losing its address space (laundered as a generic pointer every access behind it is a FLAT
 // load: both counters, out of order with the DS instructions — see tds_kernels.hip)
+#ifndef QUAD_MDL_AS
+#define QUAD_MDL_AS 4  /* 4 constant address space (the model is read-only: scalar loads at uniform addresses), 1 global, 0 generic
+                         (flat loads: round 5's first form) — laikago_soft x 8192: 23.2 / 24.5 / 24.8 us per step */
+#endif
 #define QUAD_LAUNDER_MODEL(dst, src)                                                                                    \
   const DevModel<T> *dst;                                                                                               \
   {                                                                                                                     \
-    const __attribute__((address_space(1))) DevModel<T> *g_ = (const __attribute__((address_space(1))) DevModel<T> *)(src); \
+    const __attribute__((address_space(QUAD_MDL_AS))) DevModel<T> *g_ = (const __attribute__((address_space(QUAD_MDL_AS))) DevModel<T> *)(src); \
     asm volatile("" : "+s"(g_));                                                                                        \
     dst = (const DevModel<T> *)g_;                                                                                      \
   }
@@ -234,7 +238,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   T next_act = T(0);  // (step-loop form: the action block of the NEXT step, requested a step ahead)
   for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
   // (nothing but `it` lives across an iteration: lane, model pointer and kernel-argument segment are laundered)
-  const __attribute__((address_space(1))) DevModel<T> *mdl_g = (const __attribute__((address_space(1))) DevModel<T> *)mdl_arg;
+  const __attribute__((address_space(QUAD_MDL_AS))) DevModel<T> *mdl_g = (const __attribute__((address_space(QUAD_MDL_AS))) DevModel<T> *)mdl_arg;
   const __attribute__((address_space(4))) char *ka_seg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
   int tid = threadIdx.x;
   if constexpr (LOOP) asm volatile("" : "+s"(mdl_g), "+s"(ka_seg), "+v"(tid));
