@@ -1467,7 +1467,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       if constexpr (LOOP) {
         if (np > 0 && (i >= nq + nd || !rd_only)) {
           for (int pr = 0; pr < np; ++pr) {
-            char *const pb = (char *)ctl.peer_ring[pr] + ctl.peer_off;
+            char *const pb = (char *)tds_global(((void *const TDS_AS4 *)(const TDS_AS4 void *)ctl.peer_ring)[pr]) + ctl.peer_off;  // (see put_obs_wide)
             if (ctl.ring_flags & TDS_RING_OBS_F32)
               __hip_atomic_store((float *)pb + (at + i), (float)v, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
             else
@@ -1493,7 +1493,18 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
     const int per_unit = f32w ? 2 : 1;                 // scalars per 8-byte unit
     const int n_units = (EPW * w) / per_unit;
     const int np = ctl.n_peers;
+    // (the pointer table is read through the CONSTANT address space — written once at set-up, uniform index: scalar loads.
+    //  As vector loads each pointer was fetched right in front of its store, and the wait for it — loads and stores return
+    //  through one in-order counter — was a wait for the acknowledgement of the PREVIOUS peer's row: the seven rows of an
+    //  8-GPU run went out one after the other, 2.3 us per step.  -DTDS_PEER_TAB_CONST=0)
+#ifndef TDS_PEER_TAB_CONST
+#define TDS_PEER_TAB_CONST 1
+#endif
+#if TDS_PEER_TAB_CONST
+    const unsigned long long *const TDS_AS4 *tab = (const unsigned long long *const TDS_AS4 *)(const TDS_AS4 void *)ctl.peer_ring;
+#else
     const unsigned long long *const *tab = tds_global((const unsigned long long *const *)ctl.peer_ring);
+#endif
     for (int u0 = 0; u0 < n_units; u0 += 64) {  // (one pass on a float wire up to 128 scalars per wavefront)
       const int u = u0 + wl;
       const bool on = u < n_units;
@@ -1535,10 +1546,12 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
 #else
         if (to_peers) {
 #endif
-          __hip_atomic_store((unsigned long long *)b0 + po, bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
-          if (p0 + 1 < np) __hip_atomic_store((unsigned long long *)b1 + po, bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
-          if (p0 + 2 < np) __hip_atomic_store((unsigned long long *)b2 + po, bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
-          if (p0 + 3 < np) __hip_atomic_store((unsigned long long *)b3 + po, bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
+          // (stores through explicitly global pointers: as generic ones they were FLAT stores)
+          using G64 = __attribute__((address_space(1))) unsigned long long;
+          __hip_atomic_store((G64 *)((unsigned long long *)b0 + po), bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
+          if (p0 + 1 < np) __hip_atomic_store((G64 *)((unsigned long long *)b1 + po), bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
+          if (p0 + 2 < np) __hip_atomic_store((G64 *)((unsigned long long *)b2 + po), bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
+          if (p0 + 3 < np) __hip_atomic_store((G64 *)((unsigned long long *)b3 + po), bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
         }
       }
     }
@@ -2019,8 +2032,27 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       if constexpr (LOOP && TDS_FLUSH_EARLY != 0 && TDS_SIGNAL_IN_TAIL != 0) {
         if (tds_iter > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier (0), the helper's side
       }
+      // (-DTDS_CONSUME_CONSTS=1, experiment: the phase constants requested above waited for HERE, in front of the record stores —
+      //  an empty asm that "uses" their registers — so that their first use behind barrier (1) is not a vmcnt(0) that also
+      //  waits for the stores: no gain, 11.66 against 11.67 us per step; with seven loopback peers 14.76 against 14.36)
+#ifndef TDS_CONSUME_CONSTS
+#define TDS_CONSUME_CONSTS 0
+#endif
+      if constexpr (LOOP && TDS_FLUSH_EARLY != 0 && TDS_CONSUME_CONSTS != 0) {
+        asm volatile("" ::"v"(pf_cp_link), "v"(pf_cp_anc), "v"(pf_cp_loc[0]), "v"(pf_cp_loc[1]), "v"(pf_cp_loc[2]), "v"(pf_cp_rad),
+                     "v"(pf_vis_link), "v"(pf_dof_link), "v"(pf_anc));
+        asm volatile("" ::"v"(pf_vis_X[0]), "v"(pf_vis_X[1]), "v"(pf_vis_X[2]), "v"(pf_vis_X[3]), "v"(pf_vis_X[4]), "v"(pf_vis_X[5]),
+                     "v"(pf_vis_X[6]), "v"(pf_vis_X[7]), "v"(pf_vis_X[8]), "v"(pf_vis_X[9]), "v"(pf_vis_X[10]), "v"(pf_vis_X[11]));
+      }
       if constexpr (LOOP && TDS_FLUSH_EARLY != 0) flush_prev_records();  // (behind barrier (0): see there)
-      __syncthreads();  // (1) the main wavefront has written the x record, X_world and the motion axes
+      // (the helper's side of barrier (1) does not wait for its global stores — the previous step's records, and in the
+      //  peer-store exchange the rows to every peer, issued just above: __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0)`
+      //  + s_barrier, i.e. it held the barrier until the slowest of those stores was acknowledged.  -DTDS_LIGHT_BARRIER1=0)
+#ifndef TDS_LIGHT_BARRIER1
+#define TDS_LIGHT_BARRIER1 1
+#endif
+      if constexpr (LOOP && TDS_LIGHT_BARRIER1 != 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else __syncthreads();  // (1) the main wavefront has written the x record, X_world and the motion axes
       TDS_STAMP(2);
       T *const cpx = E + L.cp;
       T *const Zs = E + L.Z;
