@@ -344,3 +344,63 @@ def test_rings_with_auto_reset_against_the_reference_at_full_size(built):
     assert resets >= n // 10, resets
     assert rel_err(sim.x.cpu().numpy()[:, :nq + nd], x[:, :nq + nd]) < TOL
     print(f"ant x{n}, auto-reset ring form, {steps} slots, {resets} resets, every env, vs {what} + host reset: ok")
+
+
+@pytest.mark.gpu
+def test_progress_counters_need_an_obs_ring(built):
+    """round 4's advisor: the progress counters are indexed per obs-ring slot — a y ring + progress without an obs ring was a
+    modulo by zero on the device; the C API refuses it (the Python binding always did)"""
+    import ctypes as C
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    m = tds_amd.load_model("ant")
+    n, steps = 64, 4
+    sim = hip_backend.HipSim(m, n)
+    actions = torch.zeros((2, n, m.action_dim), dtype=torch.float64, device="cuda")
+    y_ring = torch.zeros((steps, n, m.output_dim), dtype=torch.float64, device="cuda")
+    progress = torch.zeros(steps, dtype=torch.int64, device="cuda")
+    r = hip_backend.Rings()
+    r.y_ring, r.y_slots, r.progress = y_ring.data_ptr(), steps, progress.data_ptr()
+    with pytest.raises(hip_backend.TdsHipError, match="obs ring"):
+        sim.step_many_rings_raw(actions, steps, r)
+    assert int(progress.sum().item()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cube_floating", "two_cubes_floating"])
+def test_host_reset_and_host_step_of_a_model_without_actions(name, built):
+    """round 4's advisor: tds_hip_reset_host staged its N-byte mask through the ACTION staging buffer — zero bytes for the
+    models without actions; the staging is sized max(N x action_dim x elem, N) and allocated all-or-nothing"""
+    import ctypes as C
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    m = tds_amd.load_model(name)
+    assert m.action_dim == 0
+    n = 300
+    sim = hip_backend.HipSim(m, n)
+    L = hip_backend.lib()
+    L.tds_hip_reset_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tds_hip_step_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    # (these test worlds have no reset distribution — reset_q is all zero, a zero quaternion — so the mask selects NO
+    #  environment: what is exercised is the staging of the N mask bytes and of the records; states from the golden file)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    x = g["x"][np.arange(n) % g["x"].shape[0]]
+    sim.x.copy_(torch.from_numpy(x).cuda())
+    x0 = sim.x.clone()
+    mask = np.zeros(n, dtype=np.uint8)
+    obs = np.full((n, sim.obs_dim + 2), np.nan)
+    rc = L.tds_hip_reset_host(sim.h, mask.ctypes.data, obs.ctypes.data)
+    assert rc == 0, hip_backend.lib().tds_hip_last_error()
+    assert torch.equal(sim.x, x0)
+    y = np.full((n, m.output_dim), np.nan)
+    for _ in range(3):
+        rc = L.tds_hip_step_host(sim.h, None, 1, obs.ctypes.data, y.ctypes.data)
+        assert rc == 0, hip_backend.lib().tds_hip_last_error()
+    assert np.isfinite(obs).all() and np.isfinite(y).all()
+    assert not torch.equal(sim.x, x0)
