@@ -2022,6 +2022,15 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
   ctl.nsub = 1;
   ctl.y_stride = s->model.output_dim;
   if (s->opt.is_set(TDS_OPT_GRAM_STAMP_AT)) ctl.flags |= (int)s->opt.v[TDS_OPT_GRAM_STAMP_AT] << 8;  // (stamp 10 inside tds_gram_solve)
+  // (profiling builds of the kernels, -DTDS_PROF_LOOP: the stamps of iteration K / 2 of a K-step launch of the two-wavefront
+  //  step-loop kernel — TDS_HIP_PROF_LOOP=K; the library's own kernels have no such build and ignore the request)
+  if (const char *pl = getenv("TDS_HIP_PROF_LOOP")) {
+    const int k = atoi(pl);
+    if (k > 1 && two_waves) {
+      ctl.nsub = k;
+      ctl.flags |= (k / 2) << 16;
+    }
+  }
   int rc;
   if (s->dtype == TDS_DTYPE_F64)
     rc = tds_launch_step<double, double>((const DevModel<double> *)s->d_model, s->h64, lds, s->lanes,

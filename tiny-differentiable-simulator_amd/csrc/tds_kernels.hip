@@ -187,6 +187,9 @@ __device__ __forceinline__ void tds_row_solve(int lane, int NA, int na, int nd, 
       }
       ai = rcp_full<T>(g + cfm);
     }
+    // (measured and not kept, -DTDS_ROWS_EARLY in round 5's experiments: the row, G_rr and 1 / (G_rr + cfm) stored BEFORE the wait
+    //  for the main wavefront's y~ — seventeen LDS stores off the helper's stretch between that flag and barrier (3) on paper,
+    //  11.79 against 11.60 us per step in the same process)
     if constexpr (SPLIT && !SLAB) {
       if (yt_flag != nullptr) {  // wave-uniform
         while (__any(tds_lds_poll<2>(yt_flag) == T(0))) __builtin_amdgcn_s_sleep(1);
@@ -859,12 +862,19 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
 }
 
 // TDS_STAMP: phase-boundary timestamps (shader clock) of workgroup 0, PROF builds only
+// (-DTDS_PROF_LOOP, a profiling build outside the library: the two-wavefront STEP-LOOP kernel with stamps, taken in iteration
+//  ctl.flags >> 16 of the launch — the steady state of a step, not the first step of a launch; tools/profile_loop.sh)
+#ifdef TDS_PROF_LOOP
+#define TDS_PROF_ITER (LOOP ? (int)((unsigned)ctl.flags >> 16) : 0)
+#else
+#define TDS_PROF_ITER 0
+#endif
 #define TDS_STAMP(k)                                                        \
   do {                                                                      \
     if (PROF) {                                                             \
       __builtin_amdgcn_sched_barrier(0);                                    \
       __builtin_amdgcn_s_waitcnt(0);                                        \
-      if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tds_iter == 0)     \
+      if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && tds_iter == TDS_PROF_ITER) \
         prof[(threadIdx.x >> 6) * TDS_NUM_PHASE_STAMPS + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
       if constexpr (W2 && ((k) == 0 || (k) == 13)) { /* 23..27: wall clock (100 MHz) of workgroup 0, last workgroup */ \
         if (threadIdx.x == 0 && blockIdx.x == 0) prof[23 + ((k) == 13)] = (long long)__builtin_amdgcn_s_memrealtime(); \
@@ -886,7 +896,7 @@ __device__ __forceinline__ void tds_reset_state(T *xr, const DevModel<T> *mdl, c
       if ((ctl.flags >> 8) == (id)) {                                       \
         __builtin_amdgcn_sched_barrier(0);                                  \
         __builtin_amdgcn_s_waitcnt(0);                                      \
-        if (blockIdx.x == 0 && threadIdx.x == 0 && tds_iter == 0)           \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tds_iter == TDS_PROF_ITER) \
           prof[10] = (long long)__builtin_amdgcn_s_memtime();               \
         __builtin_amdgcn_sched_barrier(0);                                  \
       }                                                                     \
@@ -3494,7 +3504,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       const int iters = pf_iters;
       T u;
       if constexpr (GRAM) {
-        long long *const gst = PROF && tds_iter == 0 ? prof + 10 : nullptr;
+        long long *const gst = PROF && tds_iter == TDS_PROF_ITER ? prof + 10 : nullptr;
         const int gat = ctl.flags >> 8;
         if (!gram)
           u = any_slab ? tds_pgs<true, T, G, NDP>(lane, NA, ZR, OVR, iters, mu, Zs, rws, xs, zov, rov)
@@ -3900,6 +3910,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
     }
   }
   if constexpr (!LOOP) break;
+#ifdef TDS_PROF_LOOP
+  TDS_STAMP(13);
+#endif
   ++tds_iter;
   }  // ================================ end of the step loop ================================
   TDS_STAMP(13);
@@ -4013,6 +4026,18 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   // (+ the workgroup's constant table of the step-loop launches, TdsLds::cw)
   const size_t shmem = (size_t)L.stride * epw * sizeof(T) + (size_t)L.cw * lanes_per_env * sizeof(T);
   (void)h_model;
+#ifdef TDS_PROF_LOOP
+#define TDS_PROF_LOOP_LAUNCH(GG, NN)                                                                         \
+    if constexpr (KIND == 0 && NN < 24) {                                                                    \
+      if (two_waves && !simple && prof) {                                                                    \
+        hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), true, 1, 0, true>), dim3(blocks), dim3(128), shmem, \
+                           stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
+        break;                                                                                               \
+      }                                                                                                      \
+    }
+#else
+#define TDS_PROF_LOOP_LAUNCH(GG, NN)
+#endif
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \
     if constexpr (KIND == 0 && NN < 24) {                                                                    \
@@ -4027,6 +4052,7 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
         break;                                                                                               \
       }                                                                                                      \
     }                                                                                                        \
+    TDS_PROF_LOOP_LAUNCH(GG, NN)                                                                             \
     if constexpr (KIND == 0 && NN < 24) {                                                                    \
       if (two_waves && !simple && !prof) {                                                                   \
         hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 1, 0, true>), dim3(blocks), dim3(128), shmem, \
