@@ -288,7 +288,9 @@ def main():
     # BASELINE.json: config 3 (Ant x 4096 on one GPU) is the configuration the metric is quoted on; config 5 is "65 536
     # environments sharded 8 x" = 8192 per GPU.  --gpus 8 therefore runs config 5 as `value` and the 4096-per-GPU line — the
     # weak-scaling partner of the N = 1 / 2 / 4 runs — beside it under `envs_4096_per_gpu` (same ranks, same flow).
-    config5 = args.envs_per_gpu == 0 and world == 8 and args.model == "ant"
+    # (debugging aid, like TDS_BENCH_ONE_DEVICE: TDS_BENCH_FORCE_CONFIG5=1 takes the N = 8 flow — two runs, 8192 then 4096
+    #  environments per rank — at any world size; never used for numbers)
+    config5 = args.envs_per_gpu == 0 and (world == 8 or os.environ.get("TDS_BENCH_FORCE_CONFIG5") == "1") and args.model == "ant"
     n = args.envs_per_gpu if args.envs_per_gpu > 0 else (8192 if config5 else 4096)
     out = run(args, n, rank, local_rank, world, secondary=True, config5=config5)
     if config5 and not args.no_secondary:

@@ -207,6 +207,7 @@ struct tds_hip_shard {
   //      stream sends slot k as soon as the launch has counted every workgroup in for step k
   void *rwire = nullptr;   // [2 TDS_SHARD_CHUNK][n_local][w]          wire dtype (NULL with the in-place exchange)
   void *rgath = nullptr;   // [2 TDS_SHARD_CHUNK][world][n_local][w]   wire dtype
+  bool ring_uncached = false;  // rgath is uncached device memory (peers write into it)
   void *ry = nullptr;      // [TDS_SHARD_Y_SLOTS][n_local][y_stride]   record dtype: the y records (local, not exchanged)
   int ry_stride = 0;       // scalars per y record in `ry` (padded to whole 128-byte lines; option y_stride)
   bool inplace = false;    // the launch stores its records into ITS block of rgath; the all-gather is in place
@@ -617,8 +618,24 @@ int ring_alloc_impl(tds_hip_shard *sh) {
     TDS_HIP_TRY(hipMalloc(&sh->rwire, ring_slots * slot_b));
     TDS_HIP_TRY(hipMemset(sh->rwire, 0, ring_slots * slot_b));
   }
-  TDS_HIP_TRY(hipMalloc(&sh->rgath, ring_slots * slot_b * sh->world));
-  TDS_HIP_TRY(hipMemset(sh->rgath, 0, ring_slots * slot_b * sh->world));
+  // The gathered ring is written by OTHER GPUs in the peer-store exchange (system-scope stores over xGMI into this rank's
+  // memory): it is allocated UNCACHED — not held in this GPU's L2 — where that can happen (several ranks, peer stores not
+  // ruled out), as RCCL allocates its own intra-node buffers: a line of the ring that this GPU's L2 still holds from the
+  // slot's previous use would otherwise be read instead of what the peer has written since (coarse-grained memory is coherent
+  // between GPUs at kernel boundaries of its OWNER only).  One rank: ordinary device memory.
+  // (TDS_HIP_SHARD_RING_UNCACHED = 0 / 1 forces either — for measuring what the uncached ring costs this rank's own stores.)
+  {
+    bool uncached = sh->world > 1 && s->opt.get(TDS_OPT_SHARD_PEER, 1) != 0 && s->opt.get(TDS_OPT_SHARD_RING, 1) != 0;
+    if (const char *e = getenv("TDS_HIP_SHARD_RING_UNCACHED")) uncached = atoi(e) != 0;
+    const size_t bytes = ring_slots * slot_b * sh->world;
+    if (uncached && hipExtMallocWithFlags(&sh->rgath, bytes, hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      sh->rgath = nullptr;
+    }
+    sh->ring_uncached = sh->rgath != nullptr;
+    if (!sh->rgath) TDS_HIP_TRY(hipMalloc(&sh->rgath, bytes));
+    TDS_HIP_TRY(hipMemset(sh->rgath, 0, bytes));
+  }
   // y records on 128-byte line boundaries (the launch then writes whole lines only)
   {
     const int per_line = 128 / (int)s->elem;
