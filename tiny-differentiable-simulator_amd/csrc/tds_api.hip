@@ -2028,7 +2028,9 @@ int tds_hip_profile_phases(tds_hip_sim_t *s, long long *cycles_host, int n) {
     const int k = atoi(pl);
     if (k > 1 && two_waves) {
       ctl.nsub = k;
-      ctl.flags |= (k / 2) << 16;
+      int it = k / 2;
+      if (const char *pi = getenv("TDS_HIP_PROF_ITER")) it = atoi(pi);  // (which iteration is stamped; default the middle one)
+      ctl.flags |= (it < 0 ? 0 : (it >= k ? k - 1 : it)) << 16;
     }
   }
   int rc;

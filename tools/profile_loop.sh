@@ -19,5 +19,5 @@ run)
   cd $ROOT
   K=${2:-200}
   echo "# steady-state step of the two-wavefront step-loop kernel: iteration $((K/2)) of a $K-step launch (no record rings: substeps)"
-  TDS_HIP_LIB=$ROOT/ab_r05/libtds_hip_prof.so TDS_HIP_PROF_LOOP=$K python tools/profile_phases.py ant 4096 0 100 2>&1 | grep -v amdgpu.ids ;;
+  TDS_HIP_LIB=$ROOT/ab_r05/libtds_hip_prof.so TDS_HIP_PROF_LOOP=$K python tools/profile_phases.py ant 4096 0 100 2>&1 | grep -v amdgpu.ids ;;  # (TDS_HIP_PROF_ITER=i: stamp iteration i instead of K / 2)
 esac
