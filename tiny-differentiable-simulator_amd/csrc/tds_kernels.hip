@@ -471,7 +471,7 @@ __device__ __forceinline__ T tds_pgs_lds(int lane, int NA, int ZR, int iters, T 
 }
 
 // ------------------------------------------------------------------------------------------
-// the step kernel
+// hand-offs through LDS inside ONE wavefront (TDS_WAVE_SYNC)
 // ------------------------------------------------------------------------------------------
 // A workgroup is exactly ONE wavefront, and the LDS executes the DS instructions of a wavefront in
 // issue order, so cross-lane hand-offs through LDS need no s_barrier and no s_waitcnt drain:
@@ -637,20 +637,6 @@ __device__ __forceinline__ double tds_gram_solve(double *sm, const TdsLds &L, in
 // ------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------
-// A workgroup is exactly ONE wavefront, and the LDS executes the DS instructions of a wavefront in
-// issue order, so cross-lane hand-offs through LDS need no s_barrier and no s_waitcnt drain:
-// all that is required is that the compiler keeps the program order of the LDS accesses.  A real
-// __syncthreads() would also wait for every outstanding GLOBAL store (the early y writes), which
-// single-wave-per-SIMD occupancy cannot hide.
-#ifdef TDS_FULL_BARRIER
-#define TDS_WAVE_SYNC() __syncthreads()
-#else
-#define TDS_WAVE_SYNC()                                        \
-  do {                                                         \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     \
-    __builtin_amdgcn_wave_barrier();                           \
-  } while (0)
-#endif
 
 // ------------------------------------------------------------------------------------------
 // Gram form of the contact solve on the matrix cores (two-wavefront workgroups, 16 lanes per environment, double).
