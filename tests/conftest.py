@@ -26,6 +26,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """one line per session: which checker the reference-pinned tests ran against (tests/test_hip_parity.py:
+    _reference_stepper — the REAL reference compiled from /root/reference, or the C oracle where that library is absent)"""
+    mod = sys.modules.get("test_hip_parity")
+    uses = getattr(mod, "CHECKER_USES", None) if mod else None
+    if uses and (uses["reference"] or uses["oracle"]):
+        terminalreporter.write_line("checker: reference (libtds_ref.so) handed to %d tests, oracle (tds_oracle.c) to %d"
+                                    % (uses["reference"], uses["oracle"]))
+
+
 @pytest.fixture(scope="session")
 def built():
     """Build the product library and the C oracle once per session (no GPU needed)."""

@@ -239,41 +239,58 @@ def test_full_size_properties(name, built):
     assert torch.isfinite(y).all()
 
 
+# which checker every call of _reference_stepper handed out, for the session's summary line (tests/conftest.py)
+CHECKER_USES = {"reference": 0, "oracle": 0}
+
+
 def _reference_stepper(name, n):
     """y = f(x) for [n, input_dim] on the host cores: the REAL reference (oracle/_ref/libtds_ref.so travels to the GPU
-    box prebuilt; one simulation object per thread, ctypes releases the GIL) or, where it is absent, the C oracle."""
+    box prebuilt; one simulation object per thread, ctypes releases the GIL) or, where the LIBRARY FILE IS ABSENT from the
+    tree, the C oracle.  A library that is there and does not load, or whose simulation objects cannot be built, is an error
+    (a parity suite says what it checked against: no silent change of checker); TDS_REQUIRE_REFERENCE=1 makes its absence
+    one as well.  tests/conftest.py prints one summary line per session."""
     # constructors the reference library can run WITHOUT /root/reference (URDF embedded in the reference's own headers);
     # configs built on them: (constructor, apply the model's dt / solver constants)
     embedded = {"ant": ("ant", False), "laikago": ("laikago", False), "laikago_soft": ("laikago", True)}
-    try:
-        import reflib
-        if reflib.available() and name in embedded:
-            import threading
-            nth = min(os.cpu_count() or 1, 64, n)
-            ctor, tweak = embedded[name]
-            sims = [reflib.RefSim(ctor) for _ in range(nth)]
-            if tweak:  # (as oracle/gen_golden.py builds the model: spring-damper contact = cfm / erp from k, d)
-                mm = tds_amd.load_model(name)
-                for sref in sims:
-                    sref.set_dt(mm.dt)
-                    sref.set_solver(mm.cfm, mm.erp, mm.pgs_iterations, mm.friction, mm.restitution)
-            bounds = np.linspace(0, n, nth + 1).astype(int)
+    import reflib
 
-            def step(x):
-                y = [None] * nth
+    present = reflib.available()  # (the file is in the tree)
+    if not present and os.environ.get("TDS_REQUIRE_REFERENCE") == "1":
+        raise RuntimeError("TDS_REQUIRE_REFERENCE=1 and %s is not in the tree" % reflib._LIB_PATH)
+    if present and name in embedded:
+        reflib.lib()  # (in the tree but not loadable: the OSError goes up — the checker of a test never changes silently)
+        import threading
+        nth = min(os.cpu_count() or 1, 64, n)
+        ctor, tweak = embedded[name]
+        sims = [reflib.RefSim(ctor) for _ in range(nth)]
+        if tweak:  # (as oracle/gen_golden.py builds the model: spring-damper contact = cfm / erp from k, d)
+            mm = tds_amd.load_model(name)
+            for sref in sims:
+                sref.set_dt(mm.dt)
+                sref.set_solver(mm.cfm, mm.erp, mm.pgs_iterations, mm.friction, mm.restitution)
+        bounds = np.linspace(0, n, nth + 1).astype(int)
 
-                def work(i):
+        def step(x):
+            y = [None] * nth
+            errs = []
+
+            def work(i):
+                try:
                     y[i] = sims[i].step(x[bounds[i]:bounds[i + 1]])
+                except Exception as ex:  # (a thread's exception must fail the test, not vanish)
+                    errs.append(ex)
 
-                ths = [threading.Thread(target=work, args=(i,)) for i in range(nth)]
-                [t.start() for t in ths]
-                [t.join() for t in ths]
-                return np.concatenate(y)
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(nth)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            if errs:
+                raise errs[0]
+            return np.concatenate(y)
 
-            return step, "reference (libtds_ref.so, %d threads)" % nth
-    except Exception:
-        pass
+        CHECKER_USES["reference"] += 1
+        return step, "reference (libtds_ref.so, %d threads)" % nth
     m = tds_amd.load_model(name)
+    CHECKER_USES["oracle"] += 1
     return (lambda x: oraclelib.step(m, x)), "oracle (tds_oracle.c)"
 
 

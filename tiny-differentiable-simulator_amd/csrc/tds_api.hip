@@ -1273,6 +1273,13 @@ bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
     const int resident = 256 * (per_cu < 8 ? per_cu : 8);
     return (s->num_envs + 3) / 4 <= resident;
   }
+  // the 8-lane kernel of the stars with two-link legs (tds_oct.hip: the Ant): the same rule — one launch while every
+  // workgroup (eight environments + the constant table) is resident at once
+  if (s->compute_f64() && s->h64.oct) {
+    const int per_cu = (160 * 1024) / tds_oct_workgroup_bytes(s->model.input_dim);
+    const int resident = 256 * (per_cu < 8 ? per_cu : 8);
+    return (s->num_envs + 7) / 8 <= resident || s->auto_reset;
+  }
   const int n_blocks = (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
   // With auto-reset on the alternative is not the chained graphs but single steps through the reset pool: the step-loop
   // launches (pool_step_many) win at every batch size (Ant x 16384 / 32768 at 5 % resets per step: 2.81e8 / 2.87e8
@@ -2134,11 +2141,13 @@ int tds_hip_kernel_info(const tds_hip_sim_t *s, int *lds_bytes_per_env, int *thr
 
 int tds_hip_single_step_kernel(const tds_hip_sim_t *s, int *lanes_per_env, int *lds_bytes_per_env) {
   if (!s) return -1;
-  const bool quad = s->compute_f64() && s->h64.quad != 0;
-  if (lanes_per_env) *lanes_per_env = quad ? 16 : s->lanes;
+  const bool quad = s->compute_f64() && s->h64.quad != 0, oct = s->compute_f64() && s->h64.oct != 0;
+  if (lanes_per_env) *lanes_per_env = oct ? 8 : (quad ? 16 : s->lanes);
   if (lds_bytes_per_env)
-    *lds_bytes_per_env = quad ? tds_quad_lds_bytes<double>(s->model.input_dim) : (int)(s->lds.stride * (s->compute_f64() ? 8 : 4));
-  return quad ? 1 : 0;
+    *lds_bytes_per_env = oct    ? tds_oct_lds_bytes(s->model.input_dim)
+                         : quad ? tds_quad_lds_bytes<double>(s->model.input_dim)
+                                : (int)(s->lds.stride * (s->compute_f64() ? 8 : 4));
+  return oct ? 2 : (quad ? 1 : 0);
 }
 
 }  // extern "C"

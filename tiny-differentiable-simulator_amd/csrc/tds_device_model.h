@@ -30,6 +30,10 @@
 #define TDS_JOINT_SPH1 10  // second: identity transform, axis y
 #define TDS_JOINT_SPH2 11  // third (the link itself): identity transform, axis z
 
+// capacity of DevModel::oct_tab (the table itself: TdsOctTab, tds_oct_model.h — a header of its own, so that a change of the
+// table's layout recompiles tds_oct.hip and tds_api.hip only, not the fifteen translation units of the general kernel)
+#define TDS_OCT_TAB_CAP 640
+
 template <typename T>
 struct DevModel {
   int num_links, dof_q, dof_qd, num_levels;
@@ -97,6 +101,12 @@ struct DevModel {
   // on the toes only (one sphere each, in leg order), visuals on links 5 .. 21 in link order, unactuated root links without
   // joint springs.  Laikago (BASELINE config 4) is one; option quad = 0 keeps such a model on the general kernel.
   int quad;
+  // 1: the model is the STAR the 8-lane kernel of tds_oct.hip is built for: the closed-form root chain, behind it exactly four
+  // legs of two links each in consecutive lanes, every leg link with a 1-dof joint, a PD actuator and one capsule, the root
+  // body with one sphere (17 contact points in the reference's order), visuals on links 5 .. 13 in link order, env step
+  // with PD control.  The gym Ant (BASELINE configs 3 and 5) is one; option oct = 0 keeps such a model on the general kernel.
+  int oct;
+  T oct_tab[TDS_OCT_TAB_CAP];  // (TdsOctTab, tds_oct_model.h; filled where oct == 1)
   T X_T[12][TDS_NL];            // rot (row-major 9) | trans (3)
   T S[6][TDS_NL];
   T mass[TDS_NL], com[3][TDS_NL], inertia[9][TDS_NL];
@@ -138,6 +148,8 @@ struct DevModel {
                                 //    contact_point.hpp:478-495) — same contact, different rounding of the two points
   T pc_loc_a[3][TDS_NPC], pc_loc_b[3][TDS_NPC], pc_rad_a[TDS_NPC], pc_rad_b[TDS_NPC];
 };
+
+#include "tds_oct_model.h"
 
 // reference: src/mb_constraint_solver.hpp:506-520 (incl. k = sqrt(a) and p[2] quirks)
 static inline void tds_plane_space(const double *n, double *p, double *q) {
@@ -601,10 +613,20 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     for (int k = 0; k < 9; ++k) d->vis_X[k][v] = (T)V.X_rot[k];
     for (int k = 0; k < 3; ++k) d->vis_X[9 + k][v] = (T)V.X_trans[k];
   }
-  // the STAR of tds_quad.hip (see DevModel::quad): root chain in closed form + four legs of (1-dof, 1-dof, 1-dof, fixed)
+  // the STARS of tds_quad.hip / tds_oct.hip (see DevModel::quad, ::oct): root chain in closed form + four legs.  Both kernels
+  // are built for the env step with PD control on the leg joints ONLY: the root dofs carry no torque, every action belongs to
+  // a leg-joint lane (a TAU-mode model, a PD loop that starts inside the root chain or more actions than leg joints stay
+  // on the general kernel, which handles them)
+  auto star_actuation = [&](int leg_len, int leg_dofs) {
+    bool ok = m->step_mode == TDS_STEP_LOCOMOTION && m->action_dim <= 4 * leg_dofs;
+    for (int i = 0; ok && i < 6; ++i) ok = d->act_index[i] < 0;
+    for (int i = 6; ok && i < m->num_links; ++i)
+      ok = d->act_index[i] < 0 || ((i - 6) % leg_len < leg_dofs && d->act_index[i] < m->action_dim);
+    return ok;
+  };
   d->quad = 0;
   if (d->euler_root && sizeof(T) == 8 && m->num_links == 22 && m->dof_qd == 18 && m->dof_q == 18 && m->has_plane &&
-      ncp == 4 && tds_opt_now(TDS_OPT_QUAD) != 0) {
+      ncp == 4 && tds_opt_now(TDS_OPT_QUAD) != 0 && star_actuation(4, 3)) {
     bool ok = true;
     for (int k = 0; ok && k < 4; ++k) {
       for (int j = 0; ok && j < 4; ++j) {
@@ -623,6 +645,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     for (int v = 0; ok && v < d->num_visuals; ++v) ok = d->vis_link[v] == 5 + v;
     d->quad = ok ? 1 : 0;
   }
+  tds_oct_detect<T>(m, d, ncp, star_actuation(2, 2));
 #undef TDS_FAIL
   return TDS_OK;
 }

@@ -179,6 +179,18 @@ inline bool tds_quad_takes(int quad, const TdsStepCtl &ctl, const long long *pro
          ctl.progress == nullptr && ctl.peer_arrive == nullptr;
 }
 
+// the 8-lane kernel of the stars with two-link legs (tds_oct.hip; DevModel::oct: the Ant): the same launches as the 16-lane
+// kernel, and the exchange launches of the multi-GPU layer (progress counters / peer stores) as well
+template <typename T, typename TR>
+int tds_launch_oct(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
+                   TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl);
+int tds_oct_lds_bytes(int input_dim);        // LDS of one environment
+int tds_oct_workgroup_bytes(int input_dim);  // LDS of one workgroup: eight environments + the constant table
+inline bool tds_oct_takes(int oct, const TdsStepCtl &ctl, const long long *prof) {
+  return oct != 0 && prof == nullptr && ctl.nsub >= 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr &&
+         ctl.progress == nullptr && ctl.peer_arrive == nullptr;
+}
+
 // T: compute scalar, TR: record scalar (== T, or float under T = double: "f32 records / f64 arithmetic")
 template <typename T, typename TR>
 inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
@@ -189,6 +201,10 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
 #define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof, form
   if (tds_quad_takes(h_model.quad, ctl, prof))
     return tds_launch_quad<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl);
+  if constexpr (sizeof(T) == 8) {
+    if (tds_oct_takes(h_model.oct, ctl, prof))
+      return tds_launch_oct<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl);
+  }
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
   if (h_model.num_bodies >= 2 && h_model.multi_floating) return tds_launch_step_impl<T, TR, 4>(TDS_ARGS);

@@ -23,6 +23,7 @@ enum TdsOptKey {
   TDS_OPT_NO_LEGSCAN,         // 1: legs by the level loop instead of the segmented scan
   TDS_OPT_FOLD_FIXED,         // 1: fold fixed links into their parents even when the lanes would suffice
   TDS_OPT_QUAD,               // 0: a star-shaped legged robot (Laikago) stays on the general kernel instead of tds_quad.hip's 16-lane kernel
+  TDS_OPT_OCT,                // 0: a star with two-link legs (the Ant) stays on the general kernel instead of tds_oct.hip's 8-lane kernel
   // ---- run-time rows (may change between calls of a handle)
   TDS_OPT_LOOP_W2,            // step-loop launches: 0 one-wave build, 1 (default) two-wavefront build where it fits, 2 ... not with the reset pool
   TDS_OPT_LOOP_OCC,           // step-loop build: 1 / 2 wavefronts per SIMD forced (unset: by grid size)
@@ -80,6 +81,7 @@ inline const TdsOptRow *tds_opt_rows() {
       {"no_legscan", true, "TDS_HIP_NO_LEGSCAN"},
       {"fold_fixed", true, "TDS_HIP_FOLD_FIXED"},
       {"quad", true, "TDS_HIP_QUAD"},
+      {"oct", true, "TDS_HIP_OCT"},
       {"loop_w2", false, "TDS_HIP_LOOP_W2"},
       {"loop_occ", false, "TDS_HIP_LOOP_OCC"},
       {"exchange_w2", false, "TDS_HIP_EXCHANGE_W2"},

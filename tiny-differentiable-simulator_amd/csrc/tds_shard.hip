@@ -170,10 +170,16 @@ __global__ void tds_peer_arrived_kernel(const unsigned long long *flags, int n, 
     if (!tds_wait_ge(flags + i, seq, err, t0, timeout_ticks, host_latch)) return;
 }
 
-// set-up check: a token into slot `rank` of the test row of every peer's flag array (and this rank's own)
-__global__ void tds_peer_token_kernel(unsigned long long *const *flags, int n_peers, long long test_off, int rank,
-                                      unsigned long long token) {
+// set-up check: a 32-bit token into the first word of THIS rank's block of slot 0 of every peer's gathered ring — through
+// the very mapping the step kernel's record stores will use —, then, once those stores are acknowledged, a token into slot
+// `rank` of the test row of every peer's flag array (and this rank's own): a rank that sees a peer's flag token must find
+// that peer's ring token in its own ring (the protocol's visibility rule, checked once on the real memory)
+__global__ void tds_peer_token_kernel(void *const *rings, unsigned long long *const *flags, int n_peers, long long ring_off,
+                                      long long test_off, int rank, unsigned long long token) {
   const int lane = threadIdx.x;
+  if (lane < n_peers)
+    __hip_atomic_store((unsigned int *)((char *)rings[lane] + ring_off), (unsigned int)token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   if (lane <= n_peers)
     __hip_atomic_store(flags[lane] + test_off + rank, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -401,9 +407,13 @@ int comm_all_gather_bytes(tds_hip_shard *sh, const void *mine, void *all, size_t
     memcpy(all, mine, bytes);
     return TDS_OK;
   }
-  void *d_send = nullptr, *d_recv = nullptr;
-  TDS_HIP_TRY(hipMalloc(&d_send, bytes));
-  TDS_HIP_TRY(hipMalloc(&d_recv, bytes * sh->world));
+  // (one allocation for both buffers: a single failure point, nothing to leak.  A rank that cannot allocate these few hundred
+  //  bytes cannot take part in the collective at all — as with any failed rank of a communicator, the others are then in
+  //  RCCL's hands)
+  void *d_send = nullptr;
+  const size_t send_b = (bytes + 255) & ~(size_t)255;
+  TDS_HIP_TRY(hipMalloc(&d_send, send_b + bytes * sh->world));
+  void *const d_recv = (char *)d_send + send_b;
   int rc = TDS_OK;
   hipError_t e = hipMemcpyAsync(d_send, mine, bytes, hipMemcpyHostToDevice, sh->comm_stream);
   if (e == hipSuccess) {
@@ -418,7 +428,6 @@ int comm_all_gather_bytes(tds_hip_shard *sh, const void *mine, void *all, size_t
   if (e == hipSuccess && rc == TDS_OK) e = hipMemcpyAsync(all, d_recv, bytes * sh->world, hipMemcpyDeviceToHost, sh->comm_stream);
   if (e == hipSuccess && rc == TDS_OK) e = hipStreamSynchronize(sh->comm_stream);
   (void)hipFree(d_send);
-  (void)hipFree(d_recv);
   if (e != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "peer-store set-up: %s", hipGetErrorString(e));
     return TDS_ERR_HIP;
@@ -451,28 +460,40 @@ int peer_setup(tds_hip_shard *sh, size_t ring_slots, size_t slot_b) {
   sh->peer_mode = false;
   sh->reward_done_only = s->opt.get(TDS_OPT_EXCHANGE_FIELDS, 0) == 1;
   const int loopback = (int)s->opt.get(TDS_OPT_SHARD_PEER_LOOPBACK, 0);
+  // (several ranks: only with the gathered ring in UNCACHED memory — in ordinary device memory a line of a reused slot that
+  //  this GPU's L2 still holds would be read instead of what the peer has written since, and nothing would notice)
   const bool possible = want != 0 && sh->inplace && !sh->one_process_group && sh->world - 1 + (loopback > 0 ? loopback : 0) <= TDS_MAX_PEERS &&
-                        (sh->world == 1 || sh->comm != nullptr);
-  // own arrays first (every rank allocates them: the set-up below is a collective either way)
+                        (sh->world == 1 || (sh->comm != nullptr && sh->ring_uncached));
+  char why[160] = "";
+  if (want != 0 && sh->world > 1 && sh->comm != nullptr && !sh->ring_uncached)
+    snprintf(why, sizeof(why), "the gathered ring is not in uncached device memory");
+  // own arrays first (every rank allocates them: the set-up below is a collective either way — a LOCAL failure here makes this
+  // rank's verdict "no" but never keeps it away from the all-gathers the other ranks are waiting in)
   const size_t n_flags = sh->flag_count() + 2 * (size_t)sh->world;
+  bool alloc_ok = true;
   {
     void *pf = nullptr;
     // fine-grained / uncached device memory where the runtime offers it: a flag written by another GPU must never be served
     // from this GPU's L2
-    if (hipExtMallocWithFlags(&pf, n_flags * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) {
+    hipError_t e = hipExtMallocWithFlags(&pf, n_flags * sizeof(unsigned long long), hipDeviceMallocUncached);
+    if (e != hipSuccess) {
       (void)hipGetLastError();
       pf = nullptr;
-      TDS_HIP_TRY(hipMalloc(&pf, n_flags * sizeof(unsigned long long)));
+      e = hipMalloc(&pf, n_flags * sizeof(unsigned long long));
     }
-    sh->pflags = (unsigned long long *)pf;
-    TDS_HIP_TRY(hipMemset(sh->pflags, 0, n_flags * sizeof(unsigned long long)));
-    TDS_HIP_TRY(hipMalloc((void **)&sh->parrive, ring_slots * TDS_PEER_ARRIVE_STRIDE * sizeof(unsigned int)));
-    TDS_HIP_TRY(hipMemset(sh->parrive, 0, ring_slots * TDS_PEER_ARRIVE_STRIDE * sizeof(unsigned int)));
-    TDS_HIP_TRY(hipDeviceSynchronize());
+    sh->pflags = e == hipSuccess ? (unsigned long long *)pf : nullptr;
+    if (e == hipSuccess) e = hipMemset(sh->pflags, 0, n_flags * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&sh->parrive, ring_slots * TDS_PEER_ARRIVE_STRIDE * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(sh->parrive, 0, ring_slots * TDS_PEER_ARRIVE_STRIDE * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      alloc_ok = false;
+      snprintf(why, sizeof(why), "flag / counter arrays: %s", hipGetErrorString(e));
+    }
   }
   if (sh->world > 1 && !sh->comm) return TDS_OK;  // (no communicator, several ranks: nothing collective can be set up)
-  bool ok = possible;
-  char why[160] = "";
+  bool ok = possible && alloc_ok;
   std::vector<PeerHello> all((size_t)sh->world);
   PeerHello mine;
   memset(&mine, 0, sizeof(mine));
@@ -553,7 +574,9 @@ int peer_setup(tds_hip_shard *sh, size_t ring_slots, size_t slot_b) {
   if (ok && sh->world > 1) {
     const unsigned long long token = 0x7D5000000000ull + (unsigned long long)sh->rank + 1ull;
     unsigned long long *const *ftab = (unsigned long long *const *)((void **)sh->d_peer_tab + np4);
-    hipLaunchKernelGGL(tds_peer_token_kernel, dim3(1), dim3(64), 0, sh->comm_stream, ftab, np, (long long)sh->test_off(), sh->rank, token);
+    // (the real peers come first in the table; loopback rings are this rank's own memory: nothing to learn from them)
+    hipLaunchKernelGGL(tds_peer_token_kernel, dim3(1), dim3(64), 0, sh->comm_stream, (void *const *)sh->d_peer_tab, ftab, sh->n_real_peers,
+                       (long long)((size_t)sh->rank * slot_b), (long long)sh->test_off(), sh->rank, token);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(sh->comm_stream);
     std::vector<unsigned long long> got((size_t)sh->world);
@@ -573,6 +596,20 @@ int peer_setup(tds_hip_shard *sh, size_t ring_slots, size_t slot_b) {
       ok = false;
       snprintf(why, sizeof(why), "token round trip over the mapped memory failed%s%s", e != hipSuccess ? ": " : "",
                e != hipSuccess ? hipGetErrorString(e) : "");
+    } else {
+      // ... and every peer's ring token is in THIS rank's ring, in that peer's block of slot 0 (then zeroed again)
+      for (int r = 0; r < sh->world && ok; ++r) {
+        if (r == sh->rank) continue;
+        unsigned int word = 0u;
+        void *const at = (char *)sh->rgath + (size_t)r * slot_b;
+        e = hipMemcpy(&word, at, sizeof(word), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemset(at, 0, sizeof(word));
+        if (e != hipSuccess || word != (unsigned int)(0x7D5000000000ull + (unsigned long long)r + 1ull)) {
+          (void)hipGetLastError();
+          ok = false;
+          snprintf(why, sizeof(why), "rank %d's flag token arrived before its store into the gathered ring (read %#x)", r, word);
+        }
+      }
     }
   }
   // the verdict, all ranks together (a rank that failed late must take the others with it)
@@ -739,6 +776,8 @@ bool ring_form(const tds_hip_shard *sh, int n_steps) {
   // (the 16-lane kernel of the legged robots has a step-loop form, but not the exchange's part of it — progress counters,
   //  peer stores: their shards keep the per-step launches, which run on that kernel's straight-line form)
   if (s->compute_f64() && s->h64.quad) return false;
+  // (the 8-lane kernel hands its exchange launches to the general kernel: tds_oct_takes; what the ring form needs is that
+  //  kernel's step-loop form, judged as if the handle had no 8-lane kernel)
   return tds_hip_step_many_is_loop(s, n_steps > 1 ? n_steps : 2) != 0;
 }
 
