@@ -363,9 +363,10 @@ int tds_hip_option_count(void);
 const char *tds_hip_option_name(int index);
 /* 1 if tds_hip_step_many(sim, ..., n_steps, ...) runs as ONE launch of the step-loop kernel instead of graphs: worlds
    without contact points (pendulums, the cartpole), fixed-base kernels up to 16 dof with contacts (the Ant) while
-   the batch is at most three rounds of workgroups (12288 Ant environments); the star-shaped legged robots of
-   tds_hip_single_step_kernel (Laikago) take their 16-lane kernel's own step-loop form when auto-reset is on (or option
-   step_many_loop = 1), the chained graphs of its straight-line form otherwise.  No kernel boundaries; the state stays in
+   the batch is at most three rounds of workgroups; the star-shaped legged robots of tds_hip_single_step_kernel take their
+   own kernels' step-loop forms: the 16-lane kernel (Laikago) while every workgroup of the launch is resident at once —
+   computed from the device's compute-unit count and LDS size, hipDeviceProp_t: up to 6144 environments on an MI355X —
+   and the chained graphs of its straight-line form beyond; the 8-lane kernel (the Ant) always.  No kernel boundaries; the state stays in
    LDS (in the compute scalar) for the n_steps steps, every step takes its own action block, y / obs / x are written
    once at the end — what the graph form leaves behind too, whose obs_dev is overwritten by every step.  With float
    records the state is rounded to float once per call instead of once per step.
@@ -563,10 +564,12 @@ int tds_hip_kernel_info(const tds_hip_sim_t *sim, int *lds_bytes_per_env, int *t
 
 /* Which kernel a plain single step of this handle runs (tds_hip_step / _step_obs with substeps = 1, tds_hip_forward_zero_*,
    the launches of the tds_hip_step_many graphs): 0 the general kernel (csrc/tds_kernels.hip: lanes per environment as
-   tds_hip_kernel_info reports), 1 the 16-lane kernel of the star-shaped legged robots (csrc/tds_quad.hip: a root body on the
-   reference's six virtual links + four legs of three 1-dof joints and a fixed toe — Laikago, BASELINE config 4; create-time
-   option quad = 0 keeps such a model on the general kernel).  Optional outputs: that kernel's lanes and LDS bytes per
-   environment. */
+   tds_hip_kernel_info reports), 1 the 16-lane kernel of the star-shaped legged robots with four-link legs (csrc/tds_quad.hip:
+   a root body on the reference's six virtual links + four legs of three 1-dof joints and a fixed toe — Laikago, BASELINE
+   config 4; create-time option quad = 0 keeps such a model on the general kernel), 2 the 8-lane kernel of the stars with
+   two-link legs (csrc/tds_oct.hip: four legs of hip + ankle, a capsule on every leg link, a sphere on the root body — the gym
+   Ant, BASELINE configs 3 and 5; create-time option oct = 0).  Both take models stepped with PD control on the leg joints
+   only.  Optional outputs: that kernel's lanes and LDS bytes per environment. */
 int tds_hip_single_step_kernel(const tds_hip_sim_t *sim, int *lanes_per_env, int *lds_bytes_per_env);
 
 /* ======================================================================================

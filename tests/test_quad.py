@@ -39,7 +39,7 @@ def test_quad_kernel_takes_the_star_models_and_matches_the_golden_steps(name, dt
     sim = hip_backend.HipSim(m, n, dtype=dtype)
     gen = hip_backend.HipSim(m, n, dtype=dtype, options={"quad": 0})
     assert sim.single_step_kernel()[:2] == ("quad16", 16) and gen.single_step_kernel()[0] == "general"
-    assert hip_backend.HipSim(tds_amd.load_model("ant"), 8).single_step_kernel()[0] == "general"
+    assert hip_backend.HipSim(tds_amd.load_model("ant"), 8).single_step_kernel()[0] == "oct8"  # (its own star kernel: tests/test_oct.py)
     x = torch.from_numpy(g["x"]).to(sim.torch_dtype).cuda()
     y = sim.forward_zero(x).double().cpu().numpy()
     yg = gen.forward_zero(x).double().cpu().numpy()

@@ -156,7 +156,17 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   //  instead of falling back silently)
   if (occ == 1 && lds.NDP < 14 && !two_waves && (nsub != 1 || reset_mode != TDS_RESET_NONE || ro || (opts && opts->rings)))
     return fail(TDS_ERR_UNSUPPORTED, "option loop_occ = 1: no one-wavefront-per-SIMD step-loop build below 14 padded dof");
-  const int form = (two_waves ? TDS_FORM_W2 : 0) | (occ == 1 ? TDS_FORM_LOOP_OCC1 : (occ == 2 ? TDS_FORM_LOOP_OCC2 : 0));
+  // the 8-lane kernel (tds_oct.hip) takes the launch: its two-wavefront build while every workgroup of the launch is resident
+  // with at most two wavefronts per SIMD — four workgroups per compute unit, LDS permitting (Ant: up to 8192 environments)
+  bool oct_w2 = false;
+  if (s->compute_f64() && s->h64.oct != 0 && nsub >= 1 && reset_mode == TDS_RESET_NONE && !ro) {
+    const long long o2 = s->opt.get(TDS_OPT_OCT_W2, 1);
+    const int per_cu = (int)(s->lds_per_cu / (size_t)tds_oct_workgroup_bytes(s->model.input_dim));
+    const int resident = s->num_cus * (per_cu < 4 ? per_cu : 4);
+    oct_w2 = o2 == 2 || (o2 != 0 && (n_resident + 7) / 8 <= resident);
+  }
+  const int form = (two_waves ? TDS_FORM_W2 : 0) | (occ == 1 ? TDS_FORM_LOOP_OCC1 : (occ == 2 ? TDS_FORM_LOOP_OCC2 : 0)) |
+                   (oct_w2 ? TDS_FORM_OCT_W2 : 0);
   void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
   if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along
     const size_t e0 = (size_t)opts->env_first, el = s->elem;
@@ -223,8 +233,11 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
       ctl.peer_flag_off = pl.flag_off;
       ctl.peer_flag_stride = pl.flag_stride;
       if (pl.reward_done_only) ctl.ring_flags |= TDS_RING_PEER_REWARD_DONE;
+      if (s->opt.get(TDS_OPT_SHARD_PEER_RELEASE, 0) == 1) ctl.ring_flags |= TDS_RING_PEER_RELEASE;
       {  // a wavefront's records as one row of 8-byte units (put_obs_wide): every stride a multiple of 8 bytes
-        const size_t wb = r.obs_f32 ? 4 : s->elem, w = (size_t)s->obs_width(), epw = (size_t)(64 / s->lanes);
+        // (environments per wavefront: eight where the 8-lane kernel takes the launch — tds_oct_takes)
+        const bool oct_launch = s->compute_f64() && s->h64.oct != 0 && nsub >= 1 && reset_mode == TDS_RESET_NONE && !ro;
+        const size_t wb = r.obs_f32 ? 4 : s->elem, w = (size_t)s->obs_width(), epw = oct_launch ? 8 : (size_t)(64 / s->lanes);
         if ((epw * w * wb) % 8 == 0 && ((size_t)ctl.obs_envs * w * wb) % 8 == 0 && ((size_t)(uintptr_t)ctl.obs_ring) % 8 == 0 &&
             (size_t)ctl.peer_off % 8 == 0 && (size_t)n % epw == 0 && pl.wide_ok)
           ctl.ring_flags |= TDS_RING_WIDE;
@@ -364,6 +377,14 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
   tds_hip_sim *s = new (std::nothrow) tds_hip_sim();  // value-initialised: both host models start zeroed
   if (!s) return fail(TDS_ERR_INVALID_ARG, "out of host memory");
   s->opt = tds_opt_snapshot();  // (override > environment > library default; the environment is not read again)
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      if (prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount;
+      // (gfx950: 160 KiB per compute unit, of which one workgroup may take 64 KiB without opting in)
+      if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) s->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+    }
+  }
   s->model = *model;
   s->num_envs = num_envs;
   s->device = device;
@@ -1269,17 +1290,14 @@ bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
   // laikago_soft (tools/quad_occupancy_sweep.sh, us per step, loop / graphs): x 4096 13.4 / 20.8, x 6144 18.3 / 23.2,
   // x 8192 32.5 / 24.7; with auto-reset: 13.2 / 21.0, 17.8 / 25.8, 30.9 / 27.4.  Option step_many_loop = 0 / 1 forces a form.
   if (s->compute_f64() && s->h64.quad) {
-    const int per_cu = (160 * 1024) / tds_quad_loop_workgroup_bytes(s->model.input_dim);
-    const int resident = 256 * (per_cu < 8 ? per_cu : 8);
+    const int per_cu = (int)(s->lds_per_cu / (size_t)tds_quad_loop_workgroup_bytes(s->model.input_dim));
+    const int resident = s->num_cus * (per_cu < 8 ? per_cu : 8);
     return (s->num_envs + 3) / 4 <= resident;
   }
-  // the 8-lane kernel of the stars with two-link legs (tds_oct.hip: the Ant): the same rule — one launch while every
-  // workgroup (eight environments + the constant table) is resident at once
-  if (s->compute_f64() && s->h64.oct) {
-    const int per_cu = (160 * 1024) / tds_oct_workgroup_bytes(s->model.input_dim);
-    const int resident = 256 * (per_cu < 8 ? per_cu : 8);
-    return (s->num_envs + 7) / 8 <= resident || s->auto_reset;
-  }
+  // the 8-lane kernel of the stars with two-link legs (tds_oct.hip: the Ant): always one launch.  Its straight-line form costs
+  // the same table copy and workgroup rounds per step plus a kernel boundary and the state's round trip through HBM, so
+  // beyond one round of resident workgroups (8192 environments) R rounds of K steps still beat K launches of R rounds
+  if (s->compute_f64() && s->h64.oct) return true;
   const int n_blocks = (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
   // With auto-reset on the alternative is not the chained graphs but single steps through the reset pool: the step-loop
   // launches (pool_step_many) win at every batch size (Ant x 16384 / 32768 at 5 % resets per step: 2.81e8 / 2.87e8
@@ -1440,7 +1458,9 @@ int tds_hip_step_many_rings(tds_hip_sim_t *s, const void *actions_dev, int actio
 }
 
 int tds_hip_step_many_rings_blocks(const tds_hip_sim_t *s) {
-  return s ? (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes) : 0;
+  if (!s) return 0;
+  if (s->compute_f64() && s->h64.oct) return (s->num_envs + 7) / 8;  // (the 8-lane kernel: eight environments per workgroup)
+  return (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
 }
 
 int tds_hip_step_many_is_loop(const tds_hip_sim_t *s, int n_steps) { return s && step_many_as_loop(s, n_steps) ? 1 : 0; }

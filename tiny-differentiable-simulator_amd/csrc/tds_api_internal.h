@@ -36,6 +36,8 @@ struct tds_hip_sim {
   // two-wavefront workgroups (plain kernels, straight-line launches whose whole grid is resident at once)
   TdsLds lds_w2;
   int w2_max_blocks = 0;  // 0: not available for this model / dtype
+  int num_cus = 256;                // compute units and LDS bytes per compute unit of the handle's device (hipDeviceProp_t;
+  size_t lds_per_cu = 160 * 1024;   // what the residency rules of the launch forms are computed from)
   void *d_x = nullptr, *d_y = nullptr, *d_ovf = nullptr;
   unsigned int *d_reset_count = nullptr;
   void *d_split = nullptr;  // records + done mask of the two-launch auto-reset step

@@ -124,6 +124,10 @@ struct TdsStepCtl {
 // of 8 bytes — a wavefront's records may leave as one row of 8-byte units (tds_kernels.hip: put_obs_wide); the peer table is
 // padded to a multiple of four entries
 #define TDS_RING_WIDE 16
+// peer-store exchange, A/B switch for the first run on a real fabric (option shard_peer_release = 1): a SYSTEM-scope release
+// fence in front of a workgroup's arrival count and in front of the flag stores, instead of relying on "s_waitcnt vmcnt(0) =
+// acknowledged by the memory the store went to" + relaxed counters and flags
+#define TDS_RING_PEER_RELEASE 32
 // upper bound of the peers of a rank (ranks of one node - 1)
 #define TDS_MAX_PEERS 15
 
@@ -131,6 +135,7 @@ struct TdsStepCtl {
 #define TDS_FORM_W2 1         // L is the w2 layout: launch the two-wavefront form (plain kernels)
 #define TDS_FORM_LOOP_OCC1 2  // step-loop build: the one-wavefront-per-SIMD compilation whatever the grid
 #define TDS_FORM_LOOP_OCC2 4  // ... the two-wavefronts-per-SIMD compilation whatever the grid
+#define TDS_FORM_OCT_W2 8     // the 8-lane kernel (tds_oct.hip): its two-wavefront build
 
 // EXPERIMENT SLOTS (tools/build_alt.sh): the kernel sources compiled once more — other compiler flags, -DTDS_X_... source
 // switches — as a small extra translation unit holding ONE (lanes, padded dof) instantiation of the f64 / KIND 0 kernels,
@@ -183,12 +188,11 @@ inline bool tds_quad_takes(int quad, const TdsStepCtl &ctl, const long long *pro
 // kernel, and the exchange launches of the multi-GPU layer (progress counters / peer stores) as well
 template <typename T, typename TR>
 int tds_launch_oct(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
-                   TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl);
+                   TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, bool two_waves);
 int tds_oct_lds_bytes(int input_dim);        // LDS of one environment
 int tds_oct_workgroup_bytes(int input_dim);  // LDS of one workgroup: eight environments + the constant table
 inline bool tds_oct_takes(int oct, const TdsStepCtl &ctl, const long long *prof) {
-  return oct != 0 && prof == nullptr && ctl.nsub >= 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr &&
-         ctl.progress == nullptr && ctl.peer_arrive == nullptr;
+  return oct != 0 && prof == nullptr && ctl.nsub >= 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
 }
 
 // T: compute scalar, TR: record scalar (== T, or float under T = double: "f32 records / f64 arithmetic")
@@ -203,7 +207,8 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
     return tds_launch_quad<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl);
   if constexpr (sizeof(T) == 8) {
     if (tds_oct_takes(h_model.oct, ctl, prof))
-      return tds_launch_oct<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl);
+      return tds_launch_oct<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl,
+                                   (form & TDS_FORM_OCT_W2) != 0);
   }
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);

@@ -76,10 +76,8 @@ namespace {
 // inference leaves volatile accesses alone) every one of them was a FLAT instruction with sc0 sc1 and an `s_waitcnt vmcnt(0)`
 // of its own — eight flat stores + waits in the middle of the main wavefront's LDL^T (the hand-over of the first half of L),
 // a flat load + wait per poll.  These go to the LDS address space explicitly: ds_read / ds_write, lgkmcnt only.
-// (-DTDS_LDS_FLAGS=0: round 4's volatile generic pointers)
-#ifndef TDS_LDS_FLAGS
-#define TDS_LDS_FLAGS 1
-#endif
+// (the main wavefront's polls; the helper's stay volatile generic loads: as DS reads that build spilled and lost 5 % —
+//  tools/experiments/r05_not_kept.txt)
 #ifndef TDS_LDS_PUBLISH
 #define TDS_LDS_PUBLISH 1
 #endif
@@ -102,14 +100,7 @@ __device__ __forceinline__ P *tds_global(P *p) {
 }
 template <int WHO = 1, typename T>
 __device__ __forceinline__ T tds_lds_poll(const T *p) {  // WHO: 1 the main wavefront's polls, 2 the helper's
-  if constexpr ((TDS_LDS_FLAGS & WHO) != 0) return *(const volatile TDS_AS3 T *)p;
-  else if constexpr ((TDS_LDS_FLAGS & (WHO << 2)) != 0) {  // (bits 4 / 8: the DS read spelled out)
-    const unsigned a = (unsigned)(unsigned long long)(const TDS_AS3 T *)p;
-    T v;
-    if constexpr (sizeof(T) == 8) asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-    else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-    return v;
-  }
+  if constexpr (WHO == 1) return *(const volatile TDS_AS3 T *)p;
   else return *(const volatile T *)p;
 }
 template <typename T>
@@ -1260,15 +1251,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
 #ifndef TDS_FLUSH_EARLY
 #define TDS_FLUSH_EARLY 1
 #endif
-// (-DTDS_SIGNAL_IN_TAIL=1, experiment: the helper's barrier (0) behind its count-in of the step before last, so that the wait
-//  for store acknowledgements and the atomics' round trips falls into its idle tail instead of the A - C window — measured
-//  same process, one rank through the shard layer: 13.24 against 12.96 us per step at 256 steps per launch: not kept)
-#ifndef TDS_SIGNAL_IN_TAIL
-#define TDS_SIGNAL_IN_TAIL 0
-#endif
   if constexpr (W2 && LOOP) {
     if constexpr (TDS_FLUSH_EARLY != 0) {
-      if (tds_iter > 0 && (main_wave || TDS_SIGNAL_IN_TAIL == 0)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tds_iter > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
       if (main_wave && tds_iter > 0) {  // the helper has read X_world of the previous step (its late visual poses, see there)
         const T *const pf = sm + grp * L.stride + L.xrec + in_dim + 4;
@@ -1505,7 +1490,9 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       const int u = u0 + wl;
       const bool on = u < n_units;
       unsigned long long bits = 0ull;
-      bool tail = true;  // this unit holds only [reward | done] columns
+      bool tail = false;  // this unit holds a [reward | done] column (with exchange_fields = 1 a unit travels if ANY of its
+                          // columns is one of the two: on a float wire with an odd record width they share units with
+                          // observation columns — floating-base and spherical models)
       {
         unsigned lo = 0u, hi = 0u;
 #pragma unroll
@@ -1518,7 +1505,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
             const int i = f - e * w;
             const int src = i < nq + nd ? i : (i == nq + nd ? in_dim + RW_SLOT : in_dim + 1);
             const T v = i < 2 ? T(0) : sm[e * L.stride + L.xrec + src];
-            tail = tail && i >= nq + nd;
+            tail = tail || i >= nq + nd;
             if (f32w) {
               const unsigned b = (unsigned)__float_as_int((float)v);
               if (c == 0) lo = b; else hi = b;
@@ -1537,11 +1524,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       for (int p0 = 0; p0 < np; p0 += 4) {  // (the table is padded to a multiple of four entries)
         const unsigned long long *const b0 = tds_global(tab[p0]), *const b1 = tds_global(tab[p0 + 1]), *const b2 = tds_global(tab[p0 + 2]), *const b3 = tds_global(tab[p0 + 3]);
         const size_t po = (size_t)ctl.peer_off / 8 + unit_at;
-#ifdef TDS_X_PEER_NOSTORE  // (experiment: everything but the peers' stores themselves)
-        if (to_peers && po == ~(size_t)0) {
-#else
         if (to_peers) {
-#endif
           // (stores through explicitly global pointers: as generic ones they were FLAT stores)
           using G64 = __attribute__((address_space(1))) unsigned long long;
           __hip_atomic_store((G64 *)((unsigned long long *)b0 + po), bits, __ATOMIC_RELAXED, TDS_PEER_SCOPE);
@@ -1582,6 +1565,8 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
   // flag stores are issued after the last count returned: a rank that sees the flag sees the records.
   auto peer_signal = [&](int pslot) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    const bool rel = (ctl.ring_flags & TDS_RING_PEER_RELEASE) != 0;  // (A/B switch: tds_kernels.h)
+    if (rel) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     if ((threadIdx.x & 63) == 0) {
       // two levels (tds_kernels.h: TDS_PEER_SUB): workgroup b on first-level counter b mod SUB, whoever completes one on
       // the second level; every counter wraps at its own count and lives on a line of its own
@@ -1593,6 +1578,7 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       if (atomicInc(base + j * TDS_PEER_LINE, n1 - 1u) == n1 - 1u) {
         if (atomicInc(base + 32 * TDS_PEER_LINE, n2 - 1u) == n2 - 1u) {
           const size_t fi = (size_t)ctl.peer_flag_off + (size_t)pslot * (size_t)ctl.peer_flag_stride;
+          if (rel) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
           for (int pr = 0; pr <= ctl.n_peers; ++pr)
             __hip_atomic_store(ctl.peer_flags[pr] + fi, ctl.peer_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -2024,21 +2010,6 @@ void tds_step_kernel(const DevModel<T> *__restrict__ mdl_arg, TdsLds L_arg,
       TDS_STAMP(1);
       if constexpr (LOOP) {  // (TDS_RING_SIGNAL_LATE: the records stored in the iteration before this one)
         if (ctl.ring_flags & TDS_RING_SIGNAL_LATE) signal_progress(2);
-      }
-      if constexpr (LOOP && TDS_FLUSH_EARLY != 0 && TDS_SIGNAL_IN_TAIL != 0) {
-        if (tds_iter > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier (0), the helper's side
-      }
-      // (-DTDS_CONSUME_CONSTS=1, experiment: the phase constants requested above waited for HERE, in front of the record stores —
-      //  an empty asm that "uses" their registers — so that their first use behind barrier (1) is not a vmcnt(0) that also
-      //  waits for the stores: no gain, 11.66 against 11.67 us per step; with seven loopback peers 14.76 against 14.36)
-#ifndef TDS_CONSUME_CONSTS
-#define TDS_CONSUME_CONSTS 0
-#endif
-      if constexpr (LOOP && TDS_FLUSH_EARLY != 0 && TDS_CONSUME_CONSTS != 0) {
-        asm volatile("" ::"v"(pf_cp_link), "v"(pf_cp_anc), "v"(pf_cp_loc[0]), "v"(pf_cp_loc[1]), "v"(pf_cp_loc[2]), "v"(pf_cp_rad),
-                     "v"(pf_vis_link), "v"(pf_dof_link), "v"(pf_anc));
-        asm volatile("" ::"v"(pf_vis_X[0]), "v"(pf_vis_X[1]), "v"(pf_vis_X[2]), "v"(pf_vis_X[3]), "v"(pf_vis_X[4]), "v"(pf_vis_X[5]),
-                     "v"(pf_vis_X[6]), "v"(pf_vis_X[7]), "v"(pf_vis_X[8]), "v"(pf_vis_X[9]), "v"(pf_vis_X[10]), "v"(pf_vis_X[11]));
       }
       if constexpr (LOOP && TDS_FLUSH_EARLY != 0) flush_prev_records();  // (behind barrier (0): see there)
       // (the helper's side of barrier (1) does not wait for its global stores — the previous step's records, and in the

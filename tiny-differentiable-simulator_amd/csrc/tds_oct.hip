@@ -29,15 +29,38 @@
 // the general kernel, and tests/test_oct.py holds the two against each other and against the reference.
 //
 // Two forms (template parameter LOOP) as in tds_quad.hip: one step per launch, and K steps per launch with the state in
-// LDS, a fresh action block per step, per-step record rings, reset-pool entries taken inside the loop and the peer-store
-// exchange of the multi-GPU layer (tds_shard.hip).  In-kernel reset + settle, substeps with one action through a policy
-// and on-device rollouts stay with the general kernel.  Reference files as in tds_kernels.hip.
+// LDS, a fresh action block per step, per-step record rings, reset-pool entries taken inside the loop and the exchange of
+// the multi-GPU layer (tds_shard.hip: progress counters, peer stores).  Two builds of each (template parameter W2): one
+// wavefront per workgroup of eight environments, and TWO — a main wavefront on the step's dependent chain and a helper /
+// recorder beside it (narrowphase, visual poses, constraint rows, every record store), the form the host grants while
+// every workgroup is resident with at most two wavefronts per SIMD (Ant x 4096: one wavefront per SIMD; x 8192: two).
+// In-kernel reset + settle, substeps with one action through a policy and on-device rollouts stay with the general
+// kernel.  Reference files as in tds_kernels.hip.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
 #include "tds_device_model.h"
 #include "tds_kernels.h"
 #include "tds_lanes.h"
+
+// Phase stamps (a build of its own: -DTDS_OCT_PROF, tools/oct_profile.sh): workgroup TDS_OCT_PROF_WG writes the shader clock
+// at the phase boundaries of iteration TDS_OCT_PROF_ITER of a step-loop launch into tds_oct_prof_buf
+#ifdef TDS_OCT_PROF
+#ifndef TDS_OCT_PROF_WG
+#define TDS_OCT_PROF_WG 3
+#endif
+__device__ unsigned long long tds_oct_prof_buf[32];
+__device__ int tds_oct_prof_iter = 500;
+#define OCT_STAMP(k, pin)                                                                       \
+  do {                                                                                          \
+    unsigned long long t_;                                                                      \
+    auto p_ = (pin); /* a value of the phase before: computed before the clock is read */       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(p_)::"memory");        \
+    if (prof_on) prof_t[k] = t_;                                                                \
+  } while (0)
+#else
+#define OCT_STAMP(k, pin) do { } while (0)
+#endif
 
 namespace {
 
@@ -67,8 +90,13 @@ template <int K, typename T>
 __device__ __forceinline__ T pair_bcast(T v) { return oct_dpp<(K == 0 ? 0xA0 : 0xF5)>(v); }
 // sum over the 8 lanes of an environment, every lane receives the SAME bits: pair (a + b and b + a are the same sum),
 // pair of pairs, then the mirror image of the half row (lane i <- lane 7 - i: the other quad, whose four lanes agree)
+// (the operand is pinned in a register first: a product handed in must be ROUNDED before the first addition — contracted
+//  into it, lane i would add its exact product to lane i ^ 1's rounded one and lane i ^ 1 the other way round: the two
+//  "same" sums then differ in the last bit, and with them everything that is redundant on every lane behind them; an
+//  environment's result would depend on which lane solves which constraint row, i.e. on its wavefront-mates' contacts)
 template <typename T>
 __device__ __forceinline__ T oct_sum(T v) {
+  asm volatile("" : "+v"(v));
   v += oct_dpp<0xB1>(v);   // quad_perm [1, 0, 3, 2]
   v += oct_dpp<0x4E>(v);   // quad_perm [2, 3, 0, 1]
   v += oct_dpp<0x141>(v);  // row_half_mirror
@@ -90,28 +118,31 @@ __device__ __forceinline__ float oct_bcast(float v) {
 
 // LDS per environment, offsets in scalars of T
 struct OctOff {
-  int lcw, legf, swl, qdp, S, Z, xs, cp, stride;
+  int lcw, legf, swl, qdp, fac, win, xs, cp, stride;
 };
 struct OctLds {
-  static constexpr int LCW = 13;  // [8 lanes][Lc(6) | W(6)] + pad
-  static constexpr int ZW = 13;   // a window row: z~ leg (2) | z~ root (6) | b | 1 / (G + cfm) | G | owner lane | pad
+  static constexpr int LCW = 12;  // [8 lanes][Lc(6) | W(6)]
+  static constexpr int ZW = 12;   // a window row: z~ leg (2) | z~ root (6) | b | 1 / (G + cfm) | G | hip lane of the contact's leg
   static constexpr int NCP = 17;  // contact points (torso + 2 per leg link), and the stride of the contact list
 };
 __host__ __device__ inline OctOff oct_layout(int in_dim) {
   OctOff o;
-  int at = in_dim + 4;          // x record | x_{t-1} | done | reward | spare
+  int at = in_dim + 4;          // x record | x_{t-1} | done | reward | flag / count
   at = (at + 1) & ~1;
   o.lcw = at;  at += 8 * OctLds::LCW;     // L_c and W of the 8 leg-dof lanes
   o.legf = at; at += 4 * 3;               // per leg: l10 | sqrt(1/d0) | sqrt(1/d1)
-  o.swl = at;  at += 8 * 7;               // world motion axis of the 8 leg-dof lanes (6, stride 7)
+  o.swl = at;  at += 8 * 6;               // world motion axis of the 8 leg-dof lanes
   o.qdp = at;  at += 8;                   // leg velocities after integrate_euler_qdd
-  o.S = at;    at += 22;                  // the 21 lane-parallel sums of the Schur complement
-  o.Z = at;    at += 8 * OctLds::ZW;      // the window of constraint rows
-  o.xs = at;   at += 3 * OctLds::NCP + 1; // impulses
+  o.fac = at;  at += 28;                  // the 21 lane-parallel sums of the Schur complement; then (two-wavefront build) the root
+                                          // block's factors for the helper: L_S (15) | sqrt(1/D_S) (6) | root velocities (6)
+  o.win = at;  at += 2 * 8 * OctLds::ZW;  // two windows of constraint rows (the second doubles as the hand-over of the links'
+                                          // world transforms from the main wavefront to the helper: 8 x 12)
+  o.xs = at;   at += 3 * OctLds::NCP + 1; // impulses (the first six slots: the root's sines / cosines for the helper)
   o.cp = at;   at += 5 * OctLds::NCP + 1; // contact list: point (3) | distance | owner lane, per slot
-  // eight environments of a wavefront on different banks: the stride in 4-byte words == 16 mod 64
+  // the environments of a wavefront on different banks: four consecutive ones (half a wavefront) must not meet on an
+  // 8-byte bank pair — the stride in 4-byte words a multiple of 8 that is neither 0 nor 32 mod 64
   at = (at + 1) & ~1;
-  while (((at * 2) & 63) != 16) at += 2;
+  while ((((at * 2) & 63) % 8) != 0 || ((at * 2) & 63) == 0 || ((at * 2) & 63) == 32) at += 2;
   o.stride = at;
   return o;
 }
@@ -149,36 +180,61 @@ __device__ __forceinline__ P *oct_global(P *p) {  // a loaded pointer: not LDS, 
 // DevModel::oct_tab (laid out by tds_build_oct_table on the host: tds_device_model.h, TDS_OCT_*) at the top of a launch
 using TB = TdsOctTab;
 
-template <typename T, typename TR, bool LOOP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+// barrier between the two wavefronts of a workgroup (W2: LDS writes done, then s_barrier — neither wavefront waits for its
+// outstanding global stores); a compiler-level fence in the one-wave build, where the LDS executes a wavefront's
+// instructions in order
+#define OCT_BAR()                                                                        \
+  do {                                                                                   \
+    if constexpr (W2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+    else OCT_SYNC();                                                                     \
+  } while (0)
+
+// LOOP: K steps per launch (state in LDS).  W2: TWO wavefronts per workgroup of eight environments — the MAIN wavefront walks
+// the step's dependent chain (PD, kinematics, inertias, LDL^T, forward dynamics, the Gauss-Seidel sweep, integration,
+// reward), the HELPER does what hangs off it (narrowphase, visual poses, the constraint rows window by window, every record
+// store, the exchange); in the one-wave build the one wavefront plays both roles in the same order.
+template <typename T, typename TR, bool LOOP, bool W2>
+__global__ __launch_bounds__(W2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(W2 ? 2 : 1, W2 ? 2 : 1)))
 void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
                     const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */, TR *__restrict__ obs_out,
                     TdsStepCtl ctl_arg, int n_envs, OctOff O) {
   extern __shared__ __align__(16) unsigned char tds_oct_smem[];
   T *const sm = reinterpret_cast<T *>(tds_oct_smem);
   constexpr int nq = 14, nd = 14, adim = 8, in_dim = nq + nd + adim + 3, w_obs = nq + nd + 2;
+  constexpr int NT = W2 ? 128 : 64;
   T *const CT = sm + 8 * O.stride;  // the constant table
   {
     // ---- the constant table (coalesced copy) and A. x record -> LDS, fresh actions over the action slice
-    const int t = threadIdx.x & 63;
-    for (int i = t; i < TB::TOTAL; i += 64) CT[i] = mdl_arg->oct_tab[i];
-    const int lane = t & 7, grp = t >> 3, env = blockIdx.x * 8 + grp;
-    const bool valid = env < n_envs;
-    T *const xr = sm + grp * O.stride;
-    for (int i = lane; i < in_dim; i += 8) {
-      const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
-      xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+    const int t = threadIdx.x;
+    for (int i = t; i < TB::TOTAL; i += NT) CT[i] = mdl_arg->oct_tab[i];
+    if (t < 64) {
+      const int lane = t & 7, grp = t >> 3, env = blockIdx.x * 8 + grp;
+      const bool valid = env < n_envs;
+      T *const xr = sm + grp * O.stride;
+      for (int i = lane; i < in_dim; i += 8) {
+        const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
+        xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+      }
+      if (lane < 4) xr[in_dim + lane] = T(0);
     }
-    if (lane < 4) xr[in_dim + lane] = T(0);
-    OCT_SYNC();
+    if constexpr (W2) __syncthreads();
+    else OCT_SYNC();
   }
   const int nsteps = LOOP ? ctl_arg.nsub : 1;
-  T next_act = T(0);  // (step-loop form: the action of the NEXT step, requested a step ahead)
+  T next_act = T(0);  // (step-loop form, main wavefront: the action of the NEXT step, requested a step ahead)
   for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
   // (nothing but `it` and next_act lives across an iteration: lane and kernel-argument segment are laundered)
   const __attribute__((address_space(4))) char *ka_seg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
   int tid = threadIdx.x;
   if constexpr (LOOP) asm volatile("" : "+s"(ka_seg), "+v"(tid));
+  const int wv = W2 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+  const bool is_main = !W2 || wv == 0, is_help = !W2 || wv == 1;  // wave-uniform (the profile build's stamps)
+  (void)is_main;
+  (void)is_help;
+#ifdef TDS_OCT_PROF
+  unsigned long long prof_t[16];
+  const bool prof_on = blockIdx.x == TDS_OCT_PROF_WG && it == tds_oct_prof_iter;
+#endif
   const int lane = tid & 7;
   const int grp = (tid & 63) >> 3;
   const int env = blockIdx.x * 8 + grp;
@@ -191,387 +247,31 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   typename OctCtlRef<LOOP>::type ctl = OctCtlRef<LOOP>::get(ctl_arg, ka_seg + __builtin_offsetof(OctKernArgs, ctl));
   const T dt = CT[TB::SC + TB::DT];
   const bool last = it == nsteps - 1;
-  if constexpr (LOOP) {
-    // the action block of this step came in a step ago (see phase M); the next step's is requested now
-    if (ctl.act_pool != nullptr) {  // wave-uniform
-      if (it + 1 < nsteps && valid) {
-        const int blk = (ctl.act_first + it + 1) % ctl.act_blocks;
-        next_act = (T)oct_global((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
-      }
-    }
-  }
-  const T q = xr[dq];
-  const T qd = xr[nq + dq];
+  OCT_STAMP(0, tid);
 
-  // ---- PD controller (locomotion_contact_simulation.h:168-258); joint stiffness / damping
-  T tau = T(0);
-  {
-    const int act_i = (int)CL[TB::ACT];
-    if (act_i >= 0) {
-      const int var = nq + nd + adim;
-      const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
-      const T act_lim = CT[TB::SC + TB::ACTION_LIMIT];
-      T a = xr[nq + nd + act_i];
-      a = a < act_lim ? a : act_lim;
-      a = a > -act_lim ? a : -act_lim;
-      const T q_des = CL[TB::IPOSE] + a;
-      T f = kp * (q_des - q) + kd * (T(0) - qd);
-      f = f > -max_force ? f : -max_force;
-      f = f < max_force ? f : max_force;
-      tau = f;
-    }
-    tau -= CL[TB::STIFF] * q + CL[TB::DAMP] * qd;
-  }
-
-  // ---- B. jcalc (link.hpp:229-287)
-  T Sl[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) Sl[k] = CL[TB::S + k];
-  T Rp[9], tp[3];
-  {
-    const int jt = (int)CL[TB::JT];
-    T RT[9], tT[3];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) RT[k] = CL[TB::XT + k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tT[k] = CL[TB::XT + 9 + k];
-    T sn, cs;
-    sincos_t<T>(jt == TDS_JOINT_REVOLUTE_AXIS ? q * T(0.5) : q, &sn, &cs);
-    const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
-    const bool pris = jt >= TDS_JOINT_PRISMATIC_X && jt <= TDS_JOINT_PRISMATIC_AXIS;
-    T RJ[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
-    T tJ[3] = {T(0), T(0), T(0)};
-    if (pris) {
-      tJ[0] = Sl[3] * q;
-      tJ[1] = Sl[4] * q;
-      tJ[2] = Sl[5] * q;
-    }
-    if (rev) {
-      if (jt == TDS_JOINT_REVOLUTE_X) {
-        RJ[4] = cs; RJ[5] = -sn; RJ[7] = sn; RJ[8] = cs;
-      } else if (jt == TDS_JOINT_REVOLUTE_Y) {
-        RJ[0] = cs; RJ[2] = sn; RJ[6] = -sn; RJ[8] = cs;
-      } else if (jt == TDS_JOINT_REVOLUTE_Z) {
-        RJ[0] = cs; RJ[1] = -sn; RJ[3] = sn; RJ[4] = cs;
-      } else {  // axis-angle quaternion with the UNNORMALISED axis (link.hpp:256-261)
-        const T d = sqrt_t<T>(Sl[0] * Sl[0] + Sl[1] * Sl[1] + Sl[2] * Sl[2]);
-        const T sh = sn / d;
-        const T qx = Sl[0] * sh, qy = Sl[1] * sh, qz = Sl[2] * sh, qw = cs;
-        const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
-        const T xs = qx * s2, ys = qy * s2, zs = qz * s2;
-        const T wx = qw * xs, wy = qw * ys, wz = qw * zs;
-        const T xx = qx * xs, xy = qx * ys, xz = qx * zs;
-        const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
-        RJ[0] = T(1) - (yy + zz); RJ[1] = xy - wz; RJ[2] = xz + wy;
-        RJ[3] = xy + wz; RJ[4] = T(1) - (xx + zz); RJ[5] = yz - wx;
-        RJ[6] = xz - wy; RJ[7] = yz + wx; RJ[8] = T(1) - (xx + yy);
-      }
-    }
-    mat3_mul(RT, RJ, Rp);
-    T r[3];
-    mat3_mulv(RT, tJ, r);
-    tp[0] = tT[0] + r[0];
-    tp[1] = tT[1] + r[1];
-    tp[2] = tT[2] + r[2];
-  }
-
-  // ---- C. the root chain in closed form (kinematics.hpp:64-97; tds_kernels.hip phase C: same formulas), on every lane.
-  //         The three root angles' sines and cosines: lanes 0, 1, 2 of the environment, broadcast
-  T sx, cx, sy, cy, sz, cz;
-  {
-    T rs, rc;
-    sincos_t<T>(xr[3 + (lane < 3 ? lane : 0)], &rs, &rc);
-    sx = oct_bcast<0>(rs); cx = oct_bcast<0>(rc);
-    sy = oct_bcast<1>(rs); cy = oct_bcast<1>(rc);
-    sz = oct_bcast<2>(rs); cz = oct_bcast<2>(rc);
-  }
-  T R5[9];  // the root body's rotation
-  R5[0] = cy * cz;                 R5[1] = -cy * sz;                R5[2] = sy;
-  R5[3] = sx * sy * cz + cx * sz;  R5[4] = cx * cz - sx * sy * sz;  R5[5] = -sx * cy;
-  R5[6] = sx * sz - cx * sy * cz;  R5[7] = cx * sy * sz + sx * cz;  R5[8] = cx * cy;
-  const T P[3] = {xr[0] + CT[TB::SC + TB::BASE_T], xr[1] + CT[TB::SC + TB::BASE_T + 1], xr[2] + CT[TB::SC + TB::BASE_T + 2]};
-  // the root's revolute axes (angular part; A3 = e_x) and their linear parts P x A
-  const T A4[3] = {T(0), cx, sx}, A5[3] = {sy, -sx * cy, cx * cy};
-  const T pA3[3] = {T(0), P[2], -P[1]};  // P x e_x
-  T pA4[3], pA5[3];
-  cross3(P, A4, pA4);
-  cross3(P, A5, pA5);
-  T v5[6], a5[6];  // velocity and bias acceleration (a0) of the root body
-  {
-    const T d0 = xr[nq + 0], d1 = xr[nq + 1], d2 = xr[nq + 2], d3 = xr[nq + 3], d4 = xr[nq + 4], d5 = xr[nq + 5];
-    const T U[3] = {d0, d1, d2};
-    const T J3[3] = {d3, T(0), T(0)}, J4[3] = {A4[0] * d4, A4[1] * d4, A4[2] * d4}, J5[3] = {A5[0] * d5, A5[1] * d5, A5[2] * d5};
-    const T W4[3] = {J3[0] + J4[0], J3[1] + J4[1], J3[2] + J4[2]};
-    const T W5[3] = {W4[0] + J5[0], W4[1] + J5[1], W4[2] + J5[2]};
-    T pJ3[3], pJ4[3], pJ5[3];
-    cross3(P, J3, pJ3);
-    cross3(P, J4, pJ4);
-    cross3(P, J5, pJ5);
-    const T pW4[3] = {pJ3[0] + pJ4[0], pJ3[1] + pJ4[1], pJ3[2] + pJ4[2]};
-    const T pW5[3] = {pW4[0] + pJ5[0], pW4[1] + pJ5[1], pW4[2] + pJ5[2]};
-    const T V3[3] = {U[0] + pJ3[0], U[1] + pJ3[1], U[2] + pJ3[2]};
-    const T V4[3] = {U[0] + pW4[0], U[1] + pW4[1], U[2] + pW4[2]};
-    const T V5[3] = {U[0] + pW5[0], U[1] + pW5[1], U[2] + pW5[2]};
-    T a45[3], a55[3], t1[3], t2[3], l3[3], l4[3], l5[3];
-    cross3(J3, J4, a45);
-    cross3(W4, J5, a55);
-    cross3(J3, pJ3, t1);
-    cross3(V3, J3, t2);
-    l3[0] = t1[0] + t2[0]; l3[1] = t1[1] + t2[1]; l3[2] = t1[2] + t2[2];
-    cross3(W4, pJ4, t1);
-    cross3(V4, J4, t2);
-    l4[0] = t1[0] + t2[0]; l4[1] = t1[1] + t2[1]; l4[2] = t1[2] + t2[2];
-    cross3(W5, pJ5, t1);
-    cross3(V5, J5, t2);
-    l5[0] = t1[0] + t2[0]; l5[1] = t1[1] + t2[1]; l5[2] = t1[2] + t2[2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      v5[k] = W5[k];
-      v5[3 + k] = V5[k];
-      a5[k] = a45[k] + a55[k];
-      a5[3 + k] = (l3[k] + l4[k] + l5[k]) - CT[TB::SC + TB::GRAV + k];
-    }
-  }
-  // ---- the legs: the ankle composes its joint transform with the hip's (one step of a segmented scan along the pair),
-  //      the root's pose in front; prefix sums of the joint velocities and of the velocity-product accelerations
-  T R[9], p[3], sw[6], v[6], a0[6];
-  {
-    const bool take = pos == 1;
-    T Rq[9], pq[3];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const T sh = pair_bcast<0>(Rp[k]);
-      Rq[k] = take ? sh : ((k == 0 || k == 4 || k == 8) ? T(1) : T(0));
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const T sh = pair_bcast<0>(tp[k]);
-      pq[k] = take ? sh : T(0);
-    }
-    T Rl[9], pl[3], r[3];
-    mat3_mul(Rq, Rp, Rl);
-    mat3_mulv(Rq, tp, r);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) pl[k] = pq[k] + r[k];
-    mat3_mul(R5, Rl, R);
-    mat3_mulv(R5, pl, r);
-    p[0] = P[0] + r[0];
-    p[1] = P[1] + r[1];
-    p[2] = P[2] + r[2];
-    // s = X_world.apply_inverse(S) = (R w, R v + p x (R w))   (transform.hpp:232-243)
-    mat3_mulv(R, Sl, sw);
-    mat3_mulv(R, Sl + 3, sw + 3);
-    T c[3];
-    cross3(p, sw, c);
-    sw[3] += c[0];
-    sw[4] += c[1];
-    sw[5] += c[2];
-    T vJ[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) vJ[k] = sw[k] * qd;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const T sh = pair_bcast<0>(vJ[k]);
-      v[k] = v5[k] + (vJ[k] + (take ? sh : T(0)));
-    }
-    // cb = v x vJ (kinematics.hpp:96-99)
-    T cb[6];
-    cross3(v, vJ, cb);
-    T c1[3], c2[3];
-    cross3(v, vJ + 3, c1);
-    cross3(v + 3, vJ, c2);
-    cb[3] = c1[0] + c2[0];
-    cb[4] = c1[1] + c2[1];
-    cb[5] = c1[2] + c2[2];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const T sh = pair_bcast<0>(cb[k]);
-      a0[k] = a5[k] + (cb[k] + (take ? sh : T(0)));
-    }
-  }
-  // my world motion axis, for the rows of the contacts (lane-dependent reads in the row windows)
-  {
-    T *const swl = E + O.swl + lane * 7;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) swl[k] = sw[k];
-  }
-
-  // ---- I. narrowphase (contact_point.hpp:96-161): my link's capsule = two spheres; the root body's sphere on every lane.
-  //         Penetrating points in the reference's order (root, then per link +L/2 end, -L/2 end) into the contact list
+  // state shared by the phases of a role (main: kinematics .. integration; helper: narrowphase .. records); what crosses from
+  // the main wavefront to the helper goes through LDS in the two-wavefront build and stays in these registers otherwise
+  T q, qd, tau;
+  T Sl[6], R[9], p[3], sw[6], v[6], a0[6];
+  T R5[9], P[3], A4[3], A5[3], pA3[3], pA4[3], pA5[3], v5[6], a5[6];
+  T Lc[6], l10, id0, id1, my_id, Ls[15], ids[6], sq_ids[6], qd_new, qdr_new[6];
   int na = 0, NA = 0;
-  {
-    T *const cpx = E + O.cp;
-    const T n[3] = {CT[TB::SC + TB::PLANE_N], CT[TB::SC + TB::PLANE_N + 1], CT[TB::SC + TB::PLANE_N + 2]};
-    const T pc = CT[TB::SC + TB::PLANE_C];
-    auto sphere = [&](const T *Rl, const T *pl, const T *loc, T rad, T *pt, T &dist) {
-      T ctr[3];
-      mat3_mulv(Rl, loc, ctr);
-      ctr[0] += pl[0];
-      ctr[1] += pl[1];
-      ctr[2] += pl[2];
-      const T t = -((-dot3(ctr, n)) + pc);
-      dist = t - rad;
-      pt[0] = ctr[0] - rad * n[0];
-      pt[1] = ctr[1] - rad * n[1];
-      pt[2] = ctr[2] - rad * n[2];
-    };
-    T pt0[3], pt1[3], ptt[3], d0, d1, dtt;
-    sphere(R, p, CL + TB::CPL0, CL[TB::CPR0], pt0, d0);
-    sphere(R, p, CL + TB::CPL1, CL[TB::CPR1], pt1, d1);
-    sphere(R5, P, CT + TB::ROOT + TB::R_CPL, CT[TB::ROOT + TB::R_CPR], ptt, dtt);
-    const bool act0 = valid && d0 < T(0), act1 = valid && d1 < T(0), actt = valid && dtt < T(0) && CT[TB::ROOT + TB::R_CPR] >= T(0);
-    const unsigned long long b0 = __ballot(act0), b1 = __ballot(act1), bt = __ballot(actt);
-    const unsigned m0 = (unsigned)((b0 >> (grp * 8)) & 0xFFull), m1 = (unsigned)((b1 >> (grp * 8)) & 0xFFull);
-    const unsigned below = (1u << lane) - 1u;
-    const int r0 = (actt ? 1 : 0) + __popc(m0 & below) + __popc(m1 & below);
-    const int r1 = r0 + (act0 ? 1 : 0);
-    if (act0) {
-      cpx[0 * OctLds::NCP + r0] = pt0[0];
-      cpx[1 * OctLds::NCP + r0] = pt0[1];
-      cpx[2 * OctLds::NCP + r0] = pt0[2];
-      cpx[3 * OctLds::NCP + r0] = d0;
-      cpx[4 * OctLds::NCP + r0] = (T)lane;
-    }
-    if (act1) {
-      cpx[0 * OctLds::NCP + r1] = pt1[0];
-      cpx[1 * OctLds::NCP + r1] = pt1[1];
-      cpx[2 * OctLds::NCP + r1] = pt1[2];
-      cpx[3 * OctLds::NCP + r1] = d1;
-      cpx[4 * OctLds::NCP + r1] = (T)lane;
-    }
-    if (actt && lane == 0) {
-      cpx[0 * OctLds::NCP] = ptt[0];
-      cpx[1 * OctLds::NCP] = ptt[1];
-      cpx[2 * OctLds::NCP] = ptt[2];
-      cpx[3 * OctLds::NCP] = dtt;
-      cpx[4 * OctLds::NCP] = T(8);
-    }
-    na = (actt ? 1 : 0) + __popc(m0) + __popc(m1);
-    // the largest count among the wavefront's environments (scalar arithmetic on the three ballots)
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int c = __popc((unsigned)((b0 >> (g * 8)) & 0xFFull)) + __popc((unsigned)((b1 >> (g * 8)) & 0xFFull)) + (int)((bt >> (g * 8)) & 1ull);
-      NA = c > NA ? c : NA;
-    }
-  }
 
-  // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
-  //          my link's (DevModel::oct checks the order); visual 0 — the root body's — goes out on lane 7
-  const int ystr = ctl.y_stride;
-  const int out_dim = (int)CT[TB::SC + TB::OUTPUT_DIM];
-  TR *yo = nullptr, *yo2 = nullptr;
-  int yend = ystr, yend2 = out_dim;
-  if (LOOP && ctl.y_ring != nullptr) {
-    yo = oct_global((TR *)ctl.y_ring) + ((size_t)((ctl.y_first + it) % ctl.y_slots) * ctl.ring_envs + env) * ystr;
-    if (last && y_out != nullptr) yo2 = y_out + (size_t)env * out_dim;
-  } else if (last && y_out != nullptr) {
-    yo = y_out + (size_t)env * (LOOP ? out_dim : ystr);
-    yend = LOOP ? out_dim : ystr;
-  }
-  const int nv = (int)CT[TB::SC + TB::NUM_VISUALS];
-  if (valid && yo != nullptr && nv > 0) {
-    auto pose_out = [&](const T *Rl, const T *pl, const T *vx, int k) {
-      T Ro[9], po[3], qo[4];
-      mat3_mul(Rl, vx, Ro);
-      mat3_mulv(Rl, vx + 9, po);
-      matrix_to_quat(Ro, qo);
-      TR *o = yo + (nq + nd) + 7 * k;
-      o[0] = (TR)(pl[0] + po[0]);
-      o[1] = (TR)(pl[1] + po[1]);
-      o[2] = (TR)(pl[2] + po[2]);
-      o[3] = (TR)qo[0];
-      o[4] = (TR)qo[1];
-      o[5] = (TR)qo[2];
-      o[6] = (TR)qo[3];
-      if (yo2 != nullptr) {
-        TR *o2 = yo2 + (nq + nd) + 7 * k;
-        o2[0] = (TR)(pl[0] + po[0]);
-        o2[1] = (TR)(pl[1] + po[1]);
-        o2[2] = (TR)(pl[2] + po[2]);
-        o2[3] = (TR)qo[0];
-        o2[4] = (TR)qo[1];
-        o2[5] = (TR)qo[2];
-        o2[6] = (TR)qo[3];
-      }
-    };
-    pose_out(R, p, CL + TB::VIS, 1 + lane);
-    if (lane == 7) pose_out(R5, P, CT + TB::ROOT + TB::R_VIS, 0);
-  }
-
-  // ---- D. world-frame rigid inertia and bias force of my link, and (redundantly on every lane) of the root body
-  //         (kinematics.hpp:96-132, inertia.hpp:121-130): I = (Isym 6 | h 3 | m), f = I a0 + v x* I v
-  auto rigid = [&](const T *Rl, const T *pl, T m, const T *com, const T *Ib, const T *vl, const T *al, T *Ic, T *fc) {
-    T cw[3];
-    mat3_mulv(Rl, com, cw);
-    cw[0] += pl[0];
-    cw[1] += pl[1];
-    cw[2] += pl[2];
-    T RI[9], Iw[9];
-    mat3_mul(Rl, Ib, RI);
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Iw[3 * r + c] = RI[3 * r] * Rl[3 * c] + RI[3 * r + 1] * Rl[3 * c + 1] + RI[3 * r + 2] * Rl[3 * c + 2];
-    const T c2 = dot3(cw, cw);
-    Ic[0] = Iw[0] + m * (c2 - cw[0] * cw[0]);
-    Ic[1] = T(0.5) * (Iw[1] + Iw[3]) - m * cw[0] * cw[1];
-    Ic[2] = T(0.5) * (Iw[2] + Iw[6]) - m * cw[0] * cw[2];
-    Ic[3] = Iw[4] + m * (c2 - cw[1] * cw[1]);
-    Ic[4] = T(0.5) * (Iw[5] + Iw[7]) - m * cw[1] * cw[2];
-    Ic[5] = Iw[8] + m * (c2 - cw[2] * cw[2]);
-    Ic[6] = m * cw[0];
-    Ic[7] = m * cw[1];
-    Ic[8] = m * cw[2];
-    Ic[9] = m;
-    const T *const h = Ic + 6;
-    T Iv[6], Ia[6], t3[3];
-    sym3_mulv(Ic, vl, Iv);
-    cross3(h, vl + 3, t3);
-    Iv[0] += t3[0];
-    Iv[1] += t3[1];
-    Iv[2] += t3[2];
-    cross3(h, vl, t3);
-    Iv[3] = m * vl[3] - t3[0];
-    Iv[4] = m * vl[4] - t3[1];
-    Iv[5] = m * vl[5] - t3[2];
-    sym3_mulv(Ic, al, Ia);
-    cross3(h, al + 3, t3);
-    Ia[0] += t3[0];
-    Ia[1] += t3[1];
-    Ia[2] += t3[2];
-    cross3(h, al, t3);
-    Ia[3] = m * al[3] - t3[0];
-    Ia[4] = m * al[4] - t3[1];
-    Ia[5] = m * al[5] - t3[2];
-    T u3[3];
-    cross3(vl, Iv, fc);
-    cross3(vl + 3, Iv + 3, u3);
-    fc[0] += u3[0];
-    fc[1] += u3[1];
-    fc[2] += u3[2];
-    cross3(vl, Iv + 3, fc + 3);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) fc[k] += Ia[k];
+  // the root body's frame and the root's revolute axes from the six sines / cosines (kinematics.hpp:64-97; tds_kernels.hip
+  // phase C: same formulas): R5, P, A4, A5 and the linear parts P x A of the three revolute axes (A3 = e_x)
+  auto root_frame = [&](T sx, T cx, T sy, T cy, T sz, T cz) {
+    R5[0] = cy * cz;                 R5[1] = -cy * sz;                R5[2] = sy;
+    R5[3] = sx * sy * cz + cx * sz;  R5[4] = cx * cz - sx * sy * sz;  R5[5] = -sx * cy;
+    R5[6] = sx * sz - cx * sy * cz;  R5[7] = cx * sy * sz + sx * cz;  R5[8] = cx * cy;
+    P[0] = xr[0] + CT[TB::SC + TB::BASE_T];
+    P[1] = xr[1] + CT[TB::SC + TB::BASE_T + 1];
+    P[2] = xr[2] + CT[TB::SC + TB::BASE_T + 2];
+    A4[0] = T(0); A4[1] = cx; A4[2] = sx;
+    A5[0] = sy; A5[1] = -sx * cy; A5[2] = cx * cy;
+    pA3[0] = T(0); pA3[1] = P[2]; pA3[2] = -P[1];  // P x e_x
+    cross3(P, A4, pA4);
+    cross3(P, A5, pA5);
   };
-  T Ic[10], fc[6];
-  rigid(R, p, CL[TB::MASS], CL + TB::COM, CL + TB::INER, v, a0, Ic, fc);
-  T It[10], ft[6];  // the root body's; below: + the legs' = the whole robot's
-  rigid(R5, P, CT[TB::ROOT + TB::R_MASS], CT + TB::ROOT + TB::R_COM, CT + TB::ROOT + TB::R_INER, v5, a5, It, ft);
-
-  // ---- E. composite inertia / bias force (CRBA, mass_matrix.hpp:39-56): the robot's totals = root + every leg link
-  //         (8-lane sums of the rigid values: every lane the same bits); the hip's composite = hip + ankle
-#pragma unroll
-  for (int k = 0; k < 10; ++k) It[k] += oct_sum(Ic[k]);
-#pragma unroll
-  for (int k = 0; k < 6; ++k) ft[k] += oct_sum(fc[k]);
-  {
-    const T recv = pos == 0 ? T(1) : T(0);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) fc[k] += recv * pair_bcast<1>(fc[k]);
-#pragma unroll
-    for (int k = 0; k < 10; ++k) Ic[k] += recv * pair_bcast<1>(Ic[k]);
-  }
-  // F = Ic s, C = s . f of my dof
   auto times_inertia = [&](const T *I, const T *s, T *F) {  // (I w + h x v, m v - h x w)
     T t3[3];
     sym3_mulv(I, s, F);
@@ -585,269 +285,732 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     F[5] = I[9] * s[5] - t3[2];
   };
   auto dot6 = [&](const T *a, const T *b) -> T { return dot3(a, b) + dot3(a + 3, b + 3); };
-  T Fc[6];
-  times_inertia(Ic, sw, Fc);
-  const T Cb = dot6(sw, fc);
-  // the root's revolute axes as (angular | linear); the prismatic ones are (0 | e_k)
-  const T ax3[6] = {T(1), T(0), T(0), pA3[0], pA3[1], pA3[2]}, ax4[6] = {A4[0], A4[1], A4[2], pA4[0], pA4[1], pA4[2]},
-          ax5[6] = {A5[0], A5[1], A5[2], pA5[0], pA5[1], pA5[2]};
-  T Cr[6];  // bias forces of the root dofs
-  Cr[0] = ft[3];
-  Cr[1] = ft[4];
-  Cr[2] = ft[5];
-  Cr[3] = dot6(ax3, ft);
-  Cr[4] = dot6(ax4, ft);
-  Cr[5] = dot6(ax5, ft);
 
-  // ---- G. M in leaves-first order.  My row of my leg's 2 x 2 block (M[i][j] = F_i . s_j for j an ancestor of i or i,
-  //         mass_matrix.hpp:87-109) and my coupling to the root dofs
-  T Bm0, Bm1, Cc[6];
-  {
-    T s0[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s0[k] = pair_bcast<0>(sw[k]);
-    Bm0 = dot6(Fc, s0);   // hip lane: M_hh; ankle lane: M_ah
-    Bm1 = dot6(Fc, sw);   // ankle lane: M_aa
-    Cc[0] = Fc[3];
-    Cc[1] = Fc[4];
-    Cc[2] = Fc[5];
-    Cc[3] = dot6(Fc, ax3);
-    Cc[4] = dot6(Fc, ax4);
-    Cc[5] = dot6(Fc, ax5);
-  }
-  // ---- H. LDL^T.  The leg block on both lanes of the pair
-  T l10, id0, id1;
-  {
-    const T b00 = pair_bcast<0>(Bm0);
-    const T b10 = pair_bcast<1>(Bm0), b11 = pair_bcast<1>(Bm1);
-    id0 = rcp_full<T>(b00);
-    l10 = b10 * id0;
-    id1 = rcp_full<T>(b11 - l10 * b10);
-  }
-  const T my_id = pos == 0 ? id0 : id1;
-  // the coupling rows: W_hip = C_hip, W_ankle = C_ankle - l10 W_hip;  L_c = W / d
-  T W[6], Lc[6];
-  {
-    const T m1 = pos == 1 ? l10 : T(0);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      W[r] = Cc[r] - m1 * pair_bcast<0>(Cc[r]);
-      Lc[r] = W[r] * my_id;
+  auto main_kin = [&]() {
+    // ================================ main: PD, jcalc, kinematics ================================
+    if constexpr (LOOP) {
+      // the action block of this step came in a step ago (see phase M); the next step's is requested now
+      if (ctl.act_pool != nullptr) {  // wave-uniform
+        if (it + 1 < nsteps && valid) {
+          const int blk = (ctl.act_first + it + 1) % ctl.act_blocks;
+          next_act = (T)oct_global((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
+        }
+      }
     }
-    T *const lcw = E + O.lcw + lane * OctLds::LCW;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      lcw[r] = Lc[r];
-      lcw[6 + r] = W[r];
+    q = xr[dq];
+    qd = xr[nq + dq];
+    // ---- PD controller (locomotion_contact_simulation.h:168-258); joint stiffness / damping
+    tau = T(0);
+    {
+      const int act_i = (int)CL[TB::ACT];
+      if (act_i >= 0) {
+        const int var = nq + nd + adim;
+        const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
+        const T act_lim = CT[TB::SC + TB::ACTION_LIMIT];
+        T a = xr[nq + nd + act_i];
+        a = a < act_lim ? a : act_lim;
+        a = a > -act_lim ? a : -act_lim;
+        const T q_des = CL[TB::IPOSE] + a;
+        T f = kp * (q_des - q) + kd * (T(0) - qd);
+        f = f > -max_force ? f : -max_force;
+        f = f < max_force ? f : max_force;
+        tau = f;
+      }
+      tau -= CL[TB::STIFF] * q + CL[TB::DAMP] * qd;
     }
-    if (pos == 0) {
-      T *const lf = E + O.legf + leg * 3;
-      lf[0] = l10;
-      lf[1] = sqrt_t<T>(id0);
-      lf[2] = sqrt_t<T>(id1);
+    // ---- B. jcalc (link.hpp:229-287)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Sl[k] = CL[TB::S + k];
+    T Rp[9], tp[3];
+    {
+      const int jt = (int)CL[TB::JT];
+      T RT[9], tT[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) RT[k] = CL[TB::XT + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tT[k] = CL[TB::XT + 9 + k];
+      T sn, cs;
+      sincos_t<T>(jt == TDS_JOINT_REVOLUTE_AXIS ? q * T(0.5) : q, &sn, &cs);
+      const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
+      const bool pris = jt >= TDS_JOINT_PRISMATIC_X && jt <= TDS_JOINT_PRISMATIC_AXIS;
+      T RJ[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+      T tJ[3] = {T(0), T(0), T(0)};
+      if (pris) {
+        tJ[0] = Sl[3] * q;
+        tJ[1] = Sl[4] * q;
+        tJ[2] = Sl[5] * q;
+      }
+      if (rev) {
+        if (jt == TDS_JOINT_REVOLUTE_X) {
+          RJ[4] = cs; RJ[5] = -sn; RJ[7] = sn; RJ[8] = cs;
+        } else if (jt == TDS_JOINT_REVOLUTE_Y) {
+          RJ[0] = cs; RJ[2] = sn; RJ[6] = -sn; RJ[8] = cs;
+        } else if (jt == TDS_JOINT_REVOLUTE_Z) {
+          RJ[0] = cs; RJ[1] = -sn; RJ[3] = sn; RJ[4] = cs;
+        } else {  // axis-angle quaternion with the UNNORMALISED axis (link.hpp:256-261)
+          const T d = sqrt_t<T>(Sl[0] * Sl[0] + Sl[1] * Sl[1] + Sl[2] * Sl[2]);
+          const T sh = sn / d;
+          const T qx = Sl[0] * sh, qy = Sl[1] * sh, qz = Sl[2] * sh, qw = cs;
+          const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+          const T xs_ = qx * s2, ys = qy * s2, zs = qz * s2;
+          const T wx = qw * xs_, wy = qw * ys, wz = qw * zs;
+          const T xx = qx * xs_, xy = qx * ys, xz = qx * zs;
+          const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
+          RJ[0] = T(1) - (yy + zz); RJ[1] = xy - wz; RJ[2] = xz + wy;
+          RJ[3] = xy + wz; RJ[4] = T(1) - (xx + zz); RJ[5] = yz - wx;
+          RJ[6] = xz - wy; RJ[7] = yz + wx; RJ[8] = T(1) - (xx + yy);
+        }
+      }
+      mat3_mul(RT, RJ, Rp);
+      T r[3];
+      mat3_mulv(RT, tJ, r);
+      tp[0] = tT[0] + r[0];
+      tp[1] = tT[1] + r[1];
+      tp[2] = tT[2] + r[2];
     }
-  }
-  OCT_SYNC();
-  // the sums sum_lanes L_c[r] W[r'] of the Schur complement, entry e = r (r + 1) / 2 + r' on lane e mod 8 (three passes)
-  {
-    const T *const lcw = E + O.lcw;
-    T *const Ssum = E + O.S;
-#pragma unroll
-    for (int pass = 0; pass < 3; ++pass) {
-      int e = lane + 8 * pass;
-      e = e < 21 ? e : 20;
-      int r = 0;
-#pragma unroll
-      for (int k = 1; k < 6; ++k) r += e >= (k * (k + 1)) / 2 ? 1 : 0;
-      const int rp = e - (r * (r + 1)) / 2;
-      T acc = T(0);
-#pragma unroll
-      for (int l = 0; l < 8; ++l) acc += lcw[l * OctLds::LCW + r] * lcw[l * OctLds::LCW + 6 + rp];
-      Ssum[e] = acc;
+    // ---- C. the root chain in closed form, on every lane.  The three root angles' sines and cosines: lanes 0, 1, 2 of the
+    //         environment, broadcast (and, two-wavefront build, handed to the helper: the slots of the first impulses)
+    {
+      T rs, rc;
+      sincos_t<T>(xr[3 + (lane < 3 ? lane : 0)], &rs, &rc);
+      const T sx = oct_bcast<0>(rs), cx = oct_bcast<0>(rc);
+      const T sy = oct_bcast<1>(rs), cy = oct_bcast<1>(rc);
+      const T sz = oct_bcast<2>(rs), cz = oct_bcast<2>(rc);
+      if constexpr (W2) {
+        if (lane < 3) {
+          E[O.xs + 2 * lane] = rs;
+          E[O.xs + 2 * lane + 1] = rc;
+        }
+      }
+      root_frame(sx, cx, sy, cy, sz, cz);
     }
-  }
-  // the root block R[r][r'] = s_r . (It s_r') in registers (packed lower triangle, r (r + 1) / 2 + r'): the prismatic
-  // axes are unit vectors, It e_k = (h x e_k | m e_k)
-  T Sm[21];
-  {
-    const T *const h = It + 6;
-    const T m = It[9];
-    T F3[6], F4[6], F5[6];
-    times_inertia(It, ax3, F3);
-    times_inertia(It, ax4, F4);
-    times_inertia(It, ax5, F5);
-    Sm[0] = m;
-    Sm[1] = T(0); Sm[2] = m;
-    Sm[3] = T(0); Sm[4] = T(0); Sm[5] = m;
-    Sm[6] = F3[3]; Sm[7] = F3[4]; Sm[8] = F3[5]; Sm[9] = dot6(ax3, F3);
-    Sm[10] = F4[3]; Sm[11] = F4[4]; Sm[12] = F4[5]; Sm[13] = dot6(ax4, F3); Sm[14] = dot6(ax4, F4);
-    Sm[15] = F5[3]; Sm[16] = F5[4]; Sm[17] = F5[5]; Sm[18] = dot6(ax5, F3); Sm[19] = dot6(ax5, F4); Sm[20] = dot6(ax5, F5);
-    (void)h;
-  }
-  OCT_SYNC();
-  // ... the Schur complement, factorised redundantly on every lane: Ls (strictly lower, row-major packed), 1 / D
-  T Ls[15], ids[6], sq_ids[6];
-  {
-    const T *const Ssum = E + O.S;
+    {
+      const T d0 = xr[nq + 0], d1 = xr[nq + 1], d2 = xr[nq + 2], d3 = xr[nq + 3], d4 = xr[nq + 4], d5 = xr[nq + 5];
+      const T U[3] = {d0, d1, d2};
+      const T J3[3] = {d3, T(0), T(0)}, J4[3] = {A4[0] * d4, A4[1] * d4, A4[2] * d4}, J5[3] = {A5[0] * d5, A5[1] * d5, A5[2] * d5};
+      const T W4[3] = {J3[0] + J4[0], J3[1] + J4[1], J3[2] + J4[2]};
+      const T W5[3] = {W4[0] + J5[0], W4[1] + J5[1], W4[2] + J5[2]};
+      T pJ3[3], pJ4[3], pJ5[3];
+      cross3(P, J3, pJ3);
+      cross3(P, J4, pJ4);
+      cross3(P, J5, pJ5);
+      const T pW4[3] = {pJ3[0] + pJ4[0], pJ3[1] + pJ4[1], pJ3[2] + pJ4[2]};
+      const T pW5[3] = {pW4[0] + pJ5[0], pW4[1] + pJ5[1], pW4[2] + pJ5[2]};
+      const T V3[3] = {U[0] + pJ3[0], U[1] + pJ3[1], U[2] + pJ3[2]};
+      const T V4[3] = {U[0] + pW4[0], U[1] + pW4[1], U[2] + pW4[2]};
+      const T V5[3] = {U[0] + pW5[0], U[1] + pW5[1], U[2] + pW5[2]};
+      T a45[3], a55[3], t1[3], t2[3], l3[3], l4[3], l5[3];
+      cross3(J3, J4, a45);
+      cross3(W4, J5, a55);
+      cross3(J3, pJ3, t1);
+      cross3(V3, J3, t2);
+      l3[0] = t1[0] + t2[0]; l3[1] = t1[1] + t2[1]; l3[2] = t1[2] + t2[2];
+      cross3(W4, pJ4, t1);
+      cross3(V4, J4, t2);
+      l4[0] = t1[0] + t2[0]; l4[1] = t1[1] + t2[1]; l4[2] = t1[2] + t2[2];
+      cross3(W5, pJ5, t1);
+      cross3(V5, J5, t2);
+      l5[0] = t1[0] + t2[0]; l5[1] = t1[1] + t2[1]; l5[2] = t1[2] + t2[2];
 #pragma unroll
-    for (int e = 0; e < 21; ++e) Sm[e] -= Ssum[e];
-    static_for<0, 6>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      const T inv = rcp_full<T>(Sm[(k * (k + 1)) / 2 + k]);
-      ids[k] = inv;
-      T col[6];
-      static_for<k + 1, 6>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        col[r] = Sm[(r * (r + 1)) / 2 + k];           // S(r, k) before scaling
-        Ls[(r * (r - 1)) / 2 + k] = col[r] * inv;     // L(r, k)
-      });
-      static_for<k + 1, 6>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        static_for<k + 1, r + 1>([&](auto cc) {
-          constexpr int c = decltype(cc)::value;
-          Sm[(r * (r + 1)) / 2 + c] -= Ls[(r * (r - 1)) / 2 + k] * col[c];
+      for (int k = 0; k < 3; ++k) {
+        v5[k] = W5[k];
+        v5[3 + k] = V5[k];
+        a5[k] = a45[k] + a55[k];
+        a5[3 + k] = (l3[k] + l4[k] + l5[k]) - CT[TB::SC + TB::GRAV + k];
+      }
+    }
+    // ---- the legs: the ankle composes its joint transform with the hip's (one step of a segmented scan along the pair),
+    //      the root's pose in front; prefix sums of the joint velocities and of the velocity-product accelerations
+    {
+      const bool take = pos == 1;
+      T Rq[9], pq[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const T sh = pair_bcast<0>(Rp[k]);
+        Rq[k] = take ? sh : ((k == 0 || k == 4 || k == 8) ? T(1) : T(0));
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const T sh = pair_bcast<0>(tp[k]);
+        pq[k] = take ? sh : T(0);
+      }
+      T Rl[9], pl[3], r[3];
+      mat3_mul(Rq, Rp, Rl);
+      mat3_mulv(Rq, tp, r);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pl[k] = pq[k] + r[k];
+      mat3_mul(R5, Rl, R);
+      mat3_mulv(R5, pl, r);
+      p[0] = P[0] + r[0];
+      p[1] = P[1] + r[1];
+      p[2] = P[2] + r[2];
+      // s = X_world.apply_inverse(S) = (R w, R v + p x (R w))   (transform.hpp:232-243)
+      mat3_mulv(R, Sl, sw);
+      mat3_mulv(R, Sl + 3, sw + 3);
+      T c[3];
+      cross3(p, sw, c);
+      sw[3] += c[0];
+      sw[4] += c[1];
+      sw[5] += c[2];
+      T vJ[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vJ[k] = sw[k] * qd;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const T sh = pair_bcast<0>(vJ[k]);
+        v[k] = v5[k] + (vJ[k] + (take ? sh : T(0)));
+      }
+      // cb = v x vJ (kinematics.hpp:96-99)
+      T cb[6];
+      cross3(v, vJ, cb);
+      T c1[3], c2[3];
+      cross3(v, vJ + 3, c1);
+      cross3(v + 3, vJ, c2);
+      cb[3] = c1[0] + c2[0];
+      cb[4] = c1[1] + c2[1];
+      cb[5] = c1[2] + c2[2];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const T sh = pair_bcast<0>(cb[k]);
+        a0[k] = a5[k] + (cb[k] + (take ? sh : T(0)));
+      }
+    }
+    // my world motion axis, for the rows of the contacts (lane-dependent reads in the row windows); two-wavefront build: my
+    // link's world transform for the helper's narrowphase and visual poses (the slots of the second row window)
+    {
+      T *const swl = E + O.swl + lane * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) swl[k] = sw[k];
+      if constexpr (W2) {
+        T *const kin = E + O.win + 8 * OctLds::ZW + lane * 12;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) kin[k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) kin[9 + k] = p[k];
+      }
+    }
+    OCT_STAMP(1, sw[5]);
+  };
+
+  // where this step's y record goes: the slot of a y ring (every step of a step-loop launch), else the handle's y record
+  // (the last step); the last step of a ring launch leaves its record in the handle's y record as well
+  const int ystr = ctl.y_stride;
+  const int out_dim = (int)CT[TB::SC + TB::OUTPUT_DIM];
+  const int nv = (int)CT[TB::SC + TB::NUM_VISUALS];
+  TR *yo = nullptr, *yo2 = nullptr;
+  int yend = ystr, yend2 = out_dim;
+  if (LOOP && ctl.y_ring != nullptr) {
+    yo = oct_global((TR *)ctl.y_ring) + ((size_t)((ctl.y_first + it) % ctl.y_slots) * ctl.ring_envs + env) * ystr;
+    if (last && y_out != nullptr) yo2 = y_out + (size_t)env * out_dim;
+  } else if (last && y_out != nullptr) {
+    yo = y_out + (size_t)env * (LOOP ? out_dim : ystr);
+    yend = LOOP ? out_dim : ystr;
+  }
+  // ---- exchange launches of the multi-GPU layer (tds_shard.hip): the records of a step are counted in on the slot's progress
+  //      counter (RCCL forms), or on its arrival counters with the flags of every rank raised by the workgroup that
+  //      completes the slot (peer-store exchange; see tds_kernels.hip: peer_signal)
+  auto signal_slot = [&](int pslot) {
+    if (ctl.peer_arrive != nullptr) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): every store of this wavefront acknowledged by the memory it went to
+      const bool rel = (ctl.ring_flags & TDS_RING_PEER_RELEASE) != 0;  // (A/B switch for the first run on a fabric: tds_kernels.h)
+      if (rel) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      if ((tid & 63) == 0) {
+        constexpr unsigned SUB = TDS_PEER_SUB;
+        const unsigned g = gridDim.x, j = blockIdx.x % SUB;
+        const unsigned n1 = (g - j + SUB - 1u) / SUB;  // workgroups that count on first-level counter j
+        const unsigned n2 = g < SUB ? g : SUB;          // first-level counters in use
+        unsigned *const base = oct_global(ctl.peer_arrive) + (size_t)pslot * TDS_PEER_ARRIVE_STRIDE;
+        if (atomicInc(base + j * TDS_PEER_LINE, n1 - 1u) == n1 - 1u) {
+          if (atomicInc(base + 32 * TDS_PEER_LINE, n2 - 1u) == n2 - 1u) {
+            const size_t fi = (size_t)ctl.peer_flag_off + (size_t)pslot * (size_t)ctl.peer_flag_stride;
+            if (rel) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+            for (int pr = 0; pr <= ctl.n_peers; ++pr)
+              __hip_atomic_store(ctl.peer_flags[pr] + fi, ctl.peer_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+      }
+    } else if (ctl.progress != nullptr) {
+      if (ctl.ring_flags & TDS_RING_NOFENCE) __builtin_amdgcn_s_waitcnt(0x0f70);  // (write-through record stores)
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if ((tid & 63) == 0) __hip_atomic_fetch_add(oct_global(ctl.progress) + pslot, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+
+  auto help_np = [&]() {
+    // ================================ helper: narrowphase, visual poses ================================
+    if constexpr (W2) {  // my link's world transform and the root's sines / cosines, from the main wavefront
+      const T *const kin = E + O.win + 8 * OctLds::ZW + lane * 12;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = kin[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p[k] = kin[9 + k];
+      const T *const sc = E + O.xs;
+      root_frame(sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]);
+    }
+    // ---- I. narrowphase (contact_point.hpp:96-161): my link's capsule = two spheres; the root body's sphere on every lane.
+    //         Penetrating points in the reference's order (root, then per link +L/2 end, -L/2 end) into the contact list
+    {
+      T *const cpx = E + O.cp;
+      const T n[3] = {CT[TB::SC + TB::PLANE_N], CT[TB::SC + TB::PLANE_N + 1], CT[TB::SC + TB::PLANE_N + 2]};
+      const T pc = CT[TB::SC + TB::PLANE_C];
+      auto sphere = [&](const T *Rl, const T *pl, const T *loc, T rad, T *pt, T &dist) {
+        T ctr[3];
+        mat3_mulv(Rl, loc, ctr);
+        ctr[0] += pl[0];
+        ctr[1] += pl[1];
+        ctr[2] += pl[2];
+        const T t = -((-dot3(ctr, n)) + pc);
+        dist = t - rad;
+        pt[0] = ctr[0] - rad * n[0];
+        pt[1] = ctr[1] - rad * n[1];
+        pt[2] = ctr[2] - rad * n[2];
+      };
+      T pt0[3], pt1[3], ptt[3], d0, d1, dtt;
+      sphere(R, p, CL + TB::CPL0, CL[TB::CPR0], pt0, d0);
+      sphere(R, p, CL + TB::CPL1, CL[TB::CPR1], pt1, d1);
+      sphere(R5, P, CT + TB::ROOT + TB::R_CPL, CT[TB::ROOT + TB::R_CPR], ptt, dtt);
+      const bool act0 = valid && d0 < T(0), act1 = valid && d1 < T(0), actt = valid && dtt < T(0) && CT[TB::ROOT + TB::R_CPR] >= T(0);
+      const unsigned long long b0 = __ballot(act0), b1 = __ballot(act1), bt = __ballot(actt);
+      const unsigned m0 = (unsigned)((b0 >> (grp * 8)) & 0xFFull), m1 = (unsigned)((b1 >> (grp * 8)) & 0xFFull);
+      const unsigned below = (1u << lane) - 1u;
+      const int r0 = (actt ? 1 : 0) + __popc(m0 & below) + __popc(m1 & below);
+      const int r1 = r0 + (act0 ? 1 : 0);
+      if (act0) {
+        cpx[0 * OctLds::NCP + r0] = pt0[0];
+        cpx[1 * OctLds::NCP + r0] = pt0[1];
+        cpx[2 * OctLds::NCP + r0] = pt0[2];
+        cpx[3 * OctLds::NCP + r0] = d0;
+        cpx[4 * OctLds::NCP + r0] = (T)lane;
+      }
+      if (act1) {
+        cpx[0 * OctLds::NCP + r1] = pt1[0];
+        cpx[1 * OctLds::NCP + r1] = pt1[1];
+        cpx[2 * OctLds::NCP + r1] = pt1[2];
+        cpx[3 * OctLds::NCP + r1] = d1;
+        cpx[4 * OctLds::NCP + r1] = (T)lane;
+      }
+      if (actt && lane == 0) {
+        cpx[0 * OctLds::NCP] = ptt[0];
+        cpx[1 * OctLds::NCP] = ptt[1];
+        cpx[2 * OctLds::NCP] = ptt[2];
+        cpx[3 * OctLds::NCP] = dtt;
+        cpx[4 * OctLds::NCP] = T(8);
+      }
+      na = (actt ? 1 : 0) + __popc(m0) + __popc(m1);
+      // the largest count among the wavefront's environments (scalar arithmetic on the three ballots)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int c = __popc((unsigned)((b0 >> (g * 8)) & 0xFFull)) + __popc((unsigned)((b1 >> (g * 8)) & 0xFFull)) + (int)((bt >> (g * 8)) & 1ull);
+        NA = c > NA ? c : NA;
+      }
+      if constexpr (W2) {
+        if ((tid & 63) == 0) sm[in_dim + 3] = (T)NA;  // (for the main wavefront: the spare slot of environment 0's record)
+      }
+    }
+    OCT_STAMP(8, na);
+    if constexpr (LOOP) {
+      // the records of step it - 1 — stored at the end of the iteration before, long acknowledged by now: the wait costs
+      // nothing here, in front of this step's first stores — are counted in
+      if (it > 0 && ctl.obs_ring != nullptr) signal_slot((ctl.obs_first + it - 1) % ctl.obs_slots);  // (wave-uniform)
+    }
+    // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
+    //          my link's (DevModel::oct checks the order); visual 0 — the root body's — goes out on lane 7
+    if (valid && yo != nullptr && nv > 0) {
+      auto pose_out = [&](const T *Rl, const T *pl, const T *vx, int k) {
+        T Ro[9], po[3], qo[4];
+        mat3_mul(Rl, vx, Ro);
+        mat3_mulv(Rl, vx + 9, po);
+        matrix_to_quat(Ro, qo);
+        TR *o = yo + (nq + nd) + 7 * k;
+        o[0] = (TR)(pl[0] + po[0]);
+        o[1] = (TR)(pl[1] + po[1]);
+        o[2] = (TR)(pl[2] + po[2]);
+        o[3] = (TR)qo[0];
+        o[4] = (TR)qo[1];
+        o[5] = (TR)qo[2];
+        o[6] = (TR)qo[3];
+        if (yo2 != nullptr) {
+          TR *o2 = yo2 + (nq + nd) + 7 * k;
+          o2[0] = (TR)(pl[0] + po[0]);
+          o2[1] = (TR)(pl[1] + po[1]);
+          o2[2] = (TR)(pl[2] + po[2]);
+          o2[3] = (TR)qo[0];
+          o2[4] = (TR)qo[1];
+          o2[5] = (TR)qo[2];
+          o2[6] = (TR)qo[3];
+        }
+      };
+      pose_out(R, p, CL + TB::VIS, 1 + lane);
+      if (lane == 7) pose_out(R5, P, CT + TB::ROOT + TB::R_VIS, 0);
+    }
+    OCT_STAMP(9, na);
+  };
+
+  auto main_dyn = [&]() {
+    // ================================ main: inertias, LDL^T, forward dynamics ================================
+    // ---- D. world-frame rigid inertia and bias force of my link, and (redundantly on every lane) of the root body
+    //         (kinematics.hpp:96-132, inertia.hpp:121-130): I = (Isym 6 | h 3 | m), f = I a0 + v x* I v
+    auto rigid = [&](const T *Rl, const T *pl, T m, const T *com, const T *Ib, const T *vl, const T *al, T *Ic, T *fc) {
+      T cw[3];
+      mat3_mulv(Rl, com, cw);
+      cw[0] += pl[0];
+      cw[1] += pl[1];
+      cw[2] += pl[2];
+      T RI[9], Iw[9];
+      mat3_mul(Rl, Ib, RI);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Iw[3 * r + c] = RI[3 * r] * Rl[3 * c] + RI[3 * r + 1] * Rl[3 * c + 1] + RI[3 * r + 2] * Rl[3 * c + 2];
+      const T c2 = dot3(cw, cw);
+      Ic[0] = Iw[0] + m * (c2 - cw[0] * cw[0]);
+      Ic[1] = T(0.5) * (Iw[1] + Iw[3]) - m * cw[0] * cw[1];
+      Ic[2] = T(0.5) * (Iw[2] + Iw[6]) - m * cw[0] * cw[2];
+      Ic[3] = Iw[4] + m * (c2 - cw[1] * cw[1]);
+      Ic[4] = T(0.5) * (Iw[5] + Iw[7]) - m * cw[1] * cw[2];
+      Ic[5] = Iw[8] + m * (c2 - cw[2] * cw[2]);
+      Ic[6] = m * cw[0];
+      Ic[7] = m * cw[1];
+      Ic[8] = m * cw[2];
+      Ic[9] = m;
+      const T *const h = Ic + 6;
+      T Iv[6], Ia[6], t3[3];
+      sym3_mulv(Ic, vl, Iv);
+      cross3(h, vl + 3, t3);
+      Iv[0] += t3[0];
+      Iv[1] += t3[1];
+      Iv[2] += t3[2];
+      cross3(h, vl, t3);
+      Iv[3] = m * vl[3] - t3[0];
+      Iv[4] = m * vl[4] - t3[1];
+      Iv[5] = m * vl[5] - t3[2];
+      sym3_mulv(Ic, al, Ia);
+      cross3(h, al + 3, t3);
+      Ia[0] += t3[0];
+      Ia[1] += t3[1];
+      Ia[2] += t3[2];
+      cross3(h, al, t3);
+      Ia[3] = m * al[3] - t3[0];
+      Ia[4] = m * al[4] - t3[1];
+      Ia[5] = m * al[5] - t3[2];
+      T u3[3];
+      cross3(vl, Iv, fc);
+      cross3(vl + 3, Iv + 3, u3);
+      fc[0] += u3[0];
+      fc[1] += u3[1];
+      fc[2] += u3[2];
+      cross3(vl, Iv + 3, fc + 3);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fc[k] += Ia[k];
+    };
+    T Ic[10], fc[6];
+    rigid(R, p, CL[TB::MASS], CL + TB::COM, CL + TB::INER, v, a0, Ic, fc);
+    T It[10], ft[6];  // the root body's; below: + the legs' = the whole robot's
+    rigid(R5, P, CT[TB::ROOT + TB::R_MASS], CT + TB::ROOT + TB::R_COM, CT + TB::ROOT + TB::R_INER, v5, a5, It, ft);
+    OCT_STAMP(2, ft[5]);
+    // ---- E. composite inertia / bias force (CRBA, mass_matrix.hpp:39-56): the robot's totals = root + every leg link
+    //         (8-lane sums of the rigid values: every lane the same bits); the hip's composite = hip + ankle
+#pragma unroll
+    for (int k = 0; k < 10; ++k) It[k] += oct_sum(Ic[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ft[k] += oct_sum(fc[k]);
+    {
+      const T recv = pos == 0 ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fc[k] += recv * pair_bcast<1>(fc[k]);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) Ic[k] += recv * pair_bcast<1>(Ic[k]);
+    }
+    // F = Ic s, C = s . f of my dof
+    T Fc[6];
+    times_inertia(Ic, sw, Fc);
+    const T Cb = dot6(sw, fc);
+    // the root's revolute axes as (angular | linear); the prismatic ones are (0 | e_k)
+    const T ax3[6] = {T(1), T(0), T(0), pA3[0], pA3[1], pA3[2]}, ax4[6] = {A4[0], A4[1], A4[2], pA4[0], pA4[1], pA4[2]},
+            ax5[6] = {A5[0], A5[1], A5[2], pA5[0], pA5[1], pA5[2]};
+    T Cr[6];  // bias forces of the root dofs
+    Cr[0] = ft[3];
+    Cr[1] = ft[4];
+    Cr[2] = ft[5];
+    Cr[3] = dot6(ax3, ft);
+    Cr[4] = dot6(ax4, ft);
+    Cr[5] = dot6(ax5, ft);
+    // ---- G. M in leaves-first order.  My row of my leg's 2 x 2 block (M[i][j] = F_i . s_j for j an ancestor of i or i,
+    //         mass_matrix.hpp:87-109) and my coupling to the root dofs
+    T Bm0, Bm1, Cc[6];
+    {
+      T s0[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s0[k] = pair_bcast<0>(sw[k]);
+      Bm0 = dot6(Fc, s0);   // hip lane: M_hh; ankle lane: M_ah
+      Bm1 = dot6(Fc, sw);   // ankle lane: M_aa
+      Cc[0] = Fc[3];
+      Cc[1] = Fc[4];
+      Cc[2] = Fc[5];
+      Cc[3] = dot6(Fc, ax3);
+      Cc[4] = dot6(Fc, ax4);
+      Cc[5] = dot6(Fc, ax5);
+    }
+    // ---- H. LDL^T.  The leg block on both lanes of the pair
+    {
+      const T b00 = pair_bcast<0>(Bm0);
+      const T b10 = pair_bcast<1>(Bm0), b11 = pair_bcast<1>(Bm1);
+      id0 = rcp_full<T>(b00);
+      l10 = b10 * id0;
+      id1 = rcp_full<T>(b11 - l10 * b10);
+    }
+    my_id = pos == 0 ? id0 : id1;
+    // the coupling rows: W_hip = C_hip, W_ankle = C_ankle - l10 W_hip;  L_c = W / d
+    {
+      T W[6];
+      const T m1 = pos == 1 ? l10 : T(0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        W[r] = Cc[r] - m1 * pair_bcast<0>(Cc[r]);
+        Lc[r] = W[r] * my_id;
+      }
+      T *const lcw = E + O.lcw + lane * OctLds::LCW;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        lcw[r] = Lc[r];
+        lcw[6 + r] = W[r];
+      }
+      if (pos == 0) {
+        T *const lf = E + O.legf + leg * 3;
+        lf[0] = l10;
+        lf[1] = sqrt_t<T>(id0);
+        lf[2] = sqrt_t<T>(id1);
+      }
+    }
+    OCT_SYNC();
+    OCT_STAMP(3, Lc[5]);
+    // the sums sum_lanes L_c[r] W[r'] of the Schur complement, entry e = r (r + 1) / 2 + r' on lane e mod 8 (three passes)
+    {
+      const T *const lcw = E + O.lcw;
+      T *const Ssum = E + O.fac;
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+        int e = lane + 8 * pass;
+        e = e < 21 ? e : 20;
+        int r = 0;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) r += e >= (k * (k + 1)) / 2 ? 1 : 0;
+        const int rp = e - (r * (r + 1)) / 2;
+        T acc = T(0);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc += lcw[l * OctLds::LCW + r] * lcw[l * OctLds::LCW + 6 + rp];
+        Ssum[e] = acc;
+      }
+    }
+    // the root block R[r][r'] = s_r . (It s_r') in registers (packed lower triangle, r (r + 1) / 2 + r'): the prismatic
+    // axes are unit vectors, It e_k = (h x e_k | m e_k)
+    T Sm[21];
+    {
+      const T m = It[9];
+      T F3[6], F4[6], F5[6];
+      times_inertia(It, ax3, F3);
+      times_inertia(It, ax4, F4);
+      times_inertia(It, ax5, F5);
+      Sm[0] = m;
+      Sm[1] = T(0); Sm[2] = m;
+      Sm[3] = T(0); Sm[4] = T(0); Sm[5] = m;
+      Sm[6] = F3[3]; Sm[7] = F3[4]; Sm[8] = F3[5]; Sm[9] = dot6(ax3, F3);
+      Sm[10] = F4[3]; Sm[11] = F4[4]; Sm[12] = F4[5]; Sm[13] = dot6(ax4, F3); Sm[14] = dot6(ax4, F4);
+      Sm[15] = F5[3]; Sm[16] = F5[4]; Sm[17] = F5[5]; Sm[18] = dot6(ax5, F3); Sm[19] = dot6(ax5, F4); Sm[20] = dot6(ax5, F5);
+    }
+    OCT_SYNC();
+    // ... the Schur complement, factorised redundantly on every lane: Ls (strictly lower, row-major packed), 1 / D
+    {
+      const T *const Ssum = E + O.fac;
+#pragma unroll
+      for (int e = 0; e < 21; ++e) Sm[e] -= Ssum[e];
+      static_for<0, 6>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const T inv = rcp_full<T>(Sm[(k * (k + 1)) / 2 + k]);
+        ids[k] = inv;
+        T col[6];
+        static_for<k + 1, 6>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          col[r] = Sm[(r * (r + 1)) / 2 + k];           // S(r, k) before scaling
+          Ls[(r * (r - 1)) / 2 + k] = col[r] * inv;     // L(r, k)
+        });
+        static_for<k + 1, 6>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          static_for<k + 1, r + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            Sm[(r * (r + 1)) / 2 + c] -= Ls[(r * (r - 1)) / 2 + k] * col[c];
+          });
         });
       });
-    });
 #pragma unroll
-    for (int r = 0; r < 6; ++r) sq_ids[r] = sqrt_t<T>(ids[r]);
-  }
-
-  // ---- F. forward dynamics qdd = M^-1 (tau - C), integrate_euler_qdd (integrator.hpp:169-181)
-  //   leaves-first system  [B  C^T; C  R] = L D L^T,  unknown (x_leg on the dof lanes, x_root[6] on every lane)
-  T qd_new, qdr_new[6];
-  {
-    // forward: legs, pair-local
-    T y = tau - Cb;
-    y -= (pos == 1 ? l10 : T(0)) * pair_bcast<0>(y);
-    // root: y_r = b_r - sum_lanes L_c[r] y, then the root block's own forward substitution
-    T yr[6];
+      for (int r = 0; r < 6; ++r) sq_ids[r] = sqrt_t<T>(ids[r]);
+    }
+    OCT_STAMP(4, Ls[14]);
+    // ---- F. forward dynamics qdd = M^-1 (tau - C), integrate_euler_qdd (integrator.hpp:169-181)
+    //   leaves-first system  [B  C^T; C  R] = L D L^T,  unknown (x_leg on the dof lanes, x_root[6] on every lane)
+    {
+      // forward: legs, pair-local
+      T y = tau - Cb;
+      y -= (pos == 1 ? l10 : T(0)) * pair_bcast<0>(y);
+      // root: y_r = b_r - sum_lanes L_c[r] y, then the root block's own forward substitution
+      T yr[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) yr[r] = -Cr[r] - oct_sum(Lc[r] * y);
-    static_for<1, 6>([&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      static_for<0, r>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        yr[r] -= Ls[(r * (r - 1)) / 2 + c] * yr[c];
+      for (int r = 0; r < 6; ++r) yr[r] = -Cr[r] - oct_sum(Lc[r] * y);
+      static_for<1, 6>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        static_for<0, r>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          yr[r] -= Ls[(r * (r - 1)) / 2 + c] * yr[c];
+        });
       });
-    });
-    // diagonal, backward: root first
-    T xrt[6];
+      // diagonal, backward: root first
+      T xrt[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) xrt[r] = yr[r] * ids[r];
-    static_for<0, 5>([&](auto ic) {
-      constexpr int r = 4 - decltype(ic)::value;
-      static_for<r + 1, 6>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        xrt[r] -= Ls[(c * (c - 1)) / 2 + r] * xrt[c];
+      for (int r = 0; r < 6; ++r) xrt[r] = yr[r] * ids[r];
+      static_for<0, 5>([&](auto ic) {
+        constexpr int r = 4 - decltype(ic)::value;
+        static_for<r + 1, 6>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          xrt[r] -= Ls[(c * (c - 1)) / 2 + r] * xrt[c];
+        });
       });
-    });
-    // legs: x = y / d - L_c . x_root - l10 x_ankle (hip)
-    T x = y * my_id;
+      // legs: x = y / d - L_c . x_root - l10 x_ankle (hip)
+      T x = y * my_id;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) x -= Lc[r] * xrt[r];
-    x -= (pos == 0 ? l10 : T(0)) * pair_bcast<1>(x);
-    qd_new = qd + x * dt;
+      for (int r = 0; r < 6; ++r) x -= Lc[r] * xrt[r];
+      x -= (pos == 0 ? l10 : T(0)) * pair_bcast<1>(x);
+      qd_new = qd + x * dt;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) qdr_new[r] = xr[nq + r] + xrt[r] * dt;
-  }
+      for (int r = 0; r < 6; ++r) qdr_new[r] = xr[nq + r] + xrt[r] * dt;
+    }
+    // for the rows of the contacts: the velocities after integrate_euler_qdd; two-wavefront build: + the root block's factors
+    E[O.qdp + lane] = qd_new;
+    if constexpr (W2) {
+      T *const fac = E + O.fac;  // (the Schur sums are dead: every lane has read them)
+      OCT_SYNC();
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) fac[k] = Ls[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          fac[15 + k] = sq_ids[k];
+          fac[21 + k] = qdr_new[k];
+        }
+      }
+    }
+    OCT_STAMP(5, qd_new);
+  };
+  // (two-wavefront build, behind barrier (2)) the largest contact count for the main wavefront, the root block's factors for the helper
+  auto main_get_count = [&]() { NA = __builtin_amdgcn_readfirstlane((int)sm[in_dim + 3]); };
+  auto help_get_factors = [&]() {
+    const T *const fac = E + O.fac;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) Ls[k] = fac[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      sq_ids[k] = fac[15 + k];
+      qdr_new[k] = fac[21 + k];
+    }
+  };
 
   // ---- J, K, L. contacts (wave-uniform: NA = the largest count among the wavefront's environments).  The sweep's order is
   //      the reference's: rows 0 .. NA-1 normals, NA .. 2NA-1 tangents 1, 2NA .. 3NA-1 tangents 2, each by contact (an
   //      environment with fewer contacts has zero rows in its empty slots).  Rows are solved a WINDOW of eight sweep
-  //      positions at a time — lane == row — and consumed by the sweep before the next window is solved.
-  if (NA > 0) {
-    T *const qdp = E + O.qdp;
-    qdp[lane] = qd_new;
-    OCT_SYNC();
-    const T *const cpx = E + O.cp;
-    const T *const swl = E + O.swl;
-    const T *const lcw = E + O.lcw;
-    T *const Zs = E + O.Z;
-    T *const xs = E + O.xs;
-    const int nr = 3 * NA;
-    const T nb[3] = {CT[TB::SC + TB::NB], CT[TB::SC + TB::NB + 1], CT[TB::SC + TB::NB + 2]};
-    const T t1v[3] = {CT[TB::SC + TB::T1], CT[TB::SC + TB::T1 + 1], CT[TB::SC + TB::T1 + 2]};
-    const T t2v[3] = {CT[TB::SC + TB::T2], CT[TB::SC + TB::T2 + 1], CT[TB::SC + TB::T2 + 2]};
-    const T cfm = CT[TB::SC + TB::CFM], erp_dt = CT[TB::SC + TB::ERP_OVER_DT], rest = CT[TB::SC + TB::RESTITUTION], mu = CT[TB::SC + TB::FRICTION];
-    // projected Gauss-Seidel on u~ = sum_r z~_r x_r: the leg part on the dof lanes, the root part on every lane
-    T u = T(0), ur[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-    const int iters = (int)CT[TB::SC + TB::PGS_ITERATIONS];
-    const T my_lane = (T)lane, my_hip = (T)(lane & ~1);
-    for (int pit = 0; pit < iters; ++pit) {
-      for (int w0 = 0; w0 < nr; w0 += 8) {
-        {
-          // ---- the window's rows: lane == sweep position w0 + lane
-          const int s = w0 + lane;
-          const int tk = (s >= NA ? 1 : 0) + (s >= 2 * NA ? 1 : 0);
-          const int a = s - tk * NA;
-          const bool real = s < nr && a < na;
-          const int ac = real ? a : 0;
-          const T Pc[3] = {cpx[0 * OctLds::NCP + ac], cpx[1 * OctLds::NCP + ac], cpx[2 * OctLds::NCP + ac]};
-          const T dist = cpx[3 * OctLds::NCP + ac];
-          const int ol = real ? (int)cpx[4 * OctLds::NCP + ac] : 8;  // owner lane; 8: the root body
-          const bool on_leg = ol < 8;
-          const int hl = on_leg ? (ol & ~1) : 0;   // the hip lane of the contact's leg
-          const bool ank = on_leg && (ol & 1);     // the contact sits on the ankle link: both dofs of the leg
-          const T e[3] = {tk == 0 ? nb[0] : (tk == 1 ? t1v[0] : t2v[0]), tk == 0 ? nb[1] : (tk == 1 ? t1v[1] : t2v[1]),
-                          tk == 0 ? nb[2] : (tk == 1 ? t1v[2] : t2v[2])};
-          // column of the point Jacobian along e: e . s_lin + P . (e x s_ang) = e . s_lin + (P x e) . s_ang  (jacobian.hpp:56-72)
-          T mo[3];
-          cross3(Pc, e, mo);
-          T sh[6], sa[6];
+  //      positions at a time — lane == row, by the helper — and consumed by the main wavefront's sweep; two window buffers:
+  //      the helper solves window w + 1 while the main wavefront sweeps window w.
+  T u = T(0), ur[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};  // u~ = sum_r z~_r x_r: the leg part on the dof lanes, the root part on every lane
+  // window wi of the sweep: Gauss-Seidel iteration wi / nwin, sweep positions w0 .. w0 + 7, row buffer wi & 1
+  auto help_rows = [&](int wi) {
+      const int nr = 3 * NA, nwin = (nr + 7) >> 3;
+      const int w0 = (wi % nwin) * 8;
+      T *const Zs = E + O.win + (wi & 1) * (8 * OctLds::ZW);
+      {
+        // ---- the window's rows: lane == sweep position w0 + lane
+        const T *const cpx = E + O.cp;
+        const T *const swl = E + O.swl;
+        const T *const lcw = E + O.lcw;
+        const T *const qdp = E + O.qdp;
+        const T cfm = CT[TB::SC + TB::CFM], erp_dt = CT[TB::SC + TB::ERP_OVER_DT], rest = CT[TB::SC + TB::RESTITUTION];
+        const int s = w0 + lane;
+        const int tk = (s >= NA ? 1 : 0) + (s >= 2 * NA ? 1 : 0);
+        const int a = s - tk * NA;
+        const bool real = s < nr && a < na;
+        const int ac = real ? a : 0;
+        const T Pc[3] = {cpx[0 * OctLds::NCP + ac], cpx[1 * OctLds::NCP + ac], cpx[2 * OctLds::NCP + ac]};
+        const T dist = cpx[3 * OctLds::NCP + ac];
+        const int ol = real ? (int)cpx[4 * OctLds::NCP + ac] : 8;  // owner lane; 8: the root body
+        const bool on_leg = ol < 8;
+        const int hl = on_leg ? (ol & ~1) : 0;   // the hip lane of the contact's leg
+        const bool ank = on_leg && (ol & 1);     // the contact sits on the ankle link: both dofs of the leg
+        const T *const dir = CT + TB::SC + (tk == 0 ? TB::NB : (tk == 1 ? TB::T1 : TB::T2));
+        const T e[3] = {dir[0], dir[1], dir[2]};
+        // column of the point Jacobian along e: e . s_lin + P . (e x s_ang) = e . s_lin + (P x e) . s_ang  (jacobian.hpp:56-72)
+        T mo[3];
+        cross3(Pc, e, mo);
+        T sh[6], sa[6];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            sh[c] = swl[hl * 7 + c];
-            sa[c] = swl[(hl + 1) * 7 + c];
-          }
-          T z0 = on_leg ? dot3(e, sh + 3) + dot3(mo, sh) : T(0);
-          T z1 = ank ? dot3(e, sa + 3) + dot3(mo, sa) : T(0);
-          T zr[6];
-          zr[0] = e[0];
-          zr[1] = e[1];
-          zr[2] = e[2];
-          zr[3] = dot3(e, pA3) + mo[0];
-          zr[4] = dot3(e, pA4) + dot3(mo, A4);
-          zr[5] = dot3(e, pA5) + dot3(mo, A5);
-          T vrow = z0 * qdp[hl] + z1 * qdp[hl + 1];
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) vrow += zr[rr] * qdr_new[rr];
-          // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1 + e) n.rel_vel - erp dist / dt,  b_t = -t.rel_vel
-          const T brow = tk == 0 ? (T(1) + rest) * vrow - erp_dt * dist : vrow;
-          // forward substitution L z = J^T, leaves first: the contact's leg, then the root rows
-          const T *const lf = E + O.legf + (hl >> 1) * 3;
-          z1 -= lf[0] * z0;
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) zr[rr] -= lcw[hl * OctLds::LCW + rr] * z0 + lcw[(hl + 1) * OctLds::LCW + rr] * z1;
-          static_for<1, 6>([&](auto rc) {
-            constexpr int rr = decltype(rc)::value;
-            static_for<0, rr>([&](auto cc) {
-              constexpr int c = decltype(cc)::value;
-              zr[rr] -= Ls[(rr * (rr - 1)) / 2 + c] * zr[c];
-            });
-          });
-          // z~ = D^-1/2 z, G = z~ . z~
-          z0 *= lf[1];
-          z1 *= lf[2];
-          T g = z0 * z0 + z1 * z1;
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) {
-            zr[rr] *= sq_ids[rr];
-            g += zr[rr] * zr[rr];
-          }
-          const T ai = real ? rcp_full<T>(g + cfm) : T(0);
-          T *const row = Zs + lane * OctLds::ZW;
-          row[0] = real ? z0 : T(0);
-          row[1] = real ? z1 : T(0);
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) row[2 + rr] = real ? zr[rr] : T(0);
-          row[8] = real ? brow : T(0);
-          row[9] = ai;
-          row[10] = real ? g : T(0);
-          row[11] = on_leg ? (T)hl : T(-2);
+        for (int c = 0; c < 6; ++c) {
+          sh[c] = swl[hl * 6 + c];
+          sa[c] = swl[(hl + 1) * 6 + c];
         }
-        OCT_SYNC();
+        T z0 = on_leg ? dot3(e, sh + 3) + dot3(mo, sh) : T(0);
+        T z1 = ank ? dot3(e, sa + 3) + dot3(mo, sa) : T(0);
+        T zr[6];
+        zr[0] = e[0];
+        zr[1] = e[1];
+        zr[2] = e[2];
+        zr[3] = dot3(e, pA3) + mo[0];
+        zr[4] = dot3(e, pA4) + dot3(mo, A4);
+        zr[5] = dot3(e, pA5) + dot3(mo, A5);
+        T vrow = z0 * qdp[hl] + z1 * qdp[hl + 1];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) vrow += zr[rr] * qdr_new[rr];
+        // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1 + e) n.rel_vel - erp dist / dt,  b_t = -t.rel_vel
+        const T brow = tk == 0 ? (T(1) + rest) * vrow - erp_dt * dist : vrow;
+        // forward substitution L z = J^T, leaves first: the contact's leg, then the root rows
+        const T *const lf = E + O.legf + (hl >> 1) * 3;
+        z1 -= lf[0] * z0;
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) zr[rr] -= lcw[hl * OctLds::LCW + rr] * z0 + lcw[(hl + 1) * OctLds::LCW + rr] * z1;
+        static_for<1, 6>([&](auto rc) {
+          constexpr int rr = decltype(rc)::value;
+          static_for<0, rr>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            zr[rr] -= Ls[(rr * (rr - 1)) / 2 + c] * zr[c];
+          });
+        });
+        // z~ = D^-1/2 z, G = z~ . z~
+        z0 *= lf[1];
+        z1 *= lf[2];
+        T g = z0 * z0 + z1 * z1;
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) {
+          zr[rr] *= sq_ids[rr];
+          g += zr[rr] * zr[rr];
+        }
+        const T ai = real ? rcp_full<T>(g + cfm) : T(0);
+        T *const row = Zs + lane * OctLds::ZW;
+        row[0] = real ? z0 : T(0);
+        row[1] = real ? z1 : T(0);
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) row[2 + rr] = real ? zr[rr] : T(0);
+        row[8] = real ? brow : T(0);
+        row[9] = ai;
+        row[10] = real ? g : T(0);
+        row[11] = on_leg ? (T)hl : T(-2);
+        OCT_STAMP(10, ai);
+      }
+  };
+  auto main_sweep = [&](int wi) {
+      const int nr = 3 * NA, nwin = (nr + 7) >> 3;
+      const int pit = wi / nwin;
+      const int w0 = (wi - pit * nwin) * 8;
+      const T *const Zs = E + O.win + (wi & 1) * (8 * OctLds::ZW);
+      T *const xs = E + O.xs;
+      const T my_hip = (T)(lane & ~1);
+      {
         // ---- the sweep over the window (mb_constraint_solver.hpp:101-142)
+        const T mu = CT[TB::SC + TB::FRICTION];
         const int wn = nr - w0 < 8 ? nr - w0 : 8;
         for (int k = 0; k < wn; ++k) {
           const int s = w0 + k;
@@ -862,10 +1025,10 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
           const T br = row[8], ar = row[9], gr = row[10];
           const T x_old = pit > 0 ? xs[s] : T(0);
           const T sdep = is_n ? T(0) : xs[dep];
-          T jw = oct_sum(zl * u);
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) jw += zrr[rr] * ur[rr];
-          const T delta = jw - gr * x_old;
+          // (two independent chains: the leg part's 8-lane sum and the root part)
+          const T jl = oct_sum(zl * u);
+          const T jr = (zrr[0] * ur[0] + zrr[1] * ur[1]) + (zrr[2] * ur[2] + zrr[3] * ur[3]) + (zrr[4] * ur[4] + zrr[5] * ur[5]);
+          const T delta = (jl + jr) - gr * x_old;
           T xn = (br - delta) * ar;
           const T sc = sdep < T(0) ? T(0) : sdep;  // where_lt(s, 0, 0, s)
           const T lo = is_n ? T(0) : -mu * sc;
@@ -880,10 +1043,14 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
           OCT_SYNC();
         }
       }
-    }
-    (void)my_lane;
-    // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
-    {
+  };
+  auto windows = [&]() -> int { return NA > 0 ? (int)CT[TB::SC + TB::PGS_ITERATIONS] * ((3 * NA + 7) >> 3) : 0; };
+
+  auto main_fin = [&]() {
+    // ================================ main: impulse, integration, reward ================================
+    OCT_STAMP(6, u);
+    if (NA > 0) {
+      // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
       T w = u * sqrt_t<T>(my_id);
       T wr[6];
 #pragma unroll
@@ -902,105 +1069,204 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #pragma unroll
       for (int r = 0; r < 6; ++r) qdr_new[r] -= wr[r];
     }
-  }
-
-  // ---- M. integrate_euler: q += qd dt (integrator.hpp:126-131); the new state into the LDS record
-  OCT_SYNC();
-  {
-    const T q_old0 = xr[0];
-    // root coordinates: lane r < 6 stores root value r
-    T qr_sel = qdr_new[0];
+    // ---- M. integrate_euler: q += qd dt (integrator.hpp:126-131); the new state into the LDS record
+    OCT_SYNC();
+    {
+      // root coordinates: every lane holds the six velocities; lane 0 stores them and the integrated coordinates
+      T qn_root[6];
 #pragma unroll
-    for (int r = 1; r < 6; ++r) qr_sel = lane == r ? qdr_new[r] : qr_sel;
-    const T qn_root = xr[lane < 6 ? lane : 0] + qr_sel * dt;
+      for (int r = 0; r < 6; ++r) qn_root[r] = xr[r] + qdr_new[r] * dt;
+      const T q_old0 = xr[0];
+      OCT_SYNC();
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          xr[r] = qn_root[r];
+          xr[nq + r] = qdr_new[r];
+        }
+      }
+      xr[dq] = q + qd_new * dt;
+      xr[nq + dq] = qd_new;
+      if (lane == 0) {
+        xr[in_dim] = q_old0;  // x_{t-1} (the Ant's reward reads it)
+        xr[in_dim + 3] = T(0);  // "the y state of this step is out already" (set below for an environment the reset pool re-initialises)
+      }
+    }
+    if constexpr (LOOP) {
+      // The next step's actions into the record's action slots (dead since the PD block) HERE, in front of this step's
+      // record stores — not at the top of the next step: loads and stores return through one in-order counter on gfx9, a
+      // wait for this load behind the stores would be a wait for every one of them (see tds_quad.hip)
+      if (ctl.act_pool != nullptr && !last) xr[nq + nd + lane] = next_act;
+    }
     OCT_SYNC();
-    if (lane < 6) {
-      xr[lane] = qn_root;
-      xr[nq + lane] = qr_sel;
-    }
-    xr[dq] = q + qd_new * dt;
-    xr[nq + dq] = qd_new;
-    if (lane == 0) xr[in_dim] = q_old0;  // x_{t-1} (the Ant's reward reads it)
-  }
-  if constexpr (LOOP) {
-    // The next step's actions into the record's action slots (dead since the PD block) HERE, in front of this step's record
-    // stores — not at the top of the next step: loads and stores return through one in-order counter on gfx9, a wait for
-    // this load behind the stores would be a wait for every one of them (see tds_quad.hip)
-    if (ctl.act_pool != nullptr && !last) xr[nq + nd + lane] = next_act;
-  }
-  OCT_SYNC();
-  // ---- y record: q | qd | (visual poses: M1) | up.z | zero padding
-  if (valid && yo != nullptr) {
-    auto y_state = [&](TR *y, int end) {
-      for (int i = lane; i < nq + nd; i += 8) y[i] = (TR)xr[i];
-      int tail = nq + nd;
-      if ((int)CT[TB::SC + TB::PACK_VISUALS]) {
-        tail += 7 * nv;
-        if (lane == 0) y[tail] = (TR)(CT[TB::SC + TB::BASE_R8]);  // up_dot_world_z (fixed base)
-        tail += 1;
+    // ---- N. reward / done (ant_environment2.h:75-106; laikago_environment2.h:130-171)
+    {
+      const int rm = (int)CT[TB::SC + TB::REWARD_MODE];
+      T rs = T(0), rc = T(1);
+      if (rm == TDS_REWARD_LAIKAGO) sincos_t<T>(lane < 3 ? xr[3 + lane] * T(0.5) : T(0), &rs, &rc);  // (wave-uniform branch)
+      const T s1 = oct_bcast<1>(rs), c1 = oct_bcast<1>(rc), s2 = oct_bcast<2>(rs), c2 = oct_bcast<2>(rc);
+      if (lane == 0) {
+        bool done = false;
+        T reward = T(0);
+        if (rm == TDS_REWARD_ANT) {
+          const T vel_x = (xr[0] - xr[in_dim]) / dt;
+          done = xr[2] < T(0.26);
+          reward = done ? T(0) : vel_x;
+        } else if (rm == TDS_REWARD_LAIKAGO) {
+          const T sp = rs, cp = rc, st = s1, ct = c1, ss = s2, cs2 = c2;
+          const T qx = sp * ct * cs2 - cp * st * ss;
+          const T qy = cp * st * cs2 + sp * ct * ss;
+          const T qz = cp * ct * ss - sp * st * cs2;
+          const T qw = cp * ct * cs2 + sp * st * ss;
+          const T sq = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+          const T up = T(1) - (qx * (qx * sq) + qy * (qy * sq));
+          done = (up < T(0.6)) || (xr[2] < T(0.2));
+          reward = done ? T(0) : xr[0];
+        }
+        xr[in_dim + 1] = done ? T(1) : T(0);
+        xr[in_dim + 2] = reward;
       }
-      for (int i = tail + lane; i < end; i += 8) y[i] = TR(0);
-    };
-    y_state(yo, yend);
-    if (yo2 != nullptr) y_state(yo2, yend2);
-  }
-  // ---- N. reward / done (ant_environment2.h:75-106; laikago_environment2.h:130-171)
-  {
-    const int rm = (int)CT[TB::SC + TB::REWARD_MODE];
-    T rs = T(0), rc = T(1);
-    if (rm == TDS_REWARD_LAIKAGO) sincos_t<T>(lane < 3 ? xr[3 + lane] * T(0.5) : T(0), &rs, &rc);  // (wave-uniform branch)
-    const T s1 = oct_bcast<1>(rs), c1 = oct_bcast<1>(rc), s2 = oct_bcast<2>(rs), c2 = oct_bcast<2>(rc);
-    if (lane == 0) {
-      bool done = false;
-      T reward = T(0);
-      if (rm == TDS_REWARD_ANT) {
-        const T vel_x = (xr[0] - xr[in_dim]) / dt;
-        done = xr[2] < T(0.26);
-        reward = done ? T(0) : vel_x;
-      } else if (rm == TDS_REWARD_LAIKAGO) {
-        const T sp = rs, cp = rc, st = s1, ct = c1, ss = s2, cs2 = c2;
-        const T qx = sp * ct * cs2 - cp * st * ss;
-        const T qy = cp * st * cs2 + sp * ct * ss;
-        const T qz = cp * ct * ss - sp * st * cs2;
-        const T qw = cp * ct * cs2 + sp * st * ss;
-        const T sq = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
-        const T up = T(1) - (qx * (qx * sq) + qy * (qy * sq));
-        done = (up < T(0.6)) || (xr[2] < T(0.2));
-        reward = done ? T(0) : xr[0];
-      }
-      xr[in_dim + 1] = done ? T(1) : T(0);
-      xr[in_dim + 2] = reward;
     }
-  }
-  OCT_SYNC();
-  // ---- auto_reset_when_done through the reset pool (ctl.pool; ars_vectorized_environment.h:262-277): a done environment
-  //      takes its next pre-settled state — y, reward and done describe the terminal step, the observation and the state
-  //      the fresh environment
-  if (ctl.pool != nullptr && valid && xr[in_dim + 1] != T(0)) {
-    const unsigned c = ctl.reset_count[env];
-    const TR *const src = oct_global((const TR *)ctl.pool) + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
-    T v0 = (T)src[lane], v1 = (T)src[lane + 8], v2 = (T)src[lane + 16], v3 = T(0);
-    if (lane + 24 < nq + nd) v3 = (T)src[lane + 24];
     OCT_SYNC();
-    xr[lane] = v0;
-    xr[lane + 8] = v1;
-    xr[lane + 16] = v2;
-    if (lane + 24 < nq + nd) xr[lane + 24] = v3;
-    if (lane == 0) ctl.reset_count[env] = c + 1u;
-  }
-  OCT_SYNC();
-  // ---- [obs | reward | done] record (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288): the slot of an obs ring
-  //      (every step of a step-loop launch; floats on the multi-GPU wire format) and / or the caller's record (last step)
-  if (valid) {
-    if (LOOP && ctl.obs_ring != nullptr) {
-      const size_t at = ((size_t)((ctl.obs_first + it) % ctl.obs_slots) * ctl.obs_envs + env) * w_obs;
-      for (int i = lane; i < w_obs; i += 8) {
-        const T vv = i < 2 ? T(0) : xr[i < nq + nd ? i : (i == nq + nd ? in_dim + 2 : in_dim + 1)];
-        if (ctl.ring_flags & TDS_RING_OBS_F32) oct_global((float *)ctl.obs_ring)[at + i] = (float)vv;
-        else oct_global((TR *)ctl.obs_ring)[at + i] = (TR)vv;
+  };
+  // the state part of a y record — q | qd | (visual poses: M1) | up.z | zero padding — from the LDS record
+  auto y_state = [&](TR *y, int end) {
+    for (int i = lane; i < nq + nd; i += 8) y[i] = (TR)xr[i];
+    int tail = nq + nd;
+    if ((int)CT[TB::SC + TB::PACK_VISUALS]) {
+      tail += 7 * nv;
+      if (lane == 0) y[tail] = (TR)(CT[TB::SC + TB::BASE_R8]);  // up_dot_world_z (fixed base)
+      tail += 1;
+    }
+    for (int i = tail + lane; i < end; i += 8) y[i] = TR(0);
+  };
+  auto main_pool = [&]() {
+    // ---- auto_reset_when_done through the reset pool (ctl.pool; ars_vectorized_environment.h:262-277): a done environment
+    //      takes its next pre-settled state — y, reward and done describe the terminal step, the observation and the state
+    //      the fresh environment: its y state goes out HERE, before the record is overwritten
+    if (ctl.pool != nullptr && valid && xr[in_dim + 1] != T(0)) {
+      if (yo != nullptr) {
+        y_state(yo, yend);
+        if (yo2 != nullptr) y_state(yo2, yend2);
+      }
+      const unsigned c = ctl.reset_count[env];
+      const TR *const src = oct_global((const TR *)ctl.pool) + ((size_t)(c % (unsigned)ctl.pool_depth) * ctl.pool_envs + env) * (nq + nd);
+      T v0 = (T)src[lane], v1 = (T)src[lane + 8], v2 = (T)src[lane + 16], v3 = T(0);
+      if (lane + 24 < nq + nd) v3 = (T)src[lane + 24];
+      OCT_SYNC();
+      xr[lane] = v0;
+      xr[lane + 8] = v1;
+      xr[lane + 16] = v2;
+      if (lane + 24 < nq + nd) xr[lane + 24] = v3;
+      if (lane == 0) {
+        ctl.reset_count[env] = c + 1u;
+        xr[in_dim + 3] = T(1);
       }
     }
-    if (last) {
+    OCT_STAMP(7, tid);
+  };
+  auto help_rec = [&]() {
+    // ================================ helper: the step's records ================================
+    // (two-wavefront build: while the main wavefront starts the next step — it does not write the record before its own
+    //  phase M, two barriers from here)
+    // ---- y record: q | qd | (visual poses: M1) | up.z | zero padding
+    if (valid && yo != nullptr && xr[in_dim + 3] == T(0)) {
+      y_state(yo, yend);
+      if (yo2 != nullptr) y_state(yo2, yend2);
+    }
+    // ---- [obs | reward | done] record (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288): the slot of an obs ring
+    //      (every step of a step-loop launch; floats on the multi-GPU wire format) and / or the caller's record (last step)
+    if constexpr (LOOP) {
+      if (ctl.obs_ring != nullptr) {  // wave-uniform
+        const int slot = (ctl.obs_first + it) % ctl.obs_slots;
+        const int rf = ctl.ring_flags;
+        const bool f32w = (rf & TDS_RING_OBS_F32) != 0 || sizeof(TR) == 4;
+        const int np = ctl.peer_arrive != nullptr ? ctl.n_peers : 0;
+        const bool rd_only = (rf & TDS_RING_PEER_REWARD_DONE) != 0;
+        if (ctl.peer_arrive != nullptr && (rf & TDS_RING_WIDE) != 0 && __all(valid)) {
+          // Peer-store exchange, the wavefront's eight records as one row of 8-byte units (240 scalars: 960 contiguous bytes
+          // on a float wire): every lane takes 8 bytes of the row — read from the environments' LDS records, converted
+          // once — and the row goes out with one 8-byte-per-lane store instruction per destination and pass: this rank's
+          // own block (device scope, write-through), then every peer's (system scope, over xGMI), the table's pointers by
+          // scalar loads (see tds_kernels.hip: put_obs_wide)
+          const int wl = tid & 63;
+          const size_t row0 = ((size_t)slot * ctl.obs_envs + (size_t)blockIdx.x * 8) * (size_t)w_obs;
+          const int per_unit = f32w ? 2 : 1;
+          const int n_units = (8 * w_obs) / per_unit;
+          const unsigned long long *const __attribute__((address_space(4))) *tab =
+              (const unsigned long long *const __attribute__((address_space(4))) *)(const __attribute__((address_space(4))) void *)ctl.peer_ring;
+          for (int u0 = 0; u0 < n_units; u0 += 64) {
+            const int uu = u0 + wl;
+            const bool on = uu < n_units;
+            unsigned lo = 0u, hi = 0u;
+            bool tail = false;  // this unit holds a [reward | done] column
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              if (c < per_unit) {
+                const int f = on ? uu * per_unit + c : 0;
+                const int e = f / w_obs;
+                const int i = f - e * w_obs;
+                const int src = i < nq + nd ? i : (i == nq + nd ? in_dim + 2 : in_dim + 1);
+                const T vv = i < 2 ? T(0) : sm[e * O.stride + src];
+                tail = tail || i >= nq + nd;
+                if (f32w) {
+                  const unsigned b = (unsigned)__float_as_int((float)vv);
+                  if (c == 0) lo = b; else hi = b;
+                } else {
+                  const double dv = (double)vv;
+                  lo = (unsigned)__double2loint(dv);
+                  hi = (unsigned)__double2hiint(dv);
+                }
+              }
+            }
+            const unsigned long long bits = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+            const size_t unit_at = row0 / per_unit + (size_t)uu;  // (row0 is a multiple of per_unit: TDS_RING_WIDE)
+            if (on) __hip_atomic_store(oct_global((unsigned long long *)ctl.obs_ring) + unit_at, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (reward | done only: a unit travels if ANY of its columns is one of the two — on a float wire they may share a
+            //  unit with an observation column)
+            const bool to_peers = on && (!rd_only || tail);
+            for (int p0 = 0; p0 < np; p0 += 4) {  // (the table is padded to a multiple of four entries)
+              const unsigned long long *const b0 = oct_global(tab[p0]), *const b1 = oct_global(tab[p0 + 1]), *const b2 = oct_global(tab[p0 + 2]),
+                                       *const b3 = oct_global(tab[p0 + 3]);
+              const size_t po = (size_t)ctl.peer_off / 8 + unit_at;
+              if (to_peers) {
+                using G64 = __attribute__((address_space(1))) unsigned long long;
+                __hip_atomic_store((G64 *)((unsigned long long *)b0 + po), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (p0 + 1 < np) __hip_atomic_store((G64 *)((unsigned long long *)b1 + po), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (p0 + 2 < np) __hip_atomic_store((G64 *)((unsigned long long *)b2 + po), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (p0 + 3 < np) __hip_atomic_store((G64 *)((unsigned long long *)b3 + po), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              }
+            }
+          }
+        } else if (valid) {
+          const size_t at = ((size_t)slot * ctl.obs_envs + env) * w_obs;
+          for (int i = lane; i < w_obs; i += 8) {
+            const T vv = i < 2 ? T(0) : xr[i < nq + nd ? i : (i == nq + nd ? in_dim + 2 : in_dim + 1)];
+            // (TDS_RING_NOFENCE: device-scope write-through stores, visible to the exchange after a plain wait)
+            if (rf & TDS_RING_OBS_F32) {
+              float *const pp = oct_global((float *)ctl.obs_ring) + at + i;
+              if (rf & TDS_RING_NOFENCE) __hip_atomic_store(pp, (float)vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else *pp = (float)vv;
+            } else {
+              TR *const pp = oct_global((TR *)ctl.obs_ring) + at + i;
+              if (rf & TDS_RING_NOFENCE) __hip_atomic_store(pp, (TR)vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else *pp = (TR)vv;
+            }
+            if (np > 0 && (i >= nq + nd || !rd_only)) {
+              for (int pr = 0; pr < np; ++pr) {
+                char *const pb = (char *)oct_global(((void *const __attribute__((address_space(4))) *)(const __attribute__((address_space(4))) void *)ctl.peer_ring)[pr]) + ctl.peer_off;
+                if (rf & TDS_RING_OBS_F32) __hip_atomic_store((float *)pb + (at + i), (float)vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else __hip_atomic_store((TR *)pb + (at + i), (TR)vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              }
+            }
+          }
+        }
+        // (peer-store exchange: EVERY step is counted in — the last one here, by the wavefront that has just stored it; kernel
+        //  completion would tell this rank, not the peers)
+        if (last && ctl.peer_arrive != nullptr) signal_slot(slot);
+      }
+    }
+    if (valid && last) {
       for (int i = lane; i < nq + nd; i += 8) {
         const TR vv = (TR)xr[i];
         if (obs_out != nullptr) obs_out[(size_t)env * w_obs + i] = i < 2 ? TR(0) : vv;
@@ -1011,12 +1277,81 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         obs_out[(size_t)env * w_obs + nq + nd + 1] = (TR)xr[in_dim + 1];
       }
     }
+    OCT_STAMP(11, tid);
+  };
+
+  // ================================ the step ================================
+  // barriers of a two-wavefront workgroup: (1) the kinematics are in LDS; (2) factors, velocities, contact list and counts;
+  // one per row window (window wi is in LDS — the helper solves window wi + 1 while the main wavefront sweeps wi); (0) the
+  // step's state, reward and done are in the LDS record — the helper stores the step's records while the main wavefront
+  // starts the next step (it does not write the record before its own integration, two barriers on)
+  if constexpr (W2) {
+    if (wv == 0) {
+      main_kin();
+      OCT_BAR();  // (1)
+      main_dyn();
+      OCT_BAR();  // (2)
+      main_get_count();
+      const int nw = windows();
+      for (int wi = 0; wi < nw; ++wi) {
+        OCT_BAR();
+        main_sweep(wi);
+      }
+      main_fin();
+      main_pool();
+      OCT_BAR();  // (0)
+    } else {
+      OCT_BAR();  // (1)
+      help_np();
+      OCT_BAR();  // (2)
+      help_get_factors();
+      const int nw = windows();
+      for (int wi = 0; wi < nw; ++wi) {
+        help_rows(wi);
+        OCT_BAR();
+      }
+      OCT_BAR();  // (0)
+      help_rec();
+    }
+  } else {
+    main_kin();
+    OCT_SYNC();
+    help_np();
+    main_dyn();
+    OCT_SYNC();
+    const int nw = windows();
+    for (int wi = 0; wi < nw; ++wi) {
+      help_rows(wi);
+      OCT_SYNC();
+      main_sweep(wi);
+    }
+    main_fin();
+    main_pool();
+    OCT_SYNC();
+    help_rec();
+    if constexpr (LOOP) OCT_SYNC();
   }
-  if constexpr (LOOP) OCT_SYNC();
+#ifdef TDS_OCT_PROF
+  if (prof_on && (tid & 63) == 0) {
+    // (main: stamps 0 .. 7 into buf[0 .. 7]; helper: stamps 8 .. 11 and the window stamp 10 into buf[8 .. 11]; one-wave: all)
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      if ((k < 8 && is_main) || (k >= 8 && is_help)) tds_oct_prof_buf[k] = prof_t[k];
+    if (is_help) tds_oct_prof_buf[15] = (unsigned long long)NA;
+  }
+#endif
   }  // ================================ end of the step loop ================================
 }
 
 }  // namespace
+
+#ifdef TDS_OCT_PROF
+extern "C" int tds_oct_prof_read(unsigned long long *out32, int iter) {  // iter >= 0: which iteration the NEXT launches stamp
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(tds_oct_prof_buf), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (iter >= 0 && hipMemcpyToSymbol(HIP_SYMBOL(tds_oct_prof_iter), &iter, sizeof(int)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 // LDS bytes of one environment of the 8-lane kernel, and of one workgroup (eight environments + the constant table)
 int tds_oct_lds_bytes(int input_dim) { return oct_layout(input_dim).stride * (int)sizeof(double); }
@@ -1024,23 +1359,30 @@ int tds_oct_workgroup_bytes(int input_dim) {
   return (oct_layout(input_dim).stride * 8 + TdsOctTab::TOTAL) * (int)sizeof(double);
 }
 
+// two_waves: the two-wavefront build (the host grants it while every workgroup of the launch is resident with at most two
+// wavefronts per SIMD: tds_api.hip)
 template <typename T, typename TR>
 int tds_launch_oct(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
-                   TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl) {
+                   TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, bool two_waves) {
   const OctOff O = oct_layout(h_model.input_dim);
   const int blocks = (n_envs + 7) / 8;
   const size_t shmem = ((size_t)O.stride * 8 + TdsOctTab::TOTAL) * sizeof(T);
   // one plain step without rings: the straight-line form; K steps, record rings: the step-loop form
   const bool one_step = ctl.nsub == 1 && ctl.obs_ring == nullptr && ctl.y_ring == nullptr;
-  if (one_step)
-    hipLaunchKernelGGL((tds_oct_kernel<T, TR, false>), dim3(blocks), dim3(64), shmem, stream, d_model, x_in, y_out, actions,
-                       x_feedback, obs_out, ctl, n_envs, O);
-  else
-    hipLaunchKernelGGL((tds_oct_kernel<T, TR, true>), dim3(blocks), dim3(64), shmem, stream, d_model, x_in, y_out, actions,
-                       x_feedback, obs_out, ctl, n_envs, O);
+#define OCT_LAUNCH(LOOP_, W2_)                                                                                              \
+  hipLaunchKernelGGL((tds_oct_kernel<T, TR, LOOP_, W2_>), dim3(blocks), dim3(W2_ ? 128 : 64), shmem, stream, d_model, x_in, \
+                     y_out, actions, x_feedback, obs_out, ctl, n_envs, O)
+  if (one_step) {
+    if (two_waves) OCT_LAUNCH(false, true);
+    else OCT_LAUNCH(false, false);
+  } else {
+    if (two_waves) OCT_LAUNCH(true, true);
+    else OCT_LAUNCH(true, false);
+  }
+#undef OCT_LAUNCH
   return (int)hipGetLastError();
 }
 template int tds_launch_oct<double, double>(const DevModel<double> *, const DevModel<double> &, const double *, double *,
-                                            const double *, double *, double *, int, hipStream_t, const TdsStepCtl &);
+                                            const double *, double *, double *, int, hipStream_t, const TdsStepCtl &, bool);
 template int tds_launch_oct<double, float>(const DevModel<double> *, const DevModel<double> &, const float *, float *,
-                                           const float *, float *, float *, int, hipStream_t, const TdsStepCtl &);
+                                           const float *, float *, float *, int, hipStream_t, const TdsStepCtl &, bool);

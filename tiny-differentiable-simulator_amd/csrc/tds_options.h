@@ -26,6 +26,7 @@ enum TdsOptKey {
   TDS_OPT_OCT,                // 0: a star with two-link legs (the Ant) stays on the general kernel instead of tds_oct.hip's 8-lane kernel
   // ---- run-time rows (may change between calls of a handle)
   TDS_OPT_LOOP_W2,            // step-loop launches: 0 one-wave build, 1 (default) two-wavefront build where it fits, 2 ... not with the reset pool
+  TDS_OPT_OCT_W2,             // 8-lane kernel (tds_oct.hip): 0 one wavefront per workgroup, 1 / unset two (main + helper) while every workgroup is resident with at most two wavefronts per SIMD, 2 two at any grid size
   TDS_OPT_LOOP_OCC,           // step-loop build: 1 / 2 wavefronts per SIMD forced (unset: by grid size)
   TDS_OPT_EXCHANGE_W2,        // launches whose ring slots are exchanged while they run (rings->progress): 1 / unset the two-wavefront build N = 1 takes, 0 the one-wave build
   TDS_OPT_RING_NOFENCE,       // 1 (default): write-through record stores + plain wait; 0: release fence per step
@@ -56,6 +57,7 @@ enum TdsOptKey {
   TDS_OPT_ALT_BUILD,          // experiment slot k (1 .. TDS_ALT_SLOTS) of the library, where it was linked in (tds_kernels.h); f64 plain kernels
   TDS_OPT_SHARD_PEER,         // ring exchange by PEER STORES (the step kernel writes its records into the other ranks' gathered rings, IPC-mapped): unset / 1 where it can be set up on every rank (else the RCCL all-gather), 0 never, 2 required (error instead of the fallback)
   TDS_OPT_EXCHANGE_FIELDS,    // peer-store exchange: 0 / unset the whole [obs | reward | done] record travels, 1 only [reward | done]
+  TDS_OPT_SHARD_PEER_RELEASE,   // peer-store exchange: 1 = system-scope release fences in front of the arrival counts and the flag stores (A/B switch for the first run on a real fabric; default: vmcnt(0) + relaxed stores)
   TDS_OPT_SHARD_PEER_LOOPBACK,  // diagnostic: k extra "peers" mapped onto scratch rings of this rank's own GPU (the kernel-side cost of k peers, measurable on one GPU)
   TDS_OPT_COUNT
 };
@@ -83,6 +85,7 @@ inline const TdsOptRow *tds_opt_rows() {
       {"quad", true, "TDS_HIP_QUAD"},
       {"oct", true, "TDS_HIP_OCT"},
       {"loop_w2", false, "TDS_HIP_LOOP_W2"},
+      {"oct_w2", false, "TDS_HIP_OCT_W2"},
       {"loop_occ", false, "TDS_HIP_LOOP_OCC"},
       {"exchange_w2", false, "TDS_HIP_EXCHANGE_W2"},
       {"ring_nofence", false, "TDS_HIP_RING_NOFENCE"},
@@ -112,6 +115,7 @@ inline const TdsOptRow *tds_opt_rows() {
       {"alt_build", false, "TDS_HIP_ALT_BUILD"},
       {"shard_peer", false, "TDS_HIP_SHARD_PEER"},
       {"exchange_fields", false, "TDS_HIP_EXCHANGE_FIELDS"},
+      {"shard_peer_release", false, "TDS_HIP_SHARD_PEER_RELEASE"},
       {"shard_peer_loopback", false, "TDS_HIP_SHARD_PEER_LOOPBACK"},
   };
   return rows;
