@@ -158,15 +158,17 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     return fail(TDS_ERR_UNSUPPORTED, "option loop_occ = 1: no one-wavefront-per-SIMD step-loop build below 14 padded dof");
   // the 8-lane kernel (tds_oct.hip) takes the launch: its two-wavefront build while every workgroup of the launch is resident
   // with at most two wavefronts per SIMD — four workgroups per compute unit, LDS permitting (Ant: up to 8192 environments)
-  bool oct_w2 = false;
+  int oct_form = 0;
   if (s->compute_f64() && s->h64.oct != 0 && nsub >= 1 && reset_mode == TDS_RESET_NONE && !ro) {
     const long long o2 = s->opt.get(TDS_OPT_OCT_W2, 1);
     const int per_cu = (int)(s->lds_per_cu / (size_t)tds_oct_workgroup_bytes(s->model.input_dim));
-    const int resident = s->num_cus * (per_cu < 4 ? per_cu : 4);
-    oct_w2 = o2 == 2 || (o2 != 0 && (n_resident + 7) / 8 <= resident);
+    const int blocks = (n_resident + 7) / 8;
+    // (two workgroups per compute unit = one wavefront per SIMD: the build compiled for that — no register limit to spill at)
+    if (o2 != 0 && per_cu >= 2 && blocks <= 2 * s->num_cus) oct_form = TDS_FORM_OCT_W2_OCC1;
+    else if (o2 == 2 || (o2 != 0 && blocks <= s->num_cus * (per_cu < 4 ? per_cu : 4))) oct_form = TDS_FORM_OCT_W2;
   }
   const int form = (two_waves ? TDS_FORM_W2 : 0) | (occ == 1 ? TDS_FORM_LOOP_OCC1 : (occ == 2 ? TDS_FORM_LOOP_OCC2 : 0)) |
-                   (oct_w2 ? TDS_FORM_OCT_W2 : 0);
+                   oct_form;
   void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
   if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along
     const size_t e0 = (size_t)opts->env_first, el = s->elem;

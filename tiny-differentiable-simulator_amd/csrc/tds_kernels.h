@@ -135,7 +135,8 @@ struct TdsStepCtl {
 #define TDS_FORM_W2 1         // L is the w2 layout: launch the two-wavefront form (plain kernels)
 #define TDS_FORM_LOOP_OCC1 2  // step-loop build: the one-wavefront-per-SIMD compilation whatever the grid
 #define TDS_FORM_LOOP_OCC2 4  // ... the two-wavefronts-per-SIMD compilation whatever the grid
-#define TDS_FORM_OCT_W2 8     // the 8-lane kernel (tds_oct.hip): its two-wavefront build
+#define TDS_FORM_OCT_W2 8     // the 8-lane kernel (tds_oct.hip): its two-wavefront build compiled for two wavefronts per SIMD
+#define TDS_FORM_OCT_W2_OCC1 16  // ... compiled for one wavefront per SIMD (at most two workgroups per compute unit)
 
 // EXPERIMENT SLOTS (tools/build_alt.sh): the kernel sources compiled once more — other compiler flags, -DTDS_X_... source
 // switches — as a small extra translation unit holding ONE (lanes, padded dof) instantiation of the f64 / KIND 0 kernels,
@@ -188,7 +189,7 @@ inline bool tds_quad_takes(int quad, const TdsStepCtl &ctl, const long long *pro
 // kernel, and the exchange launches of the multi-GPU layer (progress counters / peer stores) as well
 template <typename T, typename TR>
 int tds_launch_oct(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
-                   TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, bool two_waves);
+                   TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, int build);
 int tds_oct_lds_bytes(int input_dim);        // LDS of one environment
 int tds_oct_workgroup_bytes(int input_dim);  // LDS of one workgroup: eight environments + the constant table
 inline bool tds_oct_takes(int oct, const TdsStepCtl &ctl, const long long *prof) {
@@ -208,7 +209,7 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
   if constexpr (sizeof(T) == 8) {
     if (tds_oct_takes(h_model.oct, ctl, prof))
       return tds_launch_oct<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl,
-                                   (form & TDS_FORM_OCT_W2) != 0);
+                                   (form & TDS_FORM_OCT_W2_OCC1) ? 3 : ((form & TDS_FORM_OCT_W2) ? 2 : 1));
   }
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);

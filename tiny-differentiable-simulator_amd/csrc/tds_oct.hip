@@ -116,28 +116,65 @@ __device__ __forceinline__ float oct_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(t, b, 0x150 + 8 + K, 0xF, 0xC, false));
 }
 
+// sin and cos of a joint angle: Cody-Waite reduction by pi / 2 in two fused steps (exact for |x| < 1e5: the product k * hi is
+// formed exactly inside the FMA and cancels against x) and the fdlibm kernels on [-pi/4, pi/4] (__kernel_sin / __kernel_cos:
+// < 1 ulp) — ~35 instructions where the library routine takes ~90 with its branch to the Payne-Hanek reduction; angles
+// beyond 1e5 rad (no simulation gets there, but a caller may hand in anything) take the library routine, wave-uniformly
+__device__ __forceinline__ void oct_sincos(double x, double *sn, double *cs) {
+  if (__builtin_expect(__any(!(__builtin_fabs(x) < 1.0e5)), 0)) {
+    sincos(x, sn, cs);
+    return;
+  }
+  const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+  double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+  r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+  const int q = (int)k;
+  const double z = r * r;
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+  ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+  ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+  const double s0 = __builtin_fma(z * r, ps, r);
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+  pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+  pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+  const double c0 = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+  const bool swap = (q & 1) != 0;
+  const double ss = swap ? c0 : s0, cc = swap ? s0 : c0;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = ((q + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ void oct_sincos(float x, float *sn, float *cs) { sincosf(x, sn, cs); }
+
 // LDS per environment, offsets in scalars of T
 struct OctOff {
   int lcw, legf, swl, qdp, fac, win, xs, cp, stride;
 };
 struct OctLds {
-  static constexpr int LCW = 12;  // [8 lanes][Lc(6) | W(6)]
-  static constexpr int ZW = 12;   // a window row: z~ leg (2) | z~ root (6) | b | 1 / (G + cfm) | G | hip lane of the contact's leg
+  static constexpr int LCW = 6;   // [8 lanes][Lc(6)]  (W = Lc D, needed for the Schur sums only, borrows the impulses' slots)
+  // a window row: z~ leg (2) | z~ root (6) | 0 | 0 | b | 1 / (G + cfm) | G | hip lane of the contact's leg.  (The two zeros: lane j
+  // of the sweep reads root entry j — lanes 6, 7 of an environment read them.)  Between its two halves (see help_rows_geom /
+  // rows_solve) a row holds the unsolved Jacobian row and the contact's distance instead.
+  static constexpr int ZW = 14;
+  static constexpr int Z_B = 10, Z_A = 11, Z_G = 12, Z_HL = 13;
   static constexpr int NCP = 17;  // contact points (torso + 2 per leg link), and the stride of the contact list
 };
 __host__ __device__ inline OctOff oct_layout(int in_dim) {
   OctOff o;
   int at = in_dim + 4;          // x record | x_{t-1} | done | reward | flag / count
   at = (at + 1) & ~1;
-  o.lcw = at;  at += 8 * OctLds::LCW;     // L_c and W of the 8 leg-dof lanes
+  o.lcw = at;  at += 8 * OctLds::LCW;     // L_c of the 8 leg-dof lanes
   o.legf = at; at += 4 * 3;               // per leg: l10 | sqrt(1/d0) | sqrt(1/d1)
   o.swl = at;  at += 8 * 6;               // world motion axis of the 8 leg-dof lanes
   o.qdp = at;  at += 8;                   // leg velocities after integrate_euler_qdd
   o.fac = at;  at += 28;                  // the 21 lane-parallel sums of the Schur complement; then (two-wavefront build) the root
                                           // block's factors for the helper: L_S (15) | sqrt(1/D_S) (6) | root velocities (6)
-  o.win = at;  at += 2 * 8 * OctLds::ZW;  // two windows of constraint rows (the second doubles as the hand-over of the links'
-                                          // world transforms from the main wavefront to the helper: 8 x 12)
-  o.xs = at;   at += 3 * OctLds::NCP + 1; // impulses (the first six slots: the root's sines / cosines for the helper)
+  o.win = at;  at += 2 * 8 * OctLds::ZW;  // two windows of constraint rows (the second doubles as the hand-over of the links' world
+                                          // transforms, 8 x 12, and the root's sines / cosines, 6, from the main wavefront to the helper)
+  o.xs = at;   at += 3 * OctLds::NCP + 1; // impulses (before the sweep: W = L_c D of the 8 leg-dof lanes, for the Schur sums)
   o.cp = at;   at += 5 * OctLds::NCP + 1; // contact list: point (3) | distance | owner lane, per slot
   // the environments of a wavefront on different banks: four consecutive ones (half a wavefront) must not meet on an
   // 8-byte bank pair — the stride in 4-byte words a multiple of 8 that is neither 0 nor 32 mod 64
@@ -193,13 +230,16 @@ using TB = TdsOctTab;
 // the step's dependent chain (PD, kinematics, inertias, LDL^T, forward dynamics, the Gauss-Seidel sweep, integration,
 // reward), the HELPER does what hangs off it (narrowphase, visual poses, the constraint rows window by window, every record
 // store, the exchange); in the one-wave build the one wavefront plays both roles in the same order.
-template <typename T, typename TR, bool LOOP, bool W2>
-__global__ __launch_bounds__(W2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(W2 ? 2 : 1, W2 ? 2 : 1)))
+// BUILD: 1 one wavefront per workgroup; 2 two, compiled for two wavefronts per SIMD (256 registers); 3 two, compiled for one
+// wavefront per SIMD (what a launch of at most two workgroups per compute unit gets anyway: Ant x 4096 — no spills)
+template <typename T, typename TR, bool LOOP, int BUILD>
+__global__ __launch_bounds__(BUILD >= 2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(BUILD == 2 ? 2 : 1, BUILD == 2 ? 2 : 1)))
 void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
                     const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */, TR *__restrict__ obs_out,
                     TdsStepCtl ctl_arg, int n_envs, OctOff O) {
   extern __shared__ __align__(16) unsigned char tds_oct_smem[];
   T *const sm = reinterpret_cast<T *>(tds_oct_smem);
+  constexpr bool W2 = BUILD >= 2;
   constexpr int nq = 14, nd = 14, adim = 8, in_dim = nq + nd + adim + 3, w_obs = nq + nd + 2;
   constexpr int NT = W2 ? 128 : 64;
   T *const CT = sm + 8 * O.stride;  // the constant table
@@ -222,6 +262,14 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   }
   const int nsteps = LOOP ? ctl_arg.nsub : 1;
   T next_act = T(0);  // (step-loop form, main wavefront: the action of the NEXT step, requested a step ahead)
+  // ring positions of the current step, carried along as scalars (a remainder by a run-time divisor per step and ring costs
+  // ~100 instructions at the top of the main wavefront's chain): action block of step it + 1, y slot and obs slot of step it
+  int act_blk = 0, y_slot = 0, o_slot = 0;
+  if constexpr (LOOP) {
+    if (ctl_arg.act_pool != nullptr && ctl_arg.act_blocks > 0) act_blk = (ctl_arg.act_first + 1) % ctl_arg.act_blocks;
+    if (ctl_arg.y_ring != nullptr && ctl_arg.y_slots > 0) y_slot = ctl_arg.y_first % ctl_arg.y_slots;
+    if (ctl_arg.obs_ring != nullptr && ctl_arg.obs_slots > 0) o_slot = ctl_arg.obs_first % ctl_arg.obs_slots;
+  }
   for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
   // (nothing but `it` and next_act lives across an iteration: lane and kernel-argument segment are laundered)
   const __attribute__((address_space(4))) char *ka_seg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -232,7 +280,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   (void)is_main;
   (void)is_help;
 #ifdef TDS_OCT_PROF
-  unsigned long long prof_t[16];
+  unsigned long long prof_t[26];
   const bool prof_on = blockIdx.x == TDS_OCT_PROF_WG && it == tds_oct_prof_iter;
 #endif
   const int lane = tid & 7;
@@ -246,6 +294,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   const T *const CL = CT + lane * TB::LSTR;  // my lane's constants
   typename OctCtlRef<LOOP>::type ctl = OctCtlRef<LOOP>::get(ctl_arg, ka_seg + __builtin_offsetof(OctKernArgs, ctl));
   const T dt = CT[TB::SC + TB::DT];
+  const int pgs_iters = (int)CT[TB::SC + TB::PGS_ITERATIONS];
   const bool last = it == nsteps - 1;
   OCT_STAMP(0, tid);
 
@@ -254,7 +303,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   T q, qd, tau;
   T Sl[6], R[9], p[3], sw[6], v[6], a0[6];
   T R5[9], P[3], A4[3], A5[3], pA3[3], pA4[3], pA5[3], v5[6], a5[6];
-  T Lc[6], l10, id0, id1, my_id, Ls[15], ids[6], sq_ids[6], qd_new, qdr_new[6];
+  T Lc[6], l10, id0, id1, sq0, sq1, my_id, my_sq, Ls[15], ids[6], sq_ids[6], qd_new, qdr_new[6];
   int na = 0, NA = 0;
 
   // the root body's frame and the root's revolute axes from the six sines / cosines (kinematics.hpp:64-97; tds_kernels.hip
@@ -292,7 +341,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       // the action block of this step came in a step ago (see phase M); the next step's is requested now
       if (ctl.act_pool != nullptr) {  // wave-uniform
         if (it + 1 < nsteps && valid) {
-          const int blk = (ctl.act_first + it + 1) % ctl.act_blocks;
+          const int blk = act_blk;
           next_act = (T)oct_global((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
         }
       }
@@ -330,7 +379,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #pragma unroll
       for (int k = 0; k < 3; ++k) tT[k] = CL[TB::XT + 9 + k];
       T sn, cs;
-      sincos_t<T>(jt == TDS_JOINT_REVOLUTE_AXIS ? q * T(0.5) : q, &sn, &cs);
+      oct_sincos(jt == TDS_JOINT_REVOLUTE_AXIS ? q * T(0.5) : q, &sn, &cs);
       const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
       const bool pris = jt >= TDS_JOINT_PRISMATIC_X && jt <= TDS_JOINT_PRISMATIC_AXIS;
       T RJ[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
@@ -348,10 +397,12 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         } else if (jt == TDS_JOINT_REVOLUTE_Z) {
           RJ[0] = cs; RJ[1] = -sn; RJ[3] = sn; RJ[4] = cs;
         } else {  // axis-angle quaternion with the UNNORMALISED axis (link.hpp:256-261)
-          const T d = sqrt_t<T>(Sl[0] * Sl[0] + Sl[1] * Sl[1] + Sl[2] * Sl[2]);
-          const T sh = sn / d;
+          // (1 / |axis| from the table; the quaternion's squared norm n2 is 1 to rounding — sin^2 + cos^2 — so 2 / n2, the
+          //  reference's quat_to_matrix scale, is 2 (2 - n2) to the last bit: one Newton step from 1, error (n2 - 1)^2)
+          const T sh = sn * CL[TB::AXINV];
           const T qx = Sl[0] * sh, qy = Sl[1] * sh, qz = Sl[2] * sh, qw = cs;
-          const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+          const T n2 = qx * qx + qy * qy + qz * qz + qw * qw;
+          const T s2 = T(4) - T(2) * n2;
           const T xs_ = qx * s2, ys = qy * s2, zs = qz * s2;
           const T wx = qw * xs_, wy = qw * ys, wz = qw * zs;
           const T xx = qx * xs_, xy = qx * ys, xz = qx * zs;
@@ -369,17 +420,18 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       tp[2] = tT[2] + r[2];
     }
     // ---- C. the root chain in closed form, on every lane.  The three root angles' sines and cosines: lanes 0, 1, 2 of the
-    //         environment, broadcast (and, two-wavefront build, handed to the helper: the slots of the first impulses)
+    //         environment, broadcast (and, two-wavefront build, handed to the helper behind the links' world transforms)
     {
       T rs, rc;
-      sincos_t<T>(xr[3 + (lane < 3 ? lane : 0)], &rs, &rc);
+      oct_sincos(xr[3 + (lane < 3 ? lane : 0)], &rs, &rc);
       const T sx = oct_bcast<0>(rs), cx = oct_bcast<0>(rc);
       const T sy = oct_bcast<1>(rs), cy = oct_bcast<1>(rc);
       const T sz = oct_bcast<2>(rs), cz = oct_bcast<2>(rc);
       if constexpr (W2) {
         if (lane < 3) {
-          E[O.xs + 2 * lane] = rs;
-          E[O.xs + 2 * lane + 1] = rc;
+          T *const sc = E + O.win + 8 * OctLds::ZW + 96;
+          sc[2 * lane] = rs;
+          sc[2 * lane + 1] = rc;
         }
       }
       root_frame(sx, cx, sy, cy, sz, cz);
@@ -500,7 +552,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   TR *yo = nullptr, *yo2 = nullptr;
   int yend = ystr, yend2 = out_dim;
   if (LOOP && ctl.y_ring != nullptr) {
-    yo = oct_global((TR *)ctl.y_ring) + ((size_t)((ctl.y_first + it) % ctl.y_slots) * ctl.ring_envs + env) * ystr;
+    yo = oct_global((TR *)ctl.y_ring) + ((size_t)y_slot * ctl.ring_envs + env) * ystr;
     if (last && y_out != nullptr) yo2 = y_out + (size_t)env * out_dim;
   } else if (last && y_out != nullptr) {
     yo = y_out + (size_t)env * (LOOP ? out_dim : ystr);
@@ -544,7 +596,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       for (int k = 0; k < 9; ++k) R[k] = kin[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) p[k] = kin[9 + k];
-      const T *const sc = E + O.xs;
+      const T *const sc = E + O.win + 8 * OctLds::ZW + 96;
       root_frame(sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]);
     }
     // ---- I. narrowphase (contact_point.hpp:96-161): my link's capsule = two spheres; the root body's sphere on every lane.
@@ -603,15 +655,16 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         const int c = __popc((unsigned)((b0 >> (g * 8)) & 0xFFull)) + __popc((unsigned)((b1 >> (g * 8)) & 0xFFull)) + (int)((bt >> (g * 8)) & 1ull);
         NA = c > NA ? c : NA;
       }
-      if constexpr (W2) {
-        if ((tid & 63) == 0) sm[in_dim + 3] = (T)NA;  // (for the main wavefront: the spare slot of environment 0's record)
+      if constexpr (W2) {  // (for the main wavefront, which solves the first row window itself)
+        if ((tid & 63) == 0) sm[in_dim + 3] = (T)NA;  // the spare slot of environment 0's record
+        if (lane == 0) cpx[5 * OctLds::NCP] = (T)na;
       }
     }
     OCT_STAMP(8, na);
     if constexpr (LOOP) {
       // the records of step it - 1 — stored at the end of the iteration before, long acknowledged by now: the wait costs
       // nothing here, in front of this step's first stores — are counted in
-      if (it > 0 && ctl.obs_ring != nullptr) signal_slot((ctl.obs_first + it - 1) % ctl.obs_slots);  // (wave-uniform)
+      if (it > 0 && ctl.obs_ring != nullptr) signal_slot((o_slot == 0 ? ctl.obs_slots : o_slot) - 1);  // (wave-uniform)
     }
     // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
     //          my link's (DevModel::oct checks the order); visual 0 — the root body's — goes out on lane 7
@@ -755,11 +808,16 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     {
       const T b00 = pair_bcast<0>(Bm0);
       const T b10 = pair_bcast<1>(Bm0), b11 = pair_bcast<1>(Bm1);
-      id0 = rcp_full<T>(b00);
+      // (1 / sqrt(d) by the hardware estimate + two Newton steps, 1 / d as its square: what a division AND a square root
+      //  per pivot cost — ~25 instructions — for 8)
+      sq0 = rsqrt_full<T>(b00);
+      id0 = sq0 * sq0;
       l10 = b10 * id0;
-      id1 = rcp_full<T>(b11 - l10 * b10);
+      sq1 = rsqrt_full<T>(b11 - l10 * b10);
+      id1 = sq1 * sq1;
     }
     my_id = pos == 0 ? id0 : id1;
+    my_sq = pos == 0 ? sq0 : sq1;
     // the coupling rows: W_hip = C_hip, W_ankle = C_ankle - l10 W_hip;  L_c = W / d
     {
       T W[6];
@@ -770,16 +828,17 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         Lc[r] = W[r] * my_id;
       }
       T *const lcw = E + O.lcw + lane * OctLds::LCW;
+      T *const wl = E + O.xs + lane * 6;  // (the impulses' slots: free until the sweep)
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         lcw[r] = Lc[r];
-        lcw[6 + r] = W[r];
+        wl[r] = W[r];
       }
       if (pos == 0) {
         T *const lf = E + O.legf + leg * 3;
         lf[0] = l10;
-        lf[1] = sqrt_t<T>(id0);
-        lf[2] = sqrt_t<T>(id1);
+        lf[1] = sq0;
+        lf[2] = sq1;
       }
     }
     OCT_SYNC();
@@ -787,6 +846,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     // the sums sum_lanes L_c[r] W[r'] of the Schur complement, entry e = r (r + 1) / 2 + r' on lane e mod 8 (three passes)
     {
       const T *const lcw = E + O.lcw;
+      const T *const wl = E + O.xs;
       T *const Ssum = E + O.fac;
 #pragma unroll
       for (int pass = 0; pass < 3; ++pass) {
@@ -798,7 +858,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         const int rp = e - (r * (r + 1)) / 2;
         T acc = T(0);
 #pragma unroll
-        for (int l = 0; l < 8; ++l) acc += lcw[l * OctLds::LCW + r] * lcw[l * OctLds::LCW + 6 + rp];
+        for (int l = 0; l < 8; ++l) acc += lcw[l * OctLds::LCW + r] * wl[l * 6 + rp];
         Ssum[e] = acc;
       }
     }
@@ -826,7 +886,9 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       for (int e = 0; e < 21; ++e) Sm[e] -= Ssum[e];
       static_for<0, 6>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        const T inv = rcp_full<T>(Sm[(k * (k + 1)) / 2 + k]);
+        const T rs = rsqrt_full<T>(Sm[(k * (k + 1)) / 2 + k]);
+        const T inv = rs * rs;
+        sq_ids[k] = rs;
         ids[k] = inv;
         T col[6];
         static_for<k + 1, 6>([&](auto rc) {
@@ -842,8 +904,6 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
           });
         });
       });
-#pragma unroll
-      for (int r = 0; r < 6; ++r) sq_ids[r] = sqrt_t<T>(ids[r]);
     }
     OCT_STAMP(4, Ls[14]);
     // ---- F. forward dynamics qdd = M^-1 (tau - C), integrate_euler_qdd (integrator.hpp:169-181)
@@ -901,7 +961,10 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     OCT_STAMP(5, qd_new);
   };
   // (two-wavefront build, behind barrier (2)) the largest contact count for the main wavefront, the root block's factors for the helper
-  auto main_get_count = [&]() { NA = __builtin_amdgcn_readfirstlane((int)sm[in_dim + 3]); };
+  auto main_get_count = [&]() {
+    NA = __builtin_amdgcn_readfirstlane((int)sm[in_dim + 3]);
+    na = (int)E[O.cp + 5 * OctLds::NCP];
+  };
   auto help_get_factors = [&]() {
     const T *const fac = E + O.fac;
 #pragma unroll
@@ -918,89 +981,122 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   //      environment with fewer contacts has zero rows in its empty slots).  Rows are solved a WINDOW of eight sweep
   //      positions at a time — lane == row, by the helper — and consumed by the main wavefront's sweep; two window buffers:
   //      the helper solves window w + 1 while the main wavefront sweeps window w.
-  T u = T(0), ur[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};  // u~ = sum_r z~_r x_r: the leg part on the dof lanes, the root part on every lane
-  // window wi of the sweep: Gauss-Seidel iteration wi / nwin, sweep positions w0 .. w0 + 7, row buffer wi & 1
-  auto help_rows = [&](int wi) {
+  T u = T(0), urm = T(0);  // u~ = sum_r z~_r x_r, distributed: my own dof's leg entry | root entry `lane` (lanes 6, 7: zero)
+  // window wi of the sweep: Gauss-Seidel iteration wi / nwin, sweep positions w0 .. w0 + 7, row buffer wi & 1; lane == row.
+  // Two halves.  rows_geom: the contact's Jacobian row along the row's direction — needs the kinematics only: the helper
+  // solves the first window's while the main wavefront is still factorising.  rows_solve: right-hand side, z~ = D^-1/2 L^-1 J^T,
+  // G — needs the factors and the velocities after integrate_euler_qdd: the main wavefront does the first window's itself
+  // (it holds the factors in registers), the helper the later ones.
+  auto rows_geom = [&](int wi) {
       const int nr = 3 * NA, nwin = (nr + 7) >> 3;
       const int w0 = (wi % nwin) * 8;
-      T *const Zs = E + O.win + (wi & 1) * (8 * OctLds::ZW);
-      {
-        // ---- the window's rows: lane == sweep position w0 + lane
-        const T *const cpx = E + O.cp;
-        const T *const swl = E + O.swl;
-        const T *const lcw = E + O.lcw;
-        const T *const qdp = E + O.qdp;
-        const T cfm = CT[TB::SC + TB::CFM], erp_dt = CT[TB::SC + TB::ERP_OVER_DT], rest = CT[TB::SC + TB::RESTITUTION];
-        const int s = w0 + lane;
-        const int tk = (s >= NA ? 1 : 0) + (s >= 2 * NA ? 1 : 0);
-        const int a = s - tk * NA;
-        const bool real = s < nr && a < na;
-        const int ac = real ? a : 0;
-        const T Pc[3] = {cpx[0 * OctLds::NCP + ac], cpx[1 * OctLds::NCP + ac], cpx[2 * OctLds::NCP + ac]};
-        const T dist = cpx[3 * OctLds::NCP + ac];
-        const int ol = real ? (int)cpx[4 * OctLds::NCP + ac] : 8;  // owner lane; 8: the root body
-        const bool on_leg = ol < 8;
-        const int hl = on_leg ? (ol & ~1) : 0;   // the hip lane of the contact's leg
-        const bool ank = on_leg && (ol & 1);     // the contact sits on the ankle link: both dofs of the leg
-        const T *const dir = CT + TB::SC + (tk == 0 ? TB::NB : (tk == 1 ? TB::T1 : TB::T2));
-        const T e[3] = {dir[0], dir[1], dir[2]};
-        // column of the point Jacobian along e: e . s_lin + P . (e x s_ang) = e . s_lin + (P x e) . s_ang  (jacobian.hpp:56-72)
-        T mo[3];
-        cross3(Pc, e, mo);
-        T sh[6], sa[6];
+      T *const row = E + O.win + (wi & 1) * (8 * OctLds::ZW) + lane * OctLds::ZW;
+      const T *const cpx = E + O.cp;
+      const T *const swl = E + O.swl;
+      const int s = w0 + lane;
+      const int tk = (s >= NA ? 1 : 0) + (s >= 2 * NA ? 1 : 0);
+      const int a = s - tk * NA;
+      const bool real = s < nr && a < na;
+      const int ac = real ? a : 0;
+      // (first batch of LDS reads: the contact and the row's direction — n, t1, t2 lie one behind the other in the table —;
+      //  every read unconditional, what a padding row reads is masked out at the end: no branch, no wait inside the batch)
+      const T Pc[3] = {cpx[0 * OctLds::NCP + ac], cpx[1 * OctLds::NCP + ac], cpx[2 * OctLds::NCP + ac]};
+      const T dist = cpx[3 * OctLds::NCP + ac];
+      const T owner = cpx[4 * OctLds::NCP + ac];
+      const T *const dir = CT + TB::SC + TB::NB + 3 * tk;
+      const T e[3] = {dir[0], dir[1], dir[2]};
+      const int ol = real ? (int)owner : 8;    // owner lane; 8: the root body
+      const bool on_leg = ol < 8;
+      const int hl = on_leg ? (ol & ~1) : 0;   // the hip lane of the contact's leg
+      const bool ank = on_leg && (ol & 1);     // the contact sits on the ankle link: both dofs of the leg
+      T sh[6], sa[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          sh[c] = swl[hl * 6 + c];
-          sa[c] = swl[(hl + 1) * 6 + c];
-        }
-        T z0 = on_leg ? dot3(e, sh + 3) + dot3(mo, sh) : T(0);
-        T z1 = ank ? dot3(e, sa + 3) + dot3(mo, sa) : T(0);
-        T zr[6];
-        zr[0] = e[0];
-        zr[1] = e[1];
-        zr[2] = e[2];
-        zr[3] = dot3(e, pA3) + mo[0];
-        zr[4] = dot3(e, pA4) + dot3(mo, A4);
-        zr[5] = dot3(e, pA5) + dot3(mo, A5);
-        T vrow = z0 * qdp[hl] + z1 * qdp[hl + 1];
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) vrow += zr[rr] * qdr_new[rr];
-        // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1 + e) n.rel_vel - erp dist / dt,  b_t = -t.rel_vel
-        const T brow = tk == 0 ? (T(1) + rest) * vrow - erp_dt * dist : vrow;
-        // forward substitution L z = J^T, leaves first: the contact's leg, then the root rows
-        const T *const lf = E + O.legf + (hl >> 1) * 3;
-        z1 -= lf[0] * z0;
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) zr[rr] -= lcw[hl * OctLds::LCW + rr] * z0 + lcw[(hl + 1) * OctLds::LCW + rr] * z1;
-        static_for<1, 6>([&](auto rc) {
-          constexpr int rr = decltype(rc)::value;
-          static_for<0, rr>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            zr[rr] -= Ls[(rr * (rr - 1)) / 2 + c] * zr[c];
-          });
-        });
-        // z~ = D^-1/2 z, G = z~ . z~
-        z0 *= lf[1];
-        z1 *= lf[2];
-        T g = z0 * z0 + z1 * z1;
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) {
-          zr[rr] *= sq_ids[rr];
-          g += zr[rr] * zr[rr];
-        }
-        const T ai = real ? rcp_full<T>(g + cfm) : T(0);
-        T *const row = Zs + lane * OctLds::ZW;
-        row[0] = real ? z0 : T(0);
-        row[1] = real ? z1 : T(0);
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) row[2 + rr] = real ? zr[rr] : T(0);
-        row[8] = real ? brow : T(0);
-        row[9] = ai;
-        row[10] = real ? g : T(0);
-        row[11] = on_leg ? (T)hl : T(-2);
-        OCT_STAMP(10, ai);
+      for (int c = 0; c < 6; ++c) {
+        sh[c] = swl[hl * 6 + c];
+        sa[c] = swl[(hl + 1) * 6 + c];
       }
+      // column of the point Jacobian along e: e . s_lin + P . (e x s_ang) = e . s_lin + (P x e) . s_ang  (jacobian.hpp:56-72)
+      T mo[3];
+      cross3(Pc, e, mo);
+      const T j0 = dot3(e, sh + 3) + dot3(mo, sh), j1 = dot3(e, sa + 3) + dot3(mo, sa);
+      row[0] = on_leg ? j0 : T(0);
+      row[1] = ank ? j1 : T(0);
+      row[2] = real ? e[0] : T(0);
+      row[3] = real ? e[1] : T(0);
+      row[4] = real ? e[2] : T(0);
+      row[5] = real ? dot3(e, pA3) + mo[0] : T(0);
+      row[6] = real ? dot3(e, pA4) + dot3(mo, A4) : T(0);
+      row[7] = real ? dot3(e, pA5) + dot3(mo, A5) : T(0);
+      row[8] = dist;
+      row[9] = real ? T(1) : T(0);
+      row[OctLds::Z_HL] = on_leg ? (T)hl : T(-2);
   };
+  auto rows_solve = [&](int wi) {
+      const int nr = 3 * NA, nwin = (nr + 7) >> 3;
+      const int w0 = (wi % nwin) * 8;
+      T *const row = E + O.win + (wi & 1) * (8 * OctLds::ZW) + lane * OctLds::ZW;
+      const T *const lcw = E + O.lcw;
+      const T *const qdp = E + O.qdp;
+      const T cfm = CT[TB::SC + TB::CFM], erp_dt = CT[TB::SC + TB::ERP_OVER_DT], rest = CT[TB::SC + TB::RESTITUTION];
+      const bool is_n = w0 + lane < NA;
+      T z0 = row[0], z1 = row[1], zr[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) zr[rr] = row[2 + rr];
+      const T dist = row[8];
+      const bool real = row[9] != T(0);
+      const T hlv = row[OctLds::Z_HL];
+      const int hl = hlv >= T(0) ? (int)hlv : 0;
+      // (second batch: the leg's velocities, factors and couplings)
+      T lch[6], lca[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        lch[c] = lcw[hl * OctLds::LCW + c];
+        lca[c] = lcw[(hl + 1) * OctLds::LCW + c];
+      }
+      const T qh = qdp[hl], qa = qdp[hl + 1];
+      const T *const lf = E + O.legf + (hl >> 1) * 3;
+      const T lf0 = lf[0], lf1 = lf[1], lf2 = lf[2];
+      const T vrow = ((z0 * qh + z1 * qa) + (zr[0] * qdr_new[0] + zr[1] * qdr_new[1])) +
+                     ((zr[2] * qdr_new[2] + zr[3] * qdr_new[3]) + (zr[4] * qdr_new[4] + zr[5] * qdr_new[5]));
+      // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1 + e) n.rel_vel - erp dist / dt,  b_t = -t.rel_vel
+      const T brow = is_n ? (T(1) + rest) * vrow - erp_dt * dist : vrow;
+      // forward substitution L z = J^T, leaves first: the contact's leg, then the root rows
+      z1 -= lf0 * z0;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) zr[rr] -= lch[rr] * z0 + lca[rr] * z1;
+      static_for<1, 6>([&](auto rc) {
+        constexpr int rr = decltype(rc)::value;
+        static_for<0, rr>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          zr[rr] -= Ls[(rr * (rr - 1)) / 2 + c] * zr[c];
+        });
+      });
+      // z~ = D^-1/2 z, G = z~ . z~
+      z0 *= lf1;
+      z1 *= lf2;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) zr[rr] *= sq_ids[rr];
+      const T g = ((z0 * z0 + z1 * z1) + (zr[0] * zr[0] + zr[1] * zr[1])) + ((zr[2] * zr[2] + zr[3] * zr[3]) + (zr[4] * zr[4] + zr[5] * zr[5]));
+      const T ai = real ? rcp_full<T>(g + cfm) : T(0);
+      row[0] = z0;  // (a padding row's Jacobian is zero: its z~, b and G are)
+      row[1] = z1;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) row[2 + rr] = zr[rr];
+      row[8] = T(0);
+      row[9] = T(0);
+      row[OctLds::Z_B] = real ? brow : T(0);
+      row[OctLds::Z_A] = ai;
+      row[OctLds::Z_G] = g;
+      OCT_STAMP(10, ai);
+  };
+  // ---- the sweep over a window (mb_constraint_solver.hpp:101-142), by the main wavefront.  A lone wavefront issues an
+  //      instruction every ~5 cycles whatever it depends on (tools/ubench/lone_wave_latency.hip): what a row costs is its
+  //      instruction count.  u~ = sum_r z~_r x_r is therefore DISTRIBUTED — lane j holds leg entry j (its own dof's) and root
+  //      entry j (lanes 6, 7: the row's zero slots) — so that z~_r . u~ is one multiply, one fma and ONE 8-lane sum; the clamp
+  //      runs redundantly on every lane; the normal rows and the friction rows of a window are separate loops (no selects on
+  //      the row's kind), the first Gauss-Seidel iteration a separate instance (x starts from 0: no G x_old, no read of the
+  //      previous impulse).  A row's operands are requested while the row before is processed (two register sets, the loop
+  //      unrolled by two: no copies).
   auto main_sweep = [&](int wi) {
       const int nr = 3 * NA, nwin = (nr + 7) >> 3;
       const int pit = wi / nwin;
@@ -1008,53 +1104,81 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       const T *const Zs = E + O.win + (wi & 1) * (8 * OctLds::ZW);
       T *const xs = E + O.xs;
       const T my_hip = (T)(lane & ~1);
-      {
-        // ---- the sweep over the window (mb_constraint_solver.hpp:101-142)
-        const T mu = CT[TB::SC + TB::FRICTION];
-        const int wn = nr - w0 < 8 ? nr - w0 : 8;
-        for (int k = 0; k < wn; ++k) {
-          const int s = w0 + k;
-          const int tk = (s >= NA ? 1 : 0) + (s >= 2 * NA ? 1 : 0);
-          const bool is_n = tk == 0;
-          const int dep = s - tk * NA;  // the normal row of the same contact
-          const T *const row = Zs + k * OctLds::ZW;
-          const T zl = row[11] == my_hip ? row[pos] : T(0);
-          T zrr[6];
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) zrr[rr] = row[2 + rr];
-          const T br = row[8], ar = row[9], gr = row[10];
-          const T x_old = pit > 0 ? xs[s] : T(0);
-          const T sdep = is_n ? T(0) : xs[dep];
-          // (two independent chains: the leg part's 8-lane sum and the root part)
-          const T jl = oct_sum(zl * u);
-          const T jr = (zrr[0] * ur[0] + zrr[1] * ur[1]) + (zrr[2] * ur[2] + zrr[3] * ur[3]) + (zrr[4] * ur[4] + zrr[5] * ur[5]);
-          const T delta = (jl + jr) - gr * x_old;
-          T xn = (br - delta) * ar;
-          const T sc = sdep < T(0) ? T(0) : sdep;  // where_lt(s, 0, 0, s)
-          const T lo = is_n ? T(0) : -mu * sc;
-          const T hi = is_n ? T(100000) : mu * sc;
-          xn = max_t<T>(xn, lo);
-          xn = min_t<T>(xn, hi);
-          const T dx = xn - x_old;
-          u += zl * dx;
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) ur[rr] += zrr[rr] * dx;
-          if (lane == 0) xs[s] = xn;
-          OCT_SYNC();
+      const T mu = CT[TB::SC + TB::FRICTION];
+      const int wn = nr - w0 < 8 ? nr - w0 : 8;
+      const int k_n = NA - w0 < 0 ? 0 : (NA - w0 < wn ? NA - w0 : wn);  // rows 0 .. k_n - 1 of the window are normal rows
+      struct Ops { T zs, zm, b, a, g, hl, sd, xo; };
+      auto request = [&](int k, Ops &o, auto firstc, auto normalc) {
+        constexpr bool FIRST = decltype(firstc)::value, NORMAL = decltype(normalc)::value;
+        const T *const row = Zs + k * OctLds::ZW;
+        o.zs = row[pos];        // my dof's leg entry, if the row's contact sits on my leg
+        o.zm = row[2 + lane];   // my root entry (lanes 6, 7: zero)
+        o.b = row[OctLds::Z_B];
+        o.a = row[OctLds::Z_A];
+        o.hl = row[OctLds::Z_HL];
+        if constexpr (!FIRST) {
+          o.g = row[OctLds::Z_G];
+          o.xo = xs[w0 + k];
         }
+        if constexpr (!NORMAL) o.sd = xs[w0 + k - ((w0 + k >= 2 * NA) ? 2 : 1) * NA];  // the impulse of the contact's normal row
+      };
+      auto process = [&](int k, const Ops &o, auto firstc, auto normalc) {
+        constexpr bool FIRST = decltype(firstc)::value, NORMAL = decltype(normalc)::value;
+        const T zl = o.hl == my_hip ? o.zs : T(0);
+        const T jw = oct_sum(zl * u + o.zm * urm);
+        T xn;
+        if constexpr (FIRST) xn = (o.b - jw) * o.a;
+        else xn = (o.b - (jw - o.g * o.xo)) * o.a;
+        if constexpr (NORMAL) {
+          xn = max_t<T>(xn, T(0));
+          xn = min_t<T>(xn, T(100000));
+        } else {
+          const T hi = mu * max_t<T>(o.sd, T(0));  // where_lt(s, 0, 0, s)
+          xn = max_t<T>(xn, -hi);
+          xn = min_t<T>(xn, hi);
+        }
+        T dx;
+        if constexpr (FIRST) dx = xn;
+        else dx = xn - o.xo;
+        u += zl * dx;
+        urm += o.zm * dx;
+        xs[w0 + k] = xn;  // (every lane the same value to the same slot)
+      };
+      auto run = [&](int k0, int k1, auto firstc, auto normalc) {  // rows k0 .. k1 - 1
+        if (k0 >= k1) return;
+        Ops A, B;
+        request(k0, A, firstc, normalc);
+        for (int k = k0; k < k1; k += 2) {
+          request(k + 1 < k1 ? k + 1 : k, B, firstc, normalc);
+          process(k, A, firstc, normalc);
+          if (k + 1 < k1) {
+            request(k + 2 < k1 ? k + 2 : k + 1, A, firstc, normalc);
+            process(k + 1, B, firstc, normalc);
+          }
+        }
+      };
+      if (pit == 0) {
+        run(0, k_n, std::true_type{}, std::true_type{});
+        run(k_n, wn, std::true_type{}, std::false_type{});
+      } else {
+        run(0, k_n, std::false_type{}, std::true_type{});
+        run(k_n, wn, std::false_type{}, std::false_type{});
       }
+      OCT_SYNC();
   };
-  auto windows = [&]() -> int { return NA > 0 ? (int)CT[TB::SC + TB::PGS_ITERATIONS] * ((3 * NA + 7) >> 3) : 0; };
+  auto windows = [&]() -> int { return NA > 0 ? pgs_iters * ((3 * NA + 7) >> 3) : 0; };
 
   auto main_fin = [&]() {
     // ================================ main: impulse, integration, reward ================================
     OCT_STAMP(6, u);
     if (NA > 0) {
       // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
-      T w = u * sqrt_t<T>(my_id);
+      T w = u * my_sq;
       T wr[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) wr[r] = ur[r] * sq_ids[r];
+      static_for<0, 6>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        wr[r] = oct_bcast<r>(urm) * sq_ids[r];  // (the root part of u~ back onto every lane)
+      });
       static_for<0, 5>([&](auto ic) {
         constexpr int r = 4 - decltype(ic)::value;
         static_for<r + 1, 6>([&](auto cc) {
@@ -1109,7 +1233,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         bool done = false;
         T reward = T(0);
         if (rm == TDS_REWARD_ANT) {
-          const T vel_x = (xr[0] - xr[in_dim]) / dt;
+          const T vel_x = (xr[0] - xr[in_dim]) * CT[TB::SC + TB::INV_DT];
           done = xr[2] < T(0.26);
           reward = done ? T(0) : vel_x;
         } else if (rm == TDS_REWARD_LAIKAGO) {
@@ -1178,7 +1302,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     //      (every step of a step-loop launch; floats on the multi-GPU wire format) and / or the caller's record (last step)
     if constexpr (LOOP) {
       if (ctl.obs_ring != nullptr) {  // wave-uniform
-        const int slot = (ctl.obs_first + it) % ctl.obs_slots;
+        const int slot = o_slot;
         const int rf = ctl.ring_flags;
         const bool f32w = (rf & TDS_RING_OBS_F32) != 0 || sizeof(TR) == 4;
         const int np = ctl.peer_arrive != nullptr ? ctl.n_peers : 0;
@@ -1282,7 +1406,8 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 
   // ================================ the step ================================
   // barriers of a two-wavefront workgroup: (1) the kinematics are in LDS; (2) factors, velocities, contact list and counts;
-  // one per row window (window wi is in LDS — the helper solves window wi + 1 while the main wavefront sweeps wi); (0) the
+  // one per row window from the second on (window wi is in LDS: the main wavefront solves and sweeps the first window
+  // itself while the helper solves the second, then the helper stays a window ahead of the sweep); (0) the
   // step's state, reward and done are in the LDS record — the helper stores the step's records while the main wavefront
   // starts the next step (it does not write the record before its own integration, two barriers on)
   if constexpr (W2) {
@@ -1293,9 +1418,17 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       OCT_BAR();  // (2)
       main_get_count();
       const int nw = windows();
-      for (int wi = 0; wi < nw; ++wi) {
-        OCT_BAR();
-        main_sweep(wi);
+      if (nw > 0) {
+        // the first window by the main wavefront itself (it holds the factors; the helper solves the second meanwhile)
+        rows_solve(0);
+        OCT_SYNC();
+        OCT_STAMP(12, tid);
+        main_sweep(0);
+        OCT_STAMP(13, u);
+        for (int wi = 1; wi < nw; ++wi) {
+          OCT_BAR();
+          main_sweep(wi);
+        }
       }
       main_fin();
       main_pool();
@@ -1303,11 +1436,14 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     } else {
       OCT_BAR();  // (1)
       help_np();
+      if (NA > 0) rows_geom(0);  // (the first window's Jacobian rows: the main wavefront completes them behind barrier (2))
       OCT_BAR();  // (2)
-      help_get_factors();
       const int nw = windows();
-      for (int wi = 0; wi < nw; ++wi) {
-        help_rows(wi);
+      if (nw > 1) help_get_factors();
+      for (int wi = 1; wi < nw; ++wi) {
+        rows_geom(wi);
+        OCT_SYNC();
+        rows_solve(wi);
         OCT_BAR();
       }
       OCT_BAR();  // (0)
@@ -1321,7 +1457,9 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     OCT_SYNC();
     const int nw = windows();
     for (int wi = 0; wi < nw; ++wi) {
-      help_rows(wi);
+      rows_geom(wi);
+      OCT_SYNC();
+      rows_solve(wi);
       OCT_SYNC();
       main_sweep(wi);
     }
@@ -1335,11 +1473,19 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   if (prof_on && (tid & 63) == 0) {
     // (main: stamps 0 .. 7 into buf[0 .. 7]; helper: stamps 8 .. 11 and the window stamp 10 into buf[8 .. 11]; one-wave: all)
 #pragma unroll
-    for (int k = 0; k < 12; ++k)
-      if ((k < 8 && is_main) || (k >= 8 && is_help)) tds_oct_prof_buf[k] = prof_t[k];
+    for (int k = 16; k < 24; ++k)
+      if (is_main) tds_oct_prof_buf[k] = prof_t[k];
+#pragma unroll
+    for (int k = 0; k < 14; ++k)
+      if (((k < 8 || k >= 12) && is_main) || (k >= 8 && k < 12 && is_help)) tds_oct_prof_buf[k] = prof_t[k];
     if (is_help) tds_oct_prof_buf[15] = (unsigned long long)NA;
   }
 #endif
+  if constexpr (LOOP) {
+    act_blk = act_blk + 1 >= ctl_arg.act_blocks ? 0 : act_blk + 1;
+    y_slot = y_slot + 1 >= ctl_arg.y_slots ? 0 : y_slot + 1;
+    o_slot = o_slot + 1 >= ctl_arg.obs_slots ? 0 : o_slot + 1;
+  }
   }  // ================================ end of the step loop ================================
 }
 
@@ -1359,30 +1505,32 @@ int tds_oct_workgroup_bytes(int input_dim) {
   return (oct_layout(input_dim).stride * 8 + TdsOctTab::TOTAL) * (int)sizeof(double);
 }
 
-// two_waves: the two-wavefront build (the host grants it while every workgroup of the launch is resident with at most two
-// wavefronts per SIMD: tds_api.hip)
+// build: 1 one wavefront per workgroup, 2 / 3 the two-wavefront builds (the host grants them while every workgroup of the
+// launch is resident with at most two wavefronts per SIMD / one: tds_api.hip)
 template <typename T, typename TR>
 int tds_launch_oct(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
-                   TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, bool two_waves) {
+                   TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, int build) {
   const OctOff O = oct_layout(h_model.input_dim);
   const int blocks = (n_envs + 7) / 8;
   const size_t shmem = ((size_t)O.stride * 8 + TdsOctTab::TOTAL) * sizeof(T);
   // one plain step without rings: the straight-line form; K steps, record rings: the step-loop form
   const bool one_step = ctl.nsub == 1 && ctl.obs_ring == nullptr && ctl.y_ring == nullptr;
-#define OCT_LAUNCH(LOOP_, W2_)                                                                                              \
-  hipLaunchKernelGGL((tds_oct_kernel<T, TR, LOOP_, W2_>), dim3(blocks), dim3(W2_ ? 128 : 64), shmem, stream, d_model, x_in, \
+#define OCT_LAUNCH(LOOP_, B_)                                                                                                 \
+  hipLaunchKernelGGL((tds_oct_kernel<T, TR, LOOP_, B_>), dim3(blocks), dim3(B_ >= 2 ? 128 : 64), shmem, stream, d_model, x_in, \
                      y_out, actions, x_feedback, obs_out, ctl, n_envs, O)
   if (one_step) {
-    if (two_waves) OCT_LAUNCH(false, true);
-    else OCT_LAUNCH(false, false);
+    if (build == 3) OCT_LAUNCH(false, 3);
+    else if (build == 2) OCT_LAUNCH(false, 2);
+    else OCT_LAUNCH(false, 1);
   } else {
-    if (two_waves) OCT_LAUNCH(true, true);
-    else OCT_LAUNCH(true, false);
+    if (build == 3) OCT_LAUNCH(true, 3);
+    else if (build == 2) OCT_LAUNCH(true, 2);
+    else OCT_LAUNCH(true, 1);
   }
 #undef OCT_LAUNCH
   return (int)hipGetLastError();
 }
 template int tds_launch_oct<double, double>(const DevModel<double> *, const DevModel<double> &, const double *, double *,
-                                            const double *, double *, double *, int, hipStream_t, const TdsStepCtl &, bool);
+                                            const double *, double *, double *, int, hipStream_t, const TdsStepCtl &, int);
 template int tds_launch_oct<double, float>(const DevModel<double> *, const DevModel<double> &, const float *, float *,
-                                           const float *, float *, float *, int, hipStream_t, const TdsStepCtl &, bool);
+                                           const float *, float *, float *, int, hipStream_t, const TdsStepCtl &, int);

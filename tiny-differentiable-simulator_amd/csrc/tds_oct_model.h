@@ -11,7 +11,8 @@ struct TdsOctTab {
   static constexpr int LSTR = 58;
   // the lane's record
   static constexpr int S = 0, XT = 6, MASS = 18, COM = 19, INER = 22, IPOSE = 31, STIFF = 32, DAMP = 33, JT = 34, ACT = 35,
-                       CPR0 = 36, CPL0 = 37, CPR1 = 40, CPL1 = 41, VIS = 44;  // VIS: 12 (rotation 9 | translation 3)
+                       CPR0 = 36, CPL0 = 37, CPR1 = 40, CPL1 = 41, VIS = 44,  // VIS: 12 (rotation 9 | translation 3)
+                       AXINV = 56;  // 1 / |S_angular| (REVOLUTE_AXIS joints: the axis-angle quaternion's normalisation, link.hpp:256-261)
   // the root body's block (link 5)
   static constexpr int ROOT = 8 * LSTR;
   static constexpr int R_MASS = 0, R_COM = 1, R_INER = 4, R_CPR = 13 /* < 0: no sphere */, R_CPL = 14, R_VIS = 17;
@@ -19,7 +20,7 @@ struct TdsOctTab {
   static constexpr int SC = ROOT + 30;
   static constexpr int DT = 0, ACTION_LIMIT = 1, BASE_T = 2, GRAV = 5, PLANE_N = 8, PLANE_C = 11, NB = 12, T1 = 15, T2 = 18, CFM = 21,
                        ERP_OVER_DT = 22, RESTITUTION = 23, FRICTION = 24, BASE_R8 = 25, NUM_VISUALS = 26, REWARD_MODE = 27,
-                       PGS_ITERATIONS = 28, PACK_VISUALS = 29, OUTPUT_DIM = 30;
+                       PGS_ITERATIONS = 28, PACK_VISUALS = 29, OUTPUT_DIM = 30, INV_DT = 31;
   static constexpr int TOTAL = SC + 32;
 };
 
@@ -59,6 +60,10 @@ static void tds_oct_detect(const tds_model_t *m, DevModel<T> *d, int ncp, bool l
         r[TB::STIFF] = d->stiffness[li];
         r[TB::DAMP] = d->damping[li];
         r[TB::JT] = (T)d->joint_type[li];
+        {
+          const double ax2 = (double)d->S[0][li] * d->S[0][li] + (double)d->S[1][li] * d->S[1][li] + (double)d->S[2][li] * d->S[2][li];
+          r[TB::AXINV] = ax2 > 0.0 ? (T)(1.0 / sqrt(ax2)) : T(0);
+        }
         r[TB::ACT] = (T)d->act_index[li];
         for (int e = 0; e < 2; ++e) {
           const int c = 1 + 2 * ln + e;
@@ -78,6 +83,7 @@ static void tds_oct_detect(const tds_model_t *m, DevModel<T> *d, int ncp, bool l
         for (int k = 0; k < 12; ++k) rt[TB::R_VIS + k] = d->vis_X[k][0];
       T *const sc = t + TB::SC;
       sc[TB::DT] = d->dt;
+      sc[TB::INV_DT] = (T)(1.0 / (double)d->dt);
       sc[TB::ACTION_LIMIT] = d->action_limit;
       for (int k = 0; k < 3; ++k) {
         sc[TB::BASE_T + k] = d->base_t[k];

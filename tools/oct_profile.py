@@ -53,12 +53,16 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     assert L.tds_oct_prof_read(buf, -1) == 0
-    t = [int(buf[k]) for k in range(16)]
+    t = [int(buf[k]) for k in range(32)]
     print(f"ant x {n}: 1000-step ring launch {ev0.elapsed_time(ev1) * 1e3 / 1000:.2f} us per step (stamped build, option oct_w2 = {w2}); "
           f"iteration {it} of workgroup 3: NA = {t[15]}")
     print(f"  main wavefront, top of the step -> end of its step: {t[7] - t[0]} cycles")
     for k in range(7):
         print(f"  {t[k + 1] - t[k]:6d}  {MAIN[k]}")
+    if w2:
+        print(f"    of the contact phase: first window solved by the main wavefront {t[12] - t[5]}, swept {t[13] - t[12]}, remaining windows {t[6] - t[13]}")
+    if w2:
+        print("    rows of the first window, end of each row's chain after the window was solved: " + " ".join(str(t[16 + k] - t[12]) for k in range(8)))
     print("  helper (cycles relative to the main wavefront's top of step):")
     print(f"    narrowphase done at {t[8] - t[0]}, visual poses out at {t[9] - t[0]}, last row window solved at {t[10] - t[0]}, records out at {t[11] - t[0]}")
 
