@@ -134,6 +134,16 @@ def pmc_traffic(model, n, dtype):
         return None, None
 
 
+def sq_counters(model, n, dtype):
+    """VALU issue fraction of the dominant kernel from the committed SQ-counter pass (profiles/sq_counters.json: VALU
+    instructions per launch x 4 cycles / (SIMDs x launch cycles) — see the file's _comment)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
+            return json.load(f)[model][str(n)][dtype]
+    except Exception:
+        return {}
+
+
 def pmc_traffic_loop(model, n, dtype, steps_per_launch):
     """The same for ONE step-loop launch of steps_per_launch steps: measured on a 500-step launch (its traffic is the
     action block per step plus the records once: linear in the steps to within the records)."""
@@ -827,19 +837,26 @@ def run(args, n, rank, local_rank, world, secondary, config5):
                 # records are written once per launch — measured on the step-loop launch itself
                 traffic, traffic_src = pmc_traffic_loop(args.model, n, args.dtype, spl)
             arith = "f32" if args.dtype == "f32-pure" else "f64"
+            # which kernel the timed launches ran (tds_hip_single_step_kernel: the star-shaped robots have their own)
+            kernel_name = {"oct8": "tds_oct_kernel", "quad16": "tds_quad_kernel"}.get(sim.single_step_kernel()[0], "tds_step_kernel")
+            sq_issue = sq_counters(args.model, n, args.dtype)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "tds_step_kernel", "kernel_ms_avg": kernel_ms * spl, "steps_per_launch": spl,
+                    "kernel": kernel_name, "kernel_ms_avg": kernel_ms * spl, "steps_per_launch": spl,
                     "kernel_ms_isolated": kernel_ms_isolated,
                     "algorithmic_bytes_per_launch": n * bytes_per_env_step * spl // conc,
                     "traffic_over_algorithmic": (traffic / (n * bytes_per_env_step * spl // conc)) if traffic else None,
                     "launches_in_flight": conc,
                     "achieved_per_launch": achieved / conc,
-                    # secondary view: flops of the reference's dense formulation per env-step
-                    "algorithmic_flops_per_env_step": ALG_FLOPS.get(args.model),
-                    "algorithmic_tflops": (ALG_FLOPS[args.model] * n / (kernel_ms * 1e-3) / 1e12
-                                           if args.model in ALG_FLOPS else None),
+                    # secondary view: flops of the reference's DENSE formulation per env-step (dense 51 x 14 x 51
+                    # products the kernels never form: NOT executed flops; the executed share is valu_issue_frac)
+                    "dense_formulation_flops_per_env_step": ALG_FLOPS.get(args.model),
+                    "dense_formulation_tflops": (ALG_FLOPS[args.model] * n / (kernel_ms * 1e-3) / 1e12
+                                                 if args.model in ALG_FLOPS else None),
                     "valu_peak_tflops": 78.6 if arith == "f64" else 157.3,
+                    # what the kernel actually keeps busy: VALU instructions issued / issue slots, from the committed SQ-counter
+                    # pass of this kernel (profiles/sq_counters.json; counters cannot be read from inside this process)
+                    "valu_issue_frac": sq_issue.get("valu_issue_frac"), "valu_issue_source": sq_issue.get("source"),
                     "note": "algorithmic bytes = (input_dim+output_dim)*sizeof(T) per env-step (SURVEY 8d: one read of the x "
                             "record + one write of the y record); achieved = launches_in_flight x algorithmic_bytes_per_launch "
                             "/ kernel_ms_avg; a step-loop launch keeps the state in LDS: per step it reads an action block "
@@ -908,8 +925,8 @@ def run(args, n, rank, local_rank, world, secondary, config5):
                            f"tds_hip_shard_step_many), {args.gather_dtype if args.dtype == 'f64' else 'f32'} on the wire (the records are "
                            f"computed and fed back in {'f64' if args.dtype == 'f64' else 'f32'} on the owning GPU), overlapped with "
                            f"the following steps" if multi else ""),
-                       "lanes_per_env": sim.kernel_info()["lanes_per_env"],
-                       "lds_bytes_per_env": sim.kernel_info()["lds_bytes_per_env"]},
+                       "lanes_per_env": sim.single_step_kernel()[1],
+                       "lds_bytes_per_env": sim.single_step_kernel()[2]},
             "roofline": roof, "finite": finite, "nonfinite_envs": bad_envs,
         }
         if substep_fused is not None:

@@ -62,6 +62,14 @@ __device__ int tds_oct_prof_iter = 500;
 #define OCT_STAMP(k, pin) do { } while (0)
 #endif
 
+// -DTDS_OCT_MARKS: "; OCTMARK <name>" comment lines in the assembly at the phase boundaries (tools/oct_isa_phases.py counts the
+// instructions between them: on a lone wavefront the instruction count IS the time)
+#ifdef TDS_OCT_MARKS
+#define OCT_MARK(name) asm volatile("; OCTMARK " name ::: "memory")
+#else
+#define OCT_MARK(name) do { } while (0)
+#endif
+
 namespace {
 
 #define OCT_SYNC()                                             \
@@ -121,10 +129,7 @@ __device__ __forceinline__ float oct_bcast(float v) {
 // < 1 ulp) — ~35 instructions where the library routine takes ~90 with its branch to the Payne-Hanek reduction; angles
 // beyond 1e5 rad (no simulation gets there, but a caller may hand in anything) take the library routine, wave-uniformly
 __device__ __forceinline__ void oct_sincos(double x, double *sn, double *cs) {
-  if (__builtin_expect(__any(!(__builtin_fabs(x) < 1.0e5)), 0)) {
-    sincos(x, sn, cs);
-    return;
-  }
+  const bool big = !(__builtin_fabs(x) < 1.0e5);
   const double k = __builtin_rint(x * 6.36619772367581382433e-01);
   double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
   r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
@@ -144,8 +149,17 @@ __device__ __forceinline__ void oct_sincos(double x, double *sn, double *cs) {
   const double c0 = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
   const bool swap = (q & 1) != 0;
   const double ss = swap ? c0 : s0, cc = swap ? s0 : c0;
-  *sn = (q & 2) ? -ss : ss;
-  *cs = ((q + 1) & 2) ? -cc : cc;
+  double s_ = (q & 2) ? -ss : ss, c_ = ((q + 1) & 2) ? -cc : cc;
+  // (the lanes beyond 1e5 — or NaN — take the library routine; the OTHER lanes of the wavefront keep their own result: an
+  //  environment's bits must not depend on a wavefront-mate that has left the finite range)
+  if (__builtin_expect(__any(big), 0)) {
+    double s2, c2;
+    sincos(x, &s2, &c2);
+    s_ = big ? s2 : s_;
+    c_ = big ? c2 : c_;
+  }
+  *sn = s_;
+  *cs = c_;
 }
 __device__ __forceinline__ void oct_sincos(float x, float *sn, float *cs) { sincosf(x, sn, cs); }
 
@@ -304,6 +318,9 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   T Sl[6], R[9], p[3], sw[6], v[6], a0[6];
   T R5[9], P[3], A4[3], A5[3], pA3[3], pA4[3], pA5[3], v5[6], a5[6];
   T Lc[6], l10, id0, id1, sq0, sq1, my_id, my_sq, Ls[15], ids[6], sq_ids[6], qd_new, qdr_new[6];
+  T Cb, Cr[6], It[10];  // (main wavefront: bias forces of my dof / the root dofs, the robot's total inertia — across its barriers)
+  T u = T(0), urm = T(0);  // u~ = -dt y~ + sum_r z~_r x_r, distributed: my own dof's leg entry | root entry `lane` (lanes 6, 7: zero)
+  T u_init = T(0), urm_init = T(0);
   int na = 0, NA = 0;
 
   // the root body's frame and the root's revolute axes from the six sines / cosines (kinematics.hpp:64-97; tds_kernels.hip
@@ -346,6 +363,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         }
       }
     }
+    OCT_MARK("main_top");
     q = xr[dq];
     qd = xr[nq + dq];
     // ---- PD controller (locomotion_contact_simulation.h:168-258); joint stiffness / damping
@@ -367,58 +385,46 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       }
       tau -= CL[TB::STIFF] * q + CL[TB::DAMP] * qd;
     }
+    OCT_MARK("main_jcalc");
     // ---- B. jcalc (link.hpp:229-287)
 #pragma unroll
     for (int k = 0; k < 6; ++k) Sl[k] = CL[TB::S + k];
     T Rp[9], tp[3];
     {
-      const int jt = (int)CL[TB::JT];
-      T RT[9], tT[3];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) RT[k] = CL[TB::XT + k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) tT[k] = CL[TB::XT + 9 + k];
+      // the joint transform: R_J = cos I + sin [n]x + (1 - cos) n n^T about the joint's unit axis (table: n, n n^T; a prismatic
+      // joint's angle is multiplied by 0), t_J = S_linear q (zero for a revolute joint) — every joint type of link.hpp:229-287
+      // without a branch; X_parent = X_T X_J, and where every X_T rotation is the identity (the Ant) no product at all
       T sn, cs;
-      oct_sincos(jt == TDS_JOINT_REVOLUTE_AXIS ? q * T(0.5) : q, &sn, &cs);
-      const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
-      const bool pris = jt >= TDS_JOINT_PRISMATIC_X && jt <= TDS_JOINT_PRISMATIC_AXIS;
-      T RJ[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
-      T tJ[3] = {T(0), T(0), T(0)};
-      if (pris) {
-        tJ[0] = Sl[3] * q;
-        tJ[1] = Sl[4] * q;
-        tJ[2] = Sl[5] * q;
+      oct_sincos(q * CL[TB::ROTF], &sn, &cs);
+      const T c1 = T(1) - cs;
+      const T nx = CL[TB::NAX], ny = CL[TB::NAX + 1], nz = CL[TB::NAX + 2];
+      T RJ[9];
+      RJ[0] = cs + c1 * CL[TB::NN + 0];
+      RJ[1] = c1 * CL[TB::NN + 1] - sn * nz;
+      RJ[2] = c1 * CL[TB::NN + 2] + sn * ny;
+      RJ[3] = c1 * CL[TB::NN + 1] + sn * nz;
+      RJ[4] = cs + c1 * CL[TB::NN + 3];
+      RJ[5] = c1 * CL[TB::NN + 4] - sn * nx;
+      RJ[6] = c1 * CL[TB::NN + 2] - sn * ny;
+      RJ[7] = c1 * CL[TB::NN + 4] + sn * nx;
+      RJ[8] = cs + c1 * CL[TB::NN + 5];
+      const T tJ[3] = {Sl[3] * q, Sl[4] * q, Sl[5] * q};
+      if (CT[TB::SC + TB::XT_IDENT] != T(0)) {  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rp[k] = RJ[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tp[k] = CL[TB::XT + 9 + k] + tJ[k];
+      } else {
+        T RT[9], r[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) RT[k] = CL[TB::XT + k];
+        mat3_mul(RT, RJ, Rp);
+        mat3_mulv(RT, tJ, r);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tp[k] = CL[TB::XT + 9 + k] + r[k];
       }
-      if (rev) {
-        if (jt == TDS_JOINT_REVOLUTE_X) {
-          RJ[4] = cs; RJ[5] = -sn; RJ[7] = sn; RJ[8] = cs;
-        } else if (jt == TDS_JOINT_REVOLUTE_Y) {
-          RJ[0] = cs; RJ[2] = sn; RJ[6] = -sn; RJ[8] = cs;
-        } else if (jt == TDS_JOINT_REVOLUTE_Z) {
-          RJ[0] = cs; RJ[1] = -sn; RJ[3] = sn; RJ[4] = cs;
-        } else {  // axis-angle quaternion with the UNNORMALISED axis (link.hpp:256-261)
-          // (1 / |axis| from the table; the quaternion's squared norm n2 is 1 to rounding — sin^2 + cos^2 — so 2 / n2, the
-          //  reference's quat_to_matrix scale, is 2 (2 - n2) to the last bit: one Newton step from 1, error (n2 - 1)^2)
-          const T sh = sn * CL[TB::AXINV];
-          const T qx = Sl[0] * sh, qy = Sl[1] * sh, qz = Sl[2] * sh, qw = cs;
-          const T n2 = qx * qx + qy * qy + qz * qz + qw * qw;
-          const T s2 = T(4) - T(2) * n2;
-          const T xs_ = qx * s2, ys = qy * s2, zs = qz * s2;
-          const T wx = qw * xs_, wy = qw * ys, wz = qw * zs;
-          const T xx = qx * xs_, xy = qx * ys, xz = qx * zs;
-          const T yy = qy * ys, yz = qy * zs, zz = qz * zs;
-          RJ[0] = T(1) - (yy + zz); RJ[1] = xy - wz; RJ[2] = xz + wy;
-          RJ[3] = xy + wz; RJ[4] = T(1) - (xx + zz); RJ[5] = yz - wx;
-          RJ[6] = xz - wy; RJ[7] = yz + wx; RJ[8] = T(1) - (xx + yy);
-        }
-      }
-      mat3_mul(RT, RJ, Rp);
-      T r[3];
-      mat3_mulv(RT, tJ, r);
-      tp[0] = tT[0] + r[0];
-      tp[1] = tT[1] + r[1];
-      tp[2] = tT[2] + r[2];
     }
+    OCT_MARK("main_rootsincos");
     // ---- C. the root chain in closed form, on every lane.  The three root angles' sines and cosines: lanes 0, 1, 2 of the
     //         environment, broadcast (and, two-wavefront build, handed to the helper behind the links' world transforms)
     {
@@ -436,6 +442,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       }
       root_frame(sx, cx, sy, cy, sz, cz);
     }
+    OCT_MARK("main_rootvel");
     {
       const T d0 = xr[nq + 0], d1 = xr[nq + 1], d2 = xr[nq + 2], d3 = xr[nq + 3], d4 = xr[nq + 4], d5 = xr[nq + 5];
       const T U[3] = {d0, d1, d2};
@@ -471,6 +478,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         a5[3 + k] = (l3[k] + l4[k] + l5[k]) - CT[TB::SC + TB::GRAV + k];
       }
     }
+    OCT_MARK("main_legs");
     // ---- the legs: the ankle composes its joint transform with the hip's (one step of a segmented scan along the pair),
     //      the root's pose in front; prefix sums of the joint velocities and of the velocity-product accelerations
     {
@@ -527,6 +535,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         a0[k] = a5[k] + (cb[k] + (take ? sh : T(0)));
       }
     }
+    OCT_MARK("main_publish_kin");
     // my world motion axis, for the rows of the contacts (lane-dependent reads in the row windows); two-wavefront build: my
     // link's world transform for the helper's narrowphase and visual poses (the slots of the second row window)
     {
@@ -541,6 +550,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         for (int k = 0; k < 3; ++k) kin[9 + k] = p[k];
       }
     }
+    OCT_MARK("main_kin_end");
     OCT_STAMP(1, sw[5]);
   };
 
@@ -589,6 +599,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   };
 
   auto help_np = [&]() {
+    OCT_MARK("help_np");
     // ================================ helper: narrowphase, visual poses ================================
     if constexpr (W2) {  // my link's world transform and the root's sines / cosines, from the main wavefront
       const T *const kin = E + O.win + 8 * OctLds::ZW + lane * 12;
@@ -655,12 +666,14 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         const int c = __popc((unsigned)((b0 >> (g * 8)) & 0xFFull)) + __popc((unsigned)((b1 >> (g * 8)) & 0xFFull)) + (int)((bt >> (g * 8)) & 1ull);
         NA = c > NA ? c : NA;
       }
-      if constexpr (W2) {  // (for the main wavefront, which solves the first row window itself)
-        if ((tid & 63) == 0) sm[in_dim + 3] = (T)NA;  // the spare slot of environment 0's record
-        if (lane == 0) cpx[5 * OctLds::NCP] = (T)na;
+      if constexpr (W2) {  // (for the main wavefront's sweep: the spare slot of environment 0's record)
+        if ((tid & 63) == 0) sm[in_dim + 3] = (T)NA;
       }
     }
     OCT_STAMP(8, na);
+  };
+  auto help_poses = [&]() {
+    OCT_MARK("help_signal_poses");
     if constexpr (LOOP) {
       // the records of step it - 1 — stored at the end of the iteration before, long acknowledged by now: the wait costs
       // nothing here, in front of this step's first stores — are counted in
@@ -696,6 +709,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       pose_out(R, p, CL + TB::VIS, 1 + lane);
       if (lane == 7) pose_out(R5, P, CT + TB::ROOT + TB::R_VIS, 0);
     }
+    OCT_MARK("help_np_end");
     OCT_STAMP(9, na);
   };
 
@@ -756,11 +770,13 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #pragma unroll
       for (int k = 0; k < 6; ++k) fc[k] += Ia[k];
     };
+    OCT_MARK("main_rigid");
     T Ic[10], fc[6];
     rigid(R, p, CL[TB::MASS], CL + TB::COM, CL + TB::INER, v, a0, Ic, fc);
-    T It[10], ft[6];  // the root body's; below: + the legs' = the whole robot's
+    T ft[6];  // (It, ft) the root body's; below: + the legs' = the whole robot's
     rigid(R5, P, CT[TB::ROOT + TB::R_MASS], CT + TB::ROOT + TB::R_COM, CT + TB::ROOT + TB::R_INER, v5, a5, It, ft);
     OCT_STAMP(2, ft[5]);
+    OCT_MARK("main_totals");
     // ---- E. composite inertia / bias force (CRBA, mass_matrix.hpp:39-56): the robot's totals = root + every leg link
     //         (8-lane sums of the rigid values: every lane the same bits); the hip's composite = hip + ankle
 #pragma unroll
@@ -774,15 +790,15 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #pragma unroll
       for (int k = 0; k < 10; ++k) Ic[k] += recv * pair_bcast<1>(Ic[k]);
     }
+    OCT_MARK("main_FC");
     // F = Ic s, C = s . f of my dof
     T Fc[6];
     times_inertia(Ic, sw, Fc);
-    const T Cb = dot6(sw, fc);
+    Cb = dot6(sw, fc);
     // the root's revolute axes as (angular | linear); the prismatic ones are (0 | e_k)
     const T ax3[6] = {T(1), T(0), T(0), pA3[0], pA3[1], pA3[2]}, ax4[6] = {A4[0], A4[1], A4[2], pA4[0], pA4[1], pA4[2]},
             ax5[6] = {A5[0], A5[1], A5[2], pA5[0], pA5[1], pA5[2]};
-    T Cr[6];  // bias forces of the root dofs
-    Cr[0] = ft[3];
+    Cr[0] = ft[3];  // bias forces of the root dofs
     Cr[1] = ft[4];
     Cr[2] = ft[5];
     Cr[3] = dot6(ax3, ft);
@@ -804,6 +820,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       Cc[4] = dot6(Fc, ax4);
       Cc[5] = dot6(Fc, ax5);
     }
+    OCT_MARK("main_legldl");
     // ---- H. LDL^T.  The leg block on both lanes of the pair
     {
       const T b00 = pair_bcast<0>(Bm0);
@@ -841,27 +858,30 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         lf[2] = sq1;
       }
     }
-    OCT_SYNC();
     OCT_STAMP(3, Lc[5]);
+  };
+  auto main_dyn2 = [&]() {
+    OCT_MARK("main_schur");
     // the sums sum_lanes L_c[r] W[r'] of the Schur complement, entry e = r (r + 1) / 2 + r' on lane e mod 8 (three passes)
     {
       const T *const lcw = E + O.lcw;
       const T *const wl = E + O.xs;
       T *const Ssum = E + O.fac;
+      const int code = (int)CL[TB::SCHUR];  // (which entries this lane sums: table)
 #pragma unroll
       for (int pass = 0; pass < 3; ++pass) {
-        int e = lane + 8 * pass;
-        e = e < 21 ? e : 20;
-        int r = 0;
-#pragma unroll
-        for (int k = 1; k < 6; ++k) r += e >= (k * (k + 1)) / 2 ? 1 : 0;
-        const int rp = e - (r * (r + 1)) / 2;
+        const int rc = (code >> (6 * pass)) & 63;
+        const int r = rc >> 3, rp = rc & 7;
+        const int e = (r * (r + 1)) / 2 + rp;
         T acc = T(0);
 #pragma unroll
         for (int l = 0; l < 8; ++l) acc += lcw[l * OctLds::LCW + r] * wl[l * 6 + rp];
         Ssum[e] = acc;
       }
     }
+    OCT_MARK("main_Rblock");
+    const T ax3[6] = {T(1), T(0), T(0), pA3[0], pA3[1], pA3[2]}, ax4[6] = {A4[0], A4[1], A4[2], pA4[0], pA4[1], pA4[2]},
+            ax5[6] = {A5[0], A5[1], A5[2], pA5[0], pA5[1], pA5[2]};
     // the root block R[r][r'] = s_r . (It s_r') in registers (packed lower triangle, r (r + 1) / 2 + r'): the prismatic
     // axes are unit vectors, It e_k = (h x e_k | m e_k)
     T Sm[21];
@@ -879,6 +899,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       Sm[15] = F5[3]; Sm[16] = F5[4]; Sm[17] = F5[5]; Sm[18] = dot6(ax5, F3); Sm[19] = dot6(ax5, F4); Sm[20] = dot6(ax5, F5);
     }
     OCT_SYNC();
+    OCT_MARK("main_ldl6");
     // ... the Schur complement, factorised redundantly on every lane: Ls (strictly lower, row-major packed), 1 / D
     {
       const T *const Ssum = E + O.fac;
@@ -906,45 +927,8 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       });
     }
     OCT_STAMP(4, Ls[14]);
-    // ---- F. forward dynamics qdd = M^-1 (tau - C), integrate_euler_qdd (integrator.hpp:169-181)
-    //   leaves-first system  [B  C^T; C  R] = L D L^T,  unknown (x_leg on the dof lanes, x_root[6] on every lane)
-    {
-      // forward: legs, pair-local
-      T y = tau - Cb;
-      y -= (pos == 1 ? l10 : T(0)) * pair_bcast<0>(y);
-      // root: y_r = b_r - sum_lanes L_c[r] y, then the root block's own forward substitution
-      T yr[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) yr[r] = -Cr[r] - oct_sum(Lc[r] * y);
-      static_for<1, 6>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        static_for<0, r>([&](auto cc) {
-          constexpr int c = decltype(cc)::value;
-          yr[r] -= Ls[(r * (r - 1)) / 2 + c] * yr[c];
-        });
-      });
-      // diagonal, backward: root first
-      T xrt[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) xrt[r] = yr[r] * ids[r];
-      static_for<0, 5>([&](auto ic) {
-        constexpr int r = 4 - decltype(ic)::value;
-        static_for<r + 1, 6>([&](auto cc) {
-          constexpr int c = decltype(cc)::value;
-          xrt[r] -= Ls[(c * (c - 1)) / 2 + r] * xrt[c];
-        });
-      });
-      // legs: x = y / d - L_c . x_root - l10 x_ankle (hip)
-      T x = y * my_id;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) x -= Lc[r] * xrt[r];
-      x -= (pos == 0 ? l10 : T(0)) * pair_bcast<1>(x);
-      qd_new = qd + x * dt;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) qdr_new[r] = xr[nq + r] + xrt[r] * dt;
-    }
-    // for the rows of the contacts: the velocities after integrate_euler_qdd; two-wavefront build: + the root block's factors
-    E[O.qdp + lane] = qd_new;
+    OCT_MARK("main_fd");
+    // two-wavefront build: the root block's factors for the helper's rows
     if constexpr (W2) {
       T *const fac = E + O.fac;  // (the Schur sums are dead: every lane has read them)
       OCT_SYNC();
@@ -952,28 +936,48 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #pragma unroll
         for (int k = 0; k < 15; ++k) fac[k] = Ls[k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          fac[15 + k] = sq_ids[k];
-          fac[21 + k] = qdr_new[k];
-        }
+        for (int k = 0; k < 6; ++k) fac[15 + k] = sq_ids[k];
       }
     }
-    OCT_STAMP(5, qd_new);
+    OCT_MARK("main_dyn_end");
+  };
+  // ---- F. forward dynamics, the forward half (forward_dynamics.hpp:11-326 as qdd = M^-1 (tau - C); integrator.hpp:169-181):
+  //      y~ = D^-1/2 L^-1 (tau - C) in the leaves-first system [B C^T; C R] = L D L^T — the leg part on the dof lanes, the root
+  //      part on every lane.  The backward half is shared with the contact impulse: the constraint rows' right-hand sides
+  //      are formed with the velocities BEFORE the step (rows_geom), and the sweep starts from u~ = -dt y~ instead of 0 —
+  //      z~_r . (dt y~) is exactly the J_r (dt qdd) the reference's b_r contains — so that ONE back-substitution at the end
+  //      gives  qd_new = qd - L^-T D^-1/2 u~  = qd + dt qdd - M^-1 J^T p  (with no contact: the plain forward dynamics).
+  auto main_fd = [&]() {
+    OCT_MARK("main_fd");
+    T y = tau - Cb;
+    y -= (pos == 1 ? l10 : T(0)) * pair_bcast<0>(y);
+    T yr[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) yr[r] = -Cr[r] - oct_sum(Lc[r] * y);
+    static_for<1, 6>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      static_for<0, r>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        yr[r] -= Ls[(r * (r - 1)) / 2 + c] * yr[c];
+      });
+    });
+    u = -dt * (y * my_sq);
+    T sel = yr[0] * sq_ids[0];
+#pragma unroll
+    for (int r = 1; r < 6; ++r) sel = lane == r ? yr[r] * sq_ids[r] : sel;
+    urm = lane < 6 ? -dt * sel : T(0);
+    u_init = u;
+    urm_init = urm;
+    OCT_STAMP(5, u);
   };
   // (two-wavefront build, behind barrier (2)) the largest contact count for the main wavefront, the root block's factors for the helper
-  auto main_get_count = [&]() {
-    NA = __builtin_amdgcn_readfirstlane((int)sm[in_dim + 3]);
-    na = (int)E[O.cp + 5 * OctLds::NCP];
-  };
+  auto main_get_count = [&]() { NA = __builtin_amdgcn_readfirstlane((int)sm[in_dim + 3]); };
   auto help_get_factors = [&]() {
     const T *const fac = E + O.fac;
 #pragma unroll
     for (int k = 0; k < 15; ++k) Ls[k] = fac[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      sq_ids[k] = fac[15 + k];
-      qdr_new[k] = fac[21 + k];
-    }
+    for (int k = 0; k < 6; ++k) sq_ids[k] = fac[15 + k];
   };
 
   // ---- J, K, L. contacts (wave-uniform: NA = the largest count among the wavefront's environments).  The sweep's order is
@@ -981,13 +985,14 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   //      environment with fewer contacts has zero rows in its empty slots).  Rows are solved a WINDOW of eight sweep
   //      positions at a time — lane == row, by the helper — and consumed by the main wavefront's sweep; two window buffers:
   //      the helper solves window w + 1 while the main wavefront sweeps window w.
-  T u = T(0), urm = T(0);  // u~ = sum_r z~_r x_r, distributed: my own dof's leg entry | root entry `lane` (lanes 6, 7: zero)
   // window wi of the sweep: Gauss-Seidel iteration wi / nwin, sweep positions w0 .. w0 + 7, row buffer wi & 1; lane == row.
-  // Two halves.  rows_geom: the contact's Jacobian row along the row's direction — needs the kinematics only: the helper
-  // solves the first window's while the main wavefront is still factorising.  rows_solve: right-hand side, z~ = D^-1/2 L^-1 J^T,
-  // G — needs the factors and the velocities after integrate_euler_qdd: the main wavefront does the first window's itself
-  // (it holds the factors in registers), the helper the later ones.
+  // Three stages, each as early as its inputs exist (two-wavefront build: all by the helper, beside the main wavefront's chain):
+  //   rows_geom  the contact's Jacobian row along the row's direction and the right-hand side c_r from the velocities BEFORE
+  //              the step (the kinematics only);
+  //   rows_leg   the contact's leg block of z~ = D^-1/2 L^-1 J^T (the leg factors: published at barrier (1b));
+  //   rows_root  the root block, G and 1 / (G + cfm) (the root block's factors: barrier (2)).
   auto rows_geom = [&](int wi) {
+      OCT_MARK("rows_geom");
       const int nr = 3 * NA, nwin = (nr + 7) >> 3;
       const int w0 = (wi % nwin) * 8;
       T *const row = E + O.win + (wi & 1) * (8 * OctLds::ZW) + lane * OctLds::ZW;
@@ -1015,55 +1020,67 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         sh[c] = swl[hl * 6 + c];
         sa[c] = swl[(hl + 1) * 6 + c];
       }
+      const T qh = xr[nq + 6 + hl], qa = xr[nq + 6 + hl + 1];  // velocities before the step
       // column of the point Jacobian along e: e . s_lin + P . (e x s_ang) = e . s_lin + (P x e) . s_ang  (jacobian.hpp:56-72)
       T mo[3];
       cross3(Pc, e, mo);
       const T j0 = dot3(e, sh + 3) + dot3(mo, sh), j1 = dot3(e, sa + 3) + dot3(mo, sa);
-      row[0] = on_leg ? j0 : T(0);
-      row[1] = ank ? j1 : T(0);
-      row[2] = real ? e[0] : T(0);
-      row[3] = real ? e[1] : T(0);
-      row[4] = real ? e[2] : T(0);
-      row[5] = real ? dot3(e, pA3) + mo[0] : T(0);
-      row[6] = real ? dot3(e, pA4) + dot3(mo, A4) : T(0);
-      row[7] = real ? dot3(e, pA5) + dot3(mo, A5) : T(0);
-      row[8] = dist;
-      row[9] = real ? T(1) : T(0);
+      const T z0 = on_leg ? j0 : T(0), z1 = ank ? j1 : T(0);
+      T zr[6];
+      zr[0] = e[0];
+      zr[1] = e[1];
+      zr[2] = e[2];
+      zr[3] = dot3(e, pA3) + mo[0];
+      zr[4] = dot3(e, pA4) + dot3(mo, A4);
+      zr[5] = dot3(e, pA5) + dot3(mo, A5);
+      const T vrow = ((z0 * qh + z1 * qa) + (zr[0] * xr[nq + 0] + zr[1] * xr[nq + 1])) +
+                     ((zr[2] * xr[nq + 2] + zr[3] * xr[nq + 3]) + (zr[4] * xr[nq + 4] + zr[5] * xr[nq + 5]));
+      // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1 + e) n.rel_vel - erp dist / dt,  b_t = -t.rel_vel  (the dt qdd share of
+      // the velocity: see main_fd)
+      const T crow = tk == 0 ? (T(1) + CT[TB::SC + TB::RESTITUTION]) * vrow - CT[TB::SC + TB::ERP_OVER_DT] * dist : vrow;
+      row[0] = z0;
+      row[1] = z1;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) row[2 + rr] = real ? zr[rr] : T(0);
+      row[8] = T(0);
+      row[9] = T(0);
+      row[OctLds::Z_B] = real ? crow : T(0);
+      row[OctLds::Z_A] = real ? T(1) : T(0);
       row[OctLds::Z_HL] = on_leg ? (T)hl : T(-2);
+      OCT_MARK("rows_geom_end");
   };
-  auto rows_solve = [&](int wi) {
-      const int nr = 3 * NA, nwin = (nr + 7) >> 3;
-      const int w0 = (wi % nwin) * 8;
+  auto rows_leg = [&](int wi) {
+      OCT_MARK("rows_leg");
       T *const row = E + O.win + (wi & 1) * (8 * OctLds::ZW) + lane * OctLds::ZW;
       const T *const lcw = E + O.lcw;
-      const T *const qdp = E + O.qdp;
-      const T cfm = CT[TB::SC + TB::CFM], erp_dt = CT[TB::SC + TB::ERP_OVER_DT], rest = CT[TB::SC + TB::RESTITUTION];
-      const bool is_n = w0 + lane < NA;
       T z0 = row[0], z1 = row[1], zr[6];
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) zr[rr] = row[2 + rr];
-      const T dist = row[8];
-      const bool real = row[9] != T(0);
       const T hlv = row[OctLds::Z_HL];
-      const int hl = hlv >= T(0) ? (int)hlv : 0;
-      // (second batch: the leg's velocities, factors and couplings)
+      const int hl = hlv >= T(0) ? (int)hlv : 0;  // (a contact of the root body: z0 = z1 = 0, whatever leg is read)
       T lch[6], lca[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         lch[c] = lcw[hl * OctLds::LCW + c];
         lca[c] = lcw[(hl + 1) * OctLds::LCW + c];
       }
-      const T qh = qdp[hl], qa = qdp[hl + 1];
       const T *const lf = E + O.legf + (hl >> 1) * 3;
       const T lf0 = lf[0], lf1 = lf[1], lf2 = lf[2];
-      const T vrow = ((z0 * qh + z1 * qa) + (zr[0] * qdr_new[0] + zr[1] * qdr_new[1])) +
-                     ((zr[2] * qdr_new[2] + zr[3] * qdr_new[3]) + (zr[4] * qdr_new[4] + zr[5] * qdr_new[5]));
-      // rel_vel = vel_a - vel_b = -J qd:  b_n = -(1 + e) n.rel_vel - erp dist / dt,  b_t = -t.rel_vel
-      const T brow = is_n ? (T(1) + rest) * vrow - erp_dt * dist : vrow;
-      // forward substitution L z = J^T, leaves first: the contact's leg, then the root rows
+      // forward substitution L z = J^T, leaves first: the contact's leg, its share of the root rows; z~_leg = D^-1/2 z
       z1 -= lf0 * z0;
 #pragma unroll
-      for (int rr = 0; rr < 6; ++rr) zr[rr] -= lch[rr] * z0 + lca[rr] * z1;
+      for (int rr = 0; rr < 6; ++rr) row[2 + rr] = zr[rr] - (lch[rr] * z0 + lca[rr] * z1);
+      row[0] = z0 * lf1;
+      row[1] = z1 * lf2;
+  };
+  auto rows_root = [&](int wi) {
+      OCT_MARK("rows_root");
+      T *const row = E + O.win + (wi & 1) * (8 * OctLds::ZW) + lane * OctLds::ZW;
+      const T z0 = row[0], z1 = row[1];
+      T zr[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) zr[rr] = row[2 + rr];
+      const bool real = row[OctLds::Z_A] != T(0);
       static_for<1, 6>([&](auto rc) {
         constexpr int rr = decltype(rc)::value;
         static_for<0, rr>([&](auto cc) {
@@ -1071,22 +1088,16 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
           zr[rr] -= Ls[(rr * (rr - 1)) / 2 + c] * zr[c];
         });
       });
-      // z~ = D^-1/2 z, G = z~ . z~
-      z0 *= lf1;
-      z1 *= lf2;
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) zr[rr] *= sq_ids[rr];
+      // G = z~ . z~
       const T g = ((z0 * z0 + z1 * z1) + (zr[0] * zr[0] + zr[1] * zr[1])) + ((zr[2] * zr[2] + zr[3] * zr[3]) + (zr[4] * zr[4] + zr[5] * zr[5]));
-      const T ai = real ? rcp_full<T>(g + cfm) : T(0);
-      row[0] = z0;  // (a padding row's Jacobian is zero: its z~, b and G are)
-      row[1] = z1;
+      const T ai = real ? rcp_full<T>(g + CT[TB::SC + TB::CFM]) : T(0);
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) row[2 + rr] = zr[rr];
-      row[8] = T(0);
-      row[9] = T(0);
-      row[OctLds::Z_B] = real ? brow : T(0);
       row[OctLds::Z_A] = ai;
       row[OctLds::Z_G] = g;
+      OCT_MARK("rows_root_end");
       OCT_STAMP(10, ai);
   };
   // ---- the sweep over a window (mb_constraint_solver.hpp:101-142), by the main wavefront.  A lone wavefront issues an
@@ -1098,13 +1109,14 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   //      previous impulse).  A row's operands are requested while the row before is processed (two register sets, the loop
   //      unrolled by two: no copies).
   auto main_sweep = [&](int wi) {
+      OCT_MARK("sweep");
       const int nr = 3 * NA, nwin = (nr + 7) >> 3;
       const int pit = wi / nwin;
       const int w0 = (wi - pit * nwin) * 8;
       const T *const Zs = E + O.win + (wi & 1) * (8 * OctLds::ZW);
       T *const xs = E + O.xs;
       const T my_hip = (T)(lane & ~1);
-      const T mu = CT[TB::SC + TB::FRICTION];
+      const T mu = CT[TB::SC + TB::FRICTION], rest = CT[TB::SC + TB::RESTITUTION];
       const int wn = nr - w0 < 8 ? nr - w0 : 8;
       const int k_n = NA - w0 < 0 ? 0 : (NA - w0 < wn ? NA - w0 : wn);  // rows 0 .. k_n - 1 of the window are normal rows
       struct Ops { T zs, zm, b, a, g, hl, sd, xo; };
@@ -1125,7 +1137,10 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       auto process = [&](int k, const Ops &o, auto firstc, auto normalc) {
         constexpr bool FIRST = decltype(firstc)::value, NORMAL = decltype(normalc)::value;
         const T zl = o.hl == my_hip ? o.zs : T(0);
-        const T jw = oct_sum(zl * u + o.zm * urm);
+        T jw;
+        // (a normal row's b_r carries (1 + e) J (dt qdd): the e-fold of z~_r . (dt y~) = -z~_r . u~_init on top of what u~ holds)
+        if constexpr (NORMAL) jw = oct_sum(zl * (u + rest * u_init) + o.zm * (urm + rest * urm_init));
+        else jw = oct_sum(zl * u + o.zm * urm);
         T xn;
         if constexpr (FIRST) xn = (o.b - jw) * o.a;
         else xn = (o.b - (jw - o.g * o.xo)) * o.a;
@@ -1165,14 +1180,17 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         run(k_n, wn, std::false_type{}, std::false_type{});
       }
       OCT_SYNC();
+      OCT_MARK("sweep_end");
   };
   auto windows = [&]() -> int { return NA > 0 ? pgs_iters * ((3 * NA + 7) >> 3) : 0; };
 
   auto main_fin = [&]() {
     // ================================ main: impulse, integration, reward ================================
+    OCT_MARK("main_fin");
     OCT_STAMP(6, u);
-    if (NA > 0) {
-      // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
+    {
+      // qd_new = qd - L^-T D^-1/2 u~: forward dynamics and contact impulse in one back-substitution (see main_fd;
+      // mb_constraint_solver.hpp:476-496: qd_b -= M^-1 J^T p)
       T w = u * my_sq;
       T wr[6];
       static_for<0, 6>([&](auto rc) {
@@ -1189,10 +1207,11 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #pragma unroll
       for (int r = 0; r < 6; ++r) w -= Lc[r] * wr[r];
       w -= (pos == 0 ? l10 : T(0)) * pair_bcast<1>(w);
-      qd_new -= w;
+      qd_new = qd - w;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) qdr_new[r] -= wr[r];
+      for (int r = 0; r < 6; ++r) qdr_new[r] = xr[nq + r] - wr[r];
     }
+    OCT_MARK("main_integrate");
     // ---- M. integrate_euler: q += qd dt (integrator.hpp:126-131); the new state into the LDS record
     OCT_SYNC();
     {
@@ -1223,6 +1242,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       if (ctl.act_pool != nullptr && !last) xr[nq + nd + lane] = next_act;
     }
     OCT_SYNC();
+    OCT_MARK("main_reward");
     // ---- N. reward / done (ant_environment2.h:75-106; laikago_environment2.h:130-171)
     {
       const int rm = (int)CT[TB::SC + TB::REWARD_MODE];
@@ -1265,6 +1285,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     for (int i = tail + lane; i < end; i += 8) y[i] = TR(0);
   };
   auto main_pool = [&]() {
+    OCT_MARK("main_pool");
     // ---- auto_reset_when_done through the reset pool (ctl.pool; ars_vectorized_environment.h:262-277): a done environment
     //      takes its next pre-settled state — y, reward and done describe the terminal step, the observation and the state
     //      the fresh environment: its y state goes out HERE, before the record is overwritten
@@ -1287,9 +1308,11 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         xr[in_dim + 3] = T(1);
       }
     }
+    OCT_MARK("main_pool_end");
     OCT_STAMP(7, tid);
   };
   auto help_rec = [&]() {
+    OCT_MARK("help_rec");
     // ================================ helper: the step's records ================================
     // (two-wavefront build: while the main wavefront starts the next step — it does not write the record before its own
     //  phase M, two barriers from here)
@@ -1401,13 +1424,14 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
         obs_out[(size_t)env * w_obs + nq + nd + 1] = (TR)xr[in_dim + 1];
       }
     }
+    OCT_MARK("help_rec_end");
     OCT_STAMP(11, tid);
   };
 
   // ================================ the step ================================
-  // barriers of a two-wavefront workgroup: (1) the kinematics are in LDS; (2) factors, velocities, contact list and counts;
-  // one per row window from the second on (window wi is in LDS: the main wavefront solves and sweeps the first window
-  // itself while the helper solves the second, then the helper stays a window ahead of the sweep); (0) the
+  // barriers of a two-wavefront workgroup: (1) the kinematics are in LDS; (1b) the leg blocks' factors and couplings; (2) the
+  // root block's factors (main wavefront), the contact list and counts (helper); one per row window (window wi is in LDS: the
+  // helper stays a window ahead of the sweep); (0) the
   // step's state, reward and done are in the LDS record — the helper stores the step's records while the main wavefront
   // starts the next step (it does not write the record before its own integration, two barriers on)
   if constexpr (W2) {
@@ -1415,20 +1439,19 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       main_kin();
       OCT_BAR();  // (1)
       main_dyn();
+      OCT_BAR();  // (1b)
+      main_dyn2();
       OCT_BAR();  // (2)
       main_get_count();
+      main_fd();
       const int nw = windows();
-      if (nw > 0) {
-        // the first window by the main wavefront itself (it holds the factors; the helper solves the second meanwhile)
-        rows_solve(0);
-        OCT_SYNC();
-        OCT_STAMP(12, tid);
-        main_sweep(0);
-        OCT_STAMP(13, u);
-        for (int wi = 1; wi < nw; ++wi) {
-          OCT_BAR();
-          main_sweep(wi);
-        }
+      // (the first window's root stage stays with the helper although the main wavefront holds the factors in registers: doing
+      //  it here measured 1.6 k cycles on the chain against 1.1 k of waiting for the helper's)
+      for (int wi = 0; wi < nw; ++wi) {
+        OCT_BAR();
+        if (wi == 0) OCT_STAMP(12, tid);
+        main_sweep(wi);
+        if (wi == 0) OCT_STAMP(13, u);
       }
       main_fin();
       main_pool();
@@ -1436,14 +1459,22 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     } else {
       OCT_BAR();  // (1)
       help_np();
-      if (NA > 0) rows_geom(0);  // (the first window's Jacobian rows: the main wavefront completes them behind barrier (2))
+      if (NA > 0) rows_geom(0);
+      OCT_BAR();  // (1b)
+      if (NA > 0) rows_leg(0);
+      help_poses();
       OCT_BAR();  // (2)
       const int nw = windows();
-      if (nw > 1) help_get_factors();
-      for (int wi = 1; wi < nw; ++wi) {
-        rows_geom(wi);
-        OCT_SYNC();
-        rows_solve(wi);
+      if (nw > 0) {
+        help_get_factors();
+        rows_root(0);
+      }
+      for (int wi = 0; wi < nw; ++wi) {
+        if (wi > 0) {
+          rows_geom(wi);
+          rows_leg(wi);
+          rows_root(wi);
+        }
         OCT_BAR();
       }
       OCT_BAR();  // (0)
@@ -1453,13 +1484,16 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     main_kin();
     OCT_SYNC();
     help_np();
+    help_poses();
     main_dyn();
     OCT_SYNC();
+    main_dyn2();
+    main_fd();
     const int nw = windows();
     for (int wi = 0; wi < nw; ++wi) {
       rows_geom(wi);
-      OCT_SYNC();
-      rows_solve(wi);
+      rows_leg(wi);
+      rows_root(wi);
       OCT_SYNC();
       main_sweep(wi);
     }

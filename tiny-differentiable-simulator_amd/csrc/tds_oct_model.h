@@ -8,11 +8,17 @@
 // Per leg-link lane (lane = 2 leg + position, link 6 + lane) a record of LSTR scalars — a stride whose eight records
 // start on different LDS banks — then the root body's block, then the model's scalars (integers as exact scalars).
 struct TdsOctTab {
-  static constexpr int LSTR = 58;
+  static constexpr int LSTR = 70;
   // the lane's record
   static constexpr int S = 0, XT = 6, MASS = 18, COM = 19, INER = 22, IPOSE = 31, STIFF = 32, DAMP = 33, JT = 34, ACT = 35,
                        CPR0 = 36, CPL0 = 37, CPR1 = 40, CPL1 = 41, VIS = 44,  // VIS: 12 (rotation 9 | translation 3)
-                       AXINV = 56;  // 1 / |S_angular| (REVOLUTE_AXIS joints: the axis-angle quaternion's normalisation, link.hpp:256-261)
+                       AXINV = 56,  // 1 / |S_angular|
+                       // the joint rotation as Rodrigues' formula R = cos I + sin [n]x + (1 - cos) n n^T about the UNIT axis n (every
+                       // revolute type of link.hpp:229-287, the unnormalised REVOLUTE_AXIS included: its axis-angle quaternion is the
+                       // rotation about S / |S|): n (3) | n n^T as xx xy xz yy yz zz (6) | 1 for a revolute joint, 0 for a prismatic one
+                       NAX = 57, NN = 60, ROTF = 66,
+                       // which entries (r, r') of the root's Schur complement this lane sums in its three passes: sum_p (8 r + r') << 6 p
+                       SCHUR = 67;
   // the root body's block (link 5)
   static constexpr int ROOT = 8 * LSTR;
   static constexpr int R_MASS = 0, R_COM = 1, R_INER = 4, R_CPR = 13 /* < 0: no sphere */, R_CPL = 14, R_VIS = 17;
@@ -20,8 +26,9 @@ struct TdsOctTab {
   static constexpr int SC = ROOT + 30;
   static constexpr int DT = 0, ACTION_LIMIT = 1, BASE_T = 2, GRAV = 5, PLANE_N = 8, PLANE_C = 11, NB = 12, T1 = 15, T2 = 18, CFM = 21,
                        ERP_OVER_DT = 22, RESTITUTION = 23, FRICTION = 24, BASE_R8 = 25, NUM_VISUALS = 26, REWARD_MODE = 27,
-                       PGS_ITERATIONS = 28, PACK_VISUALS = 29, OUTPUT_DIM = 30, INV_DT = 31;
-  static constexpr int TOTAL = SC + 32;
+                       PGS_ITERATIONS = 28, PACK_VISUALS = 29, OUTPUT_DIM = 30, INV_DT = 31,
+                       XT_IDENT = 32;  // 1: every leg link's X_T rotation is the identity (no R_T R_J product)
+  static constexpr int TOTAL = SC + 34;
 };
 
 static_assert(TdsOctTab::TOTAL <= TDS_OCT_TAB_CAP, "DevModel::oct_tab is too small for the table");
@@ -61,8 +68,31 @@ static void tds_oct_detect(const tds_model_t *m, DevModel<T> *d, int ncp, bool l
         r[TB::DAMP] = d->damping[li];
         r[TB::JT] = (T)d->joint_type[li];
         {
-          const double ax2 = (double)d->S[0][li] * d->S[0][li] + (double)d->S[1][li] * d->S[1][li] + (double)d->S[2][li] * d->S[2][li];
-          r[TB::AXINV] = ax2 > 0.0 ? (T)(1.0 / sqrt(ax2)) : T(0);
+          const double ax[3] = {(double)d->S[0][li], (double)d->S[1][li], (double)d->S[2][li]};
+          const double ax2 = ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2];
+          const int jt = d->joint_type[li];
+          const bool revolute = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS && ax2 > 0.0;
+          const double inv = ax2 > 0.0 ? 1.0 / sqrt(ax2) : 0.0;
+          r[TB::AXINV] = (T)inv;
+          const double n[3] = {revolute ? ax[0] * inv : 0.0, revolute ? ax[1] * inv : 0.0, revolute ? ax[2] * inv : 0.0};
+          for (int k = 0; k < 3; ++k) r[TB::NAX + k] = (T)n[k];
+          r[TB::NN + 0] = (T)(n[0] * n[0]);
+          r[TB::NN + 1] = (T)(n[0] * n[1]);
+          r[TB::NN + 2] = (T)(n[0] * n[2]);
+          r[TB::NN + 3] = (T)(n[1] * n[1]);
+          r[TB::NN + 4] = (T)(n[1] * n[2]);
+          r[TB::NN + 5] = (T)(n[2] * n[2]);
+          r[TB::ROTF] = revolute ? T(1) : T(0);
+          int code = 0;
+          for (int pass = 0; pass < 3; ++pass) {
+            int e = ln + 8 * pass;
+            e = e < 21 ? e : 20;
+            int rr = 0;
+            for (int k = 1; k < 6; ++k) rr += e >= (k * (k + 1)) / 2 ? 1 : 0;
+            const int rp = e - (rr * (rr + 1)) / 2;
+            code |= (8 * rr + rp) << (6 * pass);
+          }
+          r[TB::SCHUR] = (T)code;
         }
         r[TB::ACT] = (T)d->act_index[li];
         for (int e = 0; e < 2; ++e) {
@@ -84,6 +114,12 @@ static void tds_oct_detect(const tds_model_t *m, DevModel<T> *d, int ncp, bool l
       T *const sc = t + TB::SC;
       sc[TB::DT] = d->dt;
       sc[TB::INV_DT] = (T)(1.0 / (double)d->dt);
+      {
+        bool ident = true;
+        for (int li = 6; li < 14; ++li)
+          for (int k = 0; k < 9; ++k) ident = ident && d->X_T[k][li] == ((k == 0 || k == 4 || k == 8) ? T(1) : T(0));
+        sc[TB::XT_IDENT] = ident ? T(1) : T(0);
+      }
       sc[TB::ACTION_LIMIT] = d->action_limit;
       for (int k = 0; k < 3; ++k) {
         sc[TB::BASE_T + k] = d->base_t[k];

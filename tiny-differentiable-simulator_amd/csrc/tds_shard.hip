@@ -467,6 +467,9 @@ int peer_setup(tds_hip_shard *sh, size_t ring_slots, size_t slot_b) {
   char why[160] = "";
   if (want != 0 && sh->world > 1 && sh->comm != nullptr && !sh->ring_uncached)
     snprintf(why, sizeof(why), "the gathered ring is not in uncached device memory");
+  else if (want != 0 && !possible)
+    snprintf(why, sizeof(why), "not available for this shard: in-place ring %d, one process for all ranks %d, peers %d + %d loopback of at most %d, communicator %d",
+             (int)sh->inplace, (int)sh->one_process_group, sh->world - 1, loopback > 0 ? loopback : 0, TDS_MAX_PEERS, sh->comm != nullptr);
   // own arrays first (every rank allocates them: the set-up below is a collective either way — a LOCAL failure here makes this
   // rank's verdict "no" but never keeps it away from the all-gathers the other ranks are waiting in)
   const size_t n_flags = sh->flag_count() + 2 * (size_t)sh->world;

@@ -7,6 +7,8 @@
 #   trace      rocprofv3 --kernel-trace --stats of the driver's exact command             <tag>_ant4096_f64_default_{kernel_stats,dispatches}.txt
 #   traffic    HBM bytes: separate FETCH_SIZE / WRITE_SIZE passes, 20- and 1000-step      <tag>_ant4096_f64_{20,1000}_pmc_traffic.txt
 #   sq         SQ / LDS counters of the headline launch (three passes)                    <tag>_ant4096_f64_sq_counters_loop.txt
+#   others     the same two for config 5's share (Ant x 8192) and config 4 (laikago_soft x 8192, +-0.4 actions with auto-reset
+#              and without): traffic + SQ counters of THEIR kernels (tds_oct_kernel, tds_quad_kernel)
 #   exchange   one rank through tds_hip_shard_step_many (0 and 7 loopback peers): lines, kernel trace, timeline
 #   tworank    TWO processes on the one GPU through the peer-store exchange, rocprofv3 kernel trace of each + timeline
 #   phases     per-phase cycles of the two-wavefront step (both wavefronts), Ant and Laikago
@@ -76,6 +78,23 @@ sq)
   python tools/pmc_loop_summary.py 1000 $O/sq_* > $P/${TAG}_ant4096_f64_sq_counters_loop.txt 2>&1
   rm -rf $O/sq_*/
   grep -v '^# kernel' $P/${TAG}_ant4096_f64_sq_counters_loop.txt | cut -c1-140 ;;
+others)
+  SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM"
+  SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+  SQ3="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
+  for CFG in "ant8192 --envs-per-gpu 8192" "laikago_soft8192 --model laikago_soft --envs-per-gpu 8192 --action-amp 0.4"; do
+    set -- $CFG
+    NAME=$1; shift
+    i=0
+    for CTRS in FETCH_SIZE WRITE_SIZE "$SQ1" "$SQ2" "$SQ3"; do
+      i=$((i+1))
+      timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $O/o_${NAME}_$i -o p -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-secondary --spin-up-steps 0 --no-events "$@" > $O/o_${NAME}_$i.log 2>&1
+    done
+    python tools/pmc_loop_summary.py 500 $O/o_${NAME}_1 $O/o_${NAME}_2 > $P/${TAG}_${NAME}_f64_pmc_traffic.txt 2>&1
+    python tools/pmc_loop_summary.py 500 $O/o_${NAME}_3 $O/o_${NAME}_4 $O/o_${NAME}_5 > $P/${TAG}_${NAME}_f64_sq_counters.txt 2>&1
+    rm -rf $O/o_${NAME}_*/
+    grep -h -v '^# kernel' $P/${TAG}_${NAME}_f64_pmc_traffic.txt | cut -c1-140
+  done ;;
 exchange)
   for LB in 0 7; do
     $NS --steps 1024 --warmup 256 --force-gather --option shard_peer_loopback=$LB > $P/${TAG}_bench_ant4096_one_rank_exchange_${LB}peers_1024.json 2> $O/fg$LB.err

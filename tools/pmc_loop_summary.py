@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc CSV output of a run whose timed region is ONE step-loop launch (tds_hip_step_many of K steps): the
-counters of the longest tds_step_kernel dispatch, and per step.
+counters of the longest step-kernel dispatch (tds_step_kernel, tds_quad_kernel or tds_oct_kernel), and per step.
 usage: python tools/pmc_loop_summary.py K <dir> [<dir> ...]"""
 import csv
 import glob
@@ -13,7 +13,7 @@ for d in sys.argv[2:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         per = {}
         for row in csv.DictReader(open(f)):
-            if "tds_step_kernel" not in row["Kernel_Name"]:
+            if not any(k in row["Kernel_Name"] for k in ("tds_step_kernel", "tds_quad_kernel", "tds_oct_kernel")):
                 continue
             key = row["Dispatch_Id"]
             dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
@@ -23,7 +23,7 @@ for d in sys.argv[2:]:
             top = max(per.values(), key=lambda e: e["dur"])
             for k, v in top["ctr"].items():
                 best[k] = (v, top["dur"], top["name"])
-print(f"# longest tds_step_kernel dispatch of each pass = the step-loop launch of the {K} timed steps")
+print(f"# longest step-kernel dispatch of each pass = the step-loop launch of the {K} timed steps")
 for k in sorted(best):
     v, dur, name = best[k]
     print(f"# kernel: {name[:150]}")
