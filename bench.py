@@ -322,7 +322,7 @@ def run(args, n, rank, local_rank, world, secondary, config5):
     import torch.distributed as dist
 
     import tds_amd
-    from tds_amd import hip_backend
+    from tds_amd import hip_backend, ranks
 
     m = tds_amd.load_model(args.model)
     lib_dtype = {"f64": "f64", "f32": "mixed", "f32-pure": "f32"}[args.dtype]
@@ -339,12 +339,7 @@ def run(args, n, rank, local_rank, world, secondary, config5):
         def create_shard(options):
             uid = None
             if world > 1 or os.environ.get("TDS_BENCH_RCCL_SINGLE", "1") == "1":
-                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(hip_backend.HipShard.unique_id()), dtype=torch.uint8))
-                if world > 1:
-                    dist.broadcast(idt, src=0)
-                uid = bytes(idt.cpu().numpy().tobytes())
+                uid = ranks.share_id(hip_backend.HipShard.unique_id, rank, world, "cuda")
             # (RCCL prints a version banner on C stdout when a communicator comes up: keep rank 0's stdout to the one
             #  JSON line — send C-level stdout to stderr while the communicator is created)
             import ctypes
@@ -364,11 +359,8 @@ def run(args, n, rank, local_rank, world, secondary, config5):
             finally:
                 os.dup2(saved_fd, 1)
                 os.close(saved_fd)
-            if world > 1:  # every rank takes the same path
-                flag = torch.tensor([1 if err else 0], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                if int(flag.item()):
-                    err = err or "another rank could not create its shard"
+            if ranks.any_rank(bool(err), world, "cuda"):  # every rank takes the same path
+                err = err or "another rank could not create its shard"
             if err:
                 raise SystemExit(f"bench.py: tds_hip_shard_create failed on rank {rank}: {err} (no fallback under `value`)")
             return sh
@@ -538,16 +530,14 @@ def run(args, n, rank, local_rank, world, secondary, config5):
             except Exception as e:  # noqa: BLE001
                 print(f"bench.py: exchange form '{f}' {fopts or ''} failed on rank {rank}: {e!r}", file=sys.stderr)
                 err = 1
-            if world > 1:
-                flag = torch.tensor([err], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                err = int(flag.item())
+            err = 1 if ranks.any_rank(bool(err), world, "cuda") else 0
             if not err:
                 shard_form = f
                 break
         if shard_form is None:
             raise SystemExit("bench.py: no exchange form works on this node")
         exchange_form = shard.exchange_form()
+        n_peers = shard.peer_count()
         loop_form = loop_form and shard_form == "ring"
     else:
         prepare(args.warmup)
@@ -594,15 +584,7 @@ def run(args, n, rank, local_rank, world, secondary, config5):
     ev1.record()
     while not ev1.query():  # (polled: the wake-up of a blocking wait costs 10 - 60 us, a fifth of a 20-step region)
         pass
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ranks.close_region(t0, world, "cuda", torch.cuda.synchronize)  # (sync, barrier, sync; max over ranks)
 
     kernel_ms = None
     kernel_ms_isolated = None
@@ -620,6 +602,71 @@ def run(args, n, rank, local_rank, world, secondary, config5):
         kernel_ms_isolated = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         if kernel_ms is None:
             kernel_ms = kernel_ms_isolated
+
+    # secondary (N > 1, ring exchange): the same K steps (a) with only [reward | done] travelling to the peers (exchange_fields =
+    # 1: 8 of 120 bytes per Ant environment) and (b) with NO exchange at all (every rank its own step-loop launches with its own
+    # rings) — beside `value` they separate what the kernels scale like from what the links cost: value << no_exchange says
+    # "link-bound", exchange_fields_reward_done ~ no_exchange says "the per-record protocol itself is free"
+    exch_variants = None
+    if multi and secondary and not args.no_secondary and shard_form == "ring" and K >= 1:
+        exch_variants = {}
+
+        def timed_k(step_fn, sync_fn):
+            step_fn(min(K, 64))  # warm-up (graphs, rings)
+            sync_fn()
+            t1 = ranks.open_region(world, torch.cuda.synchronize)
+            step_fn(K)
+            sync_fn()
+            return ranks.close_region(t1, world, "cuda", torch.cuda.synchronize)
+
+        try:
+            shard.flush()
+            torch.cuda.synchronize()
+            sh2 = create_shard({"exchange_fields": 1})  # (a second shard beside the first: its own communicator and rings)
+            init_state(sh2.sim)
+            st2 = {"i": 0}
+
+            def steps_rd(k):
+                left = k
+                while left > 0:
+                    c = min(left, GCH)
+                    sh2.step_many(actions, c, first_block=st2["i"] % pool)
+                    st2["i"] += c
+                    left -= c
+
+            dt_rd = timed_k(steps_rd, lambda: (sh2.flush(), torch.cuda.synchronize()))
+            exch_variants["exchange_fields_reward_done"] = {
+                "value": ranks.job_rate(world, n, K, dt_rd), "unit": "env-steps/s", "ms_per_step": dt_rd / K * 1e3,
+                "exchange_form": sh2.exchange_form(),
+                "what": "the same launches, only [reward | done] of a record travel to the peers (option exchange_fields = 1; "
+                        "this rank's own block still receives the whole record)"}
+            sh2.close()
+        except Exception as e:  # noqa: BLE001  (a secondary: reported, never fatal)
+            exch_variants["exchange_fields_reward_done"] = {"error": repr(e)[:300]}
+        try:
+            plain = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype)
+            init_state(plain)
+            o_ring = torch.zeros((RS, n, plain.obs_dim + 2), dtype=tdt, device="cuda")
+            per_line = 128 // (8 if tdt == torch.float64 else 4)
+            yr = torch.zeros((RS, n, -(-m.output_dim // per_line) * per_line), dtype=tdt, device="cuda")
+            st3 = {"i": 0}
+
+            def steps_plain(k):
+                left = k
+                while left > 0:
+                    c = min(left, 256)  # (the launch length of the exchange runs)
+                    plain.step_many_rings(actions, c, o_ring, yr, first_block=st3["i"] % pool, obs_first=st3["i"] % RS, y_first=st3["i"] % RS)
+                    st3["i"] += c
+                    left -= c
+
+            dt_ne = timed_k(steps_plain, torch.cuda.synchronize)
+            exch_variants["no_exchange"] = {
+                "value": ranks.job_rate(world, n, K, dt_ne), "unit": "env-steps/s", "ms_per_step": dt_ne / K * 1e3,
+                "what": "the same step-loop launches on every rank with per-step records into the rank's own rings, nothing "
+                        "leaves the GPU: what the kernels alone scale like"}
+            del plain
+        except Exception as e:  # noqa: BLE001
+            exch_variants["no_exchange"] = {"error": repr(e)[:300]}
 
     # secondary (N > 1): the pipelined exchange — records of `pipelined_block` consecutive steps in one all-gather
     pipelined = None
@@ -811,7 +858,7 @@ def run(args, n, rank, local_rank, world, secondary, config5):
         elem = 8 if args.dtype == "f64" else 4  # bytes per scalar of the records in HBM
         bytes_per_env_step = (m.input_dim + m.output_dim) * elem  # x record in + y record out
         total_steps = world * n * K
-        value = total_steps / elapsed
+        value = ranks.job_rate(world, n, K, elapsed)
         per_step_records = use_rings or multi or not use_graph  # every step packs + stores its records
         ring_exchange = multi and shard_form == "ring"
         roof = None
@@ -913,7 +960,7 @@ def run(args, n, rank, local_rank, world, secondary, config5):
                        if auto_reset else None,
                        "launch": launch,
                        "exchange_form": ("%s / %s" % (shard_form, exchange_form)) if multi else None,
-                       "peers": shard.peer_count() if multi else None,
+                       "peers": n_peers if multi else None,
                        "spin_up": ("%d untimed steps of a scratch handle before the warm-up steps and 256 more right in front of the "
                                    "synchronisation that opens the timed region (GPU clocks)" % args.spin_up_steps)
                        if args.spin_up_steps > 0 else None,
@@ -947,6 +994,11 @@ def run(args, n, rank, local_rank, world, secondary, config5):
             out["on_device_rollout"] = rollout
         if pipelined is not None:
             out["pipelined_gather"] = pipelined
+        if exch_variants:
+            for k_, v_ in exch_variants.items():
+                if "value" in v_:
+                    v_["ratio_to_value"] = v_["value"] / value
+                out[k_] = v_
         if not args.no_cpu_baseline and world == 1 and secondary:
             cb = cpu_baseline(args.model, min(n, 4096))
             primary = cb.get("reference") or cb.get("port")

@@ -3,7 +3,7 @@ of the [obs | reward | done] records per policy step) and the hipGrap
 
 A 1-GPU box exercises the whole path with ONE rank (RCCL communicator of size 1, communication stream, ring of record
 blocks, wire conversion); the 2-rank test runs wherever tds_hip_device_count() >= 2 and skips loudly otherwise.  The
-sharding arithmetic and the N > 1 protocol on CPU are covered by tests/test_sharded_gloo.py (gloo, world_size 2)."""
+the N > 1 host protocol and the shard arithmetic on CPU are covered by tests/test_rank_protocol_gloo.py (gloo, world_size 2) and tests/test_shard_plan.py."""
 import ctypes as C
 import os
 

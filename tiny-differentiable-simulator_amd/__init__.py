@@ -5,6 +5,6 @@ from .model import *  # noqa: F401,F403
 from . import model  # noqa: F401
 
 from . import hip_backend  # noqa: F401,E402
-from . import sharded  # noqa: F401,E402
+from . import ranks  # noqa: F401,E402
 from . import vec_env  # noqa: F401,E402
 from .vec_env import VectorizedAntEnv, VectorizedLaikagoEnv, VectorizedEnv  # noqa: F401,E402

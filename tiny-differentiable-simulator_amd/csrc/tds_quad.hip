@@ -58,6 +58,42 @@ __device__ __forceinline__ float quad_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xF, 0xF, true));
 }
 
+// sin and cos of a joint angle: Cody-Waite reduction by pi / 2 in two fused steps and the fdlibm kernels on [-pi/4, pi/4]
+// (< 1 ulp; ~35 instructions where the library routine takes ~90); lanes beyond 1e5 rad — or NaN — take the library routine
+// without changing what the other lanes of the wavefront compute (see tds_oct.hip: oct_sincos)
+__device__ __forceinline__ void quad_sincos(double x, double *sn, double *cs) {
+  const bool big = !(__builtin_fabs(x) < 1.0e5);
+  const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+  double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+  r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+  const int q = (int)k;
+  const double z = r * r;
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+  ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+  ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+  const double s0 = __builtin_fma(z * r, ps, r);
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+  pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+  pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+  const double c0 = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+  const bool swap = (q & 1) != 0;
+  const double ss = swap ? c0 : s0, cc = swap ? s0 : c0;
+  double s_ = (q & 2) ? -ss : ss, c_ = ((q + 1) & 2) ? -cc : cc;
+  if (__builtin_expect(__any(big), 0)) {
+    double s2, c2;
+    sincos(x, &s2, &c2);
+    s_ = big ? s2 : s_;
+    c_ = big ? c2 : c_;
+  }
+  *sn = s_;
+  *cs = c_;
+}
+__device__ __forceinline__ void quad_sincos(float x, float *sn, float *cs) { sincosf(x, sn, cs); }
+
 // launder a model pointer WITHOUT losing its address space (laundered as a generic pointer every access behind it is a FLAT
 // load: both counters, out of order with the DS instructions — see tds_kernels.hip)
 #ifndef QUAD_MDL_AS
@@ -310,7 +346,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   T Rp[9], tp[3], sn, cs;
   {
     const T ang = dofl ? (jt == TDS_JOINT_REVOLUTE_AXIS ? q * T(0.5) : q) : xr[3 + (leg < 3 ? leg : 0)];
-    sincos_t<T>(ang, &sn, &cs);
+    quad_sincos(ang, &sn, &cs);
     const bool rev = jt >= TDS_JOINT_REVOLUTE_X && jt <= TDS_JOINT_REVOLUTE_AXIS;
     const bool pris = jt >= TDS_JOINT_PRISMATIC_X && jt <= TDS_JOINT_PRISMATIC_AXIS;
     T RJ[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
@@ -328,10 +364,11 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       } else if (jt == TDS_JOINT_REVOLUTE_Z) {
         RJ[0] = cs; RJ[1] = -sn; RJ[3] = sn; RJ[4] = cs;
       } else {  // axis-angle quaternion with the UNNORMALISED axis (link.hpp:256-261)
-        const T d = sqrt_t<T>(Sl[0] * Sl[0] + Sl[1] * Sl[1] + Sl[2] * Sl[2]);
-        const T sh = sn / d;
+        // (1 / |axis| by the reciprocal square root; the quaternion's squared norm n2 is 1 to rounding — sin^2 + cos^2 —, so
+        //  2 / n2, the reference's quat_to_matrix scale, is 2 (2 - n2) to the last bit: one Newton step from 1)
+        const T sh = sn * rsqrt_full<T>(Sl[0] * Sl[0] + Sl[1] * Sl[1] + Sl[2] * Sl[2]);
         const T qx = Sl[0] * sh, qy = Sl[1] * sh, qz = Sl[2] * sh, qw = cs;
-        const T s2 = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+        const T s2 = T(4) - T(2) * (qx * qx + qy * qy + qz * qz + qw * qw);
         const T xs = qx * s2, ys = qy * s2, zs = qz * s2;
         const T wx = qw * xs, wy = qw * ys, wz = qw * zs;
         const T xx = qx * xs, xy = qx * ys, xz = qx * zs;
@@ -729,22 +766,28 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     for (int r = 0; r < 6; ++r) Cc[r] = dofl ? dot6(Fc, axr[r]) : T(0);
   }
   // ---- H. LDL^T.  The leg block: its six entries to every lane of the quad, factorised there
-  T l10, l20, l21, id0, id1, id2;
+  T l10, l20, l21, id0, id1, id2, sq0, sq1, sq2;
   {
     const T b00 = quad_bcast<0>(Bm[0]);
     const T b10 = quad_bcast<1>(Bm[0]), b11 = quad_bcast<1>(Bm[1]);
     const T b20 = quad_bcast<2>(Bm[0]), b21 = quad_bcast<2>(Bm[1]), b22 = quad_bcast<2>(Bm[2]);
-    id0 = rcp_full<T>(b00);
+    // (1 / sqrt(d) by the hardware estimate + two Newton steps, 1 / d as its square: a division AND a square root per pivot —
+    //  ~25 instructions — for 8; a lone wavefront pays per instruction: tools/ubench/lone_wave_latency.hip)
+    sq0 = rsqrt_full<T>(b00);
+    id0 = sq0 * sq0;
     l10 = b10 * id0;
     l20 = b20 * id0;
     const T d1 = b11 - l10 * b10;
-    id1 = rcp_full<T>(d1);
+    sq1 = rsqrt_full<T>(d1);
+    id1 = sq1 * sq1;
     const T u21 = b21 - l20 * b10;  // = l21 d1
     l21 = u21 * id1;
     const T d2 = b22 - l20 * b20 - l21 * u21;
-    id2 = rcp_full<T>(d2);
+    sq2 = rsqrt_full<T>(d2);
+    id2 = sq2 * sq2;
   }
   const T my_id = pos == 0 ? id0 : (pos == 1 ? id1 : id2);
+  const T my_sq = pos == 0 ? sq0 : (pos == 1 ? sq1 : sq2);
   // the coupling rows: W_a = C_a - sum_{a' < a} L[a][a'] W_a', L_c = W / d
   T W[6], Lc[6];
   {
@@ -779,7 +822,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       T *const lf = E + O.legf + leg * 9;
       lf[0] = l10; lf[1] = l20; lf[2] = l21;
       lf[3] = id0; lf[4] = id1; lf[5] = id2;
-      lf[6] = sqrt_t<T>(id0); lf[7] = sqrt_t<T>(id1); lf[8] = sqrt_t<T>(id2);
+      lf[6] = sq0; lf[7] = sq1; lf[8] = sq2;
     }
     // the six root axes for the lane-parallel root block (every lane the same values to the same slots)
     T *const axl = E + O.ax;
@@ -818,7 +861,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   }
   QUAD_SYNC();
   // ... factorised redundantly on every lane: Ls (strictly lower, row-major packed), 1 / D
-  T Ls[15], ids[6];
+  T Ls[15], ids[6], sq_ids[6];
   {
     const T *const Sl_ = E + O.S;
     T Sm[21];
@@ -827,7 +870,9 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     // right-looking on the packed lower triangle: S(r, c) at r (r + 1) / 2 + c
     static_for<0, 6>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      const T inv = rcp_full<T>(Sm[(k * (k + 1)) / 2 + k]);
+      const T rs = rsqrt_full<T>(Sm[(k * (k + 1)) / 2 + k]);
+      const T inv = rs * rs;
+      sq_ids[k] = rs;
       ids[k] = inv;
       T col[6];
       static_for<k + 1, 6>([&](auto rc) {
@@ -985,7 +1030,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       }
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) {
-        zr[rr] *= sqrt_t<T>(ids[rr]);
+        zr[rr] *= sq_ids[rr];
         g += zr[rr] * zr[rr];
       }
       const T ai = real ? rcp_full<T>(g + cfm) : T(0);
@@ -1041,10 +1086,10 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     }
     // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
     {
-      T w = dofl ? u * sqrt_t<T>(my_id) : T(0);
+      T w = dofl ? u * my_sq : T(0);
       T wr[6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) wr[r] = ur[r] * sqrt_t<T>(ids[r]);
+      for (int r = 0; r < 6; ++r) wr[r] = ur[r] * sq_ids[r];
       static_for<0, 5>([&](auto ic) {
         constexpr int r = 4 - decltype(ic)::value;
         static_for<r + 1, 6>([&](auto cc) {
@@ -1112,7 +1157,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   // ---- N. reward / done (laikago_environment2.h:130-171; ant_environment2.h:75-106)
   {
     T rs = T(0), rc = T(1);
-    sincos_t<T>(lane < 3 ? xr[3 + lane] * T(0.5) : T(0), &rs, &rc);
+    quad_sincos(lane < 3 ? xr[3 + lane] * T(0.5) : T(0), &rs, &rc);
     const T s1 = dpp_bcast<1>(rs), c1 = dpp_bcast<1>(rc), s2 = dpp_bcast<2>(rs), c2 = dpp_bcast<2>(rc);
     if (lane == 0) {
       bool done = false;
@@ -1128,7 +1173,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
         const T qy = cp * st * cs2 + sp * ct * ss;
         const T qz = cp * ct * ss - sp * st * cs2;
         const T qw = cp * ct * cs2 + sp * st * ss;
-        const T sq = T(2) / (qx * qx + qy * qy + qz * qz + qw * qw);
+        const T sq = T(4) - T(2) * (qx * qx + qy * qy + qz * qz + qw * qw);  // 2 / |q|^2, |q|^2 = 1 to rounding
         const T up = T(1) - (qx * (qx * sq) + qy * (qy * sq));
         done = (up < T(0.6)) || (xr[2] < T(0.2));
         reward = done ? T(0) : xr[0];
