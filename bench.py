@@ -221,6 +221,10 @@ def main():
     ap.add_argument("--auto-reset", action="store_true",
                     help="secondary workload (N = 1): auto_reset_when_done on — every step resets the environments it "
                          "ends with done (reset distribution + settle steps), through the reset pool")
+    ap.add_argument("--no-auto-reset", action="store_true",
+                    help="the legged robots other than the Ant (Laikago: BASELINE config 4) run with auto_reset_when_done ON by "
+                         "default — +-0.4 rad actions with the fallen robots reset, the reference's metric loop (SURVEY 8d); this "
+                         "switch gives the round-5 line instead: +-0.1 rad actions, nothing reset")
     ap.add_argument("--action-amp", type=float, default=-1.0,
                     help="amplitude of the uniform random actions; default: 0.4 (the reference's ACTION_LIMIT, SURVEY 8d) for the "
                          "Ant and for every model when --auto-reset is on (fallen robots are reset, as in the reference's metric "
@@ -400,7 +404,12 @@ def run(args, n, rank, local_rank, world, secondary, config5):
             target.step(None)
 
     init_state(sim)
-    auto_reset = args.auto_reset and not multi and m.step_mode == tds_amd.TDS_STEP_LOCOMOTION
+    # the legged robots that fall over under +-0.4 rad random actions (Laikago, config 4) are timed the way the reference's
+    # metric loop runs them: auto_reset_when_done on.  The Ant's default stays the plain loop (its auto_reset_rate is a
+    # secondary key of the same line)
+    falls_over = m.step_mode == tds_amd.TDS_STEP_LOCOMOTION and m.reward_mode != 0 and not args.model.startswith("ant")
+    auto_reset = ((args.auto_reset or (falls_over and not args.no_auto_reset)) and not multi
+                  and m.step_mode == tds_amd.TDS_STEP_LOCOMOTION)
     if auto_reset:
         sim.set_auto_reset(True, 5)
     pool = 16
@@ -720,7 +729,7 @@ def run(args, n, rank, local_rank, world, secondary, config5):
     # ---- secondary keys of the default N = 1 line (same model, same batch, same K; each on the state the timed region left)
     substep_fused = one_rank = one_rank_7 = auto_rate = None
     steady = None
-    if use_rings and world == 1 and not args.no_secondary and not auto_reset and secondary and loop_form:
+    if use_rings and world == 1 and not args.no_secondary and secondary and loop_form:
         # (0) the steady state ("steady-state over >= 1000 steps after 100 warm-up steps"): the same form, the same
         #     rings, 100 untimed + 1000 timed steps as ONE launch, bracketed by a HIP event pair on the launch stream
         sim.step_many_rings(actions, 100, obs_ring, y_ring, first_block=state["i"] % pool, obs_first=state["i"] % RS, y_first=state["i"] % RS)
@@ -747,14 +756,17 @@ def run(args, n, rank, local_rank, world, secondary, config5):
         ms = e0.elapsed_time(e1)
         bpes = (m.input_dim + m.output_dim) * (8 if args.dtype == "f64" else 4)
         ach = n * bpes / (ms / 1000 * 1e-3) / 1e9
-        tr, tr_src = pmc_traffic_rings(args.model, n, args.dtype, 1000)
+        tr, tr_src = (None, None) if auto_reset else pmc_traffic_rings(args.model, n, args.dtype, 1000)
         steady = {"value": n * 1000 / wall, "unit": "env-steps/s", "steps": 1000, "warmup": 100, "ms_per_step": wall,
-                  "kernel_ms_avg": ms, "steps_per_launch": 1000, "us_per_step_kernel": ms,
+                  "kernel_ms_avg": ms, "steps_per_launch": 128 if auto_reset else 1000, "us_per_step_kernel": ms,
                   "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                                "traffic": tr, "traffic_source": tr_src,
                                "traffic_over_algorithmic": (tr / (n * bpes * 1000)) if tr else None},
-                  "what": "the same launches and rings as `value`, 1000 steps in ONE launch after 100 warm-up steps; value from "
-                          "the wall clock around the call, kernel_ms_avg from a HIP event pair on the launch stream"}
+                  "what": ("the same launches and rings as `value`, 1000 steps in ONE call after 100 warm-up steps (auto-reset: "
+                           "step-loop launches of 128 steps, the reset pool's refill launches beside them); "
+                           if auto_reset else
+                           "the same launches and rings as `value`, 1000 steps in ONE launch after 100 warm-up steps; ") +
+                          "value from the wall clock around the call, kernel_ms_avg from a HIP event pair on the launch stream"}
     if use_rings and world == 1 and not args.no_secondary and not auto_reset and secondary:
         # (a) the substep-fused form: the same launches WITHOUT per-step records (y / obs of the last step of a launch only)
         kk = min(K, GCH)
@@ -835,6 +847,23 @@ def run(args, n, rank, local_rank, world, secondary, config5):
                 ar.close()
             except Exception as e:  # noqa: BLE001
                 auto_rate = {"error": repr(e)}
+
+    # the config-4 default line runs with auto-reset; the plain loop (+-0.1 rad, nothing reset: round 5's line) beside it
+    no_reset = None
+    if auto_reset and use_rings and world == 1 and not args.no_secondary and secondary and not args.auto_reset:
+        try:
+            kk = min(K, GCH)
+            nr = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype, lanes_per_env=args.lanes if args.lanes else None)
+            init_state(nr)
+            act01 = (actions * (0.1 / amp)).contiguous() if amp > 0 else actions
+            nr.step_many_rings(act01, max(kk, 64), obs_ring, y_ring)
+            rates = [timed(lambda: nr.step_many_rings(act01, kk, obs_ring, y_ring), kk) for _ in range(5)]
+            no_reset = {"value": sorted(rates)[len(rates) // 2], "unit": "env-steps/s", "steps": kk, "calls": len(rates),
+                        "what": "the same launches without auto-reset, +-0.1 rad actions (nothing resets a fallen robot): "
+                                "median of %d calls" % len(rates)}
+            nr.close()
+        except Exception as e:  # noqa: BLE001
+            no_reset = {"error": repr(e)}
 
     # secondary (not the headline): the same environments driven by per-environment linear policies
     # entirely on device, R policy steps per launch (tds_hip_rollout)
@@ -990,6 +1019,8 @@ def run(args, n, rank, local_rank, world, secondary, config5):
             out["one_rank_with_exchange_7_loopback_peers"] = one_rank_7
         if auto_rate is not None:
             out["auto_reset_rate"] = auto_rate
+        if no_reset is not None:
+            out["no_auto_reset_rate"] = no_reset
         if rollout is not None:
             out["on_device_rollout"] = rollout
         if pipelined is not None:

@@ -64,6 +64,8 @@ def _reward_done(m, name, q_before, y):
 @pytest.mark.parametrize("name,n,steps,dtype,form", [
     ("ant", 4096, 20, "f64", "default"), ("pendulum5", 4096, 20, "f64", "default"), ("pendulum5", 4096, 20, "mixed", "default"),
     ("laikago_soft", 8192, 50, "f64", "default"),
+    # config 4 in the 16-lane kernel's STEP-LOOP form (resident up to 6144 environments; 8192 runs single-step launches)
+    ("laikago_soft", 4096, 20, "f64", "default"), ("laikago_soft", 6144, 20, "f64", "default"),
     ("ant", 8192, 20, "f64", "default"),       # config 5's per-GPU share: the one-wave loop build
     # the builds a MULTI-GPU run launches (tds_hip_shard_step_many): a progress counter attached -> write-through record
     # stores, in the one-wave loop build (option exchange_w2 = 0) and in the two-wavefront build (the default); the obs
@@ -162,8 +164,10 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
             assert rel_err(orr[k][~edge, -2], rew[~edge], floor=1.0) < 10 * tol, (name, k)
         # resync on the device's own (double) state: what the next step started from
         x[:, :nq + nd] = yr_state[k][:, :nq + nd]
-    print(f"{name} x{n} [{dtype}, {form}], {steps} ring slots, every env, vs {what}: worst per-step rel err {worst:.3e} "
-          f"(loop form: {sim.step_many_is_loop(steps)})")
+    if name == "laikago_soft" and n <= 6144:
+        assert sim.single_step_kernel()[0] == "quad16" and sim.step_many_is_loop(steps)
+    print(f"{name} x{n} [{dtype}, {form}, {sim.single_step_kernel()[0]}], {steps} ring slots, every env, vs {what}: worst "
+          f"per-step rel err {worst:.3e} (loop form: {sim.step_many_is_loop(steps)})")
 
 
 RING_MODELS = ["ant", "laikago", "laikago_soft", "pendulum5", "cartpole_plane", "ant_floating", "laikago_floating_env",
@@ -283,8 +287,10 @@ def test_rings_with_auto_reset(name, built):
     assert rel_err(sims[0].x.cpu().numpy(), sims[1].x.cpu().numpy()) < TOL
 
 
-def test_rings_with_auto_reset_against_the_reference_at_full_size(built):
-    """Config 3's size through the form bench.py's auto_reset_rate times: Ant x 4096, auto_reset_when_done, 20 steps as
+@pytest.mark.parametrize("name,n", [("ant", 4096), ("laikago_soft", 4096)])
+def test_rings_with_auto_reset_against_the_reference_at_full_size(name, n, built):
+    """Configs 3 and 4 through the form bench.py times with auto-reset on (config 4's default line): Ant x 4096 in the
+    8-lane kernel, laikago_soft x 4096 in the 16-lane kernel; auto_reset_when_done, 20 steps as
     step-loop launches through the reset pool with both rings on.  The host replays the reference's loop environment by
     environment — its own step (libtds_ref.so), compute_reward_done (ant_environment2.h:75-106) and, for an environment that
     ends a step with done, reset() + the ten settle steps (ant_environment2.h:109-165; the device's counter-based random
@@ -294,7 +300,7 @@ def test_rings_with_auto_reset_against_the_reference_at_full_size(built):
     torch = _torch()
     from test_hip_parity import _host_reset, _reference_stepper
 
-    name, n, steps, seed = "ant", 4096, 20, 23
+    steps, seed = 20, 23
     m = tds_amd.load_model(name)
     ref_step, what = _reference_stepper(name, n)
     rng = np.random.default_rng(99)
@@ -304,10 +310,14 @@ def test_rings_with_auto_reset_against_the_reference_at_full_size(built):
     sim.x.copy_(torch.from_numpy(x0).cuda())
     for _ in range(10):
         sim.step(None)
-    # a tenth of the batch starts just above the termination height: resets in every one of the 20 steps
+    # a tenth of the batch starts just short of termination: resets in every one of the 20 steps
     xs = sim.x.cpu().numpy().copy()
     low = rng.permutation(n)[: n // 10]
-    xs[low, 2] = 0.262 + 0.02 * rng.uniform(0, 1, len(low))
+    if m.reward_mode == tds_amd.TDS_REWARD_ANT:  # (just above the termination height)
+        xs[low, 2] = 0.262 + 0.02 * rng.uniform(0, 1, len(low))
+    else:  # Laikago: rolling over at 2 rad/s, the up vector's z just above 0.6 (laikago_environment2.h:130-171)
+        xs[low, 3] = np.arccos(np.clip((0.6 + 0.02 * rng.uniform(0, 1, len(low))) / np.cos(xs[low, 4]), -1, 1))
+        xs[low, nq + 3] = 2.0
     sim.x.copy_(torch.from_numpy(xs).cuda())
     sim.set_auto_reset(True, seed)
     act = rng.uniform(-0.4, 0.4, (steps, n, adim))
@@ -325,7 +335,11 @@ def test_rings_with_auto_reset_against_the_reference_at_full_size(built):
         x[:, nq + nd:nq + nd + adim] = act[k]
         y_ref = ref_step(x)
         rew, done = _reward_done(m, name, x[:, :nq], y_ref)
-        edge = np.abs(y_ref[:, 2] - 0.26) < 1e-7  # (within round-off of the threshold: either side)
+        # (within round-off of a threshold: either side)
+        if m.reward_mode == tds_amd.TDS_REWARD_ANT:
+            edge = np.abs(y_ref[:, 2] - 0.26) < 1e-7
+        else:
+            edge = (np.abs(np.cos(y_ref[:, 3]) * np.cos(y_ref[:, 4]) - 0.6) < 1e-7) | (np.abs(y_ref[:, 2] - 0.2) < 1e-7)
         assert rel_err(yr[k], y_ref) < TOL, k
         got_done = orr[k][:, -1] != 0
         assert (got_done[~edge] == done[~edge]).all(), k
@@ -336,14 +350,18 @@ def test_rings_with_auto_reset_against_the_reference_at_full_size(built):
             count[e] += 1
             resets += 1
         ob = nxt.copy()
+        # (ars_vectorized_environment.h:281-286: the step's observation is the state the environment goes on from — the
+        #  fresh one after a reset — with the base x, y zeroed, whatever the environment's own reset() handed out)
         ob[:, :2] = 0.0
         assert rel_err(orr[k][:, :nq + nd], ob) < TOL, k
         # resync on the device's own state: what its next step started from
         x[:, :nq + nd] = np.where(got_done[:, None], orr[k][:, :nq + nd], yr[k][:, :nq + nd])
-        x[got_done, :2] = nxt[got_done, :2]  # (the observation zeroes the base x, y; the state keeps them)
-    assert resets >= n // 10, resets
+        x[got_done, :2] = nxt[got_done, :2]  # (the state keeps the base x, y)
+    assert resets >= n // 12, resets
     assert rel_err(sim.x.cpu().numpy()[:, :nq + nd], x[:, :nq + nd]) < TOL
-    print(f"ant x{n}, auto-reset ring form, {steps} slots, {resets} resets, every env, vs {what} + host reset: ok")
+    kern = sim.single_step_kernel()[0]
+    assert kern == ("oct8" if name == "ant" else "quad16") and sim.step_many_is_loop(steps)
+    print(f"{name} x{n} [{kern}], auto-reset ring form, {steps} slots, {resets} resets, every env, vs {what} + host reset: ok")
 
 
 @pytest.mark.gpu
