@@ -903,7 +903,8 @@ def run(args, n, rank, local_rank, world, secondary, config5):
             spl = (min(K, 256) if multi else min(K, GCH)) if loop_form else 1  # steps per launch (loop form: one launch = spl steps)
             if auto_reset:  # (step-loop launches of up to 128 steps, or single steps; the refill launches run beside them)
                 spl = min(K, GCH, 128) if loop_form else 1
-                traffic, traffic_src = None, None
+                # (single-step launches: counters of this very command; step-loop launches: of the same launch without resets)
+                traffic, traffic_src = pmc_traffic_rings(args.model, n, args.dtype, spl) if loop_form else (traffic, traffic_src)
             elif loop_form and per_step_records:
                 # every step's y and obs records leave the launch, the state itself stays in LDS: measured on the
                 # driver's own command

@@ -7,8 +7,9 @@
 #   trace      rocprofv3 --kernel-trace --stats of the driver's exact command             <tag>_ant4096_f64_default_{kernel_stats,dispatches}.txt
 #   traffic    HBM bytes: separate FETCH_SIZE / WRITE_SIZE passes, 20- and 1000-step      <tag>_ant4096_f64_{20,1000}_pmc_traffic.txt
 #   sq         SQ / LDS counters of the headline launch (three passes)                    <tag>_ant4096_f64_sq_counters_loop.txt
-#   others     the same two for config 5's share (Ant x 8192) and config 4 (laikago_soft x 8192, +-0.4 actions with auto-reset
-#              and without): traffic + SQ counters of THEIR kernels (tds_oct_kernel, tds_quad_kernel)
+#   others     the same two for config 5's share (Ant x 8192), config 4 (laikago_soft x 8192, +-0.4 actions with auto-reset: its
+#              default line; and the 16-lane kernel's step-loop form at 4096) and config 2 (pendulum5, float records):
+#              traffic + SQ counters of THEIR kernels (tds_oct_kernel, tds_quad_kernel, tds_step_kernel)
 #   exchange   one rank through tds_hip_shard_step_many (0 and 7 loopback peers): lines, kernel trace, timeline
 #   tworank    TWO processes on the one GPU through the peer-store exchange, rocprofv3 kernel trace of each + timeline
 #   phases     per-phase cycles of the two-wavefront step (both wavefronts), Ant and Laikago
@@ -28,7 +29,7 @@ import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     x=['%.4g env-steps/s'%d['value'], '%.2f us/step'%(1000*d['ms_per_step']), 'kernel_ms_avg %.4f'%d['roofline'].get('kernel_ms_avg',-1), 'frac %.4f'%d['roofline']['frac']]
-    for k in ('steady_state_1000','substep_fused','one_rank_with_exchange','one_rank_with_exchange_7_loopback_peers','auto_reset_rate'):
+    for k in ('steady_state_1000','substep_fused','one_rank_with_exchange','one_rank_with_exchange_7_loopback_peers','auto_reset_rate','no_auto_reset_rate'):
         if k in d and d[k]: x.append(k+'='+('%.4g'%d[k]['value'] if 'value' in d[k] else d[k].get('error','?')[:80]))
     x.append('form=%s'%(d['config'].get('exchange_form')))
     print(' '.join(x))
@@ -44,7 +45,8 @@ lines)
   timeout 600 python bench.py --steps 20 --warmup 5 > $P/${TAG}_bench_ant4096_f64_default.json 2> $O/default20.err
   $B --steps 1000 --warmup 100 > $P/${TAG}_bench_ant4096_f64_1000.json 2> $O/b1000.err
   $NS --steps 500 --warmup 50 --envs-per-gpu 8192 > $P/${TAG}_bench_ant8192_f64.json 2> $O/ant8192.err
-  $NS --steps 500 --warmup 50 --model laikago_soft --envs-per-gpu 8192 > $P/${TAG}_bench_laikago_soft8192_f64.json 2> $O/laikago.err
+  $B --steps 500 --warmup 50 --model laikago_soft --envs-per-gpu 8192 > $P/${TAG}_bench_laikago_soft8192_f64.json 2> $O/laikago.err
+  $B --steps 1000 --warmup 100 --model laikago_soft --envs-per-gpu 4096 > $P/${TAG}_bench_laikago_soft4096_f64.json 2> $O/laikago4096.err
   $NS --steps 500 --warmup 50 --model pendulum5 --dtype f32 > $P/${TAG}_bench_pendulum5_4096_f32rec.json 2> $O/pendulum5.err
   for f in $P/${TAG}_bench_*.json; do echo "$(basename $f .json): $(line_of $f)"; done | tee $P/${TAG}_bench_lines.txt ;;
 trace)
@@ -82,19 +84,26 @@ others)
   SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM"
   SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
   SQ3="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
-  for CFG in "ant8192 --envs-per-gpu 8192" "laikago_soft8192 --model laikago_soft --envs-per-gpu 8192 --action-amp 0.4"; do
-    set -- $CFG
-    NAME=$1; shift
+  # name | steps of the launch the counters are read from (0: single-step launches, mean) | bench.py arguments
+  #   laikago_soft8192: config 4's default line (+-0.4 rad, auto-reset; single-step launches of tds_quad_kernel)
+  #   laikago_soft4096_loop: the 16-lane kernel's step-loop form, one 500-step launch (no reset, +-0.1 rad)
+  while read -r NAME K ARGS; do
     i=0
     for CTRS in FETCH_SIZE WRITE_SIZE "$SQ1" "$SQ2" "$SQ3"; do
       i=$((i+1))
-      timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $O/o_${NAME}_$i -o p -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-secondary --spin-up-steps 0 --no-events "$@" > $O/o_${NAME}_$i.log 2>&1
+      timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $O/o_${NAME}_$i -o p -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-secondary --spin-up-steps 0 --no-events $ARGS > $O/o_${NAME}_$i.log 2>&1
     done
-    python tools/pmc_loop_summary.py 500 $O/o_${NAME}_1 $O/o_${NAME}_2 > $P/${TAG}_${NAME}_f64_pmc_traffic.txt 2>&1
-    python tools/pmc_loop_summary.py 500 $O/o_${NAME}_3 $O/o_${NAME}_4 $O/o_${NAME}_5 > $P/${TAG}_${NAME}_f64_sq_counters.txt 2>&1
+    python tools/pmc_loop_summary.py $K $O/o_${NAME}_1 $O/o_${NAME}_2 > $P/${TAG}_${NAME}_pmc_traffic.txt 2>&1
+    python tools/pmc_loop_summary.py $K $O/o_${NAME}_3 $O/o_${NAME}_4 $O/o_${NAME}_5 > $P/${TAG}_${NAME}_sq_counters.txt 2>&1
     rm -rf $O/o_${NAME}_*/
-    grep -h -v '^# kernel' $P/${TAG}_${NAME}_f64_pmc_traffic.txt | cut -c1-140
-  done ;;
+    echo "$NAME:"; grep -h -v '^# kernel' $P/${TAG}_${NAME}_pmc_traffic.txt | cut -c1-140
+  done <<'CFGS'
+ant8192_f64 500 --envs-per-gpu 8192
+laikago_soft8192_f64 0 --model laikago_soft --envs-per-gpu 8192
+laikago_soft4096_f64_loop 500 --model laikago_soft --envs-per-gpu 4096 --no-auto-reset
+pendulum5_4096_f32rec 500 --model pendulum5 --dtype f32
+CFGS
+  ;;
 exchange)
   for LB in 0 7; do
     $NS --steps 1024 --warmup 256 --force-gather --option shard_peer_loopback=$LB > $P/${TAG}_bench_ant4096_one_rank_exchange_${LB}peers_1024.json 2> $O/fg$LB.err
