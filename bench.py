@@ -915,7 +915,7 @@ def run(args, n, rank, local_rank, world, secondary, config5):
                 traffic, traffic_src = pmc_traffic_loop(args.model, n, args.dtype, spl)
             arith = "f32" if args.dtype == "f32-pure" else "f64"
             # which kernel the timed launches ran (tds_hip_single_step_kernel: the star-shaped robots have their own)
-            kernel_name = {"oct8": "tds_oct_kernel", "quad16": "tds_quad_kernel"}.get(sim.single_step_kernel()[0], "tds_step_kernel")
+            kernel_name = {"oct8": "tds_oct_kernel", "quad16": "tds_quad_kernel", "chain8": "tds_chain_kernel"}.get(sim.single_step_kernel()[0], "tds_step_kernel")
             sq_issue = sq_counters(args.model, n, args.dtype)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -569,7 +569,9 @@ int tds_hip_kernel_info(const tds_hip_sim_t *sim, int *lds_bytes_per_env, int *t
    config 4; create-time option quad = 0 keeps such a model on the general kernel), 2 the 8-lane kernel of the stars with
    two-link legs (csrc/tds_oct.hip: four legs of hip + ankle, a capsule on every leg link, a sphere on the root body — the gym
    Ant, BASELINE configs 3 and 5; create-time option oct = 0).  Both take models stepped with PD control on the leg joints
-   only.  Optional outputs: that kernel's lanes and LDS bytes per environment. */
+   only.  3 the kernel of the fixed-base serial chains without contacts (csrc/tds_chain.hip: 2 .. 8 links, link i the child of
+   link i - 1, 1-dof joints, torques given directly — cartpole and pendulum5, BASELINE configs 1 and 2; create-time option
+   chain = 0).  Optional outputs: that kernel's lanes and LDS bytes per environment. */
 int tds_hip_single_step_kernel(const tds_hip_sim_t *sim, int *lanes_per_env, int *lds_bytes_per_env);
 
 /* ======================================================================================

@@ -150,12 +150,13 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
                                                     : !(opts && opts->rings));
   const TdsLds &lds = (opts && opts->lds) ? *opts->lds : (two_waves ? s->lds_w2 : s->lds);
   const long long occ = s->opt.get(TDS_OPT_LOOP_OCC, 0);
-  // (the one-wavefront-per-SIMD compilation of the step loop does not exist below 14 padded dof: built without
+  // (the one-wavefront-per-SIMD compilation of the step loop does not exist below 24 padded dof: built without
   //  MachineLICM its <double, double, 16, 8> instantiation never terminated — profiles/r04_diag_loop_hang.txt — and the
-  //  two-wavefront compilation holds no scratch there, so nothing is lost; asked for by option, the launch is refused
-  //  instead of falling back silently)
-  if (occ == 1 && lds.NDP < 14 && !two_waves && (nsub != 1 || reset_mode != TDS_RESET_NONE || ro || (opts && opts->rings)))
-    return fail(TDS_ERR_UNSUPPORTED, "option loop_occ = 1: no one-wavefront-per-SIMD step-loop build below 14 padded dof");
+  //  two-wavefront compilation holds no scratch there; at 14 - 18 dof it paid for the Ant and Laikago at small batches,
+  //  which run in kernels of their own since rounds 5 / 6; asked for by option, the launch is refused instead of
+  //  falling back silently)
+  if (occ == 1 && lds.NDP < 24 && !two_waves && (nsub != 1 || reset_mode != TDS_RESET_NONE || ro || (opts && opts->rings)))
+    return fail(TDS_ERR_UNSUPPORTED, "option loop_occ = 1: no one-wavefront-per-SIMD step-loop build below 24 padded dof");
   // the 8-lane kernel (tds_oct.hip) takes the launch: its two-wavefront build while every workgroup of the launch is resident
   // with at most two wavefronts per SIMD — four workgroups per compute unit, LDS permitting (Ant: up to 8192 environments)
   int oct_form = 0;
@@ -238,7 +239,7 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
       if (s->opt.get(TDS_OPT_SHARD_PEER_RELEASE, 0) == 1) ctl.ring_flags |= TDS_RING_PEER_RELEASE;
       {  // a wavefront's records as one row of 8-byte units (put_obs_wide): every stride a multiple of 8 bytes
         // (environments per wavefront: eight where the 8-lane kernel takes the launch — tds_oct_takes)
-        const bool oct_launch = s->compute_f64() && s->h64.oct != 0 && nsub >= 1 && reset_mode == TDS_RESET_NONE && !ro;
+        const bool oct_launch = s->compute_f64() && (s->h64.oct != 0 || s->h64.chain != 0) && nsub >= 1 && reset_mode == TDS_RESET_NONE && !ro;
         const size_t wb = r.obs_f32 ? 4 : s->elem, w = (size_t)s->obs_width(), epw = oct_launch ? 8 : (size_t)(64 / s->lanes);
         if ((epw * w * wb) % 8 == 0 && ((size_t)ctl.obs_envs * w * wb) % 8 == 0 && ((size_t)(uintptr_t)ctl.obs_ring) % 8 == 0 &&
             (size_t)ctl.peer_off % 8 == 0 && (size_t)n % epw == 0 && pl.wide_ok)
@@ -315,8 +316,8 @@ int tds_hip_set_option(tds_hip_sim_t *s, const char *key, long long value) {
   if (tds_opt_rows()[k].create_time)
     return fail(TDS_ERR_INVALID_ARG, "option '%s' is fixed when a handle is created: tds_hip_default_option before tds_hip_create", key);
   if (s->opt.v[k] == value) return TDS_OK;
-  if (k == TDS_OPT_LOOP_OCC && value == 1 && s->lds.NDP < 14)
-    return fail(TDS_ERR_UNSUPPORTED, "option loop_occ = 1: no one-wavefront-per-SIMD step-loop build below 14 padded dof");
+  if (k == TDS_OPT_LOOP_OCC && value == 1 && s->lds.NDP < 24)
+    return fail(TDS_ERR_UNSUPPORTED, "option loop_occ = 1: no one-wavefront-per-SIMD step-loop build below 24 padded dof");
   // options that shape the shard layer's ring are read ONCE, when the ring is first used: afterwards a new value would be
   // ignored silently — refused instead (set them before the first tds_hip_shard_step_many, or with tds_hip_default_option)
   if (s->shard_ring_shaped && (k == TDS_OPT_SHARD_CHUNK || k == TDS_OPT_SHARD_INPLACE || k == TDS_OPT_SHARD_WAIT ||
@@ -372,6 +373,15 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     return fail(TDS_ERR_INVALID_ARG, "unknown dtype");
   int rc = tds_hip_model_check(model);
   if (rc != TDS_OK) return rc;
+  if (dtype == TDS_DTYPE_F32) {
+    // pure float arithmetic is a measured-only variant (it misses the 1e-6 contract, tds_hip.h): built for the plain and
+    // the floating-base kernels, not for spherical joints or worlds of several bodies
+    bool sph = false;
+    for (int i = 0; i < model->num_links; ++i) sph = sph || model->links[i].joint_type == TDS_JOINT_SPHERICAL;
+    if (sph || model->num_bodies >= 2)
+      return fail(TDS_ERR_UNSUPPORTED, "TDS_DTYPE_F32 (pure float arithmetic) is not built for spherical joints or worlds of "
+                                       "several bodies: use TDS_DTYPE_F64_REC32 (float records, double arithmetic)");
+  }
   int ndev = tds_hip_device_count();
   if (ndev <= 0) return fail(TDS_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(TDS_ERR_INVALID_ARG, "device index out of range");
@@ -1299,7 +1309,7 @@ bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
   // the 8-lane kernel of the stars with two-link legs (tds_oct.hip: the Ant): always one launch.  Its straight-line form costs
   // the same table copy and workgroup rounds per step plus a kernel boundary and the state's round trip through HBM, so
   // beyond one round of resident workgroups (8192 environments) R rounds of K steps still beat K launches of R rounds
-  if (s->compute_f64() && s->h64.oct) return true;
+  if (s->compute_f64() && (s->h64.oct || s->h64.chain)) return true;  // (and the serial-chain kernel, tds_chain.hip)
   const int n_blocks = (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
   // With auto-reset on the alternative is not the chained graphs but single steps through the reset pool: the step-loop
   // launches (pool_step_many) win at every batch size (Ant x 16384 / 32768 at 5 % resets per step: 2.81e8 / 2.87e8
@@ -1461,7 +1471,7 @@ int tds_hip_step_many_rings(tds_hip_sim_t *s, const void *actions_dev, int actio
 
 int tds_hip_step_many_rings_blocks(const tds_hip_sim_t *s) {
   if (!s) return 0;
-  if (s->compute_f64() && s->h64.oct) return (s->num_envs + 7) / 8;  // (the 8-lane kernel: eight environments per workgroup)
+  if (s->compute_f64() && (s->h64.oct || s->h64.chain)) return (s->num_envs + 7) / 8;  // (the 8-lane kernels: eight environments per workgroup)
   return (s->num_envs + (64 / s->lanes) - 1) / (64 / s->lanes);
 }
 
@@ -2164,6 +2174,12 @@ int tds_hip_kernel_info(const tds_hip_sim_t *s, int *lds_bytes_per_env, int *thr
 int tds_hip_single_step_kernel(const tds_hip_sim_t *s, int *lanes_per_env, int *lds_bytes_per_env) {
   if (!s) return -1;
   const bool quad = s->compute_f64() && s->h64.quad != 0, oct = s->compute_f64() && s->h64.oct != 0;
+  const bool chain = s->compute_f64() && s->h64.chain != 0;
+  if (chain) {
+    if (lanes_per_env) *lanes_per_env = 8;
+    if (lds_bytes_per_env) *lds_bytes_per_env = tds_chain_lds_bytes(s->h64.chain);
+    return 3;
+  }
   if (lanes_per_env) *lanes_per_env = oct ? 8 : (quad ? 16 : s->lanes);
   if (lds_bytes_per_env)
     *lds_bytes_per_env = oct    ? tds_oct_lds_bytes(s->model.input_dim)

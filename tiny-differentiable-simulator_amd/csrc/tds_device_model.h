@@ -106,7 +106,11 @@ struct DevModel {
   // body with one sphere (17 contact points in the reference's order), visuals on links 5 .. 13 in link order, env step
   // with PD control.  The gym Ant (BASELINE configs 3 and 5) is one; option oct = 0 keeps such a model on the general kernel.
   int oct;
-  T oct_tab[TDS_OCT_TAB_CAP];  // (TdsOctTab, tds_oct_model.h; filled where oct == 1)
+  // n > 0: the model is a fixed-base serial CHAIN of n links (2 .. 8) without contacts, torques given directly — the kernel of
+  // tds_chain.hip (tds_chain_model.h: tds_chain_detect); BASELINE configs 1 and 2 (cartpole, pendulum5).  Option chain = 0
+  // keeps such a model on the general kernel.
+  int chain;
+  T oct_tab[TDS_OCT_TAB_CAP];  // (TdsOctTab, tds_oct_model.h, where oct == 1; TdsChainTab, tds_chain_model.h, where chain > 0)
   T X_T[12][TDS_NL];            // rot (row-major 9) | trans (3)
   T S[6][TDS_NL];
   T mass[TDS_NL], com[3][TDS_NL], inertia[9][TDS_NL];
@@ -150,6 +154,7 @@ struct DevModel {
 };
 
 #include "tds_oct_model.h"
+#include "tds_chain_model.h"
 
 // reference: src/mb_constraint_solver.hpp:506-520 (incl. k = sqrt(a) and p[2] quirks)
 static inline void tds_plane_space(const double *n, double *p, double *q) {
@@ -646,6 +651,7 @@ static int tds_build_dev_model_impl(const tds_model_t *m, DevModel<T> *d, char *
     d->quad = ok ? 1 : 0;
   }
   tds_oct_detect<T>(m, d, ncp, star_actuation(2, 2));
+  tds_chain_detect<T>(m, d);
 #undef TDS_FAIL
   return TDS_OK;
 }

@@ -196,6 +196,16 @@ inline bool tds_oct_takes(int oct, const TdsStepCtl &ctl, const long long *prof)
   return oct != 0 && prof == nullptr && ctl.nsub >= 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
 }
 
+// the serial-chain kernel (tds_chain.hip): plain steps and step loops incl. record rings and the exchange; no resets (its
+// models have no reward rule: no environment is ever done), no policy, no phase stamps
+template <typename T, typename TR>
+int tds_launch_chain(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
+                     TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl);
+int tds_chain_lds_bytes(int num_links);
+inline bool tds_chain_takes(int chain, const TdsStepCtl &ctl, const long long *prof) {
+  return chain != 0 && prof == nullptr && ctl.nsub >= 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
+}
+
 // T: compute scalar, TR: record scalar (== T, or float under T = double: "f32 records / f64 arithmetic")
 template <typename T, typename TR>
 inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_model, const TdsLds &L, int lanes_per_env,
@@ -210,11 +220,19 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
     if (tds_oct_takes(h_model.oct, ctl, prof))
       return tds_launch_oct<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl,
                                    (form & TDS_FORM_OCT_W2_OCC1) ? 3 : ((form & TDS_FORM_OCT_W2) ? 2 : 1));
+    if (tds_chain_takes(h_model.chain, ctl, prof))
+      return tds_launch_chain<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl);
   }
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
-  if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
-  if (h_model.num_bodies >= 2 && h_model.multi_floating) return tds_launch_step_impl<T, TR, 4>(TDS_ARGS);
-  if (h_model.num_bodies >= 2) return tds_launch_step_impl<T, TR, 3>(TDS_ARGS);
+  // (pure float arithmetic — measured only, it misses the 1e-6 contract: tds_hip.h TDS_DTYPE_F32 — is built for the
+  //  plain and the floating-base kernels; tds_hip_create refuses it for spherical joints and worlds of several bodies)
+  if constexpr (sizeof(T) == 8) {
+    if (h_model.num_spherical) return tds_launch_step_impl<T, TR, 2>(TDS_ARGS);
+    if (h_model.num_bodies >= 2 && h_model.multi_floating) return tds_launch_step_impl<T, TR, 4>(TDS_ARGS);
+    if (h_model.num_bodies >= 2) return tds_launch_step_impl<T, TR, 3>(TDS_ARGS);
+  } else {
+    if (h_model.num_spherical || h_model.num_bodies >= 2) return -4;
+  }
   return tds_launch_step_impl<T, TR, 0>(TDS_ARGS);
 #undef TDS_ARGS
 }
@@ -223,11 +241,15 @@ template <typename T, typename TR, int KIND>
 int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes);
 template <typename T, typename TR>
 inline int tds_kernel_max_dynamic_lds(int lanes_per_env, int ndp, int bytes, int kind) {
+  if constexpr (sizeof(T) == 8) {
+    if (kind == 2) return tds_kernel_max_dynamic_lds_impl<T, TR, 2>(lanes_per_env, ndp, bytes);
+    if (kind == 3) return tds_kernel_max_dynamic_lds_impl<T, TR, 3>(lanes_per_env, ndp, bytes);
+    if (kind == 4) return tds_kernel_max_dynamic_lds_impl<T, TR, 4>(lanes_per_env, ndp, bytes);
+  } else {
+    if (kind >= 2) return -4;
+  }
   return kind == 1 ? tds_kernel_max_dynamic_lds_impl<T, TR, 1>(lanes_per_env, ndp, bytes)
-         : kind == 2 ? tds_kernel_max_dynamic_lds_impl<T, TR, 2>(lanes_per_env, ndp, bytes)
-         : kind == 3 ? tds_kernel_max_dynamic_lds_impl<T, TR, 3>(lanes_per_env, ndp, bytes)
-         : kind == 4 ? tds_kernel_max_dynamic_lds_impl<T, TR, 4>(lanes_per_env, ndp, bytes)
-                     : tds_kernel_max_dynamic_lds_impl<T, TR, 0>(lanes_per_env, ndp, bytes);
+                   : tds_kernel_max_dynamic_lds_impl<T, TR, 0>(lanes_per_env, ndp, bytes);
 }
 
 int tds_padded_dof(int nd, int lanes_per_env = 0);

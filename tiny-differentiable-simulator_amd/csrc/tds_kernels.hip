@@ -4003,10 +4003,12 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
                            stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
         break;                                                                                               \
       }                                                                                                      \
-      if (two_waves && simple && prof) {                                                                     \
-        hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), true, 0, 0, true>), dim3(blocks), dim3(128), shmem, \
-                           stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
-        break;                                                                                               \
+      if constexpr (PROF_BUILDS) {                                                                           \
+        if (two_waves && simple && prof) {                                                                   \
+          hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), true, 0, 0, true>), dim3(blocks), dim3(128), shmem, \
+                             stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
+          break;                                                                                             \
+        }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
     TDS_PROF_LOOP_LAUNCH(GG, NN)                                                                             \
@@ -4017,22 +4019,24 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
         break;                                                                                               \
       }                                                                                                      \
     }                                                                                                        \
-    if (prof)                                                                                                \
-      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, true, 0, 0>), dim3(blocks), dim3(64), shmem, stream, \
-                         d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
-    else if (simple)                                                                                         \
+    if (prof) {                                                                                              \
+      if constexpr (PROF_BUILDS)                                                                             \
+        hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, true, 0, 0>), dim3(blocks), dim3(64), shmem, stream, \
+                           d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);   \
+      else return -2;                                                                                        \
+    } else if (simple)                                                                                         \
       hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, 0, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
-    else if (loop_occ2 && NN < 24)                                                                           \
-      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 2, KIND>), dim3(blocks), dim3(64), shmem, stream, \
-                         d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
-    else if constexpr (NN >= 14)                                                                             \
-      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN >= 14 ? NN : 32), false, 1, KIND>), dim3(blocks), dim3(64), shmem, stream, \
+    else if constexpr (NN < 24)                                                                              \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, 2, KIND>), dim3(blocks), dim3(64), shmem, stream, \
                          d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
     else                                                                                                     \
-      return -3; /* (no one-wavefront-per-SIMD step-loop build below 14 padded dof: see loop_occ2) */        \
+      hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, NN, false, 1, KIND>), dim3(blocks), dim3(64), shmem, stream, \
+                         d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs);     \
   } while (0)
-  if (prof && KIND != 0) return -2;  // the phase-stamp build exists for the plain kernels only
+  // the phase-stamp builds exist for the plain kernels with double records only (a diagnostic: profiles/*_phases.txt)
+  constexpr bool PROF_BUILDS = KIND == 0 && sizeof(T) == 8 && sizeof(TR) == 8;
+  if (prof && !PROF_BUILDS) return -2;
   // straight-line kernel when the launch is exactly one normal step without any reset
   const bool simple = ctl.nsub == 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr &&
                       ctl.obs_ring == nullptr && ctl.y_ring == nullptr;  // (record rings: the step-loop builds write them)
@@ -4047,7 +4051,9 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   //  built without the pass — profiles/r04_diag_loop_hang.txt.  Round 5: that compilation is no longer INSTANTIATED
   //  below 14 padded dof — nothing can launch it; option loop_occ = 1 is refused there by tds_api.hip: launch(),
   //  TDS_ERR_UNSUPPORTED, and tests/test_options.py runs the 8-dof loop launches under a watchdog)
-  const bool loop_occ2 = L.NDP < 24 && (loop_force == 2 || L.NDP < 14 || (loop_force != 1 && (blocks >= 1536 || L.NDP < 16)));
+  // (round 6: below 24 padded dof only the two-wavefronts-per-SIMD compilation is instantiated — the robots whose batch
+  //  sizes made the other one worth its build time, 14 and 18 dof, run in kernels of their own: tds_oct.hip, tds_quad.hip)
+  (void)loop_force;
   const int key = lanes_per_env * 100 + L.NDP;
   switch (key) {
 #define TDS_CASE(GG, NN) \
@@ -4071,21 +4077,28 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
   do {                                                                                                          \
     e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 0, KIND>,                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                 \
-    if (e == hipSuccess && NN >= 14)                                                                            \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN >= 14 ? NN : 32), false, 1, KIND>,      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
-    if (e == hipSuccess && NN < 24)                                                                             \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 2, KIND>,        \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
-    if (e == hipSuccess && KIND == 0)                                                                               \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, true, 0, 0>,                     \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
-    if (e == hipSuccess && KIND == 0 && NN < 24)                                                                    \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 0, 0, true>,      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
-    if (e == hipSuccess && KIND == 0 && NN < 24)                                                                    \
-      e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 1, 0, true>,      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                               \
+    if constexpr (NN >= 24) {                                                                                   \
+      if (e == hipSuccess)                                                                                      \
+        e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 1, KIND>,                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                             \
+    } else {                                                                                                    \
+      if (e == hipSuccess)                                                                                      \
+        e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 2, KIND>,                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                             \
+    }                                                                                                           \
+    if constexpr (KIND == 0 && sizeof(T) == 8 && sizeof(TR) == 8) {                                             \
+      if (e == hipSuccess)                                                                                      \
+        e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, true, 0, 0>,                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                             \
+    }                                                                                                           \
+    if constexpr (KIND == 0 && NN < 24) {                                                                       \
+      if (e == hipSuccess)                                                                                      \
+        e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 0, 0, true>,                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                             \
+      if (e == hipSuccess)                                                                                      \
+        e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 1, 0, true>,                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                             \
+    }                                                                                                           \
   } while (0)
   switch (lanes_per_env * 100 + ndp) {
 #define TDS_CASE(GG, NN) \

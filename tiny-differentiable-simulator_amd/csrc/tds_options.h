@@ -24,6 +24,7 @@ enum TdsOptKey {
   TDS_OPT_FOLD_FIXED,         // 1: fold fixed links into their parents even when the lanes would suffice
   TDS_OPT_QUAD,               // 0: a star-shaped legged robot (Laikago) stays on the general kernel instead of tds_quad.hip's 16-lane kernel
   TDS_OPT_OCT,                // 0: a star with two-link legs (the Ant) stays on the general kernel instead of tds_oct.hip's 8-lane kernel
+  TDS_OPT_CHAIN,              // 0: a fixed-base serial chain without contacts (cartpole, pendulum5) stays on the general kernel instead of tds_chain.hip's
   // ---- run-time rows (may change between calls of a handle)
   TDS_OPT_LOOP_W2,            // step-loop launches: 0 one-wave build, 1 (default) two-wavefront build where it fits, 2 ... not with the reset pool
   TDS_OPT_OCT_W2,             // 8-lane kernel (tds_oct.hip): 0 one wavefront per workgroup, 1 / unset two (main + helper) while every workgroup is resident with at most two wavefronts per SIMD, 2 two at any grid size
@@ -84,6 +85,7 @@ inline const TdsOptRow *tds_opt_rows() {
       {"fold_fixed", true, "TDS_HIP_FOLD_FIXED"},
       {"quad", true, "TDS_HIP_QUAD"},
       {"oct", true, "TDS_HIP_OCT"},
+      {"chain", true, "TDS_HIP_CHAIN"},
       {"loop_w2", false, "TDS_HIP_LOOP_W2"},
       {"oct_w2", false, "TDS_HIP_OCT_W2"},
       {"loop_occ", false, "TDS_HIP_LOOP_OCC"},

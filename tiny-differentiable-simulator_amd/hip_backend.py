@@ -267,7 +267,7 @@ class HipSim:
             create_opts["na_cap"] = na_cap
         if options:  # create-time options go through the process defaults, run-time ones are set on the new handle
             ct = ("lanes_per_env", "na_cap", "w2", "gram", "no_chain", "no_rootjoint", "no_kinchain", "no_eulerroot",
-                  "no_legscan", "fold_fixed", "quad", "oct")
+                  "no_legscan", "fold_fixed", "quad", "oct", "chain")
             create_opts.update({k: v for k, v in options.items() if k in ct})
         h = C.c_void_p()
         with default_options(**create_opts):
@@ -626,11 +626,11 @@ class HipSim:
         return [v - t0 for v in st[:14]], [v - t0 for v in st[14:23]], extra
 
     def single_step_kernel(self):
-        """which kernel a plain single step runs: ("general" | "quad16" | "oct8", lanes per environment, LDS bytes per environment)"""
+        """which kernel a plain single step runs: ("general" | "quad16" | "oct8" | "chain8", lanes per environment, LDS bytes per environment)"""
         a, b = C.c_int(), C.c_int()
         lib().tds_hip_single_step_kernel.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         k = lib().tds_hip_single_step_kernel(self.h, C.byref(a), C.byref(b))
-        return {1: "quad16", 2: "oct8"}.get(k, "general"), a.value, b.value
+        return {1: "quad16", 2: "oct8", 3: "chain8"}.get(k, "general"), a.value, b.value
 
     def kernel_info(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
