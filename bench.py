@@ -512,12 +512,16 @@ def run(args, n, rank, local_rank, world, secondary, config5):
         # The exchange forms, most to least ambitious:
         #   ring / peer stores   the step-loop launch (the N = 1 kernel) stores every record on every rank itself (IPC-mapped
         #                        rings): no collective, no host call per step — the library's default
+        #   ring / staged copies the same rings and flags, but the launch writes this rank's ring only and the communication
+        #                        stream copies the launch's slots into every peer's ring (option shard_peer_copy = 1: the
+        #                        runtime's copy engines instead of stores from the kernel)
         #   ring / RCCL          the same launches, the slots sent with ncclAllGather (shard re-created with shard_peer = 0)
         #   per-step eager       one tds_hip_shard_step call per step (kernel launch + ncclAllGather)
         # A form that fails during the warm-up steps on ANY rank (a wait that timed out, an RCCL error; a set-up that cannot
         # be made falls back inside the library) is dropped on EVERY rank before anything is timed.  No timing decides
         # anything here: every rank runs the library's default build of the kernel.
-        forms = [("ring", None), ("ring", {"shard_peer": 0}), ("per-step eager", None)] if shard_graph else [("per-step eager", None)]
+        forms = ([("ring", None), ("ring", {"shard_peer_copy": 1}), ("ring", {"shard_peer": 0}), ("per-step eager", None)]
+                 if shard_graph else [("per-step eager", None)])
         current_opts = None
         for f, fopts in forms:
             err = 0
@@ -628,30 +632,37 @@ def run(args, n, rank, local_rank, world, secondary, config5):
             sync_fn()
             return ranks.close_region(t1, world, "cuda", torch.cuda.synchronize)
 
-        try:
-            shard.flush()
-            torch.cuda.synchronize()
-            sh2 = create_shard({"exchange_fields": 1})  # (a second shard beside the first: its own communicator and rings)
-            init_state(sh2.sim)
-            st2 = {"i": 0}
+        def shard_variant(key, opts, what):
+            try:
+                shard.flush()
+                torch.cuda.synchronize()
+                sh2 = create_shard(opts)  # (a second shard beside the first: its own communicator and rings)
+                init_state(sh2.sim)
+                st2 = {"i": 0}
 
-            def steps_rd(k):
-                left = k
-                while left > 0:
-                    c = min(left, GCH)
-                    sh2.step_many(actions, c, first_block=st2["i"] % pool)
-                    st2["i"] += c
-                    left -= c
+                def steps_v(k):
+                    left = k
+                    while left > 0:
+                        c = min(left, GCH)
+                        sh2.step_many(actions, c, first_block=st2["i"] % pool)
+                        st2["i"] += c
+                        left -= c
 
-            dt_rd = timed_k(steps_rd, lambda: (sh2.flush(), torch.cuda.synchronize()))
-            exch_variants["exchange_fields_reward_done"] = {
-                "value": ranks.job_rate(world, n, K, dt_rd), "unit": "env-steps/s", "ms_per_step": dt_rd / K * 1e3,
-                "exchange_form": sh2.exchange_form(),
-                "what": "the same launches, only [reward | done] of a record travel to the peers (option exchange_fields = 1; "
-                        "this rank's own block still receives the whole record)"}
-            sh2.close()
-        except Exception as e:  # noqa: BLE001  (a secondary: reported, never fatal)
-            exch_variants["exchange_fields_reward_done"] = {"error": repr(e)[:300]}
+                dt_v = timed_k(steps_v, lambda: (sh2.flush(), torch.cuda.synchronize()))
+                exch_variants[key] = {"value": ranks.job_rate(world, n, K, dt_v), "unit": "env-steps/s", "ms_per_step": dt_v / K * 1e3,
+                                      "exchange_form": sh2.exchange_form(), "what": what}
+                sh2.close()
+            except Exception as e:  # noqa: BLE001  (a secondary: reported, never fatal)
+                exch_variants[key] = {"error": repr(e)[:300]}
+
+        shard_variant("exchange_fields_reward_done", {"exchange_fields": 1},
+                      "the same launches, only [reward | done] of a record travel to the peers (option exchange_fields = 1; this "
+                      "rank's own block still receives the whole record)")
+        if exchange_form != "peer_copy":
+            shard_variant("exchange_staged_copies", {"shard_peer_copy": 1},
+                          "the same rings and flags, the launch writes this rank's ring only and the communication stream copies "
+                          "the launch's slots into every peer's ring behind it (option shard_peer_copy = 1: one strided "
+                          "device-to-device copy per peer and launch — the copy engines — instead of stores from the kernel)")
         try:
             plain = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype)
             init_state(plain)
@@ -949,6 +960,9 @@ def run(args, n, rank, local_rank, world, secondary, config5):
             how = {"peer_stores": "the launch stores each record into its block of the gathered slot on EVERY rank (IPC-mapped "
                                   "rings, system-scope stores over xGMI) and raises the slot's flags when its last workgroup has "
                                   "stored it: no collective, the transfer of step k lies inside step k + 1",
+                   "peer_copy": "the launch stores its records into this rank's block of the gathered ring; behind it the "
+                                "communication stream copies the launch's slots into every peer's ring (IPC-mapped; one strided "
+                                "device-to-device copy per peer: the copy engines) and raises the slots' flags: no collective",
                    "rccl_group_after_launch": "the launch's slots are all-gathered as ONE RCCL group behind it",
                    "rccl_per_slot": "the communication stream follows the slots' progress counters and all-gathers each slot "
                                     "beside the launch"}.get(exchange_form, str(exchange_form))
@@ -998,7 +1012,7 @@ def run(args, n, rank, local_rank, world, secondary, config5):
                        "steps_per_launch": (min(K, 256) if multi else min(K, GCH)) if loop_form else 1,
                        "parallelism": f"env-shard x{world}" + (
                            f" + one exchange of the (obs|reward|done) records per {'policy step' if B == 1 else str(B) + ' steps'} "
-                           f"({'peer stores into IPC-mapped gathered rings, no collective' if exchange_form == 'peer_stores' else 'ncclAllGather, librccl called from the C ABI'}; "
+                           f"({'peer stores into IPC-mapped gathered rings, no collective' if exchange_form == 'peer_stores' else ('staged copies into IPC-mapped gathered rings, no collective' if exchange_form == 'peer_copy' else 'ncclAllGather, librccl called from the C ABI')}; "
                            f"tds_hip_shard_step_many), {args.gather_dtype if args.dtype == 'f64' else 'f32'} on the wire (the records are "
                            f"computed and fed back in {'f64' if args.dtype == 'f64' else 'f32'} on the owning GPU), overlapped with "
                            f"the following steps" if multi else ""),

@@ -671,7 +671,11 @@ enum {
   TDS_EXCHANGE_RCCL_PER_STEP = 1,     /* one kernel launch + one ncclAllGather per step (eager or from one hipGraph) */
   TDS_EXCHANGE_RCCL_AFTER_LAUNCH = 2, /* ring exchange, two-wavefront build: the launch's slots as ONE RCCL group behind it */
   TDS_EXCHANGE_RCCL_PER_SLOT = 3,     /* ring exchange, one-wave build: wait kernel + ncclAllGather per slot beside the launch */
-  TDS_EXCHANGE_PEER_STORES = 4        /* ring exchange by peer stores: no collective, the launch writes every rank's ring */
+  TDS_EXCHANGE_PEER_STORES = 4,       /* ring exchange by peer stores: no collective, the launch writes every rank's ring */
+  TDS_EXCHANGE_PEER_COPY = 5          /* the same rings, flags and credit protocol, STAGED (option shard_peer_copy = 1): the launch
+                                         writes this rank's ring only; behind it the communication stream copies the launch's
+                                         slots into every peer's ring (one strided device-to-device copy per peer: the runtime's
+                                         copy engines) and raises the flags — no collective, no fabric store from the kernel */
 };
 int tds_hip_shard_exchange_form(const tds_hip_shard_t *shard);
 /* ranks this shard stores its records to under the peer-store exchange (0 on one rank; -1: the exchange is not in use) */

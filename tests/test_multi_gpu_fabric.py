@@ -163,6 +163,7 @@ WORLDS = [2, 4, 8]
     ("peer_stores", {"TDS_HIP_SHARD_PEER": "2"}, "peer_stores"),                     # the default, required (an error instead of the fallback)
     ("peer_stores_release_fences", {"TDS_HIP_SHARD_PEER": "2", "TDS_HIP_SHARD_PEER_RELEASE": "1"}, "peer_stores"),
     ("reward_done_only", {"TDS_HIP_SHARD_PEER": "2", "TDS_HIP_EXCHANGE_FIELDS": "1"}, "peer_stores"),
+    ("staged_copies", {"TDS_HIP_SHARD_PEER": "2", "TDS_HIP_SHARD_PEER_COPY": "1"}, "peer_copy"),  # copy engines instead of stores from the kernel
     ("rccl", {"TDS_HIP_SHARD_PEER": "0"}, None),                                       # ncclAllGather of the launch's slots
 ])
 def test_every_gathered_slot_on_every_rank_over_the_fabric(world, variant, env, want_form, built, tmp_path):

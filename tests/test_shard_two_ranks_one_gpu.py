@@ -106,7 +106,12 @@ RCCL = {"TDS_HIP_SHARD_PEER": "0"}  # the forms of the exchange that go through 
     ("many", "ant", 75, {"TDS_HIP_EXCHANGE_FIELDS": "1"}, "peer_stores"),   # only [reward | done] travel to the peer
     ("many", "ant", 75, {"_n_local": "201"}, "peer_stores"),                # a ragged last wavefront: lane-per-component stores instead of whole rows
     ("many", "ant", 75, {"_n_local": "201", "TDS_HIP_EXCHANGE_FIELDS": "1"}, "peer_stores"),
-    ("many", "pendulum5", 30, {}, "peer_stores"),                           # a world without contacts (one-wave step-loop build)
+    ("many", "pendulum5", 30, {}, "peer_stores"),                           # a world without contacts (the serial-chain kernel)
+    # the STAGED form of the same exchange (option shard_peer_copy): the launch writes its own ring only, the communication
+    # stream copies the launch's slots into the peer's ring (one strided device-to-device copy) and raises the flags
+    ("many", "ant", 75, {"TDS_HIP_SHARD_PEER": "2", "TDS_HIP_SHARD_PEER_COPY": "1"}, "peer_copy"),
+    ("many", "ant", 75, {"_n_local": "201", "TDS_HIP_SHARD_PEER_COPY": "1"}, "peer_copy"),
+    ("many", "pendulum5", 30, {"TDS_HIP_SHARD_PEER_COPY": "1"}, "peer_copy"),
     ("many", "ant", 75, dict(RCCL), "rccl_group_after_launch"),             # ring exchange, two-wavefront build, slots sent behind the launch as one group
     ("many", "ant", 75, dict(RCCL, TDS_HIP_EXCHANGE_W2="0"), "rccl_per_slot"),  # ... the one-wave build: per-slot counters, a slot sent while the launch runs
     ("many", "ant", 75, dict(RCCL, TDS_HIP_SHARD_GRAPH="1"), "rccl_group_after_launch"),  # ring exchange, one hipGraph per step-loop launch
@@ -149,7 +154,7 @@ def test_two_ranks_on_one_gpu(mode, name, steps, env, want_form, built, stub_lib
     rd_only = env.get("TDS_HIP_EXCHANGE_FIELDS") == "1"
     for k in range(world):
         assert str(r[k]["form"]) == want_form, (k, str(r[k]["form"]), logs[k])
-        assert int(r[k]["peers"]) == (1 if want_form == "peer_stores" else -1)
+        assert int(r[k]["peers"]) == (1 if want_form in ("peer_stores", "peer_copy") else -1)
         got = r[k]["gathered"].reshape(-1, w)
         assert got.shape == want.shape
         if rd_only:  # the OTHER rank's block carries [reward | done] only (its observation columns are never written)

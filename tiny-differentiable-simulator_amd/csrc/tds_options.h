@@ -59,6 +59,7 @@ enum TdsOptKey {
   TDS_OPT_SHARD_PEER,         // ring exchange by PEER STORES (the step kernel writes its records into the other ranks' gathered rings, IPC-mapped): unset / 1 where it can be set up on every rank (else the RCCL all-gather), 0 never, 2 required (error instead of the fallback)
   TDS_OPT_EXCHANGE_FIELDS,    // peer-store exchange: 0 / unset the whole [obs | reward | done] record travels, 1 only [reward | done]
   TDS_OPT_SHARD_PEER_RELEASE,   // peer-store exchange: 1 = system-scope release fences in front of the arrival counts and the flag stores (A/B switch for the first run on a real fabric; default: vmcnt(0) + relaxed stores)
+  TDS_OPT_SHARD_PEER_COPY,      // peer exchange, STAGED form: 1 = the launch stores its records into this rank's own ring only and the communication stream pushes the launch's slots to every peer's ring with one strided device-to-device copy per peer (the runtime's copy engines: SDMA over xGMI) + one flag kernel — nothing of the exchange on a compute unit beside the launch, no store over the fabric from inside it (third form of bench.py's warm-up ladder; default 0: in-kernel peer stores)
   TDS_OPT_SHARD_PEER_LOOPBACK,  // diagnostic: k extra "peers" mapped onto scratch rings of this rank's own GPU (the kernel-side cost of k peers, measurable on one GPU)
   TDS_OPT_COUNT
 };
@@ -118,6 +119,7 @@ inline const TdsOptRow *tds_opt_rows() {
       {"shard_peer", false, "TDS_HIP_SHARD_PEER"},
       {"exchange_fields", false, "TDS_HIP_EXCHANGE_FIELDS"},
       {"shard_peer_release", false, "TDS_HIP_SHARD_PEER_RELEASE"},
+      {"shard_peer_copy", false, "TDS_HIP_SHARD_PEER_COPY"},
       {"shard_peer_loopback", false, "TDS_HIP_SHARD_PEER_LOOPBACK"},
   };
   return rows;

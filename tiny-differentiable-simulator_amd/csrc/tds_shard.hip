@@ -170,6 +170,16 @@ __global__ void tds_peer_arrived_kernel(const unsigned long long *flags, int n, 
     if (!tds_wait_ge(flags + i, seq, err, t0, timeout_ticks, host_latch)) return;
 }
 
+// staged peer exchange (option shard_peer_copy): the copies of a launch's slots into the peers' rings have completed on this
+// stream; raise this rank's flag of every slot of the launch on every peer (this rank's own flags were raised by the launch)
+__global__ void tds_peer_raise_kernel(unsigned long long *const *flags, int n_peers, int flag_off, int flag_stride, int n_slots,
+                                      unsigned long long seq) {
+  for (int i = threadIdx.x; i < n_peers * n_slots; i += blockDim.x) {
+    const int pr = i / n_slots, k = i - pr * n_slots;
+    __hip_atomic_store(flags[pr] + (size_t)flag_off + (size_t)k * (size_t)flag_stride, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // set-up check: a 32-bit token into the first word of THIS rank's block of slot 0 of every peer's gathered ring — through
 // the very mapping the step kernel's record stores will use —, then, once those stores are acknowledged, a token into slot
 // `rank` of the test row of every peer's flag array (and this rank's own): a rank that sees a peer's flag token must find
@@ -841,13 +851,16 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
                          sh->world, seq, sh->wait_err(), timeout_ticks, sh->host_latch);
       if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "peer-store exchange: credit kernel launch");
     }
+    // STAGED form (option shard_peer_copy = 1; full records only): the launch sees no peer — it stores into this rank's ring and
+    // raises this rank's own flags — and the communication stream moves the launch's slots behind it
+    const bool staged = s->opt.get(TDS_OPT_SHARD_PEER_COPY, 0) != 0 && !sh->reward_done_only && np > 0;
     TdsPeerLaunch pl;
     pl.rings = (const void *const *)sh->d_peer_tab;
-    pl.flags = ftab;
+    pl.flags = staged ? ftab + np : ftab;  // (the table's last entry is this rank's own flag array)
     pl.arrive = sh->parrive + (size_t)ck.slot0 * TDS_PEER_ARRIVE_STRIDE;
     pl.ring_off = (long long)(((size_t)ck.slot0 * sh->world + sh->rank) * slot_b);
     pl.epoch = seq;
-    pl.n_peers = np;
+    pl.n_peers = staged ? 0 : np;
     pl.flag_off = ck.slot0 * sh->world + sh->rank;
     pl.flag_stride = sh->world;
     pl.reward_done_only = sh->reward_done_only ? 1 : 0;
@@ -859,6 +872,17 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
     if (rc != TDS_OK) return rc;
     TDS_HIP_TRY(hipEventRecord(e_kernel, s->stream));
     TDS_HIP_TRY(hipStreamWaitEvent(sh->comm_stream, e_kernel, 0));
+    if (staged) {
+      // this rank's block of slot slot0 + k lies at the same offset of every ring: ck.steps rows of slot_b bytes, a ring slot
+      // (world blocks) apart — ONE strided copy per peer, issued to the runtime's copy path (SDMA engines between devices)
+      const size_t off = ((size_t)ck.slot0 * sh->world + sh->rank) * slot_b, pitch = (size_t)sh->world * slot_b;
+      for (int pr = 0; pr < np; ++pr)
+        TDS_HIP_TRY(hipMemcpy2DAsync((char *)sh->peer_ring_map[pr] + off, pitch, (const char *)sh->rgath + off, pitch, slot_b,
+                                     (size_t)ck.steps, hipMemcpyDeviceToDevice, sh->comm_stream));
+      hipLaunchKernelGGL(tds_peer_raise_kernel, dim3(1), dim3(64), 0, sh->comm_stream, ftab, np, ck.slot0 * sh->world + sh->rank,
+                         sh->world, ck.steps, seq);
+      if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "staged peer exchange: flag kernel launch");
+    }
     if (sh->n_real_peers > 0) {  // (one rank: the launch's completion IS the arrival of everything anybody stores here)
       hipLaunchKernelGGL(tds_peer_arrived_kernel, dim3(1), dim3(64), 0, sh->comm_stream,
                          (const unsigned long long *)(sh->pflags + (size_t)ck.slot0 * sh->world), ck.steps * sh->world, seq,
@@ -866,7 +890,7 @@ int ring_chunk(tds_hip_shard *sh, const void *actions_dev, int pool, const TdsRi
       if (hipGetLastError() != hipSuccess) return fail(TDS_ERR_HIP, "peer-store exchange: arrival kernel launch");
     }
     TDS_HIP_TRY(hipEventRecord(e_comm, sh->comm_stream));
-    sh->exchange_form = TDS_EXCHANGE_PEER_STORES;
+    sh->exchange_form = staged ? TDS_EXCHANGE_PEER_COPY : TDS_EXCHANGE_PEER_STORES;
     return TDS_OK;
   }
   const int n_blocks = tds_hip_step_many_rings_blocks(s);

@@ -709,7 +709,7 @@ class HipShard:
     def flush(self):
         _check(lib().tds_hip_shard_flush(self.h))
 
-    EXCHANGE_FORMS = {0: "none", 1: "rccl_per_step", 2: "rccl_group_after_launch", 3: "rccl_per_slot", 4: "peer_stores"}
+    EXCHANGE_FORMS = {0: "none", 1: "rccl_per_step", 2: "rccl_group_after_launch", 3: "rccl_per_slot", 4: "peer_stores", 5: "peer_copy"}
 
     def exchange_form(self) -> str:
         """which exchange the most recent step / step_many ran (tds_hip_shard_exchange_form)"""
