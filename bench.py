@@ -198,8 +198,9 @@ def main():
     ap.add_argument("--ring-slots", type=int, default=64, help="slots of the two record rings (a slot is reused that many steps later)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="library option for every handle of this run (tds_hip_default_option), e.g. loop_w2=0, shard_wait=1")
-    ap.add_argument("--y-stride", default="line", choices=["line", "packed"],
-                    help="record stride of the y ring: padded to whole 128-byte lines (default) or output_dim")
+    ap.add_argument("--y-stride", default="auto", choices=["auto", "line", "packed"],
+                    help="record stride of the y ring: padded to whole 128-byte lines, or output_dim; auto (default): lines where the "
+                         "padding is under 10 % of the record")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements of the default N = 1 line (substep_fused, one_rank_with_exchange, auto_reset_rate)")
     ap.add_argument("--shard-graph", action="store_true",
@@ -433,7 +434,10 @@ def run(args, n, rank, local_rank, world, secondary, config5):
         # y records on 128-byte line boundaries (tds_hip_rings_t::y_stride; Ant f64: 160 scalars instead of 155): the
         # launch then writes whole lines only — the payload is unchanged
         per_line = 128 // (8 if tdt == torch.float64 else 4)
-        y_str = -(-m.output_dim // per_line) * per_line if args.y_stride == "line" else m.output_dim
+        # (auto: line boundaries where the padding is under 10 % of the record — Ant 155 -> 160 doubles, Laikago 409 -> 416 —,
+        #  packed where it is not: pendulum5's 46 floats on 256 bytes would be 39 % more written than asked for)
+        y_line = -(-m.output_dim // per_line) * per_line
+        y_str = y_line if (args.y_stride == "line" or (args.y_stride == "auto" and y_line <= 1.1 * m.output_dim)) else m.output_dim
         y_ring = torch.zeros((RS, n, y_str), dtype=tdt, device="cuda")
     GCH = 1024  # steps per graph launch when K is larger (a multiple of the action pool)
     state = {"i": 0}

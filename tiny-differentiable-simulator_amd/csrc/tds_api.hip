@@ -165,8 +165,10 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     const int per_cu = (int)(s->lds_per_cu / (size_t)tds_oct_workgroup_bytes(s->model.input_dim));
     const int blocks = (n_resident + 7) / 8;
     // (two workgroups per compute unit = one wavefront per SIMD: the build compiled for that — no register limit to spill at)
-    if (o2 != 0 && per_cu >= 2 && blocks <= 2 * s->num_cus) oct_form = TDS_FORM_OCT_W2_OCC1;
-    else if (o2 == 2 || (o2 != 0 && blocks <= s->num_cus * (per_cu < 4 ? per_cu : 4))) oct_form = TDS_FORM_OCT_W2;
+    // (option oct_w2 = 3: the two-wavefronts-per-SIMD compilation at any grid size — 256 registers, so that OTHER launches fit
+    //  beside it on a SIMD: the reset pool's refill passes, see pool_step_many)
+    if (o2 != 0 && o2 != 3 && per_cu >= 2 && blocks <= 2 * s->num_cus) oct_form = TDS_FORM_OCT_W2_OCC1;
+    else if (o2 == 2 || o2 == 3 || (o2 != 0 && blocks <= s->num_cus * (per_cu < 4 ? per_cu : 4))) oct_form = TDS_FORM_OCT_W2;
   }
   const int form = (two_waves ? TDS_FORM_W2 : 0) | (occ == 1 ? TDS_FORM_LOOP_OCC1 : (occ == 2 ? TDS_FORM_LOOP_OCC2 : 0)) |
                    oct_form;
@@ -451,7 +453,9 @@ int tds_hip_create(const tds_model_t *model, int num_envs, int device, int dtype
     // (a world without contact points leaves the helper wavefront only the visual poses: the one-wave form is then the
     //  faster one — pendulum5 x 4096: 10.2 vs 10.9 us — unless TDS_HIP_W2=1/2 insists)
     const bool has_cp = model->has_plane && (c64 ? s->h64.num_cp : s->h32.num_cp) > 0;
-    if (!is_fl && !is_sph && !is_two_w && s->lds.NDP < 24 && w2_opt != 0 && (has_cp || w2_set)) {
+    // (round 6: two-wavefront builds of the general kernel up to 14 padded dof only — at 16 / 18 dof they carried 130 - 180 B of
+    //  scratch per lane, profiles/r06_kernel_resources_f64_k0.txt; Laikago, the model they were for, has its own kernel)
+    if (!is_fl && !is_sph && !is_two_w && s->lds.NDP <= 14 && w2_opt != 0 && (has_cp || w2_set)) {
       s->lds_w2 = c64 ? tds_make_lds_layout<double>(s->h64, na_cap, s->lanes, true)
                       : tds_make_lds_layout<float>(s->h32, na_cap, s->lanes, true);
       const size_t b2 = (size_t)s->lds_w2.stride * epw * celem;

@@ -3985,7 +3985,7 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
   (void)h_model;
 #ifdef TDS_PROF_LOOP
 #define TDS_PROF_LOOP_LAUNCH(GG, NN)                                                                         \
-    if constexpr (KIND == 0 && NN < 24) {                                                                    \
+    if constexpr (KIND == 0 && NN <= 14) {                                                                    \
       if (two_waves && !simple && prof) {                                                                    \
         hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), true, 1, 0, true>), dim3(blocks), dim3(128), shmem, \
                            stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
@@ -3997,7 +3997,7 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
 #endif
 #define TDS_LAUNCH(GG, NN)                                                                                   \
   do {                                                                                                       \
-    if constexpr (KIND == 0 && NN < 24) {                                                                    \
+    if constexpr (KIND == 0 && NN <= 14) {                                                                    \
       if (two_waves && simple && !prof) {                                                                    \
         hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 0, 0, true>), dim3(blocks), dim3(128), shmem, \
                            stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
@@ -4012,7 +4012,7 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
       }                                                                                                      \
     }                                                                                                        \
     TDS_PROF_LOOP_LAUNCH(GG, NN)                                                                             \
-    if constexpr (KIND == 0 && NN < 24) {                                                                    \
+    if constexpr (KIND == 0 && NN <= 14) {                                                                    \
       if (two_waves && !simple && !prof) {                                                                   \
         hipLaunchKernelGGL((tds_step_kernel<T, TR, GG, (NN < 24 ? NN : 8), false, 1, 0, true>), dim3(blocks), dim3(128), shmem, \
                            stream, d_model, L, x_in, y_out, actions, x_feedback, obs_out, ovf, prof, ctl, n_envs); \
@@ -4091,7 +4091,7 @@ int tds_kernel_max_dynamic_lds_impl(int lanes_per_env, int ndp, int bytes) {
         e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, true, 0, 0>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                             \
     }                                                                                                           \
-    if constexpr (KIND == 0 && NN < 24) {                                                                       \
+    if constexpr (KIND == 0 && NN <= 14) {                                                                       \
       if (e == hipSuccess)                                                                                      \
         e = hipFuncSetAttribute((const void *)tds_step_kernel<T, TR, GG, NN, false, 0, 0, true>,                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                             \
