@@ -658,6 +658,12 @@ int tds_hip_shard_group_step(tds_hip_shard_t **shards, int n, const void *const 
    cannot be set up on ANY rank, every rank uses the RCCL forms above (shard_peer = 2: an error instead; = 0: never
    tried).  Option exchange_fields = 1 sends only [reward | done] to the peers (8 instead of 120 bytes per Ant
    environment and step on the float wire: for runs whose policy lives on the device, tds_hip_rollout).
+   Option shard_peer_copy = 1 (round 6) is the STAGED form of the same exchange: the launch stores into this rank's block
+   only and raises this rank's own flags; behind it the communication stream copies the launch's slots into every peer's ring
+   (one strided device-to-device copy per peer: the runtime's copy engines) and a one-wave kernel raises the flags there —
+   no store over the fabric from inside the kernel, full records only.  Option shard_peer_release = 1 puts system-scope
+   release fences in front of the arrival counts and the flag stores of the in-kernel form (default: s_waitcnt vmcnt(0) +
+   relaxed stores): the ordering assumption of the protocol can be A/B-ed on a fabric in one run.
    tds_hip_shard_exchange_form tells which form the most recent call ran.
    Option shard_graph = 1 replays each launch + its exchanges from one hipGraph instead (cached by arguments; slower on
    ROCm 7: a chain of dependent graph nodes pays a node-to-node latency a stream does not).  tds_hip_shard_gathered then
