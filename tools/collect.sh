@@ -9,7 +9,8 @@
 #   sq         SQ / LDS counters of the headline launch (three passes)                    <tag>_ant4096_f64_sq_counters_loop.txt
 #   others     the same two for config 5's share (Ant x 8192), config 4 (laikago_soft x 8192, +-0.4 actions with auto-reset: its
 #              default line; and the 16-lane kernel's step-loop form at 4096) and config 2 (pendulum5, float records):
-#              traffic + SQ counters of THEIR kernels (tds_oct_kernel, tds_quad_kernel, tds_step_kernel)
+#              traffic + SQ counters of THEIR kernels (tds_oct_kernel, tds_quad_kernel, tds_chain_kernel)
+#   config2    traffic + SQ counters + kernel trace of config 2 (pendulum5 x 4096, float records: tds_chain_kernel); config 1's line
 #   exchange   one rank through tds_hip_shard_step_many (0 and 7 loopback peers): lines, kernel trace, timeline
 #   tworank    TWO processes on the one GPU through the peer-store exchange, rocprofv3 kernel trace of each + timeline
 #   phases     per-phase cycles of the two-wavefront step (both wavefronts), Ant and Laikago
@@ -104,6 +105,26 @@ laikago_soft4096_f64_loop 500 --model laikago_soft --envs-per-gpu 4096 --no-auto
 pendulum5_4096_f32rec 500 --model pendulum5 --dtype f32
 CFGS
   ;;
+config2)
+  SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM"
+  SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+  SQ3="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
+  NAME=pendulum5_4096_f32rec
+  i=0
+  for CTRS in FETCH_SIZE WRITE_SIZE "$SQ1" "$SQ2" "$SQ3"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $O/o_${NAME}_$i -o p -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-secondary --spin-up-steps 0 --no-events --model pendulum5 --dtype f32 > $O/o_${NAME}_$i.log 2>&1
+  done
+  python tools/pmc_loop_summary.py 500 $O/o_${NAME}_1 $O/o_${NAME}_2 > $P/${TAG}_${NAME}_pmc_traffic.txt 2>&1
+  python tools/pmc_loop_summary.py 500 $O/o_${NAME}_3 $O/o_${NAME}_4 $O/o_${NAME}_5 > $P/${TAG}_${NAME}_sq_counters.txt 2>&1
+  rm -rf $O/o_${NAME}_*/
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_p5 -o k -- python bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-secondary --model pendulum5 --dtype f32 > $O/kt_p5.log 2>&1
+  python tools/rocprof_summary.py "$(db_of $O/kt_p5)" > $P/${TAG}_${NAME}_kernel_stats.txt 2>&1
+  rm -rf $O/kt_p5
+  $B --steps 500 --warmup 50 --model pendulum5 --dtype f32 > $P/${TAG}_bench_pendulum5_4096_f32rec.json 2> $O/pendulum5.err
+  $B --steps 500 --warmup 50 --model cartpole --envs-per-gpu 64 > $P/${TAG}_bench_cartpole64_f64.json 2> $O/cartpole.err
+  grep -h -v '^# kernel' $P/${TAG}_${NAME}_pmc_traffic.txt | cut -c1-140; head -4 $P/${TAG}_${NAME}_kernel_stats.txt | cut -c1-160
+  echo "cartpole x 64: $(line_of $P/${TAG}_bench_cartpole64_f64.json)" ;;
 exchange)
   for LB in 0 7; do
     $NS --steps 1024 --warmup 256 --force-gather --option shard_peer_loopback=$LB > $P/${TAG}_bench_ant4096_one_rank_exchange_${LB}peers_1024.json 2> $O/fg$LB.err

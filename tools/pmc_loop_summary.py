@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc CSV output of a run whose timed region is ONE step-loop launch (tds_hip_step_many of K steps): the
-counters of the longest step-kernel dispatch (tds_step_kernel, tds_quad_kernel or tds_oct_kernel), and per step.
+counters of the longest step-kernel dispatch (tds_step_kernel, tds_quad_kernel, tds_oct_kernel or tds_chain_kernel), and per step.
 K = 0: the run's timed region is single-step launches (one per step) — the MEAN over the dispatches of the kernel that ran
 most often, per launch = per step.
 usage: python tools/pmc_loop_summary.py K <dir> [<dir> ...]"""
@@ -15,7 +15,7 @@ for d in sys.argv[2:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         per = {}
         for row in csv.DictReader(open(f)):
-            if not any(k in row["Kernel_Name"] for k in ("tds_step_kernel", "tds_quad_kernel", "tds_oct_kernel")):
+            if not any(k in row["Kernel_Name"] for k in ("tds_step_kernel", "tds_quad_kernel", "tds_oct_kernel", "tds_chain_kernel")):
                 continue
             key = row["Dispatch_Id"]
             dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])

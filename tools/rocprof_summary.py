@@ -11,7 +11,7 @@ print(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'pct':>7}  kernel")
 for name, calls, tot, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
     print(f"{calls:7d} {tot:12.2f} {avg:10.3f} {pct:7.2f}  {name[:150]}")
 row = db.execute("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count, "
-                 "min(duration), avg(duration), max(duration), count(*) from kernels where (name like '%tds_step_kernel%' or name like '%tds_quad_kernel%' or name like '%tds_oct_kernel%') "
+                 "min(duration), avg(duration), max(duration), count(*) from kernels where (name like '%tds_step_kernel%' or name like '%tds_quad_kernel%' or name like '%tds_oct_kernel%' or name like '%tds_chain_kernel%') "
                  "group by name, grid_x").fetchall()
 for r in row:
     # vgpr_count as rocprofv3 records it is the ALLOCATION in granules of this dispatch (wave64 on the unified 512-entry
