@@ -662,11 +662,6 @@ def run(args, n, rank, local_rank, world, secondary, config5):
         shard_variant("exchange_fields_reward_done", {"exchange_fields": 1},
                       "the same launches, only [reward | done] of a record travel to the peers (option exchange_fields = 1; this "
                       "rank's own block still receives the whole record)")
-        if exchange_form != "peer_copy":
-            shard_variant("exchange_staged_copies", {"shard_peer_copy": 1},
-                          "the same rings and flags, the launch writes this rank's ring only and the communication stream copies "
-                          "the launch's slots into every peer's ring behind it (option shard_peer_copy = 1: one strided "
-                          "device-to-device copy per peer and launch — the copy engines — instead of stores from the kernel)")
         try:
             plain = hip_backend.HipSim(m, n, device=local_rank, dtype=lib_dtype)
             init_state(plain)
@@ -691,6 +686,13 @@ def run(args, n, rank, local_rank, world, secondary, config5):
             del plain
         except Exception as e:  # noqa: BLE001
             exch_variants["no_exchange"] = {"error": repr(e)[:300]}
+        # (last of the secondaries: the only one that drives the runtime's copy path across devices — nothing measured above
+        #  depends on how it ends; only where the peer mappings exist, i.e. the peer-store form ran)
+        if exchange_form == "peer_stores":
+            shard_variant("exchange_staged_copies", {"shard_peer_copy": 1},
+                          "the same rings and flags, the launch writes this rank's ring only and the communication stream copies "
+                          "the launch's slots into every peer's ring behind it (option shard_peer_copy = 1: one strided "
+                          "device-to-device copy per peer and launch — the copy engines — instead of stores from the kernel)")
 
     # secondary (N > 1): the pipelined exchange — records of `pipelined_block` consecutive steps in one all-gather
     pipelined = None
