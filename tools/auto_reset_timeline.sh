@@ -1,7 +1,7 @@
 #!/bin/bash
 # auto_reset_when_done through the reset pool: the driver line's secondary key, the 1000-step rate under the pool options,
 # and the dispatch timeline of a 1000-step run (where the refill passes sit between the chunks)
-#     usage (on the GPU box): tools/r05_auto_reset.sh <tag>     ->  gpurun_out/profiles/<tag>_auto_reset_*.txt
+#     usage (on the GPU box): tools/auto_reset_timeline.sh <tag>     ->  gpurun_out/profiles/<tag>_auto_reset_*.txt
 set -u
 export TMPDIR=/tmp
 TAG=${1:-rXX}
@@ -37,7 +37,9 @@ en = "end" if "end" in cols else "end_timestamp"
 rows = con.execute(f"select name, {st}, {en}, grid_x from kernels order by {st}").fetchall() if "grid_x" in cols else \
        [r + (0,) for r in con.execute(f"select name, {st}, {en} from kernels order by {st}").fetchall()]
 # the last 1000-step call: from the 8th-last step-loop launch (LP = 1 build, > 1 ms) to the end
-big = [i for i, r in enumerate(rows) if "tds_step_kernel" in r[0] and (r[2] - r[1]) > 8e5]
+STEP = ("tds_step_kernel", "tds_oct_kernel", "tds_quad_kernel", "tds_chain_kernel")
+# (the chunks: step-loop launches of 128 steps — longer than 0.5 ms whichever kernel runs them)
+big = [i for i, r in enumerate(rows) if any(k in r[0] for k in STEP) and (r[2] - r[1]) > 5e5]
 i0 = big[-8] if len(big) >= 8 else 0
 t0 = rows[i0][1]
 print("# bench.py --auto-reset --steps 1000: every dispatch of the timed call (chunks of 128 steps; between them the refill pass)")
