@@ -121,10 +121,30 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
   T *const E = sm + grp * LD::STRIDE;
   T *const xr = E;
   {
-    for (int i = tid; i < TB::TOTAL; i += 64) CT[i] = mdl_arg->oct_tab[i];
-    for (int i = link; i < in_dim; i += 8) {
+    // (every global load of the prologue issued before the first is waited for: as loops of load -> LDS store they were ten
+    //  dependent round trips in front of every launch — tools/oct_clock_ramp.py)
+    constexpr int TN = (TB::TOTAL + 63) / 64, XN = (in_dim + 7) / 8;
+    T tv[TN], xv[XN];
+#pragma unroll
+    for (int k = 0; k < TN; ++k) {
+      const int i = tid + 64 * k;
+      tv[k] = i < TB::TOTAL ? mdl_arg->oct_tab[i] : T(0);
+    }
+#pragma unroll
+    for (int k = 0; k < XN; ++k) {
+      const int i = link + 8 * k;
       const bool act = actions != nullptr && i >= nq + nd;
-      xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+      xv[k] = (!valid || i >= in_dim) ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+    }
+#pragma unroll
+    for (int k = 0; k < TN; ++k) {
+      const int i = tid + 64 * k;
+      if (i < TB::TOTAL) CT[i] = tv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < XN; ++k) {
+      const int i = link + 8 * k;
+      if (i < in_dim) xr[i] = xv[k];
     }
     if (link == 0) {
       xr[LD::DONE] = T(0);

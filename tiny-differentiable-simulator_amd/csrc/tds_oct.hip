@@ -50,6 +50,12 @@
 #define TDS_OCT_PROF_WG 3
 #endif
 __device__ unsigned long long tds_oct_prof_buf[32];
+// (shader clock, 100 MHz real-time clock) at the top of the first 32 iterations of the stamped workgroup's main wavefront: the
+// shader clock's frequency step by step (tools/oct_clock_ramp.py)
+__device__ unsigned long long tds_oct_prof_clk[64];
+// 100 MHz real-time clock of every workgroup (up to 2048) at its first instruction, at the top of its first step and behind its
+// last step: how far apart the workgroups of a launch start and end (tools/oct_clock_ramp.py)
+__device__ unsigned long long tds_oct_prof_wg[3 * 2048];
 __device__ int tds_oct_prof_iter = 500;
 #define OCT_STAMP(k, pin)                                                                       \
   do {                                                                                          \
@@ -253,23 +259,51 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
                     TdsStepCtl ctl_arg, int n_envs, OctOff O) {
   extern __shared__ __align__(16) unsigned char tds_oct_smem[];
   T *const sm = reinterpret_cast<T *>(tds_oct_smem);
+#ifdef TDS_OCT_PROF
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {
+    unsigned long long c_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory");
+    tds_oct_prof_wg[3 * blockIdx.x] = c_;
+  }
+#endif
   constexpr bool W2 = BUILD >= 2;
   constexpr int nq = 14, nd = 14, adim = 8, in_dim = nq + nd + adim + 3, w_obs = nq + nd + 2;
   constexpr int NT = W2 ? 128 : 64;
   T *const CT = sm + 8 * O.stride;  // the constant table
   {
     // ---- the constant table (coalesced copy) and A. x record -> LDS, fresh actions over the action slice
+    // (every global load of the prologue is issued before the first of them is waited for: as loops of load -> LDS store the
+    //  table copy and the record copy were ten dependent round trips, 4.8 us in front of the first step of every launch —
+    //  tools/oct_clock_ramp.py)
     const int t = threadIdx.x;
-    for (int i = t; i < TB::TOTAL; i += NT) CT[i] = mdl_arg->oct_tab[i];
+    constexpr int TN = (TB::TOTAL + NT - 1) / NT, XN = (in_dim + 7) / 8;
+    T tv[TN], xv[XN];
+#pragma unroll
+    for (int k = 0; k < TN; ++k) {
+      const int i = t + k * NT;
+      tv[k] = i < TB::TOTAL ? mdl_arg->oct_tab[i] : T(0);
+    }
+    const int lane0 = t & 7, grp0 = (t & 63) >> 3, env0 = blockIdx.x * 8 + grp0;
+    const bool valid0 = env0 < n_envs && t < 64;
+#pragma unroll
+    for (int k = 0; k < XN; ++k) {
+      const int i = lane0 + 8 * k;
+      const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
+      xv[k] = (!valid0 || i >= in_dim) ? T(0) : act ? (T)actions[(size_t)env0 * adim + (i - nq - nd)] : (T)x_in[(size_t)env0 * in_dim + i];
+    }
+#pragma unroll
+    for (int k = 0; k < TN; ++k) {
+      const int i = t + k * NT;
+      if (i < TB::TOTAL) CT[i] = tv[k];
+    }
     if (t < 64) {
-      const int lane = t & 7, grp = t >> 3, env = blockIdx.x * 8 + grp;
-      const bool valid = env < n_envs;
-      T *const xr = sm + grp * O.stride;
-      for (int i = lane; i < in_dim; i += 8) {
-        const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
-        xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+      T *const xr = sm + grp0 * O.stride;
+#pragma unroll
+      for (int k = 0; k < XN; ++k) {
+        const int i = lane0 + 8 * k;
+        if (i < in_dim) xr[i] = xv[k];
       }
-      if (lane < 4) xr[in_dim + lane] = T(0);
+      if (lane0 < 4) xr[in_dim + lane0] = T(0);
     }
     if constexpr (W2) __syncthreads();
     else OCT_SYNC();
@@ -296,6 +330,17 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #ifdef TDS_OCT_PROF
   unsigned long long prof_t[26];
   const bool prof_on = blockIdx.x == TDS_OCT_PROF_WG && it == tds_oct_prof_iter;
+  if (it == 0 && tid == 0 && blockIdx.x < 2048) {
+    unsigned long long c_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory");
+    tds_oct_prof_wg[3 * blockIdx.x + 1] = c_;
+  }
+  if (blockIdx.x == TDS_OCT_PROF_WG && it < 32 && tid == 0) {
+    unsigned long long c0_, c1_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0_), "=s"(c1_)::"memory");
+    tds_oct_prof_clk[2 * it] = c0_;
+    tds_oct_prof_clk[2 * it + 1] = c1_;
+  }
 #endif
   const int lane = tid & 7;
   const int grp = (tid & 63) >> 3;
@@ -1521,11 +1566,24 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     o_slot = o_slot + 1 >= ctl_arg.obs_slots ? 0 : o_slot + 1;
   }
   }  // ================================ end of the step loop ================================
+#ifdef TDS_OCT_PROF
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {
+    unsigned long long c_;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory");
+    tds_oct_prof_wg[3 * blockIdx.x + 2] = c_;
+  }
+#endif
 }
 
 }  // namespace
 
 #ifdef TDS_OCT_PROF
+extern "C" int tds_oct_prof_workgroups(unsigned long long *out, int n_wg) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(tds_oct_prof_wg), (size_t)3 * n_wg * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+extern "C" int tds_oct_prof_clocks(unsigned long long *out64) {
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(tds_oct_prof_clk), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 extern "C" int tds_oct_prof_read(unsigned long long *out32, int iter) {  // iter >= 0: which iteration the NEXT launches stamp
   if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(tds_oct_prof_buf), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
   if (iter >= 0 && hipMemcpyToSymbol(HIP_SYMBOL(tds_oct_prof_iter), &iter, sizeof(int)) != hipSuccess) return -1;

@@ -122,6 +122,7 @@ struct QuadLds {
 
 struct QuadOff {
   int lcw, legf, swl, qdp, S, ax, Z, rws, xs, cp, stride;
+  int in_dim, adim;  // the model's input_dim / action_dim (kernel arguments: the prologue's record loads do not wait for the model)
 };
 // the kernel's parameter list as a struct: the layout of its kernel-argument segment (see TdsKernArgs in tds_kernels.hip)
 struct QuadKernArgs {
@@ -178,6 +179,8 @@ __host__ __device__ inline QuadOff quad_layout(int in_dim) {
   o.xs = at;   at += 12;                   // impulses
   o.cp = at;   at += 5 * 4;                // contact list: point (3) | distance | leg, per slot
   o.stride = (at + 1) & ~1;
+  o.in_dim = in_dim;
+  o.adim = 0;  // (set by the launcher)
   return o;
 }
 
@@ -200,10 +203,22 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     const int lane = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4, env = blockIdx.x * 4 + grp;
     const bool valid = env < n_envs;
     T *const xr = sm + grp * O.stride;
-    const int in_dim = mdl_arg->input_dim, adim = mdl_arg->action_dim;
-    for (int i = lane; i < in_dim; i += 16) {
+    // (dimensions from the kernel arguments and all of a lane's record loads issued before the first is waited for: as a
+    //  loop of load -> LDS store behind a load of the model's input_dim the prologue was five dependent round trips in
+    //  front of EVERY single-step launch — tools/oct_clock_ramp.py measured the same pattern in the 8-lane kernel)
+    const int in_dim = O.in_dim, adim = O.adim;
+    constexpr int XN = 5;  // (records of up to 80 scalars: 18 + 18 + actions + 3)
+    T xv[XN];
+#pragma unroll
+    for (int k = 0; k < XN; ++k) {
+      const int i = lane + 16 * k;
       const bool act = actions != nullptr && i >= nq + nd && i < nq + nd + adim;
-      xr[i] = !valid ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+      xv[k] = (!valid || i >= in_dim) ? T(0) : act ? (T)actions[(size_t)env * adim + (i - nq - nd)] : (T)x_in[(size_t)env * in_dim + i];
+    }
+#pragma unroll
+    for (int k = 0; k < XN; ++k) {
+      const int i = lane + 16 * k;
+      if (i < in_dim) xr[i] = xv[k];
     }
   }
   QuadTable<T> *const CT = reinterpret_cast<QuadTable<T> *>(sm + 4 * O.stride);  // (step-loop launches only)
@@ -1245,7 +1260,9 @@ template int tds_quad_lds_bytes<float>(int);
 template <typename T, typename TR>
 int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
                     TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl) {
-  const QuadOff O = quad_layout(h_model.input_dim);
+  QuadOff O = quad_layout(h_model.input_dim);
+  O.adim = h_model.action_dim;
+  if (O.in_dim > 80) return -1;  // (the prologue holds a record in five registers per lane)
   const int blocks = (n_envs + 3) / 4;
   // (+ the constant table of a step-loop launch behind the four environments' regions)
   const bool one_step = ctl.nsub == 1 && ctl.obs_ring == nullptr && ctl.y_ring == nullptr;
