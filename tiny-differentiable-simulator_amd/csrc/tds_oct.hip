@@ -325,6 +325,16 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   if constexpr (LOOP) asm volatile("" : "+s"(ka_seg), "+v"(tid));
   const int wv = W2 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
   const bool is_main = !W2 || wv == 0, is_help = !W2 || wv == 1;  // wave-uniform (the profile build's stamps)
+  // Two wavefronts per SIMD (BUILD 2): where a main wavefront shares its SIMD with a helper, the main one — the step's
+  // instruction stream — issues first (Ant x 8192, same box: 7.93 / 8.09e8 -> 8.42 / 8.37e8 env-steps/s; no effect at one
+  // wavefront per SIMD)
+#ifndef TDS_OCT_PRIO
+#define TDS_OCT_PRIO 1
+#endif
+  if constexpr (W2 && TDS_OCT_PRIO != 0) {
+    if (wv == 0) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+  }
   (void)is_main;
   (void)is_help;
 #ifdef TDS_OCT_PROF
@@ -1511,8 +1521,10 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
       OCT_BAR();  // (2)
       const int nw = windows();
       if (nw > 0) {
+        if constexpr (TDS_OCT_PRIO == 2) __builtin_amdgcn_s_setprio(3);  // (the stretch the main wavefront waits for)
         help_get_factors();
         rows_root(0);
+        if constexpr (TDS_OCT_PRIO == 2) __builtin_amdgcn_s_setprio(0);
       }
       for (int wi = 0; wi < nw; ++wi) {
         if (wi > 0) {
