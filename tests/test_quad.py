@@ -228,3 +228,44 @@ def test_quad_step_loop_with_auto_reset_equals_single_steps(built):
         assert rel_err(y_ring[k].cpu().numpy(), b.y.cpu().numpy()) < 1e-9, k
     assert dones >= n // 3
     assert rel_err(a.x.cpu().numpy(), b.x.cpu().numpy()) < 1e-9
+
+
+def test_single_step_auto_reset_in_environment_chains_equals_single_steps(built):
+    """Beyond residency of the step-loop form (laikago_soft x 8192: config 4) tds_hip_step_many with auto-reset runs single steps
+    through the reset pool — as two ENVIRONMENT CHAINS on two streams, like the graphs of the plain call.  Against the same
+    steps issued one call at a time (one whole-batch launch per step): the same records and reset stream, bit for bit; resets
+    from the first step on in BOTH chains, uneven call lengths across several refill passes."""
+    torch = _torch()
+    name = "laikago_soft"
+    m = tds_amd.load_model(name)
+    n = 8192
+    rng = np.random.default_rng(18)
+    from test_rings import _start_state
+
+    x = _start_state(m, name, n, rng)
+    tilt = rng.permutation(n)[: n // 4]  # (spread over both halves of the batch)
+    x[tilt, 3] = rng.uniform(1.0, 1.3, len(tilt))
+    a = hip_backend.HipSim(m, n)
+    b = hip_backend.HipSim(m, n)
+    for s_ in (a, b):
+        s_.x.copy_(torch.from_numpy(x).cuda())
+        s_.set_auto_reset(True, 7)
+    assert not a.step_many_is_loop(8)
+    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (4, n, m.action_dim))).cuda().contiguous()
+    obs = torch.zeros((n, b.obs_dim + 2), dtype=torch.float64, device="cuda")
+    done_steps, dones = 0, 0
+    for steps in (5, 33, 1, 24):
+        obs_ring = torch.full((steps, n, a.obs_dim + 2), float("nan"), dtype=torch.float64, device="cuda")
+        y_ring = torch.full((steps, n, m.output_dim), float("nan"), dtype=torch.float64, device="cuda")
+        a.step_many_rings(actions, steps, obs_ring, y_ring, first_block=done_steps % 4)
+        for k in range(steps):
+            b.step(actions[(done_steps + k) % 4], 1, obs)
+            dones += int((obs[:, -1] != 0).sum().item())
+            assert torch.equal(obs_ring[k], obs), (done_steps, k)
+            assert torch.equal(y_ring[k], b.y), (done_steps, k)
+        done_steps += steps
+        assert torch.equal(a.x, b.x) and torch.equal(a.y, b.y)
+    half = (obs_ring[:, : n // 2, -1] != 0).sum().item(), (obs_ring[:, n // 2:, -1] != 0).sum().item()
+    assert dones >= n // 4, dones
+    print(f"laikago_soft x {n}: {done_steps} auto-reset steps in two environment chains == single steps, {dones} resets "
+          f"(last call: {half[0]} / {half[1]} in the two halves)")

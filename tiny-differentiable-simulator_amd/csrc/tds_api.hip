@@ -185,6 +185,8 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     obs = at(obs, s->obs_width(), el);
     ovf = at(ovf, (size_t)s->lds.ovrows * (s->lds.NDs + 3), s->compute_f64() ? 8 : 4);
     if (mask || ro) return fail(TDS_ERR_INVALID_ARG, "environment sub-ranges: plain steps only");
+    // (the reset pool's rings are [slot][environment][q | qd]: the kernel indexes them with its LOCAL environment number)
+    if (ctl.pool) ctl.pool = at(ctl.pool, (size_t)(s->model.dof_q + s->model.dof_qd), el);
   }
   if (ro) {
     ctl.policy = ro->policy;
@@ -262,7 +264,7 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
   ctl.settle_steps = s->model.settle_steps < 0 ? 0 : s->model.settle_steps;
   ctl.seed = s->seed;
   ctl.mask = mask;
-  ctl.reset_count = s->d_reset_count;
+  ctl.reset_count = s->d_reset_count ? s->d_reset_count + ((opts && opts->env_first > 0) ? opts->env_first : 0) : nullptr;
   int rc;
   const long long alt = s->opt.get(TDS_OPT_ALT_BUILD, 0);
   if (alt != 0) {  // an experiment slot (tds_kernels.h): f64 plain kernels of the one instantiation the slot was built for
@@ -912,7 +914,10 @@ int pool_fill(tds_hip_sim *s) {
 }
 
 // one auto-reset step through the pool
-int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev, void *y_dev = nullptr, int y_stride = 0) {
+// C > 1 (inside tds_hip_step_many, between its fork and join): the step as C launches over contiguous environment ranges, chain c
+// on its own stream (chain_streams) — as the graphs of the plain call run it: a chain's kernel boundary is filled by the other
+// chain's workgroups (laikago_soft x 8192 with auto-reset: 25.2 -> see DESIGN 6)
+int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev, void *y_dev = nullptr, int y_stride = 0, int C = 1) {
   int rc;
   if (s->pool_many) {  // (the step_many form keeps its own pass schedule: start again from full rings)
     s->pool_many = false;
@@ -939,20 +944,39 @@ int pool_step(tds_hip_sim *s, const void *actions_dev, void *obs_dev, void *y_de
   const long long jstar = (t - 1 - W) / R;
   while (t - 1 - W >= R && s->pool_waited < jstar) {
     ++s->pool_waited;
-    TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->pool_ev[s->pool_waited % tds_hip_sim::kPoolEvents], 0));
+    for (int c = 0; c < C; ++c)
+      TDS_HIP_TRY(hipStreamWaitEvent(c == 0 ? s->stream : s->graph_chain[c - 1], s->pool_ev[s->pool_waited % tds_hip_sim::kPoolEvents], 0));
   }
   TdsStepCtl extra;
   memset(&extra, 0, sizeof(extra));
   extra.pool = s->d_pool;
   extra.pool_depth = s->pool_depth;
   extra.pool_envs = s->num_envs;
-  LaunchOpts o;
-  o.extra = &extra;
-  o.y_stride = y_dev ? y_stride : 0;
-  rc = launch(s, s->d_x, y_dev ? y_dev : s->d_y, actions_dev, s->d_x, obs_dev ? obs_dev : s->d_split, s->num_envs, 1,
-              TDS_RESET_NONE, nullptr, nullptr, 0, &o);
-  if (rc != TDS_OK) return rc;
+  const int epb = 64 / s->lanes, n_blocks = (s->num_envs + epb - 1) / epb;
+  for (int c = 0; c < C; ++c) {
+    LaunchOpts o;
+    o.extra = &extra;
+    o.y_stride = y_dev ? y_stride : 0;
+    int e0 = 0, e1 = s->num_envs;
+    if (C > 1) {
+      const int b0 = (int)((long long)n_blocks * c / C), b1 = (int)((long long)n_blocks * (c + 1) / C);
+      e0 = b0 * epb;
+      e1 = (b1 * epb < s->num_envs) ? b1 * epb : s->num_envs;
+      if (e1 <= e0) continue;
+      o.env_total = s->num_envs;
+      o.env_first = e0;
+      o.other_stream = true;
+      o.stream = c == 0 ? s->stream : s->graph_chain[c - 1];
+    }
+    rc = launch(s, s->d_x, y_dev ? y_dev : s->d_y, actions_dev, s->d_x, obs_dev ? obs_dev : s->d_split, e1 - e0, 1,
+                TDS_RESET_NONE, nullptr, nullptr, 0, &o);
+    if (rc != TDS_OK) return rc;
+  }
   if (t % R == 0) {  // pass t / R: plan now, launch when its size is known
+    for (int c = 1; c < C; ++c) {  // (the plan reads every environment's reset count: behind step t of every chain)
+      TDS_HIP_TRY(hipEventRecord(s->graph_join[c - 1], s->graph_chain[c - 1]));
+      TDS_HIP_TRY(hipStreamWaitEvent(s->stream, s->graph_join[c - 1], 0));
+    }
     rc = pool_plan(s);
     if (rc != TDS_OK) return rc;
     s->pool_planned = t / R;
@@ -1393,12 +1417,24 @@ int step_many_impl(tds_hip_sim_t *s, const void *actions_dev, int action_blocks,
     if (as_loop)  // (the step-loop launches write the last step's y record into d_y themselves)
       return pool_step_many(s, actions_dev, pool, first, n_steps, obs_dev, rings);
     const size_t blk = (size_t)s->num_envs * s->model.action_dim * s->elem;
+    // (environment chains as in the plain call's graphs, launched eagerly: the passes of the reset pool are host-driven)
+    const int C = chain_count(s, n_steps);
+    if (C > 1) {
+      const int rc = chain_streams(s, C);
+      if (rc != TDS_OK) return rc;
+      HIP_TRY(hipEventRecord(s->graph_fork, s->stream));
+      for (int c = 1; c < C; ++c) HIP_TRY(hipStreamWaitEvent(s->graph_chain[c - 1], s->graph_fork, 0));
+    }
     for (int k = 0; k < n_steps; ++k) {
       const void *a = actions_dev ? (const char *)actions_dev + (size_t)((first + k) % pool) * blk : nullptr;
       void *const ob = (rings && rings->obs_ring) ? ring_slot(s, rings->obs_ring, rings->obs_slots, rings->obs_first, k, s->obs_width()) : obs_dev;
       void *const yk = (rings && rings->y_ring) ? ring_slot(s, rings->y_ring, rings->y_slots, rings->y_first, k, y_width(s, rings)) : nullptr;
-      const int rc = pool_step(s, a, ob, yk, (rings && rings->y_ring && rings->y_stride > 0) ? rings->y_stride : 0);
+      const int rc = pool_step(s, a, ob, yk, (rings && rings->y_ring && rings->y_stride > 0) ? rings->y_stride : 0, C);
       if (rc != TDS_OK) return rc;
+    }
+    for (int c = 1; c < C; ++c) {
+      HIP_TRY(hipEventRecord(s->graph_join[c - 1], s->graph_chain[c - 1]));
+      HIP_TRY(hipStreamWaitEvent(s->stream, s->graph_join[c - 1], 0));
     }
     return y_back();
   }
