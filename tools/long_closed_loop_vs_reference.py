@@ -12,19 +12,23 @@ from tds_amd import hip_backend
 from test_hip_parity import _reference_stepper
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-for name, n, amp, var in (("ant", 4096, 0.4, [15, 0.3, 3]), ("laikago_soft", 2048, 0.1, [100, 2, 50])):
+for name, n, amp, var in (("ant", 4096, 0.4, [15, 0.3, 3]), ("laikago_soft", 2048, 0.1, [100, 2, 50]), ("pendulum5", 4096, 1.0, None)):
     m = tds_amd.load_model(name)
     ref_step, what = _reference_stepper(name, n)
     rng = np.random.default_rng(2025)
     nq, nd, adim = m.dof_q, m.dof_qd, m.action_dim
-    ip = np.array([m.initial_poses[i] for i in range(adim)])
     x0 = np.zeros((n, m.input_dim))
-    x0[:, 2] = 0.48
-    x0[:, 6:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
-    x0[:, -3:] = var
+    if var is not None:
+        ip = np.array([m.initial_poses[i] for i in range(adim)])
+        x0[:, 2] = 0.48
+        x0[:, 6:nq] = ip + 0.05 * rng.uniform(-1, 1, (n, nq - 6))
+        x0[:, -3:] = var
+    else:  # (torque-driven chain: random joint angles and velocities)
+        x0[:, :nq] = rng.uniform(-1, 1, (n, nq))
+        x0[:, nq:nq + nd] = rng.uniform(-1, 1, (n, nd))
     sim = hip_backend.HipSim(m, n)
     sim.x.copy_(torch.from_numpy(x0).cuda())
-    for _ in range(10):
+    for _ in range(10 if var is not None else 0):
         sim.step(None)
     worst, worst_t, wild, hist = 0.0, -1, 0, []
     for t in range(steps):
@@ -41,8 +45,8 @@ for name, n, amp, var in (("ant", 4096, 0.4, [15, 0.3, 3]), ("laikago_soft", 204
             worst, worst_t = e, t
         if (t + 1) % 200 == 0:
             up = x_before[:, 2]
-            hist.append(f"step {t + 1}: worst so far {worst:.2e}, torso z min / median {up.min():.2f} / {np.median(up):.2f}")
-    print(f"{name} x{n}, {steps} closed-loop steps (actions +-{amp}), every environment vs {what}: worst per-step rel err "
+            hist.append(f"step {t + 1}: worst so far {worst:.2e}" + (f", torso z min / median {up.min():.2f} / {np.median(up):.2f}" if var is not None else ""))
+    print(f"{name} x{n} [{sim.single_step_kernel()[0]}], {steps} closed-loop steps (actions +-{amp}), every environment vs {what}: worst per-step rel err "
           f"{worst:.3e} (step {worst_t}); environment-steps beyond |qd| = 1e3 or non-finite in the reference (excluded): {wild}")
     for h in hist:
         print("   ", h)
