@@ -170,8 +170,9 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     if (o2 != 0 && o2 != 3 && per_cu >= 2 && blocks <= 2 * s->num_cus) oct_form = TDS_FORM_OCT_W2_OCC1;
     else if (o2 == 2 || o2 == 3 || (o2 != 0 && blocks <= s->num_cus * (per_cu < 4 ? per_cu : 4))) oct_form = TDS_FORM_OCT_W2;
   }
+  const long long cw2 = s->opt.get(TDS_OPT_CHAIN_W2, 1);
   const int form = (two_waves ? TDS_FORM_W2 : 0) | (occ == 1 ? TDS_FORM_LOOP_OCC1 : (occ == 2 ? TDS_FORM_LOOP_OCC2 : 0)) |
-                   oct_form;
+                   oct_form | (cw2 == 0 ? TDS_FORM_CHAIN_W1 : (cw2 == 2 ? TDS_FORM_CHAIN_W2_ANY : 0));
   void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
   if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along
     const size_t e0 = (size_t)opts->env_first, el = s->elem;
@@ -331,7 +332,7 @@ int tds_hip_set_option(tds_hip_sim_t *s, const char *key, long long value) {
                                      "tds_hip_shard_step_many", key);
   // (cached graphs / a pool laid out for the old value must not outlive it; alt_build: the cached step_many graphs
   //  replay the kernel of the build that was current when they were captured)
-  if (k == TDS_OPT_GRAPH_CHAINS || k == TDS_OPT_STEP_MANY_LOOP || k == TDS_OPT_LOOP_W2 || k == TDS_OPT_LOOP_OCC ||
+  if (k == TDS_OPT_GRAPH_CHAINS || k == TDS_OPT_STEP_MANY_LOOP || k == TDS_OPT_LOOP_W2 || k == TDS_OPT_LOOP_OCC || k == TDS_OPT_CHAIN_W2 ||
       k == TDS_OPT_NO_GRAPH_UPLOAD || k == TDS_OPT_ALT_BUILD) {
     DeviceGuard guard(s->device);
     (void)hipStreamSynchronize(s->stream);

@@ -93,25 +93,48 @@ __device__ __forceinline__ void ch_sincos(double x, double *sn, double *cs) {
   *cs = c_;
 }
 
+template <bool LOOP>
+struct ChainCtlRef {
+  using type = const TdsStepCtl &;
+  static __device__ __forceinline__ type get(const TdsStepCtl &param, const __attribute__((address_space(4))) char *) { return param; }
+};
+template <>
+struct ChainCtlRef<true> {
+  using type = const __attribute__((address_space(4))) TdsStepCtl &;
+  static __device__ __forceinline__ type get(const TdsStepCtl &, const __attribute__((address_space(4))) char *at) {
+    return *(const __attribute__((address_space(4))) TdsStepCtl *)at;
+  }
+};
+
 // LDS per environment, in scalars: the x record [q | qd | tau] (+ 2: done, reward — always zero for these models, kept where
 // the record code of the other kernels reads them), the rows of M (NL x NL) and the right-hand side
 template <int NL>
 struct ChainLds {
+  // (+ two-wavefront build: the links' world transforms, 12 scalars each, in two buffers that alternate step by step — the
+  //  recorder wavefront packs the poses of step k while the main wavefront is in step k + 1)
   static constexpr int IN = 3 * NL, DONE = IN, REWARD = IN + 1, M = ((IN + 2 + 1) & ~1), RHS = M + NL * NL,
-                       STRIDE = ((RHS + NL + 1) & ~1) + 2;  // (+ 2: the eight regions start on different banks)
+                       KIN = ((RHS + NL + 1) & ~1), STRIDE = KIN + 2 * NL * 12 + 2;  // (+ 2: the eight regions start on different banks)
 };
 
-// NL: links of the chain.  LOOP: K steps per launch (state in LDS, per-step records into rings) / one step per launch
-template <typename T, typename TR, int NL, bool LOOP>
-__global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
+// NL: links of the chain.  LOOP: K steps per launch (state in LDS, per-step records into rings) / one step per launch.
+// W2 (step-loop form, while every workgroup is resident with at most two wavefronts per SIMD): a second wavefront per
+// workgroup is the RECORDER — it packs the visual poses and stores every record of step k (y, obs ring, the peers' rings, the
+// exchange's counters) while the main wavefront runs step k + 1: per-step records cost the main wavefront twelve LDS stores and
+// two barriers instead of a quarter of its instruction stream (pendulum5 x 4096: 4.31 -> see DESIGN 2e)
+#define CH_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <typename T, typename TR, int NL, bool LOOP, bool W2 = false>
+__global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
                                                        const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
-                                                       TR *__restrict__ obs_out, TdsStepCtl ctl, int n_envs) {
+                                                       TR *__restrict__ obs_out, TdsStepCtl ctl_arg, int n_envs) {
   extern __shared__ __align__(16) unsigned char tds_chain_smem[];
   T *const sm = reinterpret_cast<T *>(tds_chain_smem);
   using LD = ChainLds<NL>;
   constexpr int nq = NL, nd = NL, adim = NL, in_dim = 3 * NL, w_obs = 2 * NL + 2;
   T *const CT = sm + 8 * LD::STRIDE;  // the constant table
-  const int tid = threadIdx.x;
+  static_assert(!W2 || LOOP, "the recorder wavefront exists in the step-loop form only");
+  constexpr int NT = W2 ? 128 : 64;
+  const int t_all = threadIdx.x;
+  const int tid = threadIdx.x & 63;
   // lane = 16 row + 2 link + parity: environment 2 row + parity of the wavefront, link (tid & 15) >> 1
   const int link = (tid & 15) >> 1;
   const int grp = ((tid >> 4) << 1) | (tid & 1);
@@ -123,11 +146,11 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
   {
     // (every global load of the prologue issued before the first is waited for: as loops of load -> LDS store they were ten
     //  dependent round trips in front of every launch — tools/oct_clock_ramp.py)
-    constexpr int TN = (TB::TOTAL + 63) / 64, XN = (in_dim + 7) / 8;
+    constexpr int TN = (TB::TOTAL + NT - 1) / NT, XN = (in_dim + 7) / 8;
     T tv[TN], xv[XN];
 #pragma unroll
     for (int k = 0; k < TN; ++k) {
-      const int i = tid + 64 * k;
+      const int i = t_all + NT * k;
       tv[k] = i < TB::TOTAL ? mdl_arg->oct_tab[i] : T(0);
     }
 #pragma unroll
@@ -138,7 +161,7 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
     }
 #pragma unroll
     for (int k = 0; k < TN; ++k) {
-      const int i = tid + 64 * k;
+      const int i = t_all + NT * k;
       if (i < TB::TOTAL) CT[i] = tv[k];
     }
 #pragma unroll
@@ -150,7 +173,8 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
       xr[LD::DONE] = T(0);
       xr[LD::REWARD] = T(0);
     }
-    CH_SYNC();
+    if constexpr (W2) __syncthreads();
+    else CH_SYNC();
   }
   const T *const CL = CT + link * TB::LSTR;  // my link's constants
   const T dt = CT[TB::SC + TB::DT];
@@ -158,50 +182,65 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
   const int out_dim = (int)CT[TB::SC + TB::OUTPUT_DIM];
   const bool pack_vis = CT[TB::SC + TB::PACK_VISUALS] != T(0);
   const bool xt_ident = CT[TB::SC + TB::XT_IDENT] != T(0);
-  const int nsteps = LOOP ? ctl.nsub : 1;
+  const bool vis_ident = CT[TB::SC + TB::VIS_IDENT] != T(0);
+  const int nsteps = LOOP ? ctl_arg.nsub : 1;
   T next_act = T(0);
   int act_blk = 0, y_slot = 0, o_slot = 0;
   if constexpr (LOOP) {
-    if (ctl.act_pool != nullptr && ctl.act_blocks > 0) act_blk = (ctl.act_first + 1) % ctl.act_blocks;
-    if (ctl.y_ring != nullptr && ctl.y_slots > 0) y_slot = ctl.y_first % ctl.y_slots;
-    if (ctl.obs_ring != nullptr && ctl.obs_slots > 0) o_slot = ctl.obs_first % ctl.obs_slots;
+    if (ctl_arg.act_pool != nullptr && ctl_arg.act_blocks > 0) act_blk = (ctl_arg.act_first + 1) % ctl_arg.act_blocks;
+    if (ctl_arg.y_ring != nullptr && ctl_arg.y_slots > 0) y_slot = ctl_arg.y_first % ctl_arg.y_slots;
+    if (ctl_arg.obs_ring != nullptr && ctl_arg.obs_slots > 0) o_slot = ctl_arg.obs_first % ctl_arg.obs_slots;
   }
 
+  for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
+    // (step-loop form: nothing of the kernel's arguments lives across an iteration — the fields of ctl are scalar loads from
+    //  the kernel-argument segment where an iteration uses them, through a pointer laundered per iteration; held in SGPRs
+    //  across the loop they spilled: 47 spills in the 5-link instantiation)
+    const __attribute__((address_space(4))) char *ka_seg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    if constexpr (LOOP) asm volatile("" : "+s"(ka_seg));
+    typename ChainCtlRef<LOOP>::type ctl = ChainCtlRef<LOOP>::get(ctl_arg, ka_seg + 48 /* six pointers in front of ctl */);
   // a step's records counted in for the multi-GPU layer (tds_shard.hip; see tds_kernels.hip: peer_signal)
-  auto signal_slot = [&](int pslot) {
-    if (ctl.peer_arrive != nullptr) {
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): every store of this wavefront acknowledged by the memory it went to
-      const bool rel = (ctl.ring_flags & TDS_RING_PEER_RELEASE) != 0;
-      if (rel) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      if (tid == 0) {
-        constexpr unsigned SUB = TDS_PEER_SUB;
-        const unsigned g = gridDim.x, j = blockIdx.x % SUB;
-        const unsigned n1 = (g - j + SUB - 1u) / SUB;
-        const unsigned n2 = g < SUB ? g : SUB;
-        unsigned *const base = ch_global(ctl.peer_arrive) + (size_t)pslot * TDS_PEER_ARRIVE_STRIDE;
-        if (atomicInc(base + j * TDS_PEER_LINE, n1 - 1u) == n1 - 1u) {
-          if (atomicInc(base + 32 * TDS_PEER_LINE, n2 - 1u) == n2 - 1u) {
-            const size_t fi = (size_t)ctl.peer_flag_off + (size_t)pslot * (size_t)ctl.peer_flag_stride;
-            if (rel) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
-            for (int pr = 0; pr <= ctl.n_peers; ++pr)
-              __hip_atomic_store(ctl.peer_flags[pr] + fi, ctl.peer_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    auto signal_slot = [&](int pslot) {
+      if (ctl.peer_arrive != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): every store of this wavefront acknowledged by the memory it went to
+        const bool rel = (ctl.ring_flags & TDS_RING_PEER_RELEASE) != 0;
+        if (rel) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (tid == 0) {
+          constexpr unsigned SUB = TDS_PEER_SUB;
+          const unsigned g = gridDim.x, j = blockIdx.x % SUB;
+          const unsigned n1 = (g - j + SUB - 1u) / SUB;
+          const unsigned n2 = g < SUB ? g : SUB;
+          unsigned *const base = ch_global(ctl.peer_arrive) + (size_t)pslot * TDS_PEER_ARRIVE_STRIDE;
+          if (atomicInc(base + j * TDS_PEER_LINE, n1 - 1u) == n1 - 1u) {
+            if (atomicInc(base + 32 * TDS_PEER_LINE, n2 - 1u) == n2 - 1u) {
+              const size_t fi = (size_t)ctl.peer_flag_off + (size_t)pslot * (size_t)ctl.peer_flag_stride;
+              if (rel) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+              for (int pr = 0; pr <= ctl.n_peers; ++pr)
+                __hip_atomic_store(ctl.peer_flags[pr] + fi, ctl.peer_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
           }
         }
+      } else if (ctl.progress != nullptr) {
+        if (ctl.ring_flags & TDS_RING_NOFENCE) __builtin_amdgcn_s_waitcnt(0x0f70);
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (tid == 0) __hip_atomic_fetch_add(ch_global(ctl.progress) + pslot, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-    } else if (ctl.progress != nullptr) {
-      if (ctl.ring_flags & TDS_RING_NOFENCE) __builtin_amdgcn_s_waitcnt(0x0f70);
-      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (tid == 0) __hip_atomic_fetch_add(ch_global(ctl.progress) + pslot, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
+    };
 
-  for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
     const bool last = it == nsteps - 1;
+    int wv_ = 0;
+    if constexpr (W2) {
+      int w_ = threadIdx.x >> 6;
+      asm volatile("" : "+v"(w_));
+      wv_ = __builtin_amdgcn_readfirstlane(w_);
+    }
+    const bool is_main = !W2 || wv_ == 0, is_rec = !W2 || wv_ == 1;  // wave-uniform
     if constexpr (LOOP) {
-      // the records of step it - 1 are counted in here: their stores have long been acknowledged
-      if (it > 0 && ctl.obs_ring != nullptr) signal_slot((o_slot == 0 ? ctl.obs_slots : o_slot) - 1);
+      // the records of step it - 1 are counted in here (by the wavefront that stored them): their stores have long been
+      // acknowledged — or, in the recorder's case, it waits for the main wavefront's step anyway
+      if (is_rec && it > 0 && ctl.obs_ring != nullptr) signal_slot((o_slot == 0 ? ctl.obs_slots : o_slot) - 1);
       // the NEXT step's torques are requested now (a different action block per step: tds_hip_step_many)
-      if (ctl.act_pool != nullptr && it + 1 < nsteps && valid && mine)
+      if (is_main && ctl.act_pool != nullptr && it + 1 < nsteps && valid && mine)
         next_act = (T)ch_global((const TR *)ctl.act_pool)[((size_t)act_blk * ctl.act_envs + env) * adim + link];
     }
     // where this step's y record goes: the slot of a y ring (every step of a step-loop launch), else the handle's y record
@@ -217,8 +256,33 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
       yend = LOOP ? out_dim : ystr;
     }
 
-    // ---- A. my joint: coordinate, velocity, torque (multi_body.hpp:557-570; joint stiffness / damping, forward_dynamics.hpp:122-123)
     const int me = mine ? link : 0;
+    T R[9], p[3];  // my link's world transform (main wavefront: from the kinematics; recorder: from the hand-over in LDS)
+    // ---- visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual `link` is mine
+    auto poses = [&]() {
+      if (valid && yo != nullptr && link < nv) {
+        T Ro[9], po[3], qo[4];
+        if (vis_ident) {  // wave-uniform
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Ro[k] = R[k];
+        } else {
+          mat3_mul(R, CL + TB::VIS, Ro);
+        }
+        mat3_mulv(R, CL + TB::VIS + 9, po);
+        matrix_to_quat(Ro, qo);
+        const T rec[7] = {p[0] + po[0], p[1] + po[1], p[2] + po[2], qo[0], qo[1], qo[2], qo[3]};
+        TR *const o = yo + (nq + nd) + 7 * link;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = (TR)rec[k];
+        if (yo2 != nullptr) {
+          TR *const o2 = yo2 + (nq + nd) + 7 * link;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) o2[k] = (TR)rec[k];
+        }
+      }
+    };
+    if (is_main) {  // ================================ main wavefront: the step ================================
+    // ---- A. my joint: coordinate, velocity, torque (multi_body.hpp:557-570; joint stiffness / damping, forward_dynamics.hpp:122-123)
     const T q = mine ? xr[me] : T(0), qd = mine ? xr[nq + me] : T(0);
     T tau = mine ? xr[nq + nd + me] : T(0);
     tau -= CL[TB::STIFF] * q + CL[TB::DAMP] * qd;
@@ -227,7 +291,6 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
     T S[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) S[k] = CL[TB::S + k];
-    T R[9], p[3];
     {
       T sn, cs;
       ch_sincos(q * CL[TB::ROTF], &sn, &cs);
@@ -278,21 +341,16 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
         for (int k = 0; k < 3; ++k) p[k] = a[k] + r[k];
       }
     });
-    // ---- visual poses of y, from THIS (pre-step) X_world (locomotion_contact_simulation.h:281-299): visual `link` is mine
-    if (valid && yo != nullptr && link < nv) {
-      T Ro[9], po[3], qo[4];
-      mat3_mul(R, CL + TB::VIS, Ro);
-      mat3_mulv(R, CL + TB::VIS + 9, po);
-      matrix_to_quat(Ro, qo);
-      const T rec[7] = {p[0] + po[0], p[1] + po[1], p[2] + po[2], qo[0], qo[1], qo[2], qo[3]};
-      TR *const o = yo + (nq + nd) + 7 * link;
+    if constexpr (W2) {  // hand-over to the recorder: buffer it & 1
+      if (mine) {
+        T *const kin = E + LD::KIN + ((it & 1) * NL + me) * 12;
 #pragma unroll
-      for (int k = 0; k < 7; ++k) o[k] = (TR)rec[k];
-      if (yo2 != nullptr) {
-        TR *const o2 = yo2 + (nq + nd) + 7 * link;
+        for (int k = 0; k < 9; ++k) kin[k] = R[k];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) o2[k] = (TR)rec[k];
+        for (int k = 0; k < 3; ++k) kin[9 + k] = p[k];
       }
+    } else {
+      poses();
     }
     // ---- D. the world motion axis of my joint about the world origin: s = [R S_a ; p x (R S_a) + R S_l]; link velocities
     //         v_i = sum_(j <= i) s_j qd_j, bias accelerations a0_i = a_base + sum_(j <= i) v_j x s_j qd_j with a_base =
@@ -446,7 +504,7 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
           const T ljk = L[j * (j + 1) / 2 + k] * dinv[k];  // l_jk from w_jk
           dj -= L[j * (j + 1) / 2 + k] * ljk;
         });
-        dinv[j] = T(1) / dj;
+        dinv[j] = rcp_full<T>(dj);  // (v_rcp_f64 + Newton steps: a third of the division's instructions)
         static_for<j + 1, NL>([&](auto icc) {
           constexpr int i = decltype(icc)::value;
           T w = L[i * (i + 1) / 2 + j];
@@ -481,6 +539,7 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
     }
     // ---- I. integrate_euler (integrator.hpp:10-133): qd += q'' dt, q += qd dt; the new state into the LDS record, and the next
     //         step's torques into the record's action slots in front of this step's record stores
+    if constexpr (W2) CH_BAR();  // (R) the recorder has stored the records of the step before: the LDS record may change
     {
       const T qd_new = qd + qdd * dt;
       const T q_new = q + qd_new * dt;
@@ -492,7 +551,22 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
         }
       }
     }
-    CH_SYNC();
+    if constexpr (W2) CH_BAR();  // (S) the step's state is in the LDS record
+    else CH_SYNC();
+    }  // ================================ end of the main wavefront's step ================================
+    if (is_rec) {  // ================================ the step's records (one-wave build: the same wavefront) ================================
+    if constexpr (W2) {
+      if (it == 0) CH_BAR();  // (R) of the first step: nothing stored yet
+      CH_BAR();               // (S)
+      if (mine) {
+        const T *const kin = E + LD::KIN + ((it & 1) * NL + me) * 12;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = kin[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = kin[9 + k];
+      }
+      poses();
+    }
     // ---- J. the step's records.  y: q | qd | (visual poses: above) | up.z | zero padding
     auto y_state = [&](TR *y, int end) {
       for (int i = link; i < nq + nd; i += 8) y[i] = (TR)xr[i];
@@ -602,8 +676,12 @@ __global__ __launch_bounds__(64) void tds_chain_kernel(const DevModel<T> *__rest
         obs_out[(size_t)env * w_obs + nq + nd + 1] = TR(0);
       }
     }
+    if constexpr (W2) {
+      if (!last) CH_BAR();  // (R) of the next step
+    }
+    }  // ================================ end of the records ================================
     if constexpr (LOOP) {
-      CH_SYNC();
+      if constexpr (!W2) CH_SYNC();
       act_blk = act_blk + 1 >= ctl.act_blocks ? 0 : act_blk + 1;
       y_slot = y_slot + 1 >= ctl.y_slots ? 0 : y_slot + 1;
       o_slot = o_slot + 1 >= ctl.obs_slots ? 0 : o_slot + 1;
@@ -631,15 +709,21 @@ int tds_chain_lds_bytes(int num_links) {
 
 template <typename T, typename TR>
 int tds_launch_chain(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
-                     TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl) {
+                     TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, int w2_opt) {
   const int blocks = (n_envs + 7) / 8;
   // one plain step without rings: the straight-line form; K steps, record rings: the step-loop form
   const bool one_step = ctl.nsub == 1 && ctl.obs_ring == nullptr && ctl.y_ring == nullptr;
+  // the recorder wavefront: step-loop launches that store per-step records, while the launch is resident with at most two
+  // wavefronts per SIMD (1024 workgroups of two on 1024 SIMDs); option chain_w2 = 0 / 2: never / at any grid size
+  const bool two_waves = !one_step && (ctl.obs_ring != nullptr || ctl.y_ring != nullptr) && w2_opt != 0 && (blocks <= 1024 || w2_opt == 2);
 #define CH_LAUNCH(NL_)                                                                                                           \
   case NL_:                                                                                                                      \
     if (one_step)                                                                                                                \
       hipLaunchKernelGGL((tds_chain_kernel<T, TR, NL_, false>), dim3(blocks), dim3(64), chain_shmem<NL_>(), stream, d_model, x_in, \
                          y_out, actions, x_feedback, obs_out, ctl, n_envs);                                                      \
+    else if (two_waves)                                                                                                          \
+      hipLaunchKernelGGL((tds_chain_kernel<T, TR, NL_, true, true>), dim3(blocks), dim3(128), chain_shmem<NL_>(), stream, d_model, \
+                         x_in, y_out, actions, x_feedback, obs_out, ctl, n_envs);                                                \
     else                                                                                                                         \
       hipLaunchKernelGGL((tds_chain_kernel<T, TR, NL_, true>), dim3(blocks), dim3(64), chain_shmem<NL_>(), stream, d_model, x_in,  \
                          y_out, actions, x_feedback, obs_out, ctl, n_envs);                                                      \
@@ -652,6 +736,6 @@ int tds_launch_chain(const DevModel<T> *d_model, const DevModel<T> &h_model, con
   return (int)hipGetLastError();
 }
 template int tds_launch_chain<double, double>(const DevModel<double> *, const DevModel<double> &, const double *, double *,
-                                              const double *, double *, double *, int, hipStream_t, const TdsStepCtl &);
+                                              const double *, double *, double *, int, hipStream_t, const TdsStepCtl &, int);
 template int tds_launch_chain<double, float>(const DevModel<double> *, const DevModel<double> &, const float *, float *,
-                                             const float *, float *, float *, int, hipStream_t, const TdsStepCtl &);
+                                             const float *, float *, float *, int, hipStream_t, const TdsStepCtl &, int);

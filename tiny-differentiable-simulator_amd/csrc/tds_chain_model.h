@@ -15,8 +15,9 @@ struct TdsChainTab {
                        NAX = 33, NN = 36, ROTF = 42, VIS = 43 /* X_visual: rotation 9 | translation 3 */;
   static constexpr int SC = 8 * LSTR;
   static constexpr int DT = 0, GRAV = 1 /* base_X_world.rot * gravity */, BASE_R8 = 4, NUM_VISUALS = 5, PACK_VISUALS = 6, OUTPUT_DIM = 7, NUM_LINKS = 8,
-                       XT_IDENT = 9;  // 1: the X_T rotation of every link (link 0: with the base) is the identity
-  static constexpr int TOTAL = SC + 10;
+                       XT_IDENT = 9,  // 1: the X_T rotation of every link (link 0: with the base) is the identity
+                       VIS_IDENT = 10;  // 1: every visual's rotation is the identity (no R X_visual product)
+  static constexpr int TOTAL = SC + 12;
 };
 
 static_assert(TdsChainTab::TOTAL <= TDS_OCT_TAB_CAP, "DevModel::oct_tab is too small for the chain table");
@@ -115,5 +116,11 @@ static void tds_chain_detect(const tds_model_t *m, DevModel<T> *d) {
   sc[TB::OUTPUT_DIM] = (T)m->output_dim;
   sc[TB::NUM_LINKS] = (T)n;
   sc[TB::XT_IDENT] = ident ? T(1) : T(0);
+  {
+    bool vid = true;
+    for (int v = 0; v < (m->pack_visuals ? m->num_visuals : 0); ++v)
+      for (int k = 0; k < 9; ++k) vid = vid && m->visuals[v].X_rot[k] == ((k == 0 || k == 4 || k == 8) ? 1.0 : 0.0);
+    sc[TB::VIS_IDENT] = vid ? T(1) : T(0);
+  }
   d->chain = n;
 }

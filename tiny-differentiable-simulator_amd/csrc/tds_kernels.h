@@ -137,6 +137,8 @@ struct TdsStepCtl {
 #define TDS_FORM_LOOP_OCC2 4  // ... the two-wavefronts-per-SIMD compilation whatever the grid
 #define TDS_FORM_OCT_W2 8     // the 8-lane kernel (tds_oct.hip): its two-wavefront build compiled for two wavefronts per SIMD
 #define TDS_FORM_OCT_W2_OCC1 16  // ... compiled for one wavefront per SIMD (at most two workgroups per compute unit)
+#define TDS_FORM_CHAIN_W1 32     // the serial-chain kernel (tds_chain.hip): no recorder wavefront (option chain_w2 = 0)
+#define TDS_FORM_CHAIN_W2_ANY 64 // ... the recorder wavefront at any grid size (option chain_w2 = 2)
 
 // EXPERIMENT SLOTS (tools/build_alt.sh): the kernel sources compiled once more — other compiler flags, -DTDS_X_... source
 // switches — as a small extra translation unit holding ONE (lanes, padded dof) instantiation of the f64 / KIND 0 kernels,
@@ -200,7 +202,7 @@ inline bool tds_oct_takes(int oct, const TdsStepCtl &ctl, const long long *prof)
 // models have no reward rule: no environment is ever done), no policy, no phase stamps
 template <typename T, typename TR>
 int tds_launch_chain(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
-                     TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl);
+                     TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, int w2_opt);
 int tds_chain_lds_bytes(int num_links);
 inline bool tds_chain_takes(int chain, const TdsStepCtl &ctl, const long long *prof) {
   return chain != 0 && prof == nullptr && ctl.nsub >= 1 && ctl.reset_mode == TDS_RESET_NONE && ctl.policy == nullptr;
@@ -221,7 +223,8 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
       return tds_launch_oct<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl,
                                    (form & TDS_FORM_OCT_W2_OCC1) ? 3 : ((form & TDS_FORM_OCT_W2) ? 2 : 1));
     if (tds_chain_takes(h_model.chain, ctl, prof))
-      return tds_launch_chain<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl);
+      return tds_launch_chain<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl,
+                                     (form & TDS_FORM_CHAIN_W1) ? 0 : ((form & TDS_FORM_CHAIN_W2_ANY) ? 2 : 1));
   }
   if (h_model.is_floating) return tds_launch_step_impl<T, TR, 1>(TDS_ARGS);
   // (pure float arithmetic — measured only, it misses the 1e-6 contract: tds_hip.h TDS_DTYPE_F32 — is built for the
