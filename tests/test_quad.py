@@ -231,7 +231,8 @@ def test_quad_step_loop_with_auto_reset_equals_single_steps(built):
 
 
 def test_single_step_auto_reset_in_environment_chains_equals_single_steps(built):
-    """Beyond residency of the step-loop form (laikago_soft x 8192: config 4) tds_hip_step_many with auto-reset runs single steps
+    """Beyond residency of the step-loop form (laikago_soft x 8192 with option quad_wide = 0: round 6's wide workgroups keep the
+    loop form resident there by default) tds_hip_step_many with auto-reset runs single steps
     through the reset pool — as two ENVIRONMENT CHAINS on two streams, like the graphs of the plain call.  Against the same
     steps issued one call at a time (one whole-batch launch per step): the same records and reset stream, bit for bit; resets
     from the first step on in BOTH chains, uneven call lengths across several refill passes."""
@@ -245,8 +246,8 @@ def test_single_step_auto_reset_in_environment_chains_equals_single_steps(built)
     x = _start_state(m, name, n, rng)
     tilt = rng.permutation(n)[: n // 4]  # (spread over both halves of the batch)
     x[tilt, 3] = rng.uniform(1.0, 1.3, len(tilt))
-    a = hip_backend.HipSim(m, n)
-    b = hip_backend.HipSim(m, n)
+    a = hip_backend.HipSim(m, n, options={"quad_wide": 0})
+    b = hip_backend.HipSim(m, n, options={"quad_wide": 0})
     for s_ in (a, b):
         s_.x.copy_(torch.from_numpy(x).cuda())
         s_.set_auto_reset(True, 7)
@@ -269,3 +270,47 @@ def test_single_step_auto_reset_in_environment_chains_equals_single_steps(built)
     assert dones >= n // 4, dones
     print(f"laikago_soft x {n}: {done_steps} auto-reset steps in two environment chains == single steps, {dones} resets "
           f"(last call: {half[0]} / {half[1]} in the two halves)")
+
+
+@pytest.mark.parametrize("n,auto_reset", [(8192, False), (8192, True), (8161, True), (1000, False)])
+def test_quad_wide_workgroups_equal_one_wavefront_workgroups_bit_for_bit(n, auto_reset, built):
+    """The step-loop form in WIDE workgroups (eight wavefronts around one constant table, a workgroup per compute unit: what
+    keeps laikago_soft x 8192 — config 4 — resident; option quad_wide) against the same launch in one-wavefront workgroups
+    (quad_wide = 0 + step_many_loop = 1): the same kernel body, so every ring slot, the state and the reset stream bit for bit
+    — with auto-reset from the first step on, a ragged last workgroup (8161 = 255 x 32 + 1) and a batch far below residency."""
+    torch = _torch()
+    name = "laikago_soft"
+    m = tds_amd.load_model(name)
+    rng = np.random.default_rng(21)
+    from test_rings import _start_state
+
+    x = _start_state(m, name, n, rng)
+    if auto_reset:
+        tilt = rng.permutation(n)[: n // 4]
+        x[tilt, 3] = rng.uniform(1.0, 1.3, len(tilt))
+    a = hip_backend.HipSim(m, n, options={"quad_wide": 2})
+    b = hip_backend.HipSim(m, n, options={"quad_wide": 0, "step_many_loop": 1})
+    for s_ in (a, b):
+        s_.x.copy_(torch.from_numpy(x).cuda())
+        if auto_reset:
+            s_.set_auto_reset(True, 11)
+    assert a.step_many_is_loop(8) and b.step_many_is_loop(8)
+    if n == 8192:  # the library's own choice at config 4's size
+        c = hip_backend.HipSim(m, n)
+        assert c.step_many_is_loop(8) and not hip_backend.HipSim(m, n, options={"quad_wide": 0}).step_many_is_loop(8)
+    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (4, n, m.action_dim))).cuda().contiguous()
+    done_steps, dones = 0, 0
+    for steps in (6, 31, 1):
+        rings = []
+        for s_ in (a, b):
+            obs_ring = torch.full((5, n, a.obs_dim + 2), float("nan"), dtype=torch.float64, device="cuda")
+            y_ring = torch.full((steps, n, m.output_dim), float("nan"), dtype=torch.float64, device="cuda")
+            s_.step_many_rings(actions, steps, obs_ring, y_ring, first_block=done_steps % 4, obs_first=3)
+            rings.append((obs_ring, y_ring))
+        torch.cuda.synchronize()
+        assert torch.equal(rings[0][0], rings[1][0]) and torch.equal(rings[0][1], rings[1][1])
+        assert not torch.isnan(rings[0][1]).any() and (steps < 5 or not torch.isnan(rings[0][0]).any())
+        assert torch.equal(a.x, b.x) and torch.equal(a.y, b.y)
+        dones += int((rings[0][0][:, :, -1] != 0).sum().item()) if steps >= 5 else 0
+        done_steps += steps
+    assert not auto_reset or dones >= n // 8, dones

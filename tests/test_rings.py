@@ -63,8 +63,10 @@ def _reward_done(m, name, q_before, y):
 
 @pytest.mark.parametrize("name,n,steps,dtype,form", [
     ("ant", 4096, 20, "f64", "default"), ("pendulum5", 4096, 20, "f64", "default"), ("pendulum5", 4096, 20, "mixed", "default"),
-    ("laikago_soft", 8192, 50, "f64", "default"),
-    # config 4 in the 16-lane kernel's STEP-LOOP form (resident up to 6144 environments; 8192 runs single-step launches)
+    # config 4: the 16-lane kernel's step-loop form in wide workgroups (the default at 8192) and the single-step launches
+    # of round 5 (option quad_wide = 0)
+    ("laikago_soft", 8192, 50, "f64", "default"), ("laikago_soft", 8192, 20, "f64", "quad_narrow"),
+    # ... in one-wavefront workgroups (resident up to 6144 environments)
     ("laikago_soft", 4096, 20, "f64", "default"), ("laikago_soft", 6144, 20, "f64", "default"),
     ("ant", 8192, 20, "f64", "default"),       # config 5's per-GPU share: the one-wave loop build
     # the builds a MULTI-GPU run launches (tds_hip_shard_step_many): a progress counter attached -> write-through record
@@ -88,7 +90,8 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
     # ("exchange": the ONE-wave build under a progress counter, round 3's default, still an option; "exchange_w2" and
     #  "exchange_inplace": the two-wavefront build — the default since round 4, what N = 1 runs)
     opts = {"exchange_w2": 1} if form == "exchange_w2" else ({"exchange_w2": 0} if form == "exchange" else
-                                                               ({"loop_w2": 0} if form == "one_wave" else None))
+                                                               ({"loop_w2": 0} if form == "one_wave" else
+                                                                ({"quad_wide": 0} if form == "quad_narrow" else None)))
     sim = hip_backend.HipSim(m, n, dtype=dtype, options=opts)
     tdt = sim.torch_dtype
     x0 = _start_state(m, name, n, rng)
@@ -164,8 +167,8 @@ def test_every_ring_slot_of_every_env_against_the_reference(name, n, steps, dtyp
             assert rel_err(orr[k][~edge, -2], rew[~edge], floor=1.0) < 10 * tol, (name, k)
         # resync on the device's own (double) state: what the next step started from
         x[:, :nq + nd] = yr_state[k][:, :nq + nd]
-    if name == "laikago_soft" and n <= 6144:
-        assert sim.single_step_kernel()[0] == "quad16" and sim.step_many_is_loop(steps)
+    if name == "laikago_soft":  # (step-loop form everywhere up to 8192: one-wavefront workgroups up to 6144, wide ones beyond)
+        assert sim.single_step_kernel()[0] == "quad16" and sim.step_many_is_loop(steps) == (form != "quad_narrow")
     print(f"{name} x{n} [{dtype}, {form}, {sim.single_step_kernel()[0]}], {steps} ring slots, every env, vs {what}: worst "
           f"per-step rel err {worst:.3e} (loop form: {sim.step_many_is_loop(steps)})")
 
@@ -287,10 +290,10 @@ def test_rings_with_auto_reset(name, built):
     assert rel_err(sims[0].x.cpu().numpy(), sims[1].x.cpu().numpy()) < TOL
 
 
-@pytest.mark.parametrize("name,n", [("ant", 4096), ("laikago_soft", 4096)])
+@pytest.mark.parametrize("name,n", [("ant", 4096), ("laikago_soft", 4096), ("laikago_soft", 8192)])
 def test_rings_with_auto_reset_against_the_reference_at_full_size(name, n, built):
     """Configs 3 and 4 through the form bench.py times with auto-reset on (config 4's default line): Ant x 4096 in the
-    8-lane kernel, laikago_soft x 4096 in the 16-lane kernel; auto_reset_when_done, 20 steps as
+    8-lane kernel, laikago_soft x 4096 in the 16-lane kernel and x 8192 in its wide workgroups; auto_reset_when_done, 20 steps as
     step-loop launches through the reset pool with both rings on.  The host replays the reference's loop environment by
     environment — its own step (libtds_ref.so), compute_reward_done (ant_environment2.h:75-106) and, for an environment that
     ends a step with done, reset() + the ten settle steps (ant_environment2.h:109-165; the device's counter-based random

@@ -97,7 +97,20 @@ extern "C" {
 TDS_ALT_DECL(1) TDS_ALT_DECL(2) TDS_ALT_DECL(3) TDS_ALT_DECL(4) TDS_ALT_DECL(5) TDS_ALT_DECL(6)
 #undef TDS_ALT_DECL
 }
-int tds_quad_loop_workgroup_bytes(int input_dim);  // (tds_quad.hip: LDS of one workgroup of its step-loop form)
+// The 16-lane kernel's step-loop form (tds_quad.hip): how its workgroups are shaped for a launch over n_envs environments —
+// 1: one wavefront per workgroup (resident up to six workgroups per compute unit: the constant table costs LDS), W =
+// TDS_QUAD_WIDE_WAVES: W wavefronts around one table, a workgroup per compute unit (resident up to 32 environments per
+// compute unit: laikago_soft x 8192), 0: neither form has every workgroup resident (the caller takes the chained graphs)
+static int quad_loop_waves(const tds_hip_sim *s, int n_envs) {
+  const int in_dim = s->model.input_dim;
+  const int per_cu = (int)(s->lds_per_cu / (size_t)tds_quad_loop_workgroup_bytes(in_dim, 1));
+  const long long wide = s->opt.get(TDS_OPT_QUAD_WIDE, 1);  // 0: never, 1: where the narrow form is not resident, 2: always
+  const bool wide_fits = (size_t)tds_quad_loop_workgroup_bytes(in_dim, TDS_QUAD_WIDE_WAVES) <= s->lds_per_cu &&
+                         (n_envs + 4 * TDS_QUAD_WIDE_WAVES - 1) / (4 * TDS_QUAD_WIDE_WAVES) <= s->num_cus;
+  if (wide == 2 && wide_fits) return TDS_QUAD_WIDE_WAVES;
+  if ((n_envs + 3) / 4 <= s->num_cus * (per_cu < 8 ? per_cu : 8)) return 1;
+  return (wide != 0 && wide_fits) ? TDS_QUAD_WIDE_WAVES : 0;
+}
 static tds_alt_launch_fn tds_alt_slot(int k) {
   switch (k) {
     case 1: return tds_alt_launch_1;
@@ -170,9 +183,10 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     if (o2 != 0 && o2 != 3 && per_cu >= 2 && blocks <= 2 * s->num_cus) oct_form = TDS_FORM_OCT_W2_OCC1;
     else if (o2 == 2 || o2 == 3 || (o2 != 0 && blocks <= s->num_cus * (per_cu < 4 ? per_cu : 4))) oct_form = TDS_FORM_OCT_W2;
   }
+  const int quad_form = (s->compute_f64() && s->h64.quad && quad_loop_waves(s, n_resident) > 1) ? TDS_FORM_QUAD_WIDE : 0;
   const long long cw2 = s->opt.get(TDS_OPT_CHAIN_W2, 1);
   const int form = (two_waves ? TDS_FORM_W2 : 0) | (occ == 1 ? TDS_FORM_LOOP_OCC1 : (occ == 2 ? TDS_FORM_LOOP_OCC2 : 0)) |
-                   oct_form | (cw2 == 0 ? TDS_FORM_CHAIN_W1 : (cw2 == 2 ? TDS_FORM_CHAIN_W2_ANY : 0));
+                   oct_form | quad_form | (cw2 == 0 ? TDS_FORM_CHAIN_W1 : (cw2 == 2 ? TDS_FORM_CHAIN_W2_ANY : 0));
   void *ovf = (opts && opts->ovf) ? opts->ovf : ((opts && opts->lds) ? nullptr : s->d_ovf);
   if (opts && opts->env_first > 0) {  // a sub-range of the environments: every per-environment array moves along
     const size_t e0 = (size_t)opts->env_first, el = s->elem;
@@ -1331,9 +1345,7 @@ bool step_many_as_loop(const tds_hip_sim *s, int n_steps) {
   // laikago_soft (tools/quad_occupancy_sweep.sh, us per step, loop / graphs): x 4096 13.4 / 20.8, x 6144 18.3 / 23.2,
   // x 8192 32.5 / 24.7; with auto-reset: 13.2 / 21.0, 17.8 / 25.8, 30.9 / 27.4.  Option step_many_loop = 0 / 1 forces a form.
   if (s->compute_f64() && s->h64.quad) {
-    const int per_cu = (int)(s->lds_per_cu / (size_t)tds_quad_loop_workgroup_bytes(s->model.input_dim));
-    const int resident = s->num_cus * (per_cu < 8 ? per_cu : 8);
-    return (s->num_envs + 3) / 4 <= resident;
+    return quad_loop_waves(s, s->num_envs) != 0;
   }
   // the 8-lane kernel of the stars with two-link legs (tds_oct.hip: the Ant): always one launch.  Its straight-line form costs
   // the same table copy and workgroup rounds per step plus a kernel boundary and the state's round trip through HBM, so

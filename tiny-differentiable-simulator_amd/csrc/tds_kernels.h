@@ -139,6 +139,8 @@ struct TdsStepCtl {
 #define TDS_FORM_OCT_W2_OCC1 16  // ... compiled for one wavefront per SIMD (at most two workgroups per compute unit)
 #define TDS_FORM_CHAIN_W1 32     // the serial-chain kernel (tds_chain.hip): no recorder wavefront (option chain_w2 = 0)
 #define TDS_FORM_CHAIN_W2_ANY 64 // ... the recorder wavefront at any grid size (option chain_w2 = 2)
+#define TDS_FORM_QUAD_WIDE 128   // the 16-lane kernel (tds_quad.hip): step-loop launch in workgroups of TDS_QUAD_WIDE_WAVES wavefronts
+#define TDS_QUAD_WIDE_WAVES 8    // ... around ONE constant table: a workgroup per compute unit, 32 environments each
 
 // EXPERIMENT SLOTS (tools/build_alt.sh): the kernel sources compiled once more — other compiler flags, -DTDS_X_... source
 // switches — as a small extra translation unit holding ONE (lanes, padded dof) instantiation of the f64 / KIND 0 kernels,
@@ -176,9 +178,10 @@ int tds_launch_step_impl(const DevModel<T> *d_model, const DevModel<T> &h_model,
 // the 16-lane kernel of the star-shaped legged robots (tds_quad.hip; DevModel::quad): one straight-line step per launch
 template <typename T, typename TR>
 int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
-                    TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl);
+                    TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, int wide);
 template <typename T>
 int tds_quad_lds_bytes(int input_dim);
+int tds_quad_loop_workgroup_bytes(int input_dim, int waves);  // LDS of one workgroup of its step-loop form: 4 * waves environments + the table
 // what tds_launch_step hands to it: plain steps — one per launch, or K of them with action replay, record rings and
 // reset-pool entries taken in the loop (tds_hip_step_many / _rings) —, no in-kernel reset, no policy, no exchange launch
 // (progress counters / peer stores), no profile stamps
@@ -217,7 +220,8 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
                            int form = 0) {   // TDS_FORM_*: which build of the kernel
 #define TDS_ARGS d_model, h_model, L, lanes_per_env, x_in, y_out, actions, x_feedback, obs_out, ovf, n_envs, stream, ctl, prof, form
   if (tds_quad_takes(h_model.quad, ctl, prof))
-    return tds_launch_quad<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl);
+    return tds_launch_quad<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl,
+                                  (form & TDS_FORM_QUAD_WIDE) != 0);
   if constexpr (sizeof(T) == 8) {
     if (tds_oct_takes(h_model.oct, ctl, prof))
       return tds_launch_oct<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl,

@@ -29,6 +29,7 @@ enum TdsOptKey {
   TDS_OPT_LOOP_W2,            // step-loop launches: 0 one-wave build, 1 (default) two-wavefront build where it fits, 2 ... not with the reset pool
   TDS_OPT_OCT_W2,             // 8-lane kernel (tds_oct.hip): 0 one wavefront per workgroup, 1 / unset two (main + helper) while every workgroup is resident with at most two wavefronts per SIMD, 2 two at any grid size
   TDS_OPT_CHAIN_W2,           // serial-chain kernel (tds_chain.hip), step-loop launches with per-step records: 0 one wavefront per workgroup, 1 / unset a second one as the recorder while the launch is resident with at most two wavefronts per SIMD, 2 at any grid size
+  TDS_OPT_QUAD_WIDE,          // 16-lane kernel (tds_quad.hip), step-loop launches: 0 one wavefront per workgroup always, 1 / unset eight wavefronts around one constant table (a workgroup per compute unit) where the one-wavefront workgroups are not all resident, 2 wherever the wide form is
   TDS_OPT_LOOP_OCC,           // step-loop build: 1 / 2 wavefronts per SIMD forced (unset: by grid size)
   TDS_OPT_EXCHANGE_W2,        // launches whose ring slots are exchanged while they run (rings->progress): 1 / unset the two-wavefront build N = 1 takes, 0 the one-wave build
   TDS_OPT_RING_NOFENCE,       // 1 (default): write-through record stores + plain wait; 0: release fence per step
@@ -91,6 +92,7 @@ inline const TdsOptRow *tds_opt_rows() {
       {"loop_w2", false, "TDS_HIP_LOOP_W2"},
       {"oct_w2", false, "TDS_HIP_OCT_W2"},
       {"chain_w2", false, "TDS_HIP_CHAIN_W2"},
+      {"quad_wide", false, "TDS_HIP_QUAD_WIDE"},
       {"loop_occ", false, "TDS_HIP_LOOP_OCC"},
       {"exchange_w2", false, "TDS_HIP_EXCHANGE_W2"},
       {"ring_nofence", false, "TDS_HIP_RING_NOFENCE"},

@@ -139,6 +139,22 @@ struct QuadKernArgs {
 // round trip per group of constants, and the first of them also waited for the previous step's record stores (loads and
 // stores share one in-order counter on gfx9): 35.2 us per laikago_soft x 8192 step against 27.2 for the chained graphs
 // of the straight-line form (profiles/r05_quad_forms.txt).  The straight-line form reads the model directly.
+// Phase stamps (a build of its own: -DTDS_QUAD_PROF, tools/quad_profile.sh): workgroup 3 writes the shader clock at the phase
+// boundaries of a step (step-loop form: of iteration tds_quad_prof_iter) into tds_quad_prof_buf
+#ifdef TDS_QUAD_PROF
+__device__ unsigned long long tds_quad_prof_buf[32];
+__device__ int tds_quad_prof_iter = 0;
+#define QUAD_STAMP(k, pin)                                                                      \
+  do {                                                                                          \
+    unsigned long long t_;                                                                      \
+    auto p_ = (pin); /* a value of the phase before: computed before the clock is read */       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(p_)::"memory");        \
+    if (prof_on) prof_t[k] = t_;                                                                \
+  } while (0)
+#else
+#define QUAD_STAMP(k, pin) do { } while (0)
+#endif
+
 template <typename T>
 struct QuadTable {
   T S[6][16], X_T[12][16], mass[16], com[3][16], inertia[9][16], init_pose[16], stiffness[16], damping[16];
@@ -190,8 +206,14 @@ __host__ __device__ inline QuadOff quad_layout(int in_dim) {
 // taking its next pre-settled state from the reset pool inside the loop (ctl.pool).  As in the general kernel's step-loop
 // builds nothing but the loop state lives across an iteration: the model pointer and the kernel-argument segment are
 // laundered per iteration, so the lane constants and the ctl fields are loaded where an iteration uses them.
-template <typename T, typename TR, bool LOOP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+// WAVES: wavefronts per workgroup.  1 everywhere but the WIDE step-loop launches (round 6): eight wavefronts — 32 environments
+// — share ONE constant table, a workgroup takes a compute unit's whole LDS (8 x 19 456 + 6 600 of 163 840 B) and the 256
+// workgroups of laikago_soft x 8192 are resident at once: two wavefronts per SIMD exactly as eight one-wavefront workgroups
+// per compute unit would be, which the table's 6.6 KB per workgroup rules out.  The wavefronts of a workgroup never meet
+// again after the table is filled (every wavefront writes all of it — the same values — and reads it behind its own
+// wavefront barrier): no s_barrier anywhere.
+template <typename T, typename TR, bool LOOP, int WAVES = 1>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2)))
 void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
                      const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */, TR *__restrict__ obs_out,
                      TdsStepCtl ctl_arg, int n_envs, QuadOff O) {
@@ -200,7 +222,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   constexpr int nq = 18, nd = 18;
   {
     // ---- A. x record -> LDS (coalesced), fresh actions over the action slice
-    const int lane = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4, env = blockIdx.x * 4 + grp;
+    const int lane = threadIdx.x & 15, grp = threadIdx.x >> 4, env = blockIdx.x * (4 * WAVES) + grp;
     const bool valid = env < n_envs;
     T *const xr = sm + grp * O.stride;
     // (dimensions from the kernel arguments and all of a lane's record loads issued before the first is waited for: as a
@@ -221,7 +243,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       if (i < in_dim) xr[i] = xv[k];
     }
   }
-  QuadTable<T> *const CT = reinterpret_cast<QuadTable<T> *>(sm + 4 * O.stride);  // (step-loop launches only)
+  QuadTable<T> *const CT = reinterpret_cast<QuadTable<T> *>(sm + 4 * WAVES * O.stride);  // (step-loop launches only)
   if constexpr (LOOP) {
     const DevModel<T> *const md = mdl_arg;
     const int t = threadIdx.x & 63;
@@ -295,9 +317,13 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   if constexpr (LOOP) asm volatile("" : "+s"(mdl_g), "+s"(ka_seg), "+v"(tid));
   const DevModel<T> *const mdl = (const DevModel<T> *)mdl_g;
   const int lane = tid & 15;
-  const int grp = (tid & 63) >> 4;
-  const int env = blockIdx.x * 4 + grp;
+  const int grp = tid >> 4;  // (environment of the workgroup: 4 per wavefront)
+  const int env = blockIdx.x * (4 * WAVES) + grp;
   const bool valid = env < n_envs;
+#ifdef TDS_QUAD_PROF
+  unsigned long long prof_t[18];
+  const bool prof_on = blockIdx.x == 3 && tid < 64 && it == (LOOP ? tds_quad_prof_iter : 0);
+#endif
   T *const E = sm + grp * O.stride;
   T *const xr = E;
   const int leg = lane >> 2, pos = lane & 3;
@@ -336,6 +362,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   const T q = dofl ? xr[dq] : T(0);
   const T qd = dofl ? xr[nq + dq] : T(0);
 
+  QUAD_STAMP(0, q);
   // ---- PD controller (locomotion_contact_simulation.h:168-258) or direct torque; joint stiffness / damping
   T tau = T(0);
   if (QC(step_mode, step_mode) == TDS_STEP_LOCOMOTION) {
@@ -356,6 +383,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   }
   tau -= stiff_l * q + damp_l * qd;
 
+  QUAD_STAMP(1, tau);
   // ---- B. jcalc (link.hpp:229-287); the toe lanes of legs 0..2 — fixed joints, no angle of their own — take the root's
   //         three angles: their sines and cosines reach every lane by one row broadcast each
   T Rp[9], tp[3], sn, cs;
@@ -401,6 +429,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     tp[2] = tT[2] + r[2];
   }
 
+  QUAD_STAMP(2, tp[2]);
   // ---- C. the root chain in closed form (kinematics.hpp:64-97; see tds_kernels.hip phase C: same formulas), on every lane
   const T q0 = xr[0], q1 = xr[1], q2 = xr[2];
   const T sx = dpp_bcast<3>(sn), cx = dpp_bcast<3>(cs);
@@ -454,6 +483,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       a5[3 + k] = (l3[k] + l4[k] + l5[k]) - QC(grav[k], grav[k]);
     }
   }
+  QUAD_STAMP(3, a5[5]);
   // ---- the legs: one segmented prefix scan along each quad (chain-local products of the joint transforms, then the
   //      root's pose in front; prefix sums of the joint velocities and of the velocity-product accelerations)
   T R[9], p[3], sw[6], vJ[6], v[6], a0[6];
@@ -547,6 +577,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     }
   }
 
+  QUAD_STAMP(4, sw[5]);
   // ---- D. world-frame rigid inertia and bias force of my link, and (redundantly on every lane) of the root body
   //         (kinematics.hpp:96-132, inertia.hpp:121-130): I = (Isym 6 | h 3 | m), f = I a0 + v x* I v
   auto rigid = [&](const T *Rl, const T *pl, T m, const T *com, const T *Ib, const T *vl, const T *al, T *Ic, T *fc) {
@@ -602,6 +633,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
 #pragma unroll
     for (int k = 0; k < 6; ++k) fc[k] += Ia[k];
   };
+  QUAD_STAMP(5, tid);
   // ---- I. narrowphase: the contact points are the toes' own lanes (plane x sphere, contact_point.hpp:96-131)
   int na = 0;
   {
@@ -618,7 +650,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     const T dist = t - rad;
     const bool act = valid && pos == 3 && dist < T(0);
     const unsigned long long bal = __ballot(act);
-    const unsigned mine = (unsigned)((bal >> (grp * 16)) & 0xFFFFull);
+    const unsigned mine = (unsigned)((bal >> ((grp & 3) * 16)) & 0xFFFFull);
     const int pre = __popc(mine & ((1u << lane) - 1u));
     if (act) {
       cpx[0 * 4 + pre] = ctr[0] - rad * n[0];
@@ -637,6 +669,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   }
   NA = __builtin_amdgcn_readfirstlane(NA);
 
+  QUAD_STAMP(6, tid);
   // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
   //          my link's (DevModel::quad checks the order); visual 0 — the root body's — goes out on the toe lane of leg 3
   // where this step's y record goes: the slot of a y ring (every step of a step-loop launch), else the handle's y record
@@ -710,6 +743,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     rigid(R5, P, LOOP ? CT->mass5 : md4->mass[5], com5, I5, v5, a5, It, ft);
   }
 
+  QUAD_STAMP(7, tid);
   // ---- E. composite inertia / bias force (CRBA, mass_matrix.hpp:39-56): suffix sums along every quad; the chain heads'
   //         totals reach the root by two row rotations and come back to every lane by a quad broadcast
   static_for<0, 2>([&](auto dc) {
@@ -764,6 +798,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
 #pragma unroll
   for (int r = 0; r < 6; ++r) Cr[r] = dot6(axr[r], ft);
 
+  QUAD_STAMP(8, Cr[5]);
   // ---- G. M in leaves-first order.  My row of my leg's 3 x 3 block (entries against the dofs in front of me in the
   //         chain: M[i][j] = F_i . s_j for j an ancestor of i, mass_matrix.hpp:87-109) and my coupling to the root dofs
   T Bm[3], Cc[6];
@@ -780,6 +815,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
 #pragma unroll
     for (int r = 0; r < 6; ++r) Cc[r] = dofl ? dot6(Fc, axr[r]) : T(0);
   }
+  QUAD_STAMP(9, tid);
   // ---- H. LDL^T.  The leg block: its six entries to every lane of the quad, factorised there
   T l10, l20, l21, id0, id1, id2, sq0, sq1, sq2;
   {
@@ -951,6 +987,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     x_leg = dofl ? x : T(0);
   };
 
+  QUAD_STAMP(10, tid);
   // ---- F. forward dynamics qdd = M^-1 (tau - C), integrate_euler_qdd (integrator.hpp:169-181)
   T qd_new, qdr_new[6];
   {
@@ -964,6 +1001,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     for (int r = 0; r < 6; ++r) qdr_new[r] = xr[nq + r] + xrt[r] * dt;
   }
 
+  QUAD_STAMP(11, qd_new);
   // ---- J, K, L. contacts: rows of the penetrating toes (wave-uniform slots: NA = the largest count among the wavefront's
   //      environments; rows a: normals, NA + a: tangents 1, 2 NA + a: tangents 2, the reference's order under compaction)
   if (NA > 0) {
@@ -1126,6 +1164,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     }
   }
 
+  QUAD_STAMP(12, qd_new);
   // ---- M. integrate_euler: q += qd dt (integrator.hpp:126-131); the new state into the LDS record
   QUAD_SYNC();
   {
@@ -1154,6 +1193,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     if (ctl.act_pool != nullptr && !last && lane < adim) xr[nq + nd + lane] = next_act;
   }
   QUAD_SYNC();
+  QUAD_STAMP(13, tid);
   // ---- y record: q | qd | (visual poses: M1) | up.z | zero padding
   if (valid && yo != nullptr) {
     auto y_state = [&](TR *y, int end) {
@@ -1169,6 +1209,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     y_state(yo, yend);
     if (yo2 != nullptr) y_state(yo2, yend2);
   }
+  QUAD_STAMP(14, tid);
   // ---- N. reward / done (laikago_environment2.h:130-171; ant_environment2.h:75-106)
   {
     T rs = T(0), rc = T(1);
@@ -1198,6 +1239,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     }
   }
   QUAD_SYNC();
+  QUAD_STAMP(15, tid);
   // ---- auto_reset_when_done through the reset pool (ctl.pool; ars_vectorized_environment.h:262-277): a done environment
   //      takes its next pre-settled state — y, reward and done describe the terminal step, the observation and the state
   //      the fresh environment
@@ -1215,6 +1257,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     if (lane == 0) ctl.reset_count[env] = c + 1u;
   }
   QUAD_SYNC();
+  QUAD_STAMP(16, tid);
   // ---- [obs | reward | done] record (obs[0] = obs[1] = 0, ars_vectorized_environment.h:283-288): the slot of an obs ring
   //      (every step of a step-loop launch; floats on the multi-GPU wire format) and / or the caller's record (last step)
   if (valid) {
@@ -1239,11 +1282,27 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       }
     }
   }
+  QUAD_STAMP(17, tid);
+#ifdef TDS_QUAD_PROF
+  if (prof_on && (tid & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 18; ++k) tds_quad_prof_buf[k] = prof_t[k];
+    tds_quad_prof_buf[18] = (unsigned long long)NA;
+  }
+#endif
   if constexpr (LOOP) QUAD_SYNC();
   }  // ================================ end of the step loop ================================
 }
 
 }  // namespace
+
+#ifdef TDS_QUAD_PROF
+extern "C" int tds_quad_prof_read(unsigned long long *out32, int iter) {  // iter >= 0: which iteration the NEXT launches stamp
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(tds_quad_prof_buf), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (iter >= 0 && hipMemcpyToSymbol(HIP_SYMBOL(tds_quad_prof_iter), &iter, sizeof(int)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 // LDS bytes of one environment of the quadruped kernel
 template <typename T>
@@ -1252,20 +1311,33 @@ int tds_quad_lds_bytes(int input_dim) {
 }
 template int tds_quad_lds_bytes<double>(int);
 // LDS bytes of one WORKGROUP (four environments) of a step-loop launch: the environments' regions + the constant table
-int tds_quad_loop_workgroup_bytes(int input_dim) {
-  return quad_layout(input_dim).stride * 4 * (int)sizeof(double) + (int)sizeof(QuadTable<double>);
+int tds_quad_loop_workgroup_bytes(int input_dim, int waves) {
+  return quad_layout(input_dim).stride * 4 * waves * (int)sizeof(double) + (int)sizeof(QuadTable<double>);
 }
 template int tds_quad_lds_bytes<float>(int);
 
 template <typename T, typename TR>
 int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
-                    TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl) {
+                    TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, int wide) {
   QuadOff O = quad_layout(h_model.input_dim);
   O.adim = h_model.action_dim;
   if (O.in_dim > 80) return -1;  // (the prologue holds a record in five registers per lane)
   const int blocks = (n_envs + 3) / 4;
   // (+ the constant table of a step-loop launch behind the four environments' regions)
   const bool one_step = ctl.nsub == 1 && ctl.obs_ring == nullptr && ctl.y_ring == nullptr;
+  if (!one_step && wide) {  // wide step-loop launch: TDS_QUAD_WIDE_WAVES wavefronts per workgroup around one table
+    constexpr int W = TDS_QUAD_WIDE_WAVES;
+    const size_t bytes = (size_t)O.stride * 4 * W * sizeof(T) + sizeof(QuadTable<T>);
+    static bool attr_set = false;  // (per instantiation; the attribute is the same on every device)
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void *)tds_quad_kernel<T, TR, true, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return (int)hipGetLastError();
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((tds_quad_kernel<T, TR, true, W>), dim3((n_envs + 4 * W - 1) / (4 * W)), dim3(64 * W), bytes, stream, d_model,
+                       x_in, y_out, actions, x_feedback, obs_out, ctl, n_envs, O);
+    return (int)hipGetLastError();
+  }
   const size_t shmem = (size_t)O.stride * 4 * sizeof(T) + (one_step ? 0 : sizeof(QuadTable<T>));
   // one plain step without rings: the straight-line form; K steps, record rings: the step-loop form
   if (one_step)
@@ -1277,8 +1349,8 @@ int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
   return (int)hipGetLastError();
 }
 template int tds_launch_quad<double, double>(const DevModel<double> *, const DevModel<double> &, const double *, double *,
-                                             const double *, double *, double *, int, hipStream_t, const TdsStepCtl &);
+                                             const double *, double *, double *, int, hipStream_t, const TdsStepCtl &, int);
 template int tds_launch_quad<double, float>(const DevModel<double> *, const DevModel<double> &, const float *, float *,
-                                            const float *, float *, float *, int, hipStream_t, const TdsStepCtl &);
+                                            const float *, float *, float *, int, hipStream_t, const TdsStepCtl &, int);
 template int tds_launch_quad<float, float>(const DevModel<float> *, const DevModel<float> &, const float *, float *,
-                                           const float *, float *, float *, int, hipStream_t, const TdsStepCtl &);
+                                           const float *, float *, float *, int, hipStream_t, const TdsStepCtl &, int);
