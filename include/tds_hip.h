@@ -365,8 +365,9 @@ const char *tds_hip_option_name(int index);
    without contact points (pendulums, the cartpole), fixed-base kernels up to 16 dof with contacts (the Ant) while
    the batch is at most three rounds of workgroups; the star-shaped legged robots of tds_hip_single_step_kernel take their
    own kernels' step-loop forms: the 16-lane kernel (Laikago) while every workgroup of the launch is resident at once —
-   computed from the device's compute-unit count and LDS size, hipDeviceProp_t: up to 6144 environments on an MI355X —
-   and the chained graphs of its straight-line form beyond; the 8-lane kernel (the Ant) always.  No kernel boundaries; the state stays in
+   computed from the device's compute-unit count and LDS size, hipDeviceProp_t: in one-wavefront workgroups up to 6144
+   environments on an MI355X, in workgroups of eight wavefronts around one constant table (a workgroup per compute unit:
+   option quad_wide, default on) up to 8192 — and the chained graphs of its straight-line form beyond; the 8-lane kernel (the Ant) always.  No kernel boundaries; the state stays in
    LDS (in the compute scalar) for the n_steps steps, every step takes its own action block, y / obs / x are written
    once at the end — what the graph form leaves behind too, whose obs_dev is overwritten by every step.  With float
    records the state is rounded to float once per call instead of once per step.

@@ -86,8 +86,10 @@ others)
   SQ2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
   SQ3="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
   # name | steps of the launch the counters are read from (0: single-step launches, mean) | bench.py arguments
-  #   laikago_soft8192: config 4's default line (+-0.4 rad, auto-reset; single-step launches of tds_quad_kernel)
-  #   laikago_soft4096_loop: the 16-lane kernel's step-loop form, one 500-step launch (no reset, +-0.1 rad)
+  #   laikago_soft8192_loop: config 4 in the 16-lane kernel's step-loop form, wide workgroups (its default since r06e), one 500-step
+  #                          launch (no reset, +-0.1 rad)
+  #   laikago_soft8192_single: the single-step launches 8192 ran until r06d (option quad_wide = 0; +-0.4 rad, auto-reset)
+  #   laikago_soft4096_loop: the step-loop form in one-wavefront workgroups, one 500-step launch (no reset, +-0.1 rad)
   while read -r NAME K ARGS; do
     i=0
     for CTRS in FETCH_SIZE WRITE_SIZE "$SQ1" "$SQ2" "$SQ3"; do
@@ -100,7 +102,8 @@ others)
     echo "$NAME:"; grep -h -v '^# kernel' $P/${TAG}_${NAME}_pmc_traffic.txt | cut -c1-140
   done <<'CFGS'
 ant8192_f64 500 --envs-per-gpu 8192
-laikago_soft8192_f64 0 --model laikago_soft --envs-per-gpu 8192
+laikago_soft8192_f64_loop 500 --model laikago_soft --envs-per-gpu 8192 --no-auto-reset
+laikago_soft8192_f64_single 0 --model laikago_soft --envs-per-gpu 8192 --option quad_wide=0
 laikago_soft4096_f64_loop 500 --model laikago_soft --envs-per-gpu 4096 --no-auto-reset
 pendulum5_4096_f32rec 500 --model pendulum5 --dtype f32
 CFGS

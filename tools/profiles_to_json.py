@@ -44,7 +44,9 @@ sq["_comment"] = ("per launch of the dominant kernel, from separate rocprofv3 --
 CASES = [
     ("ant4096_f64_20", "ant", 4096, "f64", 20, "rings_short"), ("ant4096_f64_1000", "ant", 4096, "f64", 1000, "rings_long"),
     ("ant8192_f64", "ant", 8192, "f64", 500, "rings_both"),
-    ("laikago_soft8192_f64", "laikago_soft", 8192, "f64", 0, "single"),
+    ("laikago_soft8192_f64", "laikago_soft", 8192, "f64", 0, "single"),  # (tags up to r06d)
+    ("laikago_soft8192_f64_single", "laikago_soft", 8192, "f64", 0, "single"),
+    ("laikago_soft8192_f64_loop", "laikago_soft", 8192, "f64", 500, "rings_both"),
     ("laikago_soft4096_f64_loop", "laikago_soft", 4096, "f64", 500, "rings_both"),
     ("pendulum5_4096_f32rec", "pendulum5", 4096, "f32", 500, "rings_both"),
 ]
@@ -75,6 +77,7 @@ for stem, model, n, dt, K, slot in CASES:
 
 SQ_CASES = [("ant4096_f64_sq_counters_loop", "ant", 4096, "f64", 1000), ("ant8192_f64_sq_counters", "ant", 8192, "f64", 500),
             ("laikago_soft8192_f64_sq_counters", "laikago_soft", 8192, "f64", 0),
+            ("laikago_soft8192_f64_loop_sq_counters", "laikago_soft", 8192, "f64", 500),
             ("laikago_soft4096_f64_loop_sq_counters", "laikago_soft", 4096, "f64", 500),
             ("pendulum5_4096_f32rec_sq_counters", "pendulum5", 4096, "f32", 500)]
 for stem, model, n, dt, K in SQ_CASES:
