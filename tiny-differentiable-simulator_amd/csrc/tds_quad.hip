@@ -1328,11 +1328,13 @@ int tds_launch_quad(const DevModel<T> *d_model, const DevModel<T> &h_model, cons
   if (!one_step && wide) {  // wide step-loop launch: TDS_QUAD_WIDE_WAVES wavefronts per workgroup around one table
     constexpr int W = TDS_QUAD_WIDE_WAVES;
     const size_t bytes = (size_t)O.stride * 4 * W * sizeof(T) + sizeof(QuadTable<T>);
-    static bool attr_set = false;  // (per instantiation; the attribute is the same on every device)
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // (per instantiation and device: the attribute belongs to the device's copy of the function)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
       if (hipFuncSetAttribute((const void *)tds_quad_kernel<T, TR, true, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
         return (int)hipGetLastError();
-      attr_set = true;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((tds_quad_kernel<T, TR, true, W>), dim3((n_envs + 4 * W - 1) / (4 * W)), dim3(64 * W), bytes, stream, d_model,
                        x_in, y_out, actions, x_feedback, obs_out, ctl, n_envs, O);
