@@ -272,8 +272,9 @@ def test_single_step_auto_reset_in_environment_chains_equals_single_steps(built)
           f"(last call: {half[0]} / {half[1]} in the two halves)")
 
 
-@pytest.mark.parametrize("n,auto_reset", [(8192, False), (8192, True), (8161, True), (1000, False)])
-def test_quad_wide_workgroups_equal_one_wavefront_workgroups_bit_for_bit(n, auto_reset, built):
+@pytest.mark.parametrize("n,auto_reset,dtype", [(8192, False, "f64"), (8192, True, "f64"), (8161, True, "f64"), (1000, False, "f64"),
+                                                (8192, False, "mixed"), (8161, True, "mixed")])
+def test_quad_wide_workgroups_equal_one_wavefront_workgroups_bit_for_bit(n, auto_reset, dtype, built):
     """The step-loop form in WIDE workgroups (eight wavefronts around one constant table, a workgroup per compute unit: what
     keeps laikago_soft x 8192 — config 4 — resident; option quad_wide) against the same launch in one-wavefront workgroups
     (quad_wide = 0 + step_many_loop = 1): the same kernel body, so every ring slot, the state and the reset stream bit for bit
@@ -288,23 +289,24 @@ def test_quad_wide_workgroups_equal_one_wavefront_workgroups_bit_for_bit(n, auto
     if auto_reset:
         tilt = rng.permutation(n)[: n // 4]
         x[tilt, 3] = rng.uniform(1.0, 1.3, len(tilt))
-    a = hip_backend.HipSim(m, n, options={"quad_wide": 2})
-    b = hip_backend.HipSim(m, n, options={"quad_wide": 0, "step_many_loop": 1})
+    a = hip_backend.HipSim(m, n, dtype=dtype, options={"quad_wide": 2})
+    b = hip_backend.HipSim(m, n, dtype=dtype, options={"quad_wide": 0, "step_many_loop": 1})
+    tdt = a.torch_dtype  # (float records, double arithmetic under "mixed": the launch keeps the state in double)
     for s_ in (a, b):
-        s_.x.copy_(torch.from_numpy(x).cuda())
+        s_.x.copy_(torch.from_numpy(x).to(tdt).cuda())
         if auto_reset:
             s_.set_auto_reset(True, 11)
     assert a.step_many_is_loop(8) and b.step_many_is_loop(8)
     if n == 8192:  # the library's own choice at config 4's size
-        c = hip_backend.HipSim(m, n)
+        c = hip_backend.HipSim(m, n, dtype=dtype)
         assert c.step_many_is_loop(8) and not hip_backend.HipSim(m, n, options={"quad_wide": 0}).step_many_is_loop(8)
-    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (4, n, m.action_dim))).cuda().contiguous()
+    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (4, n, m.action_dim))).to(tdt).cuda().contiguous()
     done_steps, dones = 0, 0
     for steps in (6, 31, 1):
         rings = []
         for s_ in (a, b):
-            obs_ring = torch.full((7, n, a.obs_dim + 2), -7.0, dtype=torch.float64, device="cuda")
-            y_ring = torch.full((steps, n, m.output_dim), -7.0, dtype=torch.float64, device="cuda")
+            obs_ring = torch.full((7, n, a.obs_dim + 2), -7.0, dtype=tdt, device="cuda")
+            y_ring = torch.full((steps, n, m.output_dim), -7.0, dtype=tdt, device="cuda")
             s_.step_many_rings(actions, steps, obs_ring, y_ring, first_block=done_steps % 4, obs_first=3)
             rings.append((obs_ring, y_ring))
         torch.cuda.synchronize()
