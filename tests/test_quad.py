@@ -316,3 +316,33 @@ def test_quad_wide_workgroups_equal_one_wavefront_workgroups_bit_for_bit(n, auto
         dones += int((rings[0][0][:, :, -1] == 1.0).sum().item()) if done_steps == 0 else 0  # (the first call: 6 steps in 7 slots)
         done_steps += steps
     assert not auto_reset or dones >= n // 8, dones
+
+
+def test_quad_loop_form_selection_at_the_residency_boundaries(built):
+    """Which form tds_hip_step_many takes by batch size on an MI355X (256 compute units, 160 KB of LDS each): one-wavefront
+    workgroups up to 6144 environments, wide workgroups up to 8192, the chained graphs beyond — and three steps through each
+    side of both boundaries against single steps."""
+    torch = _torch()
+    name = "laikago_soft"
+    m = tds_amd.load_model(name)
+    rng = np.random.default_rng(31)
+    from test_rings import _start_state
+
+    props = torch.cuda.get_device_properties(0)
+    if props.multi_processor_count != 256:
+        pytest.skip(f"boundaries are those of 256 compute units, this device has {props.multi_processor_count}")
+    for n, loop in ((6145, True), (8192, True), (8193, False)):
+        a = hip_backend.HipSim(m, n)
+        b = hip_backend.HipSim(m, n, options={"step_many_loop": 0})
+        assert a.step_many_is_loop(3) == loop and not b.step_many_is_loop(3), n
+        x = _start_state(m, name, n, rng)
+        actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (3, n, m.action_dim))).cuda().contiguous()
+        obs = torch.zeros((n, a.obs_dim + 2), dtype=torch.float64, device="cuda")
+        for s_ in (a, b):
+            s_.x.copy_(torch.from_numpy(x).cuda())
+        y_ring = torch.zeros((3, n, m.output_dim), dtype=torch.float64, device="cuda")
+        a.step_many_rings(actions, 3, None, y_ring)
+        for k in range(3):
+            b.step(actions[k], 1, obs)
+            assert rel_err(y_ring[k].cpu().numpy(), b.y.cpu().numpy()) < 1e-9, (n, k)
+        assert rel_err(a.x.cpu().numpy(), b.x.cpu().numpy()) < 1e-9, n
