@@ -164,6 +164,7 @@ struct QuadTable {
   T vis_X[12][17];
   T dt, action_limit, base_t[3], grav[3], plane_n[3], plane_c, nb[3], t1[3], t2[3], cfm, erp_over_dt, restitution, friction, base_R8;
   int input_dim, action_dim, num_visuals, step_mode, reward_mode, pgs_iterations, pack_visuals, output_dim;
+  int vis_flags;  // bit 0: every visual sits at its link's origin (no offset), bit 1: the root body's visual is not rotated against it
 };
 // constant `tab` of the table in a step-loop launch, `glob` of the model otherwise
 #define QC(tab, glob) (LOOP ? (CT->tab) : (mdl->glob))
@@ -300,6 +301,12 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       CT->pgs_iterations = md->pgs_iterations;
       CT->pack_visuals = md->pack_visuals;
       CT->output_dim = md->output_dim;
+      // (what the visual poses can skip: Laikago's visuals have no offsets, its chassis visual no rotation)
+      bool no_off = true, root_id = true;
+      for (int k = 0; k < md->num_visuals && k < 17; ++k)
+        no_off = no_off && md->vis_X[9][k] == T(0) && md->vis_X[10][k] == T(0) && md->vis_X[11][k] == T(0);
+      for (int c = 0; c < 9; ++c) root_id = root_id && md->vis_X[c][0] == ((c & 3) == 0 ? T(1) : T(0));
+      CT->vis_flags = (no_off ? 1 : 0) | (root_id ? 2 : 0);
     }
     for (int i = t; i < 12 * 17; i += 64) {
       const int c = i / 17, k = i - 17 * c;
@@ -688,14 +695,26 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   const int nv = QC(num_visuals, num_visuals);
   if (valid && yo != nullptr && nv > 0) {
     QUAD_LAUNDER_MODEL(md3, mdl)  // (see the rigid inertia above: the visuals' constants are fetched where they are used)
-    auto pose_out = [&](const T *Rl, const T *pl, int k) {
-      T Rv[9], pv[3], Ro[9], po[3], qo[4];
+    // (step-loop launches: the table says which products are with zeros and ones — wave-uniform branches)
+    const int vflags = LOOP ? __builtin_amdgcn_readfirstlane(CT->vis_flags) : 0;
+    auto pose_out = [&](const T *Rl, const T *pl, int k, auto rootc) {
+      constexpr bool ROOT = decltype(rootc)::value;
+      T Ro[9], po[3] = {T(0), T(0), T(0)}, qo[4];
+      if (ROOT && (vflags & 2)) {
 #pragma unroll
-      for (int c = 0; c < 9; ++c) Rv[c] = LOOP ? CT->vis_X[c][k] : md3->vis_X[c][k];
+        for (int c = 0; c < 9; ++c) Ro[c] = Rl[c];
+      } else {
+        T Rv[9];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) pv[c] = LOOP ? CT->vis_X[9 + c][k] : md3->vis_X[9 + c][k];
-      mat3_mul(Rl, Rv, Ro);
-      mat3_mulv(Rl, pv, po);
+        for (int c = 0; c < 9; ++c) Rv[c] = LOOP ? CT->vis_X[c][k] : md3->vis_X[c][k];
+        mat3_mul(Rl, Rv, Ro);
+      }
+      if (!(vflags & 1)) {
+        T pv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pv[c] = LOOP ? CT->vis_X[9 + c][k] : md3->vis_X[9 + c][k];
+        mat3_mulv(Rl, pv, po);
+      }
       matrix_to_quat(Ro, qo);
       TR *o = yo + (nq + nd) + 7 * k;
       o[0] = (TR)(pl[0] + po[0]);
@@ -716,8 +735,8 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
         o2[6] = (TR)qo[3];
       }
     };
-    pose_out(R, p, 1 + lane);
-    if (lane == 15) pose_out(R5, P, 0);
+    pose_out(R, p, 1 + lane, std::false_type{});
+    if (lane == 15) pose_out(R5, P, 0, std::true_type{});
   }
 
   T Ic[10], fc[6];
@@ -1104,37 +1123,63 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     T u = T(0), ur[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     const int iters = LOOP ? CT->pgs_iterations : md5->pgs_iterations;
     const T my_leg = (T)leg;
+    // The reference's row order: normals, tangents 1, tangents 2, each by contact (rows live at 3 a + t).  A row's operands —
+    // its z~ (my leg entry, six root entries), b, 1 / (G + cfm), G — are requested from LDS ONE ROW AHEAD, at the top of the
+    // row before; the normal impulses the friction bounds depend on stay in registers (contact slots unrolled: four toes), and
+    // with one PGS iteration (every shipped model) nothing of the sweep is written back to LDS: as a loop of read -> wait ->
+    // compute -> write -> fence a row was three LDS round trips a lone wavefront sat out — 36 of them for four toes on the ground
+    struct RowOps {
+      T zl, zr[6], b, a, g;
+    };
+    auto load_row = [&](int tk, int ak) {
+      const int r = 3 * ak + tk;
+      RowOps o;
+      o.zl = (dofl && rws[3 * 12 + r] == my_leg) ? Zs[r * QuadLds::ZW + pos] : T(0);
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) o.zr[rr] = Zs[r * QuadLds::ZW + 3 + rr];
+      o.b = rws[0 * 12 + r];
+      o.a = rws[1 * 12 + r];
+      o.g = rws[2 * 12 + r];
+      return o;
+    };
+    T xnn[4] = {T(0), T(0), T(0), T(0)};  // the normal rows' impulses of this sweep, by contact slot
     for (int it = 0; it < iters; ++it) {
-      // the reference's row order: normals, tangents 1, tangents 2, each by contact (rows live at 3 a + t)
-      for (int rr_ = 0; rr_ < nr; ++rr_) {
-        const int tk = (rr_ >= NA ? 1 : 0) + (rr_ >= 2 * NA ? 1 : 0);
-        const int ak = rr_ - tk * NA;
-        const int r = 3 * ak + tk;
+      RowOps nxt = load_row(0, 0);
+      for (int tk = 0; tk < 3; ++tk) {
         const bool is_n = tk == 0;
-        const int dep = 3 * ak;
-        const T zl = (dofl && rws[3 * 12 + r] == my_leg) ? Zs[r * QuadLds::ZW + pos] : T(0);
-        T zrr[6];
+        static_for<0, 4>([&](auto akc) {
+          constexpr int ak = decltype(akc)::value;
+          if (ak < NA) {  // (wave-uniform)
+            const RowOps cur = nxt;
+            {  // the row after this one: (tk, ak + 1), else (tk + 1, 0); behind the last row: the first again (unused)
+              const bool wrap = ak + 1 >= NA;
+              const int tkn = wrap ? (tk < 2 ? tk + 1 : 0) : tk;
+              nxt = load_row(tkn, wrap ? 0 : ak + 1);
+            }
+            const int r = 3 * ak + tk;
+            const T x_old = it > 0 ? xs[r] : T(0);
+            const T sdep = is_n ? T(0) : xnn[ak];
+            T jw = group_sum<T, 16>(cur.zl * u);
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) zrr[rr] = Zs[r * QuadLds::ZW + 3 + rr];
-        const T br = rws[0 * 12 + r], ar = rws[1 * 12 + r], gr = rws[2 * 12 + r];
-        const T x_old = it > 0 ? xs[r] : T(0);
-        const T sdep = is_n ? T(0) : xs[dep];
-        T jw = group_sum<T, 16>(zl * u);
+            for (int rr = 0; rr < 6; ++rr) jw += cur.zr[rr] * ur[rr];
+            const T delta = jw - cur.g * x_old;
+            T xn = (cur.b - delta) * cur.a;
+            const T sc = sdep < T(0) ? T(0) : sdep;  // where_lt(s, 0, 0, s)
+            const T lo = is_n ? T(0) : -mu * sc;
+            const T hi = is_n ? T(100000) : mu * sc;
+            xn = max_t<T>(xn, lo);
+            xn = min_t<T>(xn, hi);
+            const T dx = xn - x_old;
+            u += cur.zl * dx;
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) jw += zrr[rr] * ur[rr];
-        const T delta = jw - gr * x_old;
-        T xn = (br - delta) * ar;
-        const T sc = sdep < T(0) ? T(0) : sdep;  // where_lt(s, 0, 0, s)
-        const T lo = is_n ? T(0) : -mu * sc;
-        const T hi = is_n ? T(100000) : mu * sc;
-        xn = max_t<T>(xn, lo);
-        xn = min_t<T>(xn, hi);
-        const T dx = xn - x_old;
-        u += zl * dx;
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) ur[rr] += zrr[rr] * dx;
-        xs[r] = xn;
-        QUAD_SYNC();
+            for (int rr = 0; rr < 6; ++rr) ur[rr] += cur.zr[rr] * dx;
+            xnn[ak] = is_n ? xn : xnn[ak];
+            if (iters > 1) {  // (wave-uniform: only a further sweep reads the impulses back)
+              xs[r] = xn;
+              QUAD_SYNC();
+            }
+          }
+        });
       }
     }
     // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
@@ -1196,12 +1241,20 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   QUAD_STAMP(13, tid);
   // ---- y record: q | qd | (visual poses: M1) | up.z | zero padding
   if (valid && yo != nullptr) {
+    // (every LDS / table read of the record in front of its first store: as a loop of read -> wait -> store the 36 state
+    //  values were three LDS round trips, the two constants two more — a lone wavefront sits them out one after the other)
+    static_assert(nq + nd == 36, "three values per lane: lanes 0..15 | 16..31 | 32..35");
+    const T s0 = xr[lane], s1 = xr[16 + lane], s2 = xr[32 + (lane & 3)];
+    const bool packs = QC(pack_visuals, pack_visuals) != 0;
+    const T upz = QC(base_R8, base_R[8]);  // up_dot_world_z (fixed base)
     auto y_state = [&](TR *y, int end) {
-      for (int i = lane; i < nq + nd; i += 16) y[i] = (TR)xr[i];
+      y[lane] = (TR)s0;
+      y[16 + lane] = (TR)s1;
+      if (lane < 4) y[32 + lane] = (TR)s2;
       int tail = nq + nd;
-      if (QC(pack_visuals, pack_visuals)) {
+      if (packs) {
         tail += 7 * nv;
-        if (lane == 0) y[tail] = (TR)(QC(base_R8, base_R[8]));  // up_dot_world_z (fixed base)
+        if (lane == 0) y[tail] = (TR)upz;
         tail += 1;
       }
       for (int i = tail + lane; i < end; i += 16) y[i] = TR(0);
@@ -1212,9 +1265,12 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   QUAD_STAMP(14, tid);
   // ---- N. reward / done (laikago_environment2.h:130-171; ant_environment2.h:75-106)
   {
+    // (Laikago's up . z: the reference goes rpy -> quaternion -> matrix entry (2, 2) = 1 - 2 (qx^2 + qy^2) / |q|^2, which IS
+    //  cos(roll) cos(pitch) — two cosines and a product instead of three half-angle sincos and the quaternion's 30 products;
+    //  to rounding the same number, and `done` compares it with 0.6)
     T rs = T(0), rc = T(1);
-    quad_sincos(lane < 3 ? xr[3 + lane] * T(0.5) : T(0), &rs, &rc);
-    const T s1 = dpp_bcast<1>(rs), c1 = dpp_bcast<1>(rc), s2 = dpp_bcast<2>(rs), c2 = dpp_bcast<2>(rc);
+    quad_sincos(lane < 2 ? xr[3 + lane] : T(0), &rs, &rc);
+    const T c1 = dpp_bcast<1>(rc);
     if (lane == 0) {
       bool done = false;
       T reward = T(0);
@@ -1224,13 +1280,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
         done = xr[2] < T(0.26);
         reward = done ? T(0) : vel_x;
       } else if (rm == TDS_REWARD_LAIKAGO) {
-        const T sp = rs, cp = rc, st = s1, ct = c1, ss = s2, cs2 = c2;
-        const T qx = sp * ct * cs2 - cp * st * ss;
-        const T qy = cp * st * cs2 + sp * ct * ss;
-        const T qz = cp * ct * ss - sp * st * cs2;
-        const T qw = cp * ct * cs2 + sp * st * ss;
-        const T sq = T(4) - T(2) * (qx * qx + qy * qy + qz * qz + qw * qw);  // 2 / |q|^2, |q|^2 = 1 to rounding
-        const T up = T(1) - (qx * (qx * sq) + qy * (qy * sq));
+        const T up = rc * c1;
         done = (up < T(0.6)) || (xr[2] < T(0.2));
         reward = done ? T(0) : xr[0];
       }
@@ -1262,23 +1312,37 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   //      (every step of a step-loop launch; floats on the multi-GPU wire format) and / or the caller's record (last step)
   if (valid) {
     const int w = nq + nd + 2;
+    // (the record's LDS reads in front of its stores, as in the y record: lanes 0..15 | 16..31 | 32..35 state, lane 4 / 5 of
+    //  the third group reward / done)
+    const T o0 = xr[lane], o1 = xr[16 + lane];
+    const T o2 = xr[lane < 4 ? 32 + lane : (lane == 4 ? in_dim + 2 : in_dim + 1)];
     if (LOOP && ctl.obs_ring != nullptr) {
       const size_t at = ((size_t)((ctl.obs_first + it) % ctl.obs_slots) * ctl.obs_envs + env) * w;
-      for (int i = lane; i < w; i += 16) {
-        const T vv = i < 2 ? T(0) : xr[i < nq + nd ? i : (i == nq + nd ? in_dim + 2 : in_dim + 1)];
-        if (ctl.ring_flags & TDS_RING_OBS_F32) ((float *)ctl.obs_ring)[at + i] = (float)vv;
-        else ((TR *)ctl.obs_ring)[at + i] = (TR)vv;
+      const T z0 = lane < 2 ? T(0) : o0;
+      if (ctl.ring_flags & TDS_RING_OBS_F32) {
+        float *const o = (float *)ctl.obs_ring + at;
+        o[lane] = (float)z0;
+        o[16 + lane] = (float)o1;
+        if (lane < 6) o[32 + lane] = (float)o2;
+      } else {
+        TR *const o = (TR *)ctl.obs_ring + at;
+        o[lane] = (TR)z0;
+        o[16 + lane] = (TR)o1;
+        if (lane < 6) o[32 + lane] = (TR)o2;
       }
     }
     if (last) {
-      for (int i = lane; i < nq + nd; i += 16) {
-        const TR vv = (TR)xr[i];
-        if (obs_out != nullptr) obs_out[(size_t)env * w + i] = i < 2 ? TR(0) : vv;
-        if (x_feedback != nullptr) x_feedback[(size_t)env * in_dim + i] = vv;
+      if (obs_out != nullptr) {
+        TR *const o = obs_out + (size_t)env * w;
+        o[lane] = lane < 2 ? TR(0) : (TR)o0;
+        o[16 + lane] = (TR)o1;
+        if (lane < 6) o[32 + lane] = (TR)o2;
       }
-      if (lane == 0 && obs_out != nullptr) {
-        obs_out[(size_t)env * w + nq + nd] = (TR)xr[in_dim + 2];
-        obs_out[(size_t)env * w + nq + nd + 1] = (TR)xr[in_dim + 1];
+      if (x_feedback != nullptr) {
+        TR *const f = x_feedback + (size_t)env * in_dim;
+        f[lane] = (TR)o0;
+        f[16 + lane] = (TR)o1;
+        if (lane < 4) f[32 + lane] = (TR)o2;
       }
     }
   }
