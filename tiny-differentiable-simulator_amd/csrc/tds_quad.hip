@@ -1134,13 +1134,9 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     auto load_row = [&](int tk, int ak) {
       const int r = 3 * ak + tk;
       RowOps o;
-      // (both reads issued unconditionally — a read that waits for the row's leg is a second LDS round trip per row; a toe
-      //  lane's `pos` picks the row's first root entry: a valid address, the value is dropped)
-      T legv = rws[3 * 12 + r], zv = Zs[r * QuadLds::ZW + pos];
+      o.zl = (dofl && rws[3 * 12 + r] == my_leg) ? Zs[r * QuadLds::ZW + pos] : T(0);
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) o.zr[rr] = Zs[r * QuadLds::ZW + 3 + rr];
-      asm volatile("" : "+v"(legv), "+v"(zv));  // (or the compiler sinks the second read under the comparison of the first again)
-      o.zl = (dofl && legv == my_leg) ? zv : T(0);
       o.b = rws[0 * 12 + r];
       o.a = rws[1 * 12 + r];
       o.g = rws[2 * 12 + r];
