@@ -1131,10 +1131,13 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     struct RowOps {
       T zl, zr[6], b, a, g;
     };
+    const T my_leg_or_none = dofl ? my_leg : T(-1);  // (a toe lane matches no row's leg)
     auto load_row = [&](int tk, int ak) {
       const int r = 3 * ak + tk;
       RowOps o;
-      o.zl = (dofl && rws[3 * 12 + r] == my_leg) ? Zs[r * QuadLds::ZW + pos] : T(0);
+      // (my leg entry times a 0 / 1 mask, not a select: a select lets the compiler sink the read of the entry under the comparison
+      //  of the row's leg — a second LDS round trip per row; a toe lane's `pos` picks the row's first root entry, masked out)
+      o.zl = Zs[r * QuadLds::ZW + pos] * (rws[3 * 12 + r] == my_leg_or_none ? T(1) : T(0));
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) o.zr[rr] = Zs[r * QuadLds::ZW + 3 + rr];
       o.b = rws[0 * 12 + r];
@@ -1143,7 +1146,9 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
       return o;
     };
     T xnn[4] = {T(0), T(0), T(0), T(0)};  // the normal rows' impulses of this sweep, by contact slot
-    for (int it = 0; it < iters; ++it) {
+    // one sweep; SINGLE: the only one (x starts from 0, nothing is written back — every shipped model), else sweep `it` of several
+    auto sweep = [&](int it, auto singlec) {
+      constexpr bool SINGLE = decltype(singlec)::value;
       RowOps nxt = load_row(0, 0);
       for (int tk = 0; tk < 3; ++tk) {
         const bool is_n = tk == 0;
@@ -1157,30 +1162,38 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
               nxt = load_row(tkn, wrap ? 0 : ak + 1);
             }
             const int r = 3 * ak + tk;
-            const T x_old = it > 0 ? xs[r] : T(0);
+            T x_old = T(0);
+            if constexpr (!SINGLE) x_old = it > 0 ? xs[r] : T(0);
             const T sdep = is_n ? T(0) : xnn[ak];
             T jw = group_sum<T, 16>(cur.zl * u);
 #pragma unroll
             for (int rr = 0; rr < 6; ++rr) jw += cur.zr[rr] * ur[rr];
-            const T delta = jw - cur.g * x_old;
-            T xn = (cur.b - delta) * cur.a;
+            T xn;
+            if constexpr (SINGLE) xn = (cur.b - jw) * cur.a;
+            else xn = (cur.b - (jw - cur.g * x_old)) * cur.a;
             const T sc = sdep < T(0) ? T(0) : sdep;  // where_lt(s, 0, 0, s)
             const T lo = is_n ? T(0) : -mu * sc;
             const T hi = is_n ? T(100000) : mu * sc;
             xn = max_t<T>(xn, lo);
             xn = min_t<T>(xn, hi);
-            const T dx = xn - x_old;
+            T dx = xn;
+            if constexpr (!SINGLE) dx = xn - x_old;
             u += cur.zl * dx;
 #pragma unroll
             for (int rr = 0; rr < 6; ++rr) ur[rr] += cur.zr[rr] * dx;
             xnn[ak] = is_n ? xn : xnn[ak];
-            if (iters > 1) {  // (wave-uniform: only a further sweep reads the impulses back)
+            if constexpr (!SINGLE) {  // (a further sweep reads the impulses back)
               xs[r] = xn;
               QUAD_SYNC();
             }
           }
         });
       }
+    };
+    if (iters == 1) {
+      sweep(0, std::true_type{});
+    } else {
+      for (int it = 0; it < iters; ++it) sweep(it, std::false_type{});
     }
     // delta_qd = M^-1 J^T p = L^-T D^-1/2 u~   (mb_constraint_solver.hpp:476-496: qd_b -= delta_qd)
     {
