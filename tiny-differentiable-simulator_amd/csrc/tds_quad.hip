@@ -315,6 +315,24 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     QUAD_SYNC();
   }
   const int nsteps = LOOP ? ctl_arg.nsub : 1;
+  // ring positions of a step-loop launch, carried as scalars from step to step: the action block the NEXT step takes, the y and
+  // the obs slot of THIS step — computed per step they were three integer divisions (~25 instructions each) behind three
+  // scalar-load round trips
+  int pos_act = 0, pos_y = 0, pos_obs = 0, n_act = 1, n_y = 1, n_obs = 1;
+  if constexpr (LOOP) {
+    if (ctl_arg.act_pool != nullptr) {
+      n_act = ctl_arg.act_blocks;
+      pos_act = (ctl_arg.act_first + 1) % n_act;
+    }
+    if (ctl_arg.y_ring != nullptr) {
+      n_y = ctl_arg.y_slots;
+      pos_y = ctl_arg.y_first % n_y;
+    }
+    if (ctl_arg.obs_ring != nullptr) {
+      n_obs = ctl_arg.obs_slots;
+      pos_obs = ctl_arg.obs_first % n_obs;
+    }
+  }
   T next_act = T(0);  // (step-loop form: the action block of the NEXT step, requested a step ahead)
   for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
   // (nothing but `it` lives across an iteration: lane, model pointer and kernel-argument segment are laundered)
@@ -348,7 +366,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     // next step's — block (act_first + it + 1) % act_blocks of the pool — is requested now: no step waits for HBM
     if (ctl.act_pool != nullptr) {  // wave-uniform
       if (it + 1 < nsteps && valid && lane < adim) {
-        const int blk = (ctl.act_first + it + 1) % ctl.act_blocks;
+        const int blk = pos_act;
         next_act = (T)((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
       }
     }
@@ -686,7 +704,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
   TR *yo = nullptr, *yo2 = nullptr;
   int yend = ystr, yend2 = out_dim;
   if (LOOP && ctl.y_ring != nullptr) {
-    yo = (TR *)ctl.y_ring + ((size_t)((ctl.y_first + it) % ctl.y_slots) * ctl.ring_envs + env) * ystr;
+    yo = (TR *)ctl.y_ring + ((size_t)pos_y * ctl.ring_envs + env) * ystr;
     if (last && y_out != nullptr) yo2 = y_out + (size_t)env * out_dim;
   } else if (last && y_out != nullptr) {
     yo = y_out + (size_t)env * (LOOP ? out_dim : ystr);
@@ -1330,7 +1348,7 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     const T o0 = xr[lane], o1 = xr[16 + lane];
     const T o2 = xr[lane < 4 ? 32 + lane : (lane == 4 ? in_dim + 2 : in_dim + 1)];
     if (LOOP && ctl.obs_ring != nullptr) {
-      const size_t at = ((size_t)((ctl.obs_first + it) % ctl.obs_slots) * ctl.obs_envs + env) * w;
+      const size_t at = ((size_t)pos_obs * ctl.obs_envs + env) * w;
       const T z0 = lane < 2 ? T(0) : o0;
       if (ctl.ring_flags & TDS_RING_OBS_F32) {
         float *const o = (float *)ctl.obs_ring + at;
@@ -1367,7 +1385,12 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     tds_quad_prof_buf[18] = (unsigned long long)NA;
   }
 #endif
-  if constexpr (LOOP) QUAD_SYNC();
+  if constexpr (LOOP) {
+    QUAD_SYNC();
+    pos_act = pos_act + 1 == n_act ? 0 : pos_act + 1;
+    pos_y = pos_y + 1 == n_y ? 0 : pos_y + 1;
+    pos_obs = pos_obs + 1 == n_obs ? 0 : pos_obs + 1;
+  }
   }  // ================================ end of the step loop ================================
 }
 
