@@ -1239,6 +1239,8 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
   };
   auto windows = [&]() -> int { return NA > 0 ? pgs_iters * ((3 * NA + 7) >> 3) : 0; };
 
+  // (the step's done flag on every lane of the environment, for main_pool: under the Ant's rule it never passes through LDS)
+  bool done_reg = false, done_in_reg = false;
   auto main_fin = [&]() {
     // ================================ main: impulse, integration, reward ================================
     OCT_MARK("main_fin");
@@ -1268,6 +1270,10 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     }
     OCT_MARK("main_integrate");
     // ---- M. integrate_euler: q += qd dt (integrator.hpp:126-131); the new state into the LDS record
+    T qn0, qn2, qo0;  // the new base x, z and the old base x: every lane has them — the Ant's reward reads no LDS
+    // (the reward rule's two constants requested here: behind the barrier below they were a round trip of their own)
+    const int rm = (int)CT[TB::SC + TB::REWARD_MODE];
+    const T inv_dt = CT[TB::SC + TB::INV_DT];
     OCT_SYNC();
     {
       // root coordinates: every lane holds the six velocities; lane 0 stores them and the integrated coordinates
@@ -1275,6 +1281,9 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #pragma unroll
       for (int r = 0; r < 6; ++r) qn_root[r] = xr[r] + qdr_new[r] * dt;
       const T q_old0 = xr[0];
+      qn0 = qn_root[0];
+      qn2 = qn_root[2];
+      qo0 = q_old0;
       OCT_SYNC();
       if (lane == 0) {
 #pragma unroll
@@ -1299,19 +1308,23 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     OCT_SYNC();
     OCT_MARK("main_reward");
     // ---- N. reward / done (ant_environment2.h:75-106; laikago_environment2.h:130-171)
-    {
-      const int rm = (int)CT[TB::SC + TB::REWARD_MODE];
+    done_in_reg = rm == TDS_REWARD_ANT;
+    if (rm == TDS_REWARD_ANT) {  // (wave-uniform) from registers, redundantly on every lane: (x_t - x_{t-1}) / dt, done: z < 0.26
+      const T vel_x = (qn0 - qo0) * inv_dt;
+      done_reg = qn2 < T(0.26);
+      const T reward = done_reg ? T(0) : vel_x;
+      if (lane == 0) {
+        xr[in_dim + 1] = done_reg ? T(1) : T(0);
+        xr[in_dim + 2] = reward;
+      }
+    } else {
       T rs = T(0), rc = T(1);
       if (rm == TDS_REWARD_LAIKAGO) sincos_t<T>(lane < 3 ? xr[3 + lane] * T(0.5) : T(0), &rs, &rc);  // (wave-uniform branch)
       const T s1 = oct_bcast<1>(rs), c1 = oct_bcast<1>(rc), s2 = oct_bcast<2>(rs), c2 = oct_bcast<2>(rc);
       if (lane == 0) {
         bool done = false;
         T reward = T(0);
-        if (rm == TDS_REWARD_ANT) {
-          const T vel_x = (xr[0] - xr[in_dim]) * CT[TB::SC + TB::INV_DT];
-          done = xr[2] < T(0.26);
-          reward = done ? T(0) : vel_x;
-        } else if (rm == TDS_REWARD_LAIKAGO) {
+        if (rm == TDS_REWARD_LAIKAGO) {
           const T sp = rs, cp = rc, st = s1, ct = c1, ss = s2, cs2 = c2;
           const T qx = sp * ct * cs2 - cp * st * ss;
           const T qy = cp * st * cs2 + sp * ct * ss;
@@ -1344,7 +1357,7 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
     // ---- auto_reset_when_done through the reset pool (ctl.pool; ars_vectorized_environment.h:262-277): a done environment
     //      takes its next pre-settled state — y, reward and done describe the terminal step, the observation and the state
     //      the fresh environment: its y state goes out HERE, before the record is overwritten
-    if (ctl.pool != nullptr && valid && xr[in_dim + 1] != T(0)) {
+    if (ctl.pool != nullptr && valid && (done_in_reg ? done_reg : xr[in_dim + 1] != T(0))) {
       if (yo != nullptr) {
         y_state(yo, yend);
         if (yo2 != nullptr) y_state(yo2, yend2);
