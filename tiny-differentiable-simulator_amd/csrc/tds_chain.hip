@@ -183,6 +183,26 @@ __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel
   const bool pack_vis = CT[TB::SC + TB::PACK_VISUALS] != T(0);
   const bool xt_ident = CT[TB::SC + TB::XT_IDENT] != T(0);
   const bool vis_ident = CT[TB::SC + TB::VIS_IDENT] != T(0);
+  // My link's constants IN REGISTERS for the whole launch (46 scalars: the kernel holds 140 registers without them, a SIMD has
+  // room for 256 at the two wavefronts it ever sees of this kernel).  Read from the LDS table where a step uses them — the big
+  // kernels' rule, they have no register to spare — they were seven groups of reads, each waited for at once: seven LDS round
+  // trips on the main wavefront's path, ~1 k of a step's 8.8 k cycles
+  T cS[6], cXT[12], cCOM[3], cINER[9], cNAX[3], cNN[6], cGRAV[3];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cS[k] = CL[TB::S + k];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) cXT[k] = CL[TB::XT + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cCOM[k] = CL[TB::COM + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) cINER[k] = CL[TB::INER + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cNAX[k] = CL[TB::NAX + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cNN[k] = CL[TB::NN + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cGRAV[k] = CT[TB::SC + TB::GRAV + k];
+  const T cMASS = CL[TB::MASS], cSTIFF = CL[TB::STIFF], cDAMP = CL[TB::DAMP], cROTF = CL[TB::ROTF];
   const int nsteps = LOOP ? ctl_arg.nsub : 1;
   T next_act = T(0);
   int act_blk = 0, y_slot = 0, o_slot = 0;
@@ -285,41 +305,41 @@ __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel
     // ---- A. my joint: coordinate, velocity, torque (multi_body.hpp:557-570; joint stiffness / damping, forward_dynamics.hpp:122-123)
     const T q = mine ? xr[me] : T(0), qd = mine ? xr[nq + me] : T(0);
     T tau = mine ? xr[nq + nd + me] : T(0);
-    tau -= CL[TB::STIFF] * q + CL[TB::DAMP] * qd;
+    tau -= cSTIFF * q + cDAMP * qd;
     // ---- B. jcalc (link.hpp:229-287): R_J = cos I + sin [n]x + (1 - cos) n n^T about the unit axis (every revolute type; a
     //         prismatic joint's angle is multiplied by 0), t_J = S_linear q; X_parent = X_T X_J
     T S[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) S[k] = CL[TB::S + k];
+    for (int k = 0; k < 6; ++k) S[k] = cS[k];
     {
       T sn, cs;
-      ch_sincos(q * CL[TB::ROTF], &sn, &cs);
+      ch_sincos(q * cROTF, &sn, &cs);
       const T c1 = T(1) - cs;
-      const T nx = CL[TB::NAX], ny = CL[TB::NAX + 1], nz = CL[TB::NAX + 2];
+      const T nx = cNAX[0], ny = cNAX[1], nz = cNAX[2];
       T RJ[9];
-      RJ[0] = cs + c1 * CL[TB::NN + 0];
-      RJ[1] = c1 * CL[TB::NN + 1] - sn * nz;
-      RJ[2] = c1 * CL[TB::NN + 2] + sn * ny;
-      RJ[3] = c1 * CL[TB::NN + 1] + sn * nz;
-      RJ[4] = cs + c1 * CL[TB::NN + 3];
-      RJ[5] = c1 * CL[TB::NN + 4] - sn * nx;
-      RJ[6] = c1 * CL[TB::NN + 2] - sn * ny;
-      RJ[7] = c1 * CL[TB::NN + 4] + sn * nx;
-      RJ[8] = cs + c1 * CL[TB::NN + 5];
+      RJ[0] = cs + c1 * cNN[0];
+      RJ[1] = c1 * cNN[1] - sn * nz;
+      RJ[2] = c1 * cNN[2] + sn * ny;
+      RJ[3] = c1 * cNN[1] + sn * nz;
+      RJ[4] = cs + c1 * cNN[3];
+      RJ[5] = c1 * cNN[4] - sn * nx;
+      RJ[6] = c1 * cNN[2] - sn * ny;
+      RJ[7] = c1 * cNN[4] + sn * nx;
+      RJ[8] = cs + c1 * cNN[5];
       const T tJ[3] = {S[3] * q, S[4] * q, S[5] * q};
       if (xt_ident) {  // wave-uniform
 #pragma unroll
         for (int k = 0; k < 9; ++k) R[k] = RJ[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = CL[TB::XT + 9 + k] + tJ[k];
+        for (int k = 0; k < 3; ++k) p[k] = cXT[9 + k] + tJ[k];
       } else {
         T RT[9], r[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) RT[k] = CL[TB::XT + k];
+        for (int k = 0; k < 9; ++k) RT[k] = cXT[k];
         mat3_mul(RT, RJ, R);
         mat3_mulv(RT, tJ, r);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = CL[TB::XT + 9 + k] + r[k];
+        for (int k = 0; k < 3; ++k) p[k] = cXT[9 + k] + r[k];
       }
     }
     // ---- C. forward kinematics (kinematics.hpp:64-97): X_world_i = X_world_(i-1) X_parent_i as an inclusive scan of transform
@@ -392,18 +412,18 @@ __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel
       }
     });
 #pragma unroll
-    for (int k = 0; k < 3; ++k) a0[3 + k] -= CT[TB::SC + TB::GRAV + k];
+    for (int k = 0; k < 3; ++k) a0[3 + k] -= cGRAV[k];
     // ---- E. world-frame rigid inertia and bias force of my link (kinematics.hpp:99-132, inertia.hpp:121-130):
     //         I = (Isym 6 | h 3 | m), f = I a0 + v x* I v
     T Ic[10], fc[6];
     {
-      const T m = CL[TB::MASS];
+      const T m = cMASS;
       T cw[3];
-      mat3_mulv(R, CL + TB::COM, cw);
+      mat3_mulv(R, cCOM, cw);
 #pragma unroll
       for (int k = 0; k < 3; ++k) cw[k] += p[k];
       T RI[9], Iw[9];
-      mat3_mul(R, CL + TB::INER, RI);
+      mat3_mul(R, cINER, RI);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
