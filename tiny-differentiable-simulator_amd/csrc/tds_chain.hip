@@ -204,6 +204,10 @@ __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel
   for (int k = 0; k < 3; ++k) cGRAV[k] = CT[TB::SC + TB::GRAV + k];
   const T cMASS = CL[TB::MASS], cSTIFF = CL[TB::STIFF], cDAMP = CL[TB::DAMP], cROTF = CL[TB::ROTF];
   const int nsteps = LOOP ? ctl_arg.nsub : 1;
+  // my joint's coordinate, velocity and torque IN REGISTERS across the steps of a launch (the lane that integrates them is the
+  // lane that reads them: the LDS record is written for the recorder, the main wavefront never reads it back — one LDS round
+  // trip less at the head of every step)
+  T q_c = mine ? xr[mine ? link : 0] : T(0), qd_c = mine ? xr[nq + (mine ? link : 0)] : T(0), tau_c = mine ? xr[nq + nd + (mine ? link : 0)] : T(0);
   T next_act = T(0);
   int act_blk = 0, y_slot = 0, o_slot = 0;
   if constexpr (LOOP) {
@@ -303,8 +307,8 @@ __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel
     };
     if (is_main) {  // ================================ main wavefront: the step ================================
     // ---- A. my joint: coordinate, velocity, torque (multi_body.hpp:557-570; joint stiffness / damping, forward_dynamics.hpp:122-123)
-    const T q = mine ? xr[me] : T(0), qd = mine ? xr[nq + me] : T(0);
-    T tau = mine ? xr[nq + nd + me] : T(0);
+    const T q = q_c, qd = qd_c;
+    T tau = tau_c;
     tau -= cSTIFF * q + cDAMP * qd;
     // ---- B. jcalc (link.hpp:229-287): R_J = cos I + sin [n]x + (1 - cos) n n^T about the unit axis (every revolute type; a
     //         prismatic joint's angle is multiplied by 0), t_J = S_linear q; X_parent = X_T X_J
@@ -566,8 +570,13 @@ __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel
       if (mine) {
         xr[me] = q_new;
         xr[nq + me] = qd_new;
+        q_c = q_new;
+        qd_c = qd_new;
         if constexpr (LOOP) {
-          if (ctl.act_pool != nullptr && !last) xr[nq + nd + me] = next_act;
+          if (ctl.act_pool != nullptr && !last) {
+            xr[nq + nd + me] = next_act;
+            tau_c = next_act;
+          }
         }
       }
     }
