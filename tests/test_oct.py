@@ -267,3 +267,43 @@ def test_oct_step_loop_with_auto_reset_equals_single_steps(built):
         assert rel_err(y_ring[k].cpu().numpy(), b.y.cpu().numpy()) < 1e-9, k
     assert dones >= n // 3
     assert rel_err(a.x.cpu().numpy(), b.x.cpu().numpy()) < 1e-9
+
+
+@pytest.mark.gpu
+def test_oct_refill_passes_beside_the_chunks_equal_the_passes_behind_them(built):
+    """The reset pool's refill passes of a handle whose chunks run one wavefront per SIMD use the 240-register build of the
+    8-lane kernel (it fits on a SIMD beside a chunk's wavefront and is issued next to the chunk: option pool_beside, default
+    on) — against the same run with the build the grid size selects (pool_beside = 0): four calls of 160 steps in chunks of
+    32 with a third of the environments starting below the termination height, i.e. several passes per call and every pool
+    entry consumed more than once.  Bit for bit: the kernel's builds round alike (csrc/Makefile: OCTFLAGS)."""
+    torch = _torch()
+    name = "ant"
+    m = tds_amd.load_model(name)
+    n, steps = 1024, 160
+    rng = np.random.default_rng(12)
+    from test_rings import _start_state
+
+    x = _start_state(m, name, n, rng)
+    x[: n // 3, 2] = rng.uniform(0.2, 0.27, n // 3)
+    a = hip_backend.HipSim(m, n, options={"pool_chunk": 32})
+    b = hip_backend.HipSim(m, n, options={"pool_chunk": 32, "pool_beside": 0})
+    assert a.get_option("pool_beside") is None and b.get_option("pool_beside") == 0
+    for s_ in (a, b):
+        s_.x.copy_(torch.from_numpy(x).cuda())
+        s_.set_auto_reset(True, 5)
+    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (4, n, m.action_dim))).cuda().contiguous()
+    rings = []
+    for s_ in (a, b):
+        obs_ring = torch.zeros((steps, n, s_.obs_dim + 2), dtype=torch.float64, device="cuda")
+        y_ring = torch.zeros((steps, n, m.output_dim), dtype=torch.float64, device="cuda")
+        rings.append((obs_ring, y_ring))
+    dones = 0
+    for call in range(4):
+        for s_, (obs_ring, y_ring) in zip((a, b), rings):
+            s_.step_many_rings(actions, steps, obs_ring, y_ring)
+        torch.cuda.synchronize()
+        assert torch.equal(rings[0][0], rings[1][0]), call
+        assert torch.equal(rings[0][1], rings[1][1]), call
+        assert torch.equal(a.x, b.x), call
+        dones += int((rings[0][0][:, :, -1] != 0).sum().item())
+    assert dones >= 4 * n  # (every environment reset several times: the rings wrapped)

@@ -182,6 +182,11 @@ int launch(tds_hip_sim *s, const void *x, void *y, const void *actions, void *fb
     //  beside it on a SIMD: the reset pool's refill passes, see pool_step_many)
     if (o2 != 0 && o2 != 3 && per_cu >= 2 && blocks <= 2 * s->num_cus) oct_form = TDS_FORM_OCT_W2_OCC1;
     else if (o2 == 2 || o2 == 3 || (o2 != 0 && blocks <= s->num_cus * (per_cu < 4 ? per_cu : 4))) oct_form = TDS_FORM_OCT_W2;
+    // a refill pass of the reset pool (pool stream) while the handle's own chunks are of the one-wavefront-per-SIMD build: the
+    // 240-register build, so that the pass runs BESIDE the chunk it was issued next to instead of in its tail
+    if (opts && opts->other_stream && opts->lds == &s->pool_lds && o2 != 0 && o2 != 3 && per_cu >= 4 &&
+        (s->num_envs + 7) / 8 <= 2 * s->num_cus && s->opt.get(TDS_OPT_POOL_BESIDE, 1) != 0)
+      oct_form = TDS_FORM_OCT_BESIDE;
   }
   const int quad_form = (s->compute_f64() && s->h64.quad && quad_loop_waves(s, n_resident) > 1) ? TDS_FORM_QUAD_WIDE : 0;
   const long long cw2 = s->opt.get(TDS_OPT_CHAIN_W2, 1);

@@ -140,6 +140,7 @@ struct TdsStepCtl {
 #define TDS_FORM_CHAIN_W1 32     // the serial-chain kernel (tds_chain.hip): no recorder wavefront (option chain_w2 = 0)
 #define TDS_FORM_CHAIN_W2_ANY 64 // ... the recorder wavefront at any grid size (option chain_w2 = 2)
 #define TDS_FORM_QUAD_WIDE 128   // the 16-lane kernel (tds_quad.hip): step-loop launch in workgroups of TDS_QUAD_WIDE_WAVES wavefronts
+#define TDS_FORM_OCT_BESIDE 256  // the 8-lane kernel's two-wavefront build of at most 240 registers: fits on a SIMD beside a wavefront of the OCC1 build
 #define TDS_QUAD_WIDE_WAVES 8    // ... around ONE constant table: a workgroup per compute unit, 32 environments each
 
 // EXPERIMENT SLOTS (tools/build_alt.sh): the kernel sources compiled once more — other compiler flags, -DTDS_X_... source
@@ -225,7 +226,7 @@ inline int tds_launch_step(const DevModel<T> *d_model, const DevModel<T> &h_mode
   if constexpr (sizeof(T) == 8) {
     if (tds_oct_takes(h_model.oct, ctl, prof))
       return tds_launch_oct<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl,
-                                   (form & TDS_FORM_OCT_W2_OCC1) ? 3 : ((form & TDS_FORM_OCT_W2) ? 2 : 1));
+                                   (form & TDS_FORM_OCT_BESIDE) ? 4 : (form & TDS_FORM_OCT_W2_OCC1) ? 3 : ((form & TDS_FORM_OCT_W2) ? 2 : 1));
     if (tds_chain_takes(h_model.chain, ctl, prof))
       return tds_launch_chain<T, TR>(d_model, h_model, x_in, y_out, actions, x_feedback, obs_out, n_envs, stream, ctl,
                                      (form & TDS_FORM_CHAIN_W1) ? 0 : ((form & TDS_FORM_CHAIN_W2_ANY) ? 2 : 1));

@@ -252,11 +252,14 @@ using TB = TdsOctTab;
 // store, the exchange); in the one-wave build the one wavefront plays both roles in the same order.
 // BUILD: 1 one wavefront per workgroup; 2 two, compiled for two wavefronts per SIMD (256 registers); 3 two, compiled for one
 // wavefront per SIMD (what a launch of at most two workgroups per compute unit gets anyway: Ant x 4096 — no spills)
+// BUILD 4: the two-wavefront build for launches that run BESIDE another launch's wavefronts on a SIMD (the reset pool's refill
+// passes beside the chunk they top up, tds_api.hip: pool_run): at most 240 registers — a wavefront of the one-wavefront-per-SIMD
+// build holds 272 of a SIMD's 512 — every wavefront at the lowest priority.  (The kernel's body is a device function inlined
+// into two kernels, because the register limit is an attribute that takes a literal.)
 template <typename T, typename TR, bool LOOP, int BUILD>
-__global__ __launch_bounds__(BUILD >= 2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(BUILD == 2 ? 2 : 1, BUILD == 2 ? 2 : 1)))
-void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
-                    const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */, TR *__restrict__ obs_out,
-                    TdsStepCtl ctl_arg, int n_envs, OctOff O) {
+__device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
+                                         const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
+                                         TR *__restrict__ obs_out, const TdsStepCtl &ctl_arg, int n_envs, const OctOff &O) {
   extern __shared__ __align__(16) unsigned char tds_oct_smem[];
   T *const sm = reinterpret_cast<T *>(tds_oct_smem);
 #ifdef TDS_OCT_PROF
@@ -332,8 +335,8 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #define TDS_OCT_PRIO 1
 #endif
   if constexpr (W2 && TDS_OCT_PRIO != 0) {
-    if (wv == 0) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(0);
+    if (BUILD != 4 && wv == 0) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);  // (a helper one step in front of a refill pass's wavefronts on its SIMD: measured, nothing)
   }
   (void)is_main;
   (void)is_help;
@@ -1600,6 +1603,22 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
 #endif
 }
 
+template <typename T, typename TR, bool LOOP, int BUILD>
+__global__ __launch_bounds__(BUILD >= 2 ? 128 : 64) __attribute__((amdgpu_waves_per_eu(BUILD == 2 ? 2 : 1, BUILD == 2 ? 2 : 1)))
+void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
+                    const TR *__restrict__ actions, TR *x_feedback, TR *__restrict__ obs_out, TdsStepCtl ctl_arg, int n_envs,
+                    OctOff O) {
+  oct_body<T, TR, LOOP, BUILD>(mdl_arg, x_in, y_out, actions, x_feedback, obs_out, ctl_arg, n_envs, O);
+}
+// (amdgpu_num_vgpr counts half of the unified register file of gfx90a and later: 120 = 240 registers)
+template <typename T, typename TR, bool LOOP>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(120)))
+void tds_oct_kernel_beside(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
+                           const TR *__restrict__ actions, TR *x_feedback, TR *__restrict__ obs_out, TdsStepCtl ctl_arg,
+                           int n_envs, OctOff O) {
+  oct_body<T, TR, LOOP, 4>(mdl_arg, x_in, y_out, actions, x_feedback, obs_out, ctl_arg, n_envs, O);
+}
+
 }  // namespace
 
 #ifdef TDS_OCT_PROF
@@ -1623,7 +1642,7 @@ int tds_oct_workgroup_bytes(int input_dim) {
 }
 
 // build: 1 one wavefront per workgroup, 2 / 3 the two-wavefront builds (the host grants them while every workgroup of the
-// launch is resident with at most two wavefronts per SIMD / one: tds_api.hip)
+// launch is resident with at most two wavefronts per SIMD / one: tds_api.hip), 4 the two-wavefront build of at most 240 registers
 template <typename T, typename TR>
 int tds_launch_oct(const DevModel<T> *d_model, const DevModel<T> &h_model, const TR *x_in, TR *y_out, const TR *actions,
                    TR *x_feedback, TR *obs_out, int n_envs, hipStream_t stream, const TdsStepCtl &ctl, int build) {
@@ -1635,7 +1654,14 @@ int tds_launch_oct(const DevModel<T> *d_model, const DevModel<T> &h_model, const
 #define OCT_LAUNCH(LOOP_, B_)                                                                                                 \
   hipLaunchKernelGGL((tds_oct_kernel<T, TR, LOOP_, B_>), dim3(blocks), dim3(B_ >= 2 ? 128 : 64), shmem, stream, d_model, x_in, \
                      y_out, actions, x_feedback, obs_out, ctl, n_envs, O)
-  if (one_step) {
+  if (build == 4) {
+    if (one_step)
+      hipLaunchKernelGGL((tds_oct_kernel_beside<T, TR, false>), dim3(blocks), dim3(128), shmem, stream, d_model, x_in, y_out, actions,
+                         x_feedback, obs_out, ctl, n_envs, O);
+    else
+      hipLaunchKernelGGL((tds_oct_kernel_beside<T, TR, true>), dim3(blocks), dim3(128), shmem, stream, d_model, x_in, y_out, actions,
+                         x_feedback, obs_out, ctl, n_envs, O);
+  } else if (one_step) {
     if (build == 3) OCT_LAUNCH(false, 3);
     else if (build == 2) OCT_LAUNCH(false, 2);
     else OCT_LAUNCH(false, 1);

@@ -35,6 +35,7 @@ enum TdsOptKey {
   TDS_OPT_RING_NOFENCE,       // 1 (default): write-through record stores + plain wait; 0: release fence per step
   TDS_OPT_POOL_SLAB,          // 0: refill launches keep every constraint row in LDS
   TDS_OPT_POOL_SETTLE_LOOP,   // 1: the settle steps of a refill pass as one step-loop launch
+  TDS_OPT_POOL_BESIDE,        // 1 / unset: the refill passes of a handle whose chunks run one wavefront per SIMD (8-lane kernel, at most two workgroups per compute unit) use the 240-register build, which fits beside them; 0: the build the grid size selects
   TDS_OPT_POOL_EVERY,         // reset pool: R
   TDS_OPT_POOL_HOST_LAG,      // H
   TDS_OPT_POOL_LAG,           // W
@@ -98,6 +99,7 @@ inline const TdsOptRow *tds_opt_rows() {
       {"ring_nofence", false, "TDS_HIP_RING_NOFENCE"},
       {"pool_slab", false, "TDS_HIP_POOL_SLAB"},
       {"pool_settle_loop", false, "TDS_HIP_POOL_SETTLE_LOOP"},
+      {"pool_beside", false, "TDS_HIP_POOL_BESIDE"},
       {"pool_every", false, "TDS_HIP_POOL_EVERY"},
       {"pool_host_lag", false, "TDS_HIP_POOL_HOST_LAG"},
       {"pool_lag", false, "TDS_HIP_POOL_LAG"},

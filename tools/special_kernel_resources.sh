@@ -22,6 +22,6 @@ for line in sys.stdin:
 print("%-64s %5s %5s %7s %4s %6s %6s %6s %7s"%("kernel","VGPR","AGPR","scratch","occ","sgprSp","vgprSp","SGPR","LDS"))
 for r in rows:
     d=subprocess.run(["c++filt",r["name"]],capture_output=True,text=True).stdout.strip()
-    m=re.search(r"(tds_\w+_kernel<.*?>)\(",d)
+    m=re.search(r"(tds_\w+_kernel\w*<.*?>)\(",d)
     print("%-64s %5d %5d %7d %4d %6d %6d %6d %7d"%(m.group(1) if m else d[:64], r.get("VGPRs",-1), r.get("AGPRs",-1), r.get("ScratchSize [bytes/lane]",-1), r.get("Occupancy [waves/SIMD]",-1), r.get("SGPRs Spill",-1), r.get("VGPRs Spill",-1), r.get("TotalSGPRs",-1), r.get("LDS Size [bytes/block]",-1)))
 '
