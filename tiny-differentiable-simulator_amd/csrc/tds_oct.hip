@@ -442,6 +442,10 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
         tau = f;
       }
       tau -= CL[TB::STIFF] * q + CL[TB::DAMP] * qd;
+      // (tau is next read by the forward dynamics, two barriers on: left to itself the back end moves this line down there and
+      //  keeps stiffness and damping alive for it — in the 256-register build through scratch, a memory round trip the main
+      //  wavefront waited for behind barrier (2))
+      asm volatile("" : "+v"(tau));
     }
     OCT_MARK("main_jcalc");
     // ---- B. jcalc (link.hpp:229-287)
@@ -597,6 +601,14 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
     // my world motion axis, for the rows of the contacts (lane-dependent reads in the row windows); two-wavefront build: my
     // link's world transform for the helper's narrowphase and visual poses (the slots of the second row window)
     {
+      if constexpr (LOOP) {
+        // The next step's actions into the record's action slots HERE: the slots are dead since the PD block (nothing else
+        // reads them), the load was requested a kinematics phase ago, and the main wavefront has no store in flight that a
+        // wait for it would wait for as well (loads and stores return through one in-order counter on gfx9; one-wavefront
+        // build: the last step's record stores are as old).  Held in a register until phase M the value crossed the whole
+        // step — the 256-register build kept it in scratch and reloaded it on the main wavefront's path
+        if (ctl.act_pool != nullptr && !last) xr[nq + nd + lane] = next_act;
+      }
       T *const swl = E + O.swl + lane * 6;
 #pragma unroll
       for (int k = 0; k < 6; ++k) swl[k] = sw[k];
@@ -1301,12 +1313,6 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
         xr[in_dim] = q_old0;  // x_{t-1} (the Ant's reward reads it)
         xr[in_dim + 3] = T(0);  // "the y state of this step is out already" (set below for an environment the reset pool re-initialises)
       }
-    }
-    if constexpr (LOOP) {
-      // The next step's actions into the record's action slots (dead since the PD block) HERE, in front of this step's
-      // record stores — not at the top of the next step: loads and stores return through one in-order counter on gfx9, a
-      // wait for this load behind the stores would be a wait for every one of them (see tds_quad.hip)
-      if (ctl.act_pool != nullptr && !last) xr[nq + nd + lane] = next_act;
     }
     OCT_SYNC();
     OCT_MARK("main_reward");
