@@ -412,15 +412,6 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
 
   auto main_kin = [&]() {
     // ================================ main: PD, jcalc, kinematics ================================
-    if constexpr (LOOP) {
-      // the action block of this step came in a step ago (see phase M); the next step's is requested now
-      if (ctl.act_pool != nullptr) {  // wave-uniform
-        if (it + 1 < nsteps && valid) {
-          const int blk = act_blk;
-          next_act = (T)oct_global((const TR *)ctl.act_pool)[((size_t)blk * ctl.act_envs + env) * adim + lane];
-        }
-      }
-    }
     OCT_MARK("main_top");
     q = xr[dq];
     qd = xr[nq + dq];
@@ -601,14 +592,6 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
     // my world motion axis, for the rows of the contacts (lane-dependent reads in the row windows); two-wavefront build: my
     // link's world transform for the helper's narrowphase and visual poses (the slots of the second row window)
     {
-      if constexpr (LOOP) {
-        // The next step's actions into the record's action slots HERE: the slots are dead since the PD block (nothing else
-        // reads them), the load was requested a kinematics phase ago, and the main wavefront has no store in flight that a
-        // wait for it would wait for as well (loads and stores return through one in-order counter on gfx9; one-wavefront
-        // build: the last step's record stores are as old).  Held in a register until phase M the value crossed the whole
-        // step — the 256-register build kept it in scratch and reloaded it on the main wavefront's path
-        if (ctl.act_pool != nullptr && !last) xr[nq + nd + lane] = next_act;
-      }
       T *const swl = E + O.swl + lane * 6;
 #pragma unroll
       for (int k = 0; k < 6; ++k) swl[k] = sw[k];
@@ -629,15 +612,23 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
   const int ystr = ctl.y_stride;
   const int out_dim = (int)CT[TB::SC + TB::OUTPUT_DIM];
   const int nv = (int)CT[TB::SC + TB::NUM_VISUALS];
-  TR *yo = nullptr, *yo2 = nullptr;
-  int yend = ystr, yend2 = out_dim;
-  if (LOOP && ctl.y_ring != nullptr) {
-    yo = oct_global((TR *)ctl.y_ring) + ((size_t)y_slot * ctl.ring_envs + env) * ystr;
-    if (last && y_out != nullptr) yo2 = y_out + (size_t)env * out_dim;
-  } else if (last && y_out != nullptr) {
-    yo = y_out + (size_t)env * (LOOP ? out_dim : ystr);
-    yend = LOOP ? out_dim : ystr;
-  }
+  // (worked out where a phase stores — three places — from a ring position laundered there: computed once at the top of the
+  //  step the two pointers lived across it, in the 256-register build through scratch, reloaded in front of the helper's stores)
+  auto y_where = [&](TR *&yo, TR *&yo2, int &yend, int &yend2) {
+    int ys = y_slot;
+    asm volatile("" : "+s"(ys));
+    yo = nullptr;
+    yo2 = nullptr;
+    yend = ystr;
+    yend2 = out_dim;
+    if (LOOP && ctl.y_ring != nullptr) {
+      yo = oct_global((TR *)ctl.y_ring) + ((size_t)ys * ctl.ring_envs + env) * ystr;
+      if (last && y_out != nullptr) yo2 = y_out + (size_t)env * out_dim;
+    } else if (last && y_out != nullptr) {
+      yo = y_out + (size_t)env * (LOOP ? out_dim : ystr);
+      yend = LOOP ? out_dim : ystr;
+    }
+  };
   // ---- exchange launches of the multi-GPU layer (tds_shard.hip): the records of a step are counted in on the slot's progress
   //      counter (RCCL forms), or on its arrival counters with the flags of every rank raised by the workgroup that
   //      completes the slot (peer-store exchange; see tds_kernels.hip: peer_signal)
@@ -671,6 +662,15 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
   auto help_np = [&]() {
     OCT_MARK("help_np");
     // ================================ helper: narrowphase, visual poses ================================
+    if constexpr (LOOP) {
+      // The NEXT step's action block is requested here, by the helper (a different block per step: tds_hip_step_many), and goes
+      // into the record's action slots in front of the visual poses' stores (help_poses) — the slots are dead since the PD
+      // block, in front of barrier (1); the next PD block is behind barrier (0).  Requested by the main wavefront and held
+      // until the integration, the value crossed the whole step in a register: the 256-register build spilled it to scratch
+      // at the top of the step — a wait for the load itself — and reloaded it on the main wavefront's path
+      if (ctl.act_pool != nullptr && it + 1 < nsteps && valid)  // (wave-uniform but for `valid`)
+        next_act = (T)oct_global((const TR *)ctl.act_pool)[((size_t)act_blk * ctl.act_envs + env) * adim + lane];
+    }
     if constexpr (W2) {  // my link's world transform and the root's sines / cosines, from the main wavefront
       const T *const kin = E + O.win + 8 * OctLds::ZW + lane * 12;
 #pragma unroll
@@ -745,12 +745,20 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
   auto help_poses = [&]() {
     OCT_MARK("help_signal_poses");
     if constexpr (LOOP) {
+      // (loads and stores return through one in-order counter on gfx9: this wait sees the helper's record stores of the step
+      //  before, issued a narrowphase and a row stage ago, and nothing of this step)
+      if (ctl.act_pool != nullptr && !last) xr[nq + nd + lane] = next_act;
       // the records of step it - 1 — stored at the end of the iteration before, long acknowledged by now: the wait costs
       // nothing here, in front of this step's first stores — are counted in
       if (it > 0 && ctl.obs_ring != nullptr) signal_slot((o_slot == 0 ? ctl.obs_slots : o_slot) - 1);  // (wave-uniform)
     }
     // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
     //          my link's (DevModel::oct checks the order); visual 0 — the root body's — goes out on lane 7
+    TR *yo, *yo2;
+    int yend, yend2;
+    y_where(yo, yo2, yend, yend2);
+    (void)yend;
+    (void)yend2;
     if (valid && yo != nullptr && nv > 0) {
       auto pose_out = [&](const T *Rl, const T *pl, const T *vx, int k) {
         T Ro[9], po[3], qo[4];
@@ -1367,6 +1375,9 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
     //      takes its next pre-settled state — y, reward and done describe the terminal step, the observation and the state
     //      the fresh environment: its y state goes out HERE, before the record is overwritten
     if (ctl.pool != nullptr && valid && (done_in_reg ? done_reg : xr[in_dim + 1] != T(0))) {
+      TR *yo, *yo2;
+      int yend, yend2;
+      y_where(yo, yo2, yend, yend2);
       if (yo != nullptr) {
         y_state(yo, yend);
         if (yo2 != nullptr) y_state(yo2, yend2);
@@ -1394,6 +1405,9 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
     // (two-wavefront build: while the main wavefront starts the next step — it does not write the record before its own
     //  phase M, two barriers from here)
     // ---- y record: q | qd | (visual poses: M1) | up.z | zero padding
+    TR *yo, *yo2;
+    int yend, yend2;
+    y_where(yo, yo2, yend, yend2);
     if (valid && yo != nullptr && xr[in_dim + 3] == T(0)) {
       y_state(yo, yend);
       if (yo2 != nullptr) y_state(yo2, yend2);
@@ -1616,7 +1630,8 @@ void tds_oct_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR 
                     OctOff O) {
   oct_body<T, TR, LOOP, BUILD>(mdl_arg, x_in, y_out, actions, x_feedback, obs_out, ctl_arg, n_envs, O);
 }
-// (amdgpu_num_vgpr counts half of the unified register file of gfx90a and later: 120 = 240 registers)
+// (amdgpu_num_vgpr counts half of the unified register file of gfx90a and later: 120 = 240 registers.  Measured with 128 — the
+//  254 registers of BUILD 2, no scratch —: a pass does not start beside a chunk of BUILD 3's 254, the rate falls back to 4.45e8)
 template <typename T, typename TR, bool LOOP>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(120)))
 void tds_oct_kernel_beside(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
