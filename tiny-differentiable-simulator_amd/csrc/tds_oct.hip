@@ -1360,7 +1360,15 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
   };
   // the state part of a y record — q | qd | (visual poses: M1) | up.z | zero padding — from the LDS record
   auto y_state = [&](TR *y, int end) {
-    for (int i = lane; i < nq + nd; i += 8) y[i] = (TR)xr[i];
+    {  // (the reads in one batch in front of the stores: as a loop of read -> store every value was an LDS round trip of its own)
+      constexpr int NB = (nq + nd + 7) / 8;
+      T sv[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) sv[k] = xr[lane + 8 * k < nq + nd ? lane + 8 * k : 0];
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+        if (lane + 8 * k < nq + nd) y[lane + 8 * k] = (TR)sv[k];
+    }
     int tail = nq + nd;
     if ((int)CT[TB::SC + TB::PACK_VISUALS]) {
       tail += 7 * nv;
@@ -1478,8 +1486,19 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
           }
         } else if (valid) {
           const size_t at = ((size_t)slot * ctl.obs_envs + env) * w_obs;
-          for (int i = lane; i < w_obs; i += 8) {
-            const T vv = i < 2 ? T(0) : xr[i < nq + nd ? i : (i == nq + nd ? in_dim + 2 : in_dim + 1)];
+          constexpr int NB = (w_obs + 7) / 8;
+          T ov[NB];  // (read in one batch: see y_state)
+#pragma unroll
+          for (int k = 0; k < NB; ++k) {
+            const int i = lane + 8 * k;
+            const T rv = xr[i >= w_obs ? 0 : (i < nq + nd ? i : (i == nq + nd ? in_dim + 2 : in_dim + 1))];
+            ov[k] = i < 2 ? T(0) : rv;
+          }
+#pragma unroll
+          for (int k = 0; k < NB; ++k) {
+            const int i = lane + 8 * k;
+            if (i >= w_obs) continue;
+            const T vv = ov[k];
             // (TDS_RING_NOFENCE: device-scope write-through stores, visible to the exchange after a plain wait)
             if (rf & TDS_RING_OBS_F32) {
               float *const pp = oct_global((float *)ctl.obs_ring) + at + i;
