@@ -122,7 +122,10 @@ struct ChainLds {
 // exchange's counters) while the main wavefront runs step k + 1: per-step records cost the main wavefront twelve LDS stores and
 // two barriers instead of a quarter of its instruction stream (pendulum5 x 4096: 4.31 -> see DESIGN 2e)
 #define CH_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-template <typename T, typename TR, int NL, bool LOOP, bool W2 = false>
+// CREG (with W2, launches of at most one wavefront per SIMD): my link's constants in registers for the whole launch — 276
+// registers, so only where a SIMD holds one wavefront of this kernel anyway; otherwise they are read from the LDS table where a
+// step uses them (140 registers: three wavefronts per SIMD)
+template <typename T, typename TR, int NL, bool LOOP, bool W2 = false, bool CREG = false>
 __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR *__restrict__ y_out,
                                                        const TR *__restrict__ actions, TR *x_feedback /* may alias x_in */,
                                                        TR *__restrict__ obs_out, TdsStepCtl ctl_arg, int n_envs) {
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel
   constexpr int nq = NL, nd = NL, adim = NL, in_dim = 3 * NL, w_obs = 2 * NL + 2;
   T *const CT = sm + 8 * LD::STRIDE;  // the constant table
   static_assert(!W2 || LOOP, "the recorder wavefront exists in the step-loop form only");
+  static_assert(!CREG || W2, "constants in registers: the two-wavefront build at one wavefront per SIMD only");
   constexpr int NT = W2 ? 128 : 64;
   const int t_all = threadIdx.x;
   const int tid = threadIdx.x & 63;
@@ -309,41 +313,41 @@ __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel
     // ---- A. my joint: coordinate, velocity, torque (multi_body.hpp:557-570; joint stiffness / damping, forward_dynamics.hpp:122-123)
     const T q = q_c, qd = qd_c;
     T tau = tau_c;
-    tau -= cSTIFF * q + cDAMP * qd;
+    tau -= (CREG ? cSTIFF : CL[TB::STIFF]) * q + (CREG ? cDAMP : CL[TB::DAMP]) * qd;
     // ---- B. jcalc (link.hpp:229-287): R_J = cos I + sin [n]x + (1 - cos) n n^T about the unit axis (every revolute type; a
     //         prismatic joint's angle is multiplied by 0), t_J = S_linear q; X_parent = X_T X_J
     T S[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) S[k] = cS[k];
+    for (int k = 0; k < 6; ++k) S[k] = CREG ? cS[k] : CL[TB::S + k];
     {
       T sn, cs;
-      ch_sincos(q * cROTF, &sn, &cs);
+      ch_sincos(q * (CREG ? cROTF : CL[TB::ROTF]), &sn, &cs);
       const T c1 = T(1) - cs;
-      const T nx = cNAX[0], ny = cNAX[1], nz = cNAX[2];
+      const T nx = CREG ? cNAX[0] : CL[TB::NAX], ny = CREG ? cNAX[1] : CL[TB::NAX + 1], nz = CREG ? cNAX[2] : CL[TB::NAX + 2];
       T RJ[9];
-      RJ[0] = cs + c1 * cNN[0];
-      RJ[1] = c1 * cNN[1] - sn * nz;
-      RJ[2] = c1 * cNN[2] + sn * ny;
-      RJ[3] = c1 * cNN[1] + sn * nz;
-      RJ[4] = cs + c1 * cNN[3];
-      RJ[5] = c1 * cNN[4] - sn * nx;
-      RJ[6] = c1 * cNN[2] - sn * ny;
-      RJ[7] = c1 * cNN[4] + sn * nx;
-      RJ[8] = cs + c1 * cNN[5];
+      RJ[0] = cs + c1 * (CREG ? cNN[0] : CL[TB::NN + 0]);
+      RJ[1] = c1 * (CREG ? cNN[1] : CL[TB::NN + 1]) - sn * nz;
+      RJ[2] = c1 * (CREG ? cNN[2] : CL[TB::NN + 2]) + sn * ny;
+      RJ[3] = c1 * (CREG ? cNN[1] : CL[TB::NN + 1]) + sn * nz;
+      RJ[4] = cs + c1 * (CREG ? cNN[3] : CL[TB::NN + 3]);
+      RJ[5] = c1 * (CREG ? cNN[4] : CL[TB::NN + 4]) - sn * nx;
+      RJ[6] = c1 * (CREG ? cNN[2] : CL[TB::NN + 2]) - sn * ny;
+      RJ[7] = c1 * (CREG ? cNN[4] : CL[TB::NN + 4]) + sn * nx;
+      RJ[8] = cs + c1 * (CREG ? cNN[5] : CL[TB::NN + 5]);
       const T tJ[3] = {S[3] * q, S[4] * q, S[5] * q};
       if (xt_ident) {  // wave-uniform
 #pragma unroll
         for (int k = 0; k < 9; ++k) R[k] = RJ[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = cXT[9 + k] + tJ[k];
+        for (int k = 0; k < 3; ++k) p[k] = (CREG ? cXT[9 + k] : CL[TB::XT + 9 + k]) + tJ[k];
       } else {
         T RT[9], r[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) RT[k] = cXT[k];
+        for (int k = 0; k < 9; ++k) RT[k] = CREG ? cXT[k] : CL[TB::XT + k];
         mat3_mul(RT, RJ, R);
         mat3_mulv(RT, tJ, r);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = cXT[9 + k] + r[k];
+        for (int k = 0; k < 3; ++k) p[k] = (CREG ? cXT[9 + k] : CL[TB::XT + 9 + k]) + r[k];
       }
     }
     // ---- C. forward kinematics (kinematics.hpp:64-97): X_world_i = X_world_(i-1) X_parent_i as an inclusive scan of transform
@@ -416,18 +420,18 @@ __global__ __launch_bounds__(W2 ? 128 : 64) void tds_chain_kernel(const DevModel
       }
     });
 #pragma unroll
-    for (int k = 0; k < 3; ++k) a0[3 + k] -= cGRAV[k];
+    for (int k = 0; k < 3; ++k) a0[3 + k] -= CREG ? cGRAV[k] : CT[TB::SC + TB::GRAV + k];
     // ---- E. world-frame rigid inertia and bias force of my link (kinematics.hpp:99-132, inertia.hpp:121-130):
     //         I = (Isym 6 | h 3 | m), f = I a0 + v x* I v
     T Ic[10], fc[6];
     {
-      const T m = cMASS;
+      const T m = CREG ? cMASS : CL[TB::MASS];
       T cw[3];
-      mat3_mulv(R, cCOM, cw);
+      mat3_mulv(R, CREG ? (const T *)cCOM : CL + TB::COM, cw);
 #pragma unroll
       for (int k = 0; k < 3; ++k) cw[k] += p[k];
       T RI[9], Iw[9];
-      mat3_mul(R, cINER, RI);
+      mat3_mul(R, CREG ? (const T *)cINER : CL + TB::INER, RI);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -745,11 +749,25 @@ int tds_launch_chain(const DevModel<T> *d_model, const DevModel<T> &h_model, con
   // the recorder wavefront: step-loop launches that store per-step records, while the launch is resident with at most two
   // wavefronts per SIMD (1024 workgroups of two on 1024 SIMDs); option chain_w2 = 0 / 2: never / at any grid size
   const bool two_waves = !one_step && (ctl.obs_ring != nullptr || ctl.y_ring != nullptr) && w2_opt != 0 && (blocks <= 1024 || w2_opt == 2);
+  // ... with my link's constants in registers while the launch puts at most ONE wavefront on a SIMD (that build holds 276
+  // registers: a SIMD has room for one)
+  static int n_simd = 0;
+  if (n_simd == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      n_simd = 4 * cus;
+    else
+      n_simd = 1024;
+  }
+  const bool creg = two_waves && 2 * blocks <= n_simd;
 #define CH_LAUNCH(NL_)                                                                                                           \
   case NL_:                                                                                                                      \
     if (one_step)                                                                                                                \
       hipLaunchKernelGGL((tds_chain_kernel<T, TR, NL_, false>), dim3(blocks), dim3(64), chain_shmem<NL_>(), stream, d_model, x_in, \
                          y_out, actions, x_feedback, obs_out, ctl, n_envs);                                                      \
+    else if (creg)                                                                                                               \
+      hipLaunchKernelGGL((tds_chain_kernel<T, TR, NL_, true, true, true>), dim3(blocks), dim3(128), chain_shmem<NL_>(), stream,    \
+                         d_model, x_in, y_out, actions, x_feedback, obs_out, ctl, n_envs);                                       \
     else if (two_waves)                                                                                                          \
       hipLaunchKernelGGL((tds_chain_kernel<T, TR, NL_, true, true>), dim3(blocks), dim3(128), chain_shmem<NL_>(), stream, d_model, \
                          x_in, y_out, actions, x_feedback, obs_out, ctl, n_envs);                                                \
