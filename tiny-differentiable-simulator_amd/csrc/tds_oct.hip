@@ -321,8 +321,11 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
     if (ctl_arg.y_ring != nullptr && ctl_arg.y_slots > 0) y_slot = ctl_arg.y_first % ctl_arg.y_slots;
     if (ctl_arg.obs_ring != nullptr && ctl_arg.obs_slots > 0) o_slot = ctl_arg.obs_first % ctl_arg.obs_slots;
   }
+  // (where my lane's action sits in the record: one register across the steps, against a table read in front of the PD block's
+  //  read of the action — two LDS round trips in a row at the top of the main wavefront's step)
+  const int act_slot = (int)(CT + (threadIdx.x & 7) * TB::LSTR)[TB::ACT];
   for (int it = 0; it < nsteps; ++it) {  // ================================ step loop ================================
-  // (nothing but `it` and next_act lives across an iteration: lane and kernel-argument segment are laundered)
+  // (nothing but `it`, next_act and act_slot lives across an iteration: lane and kernel-argument segment are laundered)
   const __attribute__((address_space(4))) char *ka_seg = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
   int tid = threadIdx.x;
   if constexpr (LOOP) asm volatile("" : "+s"(ka_seg), "+v"(tid));
@@ -418,7 +421,7 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
     // ---- PD controller (locomotion_contact_simulation.h:168-258); joint stiffness / damping
     tau = T(0);
     {
-      const int act_i = (int)CL[TB::ACT];
+      const int act_i = act_slot;
       if (act_i >= 0) {
         const int var = nq + nd + adim;
         const T kp = xr[var], kd = xr[var + 1], max_force = xr[var + 2];
