@@ -662,10 +662,46 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
     }
   };
 
+  // The peer form's count in two halves: the first-level atomic (with return) is ISSUED behind barrier (1) — the records of
+  // step it - 1 went out a kinematics phase ago — and its result is looked at in front of the visual poses (help_poses): as
+  // one piece there, the helper waited for the atomic's round trip to the L2 between barriers (1b) and (2), where the main
+  // wavefront waits for the helper
+  unsigned sig_tok = 0u;
+  auto signal_issue = [&](int pslot) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if ((ctl.ring_flags & TDS_RING_PEER_RELEASE) != 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if ((tid & 63) == 0) {
+      constexpr unsigned SUB = TDS_PEER_SUB;
+      const unsigned g = gridDim.x, j = blockIdx.x % SUB;
+      const unsigned n1 = (g - j + SUB - 1u) / SUB;
+      unsigned *const base = oct_global(ctl.peer_arrive) + (size_t)pslot * TDS_PEER_ARRIVE_STRIDE;
+      sig_tok = atomicInc(base + j * TDS_PEER_LINE, n1 - 1u);
+    }
+  };
+  auto signal_finish = [&](int pslot) {
+    if ((tid & 63) == 0) {
+      constexpr unsigned SUB = TDS_PEER_SUB;
+      const unsigned g = gridDim.x, j = blockIdx.x % SUB;
+      const unsigned n1 = (g - j + SUB - 1u) / SUB;
+      const unsigned n2 = g < SUB ? g : SUB;
+      unsigned *const base = oct_global(ctl.peer_arrive) + (size_t)pslot * TDS_PEER_ARRIVE_STRIDE;
+      if (sig_tok == n1 - 1u) {
+        if (atomicInc(base + 32 * TDS_PEER_LINE, n2 - 1u) == n2 - 1u) {
+          const size_t fi = (size_t)ctl.peer_flag_off + (size_t)pslot * (size_t)ctl.peer_flag_stride;
+          if ((ctl.ring_flags & TDS_RING_PEER_RELEASE) != 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+          for (int pr = 0; pr <= ctl.n_peers; ++pr)
+            __hip_atomic_store(ctl.peer_flags[pr] + fi, ctl.peer_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+  };
+
   auto help_np = [&]() {
     OCT_MARK("help_np");
     // ================================ helper: narrowphase, visual poses ================================
     if constexpr (LOOP) {
+      if (it > 0 && ctl.obs_ring != nullptr && ctl.peer_arrive != nullptr)  // (wave-uniform; in front of the action request: the wait)
+        signal_issue((o_slot == 0 ? ctl.obs_slots : o_slot) - 1);
       // The NEXT step's action block is requested here, by the helper (a different block per step: tds_hip_step_many), and goes
       // into the record's action slots in front of the visual poses' stores (help_poses) — the slots are dead since the PD
       // block, in front of barrier (1); the next PD block is behind barrier (0).  Requested by the main wavefront and held
@@ -753,7 +789,10 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
       if (ctl.act_pool != nullptr && !last) xr[nq + nd + lane] = next_act;
       // the records of step it - 1 — stored at the end of the iteration before, long acknowledged by now: the wait costs
       // nothing here, in front of this step's first stores — are counted in
-      if (it > 0 && ctl.obs_ring != nullptr) signal_slot((o_slot == 0 ? ctl.obs_slots : o_slot) - 1);  // (wave-uniform)
+      if (it > 0 && ctl.obs_ring != nullptr) {  // (wave-uniform)
+        if (ctl.peer_arrive != nullptr) signal_finish((o_slot == 0 ? ctl.obs_slots : o_slot) - 1);
+        else signal_slot((o_slot == 0 ? ctl.obs_slots : o_slot) - 1);
+      }
     }
     // ---- M1. visual poses of y, from the PRE-step X_world (locomotion_contact_simulation.h:281-299): visual 1 + lane is
     //          my link's (DevModel::oct checks the order); visual 0 — the root body's — goes out on lane 7
