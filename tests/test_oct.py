@@ -307,3 +307,32 @@ def test_oct_refill_passes_beside_the_chunks_equal_the_passes_behind_them(built)
         assert torch.equal(a.x, b.x), call
         dones += int((rings[0][0][:, :, -1] != 0).sum().item())
     assert dones >= 4 * n  # (every environment reset several times: the rings wrapped)
+
+
+def test_oct_calls_beyond_residency_run_as_environment_ranges(built):
+    """A step-loop call of more environments than are resident at once in the two-wavefront build (Ant: 8192) runs as
+    environment ranges one after the other, each in that build — against the same call on the one-wavefront build (option
+    oct_w2 = 0: one launch, several rounds of workgroups).  Ragged on purpose: 8192 + 72 environments = a range of 8192 and one of 72.  Bit for bit (the kernel's builds round alike), every ring slot, with a different action block per step."""
+    torch = _torch()
+    name = "ant"
+    m = tds_amd.load_model(name)
+    n, steps = 8192 + 72, 24
+    rng = np.random.default_rng(21)
+    from test_rings import _start_state
+
+    x = _start_state(m, name, n, rng)
+    a = hip_backend.HipSim(m, n)
+    b = hip_backend.HipSim(m, n, options={"oct_w2": 0})
+    for s_ in (a, b):
+        s_.x.copy_(torch.from_numpy(x).cuda())
+    actions = torch.from_numpy(rng.uniform(-0.4, 0.4, (5, n, m.action_dim))).cuda().contiguous()
+    out = []
+    for s_ in (a, b):
+        obs_ring = torch.zeros((steps, n, s_.obs_dim + 2), dtype=torch.float64, device="cuda")
+        y_ring = torch.zeros((steps, n, m.output_dim), dtype=torch.float64, device="cuda")
+        s_.step_many_rings(actions, steps, obs_ring, y_ring, first_block=3)
+        torch.cuda.synchronize()
+        out.append((obs_ring, y_ring, s_.x.clone(), s_.y.clone()))
+    for u, v in zip(out[0], out[1]):
+        assert torch.equal(u, v)
+    assert float(out[0][0].abs().sum()) > 0 and bool(torch.isfinite(out[0][1]).all())

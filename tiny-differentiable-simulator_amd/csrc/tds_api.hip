@@ -1468,6 +1468,26 @@ int step_many_impl(tds_hip_sim_t *s, const void *actions_dev, int action_blocks,
     lo.rings = rings;
     // (a single step with rings is a step-loop launch too: the launcher picks that build whenever a ring is set)
     // (no copy of the last y slot behind the launch: the step-loop kernel writes the last step's record into d_y as well)
+    // The 8-lane kernel beyond one round of resident two-wavefront workgroups (Ant: 8192 environments): the environments are
+    // independent, so the call runs as environment ranges of that size ONE AFTER THE OTHER, each a launch of
+    // all the steps in the two-wavefront build — instead of one launch of the one-wavefront build in several rounds
+    // (Ant x 16384: 20.8 -> see DESIGN 2d; the exchange's launches count workgroups per slot and stay whole)
+    if (s->compute_f64() && s->h64.oct != 0 && s->opt.get(TDS_OPT_OCT_W2, 1) == 1 && !(rings && rings->progress) && !s->peer_launch) {
+      const int per_cu = (int)(s->lds_per_cu / (size_t)tds_oct_workgroup_bytes(s->model.input_dim));
+      const int cap = 8 * s->num_cus * (per_cu < 4 ? per_cu : 4);
+      if (cap > 0 && s->num_envs > cap) {
+        // (full rounds first, the rest last: a step costs the same from 4097 to 8192 environments — two wavefronts on some
+        //  SIMD — and less up to 4096; x 12288 as 8192 + 4096: 15.7 us per step, as 2 x 6144: 17.5)
+        for (int e0 = 0; e0 < s->num_envs; e0 += cap) {
+          const int e1 = e0 + cap < s->num_envs ? e0 + cap : s->num_envs;
+          lo.env_first = e0;
+          lo.env_total = e1 - e0;
+          const int rc = launch(s, s->d_x, s->d_y, a0, s->d_x, obs_dev, e1 - e0, n_steps, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
+          if (rc != TDS_OK) return rc;
+        }
+        return TDS_OK;
+      }
+    }
     return launch(s, s->d_x, s->d_y, a0, s->d_x, obs_dev, s->num_envs, n_steps, TDS_RESET_NONE, nullptr, nullptr, 0, &lo);
   }
   const int C = eager ? chain_count(s, n_steps) : s->graph_chains;
