@@ -240,6 +240,11 @@ using TB = TdsOctTab;
 // barrier between the two wavefronts of a workgroup (W2: LDS writes done, then s_barrier — neither wavefront waits for its
 // outstanding global stores); a compiler-level fence in the one-wave build, where the LDS executes a wavefront's
 // instructions in order
+#ifdef TDS_OCT_NT
+#define OCT_ST(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define OCT_ST(v, p) (*(p) = (v))
+#endif
 #define OCT_BAR()                                                                        \
   do {                                                                                   \
     if constexpr (W2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
@@ -808,22 +813,22 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
         mat3_mulv(Rl, vx + 9, po);
         matrix_to_quat(Ro, qo);
         TR *o = yo + (nq + nd) + 7 * k;
-        o[0] = (TR)(pl[0] + po[0]);
-        o[1] = (TR)(pl[1] + po[1]);
-        o[2] = (TR)(pl[2] + po[2]);
-        o[3] = (TR)qo[0];
-        o[4] = (TR)qo[1];
-        o[5] = (TR)qo[2];
-        o[6] = (TR)qo[3];
+        OCT_ST((TR)(pl[0] + po[0]), &o[0]);
+        OCT_ST((TR)(pl[1] + po[1]), &o[1]);
+        OCT_ST((TR)(pl[2] + po[2]), &o[2]);
+        OCT_ST((TR)qo[0], &o[3]);
+        OCT_ST((TR)qo[1], &o[4]);
+        OCT_ST((TR)qo[2], &o[5]);
+        OCT_ST((TR)qo[3], &o[6]);
         if (yo2 != nullptr) {
           TR *o2 = yo2 + (nq + nd) + 7 * k;
-          o2[0] = (TR)(pl[0] + po[0]);
-          o2[1] = (TR)(pl[1] + po[1]);
-          o2[2] = (TR)(pl[2] + po[2]);
-          o2[3] = (TR)qo[0];
-          o2[4] = (TR)qo[1];
-          o2[5] = (TR)qo[2];
-          o2[6] = (TR)qo[3];
+          OCT_ST((TR)(pl[0] + po[0]), &o2[0]);
+          OCT_ST((TR)(pl[1] + po[1]), &o2[1]);
+          OCT_ST((TR)(pl[2] + po[2]), &o2[2]);
+          OCT_ST((TR)qo[0], &o2[3]);
+          OCT_ST((TR)qo[1], &o2[4]);
+          OCT_ST((TR)qo[2], &o2[5]);
+          OCT_ST((TR)qo[3], &o2[6]);
         }
       };
       pose_out(R, p, CL + TB::VIS, 1 + lane);
@@ -1409,15 +1414,15 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
       for (int k = 0; k < NB; ++k) sv[k] = xr[lane + 8 * k < nq + nd ? lane + 8 * k : 0];
 #pragma unroll
       for (int k = 0; k < NB; ++k)
-        if (lane + 8 * k < nq + nd) y[lane + 8 * k] = (TR)sv[k];
+        if (lane + 8 * k < nq + nd) OCT_ST((TR)sv[k], &y[lane + 8 * k]);
     }
     int tail = nq + nd;
     if ((int)CT[TB::SC + TB::PACK_VISUALS]) {
       tail += 7 * nv;
-      if (lane == 0) y[tail] = (TR)(CT[TB::SC + TB::BASE_R8]);  // up_dot_world_z (fixed base)
+      if (lane == 0) OCT_ST((TR)(CT[TB::SC + TB::BASE_R8]), &y[tail]);  // up_dot_world_z (fixed base)
       tail += 1;
     }
-    for (int i = tail + lane; i < end; i += 8) y[i] = TR(0);
+    for (int i = tail + lane; i < end; i += 8) OCT_ST(TR(0), &y[i]);
   };
   auto main_pool = [&]() {
     OCT_MARK("main_pool");
@@ -1545,11 +1550,11 @@ __device__ __forceinline__ void oct_body(const DevModel<T> *__restrict__ mdl_arg
             if (rf & TDS_RING_OBS_F32) {
               float *const pp = oct_global((float *)ctl.obs_ring) + at + i;
               if (rf & TDS_RING_NOFENCE) __hip_atomic_store(pp, (float)vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              else *pp = (float)vv;
+              else OCT_ST((float)vv, pp);
             } else {
               TR *const pp = oct_global((TR *)ctl.obs_ring) + at + i;
               if (rf & TDS_RING_NOFENCE) __hip_atomic_store(pp, (TR)vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              else *pp = (TR)vv;
+              else OCT_ST((TR)vv, pp);
             }
             if (np > 0 && (i >= nq + nd || !rd_only)) {
               for (int pr = 0; pr < np; ++pr) {
