@@ -532,12 +532,13 @@ int peer_setup(tds_hip_shard *sh, size_t ring_slots, size_t slot_b) {
       if (r == sh->rank) continue;
       void *pr = nullptr, *pf = nullptr;
       hipError_t e = hipIpcOpenMemHandle(&pr, all[(size_t)r].ring, hipIpcMemLazyEnablePeerAccess);
+      const bool ring_open = e == hipSuccess;
       if (e == hipSuccess) e = hipIpcOpenMemHandle(&pf, all[(size_t)r].flags, hipIpcMemLazyEnablePeerAccess);
       if (e != hipSuccess) {
         (void)hipGetLastError();
         if (pr) (void)hipIpcCloseMemHandle(pr);
         ok = false;
-        snprintf(why, sizeof(why), "hipIpcOpenMemHandle (rank %d): %s", r, hipGetErrorString(e));
+        snprintf(why, sizeof(why), "hipIpcOpenMemHandle (rank %d, %s): %s", r, ring_open ? "flags" : "ring", hipGetErrorString(e));
         break;
       }
       sh->peer_ring_map[np] = pr;
