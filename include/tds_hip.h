@@ -367,7 +367,9 @@ const char *tds_hip_option_name(int index);
    own kernels' step-loop forms: the 16-lane kernel (Laikago) while every workgroup of the launch is resident at once —
    computed from the device's compute-unit count and LDS size, hipDeviceProp_t: in one-wavefront workgroups up to 6144
    environments on an MI355X, in workgroups of eight wavefronts around one constant table (a workgroup per compute unit:
-   option quad_wide, default on) up to 8192 — and the chained graphs of its straight-line form beyond; the 8-lane kernel (the Ant) always.  No kernel boundaries; the state stays in
+   option quad_wide, default on) up to 8192 — and the chained graphs of its straight-line form beyond; the 8-lane kernel (the Ant) always — beyond one round of resident
+   two-wavefront workgroups (8192 environments) as environment ranges of that size one after the other, each a launch of all the
+   call's steps (the environments are independent; single steps and the exchange's launches stay whole).  No kernel boundaries; the state stays in
    LDS (in the compute scalar) for the n_steps steps, every step takes its own action block, y / obs / x are written
    once at the end — what the graph form leaves behind too, whose obs_dev is overwritten by every step.  With float
    records the state is rounded to float once per call instead of once per step.

@@ -1051,7 +1051,6 @@ void tds_quad_kernel(const DevModel<T> *__restrict__ mdl_arg, const TR *x_in, TR
     T *const Zs = E + O.Z;
     T *const rws = E + O.rws;  // [4][12]: b | 1 / (G + cfm) | G | leg
     T *const xs = E + O.xs;
-    const int nr = 3 * NA;
     QUAD_LAUNDER_MODEL(md5, mdl)  // (the contact frame and the solver's scalars are fetched here, not at the top of the step)
     const T nb[3] = {LOOP ? CT->nb[0] : md5->nb[0], LOOP ? CT->nb[1] : md5->nb[1], LOOP ? CT->nb[2] : md5->nb[2]};
     const T t1v[3] = {LOOP ? CT->t1[0] : md5->t1[0], LOOP ? CT->t1[1] : md5->t1[1], LOOP ? CT->t1[2] : md5->t1[2]};
